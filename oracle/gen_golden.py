@@ -1,0 +1,252 @@
+"""Generate tests/golden/*.npz by importing and running the REFERENCE itself (CPU, this container only).
+
+Usage (build container only; /root/reference does not exist on the GPU box):
+    python oracle/gen_golden.py
+
+TEST INFRASTRUCTURE ONLY.  Nothing from the reference is copied: the fixtures hold inputs and the
+reference's numeric outputs.  `tutel`/`timm` (absent third-party dependencies) are replaced by the
+test-only stubs in oracle/stubs/ (see its README.md for the semantics adopted, "parity unpinned").
+"""
+import argparse
+import os
+import sys
+import time
+from argparse import Namespace
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(HERE, "stubs"))
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import synth  # noqa: E402
+from switch_nerf.models import model_utils  # noqa: E402
+from switch_nerf.models.nerf import Embedding  # noqa: E402
+from switch_nerf import rendering  # noqa: E402
+from switch_nerf.modules.tutel_moe_ext import tutel_fast_dispatch as tfd  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def building_model_cfg(cfg):
+    """building.yaml's `model:` block with sizes taken from cfg (so that small fixtures can use small dims)."""
+    with open(os.path.join(REF, "switch_nerf/configs/switch_nerf/building.yaml")) as f:
+        y = yaml.safe_load(f)
+    m = y["model"]
+    M = cfg["model_dim"]
+    L = m["layers"]
+    L["xyz"]["out_ch"] = M
+    L["0"].update(in_ch=M, h_ch=M, out_ch=M, num=cfg["expert_layers"], skips=list(cfg["skips"]), gate_dim=cfg["gate_hidden"])
+    L["1"].update(in_ch=M, out_ch=M)
+    L["2"].update(in_ch=M + 27 + cfg["appearance_dim"], out_ch=cfg["layer2_out"])
+    L["sigma"].update(in_ch=M)
+    L["color"].update(in_ch=cfg["layer2_out"])
+    L["moe_external_gate"].update(in_ch=M, h_ch=cfg["gate_hidden"], out_ch=cfg["gate_hidden"])
+    L["gate_input_norm"].update(in_ch=cfg["gate_hidden"])
+    return m
+
+
+def make_hparams(cfg, capacity_factor=1.0, bpr=True, coarse=256, chunk=131072, perturb=0.0,
+                 sigma_noise=False):
+    h = Namespace(
+        container_path=None, use_cascade=False, train_mega_nerf=None, use_moe=True, ckpt_path=None,
+        pos_xyz_dim=cfg["pos_xyz_dim"], pos_dir_dim=cfg["pos_dir_dim"], appearance_dim=cfg["appearance_dim"],
+        affine_appearance=False, sh_deg=None, shifted_softplus=True, layer_dim=cfg["model_dim"],
+        moe_expert_num=cfg["num_experts"], moe_local_expert_num=cfg["num_experts"],
+        moe_capacity_factor=capacity_factor, batch_prioritized_routing=bpr, gate_noise=-1.0,
+        compute_balance_loss=False, dispatcher_no_score=False, dispatcher_no_postscore=False,
+        moe_expert_type="expertmlp", no_expert_parallel=True, single_data_group=None,
+        parallel_env=Namespace(global_rank=0), moe_return_gates=True, moe_return_gate_logits=False,
+        use_moe_external_gate=True, use_gate_input_norm=True, amp_use_bfloat16=False,
+        nerfmoe_class_name="NeRFMoE", model=building_model_cfg(cfg), perturb=perturb,
+        coarse_samples=coarse, fine_samples=0, model_chunk_size=chunk, use_sigma_noise=sigma_noise,
+        sigma_noise_std=1.0, return_pts=False, return_pts_rgb=False, return_pts_alpha=False, return_sigma=True,
+        return_alpha=False, bg_use_moe=False, use_load_importance_loss=False, white_bkgd=False,
+        use_random_background_color=False, expertmlp2seqexperts=False, bg_use_cfg=False,
+    )
+    return h
+
+
+def build_reference_model(cfg, sd_np, **kw):
+    h = make_hparams(cfg, **kw)
+    torch.manual_seed(0)
+    nerf = model_utils.get_nerf(h, cfg["appearance_count"])
+    ref_sd = nerf.state_dict()
+    assert set(ref_sd.keys()) == set(sd_np.keys()), (sorted(set(ref_sd) ^ set(sd_np)))
+    for k, v in sd_np.items():
+        assert tuple(ref_sd[k].shape) == tuple(v.shape), (k, ref_sd[k].shape, v.shape)
+    nerf.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    return nerf, h
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"  wrote {path}  ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+# ------------------------------------------------------------------------------------------ G1/G2 routing
+def gen_routing():
+    print("[G1] routing, tie-free, P=2048 E=8")
+    gates = synth.make_gates(101, 2048, 8, logit_scale=1.0)
+    g = torch.from_numpy(gates)
+    assert len(np.unique(gates.max(1))) == 2048, "fixture must be tie-free"
+    for bpr in (False, True):
+        for cf in (1.0, 1.25, 0.5):
+            crit, l_aux = tfd.extract_critical(g, 1, cf, True, bpr)
+            E, idx, loc, gs, cap = crit
+            save(f"route_p2048_e8_bpr{int(bpr)}_cf{cf}", seed=101, P=2048, E=8, logit_scale=1.0, bpr=bpr, cf=cf,
+                 idx=idx[0].numpy().astype(np.int32), loc=loc[0].numpy().astype(np.int32), gate=gs[0].numpy(),
+                 capacity=cap, l_aux=l_aux.numpy())
+    print("[G1b] routing, ragged P=1000 (not a multiple of E=16 nor of 64)")
+    gates = synth.make_gates(102, 1000, 16, logit_scale=2.0)
+    assert len(np.unique(gates.max(1))) == 1000
+    crit, l_aux = tfd.extract_critical(torch.from_numpy(gates), 1, 1.0, True, True)
+    save("route_p1000_e16_bpr1_cf1.0", seed=102, P=1000, E=16, logit_scale=2.0, bpr=True, cf=1.0,
+         idx=crit[1][0].numpy().astype(np.int32), loc=crit[2][0].numpy().astype(np.int32), gate=crit[3][0].numpy(),
+         capacity=crit[4], l_aux=l_aux.numpy())
+    print("[G2] routing at scale with exact ties, P=16384 E=8 (compared modulo tie groups)")
+    gates = synth.make_gates(103, 16384, 8, logit_scale=1.0, quantize_bits=3)
+    crit, l_aux = tfd.extract_critical(torch.from_numpy(gates), 1, 1.0, True, True)
+    save("route_ties_p16384_e8", seed=103, P=16384, E=8, logit_scale=1.0, quantize_bits=3, bpr=True, cf=1.0,
+         idx=crit[1][0].numpy().astype(np.int32), loc=crit[2][0].numpy().astype(np.int32), gate=crit[3][0].numpy(),
+         capacity=crit[4], l_aux=l_aux.numpy())
+
+
+# ------------------------------------------------------------------------------------------ G8 PE
+def gen_pe():
+    print("[G8] positional encoding")
+    rng = np.random.default_rng(8)
+    x = (rng.uniform(-1, 1, size=(256, 3))).astype(np.float32)
+    save("pe", x=x, pe12=Embedding(12)(torch.from_numpy(x)).numpy(), pe4=Embedding(4)(torch.from_numpy(x)).numpy())
+
+
+# ------------------------------------------------------------------------------------------ G3 MoE layer
+def gen_moe_layer():
+    print("[G3] moe_layer fwd+bwd (small dims, weights in fixture-free form: regenerated from synth seed)")
+    for tag, cfg, P, seed in (("m64e4", synth.small_cfg(64, 4), 1024, 31), ("m256e8", synth.BUILDING, 1024, 32)):
+        sd = synth.make_weights(seed, cfg)
+        nerf, h = build_reference_model(cfg, sd)
+        moe = nerf.layers["0"]
+        rng = np.random.default_rng(seed + 1000)
+        x = rng.standard_normal((P, cfg["model_dim"])).astype(np.float32)
+        gi = rng.standard_normal((P, cfg["gate_hidden"])).astype(np.float32)
+        xt = torch.from_numpy(x).requires_grad_(True)
+        gt = torch.from_numpy(gi).requires_grad_(True)
+        y = moe(xt, gate_input=gt)
+        l_aux = y.l_aux
+        dy = rng.standard_normal(y.shape).astype(np.float32)
+        (y * torch.from_numpy(dy)).sum().backward(retain_graph=True)
+        grads = {n: p.grad.clone() for n, p in moe.named_parameters()}
+        gx, gg = xt.grad.clone(), gt.grad.clone()
+        for p in moe.parameters():
+            p.grad = None
+        gl = torch.autograd.grad(l_aux, [gt] + list(moe.gates.parameters()), allow_unused=True)
+        out = dict(seed=seed, P=P, y=y.detach().numpy(), l_aux=l_aux.detach().numpy(), topk=y.gate_extras["gates"].numpy().astype(np.int32),
+                   dx=gx.numpy(), dgate_input=gg.numpy(), laux_dgate_input=gl[0].numpy(), laux_dwg=gl[1].numpy())
+        for n, g_ in grads.items():
+            out["grad__" + n] = g_.numpy() if g_.numel() <= 4096 else synth.checksum(g_.numpy())
+            if g_.numel() > 4096:
+                out["gslice__" + n] = g_.numpy().reshape(-1)[:: max(1, g_.numel() // 997)][:997]
+        save(f"moe_layer_{tag}", **out)
+
+
+# ------------------------------------------------------------------------------------------ G4 model fwd
+def gen_model_forward():
+    print("[G4] NeRFMoE.forward building shapes, P=4096")
+    cfg = synth.BUILDING
+    for tag, gate_scale in (("unbalanced", 1.0), ("balanced", 0.02)):
+        sd = synth.make_weights(41, cfg, gate_scale=gate_scale)
+        nerf, h = build_reference_model(cfg, sd)
+        rng = np.random.default_rng(42)
+        P = 4096
+        x = np.concatenate([rng.uniform(-1, 1, (P, 3)), rng.standard_normal((P, 3)), rng.integers(0, 10, (P, 1))], 1).astype(np.float32)
+        noise = rng.standard_normal((P, 1)).astype(np.float32)
+        nerf.eval()
+        with torch.no_grad():
+            r = nerf(torch.from_numpy(x), sigma_noise=torch.from_numpy(noise))
+        save(f"model_fwd_{tag}", seed=41, gate_scale=gate_scale, x=x, sigma_noise=noise, outputs=r["outputs"].numpy(),
+             moe_loss=r["extras"]["moe_loss"].numpy(), moe_gates=r["extras"]["moe_gates"][0].numpy().astype(np.int32))
+
+
+# ------------------------------------------------------------------------------------------ G5 render + train step
+def gen_render():
+    print("[G5] render_rays / training step (64 rays x 64 samples, chunk 1024 -> 4 chunks), fwd + grads")
+    cfg = synth.BUILDING
+    for tag, gate_scale in (("unbalanced", 1.0), ("balanced", 0.02)):
+        sd = synth.make_weights(51, cfg, gate_scale=gate_scale)
+        N, S, chunk = 64, 64, 1024
+        nerf, h = build_reference_model(cfg, sd, coarse=S, chunk=chunk, perturb=0.0, sigma_noise=False)
+        rays, img, rgbs = synth.make_rays(52, N)
+        nerf.train()
+        t0 = time.time()
+        res, _ = rendering.render_rays(nerf, None, torch.from_numpy(rays), torch.from_numpy(img), h, None, None,
+                                       get_depth=True, get_depth_variance=True, get_bg_fg_rgb=False)
+        photo = torch.nn.functional.mse_loss(res["rgb_coarse"], torch.from_numpy(rgbs))
+        gate_loss = res["gate_loss_coarse"].mean()
+        loss = photo + 5e-4 * gate_loss
+        loss.backward()
+        print(f"    reference fwd+bwd {time.time()-t0:.2f}s")
+        out = dict(seed=51, gate_scale=gate_scale, N=N, S=S, chunk=chunk, rgb=res["rgb_coarse"].detach().numpy(),
+                   depth=res["depth_coarse"].numpy(), depth_variance=res["depth_variance_coarse"].numpy(),
+                   sigma=res["sigma_coarse"].detach().numpy(), gate_loss=res["gate_loss_coarse"].detach().numpy(),
+                   moe_gates=res["moe_gates_coarse"].numpy().astype(np.int32).reshape(N, S),
+                   loss=loss.detach().numpy(), photo=photo.detach().numpy())
+        for n, p in nerf.named_parameters():
+            g_ = p.grad
+            out["gsum__" + n] = synth.checksum(g_.numpy())
+            out["gslice__" + n] = g_.numpy().reshape(-1)[:: max(1, g_.numel() // 499)][:499]
+        save(f"render_train_{tag}", **out)
+
+
+# ------------------------------------------------------------------------------------------ G5b compositing + sample_pdf
+def gen_composite():
+    print("[G5b] compositing / _sample_pdf on raw tensors")
+    rng = np.random.default_rng(61)
+    N, S = 32, 256
+    rays, _, _ = synth.make_rays(62, N)
+    h = make_hparams(synth.BUILDING, coarse=S)
+    rgbs = rng.uniform(0, 1, (N, S, 3)).astype(np.float32)
+    sig = np.abs(rng.standard_normal((N, S))).astype(np.float32) * 20
+
+    class Fake(torch.nn.Module):
+        def forward(self, x, sigma_noise=None):
+            return torch.cat([self.rgb, self.sig], -1)
+    f = Fake()
+    f.rgb = torch.from_numpy(rgbs.reshape(-1, 3))
+    f.sig = torch.from_numpy(sig.reshape(-1, 1))
+    h.use_moe = False
+    h.return_sigma = False
+    h.model_chunk_size = N * S
+    res, _ = rendering.render_rays(f.eval(), None, torch.from_numpy(rays), torch.zeros(N, dtype=torch.long), h, None, None,
+                                   get_depth=True, get_depth_variance=True, get_bg_fg_rgb=False)
+    zs = torch.linspace(0, 1, S)
+    z = torch.from_numpy(rays[:, 6:7]) * (1 - zs) + torch.from_numpy(rays[:, 7:8]) * zs
+    # weights via the get_weights branch
+    r2 = {}
+    rendering._inference(r2, "coarse", f, torch.from_numpy(rays[:, None, 3:6]), None, h,
+                         torch.zeros(N, S, 3), z, 1e10 * torch.ones(N, 1), True, True, True, True, False, False, None)
+    zmid = 0.5 * (z[:, :-1] + z[:, 1:])
+    fine_det = rendering._sample_pdf(zmid, r2["weights_coarse"][:, 1:-1], 64, det=True)
+    save("composite", rays=rays, rgbs=rgbs, sigmas=sig, rgb=res["rgb_coarse"].numpy(), depth=res["depth_coarse"].numpy(),
+         depth_variance=res["depth_variance_coarse"].numpy(), weights=r2["weights_coarse"].numpy(), z=z.numpy(),
+         fine_det=fine_det.numpy())
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    todo = dict(routing=gen_routing, pe=gen_pe, moe=gen_moe_layer, model=gen_model_forward, render=gen_render,
+                composite=gen_composite)
+    for k, fn in todo.items():
+        if a.only and k not in a.only.split(","):
+            continue
+        fn()

@@ -1,0 +1,306 @@
+"""CPU oracle for the Switch-NeRF train hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this module.
+The product path (`switch_nerf_amd/`) never imports it and fails loudly when its HIP library is missing.
+
+This is a from-scratch restatement (plain torch-CPU fp32 for the floating-point maths, numpy integer code
+for the routing) of what the reference computes on the path
+`render_rays -> _inference -> NeRFMoE.forward -> MOELayer.forward -> extract_critical / encode /
+ExpertMLP / decode -> volumetric compositing`.  Each function cites the reference lines it follows
+(paths relative to /root/reference/switch_nerf/).
+
+Pinning: the reference holds no tests or golden vectors for this path, so this
+oracle is pinned against outputs of the reference itself, imported and run in the build container by
+`oracle/gen_golden.py` (fixtures under tests/golden/, checked by tests/test_oracle_golden.py).
+The Tutel kernels the reference calls are a third-party dependency that is absent from /root/reference
+(tutel @ 56dbd664341cf6485c9fa292955f77d3ac918a65); their semantics are restated in oracle/stubs/ and
+are "parity unpinned" at that boundary (no upstream vectors exist).
+
+Tie semantics: the reference ranks tokens with an unstable argsort and picks experts with
+topk, so its answer is implementation-defined when two gate values are exactly equal.  This oracle (and
+the HIP path) define the deterministic answer: expert = FIRST index of the row maximum, rank = STABLE
+descending order of the row maximum (earlier token wins a tie).  On tie-free inputs this equals the
+reference bit for bit (tests/golden/route_*.npz).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------------
+# positional encoding / sampling
+# --------------------------------------------------------------------------------------------
+
+
+def positional_encoding(x: torch.Tensor, num_freqs: int) -> torch.Tensor:
+    """models/nerf.py:21-26 - [x, sin(2^k x), cos(2^k x)] for k = 0..L-1, concatenated per frequency."""
+    out = [x]
+    for k in range(num_freqs):
+        f = float(2 ** k)
+        out += [torch.sin(f * x), torch.cos(f * x)]
+    return torch.cat(out, -1)
+
+
+def sample_z(near: torch.Tensor, far: torch.Tensor, n_samples: int, perturb: float = 0.0,
+             perturb_rand: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """rendering.py:85-88 and :573-584.  near/far: [N,1].  perturb_rand: the U[0,1) tensor the reference
+    draws with rand_like (supplied by the caller so that runs are reproducible)."""
+    t = torch.linspace(0, 1, n_samples, dtype=near.dtype)
+    z = near * (1 - t) + far * t
+    if perturb > 0:
+        mid = 0.5 * (z[:, :-1] + z[:, 1:])
+        upper = torch.cat([mid, z[:, -1:]], -1)
+        lower = torch.cat([z[:, :1], mid], -1)
+        z = lower + (upper - lower) * (perturb * perturb_rand)
+    return z
+
+
+# --------------------------------------------------------------------------------------------
+# routing (integer work, numpy)
+# --------------------------------------------------------------------------------------------
+
+
+def capacity_of(n_tokens: int, n_experts: int, capacity_factor: float, top_k: int = 1) -> int:
+    """tutel_fast_dispatch.py:211 - top_k * int(cf * ceil(P / E))."""
+    return top_k * int(capacity_factor * ((int(n_tokens) + n_experts - 1) // n_experts))
+
+
+def route_top1(gates: np.ndarray, capacity_factor: float, batch_prioritized: bool):
+    """extract_critical, tutel_fast_dispatch.py:176-217, for top_k = 1.
+
+    gates: [P, E] fp32 softmax probabilities.
+    Returns dict(idx int32 [P], loc int32 [P], gate fp32 [P], capacity int, counts int32 [E]).
+    loc[i] = number of tokens routed to the same expert that are ranked before token i, where the
+    ranking is token order (plain) or stable descending order of max-gate (batch prioritized,
+    compute_sorted_location :136-139).  A token is kept iff loc < capacity.
+    """
+    gates = np.ascontiguousarray(gates, dtype=np.float32)
+    P, E = gates.shape
+    idx = gates.argmax(axis=1).astype(np.int32)            # first max index (topk on tie-free rows)
+    gmax = gates[np.arange(P), idx]                          # == (gates * one_hot).sum(1), :182
+    if batch_prioritized:
+        order = np.argsort(-gmax, kind="stable")            # importance = -max gate, ascending
+    else:
+        order = np.arange(P)
+    loc = np.empty(P, np.int32)
+    counts = np.zeros(E, np.int64)
+    idx_sorted = idx[order]
+    # cumsum-1 of the one-hot mask in `order`, read back at each token's own expert column (:138, :194)
+    for e in range(E):
+        sel = order[idx_sorted == e]
+        loc[sel] = np.arange(sel.shape[0], dtype=np.int32)
+        counts[e] = sel.shape[0]
+    cap = capacity_of(P, E, capacity_factor)
+    return dict(idx=idx, loc=loc, gate=gmax.astype(np.float32), capacity=cap, counts=counts.astype(np.int32))
+
+
+def load_balance_loss(gates: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """load_balance fp32 branch, tutel_fast_dispatch.py:141-145: sum_e(me*ce) * E / P^2."""
+    P, E = gates.shape
+    me = gates.float().sum(0)
+    ce = F.one_hot(idx.long(), E).to(me.dtype).sum(0)
+    return (me * ce).sum() * (E / (P * P))
+
+
+# --------------------------------------------------------------------------------------------
+# dispatch / expert MLP / combine
+# --------------------------------------------------------------------------------------------
+
+
+def dispatch(x: torch.Tensor, idx: torch.Tensor, loc: torch.Tensor, n_experts: int, capacity: int) -> torch.Tensor:
+    """GatingEncoder.forward with is_postscore (gate = 1), tutel_fast_dispatch.py:17-29: zero [E*C, M],
+    row idx*C+loc receives x[i] for kept tokens."""
+    keep = loc < capacity
+    rows = (idx.long() * capacity + loc.long())[keep]
+    d = torch.zeros(n_experts * capacity, x.shape[1], dtype=x.dtype)
+    return d.index_add(0, rows, x[keep])
+
+
+def combine(d: torch.Tensor, idx: torch.Tensor, loc: torch.Tensor, gate: torch.Tensor, capacity: int) -> torch.Tensor:
+    """GatingDecoder.forward, tutel_fast_dispatch.py:50-63: y[i] = gate[i] * D[idx*C+loc], 0 if dropped."""
+    keep = loc < capacity
+    rows = (idx.long() * capacity + loc.long()).clamp(max=d.shape[0] - 1)
+    y = gate.unsqueeze(1) * d[rows]
+    return torch.where(keep.unsqueeze(1), y, torch.zeros_like(y))
+
+
+def expert_mlp(d: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
+               skips: Sequence[int]) -> torch.Tensor:
+    """ExpertMLP.forward, tutel_moe_layer_nobatch.py:887-924.  d: [E, C, M]; weights[l]: [E, in, out];
+    biases[l]: [E, 1, out].  ReLU after every layer but the last; at a skip layer the layer input saved
+    at the previous skip (initially the expert input) is added before the ReLU."""
+    L = len(weights)
+    x = d
+    h = d
+    for l in range(L):
+        h = torch.baddbmm(biases[l], h, weights[l])
+        if l in skips:
+            h = h + x
+            if l < L - 1:
+                h = torch.relu(h)
+            x = h
+        elif l < L - 1:
+            h = torch.relu(h)
+    return h
+
+
+def moe_layer(h: torch.Tensor, gate_input: torch.Tensor, wg: torch.Tensor, weights, biases, skips,
+              capacity_factor: float, batch_prioritized: bool, routing: Optional[dict] = None):
+    """TopKGate.apply_on_expert_fn, tutel_moe_layer_nobatch.py:98-235 (k=1, fp32 gate, postscore).
+    Returns (y [P,M], l_aux, routing dict, gates [P,E]).  `routing` may be injected (idx/loc numpy) to
+    decouple numerics tests from near-tie routing flips."""
+    E = wg.shape[0]
+    logits = gate_input.float() @ wg.float().t()                               # :105-113
+    gates = torch.softmax(logits, dim=1)                                       # :126
+    if routing is None:
+        routing = route_top1(gates.detach().numpy(), capacity_factor, batch_prioritized)
+    idx = torch.from_numpy(np.asarray(routing["idx"]).astype(np.int64))
+    loc = torch.from_numpy(np.asarray(routing["loc"]).astype(np.int64))
+    cap = int(routing["capacity"])
+    gate_s = gates.gather(1, idx.unsqueeze(1)).squeeze(1)                      # differentiable gates_s, :182
+    l_aux = load_balance_loss(gates, idx)                                      # :184
+    d = dispatch(h, idx, loc, E, cap).view(E, cap, -1)                         # :146
+    o = expert_mlp(d, weights, biases, skips).reshape(E * cap, -1)             # :174
+    y = combine(o, idx, loc, gate_s, cap)                                      # :225
+    return y, l_aux, routing, gates
+
+
+# --------------------------------------------------------------------------------------------
+# NeRFMoE forward (building.yaml wiring)
+# --------------------------------------------------------------------------------------------
+
+
+def shifted_softplus(x: torch.Tensor) -> torch.Tensor:
+    """models/nerf.py:68-69 - softplus(x - 1), beta 1, threshold 20."""
+    return F.softplus(x - 1, 1, 20)
+
+
+def params_from_numpy(sd: Dict[str, np.ndarray], requires_grad: bool = False) -> Dict[str, torch.Tensor]:
+    out = {}
+    for k, v in sd.items():
+        t = torch.from_numpy(np.array(v, dtype=np.float32, copy=True))
+        t.requires_grad_(requires_grad)
+        out[k] = t
+    return out
+
+
+def nerf_moe_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: dict, capacity_factor: float = 1.0,
+                     batch_prioritized: bool = True, sigma_noise: Optional[torch.Tensor] = None,
+                     routing: Optional[dict] = None):
+    """NeRFMoE.forward, models/nerf_moe.py:320-455, with building.yaml's layer wiring.
+    x: [P, 7] = xyz(3) dir(3) image_index(1).  Returns dict(outputs [P,4], moe_loss [1], routing, gates)."""
+    L = cfg["expert_layers"]
+    xyz, dirs, img = x[:, :3], x[:, 3:6], x[:, 6].long()
+    h = F.linear(positional_encoding(xyz, cfg["pos_xyz_dim"]), p["layers.xyz.fcs.0.weight"], p["layers.xyz.fcs.0.bias"])  # :330-333
+    g = F.linear(h, p["layers.moe_external_gate.fcs.0.weight"], p["layers.moe_external_gate.fcs.0.bias"])
+    g = F.linear(torch.relu(g), p["layers.moe_external_gate.fcs.1.weight"], p["layers.moe_external_gate.fcs.1.bias"])  # :347-348, Mlp :30-49
+    g = F.layer_norm(g, (g.shape[1],), p["layers.gate_input_norm.weight"], p["layers.gate_input_norm.bias"], 1e-5)  # :370-372
+    weights = [p[f"layers.0.experts.0.weights.{l}"] for l in range(L)]
+    biases = [p[f"layers.0.experts.0.bias.{l}"] for l in range(L)]
+    y, l_aux, routing, gates = moe_layer(h, g, p["layers.0.gates.0.wg.weight"], weights, biases, cfg["skips"],
+                                         capacity_factor, batch_prioritized, routing)
+    y = torch.relu(y)                                                          # act: relu, :385-386
+    sigma = F.linear(y, p["layers.sigma.fcs.0.weight"], p["layers.sigma.fcs.0.bias"])  # :393-400
+    if sigma_noise is not None:
+        sigma = sigma + sigma_noise                                            # :414-415
+    sigma = shifted_softplus(sigma)                                            # :416
+    h1 = F.linear(y, p["layers.1.fcs.0.weight"], p["layers.1.fcs.0.bias"])     # layer "1", act none
+    feat = torch.cat([h1, positional_encoding(dirs, cfg["pos_dir_dim"]), p["embedding_a.weight"][img]], -1)  # :419-429
+    h2 = torch.relu(F.linear(feat, p["layers.2.fcs.0.weight"], p["layers.2.fcs.0.bias"]))
+    rgb = torch.sigmoid(F.linear(h2, p["layers.color.fcs.0.weight"], p["layers.color.fcs.0.bias"]))  # :431-441
+    return dict(outputs=torch.cat([rgb, sigma], -1), moe_loss=l_aux.reshape(1), routing=routing, gates=gates)
+
+
+# --------------------------------------------------------------------------------------------
+# volumetric compositing and the training step
+# --------------------------------------------------------------------------------------------
+
+
+def composite(rgbs: torch.Tensor, sigmas: torch.Tensor, z_vals: torch.Tensor, last_delta: float = 1e10):
+    """rendering.py:435-494.  rgbs [N,S,3], sigmas [N,S], z_vals [N,S]."""
+    deltas = z_vals[:, 1:] - z_vals[:, :-1]
+    deltas = torch.cat([deltas, torch.full_like(z_vals[:, :1], last_delta)], -1)            # :441
+    alphas = 1 - torch.exp(-deltas * sigmas)                                                   # :442
+    T = torch.cumprod(1 - alphas + 1e-8, -1)                                                   # :455
+    T = torch.cat((torch.ones_like(T[:, :1]), T[:, :-1]), -1)                                  # :459
+    weights = alphas * T                                                                       # :461
+    rgb = (weights.unsqueeze(-1) * rgbs).sum(1)                                                # :467
+    with torch.no_grad():
+        depth = (weights * z_vals).sum(1)                                                      # :485
+        depth_var = (weights * (z_vals - depth.unsqueeze(1)).square()).sum(-1)                 # :491-493
+    return dict(rgb=rgb, weights=weights, depth=depth, depth_variance=depth_var, alphas=alphas)
+
+
+def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_fine: int, u: Optional[torch.Tensor] = None):
+    """rendering.py:587-637 (_sample_pdf/_sample_cdf).  u=None -> deterministic linspace (eval)."""
+    w = weights + 1e-8
+    pdf = w / w.sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
+    n = pdf.shape[1]
+    if u is None:
+        u = torch.linspace(0, 1, n_fine).expand(bins.shape[0], n_fine)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = (inds - 1).clamp_min(0)
+    above = inds.clamp_max(n)
+    cdf_b, cdf_a = cdf.gather(1, below), cdf.gather(1, above)
+    bin_b, bin_a = bins.gather(1, below), bins.gather(1, above)
+    denom = cdf_a - cdf_b
+    denom = torch.where(denom < 1e-8, torch.ones_like(denom), denom)
+    return bin_b + (u - cdf_b) / denom * (bin_a - bin_b)
+
+
+def render_rays(p, rays: torch.Tensor, image_indices: torch.Tensor, cfg: dict, n_samples: int, chunk: int,
+                capacity_factor: float = 1.0, batch_prioritized: bool = True, perturb: float = 0.0,
+                perturb_rand: Optional[torch.Tensor] = None, sigma_noise: Optional[torch.Tensor] = None,
+                routings: Optional[list] = None):
+    """render_rays + _get_results + _inference for the coarse-only (fine_samples = 0) configuration,
+    rendering.py:15-196, :199-274, :277-494.  Points are evaluated in chunks of `chunk` (= model_chunk_size)
+    and the routing (capacity, ranking, l_aux) is per chunk, exactly as the reference's loop :354-383."""
+    N = rays.shape[0]
+    o, d, near, far = rays[:, 0:3], rays[:, 3:6], rays[:, 6:7], rays[:, 7:8]
+    z = sample_z(near, far, n_samples, perturb, perturb_rand)
+    xyz = o[:, None, :] + d[:, None, :] * z[:, :, None]                                      # :90
+    pts = torch.cat([xyz.reshape(-1, 3), d[:, None, :].expand(N, n_samples, 3).reshape(-1, 3),
+                     image_indices.view(N, 1, 1).expand(N, n_samples, 1).reshape(-1, 1).to(xyz.dtype)], 1)  # :311-360
+    outs, losses, routes = [], [], []
+    for ci, i in enumerate(range(0, pts.shape[0], chunk)):
+        sn = None if sigma_noise is None else sigma_noise[i:i + chunk]
+        r = nerf_moe_forward(p, pts[i:i + chunk], cfg, capacity_factor, batch_prioritized, sn,
+                             None if routings is None else routings[ci])
+        outs.append(r["outputs"])
+        losses.append(r["moe_loss"])
+        routes.append(r["routing"])
+    out = torch.cat(outs, 0).view(N, n_samples, 4)
+    comp = composite(out[..., :3], out[..., 3], z)
+    return dict(rgb_coarse=comp["rgb"], depth_variance_coarse=comp["depth_variance"], depth_coarse=comp["depth"],
+                weights_coarse=comp["weights"], gate_loss_coarse=torch.cat(losses, 0), sigma_coarse=out[..., 3],
+                raw=out, z_vals=z, routings=routes)
+
+
+def training_step(p, rays, image_indices, rgbs, cfg, n_samples, chunk, moe_l_aux_wt=5e-4, **kw):
+    """Runner._training_step, runner.py:1077-1123 + loss assembly :646-658:
+    loss = mse(rgb, rgbs) + moe_l_aux_wt * mean(gate_loss)."""
+    res = render_rays(p, rays, image_indices, cfg, n_samples, chunk, **kw)
+    photo = F.mse_loss(res["rgb_coarse"], rgbs, reduction="mean")
+    gate_loss = res["gate_loss_coarse"].mean()
+    loss = photo + moe_l_aux_wt * gate_loss
+    with torch.no_grad():
+        psnr = -10.0 * torch.log10(photo.detach())                                             # metrics.py:8-10
+    return dict(loss=loss, photo_loss=photo, gate_loss=gate_loss, psnr=psnr,
+                depth_variance=res["depth_variance_coarse"].mean(), results=res)
+
+
+def adam_step(param: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float,
+              beta1=0.9, beta2=0.999, eps=1e-8):
+    """torch.optim.Adam (runner.py:486) single-tensor update, no weight decay, no amsgrad."""
+    m.mul_(beta1).add_(grad, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    param.addcdiv_(m, denom, value=-lr / bc1)

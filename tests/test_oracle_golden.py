@@ -1,0 +1,177 @@
+"""Pin the CPU oracle (oracle/switchnerf_oracle.py) against golden vectors produced by the imported
+reference (oracle/gen_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import switchnerf_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+@pytest.mark.parametrize("bpr", [0, 1])
+@pytest.mark.parametrize("cf", [1.0, 1.25, 0.5])
+def test_routing_tie_free_bit_exact(bpr, cf):
+    g = load(f"route_p2048_e8_bpr{bpr}_cf{cf}")
+    gates = synth.make_gates(int(g["seed"]), int(g["P"]), int(g["E"]), float(g["logit_scale"]))
+    r = O.route_top1(gates, cf, bool(bpr))
+    assert np.array_equal(r["idx"], g["idx"])
+    assert np.array_equal(r["loc"], g["loc"])
+    assert np.array_equal(r["gate"], g["gate"])          # bit-exact fp32
+    assert r["capacity"] == int(g["capacity"])
+    l_aux = O.load_balance_loss(torch.from_numpy(gates), torch.from_numpy(r["idx"]))
+    assert np.array_equal(l_aux.numpy(), g["l_aux"])
+
+
+def test_routing_ragged_e16():
+    g = load("route_p1000_e16_bpr1_cf1.0")
+    gates = synth.make_gates(int(g["seed"]), 1000, 16, 2.0)
+    r = O.route_top1(gates, 1.0, True)
+    assert np.array_equal(r["idx"], g["idx"]) and np.array_equal(r["loc"], g["loc"])
+    assert r["capacity"] == int(g["capacity"]) == 63
+
+
+def test_routing_with_ties_modulo_tie_groups():
+    """The reference's answer is implementation-defined inside groups of exactly equal max-gate (unstable
+    argsort) and between experts with exactly equal probability (topk).  Outside those, we must agree."""
+    g = load("route_ties_p16384_e8")
+    gates = synth.make_gates(int(g["seed"]), 16384, 8, 1.0, quantize_bits=3)
+    r = O.route_top1(gates, 1.0, True)
+    srt = np.sort(gates, axis=1)
+    expert_tie = srt[:, -1] == srt[:, -2]
+    assert expert_tie.sum() > 0, "fixture is supposed to contain expert ties"
+    ok = ~expert_tie
+    assert np.array_equal(r["idx"][ok], g["idx"][ok])
+    # the reference's pick on an expert tie must still be one of the maxima
+    rows = np.nonzero(expert_tie)[0]
+    assert np.all(gates[rows, g["idx"][rows]] == srt[rows, -1])
+    # rank: for tokens whose (expert, gate) class is the same in both answers, loc must fall in the same
+    # [first, last] interval of its tie group, and match exactly when the group has one member.
+    same = r["idx"] == g["idx"]
+    # build tie-group intervals from the oracle's own assignment restricted to agreeing tokens
+    key = np.stack([r["idx"].astype(np.int64), gates.max(1).view(np.int32).astype(np.int64)], 1)
+    _, inv, cnt = np.unique(key, axis=0, return_inverse=True, return_counts=True)
+    single = (cnt[inv] == 1) & same
+    # a singleton group's rank only depends on how many same-expert tokens have larger gate; that count can
+    # differ between the two answers only through expert-tie tokens that were assigned differently.
+    n_diff = int((~same).sum())
+    assert np.all(np.abs(r["loc"][single].astype(np.int64) - g["loc"][single]) <= n_diff)
+    if n_diff == 0:
+        lo = np.zeros(len(cnt), np.int64) + 10 ** 9
+        hi = np.zeros(len(cnt), np.int64) - 1
+        np.minimum.at(lo, inv, r["loc"])
+        np.maximum.at(hi, inv, r["loc"])
+        assert np.all((g["loc"] >= lo[inv]) & (g["loc"] <= hi[inv]))
+        # both are permutations inside each group
+        for arr in (r["loc"], g["loc"]):
+            assert len(np.unique(np.stack([r["idx"], arr], 1), axis=0)) == 16384
+
+
+def test_positional_encoding():
+    g = load("pe")
+    x = torch.from_numpy(g["x"])
+    assert np.array_equal(O.positional_encoding(x, 12).numpy(), g["pe12"])
+    assert np.array_equal(O.positional_encoding(x, 4).numpy(), g["pe4"])
+
+
+@pytest.mark.parametrize("tag,cfg", [("m64e4", synth.small_cfg(64, 4)), ("m256e8", synth.BUILDING)])
+def test_moe_layer_fwd_bwd(tag, cfg):
+    g = load(f"moe_layer_{tag}")
+    seed, P = int(g["seed"]), int(g["P"])
+    p = O.params_from_numpy(synth.make_weights(seed, cfg), requires_grad=True)
+    rng = np.random.default_rng(seed + 1000)
+    x = torch.from_numpy(rng.standard_normal((P, cfg["model_dim"])).astype(np.float32)).requires_grad_(True)
+    gi = torch.from_numpy(rng.standard_normal((P, cfg["gate_hidden"])).astype(np.float32)).requires_grad_(True)
+    L = cfg["expert_layers"]
+    W = [p[f"layers.0.experts.0.weights.{l}"] for l in range(L)]
+    B = [p[f"layers.0.experts.0.bias.{l}"] for l in range(L)]
+    y, l_aux, routing, gates = O.moe_layer(x, gi, p["layers.0.gates.0.wg.weight"], W, B, cfg["skips"], 1.0, True)
+    assert np.array_equal(routing["idx"], g["topk"].reshape(-1))
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(l_aux.detach().numpy(), g["l_aux"], rtol=1e-6)
+    dy = torch.from_numpy(rng.standard_normal(y.shape).astype(np.float32))
+    (y * dy).sum().backward(retain_graph=True)
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(gi.grad.numpy(), g["dgate_input"], rtol=0, atol=5e-6)
+    names = {"gates.0.wg.weight": "layers.0.gates.0.wg.weight"}
+    for l in range(L):
+        names[f"experts.0.weights.{l}"] = f"layers.0.experts.0.weights.{l}"
+        names[f"experts.0.bias.{l}"] = f"layers.0.experts.0.bias.{l}"
+    for short, full in names.items():
+        got = p[full].grad.numpy()
+        ref = g["grad__" + short]
+        if got.size <= 4096:
+            np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+        else:
+            np.testing.assert_allclose(synth.checksum(got), ref, rtol=2e-5)
+            sl = got.reshape(-1)[:: max(1, got.size // 997)][:997]
+            np.testing.assert_allclose(sl, g["gslice__" + short], rtol=0, atol=2e-5)
+    gi.grad = None
+    gl = torch.autograd.grad(l_aux, [gi, p["layers.0.gates.0.wg.weight"]])
+    np.testing.assert_allclose(gl[0].numpy(), g["laux_dgate_input"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(gl[1].numpy(), g["laux_dwg"], rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["unbalanced", "balanced"])
+def test_model_forward(tag):
+    g = load(f"model_fwd_{tag}")
+    cfg = synth.BUILDING
+    p = O.params_from_numpy(synth.make_weights(int(g["seed"]), cfg, gate_scale=float(g["gate_scale"])))
+    with torch.no_grad():
+        r = O.nerf_moe_forward(p, torch.from_numpy(g["x"]), cfg, 1.0, True, torch.from_numpy(g["sigma_noise"]))
+    assert np.array_equal(r["routing"]["idx"], g["moe_gates"].reshape(-1))
+    np.testing.assert_allclose(r["outputs"].numpy(), g["outputs"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(r["moe_loss"].numpy(), g["moe_loss"], rtol=1e-6)
+    kept = (r["routing"]["loc"] < r["routing"]["capacity"]).mean()
+    print(f"{tag}: kept fraction {kept:.3f}, counts {r['routing']['counts']}")
+
+
+@pytest.mark.parametrize("tag", ["unbalanced", "balanced"])
+def test_render_and_training_step(tag):
+    g = load(f"render_train_{tag}")
+    cfg = synth.BUILDING
+    p = O.params_from_numpy(synth.make_weights(int(g["seed"]), cfg, gate_scale=float(g["gate_scale"])), requires_grad=True)
+    N, S, chunk = int(g["N"]), int(g["S"]), int(g["chunk"])
+    rays, img, rgbs = synth.make_rays(52, N)
+    st = O.training_step(p, torch.from_numpy(rays), torch.from_numpy(img), torch.from_numpy(rgbs), cfg, S, chunk)
+    res = st["results"]
+    got_idx = np.concatenate([r["idx"] for r in res["routings"]]).reshape(N, S)
+    assert np.array_equal(got_idx, g["moe_gates"])
+    np.testing.assert_allclose(res["rgb_coarse"].detach().numpy(), g["rgb"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(res["sigma_coarse"].detach().numpy(), g["sigma"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(res["depth_coarse"].numpy(), g["depth"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(res["depth_variance_coarse"].numpy(), g["depth_variance"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(res["gate_loss_coarse"].detach().numpy(), g["gate_loss"], rtol=1e-6)
+    np.testing.assert_allclose(st["loss"].detach().numpy(), g["loss"], rtol=1e-6)
+    st["loss"].backward()
+    for k, t in p.items():
+        ref_sum = g["gsum__" + k]
+        got = t.grad.numpy()
+        scale = max(1e-12, float(ref_sum[1]))
+        assert abs(synth.checksum(got)[0] - ref_sum[0]) <= 2e-4 * scale + 1e-9, k
+        assert abs(synth.checksum(got)[1] - ref_sum[1]) <= 2e-4 * scale + 1e-9, k
+        sl = got.reshape(-1)[:: max(1, got.size // 499)][:499]
+        np.testing.assert_allclose(sl, g["gslice__" + k], rtol=1e-3, atol=1e-7 + 1e-4 * np.abs(g["gslice__" + k]).max(), err_msg=k)
+
+
+def test_composite_and_sample_pdf():
+    g = load("composite")
+    z = torch.from_numpy(g["z"])
+    c = O.composite(torch.from_numpy(g["rgbs"]), torch.from_numpy(g["sigmas"]), z)
+    np.testing.assert_allclose(c["rgb"].numpy(), g["rgb"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(c["weights"].numpy(), g["weights"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(c["depth"].numpy(), g["depth"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(c["depth_variance"].numpy(), g["depth_variance"], rtol=1e-5, atol=1e-9)
+    zmid = 0.5 * (z[:, :-1] + z[:, 1:])
+    fine = O.sample_pdf(zmid, c["weights"][:, 1:-1], 64)
+    np.testing.assert_allclose(fine.numpy(), g["fine_det"], rtol=0, atol=1e-6)
+    rays = torch.from_numpy(g["rays"])
+    z2 = O.sample_z(rays[:, 6:7], rays[:, 7:8], 256)
+    assert np.array_equal(z2.numpy(), g["z"])
