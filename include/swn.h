@@ -1,0 +1,188 @@
+/*
+ * swn.h - C ABI of libswn_hip.so: the MI355X (gfx950) kernels of the Switch-NeRF train hot path.
+ *
+ * The reference (MiZhenxing/Switch-NeRF) has no C/FFI boundary of its own: it is pure Python on torch plus the
+ * third-party Tutel JIT kernels.  Every entry point below therefore names the reference *Python* interface it
+ * replaces (paths relative to /root/reference/switch_nerf/).  The reference-side binding a maintainer would add
+ * is a ctypes stub: see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's allocator in our host code); the library
+ *     allocates nothing and keeps no mutable global state besides the last-error string (thread local);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *   - return value: 0 = ok, non-zero = error (message from swn_last_error()); nothing throws or aborts;
+ *   - dtype codes: SWN_F32 = 0, SWN_BF16 = 1 (activations / compute copies of weights); master weights,
+ *     gradients, gates, z-values and all reductions are fp32; indices are int32;
+ *   - activations are row-major [rows, features]; "segments" are the reference's model chunks
+ *     (rendering.py:354 `model_chunk_size`): routing, capacity and l_aux are computed per segment.
+ */
+#ifndef SWN_H
+#define SWN_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWN_F32 0
+#define SWN_BF16 1
+
+const char* swn_last_error(void);
+int swn_version(void);
+
+/* Diagnostic: dumps the lane->element maps of v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32 as used by the
+ * kernels (out: 3*64*16 int32 = for each of A(8 used),B(8 used),C(16) slot the (row<<16|col) it addresses). */
+int swn_mfma_probe(int32_t* out, void* stream);
+
+/* ---- ray sampling + positional encoding --------------------------------------------------------------------
+ * replaces rendering.py:85-90 (z = near(1-t)+far t, xyz = o + d z), :573-584 (_expand_and_perturb_z_vals) and
+ * models/nerf.py:21-26 (Embedding.forward) for xyz (L=12) and dir (L=4).
+ *   rays[N,8] f32 (o,d,near,far); t_steps[S] f32 = linspace(0,1,S); perturb_rand[N,S] f32 U[0,1) or NULL
+ *   z_out[N,S] f32; pe_xyz[N*S, pe_stride] (dtype), columns >= 3+6*Lxyz zero-filled;
+ *   pe_dir[N, dir_stride] (dtype) or NULL.                                                                     */
+int swn_sample_pe(const float* rays, const float* t_steps, const float* perturb_rand, float perturb,
+                  int n_rays, int n_samples, int l_xyz, int l_dir, int dtype,
+                  float* z_out, void* pe_xyz, int pe_stride, void* pe_dir, int dir_stride, void* stream);
+
+/* ---- gate: LayerNorm + fp32 router GEMV + softmax + top-1 ----------------------------------------------------
+ * replaces nn.LayerNorm (models/nerf_moe.py:370-372), TopKGate logits/softmax
+ * (modules/tutel_moe_ext/tutel_moe_layer_nobatch.py:105-126) and topk/gates_s (tutel_fast_dispatch.py:177-182).
+ *   g[P,G] (dtype) gate-MLP output; ln_w, ln_b [G] f32 (NULL = no norm); wg[E,G] f32
+ *   gates[P,E] f32; idx[P] i32 (first max); gmax[P] f32; stats[P,2] f32 (mean, rstd) for backward.            */
+int swn_gate_fwd(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg,
+                 int n_tokens, int gate_dim, int n_experts,
+                 float* gates, int32_t* idx, float* gmax, float* stats, void* stream);
+
+/* backward of the above + the l_aux gradient.  d_gates[s,e] = laux_coef[seg(s)] * counts[seg(s),e]
+ * + (e==idx[s]) * d_gmax[s];  then softmax bwd, router bwd (d_wg accumulated with atomics into fp32 [E,G]),
+ * LayerNorm bwd (d_ln_w/d_ln_b accumulated).  dg[P,G] (dtype) out.
+ * counts: int32 [n_seg,E] (tokens routed to e, before capacity); laux_coef: f32 [n_seg] = dL/dl_aux_seg * E/P^2 */
+int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg,
+                 const float* gates, const int32_t* idx, const float* d_gmax, const float* stats,
+                 const int32_t* counts, const float* laux_coef, int seg_tokens,
+                 int n_tokens, int gate_dim, int n_experts,
+                 void* dg, float* d_wg, float* d_ln_w, float* d_ln_b, void* stream);
+
+/* ---- routing: batch-prioritised top-1 capacity assignment ----------------------------------------------------
+ * replaces extract_critical / compute_sorted_location / load_balance (tutel_fast_dispatch.py:136-217) and the
+ * Tutel `fast_cumsum_sub_one` kernel for top_k = 1.  Bit-exact contract: loc[i] = number of tokens of the same
+ * segment and expert ranked before i; rank = stable descending gmax (bpr=1) or token order (bpr=0).
+ *   idx[P] i32, gmax[P] f32, gates[P,E] f32 (for l_aux; may be NULL -> l_aux not computed)
+ *   P = n_seg * seg_tokens (last segment may be short: n_tokens gives the true total)
+ *   loc[P] i32; counts[n_seg,E] i32; perm[n_seg, E*capacity] i32 (row -> token, -1 = empty) or NULL;
+ *   tok2row[P] i32 (token -> row seg*E*C + idx*C + loc, -1 = dropped) or NULL;
+ *   l_aux[n_seg] f32 = sum_e(me*ce) * E / P_seg^2.
+ *   workspace: swn_route_workspace_bytes(n_tokens) bytes.                                                      */
+size_t swn_route_workspace_bytes(int n_tokens, int n_seg, int n_experts);
+int swn_route_top1(const int32_t* idx, const float* gmax, const float* gates,
+                   int n_tokens, int seg_tokens, int n_experts, int capacity, int bpr,
+                   int32_t* loc, int32_t* counts, int32_t* perm, int32_t* tok2row, float* l_aux,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- Tutel sparse kernel ABI (batched, capacity padded) ------------------------------------------------------
+ * replaces tutel.jit_kernels.sparse func_fwd / func_bwd_data / func_bwd_gate as called from
+ * tutel_fast_dispatch.py:27,36,43,61,70,76 - same argument order (gates, indices, locations, reshaped_input,
+ * dispatched_input, extra=[samples, hidden, capacity]); gates may be NULL (= the reference's ones_helper).
+ * Unlike the Tutel forward (atomicAdd into a zero-filled buffer) the forward here also writes the zeros of the
+ * unused capacity slots when `counts` is given, so the caller does not have to memset.                          */
+int swn_dispatch_fwd(const float* gates, const int32_t* indices, const int32_t* locations,
+                     const void* reshaped_input, void* dispatched, int dtype,
+                     int samples, int hidden, int capacity, int n_experts, void* stream);
+int swn_dispatch_bwd_data(const float* gates, const int32_t* indices, const int32_t* locations,
+                          void* grad_reshaped_input, const void* dispatched, int dtype,
+                          int samples, int hidden, int capacity, void* stream);
+int swn_dispatch_bwd_gate(float* grad_gates, const int32_t* indices, const int32_t* locations,
+                          const void* reshaped_input, const void* dispatched, int dtype,
+                          int samples, int hidden, int capacity, void* stream);
+
+/* Fast-path combine (the reference's decode + the MoE layer's `act: relu`, models/nerf_moe.py:385-386):
+ * y[i] = relu?(gate[i] * expert_out[seg(i)*E*C + idx*C + loc]), zero rows for dropped tokens.                 */
+int swn_combine_fwd(const float* gates, const int32_t* indices, const int32_t* locations, void* y,
+                    const void* expert_out, int dtype, int samples, int hidden, int capacity, int seg_tokens,
+                    int n_experts, int relu, void* stream);
+/* Backward of the above w.r.t. expert_out and gate, given dy_in = dL/dy (+ optional rank-1 term dsig[i]*wsig[:],
+ * the sigma head's contribution): dy = (dy_in + dsig*wsig) * (y > 0); dgate[i] = <y_i, dy_i> / gate[i];
+ * dout[i] = dy_i * gate[i] (token order; the expert backward gathers it through `perm`).                      */
+int swn_combine_bwd(const void* dy_in, const void* y, const float* dsig, const float* wsig, const float* gate,
+                    int dtype, int samples, int hidden, void* dout, float* dgate, void* stream);
+
+/* ---- sigma / colour heads ----------------------------------------------------------------------------------------
+ * replaces models/nerf_moe.py:393-416 (sigma Linear + noise + ShiftedSoftplus) and :431-441 (colour Linear + sigmoid).
+ * raw[P,4] f32 = (rgb, sigma).  w_sigma[M], b_sigma[1], w_color[3,H2], b_color[3] f32.                         */
+int swn_heads_fwd(const void* y, const void* h2, int dtype, const float* w_sigma, const float* b_sigma,
+                  const float* w_color, const float* b_color, const float* sigma_noise, int n_points,
+                  int model_dim, int h2_dim, float* raw, void* stream);
+int swn_heads_bwd(const void* y, const void* h2, int dtype, const float* w_color, const float* raw,
+                  const float* d_raw, int n_points, int model_dim, int h2_dim, void* dh2, float* dsig,
+                  float* d_w_sigma, float* d_b_sigma, float* d_w_color, float* d_b_color, void* stream);
+/* out[g][c] = sum_r in[g*rows_per_group + r][c]  (per-ray bias gradient) */
+int swn_group_colsum(const void* in, int dtype, int n_groups, int rows_per_group, int cols, float* out, void* stream);
+
+/* ---- volumetric compositing ------------------------------------------------------------------------------------
+ * replaces rendering.py:435-494.  raw[N,S,4] f32 (rgb, sigma); z[N,S] f32; last_delta scalar (1e10).
+ * rgb[N,3], depth[N], depth_var[N], weights[N,S] (any may be NULL).                                             */
+int swn_composite_fwd(const float* raw, const float* z, float last_delta, int n_rays, int n_samples,
+                      float* rgb, float* depth, float* depth_var, float* weights, void* stream);
+/* d_raw[N,S,4] = gradient of sum(d_rgb * rgb) w.r.t. raw. */
+int swn_composite_bwd(const float* raw, const float* z, float last_delta, const float* d_rgb,
+                      int n_rays, int n_samples, float* d_raw, void* stream);
+
+/* ---- dense / grouped MLP chains on MFMA ------------------------------------------------------------------------
+ * One launch runs `n_layers` (<= 8) Linear layers back to back with the activations of a 128-row tile resident in
+ * LDS.  Layer l: h <- act_l( h @ W_l^T + b_l [+ rowbias[row/rows_per_bias]] [+ skip] ).  W_l is [N_l][K_l] with K
+ * contiguous (torch.nn.Linear.weight layout) in `dtype`; b_l fp32.  Ragged groups: rows of group g are
+ * [g*group_stride, g*group_stride + group_rows[g]) and group g uses weight set g % n_wsets
+ * (expert MLP: group = (segment, expert), n_wsets = E).
+ * replaces ExpertMLP.forward (tutel_moe_layer_nobatch.py:887-924: baddbmm chain, skip, ReLU) and Mlp.forward
+ * (models/nerf_moe.py:30-49).  Details of the descriptor: see swn_chain_desc below.                             */
+typedef struct swn_chain_layer {
+  const void* w;        /* [n_wsets][N][K] dtype                                   */
+  const float* b;       /* [n_wsets][N] f32 or NULL                                */
+  void* save;           /* row-major [rows_total][N] dtype: output of this layer (post activation) or NULL */
+  uint32_t* mask;       /* packed ReLU mask: written when relu==1, read when relu==2; size =
+                           n_workgroups * 8 waves * MI * 64 uint32 (MI = 2 bf16 / 1 fp32), or NULL */
+  const float* rowbias; /* f32 [n_rows / rows_per_bias][N] extra bias shared by runs of rows (per-ray terms) or NULL */
+  int32_t rows_per_bias;
+  int32_t n, k;         /* output / input features: n multiple of 32, k multiple of 64 (bf16) / 32 (fp32), <= 256 */
+  int32_t relu;         /* 0 none; 1 ReLU (and record the mask if given); 2 multiply by the recorded mask (backward) */
+  int32_t skip;         /* add the chain input x before the activation (needs n == layers[0].k) */
+} swn_chain_layer;
+
+typedef struct swn_chain_desc {
+  int32_t dtype, n_layers, n_groups, n_wsets;
+  int32_t group_stride;         /* rows reserved per group in the row space                      */
+  const int32_t* group_rows;    /* device [n_groups] valid rows per group, or NULL = group_stride (then clamp) */
+  int32_t group_rows_clamp;     /* rows valid = min(group_rows[g], clamp)                         */
+  const void* x;                /* chain input, row-major [*, k0] dtype                           */
+  const int32_t* x_gather;      /* device [n_groups*group_stride] row -> source row of x, or NULL (identity) */
+  void* x_save;                 /* optional copy of the gathered input rows (row-major) or NULL   */
+  void* y;                      /* output rows, row-major [*, n_last] dtype                       */
+  const void* y_add;            /* row-major [*, n_last] tensor added to the output rows (skip gradient) or NULL */
+  const int32_t* y_add_gather;  /* row -> row of y_add (-1 = nothing to add), or NULL (identity)  */
+  swn_chain_layer layers[8];
+} swn_chain_desc;
+
+int swn_mlp_chain(const swn_chain_desc* desc, void* stream);
+
+/* Grouped weight gradient: for every group g, dW[g % n_wsets] += A_g^T @ B_g (fp32 atomics), and optionally
+ * db += column sums of B_g.  A[rows, m_dim], B[rows, n_dim] row-major dtype; dW [n_wsets][m_dim][n_dim] f32.
+ * With A = layer input, B = dZ this yields the reference's ExpertMLP weight layout [E, in, out]
+ * (tutel_moe_layer_nobatch.py:853); with A = dZ, B = input it yields torch.nn.Linear's [out, in].              */
+int swn_wgrad(const void* a, const void* b, int dtype, int m_dim, int n_dim,
+              int n_groups, int n_wsets, int group_stride, const int32_t* group_rows, int group_rows_clamp,
+              float* dw, float* db, int n_splits, void* stream);
+
+/* ---- optimiser -------------------------------------------------------------------------------------------------
+ * torch.optim.Adam (runner.py:486) over one flat fp32 parameter buffer; grad_scale multiplies the gradient
+ * (1/world_size after a sum all-reduce).  Also refreshes the compute copies: shadow (dtype) same layout.         */
+int swn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow, int dtype,
+                  long n, float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+int swn_cast(const float* in, void* out, int dtype, long n, void* stream);
+/* out[b][c][r] = in[b][r][c]  (fp32 master -> dtype compute copy, transposed) */
+int swn_cast_transpose(const float* in, void* out, int dtype, int batch, int rows, int cols, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWN_H */

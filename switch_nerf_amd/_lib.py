@@ -1,0 +1,80 @@
+"""ctypes binding of libswn_hip.so (C ABI: include/swn.h).  Fails loudly when the library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libswn_hip.so")
+
+F32, BF16 = 0, 1
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
+
+
+class ChainLayer(C.Structure):
+    _fields_ = [("w", vp), ("b", vp), ("save", vp), ("mask", vp), ("rowbias", vp), ("rows_per_bias", i32),
+                ("n", i32), ("k", i32), ("relu", i32), ("skip", i32)]
+
+
+class ChainDesc(C.Structure):
+    _fields_ = [("dtype", i32), ("n_layers", i32), ("n_groups", i32), ("n_wsets", i32), ("group_stride", i32),
+                ("group_rows", vp), ("group_rows_clamp", i32), ("x", vp), ("x_gather", vp), ("x_save", vp),
+                ("y", vp), ("y_add", vp), ("y_add_gather", vp), ("layers", ChainLayer * 8)]
+
+
+# name -> argtypes; every symbol declared in include/swn.h must be listed here (tests/test_abi.py checks both ways)
+SIGNATURES = {
+    "swn_version": [],
+    "swn_mfma_probe": [vp, vp],
+    "swn_sample_pe": [vp, vp, vp, f32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp],
+    "swn_gate_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
+    "swn_gate_bwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp],
+    "swn_route_top1": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp],
+    "swn_dispatch_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "swn_dispatch_bwd_data": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "swn_dispatch_bwd_gate": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "swn_combine_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "swn_combine_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp],
+    "swn_heads_fwd": [vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp],
+    "swn_heads_bwd": [vp, vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+    "swn_group_colsum": [vp, i32, i32, i32, i32, vp, vp],
+    "swn_composite_fwd": [vp, vp, f32, i32, i32, vp, vp, vp, vp, vp],
+    "swn_composite_bwd": [vp, vp, f32, vp, i32, i32, vp, vp],
+    "swn_mlp_chain": [C.POINTER(ChainDesc), vp],
+    "swn_wgrad": [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp],
+    "swn_adam_step": [vp, vp, vp, vp, vp, i32, i64, f32, f32, f32, f32, i32, f32, vp],
+    "swn_cast": [vp, vp, i32, i64, vp],
+    "swn_cast_transpose": [vp, vp, i32, i32, i32, i32, vp],
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(switch_nerf_amd/build.sh).  There is no CPU fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    lib.swn_last_error.restype = C.c_char_p
+    lib.swn_last_error.argtypes = []
+    lib.swn_route_workspace_bytes.restype = sz
+    lib.swn_route_workspace_bytes.argtypes = [i32, i32, i32]
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = i32
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {lib.swn_last_error().decode()}")

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build libswn_hip.so (gfx950 only) in-tree.  hipcc cross-compiles without a GPU.
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+cd "$HERE/csrc"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-variable -Wno-unused-but-set-variable -ffp-contract=fast"
+mkdir -p "$HERE/build"
+pids=()
+for f in elementwise route chain wgrad; do
+  if [ ! -f "$HERE/build/$f.o" ] || [ "$f.hip" -nt "$HERE/build/$f.o" ] || [ common.hpp -nt "$HERE/build/$f.o" ] || [ ../../include/swn.h -nt "$HERE/build/$f.o" ]; then
+    $HIPCC $FLAGS -c $f.hip -o "$HERE/build/$f.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC "$HERE"/build/{elementwise,route,chain,wgrad}.o -o "$HERE/libswn_hip.so"
+echo "built $HERE/libswn_hip.so"

@@ -1,0 +1,254 @@
+// swn_route_top1: batch-prioritised top-1 capacity assignment, bit-exact and deterministic.
+//
+// Replaces extract_critical / compute_sorted_location / load_balance
+// (/root/reference/switch_nerf/modules/tutel_moe_ext/tutel_fast_dispatch.py:136-217: three argsorts of the whole
+// segment, two [P,E] int64 gathers and a [P,E] int64 cumsum) and Tutel's fast_cumsum_sub_one by ONE stable LSD
+// radix sort per segment of the 32-bit key  (expert << 26) | (bits(1.0f) - bits(max gate)):
+// ascending key order = expert-major, descending gate, ties in token order.  loc = position - expert start.
+// Keys are softmax maxima, i.e. in [1/E, 1], so bits(1.0f) - bits(g) < 2^26 for E <= 64.
+#include "common.hpp"
+
+namespace swn {
+
+constexpr int KPB = 2048;  // keys per block (256 threads x 8)
+
+__global__ void route_keys_kernel(const int32_t* __restrict__ idx, const float* __restrict__ gmax, int n_tokens,
+                                  int seg_tokens, int E, int bpr, uint32_t* __restrict__ keys, int32_t* __restrict__ vals,
+                                  int32_t* __restrict__ counts) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_tokens) return;
+  const int e = idx[i];
+  uint32_t inv = 0;
+  if (bpr) {
+    const int32_t b = (int32_t)0x3F800000 - (int32_t)__float_as_uint(gmax[i]);
+    inv = b < 0 ? 0u : (b > 0x03FFFFFF ? 0x03FFFFFFu : (uint32_t)b);
+  }
+  keys[i] = ((uint32_t)e << 26) | inv;
+  const int seg = (int)(i / seg_tokens);
+  vals[i] = (int32_t)(i - (long)seg * seg_tokens);
+  atomicAdd(counts + seg * E + e, 1);
+}
+
+__global__ __launch_bounds__(256) void route_hist_kernel(const uint32_t* __restrict__ keys, int seg_tokens, int shift,
+                                                         int nblk, int32_t* __restrict__ hist) {
+  __shared__ int32_t h[256];
+  const int seg = blockIdx.y, blk = blockIdx.x;
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t* k = keys + (long)seg * seg_tokens;
+  for (int j = 0; j < KPB / 256; ++j) {
+    const int p = blk * KPB + j * 256 + threadIdx.x;
+    if (p < seg_tokens) atomicAdd(&h[(k[p] >> shift) & 255], 1);
+  }
+  __syncthreads();
+  hist[((long)seg * 256 + threadIdx.x) * nblk + blk] = h[threadIdx.x];
+}
+
+// exclusive scan of hist[seg][d][blk] in (d, blk) order; one block per segment, thread d owns row d.
+__global__ __launch_bounds__(256) void route_scan_kernel(int32_t* __restrict__ hist, int nblk) {
+  __shared__ int32_t rowsum[256];
+  const int seg = blockIdx.x, d = threadIdx.x;
+  int32_t* row = hist + ((long)seg * 256 + d) * nblk;
+  int32_t s = 0;
+  for (int b = 0; b < nblk; ++b) s += row[b];
+  rowsum[d] = s;
+  __syncthreads();
+  // exclusive scan over 256 row sums (serial in thread 0 would be 256 steps; do Hillis-Steele)
+  int32_t v = s;
+  for (int o = 1; o < 256; o <<= 1) {
+    const int32_t t = (d >= o) ? rowsum[d - o] : 0;
+    __syncthreads();
+    v += t;
+    rowsum[d] = v;
+    __syncthreads();
+  }
+  int32_t run = v - s;  // exclusive prefix of this row
+  for (int b = 0; b < nblk; ++b) {
+    const int32_t c = row[b];
+    row[b] = run;
+    run += c;
+  }
+}
+
+__device__ __forceinline__ unsigned long long match_digit(int d, bool valid) {
+  unsigned long long m = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const bool bit = (d >> b) & 1;
+    const unsigned long long bal = __ballot(bit);
+    m &= bit ? bal : ~bal;
+  }
+  return valid ? m : 0ull;
+}
+
+__global__ __launch_bounds__(256) void route_scatter_kernel(const uint32_t* __restrict__ keys_in,
+                                                            const int32_t* __restrict__ vals_in, int seg_tokens, int shift,
+                                                            int nblk, const int32_t* __restrict__ hist,
+                                                            uint32_t* __restrict__ keys_out, int32_t* __restrict__ vals_out) {
+  __shared__ int32_t wh[4][256];
+  const int seg = blockIdx.y, blk = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long sbase = (long)seg * seg_tokens;
+  for (int j = threadIdx.x; j < 1024; j += 256) (&wh[0][0])[j] = 0;
+  __syncthreads();
+  const int p0 = blk * KPB + w * (KPB / 4);
+  // phase 1: per-wave digit counts
+  for (int r = 0; r < KPB / 4 / 64; ++r) {
+    const int p = p0 + r * 64 + lane;
+    const bool valid = p < seg_tokens;
+    const int d = valid ? (int)((keys_in[sbase + p] >> shift) & 255) : 0;
+    const unsigned long long m = match_digit(d, valid);
+    if (valid && lane == __ffsll((long long)m) - 1) wh[w][d] += __popcll(m);
+  }
+  __syncthreads();
+  // phase 2: per-wave bases
+  {
+    const int d = threadIdx.x;
+    int32_t base = hist[((long)seg * 256 + d) * nblk + blk];
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) {
+      const int32_t c = wh[ww][d];
+      wh[ww][d] = base;
+      base += c;
+    }
+  }
+  __syncthreads();
+  // phase 3: stable scatter
+  for (int r = 0; r < KPB / 4 / 64; ++r) {
+    const int p = p0 + r * 64 + lane;
+    const bool valid = p < seg_tokens;
+    uint32_t key = 0;
+    int32_t val = 0;
+    if (valid) { key = keys_in[sbase + p]; val = vals_in[sbase + p]; }
+    const int d = (int)((key >> shift) & 255);
+    const unsigned long long m = match_digit(d, valid);
+    if (valid) {
+      const int rank = __popcll(m & ((1ull << lane) - 1ull));
+      const int32_t pos = wh[w][d] + rank;
+      keys_out[sbase + pos] = key;
+      vals_out[sbase + pos] = val;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (valid && lane == __ffsll((long long)m) - 1) wh[w][d] += __popcll(m);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ void route_finalize_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ vals,
+                                      const int32_t* __restrict__ counts, int n_tokens, int seg_tokens, int E, int capacity,
+                                      int32_t* __restrict__ loc, int32_t* __restrict__ perm, int32_t* __restrict__ tok2row) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_tokens) return;
+  const int seg = (int)(i / seg_tokens);
+  const int pos = (int)(i - (long)seg * seg_tokens);
+  const int e = (int)(keys[i] >> 26);
+  int start = 0;
+  for (int q = 0; q < e; ++q) start += counts[seg * E + q];
+  const int l = pos - start;
+  const long tok = (long)seg * seg_tokens + vals[i];
+  loc[tok] = l;
+  const long row = ((long)seg * E + e) * capacity + l;
+  if (l < capacity) {
+    if (perm) perm[row] = (int32_t)tok;
+    if (tok2row) tok2row[tok] = (int32_t)row;
+  } else if (tok2row) {
+    tok2row[tok] = -1;
+  }
+}
+
+// me partial sums: grid (nblk, n_seg), block 256; partial[seg][blk][e]
+__global__ __launch_bounds__(256) void laux_partial_kernel(const float* __restrict__ gates, int seg_tokens, int E, int nblk,
+                                                           float* __restrict__ partial) {
+  __shared__ float red[256];
+  const int seg = blockIdx.y, blk = blockIdx.x;
+  const float* gp = gates + (long)seg * seg_tokens * E;
+  // thread t handles expert t % E for tokens t / E + k * (256 / E)   (E divides 256 for E in {1,2,4,8,16,32,64})
+  const int e = threadIdx.x % E, t0 = threadIdx.x / E, tstep = 256 / E;
+  float s = 0.f;
+  const int pbeg = blk * KPB, pend = min(seg_tokens, pbeg + KPB);
+  for (int p = pbeg + t0; p < pend; p += tstep) s += gp[(long)p * E + e];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < E) {
+    float a = 0.f;
+    for (int t = threadIdx.x; t < 256; t += E) a += red[t];
+    partial[((long)seg * nblk + blk) * E + threadIdx.x] = a;
+  }
+}
+
+__global__ void laux_final_kernel(const float* __restrict__ partial, const int32_t* __restrict__ counts, int seg_tokens,
+                                  int E, int nblk, float* __restrict__ l_aux) {
+  const int seg = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  float tot = 0.f;
+  for (int e = 0; e < E; ++e) {
+    float me = 0.f;
+    for (int b = 0; b < nblk; ++b) me += partial[((long)seg * nblk + b) * E + e];
+    tot += me * (float)counts[seg * E + e];
+  }
+  const float scale = (float)((double)E / ((double)seg_tokens * (double)seg_tokens));
+  l_aux[seg] = tot * scale;
+}
+
+}  // namespace swn
+
+using namespace swn;
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t swn_route_workspace_bytes(int n_tokens, int n_seg, int n_experts) {
+  const int seg_tokens = n_seg > 0 ? (n_tokens + n_seg - 1) / n_seg : n_tokens;
+  const int nblk = (seg_tokens + KPB - 1) / KPB;
+  return 4 * align256((size_t)n_tokens * 4) + align256((size_t)n_seg * 256 * nblk * 4) +
+         align256((size_t)n_seg * nblk * n_experts * 4) + 1024;
+}
+
+extern "C" int swn_route_top1(const int32_t* idx, const float* gmax, const float* gates, int n_tokens, int seg_tokens,
+                              int n_experts, int capacity, int bpr, int32_t* loc, int32_t* counts, int32_t* perm,
+                              int32_t* tok2row, float* l_aux, void* workspace, size_t workspace_bytes, void* stream) {
+  SWN_CHECK(idx && gmax && loc && counts && workspace, "swn_route_top1: null pointer");
+  SWN_CHECK(n_tokens > 0 && seg_tokens > 0 && n_tokens % seg_tokens == 0,
+            "swn_route_top1: n_tokens (%d) must be a positive multiple of seg_tokens (%d)", n_tokens, seg_tokens);
+  SWN_CHECK(n_experts >= 1 && n_experts <= 64 && (256 % n_experts) == 0, "swn_route_top1: experts must divide 256 (<= 64)");
+  SWN_CHECK(capacity >= 1, "swn_route_top1: capacity must be >= 1");
+  const int n_seg = n_tokens / seg_tokens;
+  SWN_CHECK(workspace_bytes >= swn_route_workspace_bytes(n_tokens, n_seg, n_experts), "swn_route_top1: workspace too small");
+  const int nblk = cdiv(seg_tokens, KPB);
+  char* ws = (char*)workspace;
+  const size_t tb = align256((size_t)n_tokens * 4);
+  uint32_t* k0 = (uint32_t*)ws;
+  uint32_t* k1 = (uint32_t*)(ws + tb);
+  int32_t* v0 = (int32_t*)(ws + 2 * tb);
+  int32_t* v1 = (int32_t*)(ws + 3 * tb);
+  int32_t* hist = (int32_t*)(ws + 4 * tb);
+  float* partial = (float*)(ws + 4 * tb + align256((size_t)n_seg * 256 * nblk * 4));
+  hipStream_t s = as_stream(stream);
+  hipError_t e = hipMemsetAsync(counts, 0, (size_t)n_seg * n_experts * 4, s);
+  SWN_CHECK(e == hipSuccess, "memset: %s", hipGetErrorString(e));
+  if (perm) {
+    e = hipMemsetAsync(perm, 0xFF, (size_t)n_seg * n_experts * capacity * 4, s);
+    SWN_CHECK(e == hipSuccess, "memset: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(route_keys_kernel, dim3(cdiv(n_tokens, 256)), dim3(256), 0, s, idx, gmax, n_tokens, seg_tokens,
+                     n_experts, bpr, k0, v0, counts);
+  SWN_LAUNCH_CHECK();
+  uint32_t *ki = k0, *ko = k1;
+  int32_t *vi = v0, *vo = v1;
+  for (int shift = bpr ? 0 : 24; shift < 32; shift += 8) {
+    hipLaunchKernelGGL(route_hist_kernel, dim3(nblk, n_seg), dim3(256), 0, s, ki, seg_tokens, shift, nblk, hist);
+    hipLaunchKernelGGL(route_scan_kernel, dim3(n_seg), dim3(256), 0, s, hist, nblk);
+    hipLaunchKernelGGL(route_scatter_kernel, dim3(nblk, n_seg), dim3(256), 0, s, ki, vi, seg_tokens, shift, nblk, hist, ko, vo);
+    SWN_LAUNCH_CHECK();
+    uint32_t* tk = ki; ki = ko; ko = tk;
+    int32_t* tv = vi; vi = vo; vo = tv;
+  }
+  hipLaunchKernelGGL(route_finalize_kernel, dim3(cdiv(n_tokens, 256)), dim3(256), 0, s, ki, vi, counts, n_tokens,
+                     seg_tokens, n_experts, capacity, loc, perm, tok2row);
+  SWN_LAUNCH_CHECK();
+  if (gates && l_aux) {
+    hipLaunchKernelGGL(laux_partial_kernel, dim3(nblk, n_seg), dim3(256), 0, s, gates, seg_tokens, n_experts, nblk, partial);
+    hipLaunchKernelGGL(laux_final_kernel, dim3(n_seg), dim3(64), 0, s, partial, counts, seg_tokens, n_experts, nblk, l_aux);
+    SWN_LAUNCH_CHECK();
+  }
+  return 0;
+}

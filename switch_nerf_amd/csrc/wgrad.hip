@@ -1,0 +1,271 @@
+// swn_wgrad: grouped weight-gradient GEMM  dW[g % n_wsets] += A_g^T @ B_g,  db += colsum(B_g)   (fp32 atomics).
+//
+// Replaces autograd's backward of torch.baddbmm w.r.t. the expert weights (ExpertMLP,
+// /root/reference/switch_nerf/modules/tutel_moe_ext/tutel_moe_layer_nobatch.py:908) and of F.linear (Mlp,
+// models/nerf_moe.py:34).  The reduction runs over ROWS (tokens), which is the slow dimension of both row-major
+// operands, while the bf16 MFMA wants 8 consecutive k per lane.  Operand slabs [32 rows][<=256 cols] are staged
+// in LDS row-major; a lane reads an 8-byte (A) / 4-byte (B) piece of 8 rows and interleaves row pairs in registers,
+// which yields 4 (A) / 2 (B) fragments whose MFMA row/col labels are a fixed permutation of the real columns.
+// The bias gradient is one extra MFMA per step with an all-ones A fragment (no extra LDS traffic).
+// The roofline of this kernel is HBM: each operand row is read exactly once ((m+n) elements per 2*m*n flops).
+//
+// Workgroup = 512 threads = 8 waves as 2 (m) x 4 (n); wave tile 128 x 64; full 256 x 256 dW tile per workgroup;
+// grid = (groups, row splits).
+#include "common.hpp"
+
+namespace swn {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+constexpr int WG_NT = 512;
+
+template <typename T> struct WCfg;
+template <> struct WCfg<bf16_t> { static constexpr int BKR = 32; };
+template <> struct WCfg<float> { static constexpr int BKR = 16; };
+
+struct WgradArgs {
+  const void* a;
+  const void* b;
+  int m_dim, n_dim, n_groups, n_wsets, group_stride, clamp, rows_per_split;
+  const int32_t* group_rows;
+  float* dw;
+  float* db;
+};
+
+__device__ __forceinline__ bf16x8_t as_frag(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3) {
+  u32x4_t v = {r0, r1, r2, r3};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BKR = WCfg<T>::BKR;
+  constexpr int RS = 256 * (int)sizeof(T);  // LDS row stride in bytes
+  constexpr int SLAB = BKR * RS;            // bytes of one operand slab
+  auto sa = [&](int b_) -> char* { return smem + b_ * 2 * SLAB; };
+  auto sb = [&](int b_) -> char* { return smem + b_ * 2 * SLAB + SLAB; };
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int g = blockIdx.x, split = blockIdx.y;
+  int rows_valid = p.group_stride;
+  if (p.group_rows) rows_valid = min(p.group_rows[g], p.clamp);
+  const int r_begin = split * p.rows_per_split;
+  const int r_end = min(rows_valid, r_begin + p.rows_per_split);
+  if (r_begin >= r_end) return;
+  const long grow0 = (long)g * p.group_stride;
+  const int wset = g % p.n_wsets;
+  const int m_dim = p.m_dim, n_dim = p.n_dim;
+
+  f32x16_t acc[4][2];
+  f32x16_t accb[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[j][r] = 0.f;
+
+  const int a_cpr = m_dim * (int)sizeof(T) / 16, b_cpr = n_dim * (int)sizeof(T) / 16;  // 16-B chunks per row
+  const int a_total = BKR * a_cpr, b_total = BKR * b_cpr;
+  uint4 ra[2], rb[2];
+  auto gload = [&](int r0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + WG_NT * i;
+      if (c < a_total) {
+        const int row = c / a_cpr, ch = c - row * a_cpr;
+        ra[i] = (r0 + row < r_end)
+                    ? *(const uint4*)((const char*)p.a + ((grow0 + r0 + row) * (long)m_dim) * sizeof(T) + ch * 16)
+                    : make_uint4(0, 0, 0, 0);
+      }
+      if (c < b_total) {
+        const int row = c / b_cpr, ch = c - row * b_cpr;
+        rb[i] = (r0 + row < r_end)
+                    ? *(const uint4*)((const char*)p.b + ((grow0 + r0 + row) * (long)n_dim) * sizeof(T) + ch * 16)
+                    : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + WG_NT * i;
+      if (c < a_total) {
+        const int row = c / a_cpr, ch = c - row * a_cpr;
+        *(uint4*)(sa(buf) + row * RS + ch * 16) = ra[i];
+      }
+      if (c < b_total) {
+        const int row = c / b_cpr, ch = c - row * b_cpr;
+        *(uint4*)(sb(buf) + row * RS + ch * 16) = rb[i];
+      }
+    }
+  };
+
+  const bool active = (wm * 128 < m_dim) && (wn * 64 < n_dim);
+  const bool do_bias = (p.db != nullptr) && wm == 0 && (wn * 64 < n_dim);
+
+  gload(r_begin);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int r0 = r_begin; r0 < r_end; r0 += BKR) {
+    const bool more = r0 + BKR < r_end;
+    if (more) gload(r0 + BKR);
+    const char* A = sa(buf);
+    const char* B = sb(buf);
+    if (active || do_bias) {
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int kk = 0; kk < BKR / 16; ++kk) {
+          const int rb0 = kk * 16 + lhi * 8;
+          uint2 pa[8];
+          uint32_t pb[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            pa[j] = *(const uint2*)(A + (rb0 + j) * RS + (wm * 128 + 4 * l31) * 2);
+            pb[j] = *(const uint32_t*)(B + (rb0 + j) * RS + (wn * 64 + 2 * l31) * 2);
+          }
+          bf16x8_t fa[4], fb[2];
+          {
+            uint32_t lo[4], hi[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              lo[t] = (pa[2 * t].x & 0xFFFFu) | (pa[2 * t + 1].x << 16);
+              hi[t] = (pa[2 * t].x >> 16) | (pa[2 * t + 1].x & 0xFFFF0000u);
+            }
+            fa[0] = as_frag(lo[0], lo[1], lo[2], lo[3]);
+            fa[1] = as_frag(hi[0], hi[1], hi[2], hi[3]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              lo[t] = (pa[2 * t].y & 0xFFFFu) | (pa[2 * t + 1].y << 16);
+              hi[t] = (pa[2 * t].y >> 16) | (pa[2 * t + 1].y & 0xFFFF0000u);
+            }
+            fa[2] = as_frag(lo[0], lo[1], lo[2], lo[3]);
+            fa[3] = as_frag(hi[0], hi[1], hi[2], hi[3]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              lo[t] = (pb[2 * t] & 0xFFFFu) | (pb[2 * t + 1] << 16);
+              hi[t] = (pb[2 * t] >> 16) | (pb[2 * t + 1] & 0xFFFF0000u);
+            }
+            fb[0] = as_frag(lo[0], lo[1], lo[2], lo[3]);
+            fb[1] = as_frag(hi[0], hi[1], hi[2], hi[3]);
+          }
+          if (active) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int qq = 0; qq < 2; ++qq)
+                acc[q][qq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q], fb[qq], acc[q][qq], 0, 0, 0);
+          }
+          if (do_bias) {
+            const bf16x8_t ones = as_frag(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+              accb[qq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fb[qq], accb[qq], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll 2
+        for (int kk = 0; kk < BKR / 2; ++kk) {
+          const int row = kk * 2 + lhi;
+          float fa[4], fb[2];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) fa[q] = *(const float*)(A + row * RS + (wm * 128 + q * 32 + l31) * 4);
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) fb[qq] = *(const float*)(B + row * RS + (wn * 64 + qq * 32 + l31) * 4);
+          if (active) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int qq = 0; qq < 2; ++qq)
+                acc[q][qq] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q], fb[qq], acc[q][qq], 0, 0, 0);
+          }
+          if (do_bias) {
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+              accb[qq] = __builtin_amdgcn_mfma_f32_32x32x2f32(1.0f, fb[qq], accb[qq], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue: fp32 atomics into dW[wset][m][n] ----
+  float* dw = p.dw + (size_t)wset * m_dim * n_dim;
+  if (active) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          int m, n;
+          if constexpr (sizeof(T) == 2) {
+            m = wm * 128 + 4 * i + q;
+            n = wn * 64 + 2 * l31 + qq;
+          } else {
+            m = wm * 128 + q * 32 + i;
+            n = wn * 64 + qq * 32 + l31;
+          }
+          if (m < m_dim && n < n_dim) unsafeAtomicAdd(dw + (size_t)m * n_dim + n, acc[q][qq][r]);
+        }
+  }
+  if (do_bias && lhi == 0) {
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      int n;
+      if constexpr (sizeof(T) == 2) n = wn * 64 + 2 * l31 + qq; else n = wn * 64 + qq * 32 + l31;
+      if (n < n_dim) unsafeAtomicAdd(p.db + (size_t)wset * n_dim + n, accb[qq][0]);  // D row i = 0 (every row equal)
+    }
+  }
+}
+
+}  // namespace swn
+
+using namespace swn;
+
+extern "C" int swn_wgrad(const void* a, const void* b, int dtype, int m_dim, int n_dim, int n_groups, int n_wsets,
+                         int group_stride, const int32_t* group_rows, int group_rows_clamp, float* dw, float* db,
+                         int n_splits, void* stream) {
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_wgrad: bad dtype %d", dtype);
+  SWN_CHECK(m_dim >= 32 && m_dim <= 256 && m_dim % 32 == 0 && n_dim >= 32 && n_dim <= 256 && n_dim % 32 == 0,
+            "swn_wgrad: m_dim=%d n_dim=%d must be multiples of 32 in [32,256]", m_dim, n_dim);
+  SWN_CHECK(n_groups >= 1 && n_wsets >= 1 && group_stride >= 1 && n_splits >= 1, "swn_wgrad: bad geometry");
+  SWN_CHECK(a && b && dw, "swn_wgrad: null pointer");
+  const int bkr = dtype == SWN_BF16 ? 32 : 16;
+  const int max_rows = group_rows ? (group_rows_clamp < group_stride ? group_rows_clamp : group_stride) : group_stride;
+  int rps = cdiv(max_rows, n_splits);
+  rps = cdiv(rps, bkr) * bkr;
+  const int splits = cdiv(max_rows, rps);
+  WgradArgs p;
+  p.a = a; p.b = b; p.m_dim = m_dim; p.n_dim = n_dim; p.n_groups = n_groups; p.n_wsets = n_wsets;
+  p.group_stride = group_stride; p.clamp = group_rows ? group_rows_clamp : group_stride; p.rows_per_split = rps;
+  p.group_rows = group_rows; p.dw = dw; p.db = db;
+  const int lds = 4 * bkr * 256 * (dtype == SWN_BF16 ? 2 : 4);
+  hipError_t e;
+  if (dtype == SWN_BF16) {
+    e = hipFuncSetAttribute((const void*)wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(n_groups, splits), dim3(WG_NT), lds, as_stream(stream), p);
+  } else {
+    e = hipFuncSetAttribute((const void*)wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(wgrad_kernel<float>, dim3(n_groups, splits), dim3(WG_NT), lds, as_stream(stream), p);
+  }
+  SWN_LAUNCH_CHECK();
+  return 0;
+}

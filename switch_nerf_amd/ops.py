@@ -1,0 +1,252 @@
+"""Torch-tensor wrappers over the C ABI (include/swn.h).  torch is used for device memory and streams only.
+
+Every function enqueues HIP kernels from libswn_hip.so on torch's current stream.  There is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, ChainDesc, call
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "tensors passed to the HIP library must be contiguous device tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def torch_dtype(code: int):
+    return torch.float32 if code == F32 else torch.bfloat16
+
+
+def mfma_probe() -> torch.Tensor:
+    out = torch.zeros(2048, dtype=torch.int32, device="cuda")
+    call("swn_mfma_probe", _p(out), _stream())
+    return out
+
+
+def sample_pe(rays, t_steps, perturb_rand, perturb: float, n_samples: int, l_xyz: int, l_dir: int, dtype,
+              pe_stride: int, dir_stride: int):
+    """-> z [N,S] f32, pe_xyz [N*S, pe_stride] dtype, pe_dir [N, dir_stride] dtype"""
+    n = rays.shape[0]
+    z = torch.empty(n, n_samples, dtype=torch.float32, device=rays.device)
+    pe = torch.empty(n * n_samples, pe_stride, dtype=dtype, device=rays.device)
+    pd = torch.empty(n, dir_stride, dtype=dtype, device=rays.device)
+    call("swn_sample_pe", _p(rays), _p(t_steps), _p(perturb_rand), float(perturb), n, n_samples, l_xyz, l_dir, _dt(pe),
+         _p(z), _p(pe), pe_stride, _p(pd), dir_stride, _stream())
+    return z, pe, pd
+
+
+def gate_fwd(g, ln_w, ln_b, wg):
+    P, G = g.shape
+    E = wg.shape[0]
+    dev = g.device
+    gates = torch.empty(P, E, dtype=torch.float32, device=dev)
+    idx = torch.empty(P, dtype=torch.int32, device=dev)
+    gmax = torch.empty(P, dtype=torch.float32, device=dev)
+    stats = torch.empty(P, 2, dtype=torch.float32, device=dev)
+    call("swn_gate_fwd", _p(g), _dt(g), _p(ln_w), _p(ln_b), _p(wg), P, G, E, _p(gates), _p(idx), _p(gmax), _p(stats), _stream())
+    return gates, idx, gmax, stats
+
+
+def gate_bwd(g, ln_w, ln_b, wg, gates, idx, d_gmax, stats, counts, laux_coef, seg_tokens, d_wg, d_ln_w, d_ln_b):
+    """Accumulates into d_wg / d_ln_w / d_ln_b (fp32), returns dg."""
+    P, G = g.shape
+    E = wg.shape[0]
+    dg = torch.empty_like(g)
+    call("swn_gate_bwd", _p(g), _dt(g), _p(ln_w), _p(ln_b), _p(wg), _p(gates), _p(idx), _p(d_gmax), _p(stats), _p(counts),
+         _p(laux_coef), int(seg_tokens), P, G, E, _p(dg), _p(d_wg), _p(d_ln_w), _p(d_ln_b), _stream())
+    return dg
+
+
+_route_ws = {}
+
+
+def route_top1(idx, gmax, gates, seg_tokens: int, n_experts: int, capacity: int, bpr: bool, want_perm=True):
+    P = idx.shape[0]
+    n_seg = P // seg_tokens
+    dev = idx.device
+    loc = torch.empty(P, dtype=torch.int32, device=dev)
+    counts = torch.empty(n_seg, n_experts, dtype=torch.int32, device=dev)
+    perm = torch.empty(n_seg, n_experts * capacity, dtype=torch.int32, device=dev) if want_perm else None
+    tok2row = torch.empty(P, dtype=torch.int32, device=dev)
+    l_aux = torch.empty(n_seg, dtype=torch.float32, device=dev) if gates is not None else None
+    nbytes = _lib.load().swn_route_workspace_bytes(P, n_seg, n_experts)
+    key = (dev, nbytes)
+    ws = _route_ws.get(key)
+    if ws is None:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _route_ws.clear()
+        _route_ws[key] = ws
+    call("swn_route_top1", _p(idx), _p(gmax), _p(gates), P, int(seg_tokens), n_experts, int(capacity), int(bool(bpr)),
+         _p(loc), _p(counts), _p(perm), _p(tok2row), _p(l_aux), _p(ws), nbytes, _stream())
+    return loc, counts, perm, tok2row, l_aux
+
+
+def dispatch_fwd(gates, indices, locations, x, n_experts: int, capacity: int):
+    S, H = x.shape
+    d = torch.empty(n_experts * capacity, H, dtype=x.dtype, device=x.device)
+    call("swn_dispatch_fwd", _p(gates), _p(indices), _p(locations), _p(x), _p(d), _dt(x), S, H, capacity, n_experts, _stream())
+    return d
+
+
+def dispatch_bwd_data(gates, indices, locations, dispatched, capacity: int):
+    S = indices.shape[0]
+    H = dispatched.shape[1]
+    out = torch.empty(S, H, dtype=dispatched.dtype, device=dispatched.device)
+    call("swn_dispatch_bwd_data", _p(gates), _p(indices), _p(locations), _p(out), _p(dispatched), _dt(out), S, H, capacity, _stream())
+    return out
+
+
+def dispatch_bwd_gate(indices, locations, x, dispatched, capacity: int):
+    S, H = x.shape
+    gg = torch.empty(S, dtype=torch.float32, device=x.device)
+    call("swn_dispatch_bwd_gate", _p(gg), _p(indices), _p(locations), _p(x), _p(dispatched), _dt(x), S, H, capacity, _stream())
+    return gg
+
+
+def combine_fwd(gates, indices, locations, expert_out, capacity: int, seg_tokens: int, n_experts: int, relu: bool):
+    S = indices.shape[0]
+    H = expert_out.shape[1]
+    y = torch.empty(S, H, dtype=expert_out.dtype, device=expert_out.device)
+    call("swn_combine_fwd", _p(gates), _p(indices), _p(locations), _p(y), _p(expert_out), _dt(y), S, H, capacity,
+         int(seg_tokens), n_experts, int(bool(relu)), _stream())
+    return y
+
+
+def combine_bwd(dy_in, y, dsig, wsig, gate):
+    S, H = y.shape
+    dout = torch.empty_like(y)
+    dgate = torch.empty(S, dtype=torch.float32, device=y.device)
+    call("swn_combine_bwd", _p(dy_in), _p(y), _p(dsig), _p(wsig), _p(gate), _dt(y), S, H, _p(dout), _p(dgate), _stream())
+    return dout, dgate
+
+
+def heads_fwd(y, h2, w_sigma, b_sigma, w_color, b_color, sigma_noise):
+    P, M = y.shape
+    H2 = h2.shape[1]
+    raw = torch.empty(P, 4, dtype=torch.float32, device=y.device)
+    call("swn_heads_fwd", _p(y), _p(h2), _dt(y), _p(w_sigma), _p(b_sigma), _p(w_color), _p(b_color), _p(sigma_noise), P, M, H2,
+         _p(raw), _stream())
+    return raw
+
+
+def heads_bwd(y, h2, w_color, raw, d_raw, d_w_sigma, d_b_sigma, d_w_color, d_b_color):
+    P, M = y.shape
+    H2 = h2.shape[1]
+    dh2 = torch.empty_like(h2)
+    dsig = torch.empty(P, dtype=torch.float32, device=y.device)
+    call("swn_heads_bwd", _p(y), _p(h2), _dt(y), _p(w_color), _p(raw), _p(d_raw), P, M, H2, _p(dh2), _p(dsig), _p(d_w_sigma),
+         _p(d_b_sigma), _p(d_w_color), _p(d_b_color), _stream())
+    return dh2, dsig
+
+
+def group_colsum(x, rows_per_group: int):
+    R, Cc = x.shape
+    g = R // rows_per_group
+    out = torch.empty(g, Cc, dtype=torch.float32, device=x.device)
+    call("swn_group_colsum", _p(x), _dt(x), g, rows_per_group, Cc, _p(out), _stream())
+    return out
+
+
+def composite_fwd(raw, z, last_delta=1e10, want_weights=False):
+    N, S = z.shape
+    dev = z.device
+    rgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
+    depth = torch.empty(N, dtype=torch.float32, device=dev)
+    dvar = torch.empty(N, dtype=torch.float32, device=dev)
+    w = torch.empty(N, S, dtype=torch.float32, device=dev) if want_weights else None
+    call("swn_composite_fwd", _p(raw), _p(z), float(last_delta), N, S, _p(rgb), _p(depth), _p(dvar), _p(w), _stream())
+    return rgb, depth, dvar, w
+
+
+def composite_bwd(raw, z, d_rgb, last_delta=1e10):
+    N, S = z.shape
+    d_raw = torch.empty(N * S, 4, dtype=torch.float32, device=z.device)
+    call("swn_composite_bwd", _p(raw), _p(z), float(last_delta), _p(d_rgb), N, S, _p(d_raw), _stream())
+    return d_raw
+
+
+class Layer:
+    """One Linear of a chain: w [n_wsets, N, K] (compute dtype, K contiguous), b [n_wsets, N] f32 or None."""
+
+    def __init__(self, w, b=None, relu=0, skip=False, save=None, mask=None, rowbias=None, rows_per_bias=0):
+        self.w, self.b, self.relu, self.skip, self.save, self.mask = w, b, int(relu), bool(skip), save, mask
+        self.rowbias, self.rows_per_bias = rowbias, int(rows_per_bias)
+
+
+def chain_tile_rows(dtype) -> int:
+    return 128 if dtype == torch.bfloat16 else 64
+
+
+def chain_mask_words(dtype, n_groups: int, group_stride: int) -> int:
+    """uint32 words per layer mask buffer for a chain launch with this geometry."""
+    bm = chain_tile_rows(dtype)
+    tiles = (group_stride + bm - 1) // bm
+    mi = 2 if dtype == torch.bfloat16 else 1
+    return tiles * n_groups * 8 * mi * 64
+
+
+def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride=None, group_rows=None,
+              group_rows_clamp=None, x_gather=None, x_save=None, y_add=None, y_add_gather=None):
+    d = ChainDesc()
+    d.dtype = _dt(x)
+    d.n_layers = len(layers)
+    d.n_groups, d.n_wsets = int(n_groups), int(n_wsets)
+    d.group_stride = int(group_stride if group_stride is not None else y.shape[0])
+    d.group_rows = _p(group_rows)
+    d.group_rows_clamp = int(group_rows_clamp if group_rows_clamp is not None else d.group_stride)
+    d.x, d.x_gather, d.x_save, d.y = _p(x), _p(x_gather), _p(x_save), _p(y)
+    d.y_add, d.y_add_gather = _p(y_add), _p(y_add_gather)
+    for i, ly in enumerate(layers):
+        L = d.layers[i]
+        assert ly.w.dtype == x.dtype and ly.w.dim() == 3, "weights must be [n_wsets, N, K] in the compute dtype"
+        L.w, L.b, L.save, L.mask = _p(ly.w), _p(ly.b), _p(ly.save), _p(ly.mask)
+        L.rowbias, L.rows_per_bias = _p(ly.rowbias), ly.rows_per_bias
+        L.n, L.k = ly.w.shape[1], ly.w.shape[2]
+        L.relu, L.skip = ly.relu, int(ly.skip)
+    call("swn_mlp_chain", C.byref(d), _stream())
+    return y
+
+
+def wgrad(a, b, dw, db=None, n_groups=1, n_wsets=1, group_stride=None, group_rows=None, group_rows_clamp=None, n_splits=8):
+    """dw [n_wsets, m_dim, n_dim] f32 += a^T b per group; db [n_wsets, n_dim] += colsum(b)."""
+    m_dim, n_dim = a.shape[1], b.shape[1]
+    gs = int(group_stride if group_stride is not None else a.shape[0])
+    call("swn_wgrad", _p(a), _p(b), _dt(a), m_dim, n_dim, int(n_groups), int(n_wsets), gs, _p(group_rows),
+         int(group_rows_clamp if group_rows_clamp is not None else gs), _p(dw), _p(db), int(n_splits), _stream())
+
+
+def adam_step(param, grad, m, v, shadow, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    n = param.numel()
+    call("swn_adam_step", _p(param), _p(grad), _p(m), _p(v), _p(shadow), _dt(shadow) if shadow is not None else F32, n,
+         float(lr), float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _stream())
+
+
+def cast(src, dst):
+    call("swn_cast", _p(src), _p(dst), _dt(dst), src.numel(), _stream())
+    return dst
+
+
+def cast_transpose(src, dst):
+    """src [B, R, C] f32 -> dst [B, C, R] (dst dtype)"""
+    B, R, Cc = src.shape
+    call("swn_cast_transpose", _p(src), _p(dst), _dt(dst), B, R, Cc, _stream())
+    return dst

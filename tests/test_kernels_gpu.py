@@ -1,0 +1,431 @@
+"""Kernel-level parity: every HIP entry point of libswn_hip.so (called through the C ABI) against the CPU oracle.
+Integer / index outputs are compared bit-exactly; fp32 within the tolerance written at each check."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import switchnerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+REPORT = {}
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def ops():
+    from switch_nerf_amd import ops as _ops
+    return _ops
+
+
+def report(name, got, ref):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    err = (got - ref).abs().max().item()
+    REPORT[name] = dict(max_abs_err=err, ref_max=ref.abs().max().item())
+    out = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "kernel_parity.json"), "w") as f:
+        json.dump(REPORT, f, indent=1)
+    return err
+
+
+def test_mfma_layout_probe():
+    out = ops().mfma_probe().cpu().numpy()
+    t1 = out[:1024].reshape(64, 16)
+    t2 = out[1024:].reshape(64, 16)
+    for l in range(64):
+        for r in range(16):
+            j = l & 31
+            i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+            assert t1[l, r] == (i % 16) + 16 * (j % 4), ("bf16 32x32x16 C/D map", l, r, t1[l, r])
+            assert t2[l, r] == (i % 2) + 2 * (j % 8), ("f32 32x32x2 C/D map", l, r, t2[l, r])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("perturb", [0.0, 1.0])
+def test_sample_pe(dtype, perturb):
+    N, S = 37, 64
+    rays, _, _ = synth.make_rays(7, N)
+    rng = np.random.default_rng(8)
+    pr = rng.uniform(0, 1, (N, S)).astype(np.float32)
+    r = torch.from_numpy(rays)
+    zr = O.sample_z(r[:, 6:7], r[:, 7:8], S, perturb, torch.from_numpy(pr))
+    xyz = r[:, None, :3] + r[:, None, 3:6] * zr[:, :, None]
+    pe_ref = O.positional_encoding(xyz.reshape(-1, 3), 12)
+    pd_ref = O.positional_encoding(r[:, 3:6], 4)
+    t = torch.linspace(0, 1, S)
+    z, pe, pd = ops().sample_pe(r.to(dev()), t.to(dev()), torch.from_numpy(pr).to(dev()), perturb, S, 12, 4, dtype, 128, 32)
+    assert torch.equal(z.cpu(), zr), "z values must be bit-exact (same fp32 op sequence)"
+    tol = 2e-6 if dtype == torch.float32 else 8e-3
+    assert report(f"pe_xyz_{dtype}_{perturb}", pe[:, :75], pe_ref) <= tol
+    assert report(f"pe_dir_{dtype}_{perturb}", pd[:, :27], pd_ref) <= tol
+    assert pe[:, 75:].abs().max().item() == 0 and pd[:, 27:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("E", [8, 16])
+def test_gate_fwd_bwd(E):
+    P, Gd = 3000, 256
+    rng = np.random.default_rng(11)
+    g = torch.from_numpy(rng.standard_normal((P, Gd)).astype(np.float32))
+    lw = torch.from_numpy((1 + 0.1 * rng.standard_normal(Gd)).astype(np.float32))
+    lb = torch.from_numpy((0.1 * rng.standard_normal(Gd)).astype(np.float32))
+    wg = torch.from_numpy((rng.standard_normal((E, Gd)) / 16).astype(np.float32))
+    gg = g.clone().requires_grad_(True)
+    lwr, lbr, wgr = lw.clone().requires_grad_(True), lb.clone().requires_grad_(True), wg.clone().requires_grad_(True)
+    xn = torch.nn.functional.layer_norm(gg, (Gd,), lwr, lbr, 1e-5)
+    gates_ref = torch.softmax(xn @ wgr.t(), 1)
+    gates, idx, gmax, stats = ops().gate_fwd(g.to(dev()), lw.to(dev()), lb.to(dev()), wg.to(dev()))
+    assert report(f"gate_probs_E{E}", gates, gates_ref) <= 2e-6
+    ref_idx = gates_ref.argmax(1)
+    srt = gates_ref.detach().sort(1).values
+    safe = (srt[:, -1] - srt[:, -2]) > 1e-5
+    assert torch.equal(idx.cpu()[safe].long(), ref_idx[safe])
+    assert torch.equal(gmax.cpu(), gates.cpu().gather(1, idx.cpu().long()[:, None])[:, 0])
+    # backward: L = sum(d_gmax * gates[idx]) + coef * sum_e counts_e * sum_s gates[s,e]   (one segment)
+    d_gmax = torch.from_numpy(rng.standard_normal(P).astype(np.float32))
+    counts = torch.bincount(idx.cpu().long(), minlength=E).int()
+    coef = 0.37
+    loss = (d_gmax * gates_ref.gather(1, idx.cpu().long()[:, None])[:, 0]).sum() + coef * (gates_ref.sum(0) * counts.float()).sum()
+    loss.backward()
+    d_wg = torch.zeros(E, Gd, device=dev())
+    d_lw = torch.zeros(Gd, device=dev())
+    d_lb = torch.zeros(Gd, device=dev())
+    dg = ops().gate_bwd(g.to(dev()), lw.to(dev()), lb.to(dev()), wg.to(dev()), gates, idx, d_gmax.to(dev()), stats,
+                        counts.to(dev()).view(1, E), torch.tensor([coef], device=dev()), P, d_wg, d_lw, d_lb)
+    assert report(f"gate_dg_E{E}", dg, gg.grad) <= 1e-5 * max(1.0, gg.grad.abs().max().item())
+    assert report(f"gate_dwg_E{E}", d_wg, wgr.grad) <= 2e-4 * max(1.0, wgr.grad.abs().max().item())
+    assert report(f"gate_dlnw_E{E}", d_lw, lwr.grad) <= 2e-4 * max(1.0, lwr.grad.abs().max().item())
+    assert report(f"gate_dlnb_E{E}", d_lb, lbr.grad) <= 2e-4 * max(1.0, lbr.grad.abs().max().item())
+
+
+def _route_check(gates_np, seg_tokens, E, cf, bpr):
+    P = gates_np.shape[0]
+    n_seg = P // seg_tokens
+    gates = torch.from_numpy(gates_np).to(dev())
+    idx = gates.argmax(1).int()
+    # first-max semantics of the gate kernel: torch.argmax returns the first maximal index on ties as well
+    gmax = gates.gather(1, idx.long()[:, None])[:, 0].contiguous()
+    cap = O.capacity_of(seg_tokens, E, cf)
+    loc, counts, perm, tok2row, l_aux = ops().route_top1(idx, gmax, gates, seg_tokens, E, cap, bpr)
+    loc, counts, perm, tok2row, l_aux = [t.cpu().numpy() for t in (loc, counts, perm, tok2row, l_aux)]
+    for s in range(n_seg):
+        sl = slice(s * seg_tokens, (s + 1) * seg_tokens)
+        r = O.route_top1(gates_np[sl], cf, bpr)
+        assert np.array_equal(idx.cpu().numpy()[sl], r["idx"])
+        assert np.array_equal(loc[sl], r["loc"]), f"segment {s}: loc mismatch"
+        assert np.array_equal(counts[s], r["counts"])
+        rows = np.where(r["loc"] < cap, s * E * cap + r["idx"].astype(np.int64) * cap + r["loc"], -1)
+        assert np.array_equal(tok2row[sl], rows)
+        exp_perm = np.full(E * cap, -1, np.int64)
+        kept = r["loc"] < cap
+        exp_perm[r["idx"][kept].astype(np.int64) * cap + r["loc"][kept]] = np.nonzero(kept)[0] + s * seg_tokens
+        assert np.array_equal(perm[s], exp_perm)
+        la = O.load_balance_loss(torch.from_numpy(gates_np[sl]), torch.from_numpy(r["idx"]))
+        assert abs(l_aux[s] - la.item()) <= 2e-6 * abs(la.item())
+    return loc
+
+
+@pytest.mark.parametrize("bpr", [False, True])
+@pytest.mark.parametrize("cf", [1.0, 1.25, 0.5])
+def test_route_golden(bpr, cf):
+    g = np.load(os.path.join(G, f"route_p2048_e8_bpr{int(bpr)}_cf{cf}.npz"))
+    gates = synth.make_gates(int(g["seed"]), 2048, 8, 1.0)
+    loc = _route_check(gates, 2048, 8, cf, bpr)
+    assert np.array_equal(loc, g["loc"])  # the reference's own answer (tie-free fixture)
+
+
+def test_route_ragged_and_ties_and_scale():
+    g = np.load(os.path.join(G, "route_p1000_e16_bpr1_cf1.0.npz"))
+    loc = _route_check(synth.make_gates(102, 1000, 16, 2.0), 1000, 16, 1.0, True)
+    assert np.array_equal(loc, g["loc"])
+    _route_check(synth.make_gates(103, 16384, 8, 1.0, quantize_bits=3), 16384, 8, 1.0, True)   # heavy ties
+    _route_check(synth.make_gates(104, 4 * 131072, 8, 3.0), 131072, 8, 1.0, True)               # BASELINE size, 4 segments
+    _route_check(synth.make_gates(105, 2 * 2000, 4, 1.0), 2000, 4, 1.0, False)
+    _route_check(np.full((512, 8), 0.125, np.float32), 512, 8, 1.0, True)                       # everything ties
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_tutel_sparse_abi(dtype):
+    P, H, E = 1500, 256, 8
+    gates_np = synth.make_gates(21, P, E, 2.0)
+    r = O.route_top1(gates_np, 1.0, True)
+    cap = r["capacity"]
+    rng = np.random.default_rng(22)
+    x = torch.from_numpy(rng.standard_normal((P, H)).astype(np.float32)).to(dtype)
+    idx, loc = torch.from_numpy(r["idx"]), torch.from_numpy(r["loc"])
+    gate = torch.from_numpy(r["gate"])
+    d_ref = O.dispatch(x.float(), idx, loc, E, cap)
+    d = ops().dispatch_fwd(None, idx.to(dev()), loc.to(dev()), x.to(dev()), E, cap)
+    assert report(f"dispatch_fwd_{dtype}", d, d_ref) == 0.0
+    y_ref = O.combine(d_ref, idx, loc, gate, cap)
+    y = ops().dispatch_bwd_data(gate.to(dev()), idx.to(dev()), loc.to(dev()), d, cap)
+    assert report(f"dispatch_bwd_data_{dtype}", y, y_ref) <= (1e-6 if dtype == torch.float32 else 2e-2)
+    gg_ref = (d_ref[(idx.long() * cap + loc.long()).clamp(max=E * cap - 1)] * x.float()).sum(1) * (loc < cap)
+    gg = ops().dispatch_bwd_gate(idx.to(dev()), loc.to(dev()), x.to(dev()), d, cap)
+    assert report(f"dispatch_bwd_gate_{dtype}", gg, gg_ref) <= 1e-3
+    yr = ops().combine_fwd(gate.to(dev()), idx.to(dev()), loc.to(dev()), d, cap, P, E, True)
+    assert report(f"combine_relu_{dtype}", yr, torch.relu(y_ref)) <= (1e-6 if dtype == torch.float32 else 2e-2)
+
+
+def test_composite_fwd_bwd():
+    g = np.load(os.path.join(G, "composite.npz"))
+    raw = torch.cat([torch.from_numpy(g["rgbs"]), torch.from_numpy(g["sigmas"])[..., None]], -1).contiguous()
+    z = torch.from_numpy(g["z"])
+    rgb, depth, dvar, w = ops().composite_fwd(raw.to(dev()), z.to(dev()), want_weights=True)
+    assert report("composite_rgb", rgb, torch.from_numpy(g["rgb"])) <= 2e-6
+    assert report("composite_w", w, torch.from_numpy(g["weights"])) <= 1e-6
+    assert report("composite_depth", depth, torch.from_numpy(g["depth"])) <= 2e-6
+    assert report("composite_dvar", dvar, torch.from_numpy(g["depth_variance"])) <= 1e-6
+    for S in (64, 100, 256, 768):
+        rng = np.random.default_rng(S)
+        N = 19
+        rw = torch.from_numpy(np.concatenate([rng.uniform(0, 1, (N, S, 3)), np.abs(rng.standard_normal((N, S, 1))) * 30], -1).astype(np.float32))
+        zz = torch.from_numpy(np.sort(rng.uniform(0.05, 1, (N, S)), 1).astype(np.float32))
+        rr = rw.clone().requires_grad_(True)
+        c = O.composite(rr[..., :3], rr[..., 3], zz)
+        dr = torch.from_numpy(rng.standard_normal((N, 3)).astype(np.float32))
+        (c["rgb"] * dr).sum().backward()
+        rgb, *_ = ops().composite_fwd(rw.to(dev()), zz.to(dev()))
+        assert report(f"composite_rgb_S{S}", rgb, c["rgb"]) <= 3e-6
+        d_raw = ops().composite_bwd(rw.to(dev()), zz.to(dev()), dr.to(dev()))
+        assert report(f"composite_bwd_S{S}", d_raw.view(N, S, 4), rr.grad) <= 2e-5 * max(1.0, rr.grad.abs().max().item())
+
+
+def _round(t, dtype):
+    return t.to(dtype).float()
+
+
+def _chain_ref(x, Ws, Bs, relus, skips, dtype, rowbias=None, rpb=1):
+    """fp32 maths with the operands / stored activations rounded to `dtype` exactly where the kernel rounds."""
+    h = _round(x, dtype)
+    x0 = h
+    saves = []
+    for l, (W, b) in enumerate(zip(Ws, Bs)):
+        h = h @ _round(W, dtype).t()
+        if b is not None:
+            h = h + b
+        if rowbias is not None and l == rowbias[0]:
+            h = h + rowbias[1].repeat_interleave(rpb, 0)[: h.shape[0]]
+        if l in skips:
+            h = h + x0
+        if relus[l]:
+            h = torch.relu(h)
+        h = _round(h, dtype)
+        saves.append(h)
+    return h, saves
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_chain_forward_dense(dtype):
+    """3-layer dense chain 128 -> 256 -> 256(relu) -> 128 with biases, rows not a multiple of the tile."""
+    rng = np.random.default_rng(31)
+    R = 1000
+    dims = [(256, 128), (256, 256), (128, 256)]
+    x = torch.from_numpy(rng.standard_normal((R, 128)).astype(np.float32))
+    Ws = [torch.from_numpy((rng.standard_normal(d) / np.sqrt(d[1])).astype(np.float32)) for d in dims]
+    Bs = [torch.from_numpy(rng.standard_normal(d[0]).astype(np.float32) * 0.1) for d in dims]
+    relus = [0, 1, 0]
+    ref, saves = _chain_ref(x, Ws, Bs, relus, (), dtype)
+    o = ops()
+    xd = x.to(dev()).to(dtype)
+    y = torch.full((R, 128), 7.0, dtype=dtype, device=dev())
+    s0 = torch.empty(R, 256, dtype=dtype, device=dev())
+    s1 = torch.empty(R, 256, dtype=dtype, device=dev())
+    layers = [o.Layer(Ws[i].to(dev()).to(dtype)[None].contiguous(), Bs[i].to(dev())[None].contiguous(), relu=relus[i]) for i in range(3)]
+    layers[0].save, layers[1].save = s0, s1
+    o.mlp_chain(xd, layers, y)
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    assert report(f"chain_dense_y_{dtype}", y, ref) <= tol
+    assert report(f"chain_dense_s0_{dtype}", s0, saves[0]) <= tol
+    assert report(f"chain_dense_s1_{dtype}", s1, saves[1]) <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_chain_expert_mlp_forward_backward(dtype):
+    """The ExpertMLP (7 x 256, skip at 3) on ragged expert groups with gathered input rows, forward and the
+    backward-data chain with the recorded ReLU masks, plus the grouped weight gradients."""
+    rng = np.random.default_rng(41)
+    E, L, M, Cap, n_seg = 4, 7, 256, 200, 2
+    P = n_seg * 600
+    counts = torch.tensor([[200, 37, 0, 130], [64, 200, 129, 1]], dtype=torch.int32)
+    W = [torch.from_numpy((rng.standard_normal((E, M, M)) / 16).astype(np.float32)) for _ in range(L)]   # [E, in, out]
+    B = [torch.from_numpy((rng.standard_normal((E, 1, M)) * 0.1).astype(np.float32)) for _ in range(L)]
+    h0 = torch.from_numpy(rng.standard_normal((P, M)).astype(np.float32))
+    perm = torch.full((n_seg * E * Cap,), -1, dtype=torch.int32)
+    for s in range(n_seg):
+        toks = rng.permutation(600)
+        o_ = 0
+        for e in range(E):
+            c = int(counts[s, e])
+            perm[(s * E + e) * Cap:(s * E + e) * Cap + c] = torch.from_numpy(toks[o_:o_ + c] + s * 600).int()
+            o_ += c
+    o = ops()
+    rows = n_seg * E * Cap
+    # ---- reference (fp32 math on dtype-rounded operands), per group
+    Wr = [_round(w, dtype) for w in W]
+    xg = torch.zeros(rows, M)
+    valid = perm >= 0
+    xg[valid] = _round(h0, dtype)[perm[valid].long()]
+    xg_req = xg.clone().requires_grad_(True)
+    Wreq = [w.clone().requires_grad_(True) for w in Wr]
+    Breq = [b.clone().requires_grad_(True) for b in B]
+    outs = []
+    acts = []
+    for gidx in range(n_seg * E):
+        e = gidx % E
+        c = int(counts[gidx // E, e])
+        h = xg_req[gidx * Cap: gidx * Cap + c]
+        x0 = h
+        for l in range(L):
+            h = h @ Wreq[l][e] + Breq[l][e]
+            if l == 3:
+                h = h + x0
+            if l < L - 1:
+                h = torch.relu(h)
+            if dtype == torch.bfloat16:
+                h = h + (_round(h.detach(), dtype) - h.detach())   # straight-through rounding
+        outs.append(h)
+    # ---- HIP forward
+    wf = [o.cast_transpose(w.to(dev()), torch.empty(E, M, M, dtype=dtype, device=dev())) for w in W]   # [E, out, in]
+    bf = [b.to(dev()).view(E, M).contiguous() for b in B]
+    nwords = o.chain_mask_words(dtype, n_seg * E, Cap)
+    masks = [torch.zeros(nwords, dtype=torch.int32, device=dev()) for _ in range(L - 1)]
+    saves = [torch.zeros(rows, M, dtype=dtype, device=dev()) for _ in range(L - 1)]
+    xs = torch.zeros(rows, M, dtype=dtype, device=dev())
+    y = torch.zeros(rows, M, dtype=dtype, device=dev())
+    layers = [o.Layer(wf[l], bf[l], relu=1 if l < L - 1 else 0, skip=(l == 3), save=saves[l] if l < L - 1 else None,
+                      mask=masks[l] if l < L - 1 else None) for l in range(L)]
+    gr = counts.view(-1).to(dev())
+    o.mlp_chain(h0.to(dev()).to(dtype), layers, y, n_groups=n_seg * E, n_wsets=E, group_stride=Cap, group_rows=gr,
+                group_rows_clamp=Cap, x_gather=perm.to(dev()), x_save=xs)
+    tol = 5e-5 if dtype == torch.float32 else 6e-2
+    worst = 0.0
+    for gidx in range(n_seg * E):
+        c = int(counts[gidx // E, gidx % E])
+        if c:
+            worst = max(worst, report(f"expert_fwd_{dtype}_g{gidx}", y[gidx * Cap: gidx * Cap + c], outs[gidx]))
+    assert worst <= tol, worst
+    assert report(f"expert_xsave_{dtype}", xs[valid.to(dev())], xg[valid]) == 0.0
+    # ---- backward data
+    dout = torch.from_numpy(rng.standard_normal((rows, M)).astype(np.float32))
+    dout_r = _round(dout, dtype)
+    loss = sum((outs[g_] * dout_r[g_ * Cap: g_ * Cap + outs[g_].shape[0]]).sum() for g_ in range(n_seg * E))
+    loss.backward()
+    wb = [o.cast(w.to(dev()), torch.empty(E, M, M, dtype=dtype, device=dev())) for w in W]              # [E, in, out]
+    dz = [torch.zeros(rows, M, dtype=dtype, device=dev()) for _ in range(L)]    # dz[l] = grad wrt pre-activation of layer l
+    dx = torch.zeros(rows, M, dtype=dtype, device=dev())
+    blayers = []
+    for i in range(L):            # backward layer i consumes dZ_{L-1-i}, produces dZ_{L-2-i} (or dX for the last)
+        l = L - 1 - i
+        blayers.append(o.Layer(wb[l], None, relu=2 if l > 0 else 0, mask=masks[l - 1] if l > 0 else None,
+                               save=dz[l - 1] if l > 0 else None))
+    o.mlp_chain(dout.to(dev()).to(dtype), blayers, dx, n_groups=n_seg * E, n_wsets=E, group_stride=Cap, group_rows=gr,
+                group_rows_clamp=Cap, x_save=dz[L - 1], y_add=dz[3])
+    gref = xg_req.grad
+    tolb = 2e-4 if dtype == torch.float32 else 8e-2
+    vmask = torch.zeros(rows, dtype=torch.bool)
+    for gidx in range(n_seg * E):
+        vmask[gidx * Cap: gidx * Cap + int(counts[gidx // E, gidx % E])] = True
+    assert report(f"expert_bwd_dx_{dtype}", dx[vmask.to(dev())], gref[vmask]) <= tolb * max(1.0, gref.abs().max().item())
+    # ---- weight gradients: dW_l = A_{l-1}^T dZ_l, db_l = colsum dZ_l
+    for l in range(L):
+        a = xs if l == 0 else saves[l - 1]
+        dw = torch.zeros(E, M, M, device=dev())
+        db = torch.zeros(E, M, device=dev())
+        o.wgrad(a, dz[l], dw, db, n_groups=n_seg * E, n_wsets=E, group_stride=Cap, group_rows=gr, group_rows_clamp=Cap, n_splits=3)
+        sc = max(1.0, Wreq[l].grad.abs().max().item())
+        tolw = 5e-4 if dtype == torch.float32 else 5e-2
+        assert report(f"expert_dW{l}_{dtype}", dw, Wreq[l].grad) <= tolw * sc
+        assert report(f"expert_db{l}_{dtype}", db, Breq[l].grad.view(E, M)) <= tolw * max(1.0, Breq[l].grad.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_wgrad_shapes(dtype):
+    rng = np.random.default_rng(51)
+    for (R, m, n) in [(777, 128, 256), (4096, 256, 128), (300, 256, 32), (65, 32, 256)]:
+        a = torch.from_numpy(rng.standard_normal((R, m)).astype(np.float32))
+        b = torch.from_numpy(rng.standard_normal((R, n)).astype(np.float32))
+        ar, br = _round(a, dtype), _round(b, dtype)
+        dw = torch.zeros(1, m, n, device=dev())
+        db = torch.zeros(1, n, device=dev())
+        ops().wgrad(a.to(dev()).to(dtype), b.to(dev()).to(dtype), dw, db, n_splits=4)
+        ref = ar.t() @ br
+        assert report(f"wgrad_{R}_{m}_{n}_{dtype}", dw[0], ref) <= 2e-5 * R ** 0.5 * 8
+        assert report(f"wgrad_db_{R}_{m}_{n}_{dtype}", db[0], br.sum(0)) <= 2e-5 * R ** 0.5 * 8
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_heads_and_combine_bwd(dtype):
+    rng = np.random.default_rng(61)
+    P, M, H2 = 2500, 256, 128
+    y = torch.relu(torch.from_numpy(rng.standard_normal((P, M)).astype(np.float32)))
+    y[::7] = 0
+    h2 = torch.relu(torch.from_numpy(rng.standard_normal((P, H2)).astype(np.float32)))
+    ws = torch.from_numpy((rng.standard_normal(M) / 16).astype(np.float32))
+    bs = torch.tensor([0.3])
+    wc = torch.from_numpy((rng.standard_normal((3, H2)) / 11).astype(np.float32))
+    bc = torch.from_numpy(rng.standard_normal(3).astype(np.float32) * 0.1)
+    noise = torch.from_numpy(rng.standard_normal(P).astype(np.float32))
+    yr, h2r = _round(y, dtype).requires_grad_(True), _round(h2, dtype).requires_grad_(True)
+    wsr, bsr, wcr, bcr = [t.clone().requires_grad_(True) for t in (ws, bs, wc, bc)]
+    sig = O.shifted_softplus(yr @ wsr + bsr + noise)
+    rgb = torch.sigmoid(h2r @ wcr.t() + bcr)
+    raw_ref = torch.cat([rgb, sig[:, None]], 1)
+    o = ops()
+    yd, h2d = y.to(dev()).to(dtype), h2.to(dev()).to(dtype)
+    raw = o.heads_fwd(yd, h2d, ws.to(dev()), bs.to(dev()), wc.to(dev()), bc.to(dev()), noise.to(dev()))
+    assert report(f"heads_fwd_{dtype}", raw, raw_ref) <= 3e-6
+    d_raw = torch.from_numpy(rng.standard_normal((P, 4)).astype(np.float32))
+    (raw_ref * d_raw).sum().backward()
+    dws, dbs = torch.zeros(M, device=dev()), torch.zeros(1, device=dev())
+    dwc, dbc = torch.zeros(3, H2, device=dev()), torch.zeros(3, device=dev())
+    dh2, dsig = o.heads_bwd(yd, h2d, wc.to(dev()), raw, d_raw.to(dev()), dws, dbs, dwc, dbc)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert report(f"heads_dh2_{dtype}", dh2, h2r.grad * (h2r > 0)) <= tol
+    assert report(f"heads_dws_{dtype}", dws, wsr.grad) <= 1e-3
+    assert report(f"heads_dbs_{dtype}", dbs, bsr.grad) <= 1e-3
+    assert report(f"heads_dwc_{dtype}", dwc, wcr.grad) <= 1e-3
+    assert report(f"heads_dbc_{dtype}", dbc, bcr.grad) <= 1e-3
+    # combine backward: y = relu(g * o); given dy_in and the sigma head's rank-1 term
+    gate = torch.from_numpy(rng.uniform(0.125, 1, P).astype(np.float32)).requires_grad_(True)
+    oo = torch.from_numpy(rng.standard_normal((P, M)).astype(np.float32))
+    oo[::5] = 0
+    oor = _round(oo, dtype).requires_grad_(True)
+    yy = torch.relu(gate[:, None] * oor)
+    dy_in = _round(torch.from_numpy(rng.standard_normal((P, M)).astype(np.float32)), dtype)
+    ds = torch.from_numpy(rng.standard_normal(P).astype(np.float32))
+    (yy * (dy_in + ds[:, None] * ws[None, :])).sum().backward()
+    yyd = yy.detach().to(dev()).to(dtype)
+    dout, dgate = o.combine_bwd(dy_in.to(dev()).to(dtype), yyd, ds.to(dev()), ws.to(dev()), gate.detach().to(dev()))
+    kept = (yy.detach().abs().sum(1) > 0)
+    assert report(f"combine_dout_{dtype}", dout, oor.grad) <= (2e-5 if dtype == torch.float32 else 5e-2)
+    assert report(f"combine_dgate_{dtype}", dgate[kept.to(dev())], gate.grad[kept]) <= (2e-4 if dtype == torch.float32 else 0.3)
+
+
+def test_adam_and_casts():
+    rng = np.random.default_rng(71)
+    n = 100003
+    p = torch.from_numpy(rng.standard_normal(n).astype(np.float32))
+    m = torch.zeros(n)
+    v = torch.zeros(n)
+    pd, md, vd = p.to(dev()), m.to(dev()), v.to(dev())
+    sh = torch.empty(n, dtype=torch.bfloat16, device=dev())
+    for step in (1, 2, 3):
+        g = torch.from_numpy(rng.standard_normal(n).astype(np.float32))
+        O.adam_step(p, g, m, v, step, 5e-4)
+        ops().adam_step(pd, g.to(dev()), md, vd, sh, step, 5e-4)
+    assert report("adam_p", pd, p) <= 1e-6
+    assert report("adam_shadow", sh, p) <= 2e-2
+    w = torch.from_numpy(rng.standard_normal((3, 75, 256)).astype(np.float32))
+    out = ops().cast_transpose(w.to(dev()), torch.empty(3, 256, 75, dtype=torch.float32, device=dev()))
+    assert torch.equal(out.cpu(), w.transpose(1, 2).contiguous())
+    gs = ops().group_colsum(w.view(-1, 256).to(dev()), 75)
+    assert report("group_colsum", gs, w.sum(1)) <= 1e-4
