@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""bench.py - train rays/s of the Switch-NeRF hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one full training step of BASELINE.json configs[1] on every rank: 8192 synthetic rays x 256 samples
+(16 routing segments of 131072 points), 8 experts top-1, capacity_factor 1.0, batch-prioritised routing, bf16 compute,
+stratified perturbation + sigma noise drawn inside the timed region, forward + loss + backward + gradient
+all-reduce (N > 1) + Adam.  Rays are independent, so ranks are data-parallel replicas with per-rank work fixed
+(scaling = "weak"); the only collective is the RCCL all-reduce of the flat fp32 gradient buffer.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (timed live with HIP events on the launch
+stream); `cpu_baseline` is the CPU oracle (a port of the reference's CPU path) timed on this box's host cores on a
+bounded sample (one 131072-point segment = 512 rays).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
+
+
+def synth_batch(n_rays, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    o = torch.rand(n_rays, 3, generator=g) * 0.2 - 0.1
+    d = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=1)
+    rays = torch.cat([o, d, torch.full((n_rays, 1), 0.05), torch.full((n_rays, 1), 1.0)], 1)
+    idx = torch.randint(0, 10, (n_rays,), generator=g)
+    rgbs = torch.rand(n_rays, 3, generator=g)
+    return rays.to(device), idx.to(device), rgbs.to(device)
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """The CPU oracle's training step (fwd + bwd, fp32) on one routing segment; returns rays/s on the host cores."""
+    import numpy as np
+    import synth
+    from oracle import switchnerf_oracle as O
+    n_rays, S, chunk = 512, 256, 131072
+    sd = synth.make_weights(0, synth.BUILDING)
+    rays, img, rgbs = synth.make_rays(1, n_rays)
+    p = O.params_from_numpy(sd, requires_grad=True)
+    t_best, reps, t_start = None, 0, time.time()
+    while reps < 2 and (time.time() - t_start) < seconds_budget:
+        for t in p.values():
+            t.grad = None
+        t0 = time.time()
+        st = O.training_step(p, torch.from_numpy(rays), torch.from_numpy(img), torch.from_numpy(rgbs), synth.BUILDING, S, chunk)
+        st["loss"].backward()
+        dt = time.time() - t0
+        t_best = dt if t_best is None else min(t_best, dt)
+        reps += 1
+    return dict(value=n_rays / t_best, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle fwd+bwd fp32 on 1 of 16 segments (512 rays x 256 samples = 131072 points), best of {reps}; "
+                       f"{t_best:.2f} s/segment => {16 * t_best:.1f} s per 8192-ray step")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=8192)
+    ap.add_argument("--samples", type=int, default=256)
+    ap.add_argument("--chunk", type=int, default=131072)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--gate-scale", type=float, default=1.0, help="scale of the router weight (small => balanced routing)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from switch_nerf_amd.model import SwitchNeRF, BUILDING
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    model = SwitchNeRF(BUILDING, dtype=dtype, device=dev, seed=0)
+    if a.gate_scale != 1.0:
+        model.p["wg"].mul_(a.gate_scale)
+    rays, idx, rgbs = synth_batch(a.rays, 1000 + rank, dev)
+    P = a.rays * a.samples
+
+    def allreduce(flat_grad):
+        dist.all_reduce(flat_grad)           # RCCL ring over xGMI, one 16 MB bucket
+        return 1.0 / world
+
+    def step():
+        pr = torch.rand(a.rays, a.samples, device=dev)              # rendering.py:582 rand_like
+        noise = torch.randn(P, device=dev)                          # rendering.py:366, sigma_noise_std = 1
+        return model.train_step(rgbs, rays, idx, a.samples, a.chunk, perturb=1.0, perturb_rand=pr, sigma_noise=noise,
+                                grad_allreduce=allreduce if world > 1 else None)
+
+    for _ in range(a.warmup):
+        st = step()
+    model.profile = not a.no_events
+    model.events = {}
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        st = step()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms = dt / a.steps * 1e3
+    value = a.rays * world * a.steps / dt
+
+    # ---- per-kernel accounting from the live HIP events
+    c = st["ctx"]
+    kept = int(torch.minimum(c["counts"], torch.tensor(c["cap"], device=dev)).sum().item())
+    L, M, E = model.L, model.M, model.E
+    esz = 2 if dtype == torch.bfloat16 else 4
+    kern = {}
+    for name, evs in model.events.items():
+        kern[name] = sum(x.elapsed_time(y) for x, y in evs) / len(evs)          # ms per step
+    flops_chain = 2.0 * L * M * M * kept                                       # expert fwd == bwd-data == wgrad flops
+    # algorithmic HBM bytes per launch: fwd reads x, writes x copy + L-1 activations + output (+ masks)
+    bytes_fwd = kept * M * esz * (1 + 1 + (L - 1) + 1)
+    bytes_bwd = kept * M * esz * (1 + L + 1 + 1)
+    bytes_wgrad = kept * M * esz * 2 * L
+    roof = None
+    detail = {}
+    for name, fl, by in (("expert_fwd", flops_chain, bytes_fwd), ("expert_bwd", flops_chain, bytes_bwd),
+                         ("expert_wgrad", flops_chain, bytes_wgrad)):
+        if name in kern and kern[name] > 0:
+            tf = fl / (kern[name] * 1e-3) / 1e12
+            gbs = by / (kern[name] * 1e-3) / 1e9
+            detail[name] = dict(ms=round(kern[name], 4), tflops=round(tf, 1), mfma_frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                                alg_gbs=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4))
+    if detail:
+        dom = max(detail, key=lambda k: detail[k]["ms"])
+        d = detail[dom]
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get(dom)
+            except Exception:
+                traffic = None
+        if dom == "expert_wgrad":    # HBM-bound by construction (each operand row read once)
+            roof = dict(kernel="wgrad_kernel<bf16,1> (7 launches)", bound="hbm", achieved=d["alg_gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(d["alg_gbs"] / HBM_PEAK_GBS, 4), traffic=traffic)
+        else:
+            roof = dict(kernel=f"chain_kernel<bf16,{1 if dom == 'expert_fwd' else 2}> ({dom})", bound="mfma", achieved=d["tflops"],
+                        peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=d["mfma_frac"], traffic=traffic)
+
+    out = {
+        "metric": "train rays/sec (8192-ray batch, 256 samples, 8 experts)", "value": round(value, 1), "unit": "rays/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": f"configs[1]: 8-expert top-1 expertmlp, capacity_factor=1.0, BPR, {a.rays} rays x {a.samples} samples"
+                               f" per GPU, {P // a.chunk} segments of {a.chunk} points, building.yaml shapes, random-init weights,"
+                               f" gate_scale={a.gate_scale}",
+                   "rays_per_gpu": a.rays, "samples": a.samples, "segment_points": a.chunk, "parallelism": f"dp{world}",
+                   "kept_token_fraction": round(kept / P, 4), "loss": round(float(st["loss"].item()), 6)},
+        "roofline": roof, "kernels": detail,
+    }
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:      # the baseline must never take the bench line down
+                out["cpu_baseline"] = dict(value=None, unit="rays/s", cores=torch.get_num_threads(), kind="port", sample=f"failed: {e}")
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

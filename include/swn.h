@@ -160,6 +160,9 @@ typedef struct swn_chain_desc {
   void* y;                      /* output rows, row-major [*, n_last] dtype                       */
   const void* y_add;            /* row-major [*, n_last] tensor added to the output rows (skip gradient) or NULL */
   const int32_t* y_add_gather;  /* row -> row of y_add (-1 = nothing to add), or NULL (identity)  */
+  int32_t tag;                  /* profiling only: selects an identical kernel instantiation with its own symbol so that
+                                   rocprofv3 reports the roles separately (0 generic, 1 expert fwd, 2 expert bwd,
+                                   3 front fwd, 4 tail fwd, 5 tail bwd, 6 front bwd)                 */
   swn_chain_layer layers[8];
 } swn_chain_desc;
 
@@ -171,7 +174,7 @@ int swn_mlp_chain(const swn_chain_desc* desc, void* stream);
  * (tutel_moe_layer_nobatch.py:853); with A = dZ, B = input it yields torch.nn.Linear's [out, in].              */
 int swn_wgrad(const void* a, const void* b, int dtype, int m_dim, int n_dim,
               int n_groups, int n_wsets, int group_stride, const int32_t* group_rows, int group_rows_clamp,
-              float* dw, float* db, int n_splits, void* stream);
+              float* dw, float* db, int n_splits, int tag /* profiling only: 0 generic, 1 expert */, void* stream);
 
 /* ---- optimiser -------------------------------------------------------------------------------------------------
  * torch.optim.Adam (runner.py:486) over one flat fp32 parameter buffer; grad_scale multiplies the gradient

@@ -20,7 +20,7 @@ class ChainLayer(C.Structure):
 class ChainDesc(C.Structure):
     _fields_ = [("dtype", i32), ("n_layers", i32), ("n_groups", i32), ("n_wsets", i32), ("group_stride", i32),
                 ("group_rows", vp), ("group_rows_clamp", i32), ("x", vp), ("x_gather", vp), ("x_save", vp),
-                ("y", vp), ("y_add", vp), ("y_add_gather", vp), ("layers", ChainLayer * 8)]
+                ("y", vp), ("y_add", vp), ("y_add_gather", vp), ("tag", i32), ("layers", ChainLayer * 8)]
 
 
 # name -> argtypes; every symbol declared in include/swn.h must be listed here (tests/test_abi.py checks both ways)
@@ -42,7 +42,7 @@ SIGNATURES = {
     "swn_composite_fwd": [vp, vp, f32, i32, i32, vp, vp, vp, vp, vp],
     "swn_composite_bwd": [vp, vp, f32, vp, i32, i32, vp, vp],
     "swn_mlp_chain": [C.POINTER(ChainDesc), vp],
-    "swn_wgrad": [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp],
+    "swn_wgrad": [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, vp],
     "swn_adam_step": [vp, vp, vp, vp, vp, i32, i64, f32, f32, f32, f32, i32, f32, vp],
     "swn_cast": [vp, vp, i32, i64, vp],
     "swn_cast_transpose": [vp, vp, i32, i32, i32, i32, vp],

@@ -117,7 +117,7 @@ __device__ __forceinline__ void load_rows_to_lds(char* dst, const void* src, con
   }
 }
 
-template <typename T>
+template <typename T, int TAG>
 __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = Cfg<T>::BM, BK = Cfg<T>::BK, MI = Cfg<T>::MI;
@@ -375,16 +375,21 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   const long grid = (long)a.tiles_per_group * d.n_groups;
   SWN_CHECK(grid > 0 && grid < (1L << 31), "swn_mlp_chain: grid %ld out of range", grid);
   const int lds = ACT_BYTES + 2 * WBUF_BYTES;
-  hipError_t e;
-  if (d.dtype == SWN_BF16) {
-    e = hipFuncSetAttribute((const void*)chain_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(chain_kernel<bf16_t>, dim3((unsigned)grid), dim3(NT), lds, as_stream(stream), a);
-  } else {
-    e = hipFuncSetAttribute((const void*)chain_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(chain_kernel<float>, dim3((unsigned)grid), dim3(NT), lds, as_stream(stream), a);
+  SWN_CHECK(d.tag >= 0 && d.tag <= 6, "swn_mlp_chain: tag %d not in [0,6]", d.tag);
+  const void* fn = nullptr;
+#define SWN_PICK(TAGV)                                                                         \
+  case TAGV:                                                                                   \
+    fn = d.dtype == SWN_BF16 ? (const void*)chain_kernel<bf16_t, TAGV> : (const void*)chain_kernel<float, TAGV>; \
+    break;
+  switch (d.tag) {
+    SWN_PICK(0) SWN_PICK(1) SWN_PICK(2) SWN_PICK(3) SWN_PICK(4) SWN_PICK(5) SWN_PICK(6)
   }
+#undef SWN_PICK
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  void* kargs[] = {(void*)&a};
+  e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(NT), kargs, lds, as_stream(stream));
+  SWN_CHECK(e == hipSuccess, "swn_mlp_chain launch: %s", hipGetErrorString(e));
   SWN_LAUNCH_CHECK();
   return 0;
 }

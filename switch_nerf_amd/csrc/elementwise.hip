@@ -67,8 +67,12 @@ __device__ __forceinline__ void store_vals(T* dst, const float* v, int n_pad) {
 }
 
 __device__ __forceinline__ float z_of(float near, float far, float t) {
-  // rendering.py:86  near * (1 - t) + far * t, each torch op rounded separately (no fma contraction)
-  return __fadd_rn(__fmul_rn(near, __fsub_rn(1.f, t)), __fmul_rn(far, t));
+  // rendering.py:86  near * (1 - t) + far * t, each torch op rounded separately: fma contraction must stay off
+  // (ROCm's __fmul_rn/__fadd_rn are plain operators and do not prevent it).
+#pragma clang fp contract(off)
+  const float a = near * (1.f - t);
+  const float b = far * t;
+  return a + b;
 }
 
 template <typename T, int LMAX>
@@ -76,6 +80,7 @@ __global__ __launch_bounds__(256) void sample_pe_kernel(const float* __restrict_
                                                         const float* __restrict__ prand, float perturb, int n_rays,
                                                         int S, int L, float* __restrict__ z_out, T* __restrict__ pe,
                                                         int pe_stride) {
+#pragma clang fp contract(off)
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
   if (p >= (long)n_rays * S) return;
   const int ray = (int)(p / S), s = (int)(p - (long)ray * S);
@@ -85,17 +90,19 @@ __global__ __launch_bounds__(256) void sample_pe_kernel(const float* __restrict_
   if (perturb > 0.f && prand) {  // rendering.py:573-584
     const float zp = s > 0 ? z_of(near, far, tsteps[s - 1]) : z;
     const float zn = s < S - 1 ? z_of(near, far, tsteps[s + 1]) : z;
-    const float lower = s > 0 ? __fmul_rn(0.5f, __fadd_rn(zp, z)) : z;
-    const float upper = s < S - 1 ? __fmul_rn(0.5f, __fadd_rn(z, zn)) : z;
-    const float pr = __fmul_rn(perturb, prand[p]);
-    z = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), pr));
+    const float lower = s > 0 ? 0.5f * (zp + z) : z;
+    const float upper = s < S - 1 ? 0.5f * (z + zn) : z;
+    const float pr = perturb * prand[p];
+    const float span = (upper - lower) * pr;
+    z = lower + span;
   }
   z_out[p] = z;
   float v[8 + 6 * LMAX + 8];
   float x[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    x[c] = __fadd_rn(r[c], __fmul_rn(r[3 + c], z));  // rendering.py:90
+    const float dz = r[3 + c] * z;  // rendering.py:90 (mul, then add: two roundings)
+    x[c] = r[c] + dz;
     v[c] = x[c];
   }
   float f = 1.f;

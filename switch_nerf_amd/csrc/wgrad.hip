@@ -39,7 +39,7 @@ __device__ __forceinline__ bf16x8_t as_frag(uint32_t r0, uint32_t r1, uint32_t r
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <typename T>
+template <typename T, int TAG>
 __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BKR = WCfg<T>::BKR;
@@ -240,7 +240,7 @@ using namespace swn;
 
 extern "C" int swn_wgrad(const void* a, const void* b, int dtype, int m_dim, int n_dim, int n_groups, int n_wsets,
                          int group_stride, const int32_t* group_rows, int group_rows_clamp, float* dw, float* db,
-                         int n_splits, void* stream) {
+                         int n_splits, int tag, void* stream) {
   SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_wgrad: bad dtype %d", dtype);
   SWN_CHECK(m_dim >= 32 && m_dim <= 256 && m_dim % 32 == 0 && n_dim >= 32 && n_dim <= 256 && n_dim % 32 == 0,
             "swn_wgrad: m_dim=%d n_dim=%d must be multiples of 32 in [32,256]", m_dim, n_dim);
@@ -256,16 +256,15 @@ extern "C" int swn_wgrad(const void* a, const void* b, int dtype, int m_dim, int
   p.group_stride = group_stride; p.clamp = group_rows ? group_rows_clamp : group_stride; p.rows_per_split = rps;
   p.group_rows = group_rows; p.dw = dw; p.db = db;
   const int lds = 4 * bkr * 256 * (dtype == SWN_BF16 ? 2 : 4);
-  hipError_t e;
-  if (dtype == SWN_BF16) {
-    e = hipFuncSetAttribute((const void*)wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(n_groups, splits), dim3(WG_NT), lds, as_stream(stream), p);
-  } else {
-    e = hipFuncSetAttribute((const void*)wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(wgrad_kernel<float>, dim3(n_groups, splits), dim3(WG_NT), lds, as_stream(stream), p);
-  }
+  SWN_CHECK(tag == 0 || tag == 1, "swn_wgrad: tag must be 0 or 1");
+  const void* fn;
+  if (dtype == SWN_BF16) fn = tag ? (const void*)wgrad_kernel<bf16_t, 1> : (const void*)wgrad_kernel<bf16_t, 0>;
+  else fn = tag ? (const void*)wgrad_kernel<float, 1> : (const void*)wgrad_kernel<float, 0>;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  void* kargs[] = {(void*)&p};
+  e = hipLaunchKernel(fn, dim3(n_groups, splits), dim3(WG_NT), kargs, lds, as_stream(stream));
+  SWN_CHECK(e == hipSuccess, "swn_wgrad launch: %s", hipGetErrorString(e));
   SWN_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,366 @@
+"""Host-side model of the Switch-NeRF train hot path on top of libswn_hip.so.
+
+Mirrors, for the building.yaml wiring (NeRFMoE, external gate + LayerNorm, top-1 expertmlp, batched capacity path):
+  * models/nerf_moe.py:103-455  NeRFMoE            -> SwitchNeRF (parameters, state_dict layout, forward)
+  * rendering.py:15-494         render_rays        -> SwitchNeRF.render / rendering.render_rays
+  * runner.py:1077-1123, 646-686 training step      -> SwitchNeRF.train_step (loss, backward, Adam)
+(paths relative to /root/reference/switch_nerf/).  All arithmetic on points runs in HIP kernels through the C ABI;
+torch only owns the device buffers, the stream, and a handful of per-ray (N_rays x 75) tensors.
+
+MI355X-first design notes
+  * the whole ray batch (e.g. 8192 x 256 = 2M points, ~30 GB of bf16 activations) is processed in ONE pass: the
+    reference's model chunks (rendering.py:354) survive only as routing *segments* (capacity / ranking / l_aux are
+    per segment), so every kernel is launched once per step over all segments - 288 GB of HBM makes chunking for
+    memory unnecessary;
+  * dispatch and the backward scatter never materialise: the expert chain gathers its input rows through the
+    routing permutation, and the front backward gathers the expert input-gradient rows through tok2row;
+  * the direction / appearance part of layer "2" is constant along a ray: it is folded into a per-ray bias
+    (N_rays x 128) instead of being concatenated to every point (331 -> 256 input features on the hot GEMM);
+  * master weights are fp32 in [in, out] layout in one flat buffer (one Adam launch, one gradient all-reduce);
+    compute copies (bf16 or fp32) in [out, in] (forward) and [in, out] (backward-data) are refreshed after Adam.
+"""
+from __future__ import annotations
+
+import contextlib
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+
+BUILDING = dict(model_dim=256, num_experts=8, expert_layers=7, skips=(3,), pos_xyz_dim=12, pos_dir_dim=4,
+                appearance_dim=48, appearance_count=10, gate_hidden=256, gate_layers=2, layer2_out=128)
+
+
+def _ceil_to(x, m):
+    return (x + m - 1) // m * m
+
+
+class SwitchNeRF:
+    def __init__(self, cfg: dict = BUILDING, dtype=torch.bfloat16, device="cuda", capacity_factor=1.0,
+                 batch_prioritized=True, moe_l_aux_wt=5e-4, lr=5e-4, seed=0):
+        assert tuple(cfg["skips"]) == (3,) or len(cfg["skips"]) <= 1, "one skip connection supported"
+        self.cfg, self.dtype, self.dev = dict(cfg), dtype, torch.device(device)
+        self.cf, self.bpr, self.wt, self.lr = capacity_factor, batch_prioritized, moe_l_aux_wt, lr
+        M, E, L, G, H2 = cfg["model_dim"], cfg["num_experts"], cfg["expert_layers"], cfg["gate_hidden"], cfg["layer2_out"]
+        assert G == M, "external gate width must equal model_dim (building.yaml)"
+        self.in_xyz = 3 + 6 * cfg["pos_xyz_dim"]
+        self.in_dir = 3 + 6 * cfg["pos_dir_dim"]
+        self.KP = _ceil_to(self.in_xyz, 64)          # padded PE width (chain K granularity)
+        self.DP = _ceil_to(self.in_dir, 8)
+        self.n_ray_feat = self.in_dir + cfg["appearance_dim"]
+        # ---- flat master parameter buffer; name -> (offset, shape); Linear weights are [in, out]
+        spec = [("xyz.w", (self.KP, M)), ("xyz.b", (M,)), ("gate0.w", (M, G)), ("gate0.b", (G,)),
+                ("gate1.w", (G, G)), ("gate1.b", (G,)), ("ln.w", (G,)), ("ln.b", (G,)), ("wg", (E, G))]
+        for l in range(L):
+            spec += [(f"exp{l}.w", (E, M, M)), (f"exp{l}.b", (E, M))]
+        spec += [("l1.w", (M, M)), ("l1.b", (M,)), ("l2h.w", (M, H2)), ("l2r.w", (self.n_ray_feat, H2)), ("l2.b", (H2,)),
+                 ("sigma.w", (M,)), ("sigma.b", (1,)), ("color.w", (3, H2)), ("color.b", (3,)),
+                 ("emb", (cfg["appearance_count"], cfg["appearance_dim"]))]
+        self.spec, off = {}, 0
+        for name, shape in spec:
+            n = int(np.prod(shape))
+            self.spec[name] = (off, shape)
+            off += _ceil_to(n, 64)
+        self.n_flat = off
+        z = lambda: torch.zeros(self.n_flat, dtype=torch.float32, device=self.dev)
+        self.flat, self.grad, self.m, self.v = z(), z(), z(), z()
+        self.p = {k: self.flat[o:o + int(np.prod(s))].view(s) for k, (o, s) in self.spec.items()}
+        self.g = {k: self.grad[o:o + int(np.prod(s))].view(s) for k, (o, s) in self.spec.items()}
+        self.step_count = 0
+        self.L, self.M, self.E, self.G, self.H2 = L, M, E, G, H2
+        # compute copies
+        self.wf: Dict[str, torch.Tensor] = {}
+        self.wb: Dict[str, torch.Tensor] = {}
+        self._chain_weights = ["xyz", "gate0", "gate1", "l1", "l2h"] + [f"exp{l}" for l in range(L)]
+        for n in self._chain_weights:
+            s = self.spec[n + ".w"][1]
+            s3 = s if len(s) == 3 else (1,) + tuple(s)
+            self.wf[n] = torch.empty(s3[0], s3[2], s3[1], dtype=dtype, device=self.dev)
+            if n != "xyz":
+                self.wb[n] = torch.empty(s3, dtype=dtype, device=self.dev)
+        self._init_random(seed)
+        self._bufs = {}
+        self.profile = False          # bench.py: record HIP events around the major launches
+        self.events: Dict[str, list] = {}
+
+    @contextlib.contextmanager
+    def _timed(self, name):
+        if not self.profile:
+            yield
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        yield
+        b.record()
+        self.events.setdefault(name, []).append((a, b))
+
+    # ------------------------------------------------------------------------------------------ parameters
+    def _init_random(self, seed):
+        """torch.nn.Linear-style init (U(-1/sqrt(in), 1/sqrt(in))) drawn in the reference's state_dict layout."""
+        import sys, os
+        g = torch.Generator().manual_seed(seed)
+        cfg = self.cfg
+
+        def lin(out_f, in_f):
+            b = 1.0 / math.sqrt(in_f)
+            return ((torch.rand(out_f, in_f, generator=g) * 2 - 1) * b), ((torch.rand(out_f, generator=g) * 2 - 1) * b)
+        sd = {}
+        M, E, L, G, H2 = self.M, self.E, self.L, self.G, self.H2
+        sd["layers.xyz.fcs.0.weight"], sd["layers.xyz.fcs.0.bias"] = lin(M, self.in_xyz)
+        for l in range(L):
+            w = torch.empty(E, M, M)
+            b = torch.empty(E, 1, M)
+            for e in range(E):
+                wt, bt = lin(M, M)
+                w[e], b[e, 0] = wt.t(), bt
+            sd[f"layers.0.experts.0.weights.{l}"], sd[f"layers.0.experts.0.bias.{l}"] = w, b
+        sd["layers.0.gates.0.wg.weight"] = lin(E, G)[0]
+        sd["layers.1.fcs.0.weight"], sd["layers.1.fcs.0.bias"] = lin(M, M)
+        sd["layers.2.fcs.0.weight"], sd["layers.2.fcs.0.bias"] = lin(H2, M + self.n_ray_feat)
+        sd["layers.sigma.fcs.0.weight"], sd["layers.sigma.fcs.0.bias"] = lin(1, M)
+        sd["layers.color.fcs.0.weight"], sd["layers.color.fcs.0.bias"] = lin(3, H2)
+        sd["layers.moe_external_gate.fcs.0.weight"], sd["layers.moe_external_gate.fcs.0.bias"] = lin(G, M)
+        sd["layers.moe_external_gate.fcs.1.weight"], sd["layers.moe_external_gate.fcs.1.bias"] = lin(G, G)
+        sd["layers.gate_input_norm.weight"], sd["layers.gate_input_norm.bias"] = torch.ones(G), torch.zeros(G)
+        sd["embedding_a.weight"] = torch.randn(cfg["appearance_count"], cfg["appearance_dim"], generator=g)
+        self.load_state_dict(sd)
+
+    def load_state_dict(self, sd):
+        """Accepts the reference's NeRFMoE.state_dict() key layout; values torch or numpy."""
+        def t(k):
+            v = sd[k]
+            v = torch.from_numpy(np.asarray(v)) if not torch.is_tensor(v) else v
+            return v.detach().to(torch.float32).to(self.dev)
+        p, M = self.p, self.M
+        with torch.no_grad():
+            p["xyz.w"].zero_()
+            p["xyz.w"][: self.in_xyz] = t("layers.xyz.fcs.0.weight").t()
+            p["xyz.b"].copy_(t("layers.xyz.fcs.0.bias"))
+            p["gate0.w"].copy_(t("layers.moe_external_gate.fcs.0.weight").t())
+            p["gate0.b"].copy_(t("layers.moe_external_gate.fcs.0.bias"))
+            p["gate1.w"].copy_(t("layers.moe_external_gate.fcs.1.weight").t())
+            p["gate1.b"].copy_(t("layers.moe_external_gate.fcs.1.bias"))
+            p["ln.w"].copy_(t("layers.gate_input_norm.weight"))
+            p["ln.b"].copy_(t("layers.gate_input_norm.bias"))
+            p["wg"].copy_(t("layers.0.gates.0.wg.weight"))
+            for l in range(self.L):
+                p[f"exp{l}.w"].copy_(t(f"layers.0.experts.0.weights.{l}"))
+                p[f"exp{l}.b"].copy_(t(f"layers.0.experts.0.bias.{l}").view(self.E, M))
+            p["l1.w"].copy_(t("layers.1.fcs.0.weight").t())
+            p["l1.b"].copy_(t("layers.1.fcs.0.bias"))
+            w2 = t("layers.2.fcs.0.weight")
+            p["l2h.w"].copy_(w2[:, :M].t())
+            p["l2r.w"].copy_(w2[:, M:].t())
+            p["l2.b"].copy_(t("layers.2.fcs.0.bias"))
+            p["sigma.w"].copy_(t("layers.sigma.fcs.0.weight").view(-1))
+            p["sigma.b"].copy_(t("layers.sigma.fcs.0.bias"))
+            p["color.w"].copy_(t("layers.color.fcs.0.weight"))
+            p["color.b"].copy_(t("layers.color.fcs.0.bias"))
+            p["emb"].copy_(t("embedding_a.weight"))
+        self.refresh_compute_copies()
+
+    def _to_ref_layout(self, d):
+        M = self.M
+        out = {}
+        out["layers.xyz.fcs.0.weight"] = d["xyz.w"][: self.in_xyz].t().contiguous()
+        out["layers.xyz.fcs.0.bias"] = d["xyz.b"].clone()
+        out["layers.moe_external_gate.fcs.0.weight"] = d["gate0.w"].t().contiguous()
+        out["layers.moe_external_gate.fcs.0.bias"] = d["gate0.b"].clone()
+        out["layers.moe_external_gate.fcs.1.weight"] = d["gate1.w"].t().contiguous()
+        out["layers.moe_external_gate.fcs.1.bias"] = d["gate1.b"].clone()
+        out["layers.gate_input_norm.weight"] = d["ln.w"].clone()
+        out["layers.gate_input_norm.bias"] = d["ln.b"].clone()
+        out["layers.0.gates.0.wg.weight"] = d["wg"].clone()
+        for l in range(self.L):
+            out[f"layers.0.experts.0.weights.{l}"] = d[f"exp{l}.w"].clone()
+            out[f"layers.0.experts.0.bias.{l}"] = d[f"exp{l}.b"].view(self.E, 1, M).clone()
+        out["layers.1.fcs.0.weight"] = d["l1.w"].t().contiguous()
+        out["layers.1.fcs.0.bias"] = d["l1.b"].clone()
+        out["layers.2.fcs.0.weight"] = torch.cat([d["l2h.w"].t(), d["l2r.w"].t()], 1).contiguous()
+        out["layers.2.fcs.0.bias"] = d["l2.b"].clone()
+        out["layers.sigma.fcs.0.weight"] = d["sigma.w"].view(1, -1).clone()
+        out["layers.sigma.fcs.0.bias"] = d["sigma.b"].clone()
+        out["layers.color.fcs.0.weight"] = d["color.w"].clone()
+        out["layers.color.fcs.0.bias"] = d["color.b"].clone()
+        out["embedding_a.weight"] = d["emb"].clone()
+        return out
+
+    def state_dict(self):
+        """Parameters in the reference's key layout (so checkpoints are interchangeable)."""
+        return self._to_ref_layout(self.p)
+
+    def grad_dict(self):
+        """Gradients in the reference's key layout (for parity tests)."""
+        return self._to_ref_layout(self.g)
+
+    def refresh_compute_copies(self):
+        for n in self._chain_weights:
+            w = self.p[n + ".w"]
+            w3 = w if w.dim() == 3 else w.unsqueeze(0)
+            ops.cast_transpose(w3, self.wf[n])
+            if n in self.wb:
+                ops.cast(w3, self.wb[n])
+
+    # ------------------------------------------------------------------------------------------ buffers
+    def _buf(self, name, shape, dtype):
+        key = (name, tuple(shape), dtype)
+        b = self._bufs.get(key)
+        if b is None:
+            b = torch.empty(shape, dtype=dtype, device=self.dev)
+            self._bufs[key] = b
+        return b
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward_rays(self, rays, image_indices, n_samples, seg_tokens, perturb=0.0, perturb_rand=None, sigma_noise=None,
+                     training=True, routing_override=None):
+        """Coarse pass of render_rays (fine_samples = 0).  Returns a context dict holding every tensor the backward
+        needs and the rendered results."""
+        o, dt, dev = ops, self.dtype, self.dev
+        N, S = rays.shape[0], n_samples
+        P = N * S
+        M, E, L, G, H2 = self.M, self.E, self.L, self.G, self.H2
+        assert P % seg_tokens == 0, "points must be a multiple of the segment (model chunk) size"
+        n_seg = P // seg_tokens
+        cap = int(self.cf * ((seg_tokens + E - 1) // E))     # tutel_fast_dispatch.py:211
+        c = dict(N=N, S=S, P=P, n_seg=n_seg, cap=cap, seg_tokens=seg_tokens)
+        t_steps = torch.linspace(0, 1, S, dtype=torch.float32).to(dev)      # computed on the host like the reference's CPU path
+        c["z"], c["pe"], pe_dir = o.sample_pe(rays, t_steps, perturb_rand, perturb, S, self.cfg["pos_xyz_dim"],
+                                              self.cfg["pos_dir_dim"], dt, self.KP, self.DP)
+        # ---- front chain: PE -> xyz -> gate MLP
+        c["h0"] = self._buf("h0", (P, M), dt)
+        c["a1"] = self._buf("a1", (P, G), dt)
+        c["g"] = self._buf("g", (P, G), dt)
+        c["m_a1"] = self._buf("m_a1", (o.chain_mask_words(dt, 1, P),), torch.int32)
+        o.mlp_chain(c["pe"], [o.Layer(self.wf["xyz"], self.p["xyz.b"].view(1, M), save=c["h0"]),
+                              o.Layer(self.wf["gate0"], self.p["gate0.b"].view(1, G), relu=1, mask=c["m_a1"], save=c["a1"]),
+                              o.Layer(self.wf["gate1"], self.p["gate1.b"].view(1, G))], c["g"], tag=3)
+        # ---- gate + routing
+        c["gates"], c["idx"], c["gmax"], c["stats"] = o.gate_fwd(c["g"], self.p["ln.w"], self.p["ln.b"], self.p["wg"])
+        if routing_override is not None:     # tests: inject the oracle's expert choice (near-tie robustness)
+            c["idx"] = routing_override.to(dev).int().contiguous()
+            c["gmax"] = c["gates"].gather(1, c["idx"].long()[:, None])[:, 0].contiguous()
+        c["loc"], c["counts"], c["perm"], c["tok2row"], c["l_aux"] = o.route_top1(c["idx"], c["gmax"], c["gates"], seg_tokens,
+                                                                                  E, cap, self.bpr)
+        # ---- expert chain (gathers its rows through perm; ragged groups = (segment, expert))
+        rows = n_seg * E * cap
+        ng = n_seg * E
+        c["rows"], c["ng"] = rows, ng
+        c["counts_flat"] = c["counts"].view(-1)
+        c["xs"] = self._buf("xs", (rows, M), dt)
+        c["eo"] = self._buf("eo", (rows, M), dt)
+        c["saves"] = [self._buf(f"save{l}", (rows, M), dt) for l in range(L - 1)]
+        nw = o.chain_mask_words(dt, ng, cap)
+        c["masks"] = [self._buf(f"mask{l}", (nw,), torch.int32) for l in range(L - 1)]
+        skips = set(self.cfg["skips"])
+        layers = [o.Layer(self.wf[f"exp{l}"], self.p[f"exp{l}.b"], relu=1 if l < L - 1 else 0, skip=(l in skips),
+                          save=c["saves"][l] if l < L - 1 else None, mask=c["masks"][l] if l < L - 1 else None)
+                  for l in range(L)]
+        with self._timed("expert_fwd"):
+            o.mlp_chain(c["h0"], layers, c["eo"], n_groups=ng, n_wsets=E, group_stride=cap, group_rows=c["counts_flat"],
+                        group_rows_clamp=cap, x_gather=c["perm"].view(-1), x_save=c["xs"], tag=1)
+        # ---- combine (+ the MoE layer's ReLU)
+        c["y"] = o.combine_fwd(c["gmax"], c["idx"], c["loc"], c["eo"], cap, seg_tokens, E, relu=True)
+        # ---- per-ray part of layer "2": [PE(dir), appearance embedding] @ W2r + b2   (N_rays x 75, host-side torch)
+        feat = torch.cat([pe_dir[:, : self.in_dir].float(), self.p["emb"][image_indices.long()]], 1)
+        c["ray_feat"] = feat
+        c["c_ray"] = torch.addmm(self.p["l2.b"], feat, self.p["l2r.w"]).contiguous()
+        # ---- tail chain: layer "1" -> layer "2" (+ per-ray bias, ReLU)
+        c["h1"] = self._buf("h1", (P, M), dt)
+        c["h2"] = self._buf("h2", (P, H2), dt)
+        o.mlp_chain(c["y"], [o.Layer(self.wf["l1"], self.p["l1.b"].view(1, M), save=c["h1"]),
+                             o.Layer(self.wf["l2h"], None, relu=1, rowbias=c["c_ray"], rows_per_bias=S)], c["h2"], tag=4)
+        # ---- heads + compositing
+        c["raw"] = o.heads_fwd(c["y"], c["h2"], self.p["sigma.w"], self.p["sigma.b"], self.p["color.w"], self.p["color.b"],
+                               sigma_noise)
+        c["rgb"], c["depth"], c["depth_variance"], _ = o.composite_fwd(c["raw"], c["z"])
+        return c
+
+    # ------------------------------------------------------------------------------------------ backward
+    def backward(self, c, d_rgb, d_laux):
+        """Accumulates parameter gradients into self.grad given dL/d rgb [N,3] and dL/d l_aux[seg] (scalar each)."""
+        o, dt = ops, self.dtype
+        N, S, P, n_seg, cap, seg_tokens = c["N"], c["S"], c["P"], c["n_seg"], c["cap"], c["seg_tokens"]
+        M, E, L, G, H2 = self.M, self.E, self.L, self.G, self.H2
+        g = self.g
+        rows, ng = c["rows"], c["ng"]
+        d_raw = o.composite_bwd(c["raw"], c["z"], d_rgb)
+        dh2, dsig = o.heads_bwd(c["y"], c["h2"], self.p["color.w"], c["raw"], d_raw, g["sigma.w"], g["sigma.b"], g["color.w"],
+                                g["color.b"])
+        # per-ray bias gradient and the tiny per-ray GEMM's parameters
+        dc_ray = o.group_colsum(dh2, S)
+        g["l2r.w"].addmm_(c["ray_feat"].t(), dc_ray)
+        g["l2.b"].add_(dc_ray.sum(0))
+        d_feat_emb = dc_ray @ self.p["l2r.w"][self.in_dir:].t()
+        g["emb"].index_add_(0, c["image_indices"].long(), d_feat_emb)
+        # tail backward chain: dh2 -> dh1 -> dy
+        dh1 = self._buf("dh1", (P, M), dt)
+        dy = self._buf("dy", (P, M), dt)
+        o.mlp_chain(dh2, [o.Layer(self.wb["l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dy, tag=5)
+        o.wgrad(c["h1"], dh2, g["l2h.w"].view(1, M, H2), None)
+        o.wgrad(c["y"], dh1, g["l1.w"].view(1, M, M), g["l1.b"].view(1, M))
+        # combine backward (adds the sigma head's rank-1 term, applies the ReLU mask, gate gradient)
+        dout, dgmax = o.combine_bwd(dy, c["y"], dsig, self.p["sigma.w"], c["gmax"])
+        # expert backward chain
+        dz = [self._buf(f"dz{l}", (rows, M), dt) for l in range(L)]
+        dx = self._buf("dx", (rows, M), dt)
+        skip_l = list(self.cfg["skips"])[0] if len(self.cfg["skips"]) else None
+        bl = []
+        for i in range(L):
+            l = L - 1 - i
+            bl.append(o.Layer(self.wb[f"exp{l}"], None, relu=2 if l > 0 else 0, mask=c["masks"][l - 1] if l > 0 else None,
+                              save=dz[l - 1] if l > 0 else None))
+        with self._timed("expert_bwd"):
+            o.mlp_chain(dout, bl, dx, n_groups=ng, n_wsets=E, group_stride=cap, group_rows=c["counts_flat"],
+                        group_rows_clamp=cap, x_gather=c["perm"].view(-1), x_save=dz[L - 1],
+                        y_add=dz[skip_l] if skip_l is not None else None, tag=2)
+        with self._timed("expert_wgrad"):
+            for l in range(L):
+                a = c["xs"] if l == 0 else c["saves"][l - 1]
+                o.wgrad(a, dz[l], g[f"exp{l}.w"], g[f"exp{l}.b"], n_groups=ng, n_wsets=E, group_stride=cap,
+                        group_rows=c["counts_flat"], group_rows_clamp=cap, n_splits=max(1, 512 // ng), tag=1)
+        # gate backward (softmax / router / LayerNorm) including the l_aux term
+        coef = (d_laux * (E / float(seg_tokens * seg_tokens))).to(torch.float32).contiguous()
+        dg = o.gate_bwd(c["g"], self.p["ln.w"], self.p["ln.b"], self.p["wg"], c["gates"], c["idx"], dgmax, c["stats"],
+                        c["counts"], coef, seg_tokens, g["wg"], g["ln.w"], g["ln.b"])
+        # front backward chain: dg -> d(a1) -> d(h0), adding the expert path's input gradient through tok2row
+        dza1 = self._buf("dza1", (P, G), dt)
+        dh0 = self._buf("dh0", (P, M), dt)
+        o.mlp_chain(dg, [o.Layer(self.wb["gate1"], None, relu=2, mask=c["m_a1"], save=dza1), o.Layer(self.wb["gate0"], None)],
+                    dh0, y_add=dx, y_add_gather=c["tok2row"], tag=6)
+        nsp = 256
+        o.wgrad(c["a1"], dg, g["gate1.w"].view(1, G, G), g["gate1.b"].view(1, G), n_splits=nsp)
+        o.wgrad(c["h0"], dza1, g["gate0.w"].view(1, M, G), g["gate0.b"].view(1, G), n_splits=nsp)
+        o.wgrad(c["pe"], dh0, g["xyz.w"].view(1, self.KP, M), g["xyz.b"].view(1, M), n_splits=nsp)
+
+    # ------------------------------------------------------------------------------------------ training step
+    def train_step(self, rgbs, rays, image_indices, n_samples, seg_tokens, perturb=1.0, perturb_rand=None,
+                   sigma_noise=None, optimizer_step=True, routing_override=None, grad_allreduce=None):
+        """Runner._training_step + loss assembly + backward + Adam (runner.py:1077-1123, 646-686)."""
+        N = rays.shape[0]
+        self.grad.zero_()
+        c = self.forward_rays(rays, image_indices, n_samples, seg_tokens, perturb, perturb_rand, sigma_noise, True,
+                              routing_override)
+        c["image_indices"] = image_indices
+        diff = c["rgb"] - rgbs
+        photo = (diff * diff).mean()                                  # F.mse_loss, runner.py:1099
+        gate_loss = c["l_aux"].mean()                                 # runner.py:1104
+        loss = photo + self.wt * gate_loss                            # runner.py:646-651
+        d_rgb = (diff * (2.0 / diff.numel())).contiguous()
+        d_laux = torch.full((c["n_seg"],), self.wt / c["n_seg"], dtype=torch.float32, device=self.dev)
+        self.backward(c, d_rgb, d_laux)
+        scale = 1.0
+        if grad_allreduce is not None:
+            scale = grad_allreduce(self.grad)
+        if optimizer_step:
+            self.step_count += 1
+            ops.adam_step(self.flat, self.grad, self.m, self.v, None, self.step_count, self.lr, grad_scale=scale)
+            self.refresh_compute_copies()
+        return dict(loss=loss, photo_loss=photo, gate_loss=gate_loss, psnr=-10.0 * torch.log10(photo),
+                    depth_variance=c["depth_variance"].mean(), ctx=c)
+
+    # ------------------------------------------------------------------------------------------ NeRFMoE.forward mirror
+    def __call__(self, x, sigma_only=False, sigma_noise=None):
+        raise NotImplementedError("point-wise NeRFMoE.forward mirror: see switch_nerf_amd.rendering / next round")

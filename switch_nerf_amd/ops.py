@@ -205,9 +205,10 @@ def chain_mask_words(dtype, n_groups: int, group_stride: int) -> int:
 
 
 def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride=None, group_rows=None,
-              group_rows_clamp=None, x_gather=None, x_save=None, y_add=None, y_add_gather=None):
+              group_rows_clamp=None, x_gather=None, x_save=None, y_add=None, y_add_gather=None, tag=0):
     d = ChainDesc()
     d.dtype = _dt(x)
+    d.tag = int(tag)
     d.n_layers = len(layers)
     d.n_groups, d.n_wsets = int(n_groups), int(n_wsets)
     d.group_stride = int(group_stride if group_stride is not None else y.shape[0])
@@ -226,12 +227,13 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
     return y
 
 
-def wgrad(a, b, dw, db=None, n_groups=1, n_wsets=1, group_stride=None, group_rows=None, group_rows_clamp=None, n_splits=8):
+def wgrad(a, b, dw, db=None, n_groups=1, n_wsets=1, group_stride=None, group_rows=None, group_rows_clamp=None, n_splits=8,
+          tag=0):
     """dw [n_wsets, m_dim, n_dim] f32 += a^T b per group; db [n_wsets, n_dim] += colsum(b)."""
     m_dim, n_dim = a.shape[1], b.shape[1]
     gs = int(group_stride if group_stride is not None else a.shape[0])
     call("swn_wgrad", _p(a), _p(b), _dt(a), m_dim, n_dim, int(n_groups), int(n_wsets), gs, _p(group_rows),
-         int(group_rows_clamp if group_rows_clamp is not None else gs), _p(dw), _p(db), int(n_splits), _stream())
+         int(group_rows_clamp if group_rows_clamp is not None else gs), _p(dw), _p(db), int(n_splits), int(tag), _stream())
 
 
 def adam_step(param, grad, m, v, shadow, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):

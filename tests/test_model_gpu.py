@@ -1,0 +1,124 @@
+"""End-to-end parity of the HIP train step (forward, loss, backward) against (a) golden vectors produced by the
+imported reference and (b) the CPU oracle at a larger size.  fp32 mode, tolerances written at each check."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import switchnerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _model(dtype, seed, gate_scale, **kw):
+    from switch_nerf_amd.model import SwitchNeRF
+    m = SwitchNeRF(synth.BUILDING, dtype=dtype, **kw)
+    m.load_state_dict(synth.make_weights(seed, synth.BUILDING, gate_scale=gate_scale))
+    return m
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("tag", ["unbalanced", "balanced"])
+def test_train_step_vs_reference_golden_fp32(tag):
+    g = np.load(os.path.join(G, f"render_train_{tag}.npz"))
+    N, S, chunk = int(g["N"]), int(g["S"]), int(g["chunk"])
+    m = _model(torch.float32, int(g["seed"]), float(g["gate_scale"]))
+    rays, img, rgbs = synth.make_rays(52, N)
+    st = m.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0, optimizer_step=False)
+    c = st["ctx"]
+    idx = c["idx"].cpu().numpy().reshape(N, S)
+    n_mis = int((idx != g["moe_gates"]).sum())
+    print(f"{tag}: routing mismatches vs reference: {n_mis} of {idx.size}; dropped {(c['tok2row'] < 0).float().mean().item():.3f}")
+    assert n_mis == 0, "top-1 expert indices must equal the reference's"
+    np.testing.assert_allclose(c["rgb"].cpu().numpy(), g["rgb"], rtol=0, atol=1e-4)          # north-star tolerance
+    np.testing.assert_allclose(c["raw"][:, 3].cpu().numpy().reshape(N, S), g["sigma"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(c["depth_variance"].cpu().numpy(), g["depth_variance"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(c["l_aux"].cpu().numpy(), g["gate_loss"], rtol=1e-5)
+    np.testing.assert_allclose(st["loss"].item(), float(g["loss"]), rtol=1e-5)
+    gd = m.grad_dict()
+    worst = 0.0
+    for k, t in gd.items():
+        got = t.cpu().numpy()
+        ref_sum = g["gsum__" + k]
+        scale = max(1e-12, float(ref_sum[1]))
+        assert abs(synth.checksum(got)[0] - ref_sum[0]) <= 1e-3 * scale + 1e-9, k
+        assert abs(synth.checksum(got)[1] - ref_sum[1]) <= 1e-3 * scale + 1e-9, k
+        sl = got.reshape(-1)[:: max(1, got.size // 499)][:499]
+        ref = g["gslice__" + k]
+        tol = 1e-7 + 2e-4 * np.abs(ref).max()
+        worst = max(worst, float(np.abs(sl - ref).max() / (np.abs(ref).max() + 1e-12)))
+        np.testing.assert_allclose(sl, ref, rtol=2e-3, atol=tol, err_msg=k)
+    print(f"{tag}: worst relative gradient-slice error {worst:.2e}")
+
+
+def _oracle_step(sd, rays, img, rgbs, S, chunk, routings=None, noise=None, pr=None, perturb=0.0):
+    p = O.params_from_numpy(sd, requires_grad=True)
+    st = O.training_step(p, torch.from_numpy(rays), torch.from_numpy(img), torch.from_numpy(rgbs), synth.BUILDING, S, chunk,
+                         routings=routings, sigma_noise=noise, perturb=perturb, perturb_rand=pr)
+    st["loss"].backward()
+    return p, st
+
+
+@pytest.mark.parametrize("gate_scale", [1.0, 0.02])
+def test_train_step_vs_oracle_larger_fp32(gate_scale):
+    """256 rays x 128 samples, 8 segments of 4096 points, stratified perturbation and sigma noise supplied."""
+    N, S, chunk = 256, 128, 4096
+    sd = synth.make_weights(77, synth.BUILDING, gate_scale=gate_scale)
+    rays, img, rgbs = synth.make_rays(78, N)
+    rng = np.random.default_rng(79)
+    pr = rng.uniform(0, 1, (N, S)).astype(np.float32)
+    noise = rng.standard_normal((N * S, 1)).astype(np.float32)
+    m = _model(torch.float32, 77, gate_scale)
+    st = m.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=1.0, perturb_rand=_dev(pr),
+                      sigma_noise=_dev(noise.reshape(-1)), optimizer_step=False)
+    c = st["ctx"]
+    p, ost = _oracle_step(sd, rays, img, rgbs, S, chunk, noise=torch.from_numpy(noise), pr=torch.from_numpy(pr), perturb=1.0)
+    res = ost["results"]
+    ref_idx = np.concatenate([r["idx"] for r in res["routings"]])
+    ref_loc = np.concatenate([r["loc"] for r in res["routings"]])
+    mis = (c["idx"].cpu().numpy() != ref_idx) | (c["loc"].cpu().numpy() != ref_loc)
+    print(f"gate_scale {gate_scale}: routing (idx, loc) mismatches vs oracle: {int(mis.sum())} of {mis.size}")
+    if mis.any():
+        # fp32 summation-order differences can flip a near-tie; then re-run both sides with the HIP routing injected
+        routings = []
+        for s_ in range(N * S // chunk):
+            sl = slice(s_ * chunk, (s_ + 1) * chunk)
+            routings.append(dict(idx=c["idx"].cpu().numpy()[sl], loc=c["loc"].cpu().numpy()[sl], capacity=c["cap"]))
+        assert mis.mean() < 2e-3
+        p, ost = _oracle_step(sd, rays, img, rgbs, S, chunk, routings=routings, noise=torch.from_numpy(noise),
+                              pr=torch.from_numpy(pr), perturb=1.0)
+        res = ost["results"]
+    np.testing.assert_allclose(c["rgb"].cpu().numpy(), res["rgb_coarse"].detach().numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(c["raw"][:, 3].cpu().numpy(), res["sigma_coarse"].detach().numpy().reshape(-1), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(st["loss"].item(), ost["loss"].item(), rtol=2e-5)
+    gd = m.grad_dict()
+    for k, t in gd.items():
+        ref = p[k].grad.numpy()
+        got = t.cpu().numpy()
+        scale = np.abs(ref).max() + 1e-12
+        err = np.abs(got - ref).max() / scale
+        assert err <= 2e-3, (k, err)
+
+
+def test_bf16_step_close_to_fp32_and_adam_moves_loss():
+    N, S, chunk = 128, 128, 4096
+    rays, img, rgbs = synth.make_rays(88, N)
+    m32 = _model(torch.float32, 87, 0.02)
+    m16 = _model(torch.bfloat16, 87, 0.02)
+    a = m32.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0, optimizer_step=False)
+    b = m16.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0, optimizer_step=False)
+    assert (a["ctx"]["rgb"] - b["ctx"]["rgb"]).abs().max().item() < 3e-2
+    assert abs(a["loss"].item() - b["loss"].item()) < 2e-2 * abs(a["loss"].item())
+    l0 = None
+    for it in range(8):
+        st = m16.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0, optimizer_step=True)
+        l0 = st["loss"].item() if l0 is None else l0
+    assert st["loss"].item() < l0, "eight Adam steps on a fixed batch must reduce the loss"
+    sd = m16.state_dict()
+    assert set(sd.keys()) == set(synth.make_weights(1).keys())
