@@ -174,7 +174,11 @@ int swn_mlp_chain(const swn_chain_desc* desc, void* stream);
  * (tutel_moe_layer_nobatch.py:853); with A = dZ, B = input it yields torch.nn.Linear's [out, in].              */
 int swn_wgrad(const void* a, const void* b, int dtype, int m_dim, int n_dim,
               int n_groups, int n_wsets, int group_stride, const int32_t* group_rows, int group_rows_clamp,
-              float* dw, float* db, int n_splits, int tag /* profiling only: 0 generic, 1 expert */, void* stream);
+              float* dw, float* db, int n_splits, int tag /* profiling only: 0 generic, 1 expert */,
+              void* workspace, size_t workspace_bytes, void* stream);
+/* workspace (optional, recommended): n_groups * n_splits * (m_dim*n_dim + n_dim) * 4 bytes.  With it every workgroup
+ * stores its partial tile and a second kernel reduces them into dw/db (deterministic, no atomics); without it
+ * (NULL) partial tiles are added with fp32 atomics.                                                               */
 
 /* ---- optimiser -------------------------------------------------------------------------------------------------
  * torch.optim.Adam (runner.py:486) over one flat fp32 parameter buffer; grad_scale multiplies the gradient

@@ -96,24 +96,46 @@ __device__ __forceinline__ uint4 add_chunks(uint4 a, uint4 b) {
 }
 
 // Load the (gathered) input rows of this tile into an LDS tile with the activation layout.
+// kfeat * sizeof(T) / 16 (chunks per row) is a power of two; all global loads of a batch are issued before any is
+// consumed (no per-load wait), out-of-range work is clamped to a valid address and masked at the store.
 template <typename T>
 __device__ __forceinline__ void load_rows_to_lds(char* dst, const void* src, const int32_t* gather, void* save,
                                                  long grow0, int rows_valid_in_tile, int kfeat, int tid) {
   constexpr int BM = Cfg<T>::BM;
   const int row_bytes = kfeat * (int)sizeof(T);
-  const int cpr = row_bytes >> 4;  // 16-byte chunks per row
+  const int cpr = row_bytes >> 4;  // 16-byte chunks per row (power of two)
+  const int sh = 31 - __builtin_clz(cpr);
   const int total = BM * cpr;
-  for (int c = tid; c < total; c += NT) {
-    const int row = c / cpr, ch = c - row * cpr;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    const bool valid = row < rows_valid_in_tile;
-    if (valid) {
-      long srow = grow0 + row;
-      if (gather) srow = gather[grow0 + row];
-      if (srow >= 0) v = *(const uint4*)((const char*)src + srow * row_bytes + ch * 16);
-      if (save) *(uint4*)((char*)save + (grow0 + row) * row_bytes + ch * 16) = v;
+  constexpr int B = 4;
+  for (int c0 = tid; c0 < total; c0 += NT * B) {
+    long srow[B];
+    int row[B], ch[B];
+    bool in[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int c = c0 + NT * i;
+      in[i] = c < total;
+      const int cc = in[i] ? c : 0;
+      row[i] = cc >> sh;
+      ch[i] = cc & (cpr - 1);
+      const bool valid = in[i] && row[i] < rows_valid_in_tile;
+      srow[i] = valid ? (gather ? (long)gather[grow0 + row[i]] : grow0 + row[i]) : -1;
     }
-    store_chunk_to_act<T>(dst, row, ch, v);
+    uint4 v[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const long sr = srow[i] >= 0 ? srow[i] : 0;
+      v[i] = *(const uint4*)((const char*)src + sr * row_bytes + ch[i] * 16);
+    }
+    asm volatile("" ::: "memory");  // keep the whole batch of loads in flight: do not sink them next to their uses
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      if (srow[i] < 0) v[i] = make_uint4(0, 0, 0, 0);
+      if (in[i]) {
+        if (save && row[i] < rows_valid_in_tile) *(uint4*)((char*)save + (grow0 + row[i]) * row_bytes + ch[i] * 16) = v[i];
+        store_chunk_to_act<T>(dst, row[i], ch[i], v[i]);
+      }
+    }
   }
 }
 
@@ -124,6 +146,7 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
   const swn_chain_desc& d = args.d;
   char* act = smem;
   char* wbuf = smem + ACT_BYTES;  // 2 x WBUF_BYTES; also reused as a second activation-layout tile (skip input)
+  char* bias_lds = smem + ACT_BYTES + 2 * WBUF_BYTES;  // 1 KiB
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -148,13 +171,59 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
 
   f32x16_t acc[MI][NI];
 
+  // Weight K-slices travel global -> registers (W4, named members so they stay in VGPRs) -> LDS.  The loads for the
+  // next slice are issued before the MFMAs of the current one and consumed after them; at a layer boundary the
+  // "next slice" is slice 0 of the next layer (cross-layer prefetch), parked in registers across the epilogue.
+  struct W4 { uint4 a, b, c, e; };
+  auto gload = [&](const char* wgp, int n_, int k_, int s_) -> W4 {
+    W4 r;
+    const size_t kb = (size_t)s_ * BK;
+    const int n1 = n_ - 1;
+    r.a = *(const uint4*)(wgp + ((size_t)min((tid + NT * 0) >> 3, n1) * k_ + kb) * sizeof(T) + (tid & 7) * 16);
+    r.b = *(const uint4*)(wgp + ((size_t)min((tid + NT * 1) >> 3, n1) * k_ + kb) * sizeof(T) + (tid & 7) * 16);
+    r.c = *(const uint4*)(wgp + ((size_t)min((tid + NT * 2) >> 3, n1) * k_ + kb) * sizeof(T) + (tid & 7) * 16);
+    r.e = *(const uint4*)(wgp + ((size_t)min((tid + NT * 3) >> 3, n1) * k_ + kb) * sizeof(T) + (tid & 7) * 16);
+    return r;
+  };
+  auto lstore1 = [&](char* wb, int c, uint4 v) {
+    const int nrow = c >> 3, kc = c & 7;
+    if constexpr (sizeof(T) == 2) {
+      *(uint4*)(wb + w_off_chunk((bf16_t*)nullptr, nrow, kc)) = v;
+    } else {
+      *(uint32_t*)(wb + w_off_word(nrow, kc * 4 + 0)) = v.x;
+      *(uint32_t*)(wb + w_off_word(nrow, kc * 4 + 1)) = v.y;
+      *(uint32_t*)(wb + w_off_word(nrow, kc * 4 + 2)) = v.z;
+      *(uint32_t*)(wb + w_off_word(nrow, kc * 4 + 3)) = v.w;
+    }
+  };
+  auto lstore = [&](char* wb, const W4& r) {
+    lstore1(wb, tid + NT * 0, r.a);
+    lstore1(wb, tid + NT * 1, r.b);
+    lstore1(wb, tid + NT * 2, r.c);
+    lstore1(wb, tid + NT * 3, r.e);
+  };
+  auto wptr = [&](int L_) -> const char* {
+    return (const char*)d.layers[L_].w + (size_t)wset * d.layers[L_].n * d.layers[L_].k * sizeof(T);
+  };
+  auto stage_bias = [&](int L_) {
+    const swn_chain_layer& q = d.layers[L_];
+    if (q.b && tid < (q.n >> 2)) *(float4*)(bias_lds + tid * 16) = *(const float4*)(q.b + (size_t)wset * q.n + tid * 4);
+  };
+
+  {  // slice 0 of layer 0
+    const W4 w0 = gload(wptr(0), d.layers[0].n, d.layers[0].k, 0);
+    stage_bias(0);
+    lstore(wbuf, w0);
+  }
+  __syncthreads();
+
   for (int L = 0; L < d.n_layers; ++L) {
     const swn_chain_layer& ly = d.layers[L];
     const int n = ly.n, k = ly.k;
-    const char* wg = (const char*)ly.w + (size_t)wset * n * k * sizeof(T);
+    const char* wg = wptr(L);
     const int nslices = k / BK;
-    const int nchunks = n * 8;  // 16-byte chunks per slice (128 B per n-row)
     const bool wave_active = (wn * 64) < n;
+    const bool has_next = (L + 1) < d.n_layers;
 
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -163,41 +232,15 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    uint4 wreg[4];
-    auto gload = [&](int s) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = tid + NT * i;
-        if (c < nchunks) {
-          const int nrow = c >> 3, kc = c & 7;
-          wreg[i] = *(const uint4*)(wg + ((size_t)nrow * k + (size_t)s * BK) * sizeof(T) + kc * 16);
-        }
-      }
-    };
-    auto lstore = [&](char* wb) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = tid + NT * i;
-        if (c < nchunks) {
-          const int nrow = c >> 3, kc = c & 7;
-          if constexpr (sizeof(T) == 2) {
-            *(uint4*)(wb + w_off_chunk((bf16_t*)nullptr, nrow, kc)) = wreg[i];
-          } else {
-            const uint32_t w4[4] = {wreg[i].x, wreg[i].y, wreg[i].z, wreg[i].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *(uint32_t*)(wb + w_off_word(nrow, kc * 4 + j)) = w4[j];
-          }
-        }
-      }
-    };
-
-    gload(0);
-    lstore(wbuf);
-    __syncthreads();
-
+    W4 wnext;
     for (int s = 0; s < nslices; ++s) {
       const char* wb = wbuf + (s & 1) * WBUF_BYTES;
-      if (s + 1 < nslices) gload(s + 1);
+      const bool last_slice = (s + 1 == nslices);
+      {  // always issue a load: next slice of this layer, else slice 0 of the next layer, else a harmless re-read
+        const int Ln = last_slice && has_next ? L + 1 : L;
+        const int sn = last_slice ? 0 : s + 1;
+        wnext = gload(last_slice && has_next ? wptr(L + 1) : wg, d.layers[Ln].n, d.layers[Ln].k, sn);
+      }
       if (wave_active) {
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -217,8 +260,7 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
               for (int ni = 0; ni < NI; ++ni)
-                if (wn * 64 + ni * 32 < n)
-                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
           }
         } else {
 #pragma unroll 4
@@ -238,12 +280,11 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
               for (int ni = 0; ni < NI; ++ni)
-                if (wn * 64 + ni * 32 < n)
-                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
           }
         }
       }
-      if (s + 1 < nslices) lstore(wbuf + ((s + 1) & 1) * WBUF_BYTES);
+      if (!last_slice) lstore(wbuf + ((s + 1) & 1) * WBUF_BYTES, wnext);
       __syncthreads();
     }
     // every wave has finished reading `act` and the weight buffers for this layer.
@@ -255,7 +296,7 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
 
     // ---- epilogue: bias / row-bias / skip / ReLU (or stored mask) -> next layer's input tile ----
     if (wave_active) {
-      const float* bias = ly.b ? ly.b + (size_t)wset * n : nullptr;
+      const bool has_bias = ly.b != nullptr;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const int m = wm * (BM / 2) + mi * 32 + l31;
@@ -273,8 +314,8 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
               float v[4];
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][g4 * 4 + j];
-              if (bias) {
-                const float4 b4 = *(const float4*)(bias + n0);
+              if (has_bias) {
+                const float4 b4 = *(const float4*)(bias_lds + n0 * 4);
                 v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
               }
               if (rb) {
@@ -318,6 +359,10 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
       }
     }
     __syncthreads();
+    if (has_next) {  // the skip tile / bias of this layer are dead now: park next layer's slice 0 and bias in LDS
+      lstore(wbuf, wnext);
+      stage_bias(L + 1);
+    }
 
     // ---- write-out (row-major, coalesced) ----
     const bool last = (L == d.n_layers - 1);
@@ -340,7 +385,7 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
         *(uint4*)((char*)outp + (grow0 + row) * row_bytes + ch * 16) = v;
       }
     }
-    // no barrier needed here: the next layer only reads `act` until its own post-K-loop barrier.
+    __syncthreads();  // next layer's slice 0 / bias are visible; `act` is only read until its post-K-loop barrier
   }
 }
 
@@ -374,7 +419,7 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   if (!d.group_rows) a.d.group_rows_clamp = d.group_stride;
   const long grid = (long)a.tiles_per_group * d.n_groups;
   SWN_CHECK(grid > 0 && grid < (1L << 31), "swn_mlp_chain: grid %ld out of range", grid);
-  const int lds = ACT_BYTES + 2 * WBUF_BYTES;
+  const int lds = ACT_BYTES + 2 * WBUF_BYTES + 1024;
   SWN_CHECK(d.tag >= 0 && d.tag <= 6, "swn_mlp_chain: tag %d not in [0,6]", d.tag);
   const void* fn = nullptr;
 #define SWN_PICK(TAGV)                                                                         \

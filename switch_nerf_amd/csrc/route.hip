@@ -12,21 +12,36 @@ namespace swn {
 
 constexpr int KPB = 2048;  // keys per block (256 threads x 8)
 
-__global__ void route_keys_kernel(const int32_t* __restrict__ idx, const float* __restrict__ gmax, int n_tokens,
-                                  int seg_tokens, int E, int bpr, uint32_t* __restrict__ keys, int32_t* __restrict__ vals,
-                                  int32_t* __restrict__ counts) {
+__global__ __launch_bounds__(256) void route_keys_kernel(const int32_t* __restrict__ idx, const float* __restrict__ gmax,
+                                                         int n_tokens, int seg_tokens, int E, int bpr,
+                                                         uint32_t* __restrict__ keys, int32_t* __restrict__ vals,
+                                                         int32_t* __restrict__ counts) {
+  // per-block (LDS) expert histogram, then one global atomic per (segment, expert) touched by the block; a block
+  // spans at most two segments (seg_tokens >= 256 is not required: generic two-slot handling below)
+  __shared__ int32_t h[2][64];
+  if (threadIdx.x < 128) (&h[0][0])[threadIdx.x] = 0;
+  __syncthreads();
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_tokens) return;
-  const int e = idx[i];
-  uint32_t inv = 0;
-  if (bpr) {
-    const int32_t b = (int32_t)0x3F800000 - (int32_t)__float_as_uint(gmax[i]);
-    inv = b < 0 ? 0u : (b > 0x03FFFFFF ? 0x03FFFFFFu : (uint32_t)b);
+  const int seg0 = (int)(((long)blockIdx.x * blockDim.x) / seg_tokens);
+  if (i < n_tokens) {
+    const int e = idx[i];
+    uint32_t inv = 0;
+    if (bpr) {
+      const int32_t b = (int32_t)0x3F800000 - (int32_t)__float_as_uint(gmax[i]);
+      inv = b < 0 ? 0u : (b > 0x03FFFFFF ? 0x03FFFFFFu : (uint32_t)b);
+    }
+    keys[i] = ((uint32_t)e << 26) | inv;
+    const int seg = (int)(i / seg_tokens);
+    vals[i] = (int32_t)(i - (long)seg * seg_tokens);
+    if (seg - seg0 < 2) atomicAdd(&h[seg - seg0][e], 1);
+    else atomicAdd(counts + seg * E + e, 1);   // tiny segments: fall back to a direct atomic
   }
-  keys[i] = ((uint32_t)e << 26) | inv;
-  const int seg = (int)(i / seg_tokens);
-  vals[i] = (int32_t)(i - (long)seg * seg_tokens);
-  atomicAdd(counts + seg * E + e, 1);
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int s = threadIdx.x >> 6, e = threadIdx.x & 63;
+    const int c = h[s][e];
+    if (c) atomicAdd(counts + (seg0 + s) * E + e, c);
+  }
 }
 
 __global__ __launch_bounds__(256) void route_hist_kernel(const uint32_t* __restrict__ keys, int seg_tokens, int shift,

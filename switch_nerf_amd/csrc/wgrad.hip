@@ -32,6 +32,8 @@ struct WgradArgs {
   const int32_t* group_rows;
   float* dw;
   float* db;
+  float* partial;   // [n_groups * n_splits][m_dim * n_dim + n_dim] fp32 partial tiles (plain stores), or NULL = atomics
+  int n_splits;
 };
 
 __device__ __forceinline__ bf16x8_t as_frag(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3) {
@@ -75,39 +77,34 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) accb[j][r] = 0.f;
 
-  const int a_cpr = m_dim * (int)sizeof(T) / 16, b_cpr = n_dim * (int)sizeof(T) / 16;  // 16-B chunks per row
+  // 16-byte chunks per operand row (powers of two); loads are unconditional: surplus work items are clamped onto
+  // the last chunk (duplicate identical writes), rows past the end of the group are zero-filled.
+  const int a_cpr = m_dim * (int)sizeof(T) / 16, b_cpr = n_dim * (int)sizeof(T) / 16;
+  const int a_sh = 31 - __builtin_clz(a_cpr), b_sh = 31 - __builtin_clz(b_cpr);
   const int a_total = BKR * a_cpr, b_total = BKR * b_cpr;
   uint4 ra[2], rb[2];
+  int a_row[2], a_ch[2], b_row[2], b_ch[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ca = min(tid + WG_NT * i, a_total - 1), cb = min(tid + WG_NT * i, b_total - 1);
+    a_row[i] = ca >> a_sh; a_ch[i] = ca & (a_cpr - 1);
+    b_row[i] = cb >> b_sh; b_ch[i] = cb & (b_cpr - 1);
+  }
   auto gload = [&](int r0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int c = tid + WG_NT * i;
-      if (c < a_total) {
-        const int row = c / a_cpr, ch = c - row * a_cpr;
-        ra[i] = (r0 + row < r_end)
-                    ? *(const uint4*)((const char*)p.a + ((grow0 + r0 + row) * (long)m_dim) * sizeof(T) + ch * 16)
-                    : make_uint4(0, 0, 0, 0);
-      }
-      if (c < b_total) {
-        const int row = c / b_cpr, ch = c - row * b_cpr;
-        rb[i] = (r0 + row < r_end)
-                    ? *(const uint4*)((const char*)p.b + ((grow0 + r0 + row) * (long)n_dim) * sizeof(T) + ch * 16)
-                    : make_uint4(0, 0, 0, 0);
-      }
+      const int ar = min(r0 + a_row[i], r_end - 1), br = min(r0 + b_row[i], r_end - 1);
+      ra[i] = *(const uint4*)((const char*)p.a + ((grow0 + ar) * (long)m_dim) * sizeof(T) + a_ch[i] * 16);
+      rb[i] = *(const uint4*)((const char*)p.b + ((grow0 + br) * (long)n_dim) * sizeof(T) + b_ch[i] * 16);
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, int r0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int c = tid + WG_NT * i;
-      if (c < a_total) {
-        const int row = c / a_cpr, ch = c - row * a_cpr;
-        *(uint4*)(sa(buf) + row * RS + ch * 16) = ra[i];
-      }
-      if (c < b_total) {
-        const int row = c / b_cpr, ch = c - row * b_cpr;
-        *(uint4*)(sb(buf) + row * RS + ch * 16) = rb[i];
-      }
+      const uint4 za = (r0 + a_row[i] < r_end) ? ra[i] : make_uint4(0, 0, 0, 0);
+      const uint4 zb = (r0 + b_row[i] < r_end) ? rb[i] : make_uint4(0, 0, 0, 0);
+      *(uint4*)(sa(buf) + a_row[i] * RS + a_ch[i] * 16) = za;
+      *(uint4*)(sb(buf) + b_row[i] * RS + b_ch[i] * 16) = zb;
     }
   };
 
@@ -115,7 +112,7 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
   const bool do_bias = (p.db != nullptr) && wm == 0 && (wn * 64 < n_dim);
 
   gload(r_begin);
-  lstore(0);
+  lstore(0, r_begin);
   __syncthreads();
   int buf = 0;
   for (int r0 = r_begin; r0 < r_end; r0 += BKR) {
@@ -198,13 +195,16 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
         }
       }
     }
-    if (more) lstore(buf ^ 1);
+    if (more) lstore(buf ^ 1, r0 + BKR);
     __syncthreads();
     buf ^= 1;
   }
 
-  // ---- epilogue: fp32 atomics into dW[wset][m][n] ----
+  // ---- epilogue: this workgroup's partial tile goes to the workspace with plain stores (a reduce kernel sums the
+  // partials; device-scope fp32 atomics from hundreds of workgroups onto one 256 KiB tile are fabric-bound), or,
+  // without a workspace, straight into dW with atomics.
   float* dw = p.dw + (size_t)wset * m_dim * n_dim;
+  float* part = p.partial ? p.partial + ((size_t)g * p.n_splits + split) * ((size_t)m_dim * n_dim + n_dim) : nullptr;
   if (active) {
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -221,7 +221,10 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
             m = wm * 128 + q * 32 + i;
             n = wn * 64 + qq * 32 + l31;
           }
-          if (m < m_dim && n < n_dim) unsafeAtomicAdd(dw + (size_t)m * n_dim + n, acc[q][qq][r]);
+          if (m < m_dim && n < n_dim) {
+            if (part) part[(size_t)m * n_dim + n] = acc[q][qq][r];
+            else unsafeAtomicAdd(dw + (size_t)m * n_dim + n, acc[q][qq][r]);
+          }
         }
   }
   if (do_bias && lhi == 0) {
@@ -229,9 +232,32 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
     for (int qq = 0; qq < 2; ++qq) {
       int n;
       if constexpr (sizeof(T) == 2) n = wn * 64 + 2 * l31 + qq; else n = wn * 64 + qq * 32 + l31;
-      if (n < n_dim) unsafeAtomicAdd(p.db + (size_t)wset * n_dim + n, accb[qq][0]);  // D row i = 0 (every row equal)
+      if (n < n_dim) {  // D row i = 0 (every row equal)
+        if (part) part[(size_t)m_dim * n_dim + n] = accb[qq][0];
+        else unsafeAtomicAdd(p.db + (size_t)wset * n_dim + n, accb[qq][0]);
+      }
     }
   }
+}
+
+// dw[wset][:] += sum over the partial tiles of (group % n_wsets == wset, split) that were actually produced.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, const int32_t* __restrict__ group_rows,
+                                                           int clamp, int group_stride, int rows_per_split, int n_groups,
+                                                           int n_wsets, int n_splits, int tile_elems, int mn, float* __restrict__ dw,
+                                                           float* __restrict__ db) {
+  const int wset = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= tile_elems) return;
+  float s = 0.f;
+  for (int g = wset; g < n_groups; g += n_wsets) {
+    const int rows = group_rows ? min(group_rows[g], clamp) : group_stride;
+    for (int sp = 0; sp < n_splits; ++sp) {
+      if (sp * rows_per_split >= rows) break;
+      s += partial[((size_t)g * n_splits + sp) * tile_elems + e];
+    }
+  }
+  if (e < mn) dw[(size_t)wset * mn + e] += s;
+  else if (db) db[(size_t)wset * (tile_elems - mn) + (e - mn)] += s;
 }
 
 }  // namespace swn
@@ -240,7 +266,7 @@ using namespace swn;
 
 extern "C" int swn_wgrad(const void* a, const void* b, int dtype, int m_dim, int n_dim, int n_groups, int n_wsets,
                          int group_stride, const int32_t* group_rows, int group_rows_clamp, float* dw, float* db,
-                         int n_splits, int tag, void* stream) {
+                         int n_splits, int tag, void* workspace, size_t workspace_bytes, void* stream) {
   SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_wgrad: bad dtype %d", dtype);
   SWN_CHECK(m_dim >= 32 && m_dim <= 256 && m_dim % 32 == 0 && n_dim >= 32 && n_dim <= 256 && n_dim % 32 == 0,
             "swn_wgrad: m_dim=%d n_dim=%d must be multiples of 32 in [32,256]", m_dim, n_dim);
@@ -255,6 +281,11 @@ extern "C" int swn_wgrad(const void* a, const void* b, int dtype, int m_dim, int
   p.a = a; p.b = b; p.m_dim = m_dim; p.n_dim = n_dim; p.n_groups = n_groups; p.n_wsets = n_wsets;
   p.group_stride = group_stride; p.clamp = group_rows ? group_rows_clamp : group_stride; p.rows_per_split = rps;
   p.group_rows = group_rows; p.dw = dw; p.db = db;
+  p.n_splits = splits;
+  const size_t tile_elems = (size_t)m_dim * n_dim + n_dim;
+  const size_t need = (size_t)n_groups * splits * tile_elems * sizeof(float);
+  p.partial = (workspace && workspace_bytes >= need) ? (float*)workspace : nullptr;
+  if (workspace && !p.partial) return swn::set_error("swn_wgrad: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
   const int lds = 4 * bkr * 256 * (dtype == SWN_BF16 ? 2 : 4);
   SWN_CHECK(tag == 0 || tag == 1, "swn_wgrad: tag must be 0 or 1");
   const void* fn;
@@ -265,6 +296,10 @@ extern "C" int swn_wgrad(const void* a, const void* b, int dtype, int m_dim, int
   void* kargs[] = {(void*)&p};
   e = hipLaunchKernel(fn, dim3(n_groups, splits), dim3(WG_NT), kargs, lds, as_stream(stream));
   SWN_CHECK(e == hipSuccess, "swn_wgrad launch: %s", hipGetErrorString(e));
+  if (p.partial) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)tile_elems, 256), n_wsets), dim3(256), 0, as_stream(stream), p.partial,
+                       group_rows, p.clamp, group_stride, rps, n_groups, n_wsets, splits, (int)tile_elems, m_dim * n_dim, dw, db);
+  }
   SWN_LAUNCH_CHECK();
   return 0;
 }

@@ -299,8 +299,9 @@ class SwitchNeRF:
         dh1 = self._buf("dh1", (P, M), dt)
         dy = self._buf("dy", (P, M), dt)
         o.mlp_chain(dh2, [o.Layer(self.wb["l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dy, tag=5)
-        o.wgrad(c["h1"], dh2, g["l2h.w"].view(1, M, H2), None)
-        o.wgrad(c["y"], dh1, g["l1.w"].view(1, M, M), g["l1.b"].view(1, M))
+        nsp = max(1, min(256, P // 4096))          # row splits of the dense weight-gradient GEMMs (fills the 256 CUs)
+        o.wgrad(c["h1"], dh2, g["l2h.w"].view(1, M, H2), None, n_splits=nsp)
+        o.wgrad(c["y"], dh1, g["l1.w"].view(1, M, M), g["l1.b"].view(1, M), n_splits=nsp)
         # combine backward (adds the sigma head's rank-1 term, applies the ReLU mask, gate gradient)
         dout, dgmax = o.combine_bwd(dy, c["y"], dsig, self.p["sigma.w"], c["gmax"])
         # expert backward chain
@@ -320,7 +321,7 @@ class SwitchNeRF:
             for l in range(L):
                 a = c["xs"] if l == 0 else c["saves"][l - 1]
                 o.wgrad(a, dz[l], g[f"exp{l}.w"], g[f"exp{l}.b"], n_groups=ng, n_wsets=E, group_stride=cap,
-                        group_rows=c["counts_flat"], group_rows_clamp=cap, n_splits=max(1, 512 // ng), tag=1)
+                        group_rows=c["counts_flat"], group_rows_clamp=cap, n_splits=max(1, min(512 // ng, cap // 2048)), tag=1)
         # gate backward (softmax / router / LayerNorm) including the l_aux term
         coef = (d_laux * (E / float(seg_tokens * seg_tokens))).to(torch.float32).contiguous()
         dg = o.gate_bwd(c["g"], self.p["ln.w"], self.p["ln.b"], self.p["wg"], c["gates"], c["idx"], dgmax, c["stats"],
@@ -330,7 +331,6 @@ class SwitchNeRF:
         dh0 = self._buf("dh0", (P, M), dt)
         o.mlp_chain(dg, [o.Layer(self.wb["gate1"], None, relu=2, mask=c["m_a1"], save=dza1), o.Layer(self.wb["gate0"], None)],
                     dh0, y_add=dx, y_add_gather=c["tok2row"], tag=6)
-        nsp = 256
         o.wgrad(c["a1"], dg, g["gate1.w"].view(1, G, G), g["gate1.b"].view(1, G), n_splits=nsp)
         o.wgrad(c["h0"], dza1, g["gate0.w"].view(1, M, G), g["gate0.b"].view(1, G), n_splits=nsp)
         o.wgrad(c["pe"], dh0, g["xyz.w"].view(1, self.KP, M), g["xyz.b"].view(1, M), n_splits=nsp)

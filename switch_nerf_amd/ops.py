@@ -227,13 +227,24 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
     return y
 
 
+_wgrad_ws = {}
+
+
 def wgrad(a, b, dw, db=None, n_groups=1, n_wsets=1, group_stride=None, group_rows=None, group_rows_clamp=None, n_splits=8,
-          tag=0):
+          tag=0, use_workspace=True):
     """dw [n_wsets, m_dim, n_dim] f32 += a^T b per group; db [n_wsets, n_dim] += colsum(b)."""
     m_dim, n_dim = a.shape[1], b.shape[1]
     gs = int(group_stride if group_stride is not None else a.shape[0])
+    ws, ws_bytes = None, 0
+    if use_workspace:
+        ws_bytes = int(n_groups) * int(n_splits) * (m_dim * n_dim + n_dim) * 4
+        ws = _wgrad_ws.get(a.device)
+        if ws is None or ws.numel() < ws_bytes:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
+            _wgrad_ws[a.device] = ws
+        ws_bytes = ws.numel()
     call("swn_wgrad", _p(a), _p(b), _dt(a), m_dim, n_dim, int(n_groups), int(n_wsets), gs, _p(group_rows),
-         int(group_rows_clamp if group_rows_clamp is not None else gs), _p(dw), _p(db), int(n_splits), int(tag), _stream())
+         int(group_rows_clamp if group_rows_clamp is not None else gs), _p(dw), _p(db), int(n_splits), int(tag), _p(ws), ws_bytes, _stream())
 
 
 def adam_step(param, grad, m, v, shadow, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
