@@ -62,7 +62,8 @@ int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const float* ln_b,
                  const float* gates, const int32_t* idx, const float* d_gmax, const float* stats,
                  const int32_t* counts, const float* laux_coef, int seg_tokens,
                  int n_tokens, int gate_dim, int n_experts,
-                 void* dg, float* d_wg, float* d_ln_w, float* d_ln_b, void* stream);
+                 void* dg, float* dlogits /* scratch [P,E] f32, written */, float* d_wg, float* d_ln_w, float* d_ln_b,
+                 void* stream);
 
 /* ---- routing: batch-prioritised top-1 capacity assignment ----------------------------------------------------
  * replaces extract_critical / compute_sorted_location / load_balance (tutel_fast_dispatch.py:136-217) and the

@@ -29,7 +29,7 @@ SIGNATURES = {
     "swn_mfma_probe": [vp, vp],
     "swn_sample_pe": [vp, vp, vp, f32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp],
     "swn_gate_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
-    "swn_gate_bwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp],
+    "swn_gate_bwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp],
     "swn_route_top1": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp],
     "swn_dispatch_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "swn_dispatch_bwd_data": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],

@@ -210,9 +210,26 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
     if (q.b && tid < (q.n >> 2)) *(float4*)(bias_lds + tid * 16) = *(const float4*)(q.b + (size_t)wset * q.n + tid * 4);
   };
 
-  {  // slice 0 of layer 0
-    const W4 w0 = gload(wptr(0), d.layers[0].n, d.layers[0].k, 0);
+  // slice sequence of the whole chain: (L, s) -> next
+  auto next_slice = [&](int& L_, int& s_) -> bool {   // returns false past the end (L_, s_ left on the last slice)
+    if (s_ + 1 < d.layers[L_].k / BK) { ++s_; return true; }
+    if (L_ + 1 < d.n_layers) { ++L_; s_ = 0; return true; }
+    return false;
+  };
+  auto gload_at = [&](int L_, int s_) -> W4 { return gload(wptr(L_), d.layers[L_].n, d.layers[L_].k, s_); };
+
+  // Software pipeline, two slices deep: at slice u the loads of slice u+2 are issued (-> wC), the MFMAs of slice u run,
+  // then slice u+1 (wB, issued one slice earlier: ~2 MFMA phases of latency budget) is written to the other LDS buffer.
+  W4 wB, wC;
+  int Lb = 0, sb = 0;       // slice held in wB
+  int Lc = 0, sc = 0;       // slice held in wC / to be loaded next
+  {
+    const W4 w0 = gload_at(0, 0);
     stage_bias(0);
+    bool ok = next_slice(Lb, sb);          // slice 1 of the chain (or a re-read of slice 0 if there is none)
+    wB = gload_at(Lb, sb);
+    Lc = Lb; sc = sb;
+    (void)ok;
     lstore(wbuf, w0);
   }
   __syncthreads();
@@ -220,7 +237,6 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
   for (int L = 0; L < d.n_layers; ++L) {
     const swn_chain_layer& ly = d.layers[L];
     const int n = ly.n, k = ly.k;
-    const char* wg = wptr(L);
     const int nslices = k / BK;
     const bool wave_active = (wn * 64) < n;
     const bool has_next = (L + 1) < d.n_layers;
@@ -232,61 +248,66 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    W4 wnext;
-    for (int s = 0; s < nslices; ++s) {
+    // One K-slice: issue the loads of slice u+2 into `ld`, run the MFMAs of slice u from LDS buffer s&1, then write
+    // slice u+1 (held in `st`, issued one slice ago) to the other buffer.  Slices are processed in pairs with the
+    // roles of the two register sets swapped, so no register copy (and no early wait on the fresh loads) is needed.
+    auto slice_body = [&](int s, W4& st, W4& ld) {
       const char* wb = wbuf + (s & 1) * WBUF_BYTES;
       const bool last_slice = (s + 1 == nslices);
-      {  // always issue a load: next slice of this layer, else slice 0 of the next layer, else a harmless re-read
-        const int Ln = last_slice && has_next ? L + 1 : L;
-        const int sn = last_slice ? 0 : s + 1;
-        wnext = gload(last_slice && has_next ? wptr(L + 1) : wg, d.layers[Ln].n, d.layers[Ln].k, sn);
-      }
+      next_slice(Lc, sc);                  // slice u+2 (clamped at the end of the chain: harmless re-read)
+      ld = gload_at(Lc, sc);
       if (wave_active) {
-        if constexpr (sizeof(T) == 2) {
+          if constexpr (sizeof(T) == 2) {
 #pragma unroll
-          for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8_t wf[NI], af[MI];
+            for (int kk = 0; kk < BK / 16; ++kk) {
+              bf16x8_t wf[NI], af[MI];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-              const int nn = wn * 64 + ni * 32 + l31;
-              wf[ni] = *(const bf16x8_t*)(wb + w_off_chunk((bf16_t*)nullptr, nn, kk * 2 + lhi));
+              for (int ni = 0; ni < NI; ++ni) {
+                const int nn = wn * 64 + ni * 32 + l31;
+                wf[ni] = *(const bf16x8_t*)(wb + w_off_chunk((bf16_t*)nullptr, nn, kk * 2 + lhi));
+              }
+#pragma unroll
+              for (int mi = 0; mi < MI; ++mi) {
+                const int m = wm * (BM / 2) + mi * 32 + l31;
+                af[mi] = *(const bf16x8_t*)(act + act_off((bf16_t*)nullptr, m, s * BK + kk * 16 + lhi * 8));
+              }
+#pragma unroll
+              for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
             }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-              const int m = wm * (BM / 2) + mi * 32 + l31;
-              af[mi] = *(const bf16x8_t*)(act + act_off((bf16_t*)nullptr, m, s * BK + kk * 16 + lhi * 8));
-            }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < NI; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-          }
-        } else {
+          } else {
 #pragma unroll 4
-          for (int kk = 0; kk < BK / 2; ++kk) {
-            float wf[NI], af[MI];
+            for (int kk = 0; kk < BK / 2; ++kk) {
+              float wf[NI], af[MI];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-              const int nn = wn * 64 + ni * 32 + l31;
-              wf[ni] = *(const float*)(wb + w_off_word(nn, kk * 2 + lhi));
+              for (int ni = 0; ni < NI; ++ni) {
+                const int nn = wn * 64 + ni * 32 + l31;
+                wf[ni] = *(const float*)(wb + w_off_word(nn, kk * 2 + lhi));
+              }
+#pragma unroll
+              for (int mi = 0; mi < MI; ++mi) {
+                const int m = wm * (BM / 2) + mi * 32 + l31;
+                af[mi] = *(const float*)(act + act_off((float*)nullptr, m, s * BK + kk * 2 + lhi));
+              }
+#pragma unroll
+              for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
             }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-              const int m = wm * (BM / 2) + mi * 32 + l31;
-              af[mi] = *(const float*)(act + act_off((float*)nullptr, m, s * BK + kk * 2 + lhi));
-            }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < NI; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
           }
         }
-      }
-      if (!last_slice) lstore(wbuf + ((s + 1) & 1) * WBUF_BYTES, wnext);
+      if (!last_slice) lstore(wbuf + ((s + 1) & 1) * WBUF_BYTES, st);   // else: st = slice 0 of the next layer, parked
       __syncthreads();
+    };
+    for (int s = 0; s < nslices; s += 2) {
+      slice_body(s, wB, wC);
+      if (s + 1 < nslices) slice_body(s + 1, wC, wB);
     }
+    // even slice count: next layer's slice 0 is parked in wC and its slice 1 is already in wB (no register moves);
+    // odd slice count: parked in wB, the following slice in wC.
     // every wave has finished reading `act` and the weight buffers for this layer.
 
     if (ly.skip) {  // stage the chain input again (activation layout) in the idle weight buffers
@@ -360,7 +381,8 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
     }
     __syncthreads();
     if (has_next) {  // the skip tile / bias of this layer are dead now: park next layer's slice 0 and bias in LDS
-      lstore(wbuf, wnext);
+      if (nslices & 1) { lstore(wbuf, wB); wB = wC; }
+      else lstore(wbuf, wC);
       stage_bias(L + 1);
     }
 

@@ -158,55 +158,113 @@ __global__ void dir_pe_kernel(const float* __restrict__ rays, int n_rays, int L,
   }
 }
 
-// ------------------------------------------------------------------------------------------------ gate
-// one wave per token; lane owns G/64 consecutive features (G in {64,128,...,1024})
-template <typename T, int VPL>
-__device__ __forceinline__ void load_row(const T* row, int lane, float* x) {
-#pragma unroll
-  for (int j = 0; j < VPL; ++j) x[j] = ElemIO<T>::ld(row + lane * VPL + j);
+// ------------------------------------------------------------------------------------------------ row kernels
+// One token row per 16-lane group (4 rows per wave): a lane owns COLS/16 features in 16-byte chunks
+// (chunk c = j + 16 q  ->  a 16-lane group reads 256 contiguous bytes per instruction), and row reductions are four
+// DPP adds inside the 16-lane row (quad_perm, quad_perm, row_half_mirror, row_mirror) - no LDS traffic.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float sum16(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return v;
 }
 
-template <typename T, int VPL, int EMAX>
+template <typename T, int COLS> struct Row16 {
+  static constexpr int VPL = COLS / 16;                          // values per lane
+  static constexpr int EPC = 16 / (int)sizeof(T);                // elements per 16-byte chunk
+  static constexpr int NCH = VPL / EPC;                          // chunks per lane
+  static_assert(NCH >= 1, "row too narrow for the 16-lane layout");
+  static __device__ __forceinline__ int col(int j, int v) { return (j + 16 * (v / EPC)) * EPC + (v % EPC); }
+  static __device__ __forceinline__ void load(const T* row, int j, float* x) {
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const uint4 u = *(const uint4*)(row + (j + 16 * q) * EPC);
+      if constexpr (sizeof(T) == 2) {
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          x[q * 8 + 2 * i] = bf16_to_f32((bf16_t)(w[i] & 0xFFFF));
+          x[q * 8 + 2 * i + 1] = bf16_to_f32((bf16_t)(w[i] >> 16));
+        }
+      } else {
+        x[q * 4 + 0] = __uint_as_float(u.x); x[q * 4 + 1] = __uint_as_float(u.y);
+        x[q * 4 + 2] = __uint_as_float(u.z); x[q * 4 + 3] = __uint_as_float(u.w);
+      }
+    }
+  }
+  static __device__ __forceinline__ void store(T* row, int j, const float* x) {
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      uint4 u;
+      if constexpr (sizeof(T) == 2) {
+        u.x = pack_bf16x2(x[q * 8 + 0], x[q * 8 + 1]); u.y = pack_bf16x2(x[q * 8 + 2], x[q * 8 + 3]);
+        u.z = pack_bf16x2(x[q * 8 + 4], x[q * 8 + 5]); u.w = pack_bf16x2(x[q * 8 + 6], x[q * 8 + 7]);
+      } else {
+        u.x = __float_as_uint(x[q * 4 + 0]); u.y = __float_as_uint(x[q * 4 + 1]);
+        u.z = __float_as_uint(x[q * 4 + 2]); u.w = __float_as_uint(x[q * 4 + 3]);
+      }
+      *(uint4*)(row + (j + 16 * q) * EPC) = u;
+    }
+  }
+  // fp32 parameter vector laid out like the row
+  static __device__ __forceinline__ void loadf(const float* vec, int j, float* x) {
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) x[v] = vec[col(j, v)];
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ gate
+template <typename T, int G, int EMAX>
 __global__ __launch_bounds__(256) void gate_fwd_kernel(const T* __restrict__ g, const float* __restrict__ ln_w,
                                                        const float* __restrict__ ln_b, const float* __restrict__ wg,
                                                        int P, int E, float* __restrict__ gates, int32_t* __restrict__ idx,
                                                        float* __restrict__ gmax, float* __restrict__ stats) {
-  const int lane = threadIdx.x & 63;
-  const int G = VPL * 64;
-  const long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long nw = ((long)gridDim.x * blockDim.x) >> 6;
-  float w[VPL], b[VPL];
-#pragma unroll
-  for (int j = 0; j < VPL; ++j) {
-    w[j] = ln_w ? ln_w[lane * VPL + j] : 1.f;
-    b[j] = ln_b ? ln_b[lane * VPL + j] : 0.f;
+  using R = Row16<T, G>;
+  constexpr int VPL = R::VPL;
+  constexpr int LS = VPL + 4;       // lane segment stride (floats): +16 B keeps the 16 lanes of a b128 read on distinct banks
+  __shared__ float swg[EMAX * 16 * LS];   // router weights re-laid so that a lane's VPL values are contiguous: [e][j][v]
+  const int j = threadIdx.x & 15;
+  for (int t = threadIdx.x; t < EMAX * G; t += 256) {
+    const int e = t / G, r = t % G, jj = r / VPL, v = r % VPL;
+    swg[(e * 16 + jj) * LS + v] = e < E ? wg[(long)e * G + R::col(jj, v)] : 0.f;
   }
-  for (long tok = wid; tok < P; tok += nw) {
+  float w[VPL], b[VPL];
+  if (ln_w) { R::loadf(ln_w, j, w); R::loadf(ln_b, j, b); }
+  __syncthreads();
+  const long gid = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const long ngr = ((long)gridDim.x * 256) >> 4;
+  for (long tok = gid; tok < P; tok += ngr) {
     float x[VPL];
-    load_row<T, VPL>(g + tok * G, lane, x);
+    R::load(g + tok * G, j, x);
     float mean = 0.f, rstd = 1.f;
     if (ln_w) {  // torch.nn.LayerNorm, eps 1e-5 (models/nerf_moe.py:301-302)
       float s = 0.f;
 #pragma unroll
-      for (int j = 0; j < VPL; ++j) s += x[j];
-      mean = wave_sum(s) / G;
+      for (int v = 0; v < VPL; ++v) s += x[v];
+      mean = sum16(s) * (1.f / G);
       float q = 0.f;
 #pragma unroll
-      for (int j = 0; j < VPL; ++j) q += (x[j] - mean) * (x[j] - mean);
-      rstd = 1.f / sqrtf(wave_sum(q) / G + 1e-5f);
+      for (int v = 0; v < VPL; ++v) q += (x[v] - mean) * (x[v] - mean);
+      rstd = 1.f / sqrtf(sum16(q) * (1.f / G) + 1e-5f);
 #pragma unroll
-      for (int j = 0; j < VPL; ++j) x[j] = (x[j] - mean) * rstd * w[j] + b[j];
+      for (int v = 0; v < VPL; ++v) x[v] = (x[v] - mean) * rstd * w[v] + b[v];
     }
     float logit[EMAX];
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) {
       float d = 0.f;
-      if (e < E) {
+      const float4* wp = (const float4*)(swg + (e * 16 + j) * LS);
 #pragma unroll
-        for (int j = 0; j < VPL; ++j) d += x[j] * wg[(long)e * G + lane * VPL + j];
-        d = wave_sum(d);
+      for (int v4 = 0; v4 < VPL / 4; ++v4) {
+        const float4 ww = wp[v4];
+        d += x[4 * v4] * ww.x + x[4 * v4 + 1] * ww.y + x[4 * v4 + 2] * ww.z + x[4 * v4 + 3] * ww.w;
       }
-      logit[e] = d;
+      logit[e] = sum16(d);
     }
     float mx = logit[0];
 #pragma unroll
@@ -227,8 +285,8 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const T* __restrict__ g, 
     }
 #pragma unroll
     for (int e = 0; e < EMAX; ++e)
-      if (lane == e && e < E) gates[tok * E + e] = pr[e];
-    if (lane == 0) {
+      if (j == (e & 15) && e < E) gates[tok * E + e] = pr[e];
+    if (j == 0) {
       idx[tok] = best;
       gmax[tok] = bv;
       if (stats) { stats[tok * 2] = mean; stats[tok * 2 + 1] = rstd; }
@@ -236,41 +294,40 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const T* __restrict__ g, 
   }
 }
 
-template <typename T, int VPL, int EMAX>
+// backward: dlogits (softmax + l_aux), d(xn) = dlogits @ wg, LayerNorm backward -> dg; d_ln_w/d_ln_b accumulated per
+// lane; dlogits [P, E] written out for the router weight gradient (gate_dwg_kernel).
+template <typename T, int G, int EMAX>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ g, const float* __restrict__ ln_w,
                                                        const float* __restrict__ ln_b, const float* __restrict__ wg,
                                                        const float* __restrict__ gates, const int32_t* __restrict__ idx,
                                                        const float* __restrict__ d_gmax, const float* __restrict__ stats,
                                                        const int32_t* __restrict__ counts, const float* __restrict__ laux_coef,
                                                        int seg_tokens, int P, int E, T* __restrict__ dg,
-                                                       float* __restrict__ d_wg, float* __restrict__ d_ln_w,
+                                                       float* __restrict__ dlogits, float* __restrict__ d_ln_w,
                                                        float* __restrict__ d_ln_b) {
-  const int lane = threadIdx.x & 63;
-  const int G = VPL * 64;
-  const long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long nw = ((long)gridDim.x * blockDim.x) >> 6;
-  float w[VPL], b[VPL], aw[VPL], ab[VPL];
-  float awg[EMAX][VPL];
-#pragma unroll
-  for (int j = 0; j < VPL; ++j) {
-    w[j] = ln_w ? ln_w[lane * VPL + j] : 1.f;
-    b[j] = ln_b ? ln_b[lane * VPL + j] : 0.f;
-    aw[j] = 0.f;
-    ab[j] = 0.f;
+  using R = Row16<T, G>;
+  constexpr int VPL = R::VPL;
+  constexpr int LS = VPL + 4;
+  __shared__ float swg[EMAX * 16 * LS];
+  const int j = threadIdx.x & 15;
+  for (int t = threadIdx.x; t < EMAX * G; t += 256) {
+    const int e = t / G, r = t % G, jj = r / VPL, v = r % VPL;
+    swg[(e * 16 + jj) * LS + v] = e < E ? wg[(long)e * G + R::col(jj, v)] : 0.f;
   }
+  float w[VPL], aw[VPL], ab[VPL];
 #pragma unroll
-  for (int e = 0; e < EMAX; ++e)
-#pragma unroll
-    for (int j = 0; j < VPL; ++j) awg[e][j] = 0.f;
-
-  for (long tok = wid; tok < P; tok += nw) {
-    float x[VPL], xh[VPL], xn[VPL];
-    load_row<T, VPL>(g + tok * G, lane, x);
+  for (int v = 0; v < VPL; ++v) { w[v] = 1.f; aw[v] = 0.f; ab[v] = 0.f; }
+  if (ln_w) R::loadf(ln_w, j, w);
+  __syncthreads();
+  const long gid = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const long ngr = ((long)gridDim.x * 256) >> 4;
+  for (long tok = gid; tok < P; tok += ngr) {
+    float xh[VPL];
+    R::load(g + tok * G, j, xh);
     const float mean = ln_w ? stats[tok * 2] : 0.f, rstd = ln_w ? stats[tok * 2 + 1] : 1.f;
+    if (ln_w) {
 #pragma unroll
-    for (int j = 0; j < VPL; ++j) {
-      xh[j] = ln_w ? (x[j] - mean) * rstd : x[j];
-      xn[j] = ln_w ? xh[j] * w[j] + b[j] : x[j];
+      for (int v = 0; v < VPL; ++v) xh[v] = (xh[v] - mean) * rstd;
     }
     const int seg = (int)(tok / seg_tokens);
     const int my = idx[tok];
@@ -285,52 +342,97 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ g, 
     }
     float dxn[VPL];
 #pragma unroll
-    for (int j = 0; j < VPL; ++j) dxn[j] = 0.f;
+    for (int v = 0; v < VPL; ++v) dxn[v] = 0.f;
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) {
-      if (e < E) {
-        const float dl = pr[e] * (dp[e] - dot);  // softmax backward
+      const float dl = pr[e] * (dp[e] - dot);  // softmax backward
+      if (e < E && j == (e & 15)) dlogits[tok * E + e] = dl;
+      const float4* wp = (const float4*)(swg + (e * 16 + j) * LS);
 #pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          dxn[j] += dl * wg[(long)e * G + lane * VPL + j];
-          awg[e][j] += dl * xn[j];
-        }
+      for (int v4 = 0; v4 < VPL / 4; ++v4) {
+        const float4 ww = wp[v4];
+        dxn[4 * v4] += dl * ww.x; dxn[4 * v4 + 1] += dl * ww.y; dxn[4 * v4 + 2] += dl * ww.z; dxn[4 * v4 + 3] += dl * ww.w;
       }
     }
     float dx[VPL];
     if (ln_w) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int j = 0; j < VPL; ++j) {
-        const float dxh = dxn[j] * w[j];
+      for (int v = 0; v < VPL; ++v) {
+        const float dxh = dxn[v] * w[v];
         s1 += dxh;
-        s2 += dxh * xh[j];
-        aw[j] += dxn[j] * xh[j];
-        ab[j] += dxn[j];
+        s2 += dxh * xh[v];
+        aw[v] += dxn[v] * xh[v];
+        ab[v] += dxn[v];
       }
-      s1 = wave_sum(s1) / G;
-      s2 = wave_sum(s2) / G;
+      s1 = sum16(s1) * (1.f / G);
+      s2 = sum16(s2) * (1.f / G);
 #pragma unroll
-      for (int j = 0; j < VPL; ++j) dx[j] = rstd * (dxn[j] * w[j] - s1 - xh[j] * s2);
+      for (int v = 0; v < VPL; ++v) dx[v] = rstd * (dxn[v] * w[v] - s1 - xh[v] * s2);
     } else {
 #pragma unroll
-      for (int j = 0; j < VPL; ++j) dx[j] = dxn[j];
+      for (int v = 0; v < VPL; ++v) dx[v] = dxn[v];
     }
+    R::store(dg + tok * G, j, dx);
+  }
+  if (ln_w) {  // block-level reduction in LDS (16 row groups share each column), then one global atomic per column
+    __syncthreads();
+    float* red = swg;  // reuse: needs 2 * G floats <= EMAX * 16 * LS
+    for (int t = threadIdx.x; t < 2 * G; t += 256) red[t] = 0.f;
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < VPL; ++j) ElemIO<T>::st(dg + tok * G + lane * VPL + j, dx[j]);
+    for (int v = 0; v < VPL; ++v) {
+      atomicAdd(red + R::col(j, v), aw[v]);
+      atomicAdd(red + G + R::col(j, v), ab[v]);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < G; t += 256) {
+      unsafeAtomicAdd(d_ln_w + t, red[t]);
+      unsafeAtomicAdd(d_ln_b + t, red[G + t]);
+    }
+  }
+}
+
+// d_wg[e][c] += sum_tok dlogits[tok][e] * xn[tok][c]   (xn recomputed from g and the LayerNorm statistics)
+// block = G threads (one per column); a wave loads dlogits/stats of 64 tokens once (one token per lane) and
+// broadcasts them with v_readlane while every lane streams its own column of g.
+template <typename T, int E>
+__global__ void gate_dwg_kernel(const T* __restrict__ g, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                const float* __restrict__ stats, const float* __restrict__ dlogits, int P, int G,
+                                int tok_per_block, float* __restrict__ d_wg) {
+  const int c = threadIdx.x, lane = threadIdx.x & 63;
+  const float w = ln_w ? ln_w[c] : 1.f, b = ln_w ? ln_b[c] : 0.f;
+  float acc[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) acc[e] = 0.f;
+  const long t0 = (long)blockIdx.x * tok_per_block;
+  const long t1 = min((long)P, t0 + tok_per_block);
+  for (long tb = t0; tb < t1; tb += 64) {
+    const long mytok = min(tb + lane, (long)P - 1);
+    float dl[E], mu = 0.f, rs = 1.f;
+#pragma unroll
+    for (int e4 = 0; e4 < E / 4; ++e4) {
+      const float4 v = *(const float4*)(dlogits + mytok * E + e4 * 4);
+      dl[e4 * 4] = v.x; dl[e4 * 4 + 1] = v.y; dl[e4 * 4 + 2] = v.z; dl[e4 * 4 + 3] = v.w;
+    }
+    if (ln_w) { const float2 st = *(const float2*)(stats + mytok * 2); mu = st.x; rs = st.y; }
+    const int nt = (int)min(64L, t1 - tb);
+    float xv[64];
+#pragma unroll
+    for (int t = 0; t < 64; ++t)      // 64 independent loads in flight (rows past the end re-read the last row)
+      xv[t] = ElemIO<T>::ld(g + min(tb + t, (long)P - 1) * G + c);
+#pragma unroll
+    for (int t = 0; t < 64; ++t) {
+      float x = xv[t];
+      const float m_ = __shfl(mu, t, 64), r_ = __shfl(rs, t, 64);
+      if (ln_w) x = (x - m_) * r_ * w + b;
+      x = t < nt ? x : 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] += __shfl(dl[e], t, 64) * x;
+    }
   }
 #pragma unroll
-  for (int e = 0; e < EMAX; ++e)
-    if (e < E)
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) unsafeAtomicAdd(d_wg + (long)e * G + lane * VPL + j, awg[e][j]);
-  if (ln_w) {
-#pragma unroll
-    for (int j = 0; j < VPL; ++j) {
-      unsafeAtomicAdd(d_ln_w + lane * VPL + j, aw[j]);
-      unsafeAtomicAdd(d_ln_b + lane * VPL + j, ab[j]);
-    }
-  }
+  for (int e = 0; e < E; ++e) unsafeAtomicAdd(d_wg + (long)e * G + c, acc[e]);
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch / combine
@@ -393,136 +495,146 @@ __global__ __launch_bounds__(256) void sparse_kernel(const float* __restrict__ g
 }
 
 // combine backward (fast path): dy = dy_in + dsig * wsig; dy *= (y > 0); dgate = <y, dy> / gate; dout = dy * gate
-template <typename T>
+template <typename T, int H>
 __global__ __launch_bounds__(256) void combine_bwd_kernel(const T* __restrict__ dy_in, const T* __restrict__ y,
                                                           const float* __restrict__ dsig, const float* __restrict__ wsig,
-                                                          const float* __restrict__ gate, int P, int hidden,
-                                                          T* __restrict__ dout, float* __restrict__ dgate) {
-  const int lane = threadIdx.x & 63;
-  const long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long nw = ((long)gridDim.x * blockDim.x) >> 6;
-  constexpr int EPC = 16 / (int)sizeof(T);
-  const int cpr = hidden / EPC;
-  for (long i = wid; i < P; i += nw) {
+                                                          const float* __restrict__ gate, int P, T* __restrict__ dout,
+                                                          float* __restrict__ dgate) {
+  using R = Row16<T, H>;
+  constexpr int VPL = R::VPL;
+  const int j = threadIdx.x & 15;
+  float ws[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) ws[v] = 0.f;
+  if (wsig) R::loadf(wsig, j, ws);
+  const long gid = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const long ngr = ((long)gridDim.x * 256) >> 4;
+  for (long i = gid; i < P; i += ngr) {
     const float gt = gate[i];
     const float ds = dsig ? dsig[i] : 0.f;
-    float dot = 0.f;
-    for (int ch = lane; ch < cpr; ch += 64) {
-      const long off = i * hidden + ch * EPC;
-      float o[EPC];
+    float yv[VPL], d[VPL], dot = 0.f;
+    R::load(y + i * H, j, yv);
+    R::load(dy_in + i * H, j, d);
 #pragma unroll
-      for (int j = 0; j < EPC; ++j) {
-        const float yv = ElemIO<T>::ld(y + off + j);
-        float d = ElemIO<T>::ld(dy_in + off + j) + (wsig ? ds * wsig[ch * EPC + j] : 0.f);
-        d = yv > 0.f ? d : 0.f;
-        dot += yv * d;
-        o[j] = d * gt;
-      }
-#pragma unroll
-      for (int j = 0; j < EPC; ++j) ElemIO<T>::st(dout + off + j, o[j]);
+    for (int v = 0; v < VPL; ++v) {
+      float t = d[v] + ds * ws[v];
+      t = yv[v] > 0.f ? t : 0.f;
+      dot += yv[v] * t;
+      d[v] = t * gt;
     }
-    dot = wave_sum(dot);
-    if (lane == 0) dgate[i] = dot / gt;
+    R::store(dout + i * H, j, d);
+    dot = sum16(dot);
+    if (j == 0) dgate[i] = dot / gt;
   }
 }
 
 // ------------------------------------------------------------------------------------------------ heads
 // raw[i] = (sigmoid(h2 . Wc[c] + bc[c]) c<3, softplus(y . ws + bs + noise - 1))   models/nerf_moe.py:393-441
-template <typename T>
+template <typename T, int M, int H2>
 __global__ __launch_bounds__(256) void heads_fwd_kernel(const T* __restrict__ y, const T* __restrict__ h2,
                                                         const float* __restrict__ ws, const float* __restrict__ bs,
                                                         const float* __restrict__ wc, const float* __restrict__ bc,
-                                                        const float* __restrict__ noise, int P, int M, int H2,
-                                                        float* __restrict__ raw) {
-  const int lane = threadIdx.x & 63;
-  const long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long nw = ((long)gridDim.x * blockDim.x) >> 6;
-  for (long i = wid; i < P; i += nw) {
+                                                        const float* __restrict__ noise, int P, float* __restrict__ raw) {
+  using RY = Row16<T, M>;
+  using RH = Row16<T, H2>;
+  const int j = threadIdx.x & 15;
+  float wsv[RY::VPL], wcv[3][RH::VPL];
+  RY::loadf(ws, j, wsv);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) RH::loadf(wc + c * H2, j, wcv[c]);
+  const float b_s = bs[0], b0 = bc[0], b1 = bc[1], b2 = bc[2];
+  const long gid = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const long ngr = ((long)gridDim.x * 256) >> 4;
+  for (long i = gid; i < P; i += ngr) {
+    float yv[RY::VPL], hv[RH::VPL];
+    RY::load(y + i * M, j, yv);
+    RH::load(h2 + i * H2, j, hv);
     float s = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
-    for (int c = lane; c < M; c += 64) s += ElemIO<T>::ld(y + i * M + c) * ws[c];
-    for (int c = lane; c < H2; c += 64) {
-      const float h = ElemIO<T>::ld(h2 + i * H2 + c);
-      c0 += h * wc[c];
-      c1 += h * wc[H2 + c];
-      c2 += h * wc[2 * H2 + c];
-    }
-    s = wave_sum(s); c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
-    if (lane == 0) {
-      float u = s + bs[0] + (noise ? noise[i] : 0.f) - 1.f;  // ShiftedSoftplus, models/nerf.py:68-69
-      const float sp = u > 20.f ? u : log1pf(expf(u));
+#pragma unroll
+    for (int v = 0; v < RY::VPL; ++v) s += yv[v] * wsv[v];
+#pragma unroll
+    for (int v = 0; v < RH::VPL; ++v) { c0 += hv[v] * wcv[0][v]; c1 += hv[v] * wcv[1][v]; c2 += hv[v] * wcv[2][v]; }
+    s = sum16(s); c0 = sum16(c0); c1 = sum16(c1); c2 = sum16(c2);
+    if (j == 0) {
+      const float u = s + b_s + (noise ? noise[i] : 0.f) - 1.f;  // ShiftedSoftplus, models/nerf.py:68-69
       float4 o;
-      o.x = 1.f / (1.f + expf(-(c0 + bc[0])));
-      o.y = 1.f / (1.f + expf(-(c1 + bc[1])));
-      o.z = 1.f / (1.f + expf(-(c2 + bc[2])));
-      o.w = sp;
+      o.x = 1.f / (1.f + expf(-(c0 + b0)));
+      o.y = 1.f / (1.f + expf(-(c1 + b1)));
+      o.z = 1.f / (1.f + expf(-(c2 + b2)));
+      o.w = u > 20.f ? u : log1pf(expf(u));
       *(float4*)(raw + i * 4) = o;
     }
   }
 }
 
 // d_raw -> dh2 (masked by h2 > 0), dsig_pre; accumulates d_wc, d_bc, d_ws, d_bs.
-template <typename T>
+template <typename T, int M, int H2>
 __global__ __launch_bounds__(256) void heads_bwd_kernel(const T* __restrict__ y, const T* __restrict__ h2,
                                                         const float* __restrict__ wc, const float* __restrict__ raw,
-                                                        const float* __restrict__ d_raw, const float* __restrict__ pre_sig,
-                                                        int P, int M, int H2, T* __restrict__ dh2, float* __restrict__ dsig,
-                                                        float* __restrict__ d_ws, float* __restrict__ d_bs,
-                                                        float* __restrict__ d_wc, float* __restrict__ d_bc) {
-  const int lane = threadIdx.x & 63;
-  const long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long nw = ((long)gridDim.x * blockDim.x) >> 6;
-  // per-lane partial sums: d_ws for columns lane + 64*j (M <= 512), d_wc for columns lane + 64*j (H2 <= 256)
-  float aws[8], awc[3][4], abs_ = 0.f, abc[3] = {0.f, 0.f, 0.f};
+                                                        const float* __restrict__ d_raw, int P, T* __restrict__ dh2,
+                                                        float* __restrict__ dsig, float* __restrict__ d_ws,
+                                                        float* __restrict__ d_bs, float* __restrict__ d_wc,
+                                                        float* __restrict__ d_bc) {
+  using RY = Row16<T, M>;
+  using RH = Row16<T, H2>;
+  const int j = threadIdx.x & 15;
+  float wcv[3][RH::VPL], aws[RY::VPL], awc[3][RH::VPL], abs_ = 0.f, abc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-  for (int j = 0; j < 8; ++j) aws[j] = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    RH::loadf(wc + c * H2, j, wcv[c]);
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
+    for (int v = 0; v < RH::VPL; ++v) awc[c][v] = 0.f;
+  }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) awc[c][j] = 0.f;
-  for (long i = wid; i < P; i += nw) {
+  for (int v = 0; v < RY::VPL; ++v) aws[v] = 0.f;
+  const long gid = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const long ngr = ((long)gridDim.x * 256) >> 4;
+  for (long i = gid; i < P; i += ngr) {
     const float4 r = *(const float4*)(raw + i * 4);
     const float4 d = *(const float4*)(d_raw + i * 4);
     const float dc0 = d.x * r.x * (1.f - r.x), dc1 = d.y * r.y * (1.f - r.y), dc2 = d.z * r.z * (1.f - r.z);
     const float dsp = d.w * (1.f - expf(-r.w));  // softplus'(u) = sigmoid(u) = 1 - exp(-softplus(u))
-    (void)pre_sig;
-    if (lane == 0) dsig[i] = dsp;
-    abs_ += dsp;
-    abc[0] += dc0; abc[1] += dc1; abc[2] += dc2;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = lane + 64 * j;
-      if (c < M) aws[j] += dsp * ElemIO<T>::ld(y + i * M + c);
+    if (j == 0) {
+      dsig[i] = dsp;
+      abs_ += dsp; abc[0] += dc0; abc[1] += dc1; abc[2] += dc2;
     }
+    float yv[RY::VPL], hv[RH::VPL], o[RH::VPL];
+    RY::load(y + i * M, j, yv);
+    RH::load(h2 + i * H2, j, hv);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = lane + 64 * j;
-      if (c < H2) {
-        const float h = ElemIO<T>::ld(h2 + i * H2 + c);
-        awc[0][j] += dc0 * h; awc[1][j] += dc1 * h; awc[2][j] += dc2 * h;
-        const float g = dc0 * wc[c] + dc1 * wc[H2 + c] + dc2 * wc[2 * H2 + c];
-        ElemIO<T>::st(dh2 + i * H2 + c, h > 0.f ? g : 0.f);
-      }
+    for (int v = 0; v < RY::VPL; ++v) aws[v] += dsp * yv[v];
+#pragma unroll
+    for (int v = 0; v < RH::VPL; ++v) {
+      awc[0][v] += dc0 * hv[v]; awc[1][v] += dc1 * hv[v]; awc[2][v] += dc2 * hv[v];
+      const float gg = dc0 * wcv[0][v] + dc1 * wcv[1][v] + dc2 * wcv[2][v];
+      o[v] = hv[v] > 0.f ? gg : 0.f;
     }
+    RH::store(dh2 + i * H2, j, o);
   }
+  // block-level reduction in LDS, then one global atomic per parameter per block
+  __shared__ float red[M + 3 * H2 + 4];
+  for (int t = threadIdx.x; t < M + 3 * H2 + 4; t += 256) red[t] = 0.f;
+  __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = lane + 64 * j;
-    if (c < M) unsafeAtomicAdd(d_ws + c, aws[j]);
-  }
+  for (int v = 0; v < RY::VPL; ++v) atomicAdd(red + RY::col(j, v), aws[v]);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = lane + 64 * j;
-    if (c < H2) {
-      unsafeAtomicAdd(d_wc + c, awc[0][j]);
-      unsafeAtomicAdd(d_wc + H2 + c, awc[1][j]);
-      unsafeAtomicAdd(d_wc + 2 * H2 + c, awc[2][j]);
-    }
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int v = 0; v < RH::VPL; ++v) atomicAdd(red + M + c * H2 + RH::col(j, v), awc[c][v]);
+  if (j == 0) {
+    atomicAdd(red + M + 3 * H2 + 0, abs_);
+    atomicAdd(red + M + 3 * H2 + 1, abc[0]);
+    atomicAdd(red + M + 3 * H2 + 2, abc[1]);
+    atomicAdd(red + M + 3 * H2 + 3, abc[2]);
   }
-  if (lane == 0) {  // every lane accumulated the same per-token scalars; lane 0 publishes
-    unsafeAtomicAdd(d_bs, abs_);
-    unsafeAtomicAdd(d_bc + 0, abc[0]);
-    unsafeAtomicAdd(d_bc + 1, abc[1]);
-    unsafeAtomicAdd(d_bc + 2, abc[2]);
+  __syncthreads();
+  for (int t = threadIdx.x; t < M; t += 256) unsafeAtomicAdd(d_ws + t, red[t]);
+  for (int t = threadIdx.x; t < 3 * H2; t += 256) unsafeAtomicAdd(d_wc + t, red[M + t]);
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(d_bs, red[M + 3 * H2]);
+    unsafeAtomicAdd(d_bc + 0, red[M + 3 * H2 + 1]);
+    unsafeAtomicAdd(d_bc + 1, red[M + 3 * H2 + 2]);
+    unsafeAtomicAdd(d_bc + 2, red[M + 3 * H2 + 3]);
   }
 }
 
@@ -752,24 +864,30 @@ extern "C" int swn_sample_pe(const float* rays, const float* t_steps, const floa
 
 #define GATE_DISPATCH(T, KERNEL, ...)                                                                        \
   do {                                                                                                       \
-    const int vpl = gate_dim / 64;                                                                           \
     const bool e8 = n_experts <= 8;                                                                          \
-    if (vpl == 4 && e8) hipLaunchKernelGGL((KERNEL<T, 4, 8>), __VA_ARGS__);                                  \
-    else if (vpl == 4) hipLaunchKernelGGL((KERNEL<T, 4, 16>), __VA_ARGS__);                                  \
-    else if (vpl == 1 && e8) hipLaunchKernelGGL((KERNEL<T, 1, 8>), __VA_ARGS__);                             \
-    else if (vpl == 8) hipLaunchKernelGGL((KERNEL<T, 8, 16>), __VA_ARGS__);                                  \
+    if (gate_dim == 256 && e8) hipLaunchKernelGGL((KERNEL<T, 256, 8>), __VA_ARGS__);                         \
+    else if (gate_dim == 256) hipLaunchKernelGGL((KERNEL<T, 256, 16>), __VA_ARGS__);                         \
+    else if (gate_dim == 128 && e8) hipLaunchKernelGGL((KERNEL<T, 128, 8>), __VA_ARGS__);                    \
+    else if (gate_dim == 512) hipLaunchKernelGGL((KERNEL<T, 512, 16>), __VA_ARGS__);                         \
     else return swn::set_error("gate: unsupported gate_dim %d / experts %d", gate_dim, n_experts);          \
   } while (0)
+
+static inline int row_blocks(long rows) {   // 16 rows per 256-thread block iteration
+  long b = (rows + 15) / 16;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
 
 extern "C" int swn_gate_fwd(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg,
                             int n_tokens, int gate_dim, int n_experts, float* gates, int32_t* idx, float* gmax,
                             float* stats, void* stream) {
   SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_gate_fwd: bad dtype");
   SWN_CHECK(g && wg && gates && idx && gmax, "swn_gate_fwd: null pointer");
-  SWN_CHECK(gate_dim % 64 == 0 && n_experts >= 1 && n_experts <= 16, "swn_gate_fwd: gate_dim %% 64, experts <= 16");
+  SWN_CHECK(n_experts >= 1 && n_experts <= 16, "swn_gate_fwd: experts <= 16");
   SWN_CHECK((ln_w == nullptr) == (ln_b == nullptr), "swn_gate_fwd: ln_w / ln_b must both be given or both NULL");
   if (ln_w) SWN_CHECK(stats, "swn_gate_fwd: stats required with LayerNorm");
-  const int blocks = ew_blocks(n_tokens);
+  const int blocks = row_blocks(n_tokens);
   if (dtype == SWN_BF16) {
     const bf16_t* gp = (const bf16_t*)g;
     GATE_DISPATCH(bf16_t, gate_fwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, n_tokens, n_experts,
@@ -786,23 +904,45 @@ extern "C" int swn_gate_fwd(const void* g, int dtype, const float* ln_w, const f
 extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg,
                             const float* gates, const int32_t* idx, const float* d_gmax, const float* stats,
                             const int32_t* counts, const float* laux_coef, int seg_tokens, int n_tokens, int gate_dim,
-                            int n_experts, void* dg, float* d_wg, float* d_ln_w, float* d_ln_b, void* stream) {
+                            int n_experts, void* dg, float* dlogits, float* d_wg, float* d_ln_w, float* d_ln_b, void* stream) {
   SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_gate_bwd: bad dtype");
-  SWN_CHECK(g && wg && gates && idx && dg && d_wg && counts, "swn_gate_bwd: null pointer");
-  SWN_CHECK(gate_dim % 64 == 0 && n_experts >= 1 && n_experts <= 16 && seg_tokens > 0, "swn_gate_bwd: bad sizes");
+  SWN_CHECK(g && wg && gates && idx && dg && d_wg && counts && dlogits, "swn_gate_bwd: null pointer");
+  SWN_CHECK(n_experts >= 1 && n_experts <= 16 && seg_tokens > 0, "swn_gate_bwd: bad sizes");
   if (ln_w) SWN_CHECK(stats && d_ln_w && d_ln_b && ln_b, "swn_gate_bwd: LayerNorm buffers missing");
-  int blocks = ew_blocks(n_tokens);
-  if (blocks > 1024) blocks = 1024;  // each wave publishes E*G atomics at the end
+  int blocks = row_blocks(n_tokens);
+  if (blocks > 2048) blocks = 2048;
+  const int tpb = 4096;
+  const int dwg_blocks = cdiv(n_tokens, tpb);
   if (dtype == SWN_BF16) {
     const bf16_t* gp = (const bf16_t*)g;
     bf16_t* dgp = (bf16_t*)dg;
     GATE_DISPATCH(bf16_t, gate_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, gates, idx, d_gmax,
-                  stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dgp, d_wg, d_ln_w, d_ln_b);
+                  stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dgp, dlogits, d_ln_w, d_ln_b);
+    SWN_CHECK(n_experts == 4 || n_experts == 8 || n_experts == 16, "swn_gate_bwd: experts must be 4, 8 or 16");
+    if (n_experts == 8)
+      hipLaunchKernelGGL((gate_dwg_kernel<bf16_t, 8>), dim3(dwg_blocks), dim3(gate_dim), 0, as_stream(stream), gp, ln_w, ln_b, stats,
+                         dlogits, n_tokens, gate_dim, tpb, d_wg);
+    else if (n_experts == 16)
+      hipLaunchKernelGGL((gate_dwg_kernel<bf16_t, 16>), dim3(dwg_blocks), dim3(gate_dim), 0, as_stream(stream), gp, ln_w, ln_b, stats,
+                         dlogits, n_tokens, gate_dim, tpb, d_wg);
+    else
+      hipLaunchKernelGGL((gate_dwg_kernel<bf16_t, 4>), dim3(dwg_blocks), dim3(gate_dim), 0, as_stream(stream), gp, ln_w, ln_b, stats,
+                         dlogits, n_tokens, gate_dim, tpb, d_wg);
   } else {
     const float* gp = (const float*)g;
     float* dgp = (float*)dg;
     GATE_DISPATCH(float, gate_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, gates, idx, d_gmax,
-                  stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dgp, d_wg, d_ln_w, d_ln_b);
+                  stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dgp, dlogits, d_ln_w, d_ln_b);
+    SWN_CHECK(n_experts == 4 || n_experts == 8 || n_experts == 16, "swn_gate_bwd: experts must be 4, 8 or 16");
+    if (n_experts == 8)
+      hipLaunchKernelGGL((gate_dwg_kernel<float, 8>), dim3(dwg_blocks), dim3(gate_dim), 0, as_stream(stream), gp, ln_w, ln_b, stats,
+                         dlogits, n_tokens, gate_dim, tpb, d_wg);
+    else if (n_experts == 16)
+      hipLaunchKernelGGL((gate_dwg_kernel<float, 16>), dim3(dwg_blocks), dim3(gate_dim), 0, as_stream(stream), gp, ln_w, ln_b, stats,
+                         dlogits, n_tokens, gate_dim, tpb, d_wg);
+    else
+      hipLaunchKernelGGL((gate_dwg_kernel<float, 4>), dim3(dwg_blocks), dim3(gate_dim), 0, as_stream(stream), gp, ln_w, ln_b, stats,
+                         dlogits, n_tokens, gate_dim, tpb, d_wg);
   }
   SWN_LAUNCH_CHECK();
   return 0;
@@ -862,13 +1002,13 @@ extern "C" int swn_combine_bwd(const void* dy_in, const void* y, const float* ds
                                int dtype, int samples, int hidden, void* dout, float* dgate, void* stream) {
   SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_combine_bwd: bad dtype");
   SWN_CHECK(dy_in && y && gate && dout && dgate, "swn_combine_bwd: null pointer");
-  const int blocks = ew_blocks(samples);
-  if (dtype == SWN_BF16)
-    hipLaunchKernelGGL((combine_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, as_stream(stream), (const bf16_t*)dy_in,
-                       (const bf16_t*)y, dsig, wsig, gate, samples, hidden, (bf16_t*)dout, dgate);
-  else
-    hipLaunchKernelGGL((combine_bwd_kernel<float>), dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)dy_in,
-                       (const float*)y, dsig, wsig, gate, samples, hidden, (float*)dout, dgate);
+  SWN_CHECK(hidden == 256 || hidden == 128 || hidden == 512, "swn_combine_bwd: hidden must be 128, 256 or 512");
+  int blocks = row_blocks(samples);
+#define SWN_CB(T, H) hipLaunchKernelGGL((combine_bwd_kernel<T, H>), dim3(blocks), dim3(256), 0, as_stream(stream), (const T*)dy_in, \
+                                        (const T*)y, dsig, wsig, gate, samples, (T*)dout, dgate)
+  if (dtype == SWN_BF16) { if (hidden == 256) SWN_CB(bf16_t, 256); else if (hidden == 128) SWN_CB(bf16_t, 128); else SWN_CB(bf16_t, 512); }
+  else { if (hidden == 256) SWN_CB(float, 256); else if (hidden == 128) SWN_CB(float, 128); else SWN_CB(float, 512); }
+#undef SWN_CB
   SWN_LAUNCH_CHECK();
   return 0;
 }
@@ -878,13 +1018,18 @@ extern "C" int swn_heads_fwd(const void* y, const void* h2, int dtype, const flo
                              int model_dim, int h2_dim, float* raw, void* stream) {
   SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_heads_fwd: bad dtype");
   SWN_CHECK(y && h2 && w_sigma && b_sigma && w_color && b_color && raw, "swn_heads_fwd: null pointer");
-  const int blocks = ew_blocks(n_points);
-  if (dtype == SWN_BF16)
-    hipLaunchKernelGGL((heads_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, as_stream(stream), (const bf16_t*)y,
-                       (const bf16_t*)h2, w_sigma, b_sigma, w_color, b_color, sigma_noise, n_points, model_dim, h2_dim, raw);
-  else
-    hipLaunchKernelGGL((heads_fwd_kernel<float>), dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)y,
-                       (const float*)h2, w_sigma, b_sigma, w_color, b_color, sigma_noise, n_points, model_dim, h2_dim, raw);
+  SWN_CHECK((model_dim == 256 || model_dim == 512) && (h2_dim == 128 || h2_dim == 256), "swn_heads_fwd: model_dim in {256,512}, h2_dim in {128,256}");
+  const int blocks = row_blocks(n_points);
+#define SWN_HF(T, M_, H_) hipLaunchKernelGGL((heads_fwd_kernel<T, M_, H_>), dim3(blocks), dim3(256), 0, as_stream(stream), (const T*)y, \
+                                             (const T*)h2, w_sigma, b_sigma, w_color, b_color, sigma_noise, n_points, raw)
+  if (dtype == SWN_BF16) {
+    if (model_dim == 256 && h2_dim == 128) SWN_HF(bf16_t, 256, 128); else if (model_dim == 512 && h2_dim == 256) SWN_HF(bf16_t, 512, 256);
+    else if (model_dim == 256) SWN_HF(bf16_t, 256, 256); else SWN_HF(bf16_t, 512, 128);
+  } else {
+    if (model_dim == 256 && h2_dim == 128) SWN_HF(float, 256, 128); else if (model_dim == 512 && h2_dim == 256) SWN_HF(float, 512, 256);
+    else if (model_dim == 256) SWN_HF(float, 256, 256); else SWN_HF(float, 512, 128);
+  }
+#undef SWN_HF
   SWN_LAUNCH_CHECK();
   return 0;
 }
@@ -895,17 +1040,19 @@ extern "C" int swn_heads_bwd(const void* y, const void* h2, int dtype, const flo
   SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_heads_bwd: bad dtype");
   SWN_CHECK(y && h2 && w_color && raw && d_raw && dh2 && dsig && d_w_sigma && d_b_sigma && d_w_color && d_b_color,
             "swn_heads_bwd: null pointer");
-  SWN_CHECK(model_dim <= 512 && h2_dim <= 256, "swn_heads_bwd: model_dim <= 512, h2_dim <= 256");
-  int blocks = ew_blocks(n_points);
+  SWN_CHECK((model_dim == 256 || model_dim == 512) && (h2_dim == 128 || h2_dim == 256), "swn_heads_bwd: model_dim in {256,512}, h2_dim in {128,256}");
+  int blocks = row_blocks(n_points);
   if (blocks > 1024) blocks = 1024;
-  if (dtype == SWN_BF16)
-    hipLaunchKernelGGL((heads_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, as_stream(stream), (const bf16_t*)y,
-                       (const bf16_t*)h2, w_color, raw, d_raw, nullptr, n_points, model_dim, h2_dim, (bf16_t*)dh2, dsig,
-                       d_w_sigma, d_b_sigma, d_w_color, d_b_color);
-  else
-    hipLaunchKernelGGL((heads_bwd_kernel<float>), dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)y,
-                       (const float*)h2, w_color, raw, d_raw, nullptr, n_points, model_dim, h2_dim, (float*)dh2, dsig,
-                       d_w_sigma, d_b_sigma, d_w_color, d_b_color);
+#define SWN_HB(T, M_, H_) hipLaunchKernelGGL((heads_bwd_kernel<T, M_, H_>), dim3(blocks), dim3(256), 0, as_stream(stream), (const T*)y, \
+                                             (const T*)h2, w_color, raw, d_raw, n_points, (T*)dh2, dsig, d_w_sigma, d_b_sigma, d_w_color, d_b_color)
+  if (dtype == SWN_BF16) {
+    if (model_dim == 256 && h2_dim == 128) SWN_HB(bf16_t, 256, 128); else if (model_dim == 512 && h2_dim == 256) SWN_HB(bf16_t, 512, 256);
+    else if (model_dim == 256) SWN_HB(bf16_t, 256, 256); else SWN_HB(bf16_t, 512, 128);
+  } else {
+    if (model_dim == 256 && h2_dim == 128) SWN_HB(float, 256, 128); else if (model_dim == 512 && h2_dim == 256) SWN_HB(float, 512, 256);
+    else if (model_dim == 256) SWN_HB(float, 256, 256); else SWN_HB(float, 512, 128);
+  }
+#undef SWN_HB
   SWN_LAUNCH_CHECK();
   return 0;
 }

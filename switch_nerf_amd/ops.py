@@ -71,8 +71,9 @@ def gate_bwd(g, ln_w, ln_b, wg, gates, idx, d_gmax, stats, counts, laux_coef, se
     P, G = g.shape
     E = wg.shape[0]
     dg = torch.empty_like(g)
+    dlogits = torch.empty(P, E, dtype=torch.float32, device=g.device)
     call("swn_gate_bwd", _p(g), _dt(g), _p(ln_w), _p(ln_b), _p(wg), _p(gates), _p(idx), _p(d_gmax), _p(stats), _p(counts),
-         _p(laux_coef), int(seg_tokens), P, G, E, _p(dg), _p(d_wg), _p(d_ln_w), _p(d_ln_b), _stream())
+         _p(laux_coef), int(seg_tokens), P, G, E, _p(dg), _p(dlogits), _p(d_wg), _p(d_ln_w), _p(d_ln_b), _stream())
     return dg
 
 
