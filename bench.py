@@ -87,8 +87,8 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        from switch_nerf_amd import parallel
+        parallel.init_from_env("nccl", dev)
 
     from switch_nerf_amd.model import SwitchNeRF, BUILDING
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -98,9 +98,8 @@ def main():
     rays, idx, rgbs = synth_batch(a.rays, 1000 + rank, dev)
     P = a.rays * a.samples
 
-    def allreduce(flat_grad):
-        dist.all_reduce(flat_grad)           # RCCL ring over xGMI, one 16 MB bucket
-        return 1.0 / world
+    if world > 1:
+        allreduce = parallel.make_grad_allreduce()     # RCCL all-reduce over xGMI, one 16 MB bucket
 
     def step():
         pr = torch.rand(a.rays, a.samples, device=dev)              # rendering.py:582 rand_like
