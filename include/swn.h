@@ -131,21 +131,22 @@ int swn_composite_bwd(const float* raw, const float* z, float last_delta, const 
 
 /* ---- dense / grouped MLP chains on MFMA ------------------------------------------------------------------------
  * One launch runs `n_layers` (<= 8) Linear layers back to back with the activations of a 128-row tile resident in
- * LDS.  Layer l: h <- act_l( h @ W_l^T + b_l [+ rowbias[row/rows_per_bias]] [+ skip] ).  W_l is [N_l][K_l] with K
- * contiguous (torch.nn.Linear.weight layout) in `dtype`; b_l fp32.  Ragged groups: rows of group g are
+ * LDS.  Layer l: h <- act_l( h @ W_l^T + b_l [+ rowbias[row/rows_per_bias]] [+ skip] ).  W_l (logically [N_l][K_l],
+ * torch.nn.Linear.weight orientation) must be given in the MFMA-fragment-major layout produced by swn_pack_weights
+ * (compute dtype); b_l fp32.  Ragged groups: rows of group g are
  * [g*group_stride, g*group_stride + group_rows[g]) and group g uses weight set g % n_wsets
  * (expert MLP: group = (segment, expert), n_wsets = E).
  * replaces ExpertMLP.forward (tutel_moe_layer_nobatch.py:887-924: baddbmm chain, skip, ReLU) and Mlp.forward
  * (models/nerf_moe.py:30-49).  Details of the descriptor: see swn_chain_desc below.                             */
 typedef struct swn_chain_layer {
-  const void* w;        /* [n_wsets][N][K] dtype                                   */
+  const void* w;        /* [n_wsets] x packed(N, K) in dtype: output of swn_pack_weights */
   const float* b;       /* [n_wsets][N] f32 or NULL                                */
   void* save;           /* row-major [rows_total][N] dtype: output of this layer (post activation) or NULL */
   uint32_t* mask;       /* packed ReLU mask: written when relu==1, read when relu==2; size =
                            n_workgroups * 8 waves * MI * 64 uint32 (MI = 2 bf16 / 1 fp32), or NULL */
   const float* rowbias; /* f32 [n_rows / rows_per_bias][N] extra bias shared by runs of rows (per-ray terms) or NULL */
   int32_t rows_per_bias;
-  int32_t n, k;         /* output / input features: n multiple of 32, k multiple of 64 (bf16) / 32 (fp32), <= 256 */
+  int32_t n, k;         /* output / input features: n in {64,128,192,256}, k in {64,128,256}               */
   int32_t relu;         /* 0 none; 1 ReLU (and record the mask if given); 2 multiply by the recorded mask (backward) */
   int32_t skip;         /* add the chain input x before the activation (needs n == layers[0].k) */
 } swn_chain_layer;
@@ -168,6 +169,14 @@ typedef struct swn_chain_desc {
 } swn_chain_desc;
 
 int swn_mlp_chain(const swn_chain_desc* desc, void* stream);
+
+/* Pack fp32 master weights [n_wsets][in_dim][out_dim] (the reference's ExpertMLP layout, tutel_moe_layer_nobatch.py:853)
+ * into the compute copy swn_mlp_chain consumes.  transpose = 1: forward weights (N = out, K = in);
+ * transpose = 0: backward-data weights (N = in, K = out).  Output: n_wsets * in_dim * out_dim elements of dtype,
+ * ordered [wset][N/32][K/16][64 lanes][8] (bf16) or [wset][N/32][K/8][64 lanes][4] (fp32) so that one MFMA operand
+ * fragment is one contiguous 1 KiB wave load.                                                                     */
+int swn_pack_weights(const float* master, void* out, int dtype, int n_wsets, int in_dim, int out_dim, int transpose,
+                     void* stream);
 
 /* Grouped weight gradient: for every group g, dW[g % n_wsets] += A_g^T @ B_g (fp32 atomics), and optionally
  * db += column sums of B_g.  A[rows, m_dim], B[rows, n_dim] row-major dtype; dW [n_wsets][m_dim][n_dim] f32.

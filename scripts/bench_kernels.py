@@ -22,7 +22,7 @@ def timeit(fn, reps=5):
 h0 = torch.randn(ROWS, M, device=dev).to(dt)
 perm = torch.randperm(ROWS, device=dev).int()
 counts = torch.full((NG,), CAP, dtype=torch.int32, device=dev)
-W = [torch.randn(E, M, M, device=dev).mul_(1 / 16).to(dt) for _ in range(8)]
+W = [o.pack_weights(torch.randn(E, M, M, device=dev).mul_(1 / 16), dt, True) for _ in range(8)]
 B = [torch.randn(E, M, device=dev).mul_(0.1) for _ in range(8)]
 saves = [torch.empty(ROWS, M, dtype=dt, device=dev) for _ in range(8)]
 nw = o.chain_mask_words(dt, NG, CAP)

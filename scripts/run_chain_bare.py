@@ -5,7 +5,7 @@ dev = torch.device('cuda'); dt = torch.bfloat16
 E, M, CAP, NSEG = 8, 256, 16384, 16
 NG = NSEG * E; ROWS = NG * CAP
 h0 = torch.randn(ROWS, M, device=dev).to(dt)
-W = [torch.randn(E, M, M, device=dev).mul_(1 / 16).to(dt) for _ in range(8)]
+W = [o.pack_weights(torch.randn(E, M, M, device=dev).mul_(1 / 16), dt, True) for _ in range(8)]
 y = torch.empty(ROWS, M, dtype=dt, device=dev)
 layers = [o.Layer(W[l], None) for l in range(8)]
 for _ in range(3):

@@ -4,44 +4,46 @@
 // a baddbmm per layer with activations round-tripping HBM) and Mlp.forward (models/nerf_moe.py:30-49), and - run
 // with transposed weights and the stored ReLU masks - their backward-data passes.
 //
-// Geometry (one workgroup = 512 threads = 8 waves = 2 (rows) x 4 (features)):
-//   bf16: 128-row tile, v_mfma_f32_32x32x16_bf16, weight K-slices of 64 streamed L2 -> regs -> LDS (double buffer)
-//   fp32:  64-row tile, v_mfma_f32_32x32x2_f32 (exact fp32 fma chain; the parity mode)
-// The MFMA is issued "transposed": the weight fragment is the A operand and the activation fragment the B
-// operand, so a lane ends up with 4 consecutive output FEATURES of one row (D[i=feature][j=row]); the epilogue
-// can then pack them and write the next layer's input tile row-major with 8-byte LDS stores.
-// LDS: activation tile 64 KiB (XOR-swizzled 16-B chunks so the 32 rows of a fragment read hit distinct banks)
-//      + 2 x 32 KiB weight slices  = 128 KiB  -> one workgroup per CU, two waves per SIMD.
+// Geometry: one workgroup = 256 threads = 4 waves; wave w owns output features [64 w, 64 w + 64) of ALL rows of the
+// tile (bf16: 128 rows = 4 x 2 MFMA tiles of 32x32, 128 accumulator VGPRs; fp32 parity mode: 64 rows).
+//   * activations: one tile in LDS (64 KiB, 16-byte chunks XOR-swizzled with row&15 -> conflict-free fragment reads);
+//   * weights: never touch LDS.  They are pre-packed (swn_pack_weights) in MFMA-fragment-major order, so that the
+//     fragment of (32 features x 16 k) is one contiguous, fully coalesced 1 KiB wave load straight into registers; a
+//     4-step register ring keeps the next fragments in flight (also across the layer boundary), served by L1/L2
+//     (an expert's 7 layers = 0.9 MB stay in the XCD's L2: workgroup b uses expert b % 8 = its XCD);
+//   * the K loop therefore has NO barrier; a layer costs two workgroup barriers (before / after the epilogue rewrites
+//     the LDS tile).  65 KiB of LDS per workgroup -> two workgroups per CU overlap each other's epilogues/write-outs.
+// The MFMA is issued "transposed" (weight fragment = A operand, activation fragment = B operand): a lane ends up
+// with 4 consecutive output FEATURES of one row, so the epilogue packs them and writes the next layer's input tile
+// row-major with 8-byte LDS stores.
 #include "common.hpp"
 
 namespace swn {
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-constexpr int NT = 512;         // threads per workgroup
-constexpr int WN = 4;           // waves along features
-constexpr int NI = 2;           // 32-wide feature tiles per wave (4 * 2 * 32 = 256 = max features)
+constexpr int NT = 256;         // threads per workgroup (4 waves)
+constexpr int NI = 2;           // 32-wide feature tiles per wave (4 waves * 2 * 32 = 256 = max features)
 constexpr int ACT_BYTES = 65536;
-constexpr int WBUF_BYTES = 32768;
+constexpr int RING = 4;         // weight-fragment steps in flight
 
 template <typename T> struct Cfg;
 template <> struct Cfg<bf16_t> {
-  static constexpr int BM = 128, BK = 64, MI = 2;
+  static constexpr int BM = 128, MI = 4, KSTEP = 16;   // one ring step = K 16: one 16-byte fragment load per feature tile
+  typedef bf16x8_t wfrag_t;
 };
 template <> struct Cfg<float> {
-  static constexpr int BM = 64, BK = 32, MI = 1;
+  static constexpr int BM = 64, MI = 2, KSTEP = 8;     // one ring step = K 8: a float4 feeds four 32x32x2 MFMAs
+  typedef f32x4_t wfrag_t;
 };
 
-// ---- LDS addressing ---------------------------------------------------------------------------------------------
-// activation tile: row-major, row stride 256 elements.
+// ---- LDS addressing: activation tile, row-major, row stride 256 elements -------------------------------------
 __device__ __forceinline__ int act_off(bf16_t*, int row, int col) {  // byte offset of element (row, col)
   return row * 512 + ((((col >> 3) ^ (row & 15))) << 4) + ((col & 7) << 1);
 }
 __device__ __forceinline__ int act_off(float*, int row, int col) { return row * 1024 + ((col ^ (row & 31)) << 2); }
-// weight slice: [n][BK] with k contiguous (128 B per n-row for both dtypes)
-__device__ __forceinline__ int w_off_chunk(bf16_t*, int n, int kc) { return n * 128 + ((kc ^ ((n >> 1) & 7)) << 4); }
-__device__ __forceinline__ int w_off_word(int n, int k) { return (n * 32 + (k ^ (n & 31))) << 2; }
 
 struct ChainArgs {
   swn_chain_desc d;
@@ -139,19 +141,71 @@ __device__ __forceinline__ void load_rows_to_lds(char* dst, const void* src, con
   }
 }
 
+// ---- the K loop of one layer ----------------------------------------------------------------------------------
+// ring[r][ni] holds the weight fragments of step r of this layer on entry (r < RING); on exit it holds the first RING
+// steps of the next layer (prefetched while the last steps of this one run).
+// wcur / wnxt: this wave's fragment streams: [tile ni][step][lane][16 B]; tile stride = steps * 1 KiB.
+template <typename T, int NSTEPS>
+__device__ __forceinline__ void k_loop(f32x16_t (&acc)[Cfg<T>::MI][NI], typename Cfg<T>::wfrag_t (&ring)[RING][NI],
+                                       const char* act, const int (&aoff)[16], const char* wcur, const char* wnxt,
+                                       int nxt_steps, int lane) {
+  constexpr int MI = Cfg<T>::MI;
+  typedef typename Cfg<T>::wfrag_t wfrag_t;
+  const size_t ts_n = (size_t)nxt_steps * 1024;
+#pragma unroll
+  for (int ks = 0; ks < NSTEPS; ++ks) {
+    const int r = ks % RING;
+    const wfrag_t w0 = ring[r][0], w1 = ring[r][1];
+    {  // refill the slot with step ks + RING of this layer, else step (ks + RING - NSTEPS) of the next layer
+      constexpr size_t ts_c = (size_t)NSTEPS * 1024;
+      const int nx = ks + RING;
+      if (nx < NSTEPS) {
+        ring[r][0] = *(const wfrag_t*)(wcur + (size_t)nx * 1024 + lane * 16);
+        ring[r][1] = *(const wfrag_t*)(wcur + ts_c + (size_t)nx * 1024 + lane * 16);
+      } else {   // wnxt is a valid stream even at the end of the chain (re-read, discarded)
+        ring[r][0] = *(const wfrag_t*)(wnxt + (size_t)(nx - NSTEPS) * 1024 + lane * 16);
+        ring[r][1] = *(const wfrag_t*)(wnxt + ts_n + (size_t)(nx - NSTEPS) * 1024 + lane * 16);
+      }
+    }
+    if constexpr (sizeof(T) == 2) {
+      bf16x8_t af[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        af[mi] = *(const bf16x8_t*)(act + aoff[ks & 7] + mi * 16384 + (ks >> 3) * 256);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, af[mi], acc[mi][0], 0, 0, 0);
+        acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, af[mi], acc[mi][1], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float af[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          af[mi] = *(const float*)(act + aoff[(ks & 3) * 4 + j] + mi * 32768 + (ks >> 2) * 128);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j], af[mi], acc[mi][0], 0, 0, 0);
+          acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[j], af[mi], acc[mi][1], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
 template <typename T, int TAG>
-__global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
+__global__ __launch_bounds__(NT, 2) void chain_kernel(const ChainArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BM = Cfg<T>::BM, BK = Cfg<T>::BK, MI = Cfg<T>::MI;
+  constexpr int BM = Cfg<T>::BM, MI = Cfg<T>::MI, KSTEP = Cfg<T>::KSTEP;
+  typedef typename Cfg<T>::wfrag_t wfrag_t;
   const swn_chain_desc& d = args.d;
   char* act = smem;
-  char* wbuf = smem + ACT_BYTES;  // 2 x WBUF_BYTES; also reused as a second activation-layout tile (skip input)
-  char* bias_lds = smem + ACT_BYTES + 2 * WBUF_BYTES;  // 1 KiB
+  char* bias_lds = smem + ACT_BYTES;  // 1 KiB
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave = feature slab
   const int l31 = lane & 31, lhi = lane >> 5;
 
   const int g = blockIdx.x % d.n_groups;
@@ -165,81 +219,57 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
   const long grow0 = (long)g * d.group_stride + row0;
   const int wset = g % d.n_wsets;
 
-  // ---- stage the chain input ----
-  load_rows_to_lds<T>(act, d.x, d.x_gather, d.x_save, grow0, rows_in_tile, d.layers[0].k, tid);
-  __syncthreads();
+  // per-lane LDS byte offsets of the activation fragments (the swizzle makes them non-affine in k: 8 (bf16) / 16
+  // (fp32) distinct values; everything else is an immediate offset)
+  int aoff[16];
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) aoff[q] = l31 * 512 + (((2 * q + lhi) ^ (l31 & 15)) << 4);
+#pragma unroll
+    for (int q = 8; q < 16; ++q) aoff[q] = 0;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) aoff[q] = l31 * 1024 + ((((q >> 2) * 8 + 2 * (q & 3) + lhi) ^ l31) << 2);
+  }
 
-  f32x16_t acc[MI][NI];
-
-  // Weight K-slices travel global -> registers (W4, named members so they stay in VGPRs) -> LDS.  The loads for the
-  // next slice are issued before the MFMAs of the current one and consumed after them; at a layer boundary the
-  // "next slice" is slice 0 of the next layer (cross-layer prefetch), parked in registers across the epilogue.
-  struct W4 { uint4 a, b, c, e; };
-  auto gload = [&](const char* wgp, int n_, int k_, int s_) -> W4 {
-    W4 r;
-    const size_t kb = (size_t)s_ * BK;
-    const int n1 = n_ - 1;
-    r.a = *(const uint4*)(wgp + ((size_t)min((tid + NT * 0) >> 3, n1) * k_ + kb) * sizeof(T) + (tid & 7) * 16);
-    r.b = *(const uint4*)(wgp + ((size_t)min((tid + NT * 1) >> 3, n1) * k_ + kb) * sizeof(T) + (tid & 7) * 16);
-    r.c = *(const uint4*)(wgp + ((size_t)min((tid + NT * 2) >> 3, n1) * k_ + kb) * sizeof(T) + (tid & 7) * 16);
-    r.e = *(const uint4*)(wgp + ((size_t)min((tid + NT * 3) >> 3, n1) * k_ + kb) * sizeof(T) + (tid & 7) * 16);
-    return r;
-  };
-  auto lstore1 = [&](char* wb, int c, uint4 v) {
-    const int nrow = c >> 3, kc = c & 7;
-    if constexpr (sizeof(T) == 2) {
-      *(uint4*)(wb + w_off_chunk((bf16_t*)nullptr, nrow, kc)) = v;
-    } else {
-      *(uint32_t*)(wb + w_off_word(nrow, kc * 4 + 0)) = v.x;
-      *(uint32_t*)(wb + w_off_word(nrow, kc * 4 + 1)) = v.y;
-      *(uint32_t*)(wb + w_off_word(nrow, kc * 4 + 2)) = v.z;
-      *(uint32_t*)(wb + w_off_word(nrow, kc * 4 + 3)) = v.w;
-    }
-  };
-  auto lstore = [&](char* wb, const W4& r) {
-    lstore1(wb, tid + NT * 0, r.a);
-    lstore1(wb, tid + NT * 1, r.b);
-    lstore1(wb, tid + NT * 2, r.c);
-    lstore1(wb, tid + NT * 3, r.e);
-  };
-  auto wptr = [&](int L_) -> const char* {
-    return (const char*)d.layers[L_].w + (size_t)wset * d.layers[L_].n * d.layers[L_].k * sizeof(T);
+  // this wave's weight-fragment stream of layer L: [feature tile (2 wn + ni)][step][lane][16 B]
+  auto wstream = [&](int L_) -> const char* {
+    const swn_chain_layer& q = d.layers[L_];
+    const size_t steps = q.k / KSTEP;
+    const int nt0 = min(2 * wn, q.n / 32 - 2);      // waves beyond the layer width read valid tiles and discard
+    return (const char*)q.w + ((size_t)wset * (q.n / 32) + (nt0 < 0 ? 0 : nt0)) * steps * 1024;
   };
   auto stage_bias = [&](int L_) {
     const swn_chain_layer& q = d.layers[L_];
     if (q.b && tid < (q.n >> 2)) *(float4*)(bias_lds + tid * 16) = *(const float4*)(q.b + (size_t)wset * q.n + tid * 4);
   };
 
-  // slice sequence of the whole chain: (L, s) -> next
-  auto next_slice = [&](int& L_, int& s_) -> bool {   // returns false past the end (L_, s_ left on the last slice)
-    if (s_ + 1 < d.layers[L_].k / BK) { ++s_; return true; }
-    if (L_ + 1 < d.n_layers) { ++L_; s_ = 0; return true; }
-    return false;
-  };
-  auto gload_at = [&](int L_, int s_) -> W4 { return gload(wptr(L_), d.layers[L_].n, d.layers[L_].k, s_); };
-
-  // Software pipeline, two slices deep: at slice u the loads of slice u+2 are issued (-> wC), the MFMAs of slice u run,
-  // then slice u+1 (wB, issued one slice earlier: ~2 MFMA phases of latency budget) is written to the other LDS buffer.
-  W4 wB, wC;
-  int Lb = 0, sb = 0;       // slice held in wB
-  int Lc = 0, sc = 0;       // slice held in wC / to be loaded next
+  wfrag_t ring[RING][NI];
   {
-    const W4 w0 = gload_at(0, 0);
-    stage_bias(0);
-    bool ok = next_slice(Lb, sb);          // slice 1 of the chain (or a re-read of slice 0 if there is none)
-    wB = gload_at(Lb, sb);
-    Lc = Lb; sc = sb;
-    (void)ok;
-    lstore(wbuf, w0);
+    const char* w0 = wstream(0);
+    const size_t ts = (size_t)(d.layers[0].k / KSTEP) * 1024;
+#pragma unroll
+    for (int r = 0; r < RING; ++r) {
+      ring[r][0] = *(const wfrag_t*)(w0 + (size_t)r * 1024 + lane * 16);
+      ring[r][1] = *(const wfrag_t*)(w0 + ts + (size_t)r * 1024 + lane * 16);
+    }
   }
+  stage_bias(0);
+  // ---- stage the chain input ----
+  load_rows_to_lds<T>(act, d.x, d.x_gather, d.x_save, grow0, rows_in_tile, d.layers[0].k, tid);
   __syncthreads();
+
+  f32x16_t acc[MI][NI];
 
   for (int L = 0; L < d.n_layers; ++L) {
     const swn_chain_layer& ly = d.layers[L];
     const int n = ly.n, k = ly.k;
-    const int nslices = k / BK;
     const bool wave_active = (wn * 64) < n;
     const bool has_next = (L + 1) < d.n_layers;
+    const int steps = k / KSTEP;
+    const char* wcur = wstream(L);
+    const char* wnxt = has_next ? wstream(L + 1) : wcur;
+    const int nsteps_next = has_next ? d.layers[L + 1].k / KSTEP : steps;
 
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -248,70 +278,17 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    // One K-slice: issue the loads of slice u+2 into `ld`, run the MFMAs of slice u from LDS buffer s&1, then write
-    // slice u+1 (held in `st`, issued one slice ago) to the other buffer.  Slices are processed in pairs with the
-    // roles of the two register sets swapped, so no register copy (and no early wait on the fresh loads) is needed.
-    auto slice_body = [&](int s, W4& st, W4& ld) {
-      const char* wb = wbuf + (s & 1) * WBUF_BYTES;
-      const bool last_slice = (s + 1 == nslices);
-      next_slice(Lc, sc);                  // slice u+2 (clamped at the end of the chain: harmless re-read)
-      ld = gload_at(Lc, sc);
-      if (wave_active) {
-          if constexpr (sizeof(T) == 2) {
-#pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
-              bf16x8_t wf[NI], af[MI];
-#pragma unroll
-              for (int ni = 0; ni < NI; ++ni) {
-                const int nn = wn * 64 + ni * 32 + l31;
-                wf[ni] = *(const bf16x8_t*)(wb + w_off_chunk((bf16_t*)nullptr, nn, kk * 2 + lhi));
-              }
-#pragma unroll
-              for (int mi = 0; mi < MI; ++mi) {
-                const int m = wm * (BM / 2) + mi * 32 + l31;
-                af[mi] = *(const bf16x8_t*)(act + act_off((bf16_t*)nullptr, m, s * BK + kk * 16 + lhi * 8));
-              }
-#pragma unroll
-              for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-            }
-          } else {
-#pragma unroll 4
-            for (int kk = 0; kk < BK / 2; ++kk) {
-              float wf[NI], af[MI];
-#pragma unroll
-              for (int ni = 0; ni < NI; ++ni) {
-                const int nn = wn * 64 + ni * 32 + l31;
-                wf[ni] = *(const float*)(wb + w_off_word(nn, kk * 2 + lhi));
-              }
-#pragma unroll
-              for (int mi = 0; mi < MI; ++mi) {
-                const int m = wm * (BM / 2) + mi * 32 + l31;
-                af[mi] = *(const float*)(act + act_off((float*)nullptr, m, s * BK + kk * 2 + lhi));
-              }
-#pragma unroll
-              for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-            }
-          }
-        }
-      if (!last_slice) lstore(wbuf + ((s + 1) & 1) * WBUF_BYTES, st);   // else: st = slice 0 of the next layer, parked
-      __syncthreads();
-    };
-    for (int s = 0; s < nslices; s += 2) {
-      slice_body(s, wB, wC);
-      if (s + 1 < nslices) slice_body(s + 1, wC, wB);
-    }
-    // even slice count: next layer's slice 0 is parked in wC and its slice 1 is already in wB (no register moves);
-    // odd slice count: parked in wB, the following slice in wC.
-    // every wave has finished reading `act` and the weight buffers for this layer.
+    // K loop: no barrier.  (Waves beyond the layer width run it too on a clamped stream - keeps the ring logic
+    // uniform - and discard the result.  Only the 128-wide layer "2" has such waves.)
+    if (steps == 256 / KSTEP) k_loop<T, 256 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane);
+    else if (steps == 128 / KSTEP) k_loop<T, 128 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane);
+    else k_loop<T, 64 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane);
 
-    if (ly.skip) {  // stage the chain input again (activation layout) in the idle weight buffers
-      load_rows_to_lds<T>(wbuf, d.x, d.x_gather, nullptr, grow0, rows_in_tile, d.layers[0].k, tid);
+    __syncthreads();   // every wave has finished reading the activation tile of this layer
+
+    if (ly.skip) {  // the input tile is dead: bring the chain input x back into the SAME LDS tile; each lane then reads
+                    // its x values and writes h over them in place
+      load_rows_to_lds<T>(act, d.x, d.x_gather, nullptr, grow0, rows_in_tile, d.layers[0].k, tid);
       __syncthreads();
     }
 
@@ -320,9 +297,9 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
       const bool has_bias = ly.b != nullptr;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        const int m = wm * (BM / 2) + mi * 32 + l31;
+        const int m = mi * 32 + l31;
         uint32_t mbits = 0;
-        const size_t midx = ((size_t)(blockIdx.x * 8 + wave) * MI + mi) * 64 + lane;
+        const size_t midx = ((size_t)(blockIdx.x * 4 + wn) * MI + mi) * 64 + lane;
         if (ly.mask && ly.relu == 2) mbits = ly.mask[midx];
         const float* rb = nullptr;
         if (ly.rowbias) rb = ly.rowbias + ((grow0 + m) / ly.rows_per_bias) * (size_t)n;
@@ -345,12 +322,12 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
               }
               if (ly.skip) {
                 if constexpr (sizeof(T) == 2) {
-                  const uint2 xv = *(const uint2*)(wbuf + act_off((bf16_t*)nullptr, m, n0));
+                  const uint2 xv = *(const uint2*)(act + act_off((bf16_t*)nullptr, m, n0));
                   v[0] += bf16_to_f32((bf16_t)(xv.x & 0xFFFF)); v[1] += bf16_to_f32((bf16_t)(xv.x >> 16));
                   v[2] += bf16_to_f32((bf16_t)(xv.y & 0xFFFF)); v[3] += bf16_to_f32((bf16_t)(xv.y >> 16));
                 } else {
 #pragma unroll
-                  for (int j = 0; j < 4; ++j) v[j] += *(const float*)(wbuf + act_off((float*)nullptr, m, n0 + j));
+                  for (int j = 0; j < 4; ++j) v[j] += *(const float*)(act + act_off((float*)nullptr, m, n0 + j));
                 }
               }
               if (ly.relu == 1) {
@@ -380,11 +357,7 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
       }
     }
     __syncthreads();
-    if (has_next) {  // the skip tile / bias of this layer are dead now: park next layer's slice 0 and bias in LDS
-      if (nslices & 1) { lstore(wbuf, wB); wB = wC; }
-      else lstore(wbuf, wC);
-      stage_bias(L + 1);
-    }
+    if (has_next) stage_bias(L + 1);   // read after the next layer's post-K-loop barrier
 
     // ---- write-out (row-major, coalesced) ----
     const bool last = (L == d.n_layers - 1);
@@ -392,9 +365,10 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
     if (outp) {
       const int row_bytes = n * (int)sizeof(T);
       const int cpr = row_bytes >> 4;
+      const int sh = 31 - __builtin_clz(cpr);
       const int total = rows_in_tile * cpr;
       for (int c = tid; c < total; c += NT) {
-        const int row = c / cpr, ch = c - row * cpr;
+        const int row = c >> sh, ch = c & (cpr - 1);
         uint4 v = load_chunk_from_act<T>(act, row, ch);
         if (last && d.y_add) {
           long arow = grow0 + row;
@@ -407,7 +381,38 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
         *(uint4*)((char*)outp + (grow0 + row) * row_bytes + ch * 16) = v;
       }
     }
-    __syncthreads();  // next layer's slice 0 / bias are visible; `act` is only read until its post-K-loop barrier
+    // no barrier needed here: the next layer only reads `act` until its own post-K-loop barrier.
+  }
+}
+
+// Pack a master weight [wsets][in][out] (fp32) into the fragment-major compute layout of swn_mlp_chain:
+//   transpose = 1 (forward):       W[n = out][k = in]  = master[k][n]
+//   transpose = 0 (backward-data): W[n = in][k = out]  = master[n][k]
+// bf16: out[wset][n/32][k/16][lane][8]: lane l, j -> W[nt*32 + (l&31)][ks*16 + (l>>5)*8 + j]
+// fp32: out[wset][n/32][k/8 ][lane][4]: lane l, j -> W[nt*32 + (l&31)][kq*8 + 2*j + (l>>5)]
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ master, T* __restrict__ out, int in_dim, int out_dim,
+                                    int transpose, long total_chunks) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int KSTEP = Cfg<T>::KSTEP;
+  const int N = transpose ? out_dim : in_dim, K = transpose ? in_dim : out_dim;
+  const long per_set = (long)(N / 32) * (K / KSTEP) * 64;
+  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total_chunks; c += (long)gridDim.x * blockDim.x) {
+    const long ws = c / per_set;
+    long r = c - ws * per_set;
+    const int lane = (int)(r & 63);
+    r >>= 6;
+    const int ks = (int)(r % (K / KSTEP)), nt = (int)(r / (K / KSTEP));
+    const int n = nt * 32 + (lane & 31);
+    const float* m = master + ws * (long)in_dim * out_dim;
+    T* o = out + c * EPC;
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+      int kk;
+      if constexpr (sizeof(T) == 2) kk = ks * 16 + (lane >> 5) * 8 + j; else kk = ks * 8 + 2 * j + (lane >> 5);
+      const float v = transpose ? m[(long)kk * out_dim + n] : m[(long)n * out_dim + kk];
+      ElemIO<T>::st(o + j, v);
+    }
   }
 }
 
@@ -415,17 +420,36 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainArgs args) {
 
 using namespace swn;
 
+extern "C" int swn_pack_weights(const float* master, void* out, int dtype, int n_wsets, int in_dim, int out_dim,
+                                int transpose, void* stream) {
+  SWN_CHECK(master && out, "swn_pack_weights: null pointer");
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_pack_weights: bad dtype");
+  const int N = transpose ? out_dim : in_dim, K = transpose ? in_dim : out_dim;
+  const int kstep = dtype == SWN_BF16 ? 16 : 8;
+  SWN_CHECK(N % 32 == 0 && K % kstep == 0 && n_wsets >= 1, "swn_pack_weights: N=%d must be a multiple of 32, K=%d of %d", N, K, kstep);
+  const long chunks = (long)n_wsets * (N / 32) * (K / kstep) * 64;
+  int blocks = cdiv(chunks, 256);
+  if (blocks > 4096) blocks = 4096;
+  if (dtype == SWN_BF16)
+    hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(blocks), dim3(256), 0, as_stream(stream), master, (bf16_t*)out, in_dim,
+                       out_dim, transpose, chunks);
+  else
+    hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(blocks), dim3(256), 0, as_stream(stream), master, (float*)out, in_dim,
+                       out_dim, transpose, chunks);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   SWN_CHECK(desc != nullptr, "swn_mlp_chain: null descriptor");
   const swn_chain_desc& d = *desc;
   SWN_CHECK(d.dtype == SWN_F32 || d.dtype == SWN_BF16, "swn_mlp_chain: bad dtype %d", d.dtype);
   SWN_CHECK(d.n_layers >= 1 && d.n_layers <= 8, "swn_mlp_chain: n_layers %d not in [1,8]", d.n_layers);
   SWN_CHECK(d.n_groups >= 1 && d.n_wsets >= 1 && d.group_stride >= 1, "swn_mlp_chain: bad group geometry");
-  const int bk = d.dtype == SWN_BF16 ? 64 : 32;
   for (int l = 0; l < d.n_layers; ++l) {
     const swn_chain_layer& ly = d.layers[l];
-    SWN_CHECK(ly.n >= 32 && ly.n <= 256 && ly.n % 32 == 0, "swn_mlp_chain: layer %d n=%d must be a multiple of 32 <= 256", l, ly.n);
-    SWN_CHECK(ly.k >= bk && ly.k <= 256 && ly.k % bk == 0, "swn_mlp_chain: layer %d k=%d must be a multiple of %d <= 256", l, ly.k, bk);
+    SWN_CHECK(ly.n >= 64 && ly.n <= 256 && ly.n % 64 == 0, "swn_mlp_chain: layer %d n=%d must be 64, 128, 192 or 256", l, ly.n);
+    SWN_CHECK(ly.k == 64 || ly.k == 128 || ly.k == 256, "swn_mlp_chain: layer %d k=%d must be 64, 128 or 256", l, ly.k);
     if (l > 0) SWN_CHECK(ly.k == d.layers[l - 1].n, "swn_mlp_chain: layer %d k=%d != previous n=%d", l, ly.k, d.layers[l - 1].n);
     SWN_CHECK(ly.w != nullptr, "swn_mlp_chain: layer %d has no weights", l);
     if (ly.skip) SWN_CHECK(ly.n == d.layers[0].k, "swn_mlp_chain: skip layer %d needs n == chain input width", l);
@@ -441,7 +465,7 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   if (!d.group_rows) a.d.group_rows_clamp = d.group_stride;
   const long grid = (long)a.tiles_per_group * d.n_groups;
   SWN_CHECK(grid > 0 && grid < (1L << 31), "swn_mlp_chain: grid %ld out of range", grid);
-  const int lds = ACT_BYTES + 2 * WBUF_BYTES + 1024;
+  const int lds = ACT_BYTES + 1024;
   SWN_CHECK(d.tag >= 0 && d.tag <= 6, "swn_mlp_chain: tag %d not in [0,6]", d.tag);
   const void* fn = nullptr;
 #define SWN_PICK(TAGV)                                                                         \
@@ -457,6 +481,5 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   void* kargs[] = {(void*)&a};
   e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(NT), kargs, lds, as_stream(stream));
   SWN_CHECK(e == hipSuccess, "swn_mlp_chain launch: %s", hipGetErrorString(e));
-  SWN_LAUNCH_CHECK();
   return 0;
 }

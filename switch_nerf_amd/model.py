@@ -75,12 +75,6 @@ class SwitchNeRF:
         self.wf: Dict[str, torch.Tensor] = {}
         self.wb: Dict[str, torch.Tensor] = {}
         self._chain_weights = ["xyz", "gate0", "gate1", "l1", "l2h"] + [f"exp{l}" for l in range(L)]
-        for n in self._chain_weights:
-            s = self.spec[n + ".w"][1]
-            s3 = s if len(s) == 3 else (1,) + tuple(s)
-            self.wf[n] = torch.empty(s3[0], s3[2], s3[1], dtype=dtype, device=self.dev)
-            if n != "xyz":
-                self.wb[n] = torch.empty(s3, dtype=dtype, device=self.dev)
         self._init_random(seed)
         self._bufs = {}
         self.profile = False          # bench.py: record HIP events around the major launches
@@ -197,12 +191,18 @@ class SwitchNeRF:
         return self._to_ref_layout(self.g)
 
     def refresh_compute_copies(self):
+        """fp32 master [in, out] -> MFMA-fragment-major compute copies: forward (N=out, K=in), backward (N=in, K=out)."""
         for n in self._chain_weights:
             w = self.p[n + ".w"]
             w3 = w if w.dim() == 3 else w.unsqueeze(0)
-            ops.cast_transpose(w3, self.wf[n])
-            if n in self.wb:
-                ops.cast(w3, self.wb[n])
+            if n not in self.wf:
+                self.wf[n] = ops.pack_weights(w3, self.dtype, True)
+                if n != "xyz":
+                    self.wb[n] = ops.pack_weights(w3, self.dtype, False)
+            else:
+                ops.repack_weights(w3, self.wf[n], True)
+                if n in self.wb:
+                    ops.repack_weights(w3, self.wb[n], False)
 
     # ------------------------------------------------------------------------------------------ buffers
     def _buf(self, name, shape, dtype):

@@ -185,8 +185,24 @@ def composite_bwd(raw, z, d_rgb, last_delta=1e10):
     return d_raw
 
 
+def pack_weights(master, dtype, transpose: bool):
+    """master [n_wsets, in, out] fp32 -> packed compute copy for mlp_chain, tagged with its logical (n, k)."""
+    assert master.dim() == 3 and master.dtype == torch.float32
+    ws, i, o_ = master.shape
+    out = torch.empty(ws * i * o_, dtype=dtype, device=master.device)
+    call("swn_pack_weights", _p(master), _p(out), _dt(out), ws, i, o_, int(bool(transpose)), _stream())
+    out.swn_nk = (o_, i) if transpose else (i, o_)
+    return out
+
+
+def repack_weights(master, packed, transpose: bool):
+    ws, i, o_ = master.shape
+    call("swn_pack_weights", _p(master), _p(packed), _dt(packed), ws, i, o_, int(bool(transpose)), _stream())
+    return packed
+
+
 class Layer:
-    """One Linear of a chain: w [n_wsets, N, K] (compute dtype, K contiguous), b [n_wsets, N] f32 or None."""
+    """One Linear of a chain: w = pack_weights(...) output (carries .swn_nk = (N, K)), b [n_wsets, N] f32 or None."""
 
     def __init__(self, w, b=None, relu=0, skip=False, save=None, mask=None, rowbias=None, rows_per_bias=0):
         self.w, self.b, self.relu, self.skip, self.save, self.mask = w, b, int(relu), bool(skip), save, mask
@@ -219,10 +235,10 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
     d.y_add, d.y_add_gather = _p(y_add), _p(y_add_gather)
     for i, ly in enumerate(layers):
         L = d.layers[i]
-        assert ly.w.dtype == x.dtype and ly.w.dim() == 3, "weights must be [n_wsets, N, K] in the compute dtype"
+        assert ly.w.dtype == x.dtype and hasattr(ly.w, "swn_nk"), "weights must come from ops.pack_weights (compute dtype)"
         L.w, L.b, L.save, L.mask = _p(ly.w), _p(ly.b), _p(ly.save), _p(ly.mask)
         L.rowbias, L.rows_per_bias = _p(ly.rowbias), ly.rows_per_bias
-        L.n, L.k = ly.w.shape[1], ly.w.shape[2]
+        L.n, L.k = ly.w.swn_nk
         L.relu, L.skip = ly.relu, int(ly.skip)
     call("swn_mlp_chain", C.byref(d), _stream())
     return y

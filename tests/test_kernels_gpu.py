@@ -239,7 +239,8 @@ def test_chain_forward_dense(dtype):
     y = torch.full((R, 128), 7.0, dtype=dtype, device=dev())
     s0 = torch.empty(R, 256, dtype=dtype, device=dev())
     s1 = torch.empty(R, 256, dtype=dtype, device=dev())
-    layers = [o.Layer(Ws[i].to(dev()).to(dtype)[None].contiguous(), Bs[i].to(dev())[None].contiguous(), relu=relus[i]) for i in range(3)]
+    layers = [o.Layer(o.pack_weights(Ws[i].t().contiguous()[None].to(dev()), dtype, True), Bs[i].to(dev())[None].contiguous(),
+                      relu=relus[i]) for i in range(3)]
     layers[0].save, layers[1].save = s0, s1
     o.mlp_chain(xd, layers, y)
     tol = 2e-5 if dtype == torch.float32 else 3e-2
@@ -294,7 +295,7 @@ def test_chain_expert_mlp_forward_backward(dtype):
                 h = h + (_round(h.detach(), dtype) - h.detach())   # straight-through rounding
         outs.append(h)
     # ---- HIP forward
-    wf = [o.cast_transpose(w.to(dev()), torch.empty(E, M, M, dtype=dtype, device=dev())) for w in W]   # [E, out, in]
+    wf = [o.pack_weights(w.to(dev()), dtype, True) for w in W]     # forward copies (N = out, K = in)
     bf = [b.to(dev()).view(E, M).contiguous() for b in B]
     nwords = o.chain_mask_words(dtype, n_seg * E, Cap)
     masks = [torch.zeros(nwords, dtype=torch.int32, device=dev()) for _ in range(L - 1)]
@@ -319,7 +320,7 @@ def test_chain_expert_mlp_forward_backward(dtype):
     dout_r = _round(dout, dtype)
     loss = sum((outs[g_] * dout_r[g_ * Cap: g_ * Cap + outs[g_].shape[0]]).sum() for g_ in range(n_seg * E))
     loss.backward()
-    wb = [o.cast(w.to(dev()), torch.empty(E, M, M, dtype=dtype, device=dev())) for w in W]              # [E, in, out]
+    wb = [o.pack_weights(w.to(dev()), dtype, False) for w in W]    # backward-data copies (N = in, K = out)
     dz = [torch.zeros(rows, M, dtype=dtype, device=dev()) for _ in range(L)]    # dz[l] = grad wrt pre-activation of layer l
     dx = torch.zeros(rows, M, dtype=dtype, device=dev())
     blayers = []
