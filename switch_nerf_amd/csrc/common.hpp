@@ -24,15 +24,17 @@ int set_error(const char* fmt, ...);
 
 typedef uint16_t bf16_t;  // raw bits
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 hwbf16x2_t __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);  // round to nearest even (NaN payloads are not preserved; inputs are finite)
-  return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even conversions: gfx950 has a packed hardware convert (v_cvt_pk_bf16_f32); going through the
+// __bf16 vector type lets hipcc emit it (one VALU op per two values instead of ~10 of integer rounding code).
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hwbf16x2_t));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xFFFFu); }
 
 template <typename T> struct ElemIO;
 template <> struct ElemIO<float> {
