@@ -23,6 +23,7 @@ namespace swn {
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int NT = 256;         // threads per workgroup (4 waves)
 constexpr int NI = 2;           // 32-wide feature tiles per wave (4 waves * 2 * 32 = 256 = max features)
@@ -147,37 +148,63 @@ __device__ __forceinline__ void load_rows_to_lds(char* dst, const void* src, con
 // wcur / wnxt: this wave's fragment streams: [tile ni][step][lane][16 B]; tile stride = steps * 1 KiB.
 template <typename T, int NSTEPS>
 __device__ __forceinline__ void k_loop(f32x16_t (&acc)[Cfg<T>::MI][NI], typename Cfg<T>::wfrag_t (&ring)[RING][NI],
-                                       const char* act, const int (&aoff)[16], const char* wcur, const char* wnxt,
-                                       int nxt_steps, int lane) {
+                                       const char* act, const int (&aoff)[16], __amdgpu_buffer_rsrc_t wcur,
+                                       __amdgpu_buffer_rsrc_t wnxt, int nxt_steps, int lane16) {
   constexpr int MI = Cfg<T>::MI;
   typedef typename Cfg<T>::wfrag_t wfrag_t;
-  const size_t ts_n = (size_t)nxt_steps * 1024;
-#pragma unroll
-  for (int ks = 0; ks < NSTEPS; ++ks) {
-    const int r = ks % RING;
-    const wfrag_t w0 = ring[r][0], w1 = ring[r][1];
-    {  // refill the slot with step ks + RING of this layer, else step (ks + RING - NSTEPS) of the next layer
-      constexpr size_t ts_c = (size_t)NSTEPS * 1024;
-      const int nx = ks + RING;
-      if (nx < NSTEPS) {
-        ring[r][0] = *(const wfrag_t*)(wcur + (size_t)nx * 1024 + lane * 16);
-        ring[r][1] = *(const wfrag_t*)(wcur + ts_c + (size_t)nx * 1024 + lane * 16);
-      } else {   // wnxt is a valid stream even at the end of the chain (re-read, discarded)
-        ring[r][0] = *(const wfrag_t*)(wnxt + (size_t)(nx - NSTEPS) * 1024 + lane * 16);
-        ring[r][1] = *(const wfrag_t*)(wnxt + ts_n + (size_t)(nx - NSTEPS) * 1024 + lane * 16);
-      }
+  const int ts_n = nxt_steps * 1024;
+  constexpr int ts_c = NSTEPS * 1024;
+  // refill ring slot r with step ks + RING of this layer, else step (ks + RING - NSTEPS) of the next layer.
+  // Buffer loads: descriptor (SGPRs) + one per-lane offset VGPR + scalar step offset -> no address VGPRs.
+  auto refill = [&](int ks, int r) {
+    const int nx = ks + RING;
+    if (nx < NSTEPS) {
+      ring[r][0] = __builtin_bit_cast(wfrag_t, __builtin_amdgcn_raw_buffer_load_b128(wcur, lane16, nx * 1024, 0));
+      ring[r][1] = __builtin_bit_cast(wfrag_t, __builtin_amdgcn_raw_buffer_load_b128(wcur, lane16, ts_c + nx * 1024, 0));
+    } else {   // wnxt is a valid stream even at the end of the chain (re-read, discarded)
+      ring[r][0] = __builtin_bit_cast(wfrag_t, __builtin_amdgcn_raw_buffer_load_b128(wnxt, lane16, (nx - NSTEPS) * 1024, 0));
+      ring[r][1] = __builtin_bit_cast(wfrag_t, __builtin_amdgcn_raw_buffer_load_b128(wnxt, lane16, ts_n + (nx - NSTEPS) * 1024, 0));
     }
-    if constexpr (sizeof(T) == 2) {
-      bf16x8_t af[MI];
+  };
+  if constexpr (sizeof(T) == 2) {
+    // activation fragments are software-pipelined through two alternating registers: the read of fragment i+1 is
+    // issued before the two MFMAs of fragment i; a ring slot is refilled right after its last use (no copies).
+    auto aread = [&](int ks, int mi) -> bf16x8_t {
+      return *(const bf16x8_t*)(act + aoff[ks & 7] + mi * 16384 + (ks >> 3) * 256);
+    };
+    bf16x8_t a0 = aread(0, 0), a1;
+#define SWN_PIN() __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        af[mi] = *(const bf16x8_t*)(act + aoff[ks & 7] + mi * 16384 + (ks >> 3) * 256);
+    for (int ks = 0; ks < NSTEPS; ++ks) {
+      const int r = ks % RING;
+      a1 = aread(ks, 1);
+      SWN_PIN();
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a0, acc[0][1], 0, 0, 0);
+      SWN_PIN();
+      a0 = aread(ks, 2);
+      SWN_PIN();
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a1, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a1, acc[1][1], 0, 0, 0);
+      SWN_PIN();
+      a1 = aread(ks, 3);
+      SWN_PIN();
+      acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a0, acc[2][0], 0, 0, 0);
+      acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a0, acc[2][1], 0, 0, 0);
+      SWN_PIN();
+      if (ks + 1 < NSTEPS) a0 = aread(ks + 1, 0);
+      SWN_PIN();
+      acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a1, acc[3][0], 0, 0, 0);
+      acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a1, acc[3][1], 0, 0, 0);
+      SWN_PIN();
+      refill(ks, r);
+      SWN_PIN();
+    }
+#undef SWN_PIN
+  } else {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, af[mi], acc[mi][0], 0, 0, 0);
-        acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, af[mi], acc[mi][1], 0, 0, 0);
-      }
-    } else {
+    for (int ks = 0; ks < NSTEPS; ++ks) {
+      const int r = ks % RING;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float af[MI];
@@ -186,14 +213,88 @@ __device__ __forceinline__ void k_loop(f32x16_t (&acc)[Cfg<T>::MI][NI], typename
           af[mi] = *(const float*)(act + aoff[(ks & 3) * 4 + j] + mi * 32768 + (ks >> 2) * 128);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-          acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j], af[mi], acc[mi][0], 0, 0, 0);
-          acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[j], af[mi], acc[mi][1], 0, 0, 0);
+          acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[r][0][j], af[mi], acc[mi][0], 0, 0, 0);
+          acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[r][1][j], af[mi], acc[mi][1], 0, 0, 0);
         }
       }
+      refill(ks, r);
     }
   }
 }
 
+// ---- epilogue of one layer: accumulators -> (+bias, +per-ray bias, +skip input) -> ReLU / stored mask -> LDS tile ------
+// A lane owns row m = mi*32 + l31 and, per feature tile ni and group g4, features n0 .. n0+3 (n0 = wn*64+ni*32+g4*8+lhi*4).
+// Compile-time flags keep the hot variants straight-line; `mk` points at this lane's first mask word (stride 64 per mi).
+template <typename T, bool DYN, int RELU_, bool SKIP_, bool BIAS_, bool RB_>
+__device__ __forceinline__ void epilogue_body(f32x16_t (&acc)[Cfg<T>::MI][NI], char* act, const char* bias_lds, const float* rbp,
+                                              uint32_t* mk, int wn, int l31, int lhi, int nvalid, long grow0, int rows_per_bias,
+                                              int n, int relu_d, bool skip_d, bool bias_d) {
+  constexpr int MI = Cfg<T>::MI;
+  const int relu = DYN ? relu_d : RELU_;
+  const bool skip = DYN ? skip_d : SKIP_;
+  const bool bias = DYN ? bias_d : BIAS_;
+  const bool rowb = DYN ? (rbp != nullptr) : RB_;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = mi * 32 + l31;
+    uint32_t mbits = 0;
+    if (relu == 2) mbits = mk[mi * 64];
+    const float* rb = nullptr;
+    if (rowb) rb = rbp + (((grow0 % rows_per_bias) + m) / rows_per_bias) * (size_t)n;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      if (ni * 32 < nvalid) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int n0 = wn * 64 + ni * 32 + g4 * 8 + lhi * 4;
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][g4 * 4 + j];
+          if (bias) {
+            const float4 b4 = *(const float4*)(bias_lds + n0 * 4);
+            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+          }
+          if (rowb) {
+            const float4 b4 = *(const float4*)(rb + n0);
+            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+          }
+          if (skip) {
+            if constexpr (sizeof(T) == 2) {
+              const uint2 xv = *(const uint2*)(act + act_off((bf16_t*)nullptr, m, n0));
+              v[0] += bf16_to_f32((bf16_t)(xv.x & 0xFFFF)); v[1] += bf16_to_f32((bf16_t)(xv.x >> 16));
+              v[2] += bf16_to_f32((bf16_t)(xv.y & 0xFFFF)); v[3] += bf16_to_f32((bf16_t)(xv.y >> 16));
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] += *(const float*)(act + act_off((float*)nullptr, m, n0 + j));
+            }
+          }
+          if (relu == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const bool pos = v[j] > 0.f;
+              mbits |= (pos ? 1u : 0u) << (ni * 16 + g4 * 4 + j);
+              v[j] = pos ? v[j] : 0.f;
+            }
+          } else if (relu == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ((mbits >> (ni * 16 + g4 * 4 + j)) & 1u) ? v[j] : 0.f;
+          }
+          if constexpr (sizeof(T) == 2) {
+            uint2 pk;
+            pk.x = pack_bf16x2(v[0], v[1]);
+            pk.y = pack_bf16x2(v[2], v[3]);
+            *(uint2*)(act + act_off((bf16_t*)nullptr, m, n0)) = pk;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(float*)(act + act_off((float*)nullptr, m, n0 + j)) = v[j];
+          }
+          __builtin_amdgcn_sched_barrier(0);   // one group at a time: keeps the epilogue's register footprint small
+        }
+      }
+    }
+    if (relu == 1 && mk) mk[mi * 64] = mbits;
+  }
+}
 template <typename T, int TAG>
 __global__ __launch_bounds__(NT, 2) void chain_kernel(const ChainArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -244,14 +345,18 @@ __global__ __launch_bounds__(NT, 2) void chain_kernel(const ChainArgs args) {
     if (q.b && tid < (q.n >> 2)) *(float4*)(bias_lds + tid * 16) = *(const float4*)(q.b + (size_t)wset * q.n + tid * 4);
   };
 
+  auto wrsrc = [&](int L_) -> __amdgpu_buffer_rsrc_t {   // descriptor over this wave's two feature tiles of layer L_
+    return __builtin_amdgcn_make_buffer_rsrc((void*)wstream(L_), 0, 2 * (d.layers[L_].k / KSTEP) * 1024, 0x00020000);
+  };
+  const int lane16 = lane * 16;
   wfrag_t ring[RING][NI];
   {
-    const char* w0 = wstream(0);
-    const size_t ts = (size_t)(d.layers[0].k / KSTEP) * 1024;
+    const __amdgpu_buffer_rsrc_t w0 = wrsrc(0);
+    const int ts = (d.layers[0].k / KSTEP) * 1024;
 #pragma unroll
     for (int r = 0; r < RING; ++r) {
-      ring[r][0] = *(const wfrag_t*)(w0 + (size_t)r * 1024 + lane * 16);
-      ring[r][1] = *(const wfrag_t*)(w0 + ts + (size_t)r * 1024 + lane * 16);
+      ring[r][0] = __builtin_bit_cast(wfrag_t, __builtin_amdgcn_raw_buffer_load_b128(w0, lane16, r * 1024, 0));
+      ring[r][1] = __builtin_bit_cast(wfrag_t, __builtin_amdgcn_raw_buffer_load_b128(w0, lane16, ts + r * 1024, 0));
     }
   }
   stage_bias(0);
@@ -267,8 +372,8 @@ __global__ __launch_bounds__(NT, 2) void chain_kernel(const ChainArgs args) {
     const bool wave_active = (wn * 64) < n;
     const bool has_next = (L + 1) < d.n_layers;
     const int steps = k / KSTEP;
-    const char* wcur = wstream(L);
-    const char* wnxt = has_next ? wstream(L + 1) : wcur;
+    const __amdgpu_buffer_rsrc_t wcur = wrsrc(L);
+    const __amdgpu_buffer_rsrc_t wnxt = has_next ? wrsrc(L + 1) : wcur;
     const int nsteps_next = has_next ? d.layers[L + 1].k / KSTEP : steps;
 
 #pragma unroll
@@ -280,9 +385,9 @@ __global__ __launch_bounds__(NT, 2) void chain_kernel(const ChainArgs args) {
 
     // K loop: no barrier.  (Waves beyond the layer width run it too on a clamped stream - keeps the ring logic
     // uniform - and discard the result.  Only the 128-wide layer "2" has such waves.)
-    if (steps == 256 / KSTEP) k_loop<T, 256 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane);
-    else if (steps == 128 / KSTEP) k_loop<T, 128 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane);
-    else k_loop<T, 64 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane);
+    if (steps == 256 / KSTEP) k_loop<T, 256 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
+    else if (steps == 128 / KSTEP) k_loop<T, 128 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
+    else k_loop<T, 64 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
 
     __syncthreads();   // every wave has finished reading the activation tile of this layer
 
@@ -294,72 +399,22 @@ __global__ __launch_bounds__(NT, 2) void chain_kernel(const ChainArgs args) {
 
     // ---- epilogue: bias / row-bias / skip / ReLU (or stored mask) -> next layer's input tile ----
     if (wave_active) {
-      const bool has_bias = ly.b != nullptr;
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int m = mi * 32 + l31;
-        uint32_t mbits = 0;
-        const size_t midx = ((size_t)(blockIdx.x * 4 + wn) * MI + mi) * 64 + lane;
-        if (ly.mask && ly.relu == 2) mbits = ly.mask[midx];
-        const float* rb = nullptr;
-        if (ly.rowbias) rb = ly.rowbias + ((grow0 + m) / ly.rows_per_bias) * (size_t)n;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          if (wn * 64 + ni * 32 < n) {
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-              const int n0 = wn * 64 + ni * 32 + g4 * 8 + lhi * 4;
-              float v[4];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][g4 * 4 + j];
-              if (has_bias) {
-                const float4 b4 = *(const float4*)(bias_lds + n0 * 4);
-                v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-              }
-              if (rb) {
-                const float4 b4 = *(const float4*)(rb + n0);
-                v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-              }
-              if (ly.skip) {
-                if constexpr (sizeof(T) == 2) {
-                  const uint2 xv = *(const uint2*)(act + act_off((bf16_t*)nullptr, m, n0));
-                  v[0] += bf16_to_f32((bf16_t)(xv.x & 0xFFFF)); v[1] += bf16_to_f32((bf16_t)(xv.x >> 16));
-                  v[2] += bf16_to_f32((bf16_t)(xv.y & 0xFFFF)); v[3] += bf16_to_f32((bf16_t)(xv.y >> 16));
-                } else {
-#pragma unroll
-                  for (int j = 0; j < 4; ++j) v[j] += *(const float*)(act + act_off((float*)nullptr, m, n0 + j));
-                }
-              }
-              if (ly.relu == 1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                  const bool pos = v[j] > 0.f;
-                  mbits |= (pos ? 1u : 0u) << (ni * 16 + g4 * 4 + j);
-                  v[j] = pos ? v[j] : 0.f;
-                }
-              } else if (ly.relu == 2) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = ((mbits >> (ni * 16 + g4 * 4 + j)) & 1u) ? v[j] : 0.f;
-              }
-              if constexpr (sizeof(T) == 2) {
-                uint2 pk;
-                pk.x = pack_bf16x2(v[0], v[1]);
-                pk.y = pack_bf16x2(v[2], v[3]);
-                *(uint2*)(act + act_off((bf16_t*)nullptr, m, n0)) = pk;
-              } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) *(float*)(act + act_off((float*)nullptr, m, n0 + j)) = v[j];
-              }
-            }
-          }
-        }
-        if (ly.mask && ly.relu == 1) ly.mask[midx] = mbits;
-      }
+      // launder the lane coordinates: stops the compiler from hoisting every (mi, ni, g4) LDS offset of the epilogue
+      // out of the layer loop (dozens of long-lived VGPRs -> spills in the MFMA loop)
+      int l31e = l31, lhie = lhi;
+      asm volatile("" : "+v"(l31e), "+v"(lhie));
+      const float* rbp = ly.rowbias ? ly.rowbias + (grow0 / ly.rows_per_bias) * (size_t)n : nullptr;   // tile-aligned per-ray bias
+      uint32_t* mk = ly.mask ? ly.mask + (size_t)(blockIdx.x * 4 + wn) * MI * 64 + lane : nullptr;
+      const int nvalid = n - wn * 64;   // feature tiles of this wave that exist: nvalid >= 64 -> both
+      epilogue_body<T, true, 0, false, false, false>(acc, act, bias_lds, rbp, mk, wn, l31e, lhie, nvalid, grow0, ly.rows_per_bias, n,
+                                                     ly.relu, ly.skip != 0, ly.b != nullptr);
     }
     __syncthreads();
     if (has_next) stage_bias(L + 1);   // read after the next layer's post-K-loop barrier
 
     // ---- write-out (row-major, coalesced) ----
+    int tidw = tid;
+    asm volatile("" : "+v"(tidw));     // same reason: keep the write-out index math inside the loop
     const bool last = (L == d.n_layers - 1);
     void* outp = last ? d.y : ly.save;
     if (outp) {
@@ -367,7 +422,7 @@ __global__ __launch_bounds__(NT, 2) void chain_kernel(const ChainArgs args) {
       const int cpr = row_bytes >> 4;
       const int sh = 31 - __builtin_clz(cpr);
       const int total = rows_in_tile * cpr;
-      for (int c = tid; c < total; c += NT) {
+      for (int c = tidw; c < total; c += NT) {
         const int row = c >> sh, ch = c & (cpr - 1);
         uint4 v = load_chunk_from_act<T>(act, row, ch);
         if (last && d.y_add) {
