@@ -424,11 +424,13 @@ __global__ void gate_dwg_kernel(const T* __restrict__ g, const float* __restrict
 #pragma unroll
     for (int t = 0; t < 64; ++t) {
       float x = xv[t];
-      const float m_ = __shfl(mu, t, 64), r_ = __shfl(rs, t, 64);
+      // v_readlane (SGPR broadcast) instead of __shfl (ds_bpermute): t is a compile-time constant after unrolling
+      const float m_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu), t));
+      const float r_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs), t));
       if (ln_w) x = (x - m_) * r_ * w + b;
       x = t < nt ? x : 0.f;
 #pragma unroll
-      for (int e = 0; e < E; ++e) acc[e] += __shfl(dl[e], t, 64) * x;
+      for (int e = 0; e < E; ++e) acc[e] += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl[e]), t)) * x;
     }
   }
 #pragma unroll
