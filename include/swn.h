@@ -157,8 +157,11 @@ typedef struct swn_chain_desc {
   const int32_t* group_rows;    /* device [n_groups] valid rows per group, or NULL = group_stride (then clamp) */
   int32_t group_rows_clamp;     /* rows valid = min(group_rows[g], clamp)                         */
   const void* x;                /* chain input, row-major [*, k0] dtype                           */
-  const int32_t* x_gather;      /* device [n_groups*group_stride] row -> source row of x, or NULL (identity) */
-  void* x_save;                 /* optional copy of the gathered input rows (row-major) or NULL   */
+  const int32_t* x_gather;      /* device [n_groups*group_stride] row -> source row of x (-1 = zero row), or NULL */
+  void* x_save;                 /* optional copy of the (gathered, scaled) input rows (row-major) or NULL */
+  const float* x_scale;         /* per destination row scale applied to the gathered input (the gate value: fused
+                                   GatingDecoder, tutel_fast_dispatch.py:50-63), or NULL             */
+  int32_t x_relu;               /* ReLU after scaling (the MoE layer's `act: relu`, nerf_moe.py:385)  */
   void* y;                      /* output rows, row-major [*, n_last] dtype                       */
   const void* y_add;            /* row-major [*, n_last] tensor added to the output rows (skip gradient) or NULL */
   const int32_t* y_add_gather;  /* row -> row of y_add (-1 = nothing to add), or NULL (identity)  */

@@ -174,6 +174,31 @@ def gen_model_forward():
              moe_loss=r["extras"]["moe_loss"].numpy(), moe_gates=r["extras"]["moe_gates"][0].numpy().astype(np.int32))
 
 
+# ------------------------------------------------------------------------------------------ G9 eval / nobatch path
+def gen_model_forward_nobatch():
+    """The reference's eval path (README.md:172-185): --moe_expert_type=seqexperts --expertmlp2seqexperts, set_no_batch:
+    apply_on_expert_fn_nobatch, no capacity drop, rows packed per expert, in-tree kernels tutel_sparse_nobatch.py."""
+    print("[G9] NeRFMoE.forward, nobatch/eval path (seqexperts, no token dropping), P=4096")
+    cfg = synth.BUILDING
+    sd = synth.make_weights(41, cfg, gate_scale=1.0)
+    h = make_hparams(cfg, bpr=False)
+    h.moe_expert_type = "seqexperts"
+    torch.manual_seed(0)
+    nerf = model_utils.get_nerf(h, cfg["appearance_count"])
+    conv = model_utils.convert_to_seqexperts({("module." + k): torch.from_numpy(v.copy()) for k, v in sd.items()})
+    conv = {k[len("module."):]: v for k, v in conv.items()}
+    missing = set(nerf.state_dict().keys()) ^ set(conv.keys())
+    assert not missing, sorted(missing)[:5]
+    nerf.load_state_dict(conv)
+    nerf.set_no_batch(True)
+    nerf.eval()
+    g = np.load(os.path.join(OUT, "model_fwd_unbalanced.npz"))
+    with torch.no_grad():
+        r = nerf(torch.from_numpy(g["x"]), sigma_noise=None)
+    save("model_fwd_nobatch", seed=41, gate_scale=1.0, x=g["x"], outputs=r["outputs"].numpy(),
+         moe_gates=r["extras"]["moe_gates"][0].numpy().astype(np.int32))
+
+
 # ------------------------------------------------------------------------------------------ G5 render + train step
 def gen_render():
     print("[G5] render_rays / training step (64 rays x 64 samples, chunk 1024 -> 4 chunks), fwd + grads")
@@ -244,8 +269,8 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    todo = dict(routing=gen_routing, pe=gen_pe, moe=gen_moe_layer, model=gen_model_forward, render=gen_render,
-                composite=gen_composite)
+    todo = dict(routing=gen_routing, pe=gen_pe, moe=gen_moe_layer, model=gen_model_forward, nobatch=gen_model_forward_nobatch,
+                render=gen_render, composite=gen_composite)
     for k, fn in todo.items():
         if a.only and k not in a.only.split(","):
             continue

@@ -149,7 +149,7 @@ def expert_mlp(d: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequenc
 
 
 def moe_layer(h: torch.Tensor, gate_input: torch.Tensor, wg: torch.Tensor, weights, biases, skips,
-              capacity_factor: float, batch_prioritized: bool, routing: Optional[dict] = None):
+              capacity_factor: float, batch_prioritized: bool, routing: Optional[dict] = None, no_batch: bool = False):
     """TopKGate.apply_on_expert_fn, tutel_moe_layer_nobatch.py:98-235 (k=1, fp32 gate, postscore).
     Returns (y [P,M], l_aux, routing dict, gates [P,E]).  `routing` may be injected (idx/loc numpy) to
     decouple numerics tests from near-tie routing flips."""
@@ -158,6 +158,10 @@ def moe_layer(h: torch.Tensor, gate_input: torch.Tensor, wg: torch.Tensor, weigh
     gates = torch.softmax(logits, dim=1)                                       # :126
     if routing is None:
         routing = route_top1(gates.detach().numpy(), capacity_factor, batch_prioritized)
+        if no_batch:
+            # eval path, apply_on_expert_fn_nobatch (tutel_moe_layer_nobatch.py:237-352) + tutel_sparse_nobatch.py: every
+            # token is processed by its expert (no capacity test); equivalent to a capacity that nothing exceeds
+            routing = dict(routing, capacity=int(gates.shape[0]))
     idx = torch.from_numpy(np.asarray(routing["idx"]).astype(np.int64))
     loc = torch.from_numpy(np.asarray(routing["loc"]).astype(np.int64))
     cap = int(routing["capacity"])
@@ -190,7 +194,7 @@ def params_from_numpy(sd: Dict[str, np.ndarray], requires_grad: bool = False) ->
 
 def nerf_moe_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: dict, capacity_factor: float = 1.0,
                      batch_prioritized: bool = True, sigma_noise: Optional[torch.Tensor] = None,
-                     routing: Optional[dict] = None):
+                     routing: Optional[dict] = None, no_batch: bool = False):
     """NeRFMoE.forward, models/nerf_moe.py:320-455, with building.yaml's layer wiring.
     x: [P, 7] = xyz(3) dir(3) image_index(1).  Returns dict(outputs [P,4], moe_loss [1], routing, gates)."""
     L = cfg["expert_layers"]
@@ -202,7 +206,7 @@ def nerf_moe_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: dict, cap
     weights = [p[f"layers.0.experts.0.weights.{l}"] for l in range(L)]
     biases = [p[f"layers.0.experts.0.bias.{l}"] for l in range(L)]
     y, l_aux, routing, gates = moe_layer(h, g, p["layers.0.gates.0.wg.weight"], weights, biases, cfg["skips"],
-                                         capacity_factor, batch_prioritized, routing)
+                                         capacity_factor, batch_prioritized, routing, no_batch)
     y = torch.relu(y)                                                          # act: relu, :385-386
     sigma = F.linear(y, p["layers.sigma.fcs.0.weight"], p["layers.sigma.fcs.0.bias"])  # :393-400
     if sigma_noise is not None:

@@ -19,7 +19,7 @@ class ChainLayer(C.Structure):
 
 class ChainDesc(C.Structure):
     _fields_ = [("dtype", i32), ("n_layers", i32), ("n_groups", i32), ("n_wsets", i32), ("group_stride", i32),
-                ("group_rows", vp), ("group_rows_clamp", i32), ("x", vp), ("x_gather", vp), ("x_save", vp),
+                ("group_rows", vp), ("group_rows_clamp", i32), ("x", vp), ("x_gather", vp), ("x_save", vp), ("x_scale", vp), ("x_relu", i32),
                 ("y", vp), ("y_add", vp), ("y_add_gather", vp), ("tag", i32), ("layers", ChainLayer * 8)]
 
 

@@ -103,7 +103,8 @@ __device__ __forceinline__ uint4 add_chunks(uint4 a, uint4 b) {
 // consumed (no per-load wait), out-of-range work is clamped to a valid address and masked at the store.
 template <typename T>
 __device__ __forceinline__ void load_rows_to_lds(char* dst, const void* src, const int32_t* gather, void* save,
-                                                 long grow0, int rows_valid_in_tile, int kfeat, int tid) {
+                                                 long grow0, int rows_valid_in_tile, int kfeat, int tid,
+                                                 const float* scale = nullptr, int relu = 0) {
   constexpr int BM = Cfg<T>::BM;
   const int row_bytes = kfeat * (int)sizeof(T);
   const int cpr = row_bytes >> 4;  // 16-byte chunks per row (power of two)
@@ -134,6 +135,24 @@ __device__ __forceinline__ void load_rows_to_lds(char* dst, const void* src, con
 #pragma unroll
     for (int i = 0; i < B; ++i) {
       if (srow[i] < 0) v[i] = make_uint4(0, 0, 0, 0);
+      else if (scale) {   // fused combine: x = relu?(scale[row] * x)   (GatingDecoder + the MoE layer's ReLU)
+        const float sc = scale[grow0 + row[i]];
+        if constexpr (sizeof(T) == 2) {
+          uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float lo = sc * bf16_to_f32((bf16_t)(w[q] & 0xFFFF)), hi = sc * bf16_to_f32((bf16_t)(w[q] >> 16));
+            if (relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+            w[q] = pack_bf16x2(lo, hi);
+          }
+          v[i] = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+          float f[4] = {__uint_as_float(v[i].x), __uint_as_float(v[i].y), __uint_as_float(v[i].z), __uint_as_float(v[i].w)};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { f[q] *= sc; if (relu) f[q] = fmaxf(f[q], 0.f); }
+          v[i] = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+        }
+      }
       if (in[i]) {
         if (save && row[i] < rows_valid_in_tile) *(uint4*)((char*)save + (grow0 + row[i]) * row_bytes + ch[i] * 16) = v[i];
         store_chunk_to_act<T>(dst, row[i], ch[i], v[i]);
@@ -228,7 +247,7 @@ __device__ __forceinline__ void k_loop(f32x16_t (&acc)[Cfg<T>::MI][NI], typename
 template <typename T, bool DYN, int RELU_, bool SKIP_, bool BIAS_, bool RB_>
 __device__ __forceinline__ void epilogue_body(f32x16_t (&acc)[Cfg<T>::MI][NI], char* act, const char* bias_lds, const float* rbp,
                                               uint32_t* mk, int wn, int l31, int lhi, int nvalid, long grow0, int rows_per_bias,
-                                              int n, int relu_d, bool skip_d, bool bias_d) {
+                                              int n, int relu_d, bool skip_d, bool bias_d, int rows_in_tile) {
   constexpr int MI = Cfg<T>::MI;
   const int relu = DYN ? relu_d : RELU_;
   const bool skip = DYN ? skip_d : SKIP_;
@@ -240,7 +259,7 @@ __device__ __forceinline__ void epilogue_body(f32x16_t (&acc)[Cfg<T>::MI][NI], c
     uint32_t mbits = 0;
     if (relu == 2) mbits = mk[mi * 64];
     const float* rb = nullptr;
-    if (rowb) rb = rbp + (((grow0 % rows_per_bias) + m) / rows_per_bias) * (size_t)n;
+    if (rowb) rb = rbp + (((grow0 % rows_per_bias) + min(m, rows_in_tile - 1)) / rows_per_bias) * (size_t)n;   // clamp: rows past the tile end
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       if (ni * 32 < nvalid) {
@@ -361,7 +380,7 @@ __global__ __launch_bounds__(NT, 2) void chain_kernel(const ChainArgs args) {
   }
   stage_bias(0);
   // ---- stage the chain input ----
-  load_rows_to_lds<T>(act, d.x, d.x_gather, d.x_save, grow0, rows_in_tile, d.layers[0].k, tid);
+  load_rows_to_lds<T>(act, d.x, d.x_gather, d.x_save, grow0, rows_in_tile, d.layers[0].k, tid, d.x_scale, d.x_relu);
   __syncthreads();
 
   f32x16_t acc[MI][NI];
@@ -393,7 +412,7 @@ __global__ __launch_bounds__(NT, 2) void chain_kernel(const ChainArgs args) {
 
     if (ly.skip) {  // the input tile is dead: bring the chain input x back into the SAME LDS tile; each lane then reads
                     // its x values and writes h over them in place
-      load_rows_to_lds<T>(act, d.x, d.x_gather, nullptr, grow0, rows_in_tile, d.layers[0].k, tid);
+      load_rows_to_lds<T>(act, d.x, d.x_gather, nullptr, grow0, rows_in_tile, d.layers[0].k, tid, d.x_scale, d.x_relu);
       __syncthreads();
     }
 
@@ -407,7 +426,7 @@ __global__ __launch_bounds__(NT, 2) void chain_kernel(const ChainArgs args) {
       uint32_t* mk = ly.mask ? ly.mask + (size_t)(blockIdx.x * 4 + wn) * MI * 64 + lane : nullptr;
       const int nvalid = n - wn * 64;   // feature tiles of this wave that exist: nvalid >= 64 -> both
       epilogue_body<T, true, 0, false, false, false>(acc, act, bias_lds, rbp, mk, wn, l31e, lhie, nvalid, grow0, ly.rows_per_bias, n,
-                                                     ly.relu, ly.skip != 0, ly.b != nullptr);
+                                                     ly.relu, ly.skip != 0, ly.b != nullptr, rows_in_tile);
     }
     __syncthreads();
     if (has_next) stage_bias(L + 1);   // read after the next layer's post-K-loop barrier

@@ -215,7 +215,7 @@ class SwitchNeRF:
 
     # ------------------------------------------------------------------------------------------ forward
     def forward_rays(self, rays, image_indices, n_samples, seg_tokens, perturb=0.0, perturb_rand=None, sigma_noise=None,
-                     training=True, routing_override=None):
+                     training=True, routing_override=None, no_batch=False):
         """Coarse pass of render_rays (fine_samples = 0).  Returns a context dict holding every tensor the backward
         needs and the rendered results."""
         o, dt, dev = ops, self.dtype, self.dev
@@ -225,6 +225,8 @@ class SwitchNeRF:
         assert P % seg_tokens == 0, "points must be a multiple of the segment (model chunk) size"
         n_seg = P // seg_tokens
         cap = int(self.cf * ((seg_tokens + E - 1) // E))     # tutel_fast_dispatch.py:211
+        if no_batch:        # eval path (apply_on_expert_fn_nobatch): nothing is dropped == a capacity nothing exceeds
+            cap = seg_tokens
         c = dict(N=N, S=S, P=P, n_seg=n_seg, cap=cap, seg_tokens=seg_tokens)
         t_steps = torch.linspace(0, 1, S, dtype=torch.float32).to(dev)      # computed on the host like the reference's CPU path
         c["z"], c["pe"], pe_dir = o.sample_pe(rays, t_steps, perturb_rand, perturb, S, self.cfg["pos_xyz_dim"],
@@ -261,17 +263,18 @@ class SwitchNeRF:
         with self._timed("expert_fwd"):
             o.mlp_chain(c["h0"], layers, c["eo"], n_groups=ng, n_wsets=E, group_stride=cap, group_rows=c["counts_flat"],
                         group_rows_clamp=cap, x_gather=c["perm"].view(-1), x_save=c["xs"], tag=1)
-        # ---- combine (+ the MoE layer's ReLU)
-        c["y"] = o.combine_fwd(c["gmax"], c["idx"], c["loc"], c["eo"], cap, seg_tokens, E, relu=True)
         # ---- per-ray part of layer "2": [PE(dir), appearance embedding] @ W2r + b2   (N_rays x 75, host-side torch)
         feat = torch.cat([pe_dir[:, : self.in_dir].float(), self.p["emb"][image_indices.long()]], 1)
         c["ray_feat"] = feat
         c["c_ray"] = torch.addmm(self.p["l2.b"], feat, self.p["l2r.w"]).contiguous()
-        # ---- tail chain: layer "1" -> layer "2" (+ per-ray bias, ReLU)
+        # ---- tail chain.  Its input load IS the combine: rows gathered from the expert output through tok2row, scaled by
+        # the gate value, ReLU'd (dropped tokens -> zero rows) and saved as y;  then layer "1" -> layer "2" (+ per-ray bias)
+        c["y"] = self._buf("y", (P, M), dt)
         c["h1"] = self._buf("h1", (P, M), dt)
         c["h2"] = self._buf("h2", (P, H2), dt)
-        o.mlp_chain(c["y"], [o.Layer(self.wf["l1"], self.p["l1.b"].view(1, M), save=c["h1"]),
-                             o.Layer(self.wf["l2h"], None, relu=1, rowbias=c["c_ray"], rows_per_bias=S)], c["h2"], tag=4)
+        o.mlp_chain(c["eo"], [o.Layer(self.wf["l1"], self.p["l1.b"].view(1, M), save=c["h1"]),
+                              o.Layer(self.wf["l2h"], None, relu=1, rowbias=c["c_ray"], rows_per_bias=S)], c["h2"],
+                    group_stride=P, x_gather=c["tok2row"], x_save=c["y"], x_scale=c["gmax"], x_relu=True, tag=4)
         # ---- heads + compositing
         c["raw"] = o.heads_fwd(c["y"], c["h2"], self.p["sigma.w"], self.p["sigma.b"], self.p["color.w"], self.p["color.b"],
                                sigma_noise)
@@ -361,6 +364,32 @@ class SwitchNeRF:
         return dict(loss=loss, photo_loss=photo, gate_loss=gate_loss, psnr=-10.0 * torch.log10(photo),
                     depth_variance=c["depth_variance"].mean(), ctx=c)
 
-    # ------------------------------------------------------------------------------------------ NeRFMoE.forward mirror
+    # ------------------------------------------------------------------------------------------ NeRFMoE mirrors
+    training = True
+    moe_no_batch = False
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def set_no_batch(self, mode=True):
+        """NeRFMoE.set_no_batch (models/nerf_moe.py:315-318): eval path without capacity / token dropping."""
+        self.moe_no_batch = bool(mode)
+
     def __call__(self, x, sigma_only=False, sigma_noise=None):
-        raise NotImplementedError("point-wise NeRFMoE.forward mirror: see switch_nerf_amd.rendering / next round")
+        """NeRFMoE.forward (models/nerf_moe.py:320-455): x [P, 7] = xyz(3), dir(3), image index(1) ->
+        {"outputs": [P,4] (rgb, sigma), "extras": {"moe_loss": [1], "moe_gates": [[P,1]]}}.  Routing (capacity, ranking,
+        l_aux) is over the P points of this call, exactly like one model chunk of the reference.  Inference only."""
+        expected = 7
+        if x.shape[1] != expected:
+            raise Exception("Unexpected input shape: {} (expected: {}, xyz_dim: {})".format(x.shape, expected, 3))
+        P = x.shape[0]
+        xf = x.to(torch.float32)
+        rays = torch.cat([xf[:, :6], torch.zeros(P, 2, device=self.dev)], 1).contiguous()   # o = xyz, z = 0 -> sample = xyz
+        c = self.forward_rays(rays, xf[:, 6].long().contiguous(), 1, P, 0.0, None,
+                              None if sigma_noise is None else sigma_noise.reshape(-1).to(torch.float32).contiguous(),
+                              training=self.training, no_batch=self.moe_no_batch)
+        return {"outputs": c["raw"], "extras": {"moe_loss": c["l_aux"], "moe_gates": [c["idx"].long().view(P, 1)]}}

@@ -222,7 +222,8 @@ def chain_mask_words(dtype, n_groups: int, group_stride: int) -> int:
 
 
 def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride=None, group_rows=None,
-              group_rows_clamp=None, x_gather=None, x_save=None, y_add=None, y_add_gather=None, tag=0):
+              group_rows_clamp=None, x_gather=None, x_save=None, y_add=None, y_add_gather=None, tag=0, x_scale=None,
+              x_relu=False):
     d = ChainDesc()
     d.dtype = _dt(x)
     d.tag = int(tag)
@@ -232,6 +233,7 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
     d.group_rows = _p(group_rows)
     d.group_rows_clamp = int(group_rows_clamp if group_rows_clamp is not None else d.group_stride)
     d.x, d.x_gather, d.x_save, d.y = _p(x), _p(x_gather), _p(x_save), _p(y)
+    d.x_scale, d.x_relu = _p(x_scale), int(bool(x_relu))
     d.y_add, d.y_add_gather = _p(y_add), _p(y_add_gather)
     for i, ly in enumerate(layers):
         L = d.layers[i]

@@ -1,0 +1,48 @@
+"""Mirror of the reference's rendering.render_rays (/root/reference/switch_nerf/rendering.py:15-196) for the hot-path
+configuration: no background NeRF, no cascade, fine_samples = 0 (coarse pass composited), SwitchNeRF model.
+
+    results, bg_nerf_rays_present = render_rays(nerf, None, rays, image_indices, hparams, None, None,
+                                                get_depth, get_depth_variance, get_bg_fg_rgb)
+
+Result keys follow the reference: rgb_coarse, depth_coarse, depth_variance_coarse, gate_loss_coarse
+([chunks * moe layers], rendering.py:388-390), moe_gates_coarse [N, S, 1, 1], sigma_coarse (hparams.return_sigma).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+
+def render_rays(nerf, bg_nerf, rays: torch.Tensor, image_indices: Optional[torch.Tensor], hparams, sphere_center=None,
+                sphere_radius=None, get_depth: bool = True, get_depth_variance: bool = True,
+                get_bg_fg_rgb: bool = False) -> Tuple[Dict[str, torch.Tensor], bool]:
+    if bg_nerf is not None:
+        raise NotImplementedError("background NeRF is outside the hot path (SURVEY.md section 8(f) row 4)")
+    if getattr(hparams, "fine_samples", 0) > 0:
+        raise NotImplementedError("hierarchical sampling is a 'next' row (SURVEY.md section 8(f) row 2)")
+    N = rays.shape[0]
+    S = hparams.coarse_samples
+    P = N * S
+    chunk = min(hparams.model_chunk_size, P)
+    if P % chunk:
+        raise ValueError(f"N_rays * samples ({P}) must be a multiple of model_chunk_size ({chunk})")
+    perturb = hparams.perturb if nerf.training else 0
+    pr = torch.rand(N, S, device=rays.device) if perturb > 0 else None
+    noise = None
+    if getattr(hparams, "use_sigma_noise", False) and hparams.sigma_noise_std > 0 and nerf.training:
+        noise = torch.randn(P, device=rays.device) * hparams.sigma_noise_std      # rendering.py:366
+    if image_indices is None:
+        image_indices = torch.zeros(N, dtype=torch.long, device=rays.device)
+    c = nerf.forward_rays(rays.contiguous(), image_indices, S, chunk, float(perturb), pr, noise, training=nerf.training,
+                          no_batch=nerf.moe_no_batch)
+    res = {"rgb_coarse": c["rgb"], "gate_loss_coarse": c["l_aux"]}
+    if get_depth:
+        res["depth_coarse"] = c["depth"]
+    if get_depth_variance:
+        res["depth_variance_coarse"] = c["depth_variance"]
+    if getattr(hparams, "moe_return_gates", False):
+        res["moe_gates_coarse"] = c["idx"].long().view(N, S, 1, 1)
+    if getattr(hparams, "return_sigma", False):
+        res["sigma_coarse"] = c["raw"][:, 3].view(N, S)
+    return res, False

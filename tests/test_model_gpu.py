@@ -122,3 +122,35 @@ def test_bf16_step_close_to_fp32_and_adam_moves_loss():
     assert st["loss"].item() < l0, "eight Adam steps on a fixed batch must reduce the loss"
     sd = m16.state_dict()
     assert set(sd.keys()) == set(synth.make_weights(1).keys())
+
+
+@pytest.mark.parametrize("tag,no_batch", [("unbalanced", False), ("balanced", False), ("nobatch", True)])
+def test_model_call_mirror_vs_reference_golden(tag, no_batch):
+    """SwitchNeRF.__call__ == NeRFMoE.forward on 4096 points: batched/capacity path and the eval (no-batch) path."""
+    g = np.load(os.path.join(G, f"model_fwd_{tag}.npz"))
+    m = _model(torch.float32, int(g["seed"]), float(g["gate_scale"]), batch_prioritized=not no_batch)
+    m.eval()
+    m.set_no_batch(no_batch)
+    noise = _dev(g["sigma_noise"]) if "sigma_noise" in g.files else None
+    r = m(_dev(g["x"]), sigma_noise=noise)
+    idx = r["extras"]["moe_gates"][0].cpu().numpy().reshape(-1)
+    assert (idx != g["moe_gates"].reshape(-1)).sum() == 0
+    np.testing.assert_allclose(r["outputs"].cpu().numpy(), g["outputs"], rtol=0, atol=1e-4)
+    if "moe_loss" in g.files:
+        np.testing.assert_allclose(r["extras"]["moe_loss"].cpu().numpy(), g["moe_loss"], rtol=1e-5)
+
+
+def test_render_rays_mirror_keys_and_eval():
+    from argparse import Namespace
+    from switch_nerf_amd.rendering import render_rays
+    g = np.load(os.path.join(G, "render_train_balanced.npz"))
+    m = _model(torch.float32, int(g["seed"]), float(g["gate_scale"]))
+    rays, img, _ = synth.make_rays(52, 64)
+    hp = Namespace(coarse_samples=64, fine_samples=0, model_chunk_size=1024, perturb=1.0, use_sigma_noise=True, sigma_noise_std=1.0,
+                   moe_return_gates=True, return_sigma=True)
+    m.eval()          # eval: perturb = 0 and no sigma noise, like the reference (rendering.py:32, :366)
+    res, bg = render_rays(m, None, _dev(rays), _dev(img), hp, None, None, True, True, False)
+    assert bg is False and set(res) == {"rgb_coarse", "gate_loss_coarse", "depth_coarse", "depth_variance_coarse", "moe_gates_coarse", "sigma_coarse"}
+    np.testing.assert_allclose(res["rgb_coarse"].cpu().numpy(), g["rgb"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(res["depth_coarse"].cpu().numpy(), g["depth"], rtol=1e-4, atol=1e-6)
+    assert res["gate_loss_coarse"].shape == (4,) and res["moe_gates_coarse"].shape == (64, 64, 1, 1)

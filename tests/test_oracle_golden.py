@@ -175,3 +175,14 @@ def test_composite_and_sample_pdf():
     rays = torch.from_numpy(g["rays"])
     z2 = O.sample_z(rays[:, 6:7], rays[:, 7:8], 256)
     assert np.array_equal(z2.numpy(), g["z"])
+
+
+def test_model_forward_nobatch_eval_path():
+    """Reference eval path (seqexperts + set_no_batch): no token is dropped."""
+    g = load("model_fwd_nobatch")
+    cfg = synth.BUILDING
+    p = O.params_from_numpy(synth.make_weights(int(g["seed"]), cfg, gate_scale=float(g["gate_scale"])))
+    with torch.no_grad():
+        r = O.nerf_moe_forward(p, torch.from_numpy(g["x"]), cfg, 1.0, False, None, no_batch=True)
+    assert np.array_equal(r["routing"]["idx"], g["moe_gates"].reshape(-1))
+    np.testing.assert_allclose(r["outputs"].numpy(), g["outputs"], rtol=0, atol=2e-6)
