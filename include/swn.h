@@ -172,6 +172,8 @@ typedef struct swn_chain_desc {
 } swn_chain_desc;
 
 int swn_mlp_chain(const swn_chain_desc* desc, void* stream);
+/* rows per workgroup tile for dtype (sizes the ReLU mask buffers: ceil(group_stride / rows) * n_groups * rows * 8 words) */
+int swn_chain_tile_rows(int dtype);
 
 /* Pack fp32 master weights [n_wsets][in_dim][out_dim] (the reference's ExpertMLP layout, tutel_moe_layer_nobatch.py:853)
  * into the compute copy swn_mlp_chain consumes.  transpose = 1: forward weights (N = out, K = in);

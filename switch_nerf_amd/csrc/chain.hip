@@ -5,14 +5,18 @@
 // with transposed weights and the stored ReLU masks - their backward-data passes.
 //
 // Geometry: one workgroup = 256 threads = 4 waves; wave w owns output features [64 w, 64 w + 64) of ALL rows of the
-// tile (bf16: 128 rows = 4 x 2 MFMA tiles of 32x32, 128 accumulator VGPRs; fp32 parity mode: 64 rows).
-//   * activations: one tile in LDS (64 KiB, 16-byte chunks XOR-swizzled with row&15 -> conflict-free fragment reads);
+// tile (64 rows = 2 x 2 MFMA tiles of 32x32 per wave, 64 accumulator VGPRs; SWN_BF16_BM=128 selects 128-row tiles).
+//   * activations: one tile in LDS (32 KiB bf16 / 64 KiB fp32, 16-byte chunks XOR-swizzled with row&15 ->
+//     conflict-free fragment reads);
 //   * weights: never touch LDS.  They are pre-packed (swn_pack_weights) in MFMA-fragment-major order, so that the
-//     fragment of (32 features x 16 k) is one contiguous, fully coalesced 1 KiB wave load straight into registers; a
-//     4-step register ring keeps the next fragments in flight (also across the layer boundary), served by L1/L2
-//     (an expert's 7 layers = 0.9 MB stay in the XCD's L2: workgroup b uses expert b % 8 = its XCD);
-//   * the K loop therefore has NO barrier; a layer costs two workgroup barriers (before / after the epilogue rewrites
-//     the LDS tile).  65 KiB of LDS per workgroup -> two workgroups per CU overlap each other's epilogues/write-outs.
+//     fragment of (32 features x 16 k) is one contiguous, fully coalesced 1 KiB wave load straight into registers
+//     (buffer loads: SGPR descriptor + one lane-offset VGPR + scalar step offset, no address VGPRs); a 4-step register
+//     ring keeps the next fragments in flight (also across the layer boundary), served by L1/L2 (an expert's 7 layers
+//     = 0.9 MB stay in the XCD's L2: workgroup b uses expert b % 8 = its XCD);
+//   * the K loop therefore has NO barrier and its instruction order is pinned (sched_barrier): read fragment i+1,
+//     two MFMAs on fragment i, ...; a layer costs two workgroup barriers (before / after the epilogue rewrites the LDS
+//     tile).  33 KiB of LDS and <= 168 VGPRs per workgroup -> three workgroups (12 waves) per CU overlap each other's
+//     epilogues, write-outs and weight-load latencies.
 // The MFMA is issued "transposed" (weight fragment = A operand, activation fragment = B operand): a lane ends up
 // with 4 consecutive output FEATURES of one row, so the epilogue packs them and writes the next layer's input tile
 // row-major with 8-byte LDS stores.
@@ -31,12 +35,19 @@ constexpr int ACT_BYTES = 65536;
 constexpr int RING = 4;         // weight-fragment steps in flight
 
 template <typename T> struct Cfg;
+#ifndef SWN_BF16_BM
+#define SWN_BF16_BM 64
+#endif
 template <> struct Cfg<bf16_t> {
-  static constexpr int BM = 128, MI = 4, KSTEP = 16;   // one ring step = K 16: one 16-byte fragment load per feature tile
+  static constexpr int BM = SWN_BF16_BM, MI = BM / 32, KSTEP = 16;   // one ring step = K 16: one 16-byte fragment load per feature tile
+  static constexpr int ACT = BM * 512;                 // LDS tile bytes
+  static constexpr int OCC = BM == 128 ? 2 : 3;        // workgroups per CU (= waves per SIMD) the register budget must allow
   typedef bf16x8_t wfrag_t;
 };
 template <> struct Cfg<float> {
   static constexpr int BM = 64, MI = 2, KSTEP = 8;     // one ring step = K 8: a float4 feeds four 32x32x2 MFMAs
+  static constexpr int ACT = BM * 1024;
+  static constexpr int OCC = 2;
   typedef f32x4_t wfrag_t;
 };
 
@@ -193,31 +204,50 @@ __device__ __forceinline__ void k_loop(f32x16_t (&acc)[Cfg<T>::MI][NI], typename
     };
     bf16x8_t a0 = aread(0, 0), a1;
 #define SWN_PIN() __builtin_amdgcn_sched_barrier(0)
+    if constexpr (MI == 4) {
 #pragma unroll
-    for (int ks = 0; ks < NSTEPS; ++ks) {
-      const int r = ks % RING;
-      a1 = aread(ks, 1);
-      SWN_PIN();
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a0, acc[0][1], 0, 0, 0);
-      SWN_PIN();
-      a0 = aread(ks, 2);
-      SWN_PIN();
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a1, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a1, acc[1][1], 0, 0, 0);
-      SWN_PIN();
-      a1 = aread(ks, 3);
-      SWN_PIN();
-      acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a0, acc[2][0], 0, 0, 0);
-      acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a0, acc[2][1], 0, 0, 0);
-      SWN_PIN();
-      if (ks + 1 < NSTEPS) a0 = aread(ks + 1, 0);
-      SWN_PIN();
-      acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a1, acc[3][0], 0, 0, 0);
-      acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a1, acc[3][1], 0, 0, 0);
-      SWN_PIN();
-      refill(ks, r);
-      SWN_PIN();
+      for (int ks = 0; ks < NSTEPS; ++ks) {
+        const int r = ks % RING;
+        a1 = aread(ks, 1);
+        SWN_PIN();
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a0, acc[0][1], 0, 0, 0);
+        SWN_PIN();
+        a0 = aread(ks, 2);
+        SWN_PIN();
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a1, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a1, acc[1][1], 0, 0, 0);
+        SWN_PIN();
+        a1 = aread(ks, 3);
+        SWN_PIN();
+        acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a0, acc[2][0], 0, 0, 0);
+        acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a0, acc[2][1], 0, 0, 0);
+        SWN_PIN();
+        if (ks + 1 < NSTEPS) a0 = aread(ks + 1, 0);
+        SWN_PIN();
+        acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a1, acc[3][0], 0, 0, 0);
+        acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a1, acc[3][1], 0, 0, 0);
+        SWN_PIN();
+        refill(ks, r);
+        SWN_PIN();
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < NSTEPS; ++ks) {
+        const int r = ks % RING;
+        a1 = aread(ks, 1);
+        SWN_PIN();
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a0, acc[0][1], 0, 0, 0);
+        SWN_PIN();
+        if (ks + 1 < NSTEPS) a0 = aread(ks + 1, 0);
+        SWN_PIN();
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a1, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a1, acc[1][1], 0, 0, 0);
+        SWN_PIN();
+        refill(ks, r);
+        SWN_PIN();
+      }
     }
 #undef SWN_PIN
   } else {
@@ -315,13 +345,13 @@ __device__ __forceinline__ void epilogue_body(f32x16_t (&acc)[Cfg<T>::MI][NI], c
   }
 }
 template <typename T, int TAG>
-__global__ __launch_bounds__(NT, 2) void chain_kernel(const ChainArgs args) {
+__global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = Cfg<T>::BM, MI = Cfg<T>::MI, KSTEP = Cfg<T>::KSTEP;
   typedef typename Cfg<T>::wfrag_t wfrag_t;
   const swn_chain_desc& d = args.d;
   char* act = smem;
-  char* bias_lds = smem + ACT_BYTES;  // 1 KiB
+  char* bias_lds = smem + Cfg<T>::ACT;  // 1 KiB
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -514,6 +544,8 @@ extern "C" int swn_pack_weights(const float* master, void* out, int dtype, int n
   return 0;
 }
 
+extern "C" int swn_chain_tile_rows(int dtype) { return dtype == SWN_BF16 ? Cfg<bf16_t>::BM : Cfg<float>::BM; }
+
 extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   SWN_CHECK(desc != nullptr, "swn_mlp_chain: null descriptor");
   const swn_chain_desc& d = *desc;
@@ -534,12 +566,12 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   SWN_CHECK(d.x != nullptr && d.y != nullptr, "swn_mlp_chain: x / y must not be null");
   ChainArgs a;
   a.d = d;
-  const int bm = d.dtype == SWN_BF16 ? 128 : 64;
+  const int bm = d.dtype == SWN_BF16 ? Cfg<bf16_t>::BM : 64;
   a.tiles_per_group = cdiv(d.group_rows ? (d.group_rows_clamp < d.group_stride ? d.group_rows_clamp : d.group_stride) : d.group_stride, bm);
   if (!d.group_rows) a.d.group_rows_clamp = d.group_stride;
   const long grid = (long)a.tiles_per_group * d.n_groups;
   SWN_CHECK(grid > 0 && grid < (1L << 31), "swn_mlp_chain: grid %ld out of range", grid);
-  const int lds = ACT_BYTES + 1024;
+  const int lds = (d.dtype == SWN_BF16 ? Cfg<bf16_t>::ACT : Cfg<float>::ACT) + 1024;
   SWN_CHECK(d.tag >= 0 && d.tag <= 6, "swn_mlp_chain: tag %d not in [0,6]", d.tag);
   const void* fn = nullptr;
 #define SWN_PICK(TAGV)                                                                         \

@@ -210,15 +210,14 @@ class Layer:
 
 
 def chain_tile_rows(dtype) -> int:
-    return 128 if dtype == torch.bfloat16 else 64
+    return _lib.load().swn_chain_tile_rows(BF16 if dtype == torch.bfloat16 else F32)
 
 
 def chain_mask_words(dtype, n_groups: int, group_stride: int) -> int:
-    """uint32 words per layer mask buffer for a chain launch with this geometry."""
+    """uint32 words per layer mask buffer for a chain launch with this geometry (1 bit per row x 256 features)."""
     bm = chain_tile_rows(dtype)
     tiles = (group_stride + bm - 1) // bm
-    mi = 2 if dtype == torch.bfloat16 else 1
-    return tiles * n_groups * 8 * mi * 64
+    return tiles * n_groups * bm * 8
 
 
 def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride=None, group_rows=None,
