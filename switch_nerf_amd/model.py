@@ -79,6 +79,9 @@ class SwitchNeRF:
         self._bufs = {}
         self.profile = False          # bench.py: record HIP events around the major launches
         self.events: Dict[str, list] = {}
+        # side HIP stream: the HBM-bound expert weight-gradient GEMMs overlap with the rest of the backward pass
+        self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
+        self.overlap = True
 
     @contextlib.contextmanager
     def _timed(self, name):
@@ -320,11 +323,25 @@ class SwitchNeRF:
             o.mlp_chain(dout, bl, dx, n_groups=ng, n_wsets=E, group_stride=cap, group_rows=c["counts_flat"],
                         group_rows_clamp=cap, x_gather=c["perm"].view(-1), x_save=dz[L - 1],
                         y_add=dz[skip_l] if skip_l is not None else None, tag=2)
-        with self._timed("expert_wgrad"):
+        def expert_wgrads():
             for l in range(L):
                 a = c["xs"] if l == 0 else c["saves"][l - 1]
                 o.wgrad(a, dz[l], g[f"exp{l}.w"], g[f"exp{l}.b"], n_groups=ng, n_wsets=E, group_stride=cap,
                         group_rows=c["counts_flat"], group_rows_clamp=cap, n_splits=max(1, min(512 // ng, cap // 2048)), tag=1)
+        side_done = None
+        if self.overlap and self.side is not None and not self.profile:
+            # independent of everything that follows (they only read the saved activations / dZ and write their own
+            # gradient slices): run them on the side stream, join before Adam
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ready)
+                expert_wgrads()
+                side_done = torch.cuda.Event()
+                side_done.record()
+        else:
+            with self._timed("expert_wgrad"):
+                expert_wgrads()
         # gate backward (softmax / router / LayerNorm) including the l_aux term
         coef = (d_laux * (E / float(seg_tokens * seg_tokens))).to(torch.float32).contiguous()
         dg = o.gate_bwd(c["g"], self.p["ln.w"], self.p["ln.b"], self.p["wg"], c["gates"], c["idx"], dgmax, c["stats"],
@@ -337,6 +354,8 @@ class SwitchNeRF:
         o.wgrad(c["a1"], dg, g["gate1.w"].view(1, G, G), g["gate1.b"].view(1, G), n_splits=nsp)
         o.wgrad(c["h0"], dza1, g["gate0.w"].view(1, M, G), g["gate0.b"].view(1, G), n_splits=nsp)
         o.wgrad(c["pe"], dh0, g["xyz.w"].view(1, self.KP, M), g["xyz.b"].view(1, M), n_splits=nsp)
+        if side_done is not None:
+            torch.cuda.current_stream().wait_event(side_done)
 
     # ------------------------------------------------------------------------------------------ training step
     def train_step(self, rgbs, rays, image_indices, n_samples, seg_tokens, perturb=1.0, perturb_rand=None,

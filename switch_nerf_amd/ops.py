@@ -256,10 +256,11 @@ def wgrad(a, b, dw, db=None, n_groups=1, n_wsets=1, group_stride=None, group_row
     ws, ws_bytes = None, 0
     if use_workspace:
         ws_bytes = int(n_groups) * int(n_splits) * (m_dim * n_dim + n_dim) * 4
-        ws = _wgrad_ws.get(a.device)
+        key = (a.device, torch.cuda.current_stream().cuda_stream)     # one workspace per stream: launches may overlap
+        ws = _wgrad_ws.get(key)
         if ws is None or ws.numel() < ws_bytes:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
-            _wgrad_ws[a.device] = ws
+            _wgrad_ws[key] = ws
         ws_bytes = ws.numel()
     call("swn_wgrad", _p(a), _p(b), _dt(a), m_dim, n_dim, int(n_groups), int(n_wsets), gs, _p(group_rows),
          int(group_rows_clamp if group_rows_clamp is not None else gs), _p(dw), _p(db), int(n_splits), int(tag), _p(ws), ws_bytes, _stream())
