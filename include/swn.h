@@ -45,6 +45,23 @@ int swn_sample_pe(const float* rays, const float* t_steps, const float* perturb_
                   int n_rays, int n_samples, int l_xyz, int l_dir, int dtype,
                   float* z_out, void* pe_xyz, int pe_stride, void* pe_dir, int dir_stride, void* stream);
 
+/* same encoding for caller-supplied depths z[N,S] (fine pass: xyz_fine_fn, rendering.py:246) */
+int swn_pe_from_z(const float* rays, const float* z, int n_rays, int n_samples, int l_xyz, int dtype, void* pe_xyz,
+                  int pe_stride, void* stream);
+
+/* ---- hierarchical sampling (rendering.py:587-637 _sample_pdf/_sample_cdf; :419-433 coarse+fine merge) ---------
+ * z_coarse[N,S], weights[N,S] (coarse compositing weights; bins = mid points, weights[:,1:-1] as in :238-241);
+ * u[N,F] uniform samples (NULL = torch.linspace(0,1,F), the deterministic eval branch); z_fine[N,F] out.         */
+int swn_sample_pdf(const float* z_coarse, const float* weights, const float* u, int n_rays, int n_coarse, int n_fine,
+                   float* z_fine, void* stream);
+/* z_out[N,F+S] = sort(cat[z_fine, z_coarse]); order[N,F+S] = source index into the concatenation (ties keep cat order);
+ * raw_out[N,F+S,4] = cat[raw_fine, raw_coarse] gathered by order.  F + S <= 1024.                                */
+int swn_merge_samples(const float* z_fine, const float* z_coarse, const float* raw_fine, const float* raw_coarse,
+                      int n_rays, int n_fine, int n_coarse, float* z_out, int32_t* order, float* raw_out, void* stream);
+/* backward of the gather: d_fine[N,F,4], d_coarse[N,S,4] <- d_raw[N,F+S,4] */
+int swn_unmerge_grad(const float* d_raw, const int32_t* order, int n_rays, int n_fine, int n_coarse, float* d_fine,
+                     float* d_coarse, void* stream);
+
 /* ---- gate: LayerNorm + fp32 router GEMV + softmax + top-1 ----------------------------------------------------
  * replaces nn.LayerNorm (models/nerf_moe.py:370-372), TopKGate logits/softmax
  * (modules/tutel_moe_ext/tutel_moe_layer_nobatch.py:105-126) and topk/gates_s (tutel_fast_dispatch.py:177-182).

@@ -52,7 +52,7 @@ def building_model_cfg(cfg):
 
 
 def make_hparams(cfg, capacity_factor=1.0, bpr=True, coarse=256, chunk=131072, perturb=0.0,
-                 sigma_noise=False):
+                 sigma_noise=False, fine=0):
     h = Namespace(
         container_path=None, use_cascade=False, train_mega_nerf=None, use_moe=True, ckpt_path=None,
         pos_xyz_dim=cfg["pos_xyz_dim"], pos_dir_dim=cfg["pos_dir_dim"], appearance_dim=cfg["appearance_dim"],
@@ -64,7 +64,7 @@ def make_hparams(cfg, capacity_factor=1.0, bpr=True, coarse=256, chunk=131072, p
         parallel_env=Namespace(global_rank=0), moe_return_gates=True, moe_return_gate_logits=False,
         use_moe_external_gate=True, use_gate_input_norm=True, amp_use_bfloat16=False,
         nerfmoe_class_name="NeRFMoE", model=building_model_cfg(cfg), perturb=perturb,
-        coarse_samples=coarse, fine_samples=0, model_chunk_size=chunk, use_sigma_noise=sigma_noise,
+        coarse_samples=coarse, fine_samples=fine, model_chunk_size=chunk, use_sigma_noise=sigma_noise,
         sigma_noise_std=1.0, return_pts=False, return_pts_rgb=False, return_pts_alpha=False, return_sigma=True,
         return_alpha=False, bg_use_moe=False, use_load_importance_loss=False, white_bkgd=False,
         use_random_background_color=False, expertmlp2seqexperts=False, bg_use_cfg=False,
@@ -229,6 +229,44 @@ def gen_render():
         save(f"render_train_{tag}", **out)
 
 
+def gen_render_fine():
+    print("[G5f] hierarchical render_rays / training step (64 rays x (64 coarse + 96 fine), chunk 1024), fwd + grads")
+    cfg = synth.BUILDING
+    for tag, perturb in (("det", 0.0), ("perturbed", 1.0)):
+        sd = synth.make_weights(61, cfg, gate_scale=0.02)
+        N, S, Fn, chunk = 64, 64, 96, 1024
+        nerf, h = build_reference_model(cfg, sd, coarse=S, chunk=chunk, perturb=perturb, sigma_noise=False, fine=Fn)
+        rays, img, rgbs = synth.make_rays(62, N)
+        nerf.train()
+        # the reference draws rand_like(z_vals) (rendering.py:583) then torch.rand(N, fine) (:608): replay the stream
+        torch.manual_seed(77)
+        pr = torch.rand(N, S)
+        fu = torch.rand(N, Fn)
+        torch.manual_seed(77)
+        res, _ = rendering.render_rays(nerf, None, torch.from_numpy(rays), torch.from_numpy(img), h, None, None,
+                                       get_depth=True, get_depth_variance=True, get_bg_fg_rgb=False)
+        assert "rgb_coarse" not in res
+        photo = torch.nn.functional.mse_loss(res["rgb_fine"], torch.from_numpy(rgbs))
+        gate_loss = (res["gate_loss_fine"].mean() + res["gate_loss_coarse"].mean()) / 2.0       # runner.py:1104-1111
+        loss = photo + 5e-4 * gate_loss
+        loss.backward()
+        out = dict(seed=61, gate_scale=0.02, N=N, S=S, F=Fn, chunk=chunk, perturb=perturb, rgb=res["rgb_fine"].detach().numpy(),
+                   depth=res["depth_fine"].numpy(), depth_variance=res["depth_variance_fine"].numpy(),
+                   sigma_coarse=res["sigma_coarse"].detach().numpy(), sigma_fine=res["sigma_fine"].detach().numpy(),
+                   gate_loss_coarse=res["gate_loss_coarse"].detach().numpy(),
+                   gate_loss_fine=res["gate_loss_fine"].detach().numpy(),
+                   moe_gates_coarse=res["moe_gates_coarse"].numpy().astype(np.int32).reshape(N, S),
+                   moe_gates_fine=res["moe_gates_fine"].numpy().astype(np.int32).reshape(N, Fn),
+                   loss=loss.detach().numpy(), photo=photo.detach().numpy())
+        if perturb > 0:
+            out["perturb_rand"], out["fine_u"] = pr.numpy(), fu.numpy()
+        for n, p in nerf.named_parameters():
+            g_ = p.grad
+            out["gsum__" + n] = synth.checksum(g_.numpy())
+            out["gslice__" + n] = g_.numpy().reshape(-1)[:: max(1, g_.numel() // 499)][:499]
+        save(f"render_train_fine_{tag}", **out)
+
+
 # ------------------------------------------------------------------------------------------ G5b compositing + sample_pdf
 def gen_composite():
     print("[G5b] compositing / _sample_pdf on raw tensors")
@@ -270,7 +308,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     todo = dict(routing=gen_routing, pe=gen_pe, moe=gen_moe_layer, model=gen_model_forward, nobatch=gen_model_forward_nobatch,
-                render=gen_render, composite=gen_composite)
+                render=gen_render, fine=gen_render_fine, composite=gen_composite)
     for k, fn in todo.items():
         if a.only and k not in a.only.split(","):
             continue

@@ -258,19 +258,13 @@ def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_fine: int, u: Option
     return bin_b + (u - cdf_b) / denom * (bin_a - bin_b)
 
 
-def render_rays(p, rays: torch.Tensor, image_indices: torch.Tensor, cfg: dict, n_samples: int, chunk: int,
-                capacity_factor: float = 1.0, batch_prioritized: bool = True, perturb: float = 0.0,
-                perturb_rand: Optional[torch.Tensor] = None, sigma_noise: Optional[torch.Tensor] = None,
-                routings: Optional[list] = None):
-    """render_rays + _get_results + _inference for the coarse-only (fine_samples = 0) configuration,
-    rendering.py:15-196, :199-274, :277-494.  Points are evaluated in chunks of `chunk` (= model_chunk_size)
-    and the routing (capacity, ranking, l_aux) is per chunk, exactly as the reference's loop :354-383."""
-    N = rays.shape[0]
-    o, d, near, far = rays[:, 0:3], rays[:, 3:6], rays[:, 6:7], rays[:, 7:8]
-    z = sample_z(near, far, n_samples, perturb, perturb_rand)
-    xyz = o[:, None, :] + d[:, None, :] * z[:, :, None]                                      # :90
-    pts = torch.cat([xyz.reshape(-1, 3), d[:, None, :].expand(N, n_samples, 3).reshape(-1, 3),
-                     image_indices.view(N, 1, 1).expand(N, n_samples, 1).reshape(-1, 1).to(xyz.dtype)], 1)  # :311-360
+def _eval_points(p, rays, image_indices, z, cfg, chunk, capacity_factor, batch_prioritized, sigma_noise, routings):
+    """The chunked network evaluation of _inference (rendering.py:311-383): routing (capacity, ranking, l_aux) is per chunk."""
+    N, S = z.shape
+    o, d = rays[:, 0:3], rays[:, 3:6]
+    xyz = o[:, None, :] + d[:, None, :] * z[:, :, None]                                      # :90 / xyz_fine_fn :103
+    pts = torch.cat([xyz.reshape(-1, 3), d[:, None, :].expand(N, S, 3).reshape(-1, 3),
+                     image_indices.view(N, 1, 1).expand(N, S, 1).reshape(-1, 1).to(xyz.dtype)], 1)  # :311-360
     outs, losses, routes = [], [], []
     for ci, i in enumerate(range(0, pts.shape[0], chunk)):
         sn = None if sigma_noise is None else sigma_noise[i:i + chunk]
@@ -279,24 +273,57 @@ def render_rays(p, rays: torch.Tensor, image_indices: torch.Tensor, cfg: dict, n
         outs.append(r["outputs"])
         losses.append(r["moe_loss"])
         routes.append(r["routing"])
-    out = torch.cat(outs, 0).view(N, n_samples, 4)
+    return torch.cat(outs, 0).view(N, S, 4), torch.cat(losses, 0), routes
+
+
+def render_rays(p, rays: torch.Tensor, image_indices: torch.Tensor, cfg: dict, n_samples: int, chunk: int,
+                capacity_factor: float = 1.0, batch_prioritized: bool = True, perturb: float = 0.0,
+                perturb_rand: Optional[torch.Tensor] = None, sigma_noise: Optional[torch.Tensor] = None,
+                routings: Optional[list] = None, fine_samples: int = 0, fine_u: Optional[torch.Tensor] = None,
+                sigma_noise_fine: Optional[torch.Tensor] = None):
+    """render_rays + _get_results + _inference, rendering.py:15-196, :199-274, :277-494 (no background model, no cascade).
+    Points are evaluated in chunks of `chunk` (= model_chunk_size) and the routing (capacity, ranking, l_aux) is per
+    chunk, exactly as the reference's loop :354-383.
+    fine_samples > 0: the hierarchical pass :236-268 - fine depths drawn from the detached coarse weights (fine_u = the
+    U[0,1) tensor of _sample_cdf :608, None -> the deterministic linspace), the network evaluated on them, both sample
+    sets sort-merged :419-433 (stable sort here; the reference's torch.sort is only defined up to ties) and composited."""
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    z = sample_z(near, far, n_samples, perturb, perturb_rand)
+    out, gl, routes = _eval_points(p, rays, image_indices, z, cfg, chunk, capacity_factor, batch_prioritized, sigma_noise,
+                                   routings)
     comp = composite(out[..., :3], out[..., 3], z)
-    return dict(rgb_coarse=comp["rgb"], depth_variance_coarse=comp["depth_variance"], depth_coarse=comp["depth"],
-                weights_coarse=comp["weights"], gate_loss_coarse=torch.cat(losses, 0), sigma_coarse=out[..., 3],
-                raw=out, z_vals=z, routings=routes)
+    res = dict(rgb_coarse=comp["rgb"], depth_variance_coarse=comp["depth_variance"], depth_coarse=comp["depth"],
+               weights_coarse=comp["weights"], gate_loss_coarse=gl, sigma_coarse=out[..., 3], raw=out, z_vals=z,
+               routings=routes)
+    if fine_samples > 0:
+        z_mid = 0.5 * (z[:, :-1] + z[:, 1:])                                                 # :238
+        z_fine = sample_pdf(z_mid, comp["weights"][:, 1:-1].detach(), fine_samples, fine_u)  # :240
+        out_f, gl_f, routes_f = _eval_points(p, rays, image_indices, z_fine, cfg, min(chunk, z_fine.numel()), capacity_factor,
+                                             batch_prioritized, sigma_noise_fine, None)
+        z_all, order = torch.sort(torch.cat([z_fine, z], -1), dim=-1, stable=True)              # :421
+        raw_all = torch.gather(torch.cat([out_f, out], 1), 1, order[:, :, None].expand(-1, -1, 4))   # :422-430
+        comp_f = composite(raw_all[..., :3], raw_all[..., 3], z_all)
+        res.update(rgb_fine=comp_f["rgb"], depth_fine=comp_f["depth"], depth_variance_fine=comp_f["depth_variance"],
+                   gate_loss_fine=gl_f, sigma_fine=out_f[..., 3], z_fine=z_fine, z_merged=z_all, order=order,
+                   routings_fine=routes_f)
+    return res
 
 
 def training_step(p, rays, image_indices, rgbs, cfg, n_samples, chunk, moe_l_aux_wt=5e-4, **kw):
     """Runner._training_step, runner.py:1077-1123 + loss assembly :646-658:
-    loss = mse(rgb, rgbs) + moe_l_aux_wt * mean(gate_loss)."""
+    loss = mse(rgb, rgbs) + moe_l_aux_wt * gate_loss, gate_loss = mean(gate_loss_coarse), or with a fine pass the
+    average of the fine and coarse means (:1104-1111)."""
     res = render_rays(p, rays, image_indices, cfg, n_samples, chunk, **kw)
-    photo = F.mse_loss(res["rgb_coarse"], rgbs, reduction="mean")
+    typ = "fine" if "rgb_fine" in res else "coarse"                                            # :1094
+    photo = F.mse_loss(res[f"rgb_{typ}"], rgbs, reduction="mean")
     gate_loss = res["gate_loss_coarse"].mean()
+    if typ == "fine":
+        gate_loss = (res["gate_loss_fine"].mean() + gate_loss) / 2
     loss = photo + moe_l_aux_wt * gate_loss
     with torch.no_grad():
         psnr = -10.0 * torch.log10(photo.detach())                                             # metrics.py:8-10
     return dict(loss=loss, photo_loss=photo, gate_loss=gate_loss, psnr=psnr,
-                depth_variance=res["depth_variance_coarse"].mean(), results=res)
+                depth_variance=res[f"depth_variance_{typ}"].mean(), results=res)
 
 
 def adam_step(param: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float,

@@ -28,6 +28,10 @@ SIGNATURES = {
     "swn_version": [],
     "swn_mfma_probe": [vp, vp],
     "swn_sample_pe": [vp, vp, vp, f32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp],
+    "swn_pe_from_z": [vp, vp, i32, i32, i32, i32, vp, i32, vp],
+    "swn_sample_pdf": [vp, vp, vp, i32, i32, i32, vp, vp],
+    "swn_merge_samples": [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp],
+    "swn_unmerge_grad": [vp, vp, i32, i32, i32, vp, vp, vp],
     "swn_gate_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
     "swn_gate_bwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp],
     "swn_route_top1": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp],

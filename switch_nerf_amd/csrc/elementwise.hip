@@ -79,15 +79,15 @@ template <typename T, int LMAX>
 __global__ __launch_bounds__(256) void sample_pe_kernel(const float* __restrict__ rays, const float* __restrict__ tsteps,
                                                         const float* __restrict__ prand, float perturb, int n_rays,
                                                         int S, int L, float* __restrict__ z_out, T* __restrict__ pe,
-                                                        int pe_stride) {
+                                                        int pe_stride, const float* __restrict__ z_in) {
 #pragma clang fp contract(off)
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
   if (p >= (long)n_rays * S) return;
   const int ray = (int)(p / S), s = (int)(p - (long)ray * S);
   const float* r = rays + (long)ray * 8;
   const float near = r[6], far = r[7];
-  float z = z_of(near, far, tsteps[s]);
-  if (perturb > 0.f && prand) {  // rendering.py:573-584
+  float z = z_in ? z_in[p] : z_of(near, far, tsteps[s]);      // z_in: depths supplied by the caller (fine pass)
+  if (!z_in && perturb > 0.f && prand) {  // rendering.py:573-584
     const float zp = s > 0 ? z_of(near, far, tsteps[s - 1]) : z;
     const float zn = s < S - 1 ? z_of(near, far, tsteps[s + 1]) : z;
     const float lower = s > 0 ? 0.5f * (zp + z) : z;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void sample_pe_kernel(const float* __restrict_
     const float span = (upper - lower) * pr;
     z = lower + span;
   }
-  z_out[p] = z;
+  if (z_out) z_out[p] = z;
   float v[8 + 6 * LMAX + 8];
   float x[3];
 #pragma unroll
@@ -865,10 +865,10 @@ extern "C" int swn_sample_pe(const float* rays, const float* t_steps, const floa
   const int blocks = cdiv(P, 256);
   if (dtype == SWN_BF16)
     hipLaunchKernelGGL((sample_pe_kernel<bf16_t, 12>), dim3(blocks), dim3(256), 0, as_stream(stream), rays, t_steps,
-                       perturb_rand, perturb, n_rays, n_samples, l_xyz, z_out, (bf16_t*)pe_xyz, pe_stride);
+                       perturb_rand, perturb, n_rays, n_samples, l_xyz, z_out, (bf16_t*)pe_xyz, pe_stride, (const float*)nullptr);
   else
     hipLaunchKernelGGL((sample_pe_kernel<float, 12>), dim3(blocks), dim3(256), 0, as_stream(stream), rays, t_steps,
-                       perturb_rand, perturb, n_rays, n_samples, l_xyz, z_out, (float*)pe_xyz, pe_stride);
+                       perturb_rand, perturb, n_rays, n_samples, l_xyz, z_out, (float*)pe_xyz, pe_stride, (const float*)nullptr);
   SWN_LAUNCH_CHECK();
   if (pe_dir) {
     SWN_CHECK(dir_stride >= 3 + 6 * l_dir, "swn_sample_pe: dir_stride too small");
@@ -880,6 +880,26 @@ extern "C" int swn_sample_pe(const float* rays, const float* t_steps, const floa
                          n_rays, l_dir, (float*)pe_dir, dir_stride);
     SWN_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+/* positional encoding of xyz = o + d * z for caller-supplied depths z[N,S] (the fine pass: rendering.py:246 xyz_fine_fn) */
+extern "C" int swn_pe_from_z(const float* rays, const float* z, int n_rays, int n_samples, int l_xyz, int dtype, void* pe_xyz,
+                             int pe_stride, void* stream) {
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_pe_from_z: bad dtype");
+  SWN_CHECK(rays && z && pe_xyz, "swn_pe_from_z: null pointer");
+  SWN_CHECK(l_xyz >= 0 && l_xyz <= 12, "swn_pe_from_z: frequencies must be <= 12");
+  const int epc = dtype == SWN_BF16 ? 8 : 4;
+  SWN_CHECK(pe_stride >= 3 + 6 * l_xyz && pe_stride % epc == 0, "swn_pe_from_z: pe_stride %d too small / unaligned", pe_stride);
+  const long P = (long)n_rays * n_samples;
+  const int blocks = cdiv(P, 256);
+  if (dtype == SWN_BF16)
+    hipLaunchKernelGGL((sample_pe_kernel<bf16_t, 12>), dim3(blocks), dim3(256), 0, as_stream(stream), rays, (const float*)nullptr,
+                       (const float*)nullptr, 0.f, n_rays, n_samples, l_xyz, (float*)nullptr, (bf16_t*)pe_xyz, pe_stride, z);
+  else
+    hipLaunchKernelGGL((sample_pe_kernel<float, 12>), dim3(blocks), dim3(256), 0, as_stream(stream), rays, (const float*)nullptr,
+                       (const float*)nullptr, 0.f, n_rays, n_samples, l_xyz, (float*)nullptr, (float*)pe_xyz, pe_stride, z);
+  SWN_LAUNCH_CHECK();
   return 0;
 }
 

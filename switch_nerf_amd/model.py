@@ -218,11 +218,39 @@ class SwitchNeRF:
 
     # ------------------------------------------------------------------------------------------ forward
     def forward_rays(self, rays, image_indices, n_samples, seg_tokens, perturb=0.0, perturb_rand=None, sigma_noise=None,
-                     training=True, routing_override=None, no_batch=False):
-        """Coarse pass of render_rays (fine_samples = 0).  Returns a context dict holding every tensor the backward
-        needs and the rendered results."""
+                     training=True, routing_override=None, no_batch=False, z_in=None, pe_dir=None, tag="c",
+                     want_weights=False, composite=True):
+        """One pass of render_rays' _inference (rendering.py:277-494) over N rays x n_samples points: sampling (or the
+        caller's depths z_in for the fine pass), positional encoding, the network, and (optionally) compositing.
+        Returns a context dict holding every tensor the backward needs and the rendered results."""
         o, dt, dev = ops, self.dtype, self.dev
         N, S = rays.shape[0], n_samples
+        if z_in is None:
+            t_steps = torch.linspace(0, 1, S, dtype=torch.float32).to(dev)    # computed on the host like the reference's CPU path
+            z, pe, pe_dir = o.sample_pe(rays, t_steps, perturb_rand, perturb, S, self.cfg["pos_xyz_dim"],
+                                        self.cfg["pos_dir_dim"], dt, self.KP, self.DP)
+        else:
+            z = z_in
+            pe = o.pe_from_z(rays, z_in, self.cfg["pos_xyz_dim"], dt, self.KP)      # xyz_fine_fn, rendering.py:103
+            if pe_dir is None:
+                pe_dir = self._dir_pe(rays)
+        c = self._net_forward(pe, pe_dir, image_indices, N, S, seg_tokens, sigma_noise, routing_override, no_batch, tag)
+        c["z"] = z
+        if composite:
+            c["rgb"], c["depth"], c["depth_variance"], c["weights"] = o.composite_fwd(c["raw"], c["z"], want_weights=want_weights)
+        return c
+
+    def _dir_pe(self, rays):
+        """PE of the ray directions only (per ray)."""
+        N = rays.shape[0]
+        _, _, pe_dir = ops.sample_pe(rays, torch.zeros(1, device=self.dev), None, 0.0, 1, self.cfg["pos_xyz_dim"],
+                                     self.cfg["pos_dir_dim"], self.dtype, self.KP, self.DP)
+        return pe_dir
+
+    def _net_forward(self, pe, pe_dir, image_indices, N, S, seg_tokens, sigma_noise, routing_override, no_batch, tag):
+        """NeRFMoE.forward over the N*S points whose encodings are in `pe` (row-major, ray-major): front chain, gate,
+        routing, expert chain, tail chain, heads -> c["raw"] [N*S, 4]."""
+        o, dt, dev = ops, self.dtype, self.dev
         P = N * S
         M, E, L, G, H2 = self.M, self.E, self.L, self.G, self.H2
         assert P % seg_tokens == 0, "points must be a multiple of the segment (model chunk) size"
@@ -230,15 +258,14 @@ class SwitchNeRF:
         cap = int(self.cf * ((seg_tokens + E - 1) // E))     # tutel_fast_dispatch.py:211
         if no_batch:        # eval path (apply_on_expert_fn_nobatch): nothing is dropped == a capacity nothing exceeds
             cap = seg_tokens
-        c = dict(N=N, S=S, P=P, n_seg=n_seg, cap=cap, seg_tokens=seg_tokens)
-        t_steps = torch.linspace(0, 1, S, dtype=torch.float32).to(dev)      # computed on the host like the reference's CPU path
-        c["z"], c["pe"], pe_dir = o.sample_pe(rays, t_steps, perturb_rand, perturb, S, self.cfg["pos_xyz_dim"],
-                                              self.cfg["pos_dir_dim"], dt, self.KP, self.DP)
+        c = dict(N=N, S=S, P=P, n_seg=n_seg, cap=cap, seg_tokens=seg_tokens, tag=tag, image_indices=image_indices)
+        c["pe"], c["pe_dir"] = pe, pe_dir
+        _b = lambda name, shape, dtype: self._buf(tag + ":" + name, shape, dtype)
         # ---- front chain: PE -> xyz -> gate MLP
-        c["h0"] = self._buf("h0", (P, M), dt)
-        c["a1"] = self._buf("a1", (P, G), dt)
-        c["g"] = self._buf("g", (P, G), dt)
-        c["m_a1"] = self._buf("m_a1", (o.chain_mask_words(dt, 1, P),), torch.int32)
+        c["h0"] = _b("h0", (P, M), dt)
+        c["a1"] = _b("a1", (P, G), dt)
+        c["g"] = _b("g", (P, G), dt)
+        c["m_a1"] = _b("m_a1", (o.chain_mask_words(dt, 1, P),), torch.int32)
         o.mlp_chain(c["pe"], [o.Layer(self.wf["xyz"], self.p["xyz.b"].view(1, M), save=c["h0"]),
                               o.Layer(self.wf["gate0"], self.p["gate0.b"].view(1, G), relu=1, mask=c["m_a1"], save=c["a1"]),
                               o.Layer(self.wf["gate1"], self.p["gate1.b"].view(1, G))], c["g"], tag=3)
@@ -254,11 +281,11 @@ class SwitchNeRF:
         ng = n_seg * E
         c["rows"], c["ng"] = rows, ng
         c["counts_flat"] = c["counts"].view(-1)
-        c["xs"] = self._buf("xs", (rows, M), dt)
-        c["eo"] = self._buf("eo", (rows, M), dt)
-        c["saves"] = [self._buf(f"save{l}", (rows, M), dt) for l in range(L - 1)]
+        c["xs"] = _b("xs", (rows, M), dt)
+        c["eo"] = _b("eo", (rows, M), dt)
+        c["saves"] = [_b(f"save{l}", (rows, M), dt) for l in range(L - 1)]
         nw = o.chain_mask_words(dt, ng, cap)
-        c["masks"] = [self._buf(f"mask{l}", (nw,), torch.int32) for l in range(L - 1)]
+        c["masks"] = [_b(f"mask{l}", (nw,), torch.int32) for l in range(L - 1)]
         skips = set(self.cfg["skips"])
         layers = [o.Layer(self.wf[f"exp{l}"], self.p[f"exp{l}.b"], relu=1 if l < L - 1 else 0, skip=(l in skips),
                           save=c["saves"][l] if l < L - 1 else None, mask=c["masks"][l] if l < L - 1 else None)
@@ -272,27 +299,31 @@ class SwitchNeRF:
         c["c_ray"] = torch.addmm(self.p["l2.b"], feat, self.p["l2r.w"]).contiguous()
         # ---- tail chain.  Its input load IS the combine: rows gathered from the expert output through tok2row, scaled by
         # the gate value, ReLU'd (dropped tokens -> zero rows) and saved as y;  then layer "1" -> layer "2" (+ per-ray bias)
-        c["y"] = self._buf("y", (P, M), dt)
-        c["h1"] = self._buf("h1", (P, M), dt)
-        c["h2"] = self._buf("h2", (P, H2), dt)
+        c["y"] = _b("y", (P, M), dt)
+        c["h1"] = _b("h1", (P, M), dt)
+        c["h2"] = _b("h2", (P, H2), dt)
         o.mlp_chain(c["eo"], [o.Layer(self.wf["l1"], self.p["l1.b"].view(1, M), save=c["h1"]),
                               o.Layer(self.wf["l2h"], None, relu=1, rowbias=c["c_ray"], rows_per_bias=S)], c["h2"],
                     group_stride=P, x_gather=c["tok2row"], x_save=c["y"], x_scale=c["gmax"], x_relu=True, tag=4)
-        # ---- heads + compositing
+        # ---- heads
         c["raw"] = o.heads_fwd(c["y"], c["h2"], self.p["sigma.w"], self.p["sigma.b"], self.p["color.w"], self.p["color.b"],
                                sigma_noise)
-        c["rgb"], c["depth"], c["depth_variance"], _ = o.composite_fwd(c["raw"], c["z"])
         return c
 
     # ------------------------------------------------------------------------------------------ backward
     def backward(self, c, d_rgb, d_laux):
         """Accumulates parameter gradients into self.grad given dL/d rgb [N,3] and dL/d l_aux[seg] (scalar each)."""
+        d_raw = ops.composite_bwd(c["raw"], c["z"], d_rgb)
+        self.backward_net(c, d_raw, d_laux)
+
+    def backward_net(self, c, d_raw, d_laux):
+        """Backward of _net_forward given dL/d raw [N*S, 4] and dL/d l_aux[seg]; accumulates into self.grad."""
         o, dt = ops, self.dtype
         N, S, P, n_seg, cap, seg_tokens = c["N"], c["S"], c["P"], c["n_seg"], c["cap"], c["seg_tokens"]
         M, E, L, G, H2 = self.M, self.E, self.L, self.G, self.H2
         g = self.g
         rows, ng = c["rows"], c["ng"]
-        d_raw = o.composite_bwd(c["raw"], c["z"], d_rgb)
+        _b = lambda name, shape, dtype: self._buf(c["tag"] + ":" + name, shape, dtype)
         dh2, dsig = o.heads_bwd(c["y"], c["h2"], self.p["color.w"], c["raw"], d_raw, g["sigma.w"], g["sigma.b"], g["color.w"],
                                 g["color.b"])
         # per-ray bias gradient and the tiny per-ray GEMM's parameters
@@ -302,8 +333,8 @@ class SwitchNeRF:
         d_feat_emb = dc_ray @ self.p["l2r.w"][self.in_dir:].t()
         g["emb"].index_add_(0, c["image_indices"].long(), d_feat_emb)
         # tail backward chain: dh2 -> dh1 -> dy
-        dh1 = self._buf("dh1", (P, M), dt)
-        dy = self._buf("dy", (P, M), dt)
+        dh1 = _b("dh1", (P, M), dt)
+        dy = _b("dy", (P, M), dt)
         o.mlp_chain(dh2, [o.Layer(self.wb["l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dy, tag=5)
         nsp = max(1, min(256, P // 4096))          # row splits of the dense weight-gradient GEMMs (fills the 256 CUs)
         o.wgrad(c["h1"], dh2, g["l2h.w"].view(1, M, H2), None, n_splits=nsp)
@@ -311,8 +342,8 @@ class SwitchNeRF:
         # combine backward (adds the sigma head's rank-1 term, applies the ReLU mask, gate gradient)
         dout, dgmax = o.combine_bwd(dy, c["y"], dsig, self.p["sigma.w"], c["gmax"])
         # expert backward chain
-        dz = [self._buf(f"dz{l}", (rows, M), dt) for l in range(L)]
-        dx = self._buf("dx", (rows, M), dt)
+        dz = [_b(f"dz{l}", (rows, M), dt) for l in range(L)]
+        dx = _b("dx", (rows, M), dt)
         skip_l = list(self.cfg["skips"])[0] if len(self.cfg["skips"]) else None
         bl = []
         for i in range(L):
@@ -347,8 +378,8 @@ class SwitchNeRF:
         dg = o.gate_bwd(c["g"], self.p["ln.w"], self.p["ln.b"], self.p["wg"], c["gates"], c["idx"], dgmax, c["stats"],
                         c["counts"], coef, seg_tokens, g["wg"], g["ln.w"], g["ln.b"])
         # front backward chain: dg -> d(a1) -> d(h0), adding the expert path's input gradient through tok2row
-        dza1 = self._buf("dza1", (P, G), dt)
-        dh0 = self._buf("dh0", (P, M), dt)
+        dza1 = _b("dza1", (P, G), dt)
+        dh0 = _b("dh0", (P, M), dt)
         o.mlp_chain(dg, [o.Layer(self.wb["gate1"], None, relu=2, mask=c["m_a1"], save=dza1), o.Layer(self.wb["gate0"], None)],
                     dh0, y_add=dx, y_add_gather=c["tok2row"], tag=6)
         o.wgrad(c["a1"], dg, g["gate1.w"].view(1, G, G), g["gate1.b"].view(1, G), n_splits=nsp)
@@ -359,20 +390,35 @@ class SwitchNeRF:
 
     # ------------------------------------------------------------------------------------------ training step
     def train_step(self, rgbs, rays, image_indices, n_samples, seg_tokens, perturb=1.0, perturb_rand=None,
-                   sigma_noise=None, optimizer_step=True, routing_override=None, grad_allreduce=None):
-        """Runner._training_step + loss assembly + backward + Adam (runner.py:1077-1123, 646-686)."""
+                   sigma_noise=None, optimizer_step=True, routing_override=None, grad_allreduce=None, fine_samples=0,
+                   fine_u=None, sigma_noise_fine=None):
+        """Runner._training_step + loss assembly + backward + Adam (runner.py:1077-1123, 646-686).
+        fine_samples > 0 adds the hierarchical pass (rendering.py:236-268): importance-sample fine depths from the coarse
+        weights (detached), evaluate the network on them, sort-merge with the coarse samples, composite the union;
+        loss = mse(rgb_fine) + wt * (mean(gate_loss_fine) + mean(gate_loss_coarse)) / 2."""
         N = rays.shape[0]
         self.grad.zero_()
-        c = self.forward_rays(rays, image_indices, n_samples, seg_tokens, perturb, perturb_rand, sigma_noise, True,
-                              routing_override)
-        c["image_indices"] = image_indices
-        diff = c["rgb"] - rgbs
-        photo = (diff * diff).mean()                                  # F.mse_loss, runner.py:1099
-        gate_loss = c["l_aux"].mean()                                 # runner.py:1104
-        loss = photo + self.wt * gate_loss                            # runner.py:646-651
+        fine = fine_samples > 0
+        if not fine:
+            c = out = self.forward_rays(rays, image_indices, n_samples, seg_tokens, perturb, perturb_rand, sigma_noise, True,
+                                        routing_override)
+            gate_loss = c["l_aux"].mean()                                 # runner.py:1104
+        else:
+            c, cf, out = self.forward_hier(rays, image_indices, n_samples, fine_samples, seg_tokens, perturb, perturb_rand,
+                                           fine_u, sigma_noise, sigma_noise_fine, routing_override)
+            gate_loss = (cf["l_aux"].mean() + c["l_aux"].mean()) / 2.0    # runner.py:1104-1111
+        diff = out["rgb"] - rgbs
+        photo = (diff * diff).mean()                                      # F.mse_loss, runner.py:1099
+        loss = photo + self.wt * gate_loss                                # runner.py:646-651
         d_rgb = (diff * (2.0 / diff.numel())).contiguous()
-        d_laux = torch.full((c["n_seg"],), self.wt / c["n_seg"], dtype=torch.float32, device=self.dev)
-        self.backward(c, d_rgb, d_laux)
+        if not fine:
+            d_laux = torch.full((c["n_seg"],), self.wt / c["n_seg"], dtype=torch.float32, device=self.dev)
+            self.backward(c, d_rgb, d_laux)
+        else:
+            d_raw_m = ops.composite_bwd(out["raw"], out["z"], d_rgb)
+            d_raw_f, d_raw_c = ops.unmerge_grad(d_raw_m, out["order"], fine_samples, n_samples)
+            self.backward_net(cf, d_raw_f, torch.full((cf["n_seg"],), 0.5 * self.wt / cf["n_seg"], dtype=torch.float32, device=self.dev))
+            self.backward_net(c, d_raw_c, torch.full((c["n_seg"],), 0.5 * self.wt / c["n_seg"], dtype=torch.float32, device=self.dev))
         scale = 1.0
         if grad_allreduce is not None:
             scale = grad_allreduce(self.grad)
@@ -380,8 +426,32 @@ class SwitchNeRF:
             self.step_count += 1
             ops.adam_step(self.flat, self.grad, self.m, self.v, None, self.step_count, self.lr, grad_scale=scale)
             self.refresh_compute_copies()
-        return dict(loss=loss, photo_loss=photo, gate_loss=gate_loss, psnr=-10.0 * torch.log10(photo),
-                    depth_variance=c["depth_variance"].mean(), ctx=c)
+        res = dict(loss=loss, photo_loss=photo, gate_loss=gate_loss, psnr=-10.0 * torch.log10(photo),
+                   depth_variance=out["depth_variance"].mean(), ctx=c, rgb=out["rgb"], depth=out["depth"])
+        if fine:
+            res["ctx_fine"] = cf
+        return res
+
+    def forward_hier(self, rays, image_indices, n_samples, fine_samples, seg_tokens, perturb=0.0, perturb_rand=None,
+                     fine_u=None, sigma_noise=None, sigma_noise_fine=None, routing_override=None, no_batch=False):
+        """_get_results with fine_samples > 0 and no cascade (rendering.py:199-274): coarse pass (weights only, its raw
+        outputs kept), importance sampling of the fine depths from the detached coarse weights, fine pass on those
+        depths, sort-merge of both sample sets (:419-433) and compositing of the union.
+        Returns (coarse ctx, fine ctx, merged results {raw, z, order, rgb, depth, depth_variance})."""
+        N = rays.shape[0]
+        c = self.forward_rays(rays, image_indices, n_samples, seg_tokens, perturb, perturb_rand, sigma_noise, True,
+                              routing_override, no_batch=no_batch, want_weights=True)
+        if fine_u is None:                                                # det = (perturb == 0): linspace, else rand (:605-609)
+            fine_u = (torch.linspace(0, 1, fine_samples).expand(N, fine_samples).contiguous().to(self.dev) if perturb == 0
+                      else torch.rand(N, fine_samples, device=self.dev))
+        z_fine = ops.sample_pdf(c["z"], c["weights"], fine_u, fine_samples)
+        seg_f = min(seg_tokens, N * fine_samples)
+        cf = self.forward_rays(rays, image_indices, fine_samples, seg_f, 0.0, None, sigma_noise_fine, True, None,
+                               no_batch=no_batch, z_in=z_fine, pe_dir=c["pe_dir"], tag="f", composite=False)
+        zm, order, raw_m = ops.merge_samples(z_fine, c["z"], cf["raw"], c["raw"])
+        out = dict(raw=raw_m, z=zm, order=order, z_fine=z_fine)
+        out["rgb"], out["depth"], out["depth_variance"], _ = ops.composite_fwd(raw_m, zm)
+        return c, cf, out
 
     # ------------------------------------------------------------------------------------------ NeRFMoE mirrors
     training = True

@@ -54,6 +54,40 @@ def sample_pe(rays, t_steps, perturb_rand, perturb: float, n_samples: int, l_xyz
     return z, pe, pd
 
 
+def pe_from_z(rays, z, l_xyz: int, dtype, pe_stride: int):
+    n, S = z.shape
+    pe = torch.empty(n * S, pe_stride, dtype=dtype, device=rays.device)
+    call("swn_pe_from_z", _p(rays), _p(z), n, S, l_xyz, _dt(pe), _p(pe), pe_stride, _stream())
+    return pe
+
+
+def sample_pdf(z_coarse, weights, u, n_fine: int):
+    n, S = z_coarse.shape
+    zf = torch.empty(n, n_fine, dtype=torch.float32, device=z_coarse.device)
+    call("swn_sample_pdf", _p(z_coarse), _p(weights), _p(u), n, S, n_fine, _p(zf), _stream())
+    return zf
+
+
+def merge_samples(z_fine, z_coarse, raw_fine, raw_coarse):
+    n, F = z_fine.shape
+    S = z_coarse.shape[1]
+    dev = z_fine.device
+    z = torch.empty(n, F + S, dtype=torch.float32, device=dev)
+    order = torch.empty(n, F + S, dtype=torch.int32, device=dev)
+    raw = torch.empty(n * (F + S), 4, dtype=torch.float32, device=dev)
+    call("swn_merge_samples", _p(z_fine), _p(z_coarse), _p(raw_fine), _p(raw_coarse), n, F, S, _p(z), _p(order), _p(raw), _stream())
+    return z, order, raw
+
+
+def unmerge_grad(d_raw, order, n_fine: int, n_coarse: int):
+    n = order.shape[0]
+    dev = d_raw.device
+    d_fine = torch.empty(n * n_fine, 4, dtype=torch.float32, device=dev)
+    d_coarse = torch.empty(n * n_coarse, 4, dtype=torch.float32, device=dev)
+    call("swn_unmerge_grad", _p(d_raw), _p(order), n, n_fine, n_coarse, _p(d_fine), _p(d_coarse), _stream())
+    return d_fine, d_coarse
+
+
 def gate_fwd(g, ln_w, ln_b, wg):
     P, G = g.shape
     E = wg.shape[0]

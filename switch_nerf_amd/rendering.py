@@ -1,11 +1,14 @@
 """Mirror of the reference's rendering.render_rays (/root/reference/switch_nerf/rendering.py:15-196) for the hot-path
-configuration: no background NeRF, no cascade, fine_samples = 0 (coarse pass composited), SwitchNeRF model.
+configuration: no background NeRF, no cascade, SwitchNeRF model; fine_samples = 0 (coarse pass composited) or
+fine_samples > 0 (hierarchical: coarse weights -> importance samples -> fine pass -> merged compositing).
 
     results, bg_nerf_rays_present = render_rays(nerf, None, rays, image_indices, hparams, None, None,
                                                 get_depth, get_depth_variance, get_bg_fg_rgb)
 
 Result keys follow the reference: rgb_coarse, depth_coarse, depth_variance_coarse, gate_loss_coarse
-([chunks * moe layers], rendering.py:388-390), moe_gates_coarse [N, S, 1, 1], sigma_coarse (hparams.return_sigma).
+([chunks * moe layers], rendering.py:388-390), moe_gates_coarse [N, S, 1, 1], sigma_coarse (hparams.return_sigma);
+with fine_samples > 0: rgb_fine, depth_fine, depth_variance_fine, gate_loss_fine, gate_loss_coarse (and no rgb_coarse,
+exactly like the reference's composite_rgb=False coarse pass, rendering.py:227).
 """
 from __future__ import annotations
 
@@ -19,8 +22,9 @@ def render_rays(nerf, bg_nerf, rays: torch.Tensor, image_indices: Optional[torch
                 get_bg_fg_rgb: bool = False) -> Tuple[Dict[str, torch.Tensor], bool]:
     if bg_nerf is not None:
         raise NotImplementedError("background NeRF is outside the hot path (SURVEY.md section 8(f) row 4)")
-    if getattr(hparams, "fine_samples", 0) > 0:
-        raise NotImplementedError("hierarchical sampling is a 'next' row (SURVEY.md section 8(f) row 2)")
+    if getattr(hparams, "use_cascade", False):
+        raise NotImplementedError("use_cascade is outside the hot path")
+    F = int(getattr(hparams, "fine_samples", 0))
     N = rays.shape[0]
     S = hparams.coarse_samples
     P = N * S
@@ -34,6 +38,26 @@ def render_rays(nerf, bg_nerf, rays: torch.Tensor, image_indices: Optional[torch
         noise = torch.randn(P, device=rays.device) * hparams.sigma_noise_std      # rendering.py:366
     if image_indices is None:
         image_indices = torch.zeros(N, dtype=torch.long, device=rays.device)
+    if F > 0:
+        noise_f = None
+        if noise is not None:
+            noise_f = torch.randn(N * F, device=rays.device) * hparams.sigma_noise_std
+        if (N * F) % min(chunk, N * F):
+            raise ValueError(f"N_rays * fine_samples ({N * F}) must be a multiple of model_chunk_size ({chunk})")
+        c, cf, out = nerf.forward_hier(rays.contiguous(), image_indices, S, F, chunk, float(perturb), pr, None, noise, noise_f,
+                                       no_batch=nerf.moe_no_batch)
+        res = {"rgb_fine": out["rgb"], "gate_loss_coarse": c["l_aux"], "gate_loss_fine": cf["l_aux"]}
+        if get_depth:
+            res["depth_fine"] = out["depth"]
+        if get_depth_variance:
+            res["depth_variance_fine"] = out["depth_variance"]
+        if getattr(hparams, "moe_return_gates", False):
+            res["moe_gates_coarse"] = c["idx"].long().view(N, S, 1, 1)
+            res["moe_gates_fine"] = cf["idx"].long().view(N, F, 1, 1)
+        if getattr(hparams, "return_sigma", False):
+            res["sigma_coarse"] = c["raw"][:, 3].view(N, S)
+            res["sigma_fine"] = cf["raw"][:, 3].view(N, F)
+        return res, False
     c = nerf.forward_rays(rays.contiguous(), image_indices, S, chunk, float(perturb), pr, noise, training=nerf.training,
                           no_batch=nerf.moe_no_batch)
     res = {"rgb_coarse": c["rgb"], "gate_loss_coarse": c["l_aux"]}

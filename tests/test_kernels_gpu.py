@@ -199,6 +199,67 @@ def test_composite_fwd_bwd():
         assert report(f"composite_bwd_S{S}", d_raw.view(N, S, 4), rr.grad) <= 2e-5 * max(1.0, rr.grad.abs().max().item())
 
 
+def _check_fine_depths(name, got, ref, z, w, u, tol=3e-6):
+    """Inverse-CDF sampling is discontinuous where the coarse pdf is (numerically) zero: there the cdf is flat in fp32 and
+    a one-ulp difference in the normalising sum moves a sample across the whole flat stretch (u = 1.0 of the
+    deterministic linspace hits this on every ray with a transparent tail).  So: every sample must satisfy the defining
+    property cdf(z_fine) == u on the piecewise-linear cdf (to 2e-5: an fp32 cumsum of up to 1022 terms), and must equal the reference to `tol` unless it sits on
+    such a flat stretch (which must be rare)."""
+    got, ref, z, w, u = (t.detach().double().cpu().numpy() for t in (got, ref, z, w, u))
+    bins = 0.5 * (z[:, :-1] + z[:, 1:])
+    pdf = w[:, 1:-1] + 1e-8
+    cdf = np.concatenate([np.zeros_like(pdf[:, :1]), np.cumsum(pdf / pdf.sum(-1, keepdims=True), -1)], -1)
+    bad = np.abs(got - ref) > tol
+    for r in range(z.shape[0]):
+        cu = np.interp(got[r], bins[r], cdf[r])
+        assert np.abs(cu - u[r]).max() <= 2e-5, (name, r, np.abs(cu - u[r]).max())
+        for j in np.nonzero(bad[r])[0]:
+            lo, hi = sorted((got[r, j], ref[r, j]))
+            assert abs(np.interp(lo, bins[r], cdf[r]) - np.interp(hi, bins[r], cdf[r])) <= 2e-5, (name, r, j)
+    REPORT[name] = dict(max_abs_err=float(np.abs(got - ref)[~bad].max()), flat_cdf_samples=int(bad.sum()), samples=int(bad.size))
+    assert bad.mean() <= 0.02, (name, bad.mean())
+
+
+def test_sample_pdf_merge_unmerge():
+    """swn_sample_pdf vs the reference's deterministic fine depths (golden) and vs the oracle with supplied u;
+    swn_merge_samples vs a stable sort of cat[z_fine, z_coarse] (bit-exact order, incl. exact ties); swn_unmerge_grad."""
+    o = ops()
+    g = np.load(os.path.join(G, "composite.npz"))
+    z, w = torch.from_numpy(g["z"]), torch.from_numpy(g["weights"])
+    N = z.shape[0]
+    u = torch.linspace(0, 1, 64).expand(N, 64).contiguous()
+    zf = o.sample_pdf(z.to(dev()), w.to(dev()), u.to(dev()), 64)
+    _check_fine_depths("sample_pdf_det_golden", zf, torch.from_numpy(g["fine_det"]), z, w, u)
+    zf0 = o.sample_pdf(z.to(dev()), w.to(dev()), None, 64)           # u = NULL: linspace generated in the kernel
+    assert torch.equal(zf0, zf)
+    for S, Fn in ((64, 96), (256, 512), (33, 7), (3, 2)):
+        rng = np.random.default_rng(S * 1000 + Fn)
+        N = 37
+        zz = torch.from_numpy(np.sort(rng.uniform(0.05, 1, (N, S)), 1).astype(np.float32))
+        ww = torch.from_numpy((rng.uniform(0, 1, (N, S)) ** 4).astype(np.float32))
+        ww[3] = 0                                                     # all-zero weights: uniform pdf from the 1e-8 floor
+        uu = torch.from_numpy(rng.uniform(0, 1, (N, Fn)).astype(np.float32))
+        ref = O.sample_pdf(0.5 * (zz[:, :-1] + zz[:, 1:]), ww[:, 1:-1], Fn, uu)
+        got = o.sample_pdf(zz.to(dev()), ww.to(dev()), uu.to(dev()), Fn)
+        _check_fine_depths(f"sample_pdf_S{S}_F{Fn}", got, ref, zz, ww, uu)
+        # merge: integers make exact ties between fine and coarse depths
+        zc = zz if S != 33 else torch.sort(torch.from_numpy(rng.integers(0, 9, (N, S)).astype(np.float32)), 1)[0]
+        zfi = got.cpu() if S != 33 else torch.from_numpy(rng.integers(0, 9, (N, Fn)).astype(np.float32))
+        raw_f = torch.from_numpy(rng.standard_normal((N * Fn, 4)).astype(np.float32))
+        raw_c = torch.from_numpy(rng.standard_normal((N * S, 4)).astype(np.float32))
+        zm, order, raw_m = o.merge_samples(zfi.to(dev()), zc.to(dev()), raw_f.to(dev()), raw_c.to(dev()))
+        z_ref, ord_ref = torch.sort(torch.cat([zfi, zc], 1), dim=1, stable=True)
+        raw_ref = torch.gather(torch.cat([raw_f.view(N, Fn, 4), raw_c.view(N, S, 4)], 1), 1, ord_ref[:, :, None].expand(-1, -1, 4))
+        assert torch.equal(zm.cpu(), z_ref)
+        assert torch.equal(order.cpu().long(), ord_ref)
+        assert torch.equal(raw_m.cpu().view(N, Fn + S, 4), raw_ref)
+        d = torch.from_numpy(rng.standard_normal((N * (Fn + S), 4)).astype(np.float32))
+        d_f, d_c = o.unmerge_grad(d.to(dev()), order, Fn, S)
+        ref_cat = torch.zeros(N, Fn + S, 4).scatter_(1, ord_ref[:, :, None].expand(-1, -1, 4), d.view(N, Fn + S, 4))
+        assert torch.equal(d_f.cpu().view(N, Fn, 4), ref_cat[:, :Fn])
+        assert torch.equal(d_c.cpu().view(N, S, 4), ref_cat[:, Fn:])
+
+
 def _round(t, dtype):
     return t.to(dtype).float()
 

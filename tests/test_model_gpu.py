@@ -154,3 +154,76 @@ def test_render_rays_mirror_keys_and_eval():
     np.testing.assert_allclose(res["rgb_coarse"].cpu().numpy(), g["rgb"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(res["depth_coarse"].cpu().numpy(), g["depth"], rtol=1e-4, atol=1e-6)
     assert res["gate_loss_coarse"].shape == (4,) and res["moe_gates_coarse"].shape == (64, 64, 1, 1)
+
+
+@pytest.mark.parametrize("tag", ["det", "perturbed"])
+def test_hierarchical_train_step_vs_reference_golden_fp32(tag):
+    """fine_samples = 96 on top of 64 coarse samples: coarse weights -> swn_sample_pdf -> fine pass -> swn_merge_samples ->
+    compositing of the 160 merged samples, and the backward through the merge into both passes."""
+    g = np.load(os.path.join(G, f"render_train_fine_{tag}.npz"))
+    N, S, Fn, chunk = int(g["N"]), int(g["S"]), int(g["F"]), int(g["chunk"])
+    m = _model(torch.float32, int(g["seed"]), float(g["gate_scale"]))
+    rays, img, rgbs = synth.make_rays(62, N)
+    kw = dict(perturb=0.0)
+    if float(g["perturb"]) > 0:
+        kw = dict(perturb=float(g["perturb"]), perturb_rand=_dev(g["perturb_rand"]), fine_u=_dev(g["fine_u"]))
+    st = m.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, optimizer_step=False, fine_samples=Fn, **kw)
+    c, cf = st["ctx"], st["ctx_fine"]
+    mis_c = int((c["idx"].cpu().numpy().reshape(N, S) != g["moe_gates_coarse"]).sum())
+    mis_f = int((cf["idx"].cpu().numpy().reshape(N, Fn) != g["moe_gates_fine"]).sum())
+    print(f"{tag}: routing mismatches vs reference: coarse {mis_c}, fine {mis_f}")
+    assert mis_c == 0 and mis_f == 0
+    np.testing.assert_allclose(c["raw"][:, 3].cpu().numpy().reshape(N, S), g["sigma_coarse"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(cf["raw"][:, 3].cpu().numpy().reshape(N, Fn), g["sigma_fine"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(st["rgb"].cpu().numpy(), g["rgb"], rtol=0, atol=1e-4)          # north-star tolerance
+    np.testing.assert_allclose(st["depth"].cpu().numpy(), g["depth"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(c["l_aux"].cpu().numpy(), g["gate_loss_coarse"], rtol=1e-5)
+    np.testing.assert_allclose(cf["l_aux"].cpu().numpy(), g["gate_loss_fine"], rtol=1e-5)
+    np.testing.assert_allclose(st["loss"].item(), float(g["loss"]), rtol=1e-5)
+    gd = m.grad_dict()
+    worst = 0.0
+    for k, t in gd.items():
+        got = t.cpu().numpy()
+        ref_sum = g["gsum__" + k]
+        scale = max(1e-12, float(ref_sum[1]))
+        assert abs(synth.checksum(got)[0] - ref_sum[0]) <= 1e-3 * scale + 1e-9, k
+        assert abs(synth.checksum(got)[1] - ref_sum[1]) <= 1e-3 * scale + 1e-9, k
+        sl = got.reshape(-1)[:: max(1, got.size // 499)][:499]
+        ref = g["gslice__" + k]
+        worst = max(worst, float(np.abs(sl - ref).max() / (np.abs(ref).max() + 1e-12)))
+        np.testing.assert_allclose(sl, ref, rtol=2e-3, atol=1e-7 + 2e-4 * np.abs(ref).max(), err_msg=k)
+    print(f"{tag}: worst relative gradient-slice error {worst:.2e}")
+
+
+def test_render_rays_mirror_hierarchical():
+    from argparse import Namespace
+    from switch_nerf_amd.rendering import render_rays
+    g = np.load(os.path.join(G, "render_train_fine_det.npz"))
+    N, S, Fn, chunk = int(g["N"]), int(g["S"]), int(g["F"]), int(g["chunk"])
+    m = _model(torch.float32, int(g["seed"]), float(g["gate_scale"]))
+    rays, img, _ = synth.make_rays(62, N)
+    h = Namespace(coarse_samples=S, fine_samples=Fn, model_chunk_size=chunk, perturb=0.0, use_sigma_noise=False,
+                  sigma_noise_std=1.0, moe_return_gates=True, return_sigma=True, use_cascade=False)
+    m.train()
+    res, bg = render_rays(m, None, _dev(rays), _dev(img), h, None, None, True, True, False)
+    assert bg is False and "rgb_coarse" not in res
+    np.testing.assert_allclose(res["rgb_fine"].cpu().numpy(), g["rgb"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(res["depth_variance_fine"].cpu().numpy(), g["depth_variance"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(res["gate_loss_fine"].cpu().numpy(), g["gate_loss_fine"], rtol=1e-5)
+    assert np.array_equal(res["moe_gates_fine"].cpu().numpy().reshape(N, Fn), g["moe_gates_fine"])
+
+
+def test_hierarchical_bf16_runs_at_odd_sizes():
+    """bf16, 128 coarse + 192 fine samples (merged 320 -> padded to 512 in the sorter), stratified noise: loss falls."""
+    N, S, Fn, chunk = 64, 128, 192, 4096
+    rays, img, rgbs = synth.make_rays(98, N)
+    m = _model(torch.bfloat16, 97, 0.02)
+    first = last = None
+    for it in range(6):
+        st = m.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=1.0,
+                          perturb_rand=torch.rand(N, S, device="cuda"), fine_samples=Fn)
+        z = st["ctx_fine"]["z"]
+        assert torch.isfinite(st["loss"]).item()
+        first = st["loss"].item() if first is None else first
+        last = st["loss"].item()
+    assert last < first

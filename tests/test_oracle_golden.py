@@ -161,6 +161,42 @@ def test_render_and_training_step(tag):
         np.testing.assert_allclose(sl, g["gslice__" + k], rtol=1e-3, atol=1e-7 + 1e-4 * np.abs(g["gslice__" + k]).max(), err_msg=k)
 
 
+@pytest.mark.parametrize("tag", ["det", "perturbed"])
+def test_hierarchical_training_step(tag):
+    """Coarse pass -> _sample_pdf -> fine pass -> sort-merge -> compositing, forward and every parameter gradient, against
+    the reference run with fine_samples = 96 (oracle/gen_golden.py gen_render_fine)."""
+    g = load(f"render_train_fine_{tag}")
+    cfg = synth.BUILDING
+    p = O.params_from_numpy(synth.make_weights(int(g["seed"]), cfg, gate_scale=float(g["gate_scale"])), requires_grad=True)
+    N, S, Fn, chunk = int(g["N"]), int(g["S"]), int(g["F"]), int(g["chunk"])
+    rays, img, rgbs = synth.make_rays(62, N)
+    kw = {}
+    if float(g["perturb"]) > 0:
+        kw = dict(perturb=float(g["perturb"]), perturb_rand=torch.from_numpy(g["perturb_rand"]), fine_u=torch.from_numpy(g["fine_u"]))
+    st = O.training_step(p, torch.from_numpy(rays), torch.from_numpy(img), torch.from_numpy(rgbs), cfg, S, chunk,
+                         fine_samples=Fn, **kw)
+    res = st["results"]
+    assert np.array_equal(np.concatenate([r["idx"] for r in res["routings"]]).reshape(N, S), g["moe_gates_coarse"])
+    assert np.array_equal(np.concatenate([r["idx"] for r in res["routings_fine"]]).reshape(N, Fn), g["moe_gates_fine"])
+    np.testing.assert_allclose(res["sigma_coarse"].detach().numpy(), g["sigma_coarse"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(res["sigma_fine"].detach().numpy(), g["sigma_fine"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(res["rgb_fine"].detach().numpy(), g["rgb"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(res["depth_fine"].numpy(), g["depth"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(res["depth_variance_fine"].numpy(), g["depth_variance"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(res["gate_loss_coarse"].detach().numpy(), g["gate_loss_coarse"], rtol=1e-6)
+    np.testing.assert_allclose(res["gate_loss_fine"].detach().numpy(), g["gate_loss_fine"], rtol=1e-6)
+    np.testing.assert_allclose(st["loss"].detach().numpy(), g["loss"], rtol=1e-6)
+    st["loss"].backward()
+    for k, t in p.items():
+        ref_sum = g["gsum__" + k]
+        got = t.grad.numpy()
+        scale = max(1e-12, float(ref_sum[1]))
+        assert abs(synth.checksum(got)[0] - ref_sum[0]) <= 2e-4 * scale + 1e-9, k
+        assert abs(synth.checksum(got)[1] - ref_sum[1]) <= 2e-4 * scale + 1e-9, k
+        sl = got.reshape(-1)[:: max(1, got.size // 499)][:499]
+        np.testing.assert_allclose(sl, g["gslice__" + k], rtol=1e-3, atol=1e-7 + 1e-4 * np.abs(g["gslice__" + k]).max(), err_msg=k)
+
+
 def test_composite_and_sample_pdf():
     g = load("composite")
     z = torch.from_numpy(g["z"])
