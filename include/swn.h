@@ -203,8 +203,11 @@ int swn_pack_weights(const float* master, void* out, int dtype, int n_wsets, int
 /* Grouped weight gradient: for every group g, dW[g % n_wsets] += A_g^T @ B_g (fp32 atomics), and optionally
  * db += column sums of B_g.  A[rows, m_dim], B[rows, n_dim] row-major dtype; dW [n_wsets][m_dim][n_dim] f32.
  * With A = layer input, B = dZ this yields the reference's ExpertMLP weight layout [E, in, out]
- * (tutel_moe_layer_nobatch.py:853); with A = dZ, B = input it yields torch.nn.Linear's [out, in].              */
-int swn_wgrad(const void* a, const void* b, int dtype, int m_dim, int n_dim,
+ * (tutel_moe_layer_nobatch.py:853); with A = dZ, B = input it yields torch.nn.Linear's [out, in].
+ * a_gather / b_gather (device int32 [n_groups * group_stride], or NULL): row r of a group reads source row
+ * gather[g * group_stride + r] of A / B instead of row g * group_stride + r - the operand is taken through the routing
+ * permutation (swn_route_top1's perm) rather than from a dispatched copy, which then never has to be written.          */
+int swn_wgrad(const void* a, const void* b, const int32_t* a_gather, const int32_t* b_gather, int dtype, int m_dim, int n_dim,
               int n_groups, int n_wsets, int group_stride, const int32_t* group_rows, int group_rows_clamp,
               float* dw, float* db, int n_splits, int tag /* profiling only: 0 generic, 1 expert */,
               void* workspace, size_t workspace_bytes, void* stream);

@@ -48,7 +48,7 @@ SIGNATURES = {
     "swn_mlp_chain": [C.POINTER(ChainDesc), vp],
     "swn_pack_weights": [vp, vp, i32, i32, i32, i32, i32, vp],
     "swn_chain_tile_rows": [i32],
-    "swn_wgrad": [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, vp, sz, vp],
+    "swn_wgrad": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, vp, sz, vp],
     "swn_adam_step": [vp, vp, vp, vp, vp, i32, i64, f32, f32, f32, f32, i32, f32, vp],
     "swn_cast": [vp, vp, i32, i64, vp],
     "swn_cast_transpose": [vp, vp, i32, i32, i32, i32, vp],

@@ -76,13 +76,14 @@ __device__ __forceinline__ float z_of(float near, float far, float t) {
 }
 
 template <typename T, int LMAX>
-__global__ __launch_bounds__(256) void sample_pe_kernel(const float* __restrict__ rays, const float* __restrict__ tsteps,
+__global__ __launch_bounds__(128) void sample_pe_kernel(const float* __restrict__ rays, const float* __restrict__ tsteps,
                                                         const float* __restrict__ prand, float perturb, int n_rays,
                                                         int S, int L, float* __restrict__ z_out, T* __restrict__ pe,
                                                         int pe_stride, const float* __restrict__ z_in) {
 #pragma clang fp contract(off)
-  const long p = (long)blockIdx.x * 256 + threadIdx.x;
-  if (p >= (long)n_rays * S) return;
+  const long p_raw = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = p_raw < (long)n_rays * S;
+  const long p = live ? p_raw : (long)n_rays * S - 1;            // surplus threads recompute the last point, store nothing
   const int ray = (int)(p / S), s = (int)(p - (long)ray * S);
   const float* r = rays + (long)ray * 8;
   const float near = r[6], far = r[7];
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void sample_pe_kernel(const float* __restrict_
     const float span = (upper - lower) * pr;
     z = lower + span;
   }
-  if (z_out) z_out[p] = z;
+  if (z_out && live) z_out[p] = z;
   float v[8 + 6 * LMAX + 8];
   float x[3];
 #pragma unroll
@@ -139,21 +140,40 @@ __global__ __launch_bounds__(256) void sample_pe_kernel(const float* __restrict_
     }
   }
   const int used = 3 + 6 * L;
-  T* dst = pe + p * pe_stride;
   const int step = 16 / (int)sizeof(T);
+  // A thread owns a whole row (pe_stride * sizeof(T) bytes, 256 B stride between lanes): stage the block's rows in LDS and
+  // write them out as one contiguous, fully coalesced region (the block's rows are consecutive in memory).
+  constexpr int NT = sizeof(T) == 2 ? 128 : 64;                  // threads per block (see the launcher)
+  constexpr int ROWB = 128 * (int)sizeof(T) + 16;                // LDS row stride: <= 128 columns, +16 B against bank conflicts
+  __shared__ __attribute__((aligned(16))) char stage[NT * ROWB];
+  const bool staged = pe_stride <= 128;                          // (uniform) wider rows fall back to direct stores
+  T* dst = staged ? (T*)(stage + threadIdx.x * ROWB) : pe + p * pe_stride;
   // columns [used, pe_stride) are zero
   float tmp[8];
-  for (int c0 = 0; c0 < pe_stride; c0 += step) {
+  if (live) {
+    for (int c0 = 0; c0 < pe_stride; c0 += step) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) tmp[j] = 0.f;
-    for (int j = 0; j < step; ++j) {
-      const int c = c0 + j;
-      float val = 0.f;
-      // v[] is indexed with a runtime index only here; keep it small
-      if (c < used) val = v[c];
-      tmp[j] = val;
+      for (int j = 0; j < 8; ++j) tmp[j] = 0.f;
+      for (int j = 0; j < step; ++j) {
+        const int c = c0 + j;
+        float val = 0.f;
+        // v[] is indexed with a runtime index only here; keep it small
+        if (c < used) val = v[c];
+        tmp[j] = val;
+      }
+      store_vals<T>(dst + c0, tmp, step);
     }
-    store_vals<T>(dst + c0, tmp, step);
+  }
+  if (staged) {
+    __syncthreads();
+    const int cpr = pe_stride / step;                            // 16-byte chunks per row
+    const long row0 = (long)blockIdx.x * NT;
+    const long rows = min((long)NT, (long)n_rays * S - row0);
+    char* out = (char*)(pe + row0 * pe_stride);
+    for (int c = threadIdx.x; c < rows * cpr; c += NT) {
+      const int row = c / cpr, ch = c - row * cpr;
+      *(uint4*)(out + (long)c * 16) = *(const uint4*)(stage + row * ROWB + ch * 16);
+    }
   }
 }
 
@@ -862,12 +882,11 @@ extern "C" int swn_sample_pe(const float* rays, const float* t_steps, const floa
   const int epc = dtype == SWN_BF16 ? 8 : 4;
   SWN_CHECK(pe_stride >= 3 + 6 * l_xyz && pe_stride % epc == 0, "swn_sample_pe: pe_stride %d too small / unaligned", pe_stride);
   const long P = (long)n_rays * n_samples;
-  const int blocks = cdiv(P, 256);
   if (dtype == SWN_BF16)
-    hipLaunchKernelGGL((sample_pe_kernel<bf16_t, 12>), dim3(blocks), dim3(256), 0, as_stream(stream), rays, t_steps,
+    hipLaunchKernelGGL((sample_pe_kernel<bf16_t, 12>), dim3(cdiv(P, 128)), dim3(128), 0, as_stream(stream), rays, t_steps,
                        perturb_rand, perturb, n_rays, n_samples, l_xyz, z_out, (bf16_t*)pe_xyz, pe_stride, (const float*)nullptr);
   else
-    hipLaunchKernelGGL((sample_pe_kernel<float, 12>), dim3(blocks), dim3(256), 0, as_stream(stream), rays, t_steps,
+    hipLaunchKernelGGL((sample_pe_kernel<float, 12>), dim3(cdiv(P, 64)), dim3(64), 0, as_stream(stream), rays, t_steps,
                        perturb_rand, perturb, n_rays, n_samples, l_xyz, z_out, (float*)pe_xyz, pe_stride, (const float*)nullptr);
   SWN_LAUNCH_CHECK();
   if (pe_dir) {
@@ -892,12 +911,11 @@ extern "C" int swn_pe_from_z(const float* rays, const float* z, int n_rays, int 
   const int epc = dtype == SWN_BF16 ? 8 : 4;
   SWN_CHECK(pe_stride >= 3 + 6 * l_xyz && pe_stride % epc == 0, "swn_pe_from_z: pe_stride %d too small / unaligned", pe_stride);
   const long P = (long)n_rays * n_samples;
-  const int blocks = cdiv(P, 256);
   if (dtype == SWN_BF16)
-    hipLaunchKernelGGL((sample_pe_kernel<bf16_t, 12>), dim3(blocks), dim3(256), 0, as_stream(stream), rays, (const float*)nullptr,
+    hipLaunchKernelGGL((sample_pe_kernel<bf16_t, 12>), dim3(cdiv(P, 128)), dim3(128), 0, as_stream(stream), rays, (const float*)nullptr,
                        (const float*)nullptr, 0.f, n_rays, n_samples, l_xyz, (float*)nullptr, (bf16_t*)pe_xyz, pe_stride, z);
   else
-    hipLaunchKernelGGL((sample_pe_kernel<float, 12>), dim3(blocks), dim3(256), 0, as_stream(stream), rays, (const float*)nullptr,
+    hipLaunchKernelGGL((sample_pe_kernel<float, 12>), dim3(cdiv(P, 64)), dim3(64), 0, as_stream(stream), rays, (const float*)nullptr,
                        (const float*)nullptr, 0.f, n_rays, n_samples, l_xyz, (float*)nullptr, (float*)pe_xyz, pe_stride, z);
   SWN_LAUNCH_CHECK();
   return 0;

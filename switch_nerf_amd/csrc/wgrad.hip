@@ -28,6 +28,8 @@ template <> struct WCfg<float> { static constexpr int BKR = 16; };
 struct WgradArgs {
   const void* a;
   const void* b;
+  const int32_t* a_gather;   // row (in the grouped row space) -> source row of a / b, or NULL: the operand is read through
+  const int32_t* b_gather;   // the routing permutation instead of from a gathered copy (saves writing that copy)
   int m_dim, n_dim, n_groups, n_wsets, group_stride, clamp, rows_per_split;
   const int32_t* group_rows;
   float* dw;
@@ -94,8 +96,11 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int ar = min(r0 + a_row[i], r_end - 1), br = min(r0 + b_row[i], r_end - 1);
-      ra[i] = *(const uint4*)((const char*)p.a + ((grow0 + ar) * (long)m_dim) * sizeof(T) + a_ch[i] * 16);
-      rb[i] = *(const uint4*)((const char*)p.b + ((grow0 + br) * (long)n_dim) * sizeof(T) + b_ch[i] * 16);
+      long as = grow0 + ar, bs = grow0 + br;
+      if (p.a_gather) as = max(p.a_gather[as], 0);     // valid rows (< group_rows) always carry a source row
+      if (p.b_gather) bs = max(p.b_gather[bs], 0);
+      ra[i] = *(const uint4*)((const char*)p.a + (as * (long)m_dim) * sizeof(T) + a_ch[i] * 16);
+      rb[i] = *(const uint4*)((const char*)p.b + (bs * (long)n_dim) * sizeof(T) + b_ch[i] * 16);
     }
   };
   auto lstore = [&](int buf, int r0) {
@@ -264,9 +269,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 using namespace swn;
 
-extern "C" int swn_wgrad(const void* a, const void* b, int dtype, int m_dim, int n_dim, int n_groups, int n_wsets,
-                         int group_stride, const int32_t* group_rows, int group_rows_clamp, float* dw, float* db,
-                         int n_splits, int tag, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int swn_wgrad(const void* a, const void* b, const int32_t* a_gather, const int32_t* b_gather, int dtype, int m_dim,
+                         int n_dim, int n_groups, int n_wsets, int group_stride, const int32_t* group_rows, int group_rows_clamp,
+                         float* dw, float* db, int n_splits, int tag, void* workspace, size_t workspace_bytes, void* stream) {
   SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_wgrad: bad dtype %d", dtype);
   SWN_CHECK(m_dim >= 32 && m_dim <= 256 && m_dim % 32 == 0 && n_dim >= 32 && n_dim <= 256 && n_dim % 32 == 0,
             "swn_wgrad: m_dim=%d n_dim=%d must be multiples of 32 in [32,256]", m_dim, n_dim);
@@ -278,7 +283,7 @@ extern "C" int swn_wgrad(const void* a, const void* b, int dtype, int m_dim, int
   rps = cdiv(rps, bkr) * bkr;
   const int splits = cdiv(max_rows, rps);
   WgradArgs p;
-  p.a = a; p.b = b; p.m_dim = m_dim; p.n_dim = n_dim; p.n_groups = n_groups; p.n_wsets = n_wsets;
+  p.a = a; p.b = b; p.a_gather = a_gather; p.b_gather = b_gather; p.m_dim = m_dim; p.n_dim = n_dim; p.n_groups = n_groups; p.n_wsets = n_wsets;
   p.group_stride = group_stride; p.clamp = group_rows ? group_rows_clamp : group_stride; p.rows_per_split = rps;
   p.group_rows = group_rows; p.dw = dw; p.db = db;
   p.n_splits = splits;

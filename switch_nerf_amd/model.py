@@ -22,6 +22,7 @@ MI355X-first design notes
 from __future__ import annotations
 
 import contextlib
+import os
 import math
 from typing import Dict, Optional
 
@@ -82,6 +83,7 @@ class SwitchNeRF:
         # side HIP stream: the HBM-bound expert weight-gradient GEMMs overlap with the rest of the backward pass
         self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self.overlap = True
+        self.expert_wgrad_splits = int(os.environ.get("SWN_EXPERT_WGRAD_SPLITS", "0"))   # 0 = heuristic
 
     @contextlib.contextmanager
     def _timed(self, name):
@@ -281,7 +283,6 @@ class SwitchNeRF:
         ng = n_seg * E
         c["rows"], c["ng"] = rows, ng
         c["counts_flat"] = c["counts"].view(-1)
-        c["xs"] = _b("xs", (rows, M), dt)
         c["eo"] = _b("eo", (rows, M), dt)
         c["saves"] = [_b(f"save{l}", (rows, M), dt) for l in range(L - 1)]
         nw = o.chain_mask_words(dt, ng, cap)
@@ -292,7 +293,7 @@ class SwitchNeRF:
                   for l in range(L)]
         with self._timed("expert_fwd"):
             o.mlp_chain(c["h0"], layers, c["eo"], n_groups=ng, n_wsets=E, group_stride=cap, group_rows=c["counts_flat"],
-                        group_rows_clamp=cap, x_gather=c["perm"].view(-1), x_save=c["xs"], tag=1)
+                        group_rows_clamp=cap, x_gather=c["perm"].view(-1), tag=1)
         # ---- per-ray part of layer "2": [PE(dir), appearance embedding] @ W2r + b2   (N_rays x 75, host-side torch)
         feat = torch.cat([pe_dir[:, : self.in_dir].float(), self.p["emb"][image_indices.long()]], 1)
         c["ray_feat"] = feat
@@ -342,7 +343,7 @@ class SwitchNeRF:
         # combine backward (adds the sigma head's rank-1 term, applies the ReLU mask, gate gradient)
         dout, dgmax = o.combine_bwd(dy, c["y"], dsig, self.p["sigma.w"], c["gmax"])
         # expert backward chain
-        dz = [_b(f"dz{l}", (rows, M), dt) for l in range(L)]
+        dz = [_b(f"dz{l}", (rows, M), dt) for l in range(L - 1)]     # dz[L-1] = dout through perm: never materialised
         dx = _b("dx", (rows, M), dt)
         skip_l = list(self.cfg["skips"])[0] if len(self.cfg["skips"]) else None
         bl = []
@@ -352,13 +353,16 @@ class SwitchNeRF:
                               save=dz[l - 1] if l > 0 else None))
         with self._timed("expert_bwd"):
             o.mlp_chain(dout, bl, dx, n_groups=ng, n_wsets=E, group_stride=cap, group_rows=c["counts_flat"],
-                        group_rows_clamp=cap, x_gather=c["perm"].view(-1), x_save=dz[L - 1],
+                        group_rows_clamp=cap, x_gather=c["perm"].view(-1),
                         y_add=dz[skip_l] if skip_l is not None else None, tag=2)
         def expert_wgrads():
-            for l in range(L):
-                a = c["xs"] if l == 0 else c["saves"][l - 1]
-                o.wgrad(a, dz[l], g[f"exp{l}.w"], g[f"exp{l}.b"], n_groups=ng, n_wsets=E, group_stride=cap,
-                        group_rows=c["counts_flat"], group_rows_clamp=cap, n_splits=max(1, min(512 // ng, cap // 2048)), tag=1)
+            perm = c["perm"].view(-1)
+            for l in range(L):      # layer 0 reads its input rows, layer L-1 its dZ rows, through the routing permutation
+                a = c["h0"] if l == 0 else c["saves"][l - 1]
+                bz = dout if l == L - 1 else dz[l]
+                o.wgrad(a, bz, g[f"exp{l}.w"], g[f"exp{l}.b"], n_groups=ng, n_wsets=E, group_stride=cap,
+                        a_gather=perm if l == 0 else None, b_gather=perm if l == L - 1 else None,
+                        group_rows=c["counts_flat"], group_rows_clamp=cap, n_splits=self.expert_wgrad_splits or max(1, min(256 // ng, cap // 2048)), tag=1)
         side_done = None
         if self.overlap and self.side is not None and not self.profile:
             # independent of everything that follows (they only read the saved activations / dZ and write their own

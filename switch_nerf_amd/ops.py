@@ -283,9 +283,11 @@ _wgrad_ws = {}
 
 
 def wgrad(a, b, dw, db=None, n_groups=1, n_wsets=1, group_stride=None, group_rows=None, group_rows_clamp=None, n_splits=8,
-          tag=0, use_workspace=True):
-    """dw [n_wsets, m_dim, n_dim] f32 += a^T b per group; db [n_wsets, n_dim] += colsum(b)."""
+          tag=0, use_workspace=True, a_gather=None, b_gather=None):
+    """dw [n_wsets, m_dim, n_dim] f32 += a^T b per group; db [n_wsets, n_dim] += colsum(b).
+    a_gather / b_gather: read the rows of a / b through an index (the routing permutation) instead of a dispatched copy."""
     m_dim, n_dim = a.shape[1], b.shape[1]
+    assert group_stride is not None or (a_gather is None and b_gather is None)
     gs = int(group_stride if group_stride is not None else a.shape[0])
     ws, ws_bytes = None, 0
     if use_workspace:
@@ -296,7 +298,7 @@ def wgrad(a, b, dw, db=None, n_groups=1, n_wsets=1, group_stride=None, group_row
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
             _wgrad_ws[key] = ws
         ws_bytes = ws.numel()
-    call("swn_wgrad", _p(a), _p(b), _dt(a), m_dim, n_dim, int(n_groups), int(n_wsets), gs, _p(group_rows),
+    call("swn_wgrad", _p(a), _p(b), _p(a_gather), _p(b_gather), _dt(a), m_dim, n_dim, int(n_groups), int(n_wsets), gs, _p(group_rows),
          int(group_rows_clamp if group_rows_clamp is not None else gs), _p(dw), _p(db), int(n_splits), int(tag), _p(ws), ws_bytes, _stream())
 
 

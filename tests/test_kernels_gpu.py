@@ -407,6 +407,20 @@ def test_chain_expert_mlp_forward_backward(dtype):
         tolw = 5e-4 if dtype == torch.float32 else 5e-2
         assert report(f"expert_dW{l}_{dtype}", dw, Wreq[l].grad) <= tolw * sc
         assert report(f"expert_db{l}_{dtype}", db, Breq[l].grad.view(E, M)) <= tolw * max(1.0, Breq[l].grad.abs().max().item())
+        if l == 0:      # the same gradient with the layer input read through the routing permutation (no dispatched copy)
+            dw2 = torch.zeros(E, M, M, device=dev())
+            o.wgrad(h0.to(dev()).to(dtype), dz[0], dw2, None, n_groups=n_seg * E, n_wsets=E, group_stride=Cap, group_rows=gr,
+                    group_rows_clamp=Cap, n_splits=3, a_gather=perm.to(dev()))
+            assert torch.equal(dw2, dw)
+        if l == L - 1:  # ... and with dZ of the last layer read through an index (here: a shuffled copy + its inverse)
+            shuf = torch.randperm(rows)
+            src = torch.empty(rows, M, dtype=dtype, device=dev())
+            src[shuf.to(dev())] = dz[l]
+            dw2 = torch.zeros(E, M, M, device=dev())
+            db2 = torch.zeros(E, M, device=dev())
+            o.wgrad(a, src, dw2, db2, n_groups=n_seg * E, n_wsets=E, group_stride=Cap, group_rows=gr, group_rows_clamp=Cap,
+                    n_splits=3, b_gather=shuf.int().to(dev()))
+            assert torch.equal(dw2, dw) and torch.equal(db2, db)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
