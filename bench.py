@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=131072)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--gate-scale", type=float, default=1.0, help="scale of the router weight (small => balanced routing)")
+    ap.add_argument("--parallelism", default="dp", choices=["dp", "ep"],
+                    help="dp (default): experts replicated, one gradient all-reduce per step; ep: experts sharded over the ranks, "
+                         "dispatched rows exchanged with RCCL all-to-all (BASELINE.json configs[2]; needs gpus | 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     a = ap.parse_args()
@@ -100,6 +103,9 @@ def main():
 
     if world > 1:
         allreduce = parallel.make_grad_allreduce()     # RCCL all-reduce over xGMI, one 16 MB bucket
+    if a.parallelism == "ep":
+        from switch_nerf_amd.parallel import ExpertParallel
+        model.set_expert_parallel(ExpertParallel(rank, world, model.E))
 
     def step():
         pr = torch.rand(a.rays, a.samples, device=dev)              # rendering.py:582 rand_like
@@ -137,9 +143,10 @@ def main():
     for name, evs in model.events.items():
         kern[name] = sum(x.elapsed_time(y) for x, y in evs) / len(evs)          # ms per step
     flops_chain = 2.0 * L * M * M * kept                                       # expert fwd == bwd-data == wgrad flops
-    # algorithmic HBM bytes per launch: fwd reads x, writes x copy + L-1 activations + output (+ masks)
-    bytes_fwd = kept * M * esz * (1 + 1 + (L - 1) + 1)
-    bytes_bwd = kept * M * esz * (1 + L + 1 + 1)
+    # algorithmic HBM bytes per launch: fwd reads x, writes L-1 activations + output; bwd reads dout and the
+    # skip layer's dZ, writes L-1 dZ + dx; the weight gradients read L layer inputs and L dZ (ReLU masks: 1/16 of a tensor each)
+    bytes_fwd = kept * M * esz * (1 + (L - 1) + 1)
+    bytes_bwd = kept * M * esz * (1 + (L - 1) + 1 + 1)
     bytes_wgrad = kept * M * esz * 2 * L
     roof = None
     detail = {}
@@ -179,7 +186,7 @@ def main():
         "config": {"workload": f"configs[1]: 8-expert top-1 expertmlp, capacity_factor=1.0, BPR, {a.rays} rays x {a.samples} samples"
                                f" per GPU, {P // a.chunk} segments of {a.chunk} points, building.yaml shapes, random-init weights,"
                                f" gate_scale={a.gate_scale}",
-                   "rays_per_gpu": a.rays, "samples": a.samples, "segment_points": a.chunk, "parallelism": f"dp{world}",
+                   "rays_per_gpu": a.rays, "samples": a.samples, "segment_points": a.chunk, "parallelism": f"{a.parallelism}{world}",
                    "kept_token_fraction": round(kept / P, 4), "loss": round(float(st["loss"].item()), 6)},
         "roofline": roof, "kernels": detail,
     }

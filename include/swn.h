@@ -146,6 +146,11 @@ int swn_composite_fwd(const float* raw, const float* z, float last_delta, int n_
 int swn_composite_bwd(const float* raw, const float* z, float last_delta, const float* d_rgb,
                       int n_rays, int n_samples, float* d_raw, void* stream);
 
+/* dst[r] = src[index[r]] for r < n_rows (rows of row_bytes bytes, a multiple of 16), zero rows where index[r] < 0.
+ * Builds the send buffer of the expert-parallel token exchange (the reference's all-to-all payload,
+ * tutel_moe_layer_nobatch.py:157, 172) from the routing permutation.                                            */
+int swn_gather_rows(const void* src, const int32_t* index, long n_rows, int row_bytes, void* dst, void* stream);
+
 /* ---- dense / grouped MLP chains on MFMA ------------------------------------------------------------------------
  * One launch runs `n_layers` (<= 8) Linear layers back to back with the activations of a 128-row tile resident in
  * LDS.  Layer l: h <- act_l( h @ W_l^T + b_l [+ rowbias[row/rows_per_bias]] [+ skip] ).  W_l (logically [N_l][K_l],

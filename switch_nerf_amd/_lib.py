@@ -45,6 +45,7 @@ SIGNATURES = {
     "swn_group_colsum": [vp, i32, i32, i32, i32, vp, vp],
     "swn_composite_fwd": [vp, vp, f32, i32, i32, vp, vp, vp, vp, vp],
     "swn_composite_bwd": [vp, vp, f32, vp, i32, i32, vp, vp],
+    "swn_gather_rows": [vp, vp, i64, i32, vp, vp],
     "swn_mlp_chain": [C.POINTER(ChainDesc), vp],
     "swn_pack_weights": [vp, vp, i32, i32, i32, i32, i32, vp],
     "swn_chain_tile_rows": [i32],

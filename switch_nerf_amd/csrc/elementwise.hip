@@ -852,6 +852,21 @@ __global__ void cast_transpose_kernel(const float* __restrict__ in, T* __restric
   }
 }
 
+// dst[r] = src[index[r]] (16-byte pieces), zero rows for index < 0: the send buffer of the expert-parallel exchange
+__global__ void gather_rows_kernel(const char* __restrict__ src, const int32_t* __restrict__ index, long n_rows, int row_bytes,
+                                   char* __restrict__ dst) {
+  const int cpr = row_bytes >> 4;
+  const long total = n_rows * cpr;
+  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long)gridDim.x * blockDim.x) {
+    const long r = c / cpr;
+    const int ch = (int)(c - r * cpr);
+    const int s_ = index[r];
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (s_ >= 0) v = *(const uint4*)(src + (long)s_ * row_bytes + ch * 16);
+    *(uint4*)(dst + c * 16) = v;
+  }
+}
+
 }  // namespace swn
 
 using namespace swn;
@@ -1195,6 +1210,18 @@ extern "C" int swn_cast_transpose(const float* in, void* out, int dtype, int bat
     hipLaunchKernelGGL((cast_transpose_kernel<bf16_t>), grid, block, 0, as_stream(stream), in, (bf16_t*)out, rows, cols);
   else
     hipLaunchKernelGGL((cast_transpose_kernel<float>), grid, block, 0, as_stream(stream), in, (float*)out, rows, cols);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int swn_gather_rows(const void* src, const int32_t* index, long n_rows, int row_bytes, void* dst, void* stream) {
+  SWN_CHECK(src && index && dst, "swn_gather_rows: null pointer");
+  SWN_CHECK(row_bytes > 0 && row_bytes % 16 == 0, "swn_gather_rows: row_bytes %d must be a multiple of 16", row_bytes);
+  if (n_rows <= 0) return 0;
+  long blocks = (n_rows * (row_bytes >> 4) + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const char*)src, index, n_rows,
+                     row_bytes, (char*)dst);
   SWN_LAUNCH_CHECK();
   return 0;
 }

@@ -83,6 +83,7 @@ class SwitchNeRF:
         # side HIP stream: the HBM-bound expert weight-gradient GEMMs overlap with the rest of the backward pass
         self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self.overlap = True
+        self.ep = None                # parallel.ExpertParallel: experts sharded over ranks, tokens exchanged (set_expert_parallel)
         self.expert_wgrad_splits = int(os.environ.get("SWN_EXPERT_WGRAD_SPLITS", "0"))   # 0 = heuristic
 
     @contextlib.contextmanager
@@ -209,6 +210,25 @@ class SwitchNeRF:
                 if n in self.wb:
                     ops.repack_weights(w3, self.wb[n], False)
 
+    def set_expert_parallel(self, ep):
+        """Shard the experts over the ranks of `ep` (parallel.ExpertParallel) and exchange the dispatched rows instead of
+        computing every expert locally.  Parameters stay replicated: a rank only produces the gradients of its own experts
+        and the data-parallel all-reduce of the flat gradient buffer (a sum) distributes them."""
+        assert ep is None or ep.E == self.E
+        self.ep = ep
+
+    def _local_experts(self, t, per_expert_leading=True):
+        """Slice of a per-expert tensor / packed weight stream that belongs to this rank's experts."""
+        if self.ep is None:
+            return t
+        El, r = self.ep.El, self.ep.rank
+        if t.dim() == 1:                     # packed weights: [E * per]
+            per = t.numel() // self.E
+            v = t[r * El * per:(r + 1) * El * per]
+            v.swn_nk = t.swn_nk
+            return v
+        return t[r * El:(r + 1) * El]
+
     # ------------------------------------------------------------------------------------------ buffers
     def _buf(self, name, shape, dtype):
         key = (name, tuple(shape), dtype)
@@ -288,12 +308,32 @@ class SwitchNeRF:
         nw = o.chain_mask_words(dt, ng, cap)
         c["masks"] = [_b(f"mask{l}", (nw,), torch.int32) for l in range(L - 1)]
         skips = set(self.cfg["skips"])
-        layers = [o.Layer(self.wf[f"exp{l}"], self.p[f"exp{l}.b"], relu=1 if l < L - 1 else 0, skip=(l in skips),
-                          save=c["saves"][l] if l < L - 1 else None, mask=c["masks"][l] if l < L - 1 else None)
-                  for l in range(L)]
-        with self._timed("expert_fwd"):
-            o.mlp_chain(c["h0"], layers, c["eo"], n_groups=ng, n_wsets=E, group_stride=cap, group_rows=c["counts_flat"],
-                        group_rows_clamp=cap, x_gather=c["perm"].view(-1), tag=1)
+        layers = [o.Layer(self._local_experts(self.wf[f"exp{l}"]), self._local_experts(self.p[f"exp{l}.b"]),
+                          relu=1 if l < L - 1 else 0, skip=(l in skips), save=c["saves"][l] if l < L - 1 else None,
+                          mask=c["masks"][l] if l < L - 1 else None) for l in range(L)]
+        if self.ep is None:
+            c["row_of_tok"] = c["tok2row"]
+            with self._timed("expert_fwd"):
+                o.mlp_chain(c["h0"], layers, c["eo"], n_groups=ng, n_wsets=E, group_stride=cap, group_rows=c["counts_flat"],
+                            group_rows_clamp=cap, x_gather=c["perm"].view(-1), tag=1)
+        else:
+            # expert parallel: rows in payload order (destination rank, segment, local expert, slot) -> all-to-all -> the
+            # local experts run on (source rank, segment, local expert) groups -> all-to-all back (parallel.ExpertParallel)
+            ep = self.ep
+            c["send_idx"] = ep.send_index(c["perm"].view(-1), n_seg, cap)
+            c["row_of_tok"] = ep.remap_rows(c["tok2row"], n_seg, cap)
+            cnt, cwait = ep.all_to_all(ep.send_counts(c["counts"], n_seg, cap), self.side)
+            xr, xwait = ep.all_to_all(o.gather_rows(c["h0"], c["send_idx"], _b("ep_send_x", (rows, M), dt)), self.side)
+            cwait()
+            xwait()
+            c["ep_counts"], c["ep_x"] = cnt.view(-1), xr
+            eo_r = _b("ep_eo", (rows, M), dt)
+            with self._timed("expert_fwd"):
+                o.mlp_chain(xr, layers, eo_r, n_groups=ng, n_wsets=ep.El, group_stride=cap, group_rows=c["ep_counts"],
+                            group_rows_clamp=cap, tag=1)
+            eo, ewait = ep.all_to_all(eo_r, self.side)
+            ewait()
+            c["eo"] = eo
         # ---- per-ray part of layer "2": [PE(dir), appearance embedding] @ W2r + b2   (N_rays x 75, host-side torch)
         feat = torch.cat([pe_dir[:, : self.in_dir].float(), self.p["emb"][image_indices.long()]], 1)
         c["ray_feat"] = feat
@@ -305,7 +345,7 @@ class SwitchNeRF:
         c["h2"] = _b("h2", (P, H2), dt)
         o.mlp_chain(c["eo"], [o.Layer(self.wf["l1"], self.p["l1.b"].view(1, M), save=c["h1"]),
                               o.Layer(self.wf["l2h"], None, relu=1, rowbias=c["c_ray"], rows_per_bias=S)], c["h2"],
-                    group_stride=P, x_gather=c["tok2row"], x_save=c["y"], x_scale=c["gmax"], x_relu=True, tag=4)
+                    group_stride=P, x_gather=c["row_of_tok"], x_save=c["y"], x_scale=c["gmax"], x_relu=True, tag=4)
         # ---- heads
         c["raw"] = o.heads_fwd(c["y"], c["h2"], self.p["sigma.w"], self.p["sigma.b"], self.p["color.w"], self.p["color.b"],
                                sigma_noise)
@@ -338,10 +378,13 @@ class SwitchNeRF:
         dy = _b("dy", (P, M), dt)
         o.mlp_chain(dh2, [o.Layer(self.wb["l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dy, tag=5)
         nsp = max(1, min(256, P // 4096))          # row splits of the dense weight-gradient GEMMs (fills the 256 CUs)
-        o.wgrad(c["h1"], dh2, g["l2h.w"].view(1, M, H2), None, n_splits=nsp)
-        o.wgrad(c["y"], dh1, g["l1.w"].view(1, M, M), g["l1.b"].view(1, M), n_splits=nsp)
         # combine backward (adds the sigma head's rank-1 term, applies the ReLU mask, gate gradient)
         dout, dgmax = o.combine_bwd(dy, c["y"], dsig, self.p["sigma.w"], c["gmax"])
+        ep = self.ep
+        if ep is not None:      # the rows travel to their experts while the tail's weight gradients run
+            dr, dr_wait = ep.all_to_all(o.gather_rows(dout, c["send_idx"], _b("ep_send_d", (rows, M), dt)), self.side)
+        o.wgrad(c["h1"], dh2, g["l2h.w"].view(1, M, H2), None, n_splits=nsp)
+        o.wgrad(c["y"], dh1, g["l1.w"].view(1, M, M), g["l1.b"].view(1, M), n_splits=nsp)
         # expert backward chain
         dz = [_b(f"dz{l}", (rows, M), dt) for l in range(L - 1)]     # dz[L-1] = dout through perm: never materialised
         dx = _b("dx", (rows, M), dt)
@@ -349,20 +392,31 @@ class SwitchNeRF:
         bl = []
         for i in range(L):
             l = L - 1 - i
-            bl.append(o.Layer(self.wb[f"exp{l}"], None, relu=2 if l > 0 else 0, mask=c["masks"][l - 1] if l > 0 else None,
-                              save=dz[l - 1] if l > 0 else None))
-        with self._timed("expert_bwd"):
-            o.mlp_chain(dout, bl, dx, n_groups=ng, n_wsets=E, group_stride=cap, group_rows=c["counts_flat"],
-                        group_rows_clamp=cap, x_gather=c["perm"].view(-1),
-                        y_add=dz[skip_l] if skip_l is not None else None, tag=2)
-        def expert_wgrads():
+            bl.append(o.Layer(self._local_experts(self.wb[f"exp{l}"]), None, relu=2 if l > 0 else 0,
+                              mask=c["masks"][l - 1] if l > 0 else None, save=dz[l - 1] if l > 0 else None))
+        n_loc = E if ep is None else ep.El
+        grp_rows = c["counts_flat"] if ep is None else c["ep_counts"]
+        if ep is None:
             perm = c["perm"].view(-1)
+            x_first, dz_last = c["h0"], dout            # read through the routing permutation
+        else:
+            perm = None
+            dr_wait()
+            x_first, dz_last = c["ep_x"], dr            # the received rows, already in group order
+        with self._timed("expert_bwd"):
+            o.mlp_chain(dz_last, bl, dx, n_groups=ng, n_wsets=n_loc, group_stride=cap, group_rows=grp_rows,
+                        group_rows_clamp=cap, x_gather=perm, y_add=dz[skip_l] if skip_l is not None else None, tag=2)
+        if ep is not None:      # the input gradients travel home while the expert weight gradients / the router backward run
+            dx, dx_wait = ep.all_to_all(dx, self.side)
+
+        def expert_wgrads():
             for l in range(L):      # layer 0 reads its input rows, layer L-1 its dZ rows, through the routing permutation
-                a = c["h0"] if l == 0 else c["saves"][l - 1]
-                bz = dout if l == L - 1 else dz[l]
-                o.wgrad(a, bz, g[f"exp{l}.w"], g[f"exp{l}.b"], n_groups=ng, n_wsets=E, group_stride=cap,
-                        a_gather=perm if l == 0 else None, b_gather=perm if l == L - 1 else None,
-                        group_rows=c["counts_flat"], group_rows_clamp=cap, n_splits=self.expert_wgrad_splits or max(1, min(256 // ng, cap // 2048)), tag=1)
+                a = x_first if l == 0 else c["saves"][l - 1]
+                bz = dz_last if l == L - 1 else dz[l]
+                o.wgrad(a, bz, self._local_experts(g[f"exp{l}.w"]), self._local_experts(g[f"exp{l}.b"]), n_groups=ng,
+                        n_wsets=n_loc, group_stride=cap, a_gather=perm if l == 0 else None,
+                        b_gather=perm if l == L - 1 else None, group_rows=grp_rows, group_rows_clamp=cap,
+                        n_splits=self.expert_wgrad_splits or max(1, min(256 // ng, cap // 2048)), tag=1)
         side_done = None
         if self.overlap and self.side is not None and not self.profile:
             # independent of everything that follows (they only read the saved activations / dZ and write their own
@@ -384,8 +438,10 @@ class SwitchNeRF:
         # front backward chain: dg -> d(a1) -> d(h0), adding the expert path's input gradient through tok2row
         dza1 = _b("dza1", (P, G), dt)
         dh0 = _b("dh0", (P, M), dt)
+        if ep is not None:
+            dx_wait()
         o.mlp_chain(dg, [o.Layer(self.wb["gate1"], None, relu=2, mask=c["m_a1"], save=dza1), o.Layer(self.wb["gate0"], None)],
-                    dh0, y_add=dx, y_add_gather=c["tok2row"], tag=6)
+                    dh0, y_add=dx, y_add_gather=c["row_of_tok"], tag=6)
         o.wgrad(c["a1"], dg, g["gate1.w"].view(1, G, G), g["gate1.b"].view(1, G), n_splits=nsp)
         o.wgrad(c["h0"], dza1, g["gate0.w"].view(1, M, G), g["gate0.b"].view(1, G), n_splits=nsp)
         o.wgrad(c["pe"], dh0, g["xyz.w"].view(1, self.KP, M), g["xyz.b"].view(1, M), n_splits=nsp)

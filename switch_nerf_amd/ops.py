@@ -88,6 +88,15 @@ def unmerge_grad(d_raw, order, n_fine: int, n_coarse: int):
     return d_fine, d_coarse
 
 
+def gather_rows(src, index, out=None):
+    """out[r] = src[index[r]] (zero rows for index < 0); src [*, C] row-major, index int32 [R]."""
+    R, Cc = index.numel(), src.shape[1]
+    if out is None:
+        out = torch.empty(R, Cc, dtype=src.dtype, device=src.device)
+    call("swn_gather_rows", _p(src), _p(index), R, Cc * src.element_size(), _p(out), _stream())
+    return out
+
+
 def gate_fwd(g, ln_w, ln_b, wg):
     P, G = g.shape
     E = wg.shape[0]

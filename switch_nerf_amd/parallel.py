@@ -1,4 +1,6 @@
-"""Data-parallel plumbing for the hot path: one process per GPU, RCCL (backend "nccl" on ROCm) over xGMI.
+"""Multi-GPU plumbing for the hot path: one process per GPU, RCCL (backend "nccl" on ROCm) over xGMI.
+
+Default: data parallel (below).  Optional: expert parallel (class ExpertParallel at the end of the file).
 
 The reference's multi-GPU mode is DDP over rays (runner.py:203-207, :575: per-rank batch = batch_size // world_size,
 SURVEY.md F4: expert parallelism is disabled as shipped).  Rays are independent and routing is rank-local, so ranks
@@ -46,3 +48,72 @@ def make_grad_allreduce(group=None) -> Callable[[torch.Tensor], float]:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         return 1.0 / world
     return f
+
+
+
+class ExpertParallel:
+    """Expert-parallel token exchange: BASELINE.json configs[2] / the reference's optional EP mode
+    (/root/reference/switch_nerf/modules/tutel_moe_ext/tutel_moe_layer_nobatch.py:157-185: all-to-all of the dispatched
+    [W, E_local, C, M] payload before the experts and back after them; runner.py:97-101: E_local = E // W).
+
+    Rank r owns experts [r * E_local, (r + 1) * E_local).  Every rank still routes ITS OWN points (capacity, ranking and
+    l_aux stay rank-local exactly as in the data-parallel mode, so routing indices do not depend on the mode); only the
+    rows that enter the expert MLP travel.  Per MoE pass there are two exchanges of n_seg * E * C rows (dispatch and
+    return), forward and backward: four per train step.
+
+    Payload order (a "row" = one capacity slot of 2 * M bytes): the sender lays its rows out as
+    [destination rank][segment][local expert][capacity slot]; all_to_all_single (equal splits) then delivers
+    [source rank][segment][local expert][capacity slot] - the group index g of the expert kernels, with
+    g % E_local = local expert, which is exactly how swn_mlp_chain / swn_wgrad pick a group's weight set (no kernel knows
+    about ranks).  The valid-row counts travel the same way.
+
+    RCCL over xGMI is point-to-point: an all-to-all sends (W - 1) / W of the payload over the 7 links in parallel, there
+    is nothing to gain from ring-style chunking; the exchange is issued on a side HIP stream (async_op + stream events)
+    so that whatever does not depend on it (dense weight gradients, the router backward) overlaps it.
+    world == 1 degenerates to the identity (no process group needed): the single-GPU parity test runs this path.
+    """
+
+    def __init__(self, rank: int, world: int, n_experts: int, group=None):
+        if n_experts % world:
+            raise ValueError(f"expert parallelism needs world ({world}) to divide the expert count ({n_experts})")
+        self.rank, self.world, self.E, self.El, self.group = rank, world, n_experts, n_experts // world, group
+
+    # ---- index plumbing (tiny integer tensors; the 2 * M-byte rows are moved by swn_gather_rows / the collective) ----
+    def send_index(self, perm: torch.Tensor, n_seg: int, cap: int) -> torch.Tensor:
+        """perm [n_seg * E * cap] (native order (segment, expert, slot) -> source token, -1 = empty slot) -> the same
+        entries in payload order (destination rank, segment, local expert, slot)."""
+        return perm.view(n_seg, self.world, self.El, cap).permute(1, 0, 2, 3).contiguous().view(-1)
+
+    def send_counts(self, counts: torch.Tensor, n_seg: int, cap: int) -> torch.Tensor:
+        """counts [n_seg, E] -> valid rows per payload group [world, n_seg, E_local] (clamped to the capacity)."""
+        return counts.clamp(max=cap).view(n_seg, self.world, self.El).permute(1, 0, 2).contiguous()
+
+    def remap_rows(self, tok2row: torch.Tensor, n_seg: int, cap: int) -> torch.Tensor:
+        """tok2row (token -> native row id (segment * E + expert) * cap + slot, -1 = dropped) -> payload row id."""
+        r = tok2row.long().clamp(min=0)
+        slot, g = r % cap, r // cap
+        e, s = g % self.E, g // self.E
+        out = (((e // self.El) * n_seg + s) * self.El + e % self.El) * cap + slot
+        return torch.where(tok2row < 0, torch.full_like(out, -1), out).to(torch.int32)
+
+    # ---- the collective ----
+    def all_to_all(self, send: torch.Tensor, stream=None):
+        """Equal-split all-to-all over dim 0 (world chunks).  Returns (recv, wait): call wait() on the stream that consumes
+        recv.  With `stream` (a side HIP stream) the collective is ordered after the work already queued on the current
+        stream and runs concurrently with what the caller queues next."""
+        if self.world == 1:
+            return send, (lambda: None)
+        recv = torch.empty_like(send)
+        if stream is None or not send.is_cuda:
+            work = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+            return recv, work.wait
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(stream):
+            stream.wait_event(ready)
+            work = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+
+        def wait():
+            work.wait()                       # orders the consumer's (current) stream after the collective
+            send.record_stream(torch.cuda.current_stream())
+        return recv, wait

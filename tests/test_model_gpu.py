@@ -227,3 +227,29 @@ def test_hierarchical_bf16_runs_at_odd_sizes():
         first = st["loss"].item() if first is None else first
         last = st["loss"].item()
     assert last < first
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_expert_parallel_path_single_rank_equals_local_experts(dtype):
+    """The expert-parallel code path (send buffer in payload order, counts exchange, local-expert groups, return path,
+    remapped combine index) with world = 1, where the exchange is the identity: must reproduce the default path - forward
+    and loss bit for bit, every gradient up to the summation-order noise of the fp32 atomics that both paths share.
+    (World > 1 plumbing: tests/test_parallel_cpu.py, gloo.)"""
+    from switch_nerf_amd.parallel import ExpertParallel
+    N, S, chunk = 128, 64, 2048
+    rays, img, rgbs = synth.make_rays(118, N)
+    outs = []
+    for use_ep in (False, True):
+        m = _model(dtype, 117, 1.0)
+        if use_ep:
+            m.set_expert_parallel(ExpertParallel(0, 1, m.E))
+        st = m.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0, optimizer_step=False)
+        outs.append((st["rgb"].clone(), st["loss"].clone(), m.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    g0, g1 = outs[0][2], outs[1][2]
+    assert g0.abs().sum().item() > 0
+    for name, (off, shape) in m.spec.items():
+        n = int(np.prod(shape))
+        a, b = g0[off:off + n], g1[off:off + n]
+        assert (a - b).abs().max().item() <= 1e-5 * max(a.abs().max().item(), 1e-12), name

@@ -33,3 +33,84 @@ def test_dp_allreduce_and_sharding_gloo():
         b, e, scale, head, mid = out[r]
         assert scale == 0.5
         assert head == [102.0, 101.0, 3.0] and mid == 3.0     # identical summed buffer on both ranks
+
+
+def _route(rng, n_seg, seg_tokens, E, cap):
+    """Random top-1 routing with capacity in the native layout of swn_route_top1: perm, counts, tok2row."""
+    import numpy as np
+    P = n_seg * seg_tokens
+    idx = rng.integers(0, E, P)
+    perm = np.full((n_seg, E, cap), -1, np.int32)
+    counts = np.zeros((n_seg, E), np.int32)
+    tok2row = np.full(P, -1, np.int32)
+    for t in rng.permutation(P):
+        s, e = t // seg_tokens, idx[t]
+        counts[s, e] += 1                       # like the reference, counts include the dropped tokens
+        if counts[s, e] <= cap:
+            l = counts[s, e] - 1
+            perm[s, e, l] = t
+            tok2row[t] = (s * E + e) * cap + l
+    return idx, perm.reshape(-1), counts, tok2row
+
+
+def _ep_worker(rank, world, port, out):
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from switch_nerf_amd import parallel
+    parallel.init_from_env(backend="gloo")
+    E, n_seg, seg_tokens, cap, M = 4, 3, 40, 10, 8
+    ep = parallel.ExpertParallel(rank, world, E)
+    rng = np.random.default_rng(100 + rank)
+    idx, perm, counts, tok2row = _route(rng, n_seg, seg_tokens, E, cap)
+    P = n_seg * seg_tokens
+    x = torch.from_numpy(rng.standard_normal((P, M)).astype(np.float32)) + 10.0 * rank
+    perm_t, counts_t, t2r = torch.from_numpy(perm), torch.from_numpy(counts), torch.from_numpy(tok2row)
+    # dispatch
+    pe = ep.send_index(perm_t, n_seg, cap).long()
+    send = torch.where((pe >= 0)[:, None], x[pe.clamp(min=0)], torch.zeros(1, M))
+    recv, wait = ep.all_to_all(send)
+    wait()
+    crecv, cwait = ep.all_to_all(ep.send_counts(counts_t, n_seg, cap))
+    cwait()
+    crecv = crecv.view(-1)
+    # mock expert: y = x * (e + 1) + e on the valid rows of every received group; the group's local expert is g % E_local
+    y = torch.zeros_like(recv)
+    for g in range(world * n_seg * ep.El):
+        e = rank * ep.El + g % ep.El
+        n = int(crecv[g])
+        y[g * cap: g * cap + n] = recv[g * cap: g * cap + n] * (e + 1) + e
+    back, bwait = ep.all_to_all(y)
+    bwait()
+    rows = ep.remap_rows(t2r, n_seg, cap).long()
+    got = torch.where((rows >= 0)[:, None], back[rows.clamp(min=0)], torch.zeros(1, M))
+    ref = torch.where(t2r[:, None] >= 0, x * (torch.from_numpy(idx)[:, None] + 1) + torch.from_numpy(idx)[:, None], torch.zeros(1, M))
+    out[rank] = (bool(torch.equal(got, ref)), int((t2r >= 0).sum()), int(crecv.sum()))
+    dist.destroy_process_group()
+
+
+def test_expert_parallel_exchange_gloo():
+    """Tokens routed on 2 ranks reach the rank that owns their expert (payload order = the expert kernels' group order),
+    are processed by the right local expert, and come back to the row the combine gathers from."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_ep_worker, args=(world, 29331 + os.getpid() % 200, out), nprocs=world, join=True)
+    assert out[0][0] and out[1][0]
+    assert out[0][1] + out[1][1] == out[0][2] + out[1][2]      # every kept token is processed exactly once, somewhere
+
+
+def test_expert_parallel_single_rank_is_identity():
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from switch_nerf_amd import parallel
+    ep = parallel.ExpertParallel(0, 1, 8)
+    rng = np.random.default_rng(5)
+    idx, perm, counts, tok2row = _route(rng, 2, 64, 8, 8)
+    p = torch.from_numpy(perm)
+    assert torch.equal(ep.send_index(p, 2, 8), p)
+    assert torch.equal(ep.remap_rows(torch.from_numpy(tok2row), 2, 8), torch.from_numpy(tok2row))
+    s = torch.zeros(4, 2)
+    r, w = ep.all_to_all(s)
+    w()
+    assert r is s
