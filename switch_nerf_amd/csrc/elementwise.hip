@@ -680,13 +680,43 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const T* __restrict__ y,
 }
 
 // out[g][c] = sum over the group's rows of in[g*R + r][c]
+// 256 threads per group: 16-byte pieces of a row across the lanes (coalesced), the block's 256 / (pieces per row) row
+// stripes accumulate in registers and meet in LDS.  Needs C * sizeof(T) <= 4096 and a multiple of 16 (checked on the host).
 template <typename T>
-__global__ void group_colsum_kernel(const T* __restrict__ in, int R, int C, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void group_colsum_kernel(const T* __restrict__ in, int R, int C, float* __restrict__ out) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  __shared__ float red[256 * EPC];
   const int g = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s = 0.f;
-    for (int r = 0; r < R; ++r) s += ElemIO<T>::ld(in + ((long)g * R + r) * C + c);
-    out[(long)g * C + c] = s;
+  const int cpr = C / EPC;                       // pieces per row (<= 256)
+  const int stripes = 256 / cpr;                 // row stripes handled concurrently
+  const int piece = threadIdx.x % cpr, stripe = threadIdx.x / cpr;
+  float acc[EPC];
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) acc[j] = 0.f;
+  if (stripe < stripes) {
+    const T* base = in + (long)g * R * C + piece * EPC;
+    for (int r = stripe; r < R; r += stripes) {
+      const uint4 u = *(const uint4*)(base + (long)r * C);
+      if constexpr (sizeof(T) == 2) {
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[2 * i] += bf16_to_f32((bf16_t)(w[i] & 0xFFFF));
+          acc[2 * i + 1] += bf16_to_f32((bf16_t)(w[i] >> 16));
+        }
+      } else {
+        acc[0] += __uint_as_float(u.x); acc[1] += __uint_as_float(u.y);
+        acc[2] += __uint_as_float(u.z); acc[3] += __uint_as_float(u.w);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) red[threadIdx.x * EPC + j] = acc[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s_ = 0.f;
+    for (int st = 0; st < stripes; ++st) s_ += red[(st * cpr + c / EPC) * EPC + c % EPC];
+    out[(long)g * C + c] = s_;
   }
 }
 
@@ -1134,11 +1164,14 @@ extern "C" int swn_heads_bwd(const void* y, const void* h2, int dtype, const flo
 extern "C" int swn_group_colsum(const void* in, int dtype, int n_groups, int rows_per_group, int cols, float* out,
                                 void* stream) {
   SWN_CHECK(in && out, "swn_group_colsum: null pointer");
+  const int esz = dtype == SWN_BF16 ? 2 : 4;
+  SWN_CHECK(cols > 0 && (cols * esz) % 16 == 0 && cols * esz <= 4096 && 256 % (cols * esz / 16) == 0,
+            "swn_group_colsum: a row must be 16 * 2^k <= 4096 bytes (cols=%d)", cols);
   if (dtype == SWN_BF16)
-    hipLaunchKernelGGL((group_colsum_kernel<bf16_t>), dim3(n_groups), dim3(128), 0, as_stream(stream), (const bf16_t*)in,
+    hipLaunchKernelGGL((group_colsum_kernel<bf16_t>), dim3(n_groups), dim3(256), 0, as_stream(stream), (const bf16_t*)in,
                        rows_per_group, cols, out);
   else
-    hipLaunchKernelGGL((group_colsum_kernel<float>), dim3(n_groups), dim3(128), 0, as_stream(stream), (const float*)in,
+    hipLaunchKernelGGL((group_colsum_kernel<float>), dim3(n_groups), dim3(256), 0, as_stream(stream), (const float*)in,
                        rows_per_group, cols, out);
   SWN_LAUNCH_CHECK();
   return 0;
