@@ -138,13 +138,31 @@ int swn_heads_bwd(const void* y, const void* h2, int dtype, const float* w_color
 int swn_group_colsum(const void* in, int dtype, int n_groups, int rows_per_group, int cols, float* out, void* stream);
 
 /* ---- volumetric compositing ------------------------------------------------------------------------------------
- * replaces rendering.py:435-494.  raw[N,S,4] f32 (rgb, sigma); z[N,S] f32; last_delta scalar (1e10).
+ * replaces rendering.py:435-494 (and rendering_mip.py:380-425).  raw[N,S,4] f32 (rgb, sigma); z[N,S] f32; last_delta
+ * scalar (1e10); rgb_padding: the colours are widened to rgb * (1 + 2 pad) - pad first (rendering_mip.py:383-384; 0 = off).
  * rgb[N,3], depth[N], depth_var[N], weights[N,S] (any may be NULL).                                             */
-int swn_composite_fwd(const float* raw, const float* z, float last_delta, int n_rays, int n_samples,
+int swn_composite_fwd(const float* raw, const float* z, float last_delta, float rgb_padding, int n_rays, int n_samples,
                       float* rgb, float* depth, float* depth_var, float* weights, void* stream);
 /* d_raw[N,S,4] = gradient of sum(d_rgb * rgb) w.r.t. raw. */
-int swn_composite_bwd(const float* raw, const float* z, float last_delta, const float* d_rgb,
+int swn_composite_bwd(const float* raw, const float* z, float last_delta, float rgb_padding, const float* d_rgb,
                       int n_rays, int n_samples, float* d_raw, void* stream);
+
+/* ---- mip path (rendering_mip.py, MipNeRFMoE) -------------------------------------------------------------------
+ * swn_sample_z: the n_samples interval edges of a level, z = near (1 - t) + far t with the stratified perturbation of
+ *   rendering.py:573-584 (perturb_rand [N,S] U[0,1) supplied by the caller, NULL / perturb = 0: none).
+ * swn_mip_encode: replaces mip_cast_rays (rendering_mip.py:15-25) + MipEmbedder (models/nerf.py:28-56): for every ray and
+ *   every pair of consecutive edges z[i], z[i+1] the conical frustum's mean / diagonal covariance and from them the
+ *   integrated positional encoding [mean, sin(2^k mean) exp(-4^k var / 2), cos(2^k mean) exp(-4^k var / 2)]_k<l_xyz,
+ *   zero-padded to pe_stride: pe [n_rays * (n_edges - 1), pe_stride] dtype.  radii [n_rays] f32.
+ * swn_mip_resample: replaces the level hand-over rendering_mip.py:206-223 (weights blur + weights_resample_padding) and
+ *   sorted_piecewise_constant_pdf1 (:75-131): weights [N, n_edges - 1] of the level -> n_fine new edges per ray (sorted).
+ *   u_rand [N, n_fine] U[0,1) = the tensor of the randomized branch (:103), NULL = deterministic linspace (:110).        */
+int swn_sample_z(const float* rays, const float* t_steps, const float* perturb_rand, float perturb, int n_rays, int n_samples,
+                 float* z_out, void* stream);
+int swn_mip_encode(const float* rays, const float* radii, const float* z, int n_rays, int n_edges, int l_xyz, int dtype,
+                   void* pe, int pe_stride, void* stream);
+int swn_mip_resample(const float* z, const float* weights, const float* u_rand, float padding, int n_rays, int n_edges,
+                     int n_fine, float* z_out, void* stream);
 
 /* dst[r] = src[index[r]] for r < n_rows (rows of row_bytes bytes, a multiple of 16), zero rows where index[r] < 0.
  * Builds the send buffer of the expert-parallel token exchange (the reference's all-to-all payload,

@@ -28,6 +28,7 @@ import synth  # noqa: E402
 from switch_nerf.models import model_utils  # noqa: E402
 from switch_nerf.models.nerf import Embedding  # noqa: E402
 from switch_nerf import rendering  # noqa: E402
+from switch_nerf import rendering_mip  # noqa: E402
 from switch_nerf.modules.tutel_moe_ext import tutel_fast_dispatch as tfd  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -52,7 +53,7 @@ def building_model_cfg(cfg):
 
 
 def make_hparams(cfg, capacity_factor=1.0, bpr=True, coarse=256, chunk=131072, perturb=0.0,
-                 sigma_noise=False, fine=0):
+                 sigma_noise=False, fine=0, mip=False):
     h = Namespace(
         container_path=None, use_cascade=False, train_mega_nerf=None, use_moe=True, ckpt_path=None,
         pos_xyz_dim=cfg["pos_xyz_dim"], pos_dir_dim=cfg["pos_dir_dim"], appearance_dim=cfg["appearance_dim"],
@@ -63,7 +64,8 @@ def make_hparams(cfg, capacity_factor=1.0, bpr=True, coarse=256, chunk=131072, p
         moe_expert_type="expertmlp", no_expert_parallel=True, single_data_group=None,
         parallel_env=Namespace(global_rank=0), moe_return_gates=True, moe_return_gate_logits=False,
         use_moe_external_gate=True, use_gate_input_norm=True, amp_use_bfloat16=False,
-        nerfmoe_class_name="NeRFMoE", model=building_model_cfg(cfg), perturb=perturb,
+        nerfmoe_class_name="MipNeRFMoE" if mip else "NeRFMoE", model=building_model_cfg(cfg), perturb=perturb,
+        use_mip=mip, weights_resample_padding=0.01, stop_level_grad=True, rgb_padding=0.001,
         coarse_samples=coarse, fine_samples=fine, model_chunk_size=chunk, use_sigma_noise=sigma_noise,
         sigma_noise_std=1.0, return_pts=False, return_pts_rgb=False, return_pts_alpha=False, return_sigma=True,
         return_alpha=False, bg_use_moe=False, use_load_importance_loss=False, white_bkgd=False,
@@ -267,6 +269,62 @@ def gen_render_fine():
         save(f"render_train_fine_{tag}", **out)
 
 
+def gen_mip():
+    print("[G7] mip path: mip_cast_rays + MipEmbedder + MipNeRFMoE + resampling, 2 levels, loss = (fine + coarse) / 2, fwd + grads")
+    cfg = synth.BUILDING
+    for tag, perturb in (("det", 0.0), ("perturbed", 1.0)):
+        sd = synth.make_weights(71, cfg, gate_scale=0.02)
+        N, S, Fn, chunk = 64, 65, 65, 1024          # 64 intervals per level -> 4096 points = 4 chunks
+        nerf, h = build_reference_model(cfg, sd, coarse=S, chunk=chunk, perturb=perturb, sigma_noise=False, fine=Fn, mip=True)
+        rays, img, rgbs = synth.make_rays(72, N)
+        radii = (np.random.default_rng(73).uniform(0.5, 2.0, (N, 1)) * 1e-3).astype(np.float32)
+        nerf.train()
+        # random draws of the reference in call order: rand_like(z_vals) (rendering_mip.py, _expand_and_perturb_z_vals),
+        # then torch.rand([N, fine]) inside sorted_piecewise_constant_pdf1 - replayed from the seed
+        torch.manual_seed(79)
+        pr = torch.rand(N, S)
+        fu = torch.rand(N, Fn)
+        torch.manual_seed(79)
+        res, _ = rendering_mip.render_rays(nerf, torch.from_numpy(rays), torch.from_numpy(radii), torch.from_numpy(img), h,
+                                           get_depth=True, get_depth_variance=True)
+        t = torch.from_numpy(rgbs)
+        photo = (torch.nn.functional.mse_loss(res["rgb_fine"], t) + torch.nn.functional.mse_loss(res["rgb_coarse"], t)) / 2
+        gate_loss = (res["gate_loss_fine"].mean() + res["gate_loss_coarse"].mean()) / 2.0       # runner.py:1157-1163
+        loss = photo + 5e-4 * gate_loss
+        loss.backward()
+        out = dict(seed=71, gate_scale=0.02, N=N, S=S, F=Fn, chunk=chunk, perturb=perturb, radii=radii,
+                   rgb_coarse=res["rgb_coarse"].detach().numpy(), rgb_fine=res["rgb_fine"].detach().numpy(),
+                   depth=res["depth_fine"].numpy(), depth_variance=res["depth_variance_fine"].numpy(),
+                   gate_loss_coarse=res["gate_loss_coarse"].detach().numpy(), gate_loss_fine=res["gate_loss_fine"].detach().numpy(),
+                   moe_gates_coarse=res["moe_gates_coarse"].numpy().astype(np.int32).reshape(N, S - 1),
+                   moe_gates_fine=res["moe_gates_fine"].numpy().astype(np.int32).reshape(N, Fn - 1),
+                   loss=loss.detach().numpy(), photo=photo.detach().numpy())
+        if perturb > 0:
+            out["perturb_rand"], out["fine_u"] = pr.numpy(), fu.numpy()
+        for n, p in nerf.named_parameters():
+            g_ = p.grad
+            out["gsum__" + n] = synth.checksum(g_.numpy())
+            out["gslice__" + n] = g_.numpy().reshape(-1)[:: max(1, g_.numel() // 499)][:499]
+        save(f"mip_train_{tag}", **out)
+    # kernel-level vectors: cast + integrated positional encoding, resampling
+    rng = np.random.default_rng(75)
+    N, S = 32, 33
+    rays, _, _ = synth.make_rays(76, N)
+    radii = (rng.uniform(0.5, 2.0, (N, 1)) * 1e-3).astype(np.float32)
+    z = torch.from_numpy(rays[:, 6:7] * (1 - np.linspace(0, 1, S, dtype=np.float32)) + rays[:, 7:8] * np.linspace(0, 1, S, dtype=np.float32))
+    mean, cov = rendering_mip.mip_cast_rays(torch.from_numpy(rays[:, 0:3]), torch.from_numpy(rays[:, 3:6]), torch.from_numpy(radii), z)
+    from switch_nerf.models.nerf import MipEmbedder
+    ipe = MipEmbedder(12)(torch.cat([mean, cov], -1).view(-1, 6))
+    w = torch.from_numpy((rng.uniform(0, 1, (N, S - 1)) ** 3).astype(np.float32))
+    w[5] = 0
+    wp = torch.cat([w[..., :1], w, w[..., -1:]], -1)
+    wm = torch.maximum(wp[..., :-1], wp[..., 1:])
+    blur = 0.5 * (wm[..., :-1] + wm[..., 1:]) + 0.01
+    zs = rendering_mip.sorted_piecewise_constant_pdf1(z, blur.clone(), 40, randomized=False)
+    save("mip_kernels", rays=rays, radii=radii, z=z.numpy(), mean=mean.numpy(), cov=cov.numpy(), ipe=ipe.numpy(), weights=w.numpy(),
+         z_resampled_det=zs.numpy())
+
+
 # ------------------------------------------------------------------------------------------ G5b compositing + sample_pdf
 def gen_composite():
     print("[G5b] compositing / _sample_pdf on raw tensors")
@@ -308,7 +366,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     todo = dict(routing=gen_routing, pe=gen_pe, moe=gen_moe_layer, model=gen_model_forward, nobatch=gen_model_forward_nobatch,
-                render=gen_render, fine=gen_render_fine, composite=gen_composite)
+                render=gen_render, fine=gen_render_fine, mip=gen_mip, composite=gen_composite)
     for k, fn in todo.items():
         if a.only and k not in a.only.split(","):
             continue

@@ -194,12 +194,18 @@ def params_from_numpy(sd: Dict[str, np.ndarray], requires_grad: bool = False) ->
 
 def nerf_moe_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: dict, capacity_factor: float = 1.0,
                      batch_prioritized: bool = True, sigma_noise: Optional[torch.Tensor] = None,
-                     routing: Optional[dict] = None, no_batch: bool = False):
+                     routing: Optional[dict] = None, no_batch: bool = False, encoded=None):
     """NeRFMoE.forward, models/nerf_moe.py:320-455, with building.yaml's layer wiring.
-    x: [P, 7] = xyz(3) dir(3) image_index(1).  Returns dict(outputs [P,4], moe_loss [1], routing, gates)."""
+    x: [P, 7] = xyz(3) dir(3) image_index(1).  Returns dict(outputs [P,4], moe_loss [1], routing, gates).
+    encoded = (xyz encoding [P, 3 + 6 L], dirs [P,3], image index [P]): MipNeRFMoE.forward (:675-810), which is the same
+    network behind a different position encoder (MipEmbedder)."""
     L = cfg["expert_layers"]
-    xyz, dirs, img = x[:, :3], x[:, 3:6], x[:, 6].long()
-    h = F.linear(positional_encoding(xyz, cfg["pos_xyz_dim"]), p["layers.xyz.fcs.0.weight"], p["layers.xyz.fcs.0.bias"])  # :330-333
+    if encoded is None:
+        xyz, dirs, img = x[:, :3], x[:, 3:6], x[:, 6].long()
+        enc = positional_encoding(xyz, cfg["pos_xyz_dim"])
+    else:
+        enc, dirs, img = encoded[0], encoded[1], encoded[2].long()
+    h = F.linear(enc, p["layers.xyz.fcs.0.weight"], p["layers.xyz.fcs.0.bias"])  # :330-333
     g = F.linear(h, p["layers.moe_external_gate.fcs.0.weight"], p["layers.moe_external_gate.fcs.0.bias"])
     g = F.linear(torch.relu(g), p["layers.moe_external_gate.fcs.1.weight"], p["layers.moe_external_gate.fcs.1.bias"])  # :347-348, Mlp :30-49
     g = F.layer_norm(g, (g.shape[1],), p["layers.gate_input_norm.weight"], p["layers.gate_input_norm.bias"], 1e-5)  # :370-372
@@ -324,6 +330,112 @@ def training_step(p, rays, image_indices, rgbs, cfg, n_samples, chunk, moe_l_aux
         psnr = -10.0 * torch.log10(photo.detach())                                             # metrics.py:8-10
     return dict(loss=loss, photo_loss=photo, gate_loss=gate_loss, psnr=psnr,
                 depth_variance=res[f"depth_variance_{typ}"].mean(), results=res)
+
+
+# --------------------------------------------------------------------------------------------
+# mip path (rendering_mip.py, MipNeRFMoE): conical-frustum casting, integrated positional encoding, level resampling
+# --------------------------------------------------------------------------------------------
+def mip_cast_rays(o: torch.Tensor, d: torch.Tensor, radius: torch.Tensor, t: torch.Tensor):
+    """rendering_mip.py:15-25.  o, d [N,3]; radius [N,1]; t [N,S] interval edges -> mean, diagonal covariance [N,S-1,3]
+    of the conical frustum between consecutive edges (mip-NeRF eq. 7, the numerically stable form)."""
+    t0, t1 = t[:, :-1], t[:, 1:]
+    c, hw = (t0 + t1) / 2, (t1 - t0) / 2
+    den = 3 * c ** 2 + hw ** 2
+    t_mean = c + (2 * c * hw ** 2) / den
+    t_var = (hw ** 2) / 3 - (4 / 15) * ((hw ** 4 * (12 * c ** 2 - hw ** 2)) / den ** 2)
+    r_var = radius ** 2 * ((c ** 2) / 4 + (5 / 12) * hw ** 2 - (4 / 15) * (hw ** 4) / den)
+    mean = o[:, None, :] + d[:, None, :] * t_mean[..., None]
+    null_outer_diag = 1 - (d ** 2) / torch.sum(d ** 2, -1, keepdim=True)
+    cov = t_var[..., None] * (d ** 2)[:, None, :] + r_var[..., None] * null_outer_diag[:, None, :]
+    return mean, cov
+
+
+def mip_embed(mean: torch.Tensor, cov: torch.Tensor, n_freqs: int) -> torch.Tensor:
+    """MipEmbedder, models/nerf.py:28-56 (logscale): [x, sin(2^k x) exp(-4^k var / 2), cos(2^k x) exp(-4^k var / 2), ...]."""
+    out = [mean]
+    for k in range(n_freqs):
+        fy, fw = 2.0 ** k, 4.0 ** k
+        damp = torch.exp(-0.5 * fw * cov)
+        out += [torch.sin(mean * fy) * damp, torch.cos(mean * fy) * damp]
+    return torch.cat(out, -1)
+
+
+F32_EPS = float(torch.finfo(torch.float32).eps)
+
+
+def mip_resample(z: torch.Tensor, weights: torch.Tensor, n_fine: int, padding: float, u_rand: Optional[torch.Tensor] = None):
+    """The level hand-over of rendering_mip.py:218-229 (blurred, padded weights) + sorted_piecewise_constant_pdf1 (:75-131).
+    z [N,S] edges, weights [N,S-1]; u_rand = the U[0,1) tensor [N,n_fine] of the randomized branch (None: deterministic).
+    The reference finds the interval with an [N,S,F] mask; cdf is non-decreasing, starts at 0 and ends at 1 > u, so the
+    last edge with cdf <= u is searchsorted(right) - 1 and the first with cdf > u is the next one."""
+    w = torch.cat([weights[:, :1], weights, weights[:, -1:]], -1)
+    wmax = torch.maximum(w[:, :-1], w[:, 1:])
+    w = 0.5 * (wmax[:, :-1] + wmax[:, 1:]) + padding
+    wsum = w.sum(-1, keepdim=True)
+    pad = torch.clamp(1e-5 - wsum, min=0)
+    w = w + pad / w.shape[-1]
+    wsum = wsum + pad
+    pdf = w / wsum
+    cdf = torch.clamp(torch.cumsum(pdf[:, :-1], -1), max=1.0)
+    cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf, torch.ones_like(cdf[:, :1])], -1)
+    if u_rand is not None:
+        s_ = 1.0 / n_fine
+        u = torch.arange(n_fine) * s_ + u_rand * (s_ - F32_EPS)
+        u = torch.clamp(u, max=1.0 - F32_EPS)
+    else:
+        u = torch.linspace(0.0, 1.0 - F32_EPS, n_fine).expand(z.shape[0], n_fine)
+    u = u.contiguous()
+    i0 = torch.searchsorted(cdf, u, right=True) - 1
+    i1 = i0 + 1
+    b0, b1 = z.gather(1, i0), z.gather(1, i1)
+    c0, c1 = cdf.gather(1, i0), cdf.gather(1, i1)
+    t = torch.clamp(torch.nan_to_num((u - c0) / (c1 - c0), 0.0), 0, 1)
+    return torch.sort(b0 + t * (b1 - b0), -1)[0]                                              # :223
+
+
+def render_rays_mip(p, rays, radii, image_indices, cfg, n_samples: int, n_fine: int, chunk: int, capacity_factor: float = 1.0,
+                    batch_prioritized: bool = True, perturb: float = 0.0, perturb_rand=None, fine_u=None, sigma_noise=None,
+                    sigma_noise_fine=None, rgb_padding: float = 0.001, resample_padding: float = 0.01):
+    """rendering_mip.render_rays / _get_results / _inference (rendering_mip.py:133-425) for MipNeRFMoE with direction and
+    appearance inputs: n_samples edges -> n_samples - 1 frustums per level; the fine level's edges are resampled from the
+    coarse weights (stop_level_grad: detached)."""
+    N = rays.shape[0]
+    o, d, near, far = rays[:, 0:3], rays[:, 3:6], rays[:, 6:7], rays[:, 7:8]
+
+    def level(z, noise):
+        mean, cov = mip_cast_rays(o, d, radii, z)
+        S1 = z.shape[1] - 1
+        enc = mip_embed(mean, cov, cfg["pos_xyz_dim"]).reshape(N * S1, -1)
+        ddir = d[:, None, :].expand(N, S1, 3).reshape(-1, 3)
+        idx = image_indices.view(N, 1).expand(N, S1).reshape(-1)
+        outs, losses, routes = [], [], []
+        for i in range(0, N * S1, chunk):
+            r = nerf_moe_forward(p, None, cfg, capacity_factor, batch_prioritized, None if noise is None else noise[i:i + chunk],
+                                 encoded=(enc[i:i + chunk], ddir[i:i + chunk], idx[i:i + chunk]))
+            outs.append(r["outputs"]); losses.append(r["moe_loss"]); routes.append(r["routing"])
+        out = torch.cat(outs, 0).view(N, S1, 4)
+        rgbs = out[..., :3] * (1 + 2 * rgb_padding) - rgb_padding                              # :383-384
+        zm = 0.5 * (z[:, 1:] + z[:, :-1])                                                        # :386
+        comp = composite(rgbs, out[..., 3], zm)
+        return comp, torch.cat(losses, 0), routes, out
+
+    z = sample_z(near, far, n_samples, perturb, perturb_rand)
+    comp_c, gl_c, routes_c, out_c = level(z, sigma_noise)
+    res = dict(rgb_coarse=comp_c["rgb"], gate_loss_coarse=gl_c, routings=routes_c, z_vals=z, weights_coarse=comp_c["weights"])
+    if n_fine > 0:
+        z_f = mip_resample(z, comp_c["weights"], n_fine, resample_padding, fine_u).detach()     # :218-223 (stop_level_grad)
+        comp_f, gl_f, routes_f, out_f = level(z_f, sigma_noise_fine)
+        res.update(rgb_fine=comp_f["rgb"], depth_fine=comp_f["depth"], depth_variance_fine=comp_f["depth_variance"],
+                   gate_loss_fine=gl_f, routings_fine=routes_f, z_fine=z_f)
+    return res
+
+
+def training_step_mip(p, rays, radii, image_indices, rgbs, cfg, n_samples, n_fine, chunk, moe_l_aux_wt=5e-4, **kw):
+    """Runner._training_step_mip, runner.py:1126-1167: loss = (mse(rgb_fine) + mse(rgb_coarse)) / 2 + wt * mean gate losses."""
+    res = render_rays_mip(p, rays, radii, image_indices, cfg, n_samples, n_fine, chunk, **kw)
+    photo = (F.mse_loss(res["rgb_fine"], rgbs) + F.mse_loss(res["rgb_coarse"], rgbs)) / 2
+    gate_loss = (res["gate_loss_fine"].mean() + res["gate_loss_coarse"].mean()) / 2
+    return dict(loss=photo + moe_l_aux_wt * gate_loss, photo_loss=photo, gate_loss=gate_loss, results=res)
 
 
 def adam_step(param: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float,

@@ -43,8 +43,11 @@ SIGNATURES = {
     "swn_heads_fwd": [vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp],
     "swn_heads_bwd": [vp, vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "swn_group_colsum": [vp, i32, i32, i32, i32, vp, vp],
-    "swn_composite_fwd": [vp, vp, f32, i32, i32, vp, vp, vp, vp, vp],
-    "swn_composite_bwd": [vp, vp, f32, vp, i32, i32, vp, vp],
+    "swn_composite_fwd": [vp, vp, f32, f32, i32, i32, vp, vp, vp, vp, vp],
+    "swn_composite_bwd": [vp, vp, f32, f32, vp, i32, i32, vp, vp],
+    "swn_sample_z": [vp, vp, vp, f32, i32, i32, vp, vp],
+    "swn_mip_encode": [vp, vp, vp, i32, i32, i32, i32, vp, i32, vp],
+    "swn_mip_resample": [vp, vp, vp, f32, i32, i32, i32, vp, vp],
     "swn_gather_rows": [vp, vp, i64, i32, vp, vp],
     "swn_mlp_chain": [C.POINTER(ChainDesc), vp],
     "swn_pack_weights": [vp, vp, i32, i32, i32, i32, i32, vp],

@@ -7,12 +7,12 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="${SWN_DEFS:-} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-variable -Wno-unused-but-set-variable -ffp-contract=fast-honor-pragmas"
 mkdir -p "$HERE/build"
 pids=()
-for f in elementwise route chain wgrad sampling; do
+for f in elementwise route chain wgrad sampling mip; do
   if [ ! -f "$HERE/build/$f.o" ] || [ "$f.hip" -nt "$HERE/build/$f.o" ] || [ common.hpp -nt "$HERE/build/$f.o" ] || [ ../../include/swn.h -nt "$HERE/build/$f.o" ]; then
     $HIPCC $FLAGS -c $f.hip -o "$HERE/build/$f.o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC "$HERE"/build/{elementwise,route,chain,wgrad,sampling}.o -o "$HERE/libswn_hip.so"
+$HIPCC --offload-arch=gfx950 -shared -fPIC "$HERE"/build/{elementwise,route,chain,wgrad,sampling,mip}.o -o "$HERE/libswn_hip.so"
 echo "built $HERE/libswn_hip.so"

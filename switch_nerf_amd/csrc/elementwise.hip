@@ -724,7 +724,7 @@ __global__ __launch_bounds__(256) void group_colsum_kernel(const T* __restrict__
 // one wave per ray; lane owns a contiguous run of ceil(S/64) samples.  rendering.py:435-494
 template <int SPL>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ raw, const float* __restrict__ z,
-                                                            float last_delta, int N, int S, float* __restrict__ rgb,
+                                                            float last_delta, float rgb_pad, int N, int S, float* __restrict__ rgb,
                                                             float* __restrict__ depth, float* __restrict__ dvar,
                                                             float* __restrict__ weights) {
   const int lane = threadIdx.x & 63;
@@ -743,6 +743,11 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
       zz[j] = zr[s];
       const float dl = (s + 1 < S) ? (zr[s + 1] - zz[j]) : last_delta;
       cs[j] = rr[s];
+      if (rgb_pad != 0.f) {   // rendering_mip.py:383-384: rgbs * (1 + 2 pad) - pad
+        cs[j].x = cs[j].x * (1.f + 2.f * rgb_pad) - rgb_pad;
+        cs[j].y = cs[j].y * (1.f + 2.f * rgb_pad) - rgb_pad;
+        cs[j].z = cs[j].z * (1.f + 2.f * rgb_pad) - rgb_pad;
+      }
       al[j] = 1.f - expf(-dl * cs[j].w);
       prod *= (1.f - al[j] + 1e-8f);
     }
@@ -780,7 +785,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
 
 template <int SPL>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ z,
-                                                            float last_delta, const float* __restrict__ d_rgb, int N, int S,
+                                                            float last_delta, float rgb_pad, const float* __restrict__ d_rgb, int N, int S,
                                                             float* __restrict__ d_raw) {
   const int lane = threadIdx.x & 63;
   const long ray = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -797,7 +802,12 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
     if (s < S) {
       const float zc = zr[s];
       dl[j] = (s + 1 < S) ? (zr[s + 1] - zc) : last_delta;
-      const float4 c = rr[s];
+      float4 c = rr[s];
+      if (rgb_pad != 0.f) {
+        c.x = c.x * (1.f + 2.f * rgb_pad) - rgb_pad;
+        c.y = c.y * (1.f + 2.f * rgb_pad) - rgb_pad;
+        c.z = c.z * (1.f + 2.f * rgb_pad) - rgb_pad;
+      }
       al[j] = 1.f - expf(-dl[j] * c.w);
       cg[j] = c.x * g0 + c.y * g1 + c.z * g2;
       prod *= (1.f - al[j] + 1e-8f);
@@ -834,7 +844,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
       // d/d alpha_j = T_j (c_j.g) - (sum_{i>j} u_i) / (1 - alpha_j + 1e-8)
       const float dalpha = Ts[j] * cg[j] - suffix / (1.f - al[j] + 1e-8f);
       const float dsigma = dalpha * dl[j] * (1.f - al[j]);  // d alpha / d sigma = delta * exp(-delta sigma)
-      const float wj = al[j] * Ts[j];
+      const float wj = al[j] * Ts[j] * (1.f + 2.f * rgb_pad);
       *(float4*)(d_raw + (ray * S + s) * 4) = make_float4(wj * g0, wj * g1, wj * g2, dsigma);
     }
     suffix += u[j];
@@ -1188,19 +1198,19 @@ extern "C" int swn_group_colsum(const void* in, int dtype, int n_groups, int row
     else return swn::set_error("composite: n_samples %d > 1024", n_samples);       \
   } while (0)
 
-extern "C" int swn_composite_fwd(const float* raw, const float* z, float last_delta, int n_rays, int n_samples,
+extern "C" int swn_composite_fwd(const float* raw, const float* z, float last_delta, float rgb_padding, int n_rays, int n_samples,
                                  float* rgb, float* depth, float* depth_var, float* weights, void* stream) {
   SWN_CHECK(raw && z, "swn_composite_fwd: null pointer");
-  COMPOSITE_DISPATCH(composite_fwd_kernel, dim3(cdiv(n_rays, 4)), dim3(256), 0, as_stream(stream), raw, z, last_delta,
+  COMPOSITE_DISPATCH(composite_fwd_kernel, dim3(cdiv(n_rays, 4)), dim3(256), 0, as_stream(stream), raw, z, last_delta, rgb_padding,
                      n_rays, n_samples, rgb, depth, depth_var, weights);
   SWN_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int swn_composite_bwd(const float* raw, const float* z, float last_delta, const float* d_rgb, int n_rays,
-                                 int n_samples, float* d_raw, void* stream) {
+extern "C" int swn_composite_bwd(const float* raw, const float* z, float last_delta, float rgb_padding, const float* d_rgb,
+                                 int n_rays, int n_samples, float* d_raw, void* stream) {
   SWN_CHECK(raw && z && d_rgb && d_raw, "swn_composite_bwd: null pointer");
-  COMPOSITE_DISPATCH(composite_bwd_kernel, dim3(cdiv(n_rays, 4)), dim3(256), 0, as_stream(stream), raw, z, last_delta,
+  COMPOSITE_DISPATCH(composite_bwd_kernel, dim3(cdiv(n_rays, 4)), dim3(256), 0, as_stream(stream), raw, z, last_delta, rgb_padding,
                      d_rgb, n_rays, n_samples, d_raw);
   SWN_LAUNCH_CHECK();
   return 0;

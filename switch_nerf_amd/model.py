@@ -513,6 +513,78 @@ class SwitchNeRF:
         out["rgb"], out["depth"], out["depth_variance"], _ = ops.composite_fwd(raw_m, zm)
         return c, cf, out
 
+    # ------------------------------------------------------------------------------------------ mip path
+    def forward_level_mip(self, rays, radii, image_indices, z, seg_tokens, sigma_noise=None, no_batch=False, tag="c",
+                          want_weights=False, rgb_padding=0.001, pe_dir=None):
+        """One level of rendering_mip._get_results (rendering_mip.py:195-215 / :236-253): the S edges `z` of every ray give
+        S - 1 conical frustums; integrated positional encoding (swn_mip_encode) -> the same network (MipNeRFMoE.forward is
+        NeRFMoE.forward behind MipEmbedder, nerf_moe.py:675-810) -> compositing at the frustum mid points with the colour
+        padding of :383-386."""
+        N, S1 = rays.shape[0], z.shape[1] - 1
+        pe = ops.mip_encode(rays, radii, z, self.cfg["pos_xyz_dim"], self.dtype, self.KP)
+        if pe_dir is None:
+            pe_dir = self._dir_pe(rays)
+        seg = min(seg_tokens, N * S1)
+        c = self._net_forward(pe, pe_dir, image_indices, N, S1, seg, sigma_noise, None, no_batch, tag)
+        c["z_edges"] = z
+        c["z"] = (0.5 * (z[:, 1:] + z[:, :-1])).contiguous()
+        c["rgb_padding"] = float(rgb_padding)
+        c["rgb"], c["depth"], c["depth_variance"], c["weights"] = ops.composite_fwd(c["raw"], c["z"], want_weights=want_weights,
+                                                                                    rgb_padding=rgb_padding)
+        return c
+
+    def forward_mip(self, rays, radii, image_indices, n_samples, n_fine, seg_tokens, perturb=0.0, perturb_rand=None, fine_u=None,
+                    sigma_noise=None, sigma_noise_fine=None, no_batch=False, rgb_padding=0.001, resample_padding=0.01):
+        """rendering_mip.render_rays (rendering_mip.py:133-172): coarse level on n_samples edges, then (n_fine > 0) the fine
+        level on n_fine edges resampled from the blurred coarse weights (stop_level_grad: no gradient through the edges).
+        fine_u: the U[0,1) tensor [N, n_fine] of sorted_piecewise_constant_pdf1's randomized branch (drawn here if perturb > 0
+        and none is given); perturb = 0 -> deterministic."""
+        N = rays.shape[0]
+        t_steps = torch.linspace(0, 1, n_samples, dtype=torch.float32).to(self.dev)
+        radii = radii.reshape(-1).contiguous()
+        z = ops.sample_z(rays, t_steps, perturb_rand, perturb, n_samples)
+        c = self.forward_level_mip(rays, radii, image_indices, z, seg_tokens, sigma_noise, no_batch, "c", n_fine > 0, rgb_padding)
+        if n_fine <= 0:
+            return c, None
+        if fine_u is None and perturb > 0:
+            fine_u = torch.rand(N, n_fine, device=self.dev)
+        z_f = ops.mip_resample(z, c["weights"], fine_u if perturb > 0 else None, n_fine, resample_padding)
+        cf = self.forward_level_mip(rays, radii, image_indices, z_f, seg_tokens, sigma_noise_fine, no_batch, "f", False, rgb_padding,
+                                    pe_dir=c["pe_dir"])
+        return c, cf
+
+    def train_step_mip(self, rgbs, rays, radii, image_indices, n_samples, n_fine, seg_tokens, perturb=1.0, perturb_rand=None,
+                       fine_u=None, sigma_noise=None, sigma_noise_fine=None, optimizer_step=True, grad_allreduce=None,
+                       rgb_padding=0.001, resample_padding=0.01):
+        """Runner._training_step_mip (runner.py:1126-1167): loss = (mse(rgb_fine) + mse(rgb_coarse)) / 2
+        + wt * (mean(gate_loss_fine) + mean(gate_loss_coarse)) / 2, backward through both levels, Adam."""
+        self.grad.zero_()
+        c, cf = self.forward_mip(rays, radii, image_indices, n_samples, n_fine, seg_tokens, perturb, perturb_rand, fine_u,
+                                 sigma_noise, sigma_noise_fine, False, rgb_padding, resample_padding)
+        levels = [c] if cf is None else [cf, c]
+        share = 1.0 / len(levels)
+        photo, gate_loss = 0.0, 0.0
+        for lv in levels:
+            diff = lv["rgb"] - rgbs
+            lv["_d_rgb"] = (diff * (2.0 * share / diff.numel())).contiguous()
+            photo = photo + share * (diff * diff).mean()
+            gate_loss = gate_loss + share * lv["l_aux"].mean()
+        loss = photo + self.wt * gate_loss
+        for lv in levels:
+            d_raw = ops.composite_bwd(lv["raw"], lv["z"], lv["_d_rgb"], rgb_padding=lv["rgb_padding"])
+            d_laux = torch.full((lv["n_seg"],), share * self.wt / lv["n_seg"], dtype=torch.float32, device=self.dev)
+            self.backward_net(lv, d_raw, d_laux)
+        scale = 1.0
+        if grad_allreduce is not None:
+            scale = grad_allreduce(self.grad)
+        if optimizer_step:
+            self.step_count += 1
+            ops.adam_step(self.flat, self.grad, self.m, self.v, None, self.step_count, self.lr, grad_scale=scale)
+            self.refresh_compute_copies()
+        top = levels[0]
+        return dict(loss=loss, photo_loss=photo, gate_loss=gate_loss, psnr=-10.0 * torch.log10(((top["rgb"] - rgbs) ** 2).mean()),
+                    depth_variance=top["depth_variance"].mean(), ctx=c, ctx_fine=cf, rgb=top["rgb"], depth=top["depth"])
+
     # ------------------------------------------------------------------------------------------ NeRFMoE mirrors
     training = True
     moe_no_batch = False

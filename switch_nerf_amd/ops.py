@@ -210,21 +210,43 @@ def group_colsum(x, rows_per_group: int):
     return out
 
 
-def composite_fwd(raw, z, last_delta=1e10, want_weights=False):
+def sample_z(rays, t_steps, perturb_rand, perturb: float, n_samples: int):
+    n = rays.shape[0]
+    z = torch.empty(n, n_samples, dtype=torch.float32, device=rays.device)
+    call("swn_sample_z", _p(rays), _p(t_steps), _p(perturb_rand), float(perturb), n, n_samples, _p(z), _stream())
+    return z
+
+
+def mip_encode(rays, radii, z, l_xyz: int, dtype, pe_stride: int):
+    """-> integrated positional encoding of the n_edges - 1 frustums per ray: [N * (S - 1), pe_stride] dtype"""
+    n, S = z.shape
+    pe = torch.empty(n * (S - 1), pe_stride, dtype=dtype, device=rays.device)
+    call("swn_mip_encode", _p(rays), _p(radii), _p(z), n, S, l_xyz, _dt(pe), _p(pe), pe_stride, _stream())
+    return pe
+
+
+def mip_resample(z, weights, u_rand, n_fine: int, padding: float = 0.01):
+    n, S = z.shape
+    zf = torch.empty(n, n_fine, dtype=torch.float32, device=z.device)
+    call("swn_mip_resample", _p(z), _p(weights), _p(u_rand), float(padding), n, S, n_fine, _p(zf), _stream())
+    return zf
+
+
+def composite_fwd(raw, z, last_delta=1e10, want_weights=False, rgb_padding=0.0):
     N, S = z.shape
     dev = z.device
     rgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
     depth = torch.empty(N, dtype=torch.float32, device=dev)
     dvar = torch.empty(N, dtype=torch.float32, device=dev)
     w = torch.empty(N, S, dtype=torch.float32, device=dev) if want_weights else None
-    call("swn_composite_fwd", _p(raw), _p(z), float(last_delta), N, S, _p(rgb), _p(depth), _p(dvar), _p(w), _stream())
+    call("swn_composite_fwd", _p(raw), _p(z), float(last_delta), float(rgb_padding), N, S, _p(rgb), _p(depth), _p(dvar), _p(w), _stream())
     return rgb, depth, dvar, w
 
 
-def composite_bwd(raw, z, d_rgb, last_delta=1e10):
+def composite_bwd(raw, z, d_rgb, last_delta=1e10, rgb_padding=0.0):
     N, S = z.shape
     d_raw = torch.empty(N * S, 4, dtype=torch.float32, device=z.device)
-    call("swn_composite_bwd", _p(raw), _p(z), float(last_delta), _p(d_rgb), N, S, _p(d_raw), _stream())
+    call("swn_composite_bwd", _p(raw), _p(z), float(last_delta), float(rgb_padding), _p(d_rgb), N, S, _p(d_raw), _stream())
     return d_raw
 
 

@@ -70,3 +70,37 @@ def render_rays(nerf, bg_nerf, rays: torch.Tensor, image_indices: Optional[torch
     if getattr(hparams, "return_sigma", False):
         res["sigma_coarse"] = c["raw"][:, 3].view(N, S)
     return res, False
+
+
+def render_rays_mip(nerf, rays: torch.Tensor, radii: torch.Tensor, image_indices: Optional[torch.Tensor], hparams,
+                    get_depth: bool = True, get_depth_variance: bool = True) -> Tuple[Dict[str, torch.Tensor], bool]:
+    """Mirror of rendering_mip.render_rays (/root/reference/switch_nerf/rendering_mip.py:133-172) for MipNeRFMoE-style models:
+    results carry rgb_coarse, gate_loss_coarse and, with fine_samples > 0, rgb_fine, depth_fine, depth_variance_fine,
+    gate_loss_fine (the coarse level reports depth only when it is the last one, :207-208)."""
+    N = rays.shape[0]
+    S, F = hparams.coarse_samples, int(getattr(hparams, "fine_samples", 0))
+    perturb = hparams.perturb if nerf.training else 0
+    pr = torch.rand(N, S, device=rays.device) if perturb > 0 else None
+    chunk = hparams.model_chunk_size
+    noise = noise_f = None
+    if getattr(hparams, "use_sigma_noise", False) and hparams.sigma_noise_std > 0 and nerf.training:
+        noise = torch.randn(N * (S - 1), device=rays.device) * hparams.sigma_noise_std
+        noise_f = torch.randn(N * max(F - 1, 0), device=rays.device) * hparams.sigma_noise_std if F > 0 else None
+    if image_indices is None:
+        image_indices = torch.zeros(N, dtype=torch.long, device=rays.device)
+    c, cf = nerf.forward_mip(rays.contiguous(), radii, image_indices, S, F, chunk, float(perturb), pr, None, noise, noise_f,
+                             no_batch=nerf.moe_no_batch, rgb_padding=float(getattr(hparams, "rgb_padding", 0.001) or 0.0),
+                             resample_padding=float(getattr(hparams, "weights_resample_padding", 0.01)))
+    res = {"rgb_coarse": c["rgb"], "gate_loss_coarse": c["l_aux"]}
+    top, typ = (c, "coarse") if cf is None else (cf, "fine")
+    if cf is not None:
+        res["rgb_fine"], res["gate_loss_fine"] = cf["rgb"], cf["l_aux"]
+    if get_depth:
+        res[f"depth_{typ}"] = top["depth"]
+    if get_depth_variance:
+        res[f"depth_variance_{typ}"] = top["depth_variance"]
+    if getattr(hparams, "moe_return_gates", False):
+        res["moe_gates_coarse"] = c["idx"].long().view(N, S - 1, 1, 1)
+        if cf is not None:
+            res["moe_gates_fine"] = cf["idx"].long().view(N, F - 1, 1, 1)
+    return res, False

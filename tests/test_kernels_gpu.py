@@ -505,3 +505,41 @@ def test_adam_and_casts():
     assert torch.equal(out.cpu(), w.transpose(1, 2).contiguous())
     gs = ops().group_colsum(w.view(-1, 256).to(dev()), 75)
     assert report("group_colsum", gs, w.sum(1)) <= 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mip_encode_and_resample(dtype):
+    """swn_sample_z + swn_mip_encode vs the reference's mip_cast_rays + MipEmbedder (golden); swn_mip_resample vs the reference's
+    deterministic sorted_piecewise_constant_pdf1 (golden) and vs the oracle with supplied jitter."""
+    o = ops()
+    g = np.load(os.path.join(G, "mip_kernels.npz"))
+    rays, radii, z = torch.from_numpy(g["rays"]), torch.from_numpy(g["radii"]), torch.from_numpy(g["z"])
+    N, S = z.shape
+    zd = o.sample_z(rays.to(dev()), torch.linspace(0, 1, S).to(dev()), None, 0.0, S)
+    assert torch.equal(zd.cpu(), z)
+    pe = o.mip_encode(rays.to(dev()), radii.reshape(-1).contiguous().to(dev()), zd, 12, dtype, 128)
+    ref = torch.from_numpy(g["ipe"])
+    assert report(f"mip_ipe_{dtype}", pe[:, :75], ref) <= (3e-6 if dtype == torch.float32 else 8e-3)
+    assert pe[:, 75:].abs().max().item() == 0.0
+    if dtype == torch.bfloat16:
+        return
+    w = torch.from_numpy(g["weights"])
+    zs = o.mip_resample(zd, w.to(dev()), None, 40, 0.01)
+    assert report("mip_resample_det_golden", zs, torch.from_numpy(g["z_resampled_det"])) <= 2e-6
+    for (S2, F2) in ((65, 65), (257, 257), (9, 33), (513, 513)):
+        rng = np.random.default_rng(S2 + F2)
+        N2 = 21
+        z2 = torch.from_numpy(np.sort(rng.uniform(0.05, 1, (N2, S2)), 1).astype(np.float32))
+        w2 = torch.from_numpy((rng.uniform(0, 1, (N2, S2 - 1)) ** 4).astype(np.float32))
+        w2[2] = 0
+        u2 = torch.from_numpy(rng.uniform(0, 1, (N2, F2)).astype(np.float32))
+        refz = O.mip_resample(z2, w2, F2, 0.01, u2)
+        got = o.mip_resample(z2.to(dev()), w2.to(dev()), u2.to(dev()), F2, 0.01)
+        # t = (u - cdf0) / (cdf1 - cdf0) amplifies the 1-ulp difference of the normalising sum by 1 / pdf of the bin: with random
+        # edges (bins up to 0.05 wide) that is a few 1e-6 .. 1e-5 in z; the golden above (regular edges) holds 2e-6
+        assert report(f"mip_resample_S{S2}_F{F2}", got, refz) <= 5e-5
+        assert bool((got[:, 1:] >= got[:, :-1]).all().item())       # sorted: the reference's torch.sort is the identity
+    # perturbed edges
+    pr = torch.rand(N, S)
+    zp = o.sample_z(rays.to(dev()), torch.linspace(0, 1, S).to(dev()), pr.to(dev()), 1.0, S)
+    assert torch.equal(zp.cpu(), O.sample_z(rays[:, 6:7], rays[:, 7:8], S, 1.0, pr))

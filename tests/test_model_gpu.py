@@ -253,3 +253,56 @@ def test_expert_parallel_path_single_rank_equals_local_experts(dtype):
         n = int(np.prod(shape))
         a, b = g0[off:off + n], g1[off:off + n]
         assert (a - b).abs().max().item() <= 1e-5 * max(a.abs().max().item(), 1e-12), name
+
+
+@pytest.mark.parametrize("tag", ["det", "perturbed"])
+def test_mip_train_step_vs_reference_golden_fp32(tag):
+    """Two-level mip training step (frustum casting + integrated encoding, weights blur + resampling, colour padding,
+    loss = (fine + coarse) / 2) against the reference's MipNeRFMoE run: routing of both levels exact, rgb <= 1e-4, all grads."""
+    g = np.load(os.path.join(G, f"mip_train_{tag}.npz"))
+    N, S, Fn, chunk = int(g["N"]), int(g["S"]), int(g["F"]), int(g["chunk"])
+    m = _model(torch.float32, int(g["seed"]), float(g["gate_scale"]))
+    rays, img, rgbs = synth.make_rays(72, N)
+    kw = dict(perturb=0.0)
+    if float(g["perturb"]) > 0:
+        kw = dict(perturb=float(g["perturb"]), perturb_rand=_dev(g["perturb_rand"]), fine_u=_dev(g["fine_u"]))
+    st = m.train_step_mip(_dev(rgbs), _dev(rays), _dev(g["radii"]), _dev(img), S, Fn, chunk, optimizer_step=False, **kw)
+    c, cf = st["ctx"], st["ctx_fine"]
+    mis_c = int((c["idx"].cpu().numpy().reshape(N, S - 1) != g["moe_gates_coarse"]).sum())
+    mis_f = int((cf["idx"].cpu().numpy().reshape(N, Fn - 1) != g["moe_gates_fine"]).sum())
+    print(f"mip {tag}: routing mismatches vs reference: coarse {mis_c}, fine {mis_f}")
+    assert mis_c == 0 and mis_f == 0
+    np.testing.assert_allclose(c["rgb"].cpu().numpy(), g["rgb_coarse"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(cf["rgb"].cpu().numpy(), g["rgb_fine"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(cf["depth_variance"].cpu().numpy(), g["depth_variance"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(c["l_aux"].cpu().numpy(), g["gate_loss_coarse"], rtol=1e-5)
+    np.testing.assert_allclose(cf["l_aux"].cpu().numpy(), g["gate_loss_fine"], rtol=1e-5)
+    np.testing.assert_allclose(st["loss"].item(), float(g["loss"]), rtol=1e-5)
+    gd = m.grad_dict()
+    worst = 0.0
+    for k, t in gd.items():
+        got = t.cpu().numpy()
+        ref_sum = g["gsum__" + k]
+        scale = max(1e-12, float(ref_sum[1]))
+        assert abs(synth.checksum(got)[0] - ref_sum[0]) <= 1e-3 * scale + 1e-9, k
+        assert abs(synth.checksum(got)[1] - ref_sum[1]) <= 1e-3 * scale + 1e-9, k
+        sl = got.reshape(-1)[:: max(1, got.size // 499)][:499]
+        ref = g["gslice__" + k]
+        worst = max(worst, float(np.abs(sl - ref).max() / (np.abs(ref).max() + 1e-12)))
+        np.testing.assert_allclose(sl, ref, rtol=2e-3, atol=1e-7 + 2e-4 * np.abs(ref).max(), err_msg=k)
+    print(f"mip {tag}: worst relative gradient-slice error {worst:.2e}")
+
+
+def test_mip_bf16_step_runs_and_learns():
+    N, S, Fn, chunk = 64, 129, 129, 4096
+    rays, img, rgbs = synth.make_rays(128, N)
+    radii = torch.full((N, 1), 1e-3, device="cuda")
+    m = _model(torch.bfloat16, 127, 0.02)
+    first = last = None
+    for it in range(6):
+        st = m.train_step_mip(_dev(rgbs), _dev(rays), radii, _dev(img), S, Fn, chunk, perturb=1.0,
+                              perturb_rand=torch.rand(N, S, device="cuda"))
+        assert torch.isfinite(st["loss"]).item()
+        first = st["loss"].item() if first is None else first
+        last = st["loss"].item()
+    assert last < first

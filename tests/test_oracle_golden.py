@@ -222,3 +222,48 @@ def test_model_forward_nobatch_eval_path():
         r = O.nerf_moe_forward(p, torch.from_numpy(g["x"]), cfg, 1.0, False, None, no_batch=True)
     assert np.array_equal(r["routing"]["idx"], g["moe_gates"].reshape(-1))
     np.testing.assert_allclose(r["outputs"].numpy(), g["outputs"], rtol=0, atol=2e-6)
+
+
+def test_mip_cast_embed_resample():
+    """mip_cast_rays, MipEmbedder and the deterministic level resampling against the reference's own outputs."""
+    g = load("mip_kernels")
+    rays, radii, z = torch.from_numpy(g["rays"]), torch.from_numpy(g["radii"]), torch.from_numpy(g["z"])
+    mean, cov = O.mip_cast_rays(rays[:, 0:3], rays[:, 3:6], radii, z)
+    np.testing.assert_allclose(mean.numpy(), g["mean"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(cov.numpy(), g["cov"], rtol=1e-5, atol=1e-12)
+    ipe = O.mip_embed(mean, cov, 12).reshape(-1, 75)
+    np.testing.assert_allclose(ipe.numpy(), g["ipe"], rtol=0, atol=2e-6)
+    zs = O.mip_resample(z, torch.from_numpy(g["weights"]), 40, 0.01)
+    np.testing.assert_allclose(zs.numpy(), g["z_resampled_det"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["det", "perturbed"])
+def test_mip_training_step(tag):
+    """Two-level mip render + loss + every parameter gradient against the reference's MipNeRFMoE run."""
+    g = load(f"mip_train_{tag}")
+    cfg = synth.BUILDING
+    p = O.params_from_numpy(synth.make_weights(int(g["seed"]), cfg, gate_scale=float(g["gate_scale"])), requires_grad=True)
+    N, S, Fn, chunk = int(g["N"]), int(g["S"]), int(g["F"]), int(g["chunk"])
+    rays, img, rgbs = synth.make_rays(72, N)
+    kw = {}
+    if float(g["perturb"]) > 0:
+        kw = dict(perturb=float(g["perturb"]), perturb_rand=torch.from_numpy(g["perturb_rand"]), fine_u=torch.from_numpy(g["fine_u"]))
+    st = O.training_step_mip(p, torch.from_numpy(rays), torch.from_numpy(g["radii"]), torch.from_numpy(img), torch.from_numpy(rgbs),
+                             cfg, S, Fn, chunk, **kw)
+    res = st["results"]
+    assert np.array_equal(np.concatenate([r["idx"] for r in res["routings"]]).reshape(N, S - 1), g["moe_gates_coarse"])
+    assert np.array_equal(np.concatenate([r["idx"] for r in res["routings_fine"]]).reshape(N, Fn - 1), g["moe_gates_fine"])
+    np.testing.assert_allclose(res["rgb_coarse"].detach().numpy(), g["rgb_coarse"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(res["rgb_fine"].detach().numpy(), g["rgb_fine"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(res["depth_variance_fine"].numpy(), g["depth_variance"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(res["gate_loss_fine"].detach().numpy(), g["gate_loss_fine"], rtol=1e-6)
+    np.testing.assert_allclose(st["loss"].detach().numpy(), g["loss"], rtol=1e-6)
+    st["loss"].backward()
+    for k, t in p.items():
+        ref_sum = g["gsum__" + k]
+        got = t.grad.numpy()
+        scale = max(1e-12, float(ref_sum[1]))
+        assert abs(synth.checksum(got)[0] - ref_sum[0]) <= 2e-4 * scale + 1e-9, k
+        assert abs(synth.checksum(got)[1] - ref_sum[1]) <= 2e-4 * scale + 1e-9, k
+        sl = got.reshape(-1)[:: max(1, got.size // 499)][:499]
+        np.testing.assert_allclose(sl, g["gslice__" + k], rtol=1e-3, atol=1e-7 + 1e-4 * np.abs(g["gslice__" + k]).max(), err_msg=k)
