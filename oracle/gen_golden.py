@@ -325,6 +325,16 @@ def gen_mip():
          z_resampled_det=zs.numpy())
 
 
+def gen_checkpoint_layout():
+    print("[G9] checkpoint layouts: expertmlp state_dict -> the reference's convert_to_seqexperts (model_utils.py:12-28)")
+    cfg = synth.BUILDING
+    sd = {("module." + k): torch.from_numpy(v.copy()) for k, v in synth.make_weights(91, cfg).items()}   # DDP-prefixed, as saved
+    conv = model_utils.convert_to_seqexperts(dict(sd))
+    keys = sorted(conv.keys())
+    save("checkpoint_seqexperts", keys=np.array(keys), sums=np.stack([synth.checksum(conv[k].numpy()) for k in keys]),
+         shapes=np.array([str(tuple(conv[k].shape)) for k in keys]))
+
+
 # ------------------------------------------------------------------------------------------ G5b compositing + sample_pdf
 def gen_composite():
     print("[G5b] compositing / _sample_pdf on raw tensors")
@@ -366,7 +376,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     todo = dict(routing=gen_routing, pe=gen_pe, moe=gen_moe_layer, model=gen_model_forward, nobatch=gen_model_forward_nobatch,
-                render=gen_render, fine=gen_render_fine, mip=gen_mip, composite=gen_composite)
+                render=gen_render, fine=gen_render_fine, mip=gen_mip, ckpt=gen_checkpoint_layout, composite=gen_composite)
     for k, fn in todo.items():
         if a.only and k not in a.only.split(","):
             continue

@@ -129,7 +129,12 @@ class SwitchNeRF:
         self.load_state_dict(sd)
 
     def load_state_dict(self, sd):
-        """Accepts the reference's NeRFMoE.state_dict() key layout; values torch or numpy."""
+        """Accepts the reference's NeRFMoE.state_dict() key layout - as saved (`module.` prefix of
+        the DDP wrapper, expertmlp stacking) or after the reference's convert_to_seqexperts (per-expert modules,
+        models/model_utils.py:12-28); values torch or numpy.  See checkpoint.py."""
+        from . import checkpoint
+        sd = checkpoint.to_expertmlp(sd)
+
         def t(k):
             v = sd[k]
             v = torch.from_numpy(np.asarray(v)) if not torch.is_tensor(v) else v
@@ -188,9 +193,15 @@ class SwitchNeRF:
         out["embedding_a.weight"] = d["emb"].clone()
         return out
 
-    def state_dict(self):
-        """Parameters in the reference's key layout (so checkpoints are interchangeable)."""
-        return self._to_ref_layout(self.p)
+    def state_dict(self, layout="expertmlp", prefix=""):
+        """Parameters in the reference's key layout (so checkpoints are interchangeable): layout "expertmlp" (what the
+        reference trains and saves) or "seqexperts" (what its evaluation loads after convert_to_seqexperts)."""
+        sd = self._to_ref_layout(self.p)
+        if layout == "seqexperts":
+            from . import checkpoint
+            return checkpoint.to_seqexperts(sd, prefix)
+        assert layout == "expertmlp"
+        return {prefix + k: v for k, v in sd.items()}
 
     def grad_dict(self):
         """Gradients in the reference's key layout (for parity tests)."""

@@ -306,3 +306,50 @@ def test_mip_bf16_step_runs_and_learns():
         first = st["loss"].item() if first is None else first
         last = st["loss"].item()
     assert last < first
+
+
+def test_checkpoint_layouts_round_trip_through_the_model():
+    """load_state_dict takes the DDP-prefixed expertmlp layout and the seqexperts layout of the reference's evaluation;
+    both give the same model (identical render), and state_dict(layout=...) writes them back exactly."""
+    from switch_nerf_amd.model import SwitchNeRF
+    sd = synth.make_weights(131, synth.BUILDING)
+    rays, img, _ = synth.make_rays(132, 32)
+    outs = []
+    m0 = _model(torch.float32, 131, 1.0)
+    variants = [sd, {"module." + k: v for k, v in sd.items()}, m0.state_dict(layout="seqexperts", prefix="module.")]
+    for v in variants:
+        m = SwitchNeRF(synth.BUILDING, dtype=torch.float32)
+        m.load_state_dict(v)
+        c = m.forward_rays(_dev(rays), _dev(img), 64, 2048)
+        outs.append(c["rgb"].clone())
+        back = m.state_dict()
+        for k, ref in sd.items():
+            assert torch.equal(back[k].cpu(), torch.from_numpy(ref)), k
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_sixteen_experts_vs_oracle_fp32():
+    """16 experts (the expert count of the Mission Bay recipe) at building widths: routing, render and gradients vs the oracle."""
+    cfg = dict(synth.BUILDING, num_experts=16)
+    N, S, chunk = 64, 64, 2048
+    sd = synth.make_weights(141, cfg, gate_scale=0.05)
+    rays, img, rgbs = synth.make_rays(142, N)
+    from switch_nerf_amd.model import SwitchNeRF
+    m = SwitchNeRF(cfg, dtype=torch.float32)
+    m.load_state_dict(sd)
+    st = m.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0, optimizer_step=False)
+    c = st["ctx"]
+    p = O.params_from_numpy(sd, requires_grad=True)
+    ost = O.training_step(p, torch.from_numpy(rays), torch.from_numpy(img), torch.from_numpy(rgbs), cfg, S, chunk)
+    ost["loss"].backward()
+    res = ost["results"]
+    ref_idx = np.concatenate([r["idx"] for r in res["routings"]])
+    mis = int((c["idx"].cpu().numpy() != ref_idx).sum())
+    print(f"E=16: routing mismatches vs oracle {mis} of {ref_idx.size}; experts used {len(np.unique(ref_idx))}")
+    assert mis == 0 and len(np.unique(ref_idx)) >= 12
+    np.testing.assert_allclose(c["rgb"].cpu().numpy(), res["rgb_coarse"].detach().numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(st["loss"].item(), ost["loss"].item(), rtol=2e-5)
+    for k, t in m.grad_dict().items():
+        ref = p[k].grad.numpy()
+        err = np.abs(t.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err <= (2e-3 if ref.size > 4 else 1e-2), (k, err)       # scalar biases: a cancelling sum over all points

@@ -267,3 +267,23 @@ def test_mip_training_step(tag):
         assert abs(synth.checksum(got)[1] - ref_sum[1]) <= 2e-4 * scale + 1e-9, k
         sl = got.reshape(-1)[:: max(1, got.size // 499)][:499]
         np.testing.assert_allclose(sl, g["gslice__" + k], rtol=1e-3, atol=1e-7 + 1e-4 * np.abs(g["gslice__" + k]).max(), err_msg=k)
+
+
+def test_checkpoint_layouts_match_reference_conversion():
+    """switch_nerf_amd.checkpoint.to_seqexperts reproduces the reference's convert_to_seqexperts key for key (names, shapes,
+    values), and to_expertmlp inverts it (and strips the DDP prefix)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from switch_nerf_amd import checkpoint as ck
+    g = load("checkpoint_seqexperts")
+    sd = {("module." + k): torch.from_numpy(v.copy()) for k, v in synth.make_weights(91, synth.BUILDING).items()}
+    conv = ck.to_seqexperts(sd, prefix="module.")
+    assert sorted(conv.keys()) == list(g["keys"])
+    for k, s_ref, shp in zip(g["keys"], g["sums"], g["shapes"]):
+        assert str(tuple(conv[k].shape)) == shp, k
+        np.testing.assert_allclose(synth.checksum(conv[k].numpy()), s_ref, rtol=1e-6, err_msg=k)
+    back = ck.to_expertmlp(conv)
+    ref = synth.make_weights(91, synth.BUILDING)
+    assert sorted(back.keys()) == sorted(ref.keys())
+    for k, v in ref.items():
+        assert torch.equal(back[k], torch.from_numpy(v)), k
