@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--parallelism", default="dp", choices=["dp", "ep"],
                     help="dp (default): experts replicated, one gradient all-reduce per step; ep: experts sharded over the ranks, "
                          "dispatched rows exchanged with RCCL all-to-all (BASELINE.json configs[2]; needs gpus | 8)")
+    ap.add_argument("--fine", type=int, default=0, help="hierarchical sampling: fine samples per ray on top of --samples (other recipes; "
+                                                        "the headline metric is --fine 0)")
+    ap.add_argument("--mip", action="store_true", help="mip recipe: --samples edges per level (frustums = edges - 1), two levels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     a = ap.parse_args()
@@ -107,11 +110,22 @@ def main():
         from switch_nerf_amd.parallel import ExpertParallel
         model.set_expert_parallel(ExpertParallel(rank, world, model.E))
 
+    radii = torch.full((a.rays, 1), 1e-3, device=dev)
+
     def step():
         pr = torch.rand(a.rays, a.samples, device=dev)              # rendering.py:582 rand_like
+        ar = allreduce if world > 1 else None
+        if a.mip:      # rendering_mip recipe: a.samples edges -> a.samples - 1 frustums per level, coarse + fine level
+            nf = a.rays * (a.samples - 1)
+            return model.train_step_mip(rgbs, rays, radii, idx, a.samples, a.samples, a.chunk, perturb=1.0, perturb_rand=pr,
+                                        sigma_noise=torch.randn(nf, device=dev), sigma_noise_fine=torch.randn(nf, device=dev),
+                                        grad_allreduce=ar)
         noise = torch.randn(P, device=dev)                          # rendering.py:366, sigma_noise_std = 1
+        kw = {}
+        if a.fine > 0:
+            kw = dict(fine_samples=a.fine, sigma_noise_fine=torch.randn(a.rays * a.fine, device=dev))
         return model.train_step(rgbs, rays, idx, a.samples, a.chunk, perturb=1.0, perturb_rand=pr, sigma_noise=noise,
-                                grad_allreduce=allreduce if world > 1 else None)
+                                grad_allreduce=ar, **kw)
 
     for _ in range(a.warmup):
         st = step()
@@ -140,7 +154,7 @@ def main():
     L, M, E = model.L, model.M, model.E
     esz = 2 if dtype == torch.bfloat16 else 4
     kern = {}
-    for name, evs in model.events.items():
+    for name, evs in ({} if (a.fine or a.mip) else model.events).items():       # (other recipes: headline number only)
         kern[name] = sum(x.elapsed_time(y) for x, y in evs) / len(evs)          # ms per step
     flops_chain = 2.0 * L * M * M * kept                                       # expert fwd == bwd-data == wgrad flops
     # algorithmic HBM bytes per launch: fwd reads x, writes L-1 activations + output; bwd reads dout and the
@@ -185,13 +199,14 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": f"configs[1]: 8-expert top-1 expertmlp, capacity_factor=1.0, BPR, {a.rays} rays x {a.samples} samples"
                                f" per GPU, {P // a.chunk} segments of {a.chunk} points, building.yaml shapes, random-init weights,"
-                               f" gate_scale={a.gate_scale}",
+                               f" gate_scale={a.gate_scale}" + (f", + {a.fine} fine samples (hierarchical)" if a.fine else "")
+                               + (", mip recipe (two levels)" if a.mip else ""),
                    "rays_per_gpu": a.rays, "samples": a.samples, "segment_points": a.chunk, "parallelism": f"{a.parallelism}{world}",
                    "kept_token_fraction": round(kept / P, 4), "loss": round(float(st["loss"].item()), 6)},
         "roofline": roof, "kernels": detail,
     }
     if rank == 0:
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not (a.fine or a.mip):
             try:
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:      # the baseline must never take the bench line down
