@@ -234,6 +234,20 @@ int swn_wgrad(const void* a, const void* b, const int32_t* a_gather, const int32
               int n_groups, int n_wsets, int group_stride, const int32_t* group_rows, int group_rows_clamp,
               float* dw, float* db, int n_splits, int tag /* profiling only: 0 generic, 1 expert */,
               void* workspace, size_t workspace_bytes, void* stream);
+/* Up to 8 such GEMMs of identical shape and grouping in ONE launch (grid z): the weight gradients of all layers of the
+ * ragged expert MLP - a group with few rows finishes early, and only a launch that holds every layer's workgroups lets the
+ * hardware fill the freed CUs (per-layer launches run as long as their fullest group).  workspace: n_items x the size below. */
+typedef struct swn_wgrad_item {
+  const void* a;
+  const void* b;
+  const int32_t* a_gather;
+  const int32_t* b_gather;
+  float* dw;
+  float* db;
+} swn_wgrad_item;
+int swn_wgrad_batched(const swn_wgrad_item* items, int n_items, int dtype, int m_dim, int n_dim,
+                      int n_groups, int n_wsets, int group_stride, const int32_t* group_rows, int group_rows_clamp,
+                      int n_splits, int tag, void* workspace, size_t workspace_bytes, void* stream);
 /* workspace (optional, recommended): n_groups * n_splits * (m_dim*n_dim + n_dim) * 4 bytes.  With it every workgroup
  * stores its partial tile and a second kernel reduces them into dw/db (deterministic, no atomics); without it
  * (NULL) partial tiles are added with fp32 atomics.                                                               */

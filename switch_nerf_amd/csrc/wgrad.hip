@@ -26,14 +26,12 @@ template <> struct WCfg<bf16_t> { static constexpr int BKR = 32; };
 template <> struct WCfg<float> { static constexpr int BKR = 16; };
 
 struct WgradArgs {
-  const void* a;
-  const void* b;
-  const int32_t* a_gather;   // row (in the grouped row space) -> source row of a / b, or NULL: the operand is read through
-  const int32_t* b_gather;   // the routing permutation instead of from a gathered copy (saves writing that copy)
+  swn_wgrad_item it[8];      // one GEMM per blockIdx.z (same shapes and grouping); a_gather / b_gather: row (in the grouped row
+                             // space) -> source row of a / b, or NULL: the operand is read through the routing permutation
+                             // instead of from a gathered copy (saves writing that copy)
+  size_t partial_stride;     // floats between the partial-tile areas of consecutive items
   int m_dim, n_dim, n_groups, n_wsets, group_stride, clamp, rows_per_split;
   const int32_t* group_rows;
-  float* dw;
-  float* db;
   float* partial;   // [n_groups * n_splits][m_dim * n_dim + n_dim] fp32 partial tiles (plain stores), or NULL = atomics
   int n_splits;
 };
@@ -57,6 +55,7 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
   const int wm = wave >> 2, wn = wave & 3;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int g = blockIdx.x, split = blockIdx.y;
+  const swn_wgrad_item& it = p.it[blockIdx.z];
   int rows_valid = p.group_stride;
   if (p.group_rows) rows_valid = min(p.group_rows[g], p.clamp);
   const int r_begin = split * p.rows_per_split;
@@ -97,10 +96,10 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
     for (int i = 0; i < 2; ++i) {
       const int ar = min(r0 + a_row[i], r_end - 1), br = min(r0 + b_row[i], r_end - 1);
       long as = grow0 + ar, bs = grow0 + br;
-      if (p.a_gather) as = max(p.a_gather[as], 0);     // valid rows (< group_rows) always carry a source row
-      if (p.b_gather) bs = max(p.b_gather[bs], 0);
-      ra[i] = *(const uint4*)((const char*)p.a + (as * (long)m_dim) * sizeof(T) + a_ch[i] * 16);
-      rb[i] = *(const uint4*)((const char*)p.b + (bs * (long)n_dim) * sizeof(T) + b_ch[i] * 16);
+      if (it.a_gather) as = max(it.a_gather[as], 0);     // valid rows (< group_rows) always carry a source row
+      if (it.b_gather) bs = max(it.b_gather[bs], 0);
+      ra[i] = *(const uint4*)((const char*)it.a + (as * (long)m_dim) * sizeof(T) + a_ch[i] * 16);
+      rb[i] = *(const uint4*)((const char*)it.b + (bs * (long)n_dim) * sizeof(T) + b_ch[i] * 16);
     }
   };
   auto lstore = [&](int buf, int r0) {
@@ -114,7 +113,7 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
   };
 
   const bool active = (wm * 128 < m_dim) && (wn * 64 < n_dim);
-  const bool do_bias = (p.db != nullptr) && wm == 0 && (wn * 64 < n_dim);
+  const bool do_bias = (it.db != nullptr) && wm == 0 && (wn * 64 < n_dim);
 
   gload(r_begin);
   lstore(0, r_begin);
@@ -208,8 +207,9 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
   // ---- epilogue: this workgroup's partial tile goes to the workspace with plain stores (a reduce kernel sums the
   // partials; device-scope fp32 atomics from hundreds of workgroups onto one 256 KiB tile are fabric-bound), or,
   // without a workspace, straight into dW with atomics.
-  float* dw = p.dw + (size_t)wset * m_dim * n_dim;
-  float* part = p.partial ? p.partial + ((size_t)g * p.n_splits + split) * ((size_t)m_dim * n_dim + n_dim) : nullptr;
+  float* dw = it.dw + (size_t)wset * m_dim * n_dim;
+  float* part = p.partial ? p.partial + blockIdx.z * p.partial_stride + ((size_t)g * p.n_splits + split) * ((size_t)m_dim * n_dim + n_dim)
+                          : nullptr;
   if (active) {
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -239,17 +239,24 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
       if constexpr (sizeof(T) == 2) n = wn * 64 + 2 * l31 + qq; else n = wn * 64 + qq * 32 + l31;
       if (n < n_dim) {  // D row i = 0 (every row equal)
         if (part) part[(size_t)m_dim * n_dim + n] = accb[qq][0];
-        else unsafeAtomicAdd(p.db + (size_t)wset * n_dim + n, accb[qq][0]);
+        else unsafeAtomicAdd(it.db + (size_t)wset * n_dim + n, accb[qq][0]);
       }
     }
   }
 }
 
 // dw[wset][:] += sum over the partial tiles of (group % n_wsets == wset, split) that were actually produced.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, const int32_t* __restrict__ group_rows,
-                                                           int clamp, int group_stride, int rows_per_split, int n_groups,
-                                                           int n_wsets, int n_splits, int tile_elems, int mn, float* __restrict__ dw,
-                                                           float* __restrict__ db) {
+struct WgradReduceArgs {
+  float* dw[8];
+  float* db[8];
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial_all, size_t partial_stride,
+                                                           const int32_t* __restrict__ group_rows, int clamp, int group_stride,
+                                                           int rows_per_split, int n_groups, int n_wsets, int n_splits, int tile_elems,
+                                                           int mn, const WgradReduceArgs ra) {
+  const float* partial = partial_all + blockIdx.z * partial_stride;
+  float* dw = ra.dw[blockIdx.z];
+  float* db = ra.db[blockIdx.z];
   const int wset = blockIdx.y;
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= tile_elems) return;
@@ -269,26 +276,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 using namespace swn;
 
-extern "C" int swn_wgrad(const void* a, const void* b, const int32_t* a_gather, const int32_t* b_gather, int dtype, int m_dim,
-                         int n_dim, int n_groups, int n_wsets, int group_stride, const int32_t* group_rows, int group_rows_clamp,
-                         float* dw, float* db, int n_splits, int tag, void* workspace, size_t workspace_bytes, void* stream) {
+static int wgrad_launch(const swn_wgrad_item* items, int n_items, int dtype, int m_dim, int n_dim, int n_groups, int n_wsets,
+                        int group_stride, const int32_t* group_rows, int group_rows_clamp, int n_splits, int tag, void* workspace,
+                        size_t workspace_bytes, void* stream) {
   SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_wgrad: bad dtype %d", dtype);
   SWN_CHECK(m_dim >= 32 && m_dim <= 256 && m_dim % 32 == 0 && n_dim >= 32 && n_dim <= 256 && n_dim % 32 == 0,
             "swn_wgrad: m_dim=%d n_dim=%d must be multiples of 32 in [32,256]", m_dim, n_dim);
   SWN_CHECK(n_groups >= 1 && n_wsets >= 1 && group_stride >= 1 && n_splits >= 1, "swn_wgrad: bad geometry");
-  SWN_CHECK(a && b && dw, "swn_wgrad: null pointer");
+  SWN_CHECK(items && n_items >= 1 && n_items <= 8, "swn_wgrad: 1..8 items");
+  WgradArgs p;
+  WgradReduceArgs ra;
+  for (int i = 0; i < 8; ++i) {
+    p.it[i] = items[i < n_items ? i : 0];
+    ra.dw[i] = p.it[i].dw;
+    ra.db[i] = p.it[i].db;
+    SWN_CHECK(p.it[i].a && p.it[i].b && p.it[i].dw, "swn_wgrad: null pointer in item %d", i);
+    SWN_CHECK((p.it[i].db != nullptr) == (p.it[0].db != nullptr), "swn_wgrad: db must be given for all items or for none");
+  }
   const int bkr = dtype == SWN_BF16 ? 32 : 16;
   const int max_rows = group_rows ? (group_rows_clamp < group_stride ? group_rows_clamp : group_stride) : group_stride;
   int rps = cdiv(max_rows, n_splits);
   rps = cdiv(rps, bkr) * bkr;
   const int splits = cdiv(max_rows, rps);
-  WgradArgs p;
-  p.a = a; p.b = b; p.a_gather = a_gather; p.b_gather = b_gather; p.m_dim = m_dim; p.n_dim = n_dim; p.n_groups = n_groups; p.n_wsets = n_wsets;
+  p.m_dim = m_dim; p.n_dim = n_dim; p.n_groups = n_groups; p.n_wsets = n_wsets;
   p.group_stride = group_stride; p.clamp = group_rows ? group_rows_clamp : group_stride; p.rows_per_split = rps;
-  p.group_rows = group_rows; p.dw = dw; p.db = db;
+  p.group_rows = group_rows;
   p.n_splits = splits;
   const size_t tile_elems = (size_t)m_dim * n_dim + n_dim;
-  const size_t need = (size_t)n_groups * splits * tile_elems * sizeof(float);
+  p.partial_stride = (size_t)n_groups * splits * tile_elems;
+  const size_t need = (size_t)n_items * p.partial_stride * sizeof(float);
   p.partial = (workspace && workspace_bytes >= need) ? (float*)workspace : nullptr;
   if (workspace && !p.partial) return swn::set_error("swn_wgrad: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
   const int lds = 4 * bkr * 256 * (dtype == SWN_BF16 ? 2 : 4);
@@ -299,12 +315,28 @@ extern "C" int swn_wgrad(const void* a, const void* b, const int32_t* a_gather, 
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   void* kargs[] = {(void*)&p};
-  e = hipLaunchKernel(fn, dim3(n_groups, splits), dim3(WG_NT), kargs, lds, as_stream(stream));
+  e = hipLaunchKernel(fn, dim3(n_groups, splits, n_items), dim3(WG_NT), kargs, lds, as_stream(stream));
   SWN_CHECK(e == hipSuccess, "swn_wgrad launch: %s", hipGetErrorString(e));
   if (p.partial) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)tile_elems, 256), n_wsets), dim3(256), 0, as_stream(stream), p.partial,
-                       group_rows, p.clamp, group_stride, rps, n_groups, n_wsets, splits, (int)tile_elems, m_dim * n_dim, dw, db);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)tile_elems, 256), n_wsets, n_items), dim3(256), 0, as_stream(stream),
+                       p.partial, p.partial_stride, group_rows, p.clamp, group_stride, rps, n_groups, n_wsets, splits, (int)tile_elems,
+                       m_dim * n_dim, ra);
   }
   SWN_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int swn_wgrad(const void* a, const void* b, const int32_t* a_gather, const int32_t* b_gather, int dtype, int m_dim,
+                         int n_dim, int n_groups, int n_wsets, int group_stride, const int32_t* group_rows, int group_rows_clamp,
+                         float* dw, float* db, int n_splits, int tag, void* workspace, size_t workspace_bytes, void* stream) {
+  swn_wgrad_item it = {a, b, a_gather, b_gather, dw, db};
+  return wgrad_launch(&it, 1, dtype, m_dim, n_dim, n_groups, n_wsets, group_stride, group_rows, group_rows_clamp, n_splits, tag,
+                      workspace, workspace_bytes, stream);
+}
+
+extern "C" int swn_wgrad_batched(const swn_wgrad_item* items, int n_items, int dtype, int m_dim, int n_dim, int n_groups,
+                                 int n_wsets, int group_stride, const int32_t* group_rows, int group_rows_clamp, int n_splits,
+                                 int tag, void* workspace, size_t workspace_bytes, void* stream) {
+  return wgrad_launch(items, n_items, dtype, m_dim, n_dim, n_groups, n_wsets, group_stride, group_rows, group_rows_clamp, n_splits,
+                      tag, workspace, workspace_bytes, stream);
 }

@@ -421,13 +421,16 @@ class SwitchNeRF:
             dx, dx_wait = ep.all_to_all(dx, self.side)
 
         def expert_wgrads():
-            for l in range(L):      # layer 0 reads its input rows, layer L-1 its dZ rows, through the routing permutation
+            # all layers in ONE launch: layer 0 reads its input rows, layer L-1 its dZ rows, through the routing permutation
+            items = []
+            for l in range(L):
                 a = x_first if l == 0 else c["saves"][l - 1]
                 bz = dz_last if l == L - 1 else dz[l]
-                o.wgrad(a, bz, self._local_experts(g[f"exp{l}.w"]), self._local_experts(g[f"exp{l}.b"]), n_groups=ng,
-                        n_wsets=n_loc, group_stride=cap, a_gather=perm if l == 0 else None,
-                        b_gather=perm if l == L - 1 else None, group_rows=grp_rows, group_rows_clamp=cap,
-                        n_splits=self.expert_wgrad_splits or max(1, min(256 // ng, cap // 2048)), tag=1)
+                items.append((a, bz, self._local_experts(g[f"exp{l}.w"]), self._local_experts(g[f"exp{l}.b"]),
+                              perm if l == 0 else None, perm if l == L - 1 else None))
+            for i0 in range(0, L, 8):
+                o.wgrad_batched(items[i0:i0 + 8], n_groups=ng, n_wsets=n_loc, group_stride=cap, group_rows=grp_rows,
+                                group_rows_clamp=cap, n_splits=self.expert_wgrad_splits or max(1, min(256 // ng, cap // 2048)), tag=1)
         side_done = None
         if self.overlap and self.side is not None and not self.profile:
             # independent of everything that follows (they only read the saved activations / dZ and write their own

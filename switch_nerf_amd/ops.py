@@ -10,7 +10,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, ChainDesc, call
+from ._lib import BF16, F32, ChainDesc, WgradItem, call
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -331,6 +331,25 @@ def wgrad(a, b, dw, db=None, n_groups=1, n_wsets=1, group_stride=None, group_row
         ws_bytes = ws.numel()
     call("swn_wgrad", _p(a), _p(b), _p(a_gather), _p(b_gather), _dt(a), m_dim, n_dim, int(n_groups), int(n_wsets), gs, _p(group_rows),
          int(group_rows_clamp if group_rows_clamp is not None else gs), _p(dw), _p(db), int(n_splits), int(tag), _p(ws), ws_bytes, _stream())
+
+
+def wgrad_batched(items, n_groups=1, n_wsets=1, group_stride=None, group_rows=None, group_rows_clamp=None, n_splits=8, tag=0):
+    """items: up to 8 tuples (a, b, dw, db, a_gather, b_gather) of identical shapes / grouping -> one launch (see wgrad)."""
+    a0, b0 = items[0][0], items[0][1]
+    m_dim, n_dim = a0.shape[1], b0.shape[1]
+    gs = int(group_stride if group_stride is not None else a0.shape[0])
+    arr = (WgradItem * len(items))()
+    for i, (a, b, dw, db, ag, bg) in enumerate(items):
+        assert a.shape[1] == m_dim and b.shape[1] == n_dim and a.dtype == a0.dtype
+        arr[i].a, arr[i].b, arr[i].a_gather, arr[i].b_gather, arr[i].dw, arr[i].db = _p(a), _p(b), _p(ag), _p(bg), _p(dw), _p(db)
+    ws_bytes = len(items) * int(n_groups) * int(n_splits) * (m_dim * n_dim + n_dim) * 4
+    key = (a0.device, torch.cuda.current_stream().cuda_stream)
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() < ws_bytes:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a0.device)
+        _wgrad_ws[key] = ws
+    call("swn_wgrad_batched", arr, len(items), _dt(a0), m_dim, n_dim, int(n_groups), int(n_wsets), gs, _p(group_rows),
+         int(group_rows_clamp if group_rows_clamp is not None else gs), int(n_splits), int(tag), _p(ws), ws.numel(), _stream())
 
 
 def adam_step(param, grad, m, v, shadow, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
