@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--fine", type=int, default=0, help="hierarchical sampling: fine samples per ray on top of --samples (other recipes; "
                                                         "the headline metric is --fine 0)")
     ap.add_argument("--mip", action="store_true", help="mip recipe: --samples edges per level (frustums = edges - 1), two levels")
+    ap.add_argument("--model-dim", type=int, default=256, help="layer width (512 = mission_bay.yaml, other recipes)")
+    ap.add_argument("--experts", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     a = ap.parse_args()
@@ -98,7 +100,9 @@ def main():
 
     from switch_nerf_amd.model import SwitchNeRF, BUILDING
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    model = SwitchNeRF(BUILDING, dtype=dtype, device=dev, seed=0)
+    cfg = dict(BUILDING, model_dim=a.model_dim, gate_hidden=a.model_dim, num_experts=a.experts)
+    other = a.fine or a.mip or a.model_dim != 256 or a.experts != 8
+    model = SwitchNeRF(cfg, dtype=dtype, device=dev, seed=0)
     if a.gate_scale != 1.0:
         model.p["wg"].mul_(a.gate_scale)
     rays, idx, rgbs = synth_batch(a.rays, 1000 + rank, dev)
@@ -154,7 +158,7 @@ def main():
     L, M, E = model.L, model.M, model.E
     esz = 2 if dtype == torch.bfloat16 else 4
     kern = {}
-    for name, evs in ({} if (a.fine or a.mip) else model.events).items():       # (other recipes: headline number only)
+    for name, evs in ({} if other else model.events).items():       # (other recipes: headline number only)
         kern[name] = sum(x.elapsed_time(y) for x, y in evs) / len(evs)          # ms per step
     flops_chain = 2.0 * L * M * M * kept                                       # expert fwd == bwd-data == wgrad flops
     # algorithmic HBM bytes per launch: fwd reads x, writes L-1 activations + output; bwd reads dout and the
@@ -197,16 +201,17 @@ def main():
         "metric": "train rays/sec (8192-ray batch, 256 samples, 8 experts)", "value": round(value, 1), "unit": "rays/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": f"configs[1]: 8-expert top-1 expertmlp, capacity_factor=1.0, BPR, {a.rays} rays x {a.samples} samples"
+        "config": {"workload": ("other recipe (informational): " if other else "configs[1]: ") + f"{a.experts}-expert top-1 expertmlp, capacity_factor=1.0, BPR, {a.rays} rays x {a.samples} samples"
                                f" per GPU, {P // a.chunk} segments of {a.chunk} points, building.yaml shapes, random-init weights,"
                                f" gate_scale={a.gate_scale}" + (f", + {a.fine} fine samples (hierarchical)" if a.fine else "")
-                               + (", mip recipe (two levels)" if a.mip else ""),
+                               + (", mip recipe (two levels)" if a.mip else "")
+                               + (f", model_dim {a.model_dim}, {a.experts} experts" if (a.model_dim != 256 or a.experts != 8) else ""),
                    "rays_per_gpu": a.rays, "samples": a.samples, "segment_points": a.chunk, "parallelism": f"{a.parallelism}{world}",
                    "kept_token_fraction": round(kept / P, 4), "loss": round(float(st["loss"].item()), 6)},
         "roofline": roof, "kernels": detail,
     }
     if rank == 0:
-        if world == 1 and not a.no_cpu_baseline and not (a.fine or a.mip):
+        if world == 1 and not a.no_cpu_baseline and not other:
             try:
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:      # the baseline must never take the bench line down

@@ -186,7 +186,8 @@ typedef struct swn_chain_layer {
                            n_workgroups * 8 waves * MI * 64 uint32 (MI = 2 bf16 / 1 fp32), or NULL */
   const float* rowbias; /* f32 [n_rows / rows_per_bias][N] extra bias shared by runs of rows (per-ray terms) or NULL */
   int32_t rows_per_bias;
-  int32_t n, k;         /* output / input features: n in {64,128,192,256}, k in {64,128,256}               */
+  int32_t n, k;         /* output / input features: n a multiple of 64 up to 512, k in {64,128,256,512}; any layer wider than
+                           256 selects the 512-feature kernels for the whole chain                                */
   int32_t relu;         /* 0 none; 1 ReLU (and record the mask if given); 2 multiply by the recorded mask (backward) */
   int32_t skip;         /* add the chain input x before the activation (needs n == layers[0].k) */
 } swn_chain_layer;
@@ -214,6 +215,9 @@ typedef struct swn_chain_desc {
 int swn_mlp_chain(const swn_chain_desc* desc, void* stream);
 /* rows per workgroup tile for dtype (sizes the ReLU mask buffers: ceil(group_stride / rows) * n_groups * rows * 8 words) */
 int swn_chain_tile_rows(int dtype);
+/* uint32 words of one ReLU mask buffer of a chain over n_groups x group_stride rows whose widest layer has max_width features
+ * (layers wider than 256 features run on the 512-feature kernels, whose tiles carry twice the bits per row).           */
+long swn_chain_mask_words(int dtype, int n_groups, int group_stride, int max_width);
 
 /* Pack fp32 master weights [n_wsets][in_dim][out_dim] (the reference's ExpertMLP layout, tutel_moe_layer_nobatch.py:853)
  * into the compute copy swn_mlp_chain consumes.  transpose = 1: forward weights (N = out, K = in);
@@ -248,6 +252,13 @@ typedef struct swn_wgrad_item {
 int swn_wgrad_batched(const swn_wgrad_item* items, int n_items, int dtype, int m_dim, int n_dim,
                       int n_groups, int n_wsets, int group_stride, const int32_t* group_rows, int group_rows_clamp,
                       int n_splits, int tag, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the items being column BLOCKS of wider operands (layers of more than 256 features): item.a / item.b / item.dw point
+ * at the block's first column, lda / ldb / ldw are the row strides (elements) of the full matrices, dw_set_stride / db_set_stride
+ * the elements between consecutive weight sets of the full dW / db; give db only to the items of one row block of dW.            */
+int swn_wgrad_blocks(const swn_wgrad_item* items, int n_items, int dtype, int m_dim, int n_dim, int lda, int ldb, int ldw,
+                     size_t dw_set_stride, size_t db_set_stride, int n_groups, int n_wsets, int group_stride,
+                     const int32_t* group_rows, int group_rows_clamp, int n_splits, int tag, void* workspace,
+                     size_t workspace_bytes, void* stream);
 /* workspace (optional, recommended): n_groups * n_splits * (m_dim*n_dim + n_dim) * 4 bytes.  With it every workgroup
  * stores its partial tile and a second kernel reduces them into dw/db (deterministic, no atomics); without it
  * (NULL) partial tiles are added with fp32 atomics.                                                               */

@@ -56,6 +56,7 @@ SIGNATURES = {
     "swn_mlp_chain": [C.POINTER(ChainDesc), vp],
     "swn_pack_weights": [vp, vp, i32, i32, i32, i32, i32, vp],
     "swn_chain_tile_rows": [i32],
+    "swn_wgrad_blocks": [C.POINTER(WgradItem), i32, i32, i32, i32, i32, i32, i32, sz, sz, i32, i32, i32, vp, i32, i32, i32, vp, sz, vp],
     "swn_wgrad_batched": [C.POINTER(WgradItem), i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, sz, vp],
     "swn_wgrad": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, vp, sz, vp],
     "swn_adam_step": [vp, vp, vp, vp, vp, i32, i64, f32, f32, f32, f32, i32, f32, vp],
@@ -80,6 +81,8 @@ def load():
     lib.swn_last_error.argtypes = []
     lib.swn_route_workspace_bytes.restype = sz
     lib.swn_route_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.swn_chain_mask_words.restype = i64
+    lib.swn_chain_mask_words.argtypes = [i32, i32, i32, i32]
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = i32

@@ -13,6 +13,11 @@ for f in elementwise route chain wgrad sampling mip; do
     pids+=($!)
   fi
 done
+# chain.hip a second time: the 512-feature geometry
+if [ ! -f "$HERE/build/chain_wide.o" ] || [ chain.hip -nt "$HERE/build/chain_wide.o" ] || [ common.hpp -nt "$HERE/build/chain_wide.o" ] || [ ../../include/swn.h -nt "$HERE/build/chain_wide.o" ]; then
+  $HIPCC $FLAGS -DSWN_WIDE=1 -c chain.hip -o "$HERE/build/chain_wide.o" &
+  pids+=($!)
+fi
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC "$HERE"/build/{elementwise,route,chain,wgrad,sampling,mip}.o -o "$HERE/libswn_hip.so"
+$HIPCC --offload-arch=gfx950 -shared -fPIC "$HERE"/build/{elementwise,route,chain,chain_wide,wgrad,sampling,mip}.o -o "$HERE/libswn_hip.so"
 echo "built $HERE/libswn_hip.so"

@@ -22,40 +22,61 @@
 // row-major with 8-byte LDS stores.
 #include "common.hpp"
 
-namespace swn {
+#ifndef SWN_WIDE
+#define SWN_WIDE 0
+#endif
+#if SWN_WIDE
+#define SWN_NS swn_wide
+#else
+#define SWN_NS swn
+#endif
+
+namespace SWN_NS {
+using namespace swn;
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
+// This file is compiled twice (build.sh): as is - layers up to 256 features, the tuned geometry described above - and with
+// -DSWN_WIDE=1 into a second set of kernels for layers up to 512 features (the Mission Bay recipe's model width): a wave then owns
+// 128 output features (4 MFMA feature tiles, 128 accumulator VGPRs), the LDS tile is 64 rows x 1 KiB (bf16; two workgroups per CU)
+// or 2 KiB (fp32; one), and the K loop is left to the compiler's scheduler.
 constexpr int NT = 256;         // threads per workgroup (4 waves)
-constexpr int NI = 2;           // 32-wide feature tiles per wave (4 waves * 2 * 32 = 256 = max features)
-constexpr int ACT_BYTES = 65536;
+constexpr int NI = SWN_WIDE ? 4 : 2;        // 32-wide feature tiles per wave (4 waves * NI * 32 = max features)
+constexpr int ROW_ELEMS = 128 * NI;         // features per LDS tile row: 256 / 512
 constexpr int RING = 4;         // weight-fragment steps in flight
+#if SWN_WIDE
+typedef uint64_t mbits_t;
+#else
+typedef uint32_t mbits_t;
+#endif
 
 template <typename T> struct Cfg;
 #ifndef SWN_BF16_BM
 #define SWN_BF16_BM 64
 #endif
 template <> struct Cfg<bf16_t> {
-  static constexpr int BM = SWN_BF16_BM, MI = BM / 32, KSTEP = 16;   // one ring step = K 16: one 16-byte fragment load per feature tile
-  static constexpr int ACT = BM * 512;                 // LDS tile bytes
-  static constexpr int OCC = BM == 128 ? 2 : 3;        // workgroups per CU (= waves per SIMD) the register budget must allow
+  static constexpr int BM = SWN_WIDE ? 64 : SWN_BF16_BM, MI = BM / 32, KSTEP = 16;   // one ring step = K 16: one 16-byte fragment load per feature tile
+  static constexpr int ROWB = ROW_ELEMS * 2;           // LDS tile row stride in bytes
+  static constexpr int ACT = BM * ROWB;                // LDS tile bytes
+  static constexpr int OCC = SWN_WIDE ? 2 : (BM == 128 ? 2 : 3);   // workgroups per CU (= waves per SIMD) the register budget must allow
   typedef bf16x8_t wfrag_t;
 };
 template <> struct Cfg<float> {
   static constexpr int BM = 64, MI = 2, KSTEP = 8;     // one ring step = K 8: a float4 feeds four 32x32x2 MFMAs
-  static constexpr int ACT = BM * 1024;
-  static constexpr int OCC = 2;
+  static constexpr int ROWB = ROW_ELEMS * 4;
+  static constexpr int ACT = BM * ROWB;
+  static constexpr int OCC = SWN_WIDE ? 1 : 2;
   typedef f32x4_t wfrag_t;
 };
 
 // ---- LDS addressing: activation tile, row-major, row stride 256 elements -------------------------------------
 __device__ __forceinline__ int act_off(bf16_t*, int row, int col) {  // byte offset of element (row, col)
-  return row * 512 + ((((col >> 3) ^ (row & 15))) << 4) + ((col & 7) << 1);
+  return row * Cfg<bf16_t>::ROWB + ((((col >> 3) ^ (row & 15))) << 4) + ((col & 7) << 1);
 }
-__device__ __forceinline__ int act_off(float*, int row, int col) { return row * 1024 + ((col ^ (row & 31)) << 2); }
+__device__ __forceinline__ int act_off(float*, int row, int col) { return row * Cfg<float>::ROWB + ((col ^ (row & 31)) << 2); }
 
 struct ChainArgs {
   swn_chain_desc d;
@@ -189,19 +210,34 @@ __device__ __forceinline__ void k_loop(f32x16_t (&acc)[Cfg<T>::MI][NI], typename
   auto refill = [&](int ks, int r) {
     const int nx = ks + RING;
     if (nx < NSTEPS) {
-      ring[r][0] = __builtin_bit_cast(wfrag_t, __builtin_amdgcn_raw_buffer_load_b128(wcur, lane16, nx * 1024, 0));
-      ring[r][1] = __builtin_bit_cast(wfrag_t, __builtin_amdgcn_raw_buffer_load_b128(wcur, lane16, ts_c + nx * 1024, 0));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        ring[r][ni] = __builtin_bit_cast(wfrag_t, __builtin_amdgcn_raw_buffer_load_b128(wcur, lane16, ni * ts_c + nx * 1024, 0));
     } else {   // wnxt is a valid stream even at the end of the chain (re-read, discarded)
-      ring[r][0] = __builtin_bit_cast(wfrag_t, __builtin_amdgcn_raw_buffer_load_b128(wnxt, lane16, (nx - NSTEPS) * 1024, 0));
-      ring[r][1] = __builtin_bit_cast(wfrag_t, __builtin_amdgcn_raw_buffer_load_b128(wnxt, lane16, ts_n + (nx - NSTEPS) * 1024, 0));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        ring[r][ni] = __builtin_bit_cast(wfrag_t, __builtin_amdgcn_raw_buffer_load_b128(wnxt, lane16, ni * ts_n + (nx - NSTEPS) * 1024, 0));
     }
   };
   if constexpr (sizeof(T) == 2) {
     // activation fragments are software-pipelined through two alternating registers: the read of fragment i+1 is
     // issued before the two MFMAs of fragment i; a ring slot is refilled right after its last use (no copies).
     auto aread = [&](int ks, int mi) -> bf16x8_t {
-      return *(const bf16x8_t*)(act + aoff[ks & 7] + mi * 16384 + (ks >> 3) * 256);
+      return *(const bf16x8_t*)(act + aoff[ks & 7] + mi * (32 * Cfg<T>::ROWB) + (ks >> 3) * 256);
     };
+#if SWN_WIDE
+#pragma unroll
+    for (int ks = 0; ks < NSTEPS; ++ks) {
+      const int r = ks % RING;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const bf16x8_t a = aread(ks, mi);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][ni], a, acc[mi][ni], 0, 0, 0);
+      }
+      refill(ks, r);
+    }
+#else
     bf16x8_t a0 = aread(0, 0), a1;
 #define SWN_PIN() __builtin_amdgcn_sched_barrier(0)
     if constexpr (MI == 4) {
@@ -250,6 +286,7 @@ __device__ __forceinline__ void k_loop(f32x16_t (&acc)[Cfg<T>::MI][NI], typename
       }
     }
 #undef SWN_PIN
+#endif
   } else {
 #pragma unroll
     for (int ks = 0; ks < NSTEPS; ++ks) {
@@ -259,11 +296,12 @@ __device__ __forceinline__ void k_loop(f32x16_t (&acc)[Cfg<T>::MI][NI], typename
         float af[MI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
-          af[mi] = *(const float*)(act + aoff[(ks & 3) * 4 + j] + mi * 32768 + (ks >> 2) * 128);
+          af[mi] = *(const float*)(act + aoff[(ks & 3) * 4 + j] + mi * (32 * Cfg<T>::ROWB) + (ks >> 2) * 128);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-          acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[r][0][j], af[mi], acc[mi][0], 0, 0, 0);
-          acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[r][1][j], af[mi], acc[mi][1], 0, 0, 0);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[r][ni][j], af[mi], acc[mi][ni], 0, 0, 0);
         }
       }
       refill(ks, r);
@@ -286,8 +324,11 @@ __device__ __forceinline__ void epilogue_body(f32x16_t (&acc)[Cfg<T>::MI][NI], c
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = mi * 32 + l31;
-    uint32_t mbits = 0;
-    if (relu == 2) mbits = mk[mi * 64];
+    mbits_t mbits = 0;       // 16 bits per feature tile: one word per pair of tiles ([half][mi][lane] per wave)
+    if (relu == 2) {
+      mbits = mk[mi * 64];
+      if constexpr (NI == 4) mbits |= (mbits_t)((uint64_t)mk[(MI + mi) * 64] << 32);
+    }
     const float* rb = nullptr;
     if (rowb) rb = rbp + (((grow0 % rows_per_bias) + min(m, rows_in_tile - 1)) / rows_per_bias) * (size_t)n;   // clamp: rows past the tile end
 #pragma unroll
@@ -295,7 +336,7 @@ __device__ __forceinline__ void epilogue_body(f32x16_t (&acc)[Cfg<T>::MI][NI], c
       if (ni * 32 < nvalid) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          const int n0 = wn * 64 + ni * 32 + g4 * 8 + lhi * 4;
+          const int n0 = wn * (32 * NI) + ni * 32 + g4 * 8 + lhi * 4;
           float v[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][g4 * 4 + j];
@@ -321,12 +362,12 @@ __device__ __forceinline__ void epilogue_body(f32x16_t (&acc)[Cfg<T>::MI][NI], c
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const bool pos = v[j] > 0.f;
-              mbits |= (pos ? 1u : 0u) << (ni * 16 + g4 * 4 + j);
+              mbits |= (mbits_t)(pos ? 1u : 0u) << (ni * 16 + g4 * 4 + j);
               v[j] = pos ? v[j] : 0.f;
             }
           } else if (relu == 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = ((mbits >> (ni * 16 + g4 * 4 + j)) & 1u) ? v[j] : 0.f;
+            for (int j = 0; j < 4; ++j) v[j] = ((mbits >> (ni * 16 + g4 * 4 + j)) & (mbits_t)1) ? v[j] : 0.f;
           }
           if constexpr (sizeof(T) == 2) {
             uint2 pk;
@@ -341,7 +382,10 @@ __device__ __forceinline__ void epilogue_body(f32x16_t (&acc)[Cfg<T>::MI][NI], c
         }
       }
     }
-    if (relu == 1 && mk) mk[mi * 64] = mbits;
+    if (relu == 1 && mk) {
+      mk[mi * 64] = (uint32_t)mbits;
+      if constexpr (NI == 4) mk[(MI + mi) * 64] = (uint32_t)((uint64_t)mbits >> 32);
+    }
   }
 }
 template <typename T, int TAG>
@@ -351,7 +395,7 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
   typedef typename Cfg<T>::wfrag_t wfrag_t;
   const swn_chain_desc& d = args.d;
   char* act = smem;
-  char* bias_lds = smem + Cfg<T>::ACT;  // 1 KiB
+  char* bias_lds = smem + Cfg<T>::ACT;  // ROW_ELEMS floats
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -374,19 +418,19 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
   int aoff[16];
   if constexpr (sizeof(T) == 2) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) aoff[q] = l31 * 512 + (((2 * q + lhi) ^ (l31 & 15)) << 4);
+    for (int q = 0; q < 8; ++q) aoff[q] = l31 * Cfg<T>::ROWB + (((2 * q + lhi) ^ (l31 & 15)) << 4);
 #pragma unroll
     for (int q = 8; q < 16; ++q) aoff[q] = 0;
   } else {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) aoff[q] = l31 * 1024 + ((((q >> 2) * 8 + 2 * (q & 3) + lhi) ^ l31) << 2);
+    for (int q = 0; q < 16; ++q) aoff[q] = l31 * Cfg<T>::ROWB + ((((q >> 2) * 8 + 2 * (q & 3) + lhi) ^ l31) << 2);
   }
 
   // this wave's weight-fragment stream of layer L: [feature tile (2 wn + ni)][step][lane][16 B]
   auto wstream = [&](int L_) -> const char* {
     const swn_chain_layer& q = d.layers[L_];
     const size_t steps = q.k / KSTEP;
-    const int nt0 = min(2 * wn, q.n / 32 - 2);      // waves beyond the layer width read valid tiles and discard
+    const int nt0 = min(NI * wn, q.n / 32 - NI);    // waves beyond the layer width read valid tiles and discard
     return (const char*)q.w + ((size_t)wset * (q.n / 32) + (nt0 < 0 ? 0 : nt0)) * steps * 1024;
   };
   auto stage_bias = [&](int L_) {
@@ -395,7 +439,7 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
   };
 
   auto wrsrc = [&](int L_) -> __amdgpu_buffer_rsrc_t {   // descriptor over this wave's two feature tiles of layer L_
-    return __builtin_amdgcn_make_buffer_rsrc((void*)wstream(L_), 0, 2 * (d.layers[L_].k / KSTEP) * 1024, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)wstream(L_), 0, NI * (d.layers[L_].k / KSTEP) * 1024, 0x00020000);
   };
   const int lane16 = lane * 16;
   wfrag_t ring[RING][NI];
@@ -404,8 +448,9 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
     const int ts = (d.layers[0].k / KSTEP) * 1024;
 #pragma unroll
     for (int r = 0; r < RING; ++r) {
-      ring[r][0] = __builtin_bit_cast(wfrag_t, __builtin_amdgcn_raw_buffer_load_b128(w0, lane16, r * 1024, 0));
-      ring[r][1] = __builtin_bit_cast(wfrag_t, __builtin_amdgcn_raw_buffer_load_b128(w0, lane16, ts + r * 1024, 0));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        ring[r][ni] = __builtin_bit_cast(wfrag_t, __builtin_amdgcn_raw_buffer_load_b128(w0, lane16, ni * ts + r * 1024, 0));
     }
   }
   stage_bias(0);
@@ -418,7 +463,7 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
   for (int L = 0; L < d.n_layers; ++L) {
     const swn_chain_layer& ly = d.layers[L];
     const int n = ly.n, k = ly.k;
-    const bool wave_active = (wn * 64) < n;
+    const bool wave_active = (wn * 32 * NI) < n;
     const bool has_next = (L + 1) < d.n_layers;
     const int steps = k / KSTEP;
     const __amdgpu_buffer_rsrc_t wcur = wrsrc(L);
@@ -434,6 +479,10 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
 
     // K loop: no barrier.  (Waves beyond the layer width run it too on a clamped stream - keeps the ring logic
     // uniform - and discard the result.  Only the 128-wide layer "2" has such waves.)
+#if SWN_WIDE
+    if (steps == 512 / KSTEP) k_loop<T, 512 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
+    else
+#endif
     if (steps == 256 / KSTEP) k_loop<T, 256 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
     else if (steps == 128 / KSTEP) k_loop<T, 128 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
     else k_loop<T, 64 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
@@ -453,8 +502,8 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
       int l31e = l31, lhie = lhi;
       asm volatile("" : "+v"(l31e), "+v"(lhie));
       const float* rbp = ly.rowbias ? ly.rowbias + (grow0 / ly.rows_per_bias) * (size_t)n : nullptr;   // tile-aligned per-ray bias
-      uint32_t* mk = ly.mask ? ly.mask + (size_t)(blockIdx.x * 4 + wn) * MI * 64 + lane : nullptr;
-      const int nvalid = n - wn * 64;   // feature tiles of this wave that exist: nvalid >= 64 -> both
+      uint32_t* mk = ly.mask ? ly.mask + (size_t)(blockIdx.x * 4 + wn) * MI * 64 * (NI / 2) + lane : nullptr;
+      const int nvalid = n - wn * 32 * NI;   // feature tiles of this wave that exist: nvalid >= 32 NI -> all
       epilogue_body<T, true, 0, false, false, false>(acc, act, bias_lds, rbp, mk, wn, l31e, lhie, nvalid, grow0, ly.rows_per_bias, n,
                                                      ly.relu, ly.skip != 0, ly.b != nullptr, rows_in_tile);
     }
@@ -489,6 +538,7 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
   }
 }
 
+#if !SWN_WIDE
 // Pack a master weight [wsets][in][out] (fp32) into the fragment-major compute layout of swn_mlp_chain:
 //   transpose = 1 (forward):       W[n = out][k = in]  = master[k][n]
 //   transpose = 0 (backward-data): W[n = in][k = out]  = master[n][k]
@@ -520,7 +570,43 @@ __global__ void pack_weights_kernel(const float* __restrict__ master, T* __restr
   }
 }
 
+#endif   // !SWN_WIDE
+
+// host side of one launch (shared by both builds; the narrow build's swn_mlp_chain forwards wide descriptors to the wide one)
+static int chain_launch(const swn_chain_desc& d, void* stream) {
+  ChainArgs a;
+  a.d = d;
+  const int bm = d.dtype == SWN_BF16 ? Cfg<bf16_t>::BM : Cfg<float>::BM;
+  a.tiles_per_group = cdiv(d.group_rows ? (d.group_rows_clamp < d.group_stride ? d.group_rows_clamp : d.group_stride) : d.group_stride, bm);
+  if (!d.group_rows) a.d.group_rows_clamp = d.group_stride;
+  const long grid = (long)a.tiles_per_group * d.n_groups;
+  SWN_CHECK(grid > 0 && grid < (1L << 31), "swn_mlp_chain: grid %ld out of range", grid);
+  const int lds = (d.dtype == SWN_BF16 ? Cfg<bf16_t>::ACT : Cfg<float>::ACT) + ROW_ELEMS * 4;
+  const void* fn = nullptr;
+#define SWN_PICK(TAGV)                                                                         \
+  case TAGV:                                                                                   \
+    fn = d.dtype == SWN_BF16 ? (const void*)chain_kernel<bf16_t, TAGV> : (const void*)chain_kernel<float, TAGV>; \
+    break;
+  switch (d.tag) {
+    SWN_PICK(0) SWN_PICK(1) SWN_PICK(2) SWN_PICK(3) SWN_PICK(4) SWN_PICK(5) SWN_PICK(6)
+  }
+#undef SWN_PICK
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  void* kargs[] = {(void*)&a};
+  e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(NT), kargs, lds, as_stream(stream));
+  SWN_CHECK(e == hipSuccess, "swn_mlp_chain launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+}  // namespace SWN_NS
+
+#if SWN_WIDE
+namespace swn {
+int chain_wide_launch(const swn_chain_desc& d, void* stream) { return swn_wide::chain_launch(d, stream); }
+int chain_wide_tile_rows(int dtype) { return dtype == SWN_BF16 ? swn_wide::Cfg<bf16_t>::BM : swn_wide::Cfg<float>::BM; }
 }  // namespace swn
+#else
 
 using namespace swn;
 
@@ -546,16 +632,25 @@ extern "C" int swn_pack_weights(const float* master, void* out, int dtype, int n
 
 extern "C" int swn_chain_tile_rows(int dtype) { return dtype == SWN_BF16 ? Cfg<bf16_t>::BM : Cfg<float>::BM; }
 
+/* uint32 words of one ReLU mask buffer for a chain over n_groups x group_stride rows whose widest layer has max_width features */
+extern "C" long swn_chain_mask_words(int dtype, int n_groups, int group_stride, int max_width) {
+  const bool wide = max_width > 256;
+  const int bm = wide ? chain_wide_tile_rows(dtype) : swn_chain_tile_rows(dtype);
+  return (long)cdiv(group_stride, bm) * n_groups * bm * (wide ? 16 : 8);
+}
+
 extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   SWN_CHECK(desc != nullptr, "swn_mlp_chain: null descriptor");
   const swn_chain_desc& d = *desc;
   SWN_CHECK(d.dtype == SWN_F32 || d.dtype == SWN_BF16, "swn_mlp_chain: bad dtype %d", d.dtype);
   SWN_CHECK(d.n_layers >= 1 && d.n_layers <= 8, "swn_mlp_chain: n_layers %d not in [1,8]", d.n_layers);
   SWN_CHECK(d.n_groups >= 1 && d.n_wsets >= 1 && d.group_stride >= 1, "swn_mlp_chain: bad group geometry");
+  bool wide = false;
   for (int l = 0; l < d.n_layers; ++l) {
     const swn_chain_layer& ly = d.layers[l];
-    SWN_CHECK(ly.n >= 64 && ly.n <= 256 && ly.n % 64 == 0, "swn_mlp_chain: layer %d n=%d must be 64, 128, 192 or 256", l, ly.n);
-    SWN_CHECK(ly.k == 64 || ly.k == 128 || ly.k == 256, "swn_mlp_chain: layer %d k=%d must be 64, 128 or 256", l, ly.k);
+    SWN_CHECK(ly.n >= 64 && ly.n <= 512 && ly.n % 64 == 0, "swn_mlp_chain: layer %d n=%d must be a multiple of 64 in [64, 512]", l, ly.n);
+    SWN_CHECK(ly.k == 64 || ly.k == 128 || ly.k == 256 || ly.k == 512, "swn_mlp_chain: layer %d k=%d must be 64, 128, 256 or 512", l, ly.k);
+    wide = wide || ly.n > 256 || ly.k > 256;
     if (l > 0) SWN_CHECK(ly.k == d.layers[l - 1].n, "swn_mlp_chain: layer %d k=%d != previous n=%d", l, ly.k, d.layers[l - 1].n);
     SWN_CHECK(ly.w != nullptr, "swn_mlp_chain: layer %d has no weights", l);
     if (ly.skip) SWN_CHECK(ly.n == d.layers[0].k, "swn_mlp_chain: skip layer %d needs n == chain input width", l);
@@ -564,28 +659,8 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
     if (ly.relu == 2) SWN_CHECK(ly.mask != nullptr, "swn_mlp_chain: relu=2 (apply stored mask) needs a mask");
   }
   SWN_CHECK(d.x != nullptr && d.y != nullptr, "swn_mlp_chain: x / y must not be null");
-  ChainArgs a;
-  a.d = d;
-  const int bm = d.dtype == SWN_BF16 ? Cfg<bf16_t>::BM : 64;
-  a.tiles_per_group = cdiv(d.group_rows ? (d.group_rows_clamp < d.group_stride ? d.group_rows_clamp : d.group_stride) : d.group_stride, bm);
-  if (!d.group_rows) a.d.group_rows_clamp = d.group_stride;
-  const long grid = (long)a.tiles_per_group * d.n_groups;
-  SWN_CHECK(grid > 0 && grid < (1L << 31), "swn_mlp_chain: grid %ld out of range", grid);
-  const int lds = (d.dtype == SWN_BF16 ? Cfg<bf16_t>::ACT : Cfg<float>::ACT) + 1024;
   SWN_CHECK(d.tag >= 0 && d.tag <= 6, "swn_mlp_chain: tag %d not in [0,6]", d.tag);
-  const void* fn = nullptr;
-#define SWN_PICK(TAGV)                                                                         \
-  case TAGV:                                                                                   \
-    fn = d.dtype == SWN_BF16 ? (const void*)chain_kernel<bf16_t, TAGV> : (const void*)chain_kernel<float, TAGV>; \
-    break;
-  switch (d.tag) {
-    SWN_PICK(0) SWN_PICK(1) SWN_PICK(2) SWN_PICK(3) SWN_PICK(4) SWN_PICK(5) SWN_PICK(6)
-  }
-#undef SWN_PICK
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-  void* kargs[] = {(void*)&a};
-  e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(NT), kargs, lds, as_stream(stream));
-  SWN_CHECK(e == hipSuccess, "swn_mlp_chain launch: %s", hipGetErrorString(e));
-  return 0;
+  if (wide) return chain_wide_launch(d, stream);        // 512-feature geometry (this file compiled with -DSWN_WIDE=1)
+  return chain_launch(d, stream);
 }
+#endif   // !SWN_WIDE

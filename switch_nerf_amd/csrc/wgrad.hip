@@ -30,6 +30,8 @@ struct WgradArgs {
                              // space) -> source row of a / b, or NULL: the operand is read through the routing permutation
                              // instead of from a gathered copy (saves writing that copy)
   size_t partial_stride;     // floats between the partial-tile areas of consecutive items
+  int lda, ldb, ldw;         // row strides (elements) of a, b and dw: the items may be column blocks of wider matrices
+  size_t dw_set_stride, db_set_stride;   // elements between the weight sets of dw / db
   int m_dim, n_dim, n_groups, n_wsets, group_stride, clamp, rows_per_split;
   const int32_t* group_rows;
   float* partial;   // [n_groups * n_splits][m_dim * n_dim + n_dim] fp32 partial tiles (plain stores), or NULL = atomics
@@ -98,8 +100,8 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
       long as = grow0 + ar, bs = grow0 + br;
       if (it.a_gather) as = max(it.a_gather[as], 0);     // valid rows (< group_rows) always carry a source row
       if (it.b_gather) bs = max(it.b_gather[bs], 0);
-      ra[i] = *(const uint4*)((const char*)it.a + (as * (long)m_dim) * sizeof(T) + a_ch[i] * 16);
-      rb[i] = *(const uint4*)((const char*)it.b + (bs * (long)n_dim) * sizeof(T) + b_ch[i] * 16);
+      ra[i] = *(const uint4*)((const char*)it.a + (as * (long)p.lda) * sizeof(T) + a_ch[i] * 16);
+      rb[i] = *(const uint4*)((const char*)it.b + (bs * (long)p.ldb) * sizeof(T) + b_ch[i] * 16);
     }
   };
   auto lstore = [&](int buf, int r0) {
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
   // ---- epilogue: this workgroup's partial tile goes to the workspace with plain stores (a reduce kernel sums the
   // partials; device-scope fp32 atomics from hundreds of workgroups onto one 256 KiB tile are fabric-bound), or,
   // without a workspace, straight into dW with atomics.
-  float* dw = it.dw + (size_t)wset * m_dim * n_dim;
+  float* dw = it.dw + (size_t)wset * p.dw_set_stride;
   float* part = p.partial ? p.partial + blockIdx.z * p.partial_stride + ((size_t)g * p.n_splits + split) * ((size_t)m_dim * n_dim + n_dim)
                           : nullptr;
   if (active) {
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
           }
           if (m < m_dim && n < n_dim) {
             if (part) part[(size_t)m * n_dim + n] = acc[q][qq][r];
-            else unsafeAtomicAdd(dw + (size_t)m * n_dim + n, acc[q][qq][r]);
+            else unsafeAtomicAdd(dw + (size_t)m * p.ldw + n, acc[q][qq][r]);
           }
         }
   }
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
       if constexpr (sizeof(T) == 2) n = wn * 64 + 2 * l31 + qq; else n = wn * 64 + qq * 32 + l31;
       if (n < n_dim) {  // D row i = 0 (every row equal)
         if (part) part[(size_t)m_dim * n_dim + n] = accb[qq][0];
-        else unsafeAtomicAdd(it.db + (size_t)wset * n_dim + n, accb[qq][0]);
+        else unsafeAtomicAdd(it.db + (size_t)wset * p.db_set_stride + n, accb[qq][0]);
       }
     }
   }
@@ -253,7 +255,8 @@ struct WgradReduceArgs {
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial_all, size_t partial_stride,
                                                            const int32_t* __restrict__ group_rows, int clamp, int group_stride,
                                                            int rows_per_split, int n_groups, int n_wsets, int n_splits, int tile_elems,
-                                                           int mn, const WgradReduceArgs ra) {
+                                                           int mn, int n_dim, int ldw, size_t dw_set_stride, size_t db_set_stride,
+                                                           const WgradReduceArgs ra) {
   const float* partial = partial_all + blockIdx.z * partial_stride;
   float* dw = ra.dw[blockIdx.z];
   float* db = ra.db[blockIdx.z];
@@ -268,16 +271,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       s += partial[((size_t)g * n_splits + sp) * tile_elems + e];
     }
   }
-  if (e < mn) dw[(size_t)wset * mn + e] += s;
-  else if (db) db[(size_t)wset * (tile_elems - mn) + (e - mn)] += s;
+  if (e < mn) dw[(size_t)wset * dw_set_stride + (size_t)(e / n_dim) * ldw + e % n_dim] += s;
+  else if (db) db[(size_t)wset * db_set_stride + (e - mn)] += s;
 }
 
 }  // namespace swn
 
 using namespace swn;
 
-static int wgrad_launch(const swn_wgrad_item* items, int n_items, int dtype, int m_dim, int n_dim, int n_groups, int n_wsets,
-                        int group_stride, const int32_t* group_rows, int group_rows_clamp, int n_splits, int tag, void* workspace,
+static int wgrad_launch(const swn_wgrad_item* items, int n_items, int dtype, int m_dim, int n_dim, int lda, int ldb, int ldw,
+                        size_t dw_set_stride, size_t db_set_stride, int n_groups, int n_wsets, int group_stride,
+                        const int32_t* group_rows, int group_rows_clamp, int n_splits, int tag, void* workspace,
                         size_t workspace_bytes, void* stream) {
   SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_wgrad: bad dtype %d", dtype);
   SWN_CHECK(m_dim >= 32 && m_dim <= 256 && m_dim % 32 == 0 && n_dim >= 32 && n_dim <= 256 && n_dim % 32 == 0,
@@ -291,13 +295,14 @@ static int wgrad_launch(const swn_wgrad_item* items, int n_items, int dtype, int
     ra.dw[i] = p.it[i].dw;
     ra.db[i] = p.it[i].db;
     SWN_CHECK(p.it[i].a && p.it[i].b && p.it[i].dw, "swn_wgrad: null pointer in item %d", i);
-    SWN_CHECK((p.it[i].db != nullptr) == (p.it[0].db != nullptr), "swn_wgrad: db must be given for all items or for none");
   }
   const int bkr = dtype == SWN_BF16 ? 32 : 16;
   const int max_rows = group_rows ? (group_rows_clamp < group_stride ? group_rows_clamp : group_stride) : group_stride;
   int rps = cdiv(max_rows, n_splits);
   rps = cdiv(rps, bkr) * bkr;
   const int splits = cdiv(max_rows, rps);
+  SWN_CHECK(lda >= m_dim && ldb >= n_dim && ldw >= n_dim, "swn_wgrad: leading dimensions smaller than the block");
+  p.lda = lda; p.ldb = ldb; p.ldw = ldw; p.dw_set_stride = dw_set_stride; p.db_set_stride = db_set_stride;
   p.m_dim = m_dim; p.n_dim = n_dim; p.n_groups = n_groups; p.n_wsets = n_wsets;
   p.group_stride = group_stride; p.clamp = group_rows ? group_rows_clamp : group_stride; p.rows_per_split = rps;
   p.group_rows = group_rows;
@@ -320,7 +325,7 @@ static int wgrad_launch(const swn_wgrad_item* items, int n_items, int dtype, int
   if (p.partial) {
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)tile_elems, 256), n_wsets, n_items), dim3(256), 0, as_stream(stream),
                        p.partial, p.partial_stride, group_rows, p.clamp, group_stride, rps, n_groups, n_wsets, splits, (int)tile_elems,
-                       m_dim * n_dim, ra);
+                       m_dim * n_dim, n_dim, ldw, dw_set_stride, db_set_stride, ra);
   }
   SWN_LAUNCH_CHECK();
   return 0;
@@ -330,13 +335,21 @@ extern "C" int swn_wgrad(const void* a, const void* b, const int32_t* a_gather, 
                          int n_dim, int n_groups, int n_wsets, int group_stride, const int32_t* group_rows, int group_rows_clamp,
                          float* dw, float* db, int n_splits, int tag, void* workspace, size_t workspace_bytes, void* stream) {
   swn_wgrad_item it = {a, b, a_gather, b_gather, dw, db};
-  return wgrad_launch(&it, 1, dtype, m_dim, n_dim, n_groups, n_wsets, group_stride, group_rows, group_rows_clamp, n_splits, tag,
-                      workspace, workspace_bytes, stream);
+  return wgrad_launch(&it, 1, dtype, m_dim, n_dim, m_dim, n_dim, n_dim, (size_t)m_dim * n_dim, (size_t)n_dim, n_groups, n_wsets,
+                      group_stride, group_rows, group_rows_clamp, n_splits, tag, workspace, workspace_bytes, stream);
 }
 
 extern "C" int swn_wgrad_batched(const swn_wgrad_item* items, int n_items, int dtype, int m_dim, int n_dim, int n_groups,
                                  int n_wsets, int group_stride, const int32_t* group_rows, int group_rows_clamp, int n_splits,
                                  int tag, void* workspace, size_t workspace_bytes, void* stream) {
-  return wgrad_launch(items, n_items, dtype, m_dim, n_dim, n_groups, n_wsets, group_stride, group_rows, group_rows_clamp, n_splits,
-                      tag, workspace, workspace_bytes, stream);
+  return wgrad_launch(items, n_items, dtype, m_dim, n_dim, m_dim, n_dim, n_dim, (size_t)m_dim * n_dim, (size_t)n_dim, n_groups, n_wsets,
+                      group_stride, group_rows, group_rows_clamp, n_splits, tag, workspace, workspace_bytes, stream);
+}
+
+extern "C" int swn_wgrad_blocks(const swn_wgrad_item* items, int n_items, int dtype, int m_dim, int n_dim, int lda, int ldb, int ldw,
+                                size_t dw_set_stride, size_t db_set_stride, int n_groups, int n_wsets, int group_stride,
+                                const int32_t* group_rows, int group_rows_clamp, int n_splits, int tag, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  return wgrad_launch(items, n_items, dtype, m_dim, n_dim, lda, ldb, ldw, dw_set_stride, db_set_stride, n_groups, n_wsets, group_stride,
+                      group_rows, group_rows_clamp, n_splits, tag, workspace, workspace_bytes, stream);
 }

@@ -298,7 +298,7 @@ class SwitchNeRF:
         c["h0"] = _b("h0", (P, M), dt)
         c["a1"] = _b("a1", (P, G), dt)
         c["g"] = _b("g", (P, G), dt)
-        c["m_a1"] = _b("m_a1", (o.chain_mask_words(dt, 1, P),), torch.int32)
+        c["m_a1"] = _b("m_a1", (o.chain_mask_words(dt, 1, P, max(M, G, self.KP)),), torch.int32)
         o.mlp_chain(c["pe"], [o.Layer(self.wf["xyz"], self.p["xyz.b"].view(1, M), save=c["h0"]),
                               o.Layer(self.wf["gate0"], self.p["gate0.b"].view(1, G), relu=1, mask=c["m_a1"], save=c["a1"]),
                               o.Layer(self.wf["gate1"], self.p["gate1.b"].view(1, G))], c["g"], tag=3)
@@ -316,7 +316,7 @@ class SwitchNeRF:
         c["counts_flat"] = c["counts"].view(-1)
         c["eo"] = _b("eo", (rows, M), dt)
         c["saves"] = [_b(f"save{l}", (rows, M), dt) for l in range(L - 1)]
-        nw = o.chain_mask_words(dt, ng, cap)
+        nw = o.chain_mask_words(dt, ng, cap, M)
         c["masks"] = [_b(f"mask{l}", (nw,), torch.int32) for l in range(L - 1)]
         skips = set(self.cfg["skips"])
         layers = [o.Layer(self._local_experts(self.wf[f"exp{l}"]), self._local_experts(self.p[f"exp{l}.b"]),

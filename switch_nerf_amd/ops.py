@@ -278,11 +278,10 @@ def chain_tile_rows(dtype) -> int:
     return _lib.load().swn_chain_tile_rows(BF16 if dtype == torch.bfloat16 else F32)
 
 
-def chain_mask_words(dtype, n_groups: int, group_stride: int) -> int:
-    """uint32 words per layer mask buffer for a chain launch with this geometry (1 bit per row x 256 features)."""
-    bm = chain_tile_rows(dtype)
-    tiles = (group_stride + bm - 1) // bm
-    return tiles * n_groups * bm * 8
+def chain_mask_words(dtype, n_groups: int, group_stride: int, max_width: int = 256) -> int:
+    """uint32 words per layer mask buffer for a chain launch with this geometry (1 bit per row x feature of the kernel's tile;
+    max_width = the widest layer of the chain: > 256 selects the 512-feature kernels)."""
+    return int(_lib.load().swn_chain_mask_words(BF16 if dtype == torch.bfloat16 else F32, int(n_groups), int(group_stride), int(max_width)))
 
 
 def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride=None, group_rows=None,
@@ -319,6 +318,9 @@ def wgrad(a, b, dw, db=None, n_groups=1, n_wsets=1, group_stride=None, group_row
     a_gather / b_gather: read the rows of a / b through an index (the routing permutation) instead of a dispatched copy."""
     m_dim, n_dim = a.shape[1], b.shape[1]
     assert group_stride is not None or (a_gather is None and b_gather is None)
+    if m_dim > 256 or n_dim > 256:      # wider than one 256 x 256 tile: column blocks of the operands, one launch
+        return wgrad_batched([(a, b, dw, db, a_gather, b_gather)], n_groups, n_wsets, group_stride, group_rows, group_rows_clamp,
+                             n_splits, tag)
     gs = int(group_stride if group_stride is not None else a.shape[0])
     ws, ws_bytes = None, 0
     if use_workspace:
@@ -334,22 +336,33 @@ def wgrad(a, b, dw, db=None, n_groups=1, n_wsets=1, group_stride=None, group_row
 
 
 def wgrad_batched(items, n_groups=1, n_wsets=1, group_stride=None, group_rows=None, group_rows_clamp=None, n_splits=8, tag=0):
-    """items: up to 8 tuples (a, b, dw, db, a_gather, b_gather) of identical shapes / grouping -> one launch (see wgrad)."""
+    """items: tuples (a, b, dw, db, a_gather, b_gather) of identical shapes / grouping -> launches of up to 8 GEMM blocks
+    (see wgrad).  Operands wider than 256 features are cut into 256-column blocks (swn_wgrad_blocks)."""
     a0, b0 = items[0][0], items[0][1]
-    m_dim, n_dim = a0.shape[1], b0.shape[1]
+    M, N = a0.shape[1], b0.shape[1]
+    bm, bn = min(M, 256), min(N, 256)
+    esz = a0.element_size()
     gs = int(group_stride if group_stride is not None else a0.shape[0])
-    arr = (WgradItem * len(items))()
-    for i, (a, b, dw, db, ag, bg) in enumerate(items):
-        assert a.shape[1] == m_dim and b.shape[1] == n_dim and a.dtype == a0.dtype
-        arr[i].a, arr[i].b, arr[i].a_gather, arr[i].b_gather, arr[i].dw, arr[i].db = _p(a), _p(b), _p(ag), _p(bg), _p(dw), _p(db)
-    ws_bytes = len(items) * int(n_groups) * int(n_splits) * (m_dim * n_dim + n_dim) * 4
+    blocks = []
+    for (a, b, dw, db, ag, bg) in items:
+        assert a.shape[1] == M and b.shape[1] == N and a.dtype == a0.dtype and dw.shape[-2:] == (M, N)
+        for i in range(0, M, bm):
+            for j in range(0, N, bn):
+                blocks.append((a.data_ptr() + i * esz, b.data_ptr() + j * esz, _p(ag), _p(bg), dw.data_ptr() + (i * N + j) * 4,
+                               (db.data_ptr() + j * 4) if (db is not None and i == 0) else None))
+    per = int(n_groups) * int(n_splits) * (bm * bn + bn) * 4
     key = (a0.device, torch.cuda.current_stream().cuda_stream)
     ws = _wgrad_ws.get(key)
-    if ws is None or ws.numel() < ws_bytes:
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a0.device)
+    if ws is None or ws.numel() < 8 * per:
+        ws = torch.empty(8 * per, dtype=torch.uint8, device=a0.device)
         _wgrad_ws[key] = ws
-    call("swn_wgrad_batched", arr, len(items), _dt(a0), m_dim, n_dim, int(n_groups), int(n_wsets), gs, _p(group_rows),
-         int(group_rows_clamp if group_rows_clamp is not None else gs), int(n_splits), int(tag), _p(ws), ws.numel(), _stream())
+    for i0 in range(0, len(blocks), 8):
+        chunk = blocks[i0:i0 + 8]
+        arr = (WgradItem * len(chunk))()
+        for i, (pa, pb, ag, bg, pdw, pdb) in enumerate(chunk):
+            arr[i].a, arr[i].b, arr[i].a_gather, arr[i].b_gather, arr[i].dw, arr[i].db = pa, pb, ag, bg, pdw, pdb
+        call("swn_wgrad_blocks", arr, len(chunk), _dt(a0), bm, bn, M, N, N, M * N, N, int(n_groups), int(n_wsets), gs, _p(group_rows),
+             int(group_rows_clamp if group_rows_clamp is not None else gs), int(n_splits), int(tag), _p(ws), ws.numel(), _stream())
 
 
 def adam_step(param, grad, m, v, shadow, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):

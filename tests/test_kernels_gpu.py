@@ -426,7 +426,8 @@ def test_chain_expert_mlp_forward_backward(dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_wgrad_shapes(dtype):
     rng = np.random.default_rng(51)
-    for (R, m, n) in [(777, 128, 256), (4096, 256, 128), (300, 256, 32), (65, 32, 256)]:
+    for (R, m, n) in [(777, 128, 256), (4096, 256, 128), (300, 256, 32), (65, 32, 256), (1000, 512, 512), (515, 128, 512),
+                      (2049, 512, 128)]:
         a = torch.from_numpy(rng.standard_normal((R, m)).astype(np.float32))
         b = torch.from_numpy(rng.standard_normal((R, n)).astype(np.float32))
         ar, br = _round(a, dtype), _round(b, dtype)
@@ -543,3 +544,49 @@ def test_mip_encode_and_resample(dtype):
     pr = torch.rand(N, S)
     zp = o.sample_z(rays.to(dev()), torch.linspace(0, 1, S).to(dev()), pr.to(dev()), 1.0, S)
     assert torch.equal(zp.cpu(), O.sample_z(rays[:, 6:7], rays[:, 7:8], S, 1.0, pr))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_chain_wide_512(dtype):
+    """The 512-feature geometry (Mission Bay widths): 128 -> 512 -> 512 (ReLU, mask, skip-free) -> 128 with saves, forward and the
+    backward-data chain through the stored mask, ragged row count."""
+    rng = np.random.default_rng(77)
+    R = 333
+    dims = [(128, 512), (512, 512), (512, 512), (512, 128)]
+    x = torch.from_numpy(rng.standard_normal((R, 128)).astype(np.float32))
+    Ws = [torch.from_numpy((rng.standard_normal((o_, i_)) / np.sqrt(i_)).astype(np.float32)) for (i_, o_) in dims]      # [out, in]
+    Bs = [torch.from_numpy((rng.standard_normal(o_) * 0.1).astype(np.float32)) for (_, o_) in dims]
+    relus = [0, 1, 1, 0]
+    ref, saves = _chain_ref(x, Ws, Bs, relus, (), dtype)
+    o = ops()
+    xd = x.to(dev()).to(dtype)
+    y = torch.full((R, 128), 7.0, dtype=dtype, device=dev())
+    sv = [torch.empty(R, 512, dtype=dtype, device=dev()) for _ in range(3)]
+    nw = o.chain_mask_words(dtype, 1, R, 512)
+    masks = [torch.zeros(nw, dtype=torch.int32, device=dev()) for _ in range(2)]
+    layers = [o.Layer(o.pack_weights(Ws[i].t().contiguous()[None].to(dev()), dtype, True), Bs[i].to(dev())[None].contiguous(),
+                      relu=relus[i]) for i in range(4)]
+    for i in range(3):
+        layers[i].save = sv[i]
+    layers[1].mask, layers[2].mask = masks[0], masks[1]
+    o.mlp_chain(xd, layers, y)
+    tol = 5e-5 if dtype == torch.float32 else 5e-2
+    assert report(f"chain512_y_{dtype}", y, ref) <= tol
+    for i in range(3):
+        assert report(f"chain512_s{i}_{dtype}", sv[i], saves[i]) <= tol
+    # backward-data through the last three layers with the stored masks: dY -> d(s2) -> d(s1) -> d(s0)
+    dy = torch.from_numpy(rng.standard_normal((R, 128)).astype(np.float32))
+    dyr = _round(dy, dtype)
+    Wr = [_round(w, dtype) for w in Ws]
+    g2 = (dyr @ Wr[3]) * (saves[2] > 0)
+    g1 = (_round(g2, dtype) @ Wr[2]) * (saves[1] > 0)
+    g0 = _round(g1, dtype) @ Wr[1]
+    wb = [o.pack_weights(Ws[i].t().contiguous()[None].to(dev()), dtype, False) for i in range(4)]
+    d2 = torch.empty(R, 512, dtype=dtype, device=dev())
+    d1 = torch.empty(R, 512, dtype=dtype, device=dev())
+    d0 = torch.empty(R, 512, dtype=dtype, device=dev())
+    o.mlp_chain(dy.to(dev()).to(dtype), [o.Layer(wb[3], None, relu=2, mask=masks[1], save=d2),
+                                          o.Layer(wb[2], None, relu=2, mask=masks[0], save=d1), o.Layer(wb[1], None)], d0)
+    tolb = 2e-4 if dtype == torch.float32 else 8e-2
+    assert report(f"chain512_d2_{dtype}", d2, g2) <= tolb * max(1.0, g2.abs().max().item())
+    assert report(f"chain512_d0_{dtype}", d0, g0) <= tolb * max(1.0, g0.abs().max().item())

@@ -353,3 +353,36 @@ def test_sixteen_experts_vs_oracle_fp32():
         ref = p[k].grad.numpy()
         err = np.abs(t.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
         assert err <= (2e-3 if ref.size > 4 else 1e-2), (k, err)       # scalar biases: a cancelling sum over all points
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mission_bay_widths_vs_oracle(dtype):
+    """512-wide layers and 16 experts (mission_bay.yaml's model block) through the 512-feature chain / weight-gradient kernels:
+    fp32 against the oracle (routing exact, rgb 1e-4, all gradients); bf16 against the fp32 run."""
+    cfg = dict(synth.BUILDING, model_dim=512, gate_hidden=512, num_experts=16)
+    N, S, chunk = 32, 64, 2048
+    sd = synth.make_weights(151, cfg, gate_scale=0.05)
+    rays, img, rgbs = synth.make_rays(152, N)
+    from switch_nerf_amd.model import SwitchNeRF
+    m = SwitchNeRF(cfg, dtype=dtype)
+    m.load_state_dict(sd)
+    st = m.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0, optimizer_step=False)
+    c = st["ctx"]
+    p = O.params_from_numpy(sd, requires_grad=True)
+    ost = O.training_step(p, torch.from_numpy(rays), torch.from_numpy(img), torch.from_numpy(rgbs), cfg, S, chunk)
+    ost["loss"].backward()
+    res = ost["results"]
+    if dtype == torch.bfloat16:
+        assert (c["rgb"].cpu() - res["rgb_coarse"].detach()).abs().max().item() < 4e-2
+        assert abs(st["loss"].item() - ost["loss"].item()) < 3e-2 * abs(ost["loss"].item())
+        return
+    ref_idx = np.concatenate([r["idx"] for r in res["routings"]])
+    mis = int((c["idx"].cpu().numpy() != ref_idx).sum())
+    print(f"512-wide, E=16: routing mismatches vs oracle {mis} of {ref_idx.size}")
+    assert mis == 0
+    np.testing.assert_allclose(c["rgb"].cpu().numpy(), res["rgb_coarse"].detach().numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(st["loss"].item(), ost["loss"].item(), rtol=2e-5)
+    for k, t in m.grad_dict().items():
+        ref = p[k].grad.numpy()
+        err = np.abs(t.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err <= (2e-3 if ref.size > 4 else 1e-2), (k, err)
