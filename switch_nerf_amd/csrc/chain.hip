@@ -10,12 +10,12 @@
 //     conflict-free fragment reads);
 //   * weights: never touch LDS.  They are pre-packed (swn_pack_weights) in MFMA-fragment-major order, so that the
 //     fragment of (32 features x 16 k) is one contiguous, fully coalesced 1 KiB wave load straight into registers
-//     (buffer loads: SGPR descriptor + one lane-offset VGPR + scalar step offset, no address VGPRs); a 4-step register
+//     (buffer loads: SGPR descriptor + one lane-offset VGPR + scalar step offset, no address VGPRs); a 2-step register
 //     ring keeps the next fragments in flight (also across the layer boundary), served by L1/L2 (an expert's 7 layers
 //     = 0.9 MB stay in the XCD's L2: workgroup b uses expert b % 8 = its XCD);
 //   * the K loop therefore has NO barrier and its instruction order is pinned (sched_barrier): read fragment i+1,
 //     two MFMAs on fragment i, ...; a layer costs two workgroup barriers (before / after the epilogue rewrites the LDS
-//     tile).  33 KiB of LDS and <= 168 VGPRs per workgroup -> three workgroups (12 waves) per CU overlap each other's
+//     tile).  33 KiB of LDS and <= 128 VGPRs per workgroup -> four workgroups (16 waves) per CU overlap each other's
 //     epilogues, write-outs and weight-load latencies.
 // The MFMA is issued "transposed" (weight fragment = A operand, activation fragment = B operand): a lane ends up
 // with 4 consecutive output FEATURES of one row, so the epilogue packs them and writes the next layer's input tile
@@ -46,7 +46,10 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int NT = 256;         // threads per workgroup (4 waves)
 constexpr int NI = SWN_WIDE ? 4 : 2;        // 32-wide feature tiles per wave (4 waves * NI * 32 = max features)
 constexpr int ROW_ELEMS = 128 * NI;         // features per LDS tile row: 256 / 512
-constexpr int RING = 4;         // weight-fragment steps in flight
+#ifndef SWN_RING
+#define SWN_RING 2
+#endif
+constexpr int RING = SWN_RING;  // weight-fragment steps in flight
 #if SWN_WIDE
 typedef uint64_t mbits_t;
 #else
@@ -61,7 +64,10 @@ template <> struct Cfg<bf16_t> {
   static constexpr int BM = SWN_WIDE ? 64 : SWN_BF16_BM, MI = BM / 32, KSTEP = 16;   // one ring step = K 16: one 16-byte fragment load per feature tile
   static constexpr int ROWB = ROW_ELEMS * 2;           // LDS tile row stride in bytes
   static constexpr int ACT = BM * ROWB;                // LDS tile bytes
-  static constexpr int OCC = SWN_WIDE ? 2 : (BM == 128 ? 2 : 3);   // workgroups per CU (= waves per SIMD) the register budget must allow
+#ifndef SWN_OCC
+#define SWN_OCC 4
+#endif
+  static constexpr int OCC = SWN_WIDE ? 2 : (BM == 128 ? 2 : SWN_OCC);   // workgroups per CU (= waves per SIMD) the register budget must allow
   typedef bf16x8_t wfrag_t;
 };
 template <> struct Cfg<float> {
