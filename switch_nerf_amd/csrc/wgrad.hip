@@ -247,32 +247,43 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
   }
 }
 
-// dw[wset][:] += sum over the partial tiles of (group % n_wsets == wset, split) that were actually produced.
 struct WgradReduceArgs {
   float* dw[8];
   float* db[8];
 };
+// dw[wset][:] += sum over the partial tiles of (group % n_wsets == wset, split) that were actually produced.  A thread owns 4
+// consecutive elements (16-byte loads); the list of partial tiles of a weight set is cut into chunks of RED_CHUNK (grid y), each
+// chunk ends in one fp32 atomic per element - enough workgroups to pull the partials at HBM speed (256 row splits x 256 KiB for
+// a dense layer) without a second pass.
+constexpr int RED_CHUNK = 16;
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial_all, size_t partial_stride,
                                                            const int32_t* __restrict__ group_rows, int clamp, int group_stride,
                                                            int rows_per_split, int n_groups, int n_wsets, int n_splits, int tile_elems,
                                                            int mn, int n_dim, int ldw, size_t dw_set_stride, size_t db_set_stride,
-                                                           const WgradReduceArgs ra) {
+                                                           int n_chunks, const WgradReduceArgs ra) {
   const float* partial = partial_all + blockIdx.z * partial_stride;
   float* dw = ra.dw[blockIdx.z];
   float* db = ra.db[blockIdx.z];
-  const int wset = blockIdx.y;
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int wset = blockIdx.y / n_chunks, chunk = blockIdx.y % n_chunks;
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (e >= tile_elems) return;
-  float s = 0.f;
-  for (int g = wset; g < n_groups; g += n_wsets) {
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  // partial tile t of this weight set = (group wset + (t / n_splits) * n_wsets, split t % n_splits)
+  const int t0 = chunk * RED_CHUNK;
+  const int t1 = min(t0 + RED_CHUNK, ((n_groups - wset + n_wsets - 1) / n_wsets) * n_splits);
+  for (int t = t0; t < t1; ++t) {
+    const int g = wset + (t / n_splits) * n_wsets, sp = t % n_splits;
     const int rows = group_rows ? min(group_rows[g], clamp) : group_stride;
-    for (int sp = 0; sp < n_splits; ++sp) {
-      if (sp * rows_per_split >= rows) break;
-      s += partial[((size_t)g * n_splits + sp) * tile_elems + e];
-    }
+    if (sp * rows_per_split >= rows) continue;
+    const float4 v = *(const float4*)(partial + ((size_t)g * n_splits + sp) * tile_elems + e);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
-  if (e < mn) dw[(size_t)wset * dw_set_stride + (size_t)(e / n_dim) * ldw + e % n_dim] += s;
-  else if (db) db[(size_t)wset * db_set_stride + (e - mn)] += s;
+  float* dst = nullptr;
+  if (e < mn) dst = dw + (size_t)wset * dw_set_stride + (size_t)(e / n_dim) * ldw + e % n_dim;
+  else if (db) dst = db + (size_t)wset * db_set_stride + (e - mn);
+  if (dst) {
+    unsafeAtomicAdd(dst, s.x); unsafeAtomicAdd(dst + 1, s.y); unsafeAtomicAdd(dst + 2, s.z); unsafeAtomicAdd(dst + 3, s.w);
+  }
 }
 
 }  // namespace swn
@@ -323,9 +334,11 @@ static int wgrad_launch(const swn_wgrad_item* items, int n_items, int dtype, int
   e = hipLaunchKernel(fn, dim3(n_groups, splits, n_items), dim3(WG_NT), kargs, lds, as_stream(stream));
   SWN_CHECK(e == hipSuccess, "swn_wgrad launch: %s", hipGetErrorString(e));
   if (p.partial) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)tile_elems, 256), n_wsets, n_items), dim3(256), 0, as_stream(stream),
-                       p.partial, p.partial_stride, group_rows, p.clamp, group_stride, rps, n_groups, n_wsets, splits, (int)tile_elems,
-                       m_dim * n_dim, n_dim, ldw, dw_set_stride, db_set_stride, ra);
+    const int tiles_per_set = cdiv(n_groups, n_wsets) * splits;
+    const int n_chunks = cdiv(tiles_per_set, RED_CHUNK);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)tile_elems, 1024), n_wsets * n_chunks, n_items), dim3(256), 0,
+                       as_stream(stream), p.partial, p.partial_stride, group_rows, p.clamp, group_stride, rps, n_groups, n_wsets, splits,
+                       (int)tile_elems, m_dim * n_dim, n_dim, ldw, dw_set_stride, db_set_stride, n_chunks, ra);
   }
   SWN_LAUNCH_CHECK();
   return 0;

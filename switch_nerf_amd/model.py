@@ -82,7 +82,7 @@ class SwitchNeRF:
         self.events: Dict[str, list] = {}
         # side HIP stream: the HBM-bound expert weight-gradient GEMMs overlap with the rest of the backward pass
         self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
-        self.overlap = True
+        self.overlap = os.environ.get("SWN_NO_OVERLAP", "0") != "1"   # side-stream overlap of the expert weight gradients
         self.ep = None                # parallel.ExpertParallel: experts sharded over ranks, tokens exchanged (set_expert_parallel)
         self.expert_wgrad_splits = int(os.environ.get("SWN_EXPERT_WGRAD_SPLITS", "0"))   # 0 = heuristic
 
