@@ -187,7 +187,7 @@ def main():
                 traffic = None
         names = {"expert_fwd": "chain_kernel<bf16,1> (expert forward, 7 fused layers)",
                  "expert_bwd": "chain_kernel<bf16,2> (expert backward-data, 7 fused layers)",
-                 "expert_wgrad": "wgrad_kernel<bf16,1> (expert weight gradients, 7 launches)"}
+                 "expert_wgrad": "wgrad_kernel<bf16,1> (expert weight gradients, 7 layers in one launch)"}
         # the binding roofline is the one the kernel is closest to: in training the expert
         # chains must save every activation for the weight-gradient GEMM, which makes them HBM-leaning
         if d["hbm_frac"] >= d["mfma_frac"]:
