@@ -335,6 +335,34 @@ def gen_checkpoint_layout():
          shapes=np.array([str(tuple(conv[k].shape)) for k in keys]))
 
 
+def gen_dense():
+    print("[G6] BASELINE configs[0]: dense NeRF (use_moe off), 1024 rays x 64 samples, fwd + grads of mse")
+    cfg = synth.DENSE
+    sd = synth.make_dense_weights(161, cfg)
+    h = make_hparams(synth.BUILDING, coarse=64, chunk=65536, perturb=0.0)
+    h.use_moe = False
+    h.layers, h.skip_layers, h.layer_dim = cfg["layers"], list(cfg["skip_layers"]), cfg["layer_dim"]
+    torch.manual_seed(0)
+    nerf = model_utils.get_nerf(h, cfg["appearance_count"])
+    ref_sd = nerf.state_dict()
+    assert set(ref_sd.keys()) == set(sd.keys()), sorted(set(ref_sd) ^ set(sd))
+    nerf.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    N, S = 1024, 64
+    rays, img, rgbs = synth.make_rays(162, N)
+    nerf.train()
+    res, _ = rendering.render_rays(nerf, None, torch.from_numpy(rays), torch.from_numpy(img), h, None, None,
+                                   get_depth=True, get_depth_variance=True, get_bg_fg_rgb=False)
+    loss = torch.nn.functional.mse_loss(res["rgb_coarse"], torch.from_numpy(rgbs))
+    loss.backward()
+    out = dict(seed=161, N=N, S=S, rgb=res["rgb_coarse"].detach().numpy(), depth=res["depth_coarse"].numpy(),
+               sigma_head=res["sigma_coarse"].detach().numpy()[:64], loss=loss.detach().numpy())
+    for n, p in nerf.named_parameters():
+        g_ = p.grad
+        out["gsum__" + n] = synth.checksum(g_.numpy())
+        out["gslice__" + n] = g_.numpy().reshape(-1)[:: max(1, g_.numel() // 499)][:499]
+    save("dense_nerf_train", **out)
+
+
 # ------------------------------------------------------------------------------------------ G5b compositing + sample_pdf
 def gen_composite():
     print("[G5b] compositing / _sample_pdf on raw tensors")
@@ -376,7 +404,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     todo = dict(routing=gen_routing, pe=gen_pe, moe=gen_moe_layer, model=gen_model_forward, nobatch=gen_model_forward_nobatch,
-                render=gen_render, fine=gen_render_fine, mip=gen_mip, ckpt=gen_checkpoint_layout, composite=gen_composite)
+                render=gen_render, fine=gen_render_fine, mip=gen_mip, ckpt=gen_checkpoint_layout, dense=gen_dense, composite=gen_composite)
     for k, fn in todo.items():
         if a.only and k not in a.only.split(","):
             continue

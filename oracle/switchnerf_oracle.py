@@ -333,6 +333,44 @@ def training_step(p, rays, image_indices, rgbs, cfg, n_samples, chunk, moe_l_aux
 
 
 # --------------------------------------------------------------------------------------------
+# dense NeRF (BASELINE configs[0]; also the background network)
+# --------------------------------------------------------------------------------------------
+def nerf_dense_forward(p, x: torch.Tensor, cfg: dict, sigma_noise: Optional[torch.Tensor] = None):
+    """NeRF.forward, models/nerf.py:143-190: x [P, xyz_dim + 3 + 1] = position, direction, image index.  8 x Linear + ReLU
+    with the encoded position concatenated again in front of the skip layers, sigma head, then the same direction /
+    appearance tail as NeRFMoE."""
+    xd = cfg["xyz_dim"]
+    enc = positional_encoding(x[:, :xd], cfg["pos_xyz_dim"])
+    h = enc
+    for i in range(cfg["layers"]):
+        if i in cfg["skip_layers"]:
+            h = torch.cat([enc, h], -1)                                                       # :155-156
+        h = torch.relu(F.linear(h, p[f"xyz_encodings.{i}.0.weight"], p[f"xyz_encodings.{i}.0.bias"]))
+    sigma = F.linear(h, p["sigma.weight"], p["sigma.bias"])
+    if sigma_noise is not None:
+        sigma = sigma + sigma_noise
+    sigma = shifted_softplus(sigma)
+    h1 = F.linear(h, p["xyz_encoding_final.weight"], p["xyz_encoding_final.bias"])
+    feat = torch.cat([h1, positional_encoding(x[:, xd:xd + 3], cfg["pos_dir_dim"]), p["embedding_a.weight"][x[:, -1].long()]], -1)
+    h2 = torch.relu(F.linear(feat, p["dir_a_encoding.0.weight"], p["dir_a_encoding.0.bias"]))
+    rgb = torch.sigmoid(F.linear(h2, p["rgb.weight"], p["rgb.bias"]))
+    return torch.cat([rgb, sigma], -1)
+
+
+def render_rays_dense(p, rays, image_indices, cfg, n_samples, perturb=0.0, perturb_rand=None, sigma_noise=None):
+    """render_rays for a non-MoE model, coarse pass only (rendering.py:15-196, :277-494; BASELINE configs[0])."""
+    N = rays.shape[0]
+    o, d, near, far = rays[:, 0:3], rays[:, 3:6], rays[:, 6:7], rays[:, 7:8]
+    z = sample_z(near, far, n_samples, perturb, perturb_rand)
+    xyz = o[:, None, :] + d[:, None, :] * z[:, :, None]
+    pts = torch.cat([xyz.reshape(-1, 3), d[:, None, :].expand(N, n_samples, 3).reshape(-1, 3),
+                     image_indices.view(N, 1, 1).expand(N, n_samples, 1).reshape(-1, 1).to(xyz.dtype)], 1)
+    out = nerf_dense_forward(p, pts, cfg, sigma_noise).view(N, n_samples, 4)
+    comp = composite(out[..., :3], out[..., 3], z)
+    return dict(rgb_coarse=comp["rgb"], depth_coarse=comp["depth"], depth_variance_coarse=comp["depth_variance"], raw=out, z_vals=z)
+
+
+# --------------------------------------------------------------------------------------------
 # mip path (rendering_mip.py, MipNeRFMoE): conical-frustum casting, integrated positional encoding, level resampling
 # --------------------------------------------------------------------------------------------
 def mip_cast_rays(o: torch.Tensor, d: torch.Tensor, radius: torch.Tensor, t: torch.Tensor):

@@ -74,6 +74,29 @@ def make_weights(seed: int, cfg=BUILDING, gate_scale: float = 1.0):
     return sd
 
 
+DENSE = dict(layer_dim=256, layers=8, skip_layers=(4,), pos_xyz_dim=12, pos_dir_dim=4, appearance_dim=48, appearance_count=10,
+             xyz_dim=3)
+
+
+def make_dense_weights(seed: int, cfg=DENSE):
+    """{state_dict key: np.float32 array} of the reference's dense NeRF (models/nerf.py NeRF: BASELINE configs[0], and the
+    background network with xyz_dim = 4)."""
+    rng = np.random.default_rng(seed)
+    W, xd = cfg["layer_dim"], cfg["xyz_dim"]
+    in_xyz = xd + xd * 2 * cfg["pos_xyz_dim"]
+    in_dir = 3 + 3 * 2 * cfg["pos_dir_dim"]
+    sd = {}
+    for i in range(cfg["layers"]):
+        k = in_xyz if i == 0 else (W + in_xyz if i in cfg["skip_layers"] else W)
+        sd[f"xyz_encodings.{i}.0.weight"], sd[f"xyz_encodings.{i}.0.bias"] = _linear(rng, W, k)
+    sd["embedding_a.weight"] = rng.standard_normal((cfg["appearance_count"], cfg["appearance_dim"])).astype(np.float32)
+    sd["xyz_encoding_final.weight"], sd["xyz_encoding_final.bias"] = _linear(rng, W, W)
+    sd["dir_a_encoding.0.weight"], sd["dir_a_encoding.0.bias"] = _linear(rng, W // 2, W + in_dir + cfg["appearance_dim"])
+    sd["sigma.weight"], sd["sigma.bias"] = _linear(rng, 1, W)
+    sd["rgb.weight"], sd["rgb.bias"] = _linear(rng, 3, W // 2)
+    return sd
+
+
 def make_rays(seed: int, n_rays: int, appearance_count: int = 10, near=0.05, far=1.0):
     """SURVEY.md section 8(d) synthetic rays: o~U(-0.1,0.1)^3, d=normalize(N(0,I)), near/far constants."""
     rng = np.random.default_rng(seed)

@@ -287,3 +287,30 @@ def test_checkpoint_layouts_match_reference_conversion():
     assert sorted(back.keys()) == sorted(ref.keys())
     for k, v in ref.items():
         assert torch.equal(back[k], torch.from_numpy(v)), k
+
+
+def test_dense_nerf_config0():
+    """BASELINE configs[0]: the reference's dense NeRF (use_moe off) on 1024 rays x 64 samples - render, loss and every gradient."""
+    g = load("dense_nerf_train")
+    cfg = synth.DENSE
+    p = O.params_from_numpy(synth.make_dense_weights(int(g["seed"]), cfg), requires_grad=True)
+    N, S = int(g["N"]), int(g["S"])
+    rays, img, rgbs = synth.make_rays(162, N)
+    res = O.render_rays_dense(p, torch.from_numpy(rays), torch.from_numpy(img), cfg, S)
+    np.testing.assert_allclose(res["rgb_coarse"].detach().numpy(), g["rgb"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(res["depth_coarse"].numpy(), g["depth"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(res["raw"][..., 3].detach().numpy()[:64], g["sigma_head"], rtol=1e-5, atol=2e-6)
+    loss = F_mse(res["rgb_coarse"], torch.from_numpy(rgbs))
+    np.testing.assert_allclose(loss.detach().numpy(), g["loss"], rtol=1e-6)
+    loss.backward()
+    for k, t in p.items():
+        ref_sum = g["gsum__" + k]
+        got = t.grad.numpy()
+        scale = max(1e-12, float(ref_sum[1]))
+        assert abs(synth.checksum(got)[0] - ref_sum[0]) <= 2e-4 * scale + 1e-9, k
+        sl = got.reshape(-1)[:: max(1, got.size // 499)][:499]
+        np.testing.assert_allclose(sl, g["gslice__" + k], rtol=1e-3, atol=1e-7 + 1e-4 * np.abs(g["gslice__" + k]).max(), err_msg=k)
+
+
+def F_mse(a, b):
+    return torch.nn.functional.mse_loss(a, b, reduction="mean")
