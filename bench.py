@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--mip", action="store_true", help="mip recipe: --samples edges per level (frustums = edges - 1), two levels")
     ap.add_argument("--model-dim", type=int, default=256, help="layer width (512 = mission_bay.yaml, other recipes)")
     ap.add_argument("--experts", type=int, default=8)
+    ap.add_argument("--dense", action="store_true", help="BASELINE configs[0]: the dense NeRF (--no-use_moe), other recipes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     a = ap.parse_args()
@@ -101,9 +102,13 @@ def main():
     from switch_nerf_amd.model import SwitchNeRF, BUILDING
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     cfg = dict(BUILDING, model_dim=a.model_dim, gate_hidden=a.model_dim, num_experts=a.experts)
-    other = a.fine or a.mip or a.model_dim != 256 or a.experts != 8
-    model = SwitchNeRF(cfg, dtype=dtype, device=dev, seed=0)
-    if a.gate_scale != 1.0:
+    other = a.fine or a.mip or a.model_dim != 256 or a.experts != 8 or a.dense
+    if a.dense:
+        from switch_nerf_amd.dense import DenseNeRF
+        model = DenseNeRF(dtype=dtype, device=dev, seed=0)
+    else:
+        model = SwitchNeRF(cfg, dtype=dtype, device=dev, seed=0)
+    if a.gate_scale != 1.0 and not a.dense:
         model.p["wg"].mul_(a.gate_scale)
     rays, idx, rgbs = synth_batch(a.rays, 1000 + rank, dev)
     P = a.rays * a.samples
@@ -154,7 +159,7 @@ def main():
 
     # ---- per-kernel accounting from the live HIP events
     c = st["ctx"]
-    kept = int(torch.minimum(c["counts"], torch.tensor(c["cap"], device=dev)).sum().item())
+    kept = P if a.dense else int(torch.minimum(c["counts"], torch.tensor(c["cap"], device=dev)).sum().item())
     L, M, E = model.L, model.M, model.E
     esz = 2 if dtype == torch.bfloat16 else 4
     kern = {}
@@ -201,7 +206,9 @@ def main():
         "metric": "train rays/sec (8192-ray batch, 256 samples, 8 experts)", "value": round(value, 1), "unit": "rays/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": ("other recipe (informational): " if other else "configs[1]: ") + f"{a.experts}-expert top-1 expertmlp, capacity_factor=1.0, BPR, {a.rays} rays x {a.samples} samples"
+        "config": {"workload": ("other recipe (informational): " if other else "configs[1]: ")
+                               + ("dense NeRF 8 x 256 (configs[0] network, --no-use_moe)" if a.dense else f"{a.experts}-expert top-1 expertmlp, capacity_factor=1.0, BPR")
+                               + f", {a.rays} rays x {a.samples} samples"
                                f" per GPU, {P // a.chunk} segments of {a.chunk} points, building.yaml shapes, random-init weights,"
                                f" gate_scale={a.gate_scale}" + (f", + {a.fine} fine samples (hierarchical)" if a.fine else "")
                                + (", mip recipe (two levels)" if a.mip else "")

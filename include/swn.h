@@ -169,6 +169,15 @@ int swn_mip_resample(const float* z, const float* weights, const float* u_rand, 
  * tutel_moe_layer_nobatch.py:157, 172) from the routing permutation.                                            */
 int swn_gather_rows(const void* src, const int32_t* index, long n_rows, int row_bytes, void* dst, void* stream);
 
+/* The dense NeRF's concat-skip (/root/reference/switch_nerf/models/nerf.py:155-156, torch.cat([enc, h], -1) in front of a
+ * skip layer):  out[r] = [a[r] | b[r] | zeros] with rows of a_bytes / b_bytes / out_bytes bytes (multiples of 16,
+ * out_bytes >= a_bytes + b_bytes; the zero tail pads the row to a chain input width), and the backward of its h-part:
+ * out[r, j] = act[r, j] > 0 ? src[r, col0 + j] : 0  (src [n_rows, ld_src] is the gradient w.r.t. the concatenated input,
+ * act [n_rows, n] the ReLU output that was concatenated; elements of `dtype`).                                          */
+int swn_concat_cols(const void* a, int a_bytes, const void* b, int b_bytes, long n_rows, int out_bytes, void* out, void* stream);
+int swn_slice_relu_bwd(const void* src, int ld_src, int col0, const void* act, int n, long n_rows, int dtype, void* out,
+                       void* stream);
+
 /* ---- dense / grouped MLP chains on MFMA ------------------------------------------------------------------------
  * One launch runs `n_layers` (<= 8) Linear layers back to back with the activations of a 128-row tile resident in
  * LDS.  Layer l: h <- act_l( h @ W_l^T + b_l [+ rowbias[row/rows_per_bias]] [+ skip] ).  W_l (logically [N_l][K_l],

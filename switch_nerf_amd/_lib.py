@@ -53,6 +53,8 @@ SIGNATURES = {
     "swn_mip_encode": [vp, vp, vp, i32, i32, i32, i32, vp, i32, vp],
     "swn_mip_resample": [vp, vp, vp, f32, i32, i32, i32, vp, vp],
     "swn_gather_rows": [vp, vp, i64, i32, vp, vp],
+    "swn_concat_cols": [vp, i32, vp, i32, i64, i32, vp, vp],
+    "swn_slice_relu_bwd": [vp, i32, i32, vp, i32, i64, i32, vp, vp],
     "swn_mlp_chain": [C.POINTER(ChainDesc), vp],
     "swn_pack_weights": [vp, vp, i32, i32, i32, i32, i32, vp],
     "swn_chain_tile_rows": [i32],

@@ -1,0 +1,255 @@
+"""The reference's dense (non-MoE) NeRF on the same HIP kernels: BASELINE.json configs[0] (`--no-use_moe`), and the network
+the reference also uses as its background model.
+
+Mirrors /root/reference/switch_nerf/models/nerf.py:60-190 (class NeRF; built by models/model_utils.py:90-120 get_nerf with
+use_moe = False): `layers` x (Linear + ReLU) of width `layer_dim`, the encoded position concatenated again in front of the
+layers named in `skip_layers` (torch.cat([enc, h]), nerf.py:155-156), the sigma head, then the same direction /
+appearance tail as NeRFMoE (xyz_encoding_final -> dir_a_encoding + ReLU -> rgb + sigmoid).
+
+DenseNeRF derives from SwitchNeRF: ray sampling, positional encoding, the tail chain, the heads, compositing, the loss
+assembly and Adam are the same launches; only the trunk differs - two MLP chains instead of gate + routing + experts:
+
+  chain A   PE [P, KP] -> layers 0 .. s-1                 (s = the skip layer; 256-feature kernels)
+  concat    [PE | h_{s-1} | 0] -> [P, KC]                 (swn_concat_cols; KC = the next supported chain width >= KP + W)
+  chain B   [P, KC] -> layers s .. L-1                    (layer s has K = KC: the 512-feature kernels)
+
+The state_dict layout is the reference NeRF's (xyz_encodings.{i}.0.weight, xyz_encoding_final.weight, dir_a_encoding.0.*,
+sigma.*, rgb.*, embedding_a.weight), so checkpoints interchange.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .model import SwitchNeRF, _ceil_to
+
+# /root/reference/switch_nerf/opts.py defaults for the non-MoE model (layer_dim 256, 8 layers, skip at 4, appearance 48)
+DENSE = dict(layer_dim=256, layers=8, skip_layers=(4,), pos_xyz_dim=12, pos_dir_dim=4, appearance_dim=48,
+             appearance_count=1920, xyz_dim=3)
+
+
+def _chain_width(k):
+    for w in (64, 128, 256, 512):
+        if k <= w:
+            return w
+    raise ValueError(f"chain input width {k} > 512")
+
+
+class DenseNeRF(SwitchNeRF):
+    def __init__(self, cfg: dict = DENSE, dtype=torch.bfloat16, device="cuda", lr=5e-4, seed=0):
+        super().__init__(cfg, dtype, device, capacity_factor=1.0, batch_prioritized=False, moe_l_aux_wt=0.0, lr=lr, seed=seed)
+
+    def _configure(self, cfg):
+        W, L, xd = cfg["layer_dim"], cfg["layers"], cfg.get("xyz_dim", 3)
+        skips = tuple(cfg["skip_layers"])
+        assert len(skips) <= 1 and all(0 < s < L for s in skips), "at most one concat-skip layer, not the first"
+        assert W % 64 == 0 and W <= 256, "layer_dim: a multiple of 64 up to 256 (the concatenated input must fit 512 columns)"
+        self.xyz_dim = xd
+        self.in_xyz = xd + 2 * xd * cfg["pos_xyz_dim"]
+        self.in_dir = 3 + 6 * cfg["pos_dir_dim"]
+        self.KP = _ceil_to(self.in_xyz, 64)
+        self.DP = _ceil_to(self.in_dir, 8)
+        self.n_ray_feat = self.in_dir + cfg["appearance_dim"]
+        self.skip_l = skips[0] if skips else None
+        self.KC = _chain_width(self.KP + W)          # [PE (KP) | h (W) | zero pad]
+        M, H2 = W, W // 2
+        self.L, self.M, self.E, self.G, self.H2 = L, M, 1, M, H2
+        spec = []
+        for i in range(L):
+            k = self.KP if i == 0 else (self.KC if i == self.skip_l else W)
+            spec += [(f"enc{i}.w", (k, W)), (f"enc{i}.b", (W,))]
+        spec += [("l1.w", (M, M)), ("l1.b", (M,)), ("l2h.w", (M, H2)), ("l2r.w", (self.n_ray_feat, H2)), ("l2.b", (H2,)),
+                 ("sigma.w", (M,)), ("sigma.b", (1,)), ("color.w", (3, H2)), ("color.b", (3,)),
+                 ("emb", (cfg["appearance_count"], cfg["appearance_dim"]))]
+        self._chain_weights = [f"enc{i}" for i in range(L)] + ["l1", "l2h"]
+        self._fwd_only_weights = {"enc0"}
+        return spec
+
+    # ------------------------------------------------------------------------------------------ parameters
+    def _init_random(self, seed):
+        g = torch.Generator().manual_seed(seed)
+        cfg, W = self.cfg, self.M
+
+        def lin(out_f, in_f):
+            b = 1.0 / math.sqrt(in_f)
+            return ((torch.rand(out_f, in_f, generator=g) * 2 - 1) * b), ((torch.rand(out_f, generator=g) * 2 - 1) * b)
+        sd = {}
+        for i in range(self.L):
+            k = self.in_xyz if i == 0 else (W + self.in_xyz if i == self.skip_l else W)
+            sd[f"xyz_encodings.{i}.0.weight"], sd[f"xyz_encodings.{i}.0.bias"] = lin(W, k)
+        sd["xyz_encoding_final.weight"], sd["xyz_encoding_final.bias"] = lin(W, W)
+        sd["dir_a_encoding.0.weight"], sd["dir_a_encoding.0.bias"] = lin(self.H2, W + self.n_ray_feat)
+        sd["sigma.weight"], sd["sigma.bias"] = lin(1, W)
+        sd["rgb.weight"], sd["rgb.bias"] = lin(3, self.H2)
+        sd["embedding_a.weight"] = torch.randn(cfg["appearance_count"], cfg["appearance_dim"], generator=g)
+        self.load_state_dict(sd)
+
+    def load_state_dict(self, sd):
+        """Accepts the reference NeRF's state_dict (optionally with the DDP wrapper's `module.` prefix)."""
+        from . import checkpoint
+        sd = checkpoint.strip_module_prefix(sd)
+
+        def t(k):
+            v = sd[k]
+            v = torch.from_numpy(np.asarray(v)) if not torch.is_tensor(v) else v
+            return v.detach().to(torch.float32).to(self.dev)
+        p, W, nx = self.p, self.M, self.in_xyz
+        with torch.no_grad():
+            for i in range(self.L):
+                w = t(f"xyz_encodings.{i}.0.weight").t()            # [in, out]
+                p[f"enc{i}.w"].zero_()
+                if i == self.skip_l:                                 # rows: [PE (nx of KP) | h (W) | pad]
+                    p[f"enc{i}.w"][:nx] = w[:nx]
+                    p[f"enc{i}.w"][self.KP: self.KP + W] = w[nx:]
+                else:
+                    p[f"enc{i}.w"][: w.shape[0]] = w
+                p[f"enc{i}.b"].copy_(t(f"xyz_encodings.{i}.0.bias"))
+            p["l1.w"].copy_(t("xyz_encoding_final.weight").t())
+            p["l1.b"].copy_(t("xyz_encoding_final.bias"))
+            w2 = t("dir_a_encoding.0.weight")
+            p["l2h.w"].copy_(w2[:, :W].t())
+            p["l2r.w"].copy_(w2[:, W:].t())
+            p["l2.b"].copy_(t("dir_a_encoding.0.bias"))
+            p["sigma.w"].copy_(t("sigma.weight").view(-1))
+            p["sigma.b"].copy_(t("sigma.bias"))
+            p["color.w"].copy_(t("rgb.weight"))
+            p["color.b"].copy_(t("rgb.bias"))
+            p["emb"].copy_(t("embedding_a.weight"))
+        self.refresh_compute_copies()
+
+    def _to_ref_layout(self, d):
+        W, nx = self.M, self.in_xyz
+        out = {}
+        for i in range(self.L):
+            w = d[f"enc{i}.w"]
+            if i == 0:
+                w = w[:nx]
+            elif i == self.skip_l:
+                w = torch.cat([w[:nx], w[self.KP: self.KP + W]], 0)
+            out[f"xyz_encodings.{i}.0.weight"] = w.t().contiguous()
+            out[f"xyz_encodings.{i}.0.bias"] = d[f"enc{i}.b"].clone()
+        out["xyz_encoding_final.weight"] = d["l1.w"].t().contiguous()
+        out["xyz_encoding_final.bias"] = d["l1.b"].clone()
+        out["dir_a_encoding.0.weight"] = torch.cat([d["l2h.w"].t(), d["l2r.w"].t()], 1).contiguous()
+        out["dir_a_encoding.0.bias"] = d["l2.b"].clone()
+        out["sigma.weight"] = d["sigma.w"].view(1, -1).clone()
+        out["sigma.bias"] = d["sigma.b"].clone()
+        out["rgb.weight"] = d["color.w"].clone()
+        out["rgb.bias"] = d["color.b"].clone()
+        out["embedding_a.weight"] = d["emb"].clone()
+        return out
+
+    def state_dict(self, layout="nerf", prefix=""):
+        return {prefix + k: v for k, v in self._to_ref_layout(self.p).items()}
+
+    def set_expert_parallel(self, ep):
+        raise NotImplementedError("the dense NeRF has no experts to shard")
+
+    # ------------------------------------------------------------------------------------------ forward
+    def _net_forward(self, pe, pe_dir, image_indices, N, S, seg_tokens, sigma_noise, routing_override, no_batch, tag):
+        """NeRF.forward (nerf.py:143-190) over the N*S points whose encodings are in `pe` -> c["raw"] [N*S, 4]."""
+        o, dt = ops, self.dtype
+        P = N * S
+        W, L, H2, s = self.M, self.L, self.H2, self.skip_l
+        c = dict(N=N, S=S, P=P, n_seg=max(1, P // seg_tokens), seg_tokens=seg_tokens, tag=tag, image_indices=image_indices)
+        c["pe"], c["pe_dir"] = pe, pe_dir
+        _b = lambda name, shape, dtype: self._buf(tag + ":" + name, shape, dtype)
+        c["acts"] = [_b(f"act{i}", (P, W), dt) for i in range(L)]          # post-ReLU outputs; acts[L-1] = xyz_ (c["y"])
+        nA = L if s is None else s
+        mwA = o.chain_mask_words(dt, 1, P, max(W, self.KP))
+        mwB = o.chain_mask_words(dt, 1, P, self.KC)
+        c["masks"] = [_b(f"mask{i}", (mwA if i < nA else mwB,), torch.int32) for i in range(L)]
+
+        def layer(i, last):
+            return o.Layer(self.wf[f"enc{i}"], self.p[f"enc{i}.b"].view(1, W), relu=1, mask=c["masks"][i],
+                           save=None if last else c["acts"][i])
+        with self._timed("trunk_fwd"):
+            o.mlp_chain(pe, [layer(i, i == nA - 1) for i in range(nA)], c["acts"][nA - 1], tag=1)
+            if s is not None:
+                c["cat"] = o.concat_cols(pe, c["acts"][s - 1], _b("cat", (P, self.KC), dt))
+                o.mlp_chain(c["cat"], [layer(i, i == L - 1) for i in range(s, L)], c["acts"][L - 1], tag=1)
+        c["y"] = c["acts"][L - 1]
+        # ---- per-ray part of dir_a_encoding: [PE(dir), appearance embedding] @ W2r + b2 (nerf.py:173-181)
+        feat = torch.cat([pe_dir[:, : self.in_dir].float(), self.p["emb"][image_indices.long()]], 1)
+        c["ray_feat"] = feat
+        c["c_ray"] = torch.addmm(self.p["l2.b"], feat, self.p["l2r.w"]).contiguous()
+        c["h1"] = _b("h1", (P, W), dt)
+        c["h2"] = _b("h2", (P, H2), dt)
+        o.mlp_chain(c["y"], [o.Layer(self.wf["l1"], self.p["l1.b"].view(1, W), save=c["h1"]),
+                             o.Layer(self.wf["l2h"], None, relu=1, rowbias=c["c_ray"], rows_per_bias=S)], c["h2"], tag=4)
+        c["raw"] = o.heads_fwd(c["y"], c["h2"], self.p["sigma.w"], self.p["sigma.b"], self.p["color.w"], self.p["color.b"],
+                               sigma_noise)
+        c["l_aux"] = torch.zeros(c["n_seg"], dtype=torch.float32, device=self.dev)     # no gate loss (runner.py:1104 guards on use_moe)
+        c["idx"] = None
+        return c
+
+    # ------------------------------------------------------------------------------------------ backward
+    def backward_net(self, c, d_raw, d_laux=None):
+        o, dt = ops, self.dtype
+        S, P = c["S"], c["P"]
+        W, L, H2, s = self.M, self.L, self.H2, self.skip_l
+        g, acts, masks = self.g, c["acts"], c["masks"]
+        _b = lambda name, shape, dtype: self._buf(c["tag"] + ":" + name, shape, dtype)
+        dh2, dsig = o.heads_bwd(c["y"], c["h2"], self.p["color.w"], c["raw"], d_raw, g["sigma.w"], g["sigma.b"], g["color.w"],
+                                g["color.b"])
+        dc_ray = o.group_colsum(dh2, S)
+        g["l2r.w"].addmm_(c["ray_feat"].t(), dc_ray)
+        g["l2.b"].add_(dc_ray.sum(0))
+        g["emb"].index_add_(0, c["image_indices"].long(), dc_ray @ self.p["l2r.w"][self.in_dir:].t())
+        dh1 = _b("dh1", (P, W), dt)
+        dy = _b("dy", (P, W), dt)
+        o.mlp_chain(dh2, [o.Layer(self.wb["l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dy, tag=5)
+        nsp = max(1, min(256, P // 4096))
+        # d(pre-activation of the last trunk layer) = (dy + dsigma * w_sigma) * (xyz_ > 0): the combine backward with a unit gate
+        ones = self._buf("ones", (P,), torch.float32)
+        if not getattr(self, "_ones_set", False):
+            ones.fill_(1.0)
+            self._ones_set = True
+        dz = [_b(f"dz{i}", (P, W), dt) for i in range(L - 1)]
+        dz.append(o.combine_bwd(dy, c["y"], dsig, self.p["sigma.w"], ones)[0])
+        o.wgrad(c["h1"], dh2, g["l2h.w"].view(1, W, H2), None, n_splits=nsp)
+        o.wgrad(c["y"], dh1, g["l1.w"].view(1, W, W), g["l1.b"].view(1, W), n_splits=nsp)
+        nA = L if s is None else s
+        with self._timed("trunk_bwd"):
+            if s is not None:
+                # chain B backward: dz[L-1] -> ... -> dz[s] -> d(cat) (no mask: the concatenated input is not an activation)
+                bl = [o.Layer(self.wb[f"enc{i}"], None, relu=2 if i > s else 0, mask=masks[i - 1] if i > s else None,
+                              save=dz[i - 1] if i > s else None) for i in range(L - 1, s - 1, -1)]
+                dcat = _b("dcat", (P, self.KC), dt)
+                o.mlp_chain(dz[L - 1], bl, dcat, tag=2)
+                o.slice_relu_bwd(dcat, self.KP, acts[s - 1], dz[s - 1])
+            if nA > 1:
+                bl = [o.Layer(self.wb[f"enc{i}"], None, relu=2, mask=masks[i - 1], save=dz[i - 1] if i > 1 else None)
+                      for i in range(nA - 1, 0, -1)]
+                o.mlp_chain(dz[nA - 1], bl, dz[0], tag=2)
+        with self._timed("trunk_wgrad"):
+            for i in range(L):
+                a = c["pe"] if i == 0 else (c["cat"] if i == s else acts[i - 1])
+                k = a.shape[1]
+                o.wgrad(a, dz[i], g[f"enc{i}.w"].view(1, k, W), g[f"enc{i}.b"].view(1, W), n_splits=nsp)
+
+    # ------------------------------------------------------------------------------------------ NeRF mirrors
+    def set_no_batch(self, mode=True):
+        pass
+
+    def __call__(self, x, sigma_only=False, sigma_noise=None):
+        """NeRF.forward (nerf.py:143-190): x [P, 7] = xyz(3), dir(3), image index(1) -> [P, 4] (rgb, sigma), or
+        x [P, 3] with sigma_only -> [P, 1].  Inference only."""
+        if self.xyz_dim != 3:
+            raise NotImplementedError("xyz_dim 4 (the background model's inverted-sphere input) has no encoding kernel yet")
+        expected = 3 if sigma_only else 7
+        if x.shape[1] != expected:
+            raise Exception("Unexpected input shape: {} (expected: {}, xyz_dim: {})".format(x.shape, expected, 3))
+        P = x.shape[0]
+        xf = x.to(torch.float32)
+        if sigma_only:
+            xf = torch.cat([xf, torch.zeros(P, 4, device=self.dev)], 1)
+            xf[:, 5] = 1.0
+        rays = torch.cat([xf[:, :6], torch.zeros(P, 2, device=self.dev)], 1).contiguous()
+        c = self.forward_rays(rays, xf[:, 6].long().contiguous(), 1, P, 0.0, None,
+                              None if sigma_noise is None else sigma_noise.reshape(-1).to(torch.float32).contiguous(),
+                              training=self.training, composite=False)
+        return c["raw"][:, 3:4] if sigma_only else c["raw"]

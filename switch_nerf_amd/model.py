@@ -42,24 +42,9 @@ def _ceil_to(x, m):
 class SwitchNeRF:
     def __init__(self, cfg: dict = BUILDING, dtype=torch.bfloat16, device="cuda", capacity_factor=1.0,
                  batch_prioritized=True, moe_l_aux_wt=5e-4, lr=5e-4, seed=0):
-        assert tuple(cfg["skips"]) == (3,) or len(cfg["skips"]) <= 1, "one skip connection supported"
         self.cfg, self.dtype, self.dev = dict(cfg), dtype, torch.device(device)
         self.cf, self.bpr, self.wt, self.lr = capacity_factor, batch_prioritized, moe_l_aux_wt, lr
-        M, E, L, G, H2 = cfg["model_dim"], cfg["num_experts"], cfg["expert_layers"], cfg["gate_hidden"], cfg["layer2_out"]
-        assert G == M, "external gate width must equal model_dim (building.yaml)"
-        self.in_xyz = 3 + 6 * cfg["pos_xyz_dim"]
-        self.in_dir = 3 + 6 * cfg["pos_dir_dim"]
-        self.KP = _ceil_to(self.in_xyz, 64)          # padded PE width (chain K granularity)
-        self.DP = _ceil_to(self.in_dir, 8)
-        self.n_ray_feat = self.in_dir + cfg["appearance_dim"]
-        # ---- flat master parameter buffer; name -> (offset, shape); Linear weights are [in, out]
-        spec = [("xyz.w", (self.KP, M)), ("xyz.b", (M,)), ("gate0.w", (M, G)), ("gate0.b", (G,)),
-                ("gate1.w", (G, G)), ("gate1.b", (G,)), ("ln.w", (G,)), ("ln.b", (G,)), ("wg", (E, G))]
-        for l in range(L):
-            spec += [(f"exp{l}.w", (E, M, M)), (f"exp{l}.b", (E, M))]
-        spec += [("l1.w", (M, M)), ("l1.b", (M,)), ("l2h.w", (M, H2)), ("l2r.w", (self.n_ray_feat, H2)), ("l2.b", (H2,)),
-                 ("sigma.w", (M,)), ("sigma.b", (1,)), ("color.w", (3, H2)), ("color.b", (3,)),
-                 ("emb", (cfg["appearance_count"], cfg["appearance_dim"]))]
+        spec = self._configure(cfg)
         self.spec, off = {}, 0
         for name, shape in spec:
             n = int(np.prod(shape))
@@ -71,11 +56,9 @@ class SwitchNeRF:
         self.p = {k: self.flat[o:o + int(np.prod(s))].view(s) for k, (o, s) in self.spec.items()}
         self.g = {k: self.grad[o:o + int(np.prod(s))].view(s) for k, (o, s) in self.spec.items()}
         self.step_count = 0
-        self.L, self.M, self.E, self.G, self.H2 = L, M, E, G, H2
         # compute copies
         self.wf: Dict[str, torch.Tensor] = {}
         self.wb: Dict[str, torch.Tensor] = {}
-        self._chain_weights = ["xyz", "gate0", "gate1", "l1", "l2h"] + [f"exp{l}" for l in range(L)]
         self._init_random(seed)
         self._bufs = {}
         self.profile = False          # bench.py: record HIP events around the major launches
@@ -85,6 +68,28 @@ class SwitchNeRF:
         self.overlap = os.environ.get("SWN_NO_OVERLAP", "0") != "1"   # side-stream overlap of the expert weight gradients
         self.ep = None                # parallel.ExpertParallel: experts sharded over ranks, tokens exchanged (set_expert_parallel)
         self.expert_wgrad_splits = int(os.environ.get("SWN_EXPERT_WGRAD_SPLITS", "0"))   # 0 = heuristic
+
+    def _configure(self, cfg):
+        """Sets the network dimensions and returns the flat parameter layout [(name, shape)]; Linear weights are [in, out]."""
+        assert tuple(cfg["skips"]) == (3,) or len(cfg["skips"]) <= 1, "one skip connection supported"
+        M, E, L, G, H2 = cfg["model_dim"], cfg["num_experts"], cfg["expert_layers"], cfg["gate_hidden"], cfg["layer2_out"]
+        assert G == M, "external gate width must equal model_dim (building.yaml)"
+        self.in_xyz = 3 + 6 * cfg["pos_xyz_dim"]
+        self.in_dir = 3 + 6 * cfg["pos_dir_dim"]
+        self.KP = _ceil_to(self.in_xyz, 64)          # padded PE width (chain K granularity)
+        self.DP = _ceil_to(self.in_dir, 8)
+        self.n_ray_feat = self.in_dir + cfg["appearance_dim"]
+        spec = [("xyz.w", (self.KP, M)), ("xyz.b", (M,)), ("gate0.w", (M, G)), ("gate0.b", (G,)),
+                ("gate1.w", (G, G)), ("gate1.b", (G,)), ("ln.w", (G,)), ("ln.b", (G,)), ("wg", (E, G))]
+        for l in range(L):
+            spec += [(f"exp{l}.w", (E, M, M)), (f"exp{l}.b", (E, M))]
+        spec += [("l1.w", (M, M)), ("l1.b", (M,)), ("l2h.w", (M, H2)), ("l2r.w", (self.n_ray_feat, H2)), ("l2.b", (H2,)),
+                 ("sigma.w", (M,)), ("sigma.b", (1,)), ("color.w", (3, H2)), ("color.b", (3,)),
+                 ("emb", (cfg["appearance_count"], cfg["appearance_dim"]))]
+        self.L, self.M, self.E, self.G, self.H2 = L, M, E, G, H2
+        self._chain_weights = ["xyz", "gate0", "gate1", "l1", "l2h"] + [f"exp{l}" for l in range(L)]
+        self._fwd_only_weights = {"xyz"}              # first layer: no input gradient, no transposed copy
+        return spec
 
     @contextlib.contextmanager
     def _timed(self, name):
@@ -214,7 +219,7 @@ class SwitchNeRF:
             w3 = w if w.dim() == 3 else w.unsqueeze(0)
             if n not in self.wf:
                 self.wf[n] = ops.pack_weights(w3, self.dtype, True)
-                if n != "xyz":
+                if n not in self._fwd_only_weights:
                     self.wb[n] = ops.pack_weights(w3, self.dtype, False)
             else:
                 ops.repack_weights(w3, self.wf[n], True)

@@ -97,6 +97,21 @@ def gather_rows(src, index, out=None):
     return out
 
 
+def concat_cols(a, b, out):
+    """out[r] = [a[r] | b[r] | zeros]: the input of the dense NeRF's concat-skip layer (models/nerf.py:155-156)."""
+    assert a.shape[0] == b.shape[0] == out.shape[0] and a.dtype == b.dtype == out.dtype
+    es = a.element_size()
+    call("swn_concat_cols", _p(a), a.shape[1] * es, _p(b), b.shape[1] * es, a.shape[0], out.shape[1] * es, _p(out), _stream())
+    return out
+
+
+def slice_relu_bwd(src, col0, act, out):
+    """out = src[:, col0:col0+n] * (act > 0), act [R, n]: gradient of the concatenated hidden state through its ReLU."""
+    assert src.dtype == act.dtype == out.dtype and act.shape == out.shape and src.shape[0] == act.shape[0]
+    call("swn_slice_relu_bwd", _p(src), src.shape[1], col0, _p(act), act.shape[1], act.shape[0], _dt(src), _p(out), _stream())
+    return out
+
+
 def gate_fwd(g, ln_w, ln_b, wg):
     P, G = g.shape
     E = wg.shape[0]
