@@ -397,6 +397,68 @@ def gen_composite():
          fine_det=fine_det.numpy())
 
 
+def gen_bg():
+    print("[G8] background model + ellipsoid bound: NeRFMoE foreground + dense 4-D background NeRF (rendering.py:32-159), fwd + grads")
+    cfg, cfg_bg = synth.BUILDING, synth.DENSE_BG
+    center, radius = torch.from_numpy(synth.SPHERE_CENTER), torch.from_numpy(synth.SPHERE_RADIUS)
+    for tag, perturb, Fn in (("coarse_det", 0.0, 0), ("coarse", 1.0, 0), ("fine", 1.0, 48)):
+        sd = synth.make_weights(81, cfg, gate_scale=0.02)
+        sd_bg = synth.make_dense_weights(82, cfg_bg)
+        N, S, chunk = 96, 64, 1024
+        nerf, h = build_reference_model(cfg, sd, coarse=S, chunk=chunk, perturb=perturb, sigma_noise=False, fine=Fn)
+        h.layers, h.skip_layers, h.bg_layer_dim = cfg_bg["layers"], list(cfg_bg["skip_layers"]), cfg_bg["layer_dim"]
+        bg = model_utils.get_bg_nerf(h, cfg_bg["appearance_count"])
+        assert set(bg.state_dict().keys()) == set(sd_bg.keys())
+        bg.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_bg.items()})
+        rays, img, rgbs = synth.make_bg_rays(83, N)
+        nerf.train()
+        bg.train()
+        r = torch.from_numpy(rays)
+        fg_far = torch.maximum(rendering._intersect_sphere(r[:, :3], r[:, 3:6], center, radius), r[:, 6])
+        Nb = int((r[:, 7] > fg_far).sum())
+        assert 0 < Nb < N, Nb
+        # the reference's random draws in call order (background first): rand_like(bg z) :583, rand(Nb, fine // 2) :608,
+        # rand_like(z) :583, rand(N, fine) :608 - replayed from the seed
+        torch.manual_seed(87)
+        draws = dict(perturb_rand_bg=torch.rand(Nb, S // 2))
+        if Fn:
+            draws["fine_u_bg"] = torch.rand(Nb, Fn // 2)
+        draws["perturb_rand"] = torch.rand(N, S)
+        if Fn:
+            draws["fine_u"] = torch.rand(N, Fn)
+        torch.manual_seed(87)
+        res, present = rendering.render_rays(nerf, bg, r, torch.from_numpy(img), h, center, radius,
+                                             get_depth=True, get_depth_variance=True, get_bg_fg_rgb=True)
+        assert present
+        typ = "fine" if Fn else "coarse"
+        photo = torch.nn.functional.mse_loss(res[f"rgb_{typ}"], torch.from_numpy(rgbs))
+        gate_loss = res["gate_loss_coarse"].mean()
+        if Fn:
+            gate_loss = (res["gate_loss_fine"].mean() + gate_loss) / 2.0
+        loss = photo + 5e-4 * gate_loss
+        loss.backward()
+        out = dict(seed=81, seed_bg=82, gate_scale=0.02, N=N, S=S, F=Fn, chunk=chunk, perturb=perturb, n_bg=Nb,
+                   rgb=res[f"rgb_{typ}"].detach().numpy(), depth=res[f"depth_{typ}"].detach().numpy(),
+                   depth_variance=res[f"depth_variance_{typ}"].numpy(), fg_rgb=res[f"fg_rgb_{typ}"].detach().numpy(),
+                   bg_rgb=res[f"bg_rgb_{typ}"].detach().numpy(), fg_far=fg_far.numpy(),
+                   loss=loss.detach().numpy(), photo=photo.detach().numpy())
+        if perturb > 0:
+            out.update({k: v.numpy() for k, v in draws.items()})
+        for pre, mod in (("", nerf), ("bg__", bg)):
+            for n, p in mod.named_parameters():
+                g_ = p.grad
+                out["gsum__" + pre + n] = synth.checksum(g_.numpy())
+                out["gslice__" + pre + n] = g_.numpy().reshape(-1)[:: max(1, g_.numel() // 499)][:499]
+        save(f"bg_train_{tag}", **out)
+    # _depth2pts_outside / _intersect_sphere on their own (kernel-level fixture)
+    rays, _, _ = synth.make_bg_rays(84, 40)
+    r = torch.from_numpy(rays)
+    depth = torch.from_numpy(np.random.default_rng(85).uniform(1e-3, 1.0, (40, 24)).astype(np.float32))
+    pts, dreal = rendering._depth2pts_outside(r[:, None, :3], r[:, None, 3:6], depth, center, radius, False, False)
+    save("bg_points", depth=depth.numpy(), pts=pts.numpy(), depth_real=dreal.numpy(),
+         fg_far=rendering._intersect_sphere(r[:, :3], r[:, 3:6], center, radius).numpy())
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -404,7 +466,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     todo = dict(routing=gen_routing, pe=gen_pe, moe=gen_moe_layer, model=gen_model_forward, nobatch=gen_model_forward_nobatch,
-                render=gen_render, fine=gen_render_fine, mip=gen_mip, ckpt=gen_checkpoint_layout, dense=gen_dense, composite=gen_composite)
+                render=gen_render, fine=gen_render_fine, mip=gen_mip, ckpt=gen_checkpoint_layout, dense=gen_dense, composite=gen_composite, bg=gen_bg)
     for k, fn in todo.items():
         if a.only and k not in a.only.split(","):
             continue

@@ -230,19 +230,25 @@ def nerf_moe_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: dict, cap
 # --------------------------------------------------------------------------------------------
 
 
-def composite(rgbs: torch.Tensor, sigmas: torch.Tensor, z_vals: torch.Tensor, last_delta: float = 1e10):
-    """rendering.py:435-494.  rgbs [N,S,3], sigmas [N,S], z_vals [N,S]."""
-    deltas = z_vals[:, 1:] - z_vals[:, :-1]
-    deltas = torch.cat([deltas, torch.full_like(z_vals[:, :1], last_delta)], -1)            # :441
+def composite(rgbs: torch.Tensor, sigmas: torch.Tensor, z_vals: torch.Tensor, last_delta=1e10, flip: bool = False,
+              depth_real: Optional[torch.Tensor] = None):
+    """rendering.py:435-494.  rgbs [N,S,3], sigmas [N,S], z_vals [N,S]; last_delta a number or a [N,1] tensor (the distance
+    to the foreground bound for rays that continue into the background model, :32-46, :216-217); flip: z_vals descend
+    (the background's inverse-distance samples, :436-437); depth_real: the metric depths the depth map is taken over (:483-484).
+    bg_lambda = the transmittance left after the last sample (:456-457)."""
+    deltas = (z_vals[:, :-1] - z_vals[:, 1:]) if flip else (z_vals[:, 1:] - z_vals[:, :-1])    # :436-439
+    ld = last_delta if torch.is_tensor(last_delta) else torch.full_like(z_vals[:, :1], last_delta)
+    deltas = torch.cat([deltas, ld], -1)                                                       # :441
     alphas = 1 - torch.exp(-deltas * sigmas)                                                   # :442
     T = torch.cumprod(1 - alphas + 1e-8, -1)                                                   # :455
+    bg_lambda = T[:, -1]                                                                       # :457
     T = torch.cat((torch.ones_like(T[:, :1]), T[:, :-1]), -1)                                  # :459
     weights = alphas * T                                                                       # :461
     rgb = (weights.unsqueeze(-1) * rgbs).sum(1)                                                # :467
     with torch.no_grad():
-        depth = (weights * z_vals).sum(1)                                                      # :485
+        depth = (weights * (z_vals if depth_real is None else depth_real)).sum(1)              # :483-486
         depth_var = (weights * (z_vals - depth.unsqueeze(1)).square()).sum(-1)                 # :491-493
-    return dict(rgb=rgb, weights=weights, depth=depth, depth_variance=depth_var, alphas=alphas)
+    return dict(rgb=rgb, weights=weights, depth=depth, depth_variance=depth_var, alphas=alphas, bg_lambda=bg_lambda)
 
 
 def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_fine: int, u: Optional[torch.Tensor] = None):
@@ -368,6 +374,131 @@ def render_rays_dense(p, rays, image_indices, cfg, n_samples, perturb=0.0, pertu
     out = nerf_dense_forward(p, pts, cfg, sigma_noise).view(N, n_samples, 4)
     comp = composite(out[..., :3], out[..., 3], z)
     return dict(rgb_coarse=comp["rgb"], depth_coarse=comp["depth"], depth_variance_coarse=comp["depth_variance"], raw=out, z_vals=z)
+
+
+# --------------------------------------------------------------------------------------------
+# background model + foreground bounds (rendering.py:32-159, 497-570; the Mega-NeRF scenes' default, opts.py:89)
+# --------------------------------------------------------------------------------------------
+def intersect_sphere(o: torch.Tensor, d: torch.Tensor, center: Optional[torch.Tensor], radius: Optional[torch.Tensor]):
+    """_intersect_sphere, rendering.py:497-518: depth at which o + t d leaves the (ellipsoidal) foreground bound."""
+    if radius is not None:
+        o = (o - center) / radius
+        d = d / radius
+    d1 = -torch.sum(d * o, -1) / torch.sum(d * d, -1)
+    pm = o + d1.unsqueeze(-1) * d
+    cos = 1.0 / torch.norm(d, dim=-1)
+    pn = torch.sum(pm * pm, -1)
+    if (pn >= 1.0).any():
+        raise Exception("Not all your cameras are bounded by the unit sphere; please make sure the cameras are normalized properly!")
+    return d1 + torch.sqrt(1.0 - pn) * cos
+
+
+def depth2pts_outside(o: torch.Tensor, d: torch.Tensor, depth: torch.Tensor, center, radius):
+    """_depth2pts_outside, rendering.py:521-570 (include_xyz_real False): o, d [N,1,3], depth [N,S] = inverse distance in
+    (0,1] -> points on the unit sphere + the inverse distance [N,S,4] (the NeRF++ inverted-sphere parametrisation) and
+    the metric depth along the ray [N,S]."""
+    if radius is not None:
+        o = (o - center) / radius
+        d = d / radius
+    d1 = -torch.sum(d * o, -1) / torch.sum(d * d, -1)
+    p_mid = o + d1.unsqueeze(-1) * d
+    p_mid_norm = torch.norm(p_mid, dim=-1)
+    cos = 1.0 / d.norm(dim=-1)
+    d2 = torch.sqrt(1.0 - p_mid_norm * p_mid_norm) * cos
+    p_sphere = o + (d1 + d2).unsqueeze(-1) * d
+    axis = torch.cross(o, p_sphere, dim=-1)
+    axis = axis / (torch.norm(axis, dim=-1, keepdim=True) + 1e-8)
+    phi = torch.asin(p_mid_norm)
+    theta = torch.asin(p_mid_norm * depth)
+    ang = (phi - theta).unsqueeze(-1)
+    p_new = p_sphere * torch.cos(ang) + torch.cross(axis, p_sphere, dim=-1) * torch.sin(ang) + \
+        axis * torch.sum(axis * p_sphere, -1, keepdim=True) * (1.0 - torch.cos(ang))             # Rodrigues, :548-550
+    p_new = p_new / torch.norm(p_new, dim=-1, keepdim=True)
+    depth_real = 1.0 / (depth + 1e-8) * torch.cos(theta) + d1                                   # :554
+    return torch.cat((p_new, depth.unsqueeze(-1)), -1), depth_real
+
+
+def _eval_dense(p_bg, pts, d, image_indices, cfg_bg, sigma_noise=None):
+    """The background model on [Nb, S, 4] points (one chunk: nothing depends on the chunking of a dense model)."""
+    Nb, S = pts.shape[:2]
+    x = torch.cat([pts.reshape(-1, 4), d[:, None, :].expand(Nb, S, 3).reshape(-1, 3),
+                   image_indices.view(Nb, 1, 1).expand(Nb, S, 1).reshape(-1, 1).to(pts.dtype)], 1)
+    return nerf_dense_forward(p_bg, x, cfg_bg, sigma_noise).view(Nb, S, 4)
+
+
+def render_rays_bg(p, p_bg, rays, image_indices, cfg, cfg_bg, n_samples: int, chunk: int, center, radius,
+                   capacity_factor: float = 1.0, batch_prioritized: bool = True, perturb: float = 0.0,
+                   perturb_rand: Optional[torch.Tensor] = None, perturb_rand_bg: Optional[torch.Tensor] = None,
+                   sigma_noise=None, sigma_noise_bg=None, fine_samples: int = 0, fine_u=None, fine_u_bg=None,
+                   sigma_noise_fine=None, sigma_noise_bg_fine=None):
+    """render_rays with a background model, rendering.py:15-196: the foreground network samples [near, min(far, bound)],
+    rays that leave the bound (far > fg_far, :36) are continued by the dense 4-D background model on coarse_samples // 2
+    inverse-distance samples (:48-78, flip), and both renderings are blended with the foreground's leftover transmittance
+    (:104-131).  perturb_rand_bg [Nb, S // 2] are the background's stratified draws (it is sampled first, :50-52).
+    fine_samples > 0: both models run the hierarchical pass (:236-268, fine_samples // 2 for the background, :241)."""
+    N = rays.shape[0]
+    o, d, near, far = rays[:, 0:3], rays[:, 3:6], rays[:, 6:7], rays[:, 7:8]
+    fg_far = torch.maximum(intersect_sphere(o, d, center, radius), near.squeeze(-1))             # :34-35
+    with_bg = torch.arange(N)[far.squeeze(-1) > fg_far]                                        # :36
+    last_delta = 1e10 * torch.ones(N, 1)
+    res_bg = None
+    Fn = fine_samples
+    if with_bg.numel() > 0:
+        last_delta[with_bg, 0] = fg_far[with_bg]                                               # :42
+        far = torch.minimum(far.squeeze(-1), fg_far).unsqueeze(-1)                             # :44
+        Sb = n_samples // 2
+        ob, db, ib = o[with_bg], d[with_bg], image_indices[with_bg]
+        zb = sample_z(torch.zeros(len(with_bg), 1), torch.ones(len(with_bg), 1), Sb, perturb, perturb_rand_bg)   # :46-49
+        pts, depth_real = depth2pts_outside(ob[:, None, :], db[:, None, :], zb, center, radius)
+        pts_f, zb_f = torch.flip(pts, dims=[-2]), torch.flip(zb, dims=[-1])                    # :302-304 (depth_real is NOT flipped)
+        out_b = _eval_dense(p_bg, pts_f, db, ib, cfg_bg, sigma_noise_bg)
+        comp_b = composite(out_b[..., :3], out_b[..., 3], zb_f, 1e10, flip=True, depth_real=depth_real)
+        res_bg = dict(rgb=comp_b["rgb"], depth=comp_b["depth"], raw=out_b, z=zb_f, depth_real=depth_real)
+        if Fn > 0:
+            # _get_results' own z_vals are the UN-flipped depths (only _inference's local copy is flipped, :302-304) while
+            # weights_coarse is in the flipped order: the reference pairs ascending bins with the reversed weights
+            z_mid = 0.5 * (zb[:, :-1] + zb[:, 1:])                                              # :238
+            zf = sample_pdf(z_mid, comp_b["weights"][:, 1:-1].detach(), Fn // 2, fine_u_bg)     # :240-241
+            pts2, dreal2 = depth2pts_outside(ob[:, None, :], db[:, None, :], zf, center, radius)
+            out_f = _eval_dense(p_bg, pts2, db, ib, cfg_bg, sigma_noise_bg_fine)
+            z_all, order = torch.sort(torch.cat([zf, zb_f], -1), dim=-1, descending=True, stable=True)   # :421
+            raw_all = torch.gather(torch.cat([out_f, out_b], 1), 1, order[:, :, None].expand(-1, -1, 4))
+            dreal_all = torch.gather(torch.cat([dreal2, depth_real], 1), 1, order)              # :432-433
+            comp_bf = composite(raw_all[..., :3], raw_all[..., 3], z_all, 1e10, flip=True, depth_real=dreal_all)
+            res_bg.update(rgb=comp_bf["rgb"], depth=comp_bf["depth"], z_fine=zf, z_merged=z_all)
+    z = sample_z(near, far, n_samples, perturb, perturb_rand)                                   # :85-88
+    out, gl, routes = _eval_points(p, rays, image_indices, z, cfg, chunk, capacity_factor, batch_prioritized, sigma_noise, None)
+
+    def bounded(zz):                                                                            # :216-217 / :249-250
+        ld = last_delta.clone()
+        sel = last_delta.squeeze(-1) < 1e10
+        ld[sel, 0] = last_delta[sel, 0] - zz[sel].max(dim=-1)[0]
+        return ld
+    comp = composite(out[..., :3], out[..., 3], z, bounded(z))
+    res = dict(gate_loss_coarse=gl, raw=out, z_vals=z, fg_far=fg_far, with_bg=with_bg, routings=routes, bg=res_bg)
+    typ = "coarse"
+    if Fn > 0:
+        typ = "fine"
+        z_mid = 0.5 * (z[:, :-1] + z[:, 1:])
+        z_fine = sample_pdf(z_mid, comp["weights"][:, 1:-1].detach(), Fn, fine_u)
+        out_f, gl_f, routes_f = _eval_points(p, rays, image_indices, z_fine, cfg, min(chunk, z_fine.numel()), capacity_factor,
+                                             batch_prioritized, sigma_noise_fine, None)
+        z_all, order = torch.sort(torch.cat([z_fine, z], -1), dim=-1, stable=True)
+        raw_all = torch.gather(torch.cat([out_f, out], 1), 1, order[:, :, None].expand(-1, -1, 4))
+        comp = composite(raw_all[..., :3], raw_all[..., 3], z_all, bounded(z_fine))             # the FINE depths' maximum, :249-250
+        res.update(gate_loss_fine=gl_f, z_fine=z_fine, routings_fine=routes_f)
+    rgb, depth = comp["rgb"], comp["depth"]
+    res["fg_rgb"], res["bg_lambda"] = rgb, comp["bg_lambda"]
+    if res_bg is not None:                                                                      # :104-131
+        lam = comp["bg_lambda"][with_bg]
+        add = torch.zeros_like(rgb)
+        add[with_bg] = res_bg["rgb"] * lam.unsqueeze(-1)
+        rgb = rgb + add
+        addd = torch.zeros_like(depth)
+        addd[with_bg] = res_bg["depth"] * lam.detach()
+        depth = depth + addd
+    res[f"rgb_{typ}"], res[f"depth_{typ}"], res[f"depth_variance_{typ}"] = rgb, depth, comp["depth_variance"]
+    return res
 
 
 # --------------------------------------------------------------------------------------------

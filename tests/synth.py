@@ -109,6 +109,20 @@ def make_rays(seed: int, n_rays: int, appearance_count: int = 10, near=0.05, far
     return rays, image_indices, rgbs
 
 
+DENSE_BG = dict(DENSE, xyz_dim=4)          # the background model (models/model_utils.py:73-84 get_bg_nerf: xyz_dim 4)
+SPHERE_CENTER = np.array([0.02, -0.03, 0.01], np.float32)      # ellipsoidal foreground bound (runner.py:221-243)
+SPHERE_RADIUS = np.array([0.6, 0.8, 0.7], np.float32)
+
+
+def make_bg_rays(seed: int, n_rays: int, appearance_count: int = 10):
+    """Rays for the background path: origins inside the foreground ellipsoid, far in U(0.3, 1.5) so that some rays stop
+    inside the bound (no background) and the others leave it (continued by the background model)."""
+    rays, img, rgbs = make_rays(seed, n_rays, appearance_count)
+    rng = np.random.default_rng(seed + 7919)
+    rays[:, 7] = rng.uniform(0.3, 1.5, n_rays).astype(np.float32)
+    return rays, img, rgbs
+
+
 def make_gates(seed: int, n_tokens: int, n_experts: int, logit_scale: float = 1.0, quantize_bits: int = 0):
     """Softmax probabilities [P,E] fp32.  quantize_bits>0 rounds logits to a coarse grid to force ties."""
     rng = np.random.default_rng(seed)

@@ -314,3 +314,61 @@ def test_dense_nerf_config0():
 
 def F_mse(a, b):
     return torch.nn.functional.mse_loss(a, b, reduction="mean")
+
+
+def test_background_points_and_bound():
+    """_depth2pts_outside / _intersect_sphere (rendering.py:497-570) on raw tensors."""
+    g = load("bg_points")
+    rays, _, _ = synth.make_bg_rays(84, 40)
+    r = torch.from_numpy(rays)
+    c, rad = torch.from_numpy(synth.SPHERE_CENTER), torch.from_numpy(synth.SPHERE_RADIUS)
+    pts, dreal = O.depth2pts_outside(r[:, None, :3], r[:, None, 3:6], torch.from_numpy(g["depth"]), c, rad)
+    np.testing.assert_allclose(pts.numpy(), g["pts"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(dreal.numpy(), g["depth_real"], rtol=1e-6)
+    np.testing.assert_allclose(O.intersect_sphere(r[:, :3], r[:, 3:6], c, rad).numpy(), g["fg_far"], rtol=1e-6)
+    with pytest.raises(Exception, match="bounded by the unit sphere"):
+        O.intersect_sphere(r[:, :3] + 5.0, r[:, 3:6], c, rad)
+
+
+@pytest.mark.parametrize("tag", ["coarse_det", "coarse", "fine"])
+def test_background_render_train(tag):
+    """render_rays with the dense background model and the ellipsoid bound (rendering.py:32-159): blended rgb / depth,
+    loss and every gradient of both models against the reference's own run."""
+    g = load(f"bg_train_{tag}")
+    cfg, cfg_bg = synth.BUILDING, synth.DENSE_BG
+    p = O.params_from_numpy(synth.make_weights(int(g["seed"]), cfg, gate_scale=float(g["gate_scale"])), requires_grad=True)
+    pb = O.params_from_numpy(synth.make_dense_weights(int(g["seed_bg"]), cfg_bg), requires_grad=True)
+    N, S, Fn, chunk = int(g["N"]), int(g["S"]), int(g["F"]), int(g["chunk"])
+    rays, img, rgbs = synth.make_bg_rays(83, N)
+    kw = {}
+    if float(g["perturb"]) > 0:
+        kw = dict(perturb=1.0, perturb_rand=torch.from_numpy(g["perturb_rand"]), perturb_rand_bg=torch.from_numpy(g["perturb_rand_bg"]))
+        if Fn:
+            kw.update(fine_u=torch.from_numpy(g["fine_u"]), fine_u_bg=torch.from_numpy(g["fine_u_bg"]))
+    res = O.render_rays_bg(p, pb, torch.from_numpy(rays), torch.from_numpy(img), cfg, cfg_bg, S, chunk,
+                           torch.from_numpy(synth.SPHERE_CENTER), torch.from_numpy(synth.SPHERE_RADIUS), fine_samples=Fn, **kw)
+    typ = "fine" if Fn else "coarse"
+    assert len(res["with_bg"]) == int(g["n_bg"])
+    np.testing.assert_allclose(res["fg_far"].numpy(), g["fg_far"], rtol=1e-6)
+    np.testing.assert_allclose(res["fg_rgb"].detach().numpy(), g["fg_rgb"], rtol=0, atol=3e-6)
+    # (the background's hierarchical pass is evaluated in one chunk here and in 1024-point chunks by the reference:
+    #  the CPU GEMMs round differently, hence 1e-5 instead of 3e-6 on the blended colour)
+    np.testing.assert_allclose(res[f"rgb_{typ}"].detach().numpy(), g["rgb"], rtol=0, atol=1e-5 if Fn else 3e-6)
+    np.testing.assert_allclose(res[f"depth_{typ}"].detach().numpy(), g["depth"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(res[f"depth_variance_{typ}"].numpy(), g["depth_variance"], rtol=1e-4, atol=1e-7)
+    photo = F_mse(res[f"rgb_{typ}"], torch.from_numpy(rgbs))
+    gl = res["gate_loss_coarse"].mean()
+    if Fn:
+        gl = (res["gate_loss_fine"].mean() + gl) / 2
+    loss = photo + 5e-4 * gl
+    np.testing.assert_allclose(loss.detach().numpy(), g["loss"], rtol=2e-6)
+    loss.backward()
+    for pre, params in (("", p), ("bg__", pb)):
+        for k, t in params.items():
+            ref_sum = g["gsum__" + pre + k]
+            got = t.grad.numpy()
+            scale = max(1e-12, float(ref_sum[1]))
+            assert abs(synth.checksum(got)[0] - ref_sum[0]) <= 5e-4 * scale + 1e-9, pre + k
+            sl = got.reshape(-1)[:: max(1, got.size // 499)][:499]
+            ref = g["gslice__" + pre + k]
+            np.testing.assert_allclose(sl, ref, rtol=2e-3, atol=1e-7 + 2e-4 * np.abs(ref).max(), err_msg=pre + k)
