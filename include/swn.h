@@ -164,6 +164,38 @@ int swn_mip_encode(const float* rays, const float* radii, const float* z, int n_
 int swn_mip_resample(const float* z, const float* weights, const float* u_rand, float padding, int n_rays, int n_edges,
                      int n_fine, float* z_out, void* stream);
 
+/* ---- background model + foreground bound (render_rays' bg_nerf branch, /root/reference/switch_nerf/rendering.py:32-159) ---
+ * swn_fg_bounds: _intersect_sphere (:497-518) per ray against the ellipsoid (center, radius: 3 floats each in HOST memory,
+ *   both NULL = the unit sphere) and the bookkeeping of :34-44:
+ *     fg_far[r]     = max(intersection depth, near)
+ *     has_bg[r]     = far > fg_far          (the rays `rays_with_bg` that continue into the background model)
+ *     last_delta[r] = has_bg ? fg_far : 1e10 (before :216-217 subtracts the ray's last sample depth)
+ *     rays_fg[r]    = the ray with far = min(far, fg_far)
+ *   *n_outside (int32, zeroed by the caller) counts rays whose closest approach lies outside the unit sphere - the
+ *   reference raises "Not all your cameras are bounded by the unit sphere" (:515-517); the host mirror does the same.
+ * swn_bg_sample_pe: the background samples of `n_rays` (already gathered) rays:
+ *   z_in == NULL: n_samples stratified inverse-distance depths in [0,1] (t_steps = linspace(0,1,n_samples) on the device,
+ *     perturb_rand [n_rays, n_samples] in ascending-sample order or NULL, _expand_and_perturb_z_vals :573-584), evaluated in
+ *     the flipped (descending) order of :302-304: z_out[r, j] and PE row r * n_samples + j belong to ascending sample
+ *     n_samples - 1 - j, while depth_real[r, a] stays in ascending order a exactly like the reference's un-flipped tensor;
+ *   z_in != NULL: the caller's depths (hierarchical pass :246), everything in the order of z_in.
+ *   Points: _depth2pts_outside (:521-570, include_xyz_real False): unit-sphere point rotated by Rodrigues' formula + the
+ *   inverse distance -> 4-D, encoded with l_xyz octaves (4 + 8 l_xyz columns, zero-padded to pe_stride elements of `dtype`).
+ * swn_composite_bounded_fwd / _bwd: volumetric compositing (:435-494) with a per-ray last delta (last_delta [n_rays] or
+ *   NULL = 1e10), flip != 0 for descending depths (:436-437), depth_real [n_rays, n_samples] or NULL as the depth map's
+ *   source (:483-484) and bg_lambda [n_rays] or NULL = the transmittance behind the last sample (:456-457); the backward
+ *   takes dL/d bg_lambda [n_rays] or NULL in addition to dL/d rgb.                                                        */
+int swn_fg_bounds(const float* rays, const float* center_host, const float* radius_host, int n_rays, float* rays_fg,
+                  float* fg_far, float* last_delta, int32_t* has_bg, int32_t* n_outside, void* stream);
+int swn_bg_sample_pe(const float* rays, const float* center_host, const float* radius_host, const float* t_steps,
+                     const float* perturb_rand, float perturb, int n_rays, int n_samples, int l_xyz, int dtype,
+                     const float* z_in, float* z_out, float* depth_real, void* pe, int pe_stride, void* stream);
+int swn_composite_bounded_fwd(const float* raw, const float* z, const float* last_delta, int flip, const float* depth_real,
+                              int n_rays, int n_samples, float* rgb, float* depth, float* depth_var, float* weights,
+                              float* bg_lambda, void* stream);
+int swn_composite_bounded_bwd(const float* raw, const float* z, const float* last_delta, int flip, const float* d_rgb,
+                              const float* d_bg_lambda, int n_rays, int n_samples, float* d_raw, void* stream);
+
 /* dst[r] = src[index[r]] for r < n_rows (rows of row_bytes bytes, a multiple of 16), zero rows where index[r] < 0.
  * Builds the send buffer of the expert-parallel token exchange (the reference's all-to-all payload,
  * tutel_moe_layer_nobatch.py:157, 172) from the routing permutation.                                            */

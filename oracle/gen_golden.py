@@ -401,7 +401,7 @@ def gen_bg():
     print("[G8] background model + ellipsoid bound: NeRFMoE foreground + dense 4-D background NeRF (rendering.py:32-159), fwd + grads")
     cfg, cfg_bg = synth.BUILDING, synth.DENSE_BG
     center, radius = torch.from_numpy(synth.SPHERE_CENTER), torch.from_numpy(synth.SPHERE_RADIUS)
-    for tag, perturb, Fn in (("coarse_det", 0.0, 0), ("coarse", 1.0, 0), ("fine", 1.0, 48)):
+    for tag, perturb, Fn in (("coarse_det", 0.0, 0), ("coarse", 1.0, 0), ("fine", 1.0, 64)):
         sd = synth.make_weights(81, cfg, gate_scale=0.02)
         sd_bg = synth.make_dense_weights(82, cfg_bg)
         N, S, chunk = 96, 64, 1024

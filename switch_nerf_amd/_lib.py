@@ -52,6 +52,10 @@ SIGNATURES = {
     "swn_sample_z": [vp, vp, vp, f32, i32, i32, vp, vp],
     "swn_mip_encode": [vp, vp, vp, i32, i32, i32, i32, vp, i32, vp],
     "swn_mip_resample": [vp, vp, vp, f32, i32, i32, i32, vp, vp],
+    "swn_fg_bounds": [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp],
+    "swn_bg_sample_pe": [vp, vp, vp, vp, vp, f32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp],
+    "swn_composite_bounded_fwd": [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp],
+    "swn_composite_bounded_bwd": [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp],
     "swn_gather_rows": [vp, vp, i64, i32, vp, vp],
     "swn_concat_cols": [vp, i32, vp, i32, i64, i32, vp, vp],
     "swn_slice_relu_bwd": [vp, i32, i32, vp, i32, i64, i32, vp, vp],

@@ -3,6 +3,7 @@
 // Adam.  One 64-lane wave per token/ray row, 16-byte accesses, wave shuffles for the reductions.
 #include <stdarg.h>
 #include "common.hpp"
+#include "pe_store.hpp"
 
 namespace swn {
 
@@ -50,22 +51,6 @@ __global__ void probe_kernel(int32_t* out) {
 }
 
 // ------------------------------------------------------------------------------------------------ sample + PE
-template <typename T>
-__device__ __forceinline__ void store_vals(T* dst, const float* v, int n_pad) {
-  if constexpr (sizeof(T) == 2) {
-    for (int c = 0; c < n_pad; c += 8) {
-      uint4 u;
-      u.x = pack_bf16x2(v[c + 0], v[c + 1]);
-      u.y = pack_bf16x2(v[c + 2], v[c + 3]);
-      u.z = pack_bf16x2(v[c + 4], v[c + 5]);
-      u.w = pack_bf16x2(v[c + 6], v[c + 7]);
-      *(uint4*)(dst + c) = u;
-    }
-  } else {
-    for (int c = 0; c < n_pad; c += 4) *(float4*)(dst + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
-  }
-}
-
 __device__ __forceinline__ float z_of(float near, float far, float t) {
   // rendering.py:86  near * (1 - t) + far * t, each torch op rounded separately: fma contraction must stay off
   // (ROCm's __fmul_rn/__fadd_rn are plain operators and do not prevent it).
@@ -139,42 +124,7 @@ __global__ __launch_bounds__(128) void sample_pe_kernel(const float* __restrict_
       }
     }
   }
-  const int used = 3 + 6 * L;
-  const int step = 16 / (int)sizeof(T);
-  // A thread owns a whole row (pe_stride * sizeof(T) bytes, 256 B stride between lanes): stage the block's rows in LDS and
-  // write them out as one contiguous, fully coalesced region (the block's rows are consecutive in memory).
-  constexpr int NT = sizeof(T) == 2 ? 128 : 64;                  // threads per block (see the launcher)
-  constexpr int ROWB = 128 * (int)sizeof(T) + 16;                // LDS row stride: <= 128 columns, +16 B against bank conflicts
-  __shared__ __attribute__((aligned(16))) char stage[NT * ROWB];
-  const bool staged = pe_stride <= 128;                          // (uniform) wider rows fall back to direct stores
-  T* dst = staged ? (T*)(stage + threadIdx.x * ROWB) : pe + p * pe_stride;
-  // columns [used, pe_stride) are zero
-  float tmp[8];
-  if (live) {
-    for (int c0 = 0; c0 < pe_stride; c0 += step) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) tmp[j] = 0.f;
-      for (int j = 0; j < step; ++j) {
-        const int c = c0 + j;
-        float val = 0.f;
-        // v[] is indexed with a runtime index only here; keep it small
-        if (c < used) val = v[c];
-        tmp[j] = val;
-      }
-      store_vals<T>(dst + c0, tmp, step);
-    }
-  }
-  if (staged) {
-    __syncthreads();
-    const int cpr = pe_stride / step;                            // 16-byte chunks per row
-    const long row0 = (long)blockIdx.x * NT;
-    const long rows = min((long)NT, (long)n_rays * S - row0);
-    char* out = (char*)(pe + row0 * pe_stride);
-    for (int c = threadIdx.x; c < rows * cpr; c += NT) {
-      const int row = c / cpr, ch = c - row * cpr;
-      *(uint4*)(out + (long)c * 16) = *(const uint4*)(stage + row * ROWB + ch * 16);
-    }
-  }
+  pe_store_rows<T>(v, 3 + 6 * L, pe, pe_stride, p, live, (long)n_rays * S);
 }
 
 template <typename T, int LMAX>
@@ -726,12 +676,15 @@ template <int SPL>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ raw, const float* __restrict__ z,
                                                             float last_delta, float rgb_pad, int N, int S, float* __restrict__ rgb,
                                                             float* __restrict__ depth, float* __restrict__ dvar,
-                                                            float* __restrict__ weights) {
+                                                            float* __restrict__ weights, const float* __restrict__ last_delta_ray,
+                                                            float zsign, const float* __restrict__ depth_src,
+                                                            float* __restrict__ bg_lambda) {
   const int lane = threadIdx.x & 63;
   const long ray = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (ray >= N) return;
   const float* zr = z + ray * S;
   const float4* rr = (const float4*)(raw + ray * S * 4);
+  if (last_delta_ray) last_delta = last_delta_ray[ray];
   float al[SPL], zz[SPL];
   float4 cs[SPL];
   float prod = 1.f;
@@ -741,7 +694,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
     al[j] = 0.f; zz[j] = 0.f; cs[j] = make_float4(0, 0, 0, 0);
     if (s < S) {
       zz[j] = zr[s];
-      const float dl = (s + 1 < S) ? (zr[s + 1] - zz[j]) : last_delta;
+      const float dl = (s + 1 < S) ? zsign * (zr[s + 1] - zz[j]) : last_delta;     // zsign = -1: descending depths (flip)
       cs[j] = rr[s];
       if (rgb_pad != 0.f) {   // rendering_mip.py:383-384: rgbs * (1 + 2 pad) - pad
         cs[j].x = cs[j].x * (1.f + 2.f * rgb_pad) - rgb_pad;
@@ -761,14 +714,17 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
   }
   float T = __shfl_up(incl, 1, 64);
   if (lane == 0) T = 1.f;
+  if (bg_lambda && lane == 63) bg_lambda[ray] = incl;          // transmittance behind the last sample (rendering.py:456-457)
   float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f;
   float w[SPL];
+  const float* dsrc = depth_src ? depth_src + ray * S : nullptr;
 #pragma unroll
   for (int j = 0; j < SPL; ++j) {
     w[j] = al[j] * T;
     T *= (1.f - al[j] + 1e-8f);
-    ar += w[j] * cs[j].x; ag += w[j] * cs[j].y; ab += w[j] * cs[j].z; ad += w[j] * zz[j];
     const int s = lane * SPL + j;
+    const float dj = (dsrc && s < S) ? dsrc[s] : zz[j];        // depth map over the metric depths (:483-484)
+    ar += w[j] * cs[j].x; ag += w[j] * cs[j].y; ab += w[j] * cs[j].z; ad += w[j] * dj;
     if (weights && s < S) weights[ray * S + s] = w[j];
   }
   ar = wave_sum(ar); ag = wave_sum(ag); ab = wave_sum(ab); ad = wave_sum(ad);
@@ -786,12 +742,14 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
 template <int SPL>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ z,
                                                             float last_delta, float rgb_pad, const float* __restrict__ d_rgb, int N, int S,
-                                                            float* __restrict__ d_raw) {
+                                                            float* __restrict__ d_raw, const float* __restrict__ last_delta_ray,
+                                                            float zsign, const float* __restrict__ d_bg_lambda) {
   const int lane = threadIdx.x & 63;
   const long ray = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (ray >= N) return;
   const float* zr = z + ray * S;
   const float4* rr = (const float4*)(raw + ray * S * 4);
+  if (last_delta_ray) last_delta = last_delta_ray[ray];
   const float g0 = d_rgb[ray * 3], g1 = d_rgb[ray * 3 + 1], g2 = d_rgb[ray * 3 + 2];
   float al[SPL], dl[SPL], cg[SPL];
   float prod = 1.f;
@@ -801,7 +759,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
     al[j] = 0.f; dl[j] = 0.f; cg[j] = 0.f;
     if (s < S) {
       const float zc = zr[s];
-      dl[j] = (s + 1 < S) ? (zr[s + 1] - zc) : last_delta;
+      dl[j] = (s + 1 < S) ? zsign * (zr[s + 1] - zc) : last_delta;
       float4 c = rr[s];
       if (rgb_pad != 0.f) {
         c.x = c.x * (1.f + 2.f * rgb_pad) - rgb_pad;
@@ -837,6 +795,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
     if (lane + o < 64) incl_s += t;
   }
   float suffix = incl_s - usum;  // strictly after this lane
+  // bg_lambda = prod_i (1 - alpha_i + 1e-8): d bg_lambda / d alpha_j = -bg_lambda / (1 - alpha_j + 1e-8), i.e. one more
+  // term "behind the last sample" of the suffix sum
+  if (d_bg_lambda) suffix += d_bg_lambda[ray] * __shfl(incl, 63, 64);
 #pragma unroll
   for (int j = SPL - 1; j >= 0; --j) {
     const int s = lane * SPL + j;
@@ -1242,7 +1203,8 @@ extern "C" int swn_composite_fwd(const float* raw, const float* z, float last_de
                                  float* rgb, float* depth, float* depth_var, float* weights, void* stream) {
   SWN_CHECK(raw && z, "swn_composite_fwd: null pointer");
   COMPOSITE_DISPATCH(composite_fwd_kernel, dim3(cdiv(n_rays, 4)), dim3(256), 0, as_stream(stream), raw, z, last_delta, rgb_padding,
-                     n_rays, n_samples, rgb, depth, depth_var, weights);
+                     n_rays, n_samples, rgb, depth, depth_var, weights, (const float*)nullptr, 1.f, (const float*)nullptr,
+                     (float*)nullptr);
   SWN_LAUNCH_CHECK();
   return 0;
 }
@@ -1251,7 +1213,28 @@ extern "C" int swn_composite_bwd(const float* raw, const float* z, float last_de
                                  int n_rays, int n_samples, float* d_raw, void* stream) {
   SWN_CHECK(raw && z && d_rgb && d_raw, "swn_composite_bwd: null pointer");
   COMPOSITE_DISPATCH(composite_bwd_kernel, dim3(cdiv(n_rays, 4)), dim3(256), 0, as_stream(stream), raw, z, last_delta, rgb_padding,
-                     d_rgb, n_rays, n_samples, d_raw);
+                     d_rgb, n_rays, n_samples, d_raw, (const float*)nullptr, 1.f, (const float*)nullptr);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int swn_composite_bounded_fwd(const float* raw, const float* z, const float* last_delta, int flip, const float* depth_real,
+                                         int n_rays, int n_samples, float* rgb, float* depth, float* depth_var, float* weights,
+                                         float* bg_lambda, void* stream) {
+  SWN_CHECK(raw && z, "swn_composite_bounded_fwd: null pointer");
+  if (n_rays <= 0) return 0;
+  COMPOSITE_DISPATCH(composite_fwd_kernel, dim3(cdiv(n_rays, 4)), dim3(256), 0, as_stream(stream), raw, z, 1e10f, 0.f, n_rays,
+                     n_samples, rgb, depth, depth_var, weights, last_delta, flip ? -1.f : 1.f, depth_real, bg_lambda);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int swn_composite_bounded_bwd(const float* raw, const float* z, const float* last_delta, int flip, const float* d_rgb,
+                                         const float* d_bg_lambda, int n_rays, int n_samples, float* d_raw, void* stream) {
+  SWN_CHECK(raw && z && d_rgb && d_raw, "swn_composite_bounded_bwd: null pointer");
+  if (n_rays <= 0) return 0;
+  COMPOSITE_DISPATCH(composite_bwd_kernel, dim3(cdiv(n_rays, 4)), dim3(256), 0, as_stream(stream), raw, z, 1e10f, 0.f, d_rgb,
+                     n_rays, n_samples, d_raw, last_delta, flip ? -1.f : 1.f, d_bg_lambda);
   SWN_LAUNCH_CHECK();
   return 0;
 }

@@ -204,10 +204,9 @@ class DenseNeRF(SwitchNeRF):
         o.mlp_chain(dh2, [o.Layer(self.wb["l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dy, tag=5)
         nsp = max(1, min(256, P // 4096))
         # d(pre-activation of the last trunk layer) = (dy + dsigma * w_sigma) * (xyz_ > 0): the combine backward with a unit gate
-        ones = self._buf("ones", (P,), torch.float32)
-        if not getattr(self, "_ones_set", False):
-            ones.fill_(1.0)
-            self._ones_set = True
+        if getattr(self, "_ones", None) is None or self._ones.numel() < P:
+            self._ones = torch.ones(P, dtype=torch.float32, device=self.dev)
+        ones = self._ones[:P]
         dz = [_b(f"dz{i}", (P, W), dt) for i in range(L - 1)]
         dz.append(o.combine_bwd(dy, c["y"], dsig, self.p["sigma.w"], ones)[0])
         o.wgrad(c["h1"], dh2, g["l2h.w"].view(1, W, H2), None, n_splits=nsp)

@@ -246,7 +246,16 @@ class SwitchNeRF:
         return t[r * El:(r + 1) * El]
 
     # ------------------------------------------------------------------------------------------ buffers
+    _grow_bufs = False      # True: one buffer per name, grown to the largest row count seen (row counts that vary per step)
+
     def _buf(self, name, shape, dtype):
+        if self._grow_bufs:
+            key = (name, tuple(shape[1:]), dtype)
+            b = self._bufs.get(key)
+            if b is None or b.shape[0] < shape[0]:
+                b = torch.empty(shape, dtype=dtype, device=self.dev)
+                self._bufs[key] = b
+            return b[: shape[0]]
         key = (name, tuple(shape), dtype)
         b = self._bufs.get(key)
         if b is None:

@@ -265,6 +265,69 @@ def composite_bwd(raw, z, d_rgb, last_delta=1e10, rgb_padding=0.0):
     return d_raw
 
 
+def _host3(v):
+    """3 floats in host memory (sphere centre / radii) as a ctypes array; None stays None."""
+    if v is None:
+        return None
+    arr = v.detach().cpu().numpy() if torch.is_tensor(v) else v
+    vals = [float(x) for x in arr]
+    assert len(vals) == 3
+    return (C.c_float * 3)(*vals)
+
+
+def fg_bounds(rays, center, radius):
+    """render_rays' foreground bound (rendering.py:32-44, 497-518) -> rays with the clipped far plane, fg_far [N],
+    last_delta [N] (fg_far for rays that continue into the background, 1e10 otherwise), has_bg [N] int32.
+    Raises like the reference when a ray's closest approach to the centre is outside the bound."""
+    N = rays.shape[0]
+    dev = rays.device
+    rays_fg = torch.empty_like(rays)
+    fg_far = torch.empty(N, dtype=torch.float32, device=dev)
+    last_delta = torch.empty(N, dtype=torch.float32, device=dev)
+    has_bg = torch.empty(N, dtype=torch.int32, device=dev)
+    n_out = torch.zeros(1, dtype=torch.int32, device=dev)
+    call("swn_fg_bounds", _p(rays), _host3(center), _host3(radius), N, _p(rays_fg), _p(fg_far), _p(last_delta), _p(has_bg), _p(n_out),
+         _stream())
+    return rays_fg, fg_far, last_delta, has_bg, n_out
+
+
+def bg_sample_pe(rays, center, radius, n_samples, l_xyz, dtype, pe_stride, perturb_rand=None, perturb=0.0, z_in=None, pe_out=None):
+    """Background samples of the (gathered) rays: see swn_bg_sample_pe in include/swn.h.  -> z [N,S], depth_real [N,S], pe."""
+    N = rays.shape[0]
+    dev = rays.device
+    S = n_samples if z_in is None else z_in.shape[1]
+    z = torch.empty(N, S, dtype=torch.float32, device=dev) if z_in is None else z_in
+    dreal = torch.empty(N, S, dtype=torch.float32, device=dev)
+    pe = pe_out if pe_out is not None else torch.empty(N * S, pe_stride, dtype=dtype, device=dev)
+    t_steps = torch.linspace(0, 1, S, dtype=torch.float32).to(dev) if z_in is None else None
+    call("swn_bg_sample_pe", _p(rays), _host3(center), _host3(radius), _p(t_steps), _p(perturb_rand), float(perturb), N, S, int(l_xyz),
+         BF16 if dtype == torch.bfloat16 else F32, _p(z_in), _p(z) if z_in is None else None, _p(dreal), _p(pe), int(pe_stride), _stream())
+    return z, dreal, pe
+
+
+def composite_bounded_fwd(raw, z, last_delta=None, flip=False, depth_real=None, want_weights=False, want_bg_lambda=False):
+    """Compositing with a per-ray last delta / descending depths / metric depth source / leftover transmittance
+    (rendering.py:435-494 with last_delta, flip, depth_real, get_bg_lambda) -> rgb, depth, depth_variance, weights, bg_lambda."""
+    N, S = z.shape
+    dev = z.device
+    rgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
+    depth = torch.empty(N, dtype=torch.float32, device=dev)
+    dvar = torch.empty(N, dtype=torch.float32, device=dev)
+    w = torch.empty(N, S, dtype=torch.float32, device=dev) if want_weights else None
+    lam = torch.empty(N, dtype=torch.float32, device=dev) if want_bg_lambda else None
+    call("swn_composite_bounded_fwd", _p(raw), _p(z), _p(last_delta), int(bool(flip)), _p(depth_real), N, S, _p(rgb), _p(depth),
+         _p(dvar), _p(w), _p(lam), _stream())
+    return rgb, depth, dvar, w, lam
+
+
+def composite_bounded_bwd(raw, z, d_rgb, last_delta=None, flip=False, d_bg_lambda=None):
+    N, S = z.shape
+    d_raw = torch.empty(N * S, 4, dtype=torch.float32, device=z.device)
+    call("swn_composite_bounded_bwd", _p(raw), _p(z), _p(last_delta), int(bool(flip)), _p(d_rgb), _p(d_bg_lambda), N, S, _p(d_raw),
+         _stream())
+    return d_raw
+
+
 def pack_weights(master, dtype, transpose: bool):
     """master [n_wsets, in, out] fp32 -> packed compute copy for mlp_chain, tagged with its logical (n, k)."""
     assert master.dim() == 3 and master.dtype == torch.float32

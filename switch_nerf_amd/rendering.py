@@ -1,6 +1,7 @@
-"""Mirror of the reference's rendering.render_rays (/root/reference/switch_nerf/rendering.py:15-196) for the hot-path
-configuration: no background NeRF, no cascade, SwitchNeRF model; fine_samples = 0 (coarse pass composited) or
-fine_samples > 0 (hierarchical: coarse weights -> importance samples -> fine pass -> merged compositing).
+"""Mirror of the reference's rendering.render_rays (/root/reference/switch_nerf/rendering.py:15-196): SwitchNeRF (or
+DenseNeRF) model, optional dense background model behind the foreground bound (background.py), no cascade;
+fine_samples = 0 (coarse pass composited) or fine_samples > 0 (hierarchical: coarse weights -> importance samples -> fine
+pass -> merged compositing).
 
     results, bg_nerf_rays_present = render_rays(nerf, None, rays, image_indices, hparams, None, None,
                                                 get_depth, get_depth_variance, get_bg_fg_rgb)
@@ -20,13 +21,14 @@ import torch
 def render_rays(nerf, bg_nerf, rays: torch.Tensor, image_indices: Optional[torch.Tensor], hparams, sphere_center=None,
                 sphere_radius=None, get_depth: bool = True, get_depth_variance: bool = True,
                 get_bg_fg_rgb: bool = False) -> Tuple[Dict[str, torch.Tensor], bool]:
-    if bg_nerf is not None:
-        raise NotImplementedError("background NeRF is outside the hot path (SURVEY.md section 8(f) row 4)")
     if getattr(hparams, "use_cascade", False):
         raise NotImplementedError("use_cascade is outside the hot path")
     F = int(getattr(hparams, "fine_samples", 0))
     N = rays.shape[0]
     S = hparams.coarse_samples
+    if bg_nerf is not None:
+        return _render_rays_bg(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sphere_radius, get_depth,
+                               get_depth_variance, get_bg_fg_rgb)
     P = N * S
     chunk = min(hparams.model_chunk_size, P)
     if P % chunk:
@@ -70,6 +72,46 @@ def render_rays(nerf, bg_nerf, rays: torch.Tensor, image_indices: Optional[torch
     if getattr(hparams, "return_sigma", False):
         res["sigma_coarse"] = c["raw"][:, 3].view(N, S)
     return res, False
+
+
+def _render_rays_bg(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sphere_radius, get_depth, get_depth_variance,
+                    get_bg_fg_rgb):
+    """The bg_nerf branch (rendering.py:32-159) through background.BackgroundScene."""
+    from .background import BackgroundScene
+    N, S, F = rays.shape[0], hparams.coarse_samples, int(getattr(hparams, "fine_samples", 0))
+    perturb = hparams.perturb if nerf.training else 0
+    use_noise = getattr(hparams, "use_sigma_noise", False) and hparams.sigma_noise_std > 0 and nerf.training
+    std = hparams.sigma_noise_std if use_noise else 0.0
+    if image_indices is None:
+        image_indices = torch.zeros(N, dtype=torch.long, device=rays.device)
+    scene = getattr(nerf, "_bg_scene", None)
+    if scene is None or scene.bg is not bg_nerf:
+        scene = nerf._bg_scene = BackgroundScene(nerf, bg_nerf, sphere_center, sphere_radius)
+    scene.center, scene.radius = sphere_center, sphere_radius
+    kw = {}
+    if use_noise:        # rendering.py:366: randn per evaluated chunk, for either model
+        kw = dict(sigma_noise=torch.randn(N * S, device=rays.device) * std, sigma_noise_bg="randn", sigma_noise_bg_fine="randn",
+                  sigma_noise_fine=torch.randn(N * F, device=rays.device) * std if F else None)
+    ctx = scene.forward(rays.contiguous(), image_indices, S, min(hparams.model_chunk_size, N * S), float(perturb), fine_samples=F,
+                        no_batch=nerf.moe_no_batch, noise_std=std, **kw)
+    typ = "fine" if F > 0 else "coarse"
+    res = {f"rgb_{typ}": ctx["rgb"], "gate_loss_coarse": ctx["c"]["l_aux"]}
+    if F > 0:
+        res["gate_loss_fine"] = ctx["cf"]["l_aux"]
+    if get_depth:
+        res[f"depth_{typ}"] = ctx["depth"]
+    if get_depth_variance:
+        res[f"depth_variance_{typ}"] = ctx["depth_variance"]
+    if get_bg_fg_rgb:                                                    # :111-112, :124-125
+        res[f"fg_rgb_{typ}"] = ctx["fg_rgb"]
+        res[f"bg_rgb_{typ}"] = ctx["rgb"] - ctx["fg_rgb"]
+        res[f"fg_depth_{typ}"] = ctx["fg_depth"]
+        res[f"bg_depth_{typ}"] = ctx["depth"] - ctx["fg_depth"]
+    if getattr(hparams, "moe_return_gates", False):
+        res["moe_gates_coarse"] = ctx["c"]["idx"].long().view(N, S, 1, 1)
+        if F > 0:
+            res["moe_gates_fine"] = ctx["cf"]["idx"].long().view(N, F, 1, 1)
+    return res, ctx["Nb"] > 0
 
 
 def render_rays_mip(nerf, rays: torch.Tensor, radii: torch.Tensor, image_indices: Optional[torch.Tensor], hparams,
