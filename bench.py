@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--mip", action="store_true", help="mip recipe: --samples edges per level (frustums = edges - 1), two levels")
     ap.add_argument("--model-dim", type=int, default=256, help="layer width (512 = mission_bay.yaml, other recipes)")
     ap.add_argument("--experts", type=int, default=8)
+    ap.add_argument("--bg", action="store_true", help="with the dense background model behind an ellipsoidal foreground bound "
+                    "(the Mega-NeRF scenes' default recipe, rendering.py:32-159), other recipes")
     ap.add_argument("--dense", action="store_true", help="BASELINE configs[0]: the dense NeRF (--no-use_moe), other recipes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
@@ -102,7 +104,7 @@ def main():
     from switch_nerf_amd.model import SwitchNeRF, BUILDING
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     cfg = dict(BUILDING, model_dim=a.model_dim, gate_hidden=a.model_dim, num_experts=a.experts)
-    other = a.fine or a.mip or a.model_dim != 256 or a.experts != 8 or a.dense
+    other = a.fine or a.mip or a.model_dim != 256 or a.experts != 8 or a.dense or a.bg
     if a.dense:
         from switch_nerf_amd.dense import DenseNeRF
         model = DenseNeRF(dtype=dtype, device=dev, seed=0)
@@ -120,6 +122,13 @@ def main():
         model.set_expert_parallel(ExpertParallel(rank, world, model.E))
 
     radii = torch.full((a.rays, 1), 1e-3, device=dev)
+    scene = None
+    if a.bg:
+        from switch_nerf_amd.background import BackgroundScene
+        from switch_nerf_amd.dense import DenseNeRF, DENSE
+        bg = DenseNeRF(dict(DENSE, xyz_dim=4), dtype=dtype, device=dev, seed=1)
+        scene = BackgroundScene(model, bg, [0.02, -0.03, 0.01], [0.6, 0.8, 0.7])
+        rays[:, 7] = torch.rand(a.rays, device=dev) * 1.2 + 0.3          # about half of the rays leave the bound
 
     def step():
         pr = torch.rand(a.rays, a.samples, device=dev)              # rendering.py:582 rand_like
@@ -130,6 +139,11 @@ def main():
                                         sigma_noise=torch.randn(nf, device=dev), sigma_noise_fine=torch.randn(nf, device=dev),
                                         grad_allreduce=ar)
         noise = torch.randn(P, device=dev)                          # rendering.py:366, sigma_noise_std = 1
+        if scene is not None:
+            return scene.train_step(rgbs, rays, idx, a.samples, a.chunk, perturb=1.0, perturb_rand=pr, sigma_noise=noise,
+                                    sigma_noise_bg="randn", sigma_noise_bg_fine="randn", noise_std=1.0, grad_allreduce=ar,
+                                    fine_samples=a.fine,
+                                    sigma_noise_fine=torch.randn(a.rays * a.fine, device=dev) if a.fine else None)
         kw = {}
         if a.fine > 0:
             kw = dict(fine_samples=a.fine, sigma_noise_fine=torch.randn(a.rays * a.fine, device=dev))
@@ -158,7 +172,7 @@ def main():
     value = a.rays * world * a.steps / dt
 
     # ---- per-kernel accounting from the live HIP events
-    c = st["ctx"]
+    c = st["ctx"]["c"] if a.bg else st["ctx"]
     kept = P if a.dense else int(torch.minimum(c["counts"], torch.tensor(c["cap"], device=dev)).sum().item())
     L, M, E = model.L, model.M, model.E
     esz = 2 if dtype == torch.bfloat16 else 4
@@ -212,6 +226,7 @@ def main():
                                f" per GPU, {P // a.chunk} segments of {a.chunk} points, building.yaml shapes, random-init weights,"
                                f" gate_scale={a.gate_scale}" + (f", + {a.fine} fine samples (hierarchical)" if a.fine else "")
                                + (", mip recipe (two levels)" if a.mip else "")
+                               + (f", + dense background model on {st['ctx']['Nb']} of {a.rays} rays x {a.samples // 2} samples" if a.bg else "")
                                + (f", model_dim {a.model_dim}, {a.experts} experts" if (a.model_dim != 256 or a.experts != 8) else ""),
                    "rays_per_gpu": a.rays, "samples": a.samples, "segment_points": a.chunk, "parallelism": f"{a.parallelism}{world}",
                    "kept_token_fraction": round(kept / P, 4), "loss": round(float(st["loss"].item()), 6)},
