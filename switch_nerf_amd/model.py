@@ -295,10 +295,34 @@ class SwitchNeRF:
         return pe_dir
 
     def _net_forward(self, pe, pe_dir, image_indices, N, S, seg_tokens, sigma_noise, routing_override, no_batch, tag):
-        """NeRFMoE.forward over the N*S points whose encodings are in `pe` (row-major, ray-major): front chain, gate,
-        routing, expert chain, tail chain, heads -> c["raw"] [N*S, 4]."""
+        """NeRFMoE.forward over the N*S points whose encodings are in `pe`, evaluated in model chunks of seg_tokens points like
+        the reference's loop (rendering.py:354-383): routing, capacity and l_aux are per chunk.  A ragged last chunk
+        (N*S not a multiple of seg_tokens - evaluation batches) is routed on its own with its own capacity, exactly as the
+        reference does; that case is inference-only here (no backward through a ragged context)."""
+        P = N * S
+        seg_tokens = min(seg_tokens, P)
+        if P % seg_tokens == 0:
+            return self._net_forward_rows(pe, pe_dir, image_indices, N, S, seg_tokens, sigma_noise, routing_override, no_batch, tag, None)
+        main = (P // seg_tokens) * seg_tokens
+        a = self._net_forward_rows(pe, pe_dir, image_indices, N, S, seg_tokens, sigma_noise, routing_override, no_batch, tag, (0, main))
+        b = self._net_forward_rows(pe, pe_dir, image_indices, N, S, P - main, sigma_noise, routing_override, no_batch, tag + "t", (main, P))
+        c = dict(N=N, S=S, P=P, n_seg=a["n_seg"] + 1, seg_tokens=seg_tokens, tag=tag, image_indices=image_indices, ragged=True,
+                 parts=(a, b), pe=pe, pe_dir=pe_dir)
+        for k in ("raw", "l_aux", "idx", "gmax"):
+            c[k] = torch.cat([a[k], b[k]], 0)
+        return c
+
+    def _net_forward_rows(self, pe, pe_dir, image_indices, N, S, seg_tokens, sigma_noise, routing_override, no_batch, tag, row_range):
+        """One or more whole model chunks: front chain, gate, routing, expert chain, tail chain, heads -> c["raw"] [P, 4].
+        row_range = None: all N*S points; (r0, r1): that row range of the ray-major point grid (ragged evaluation)."""
         o, dt, dev = ops, self.dtype, self.dev
         P = N * S
+        if row_range is not None:
+            r0, r1 = row_range
+            P = r1 - r0
+            pe = pe[r0:r1]
+            sigma_noise = None if sigma_noise is None else sigma_noise[r0:r1]
+            routing_override = None if routing_override is None else routing_override[r0:r1]
         M, E, L, G, H2 = self.M, self.E, self.L, self.G, self.H2
         assert P % seg_tokens == 0, "points must be a multiple of the segment (model chunk) size"
         n_seg = P // seg_tokens
@@ -368,8 +392,12 @@ class SwitchNeRF:
         c["y"] = _b("y", (P, M), dt)
         c["h1"] = _b("h1", (P, M), dt)
         c["h2"] = _b("h2", (P, H2), dt)
+        rowbias, rpb = c["c_ray"], S
+        if row_range is not None:  # a row range of the point grid: the rows' rays through an explicit per-row gather
+            rowbias, rpb = c["c_ray"].index_select(0, torch.arange(r0, r1, device=dev) // S), 1
+            c["ragged"] = True
         o.mlp_chain(c["eo"], [o.Layer(self.wf["l1"], self.p["l1.b"].view(1, M), save=c["h1"]),
-                              o.Layer(self.wf["l2h"], None, relu=1, rowbias=c["c_ray"], rows_per_bias=S)], c["h2"],
+                              o.Layer(self.wf["l2h"], None, relu=1, rowbias=rowbias, rows_per_bias=rpb)], c["h2"],
                     group_stride=P, x_gather=c["row_of_tok"], x_save=c["y"], x_scale=c["gmax"], x_relu=True, tag=4)
         # ---- heads
         c["raw"] = o.heads_fwd(c["y"], c["h2"], self.p["sigma.w"], self.p["sigma.b"], self.p["color.w"], self.p["color.b"],
@@ -385,6 +413,9 @@ class SwitchNeRF:
     def backward_net(self, c, d_raw, d_laux):
         """Backward of _net_forward given dL/d raw [N*S, 4] and dL/d l_aux[seg]; accumulates into self.grad."""
         o, dt = ops, self.dtype
+        if c.get("ragged"):
+            raise NotImplementedError("backward through a ragged last model chunk: training batches must be a multiple of "
+                                      "model_chunk_size points (evaluation handles any size)")
         N, S, P, n_seg, cap, seg_tokens = c["N"], c["S"], c["P"], c["n_seg"], c["cap"], c["seg_tokens"]
         M, E, L, G, H2 = self.M, self.E, self.L, self.G, self.H2
         g = self.g

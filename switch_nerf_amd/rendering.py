@@ -31,8 +31,8 @@ def render_rays(nerf, bg_nerf, rays: torch.Tensor, image_indices: Optional[torch
                                get_depth_variance, get_bg_fg_rgb)
     P = N * S
     chunk = min(hparams.model_chunk_size, P)
-    if P % chunk:
-        raise ValueError(f"N_rays * samples ({P}) must be a multiple of model_chunk_size ({chunk})")
+    if P % chunk and nerf.training:     # evaluation handles a ragged last chunk like the reference's loop (rendering.py:354-383)
+        raise ValueError(f"training: N_rays * samples ({P}) must be a multiple of model_chunk_size ({chunk})")
     perturb = hparams.perturb if nerf.training else 0
     pr = torch.rand(N, S, device=rays.device) if perturb > 0 else None
     noise = None
@@ -44,7 +44,7 @@ def render_rays(nerf, bg_nerf, rays: torch.Tensor, image_indices: Optional[torch
         noise_f = None
         if noise is not None:
             noise_f = torch.randn(N * F, device=rays.device) * hparams.sigma_noise_std
-        if (N * F) % min(chunk, N * F):
+        if (N * F) % min(chunk, N * F) and nerf.training:
             raise ValueError(f"N_rays * fine_samples ({N * F}) must be a multiple of model_chunk_size ({chunk})")
         c, cf, out = nerf.forward_hier(rays.contiguous(), image_indices, S, F, chunk, float(perturb), pr, None, noise, noise_f,
                                        no_batch=nerf.moe_no_batch)

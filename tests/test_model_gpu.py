@@ -386,3 +386,35 @@ def test_mission_bay_widths_vs_oracle(dtype):
         ref = p[k].grad.numpy()
         err = np.abs(t.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
         assert err <= (2e-3 if ref.size > 4 else 1e-2), (k, err)
+
+
+def test_ragged_last_chunk_inference_vs_oracle_fp32():
+    """Evaluation batches whose point count is not a multiple of model_chunk_size: the last chunk is routed on its own with
+    its own capacity, like the reference's `range(0, B, model_chunk_size)` loop (rendering.py:354-383).  50 rays x 64
+    samples = 3 chunks of 1024 + 128 points; both the capacity (token-dropping) mode and the no-batch mode."""
+    from switch_nerf_amd import rendering
+    from argparse import Namespace
+    N, S, chunk = 50, 64, 1024
+    sd = synth.make_weights(131, synth.BUILDING, gate_scale=0.02)
+    rays, img, _ = synth.make_rays(132, N)
+    m = _model(torch.float32, 131, 0.02)
+    m.eval()
+    p = O.params_from_numpy(sd)
+    with torch.no_grad():
+        ref = O.render_rays(p, torch.from_numpy(rays), torch.from_numpy(img), synth.BUILDING, S, chunk)
+    h = Namespace(coarse_samples=S, fine_samples=0, model_chunk_size=chunk, perturb=1.0, use_sigma_noise=True, sigma_noise_std=1.0,
+                  use_cascade=False, moe_return_gates=True, return_sigma=True)
+    res, _ = rendering.render_rays(m, None, _dev(rays), _dev(img), h, None, None, True, True, False)
+    idx_ref = np.concatenate([r["idx"] for r in ref["routings"]])
+    np.testing.assert_array_equal(res["moe_gates_coarse"].cpu().numpy().reshape(-1), idx_ref)
+    np.testing.assert_allclose(res["rgb_coarse"].cpu().numpy(), ref["rgb_coarse"].numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(res["sigma_coarse"].cpu().numpy(), ref["sigma_coarse"].numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(res["gate_loss_coarse"].cpu().numpy(), ref["gate_loss_coarse"].numpy(), rtol=1e-5)
+    assert res["gate_loss_coarse"].numel() == 4
+    # training through a ragged context is refused loudly
+    m.train()
+    with pytest.raises(ValueError, match="multiple of model_chunk_size"):
+        rendering.render_rays(m, None, _dev(rays), _dev(img), h, None, None, True, True, False)
+    c = m.forward_rays(_dev(rays), _dev(img), S, chunk)
+    with pytest.raises(NotImplementedError, match="ragged"):
+        m.backward(c, torch.zeros(N, 3, device="cuda"), torch.zeros(4, device="cuda"))
