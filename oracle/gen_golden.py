@@ -202,13 +202,13 @@ def gen_model_forward_nobatch():
 
 
 # ------------------------------------------------------------------------------------------ G5 render + train step
-def gen_render():
+def gen_render(variants=(("unbalanced", 1.0, 1.0, True), ("balanced", 0.02, 1.0, True))):
     print("[G5] render_rays / training step (64 rays x 64 samples, chunk 1024 -> 4 chunks), fwd + grads")
     cfg = synth.BUILDING
-    for tag, gate_scale in (("unbalanced", 1.0), ("balanced", 0.02)):
+    for tag, gate_scale, cf, bpr in variants:
         sd = synth.make_weights(51, cfg, gate_scale=gate_scale)
         N, S, chunk = 64, 64, 1024
-        nerf, h = build_reference_model(cfg, sd, coarse=S, chunk=chunk, perturb=0.0, sigma_noise=False)
+        nerf, h = build_reference_model(cfg, sd, coarse=S, chunk=chunk, perturb=0.0, sigma_noise=False, capacity_factor=cf, bpr=bpr)
         rays, img, rgbs = synth.make_rays(52, N)
         nerf.train()
         t0 = time.time()
@@ -219,7 +219,7 @@ def gen_render():
         loss = photo + 5e-4 * gate_loss
         loss.backward()
         print(f"    reference fwd+bwd {time.time()-t0:.2f}s")
-        out = dict(seed=51, gate_scale=gate_scale, N=N, S=S, chunk=chunk, rgb=res["rgb_coarse"].detach().numpy(),
+        out = dict(seed=51, gate_scale=gate_scale, capacity_factor=cf, bpr=int(bpr), N=N, S=S, chunk=chunk, rgb=res["rgb_coarse"].detach().numpy(),
                    depth=res["depth_coarse"].numpy(), depth_variance=res["depth_variance_coarse"].numpy(),
                    sigma=res["sigma_coarse"].detach().numpy(), gate_loss=res["gate_loss_coarse"].detach().numpy(),
                    moe_gates=res["moe_gates_coarse"].numpy().astype(np.int32).reshape(N, S),
@@ -229,6 +229,12 @@ def gen_render():
             out["gsum__" + n] = synth.checksum(g_.numpy())
             out["gslice__" + n] = g_.numpy().reshape(-1)[:: max(1, g_.numel() // 499)][:499]
         save(f"render_train_{tag}", **out)
+
+
+def gen_render_capacity():
+    """Other capacity factors / ranking modes (BASELINE configs[4]: capacity_factor 1.25 with token dropping; no BPR =
+    position-order ranking, tutel_fast_dispatch.py:177-191)."""
+    gen_render((("cf125_nobpr", 1.0, 1.25, False), ("cf125_bpr", 1.0, 1.25, True), ("cf050_bpr", 0.02, 0.5, True)))
 
 
 def gen_render_fine():
@@ -466,7 +472,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     todo = dict(routing=gen_routing, pe=gen_pe, moe=gen_moe_layer, model=gen_model_forward, nobatch=gen_model_forward_nobatch,
-                render=gen_render, fine=gen_render_fine, mip=gen_mip, ckpt=gen_checkpoint_layout, dense=gen_dense, composite=gen_composite, bg=gen_bg)
+                render=gen_render, capacity=gen_render_capacity, fine=gen_render_fine, mip=gen_mip, ckpt=gen_checkpoint_layout, dense=gen_dense, composite=gen_composite, bg=gen_bg)
     for k, fn in todo.items():
         if a.only and k not in a.only.split(","):
             continue

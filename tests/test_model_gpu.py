@@ -24,11 +24,14 @@ def _dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("tag", ["unbalanced", "balanced"])
+@pytest.mark.parametrize("tag", ["unbalanced", "balanced", "cf125_nobpr", "cf125_bpr", "cf050_bpr"])
 def test_train_step_vs_reference_golden_fp32(tag):
     g = np.load(os.path.join(G, f"render_train_{tag}.npz"))
     N, S, chunk = int(g["N"]), int(g["S"]), int(g["chunk"])
-    m = _model(torch.float32, int(g["seed"]), float(g["gate_scale"]))
+    kw = {}
+    if "capacity_factor" in g:       # other capacity factors (token dropping at 1.25 / 0.5) and position-order ranking
+        kw = dict(capacity_factor=float(g["capacity_factor"]), batch_prioritized=bool(int(g["bpr"])))
+    m = _model(torch.float32, int(g["seed"]), float(g["gate_scale"]), **kw)
     rays, img, rgbs = synth.make_rays(52, N)
     st = m.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0, optimizer_step=False)
     c = st["ctx"]

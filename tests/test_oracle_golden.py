@@ -133,14 +133,17 @@ def test_model_forward(tag):
     print(f"{tag}: kept fraction {kept:.3f}, counts {r['routing']['counts']}")
 
 
-@pytest.mark.parametrize("tag", ["unbalanced", "balanced"])
+@pytest.mark.parametrize("tag", ["unbalanced", "balanced", "cf125_nobpr", "cf125_bpr", "cf050_bpr"])
 def test_render_and_training_step(tag):
     g = load(f"render_train_{tag}")
     cfg = synth.BUILDING
     p = O.params_from_numpy(synth.make_weights(int(g["seed"]), cfg, gate_scale=float(g["gate_scale"])), requires_grad=True)
     N, S, chunk = int(g["N"]), int(g["S"]), int(g["chunk"])
     rays, img, rgbs = synth.make_rays(52, N)
-    st = O.training_step(p, torch.from_numpy(rays), torch.from_numpy(img), torch.from_numpy(rgbs), cfg, S, chunk)
+    kw = {}
+    if "capacity_factor" in g:
+        kw = dict(capacity_factor=float(g["capacity_factor"]), batch_prioritized=bool(int(g["bpr"])))
+    st = O.training_step(p, torch.from_numpy(rays), torch.from_numpy(img), torch.from_numpy(rgbs), cfg, S, chunk, **kw)
     res = st["results"]
     got_idx = np.concatenate([r["idx"] for r in res["routings"]]).reshape(N, S)
     assert np.array_equal(got_idx, g["moe_gates"])
