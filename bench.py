@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--experts", type=int, default=8)
     ap.add_argument("--bg", action="store_true", help="with the dense background model behind an ellipsoidal foreground bound "
                     "(the Mega-NeRF scenes' default recipe, rendering.py:32-159), other recipes")
+    ap.add_argument("--hash", action="store_true", help="BASELINE configs[4] input: multiresolution hash-grid encoding (16 levels, "
+                    "2^19 entries x 2 features) instead of the frequency encoding, other recipes")
+    ap.add_argument("--capacity-factor", type=float, default=1.0)
     ap.add_argument("--dense", action="store_true", help="BASELINE configs[0]: the dense NeRF (--no-use_moe), other recipes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
@@ -104,12 +107,14 @@ def main():
     from switch_nerf_amd.model import SwitchNeRF, BUILDING
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     cfg = dict(BUILDING, model_dim=a.model_dim, gate_hidden=a.model_dim, num_experts=a.experts)
-    other = a.fine or a.mip or a.model_dim != 256 or a.experts != 8 or a.dense or a.bg
+    if a.hash:
+        cfg["hash"] = dict(n_levels=16, log2_table=19, base_res=16, per_level_scale=1.3819, aabb_lo=(-1.2, -1.2, -1.2), aabb_hi=(1.2, 1.2, 1.2))
+    other = a.fine or a.mip or a.model_dim != 256 or a.experts != 8 or a.dense or a.bg or a.hash or a.capacity_factor != 1.0
     if a.dense:
         from switch_nerf_amd.dense import DenseNeRF
         model = DenseNeRF(dtype=dtype, device=dev, seed=0)
     else:
-        model = SwitchNeRF(cfg, dtype=dtype, device=dev, seed=0)
+        model = SwitchNeRF(cfg, dtype=dtype, device=dev, seed=0, capacity_factor=a.capacity_factor)
     if a.gate_scale != 1.0 and not a.dense:
         model.p["wg"].mul_(a.gate_scale)
     rays, idx, rgbs = synth_batch(a.rays, 1000 + rank, dev)
@@ -226,6 +231,8 @@ def main():
                                f" per GPU, {P // a.chunk} segments of {a.chunk} points, building.yaml shapes, random-init weights,"
                                f" gate_scale={a.gate_scale}" + (f", + {a.fine} fine samples (hierarchical)" if a.fine else "")
                                + (", mip recipe (two levels)" if a.mip else "")
+                               + (", hash-grid input encoding (16 levels x 2^19 x 2)" if a.hash else "")
+                               + (f", capacity_factor {a.capacity_factor}" if a.capacity_factor != 1.0 else "")
                                + (f", + dense background model on {st['ctx']['Nb']} of {a.rays} rays x {a.samples // 2} samples" if a.bg else "")
                                + (f", model_dim {a.model_dim}, {a.experts} experts" if (a.model_dim != 256 or a.experts != 8) else ""),
                    "rays_per_gpu": a.rays, "samples": a.samples, "segment_points": a.chunk, "parallelism": f"{a.parallelism}{world}",

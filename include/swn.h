@@ -164,6 +164,30 @@ int swn_mip_encode(const float* rays, const float* radii, const float* z, int n_
 int swn_mip_resample(const float* z, const float* weights, const float* u_rand, float padding, int n_rays, int n_edges,
                      int n_fine, float* z_out, void* stream);
 
+/* ---- multiresolution hash-grid input encoding (BASELINE.json configs[4]; NOT in the reference: own definition) ----------
+ * Algorithm: Mueller et al., "Instant Neural Graphics Primitives with a Multiresolution Hash Encoding" (2022), section 3.
+ * Conventions of this library (restated on the CPU in oracle/switchnerf_oracle.py hash_encode):
+ *   x' = clamp((x - aabb_lo) / (aabb_hi - aabb_lo), 0, 1) with x = o + d * z;
+ *   level l < n_levels: scale_l = base_res * per_level_scale^l - 1 (evaluated in double, rounded to float),
+ *     R_l = ceil(scale_l) + 2 grid points per axis; pos = x' * scale_l + 0.5; cell = floor(pos); w = pos - cell;
+ *     corner c = cell + {0,1}^3 -> entry = cx + R_l * (cy + R_l * cz)                      if R_l^3 <= T = 2^log2_table
+ *                                  entry = (cx ^ cy * 2654435761 ^ cz * 805459861) mod T   otherwise (uint32 arithmetic);
+ *   feature pair l = sum over the 8 corners of the trilinear weight * table[l][entry][0..1].
+ * table: fp32 [n_levels, T, 2].  out: [n_rays * n_samples, out_stride] of `dtype`, columns [0, 2 n_levels) = the features,
+ * the rest zero (out_stride <= 128, a multiple of 16 bytes).  The backward adds dL/d table (fp32 atomics) given
+ * d_out [n_rays * n_samples, d_stride]; positions carry no gradient (the rays are data).                              */
+typedef struct {
+  int n_levels;          /* <= 16 */
+  int log2_table;        /* T = 2^log2_table entries of 2 features per level */
+  int base_res;
+  float per_level_scale;
+  float aabb_lo[3], aabb_hi[3];
+} swn_hash_cfg;
+int swn_hash_encode_fwd(const float* rays, const float* z, int n_rays, int n_samples, const swn_hash_cfg* cfg,
+                        const float* table, int dtype, void* out, int out_stride, void* stream);
+int swn_hash_encode_bwd(const float* rays, const float* z, int n_rays, int n_samples, const swn_hash_cfg* cfg,
+                        const void* d_out, int dtype, int d_stride, float* d_table, void* stream);
+
 /* ---- background model + foreground bound (render_rays' bg_nerf branch, /root/reference/switch_nerf/rendering.py:32-159) ---
  * swn_fg_bounds: _intersect_sphere (:497-518) per ray against the ellipsoid (center, radius: 3 floats each in HOST memory,
  *   both NULL = the unit sphere) and the bookkeeping of :34-44:

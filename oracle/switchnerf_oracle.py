@@ -270,18 +270,21 @@ def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_fine: int, u: Option
     return bin_b + (u - cdf_b) / denom * (bin_a - bin_b)
 
 
-def _eval_points(p, rays, image_indices, z, cfg, chunk, capacity_factor, batch_prioritized, sigma_noise, routings):
-    """The chunked network evaluation of _inference (rendering.py:311-383): routing (capacity, ranking, l_aux) is per chunk."""
+def _eval_points(p, rays, image_indices, z, cfg, chunk, capacity_factor, batch_prioritized, sigma_noise, routings, hash_cfg=None):
+    """The chunked network evaluation of _inference (rendering.py:311-383): routing (capacity, ranking, l_aux) is per chunk.
+    hash_cfg: the positions enter through the hash-grid encoding (p["embedding_xyz.table"]) instead of the frequency one."""
     N, S = z.shape
     o, d = rays[:, 0:3], rays[:, 3:6]
     xyz = o[:, None, :] + d[:, None, :] * z[:, :, None]                                      # :90 / xyz_fine_fn :103
     pts = torch.cat([xyz.reshape(-1, 3), d[:, None, :].expand(N, S, 3).reshape(-1, 3),
                      image_indices.view(N, 1, 1).expand(N, S, 1).reshape(-1, 1).to(xyz.dtype)], 1)  # :311-360
+    enc = hash_encode(pts[:, :3], p["embedding_xyz.table"], hash_cfg) if hash_cfg is not None else None
     outs, losses, routes = [], [], []
     for ci, i in enumerate(range(0, pts.shape[0], chunk)):
         sn = None if sigma_noise is None else sigma_noise[i:i + chunk]
         r = nerf_moe_forward(p, pts[i:i + chunk], cfg, capacity_factor, batch_prioritized, sn,
-                             None if routings is None else routings[ci])
+                             None if routings is None else routings[ci],
+                             encoded=None if enc is None else (enc[i:i + chunk], pts[i:i + chunk, 3:6], pts[i:i + chunk, 6]))
         outs.append(r["outputs"])
         losses.append(r["moe_loss"])
         routes.append(r["routing"])
@@ -292,7 +295,7 @@ def render_rays(p, rays: torch.Tensor, image_indices: torch.Tensor, cfg: dict, n
                 capacity_factor: float = 1.0, batch_prioritized: bool = True, perturb: float = 0.0,
                 perturb_rand: Optional[torch.Tensor] = None, sigma_noise: Optional[torch.Tensor] = None,
                 routings: Optional[list] = None, fine_samples: int = 0, fine_u: Optional[torch.Tensor] = None,
-                sigma_noise_fine: Optional[torch.Tensor] = None):
+                sigma_noise_fine: Optional[torch.Tensor] = None, hash_cfg: Optional[dict] = None):
     """render_rays + _get_results + _inference, rendering.py:15-196, :199-274, :277-494 (no background model, no cascade).
     Points are evaluated in chunks of `chunk` (= model_chunk_size) and the routing (capacity, ranking, l_aux) is per
     chunk, exactly as the reference's loop :354-383.
@@ -302,7 +305,7 @@ def render_rays(p, rays: torch.Tensor, image_indices: torch.Tensor, cfg: dict, n
     near, far = rays[:, 6:7], rays[:, 7:8]
     z = sample_z(near, far, n_samples, perturb, perturb_rand)
     out, gl, routes = _eval_points(p, rays, image_indices, z, cfg, chunk, capacity_factor, batch_prioritized, sigma_noise,
-                                   routings)
+                                   routings, hash_cfg)
     comp = composite(out[..., :3], out[..., 3], z)
     res = dict(rgb_coarse=comp["rgb"], depth_variance_coarse=comp["depth_variance"], depth_coarse=comp["depth"],
                weights_coarse=comp["weights"], gate_loss_coarse=gl, sigma_coarse=out[..., 3], raw=out, z_vals=z,
@@ -311,7 +314,7 @@ def render_rays(p, rays: torch.Tensor, image_indices: torch.Tensor, cfg: dict, n
         z_mid = 0.5 * (z[:, :-1] + z[:, 1:])                                                 # :238
         z_fine = sample_pdf(z_mid, comp["weights"][:, 1:-1].detach(), fine_samples, fine_u)  # :240
         out_f, gl_f, routes_f = _eval_points(p, rays, image_indices, z_fine, cfg, min(chunk, z_fine.numel()), capacity_factor,
-                                             batch_prioritized, sigma_noise_fine, None)
+                                             batch_prioritized, sigma_noise_fine, None, hash_cfg)
         z_all, order = torch.sort(torch.cat([z_fine, z], -1), dim=-1, stable=True)              # :421
         raw_all = torch.gather(torch.cat([out_f, out], 1), 1, order[:, :, None].expand(-1, -1, 4))   # :422-430
         comp_f = composite(raw_all[..., :3], raw_all[..., 3], z_all)
@@ -499,6 +502,48 @@ def render_rays_bg(p, p_bg, rays, image_indices, cfg, cfg_bg, n_samples: int, ch
         depth = depth + addd
     res[f"rgb_{typ}"], res[f"depth_{typ}"], res[f"depth_variance_{typ}"] = rgb, depth, comp["depth_variance"]
     return res
+
+
+# --------------------------------------------------------------------------------------------
+# multiresolution hash-grid encoding (BASELINE configs[4]).  NOT in the reference - PARITY UNPINNED: this restates the
+# conventions of include/swn.h (swn_hash_encode_fwd) for Mueller et al. 2022, section 3; it pins the HIP kernels to this file,
+# nothing pins this file to the reference.
+# --------------------------------------------------------------------------------------------
+HASH = dict(n_levels=16, log2_table=19, base_res=16, per_level_scale=1.3819, aabb_lo=(-1.0, -1.0, -1.0), aabb_hi=(1.0, 1.0, 1.0))
+
+
+def hash_levels(hc: dict):
+    """[(scale fp32, grid points per axis, dense?)] per level."""
+    T = 1 << hc["log2_table"]
+    out = []
+    for l in range(hc["n_levels"]):
+        s = np.float32(float(hc["base_res"]) * float(np.float32(hc["per_level_scale"])) ** l - 1.0)
+        r = int(np.ceil(float(s))) + 2
+        out.append((s, r, r ** 3 <= T))
+    return out
+
+
+def hash_encode(x: torch.Tensor, table: torch.Tensor, hc: dict) -> torch.Tensor:
+    """x [P,3] world positions, table [L, T, 2] -> [P, 2 L] (trilinear interpolation of hashed / dense grid entries)."""
+    lo = torch.tensor(hc["aabb_lo"], dtype=torch.float32)
+    inv = (1.0 / (torch.tensor(hc["aabb_hi"], dtype=torch.float32) - lo)).to(torch.float32)
+    xn = ((x - lo) * inv).clamp(0.0, 1.0)
+    T = 1 << hc["log2_table"]
+    feats = []
+    for l, (s, r, dense) in enumerate(hash_levels(hc)):
+        pos = xn * float(s) + 0.5
+        cell = torch.floor(pos)
+        w = pos - cell
+        c0 = cell.long()
+        f = torch.zeros(x.shape[0], 2, dtype=torch.float32)
+        for k in range(8):
+            dx, dy, dz = k & 1, (k >> 1) & 1, k >> 2
+            wk = ((w[:, 0] if dx else 1.0 - w[:, 0]) * (w[:, 1] if dy else 1.0 - w[:, 1])) * (w[:, 2] if dz else 1.0 - w[:, 2])
+            cx, cy, cz = c0[:, 0] + dx, c0[:, 1] + dy, c0[:, 2] + dz
+            idx = (cx + r * (cy + r * cz)) if dense else ((cx ^ (cy * 2654435761) ^ (cz * 805459861)) & (T - 1))
+            f = f + wk[:, None] * table[l][idx]
+        feats.append(f)
+    return torch.cat(feats, -1)
 
 
 # --------------------------------------------------------------------------------------------

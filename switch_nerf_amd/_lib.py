@@ -21,6 +21,11 @@ class WgradItem(C.Structure):
     _fields_ = [("a", vp), ("b", vp), ("a_gather", vp), ("b_gather", vp), ("dw", vp), ("db", vp)]
 
 
+class HashCfg(C.Structure):
+    _fields_ = [("n_levels", i32), ("log2_table", i32), ("base_res", i32), ("per_level_scale", f32), ("aabb_lo", f32 * 3),
+                ("aabb_hi", f32 * 3)]
+
+
 class ChainDesc(C.Structure):
     _fields_ = [("dtype", i32), ("n_layers", i32), ("n_groups", i32), ("n_wsets", i32), ("group_stride", i32),
                 ("group_rows", vp), ("group_rows_clamp", i32), ("x", vp), ("x_gather", vp), ("x_save", vp), ("x_scale", vp), ("x_relu", i32),
@@ -56,6 +61,8 @@ SIGNATURES = {
     "swn_bg_sample_pe": [vp, vp, vp, vp, vp, f32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp],
     "swn_composite_bounded_fwd": [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp],
     "swn_composite_bounded_bwd": [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp],
+    "swn_hash_encode_fwd": [vp, vp, i32, i32, C.POINTER(HashCfg), vp, i32, vp, i32, vp],
+    "swn_hash_encode_bwd": [vp, vp, i32, i32, C.POINTER(HashCfg), vp, i32, i32, vp, vp],
     "swn_gather_rows": [vp, vp, i64, i32, vp, vp],
     "swn_concat_cols": [vp, i32, vp, i32, i64, i32, vp, vp],
     "swn_slice_relu_bwd": [vp, i32, i32, vp, i32, i64, i32, vp, vp],

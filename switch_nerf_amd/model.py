@@ -74,7 +74,8 @@ class SwitchNeRF:
         assert tuple(cfg["skips"]) == (3,) or len(cfg["skips"]) <= 1, "one skip connection supported"
         M, E, L, G, H2 = cfg["model_dim"], cfg["num_experts"], cfg["expert_layers"], cfg["gate_hidden"], cfg["layer2_out"]
         assert G == M, "external gate width must equal model_dim (building.yaml)"
-        self.in_xyz = 3 + 6 * cfg["pos_xyz_dim"]
+        self.hash = cfg.get("hash")                  # multiresolution hash-grid input encoding (ops.hash_encode_fwd) or None
+        self.in_xyz = 3 + 6 * cfg["pos_xyz_dim"] if self.hash is None else 2 * self.hash["n_levels"]
         self.in_dir = 3 + 6 * cfg["pos_dir_dim"]
         self.KP = _ceil_to(self.in_xyz, 64)          # padded PE width (chain K granularity)
         self.DP = _ceil_to(self.in_dir, 8)
@@ -89,6 +90,9 @@ class SwitchNeRF:
         self.L, self.M, self.E, self.G, self.H2 = L, M, E, G, H2
         self._chain_weights = ["xyz", "gate0", "gate1", "l1", "l2h"] + [f"exp{l}" for l in range(L)]
         self._fwd_only_weights = {"xyz"}              # first layer: no input gradient, no transposed copy
+        if self.hash is not None:                     # trainable encoding: the first layer's input gradient feeds the table
+            spec.append(("hash.table", (self.hash["n_levels"], 1 << self.hash["log2_table"], 2)))
+            self._fwd_only_weights = set()
         return spec
 
     @contextlib.contextmanager
@@ -131,6 +135,8 @@ class SwitchNeRF:
         sd["layers.moe_external_gate.fcs.1.weight"], sd["layers.moe_external_gate.fcs.1.bias"] = lin(G, G)
         sd["layers.gate_input_norm.weight"], sd["layers.gate_input_norm.bias"] = torch.ones(G), torch.zeros(G)
         sd["embedding_a.weight"] = torch.randn(cfg["appearance_count"], cfg["appearance_dim"], generator=g)
+        if self.hash is not None:         # instant-NGP initialisation: U(-1e-4, 1e-4)
+            sd["embedding_xyz.table"] = (torch.rand(self.spec["hash.table"][1], generator=g) * 2 - 1) * 1e-4
         self.load_state_dict(sd)
 
     def load_state_dict(self, sd):
@@ -170,6 +176,8 @@ class SwitchNeRF:
             p["color.w"].copy_(t("layers.color.fcs.0.weight"))
             p["color.b"].copy_(t("layers.color.fcs.0.bias"))
             p["emb"].copy_(t("embedding_a.weight"))
+            if self.hash is not None:
+                p["hash.table"].copy_(t("embedding_xyz.table"))
         self.refresh_compute_copies()
 
     def _to_ref_layout(self, d):
@@ -196,6 +204,8 @@ class SwitchNeRF:
         out["layers.color.fcs.0.weight"] = d["color.w"].clone()
         out["layers.color.fcs.0.bias"] = d["color.b"].clone()
         out["embedding_a.weight"] = d["emb"].clone()
+        if self.hash is not None:
+            out["embedding_xyz.table"] = d["hash.table"].clone()
         return out
 
     def state_dict(self, layout="expertmlp", prefix=""):
@@ -272,7 +282,13 @@ class SwitchNeRF:
         Returns a context dict holding every tensor the backward needs and the rendered results."""
         o, dt, dev = ops, self.dtype, self.dev
         N, S = rays.shape[0], n_samples
-        if z_in is None:
+        if self.hash is not None:         # hash-grid encoding of the sample positions (BASELINE configs[4])
+            z = z_in if z_in is not None else o.sample_z(rays, torch.linspace(0, 1, S, dtype=torch.float32).to(dev), perturb_rand,
+                                                         perturb, S)
+            pe = o.hash_encode_fwd(rays, z, self.p["hash.table"], self.hash, dt, self.KP)
+            if pe_dir is None:
+                pe_dir = self._dir_pe(rays)
+        elif z_in is None:
             t_steps = torch.linspace(0, 1, S, dtype=torch.float32).to(dev)    # computed on the host like the reference's CPU path
             z, pe, pe_dir = o.sample_pe(rays, t_steps, perturb_rand, perturb, S, self.cfg["pos_xyz_dim"],
                                         self.cfg["pos_dir_dim"], dt, self.KP, self.DP)
@@ -282,7 +298,7 @@ class SwitchNeRF:
             if pe_dir is None:
                 pe_dir = self._dir_pe(rays)
         c = self._net_forward(pe, pe_dir, image_indices, N, S, seg_tokens, sigma_noise, routing_override, no_batch, tag)
-        c["z"] = z
+        c["z"], c["rays"] = z, rays
         if composite:
             c["rgb"], c["depth"], c["depth_variance"], c["weights"] = o.composite_fwd(c["raw"], c["z"], want_weights=want_weights)
         return c
@@ -290,7 +306,8 @@ class SwitchNeRF:
     def _dir_pe(self, rays):
         """PE of the ray directions only (per ray)."""
         N = rays.shape[0]
-        _, _, pe_dir = ops.sample_pe(rays, torch.zeros(1, device=self.dev), None, 0.0, 1, self.cfg["pos_xyz_dim"],
+        l_xyz = 0 if self.hash is not None else self.cfg["pos_xyz_dim"]      # (the position encoding of this call is discarded)
+        _, _, pe_dir = ops.sample_pe(rays, torch.zeros(1, device=self.dev), None, 0.0, 1, l_xyz,
                                      self.cfg["pos_dir_dim"], self.dtype, self.KP, self.DP)
         return pe_dir
 
@@ -504,6 +521,10 @@ class SwitchNeRF:
         o.wgrad(c["a1"], dg, g["gate1.w"].view(1, G, G), g["gate1.b"].view(1, G), n_splits=nsp)
         o.wgrad(c["h0"], dza1, g["gate0.w"].view(1, M, G), g["gate0.b"].view(1, G), n_splits=nsp)
         o.wgrad(c["pe"], dh0, g["xyz.w"].view(1, self.KP, M), g["xyz.b"].view(1, M), n_splits=nsp)
+        if self.hash is not None:          # dL/d encoding = dh0 W_xyz^T, scattered into the hash table's gradient
+            d_enc = _b("d_enc", (P, self.KP), dt)
+            o.mlp_chain(dh0, [o.Layer(self.wb["xyz"], None)], d_enc, tag=0)
+            o.hash_encode_bwd(c["rays"], c["z"], d_enc, self.hash, g["hash.table"])
         if side_done is not None:
             torch.cuda.current_stream().wait_event(side_done)
 

@@ -232,6 +232,30 @@ def sample_z(rays, t_steps, perturb_rand, perturb: float, n_samples: int):
     return z
 
 
+def _hash_cfg(hc: dict):
+    c = _lib.HashCfg()
+    c.n_levels, c.log2_table, c.base_res = int(hc["n_levels"]), int(hc["log2_table"]), int(hc["base_res"])
+    c.per_level_scale = float(hc["per_level_scale"])
+    for i in range(3):
+        c.aabb_lo[i], c.aabb_hi[i] = float(hc["aabb_lo"][i]), float(hc["aabb_hi"][i])
+    return c
+
+
+def hash_encode_fwd(rays, z, table, hc: dict, dtype, out_stride: int):
+    """Multiresolution hash-grid encoding of the points o + d z (include/swn.h swn_hash_encode_fwd) -> [N * S, out_stride]."""
+    n, S = z.shape
+    out = torch.empty(n * S, out_stride, dtype=dtype, device=rays.device)
+    call("swn_hash_encode_fwd", _p(rays), _p(z), n, S, C.byref(_hash_cfg(hc)), _p(table), BF16 if dtype == torch.bfloat16 else F32,
+         _p(out), int(out_stride), _stream())
+    return out
+
+
+def hash_encode_bwd(rays, z, d_out, hc: dict, d_table):
+    """d_table [L, T, 2] fp32 += the table gradient for dL/d encoding d_out [N * S, stride]."""
+    n, S = z.shape
+    call("swn_hash_encode_bwd", _p(rays), _p(z), n, S, C.byref(_hash_cfg(hc)), _p(d_out), _dt(d_out), d_out.shape[1], _p(d_table), _stream())
+
+
 def mip_encode(rays, radii, z, l_xyz: int, dtype, pe_stride: int):
     """-> integrated positional encoding of the n_edges - 1 frustums per ray: [N * (S - 1), pe_stride] dtype"""
     n, S = z.shape

@@ -375,3 +375,27 @@ def test_background_render_train(tag):
             sl = got.reshape(-1)[:: max(1, got.size // 499)][:499]
             ref = g["gslice__" + pre + k]
             np.testing.assert_allclose(sl, ref, rtol=2e-3, atol=1e-7 + 2e-4 * np.abs(ref).max(), err_msg=pre + k)
+
+
+def test_hash_encode_restatement_properties():
+    """Hash-grid encoding (no reference counterpart, "parity unpinned"): properties of the restatement itself - trilinear
+    weights sum to one, grid points reproduce their table entry, the encoding is continuous across cell faces, dense levels
+    index without collisions."""
+    hc = dict(n_levels=6, log2_table=10, base_res=2, per_level_scale=2.0, aabb_lo=(0.0, 0.0, 0.0), aabb_hi=(1.0, 1.0, 1.0))
+    T = 1 << hc["log2_table"]
+    x = torch.from_numpy(np.random.default_rng(5).uniform(0, 1, (500, 3)).astype(np.float32))
+    ones = torch.ones(hc["n_levels"], T, 2)
+    np.testing.assert_allclose(O.hash_encode(x, ones, hc).numpy(), 1.0, atol=1e-6)
+    table = torch.from_numpy(np.random.default_rng(6).standard_normal((hc["n_levels"], T, 2)).astype(np.float32))
+    lv = O.hash_levels(hc)
+    assert [d for _, _, d in lv] == [True, True, True, False, False, False]     # 3^3, 4^3, 6^3 <= 1024 < 10^3
+    s, r, _ = lv[1]                                                             # level 1: scale 3, 5 grid points... r = 5
+    assert (float(s), r) == (3.0, 5)
+    # a grid point of level 1: pos = x * 3 + 0.5 integral -> weight 1 on one corner
+    g = torch.tensor([[(2 - 0.5) / 3.0, (1 - 0.5) / 3.0, (3 - 0.5) / 3.0]], dtype=torch.float32)
+    got = O.hash_encode(g, table, hc)[0, 2:4]
+    np.testing.assert_allclose(got.numpy(), table[1][2 + 5 * (1 + 5 * 3)].numpy(), atol=2e-6)
+    # continuity across a cell face
+    a = O.hash_encode(torch.tensor([[0.5 - 1e-6, 0.3, 0.7]]), table, hc)
+    b = O.hash_encode(torch.tensor([[0.5 + 1e-6, 0.3, 0.7]]), table, hc)
+    assert (a - b).abs().max().item() < 1e-3
