@@ -115,6 +115,8 @@ def main():
         model = DenseNeRF(dtype=dtype, device=dev, seed=0)
     else:
         model = SwitchNeRF(cfg, dtype=dtype, device=dev, seed=0, capacity_factor=a.capacity_factor)
+    if a.hash:      # emulate a trained encoding (features O(1)): the standard U(-1e-4, 1e-4) initialisation gives every point the
+        model.p["hash.table"].mul_(1e4)      # same first-layer output and the random-init router sends everything to one expert
     if a.gate_scale != 1.0 and not a.dense:
         model.p["wg"].mul_(a.gate_scale)
     rays, idx, rgbs = synth_batch(a.rays, 1000 + rank, dev)
@@ -231,7 +233,7 @@ def main():
                                f" per GPU, {P // a.chunk} segments of {a.chunk} points, building.yaml shapes, random-init weights,"
                                f" gate_scale={a.gate_scale}" + (f", + {a.fine} fine samples (hierarchical)" if a.fine else "")
                                + (", mip recipe (two levels)" if a.mip else "")
-                               + (", hash-grid input encoding (16 levels x 2^19 x 2)" if a.hash else "")
+                               + (", hash-grid input encoding (16 levels x 2^19 x 2, table scaled to U(-1,1))" if a.hash else "")
                                + (f", capacity_factor {a.capacity_factor}" if a.capacity_factor != 1.0 else "")
                                + (f", + dense background model on {st['ctx']['Nb']} of {a.rays} rays x {a.samples // 2} samples" if a.bg else "")
                                + (f", model_dim {a.model_dim}, {a.experts} experts" if (a.model_dim != 256 or a.experts != 8) else ""),
