@@ -256,6 +256,7 @@ class SwitchNeRF:
         return t[r * El:(r + 1) * El]
 
     # ------------------------------------------------------------------------------------------ buffers
+    hash = None             # multiresolution hash-grid input encoding (cfg["hash"]) or None
     _grow_bufs = False      # True: one buffer per name, grown to the largest row count seen (row counts that vary per step)
 
     def _buf(self, name, shape, dtype):
