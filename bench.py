@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--hash", action="store_true", help="BASELINE configs[4] input: multiresolution hash-grid encoding (16 levels, "
                     "2^19 entries x 2 features) instead of the frequency encoding, other recipes")
     ap.add_argument("--capacity-factor", type=float, default=1.0)
+    ap.add_argument("--eval", action="store_true", help="inference only (render path: forward without activation saves, no "
+                    "perturbation / noise / backward / Adam), other recipes")
     ap.add_argument("--dense", action="store_true", help="BASELINE configs[0]: the dense NeRF (--no-use_moe), other recipes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
@@ -109,7 +111,7 @@ def main():
     cfg = dict(BUILDING, model_dim=a.model_dim, gate_hidden=a.model_dim, num_experts=a.experts)
     if a.hash:
         cfg["hash"] = dict(n_levels=16, log2_table=19, base_res=16, per_level_scale=1.3819, aabb_lo=(-1.2, -1.2, -1.2), aabb_hi=(1.2, 1.2, 1.2))
-    other = a.fine or a.mip or a.model_dim != 256 or a.experts != 8 or a.dense or a.bg or a.hash or a.capacity_factor != 1.0
+    other = a.fine or a.mip or a.model_dim != 256 or a.experts != 8 or a.dense or a.bg or a.hash or a.capacity_factor != 1.0 or a.eval
     if a.dense:
         from switch_nerf_amd.dense import DenseNeRF
         model = DenseNeRF(dtype=dtype, device=dev, seed=0)
@@ -138,6 +140,10 @@ def main():
         rays[:, 7] = torch.rand(a.rays, device=dev) * 1.2 + 0.3          # about half of the rays leave the bound
 
     def step():
+        if a.eval:       # render_rays in eval mode (runner.py:2835-2885 render_image's inner call): forward only
+            with torch.no_grad():
+                c = model.forward_rays(rays, idx, a.samples, a.chunk, 0.0, None, None, training=False)
+            return dict(ctx=c, loss=c["rgb"].sum() * 0)
         pr = torch.rand(a.rays, a.samples, device=dev)              # rendering.py:582 rand_like
         ar = allreduce if world > 1 else None
         if a.mip:      # rendering_mip recipe: a.samples edges -> a.samples - 1 frustums per level, coarse + fine level
@@ -233,6 +239,7 @@ def main():
                                f" per GPU, {P // a.chunk} segments of {a.chunk} points, building.yaml shapes, random-init weights,"
                                f" gate_scale={a.gate_scale}" + (f", + {a.fine} fine samples (hierarchical)" if a.fine else "")
                                + (", mip recipe (two levels)" if a.mip else "")
+                               + (", INFERENCE ONLY (forward without saves; no backward / Adam)" if a.eval else "")
                                + (", hash-grid input encoding (16 levels x 2^19 x 2, table scaled to U(-1,1))" if a.hash else "")
                                + (f", capacity_factor {a.capacity_factor}" if a.capacity_factor != 1.0 else "")
                                + (f", + dense background model on {st['ctx']['Nb']} of {a.rays} rays x {a.samples // 2} samples" if a.bg else "")

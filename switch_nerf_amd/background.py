@@ -36,7 +36,7 @@ class BackgroundScene:
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, rays, image_indices, n_samples, seg_tokens, perturb=0.0, perturb_rand=None, perturb_rand_bg=None,
                 sigma_noise=None, sigma_noise_bg=None, fine_samples=0, fine_u=None, fine_u_bg=None, sigma_noise_fine=None,
-                sigma_noise_bg_fine=None, no_batch=False, noise_std=0.0):
+                sigma_noise_bg_fine=None, no_batch=False, noise_std=0.0, training=True):
         """sigma_noise_bg / sigma_noise_bg_fine: [Nb * samples] tensors, or the string "randn" to draw noise_std * N(0,1)
         here (the number of background rays is only known inside)."""
         o, nerf, bg = ops, self.nerf, self.bg
@@ -49,6 +49,7 @@ class BackgroundScene:
         ctx = dict(N=N, S=S, F=Fn, idx_bg=idx_bg, Nb=Nb, fg_far=fg_far, has_bg=has_bg)
         det_u = lambda n, k: torch.linspace(0, 1, k).expand(n, k).contiguous().to(self.dev) if perturb == 0 else torch.rand(n, k, device=self.dev)
         # ---- background first (the reference's order, and so the order of its random draws)
+        bg._saving = bool(training)          # (DenseNeRF._net_forward is called directly below; reset after the block)
         if Nb > 0:
             Sb = S // 2
             rays_b = rays.index_select(0, idx_bg).contiguous()
@@ -83,7 +84,8 @@ class BackgroundScene:
             b.update(rgb=rgb_b, depth=depth_b)
             ctx["bg"] = b
         # ---- foreground on the clipped rays
-        c = nerf.forward_rays(rays_fg, image_indices, S, seg_tokens, perturb, perturb_rand, sigma_noise, True, None,
+        bg._saving = True
+        c = nerf.forward_rays(rays_fg, image_indices, S, seg_tokens, perturb, perturb_rand, sigma_noise, training, None,
                               no_batch=no_batch, want_weights=Fn > 0, composite=Fn > 0)
         ctx["c"] = c
         if Fn == 0:
@@ -92,7 +94,7 @@ class BackgroundScene:
             if fine_u is None:
                 fine_u = det_u(N, Fn)
             z_fine = o.sample_pdf(c["z"], c["weights"], fine_u, Fn)
-            cf = nerf.forward_rays(rays_fg, image_indices, Fn, min(seg_tokens, N * Fn), 0.0, None, sigma_noise_fine, True, None,
+            cf = nerf.forward_rays(rays_fg, image_indices, Fn, min(seg_tokens, N * Fn), 0.0, None, sigma_noise_fine, training, None,
                                    no_batch=no_batch, z_in=z_fine, pe_dir=c["pe_dir"], tag="f", composite=False)
             z, order, raw = o.merge_samples(z_fine, c["z"], cf["raw"], c["raw"])
             z_last = z_fine.max(dim=-1)[0]                               # the FINE depths' maximum (:249-250)

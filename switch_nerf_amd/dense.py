@@ -163,9 +163,12 @@ class DenseNeRF(SwitchNeRF):
         mwB = o.chain_mask_words(dt, 1, P, self.KC)
         c["masks"] = [_b(f"mask{i}", (mwA if i < nA else mwB,), torch.int32) for i in range(L)]
 
+        sv = self._saving
+        c["no_grad"] = not sv
+
         def layer(i, last):
-            return o.Layer(self.wf[f"enc{i}"], self.p[f"enc{i}.b"].view(1, W), relu=1, mask=c["masks"][i],
-                           save=None if last else c["acts"][i])
+            return o.Layer(self.wf[f"enc{i}"], self.p[f"enc{i}.b"].view(1, W), relu=1, mask=c["masks"][i] if sv else None,
+                           save=c["acts"][i] if (sv and not last) else None)
         with self._timed("trunk_fwd"):
             o.mlp_chain(pe, [layer(i, i == nA - 1) for i in range(nA)], c["acts"][nA - 1], tag=1)
             if s is not None:
@@ -178,7 +181,7 @@ class DenseNeRF(SwitchNeRF):
         c["c_ray"] = torch.addmm(self.p["l2.b"], feat, self.p["l2r.w"]).contiguous()
         c["h1"] = _b("h1", (P, W), dt)
         c["h2"] = _b("h2", (P, H2), dt)
-        o.mlp_chain(c["y"], [o.Layer(self.wf["l1"], self.p["l1.b"].view(1, W), save=c["h1"]),
+        o.mlp_chain(c["y"], [o.Layer(self.wf["l1"], self.p["l1.b"].view(1, W), save=c["h1"] if sv else None),
                              o.Layer(self.wf["l2h"], None, relu=1, rowbias=c["c_ray"], rows_per_bias=S)], c["h2"], tag=4)
         c["raw"] = o.heads_fwd(c["y"], c["h2"], self.p["sigma.w"], self.p["sigma.b"], self.p["color.w"], self.p["color.b"],
                                sigma_noise)
@@ -189,6 +192,8 @@ class DenseNeRF(SwitchNeRF):
     # ------------------------------------------------------------------------------------------ backward
     def backward_net(self, c, d_raw, d_laux=None):
         o, dt = ops, self.dtype
+        if c.get("no_grad"):
+            raise RuntimeError("this context comes from an inference forward (training=False): nothing was saved for the backward")
         S, P = c["S"], c["P"]
         W, L, H2, s = self.M, self.L, self.H2, self.skip_l
         g, acts, masks = self.g, c["acts"], c["masks"]

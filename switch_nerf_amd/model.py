@@ -256,6 +256,7 @@ class SwitchNeRF:
         return t[r * El:(r + 1) * El]
 
     # ------------------------------------------------------------------------------------------ buffers
+    _saving = True          # False inside an inference forward: the chains skip the activation saves and ReLU masks
     hash = None             # multiresolution hash-grid input encoding (cfg["hash"]) or None
     _grow_bufs = False      # True: one buffer per name, grown to the largest row count seen (row counts that vary per step)
 
@@ -298,7 +299,11 @@ class SwitchNeRF:
             pe = o.pe_from_z(rays, z_in, self.cfg["pos_xyz_dim"], dt, self.KP)      # xyz_fine_fn, rendering.py:103
             if pe_dir is None:
                 pe_dir = self._dir_pe(rays)
-        c = self._net_forward(pe, pe_dir, image_indices, N, S, seg_tokens, sigma_noise, routing_override, no_batch, tag)
+        self._saving = bool(training)      # inference: no activation saves / ReLU masks (nothing will run backward)
+        try:
+            c = self._net_forward(pe, pe_dir, image_indices, N, S, seg_tokens, sigma_noise, routing_override, no_batch, tag)
+        finally:
+            self._saving = True
         c["z"], c["rays"] = z, rays
         if composite:
             c["rgb"], c["depth"], c["depth_variance"], c["weights"] = o.composite_fwd(c["raw"], c["z"], want_weights=want_weights)
@@ -355,8 +360,11 @@ class SwitchNeRF:
         c["a1"] = _b("a1", (P, G), dt)
         c["g"] = _b("g", (P, G), dt)
         c["m_a1"] = _b("m_a1", (o.chain_mask_words(dt, 1, P, max(M, G, self.KP)),), torch.int32)
+        sv = self._saving
+        c["no_grad"] = not sv
         o.mlp_chain(c["pe"], [o.Layer(self.wf["xyz"], self.p["xyz.b"].view(1, M), save=c["h0"]),
-                              o.Layer(self.wf["gate0"], self.p["gate0.b"].view(1, G), relu=1, mask=c["m_a1"], save=c["a1"]),
+                              o.Layer(self.wf["gate0"], self.p["gate0.b"].view(1, G), relu=1, mask=c["m_a1"] if sv else None,
+                                      save=c["a1"] if sv else None),
                               o.Layer(self.wf["gate1"], self.p["gate1.b"].view(1, G))], c["g"], tag=3)
         # ---- gate + routing
         c["gates"], c["idx"], c["gmax"], c["stats"] = o.gate_fwd(c["g"], self.p["ln.w"], self.p["ln.b"], self.p["wg"])
@@ -376,8 +384,8 @@ class SwitchNeRF:
         c["masks"] = [_b(f"mask{l}", (nw,), torch.int32) for l in range(L - 1)]
         skips = set(self.cfg["skips"])
         layers = [o.Layer(self._local_experts(self.wf[f"exp{l}"]), self._local_experts(self.p[f"exp{l}.b"]),
-                          relu=1 if l < L - 1 else 0, skip=(l in skips), save=c["saves"][l] if l < L - 1 else None,
-                          mask=c["masks"][l] if l < L - 1 else None) for l in range(L)]
+                          relu=1 if l < L - 1 else 0, skip=(l in skips), save=c["saves"][l] if (sv and l < L - 1) else None,
+                          mask=c["masks"][l] if (sv and l < L - 1) else None) for l in range(L)]
         if self.ep is None:
             c["row_of_tok"] = c["tok2row"]
             with self._timed("expert_fwd"):
@@ -414,7 +422,7 @@ class SwitchNeRF:
         if row_range is not None:  # a row range of the point grid: the rows' rays through an explicit per-row gather
             rowbias, rpb = c["c_ray"].index_select(0, torch.arange(r0, r1, device=dev) // S), 1
             c["ragged"] = True
-        o.mlp_chain(c["eo"], [o.Layer(self.wf["l1"], self.p["l1.b"].view(1, M), save=c["h1"]),
+        o.mlp_chain(c["eo"], [o.Layer(self.wf["l1"], self.p["l1.b"].view(1, M), save=c["h1"] if sv else None),
                               o.Layer(self.wf["l2h"], None, relu=1, rowbias=rowbias, rows_per_bias=rpb)], c["h2"],
                     group_stride=P, x_gather=c["row_of_tok"], x_save=c["y"], x_scale=c["gmax"], x_relu=True, tag=4)
         # ---- heads
@@ -431,6 +439,8 @@ class SwitchNeRF:
     def backward_net(self, c, d_raw, d_laux):
         """Backward of _net_forward given dL/d raw [N*S, 4] and dL/d l_aux[seg]; accumulates into self.grad."""
         o, dt = ops, self.dtype
+        if c.get("no_grad"):
+            raise RuntimeError("this context comes from an inference forward (training=False): nothing was saved for the backward")
         if c.get("ragged"):
             raise NotImplementedError("backward through a ragged last model chunk: training batches must be a multiple of "
                                       "model_chunk_size points (evaluation handles any size)")
@@ -574,20 +584,20 @@ class SwitchNeRF:
         return res
 
     def forward_hier(self, rays, image_indices, n_samples, fine_samples, seg_tokens, perturb=0.0, perturb_rand=None,
-                     fine_u=None, sigma_noise=None, sigma_noise_fine=None, routing_override=None, no_batch=False):
+                     fine_u=None, sigma_noise=None, sigma_noise_fine=None, routing_override=None, no_batch=False, training=True):
         """_get_results with fine_samples > 0 and no cascade (rendering.py:199-274): coarse pass (weights only, its raw
         outputs kept), importance sampling of the fine depths from the detached coarse weights, fine pass on those
         depths, sort-merge of both sample sets (:419-433) and compositing of the union.
         Returns (coarse ctx, fine ctx, merged results {raw, z, order, rgb, depth, depth_variance})."""
         N = rays.shape[0]
-        c = self.forward_rays(rays, image_indices, n_samples, seg_tokens, perturb, perturb_rand, sigma_noise, True,
+        c = self.forward_rays(rays, image_indices, n_samples, seg_tokens, perturb, perturb_rand, sigma_noise, training,
                               routing_override, no_batch=no_batch, want_weights=True)
         if fine_u is None:                                                # det = (perturb == 0): linspace, else rand (:605-609)
             fine_u = (torch.linspace(0, 1, fine_samples).expand(N, fine_samples).contiguous().to(self.dev) if perturb == 0
                       else torch.rand(N, fine_samples, device=self.dev))
         z_fine = ops.sample_pdf(c["z"], c["weights"], fine_u, fine_samples)
         seg_f = min(seg_tokens, N * fine_samples)
-        cf = self.forward_rays(rays, image_indices, fine_samples, seg_f, 0.0, None, sigma_noise_fine, True, None,
+        cf = self.forward_rays(rays, image_indices, fine_samples, seg_f, 0.0, None, sigma_noise_fine, training, None,
                                no_batch=no_batch, z_in=z_fine, pe_dir=c["pe_dir"], tag="f", composite=False)
         zm, order, raw_m = ops.merge_samples(z_fine, c["z"], cf["raw"], c["raw"])
         out = dict(raw=raw_m, z=zm, order=order, z_fine=z_fine)

@@ -47,7 +47,7 @@ def render_rays(nerf, bg_nerf, rays: torch.Tensor, image_indices: Optional[torch
         if (N * F) % min(chunk, N * F) and nerf.training:
             raise ValueError(f"N_rays * fine_samples ({N * F}) must be a multiple of model_chunk_size ({chunk})")
         c, cf, out = nerf.forward_hier(rays.contiguous(), image_indices, S, F, chunk, float(perturb), pr, None, noise, noise_f,
-                                       no_batch=nerf.moe_no_batch)
+                                       no_batch=nerf.moe_no_batch, training=nerf.training)
         res = {"rgb_fine": out["rgb"], "gate_loss_coarse": c["l_aux"], "gate_loss_fine": cf["l_aux"]}
         if get_depth:
             res["depth_fine"] = out["depth"]
@@ -93,7 +93,7 @@ def _render_rays_bg(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, 
         kw = dict(sigma_noise=torch.randn(N * S, device=rays.device) * std, sigma_noise_bg="randn", sigma_noise_bg_fine="randn",
                   sigma_noise_fine=torch.randn(N * F, device=rays.device) * std if F else None)
     ctx = scene.forward(rays.contiguous(), image_indices, S, min(hparams.model_chunk_size, N * S), float(perturb), fine_samples=F,
-                        no_batch=nerf.moe_no_batch, noise_std=std, **kw)
+                        no_batch=nerf.moe_no_batch, noise_std=std, training=nerf.training, **kw)
     typ = "fine" if F > 0 else "coarse"
     res = {f"rgb_{typ}": ctx["rgb"], "gate_loss_coarse": ctx["c"]["l_aux"]}
     if F > 0:

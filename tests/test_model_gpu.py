@@ -421,3 +421,25 @@ def test_ragged_last_chunk_inference_vs_oracle_fp32():
     c = m.forward_rays(_dev(rays), _dev(img), S, chunk)
     with pytest.raises(NotImplementedError, match="ragged"):
         m.backward(c, torch.zeros(N, 3, device="cuda"), torch.zeros(4, device="cuda"))
+
+
+def test_inference_forward_skips_saves_and_matches_training_forward():
+    """training=False: the chains write no activation saves / ReLU masks; the outputs are bit-identical to the training
+    forward, and a backward through such a context is refused."""
+    N, S, chunk = 64, 64, 1024
+    rays, img, _ = synth.make_rays(141, N)
+    for dt in (torch.float32, torch.bfloat16):
+        m = _model(dt, 142, 0.02)
+        a = m.forward_rays(_dev(rays), _dev(img), S, chunk, training=True)
+        raw_a, rgb_a = a["raw"].clone(), a["rgb"].clone()
+        b = m.forward_rays(_dev(rays), _dev(img), S, chunk, training=False)
+        assert torch.equal(raw_a, b["raw"]) and torch.equal(rgb_a, b["rgb"]) and torch.equal(a["idx"], b["idx"])
+        with pytest.raises(RuntimeError, match="inference forward"):
+            m.backward(b, torch.zeros(N, 3, device="cuda"), torch.zeros(4, device="cuda"))
+    from switch_nerf_amd.dense import DenseNeRF
+    d = DenseNeRF(synth.DENSE, dtype=torch.float32)
+    d.load_state_dict(synth.make_dense_weights(143))
+    a = d.forward_rays(_dev(rays), _dev(img), S, N * S, training=True)
+    raw_a = a["raw"].clone()
+    b = d.forward_rays(_dev(rays), _dev(img), S, N * S, training=False)
+    assert torch.equal(raw_a, b["raw"])
