@@ -1,0 +1,95 @@
+"""The stand-alone MoE layer mirror (switch_nerf_amd.moe.MoELayer) under torch autograd against the golden vectors of the
+reference's own `moe_layer` module (oracle/gen_golden.py gen_moe_layer: forward, l_aux, top-1 indices, input / gate-input /
+parameter gradients, and the gradients of l_aux)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _layer(dtype, **kw):
+    from switch_nerf_amd.moe import moe_layer
+    cfg = synth.BUILDING
+    return moe_layer(gate_type=dict(type="top", k=1, fp32_gate=True, capacity_factor=1.0, batch_prioritized_routing=True, gate_noise=-1.0,
+                                    compute_balance_loss=False, dispatcher_no_score=False, is_postscore=True, gate_dim=cfg["gate_hidden"]),
+                     model_dim=cfg["model_dim"],
+                     experts=dict(type="expertmlp", count_per_node=cfg["num_experts"], hidden_size_per_expert=cfg["model_dim"],
+                                  layer_num=cfg["expert_layers"], skips=list(cfg["skips"])),
+                     seeds=(1, 1, 1), return_gates=True, dtype=dtype, **kw).cuda()
+
+
+def _load(moe, seed):
+    sd = synth.make_weights(seed, synth.BUILDING)
+    sub = {k[len("layers.0."):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith("layers.0.")}
+    assert set(sub) == set(moe.state_dict()), sorted(set(sub) ^ set(moe.state_dict()))
+    moe.load_state_dict(sub)
+
+
+def test_moe_layer_vs_reference_golden_fp32():
+    g = np.load(os.path.join(G, "moe_layer_m256e8.npz"))
+    seed, P = int(g["seed"]), int(g["P"])
+    moe = _layer(torch.float32)
+    _load(moe, seed)
+    rng = np.random.default_rng(seed + 1000)
+    x = rng.standard_normal((P, 256)).astype(np.float32)
+    gi = rng.standard_normal((P, 256)).astype(np.float32)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    gt = torch.from_numpy(gi).cuda().requires_grad_(True)
+    y = moe(xt, gate_input=gt)
+    np.testing.assert_array_equal(y.gate_extras["gates"].cpu().numpy().reshape(-1), g["topk"].reshape(-1))      # bit-exact routing
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["y"], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(y.l_aux.item(), float(g["l_aux"]), rtol=1e-6)
+    dy = rng.standard_normal((P, 256)).astype(np.float32)
+    (y * torch.from_numpy(dy).cuda()).sum().backward(retain_graph=True)
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), g["dx"], rtol=1e-3, atol=2e-4 * np.abs(g["dx"]).max())
+    np.testing.assert_allclose(gt.grad.cpu().numpy(), g["dgate_input"], rtol=1e-3, atol=2e-4 * np.abs(g["dgate_input"]).max())
+    for n, p in moe.named_parameters():
+        got = p.grad.cpu().numpy()
+        if "grad__" + n in g and g["grad__" + n].shape == got.shape:
+            ref = g["grad__" + n]
+            np.testing.assert_allclose(got, ref, rtol=1e-3, atol=5e-4 * np.abs(ref).max(), err_msg=n)
+        else:
+            ref_sum = g["grad__" + n]
+            scale = max(1e-12, float(ref_sum[1]))
+            assert abs(synth.checksum(got)[0] - ref_sum[0]) <= 1e-3 * scale, n
+            sl = got.reshape(-1)[:: max(1, got.size // 997)][:997]
+            ref = g["gslice__" + n]
+            np.testing.assert_allclose(sl, ref, rtol=2e-3, atol=5e-4 * np.abs(ref).max(), err_msg=n)
+    # gradients of the load-balance loss alone
+    d_g, d_wg = torch.autograd.grad(y.l_aux, [gt, moe.gates[0].wg.weight])
+    np.testing.assert_allclose(d_g.cpu().numpy(), g["laux_dgate_input"], rtol=1e-3, atol=2e-4 * np.abs(g["laux_dgate_input"]).max())
+    np.testing.assert_allclose(d_wg.cpu().numpy(), g["laux_dwg"], rtol=1e-3, atol=2e-4 * np.abs(g["laux_dwg"]).max())
+
+
+def test_moe_layer_bf16_shapes_no_batch_and_errors():
+    moe = _layer(torch.bfloat16)
+    _load(moe, 33)
+    x = torch.randn(4, 300, 256, device="cuda")                       # leading dims are flattened like the reference (:741-745)
+    gi = torch.randn(4, 300, 256, device="cuda")
+    y = moe(x, gate_input=gi)
+    assert y.shape == x.shape and y.dtype == x.dtype and y.l_aux.ndim == 0
+    ref = _layer(torch.float32)
+    ref.load_state_dict(moe.state_dict())
+    y32 = ref(x, gate_input=gi)
+    same = (y.gate_extras["gates"] == y32.gate_extras["gates"]).float().mean().item()
+    assert same > 0.99                                                # bf16 gate inputs may flip near-ties
+    kept = (y32.abs().sum(-1) > 0) & (y.abs().sum(-1) > 0)
+    assert (y - y32)[kept].abs().max().item() < 0.15 * y32.abs().max().item()
+    dropped = (y32.abs().sum(-1) == 0).float().mean().item()
+    assert dropped > 0.0                                              # capacity 1.0 on random-init gates drops tokens
+    nb = _layer(torch.float32, moe_no_batch=True)
+    nb.load_state_dict(moe.state_dict())
+    with torch.no_grad():
+        ynb = nb(x, gate_input=gi)
+    assert (ynb.abs().sum(-1) == 0).float().mean().item() == 0.0      # eval path: nothing is dropped
+    with pytest.raises(RuntimeError, match="HIP library only"):
+        moe(x.cpu(), gate_input=gi.cpu())
+    with pytest.raises(NotImplementedError):
+        from switch_nerf_amd.moe import moe_layer
+        moe_layer(gate_type=dict(type="top", k=2), model_dim=256, experts=dict(type="expertmlp", count_per_node=8, layer_num=7))
