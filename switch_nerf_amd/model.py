@@ -687,6 +687,20 @@ class SwitchNeRF:
     def eval(self):
         return self.train(False)
 
+    def modules(self):
+        """nn.Module.modules() stand-in: Runner.set_no_batch (runner.py:946-951) walks it looking for `moe_no_batch`."""
+        yield self
+
+    def named_parameters(self):
+        """(reference key, tensor) pairs - views of the flat fp32 master buffer (count_parameters, runner.py:196-199)."""
+        return iter(self._to_ref_layout(self.p).items())
+
+    def parameters(self):
+        return (v for _, v in self.named_parameters())
+
+    def to(self, *_a, **_k):
+        return self
+
     def set_no_batch(self, mode=True):
         """NeRFMoE.set_no_batch (models/nerf_moe.py:315-318): eval path without capacity / token dropping."""
         self.moe_no_batch = bool(mode)

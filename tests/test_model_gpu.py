@@ -443,3 +443,18 @@ def test_inference_forward_skips_saves_and_matches_training_forward():
     raw_a = a["raw"].clone()
     b = d.forward_rays(_dev(rays), _dev(img), S, N * S, training=False)
     assert torch.equal(raw_a, b["raw"])
+
+
+def test_module_surface_used_by_the_runner():
+    """Runner.set_no_batch walks nerf.modules() for `moe_no_batch` (runner.py:946-951); count_parameters sums
+    p.numel() over nerf.parameters() (3.947 M for building.yaml)."""
+    m = _model(torch.float32, 151, 1.0)
+    for net in m.modules():
+        if hasattr(net, "moe_no_batch"):
+            net.moe_no_batch = True
+    assert m.moe_no_batch is True
+    n = sum(p.numel() for p in m.parameters())
+    sd = synth.make_weights(151, synth.BUILDING)
+    assert n == sum(v.size for v in sd.values())
+    assert {k for k, _ in m.named_parameters()} == set(sd)
+    assert m.to("cuda") is m and m.train(False).training is False and m.eval().training is False
