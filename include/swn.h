@@ -225,17 +225,8 @@ int swn_composite_bounded_bwd(const float* raw, const float* z, const float* las
  * tutel_moe_layer_nobatch.py:157, 172) from the routing permutation.                                            */
 int swn_gather_rows(const void* src, const int32_t* index, long n_rows, int row_bytes, void* dst, void* stream);
 
-/* The dense NeRF's concat-skip (/root/reference/switch_nerf/models/nerf.py:155-156, torch.cat([enc, h], -1) in front of a
- * skip layer):  out[r] = [a[r] | b[r] | zeros] with rows of a_bytes / b_bytes / out_bytes bytes (multiples of 16,
- * out_bytes >= a_bytes + b_bytes; the zero tail pads the row to a chain input width), and the backward of its h-part:
- * out[r, j] = act[r, j] > 0 ? src[r, col0 + j] : 0  (src [n_rows, ld_src] is the gradient w.r.t. the concatenated input,
- * act [n_rows, n] the ReLU output that was concatenated; elements of `dtype`).                                          */
-int swn_concat_cols(const void* a, int a_bytes, const void* b, int b_bytes, long n_rows, int out_bytes, void* out, void* stream);
-int swn_slice_relu_bwd(const void* src, int ld_src, int col0, const void* act, int n, long n_rows, int dtype, void* out,
-                       void* stream);
-
 /* ---- dense / grouped MLP chains on MFMA ------------------------------------------------------------------------
- * One launch runs `n_layers` (<= 8) Linear layers back to back with the activations of a 128-row tile resident in
+ * One launch runs `n_layers` (<= SWN_MAX_CHAIN_LAYERS) Linear layers back to back with the activations of a 128-row tile resident in
  * LDS.  Layer l: h <- act_l( h @ W_l^T + b_l [+ rowbias[row/rows_per_bias]] [+ skip] ).  W_l (logically [N_l][K_l],
  * torch.nn.Linear.weight orientation) must be given in the MFMA-fragment-major layout produced by swn_pack_weights
  * (compute dtype); b_l fp32.  Ragged groups: rows of group g are
@@ -243,6 +234,7 @@ int swn_slice_relu_bwd(const void* src, int ld_src, int col0, const void* act, i
  * (expert MLP: group = (segment, expert), n_wsets = E).
  * replaces ExpertMLP.forward (tutel_moe_layer_nobatch.py:887-924: baddbmm chain, skip, ReLU) and Mlp.forward
  * (models/nerf_moe.py:30-49).  Details of the descriptor: see swn_chain_desc below.                             */
+#define SWN_MAX_CHAIN_LAYERS 12
 typedef struct swn_chain_layer {
   const void* w;        /* [n_wsets] x packed(N, K) in dtype: output of swn_pack_weights */
   const float* b;       /* [n_wsets][N] f32 or NULL                                */
@@ -254,7 +246,10 @@ typedef struct swn_chain_layer {
   int32_t n, k;         /* output / input features: n a multiple of 64 up to 512, k in {64,128,256,512}; any layer wider than
                            256 selects the 512-feature kernels for the whole chain                                */
   int32_t relu;         /* 0 none; 1 ReLU (and record the mask if given); 2 multiply by the recorded mask (backward) */
-  int32_t skip;         /* add the chain input x before the activation (needs n == layers[0].k) */
+  int32_t skip;         /* 1: add the chain input x before the activation (residual; needs n == layers[0].k).
+                         * 2: first half of a concat-skip Linear(cat([x, h])) = h W_h + x W_x (models/nerf.py:155-156): this
+                         *    entry is h W_h - no bias / activation / save; the NEXT entry (k = layers[0].k, same n) multiplies
+                         *    the re-staged chain input and carries the bias, activation, mask and save of the layer */
 } swn_chain_layer;
 
 typedef struct swn_chain_desc {
@@ -274,7 +269,7 @@ typedef struct swn_chain_desc {
   int32_t tag;                  /* profiling only: selects an identical kernel instantiation with its own symbol so that
                                    rocprofv3 reports the roles separately (0 generic, 1 expert fwd, 2 expert bwd,
                                    3 front fwd, 4 tail fwd, 5 tail bwd, 6 front bwd)                 */
-  swn_chain_layer layers[8];
+  swn_chain_layer layers[SWN_MAX_CHAIN_LAYERS];
 } swn_chain_desc;
 
 int swn_mlp_chain(const swn_chain_desc* desc, void* stream);

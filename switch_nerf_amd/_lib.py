@@ -29,7 +29,7 @@ class HashCfg(C.Structure):
 class ChainDesc(C.Structure):
     _fields_ = [("dtype", i32), ("n_layers", i32), ("n_groups", i32), ("n_wsets", i32), ("group_stride", i32),
                 ("group_rows", vp), ("group_rows_clamp", i32), ("x", vp), ("x_gather", vp), ("x_save", vp), ("x_scale", vp), ("x_relu", i32),
-                ("y", vp), ("y_add", vp), ("y_add_gather", vp), ("tag", i32), ("layers", ChainLayer * 8)]
+                ("y", vp), ("y_add", vp), ("y_add_gather", vp), ("tag", i32), ("layers", ChainLayer * 12)]
 
 
 # name -> argtypes; every symbol declared in include/swn.h must be listed here (tests/test_abi.py checks both ways)
@@ -64,8 +64,6 @@ SIGNATURES = {
     "swn_hash_encode_fwd": [vp, vp, i32, i32, C.POINTER(HashCfg), vp, i32, vp, i32, vp],
     "swn_hash_encode_bwd": [vp, vp, i32, i32, C.POINTER(HashCfg), vp, i32, i32, vp, vp],
     "swn_gather_rows": [vp, vp, i64, i32, vp, vp],
-    "swn_concat_cols": [vp, i32, vp, i32, i64, i32, vp, vp],
-    "swn_slice_relu_bwd": [vp, i32, i32, vp, i32, i64, i32, vp, vp],
     "swn_mlp_chain": [C.POINTER(ChainDesc), vp],
     "swn_pack_weights": [vp, vp, i32, i32, i32, i32, i32, vp],
     "swn_chain_tile_rows": [i32],

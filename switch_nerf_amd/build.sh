@@ -18,6 +18,11 @@ if [ ! -f "$HERE/build/chain_wide.o" ] || [ chain.hip -nt "$HERE/build/chain_wid
   $HIPCC $FLAGS -DSWN_WIDE=1 -c chain.hip -o "$HERE/build/chain_wide.o" &
   pids+=($!)
 fi
+# ... and a third time: the concat-skip layer mode of the dense NeRF trunk (kept out of the default build's register budget)
+if [ ! -f "$HERE/build/chain_cat.o" ] || [ chain.hip -nt "$HERE/build/chain_cat.o" ] || [ common.hpp -nt "$HERE/build/chain_cat.o" ] || [ ../../include/swn.h -nt "$HERE/build/chain_cat.o" ]; then
+  $HIPCC $FLAGS -DSWN_CONCAT=1 -c chain.hip -o "$HERE/build/chain_cat.o" &
+  pids+=($!)
+fi
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC "$HERE"/build/{elementwise,route,chain,chain_wide,wgrad,sampling,mip,bounds,hashgrid}.o -o "$HERE/libswn_hip.so"
+$HIPCC --offload-arch=gfx950 -shared -fPIC "$HERE"/build/{elementwise,route,chain,chain_wide,chain_cat,wgrad,sampling,mip,bounds,hashgrid}.o -o "$HERE/libswn_hip.so"
 echo "built $HERE/libswn_hip.so"

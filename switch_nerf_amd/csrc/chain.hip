@@ -25,11 +25,17 @@
 #ifndef SWN_WIDE
 #define SWN_WIDE 0
 #endif
+#ifndef SWN_CONCAT
+#define SWN_CONCAT 0     // 1: third build of this file with the concat-skip layer mode (skip = 2) enabled, namespace swn_cat
+#endif
 #if SWN_WIDE
 #define SWN_NS swn_wide
+#elif SWN_CONCAT
+#define SWN_NS swn_cat
 #else
 #define SWN_NS swn
 #endif
+#define SWN_AUX (SWN_WIDE || SWN_CONCAT)      // an auxiliary build: kernels + launcher only, no C entry points
 
 namespace SWN_NS {
 using namespace swn;
@@ -67,7 +73,7 @@ template <> struct Cfg<bf16_t> {
 #ifndef SWN_OCC
 #define SWN_OCC 4
 #endif
-  static constexpr int OCC = SWN_WIDE ? 2 : (BM == 128 ? 2 : SWN_OCC);   // workgroups per CU (= waves per SIMD) the register budget must allow
+  static constexpr int OCC = SWN_WIDE ? 2 : (BM == 128 ? 2 : (SWN_CONCAT ? 3 : SWN_OCC));   // workgroups per CU (= waves per SIMD) the register budget must allow
   typedef bf16x8_t wfrag_t;
 };
 template <> struct Cfg<float> {
@@ -139,7 +145,7 @@ __device__ __forceinline__ uint4 add_chunks(uint4 a, uint4 b) {
 // Load the (gathered) input rows of this tile into an LDS tile with the activation layout.
 // kfeat * sizeof(T) / 16 (chunks per row) is a power of two; all global loads of a batch are issued before any is
 // consumed (no per-load wait), out-of-range work is clamped to a valid address and masked at the store.
-template <typename T>
+template <typename T, int B = 4>
 __device__ __forceinline__ void load_rows_to_lds(char* dst, const void* src, const int32_t* gather, void* save,
                                                  long grow0, int rows_valid_in_tile, int kfeat, int tid,
                                                  const float* scale = nullptr, int relu = 0) {
@@ -147,8 +153,7 @@ __device__ __forceinline__ void load_rows_to_lds(char* dst, const void* src, con
   const int row_bytes = kfeat * (int)sizeof(T);
   const int cpr = row_bytes >> 4;  // 16-byte chunks per row (power of two)
   const int sh = 31 - __builtin_clz(cpr);
-  const int total = BM * cpr;
-  constexpr int B = 4;
+  const int total = BM * cpr;      // B = loads in flight per thread (1: minimal register footprint, for the concat re-stage)
   for (int c0 = tid; c0 < total; c0 += NT * B) {
     long srow[B];
     int row[B], ch[B];
@@ -466,6 +471,57 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
 
   f32x16_t acc[MI][NI];
 
+#if SWN_CONCAT
+  // K loop of entry Lx: no barrier.  (Waves beyond the layer width run it too on a clamped stream - keeps the ring logic
+  // uniform - and discard the result.  Only the 128-wide layer "2" has such waves.)
+  auto run_k = [&](int Lx) {
+    const bool nx = (Lx + 1) < d.n_layers;
+    const int steps = d.layers[Lx].k / KSTEP;
+    const __amdgpu_buffer_rsrc_t wcur = wrsrc(Lx);
+    const __amdgpu_buffer_rsrc_t wnxt = nx ? wrsrc(Lx + 1) : wcur;
+    const int nsteps_next = nx ? d.layers[Lx + 1].k / KSTEP : steps;
+#if SWN_WIDE
+    if (steps == 512 / KSTEP) k_loop<T, 512 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
+    else
+#endif
+    if (steps == 256 / KSTEP) k_loop<T, 256 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
+    else if (steps == 128 / KSTEP) k_loop<T, 128 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
+    else k_loop<T, 64 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
+  };
+
+  for (int L0 = 0; L0 < d.n_layers; ++L0) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    run_k(L0);
+    __syncthreads();   // every wave has finished reading the activation tile of this layer
+
+    int L = L0;
+#if SWN_CONCAT
+    if (d.layers[L0].skip == 2) {
+      // concat-skip (models/nerf.py:155-156, Linear(cat([enc, h])) = h W_h + enc W_enc): entry L0 was the h half.  No
+      // epilogue yet: re-stage the chain input (enc) as the tile and let the next entry (the enc half, K = the chain input
+      // width) accumulate on top; bias / ReLU / mask / save belong to that entry.  Both K loops live in this iteration so
+      // that the accumulators are never carried across the layer loop's back edge.
+      load_rows_to_lds<T, 1>(act, d.x, d.x_gather, nullptr, grow0, rows_in_tile, d.layers[0].k, tid, d.x_scale, d.x_relu);
+      stage_bias(L0 + 1);
+      __syncthreads();
+      L = L0 + 1;
+      run_k(L);
+      __syncthreads();
+      L0 = L;
+    }
+#endif
+    const swn_chain_layer& ly = d.layers[L];
+    const int n = ly.n;
+    const bool wave_active = (wn * 32 * NI) < n;
+    const bool has_next = (L + 1) < d.n_layers;
+
+#else
   for (int L = 0; L < d.n_layers; ++L) {
     const swn_chain_layer& ly = d.layers[L];
     const int n = ly.n, k = ly.k;
@@ -495,6 +551,7 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
 
     __syncthreads();   // every wave has finished reading the activation tile of this layer
 
+#endif
     if (ly.skip) {  // the input tile is dead: bring the chain input x back into the SAME LDS tile; each lane then reads
                     // its x values and writes h over them in place
       load_rows_to_lds<T>(act, d.x, d.x_gather, nullptr, grow0, rows_in_tile, d.layers[0].k, tid, d.x_scale, d.x_relu);
@@ -511,7 +568,7 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
       uint32_t* mk = ly.mask ? ly.mask + (size_t)(blockIdx.x * 4 + wn) * MI * 64 * (NI / 2) + lane : nullptr;
       const int nvalid = n - wn * 32 * NI;   // feature tiles of this wave that exist: nvalid >= 32 NI -> all
       epilogue_body<T, true, 0, false, false, false>(acc, act, bias_lds, rbp, mk, wn, l31e, lhie, nvalid, grow0, ly.rows_per_bias, n,
-                                                     ly.relu, ly.skip != 0, ly.b != nullptr, rows_in_tile);
+                                                     ly.relu, ly.skip == 1, ly.b != nullptr, rows_in_tile);
     }
     __syncthreads();
     if (has_next) stage_bias(L + 1);   // read after the next layer's post-K-loop barrier
@@ -544,7 +601,7 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
   }
 }
 
-#if !SWN_WIDE
+#if !SWN_AUX
 // Pack a master weight [wsets][in][out] (fp32) into the fragment-major compute layout of swn_mlp_chain:
 //   transpose = 1 (forward):       W[n = out][k = in]  = master[k][n]
 //   transpose = 0 (backward-data): W[n = in][k = out]  = master[n][k]
@@ -576,7 +633,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ master, T* __restr
   }
 }
 
-#endif   // !SWN_WIDE
+#endif   // !SWN_AUX
 
 // host side of one launch (shared by both builds; the narrow build's swn_mlp_chain forwards wide descriptors to the wide one)
 static int chain_launch(const swn_chain_desc& d, void* stream) {
@@ -611,6 +668,10 @@ static int chain_launch(const swn_chain_desc& d, void* stream) {
 namespace swn {
 int chain_wide_launch(const swn_chain_desc& d, void* stream) { return swn_wide::chain_launch(d, stream); }
 int chain_wide_tile_rows(int dtype) { return dtype == SWN_BF16 ? swn_wide::Cfg<bf16_t>::BM : swn_wide::Cfg<float>::BM; }
+}  // namespace swn
+#elif SWN_CONCAT
+namespace swn {
+int chain_concat_launch(const swn_chain_desc& d, void* stream) { return swn_cat::chain_launch(d, stream); }
 }  // namespace swn
 #else
 
@@ -649,24 +710,33 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   SWN_CHECK(desc != nullptr, "swn_mlp_chain: null descriptor");
   const swn_chain_desc& d = *desc;
   SWN_CHECK(d.dtype == SWN_F32 || d.dtype == SWN_BF16, "swn_mlp_chain: bad dtype %d", d.dtype);
-  SWN_CHECK(d.n_layers >= 1 && d.n_layers <= 8, "swn_mlp_chain: n_layers %d not in [1,8]", d.n_layers);
+  SWN_CHECK(d.n_layers >= 1 && d.n_layers <= SWN_MAX_CHAIN_LAYERS, "swn_mlp_chain: n_layers %d not in [1,%d]", d.n_layers, SWN_MAX_CHAIN_LAYERS);
   SWN_CHECK(d.n_groups >= 1 && d.n_wsets >= 1 && d.group_stride >= 1, "swn_mlp_chain: bad group geometry");
-  bool wide = false;
+  bool wide = false, concat = false;
   for (int l = 0; l < d.n_layers; ++l) {
     const swn_chain_layer& ly = d.layers[l];
     SWN_CHECK(ly.n >= 64 && ly.n <= 512 && ly.n % 64 == 0, "swn_mlp_chain: layer %d n=%d must be a multiple of 64 in [64, 512]", l, ly.n);
     SWN_CHECK(ly.k == 64 || ly.k == 128 || ly.k == 256 || ly.k == 512, "swn_mlp_chain: layer %d k=%d must be 64, 128, 256 or 512", l, ly.k);
     wide = wide || ly.n > 256 || ly.k > 256;
-    if (l > 0) SWN_CHECK(ly.k == d.layers[l - 1].n, "swn_mlp_chain: layer %d k=%d != previous n=%d", l, ly.k, d.layers[l - 1].n);
+    concat = concat || ly.skip == 2;
+    if (l > 0 && d.layers[l - 1].skip == 2)
+      SWN_CHECK(ly.k == d.layers[0].k && ly.n == d.layers[l - 1].n, "swn_mlp_chain: layer %d after a concat half needs k = chain input width "
+                "and the same n", l);
+    else if (l > 0) SWN_CHECK(ly.k == d.layers[l - 1].n, "swn_mlp_chain: layer %d k=%d != previous n=%d", l, ly.k, d.layers[l - 1].n);
     SWN_CHECK(ly.w != nullptr, "swn_mlp_chain: layer %d has no weights", l);
-    if (ly.skip) SWN_CHECK(ly.n == d.layers[0].k, "swn_mlp_chain: skip layer %d needs n == chain input width", l);
+    SWN_CHECK(ly.skip >= 0 && ly.skip <= 2, "swn_mlp_chain: skip mode %d", ly.skip);
+    if (ly.skip == 1) SWN_CHECK(ly.n == d.layers[0].k, "swn_mlp_chain: skip layer %d needs n == chain input width", l);
+    if (ly.skip == 2) SWN_CHECK(l + 1 < d.n_layers && !ly.save && !ly.mask && !ly.b && !ly.rowbias && ly.relu == 0,
+                                "swn_mlp_chain: a concat half (skip = 2) carries no bias / activation / save and is followed by its other half");
     if (ly.rowbias) SWN_CHECK(ly.rows_per_bias > 0, "swn_mlp_chain: rows_per_bias must be > 0");
     SWN_CHECK(ly.relu >= 0 && ly.relu <= 2, "swn_mlp_chain: relu mode %d", ly.relu);
     if (ly.relu == 2) SWN_CHECK(ly.mask != nullptr, "swn_mlp_chain: relu=2 (apply stored mask) needs a mask");
   }
   SWN_CHECK(d.x != nullptr && d.y != nullptr, "swn_mlp_chain: x / y must not be null");
   SWN_CHECK(d.tag >= 0 && d.tag <= 6, "swn_mlp_chain: tag %d not in [0,6]", d.tag);
+  SWN_CHECK(!(wide && concat), "swn_mlp_chain: concat-skip layers are built for the 256-feature kernels only");
   if (wide) return chain_wide_launch(d, stream);        // 512-feature geometry (this file compiled with -DSWN_WIDE=1)
+  if (concat) return chain_concat_launch(d, stream);    // concat-skip layers (this file compiled with -DSWN_CONCAT=1)
   return chain_launch(d, stream);
 }
-#endif   // !SWN_WIDE
+#endif   // !SWN_AUX

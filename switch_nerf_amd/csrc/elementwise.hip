@@ -868,46 +868,6 @@ __global__ void gather_rows_kernel(const char* __restrict__ src, const int32_t* 
   }
 }
 
-// out[r] = [a[r] | b[r] | 0...] in 16-byte pieces: the input of a concat-skip layer (models/nerf.py:155-156 torch.cat([enc, h]))
-__global__ void concat_cols_kernel(const char* __restrict__ a, int a_bytes, const char* __restrict__ b, int b_bytes, long n_rows,
-                                   int out_bytes, char* __restrict__ out) {
-  const int cpr = out_bytes >> 4, ca = a_bytes >> 4, cb = b_bytes >> 4;
-  const long total = n_rows * cpr;
-  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long)gridDim.x * blockDim.x) {
-    const long r = c / cpr;
-    const int ch = (int)(c - r * cpr);
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (ch < ca) v = *(const uint4*)(a + r * a_bytes + ch * 16);
-    else if (ch < ca + cb) v = *(const uint4*)(b + r * b_bytes + (ch - ca) * 16);
-    *(uint4*)(out + c * 16) = v;
-  }
-}
-
-// out[r, j] = act[r, j] > 0 ? src[r, col0 + j] : 0 (8 / 4 elements per thread): the gradient of the h-part of a concat-skip
-// layer's input, through the ReLU that produced h
-__device__ inline bool is_pos(float v) { return v > 0.f; }
-__device__ inline bool is_pos(bf16_t v) { return v != 0 && v < 0x8000; }        // raw bf16 bits: > +0
-
-template <typename T>
-__global__ void slice_relu_bwd_kernel(const T* __restrict__ src, int ld_src, int col0, const T* __restrict__ act, int n, long n_rows,
-                                      T* __restrict__ out) {
-  constexpr int V = 16 / sizeof(T);
-  const int cpr = n / V;
-  const long total = n_rows * cpr;
-  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long)gridDim.x * blockDim.x) {
-    const long r = c / cpr;
-    const int j = (int)(c - r * cpr) * V;
-    uint4 sv = *(const uint4*)(src + r * ld_src + col0 + j);
-    const uint4 av = *(const uint4*)(act + r * n + j);
-    T* s_ = (T*)&sv;
-    const T* a_ = (const T*)&av;
-#pragma unroll
-    for (int i = 0; i < V; ++i)
-      if (!is_pos(a_[i])) s_[i] = (T)0;
-    *(uint4*)(out + r * n + j) = sv;
-  }
-}
-
 }  // namespace swn
 
 using namespace swn;
@@ -1288,41 +1248,6 @@ extern "C" int swn_gather_rows(const void* src, const int32_t* index, long n_row
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const char*)src, index, n_rows,
                      row_bytes, (char*)dst);
-  SWN_LAUNCH_CHECK();
-  return 0;
-}
-
-extern "C" int swn_concat_cols(const void* a, int a_bytes, const void* b, int b_bytes, long n_rows, int out_bytes, void* out,
-                               void* stream) {
-  SWN_CHECK(a && b && out, "swn_concat_cols: null pointer");
-  SWN_CHECK(a_bytes > 0 && b_bytes > 0 && a_bytes % 16 == 0 && b_bytes % 16 == 0 && out_bytes % 16 == 0 &&
-                out_bytes >= a_bytes + b_bytes, "swn_concat_cols: row sizes (%d, %d -> %d) must be multiples of 16, out >= a + b",
-            a_bytes, b_bytes, out_bytes);
-  if (n_rows <= 0) return 0;
-  long blocks = (n_rows * (out_bytes >> 4) + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(concat_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const char*)a, a_bytes,
-                     (const char*)b, b_bytes, n_rows, out_bytes, (char*)out);
-  SWN_LAUNCH_CHECK();
-  return 0;
-}
-
-extern "C" int swn_slice_relu_bwd(const void* src, int ld_src, int col0, const void* act, int n, long n_rows, int dtype, void* out,
-                                  void* stream) {
-  SWN_CHECK(src && act && out, "swn_slice_relu_bwd: null pointer");
-  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_slice_relu_bwd: bad dtype %d", dtype);
-  const int v = dtype == SWN_BF16 ? 8 : 4;
-  SWN_CHECK(n > 0 && n % v == 0 && col0 % v == 0 && ld_src % v == 0 && col0 + n <= ld_src,
-            "swn_slice_relu_bwd: slice [%d, %d) of %d columns must be 16-byte aligned", col0, col0 + n, ld_src);
-  if (n_rows <= 0) return 0;
-  long blocks = (n_rows * (n / v) + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  if (dtype == SWN_BF16)
-    hipLaunchKernelGGL(slice_relu_bwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const bf16_t*)src,
-                       ld_src, col0, (const bf16_t*)act, n, n_rows, (bf16_t*)out);
-  else
-    hipLaunchKernelGGL(slice_relu_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)src,
-                       ld_src, col0, (const float*)act, n, n_rows, (float*)out);
   SWN_LAUNCH_CHECK();
   return 0;
 }

@@ -7,11 +7,11 @@ layers named in `skip_layers` (torch.cat([enc, h]), nerf.py:155-156), the sigma 
 appearance tail as NeRFMoE (xyz_encoding_final -> dir_a_encoding + ReLU -> rgb + sigmoid).
 
 DenseNeRF derives from SwitchNeRF: ray sampling, positional encoding, the tail chain, the heads, compositing, the loss
-assembly and Adam are the same launches; only the trunk differs - two MLP chains instead of gate + routing + experts:
-
-  chain A   PE [P, KP] -> layers 0 .. s-1                 (s = the skip layer; 256-feature kernels)
-  concat    [PE | h_{s-1} | 0] -> [P, KC]                 (swn_concat_cols; KC = the next supported chain width >= KP + W)
-  chain B   [P, KC] -> layers s .. L-1                    (layer s has K = KC: the 512-feature kernels)
+assembly and Adam are the same launches; only the trunk differs - ONE MLP chain launch instead of gate + routing + experts.
+The concat-skip is not materialised: Linear(cat([enc, h])) = h W_h + enc W_enc runs as two consecutive K loops on the same
+accumulators (chain layer mode skip = 2: the h half, then the chain input re-staged in the LDS tile for the enc half, which
+carries the bias / ReLU / mask / save).  The backward is a plain chain through W_h^T (the encoding has no gradient) and the
+weight gradient of the skip layer is two GEMMs (h^T dZ, enc^T dZ).
 
 The state_dict layout is the reference NeRF's (xyz_encodings.{i}.0.weight, xyz_encoding_final.weight, dir_a_encoding.0.*,
 sigma.*, rgb.*, embedding_a.weight), so checkpoints interchange.
@@ -31,13 +31,6 @@ DENSE = dict(layer_dim=256, layers=8, skip_layers=(4,), pos_xyz_dim=12, pos_dir_
              appearance_count=1920, xyz_dim=3)
 
 
-def _chain_width(k):
-    for w in (64, 128, 256, 512):
-        if k <= w:
-            return w
-    raise ValueError(f"chain input width {k} > 512")
-
-
 class DenseNeRF(SwitchNeRF):
     def __init__(self, cfg: dict = DENSE, dtype=torch.bfloat16, device="cuda", lr=5e-4, seed=0):
         super().__init__(cfg, dtype, device, capacity_factor=1.0, batch_prioritized=False, moe_l_aux_wt=0.0, lr=lr, seed=seed)
@@ -46,7 +39,7 @@ class DenseNeRF(SwitchNeRF):
         W, L, xd = cfg["layer_dim"], cfg["layers"], cfg.get("xyz_dim", 3)
         skips = tuple(cfg["skip_layers"])
         assert len(skips) <= 1 and all(0 < s < L for s in skips), "at most one concat-skip layer, not the first"
-        assert W % 64 == 0 and W <= 256, "layer_dim: a multiple of 64 up to 256 (the concatenated input must fit 512 columns)"
+        assert W % 64 == 0 and W <= 256, "layer_dim: a multiple of 64 up to 256"
         self.xyz_dim = xd
         self.in_xyz = xd + 2 * xd * cfg["pos_xyz_dim"]
         self.in_dir = 3 + 6 * cfg["pos_dir_dim"]
@@ -54,18 +47,20 @@ class DenseNeRF(SwitchNeRF):
         self.DP = _ceil_to(self.in_dir, 8)
         self.n_ray_feat = self.in_dir + cfg["appearance_dim"]
         self.skip_l = skips[0] if skips else None
-        self.KC = _chain_width(self.KP + W)          # [PE (KP) | h (W) | zero pad]
         M, H2 = W, W // 2
         self.L, self.M, self.E, self.G, self.H2 = L, M, 1, M, H2
         spec = []
         for i in range(L):
-            k = self.KP if i == 0 else (self.KC if i == self.skip_l else W)
-            spec += [(f"enc{i}.w", (k, W)), (f"enc{i}.b", (W,))]
+            if i == self.skip_l:          # Linear(cat([enc, h])): the enc rows and the h rows as two matrices
+                spec += [(f"enc{i}p.w", (self.KP, W)), (f"enc{i}h.w", (W, W)), (f"enc{i}.b", (W,))]
+            else:
+                spec += [(f"enc{i}.w", (self.KP if i == 0 else W, W)), (f"enc{i}.b", (W,))]
         spec += [("l1.w", (M, M)), ("l1.b", (M,)), ("l2h.w", (M, H2)), ("l2r.w", (self.n_ray_feat, H2)), ("l2.b", (H2,)),
                  ("sigma.w", (M,)), ("sigma.b", (1,)), ("color.w", (3, H2)), ("color.b", (3,)),
                  ("emb", (cfg["appearance_count"], cfg["appearance_dim"]))]
-        self._chain_weights = [f"enc{i}" for i in range(L)] + ["l1", "l2h"]
-        self._fwd_only_weights = {"enc0"}
+        s = self.skip_l
+        self._chain_weights = [f"enc{i}" for i in range(L) if i != s] + ([f"enc{s}p", f"enc{s}h"] if s is not None else []) + ["l1", "l2h"]
+        self._fwd_only_weights = {"enc0"} | ({f"enc{s}p"} if s is not None else set())
         return spec
 
     # ------------------------------------------------------------------------------------------ parameters
@@ -100,11 +95,12 @@ class DenseNeRF(SwitchNeRF):
         with torch.no_grad():
             for i in range(self.L):
                 w = t(f"xyz_encodings.{i}.0.weight").t()            # [in, out]
-                p[f"enc{i}.w"].zero_()
-                if i == self.skip_l:                                 # rows: [PE (nx of KP) | h (W) | pad]
-                    p[f"enc{i}.w"][:nx] = w[:nx]
-                    p[f"enc{i}.w"][self.KP: self.KP + W] = w[nx:]
+                if i == self.skip_l:                                 # input rows: [enc (nx) | h (W)]  (torch.cat([enc, h]))
+                    p[f"enc{i}p.w"].zero_()
+                    p[f"enc{i}p.w"][:nx] = w[:nx]
+                    p[f"enc{i}h.w"].copy_(w[nx:])
                 else:
+                    p[f"enc{i}.w"].zero_()
                     p[f"enc{i}.w"][: w.shape[0]] = w
                 p[f"enc{i}.b"].copy_(t(f"xyz_encodings.{i}.0.bias"))
             p["l1.w"].copy_(t("xyz_encoding_final.weight").t())
@@ -124,11 +120,12 @@ class DenseNeRF(SwitchNeRF):
         W, nx = self.M, self.in_xyz
         out = {}
         for i in range(self.L):
-            w = d[f"enc{i}.w"]
-            if i == 0:
-                w = w[:nx]
-            elif i == self.skip_l:
-                w = torch.cat([w[:nx], w[self.KP: self.KP + W]], 0)
+            if i == self.skip_l:
+                w = torch.cat([d[f"enc{i}p.w"][:nx], d[f"enc{i}h.w"]], 0)
+            else:
+                w = d[f"enc{i}.w"]
+                if i == 0:
+                    w = w[:nx]
             out[f"xyz_encodings.{i}.0.weight"] = w.t().contiguous()
             out[f"xyz_encodings.{i}.0.bias"] = d[f"enc{i}.b"].clone()
         out["xyz_encoding_final.weight"] = d["l1.w"].t().contiguous()
@@ -158,22 +155,21 @@ class DenseNeRF(SwitchNeRF):
         c["pe"], c["pe_dir"] = pe, pe_dir
         _b = lambda name, shape, dtype: self._buf(tag + ":" + name, shape, dtype)
         c["acts"] = [_b(f"act{i}", (P, W), dt) for i in range(L)]          # post-ReLU outputs; acts[L-1] = xyz_ (c["y"])
-        nA = L if s is None else s
-        mwA = o.chain_mask_words(dt, 1, P, max(W, self.KP))
-        mwB = o.chain_mask_words(dt, 1, P, self.KC)
-        c["masks"] = [_b(f"mask{i}", (mwA if i < nA else mwB,), torch.int32) for i in range(L)]
-
+        mw = o.chain_mask_words(dt, 1, P, max(W, self.KP))
+        c["masks"] = [_b(f"mask{i}", (mw,), torch.int32) for i in range(L)]
         sv = self._saving
         c["no_grad"] = not sv
-
-        def layer(i, last):
-            return o.Layer(self.wf[f"enc{i}"], self.p[f"enc{i}.b"].view(1, W), relu=1, mask=c["masks"][i] if sv else None,
-                           save=c["acts"][i] if (sv and not last) else None)
+        layers = []
+        for i in range(L):
+            last = i == L - 1
+            kw = dict(relu=1, mask=c["masks"][i] if sv else None, save=c["acts"][i] if (sv and not last) else None)
+            bias = self.p[f"enc{i}.b"].view(1, W)
+            if i == s:      # h W_h (+ nothing), then enc W_enc + b -> ReLU: two K loops on the same accumulators
+                layers += [o.Layer(self.wf[f"enc{i}h"], None, skip=2), o.Layer(self.wf[f"enc{i}p"], bias, **kw)]
+            else:
+                layers.append(o.Layer(self.wf[f"enc{i}"], bias, **kw))
         with self._timed("trunk_fwd"):
-            o.mlp_chain(pe, [layer(i, i == nA - 1) for i in range(nA)], c["acts"][nA - 1], tag=1)
-            if s is not None:
-                c["cat"] = o.concat_cols(pe, c["acts"][s - 1], _b("cat", (P, self.KC), dt))
-                o.mlp_chain(c["cat"], [layer(i, i == L - 1) for i in range(s, L)], c["acts"][L - 1], tag=1)
+            o.mlp_chain(pe, layers, c["acts"][L - 1], tag=1)
         c["y"] = c["acts"][L - 1]
         # ---- per-ray part of dir_a_encoding: [PE(dir), appearance embedding] @ W2r + b2 (nerf.py:173-181)
         feat = torch.cat([pe_dir[:, : self.in_dir].float(), self.p["emb"][image_indices.long()]], 1)
@@ -216,24 +212,20 @@ class DenseNeRF(SwitchNeRF):
         dz.append(o.combine_bwd(dy, c["y"], dsig, self.p["sigma.w"], ones)[0])
         o.wgrad(c["h1"], dh2, g["l2h.w"].view(1, W, H2), None, n_splits=nsp)
         o.wgrad(c["y"], dh1, g["l1.w"].view(1, W, W), g["l1.b"].view(1, W), n_splits=nsp)
-        nA = L if s is None else s
         with self._timed("trunk_bwd"):
-            if s is not None:
-                # chain B backward: dz[L-1] -> ... -> dz[s] -> d(cat) (no mask: the concatenated input is not an activation)
-                bl = [o.Layer(self.wb[f"enc{i}"], None, relu=2 if i > s else 0, mask=masks[i - 1] if i > s else None,
-                              save=dz[i - 1] if i > s else None) for i in range(L - 1, s - 1, -1)]
-                dcat = _b("dcat", (P, self.KC), dt)
-                o.mlp_chain(dz[L - 1], bl, dcat, tag=2)
-                o.slice_relu_bwd(dcat, self.KP, acts[s - 1], dz[s - 1])
-            if nA > 1:
-                bl = [o.Layer(self.wb[f"enc{i}"], None, relu=2, mask=masks[i - 1], save=dz[i - 1] if i > 1 else None)
-                      for i in range(nA - 1, 0, -1)]
-                o.mlp_chain(dz[nA - 1], bl, dz[0], tag=2)
+            # dz[L-1] -> ... -> dz[0]: the encoding carries no gradient, so the skip layer is just W_h^T here
+            if L > 1:
+                bl = [o.Layer(self.wb[f"enc{i}h" if i == s else f"enc{i}"], None, relu=2, mask=masks[i - 1], save=dz[i - 1] if i > 1 else None)
+                      for i in range(L - 1, 0, -1)]
+                o.mlp_chain(dz[L - 1], bl, dz[0], tag=2)
         with self._timed("trunk_wgrad"):
-            for i in range(L):
-                a = c["pe"] if i == 0 else (c["cat"] if i == s else acts[i - 1])
-                k = a.shape[1]
-                o.wgrad(a, dz[i], g[f"enc{i}.w"].view(1, k, W), g[f"enc{i}.b"].view(1, W), n_splits=nsp)
+            same = [(acts[i - 1], dz[i], g[f"enc{i}h.w" if i == s else f"enc{i}.w"].view(1, W, W), g[f"enc{i}.b"].view(1, W), None, None)
+                    for i in range(1, L)]
+            for i0 in range(0, len(same), 8):          # the W x W layers in one launch per 8
+                o.wgrad_batched(same[i0:i0 + 8], n_splits=nsp)
+            o.wgrad(c["pe"], dz[0], g["enc0.w"].view(1, self.KP, W), g["enc0.b"].view(1, W), n_splits=nsp)
+            if s is not None:
+                o.wgrad(c["pe"], dz[s], g[f"enc{s}p.w"].view(1, self.KP, W), None, n_splits=nsp)
 
     # ------------------------------------------------------------------------------------------ NeRF mirrors
     def set_no_batch(self, mode=True):

@@ -97,21 +97,6 @@ def gather_rows(src, index, out=None):
     return out
 
 
-def concat_cols(a, b, out):
-    """out[r] = [a[r] | b[r] | zeros]: the input of the dense NeRF's concat-skip layer (models/nerf.py:155-156)."""
-    assert a.shape[0] == b.shape[0] == out.shape[0] and a.dtype == b.dtype == out.dtype
-    es = a.element_size()
-    call("swn_concat_cols", _p(a), a.shape[1] * es, _p(b), b.shape[1] * es, a.shape[0], out.shape[1] * es, _p(out), _stream())
-    return out
-
-
-def slice_relu_bwd(src, col0, act, out):
-    """out = src[:, col0:col0+n] * (act > 0), act [R, n]: gradient of the concatenated hidden state through its ReLU."""
-    assert src.dtype == act.dtype == out.dtype and act.shape == out.shape and src.shape[0] == act.shape[0]
-    call("swn_slice_relu_bwd", _p(src), src.shape[1], col0, _p(act), act.shape[1], act.shape[0], _dt(src), _p(out), _stream())
-    return out
-
-
 def gate_fwd(g, ln_w, ln_b, wg):
     P, G = g.shape
     E = wg.shape[0]
@@ -372,7 +357,7 @@ class Layer:
     """One Linear of a chain: w = pack_weights(...) output (carries .swn_nk = (N, K)), b [n_wsets, N] f32 or None."""
 
     def __init__(self, w, b=None, relu=0, skip=False, save=None, mask=None, rowbias=None, rows_per_bias=0):
-        self.w, self.b, self.relu, self.skip, self.save, self.mask = w, b, int(relu), bool(skip), save, mask
+        self.w, self.b, self.relu, self.skip, self.save, self.mask = w, b, int(relu), int(skip), save, mask      # skip: 0 / 1 residual / 2 concat half
         self.rowbias, self.rows_per_bias = rowbias, int(rows_per_bias)
 
 

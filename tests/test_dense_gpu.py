@@ -24,20 +24,6 @@ def _model(dtype, seed, cfg=synth.DENSE):
     return m
 
 
-def test_concat_and_slice_kernels():
-    from switch_nerf_amd import ops
-    torch.manual_seed(0)
-    for dt in (torch.float32, torch.bfloat16):
-        a = torch.randn(1000, 128, device="cuda").to(dt)
-        b = torch.relu(torch.randn(1000, 256, device="cuda")).to(dt)
-        out = torch.full((1000, 512), 7.0, device="cuda").to(dt)
-        ops.concat_cols(a, b, out)
-        assert torch.equal(out, torch.cat([a, b, torch.zeros(1000, 128, device="cuda").to(dt)], 1))
-        src = torch.randn(1000, 512, device="cuda").to(dt)
-        got = ops.slice_relu_bwd(src, 128, b, torch.empty_like(b))
-        assert torch.equal(got, torch.where(b > 0, src[:, 128:384], torch.zeros_like(b)))
-
-
 def test_dense_train_step_vs_reference_golden_fp32():
     g = np.load(os.path.join(G, "dense_nerf_train.npz"))
     N, S = int(g["N"]), int(g["S"])
