@@ -232,20 +232,35 @@ class DenseNeRF(SwitchNeRF):
         pass
 
     def __call__(self, x, sigma_only=False, sigma_noise=None):
-        """NeRF.forward (nerf.py:143-190): x [P, 7] = xyz(3), dir(3), image index(1) -> [P, 4] (rgb, sigma), or
-        x [P, 3] with sigma_only -> [P, 1].  Inference only."""
-        if self.xyz_dim != 3:
-            raise NotImplementedError("xyz_dim 4 (the background model's inverted-sphere input) has no encoding kernel yet")
-        expected = 3 if sigma_only else 7
+        """NeRF.forward (nerf.py:143-190): x [P, xyz_dim + 3 + 1] = position, direction, image index -> [P, 4] (rgb, sigma), or
+        x [P, xyz_dim] with sigma_only -> [P, 1].  Inference only.  xyz_dim 4 (the background model called on explicit
+        inverted-sphere points): the points are encoded here on the host (BackgroundScene encodes them inside
+        swn_bg_sample_pe instead)."""
+        xd = self.xyz_dim
+        expected = xd if sigma_only else xd + 4
         if x.shape[1] != expected:
-            raise Exception("Unexpected input shape: {} (expected: {}, xyz_dim: {})".format(x.shape, expected, 3))
+            raise Exception("Unexpected input shape: {} (expected: {}, xyz_dim: {})".format(x.shape, expected, xd))
         P = x.shape[0]
         xf = x.to(torch.float32)
         if sigma_only:
             xf = torch.cat([xf, torch.zeros(P, 4, device=self.dev)], 1)
-            xf[:, 5] = 1.0
-        rays = torch.cat([xf[:, :6], torch.zeros(P, 2, device=self.dev)], 1).contiguous()
-        c = self.forward_rays(rays, xf[:, 6].long().contiguous(), 1, P, 0.0, None,
-                              None if sigma_noise is None else sigma_noise.reshape(-1).to(torch.float32).contiguous(),
-                              training=self.training, composite=False)
+            xf[:, xd + 2] = 1.0
+        noise = None if sigma_noise is None else sigma_noise.reshape(-1).to(torch.float32).contiguous()
+        img = xf[:, xd + 3].long().contiguous()
+        if xd == 3:
+            rays = torch.cat([xf[:, :6], torch.zeros(P, 2, device=self.dev)], 1).contiguous()
+            c = self.forward_rays(rays, img, 1, P, 0.0, None, noise, training=self.training, composite=False)
+        else:
+            pts = xf[:, :xd]
+            f = 2.0 ** torch.arange(self.cfg["pos_xyz_dim"], device=self.dev, dtype=torch.float32)
+            ang = pts[:, None, :] * f[:, None]                                             # [P, L, xd]
+            enc = torch.cat([pts, torch.stack([torch.sin(ang), torch.cos(ang)], 2).reshape(P, -1)], 1)   # nerf.py:21-26 order
+            pe = torch.zeros(P, self.KP, dtype=self.dtype, device=self.dev)
+            pe[:, : self.in_xyz] = enc.to(self.dtype)
+            rays = torch.cat([torch.zeros(P, 3, device=self.dev), xf[:, xd:xd + 3], torch.zeros(P, 2, device=self.dev)], 1).contiguous()
+            self._saving = bool(self.training)
+            try:
+                c = self._net_forward(pe, self._dir_pe(rays), img, P, 1, P, noise, None, False, "c")
+            finally:
+                self._saving = True
         return c["raw"][:, 3:4] if sigma_only else c["raw"]

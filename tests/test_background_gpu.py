@@ -212,3 +212,27 @@ def test_background_bf16_step_close_to_fp32_and_adam_updates_both():
         assert m.step_count == 1 and b.step_count == 1
     assert np.abs(out[torch.float32][0] - out[torch.bfloat16][0]).max() < 3e-2
     assert abs(out[torch.float32][1] - out[torch.bfloat16][1]) < 2e-2 * out[torch.float32][1]
+
+
+def test_background_model_call_mirror_on_explicit_points():
+    """NeRF.forward of the xyz_dim = 4 background model on explicit inverted-sphere points (nerf.py:143-190)."""
+    from switch_nerf_amd.dense import DenseNeRF
+    b = DenseNeRF(synth.DENSE_BG, dtype=torch.float32)
+    sd = synth.make_dense_weights(121, synth.DENSE_BG)
+    b.load_state_dict(sd)
+    b.eval()
+    rng = np.random.default_rng(122)
+    P = 555
+    p3 = rng.standard_normal((P, 3))
+    p3 /= np.linalg.norm(p3, axis=1, keepdims=True)
+    d = rng.standard_normal((P, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    x = np.concatenate([p3, rng.uniform(0.01, 1, (P, 1)), d, rng.integers(0, 10, (P, 1))], 1).astype(np.float32)
+    got = b(_dev(x)).cpu().numpy()
+    ref = O.nerf_dense_forward(O.params_from_numpy(sd), torch.from_numpy(x), synth.DENSE_BG).detach().numpy()
+    np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(got[:, 3], ref[:, 3], rtol=1e-4, atol=1e-4)
+    sig = b(_dev(x[:, :4]), sigma_only=True).cpu().numpy()
+    np.testing.assert_allclose(sig[:, 0], ref[:, 3], rtol=1e-4, atol=1e-4)
+    with pytest.raises(Exception, match="Unexpected input shape"):
+        b(_dev(x[:, :7]))
