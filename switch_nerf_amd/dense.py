@@ -85,13 +85,15 @@ class DenseNeRF(SwitchNeRF):
     def load_state_dict(self, sd):
         """Accepts the reference NeRF's state_dict (optionally with the DDP wrapper's `module.` prefix)."""
         from . import checkpoint
-        sd = checkpoint.strip_module_prefix(sd)
+        self._load_ref_layout(checkpoint.strip_module_prefix(sd), self.p)
+        self.refresh_compute_copies()
 
+    def _load_ref_layout(self, sd, p):
         def t(k):
             v = sd[k]
             v = torch.from_numpy(np.asarray(v)) if not torch.is_tensor(v) else v
             return v.detach().to(torch.float32).to(self.dev)
-        p, W, nx = self.p, self.M, self.in_xyz
+        W, nx = self.M, self.in_xyz
         with torch.no_grad():
             for i in range(self.L):
                 w = t(f"xyz_encodings.{i}.0.weight").t()            # [in, out]
@@ -114,7 +116,6 @@ class DenseNeRF(SwitchNeRF):
             p["color.w"].copy_(t("rgb.weight"))
             p["color.b"].copy_(t("rgb.bias"))
             p["emb"].copy_(t("embedding_a.weight"))
-        self.refresh_compute_copies()
 
     def _to_ref_layout(self, d):
         W, nx = self.M, self.in_xyz

@@ -144,13 +144,20 @@ class SwitchNeRF:
         the DDP wrapper, expertmlp stacking) or after the reference's convert_to_seqexperts (per-expert modules,
         models/model_utils.py:12-28); values torch or numpy.  See checkpoint.py."""
         from . import checkpoint
-        sd = checkpoint.to_expertmlp(sd)
+        self._load_ref_layout(checkpoint.to_expertmlp(sd), self.p)
+        self.refresh_compute_copies()
 
+    def _views(self, flat):
+        """name -> view dict over a flat buffer laid out like the parameters (gradients, Adam moments)."""
+        return {k: flat[o:o + int(np.prod(s))].view(s) for k, (o, s) in self.spec.items()}
+
+    def _load_ref_layout(self, sd, p):
+        """Inverse of _to_ref_layout: tensors keyed like the reference's state_dict -> the flat-buffer views `p`."""
         def t(k):
             v = sd[k]
             v = torch.from_numpy(np.asarray(v)) if not torch.is_tensor(v) else v
             return v.detach().to(torch.float32).to(self.dev)
-        p, M = self.p, self.M
+        M = self.M
         with torch.no_grad():
             p["xyz.w"].zero_()
             p["xyz.w"][: self.in_xyz] = t("layers.xyz.fcs.0.weight").t()
@@ -178,7 +185,6 @@ class SwitchNeRF:
             p["emb"].copy_(t("embedding_a.weight"))
             if self.hash is not None:
                 p["hash.table"].copy_(t("embedding_xyz.table"))
-        self.refresh_compute_copies()
 
     def _to_ref_layout(self, d):
         M = self.M

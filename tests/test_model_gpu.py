@@ -524,3 +524,58 @@ def test_training_reduces_the_loss(dtype):
     print(f"{dtype}: photo loss {first:.4f} -> {last:.4f}")
     assert last < 0.35 * first, (first, last)
     assert torch.isfinite(m.flat).all() and m.step_count == 80
+
+
+def test_checkpoint_file_roundtrip_with_adam_state(tmp_path):
+    """Runner._save_checkpoint format (runner.py:2799-2818): parameters + torch.optim.Adam state in the reference's
+    parameter order.  A fresh pair of models restored from the file continues bit-identically; the saved optimizer state
+    loads into a real torch.optim.Adam over tensors in the reference order and its next step equals ours."""
+    from switch_nerf_amd import checkpoint
+    from switch_nerf_amd.model import SwitchNeRF
+    from switch_nerf_amd.dense import DenseNeRF
+    from switch_nerf_amd.background import BackgroundScene
+    N, S, chunk = 128, 64, 2048
+    rays, img, rgbs = synth.make_bg_rays(181, N)
+    C_, R_ = synth.SPHERE_CENTER, synth.SPHERE_RADIUS
+
+    def fresh(seed):
+        return SwitchNeRF(synth.BUILDING, dtype=torch.float32, seed=seed), DenseNeRF(synth.DENSE_BG, dtype=torch.float32, seed=seed + 1)
+    m, b = fresh(5)
+    scene = BackgroundScene(m, b, C_, R_)
+    for _ in range(3):
+        scene.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0)
+    path = str(tmp_path / "3.pt")
+    checkpoint.save_checkpoint(path, m, b, iteration=3)
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) >= {"model_state_dict", "bg_model_state_dict", "optimizers", "iteration"} and ck["iteration"] == 3
+    assert all(k.startswith("module.") for k in ck["model_state_dict"])
+    m2, b2 = fresh(77)
+    assert checkpoint.load_checkpoint(path, m2, b2) == 3
+    assert torch.equal(m2.flat, m.flat) and torch.equal(m2.m, m.m) and torch.equal(m2.v, m.v) and m2.step_count == 3
+    assert torch.equal(b2.flat, b.flat) and torch.equal(b2.v, b.v) and b2.step_count == 3
+    o1 = scene.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0)
+    o2 = BackgroundScene(m2, b2, C_, R_).train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0)
+    assert torch.equal(o1["rgb"], o2["rgb"]) and o1["loss"].item() == o2["loss"].item()
+    np.testing.assert_allclose(m2.flat.cpu().numpy(), m.flat.cpu().numpy(), rtol=0, atol=1e-7)   # (atomics order in the weight gradients)
+    # the reference side: torch.optim.Adam over the parameters in module order, state loaded from the file
+    m3, _ = fresh(5)
+    checkpoint.load_checkpoint(path, m3)
+    sd = {k: v.clone() for k, v in m3.state_dict().items()}
+    order = checkpoint.param_order(sd.keys())
+    params = [torch.nn.Parameter(sd[k].cpu()) for k in order]
+    opt = torch.optim.Adam(params, lr=m3.lr)
+    osd = opt.state_dict()
+    osd.update(ck["optimizers"]["nerf"])
+    opt.load_state_dict(osd)
+    m3.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0, optimizer_step=False)      # gradients only
+    gd = m3.grad_dict()
+    for k, p in zip(order, params):
+        p.grad = gd[k].cpu().clone()
+    opt.step()
+    ops_adam = m3
+    ops_adam.step_count += 1
+    from switch_nerf_amd import ops as O_
+    O_.adam_step(m3.flat, m3.grad, m3.m, m3.v, None, m3.step_count, m3.lr)
+    new = m3.state_dict()
+    for k, p in zip(order, params):
+        np.testing.assert_allclose(new[k].cpu().numpy(), p.detach().numpy(), rtol=0, atol=2e-6, err_msg=k)
