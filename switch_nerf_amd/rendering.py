@@ -146,3 +146,30 @@ def render_rays_mip(nerf, rays: torch.Tensor, radii: torch.Tensor, image_indices
         if cf is not None:
             res["moe_gates_fine"] = cf["idx"].long().view(N, F - 1, 1, 1)
     return res, False
+
+
+def render_image_rays(nerf, bg_nerf, rays: torch.Tensor, image_index, hparams, sphere_center=None, sphere_radius=None,
+                      radii: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """The pixel-batch loop of Runner.render_image / render_image_blocknerf (/root/reference/switch_nerf/runner.py:2835-2885,
+    :2887-2950) over rays that are already built ([R, 8], R = H * W; ray construction from camera metadata is dataset code):
+    batches of hparams.image_pixel_batch_size rays through render_rays (or render_rays_mip when radii are given) with
+    get_depth=True, get_depth_variance=False, get_bg_fg_rgb=True, results concatenated on the host like the reference.
+    The last batch of an image - and the last model chunk inside a batch - may be ragged."""
+    R = rays.shape[0]
+    rays = rays.reshape(-1, 8)
+    idx = None
+    if getattr(hparams, "appearance_dim", 1) > 0:
+        idx = image_index if torch.is_tensor(image_index) and image_index.numel() == R else \
+            torch.full((R,), int(image_index), dtype=torch.long, device=rays.device)
+    results: Dict[str, list] = {}
+    step = int(hparams.image_pixel_batch_size)
+    for i in range(0, R, step):
+        r = rays[i:i + step].contiguous()
+        ii = None if idx is None else idx[i:i + step].contiguous()
+        if radii is not None:
+            batch, _ = render_rays_mip(nerf, r, radii.reshape(-1, 1)[i:i + step].contiguous(), ii, hparams, True, False)
+        else:
+            batch, _ = render_rays(nerf, bg_nerf, r, ii, hparams, sphere_center, sphere_radius, True, False, True)
+        for k, v in batch.items():
+            results.setdefault(k, []).append(v.cpu())
+    return {k: torch.cat(v) for k, v in results.items()}

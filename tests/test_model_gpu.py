@@ -579,3 +579,26 @@ def test_checkpoint_file_roundtrip_with_adam_state(tmp_path):
     new = m3.state_dict()
     for k, p in zip(order, params):
         np.testing.assert_allclose(new[k].cpu().numpy(), p.detach().numpy(), rtol=0, atol=2e-6, err_msg=k)
+
+
+def test_render_image_rays_loop_with_ragged_batches():
+    """Runner.render_image's pixel-batch loop: 1000 rays in batches of 384 (last batch 232 rays, its last model chunk ragged),
+    eval mode, against the oracle evaluated batch by batch with the same chunking."""
+    from argparse import Namespace
+    from switch_nerf_amd import rendering
+    R, S, chunk, pb = 1000, 64, 4096, 384
+    sd = synth.make_weights(191, synth.BUILDING, gate_scale=0.02)
+    rays, _, _ = synth.make_rays(192, R)
+    m = _model(torch.float32, 191, 0.02)
+    m.eval()
+    h = Namespace(coarse_samples=S, fine_samples=0, model_chunk_size=chunk, perturb=1.0, use_sigma_noise=True, sigma_noise_std=1.0,
+                  use_cascade=False, image_pixel_batch_size=pb, appearance_dim=48, moe_return_gates=False)
+    res = rendering.render_image_rays(m, None, _dev(rays), 7, h)
+    assert res["rgb_coarse"].shape == (R, 3) and res["depth_coarse"].shape == (R,) and not res["rgb_coarse"].is_cuda
+    p = O.params_from_numpy(sd)
+    img = torch.full((R,), 7, dtype=torch.long)
+    with torch.no_grad():
+        ref = torch.cat([O.render_rays(p, torch.from_numpy(rays[i:i + pb]), img[i:i + pb], synth.BUILDING, S, chunk)["rgb_coarse"]
+                         for i in range(0, R, pb)])
+    np.testing.assert_allclose(res["rgb_coarse"].numpy(), ref.numpy(), rtol=0, atol=1e-4)
+    assert res["gate_loss_coarse"].numel() == 6 + 6 + 4        # chunks per batch: 6, 6, 3 full + 1 ragged
