@@ -186,6 +186,28 @@ template <typename T, int COLS> struct Row16 {
       }
     }
   }
+  // the same in two halves, so that the next row's 16-byte loads can be in flight while this row is processed
+  static __device__ __forceinline__ void load_raw(const T* row, int j, uint4* raw) {
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) raw[q] = *(const uint4*)(row + (j + 16 * q) * EPC);
+  }
+  static __device__ __forceinline__ void unpack(const uint4* raw, float* x) {
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const uint4 u = raw[q];
+      if constexpr (sizeof(T) == 2) {
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          x[q * 8 + 2 * i] = bf16_to_f32((bf16_t)(w[i] & 0xFFFF));
+          x[q * 8 + 2 * i + 1] = bf16_to_f32((bf16_t)(w[i] >> 16));
+        }
+      } else {
+        x[q * 4 + 0] = __uint_as_float(u.x); x[q * 4 + 1] = __uint_as_float(u.y);
+        x[q * 4 + 2] = __uint_as_float(u.z); x[q * 4 + 3] = __uint_as_float(u.w);
+      }
+    }
+  }
   static __device__ __forceinline__ void store(T* row, int j, const float* x) {
 #pragma unroll
     for (int q = 0; q < NCH; ++q) {
@@ -227,9 +249,12 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const T* __restrict__ g, 
   __syncthreads();
   const long gid = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
   const long ngr = ((long)gridDim.x * 256) >> 4;
+  uint4 nxt[R::NCH];
+  if (gid < P) R::load_raw(g + gid * G, j, nxt);
   for (long tok = gid; tok < P; tok += ngr) {
     float x[VPL];
-    R::load(g + tok * G, j, x);
+    R::unpack(nxt, x);
+    if (tok + ngr < P) R::load_raw(g + (tok + ngr) * G, j, nxt);     // next row in flight during this row's arithmetic
     float mean = 0.f, rstd = 1.f;
     if (ln_w) {  // torch.nn.LayerNorm, eps 1e-5 (models/nerf_moe.py:301-302)
       float s = 0.f;

@@ -18,3 +18,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+import pytest
+
+
+@pytest.fixture(autouse=True)
+def _seed_torch():
+    """Every test starts from the same torch RNG state (a few tests draw stratified jitter with torch.rand)."""
+    import torch
+    torch.manual_seed(1234)
+    yield
