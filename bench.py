@@ -96,7 +96,7 @@ def main():
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    local = int(os.environ.get("SWN_FORCE_DEVICE", os.environ.get("LOCAL_RANK", 0)))     # (override: several ranks on one GPU, for testing)
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -104,7 +104,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         from switch_nerf_amd import parallel
-        parallel.init_from_env("nccl", dev)
+        parallel.init_from_env(os.environ.get("SWN_DIST_BACKEND", "nccl"), dev)       # "nccl" = RCCL; gloo only for single-GPU tests of this path
 
     from switch_nerf_amd.model import SwitchNeRF, BUILDING
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32

@@ -1,0 +1,34 @@
+"""bench.py's multi-rank flow on a real GPU: two ranks share cuda:0 and talk over gloo (RCCL needs one GPU per rank; the
+collectives are backend-agnostic torch.distributed calls).  Data parallel and expert parallel must train identically:
+routing is rank-local and the parameters stay replicated, so after two optimizer steps both modes report the same loss."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(parallelism, port):
+    env = dict(os.environ, SWN_DIST_BACKEND="gloo", SWN_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--rays", "1024",
+           "--parallelism", parallelism, "--no-events"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, printed by rank 0"
+    return json.loads(lines[0])
+
+
+def test_two_ranks_dp_and_ep_agree():
+    dp = _run("dp", 29561)
+    ep = _run("ep", 29562)
+    assert dp["n_gpus"] == ep["n_gpus"] == 2 and dp["config"]["parallelism"] == "dp2" and ep["config"]["parallelism"] == "ep2"
+    assert dp["scaling"] == "weak" and dp["cpu_baseline"] is None
+    assert abs(dp["config"]["loss"] - ep["config"]["loss"]) <= 2e-5 * abs(dp["config"]["loss"]) + 1e-6
+    assert abs(dp["config"]["kept_token_fraction"] - ep["config"]["kept_token_fraction"]) < 1e-3
+    assert dp["value"] > 0 and ep["value"] > 0
