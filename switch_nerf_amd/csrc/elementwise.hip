@@ -408,47 +408,75 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ g, 
 }
 
 // d_wg[e][c] += sum_tok dlogits[tok][e] * xn[tok][c]   (xn recomputed from g and the LayerNorm statistics)
-// block = G threads (one per column); a wave loads dlogits/stats of 64 tokens once (one token per lane) and
-// broadcasts them with v_readlane while every lane streams its own column of g.
-template <typename T, int E>
-__global__ void gate_dwg_kernel(const T* __restrict__ g, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-                                const float* __restrict__ stats, const float* __restrict__ dlogits, int P, int G,
-                                int tok_per_block, float* __restrict__ d_wg) {
-  const int c = threadIdx.x, lane = threadIdx.x & 63;
-  const float w = ln_w ? ln_w[c] : 1.f, b = ln_w ? ln_b[c] : 0.f;
-  float acc[E];
+// block = 256 threads = SG token sub-groups x LPT lanes; a lane owns one 16-byte chunk of the row (8 bf16 / 4 fp32 columns), so a
+// sub-group reads a token's row as one contiguous run; each sub-group walks its tokens with UNR rows in flight and keeps
+// E x VPT accumulators; the sub-groups are summed with LDS atomics and the block issues one global atomic per (expert, column).
+template <typename T, int E, int G>
+__global__ __launch_bounds__(256) void gate_dwg_kernel(const T* __restrict__ g, const float* __restrict__ ln_w,
+                                                       const float* __restrict__ ln_b, const float* __restrict__ stats,
+                                                       const float* __restrict__ dlogits, int P, int tok_per_block,
+                                                       float* __restrict__ d_wg) {
+  constexpr int VPT = 16 / (int)sizeof(T);     // columns per lane
+  constexpr int LPT = G / VPT;                 // lanes per token
+  constexpr int SG = 256 / LPT;                // token sub-groups per block
+  constexpr int UNR = 4;
+  static_assert(LPT <= 256 && 256 % LPT == 0, "gate width");
+  __shared__ float red[E * G];
+  const int lane = threadIdx.x % LPT, sg = threadIdx.x / LPT;
+  const int c0 = lane * VPT;
+  float w[VPT], bb[VPT];
 #pragma unroll
-  for (int e = 0; e < E; ++e) acc[e] = 0.f;
+  for (int v = 0; v < VPT; ++v) { w[v] = ln_w ? ln_w[c0 + v] : 1.f; bb[v] = ln_w ? ln_b[c0 + v] : 0.f; }
+  for (int t = threadIdx.x; t < E * G; t += 256) red[t] = 0.f;
+  float acc[E][VPT];
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) acc[e][v] = 0.f;
   const long t0 = (long)blockIdx.x * tok_per_block;
   const long t1 = min((long)P, t0 + tok_per_block);
-  for (long tb = t0; tb < t1; tb += 64) {
-    const long mytok = min(tb + lane, (long)P - 1);
-    float dl[E], mu = 0.f, rs = 1.f;
+  for (long tb = t0 + sg; tb < t1; tb += (long)SG * UNR) {
+    uint4 raw[UNR];
+    float dl[UNR][E], mu[UNR], rs[UNR];
 #pragma unroll
-    for (int e4 = 0; e4 < E / 4; ++e4) {
-      const float4 v = *(const float4*)(dlogits + mytok * E + e4 * 4);
-      dl[e4 * 4] = v.x; dl[e4 * 4 + 1] = v.y; dl[e4 * 4 + 2] = v.z; dl[e4 * 4 + 3] = v.w;
+    for (int u = 0; u < UNR; ++u) {            // all loads of the UNR tokens first
+      const long tok = min(tb + (long)u * SG, (long)P - 1);
+      raw[u] = *(const uint4*)(g + tok * G + c0);
+#pragma unroll
+      for (int e4 = 0; e4 < E / 4; ++e4) {
+        const float4 v = *(const float4*)(dlogits + tok * E + e4 * 4);
+        dl[u][e4 * 4] = v.x; dl[u][e4 * 4 + 1] = v.y; dl[u][e4 * 4 + 2] = v.z; dl[u][e4 * 4 + 3] = v.w;
+      }
+      mu[u] = 0.f; rs[u] = 1.f;
+      if (ln_w) { const float2 st = *(const float2*)(stats + tok * 2); mu[u] = st.x; rs[u] = st.y; }
     }
-    if (ln_w) { const float2 st = *(const float2*)(stats + mytok * 2); mu = st.x; rs = st.y; }
-    const int nt = (int)min(64L, t1 - tb);
-    float xv[64];
 #pragma unroll
-    for (int t = 0; t < 64; ++t)      // 64 independent loads in flight (rows past the end re-read the last row)
-      xv[t] = ElemIO<T>::ld(g + min(tb + t, (long)P - 1) * G + c);
+    for (int u = 0; u < UNR; ++u) {
+      const bool live = tb + (long)u * SG < t1;
+      float x[VPT];
+      if constexpr (sizeof(T) == 2) {
+        const uint32_t ww[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
 #pragma unroll
-    for (int t = 0; t < 64; ++t) {
-      float x = xv[t];
-      // v_readlane (SGPR broadcast) instead of __shfl (ds_bpermute): t is a compile-time constant after unrolling
-      const float m_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu), t));
-      const float r_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs), t));
-      if (ln_w) x = (x - m_) * r_ * w + b;
-      x = t < nt ? x : 0.f;
+        for (int i = 0; i < 4; ++i) { x[2 * i] = bf16_to_f32((bf16_t)(ww[i] & 0xFFFF)); x[2 * i + 1] = bf16_to_f32((bf16_t)(ww[i] >> 16)); }
+      } else {
+        x[0] = __uint_as_float(raw[u].x); x[1] = __uint_as_float(raw[u].y); x[2] = __uint_as_float(raw[u].z); x[3] = __uint_as_float(raw[u].w);
+      }
 #pragma unroll
-      for (int e = 0; e < E; ++e) acc[e] += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl[e]), t)) * x;
+      for (int v = 0; v < VPT; ++v) {
+        float xn = ln_w ? (x[v] - mu[u]) * rs[u] * w[v] + bb[v] : x[v];
+        xn = live ? xn : 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e][v] += dl[u][e] * xn;
+      }
     }
   }
+  __syncthreads();
 #pragma unroll
-  for (int e = 0; e < E; ++e) unsafeAtomicAdd(d_wg + (long)e * G + c, acc[e]);
+  for (int e = 0; e < E; ++e)
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) atomicAdd(red + e * G + c0 + v, acc[e][v]);
+  __syncthreads();
+  for (int t = threadIdx.x; t < E * G; t += 256) unsafeAtomicAdd(d_wg + t, red[t]);
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch / combine
@@ -1001,6 +1029,21 @@ extern "C" int swn_gate_fwd(const void* g, int dtype, const float* ln_w, const f
   return 0;
 }
 
+#define DWG_LAUNCH(T, EV, GV, GP)                                                                                  \
+  hipLaunchKernelGGL((gate_dwg_kernel<T, EV, GV>), dim3(dwg_blocks), dim3(256), 0, as_stream(stream), GP, ln_w, ln_b, stats, \
+                     dlogits, n_tokens, tpb, d_wg)
+#define DWG_DISPATCH(T, GP)                                                                                         \
+  do {                                                                                                              \
+    if (gate_dim == 256 && n_experts == 8) DWG_LAUNCH(T, 8, 256, GP);                                               \
+    else if (gate_dim == 256 && n_experts == 16) DWG_LAUNCH(T, 16, 256, GP);                                        \
+    else if (gate_dim == 256 && n_experts == 4) DWG_LAUNCH(T, 4, 256, GP);                                          \
+    else if (gate_dim == 128 && n_experts == 8) DWG_LAUNCH(T, 8, 128, GP);                                          \
+    else if (gate_dim == 128 && n_experts == 4) DWG_LAUNCH(T, 4, 128, GP);                                          \
+    else if (gate_dim == 512 && n_experts == 16) DWG_LAUNCH(T, 16, 512, GP);                                        \
+    else if (gate_dim == 512 && n_experts == 8) DWG_LAUNCH(T, 8, 512, GP);                                          \
+    else return swn::set_error("gate dW: unsupported gate_dim %d / experts %d", gate_dim, n_experts);              \
+  } while (0)
+
 extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg,
                             const float* gates, const int32_t* idx, const float* d_gmax, const float* stats,
                             const int32_t* counts, const float* laux_coef, int seg_tokens, int n_tokens, int gate_dim,
@@ -1019,30 +1062,14 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
     GATE_DISPATCH(bf16_t, gate_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, gates, idx, d_gmax,
                   stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dgp, dlogits, d_ln_w, d_ln_b);
     SWN_CHECK(n_experts == 4 || n_experts == 8 || n_experts == 16, "swn_gate_bwd: experts must be 4, 8 or 16");
-    if (n_experts == 8)
-      hipLaunchKernelGGL((gate_dwg_kernel<bf16_t, 8>), dim3(dwg_blocks), dim3(gate_dim), 0, as_stream(stream), gp, ln_w, ln_b, stats,
-                         dlogits, n_tokens, gate_dim, tpb, d_wg);
-    else if (n_experts == 16)
-      hipLaunchKernelGGL((gate_dwg_kernel<bf16_t, 16>), dim3(dwg_blocks), dim3(gate_dim), 0, as_stream(stream), gp, ln_w, ln_b, stats,
-                         dlogits, n_tokens, gate_dim, tpb, d_wg);
-    else
-      hipLaunchKernelGGL((gate_dwg_kernel<bf16_t, 4>), dim3(dwg_blocks), dim3(gate_dim), 0, as_stream(stream), gp, ln_w, ln_b, stats,
-                         dlogits, n_tokens, gate_dim, tpb, d_wg);
+    DWG_DISPATCH(bf16_t, gp);
   } else {
     const float* gp = (const float*)g;
     float* dgp = (float*)dg;
     GATE_DISPATCH(float, gate_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, gates, idx, d_gmax,
                   stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dgp, dlogits, d_ln_w, d_ln_b);
     SWN_CHECK(n_experts == 4 || n_experts == 8 || n_experts == 16, "swn_gate_bwd: experts must be 4, 8 or 16");
-    if (n_experts == 8)
-      hipLaunchKernelGGL((gate_dwg_kernel<float, 8>), dim3(dwg_blocks), dim3(gate_dim), 0, as_stream(stream), gp, ln_w, ln_b, stats,
-                         dlogits, n_tokens, gate_dim, tpb, d_wg);
-    else if (n_experts == 16)
-      hipLaunchKernelGGL((gate_dwg_kernel<float, 16>), dim3(dwg_blocks), dim3(gate_dim), 0, as_stream(stream), gp, ln_w, ln_b, stats,
-                         dlogits, n_tokens, gate_dim, tpb, d_wg);
-    else
-      hipLaunchKernelGGL((gate_dwg_kernel<float, 4>), dim3(dwg_blocks), dim3(gate_dim), 0, as_stream(stream), gp, ln_w, ln_b, stats,
-                         dlogits, n_tokens, gate_dim, tpb, d_wg);
+    DWG_DISPATCH(float, gp);
   }
   SWN_LAUNCH_CHECK();
   return 0;
