@@ -36,6 +36,13 @@
 #define SWN_NS swn
 #endif
 #define SWN_AUX (SWN_WIDE || SWN_CONCAT)      // an auxiliary build: kernels + launcher only, no C entry points
+// -DSWN_EXP_TIMING: s_memtime phase timers of wave 0 of the first 4096 workgroups, written through d.y_add_gather (reinterpreted
+// as int64 [4096][8]; scripts/chain_timing.py).  Default build only; off = no code.
+#if defined(SWN_EXP_TIMING) && !SWN_AUX
+#define SWN_TIMING_ON 1
+#else
+#define SWN_TIMING_ON 0
+#endif
 
 namespace SWN_NS {
 using namespace swn;
@@ -470,6 +477,10 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
   __syncthreads();
 
   f32x16_t acc[MI][NI];
+#if SWN_TIMING_ON
+  long long tk = 0, tb1 = 0, tep = 0, tb2 = 0, two = 0, tstart = __builtin_amdgcn_s_memtime();
+#define TICK() __builtin_amdgcn_s_memtime()
+#endif
 
 #if SWN_CONCAT
   // K loop of entry Lx: no barrier.  (Waves beyond the layer width run it too on a clamped stream - keeps the ring logic
@@ -545,11 +556,20 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
     if (steps == 512 / KSTEP) k_loop<T, 512 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
     else
 #endif
+#if SWN_TIMING_ON
+    long long q0 = TICK();
+#endif
     if (steps == 256 / KSTEP) k_loop<T, 256 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
     else if (steps == 128 / KSTEP) k_loop<T, 128 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
     else k_loop<T, 64 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
+#if SWN_TIMING_ON
+    long long q1 = TICK();
+#endif
 
     __syncthreads();   // every wave has finished reading the activation tile of this layer
+#if SWN_TIMING_ON
+    long long q2 = TICK();
+#endif
 
 #endif
     if (ly.skip) {  // the input tile is dead: bring the chain input x back into the SAME LDS tile; each lane then reads
@@ -570,7 +590,14 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
       epilogue_body<T, true, 0, false, false, false>(acc, act, bias_lds, rbp, mk, wn, l31e, lhie, nvalid, grow0, ly.rows_per_bias, n,
                                                      ly.relu, ly.skip == 1, ly.b != nullptr, rows_in_tile);
     }
+#if SWN_TIMING_ON
+    long long q3 = TICK();
+#endif
     __syncthreads();
+#if SWN_TIMING_ON
+    long long q4 = TICK();
+    tk += q1 - q0; tb1 += q2 - q1; tep += q3 - q2; tb2 += q4 - q3;
+#endif
     if (has_next) stage_bias(L + 1);   // read after the next layer's post-K-loop barrier
 
     // ---- write-out (row-major, coalesced) ----
@@ -598,7 +625,16 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
       }
     }
     // no barrier needed here: the next layer only reads `act` until its own post-K-loop barrier.
+#if SWN_TIMING_ON
+    two += TICK() - q4;
+#endif
   }
+#if SWN_TIMING_ON
+  if (d.y_add_gather && tid == 0 && blockIdx.x < 4096) {
+    long long* dbg = (long long*)d.y_add_gather + (long)blockIdx.x * 8;
+    dbg[0] = tk; dbg[1] = tb1; dbg[2] = tep; dbg[3] = tb2; dbg[4] = two; dbg[5] = TICK() - tstart; dbg[6] = tstart;
+  }
+#endif
 }
 
 #if !SWN_AUX
@@ -644,7 +680,10 @@ static int chain_launch(const swn_chain_desc& d, void* stream) {
   if (!d.group_rows) a.d.group_rows_clamp = d.group_stride;
   const long grid = (long)a.tiles_per_group * d.n_groups;
   SWN_CHECK(grid > 0 && grid < (1L << 31), "swn_mlp_chain: grid %ld out of range", grid);
-  const int lds = (d.dtype == SWN_BF16 ? Cfg<bf16_t>::ACT : Cfg<float>::ACT) + ROW_ELEMS * 4;
+  int lds = (d.dtype == SWN_BF16 ? Cfg<bf16_t>::ACT : Cfg<float>::ACT) + ROW_ELEMS * 4;
+#ifdef SWN_EXP_LDSPAD
+  lds += SWN_EXP_LDSPAD;      // experiment: fewer resident workgroups per CU (scripts/chain_timing.py)
+#endif
   const void* fn = nullptr;
 #define SWN_PICK(TAGV)                                                                         \
   case TAGV:                                                                                   \
