@@ -421,13 +421,13 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
   const int l31 = lane & 31, lhi = lane >> 5;
 
   // workgroup -> (group, tile).  Workgroups are dealt round-robin to the 8 XCDs, and group g uses weight set g % n_wsets:
-  // with 8 weight sets XCD x works on expert x (its L2 holds that expert's weights) either way; the "sequential" mapping
+  // with a multiple of 8 weight sets XCD x works on the experts e = x (mod 8) (its L2 holds their weights) either way; the "sequential" mapping
   // additionally lets the workgroups that are resident together on an XCD walk CONSECUTIVE tiles of one group, so that their
   // save stores form a few long sequential streams per buffer instead of hundreds of scattered 32 KiB bursts.
   int g = blockIdx.x % d.n_groups;
   int tile = blockIdx.x / d.n_groups;
 #ifndef SWN_NO_SEQ_TILES
-  if (d.n_wsets == 8 && (d.n_groups & 7) == 0) {
+  if ((d.n_wsets & 7) == 0 && (d.n_groups & 7) == 0) {
     const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int s_ = q / args.tiles_per_group;
     tile = q - s_ * args.tiles_per_group;
