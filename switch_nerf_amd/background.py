@@ -157,11 +157,21 @@ class BackgroundScene:
         loss = photo + nerf.wt * gate_loss
         d_rgb = (diff * (2.0 / diff.numel())).contiguous()
         self.backward(ctx, d_rgb, nerf.wt * (0.5 if fine else 1.0), nerf.wt * 0.5)
+        # the reference skips the background optimizer on batches without background rays (runner.py:683: `if key == 'bg_nerf'
+        # and not bg_nerf_rays_present: continue`): no Adam step, no moment decay, no step-counter increment.  Under data
+        # parallelism the flag is the OR over the ranks (every rank still joins the gradient all-reduce).
+        bg_present = ctx["Nb"] > 0
+        if grad_allreduce is not None:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                flag = torch.tensor([1.0 if bg_present else 0.0], device=self.dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                bg_present = bool(flag.item() > 0)
         for m in (nerf, bg):
             scale = grad_allreduce(m.grad) if grad_allreduce is not None else 1.0
-            if optimizer_step:
+            if optimizer_step and (m is nerf or bg_present):
                 m.step_count += 1
                 ops.adam_step(m.flat, m.grad, m.m, m.v, None, m.step_count, m.lr, grad_scale=scale)
                 m.refresh_compute_copies()
         return dict(loss=loss, photo_loss=photo, gate_loss=gate_loss, psnr=-10.0 * torch.log10(photo), rgb=ctx["rgb"],
-                    depth=ctx["depth"], depth_variance=ctx["depth_variance"].mean(), ctx=ctx)
+                    depth=ctx["depth"], depth_variance=ctx["depth_variance"].mean(), ctx=ctx, bg_nerf_rays_present=bg_present)

@@ -129,14 +129,20 @@ def adam_state_dict(model) -> dict:
     if model.step_count > 0:
         for i, k in enumerate(order):
             state[i] = {"step": torch.tensor(float(model.step_count)), "exp_avg": m[k].detach().cpu(), "exp_avg_sq": v[k].detach().cpu()}
-    group = dict(lr=model.lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
-                 capturable=False, differentiable=False, fused=None, params=list(range(len(order))))
+    # 'initial_lr' = the undecayed base rate: the reference rebuilds ExponentialLR(optimizer, last_epoch=iteration - 1) on resume
+    # (runner.py:505-510), which raises KeyError without it; 'lr' = the rate of the current iteration
+    group = dict(lr=model.lr, initial_lr=getattr(model, "base_lr", model.lr), betas=(0.9, 0.999), eps=1e-8, weight_decay=0,
+                 amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                 params=list(range(len(order))))
     return {"state": state, "param_groups": [group]}
 
 
 def load_adam_state_dict(model, osd: dict) -> None:
     order = param_order(model._to_ref_layout(model.p).keys())
     st = osd.get("state", {})
+    grp = osd["param_groups"][0] if osd.get("param_groups") else {}
+    model.lr = float(grp.get("lr", model.lr))
+    model.base_lr = float(grp.get("initial_lr", getattr(model, "base_lr", model.lr)))
     if not st:
         model.m.zero_(); model.v.zero_(); model.step_count = 0
         return
@@ -145,7 +151,12 @@ def load_adam_state_dict(model, osd: dict) -> None:
     model._load_ref_layout(m, model._views(model.m))
     model._load_ref_layout(v, model._views(model.v))
     model.step_count = int(float(st[0]["step"]))
-    model.lr = float(osd["param_groups"][0].get("lr", model.lr))
+
+
+def exponential_lr(base_lr: float, iteration: int, lr_decay_factor: float = 0.1, train_iterations: int = 500000) -> float:
+    """The rate torch's ExponentialLR(gamma = lr_decay_factor ** (1 / train_iterations)) holds after `iteration` scheduler
+    steps (runner.py:505-512): base_lr * lr_decay_factor ** (iteration / train_iterations).  SwitchNeRF.set_iteration applies it."""
+    return float(base_lr) * float(lr_decay_factor) ** (float(iteration) / float(train_iterations))
 
 
 def save_checkpoint(path, nerf, bg_nerf=None, iteration: int = 0, dataset_index: int = 0, module_prefix: bool = True) -> dict:
@@ -164,7 +175,9 @@ def save_checkpoint(path, nerf, bg_nerf=None, iteration: int = 0, dataset_index:
 
 def load_checkpoint(path_or_dict, nerf, bg_nerf=None) -> int:
     """Restores parameters and Adam moments from a checkpoint written by either side; returns its iteration."""
-    ck = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location="cpu")
+    # weights_only=False: the reference's Runner._save_checkpoint (runner.py:2799-2818) also pickles numpy / python RNG states
+    # ('np_random_state', 'random_state'), which torch >= 2.6's default weights_only=True refuses; these are the user's own files
+    ck = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location="cpu", weights_only=False)
     nerf.load_state_dict(ck["model_state_dict"])
     if "optimizers" in ck and "nerf" in ck["optimizers"]:
         load_adam_state_dict(nerf, ck["optimizers"]["nerf"])

@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const T* __restrict__ y,
     const float4 r = *(const float4*)(raw + i * 4);
     const float4 d = *(const float4*)(d_raw + i * 4);
     const float dc0 = d.x * r.x * (1.f - r.x), dc1 = d.y * r.y * (1.f - r.y), dc2 = d.z * r.z * (1.f - r.z);
-    const float dsp = d.w * (1.f - expf(-r.w));  // softplus'(u) = sigmoid(u) = 1 - exp(-softplus(u))
+    const float dsp = d.w * -expm1f(-r.w);  // softplus'(u) = sigmoid(u) = 1 - exp(-softplus(u)); expm1: no cancellation for near-empty samples
     if (j == 0) {
       dsig[i] = dsp;
       abs_ += dsp; abc[0] += dc0; abc[1] += dc1; abc[2] += dc2;

@@ -44,6 +44,7 @@ class SwitchNeRF:
                  batch_prioritized=True, moe_l_aux_wt=5e-4, lr=5e-4, seed=0):
         self.cfg, self.dtype, self.dev = dict(cfg), dtype, torch.device(device)
         self.cf, self.bpr, self.wt, self.lr = capacity_factor, batch_prioritized, moe_l_aux_wt, lr
+        self.base_lr = lr             # undecayed rate ('initial_lr' of the reference's ExponentialLR); self.lr = the current rate
         spec = self._configure(cfg)
         self.spec, off = {}, 0
         for name, shape in spec:
@@ -612,7 +613,7 @@ class SwitchNeRF:
 
     # ------------------------------------------------------------------------------------------ mip path
     def forward_level_mip(self, rays, radii, image_indices, z, seg_tokens, sigma_noise=None, no_batch=False, tag="c",
-                          want_weights=False, rgb_padding=0.001, pe_dir=None):
+                          want_weights=False, rgb_padding=0.001, pe_dir=None, training=True):
         """One level of rendering_mip._get_results (rendering_mip.py:195-215 / :236-253): the S edges `z` of every ray give
         S - 1 conical frustums; integrated positional encoding (swn_mip_encode) -> the same network (MipNeRFMoE.forward is
         NeRFMoE.forward behind MipEmbedder, nerf_moe.py:675-810) -> compositing at the frustum mid points with the colour
@@ -622,7 +623,11 @@ class SwitchNeRF:
         if pe_dir is None:
             pe_dir = self._dir_pe(rays)
         seg = min(seg_tokens, N * S1)
-        c = self._net_forward(pe, pe_dir, image_indices, N, S1, seg, sigma_noise, None, no_batch, tag)
+        self._saving = bool(training)      # inference: no activation saves / ReLU masks (like forward_rays)
+        try:
+            c = self._net_forward(pe, pe_dir, image_indices, N, S1, seg, sigma_noise, None, no_batch, tag)
+        finally:
+            self._saving = True
         c["z_edges"] = z
         c["z"] = (0.5 * (z[:, 1:] + z[:, :-1])).contiguous()
         c["rgb_padding"] = float(rgb_padding)
@@ -631,23 +636,29 @@ class SwitchNeRF:
         return c
 
     def forward_mip(self, rays, radii, image_indices, n_samples, n_fine, seg_tokens, perturb=0.0, perturb_rand=None, fine_u=None,
-                    sigma_noise=None, sigma_noise_fine=None, no_batch=False, rgb_padding=0.001, resample_padding=0.01):
+                    sigma_noise=None, sigma_noise_fine=None, no_batch=False, rgb_padding=0.001, resample_padding=0.01,
+                    training=True, fine_randomized=None):
         """rendering_mip.render_rays (rendering_mip.py:133-172): coarse level on n_samples edges, then (n_fine > 0) the fine
         level on n_fine edges resampled from the blurred coarse weights (stop_level_grad: no gradient through the edges).
         fine_u: the U[0,1) tensor [N, n_fine] of sorted_piecewise_constant_pdf1's randomized branch (drawn here if perturb > 0
-        and none is given); perturb = 0 -> deterministic."""
+        and none is given); perturb = 0 -> deterministic.  fine_randomized (default: perturb > 0) decouples the fine level's
+        randomisation from the coarse jitter: the reference resamples with randomized=hparams.perturb even in eval mode
+        (rendering_mip.py:227) while its coarse jitter is off there (:147).  training=False skips the activation saves."""
         N = rays.shape[0]
+        if fine_randomized is None:
+            fine_randomized = perturb > 0
         t_steps = torch.linspace(0, 1, n_samples, dtype=torch.float32).to(self.dev)
         radii = radii.reshape(-1).contiguous()
         z = ops.sample_z(rays, t_steps, perturb_rand, perturb, n_samples)
-        c = self.forward_level_mip(rays, radii, image_indices, z, seg_tokens, sigma_noise, no_batch, "c", n_fine > 0, rgb_padding)
+        c = self.forward_level_mip(rays, radii, image_indices, z, seg_tokens, sigma_noise, no_batch, "c", n_fine > 0, rgb_padding,
+                                   training=training)
         if n_fine <= 0:
             return c, None
-        if fine_u is None and perturb > 0:
+        if fine_u is None and fine_randomized:
             fine_u = torch.rand(N, n_fine, device=self.dev)
-        z_f = ops.mip_resample(z, c["weights"], fine_u if perturb > 0 else None, n_fine, resample_padding)
+        z_f = ops.mip_resample(z, c["weights"], fine_u if fine_randomized else None, n_fine, resample_padding)
         cf = self.forward_level_mip(rays, radii, image_indices, z_f, seg_tokens, sigma_noise_fine, no_batch, "f", False, rgb_padding,
-                                    pe_dir=c["pe_dir"])
+                                    pe_dir=c["pe_dir"], training=training)
         return c, cf
 
     def train_step_mip(self, rgbs, rays, radii, image_indices, n_samples, n_fine, seg_tokens, perturb=1.0, perturb_rand=None,
@@ -681,6 +692,13 @@ class SwitchNeRF:
         top = levels[0]
         return dict(loss=loss, photo_loss=photo, gate_loss=gate_loss, psnr=-10.0 * torch.log10(((top["rgb"] - rgbs) ** 2).mean()),
                     depth_variance=top["depth_variance"].mean(), ctx=c, ctx_fine=cf, rgb=top["rgb"], depth=top["depth"])
+
+    def set_iteration(self, iteration: int, lr_decay_factor: float = 0.1, train_iterations: int = 500000):
+        """Learning-rate schedule hook = the reference's ExponentialLR(gamma = lr_decay_factor ** (1 / train_iterations)) stepped
+        once per iteration (runner.py:505-512, 688-693): the rate the step of `iteration` (0-based) uses."""
+        from . import checkpoint
+        self.lr = checkpoint.exponential_lr(self.base_lr, iteration, lr_decay_factor, train_iterations)
+        return self.lr
 
     # ------------------------------------------------------------------------------------------ NeRFMoE mirrors
     training = True

@@ -132,7 +132,8 @@ def render_rays_mip(nerf, rays: torch.Tensor, radii: torch.Tensor, image_indices
         image_indices = torch.zeros(N, dtype=torch.long, device=rays.device)
     c, cf = nerf.forward_mip(rays.contiguous(), radii, image_indices, S, F, chunk, float(perturb), pr, None, noise, noise_f,
                              no_batch=nerf.moe_no_batch, rgb_padding=float(getattr(hparams, "rgb_padding", 0.001) or 0.0),
-                             resample_padding=float(getattr(hparams, "weights_resample_padding", 0.01)))
+                             resample_padding=float(getattr(hparams, "weights_resample_padding", 0.01)), training=nerf.training,
+                             fine_randomized=bool(hparams.perturb))      # rendering_mip.py:227: randomized=hparams.perturb, also in eval
     res = {"rgb_coarse": c["rgb"], "gate_loss_coarse": c["l_aux"]}
     top, typ = (c, "coarse") if cf is None else (cf, "fine")
     if cf is not None:
