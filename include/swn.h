@@ -27,6 +27,7 @@ extern "C" {
 
 #define SWN_F32 0
 #define SWN_BF16 1
+#define SWN_F16 2   /* half precision compute copies (BASELINE configs[4]: fp16 MFMA); 256-row chain geometry */
 
 const char* swn_last_error(void);
 int swn_version(void);
@@ -266,6 +267,8 @@ typedef struct swn_chain_desc {
   void* y;                      /* output rows, row-major [*, n_last] dtype                       */
   const void* y_add;            /* row-major [*, n_last] tensor added to the output rows (skip gradient) or NULL */
   const int32_t* y_add_gather;  /* row -> row of y_add (-1 = nothing to add), or NULL (identity)  */
+  int32_t geometry;             /* 0 = automatic; 1 = force the 64-row tile kernels (chain.hip); 2 = force the 256-row kernel
+                                   (chain_big.hip: 256 x 256 layers, bf16 / fp16, no rowbias / x_scale / x_save / y_add_gather) */
   int32_t tag;                  /* profiling only: selects an identical kernel instantiation with its own symbol so that
                                    rocprofv3 reports the roles separately (0 generic, 1 expert fwd, 2 expert bwd,
                                    3 front fwd, 4 tail fwd, 5 tail bwd, 6 front bwd)                 */

@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libswn_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
@@ -29,7 +29,7 @@ class HashCfg(C.Structure):
 class ChainDesc(C.Structure):
     _fields_ = [("dtype", i32), ("n_layers", i32), ("n_groups", i32), ("n_wsets", i32), ("group_stride", i32),
                 ("group_rows", vp), ("group_rows_clamp", i32), ("x", vp), ("x_gather", vp), ("x_save", vp), ("x_scale", vp), ("x_relu", i32),
-                ("y", vp), ("y_add", vp), ("y_add_gather", vp), ("tag", i32), ("layers", ChainLayer * 12)]
+                ("y", vp), ("y_add", vp), ("y_add_gather", vp), ("geometry", i32), ("tag", i32), ("layers", ChainLayer * 12)]
 
 
 # name -> argtypes; every symbol declared in include/swn.h must be listed here (tests/test_abi.py checks both ways)

@@ -7,7 +7,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="${SWN_DEFS:-} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-variable -Wno-unused-but-set-variable -ffp-contract=fast-honor-pragmas"
 mkdir -p "$HERE/build"
 pids=()
-for f in elementwise route chain wgrad sampling mip bounds hashgrid; do
+for f in elementwise route chain chain_big wgrad sampling mip bounds hashgrid; do
   if [ ! -f "$HERE/build/$f.o" ] || [ "$f.hip" -nt "$HERE/build/$f.o" ] || [ common.hpp -nt "$HERE/build/$f.o" ] || [ pe_store.hpp -nt "$HERE/build/$f.o" ] || [ ../../include/swn.h -nt "$HERE/build/$f.o" ]; then
     $HIPCC $FLAGS -c $f.hip -o "$HERE/build/$f.o" &
     pids+=($!)
@@ -24,5 +24,5 @@ if [ ! -f "$HERE/build/chain_cat.o" ] || [ chain.hip -nt "$HERE/build/chain_cat.
   pids+=($!)
 fi
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC "$HERE"/build/{elementwise,route,chain,chain_wide,chain_cat,wgrad,sampling,mip,bounds,hashgrid}.o -o "$HERE/libswn_hip.so"
+$HIPCC --offload-arch=gfx950 -shared -fPIC "$HERE"/build/{elementwise,route,chain,chain_big,chain_wide,chain_cat,wgrad,sampling,mip,bounds,hashgrid}.o -o "$HERE/libswn_hip.so"
 echo "built $HERE/libswn_hip.so"

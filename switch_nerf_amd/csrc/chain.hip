@@ -21,6 +21,7 @@
 // with 4 consecutive output FEATURES of one row, so the epilogue packs them and writes the next layer's input tile
 // row-major with 8-byte LDS stores.
 #include "common.hpp"
+#include <stdlib.h>
 
 #ifndef SWN_WIDE
 #define SWN_WIDE 0
@@ -753,14 +754,15 @@ extern "C" int swn_chain_tile_rows(int dtype) { return dtype == SWN_BF16 ? Cfg<b
 /* uint32 words of one ReLU mask buffer for a chain over n_groups x group_stride rows whose widest layer has max_width features */
 extern "C" long swn_chain_mask_words(int dtype, int n_groups, int group_stride, int max_width) {
   const bool wide = max_width > 256;
-  const int bm = wide ? chain_wide_tile_rows(dtype) : swn_chain_tile_rows(dtype);
+  int bm = wide ? chain_wide_tile_rows(dtype) : swn_chain_tile_rows(dtype);
+  if (!wide && dtype != SWN_F32) bm = 256;     // covers the 64-row and the 256-row (chain_big.hip) geometry alike
   return (long)cdiv(group_stride, bm) * n_groups * bm * (wide ? 16 : 8);
 }
 
 extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   SWN_CHECK(desc != nullptr, "swn_mlp_chain: null descriptor");
   const swn_chain_desc& d = *desc;
-  SWN_CHECK(d.dtype == SWN_F32 || d.dtype == SWN_BF16, "swn_mlp_chain: bad dtype %d", d.dtype);
+  SWN_CHECK(d.dtype == SWN_F32 || d.dtype == SWN_BF16 || d.dtype == SWN_F16, "swn_mlp_chain: bad dtype %d", d.dtype);
   SWN_CHECK(d.n_layers >= 1 && d.n_layers <= SWN_MAX_CHAIN_LAYERS, "swn_mlp_chain: n_layers %d not in [1,%d]", d.n_layers, SWN_MAX_CHAIN_LAYERS);
   SWN_CHECK(d.n_groups >= 1 && d.n_wsets >= 1 && d.group_stride >= 1, "swn_mlp_chain: bad group geometry");
   bool wide = false, concat = false;
@@ -786,6 +788,14 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   SWN_CHECK(d.x != nullptr && d.y != nullptr, "swn_mlp_chain: x / y must not be null");
   SWN_CHECK(d.tag >= 0 && d.tag <= 6, "swn_mlp_chain: tag %d not in [0,6]", d.tag);
   SWN_CHECK(!(wide && concat), "swn_mlp_chain: concat-skip layers are built for the 256-feature kernels only");
+  SWN_CHECK(d.geometry >= 0 && d.geometry <= 2, "swn_mlp_chain: geometry %d not in [0,2]", d.geometry);
+  {   // 256-row geometry (chain_big.hip): chains of 256 x 256 layers over groups of at least one full tile
+    const bool can = chain_big_eligible(d);
+    SWN_CHECK(d.geometry != 2 || can, "swn_mlp_chain: geometry 2 needs bf16 / fp16 chains of 256 x 256 layers without rowbias / x_scale / x_save / y_add_gather");
+    SWN_CHECK(d.dtype != SWN_F16 || can, "swn_mlp_chain: fp16 chains run on the 256-row geometry only (256 x 256 layers)");
+    static const int big_default = [] { const char* e = getenv("SWN_CHAIN_BIG"); return e ? atoi(e) : 1; }();
+    if (can && (d.geometry == 2 || d.dtype == SWN_F16 || (d.geometry == 0 && big_default && d.group_stride >= 256))) return chain_big_launch(d, stream);
+  }
   if (wide) return chain_wide_launch(d, stream);        // 512-feature geometry (this file compiled with -DSWN_WIDE=1)
   if (concat) return chain_concat_launch(d, stream);    // concat-skip layers (this file compiled with -DSWN_CONCAT=1)
   return chain_launch(d, stream);

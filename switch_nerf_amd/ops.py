@@ -373,10 +373,12 @@ def chain_mask_words(dtype, n_groups: int, group_stride: int, max_width: int = 2
 
 def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride=None, group_rows=None,
               group_rows_clamp=None, x_gather=None, x_save=None, y_add=None, y_add_gather=None, tag=0, x_scale=None,
-              x_relu=False):
+              x_relu=False, geometry=0):
+    """geometry: 0 automatic, 1 the 64-row tile kernels, 2 the 256-row kernel (include/swn.h)."""
     d = ChainDesc()
     d.dtype = _dt(x)
     d.tag = int(tag)
+    d.geometry = int(geometry)
     d.n_layers = len(layers)
     d.n_groups, d.n_wsets = int(n_groups), int(n_wsets)
     d.group_stride = int(group_stride if group_stride is not None else y.shape[0])
