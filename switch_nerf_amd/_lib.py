@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libswn_hip.so")
+LIB_PATH = os.environ.get("SWN_LIB") or os.path.join(_HERE, "libswn_hip.so")      # (SWN_LIB: A/B builds of the library, experiments only)
 
 F32, BF16, F16 = 0, 1, 2
 

@@ -48,6 +48,18 @@ struct Args {
   int tiles_per_group;
 };
 
+// -DSWN_BIG_TIMING: s_memtime phase timers of wave 0 of the first 4096 workgroups, written through d.y_add_gather (reinterpreted as
+// int64 [4096][8]: K-loop waits, K-loop barriers, K loops, epilogues, post-K barrier + restage, prologue, write-out, total;
+// scripts/chain_big_check.py timing).  Off = no code.
+#ifdef SWN_BIG_TIMING
+#define TICK() __builtin_amdgcn_s_memtime()
+struct Timers { long long wait = 0, bar = 0, kloop = 0, epi = 0, mid = 0, pro = 0, wout = 0; };
+#define SWN_TM(x) x
+#else
+#define SWN_TM(x)
+struct Timers {};
+#endif
+
 // element type: packs / unpacks two features per dword and picks the MFMA
 struct Bf16 {
   static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
@@ -77,6 +89,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, in
   return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
+#ifndef SWN_BIG_STORE_AUX
+#define SWN_BIG_STORE_AUX 2       // cache policy of the activation stores (1 = sc0, 2 = nt, 16 = sc1)
+#endif
 #define SWN_PIN() __builtin_amdgcn_sched_barrier(0)
 #define SWN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define SWN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -87,110 +102,203 @@ struct Ctx {
   int w, lane, l31, lhi;
   uint32_t a_base;       // LDS byte address of this lane's activation-fragment row (mi = 0) incl. the swizzle seed; ^ (ks << 5) per step
   uint32_t e_base;       // ... of this lane's epilogue row incl. swizzle seed, half-wave and wave feature offset; ^ ((4 ni + g4) << 4)
+  uint32_t e2_base;      // the same for the 16-byte writes after the half-wave exchange: chunk g4 + lhi, no 8-byte half offset
   uint32_t wf_base;      // RING0 + this wave's first feature tile + lane * 16 (add the slot offset)
-  uint32_t wo_base;      // write-out: LDS byte address of this lane's 16 bytes of chunk (ks = 0); + ks * 8192
+  uint32_t wo_base;      // write-out of the chain output (all 8 waves): LDS byte address of this lane's 16 bytes of piece j = 0; + j * 8192
+  uint32_t wos_base[2];  // write-out inside the K loop (store waves 4..7, two pieces per step): ... of piece (ks = 0, i); + ks * 8192
   int slot_off[3];       // byte offset of the ring slot of K step (16 L + j), j mod 3 - refreshed per layer
 };
 
 // ---- the K loop of one layer ------------------------------------------------------------------------------------------------
-// SAVE: the input tile of this layer is written out (1 KiB per wave and K step) through rs_save.
+// Roles (vmcnt completes in order per wave, so a wave that both copies weights and stores activations can keep only ~2 stores in
+// flight behind the copy it waits for - far too few bytes to cover the HBM write latency):
+//   COPY  (waves 0..3): two weight copies per K step (feature tiles 2 w, 2 w + 1), counted wait for the copies of step ks + 1;
+//   STORE (waves 4..7): two 1 KiB pieces of the write-out per K step (SAVE: the input tile of this layer is a saved activation),
+//                       never waits for its stores - up to 63 of them in flight per wave.
+// One wave of each role per SIMD.
 template <typename E, bool SAVE>
 __device__ __forceinline__ void k_loop(f32x16_t (&acc)[4][2], const Ctx& cx, __amdgpu_buffer_rsrc_t rs_cur, __amdgpu_buffer_rsrc_t rs_nxt,
-                                       __amdgpu_buffer_rsrc_t rs_save) {
+                                       __amdgpu_buffer_rsrc_t rs_save, const bool COPY /* wave-uniform */, Timers& tm) {
   char* smem = cx.smem;
   const int lane16 = cx.lane * 16;
+  const bool STORE = SAVE && !COPY;
   u32x4_t fa[2][4], fw[2][2];
-  u32x4_t wo = {0u, 0u, 0u, 0u};
-  auto read_frags = [&](int ks, int set) {
-    const uint32_t ab = cx.a_base ^ (uint32_t)(ks << 5);
-    const uint32_t wb = cx.wf_base + cx.slot_off[ks % 3];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) fw[set][ni] = *(const u32x4_t*)(smem + wb + ni * 1024);
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) fa[set][mi] = *(const u32x4_t*)(smem + ab + mi * (32 * ROWB));
+  u32x4_t wo[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+  // launder the per-lane bases: stops the compiler from hoisting the 16 swizzled fragment addresses (and friends) of the unrolled
+  // steps out of the layer loop into long-lived registers (spills next to 128 accumulators)
+  uint32_t a_base = cx.a_base, wf_base = cx.wf_base;
+  asm volatile("" : "+v"(a_base), "+v"(wf_base));
+  auto read_w = [&](int ks, int set, int ni) {
+    fw[set][ni] = *(const u32x4_t*)(smem + wf_base + cx.slot_off[ks % 3] + ni * 1024);
   };
-  read_frags(0, 0);
+  auto read_a = [&](int ks, int set, int mi) {
+    fa[set][mi] = *(const u32x4_t*)(smem + (a_base ^ (uint32_t)(ks << 5)) + mi * (32 * ROWB));
+  };
+  auto copy = [&](int ks, int i) {     // feature tile 2 w + i of K step ks + 3 of the stream -> the slot of step ks
+    const int nx = ks + 3, t = 2 * cx.w + i;
+    if (nx < KSTEPS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_cur, SWN_LDS(smem + RING0 + cx.slot_off[nx % 3] + t * 1024), 16, lane16, (t * KSTEPS + nx) * 1024, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_nxt, SWN_LDS(smem + RING0 + cx.slot_off[nx % 3] + t * 1024), 16, lane16, (t * KSTEPS + nx - KSTEPS) * 1024, 0, 0);
+  };
+  auto store = [&](int ks, int i) {    // piece (ks, wave, i) of the write-out: rows 16 ks + 4 (w - 4) + 2 i + {0, 1}
+    __builtin_amdgcn_raw_buffer_store_b128(wo[i], rs_save, lane16, (ks * 8 + 2 * (cx.w - 4) + i) * 1024, SWN_BIG_STORE_AUX);
+  };
+  read_w(0, 0, 0); read_w(0, 0, 1);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) read_a(0, 0, mi);
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
-    const int cur = ks & 1;
-    SWN_WAIT_LGKM0();                       // the fragments of step ks (and the write-out piece read in step ks - 1) are in registers
-    if constexpr (SAVE) SWN_WAIT_VM(2); else SWN_WAIT_VM(1);   // this wave's copy of step ks + 1 has landed (in-order counter: every
-                                                               // step issues [store,] copy - see the header)
+    const int cur = ks & 1, nxt = cur ^ 1;
+    const bool more = ks + 1 < KSTEPS;
+    SWN_TM(const long long q0 = TICK();)
+    SWN_WAIT_LGKM0();                       // the fragments of step ks (and the write-out pieces read in step ks - 1) are in registers
+    if (COPY) SWN_WAIT_VM(2);               // this wave's copies of step ks + 1 have landed (younger: the two copies of step ks + 2)
+    SWN_TM(const long long q1 = TICK();)
     __builtin_amdgcn_s_barrier();           // ... and everybody else's; every wave is done reading the slot of step ks
+    SWN_TM(const long long q2 = TICK(); tm.wait += q1 - q0; tm.bar += q2 - q1;)
     SWN_PIN();
-    if constexpr (SAVE) {                   // (first: the piece was read a step ago, no LDS read of this step is pending yet)
-      if (ks >= 1) __builtin_amdgcn_raw_buffer_store_b128(wo, rs_save, lane16, ((ks - 1) * 8 + cx.w) * 1024, 0);
-    }
+    // The matrix pipe starts at once; the LDS reads of the next step, the copies of step ks + 3 / the stores of the previous
+    // write-out pieces and the reads of this step's pieces are spread between the MFMAs (order pinned).
+#define SWN_MM(mi, ni) acc[mi][ni] = E::mfma(fw[cur][ni], fa[cur][mi], acc[mi][ni])
+    SWN_MM(0, 0);
     SWN_PIN();
-    if (ks + 1 < KSTEPS) read_frags(ks + 1, cur ^ 1);
-    {   // copy of K step (ks + 3) of the stream into the slot of step ks: this wave's feature tile, 1 KiB
-      const int nx = ks + 3;
-      if (nx < KSTEPS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_cur, SWN_LDS(smem + RING0 + cx.slot_off[nx % 3] + cx.w * 1024), 16, lane16, nx * 1024, 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_nxt, SWN_LDS(smem + RING0 + cx.slot_off[nx % 3] + cx.w * 1024), 16, lane16, (nx - KSTEPS) * 1024, 0, 0);
-    }
-    if constexpr (SAVE) wo = *(const u32x4_t*)(smem + cx.wo_base + ks * 8192);
+    if (more) { read_w(ks + 1, nxt, 0); read_w(ks + 1, nxt, 1); }
     SWN_PIN();
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = E::mfma(fw[cur][ni], fa[cur][mi], acc[mi][ni]);
-    }
+    SWN_MM(0, 1);
+    SWN_PIN();
+    if (more) read_a(ks + 1, nxt, 0);
+    if (COPY) copy(ks, 0);
+    else if (SAVE && ks >= 1) store(ks - 1, 0);
+    SWN_PIN();
+    SWN_MM(1, 0);
+    SWN_PIN();
+    if (more) read_a(ks + 1, nxt, 1);
+    if (COPY) copy(ks, 1);
+    else if (SAVE && ks >= 1) store(ks - 1, 1);
+    SWN_PIN();
+    SWN_MM(1, 1);
+    SWN_PIN();
+    if (more) read_a(ks + 1, nxt, 2);
+    SWN_PIN();
+    SWN_MM(2, 0);
+    SWN_PIN();
+    if (more) read_a(ks + 1, nxt, 3);
+    SWN_PIN();
+    SWN_MM(2, 1);
+    SWN_PIN();
+    if (STORE) wo[0] = *(const u32x4_t*)(smem + cx.wos_base[0] + ks * 8192);
+    SWN_PIN();
+    SWN_MM(3, 0);
+    SWN_PIN();
+    if (STORE) wo[1] = *(const u32x4_t*)(smem + cx.wos_base[1] + ks * 8192);
+    SWN_PIN();
+    SWN_MM(3, 1);
+#undef SWN_MM
     SWN_PIN();
   }
-  if constexpr (SAVE) {
+  if (STORE) {
     SWN_WAIT_LGKM0();
-    __builtin_amdgcn_raw_buffer_store_b128(wo, rs_save, lane16, ((KSTEPS - 1) * 8 + cx.w) * 1024, 0);
+    store(KSTEPS - 1, 0);
+    store(KSTEPS - 1, 1);
   }
 }
 
 // ---- epilogue of one layer: accumulators (+bias, +skip input) -> ReLU (recording the mask) / stored mask -> the tile, in place ----
 // A lane owns row 128 rg + 32 mi + l31 and, per (ni, g4), features 64 fg + 32 ni + 8 g4 + 4 lhi .. + 3.
-// Mask layout: 128 bits per lane and layer = one dword per mi; value e = ni * 16 + g4 * 4 + j sits at bit 31 - e.
+// A non-packed VALU instruction costs a wave 4 clocks on CDNA4 (16 lanes per clock), an MFMA 32: ~5 VALU per value were as
+// expensive as the K loop.  ReLU and its mask therefore work on the PACKED 16-bit results (two values per instruction; bf16 and
+// fp16 are sign-magnitude, so as int16 a negative value or -0 is < 0):
+//   forward:  p = cvt_pk(z0, z1);  p = pk_max_i16(p, 0)  [ReLU];  q = pk_min_u16(p, 1)  [1 where the output is > 0];  m |= q << d
+//   backward: t = pk_min_u16(m & (0x00010001 << d), 1);  p = pk_mul_lo_u16(cvt_pk(g0, g1), t)
+// The mask bit is (rounded output > 0) - what the reference's autocast ReLU backward tests - and equals (z > 0) unless
+// 0 < z < 2^-134.  Mask layout: 128 bits per lane and layer = one dword per mi; packed dword d = ni * 8 + g4 * 2 + i of that mi
+// has its low half at bit d, its high half at bit d + 16.
+// The half-waves exchange 8-byte pieces (v_permlane32_swap) so that a lane writes one whole 16-byte chunk: ds_write_b128 into the
+// swizzled tile is conflict-free, the 8-byte form is 2-way conflicted.
+typedef __attribute__((ext_vector_type(2))) short i16x2_t;
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t_;
+__device__ __forceinline__ uint32_t pk_relu16(uint32_t p) {
+  const i16x2_t z = {0, 0};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, p), z));
+}
+// (inline asm: hipcc rewrites the vector-extension forms of these two into compare / select / v_perm sequences of five instructions)
+__device__ __forceinline__ uint32_t pk_nonzero16(uint32_t p) {      // 0 / 1 per half: min(half, 1) unsigned
+  uint32_t q;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(q) : "v"(p), "s"(0x00010001u));
+  return q;
+}
+__device__ __forceinline__ uint32_t pk_mul16(uint32_t p, uint32_t t) {
+  uint32_t q;
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(q) : "v"(p), "v"(t));
+  return q;
+}
+
 template <typename E, int RELU, bool BIAS, bool SKIP>
 __device__ __forceinline__ void epilogue(f32x16_t (&acc)[4][2], const Ctx& cx, u32x4_t& mk) {
   char* smem = cx.smem;
+  uint32_t e_base = cx.e_base, e2_base = cx.e2_base;      // laundered: keeps the swizzled addresses inside the layer loop (see k_loop)
+  asm volatile("" : "+v"(e_base), "+v"(e2_base));
+  f32x4_t bias[2][4];
+  if constexpr (BIAS) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+        bias[ni][g4] = *(const f32x4_t*)(smem + BIAS0 + (((cx.w & 3) * 64 + 32 * ni + 8 * g4 + 4 * cx.lhi) << 2));
+  }
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
+    u32x2_t xv[2][4];
+    if constexpr (SKIP) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          xv[ni][g4] = *(const u32x2_t*)(smem + (e_base ^ (uint32_t)((4 * ni + g4) << 4)) + mi * (32 * ROWB));
+    }
     uint32_t mbits = (RELU == 2) ? mk[mi] : 0u;
+    u32x2_t pk[2][4];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        const uint32_t addr = (cx.e_base ^ (uint32_t)((4 * ni + g4) << 4)) + mi * (32 * ROWB);
-        float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][g4 * 4 + j];
-        if constexpr (BIAS) {
-          // bias of features 64 fg + 32 ni + 8 g4 + 4 lhi ..: e_base's feature part is not needed, rebuild the index
-          const f32x4_t b4 = *(const f32x4_t*)(smem + BIAS0 + (((cx.w & 3) * 64 + 32 * ni + 8 * g4 + 4 * cx.lhi) << 2));
-          v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
-        }
-        if constexpr (SKIP) {
-          const u32x2_t xv = *(const u32x2_t*)(smem + addr);
-          v[0] += E::lo(xv[0]); v[1] += E::hi(xv[0]); v[2] += E::lo(xv[1]); v[3] += E::hi(xv[1]);
-        }
-        if constexpr (RELU == 1) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const bool pos = v[j] > 0.f;
-            mbits = (mbits << 1) | (pos ? 1u : 0u);
-            v[j] = pos ? v[j] : 0.f;
+        for (int i = 0; i < 2; ++i) {
+          f32x2_t_ v = {acc[mi][ni][g4 * 4 + 2 * i], acc[mi][ni][g4 * 4 + 2 * i + 1]};
+          if constexpr (BIAS) {
+            const f32x2_t_ b2 = {bias[ni][g4][2 * i], bias[ni][g4][2 * i + 1]};
+            v += b2;
           }
-        } else if constexpr (RELU == 2) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int e = ni * 16 + g4 * 4 + j;
-            v[j] = ((mbits >> (31 - e)) & 1u) ? v[j] : 0.f;
+          if constexpr (SKIP) {
+            const f32x2_t_ x2 = {E::lo(xv[ni][g4][i]), E::hi(xv[ni][g4][i])};
+            v += x2;
           }
+          uint32_t p = E::pack2(v[0], v[1]);
+          const int d = ni * 8 + g4 * 2 + i;
+          if constexpr (RELU == 1) {
+            p = pk_relu16(p);
+            mbits |= pk_nonzero16(p) << d;
+          } else if constexpr (RELU == 2) {
+            p = pk_mul16(p, pk_nonzero16(mbits & (0x00010001u << d)));
+          }
+          pk[ni][g4][i] = p;
         }
-        u32x2_t pk;
-        pk[0] = E::pack2(v[0], v[1]);
-        pk[1] = E::pack2(v[2], v[3]);
-        *(u32x2_t*)(smem + addr) = pk;
-        SWN_PIN();                            // one group at a time: small register footprint
       }
     }
     if constexpr (RELU == 1) mk[mi] = mbits;
+    if constexpr (SKIP) SWN_PIN();          // every read of the residual rows of this mi is consumed before the tile rows are rewritten
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        // lower half-wave ends up with chunk g (features 8 g .. 8 g + 7 of its row), the upper one with chunk g + 1
+        auto r0 = __builtin_amdgcn_permlane32_swap(pk[ni][g][0], pk[ni][g + 1][0], false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(pk[ni][g][1], pk[ni][g + 1][1], false, false);
+        const u32x4_t o = {(uint32_t)r0[0], (uint32_t)r1[0], (uint32_t)r0[1], (uint32_t)r1[1]};
+        *(u32x4_t*)(smem + (e2_base ^ (uint32_t)((4 * ni + g) << 4)) + mi * (32 * ROWB)) = o;
+      }
+    }
+    SWN_PIN();                              // one row tile at a time: bounded register footprint
   }
 }
 
@@ -255,14 +363,21 @@ __global__ __launch_bounds__(NT, 2) void chainb_kernel(const Args args) {
 
   cx.a_base = (uint32_t)((128 * rg + cx.l31) * ROWB + ((cx.lhi ^ r15) << 4));
   cx.e_base = (uint32_t)((128 * rg + cx.l31) * ROWB + (r15 << 4) + 8 * cx.lhi) ^ (uint32_t)(fg << 7);
+  cx.e2_base = (uint32_t)((128 * rg + cx.l31) * ROWB + (r15 << 4)) ^ (uint32_t)((fg << 7) | (cx.lhi << 4));
   cx.wf_base = (uint32_t)(RING0 + (2 * fg) * 1024 + cx.lane * 16);
   cx.wo_base = (uint32_t)((2 * cx.w + cx.lhi) * ROWB + ((cx.l31 ^ ((2 * cx.w + cx.lhi) & 15)) << 4));
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = 4 * (cx.w & 3) + 2 * i + cx.lhi;
+    cx.wos_base[i] = (uint32_t)(r * ROWB + ((cx.l31 ^ (r & 15)) << 4));
+  }
   const int lane16 = cx.lane * 16;
+  const bool copy_role = cx.w < 4;
 
-  // this wave's weight-fragment stream of layer L: feature tile w, 16 K steps of 1 KiB
+  // the weight-fragment stream of layer L, weight set `wset`: 8 feature tiles x 16 K steps of 1 KiB
   auto wrs = [&](int L) -> __amdgpu_buffer_rsrc_t {
-    const char* p = (const char*)d.layers[L].w + ((size_t)wset * 8 + cx.w) * (KSTEPS * 1024);
-    return uniform_rsrc(p, KSTEPS * 1024);
+    const char* p = (const char*)d.layers[L].w + (size_t)wset * 8 * (KSTEPS * 1024);
+    return uniform_rsrc(p, 8 * KSTEPS * 1024);
   };
   auto out_rs = [&](void* base) -> __amdgpu_buffer_rsrc_t {     // rows of this tile in a row-major [*, 256] tensor, clipped to the valid rows
     return uniform_rsrc((char*)base + grow0 * ROWB, rows_in_tile * ROWB);
@@ -275,13 +390,14 @@ __global__ __launch_bounds__(NT, 2) void chainb_kernel(const Args args) {
     }
   };
 
+  SWN_TM(const long long t_start = TICK();)
   // ---- prologue: weight ring (steps 0..2 of layer 0), source rows, input tile, bias ----
   cx.slot_off[0] = 0; cx.slot_off[1] = SLOT_B; cx.slot_off[2] = 2 * SLOT_B;
   {
     const __amdgpu_buffer_rsrc_t r0 = wrs(0);
 #pragma unroll
     for (int s = 0; s < 3; ++s)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, SWN_LDS(smem + RING0 + s * SLOT_B + cx.w * 1024), 16, lane16, s * 1024, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, SWN_LDS(smem + RING0 + s * SLOT_B + cx.w * 1024), 16, lane16, (cx.w * KSTEPS + s) * 1024, 0, 0);
   }
   if (tid < BM) {
     const long gr = grow0 + (tid < rows_in_tile ? tid : 0);      // rows past the end repeat the first row (computed, never stored)
@@ -297,6 +413,8 @@ __global__ __launch_bounds__(NT, 2) void chainb_kernel(const Args args) {
   __builtin_amdgcn_s_barrier();
 
   f32x16_t acc[4][2];
+  Timers tm;
+  SWN_TM(long long t_a = t_start;)
   for (int L = 0; L < n_layers; ++L) {
     const swn_chain_layer& ly = d.layers[L];
     const bool has_next = (L + 1) < n_layers;
@@ -319,8 +437,10 @@ __global__ __launch_bounds__(NT, 2) void chainb_kernel(const Args args) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    if (save_in) k_loop<E, true>(acc, cx, rs_cur, rs_nxt, out_rs(save_in));
-    else k_loop<E, false>(acc, cx, rs_cur, rs_nxt, rs_cur);
+    SWN_TM(const long long p0 = TICK(); if (L == 0) tm.pro = p0 - t_a;)
+    if (save_in) k_loop<E, true>(acc, cx, rs_cur, rs_nxt, out_rs(save_in), copy_role, tm);
+    else k_loop<E, false>(acc, cx, rs_cur, rs_nxt, rs_cur, copy_role, tm);
+    SWN_TM(const long long p1 = TICK(); tm.kloop += p1 - p0;)
 
     SWN_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();       // every wave has finished reading the tile (fragments and write-out)
@@ -329,12 +449,17 @@ __global__ __launch_bounds__(NT, 2) void chainb_kernel(const Args args) {
       SWN_WAIT_VM(0);
       __builtin_amdgcn_s_barrier();
     }
+    SWN_TM(const long long p2 = TICK(); tm.mid += p2 - p1;)
     epilogue_dispatch<E>(acc, cx, mk, ly.relu, ly.b != nullptr, ly.skip != 0);
     if (ly.relu == 1 && mkp) *(u32x4_t*)mkp = mk;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // copies of the next steps landed long ago; the tile is rewritten
+    SWN_WAIT_LGKM0();                   // the tile is rewritten
+    if (copy_role) SWN_WAIT_VM(0);      // the copies of the next layer's first steps landed long ago (store waves: nothing to wait for,
+                                        // their activation stores stay in flight)
     __builtin_amdgcn_s_barrier();
     if (has_next) stage_bias(L + 1);    // (the bias slot is free: every wave is past its epilogue)
+    SWN_TM(tm.epi += TICK() - p2;)
   }
+  SWN_TM(t_a = TICK();)
 
   // ---- the chain output: row-major, coalesced, + y_add rows ----
   {
@@ -353,6 +478,13 @@ __global__ __launch_bounds__(NT, 2) void chainb_kernel(const Args args) {
     }
   }
   SWN_WAIT_VM(0);      // no LDS copy may be in flight when the workgroup retires
+#ifdef SWN_BIG_TIMING
+  if (d.y_add_gather && tid == 0 && blockIdx.x < 4096) {
+    long long* dbg = (long long*)d.y_add_gather + (long)blockIdx.x * 8;
+    const long long t_end = TICK();
+    dbg[0] = tm.wait; dbg[1] = tm.bar; dbg[2] = tm.kloop; dbg[3] = tm.epi; dbg[4] = tm.mid; dbg[5] = tm.pro; dbg[6] = t_end - t_a; dbg[7] = t_end - t_start;
+  }
+#endif
 }
 
 }  // namespace swn_big
@@ -361,7 +493,11 @@ namespace swn {
 
 bool chain_big_eligible(const swn_chain_desc& d) {
   if (d.dtype != SWN_BF16 && d.dtype != SWN_F16) return false;
+#ifdef SWN_BIG_TIMING
+  if (d.x_save || d.x_scale) return false;
+#else
   if (d.x_save || d.x_scale || d.y_add_gather) return false;
+#endif
   for (int l = 0; l < d.n_layers; ++l) {
     const swn_chain_layer& ly = d.layers[l];
     if (ly.n != 256 || ly.k != 256 || ly.rowbias || ly.skip > 1) return false;
