@@ -267,8 +267,10 @@ typedef struct swn_chain_desc {
   void* y;                      /* output rows, row-major [*, n_last] dtype                       */
   const void* y_add;            /* row-major [*, n_last] tensor added to the output rows (skip gradient) or NULL */
   const int32_t* y_add_gather;  /* row -> row of y_add (-1 = nothing to add), or NULL (identity)  */
-  int32_t geometry;             /* 0 = automatic; 1 = force the 64-row tile kernels (chain.hip); 2 = force the 256-row kernel
-                                   (chain_big.hip: 256 x 256 layers, bf16 / fp16, no rowbias / x_scale / x_save / y_add_gather) */
+  int32_t geometry;             /* 0 / 1 = the 64-row tile kernels (chain.hip); 2 = the 256-row kernel (chain_big.hip: chains of
+                                   256 x 256 layers, bf16 / fp16, no rowbias / x_scale / x_save / y_add_gather; swn_chain_big_ok).
+                                   The ReLU masks of the two geometries are laid out differently: run a backward chain (relu = 2)
+                                   on the geometry of the forward chain that recorded its masks.  fp16 chains always use 2.   */
   int32_t tag;                  /* profiling only: selects an identical kernel instantiation with its own symbol so that
                                    rocprofv3 reports the roles separately (0 generic, 1 expert fwd, 2 expert bwd,
                                    3 front fwd, 4 tail fwd, 5 tail bwd, 6 front bwd)                 */
@@ -276,6 +278,8 @@ typedef struct swn_chain_desc {
 } swn_chain_desc;
 
 int swn_mlp_chain(const swn_chain_desc* desc, void* stream);
+/* 1 if the chain can run on the 256-row geometry (geometry = 2) */
+int swn_chain_big_ok(const swn_chain_desc* desc);
 /* rows per workgroup tile for dtype (sizes the ReLU mask buffers: ceil(group_stride / rows) * n_groups * rows * 8 words) */
 int swn_chain_tile_rows(int dtype);
 /* uint32 words of one ReLU mask buffer of a chain over n_groups x group_stride rows whose widest layer has max_width features

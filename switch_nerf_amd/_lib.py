@@ -65,6 +65,7 @@ SIGNATURES = {
     "swn_hash_encode_bwd": [vp, vp, i32, i32, C.POINTER(HashCfg), vp, i32, i32, vp, vp],
     "swn_gather_rows": [vp, vp, i64, i32, vp, vp],
     "swn_mlp_chain": [C.POINTER(ChainDesc), vp],
+    "swn_chain_big_ok": [C.POINTER(ChainDesc)],
     "swn_pack_weights": [vp, vp, i32, i32, i32, i32, i32, vp],
     "swn_chain_tile_rows": [i32],
     "swn_wgrad_blocks": [C.POINTER(WgradItem), i32, i32, i32, i32, i32, i32, i32, sz, sz, i32, i32, i32, vp, i32, i32, i32, vp, sz, vp],

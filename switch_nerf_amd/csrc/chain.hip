@@ -21,7 +21,6 @@
 // with 4 consecutive output FEATURES of one row, so the epilogue packs them and writes the next layer's input tile
 // row-major with 8-byte LDS stores.
 #include "common.hpp"
-#include <stdlib.h>
 
 #ifndef SWN_WIDE
 #define SWN_WIDE 0
@@ -789,12 +788,12 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   SWN_CHECK(d.tag >= 0 && d.tag <= 6, "swn_mlp_chain: tag %d not in [0,6]", d.tag);
   SWN_CHECK(!(wide && concat), "swn_mlp_chain: concat-skip layers are built for the 256-feature kernels only");
   SWN_CHECK(d.geometry >= 0 && d.geometry <= 2, "swn_mlp_chain: geometry %d not in [0,2]", d.geometry);
-  {   // 256-row geometry (chain_big.hip): chains of 256 x 256 layers over groups of at least one full tile
+  {   // 256-row geometry (chain_big.hip).  Never chosen silently for bf16: the ReLU mask layout differs between the geometries,
+      // and a backward chain must run on the geometry of the forward chain that recorded its masks - the caller pairs them.
     const bool can = chain_big_eligible(d);
     SWN_CHECK(d.geometry != 2 || can, "swn_mlp_chain: geometry 2 needs bf16 / fp16 chains of 256 x 256 layers without rowbias / x_scale / x_save / y_add_gather");
     SWN_CHECK(d.dtype != SWN_F16 || can, "swn_mlp_chain: fp16 chains run on the 256-row geometry only (256 x 256 layers)");
-    static const int big_default = [] { const char* e = getenv("SWN_CHAIN_BIG"); return e ? atoi(e) : 1; }();
-    if (can && (d.geometry == 2 || d.dtype == SWN_F16 || (d.geometry == 0 && big_default && d.group_stride >= 256))) return chain_big_launch(d, stream);
+    if (d.geometry == 2 || d.dtype == SWN_F16) return chain_big_launch(d, stream);
   }
   if (wide) return chain_wide_launch(d, stream);        // 512-feature geometry (this file compiled with -DSWN_WIDE=1)
   if (concat) return chain_concat_launch(d, stream);    // concat-skip layers (this file compiled with -DSWN_CONCAT=1)

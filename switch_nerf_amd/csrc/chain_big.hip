@@ -532,3 +532,5 @@ int chain_big_launch(const swn_chain_desc& d, void* stream) {
 }
 
 }  // namespace swn
+
+extern "C" int swn_chain_big_ok(const swn_chain_desc* desc) { return desc != nullptr && swn::chain_big_eligible(*desc) ? 1 : 0; }

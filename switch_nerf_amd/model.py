@@ -390,6 +390,9 @@ class SwitchNeRF:
         nw = o.chain_mask_words(dt, ng, cap, M)
         c["masks"] = [_b(f"mask{l}", (nw,), torch.int32) for l in range(L - 1)]
         skips = set(self.cfg["skips"])
+        # expert chains (forward here, backward-data in backward_net - the pair shares its ReLU mask layout): the 256-row geometry
+        # (chain_big.hip) for 256-feature experts in a 16-bit compute dtype once a group holds at least one full tile
+        c["geom"] = 2 if (M == 256 and dt != torch.float32 and cap >= 256 and os.environ.get("SWN_CHAIN_BIG", "1") != "0") else 1
         layers = [o.Layer(self._local_experts(self.wf[f"exp{l}"]), self._local_experts(self.p[f"exp{l}.b"]),
                           relu=1 if l < L - 1 else 0, skip=(l in skips), save=c["saves"][l] if (sv and l < L - 1) else None,
                           mask=c["masks"][l] if (sv and l < L - 1) else None) for l in range(L)]
@@ -397,7 +400,7 @@ class SwitchNeRF:
             c["row_of_tok"] = c["tok2row"]
             with self._timed("expert_fwd"):
                 o.mlp_chain(c["h0"], layers, c["eo"], n_groups=ng, n_wsets=E, group_stride=cap, group_rows=c["counts_flat"],
-                            group_rows_clamp=cap, x_gather=c["perm"].view(-1), tag=1)
+                            group_rows_clamp=cap, x_gather=c["perm"].view(-1), tag=1, geometry=c["geom"])
         else:
             # expert parallel: rows in payload order (destination rank, segment, local expert, slot) -> all-to-all -> the
             # local experts run on (source rank, segment, local expert) groups -> all-to-all back (parallel.ExpertParallel)
@@ -412,7 +415,7 @@ class SwitchNeRF:
             eo_r = _b("ep_eo", (rows, M), dt)
             with self._timed("expert_fwd"):
                 o.mlp_chain(xr, layers, eo_r, n_groups=ng, n_wsets=ep.El, group_stride=cap, group_rows=c["ep_counts"],
-                            group_rows_clamp=cap, tag=1)
+                            group_rows_clamp=cap, tag=1, geometry=c["geom"])
             eo, ewait = ep.all_to_all(eo_r, self.side)
             ewait()
             c["eo"] = eo
@@ -496,7 +499,8 @@ class SwitchNeRF:
             x_first, dz_last = c["ep_x"], dr            # the received rows, already in group order
         with self._timed("expert_bwd"):
             o.mlp_chain(dz_last, bl, dx, n_groups=ng, n_wsets=n_loc, group_stride=cap, group_rows=grp_rows,
-                        group_rows_clamp=cap, x_gather=perm, y_add=dz[skip_l] if skip_l is not None else None, tag=2)
+                        group_rows_clamp=cap, x_gather=perm, y_add=dz[skip_l] if skip_l is not None else None, tag=2,
+                        geometry=c["geom"])
         if ep is not None:      # the input gradients travel home while the expert weight gradients / the router backward run
             dx, dx_wait = ep.all_to_all(dx, self.side)
 

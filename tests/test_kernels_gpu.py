@@ -590,3 +590,60 @@ def test_chain_wide_512(dtype):
     tolb = 2e-4 if dtype == torch.float32 else 8e-2
     assert report(f"chain512_d2_{dtype}", d2, g2) <= tolb * max(1.0, g2.abs().max().item())
     assert report(f"chain512_d0_{dtype}", d0, g0) <= tolb * max(1.0, g0.abs().max().item())
+
+
+@pytest.mark.parametrize("ng,cap,seed", [(16, 1000, 1), (8, 256, 2), (24, 700, 3), (8, 4096, 4)])
+def test_chain_256_row_geometry_bit_exact(ng, cap, seed):
+    """The 256-row chain geometry (chain_big.hip: one 512-thread workgroup per 256-row tile, weights shared through an LDS ring,
+    write-out interleaved into the next layer's K loop) against the 64-row kernels (chain.hip, pinned on the fp32 oracle above):
+    the MFMA accumulation order and the epilogue arithmetic are the same, so every output, every saved activation and every dZ of
+    the ExpertMLP forward and backward-data chains must be BIT-identical, on ragged (segment, expert) groups (empty, 1 row, one
+    row past a tile, full), with gathered input rows; rows past a group's count must stay untouched."""
+    o = ops()
+    dt = torch.bfloat16
+    M, E, L = 256, 8, 7
+    g = torch.Generator().manual_seed(seed)
+    counts = torch.randint(0, cap + 1, (ng,), generator=g)
+    counts[0], counts[1], counts[2], counts[3] = cap, 0, 1, min(cap, 257)
+    rows = ng * cap
+    P = rows + 1000
+    h0 = torch.randn(P, M, generator=g).to(dev()).to(dt)
+    perm = torch.full((rows,), -1, dtype=torch.int32)
+    src = torch.randperm(P, generator=g)[:rows].int()
+    vm = torch.zeros(rows, dtype=torch.bool)
+    for gi in range(ng):
+        c = int(counts[gi])
+        perm[gi * cap: gi * cap + c] = src[gi * cap: gi * cap + c]
+        vm[gi * cap: gi * cap + c] = True
+    perm, vm, counts_t = perm.to(dev()), vm.to(dev()), counts.int().to(dev())
+    Wm = [torch.randn(E, M, M, generator=g).mul_(1 / 16).to(dev()) for _ in range(L)]
+    B = [torch.randn(E, M, generator=g).mul_(0.1).to(dev()) for _ in range(L)]
+    wf = [o.pack_weights(w, dt, True) for w in Wm]
+    wb = [o.pack_weights(w, dt, False) for w in Wm]
+    dout = (torch.randn(P, M, generator=g) * 0.1).to(dev()).to(dt)
+    skip_add = torch.randn(rows, M, generator=g).to(dev()).to(dt)
+    res = {}
+    for geom in (1, 2):
+        saves = [torch.zeros(rows, M, dtype=dt, device=dev()) for _ in range(L - 1)]
+        masks = [torch.zeros(o.chain_mask_words(dt, ng, cap, M), dtype=torch.int32, device=dev()) for _ in range(L - 1)]
+        y = torch.zeros(rows, M, dtype=dt, device=dev())
+        layers = [o.Layer(wf[l], B[l], relu=1 if l < L - 1 else 0, skip=(l == 3), save=saves[l] if l < L - 1 else None,
+                          mask=masks[l] if l < L - 1 else None) for l in range(L)]
+        o.mlp_chain(h0, layers, y, n_groups=ng, n_wsets=E, group_stride=cap, group_rows=counts_t, group_rows_clamp=cap,
+                    x_gather=perm, tag=1, geometry=geom)
+        dz = [torch.zeros(rows, M, dtype=dt, device=dev()) for _ in range(L - 1)]
+        dx = torch.zeros(rows, M, dtype=dt, device=dev())
+        bl = [o.Layer(wb[l], None, relu=2 if l > 0 else 0, mask=masks[l - 1] if l > 0 else None, save=dz[l - 1] if l > 0 else None)
+              for l in range(L - 1, -1, -1)]
+        o.mlp_chain(dout, bl, dx, n_groups=ng, n_wsets=E, group_stride=cap, group_rows=counts_t, group_rows_clamp=cap, x_gather=perm,
+                    y_add=skip_add, tag=2, geometry=geom)
+        y_inf = torch.zeros(rows, M, dtype=dt, device=dev())           # inference variant: no saves, no masks
+        o.mlp_chain(h0, [o.Layer(wf[l], B[l], relu=1 if l < L - 1 else 0, skip=(l == 3)) for l in range(L)], y_inf, n_groups=ng,
+                    n_wsets=E, group_stride=cap, group_rows=counts_t, group_rows_clamp=cap, x_gather=perm, tag=1, geometry=geom)
+        torch.cuda.synchronize()
+        res[geom] = [("y", y), ("y_inference", y_inf), ("dx", dx)] + [(f"save{l}", saves[l]) for l in range(L - 1)] + \
+                    [(f"dz{l}", dz[l]) for l in range(L - 1)]
+    for (name, a), (_, b) in zip(res[1], res[2]):
+        assert torch.equal(a[vm], b[vm]), f"{name}: {(a[vm] != b[vm]).float().mean().item():.3g} of the valid elements differ"
+        assert b[~vm].abs().sum().item() == 0, f"{name}: rows past a group's count were written"
+    assert (res[2][0][1][vm].float().abs().sum() > 0) and torch.isfinite(res[2][0][1].float()).all()
