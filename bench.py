@@ -2,17 +2,27 @@
 """bench.py - train rays/s of the Switch-NeRF hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+        N > 1 without torchrun's environment: bench.py re-launches itself as N ranks
+        (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>)
+        and fails if fewer than N devices are visible.  Under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*.
 
-One step = one full training step of BASELINE.json configs[1] on every rank: 8192 synthetic rays x 256 samples
-(16 routing segments of 131072 points), 8 experts top-1, capacity_factor 1.0, batch-prioritised routing, bf16 compute,
-stratified perturbation + sigma noise drawn inside the timed region, forward + loss + backward + gradient
-all-reduce (N > 1) + Adam.  Rays are independent, so ranks are data-parallel replicas with per-rank work fixed
-(scaling = "weak"); the only collective is the RCCL all-reduce of the flat fp32 gradient buffer.
+One step = one full training step of BASELINE.json configs[1]: 8192 synthetic rays x 256 samples (routing segments of 131072
+points), 8 experts top-1, capacity_factor 1.0, batch-prioritised routing, bf16 compute, stratified perturbation + sigma noise
+drawn inside the timed region, forward + loss + backward + gradient all-reduce (N > 1) + Adam.
 
-Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (timed live with HIP events on the launch
-stream); `cpu_baseline` is the CPU oracle (a port of the reference's CPU path) timed on this box's host cores on a
-bounded sample (one 131072-point segment = 512 rays).
+Scaling (N > 1): "strong" (default) = the reference's mode, the 8192-ray batch is split over the ranks (runner.py:573-575: batch_size
+// world_size rays per rank; SURVEY cfg 3 = 1024 rays per GPU at N = 8); "weak" = 8192 rays per rank.  `value` is always the whole
+job's rays per second.  Rays are independent: ranks are data-parallel replicas (one RCCL all-reduce of the flat fp32 gradient
+buffer per step) or, with --parallelism ep, expert-parallel (dispatched rows exchanged with RCCL all-to-all).
+
+Reproducibility: the device RNG is seeded, and after the warm-up steps the parameters, the Adam state and the RNG are reset, so the
+timed steps are the same computation (same routing, same kept-token fraction) whatever the warm-up count.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant expert kernel against the bf16 MFMA peak (the expert
+grouped GEMM is the MFMA-bound part), timed live with HIP events on the launch stream inside the timed region; `kernels` carries
+the MFMA fraction, the algorithmic HBM rate and the counter-measured HBM bytes (profiles/traffic.json) of all three expert kernels;
+`balanced` repeats the measurement with a near-uniform router (gate_scale 0.02, ~100 % of the tokens kept); `cpu_baseline` is the CPU
+oracle (a port of the reference's CPU path) timed on this box's host cores on a bounded sample (one 131072-point segment).
 """
 import argparse
 import json
@@ -67,8 +77,8 @@ def cpu_baseline(seconds_budget=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rays", type=int, default=8192)
     ap.add_argument("--samples", type=int, default=256)
     ap.add_argument("--chunk", type=int, default=131072)
@@ -90,14 +100,27 @@ def main():
     ap.add_argument("--eval", action="store_true", help="inference only (render path: forward without activation saves, no "
                     "perturbation / noise / backward / Adam), other recipes")
     ap.add_argument("--dense", action="store_true", help="BASELINE configs[0]: the dense NeRF (--no-use_moe), other recipes")
+    ap.add_argument("--scaling", default=None, choices=["strong", "weak"],
+                    help="N > 1: strong (default) = the --rays batch is split over the ranks like the reference (runner.py:573-575); "
+                         "weak = --rays per rank")
+    ap.add_argument("--no-balanced", action="store_true", help="skip the extra balanced-routing measurement (gate_scale 0.02)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a.gpus)                  # does not return
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("SWN_FORCE_DEVICE", os.environ.get("LOCAL_RANK", 0)))     # (override: several ranks on one GPU, for testing)
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch {a.gpus} ranks (or drop WORLD_SIZE and let bench.py launch them)")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants device {local} but only {torch.cuda.device_count()} are visible")
+    scaling = a.scaling or ("strong" if world > 1 else "weak")
+    if scaling == "strong" and a.rays % world:
+        raise SystemExit(f"bench.py: --rays {a.rays} is not divisible by {world} ranks")
+    n_rays = a.rays // world if scaling == "strong" else a.rays          # rays of THIS rank per step
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -121,8 +144,12 @@ def main():
         model.p["hash.table"].mul_(1e4)      # same first-layer output and the random-init router sends everything to one expert
     if a.gate_scale != 1.0 and not a.dense:
         model.p["wg"].mul_(a.gate_scale)
-    rays, idx, rgbs = synth_batch(a.rays, 1000 + rank, dev)
-    P = a.rays * a.samples
+    if scaling == "strong":      # this rank's contiguous slice of the global batch (runner.py:575)
+        rays, idx, rgbs = (t[rank * n_rays:(rank + 1) * n_rays].contiguous() for t in synth_batch(a.rays, 1000, dev))
+    else:
+        rays, idx, rgbs = synth_batch(n_rays, 1000 + rank, dev)
+    P = n_rays * a.samples
+    a.chunk = min(a.chunk, P)
 
     if world > 1:
         allreduce = parallel.make_grad_allreduce()     # RCCL all-reduce over xGMI, one 16 MB bucket
@@ -130,24 +157,26 @@ def main():
         from switch_nerf_amd.parallel import ExpertParallel
         model.set_expert_parallel(ExpertParallel(rank, world, model.E))
 
-    radii = torch.full((a.rays, 1), 1e-3, device=dev)
+    radii = torch.full((n_rays, 1), 1e-3, device=dev)
     scene = None
     if a.bg:
         from switch_nerf_amd.background import BackgroundScene
         from switch_nerf_amd.dense import DenseNeRF, DENSE
         bg = DenseNeRF(dict(DENSE, xyz_dim=4), dtype=dtype, device=dev, seed=1)
         scene = BackgroundScene(model, bg, [0.02, -0.03, 0.01], [0.6, 0.8, 0.7])
-        rays[:, 7] = torch.rand(a.rays, device=dev) * 1.2 + 0.3          # about half of the rays leave the bound
+        rays[:, 7] = torch.rand(n_rays, device=dev) * 1.2 + 0.3          # about half of the rays leave the bound
+
+    route_override = [None]       # [P] int32 expert of every point (the balanced-routing measurement) or None = the router's choice
 
     def step():
         if a.eval:       # render_rays in eval mode (runner.py:2835-2885 render_image's inner call): forward only
             with torch.no_grad():
                 c = model.forward_rays(rays, idx, a.samples, a.chunk, 0.0, None, None, training=False)
             return dict(ctx=c, loss=c["rgb"].sum() * 0)
-        pr = torch.rand(a.rays, a.samples, device=dev)              # rendering.py:582 rand_like
+        pr = torch.rand(n_rays, a.samples, device=dev)              # rendering.py:582 rand_like
         ar = allreduce if world > 1 else None
         if a.mip:      # rendering_mip recipe: a.samples edges -> a.samples - 1 frustums per level, coarse + fine level
-            nf = a.rays * (a.samples - 1)
+            nf = n_rays * (a.samples - 1)
             return model.train_step_mip(rgbs, rays, radii, idx, a.samples, a.samples, a.chunk, perturb=1.0, perturb_rand=pr,
                                         sigma_noise=torch.randn(nf, device=dev), sigma_noise_fine=torch.randn(nf, device=dev),
                                         grad_allreduce=ar)
@@ -156,97 +185,152 @@ def main():
             return scene.train_step(rgbs, rays, idx, a.samples, a.chunk, perturb=1.0, perturb_rand=pr, sigma_noise=noise,
                                     sigma_noise_bg="randn", sigma_noise_bg_fine="randn", noise_std=1.0, grad_allreduce=ar,
                                     fine_samples=a.fine,
-                                    sigma_noise_fine=torch.randn(a.rays * a.fine, device=dev) if a.fine else None)
+                                    sigma_noise_fine=torch.randn(n_rays * a.fine, device=dev) if a.fine else None)
         kw = {}
         if a.fine > 0:
-            kw = dict(fine_samples=a.fine, sigma_noise_fine=torch.randn(a.rays * a.fine, device=dev))
+            kw = dict(fine_samples=a.fine, sigma_noise_fine=torch.randn(n_rays * a.fine, device=dev))
         return model.train_step(rgbs, rays, idx, a.samples, a.chunk, perturb=1.0, perturb_rand=pr, sigma_noise=noise,
-                                grad_allreduce=ar, **kw)
+                                grad_allreduce=ar, routing_override=route_override[0], **kw)
 
+    models = [model] + ([scene.bg] if scene is not None else [])
+    snap = [m.flat.clone() for m in models]
+
+    def reset_state(seed):
+        """Parameters, Adam state and RNG back to the start: what follows is the same computation in every run."""
+        for m, f0 in zip(models, snap):
+            m.flat.copy_(f0); m.m.zero_(); m.v.zero_(); m.step_count = 0
+            m.refresh_compute_copies()
+        torch.manual_seed(seed + rank)
+        torch.cuda.manual_seed(seed + rank)
+
+    def timed(steps, events):
+        model.profile = events
+        model.events = {}
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st = None
+        for _ in range(steps):
+            st = step()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        model.profile = False
+        return dt, st
+
+    reset_state(4321)
     for _ in range(a.warmup):
         st = step()
-    model.profile = not a.no_events
-    model.events = {}
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        st = step()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    reset_state(1234)
+    dt, st = timed(a.steps, not a.no_events)
     ms = dt / a.steps * 1e3
-    value = a.rays * world * a.steps / dt
+    value = n_rays * world * a.steps / dt
 
     # ---- per-kernel accounting from the live HIP events
-    c = st["ctx"]["c"] if a.bg else st["ctx"]
-    kept = P if a.dense else int(torch.minimum(c["counts"], torch.tensor(c["cap"], device=dev)).sum().item())
     L, M, E = model.L, model.M, model.E
     esz = 2 if dtype == torch.bfloat16 else 4
-    kern = {}
-    for name, evs in ({} if other else model.events).items():       # (other recipes: headline number only)
-        kern[name] = sum(x.elapsed_time(y) for x, y in evs) / len(evs)          # ms per step
-    flops_chain = 2.0 * L * M * M * kept                                       # expert fwd == bwd-data == wgrad flops
-    # algorithmic HBM bytes per launch: fwd reads x, writes L-1 activations + output; bwd reads dout and the
-    # skip layer's dZ, writes L-1 dZ + dx; the weight gradients read L layer inputs and L dZ (ReLU masks: 1/16 of a tensor each)
-    bytes_fwd = kept * M * esz * (1 + (L - 1) + 1)
-    bytes_bwd = kept * M * esz * (1 + (L - 1) + 1 + 1)
-    bytes_wgrad = kept * M * esz * 2 * L
+    traffic_tab = {}
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tp):
+        try:
+            traffic_tab = json.load(open(tp))
+        except Exception:
+            traffic_tab = {}
+    names = {"expert_fwd": "chainb_kernel<Bf16,1> (expert forward: 7 fused layers, 256-row tiles)",
+             "expert_bwd": "chainb_kernel<Bf16,2> (expert backward-data: 7 fused layers, 256-row tiles)",
+             "expert_wgrad": "wgrad_kernel<bf16,1> (expert weight gradients, 7 layers in one launch)"}
+
+    def kept_of(st_):
+        c_ = st_["ctx"]["c"] if a.bg else st_["ctx"]
+        return P if a.dense else int(torch.minimum(c_["counts"], torch.tensor(c_["cap"], device=dev)).sum().item())
+
+    def account(events, kept_):
+        """Expert kernels against both rooflines.  flops: 2 L M^2 per KEPT row for each of forward, backward-data and weight
+        gradients.  Algorithmic HBM bytes per launch: fwd reads x, writes L-1 activations +
+        the output; bwd reads dout and the skip layer's dZ, writes L-1 dZ + dx; the weight gradients read L layer inputs and L dZ.
+        hbm_measured_*: bytes from the FETCH_SIZE / WRITE_SIZE counters of a separate profiling pass (profiles/traffic.json,
+        stored per kept row), i.e. what actually crossed the memory-side fabric."""
+        detail_ = {}
+        flops = 2.0 * L * M * M * kept_
+        alg = {"expert_fwd": kept_ * M * esz * (1 + (L - 1) + 1), "expert_bwd": kept_ * M * esz * (1 + (L - 1) + 1 + 1),
+               "expert_wgrad": kept_ * M * esz * 2 * L}
+        for name in ("expert_fwd", "expert_bwd", "expert_wgrad"):
+            evs = events.get(name)
+            if not evs:
+                continue
+            ms_ = sum(x.elapsed_time(y) for x, y in evs) / len(evs)
+            if ms_ <= 0:
+                continue
+            tf = flops / (ms_ * 1e-3) / 1e12
+            gbs = alg[name] / (ms_ * 1e-3) / 1e9
+            d_ = dict(ms=round(ms_, 4), tflops=round(tf, 1), mfma_frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4), alg_bytes=int(alg[name]),
+                      alg_gbs=round(gbs, 1), hbm_frac_alg=round(gbs / HBM_PEAK_GBS, 4))
+            per_row = traffic_tab.get(name + "_bytes_per_kept_row")
+            if per_row:
+                tb = per_row * kept_
+                d_.update(hbm_measured_bytes=int(tb), hbm_measured_gbs=round(tb / (ms_ * 1e-3) / 1e9, 1),
+                          hbm_frac_measured=round(tb / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            detail_[name] = d_
+        return detail_
+
+    kept = kept_of(st)
+    detail = {} if other else account(model.events, kept)          # (other recipes: headline number only)
     roof = None
-    detail = {}
-    for name, fl, by in (("expert_fwd", flops_chain, bytes_fwd), ("expert_bwd", flops_chain, bytes_bwd),
-                         ("expert_wgrad", flops_chain, bytes_wgrad)):
-        if name in kern and kern[name] > 0:
-            tf = fl / (kern[name] * 1e-3) / 1e12
-            gbs = by / (kern[name] * 1e-3) / 1e9
-            detail[name] = dict(ms=round(kern[name], 4), tflops=round(tf, 1), mfma_frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
-                                alg_gbs=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4))
     if detail:
+        # SURVEY 8(d): the expert grouped GEMM is priced against the bf16 MFMA peak; the dominant kernel = the slowest of its three
+        # launches.  (Their HBM side - a training chain must save every activation for the weight gradients - is in `kernels`.)
         dom = max(detail, key=lambda k: detail[k]["ms"])
         d = detail[dom]
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get(dom)
-            except Exception:
-                traffic = None
-        names = {"expert_fwd": "chain_kernel<bf16,1> (expert forward, 7 fused layers)",
-                 "expert_bwd": "chain_kernel<bf16,2> (expert backward-data, 7 fused layers)",
-                 "expert_wgrad": "wgrad_kernel<bf16,1> (expert weight gradients, 7 layers in one launch)"}
-        # the binding roofline is the one the kernel is closest to: in training the expert
-        # chains must save every activation for the weight-gradient GEMM, which makes them HBM-leaning
-        if d["hbm_frac"] >= d["mfma_frac"]:
-            roof = dict(kernel=names[dom], bound="hbm", achieved=d["alg_gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=d["hbm_frac"], traffic=traffic, mfma_tflops=d["tflops"], mfma_frac=d["mfma_frac"])
-        else:
-            roof = dict(kernel=names[dom], bound="mfma", achieved=d["tflops"], peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=d["mfma_frac"], traffic=traffic, alg_gbs=d["alg_gbs"], hbm_frac=d["hbm_frac"])
+        roof = dict(kernel=names[dom], bound="mfma", achieved=d["tflops"], peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=d["mfma_frac"], traffic=d.get("hbm_measured_bytes"), alg_gbs=d["alg_gbs"],
+                    hbm_frac_measured=d.get("hbm_frac_measured"))
+    loss_main = float(st["loss"].item())
 
+    # ---- the same measurement with perfectly balanced routing (SURVEY 8(d): GEMM work follows the kept tokens; the random-init
+    #      router fills some experts to capacity and starves others).  Point i goes to expert i mod E - every (segment, expert) group
+    #      is exactly full, nothing is dropped; gate values, ranking, dispatch and every kernel run as usual.
+    balanced = None
+    if not other and not a.no_balanced and not a.fine:
+        route_override[0] = (torch.arange(P, device=dev, dtype=torch.int32) % E).contiguous()
+        reset_state(4321)
+        for _ in range(2):
+            step()
+        reset_state(1234)
+        bsteps = max(2, min(10, a.steps))
+        bdt, bst = timed(bsteps, not a.no_events)
+        balanced = dict(routing="expert = point index mod E (every group full)", steps=bsteps, ms_per_step=round(bdt / bsteps * 1e3, 3),
+                        value=round(n_rays * world * bsteps / bdt, 1), kept_token_fraction=round(kept_of(bst) / P, 4),
+                        kernels=account(model.events, kept_of(bst)))
+        route_override[0] = None
+
+    gb = a.rays if scaling == "strong" else a.rays * world
     out = {
         "metric": "train rays/sec (8192-ray batch, 256 samples, 8 experts)", "value": round(value, 1), "unit": "rays/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "scaling": scaling, "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": ("other recipe (informational): " if other else "configs[1]: ")
                                + ("dense NeRF 8 x 256 (configs[0] network, --no-use_moe)" if a.dense else f"{a.experts}-expert top-1 expertmlp, capacity_factor=1.0, BPR")
-                               + f", {a.rays} rays x {a.samples} samples"
-                               f" per GPU, {P // a.chunk} segments of {a.chunk} points, building.yaml shapes, random-init weights,"
+                               + f", {gb} rays x {a.samples} samples per step over {world} GPU(s) ({n_rays} rays per GPU)"
+                               f", {P // a.chunk} segments of {a.chunk} points per GPU, building.yaml shapes, random-init weights,"
                                f" gate_scale={a.gate_scale}" + (f", + {a.fine} fine samples (hierarchical)" if a.fine else "")
                                + (", mip recipe (two levels)" if a.mip else "")
                                + (", INFERENCE ONLY (forward without saves; no backward / Adam)" if a.eval else "")
                                + (", hash-grid input encoding (16 levels x 2^19 x 2, table scaled to U(-1,1))" if a.hash else "")
                                + (f", capacity_factor {a.capacity_factor}" if a.capacity_factor != 1.0 else "")
-                               + (f", + dense background model on {st['ctx']['Nb']} of {a.rays} rays x {a.samples // 2} samples" if a.bg else "")
+                               + (f", + dense background model on {st['ctx']['Nb']} of {n_rays} rays x {a.samples // 2} samples" if a.bg else "")
                                + (f", model_dim {a.model_dim}, {a.experts} experts" if (a.model_dim != 256 or a.experts != 8) else ""),
-                   "rays_per_gpu": a.rays, "samples": a.samples, "segment_points": a.chunk, "parallelism": f"{a.parallelism}{world}",
-                   "kept_token_fraction": round(kept / P, 4), "loss": round(float(st["loss"].item()), 6)},
-        "roofline": roof, "kernels": detail,
+                   "global_batch_rays": gb, "rays_per_gpu": n_rays, "samples": a.samples, "segment_points": a.chunk,
+                   "parallelism": f"{a.parallelism}{world}", "kept_token_fraction": round(kept / P, 4), "loss": round(loss_main, 6),
+                   "timed_region": "per-kernel HIP events recorded inside it; expert weight gradients on the main stream (no side-stream "
+                                   "overlap) while events are on" if not a.no_events else "no per-kernel events; expert weight gradients "
+                                   "overlapped on the side stream"},
+        "roofline": roof, "kernels": detail, "balanced": balanced,
     }
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline and not other:
@@ -256,9 +340,25 @@ def main():
                 out["cpu_baseline"] = dict(value=None, unit="rays/s", cores=torch.get_num_threads(), kind="port", sample=f"failed: {e}")
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()
+
+
+def self_launch(n: int):
+    """`python bench.py --gpus N` without torchrun's environment: become the launcher of N ranks on this node (one per GPU, RCCL)."""
+    import socket
+    have = torch.cuda.device_count()
+    if have < n and "SWN_FORCE_DEVICE" not in os.environ:
+        raise SystemExit(f"bench.py: --gpus {n} but only {have} GPU(s) are visible on this node")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 if __name__ == "__main__":

@@ -28,8 +28,28 @@ def test_two_ranks_dp_and_ep_agree():
     dp = _run("dp", 29561)
     ep = _run("ep", 29562)
     assert dp["n_gpus"] == ep["n_gpus"] == 2 and dp["config"]["parallelism"] == "dp2" and ep["config"]["parallelism"] == "ep2"
-    assert dp["scaling"] == "weak" and dp["cpu_baseline"] is None
+    assert dp["scaling"] == "strong" and dp["cpu_baseline"] is None        # N > 1 default: the batch is split over the ranks (runner.py:575)
+    assert dp["config"]["global_batch_rays"] == 1024 and dp["config"]["rays_per_gpu"] == 512
     # bf16 steps with atomically accumulated weight gradients: run-to-run noise of a few 1e-6 on a loss of 0.085 after two steps
     assert abs(dp["config"]["loss"] - ep["config"]["loss"]) <= 5e-4 * abs(dp["config"]["loss"])
     assert abs(dp["config"]["kept_token_fraction"] - ep["config"]["kept_token_fraction"]) < 1e-3
     assert dp["value"] > 0 and ep["value"] > 0
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` without torchrun's environment must start N ranks itself (the driver calls it that way) - and
+    must refuse, not silently run one rank, when the node has fewer devices."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SWN_DIST_BACKEND="gloo", SWN_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rays", "1024", "--no-events",
+           "--scaling", "weak"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["global_batch_rays"] == 2048 and j["value"] > 0
+    env.pop("SWN_FORCE_DEVICE")
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "GPU(s) are visible" in bad.stderr
