@@ -103,6 +103,10 @@ def main():
     ap.add_argument("--scaling", default=None, choices=["strong", "weak"],
                     help="N > 1: strong (default) = the --rays batch is split over the ranks like the reference (runner.py:573-575); "
                          "weak = --rays per rank")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step's forward + backward launch sequence from a hipGraph (switch_nerf_amd/graph.py).  auto: on for "
+                         "N > 1 data parallel (1024 rays per GPU are launch-bound from Python), off for N = 1 where the per-kernel HIP "
+                         "events are recorded inside the timed region")
     ap.add_argument("--no-balanced", action="store_true", help="skip the extra balanced-routing measurement (gate_scale 0.02)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
@@ -167,6 +171,9 @@ def main():
         rays[:, 7] = torch.rand(n_rays, device=dev) * 1.2 + 0.3          # about half of the rays leave the bound
 
     route_override = [None]       # [P] int32 expert of every point (the balanced-routing measurement) or None = the router's choice
+    plain = not (a.eval or a.mip or a.bg or a.fine or a.dense)
+    use_graph = plain and a.parallelism == "dp" and (a.graph == "on" or (a.graph == "auto" and world > 1))
+    graphed = [None]
 
     def step():
         if a.eval:       # render_rays in eval mode (runner.py:2835-2885 render_image's inner call): forward only
@@ -180,6 +187,8 @@ def main():
             return model.train_step_mip(rgbs, rays, radii, idx, a.samples, a.samples, a.chunk, perturb=1.0, perturb_rand=pr,
                                         sigma_noise=torch.randn(nf, device=dev), sigma_noise_fine=torch.randn(nf, device=dev),
                                         grad_allreduce=ar)
+        if graphed[0] is not None:   # forward + loss + backward replayed from the hipGraph (jitter / noise drawn inside it), then
+            return graphed[0](grad_allreduce=ar)                    # all-reduce + Adam + compute-copy refresh
         noise = torch.randn(P, device=dev)                          # rendering.py:366, sigma_noise_std = 1
         if scene is not None:
             return scene.train_step(rgbs, rays, idx, a.samples, a.chunk, perturb=1.0, perturb_rand=pr, sigma_noise=noise,
@@ -225,11 +234,18 @@ def main():
         return dt, st
 
     reset_state(4321)
+    if use_graph:
+        from switch_nerf_amd.graph import GraphedTrainStep
+        graphed[0] = GraphedTrainStep(model, rgbs, rays, idx, a.samples, a.chunk, perturb=1.0, noise_std=1.0)
     for _ in range(a.warmup):
         st = step()
     reset_state(1234)
-    dt, st = timed(a.steps, not a.no_events)
+    dt, st = timed(a.steps, (not a.no_events) and not use_graph)
     ms = dt / a.steps * 1e3
+    if use_graph:                # per-kernel events cannot be recorded inside a graph: three more (eager, untimed) steps fill the table
+        graphed[0] = None
+        if not a.no_events:
+            _, st = timed(3, True)
     value = n_rays * world * a.steps / dt
 
     # ---- per-kernel accounting from the live HIP events
@@ -327,9 +343,11 @@ def main():
                                + (f", model_dim {a.model_dim}, {a.experts} experts" if (a.model_dim != 256 or a.experts != 8) else ""),
                    "global_batch_rays": gb, "rays_per_gpu": n_rays, "samples": a.samples, "segment_points": a.chunk,
                    "parallelism": f"{a.parallelism}{world}", "kept_token_fraction": round(kept / P, 4), "loss": round(loss_main, 6),
-                   "timed_region": "per-kernel HIP events recorded inside it; expert weight gradients on the main stream (no side-stream "
-                                   "overlap) while events are on" if not a.no_events else "no per-kernel events; expert weight gradients "
-                                   "overlapped on the side stream"},
+                   "timed_region": ("forward + backward replayed from a hipGraph, all-reduce + Adam eager; per-kernel events from 3 extra "
+                                    "eager steps after the timed region" if use_graph else
+                                    "per-kernel HIP events recorded inside it; expert weight gradients on the main stream (no side-stream "
+                                    "overlap) while events are on" if not a.no_events else "no per-kernel events; expert weight gradients "
+                                    "overlapped on the side stream")},
         "roofline": roof, "kernels": detail, "balanced": balanced,
     }
     if rank == 0:

@@ -294,6 +294,15 @@ long swn_chain_mask_words(int dtype, int n_groups, int group_stride, int max_wid
 int swn_pack_weights(const float* master, void* out, int dtype, int n_wsets, int in_dim, int out_dim, int transpose,
                      void* stream);
 
+/* The same for up to SWN_MAX_PACK_ITEMS weights in one launch (the per-step refresh of all compute copies after the optimizer). */
+#define SWN_MAX_PACK_ITEMS 32
+typedef struct swn_pack_item {
+  const float* master;  /* [n_wsets][in_dim][out_dim] f32 */
+  void* out;            /* packed compute copy (dtype of the call) */
+  int32_t n_wsets, in_dim, out_dim, transpose;
+} swn_pack_item;
+int swn_pack_weights_batched(const swn_pack_item* items, int n_items, int dtype, void* stream);
+
 /* Grouped weight gradient: for every group g, dW[g % n_wsets] += A_g^T @ B_g (fp32 atomics), and optionally
  * db += column sums of B_g.  A[rows, m_dim], B[rows, n_dim] row-major dtype; dW [n_wsets][m_dim][n_dim] f32.
  * With A = layer input, B = dZ this yields the reference's ExpertMLP weight layout [E, in, out]

@@ -21,6 +21,10 @@ class WgradItem(C.Structure):
     _fields_ = [("a", vp), ("b", vp), ("a_gather", vp), ("b_gather", vp), ("dw", vp), ("db", vp)]
 
 
+class PackItem(C.Structure):
+    _fields_ = [("master", vp), ("out", vp), ("n_wsets", i32), ("in_dim", i32), ("out_dim", i32), ("transpose", i32)]
+
+
 class HashCfg(C.Structure):
     _fields_ = [("n_levels", i32), ("log2_table", i32), ("base_res", i32), ("per_level_scale", f32), ("aabb_lo", f32 * 3),
                 ("aabb_hi", f32 * 3)]
@@ -67,6 +71,7 @@ SIGNATURES = {
     "swn_mlp_chain": [C.POINTER(ChainDesc), vp],
     "swn_chain_big_ok": [C.POINTER(ChainDesc)],
     "swn_pack_weights": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "swn_pack_weights_batched": [C.POINTER(PackItem), i32, i32, vp],
     "swn_chain_tile_rows": [i32],
     "swn_wgrad_blocks": [C.POINTER(WgradItem), i32, i32, i32, i32, i32, i32, i32, sz, sz, i32, i32, i32, vp, i32, i32, i32, vp, sz, vp],
     "swn_wgrad_batched": [C.POINTER(WgradItem), i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, sz, vp],

@@ -681,6 +681,40 @@ __global__ void pack_weights_kernel(const float* __restrict__ master, T* __restr
   }
 }
 
+// the same for a table of weights in ONE launch (blockIdx.y = entry): the per-step refresh of every compute copy after Adam
+struct PackTable {
+  swn_pack_item it[SWN_MAX_PACK_ITEMS];
+};
+template <typename T>
+__global__ void pack_weights_batched_kernel(const PackTable tab) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int KSTEP = Cfg<T>::KSTEP;
+  const swn_pack_item& q = tab.it[blockIdx.y];
+  const int in_dim = q.in_dim, out_dim = q.out_dim, transpose = q.transpose;
+  const int N = transpose ? out_dim : in_dim, K = transpose ? in_dim : out_dim;
+  const long per_set = (long)(N / 32) * (K / KSTEP) * 64;
+  const long total_chunks = per_set * q.n_wsets;
+  const float* master = q.master;
+  T* out = (T*)q.out;
+  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total_chunks; c += (long)gridDim.x * blockDim.x) {
+    const long ws = c / per_set;
+    long r = c - ws * per_set;
+    const int lane = (int)(r & 63);
+    r >>= 6;
+    const int ks = (int)(r % (K / KSTEP)), nt = (int)(r / (K / KSTEP));
+    const int n = nt * 32 + (lane & 31);
+    const float* m = master + ws * (long)in_dim * out_dim;
+    T* o = out + c * EPC;
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+      int kk;
+      if constexpr (sizeof(T) == 2) kk = ks * 16 + (lane >> 5) * 8 + j; else kk = ks * 8 + 2 * j + (lane >> 5);
+      const float v = transpose ? m[(long)kk * out_dim + n] : m[(long)n * out_dim + kk];
+      ElemIO<T>::st(o + j, v);
+    }
+  }
+}
+
 #endif   // !SWN_AUX
 
 // host side of one launch (shared by both builds; the narrow build's swn_mlp_chain forwards wide descriptors to the wide one)
@@ -744,6 +778,29 @@ extern "C" int swn_pack_weights(const float* master, void* out, int dtype, int n
   else
     hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(blocks), dim3(256), 0, as_stream(stream), master, (float*)out, in_dim,
                        out_dim, transpose, chunks);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int swn_pack_weights_batched(const swn_pack_item* items, int n_items, int dtype, void* stream) {
+  SWN_CHECK(items && n_items >= 1 && n_items <= SWN_MAX_PACK_ITEMS, "swn_pack_weights_batched: 1..%d items", SWN_MAX_PACK_ITEMS);
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_pack_weights_batched: bad dtype");
+  PackTable tab;
+  const int kstep = dtype == SWN_BF16 ? 16 : 8;
+  long max_chunks = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const swn_pack_item& q = items[i];
+    SWN_CHECK(q.master && q.out && q.n_wsets >= 1, "swn_pack_weights_batched: item %d: null pointer / no weight sets", i);
+    const int N = q.transpose ? q.out_dim : q.in_dim, K = q.transpose ? q.in_dim : q.out_dim;
+    SWN_CHECK(N % 32 == 0 && K % kstep == 0, "swn_pack_weights_batched: item %d: N=%d must be a multiple of 32, K=%d of %d", i, N, K, kstep);
+    const long chunks = (long)q.n_wsets * (N / 32) * (K / kstep) * 64;
+    if (chunks > max_chunks) max_chunks = chunks;
+    tab.it[i] = q;
+  }
+  int blocks = cdiv(max_chunks, 256);
+  if (blocks > 512) blocks = 512;
+  if (dtype == SWN_BF16) hipLaunchKernelGGL((pack_weights_batched_kernel<bf16_t>), dim3(blocks, n_items), dim3(256), 0, as_stream(stream), tab);
+  else hipLaunchKernelGGL((pack_weights_batched_kernel<float>), dim3(blocks, n_items), dim3(256), 0, as_stream(stream), tab);
   SWN_LAUNCH_CHECK();
   return 0;
 }

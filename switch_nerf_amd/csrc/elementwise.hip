@@ -1054,7 +1054,10 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
   if (ln_w) SWN_CHECK(stats && d_ln_w && d_ln_b && ln_b, "swn_gate_bwd: LayerNorm buffers missing");
   int blocks = row_blocks(n_tokens);
   if (blocks > 2048) blocks = 2048;
-  const int tpb = 4096;
+  // router weight gradient: a block walks its tokens serially (32 per iteration), so its run time is set by tokens per block, not by
+  // the batch - ~1024 blocks (4 per CU) whatever the batch size (4096 tokens per block took 0.5 ms for 2M and for 262144 tokens alike)
+  int tpb = cdiv(n_tokens, 1024);
+  tpb = ((tpb < 256 ? 256 : (tpb > 4096 ? 4096 : tpb)) + 31) / 32 * 32;
   const int dwg_blocks = cdiv(n_tokens, tpb);
   if (dtype == SWN_BF16) {
     const bf16_t* gp = (const bf16_t*)g;

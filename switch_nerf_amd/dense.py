@@ -204,7 +204,7 @@ class DenseNeRF(SwitchNeRF):
         dh1 = _b("dh1", (P, W), dt)
         dy = _b("dy", (P, W), dt)
         o.mlp_chain(dh2, [o.Layer(self.wb["l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dy, tag=5)
-        nsp = max(1, min(256, P // 4096))
+        nsp = max(1, min(256, P // 1024))
         # d(pre-activation of the last trunk layer) = (dy + dsigma * w_sigma) * (xyz_ > 0): the combine backward with a unit gate
         if getattr(self, "_ones", None) is None or self._ones.numel() < P:
             self._ones = torch.ones(P, dtype=torch.float32, device=self.dev)

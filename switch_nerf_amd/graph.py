@@ -1,0 +1,70 @@
+"""hipGraph capture of the training step's launch sequence.
+
+A train step of the hot path is ~150 kernel launches.  At the reference's multi-GPU batch (8192 rays split over 8 ranks = 1024 rays
+per GPU, runner.py:573-575) they hold ~2.5 ms of GPU work while the Python host needs ~3.7 ms to enqueue them: the step is
+launch-bound.  Nothing in forward + loss + backward depends on host state that changes between steps (shapes, capacities and
+buffer addresses are static; the random draws are device-side), so the sequence is captured once into a hipGraph and replayed:
+one host call per step, kernels back to back.  The gradient all-reduce (RCCL) and Adam (its bias correction takes the step count
+as a launch argument) stay outside the graph; the refresh of the compute copies of the weights is a second small graph.
+"""
+from __future__ import annotations
+
+import torch
+
+
+class GraphedTrainStep:
+    """step = GraphedTrainStep(model, rgbs, rays, image_indices, n_samples, seg_tokens, ...); res = step(rgbs, rays, image_indices)
+
+    Same result dict as SwitchNeRF.train_step (tensors live in static graph memory: read them before the next call).  The inputs
+    are copied into static buffers; stratified jitter (perturb > 0) and the sigma noise (noise_std > 0) are drawn inside the
+    graph from the device generator, like rendering.py:582 / :366.  Only the plain (non-hierarchical, non-mip) step is graphed."""
+
+    def __init__(self, model, rgbs, rays, image_indices, n_samples: int, seg_tokens: int, perturb: float = 1.0, noise_std: float = 1.0,
+                 routing_override=None, warmup: int = 2):
+        self.model = model
+        dev = model.dev
+        self.rgbs, self.rays, self.idx = rgbs.clone(), rays.clone(), image_indices.clone()
+        N, S = rays.shape[0], int(n_samples)
+        P = N * S
+        ro = None if routing_override is None else routing_override.to(dev).int().contiguous()
+
+        def run():
+            pr = torch.rand(N, S, device=dev) if perturb > 0 else None
+            noise = torch.randn(P, device=dev) * noise_std if noise_std > 0 else None
+            return model.grad_step(self.rgbs, self.rays, self.idx, S, min(int(seg_tokens), P), perturb=perturb, perturb_rand=pr,
+                                   sigma_noise=noise, routing_override=ro)
+
+        was_profile, model.profile = model.profile, False
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up on a side stream: allocates every cached buffer / workspace
+            for _ in range(max(1, warmup)):
+                run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self.res = run()
+        self.copies = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.copies, stream=side):
+            model.refresh_compute_copies()
+        model.profile = was_profile
+
+    def __call__(self, rgbs=None, rays=None, image_indices=None, grad_allreduce=None, optimizer_step=True):
+        m = self.model
+        if rgbs is not None:
+            self.rgbs.copy_(rgbs)
+        if rays is not None:
+            self.rays.copy_(rays)
+        if image_indices is not None:
+            self.idx.copy_(image_indices)
+        self.graph.replay()
+        scale = 1.0
+        if grad_allreduce is not None:
+            scale = grad_allreduce(m.grad)
+        if optimizer_step:
+            from . import ops
+            m.step_count += 1
+            ops.adam_step(m.flat, m.grad, m.m, m.v, None, m.step_count, m.lr, grad_scale=scale)
+            self.copies.replay()
+        return self.res

@@ -231,6 +231,7 @@ class SwitchNeRF:
 
     def refresh_compute_copies(self):
         """fp32 master [in, out] -> MFMA-fragment-major compute copies: forward (N=out, K=in), backward (N=in, K=out)."""
+        pairs = []
         for n in self._chain_weights:
             w = self.p[n + ".w"]
             w3 = w if w.dim() == 3 else w.unsqueeze(0)
@@ -239,9 +240,11 @@ class SwitchNeRF:
                 if n not in self._fwd_only_weights:
                     self.wb[n] = ops.pack_weights(w3, self.dtype, False)
             else:
-                ops.repack_weights(w3, self.wf[n], True)
+                pairs.append((w3, self.wf[n], True))
                 if n in self.wb:
-                    ops.repack_weights(w3, self.wb[n], False)
+                    pairs.append((w3, self.wb[n], False))
+        if pairs:
+            ops.repack_weights_batched(pairs)      # one launch (was 23 of ~5 us each: a tenth of the step at 1024 rays per GPU)
 
     def set_expert_parallel(self, ep):
         """Shard the experts over the ranks of `ep` (parallel.ExpertParallel) and exchange the dispatched rows instead of
@@ -282,6 +285,16 @@ class SwitchNeRF:
             self._bufs[key] = b
         return b
 
+    def _linspace(self, n):
+        """torch.linspace(0, 1, n) computed on the host like the reference's CPU path, cached on the device (no host-to-device copy
+        inside a step: a copy from pageable memory cannot be captured into a hipGraph)."""
+        key = ("linspace", int(n))
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.linspace(0, 1, int(n), dtype=torch.float32).to(self.dev)
+            self._bufs[key] = t
+        return t
+
     # ------------------------------------------------------------------------------------------ forward
     def forward_rays(self, rays, image_indices, n_samples, seg_tokens, perturb=0.0, perturb_rand=None, sigma_noise=None,
                      training=True, routing_override=None, no_batch=False, z_in=None, pe_dir=None, tag="c",
@@ -292,13 +305,13 @@ class SwitchNeRF:
         o, dt, dev = ops, self.dtype, self.dev
         N, S = rays.shape[0], n_samples
         if self.hash is not None:         # hash-grid encoding of the sample positions (BASELINE configs[4])
-            z = z_in if z_in is not None else o.sample_z(rays, torch.linspace(0, 1, S, dtype=torch.float32).to(dev), perturb_rand,
+            z = z_in if z_in is not None else o.sample_z(rays, self._linspace(S), perturb_rand,
                                                          perturb, S)
             pe = o.hash_encode_fwd(rays, z, self.p["hash.table"], self.hash, dt, self.KP)
             if pe_dir is None:
                 pe_dir = self._dir_pe(rays)
         elif z_in is None:
-            t_steps = torch.linspace(0, 1, S, dtype=torch.float32).to(dev)    # computed on the host like the reference's CPU path
+            t_steps = self._linspace(S)
             z, pe, pe_dir = o.sample_pe(rays, t_steps, perturb_rand, perturb, S, self.cfg["pos_xyz_dim"],
                                         self.cfg["pos_dir_dim"], dt, self.KP, self.DP)
         else:
@@ -471,7 +484,8 @@ class SwitchNeRF:
         dh1 = _b("dh1", (P, M), dt)
         dy = _b("dy", (P, M), dt)
         o.mlp_chain(dh2, [o.Layer(self.wb["l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dy, tag=5)
-        nsp = max(1, min(256, P // 4096))          # row splits of the dense weight-gradient GEMMs (fills the 256 CUs)
+        nsp = max(1, min(256, P // 1024))          # row splits of the dense weight-gradient GEMMs: one workgroup per CU also at the
+                                                   # per-GPU batch of an 8-GPU run (262144 points)
         # combine backward (adds the sigma head's rank-1 term, applies the ReLU mask, gate gradient)
         dout, dgmax = o.combine_bwd(dy, c["y"], dsig, self.p["sigma.w"], c["gmax"])
         ep = self.ep
@@ -554,7 +568,17 @@ class SwitchNeRF:
     def train_step(self, rgbs, rays, image_indices, n_samples, seg_tokens, perturb=1.0, perturb_rand=None,
                    sigma_noise=None, optimizer_step=True, routing_override=None, grad_allreduce=None, fine_samples=0,
                    fine_u=None, sigma_noise_fine=None):
-        """Runner._training_step + loss assembly + backward + Adam (runner.py:1077-1123, 646-686).
+        """Runner._training_step + loss assembly + backward + Adam (runner.py:1077-1123, 646-686) = grad_step + apply_step."""
+        res = self.grad_step(rgbs, rays, image_indices, n_samples, seg_tokens, perturb, perturb_rand, sigma_noise, routing_override,
+                             fine_samples, fine_u, sigma_noise_fine)
+        self.apply_step(grad_allreduce, optimizer_step)
+        return res
+
+    def grad_step(self, rgbs, rays, image_indices, n_samples, seg_tokens, perturb=1.0, perturb_rand=None, sigma_noise=None,
+                  routing_override=None, fine_samples=0, fine_u=None, sigma_noise_fine=None):
+        """Forward + loss + backward of one training step: fills self.grad (zeroed first) and returns the metrics.  Nothing here
+        depends on host state that changes from step to step, so the whole launch sequence can be captured into a hipGraph
+        (graph.GraphedTrainStep).
         fine_samples > 0 adds the hierarchical pass (rendering.py:236-268): importance-sample fine depths from the coarse
         weights (detached), evaluate the network on them, sort-merge with the coarse samples, composite the union;
         loss = mse(rgb_fine) + wt * (mean(gate_loss_fine) + mean(gate_loss_coarse)) / 2."""
@@ -581,6 +605,14 @@ class SwitchNeRF:
             d_raw_f, d_raw_c = ops.unmerge_grad(d_raw_m, out["order"], fine_samples, n_samples)
             self.backward_net(cf, d_raw_f, torch.full((cf["n_seg"],), 0.5 * self.wt / cf["n_seg"], dtype=torch.float32, device=self.dev))
             self.backward_net(c, d_raw_c, torch.full((c["n_seg"],), 0.5 * self.wt / c["n_seg"], dtype=torch.float32, device=self.dev))
+        res = dict(loss=loss, photo_loss=photo, gate_loss=gate_loss, psnr=-10.0 * torch.log10(photo),
+                   depth_variance=out["depth_variance"].mean(), ctx=c, rgb=out["rgb"], depth=out["depth"])
+        if fine:
+            res["ctx_fine"] = cf
+        return res
+
+    def apply_step(self, grad_allreduce=None, optimizer_step=True):
+        """Gradient all-reduce (N > 1) + Adam (runner.py:486, 686) + refresh of the compute copies of the weights."""
         scale = 1.0
         if grad_allreduce is not None:
             scale = grad_allreduce(self.grad)
@@ -588,11 +620,6 @@ class SwitchNeRF:
             self.step_count += 1
             ops.adam_step(self.flat, self.grad, self.m, self.v, None, self.step_count, self.lr, grad_scale=scale)
             self.refresh_compute_copies()
-        res = dict(loss=loss, photo_loss=photo, gate_loss=gate_loss, psnr=-10.0 * torch.log10(photo),
-                   depth_variance=out["depth_variance"].mean(), ctx=c, rgb=out["rgb"], depth=out["depth"])
-        if fine:
-            res["ctx_fine"] = cf
-        return res
 
     def forward_hier(self, rays, image_indices, n_samples, fine_samples, seg_tokens, perturb=0.0, perturb_rand=None,
                      fine_u=None, sigma_noise=None, sigma_noise_fine=None, routing_override=None, no_batch=False, training=True):
@@ -604,7 +631,7 @@ class SwitchNeRF:
         c = self.forward_rays(rays, image_indices, n_samples, seg_tokens, perturb, perturb_rand, sigma_noise, training,
                               routing_override, no_batch=no_batch, want_weights=True)
         if fine_u is None:                                                # det = (perturb == 0): linspace, else rand (:605-609)
-            fine_u = (torch.linspace(0, 1, fine_samples).expand(N, fine_samples).contiguous().to(self.dev) if perturb == 0
+            fine_u = (self._linspace(fine_samples).expand(N, fine_samples).contiguous() if perturb == 0
                       else torch.rand(N, fine_samples, device=self.dev))
         z_fine = ops.sample_pdf(c["z"], c["weights"], fine_u, fine_samples)
         seg_f = min(seg_tokens, N * fine_samples)
@@ -651,7 +678,7 @@ class SwitchNeRF:
         N = rays.shape[0]
         if fine_randomized is None:
             fine_randomized = perturb > 0
-        t_steps = torch.linspace(0, 1, n_samples, dtype=torch.float32).to(self.dev)
+        t_steps = self._linspace(n_samples)
         radii = radii.reshape(-1).contiguous()
         z = ops.sample_z(rays, t_steps, perturb_rand, perturb, n_samples)
         c = self.forward_level_mip(rays, radii, image_indices, z, seg_tokens, sigma_noise, no_batch, "c", n_fine > 0, rgb_padding,

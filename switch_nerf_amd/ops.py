@@ -353,6 +353,18 @@ def repack_weights(master, packed, transpose: bool):
     return packed
 
 
+def repack_weights_batched(pairs):
+    """pairs: (master [ws, in, out] f32, packed, transpose) of one compute dtype -> one launch per 32 weights."""
+    from ._lib import PackItem
+    for i0 in range(0, len(pairs), 32):
+        chunk = pairs[i0:i0 + 32]
+        arr = (PackItem * len(chunk))()
+        for it, (master, packed, transpose) in zip(arr, chunk):
+            ws, i, o_ = master.shape
+            it.master, it.out, it.n_wsets, it.in_dim, it.out_dim, it.transpose = _p(master), _p(packed), ws, i, o_, int(bool(transpose))
+        call("swn_pack_weights_batched", arr, len(chunk), _dt(chunk[0][1]), _stream())
+
+
 class Layer:
     """One Linear of a chain: w = pack_weights(...) output (carries .swn_nk = (N, K)), b [n_wsets, N] f32 or None."""
 
