@@ -11,6 +11,10 @@
 //
 // Workgroup = 512 threads = 8 waves as 2 (m) x 4 (n); wave tile 128 x 64; full 256 x 256 dW tile per workgroup;
 // grid = (groups, row splits).
+// Staging: the slabs come in by `global_load ... lds` (no staging registers, per-lane source address = row gather for free) into a
+// ring of NS = 4 slots, three slabs (96 KiB per CU) in flight: with one 128-accumulator workgroup per CU the previous register
+// double buffer held one slab (32 KiB) in flight, i.e. ~4 TB/s chip-wide at ~2 us of HBM latency - the kernel ran at that rate.
+// Rows past the end of the group read a zero page.
 #include "common.hpp"
 
 namespace swn {
@@ -20,6 +24,16 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 constexpr int WG_NT = 512;
+constexpr int WG_NS = 4;          // LDS ring slots (A slab + B slab each)
+__device__ __attribute__((aligned(16))) uint32_t g_zero_page[256];   // 1 KiB of zeros: source of the rows past a group's end
+// 16 bytes per lane from each lane's own global address into LDS at lds_dst (wave-uniform byte address) + lane * 16.  Inline asm on
+// purpose: with the builtin, hipcc treats every later ds_read of the same array as possibly aliasing the pending copy and drains the
+// queue (s_waitcnt vmcnt(0)) in front of it; the waits here are counted by hand.  M0 is saved / restored (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 
 template <typename T> struct WCfg;
 template <> struct WCfg<bf16_t> { static constexpr int BKR = 32; };
@@ -80,50 +94,54 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) accb[j][r] = 0.f;
 
-  // 16-byte chunks per operand row (powers of two); loads are unconditional: surplus work items are clamped onto
-  // the last chunk (duplicate identical writes), rows past the end of the group are zero-filled.
-  const int a_cpr = m_dim * (int)sizeof(T) / 16, b_cpr = n_dim * (int)sizeof(T) / 16;
-  const int a_sh = 31 - __builtin_clz(a_cpr), b_sh = 31 - __builtin_clz(b_cpr);
-  const int a_total = BKR * a_cpr, b_total = BKR * b_cpr;
-  uint4 ra[2], rb[2];
-  int a_row[2], a_ch[2], b_row[2], b_ch[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int ca = min(tid + WG_NT * i, a_total - 1), cb = min(tid + WG_NT * i, b_total - 1);
-    a_row[i] = ca >> a_sh; a_ch[i] = ca & (a_cpr - 1);
-    b_row[i] = cb >> b_sh; b_ch[i] = cb & (b_cpr - 1);
-  }
-  auto gload = [&](int r0) {
+  // ---- staging by LDS DMA.  A slab = BKR rows x RS bytes = 16 pieces of 1 KiB (RPP rows each); wave w copies pieces 2 w, 2 w + 1 of
+  // the A slab and of the B slab: 4 copies per wave and slab.  Lane -> (row in piece, 16-byte column): columns past the operand's
+  // width re-read column 0 (those tile columns are never used), rows past r_end read the zero page.
+  constexpr int RPP = 1024 / RS;                       // rows per piece: 2 (bf16) / 1 (fp32)
+  constexpr int LPR = RS / 16;                         // lanes per row: 32 / 64
+  const int prow = lane / LPR, pcol = (lane % LPR) * 16;
+  const int a_colb = pcol < m_dim * (int)sizeof(T) ? pcol : 0, b_colb = pcol < n_dim * (int)sizeof(T) ? pcol : 0;
+  const char* zero = (const char*)g_zero_page + (lane & 31) * 16;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;     // LDS byte address of the ring
+  // The gather indices are fetched with SCALAR loads (wave-uniform addresses: a piece holds RPP consecutive rows): a vector load
+  // here would sit behind the copies in flight in the in-order vmcnt queue, and waiting for it would drain them.
+  auto dma_slab = [&](int slot, int r0) {              // rows r0 .. r0 + BKR of the group -> ring slot
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int ar = min(r0 + a_row[i], r_end - 1), br = min(r0 + b_row[i], r_end - 1);
-      long as = grow0 + ar, bs = grow0 + br;
-      if (it.a_gather) as = max(it.a_gather[as], 0);     // valid rows (< group_rows) always carry a source row
-      if (it.b_gather) bs = max(it.b_gather[bs], 0);
-      ra[i] = *(const uint4*)((const char*)it.a + (as * (long)p.lda) * sizeof(T) + a_ch[i] * 16);
-      rb[i] = *(const uint4*)((const char*)it.b + (bs * (long)p.ldb) * sizeof(T) + b_ch[i] * 16);
-    }
-  };
-  auto lstore = [&](int buf, int r0) {
+      const int piece = 2 * wave + i;
+      const int rf = r0 + piece * RPP;                 // first row of the piece (wave-uniform)
+      long asr[RPP], bsr[RPP];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const uint4 za = (r0 + a_row[i] < r_end) ? ra[i] : make_uint4(0, 0, 0, 0);
-      const uint4 zb = (r0 + b_row[i] < r_end) ? rb[i] : make_uint4(0, 0, 0, 0);
-      *(uint4*)(sa(buf) + a_row[i] * RS + a_ch[i] * 16) = za;
-      *(uint4*)(sb(buf) + b_row[i] * RS + b_ch[i] * 16) = zb;
+      for (int q = 0; q < RPP; ++q) {
+        const long row = grow0 + min(rf + q, r_end - 1);
+        // (constant address space + uniform address = s_load_dword; the routing permutation is not written while this kernel runs)
+        typedef const __attribute__((address_space(4))) int32_t* cidx_t;
+        asr[q] = it.a_gather ? (long)max(((cidx_t)it.a_gather)[row], 0) : row;      // valid rows (< group_rows) always carry a source row
+        bsr[q] = it.b_gather ? (long)max(((cidx_t)it.b_gather)[row], 0) : row;
+      }
+      const bool ok = rf + prow < r_end;
+      const long as = RPP == 2 ? (prow ? asr[RPP - 1] : asr[0]) : asr[0];
+      const long bs = RPP == 2 ? (prow ? bsr[RPP - 1] : bsr[0]) : bsr[0];
+      const char* ap = ok ? (const char*)it.a + (as * (long)p.lda) * sizeof(T) + a_colb : zero;
+      const char* bp = ok ? (const char*)it.b + (bs * (long)p.ldb) * sizeof(T) + b_colb : zero;
+      dma16(ap, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(slot * 2 * SLAB + piece * 1024)));
+      dma16(bp, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(slot * 2 * SLAB + SLAB + piece * 1024)));
     }
   };
 
   const bool active = (wm * 128 < m_dim) && (wn * 64 < n_dim);
   const bool do_bias = (it.db != nullptr) && wm == 0 && (wn * 64 < n_dim);
 
-  gload(r_begin);
-  lstore(0, r_begin);
-  __syncthreads();
-  int buf = 0;
+  // prologue: slabs 0, 1, 2 in flight (slabs past the end copy zeros: every wave issues 4 copies per slab, the counted waits below
+  // rely on it)
+#pragma unroll
+  for (int s0 = 0; s0 < WG_NS - 1; ++s0) dma_slab(s0, r_begin + s0 * BKR);
+  int slot = 0;
   for (int r0 = r_begin; r0 < r_end; r0 += BKR) {
-    const bool more = r0 + BKR < r_end;
-    if (more) gload(r0 + BKR);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's copies of the current slab have landed (younger: two slabs x 4)
+    __builtin_amdgcn_s_barrier();                      // ... everybody's; and every wave is done reading the previous slab's slot
+    dma_slab((slot + WG_NS - 1) % WG_NS, r0 + (WG_NS - 1) * BKR);
+    const int buf = slot;
     const char* A = sa(buf);
     const char* B = sb(buf);
     if (active || do_bias) {
@@ -201,10 +219,10 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
         }
       }
     }
-    if (more) lstore(buf ^ 1, r0 + BKR);
-    __syncthreads();
-    buf ^= 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads of the slab are done before the next barrier frees its slot
+    slot = (slot + 1) % WG_NS;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS copy may be in flight when the workgroup retires
 
   // ---- epilogue: this workgroup's partial tile goes to the workspace with plain stores (a reduce kernel sums the
   // partials; device-scope fp32 atomics from hundreds of workgroups onto one 256 KiB tile are fabric-bound), or,
@@ -323,7 +341,7 @@ static int wgrad_launch(const swn_wgrad_item* items, int n_items, int dtype, int
   const size_t need = (size_t)n_items * p.partial_stride * sizeof(float);
   p.partial = (workspace && workspace_bytes >= need) ? (float*)workspace : nullptr;
   if (workspace && !p.partial) return swn::set_error("swn_wgrad: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
-  const int lds = 4 * bkr * 256 * (dtype == SWN_BF16 ? 2 : 4);
+  const int lds = WG_NS * 2 * bkr * 256 * (dtype == SWN_BF16 ? 2 : 4);      // ring of WG_NS (A slab + B slab) slots: 128 KiB
   SWN_CHECK(tag == 0 || tag == 1, "swn_wgrad: tag must be 0 or 1");
   const void* fn;
   if (dtype == SWN_BF16) fn = tag ? (const void*)wgrad_kernel<bf16_t, 1> : (const void*)wgrad_kernel<bf16_t, 0>;
