@@ -267,8 +267,9 @@ typedef struct swn_chain_desc {
   void* y;                      /* output rows, row-major [*, n_last] dtype                       */
   const void* y_add;            /* row-major [*, n_last] tensor added to the output rows (skip gradient) or NULL */
   const int32_t* y_add_gather;  /* row -> row of y_add (-1 = nothing to add), or NULL (identity)  */
-  int32_t geometry;             /* 0 / 1 = the 64-row tile kernels (chain.hip); 2 = the 256-row kernel (chain_big.hip: chains of
-                                   256 x 256 layers, bf16 / fp16, no rowbias / x_scale / x_save / y_add_gather; swn_chain_big_ok).
+  int32_t geometry;             /* 0 / 1 = the 64-row tile kernels (chain.hip); 2 = one 256-row workgroup per CU, 3 = two 96-row
+                                   workgroups per CU (chain_big.hip: chains of 256 x 256 layers, bf16 / fp16, no rowbias / x_scale /
+                                   x_save / y_add_gather; swn_chain_big_ok).
                                    The ReLU masks of the two geometries are laid out differently: run a backward chain (relu = 2)
                                    on the geometry of the forward chain that recorded its masks.  fp16 chains always use 2.   */
   int32_t tag;                  /* profiling only: selects an identical kernel instantiation with its own symbol so that

@@ -76,7 +76,7 @@ def check():
         Wb = [o.pack_weights(w, dt, False) for w in Wm]
         vm = valid_rows(ng, cap, counts)
         res = {}
-        for geom in (1, 2):
+        for geom in (1, 2, 3):
             y, saves, masks = run_fwd(geom, h0, perm, counts_t, Wf, B, ng, cap)
             dout = (torch.randn(h0.shape[0], M, generator=torch.Generator().manual_seed(seed + 7)).to(dev) * 0.1).to(dt)
             skip_add = torch.randn(ng * cap, M, generator=torch.Generator().manual_seed(seed + 9)).to(dev).to(dt)
@@ -94,17 +94,19 @@ def check():
                 ok = False
             return same
         print(f"groups {ng} cap {cap} counts {counts.tolist()[:8]}...")
-        allsame = cmp("y", res[1]["y"], res[2]["y"])
-        for l in range(L - 1):
-            allsame &= cmp(f"save{l}", res[1]["saves"][l], res[2]["saves"][l])
-        allsame &= cmp("dx", res[1]["dx"], res[2]["dx"])
-        for l in range(L - 1):
-            allsame &= cmp(f"dz{l}", res[1]["dz"][l], res[2]["dz"][l])
-        # rows past the valid ones must be untouched (zeros)
-        for nm, t in (("y", res[2]["y"]), ("save0", res[2]["saves"][0]), ("dx", res[2]["dx"]), ("dz0", res[2]["dz"][0])):
-            if t[~vm].abs().sum().item() != 0:
-                print(f"  WROTE PAST THE VALID ROWS: {nm}")
-                ok = False
+        allsame = True
+        for gg in (2, 3):
+            allsame &= cmp(f"g{gg} y", res[1]["y"], res[gg]["y"])
+            for l in range(L - 1):
+                allsame &= cmp(f"g{gg} save{l}", res[1]["saves"][l], res[gg]["saves"][l])
+            allsame &= cmp(f"g{gg} dx", res[1]["dx"], res[gg]["dx"])
+            for l in range(L - 1):
+                allsame &= cmp(f"g{gg} dz{l}", res[1]["dz"][l], res[gg]["dz"][l])
+            # rows past the valid ones must be untouched (zeros)
+            for nm, t in (("y", res[gg]["y"]), ("save0", res[gg]["saves"][0]), ("dx", res[gg]["dx"]), ("dz0", res[gg]["dz"][0])):
+                if t[~vm].abs().sum().item() != 0:
+                    print(f"  WROTE PAST THE VALID ROWS: g{gg} {nm}")
+                    ok = False
         # inference variant (no saves / masks)
         y1, _, _ = run_fwd(1, h0, perm, counts_t, Wf, B, ng, cap, save=False)
         y2, _, _ = run_fwd(2, h0, perm, counts_t, Wf, B, ng, cap, save=False)
@@ -147,7 +149,7 @@ def time_all():
             c[1::2] = int(CAP * (2 * frac - 1))
             counts = c.to(dev)
         kept = int(counts.sum().item())
-        for geom in (1, 2):
+        for geom in (1, 2, 3):
             def fwd(save=True, bare=False):
                 layers = [o.Layer(Wf[l], None if bare else B[l], relu=0 if bare else (1 if l < L - 1 else 0), skip=(l == 3 and not bare),
                                   save=saves[l] if (save and l < L - 1) else None, mask=masks[l] if (save and l < L - 1 and not bare) else None)

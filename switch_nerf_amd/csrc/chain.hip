@@ -633,6 +633,8 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
             v = add_chunks<T>(v, a);
           }
         }
+        // (plain stores: these tensors are read back by the next kernels while still on-die; non-temporal stores measured 5 % slower
+        //  per step here - unlike the expert chains' seven write-only activation streams, chain_big.hip)
         *(uint4*)((char*)outp + (grow0 + row) * row_bytes + ch * 16) = v;
       }
     }
@@ -810,9 +812,15 @@ extern "C" int swn_chain_tile_rows(int dtype) { return dtype == SWN_BF16 ? Cfg<b
 /* uint32 words of one ReLU mask buffer for a chain over n_groups x group_stride rows whose widest layer has max_width features */
 extern "C" long swn_chain_mask_words(int dtype, int n_groups, int group_stride, int max_width) {
   const bool wide = max_width > 256;
-  int bm = wide ? chain_wide_tile_rows(dtype) : swn_chain_tile_rows(dtype);
-  if (!wide && dtype != SWN_F32) bm = 256;     // covers the 64-row and the 256-row (chain_big.hip) geometry alike
-  return (long)cdiv(group_stride, bm) * n_groups * bm * (wide ? 16 : 8);
+  const int bm = wide ? chain_wide_tile_rows(dtype) : swn_chain_tile_rows(dtype);
+  long words = (long)cdiv(group_stride, bm) * n_groups * bm * (wide ? 16 : 8);
+  if (!wide && dtype != SWN_F32) {             // ... or any of the chain_big.hip geometries (one buffer size fits all)
+    for (int geo = 2; geo <= 3; ++geo) {
+      const long w = (long)cdiv(group_stride, chain_big_tile_rows(geo)) * n_groups * chain_big_mask_words_per_tile(geo);
+      if (w > words) words = w;
+    }
+  }
+  return words;
 }
 
 extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
@@ -844,13 +852,13 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   SWN_CHECK(d.x != nullptr && d.y != nullptr, "swn_mlp_chain: x / y must not be null");
   SWN_CHECK(d.tag >= 0 && d.tag <= 6, "swn_mlp_chain: tag %d not in [0,6]", d.tag);
   SWN_CHECK(!(wide && concat), "swn_mlp_chain: concat-skip layers are built for the 256-feature kernels only");
-  SWN_CHECK(d.geometry >= 0 && d.geometry <= 2, "swn_mlp_chain: geometry %d not in [0,2]", d.geometry);
+  SWN_CHECK(d.geometry >= 0 && d.geometry <= 3, "swn_mlp_chain: geometry %d not in [0,3]", d.geometry);
   {   // 256-row geometry (chain_big.hip).  Never chosen silently for bf16: the ReLU mask layout differs between the geometries,
       // and a backward chain must run on the geometry of the forward chain that recorded its masks - the caller pairs them.
     const bool can = chain_big_eligible(d);
-    SWN_CHECK(d.geometry != 2 || can, "swn_mlp_chain: geometry 2 needs bf16 / fp16 chains of 256 x 256 layers without rowbias / x_scale / x_save / y_add_gather");
+    SWN_CHECK(d.geometry < 2 || can, "swn_mlp_chain: geometry 2 / 3 needs bf16 / fp16 chains of 256 x 256 layers without rowbias / x_scale / x_save / y_add_gather");
     SWN_CHECK(d.dtype != SWN_F16 || can, "swn_mlp_chain: fp16 chains run on the 256-row geometry only (256 x 256 layers)");
-    if (d.geometry == 2 || d.dtype == SWN_F16) return chain_big_launch(d, stream);
+    if (d.geometry >= 2 || d.dtype == SWN_F16) return chain_big_launch(d, stream);
   }
   if (wide) return chain_wide_launch(d, stream);        // 512-feature geometry (this file compiled with -DSWN_WIDE=1)
   if (concat) return chain_concat_launch(d, stream);    // concat-skip layers (this file compiled with -DSWN_CONCAT=1)

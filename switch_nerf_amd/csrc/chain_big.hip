@@ -31,17 +31,35 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 #define SWN_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 #define SWN_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
 
-constexpr int NT = 512;                 // 8 waves
-constexpr int BM = 256;                 // rows per tile
+// Two workgroup geometries share the code (template parameters NW = waves, MI = 32-row tiles per wave):
+//   G256 (NW 8, MI 4): ONE 512-thread workgroup per CU on a 256-row tile; wave (rg, fg) owns rows [128 rg, +128) x features [64 fg, +64);
+//                      LDS 128 KiB tile + 24 KiB ring + index / bias scratch.
+//   G96  (NW 4, MI 3): TWO independent 256-thread workgroups per CU on 96-row tiles (48 KiB tile + 24 KiB ring each); wave fg owns all
+//                      96 rows x features [64 fg, +64).  A workgroup's epilogue / prologue / write-out (VALU, LDS, latency) overlaps the
+//                      other one's K loop on the same SIMDs - the lockstep G256 workgroup leaves the matrix pipe idle there - at the
+//                      price of 2.7x the weight copies per row of G256 (still 1.5x fewer than the 64-row kernels).
 constexpr int ROWB = 512;               // tile row stride in bytes (256 two-byte features)
-constexpr int TILE_B = BM * ROWB;       // 128 KiB
 constexpr int SLOT_B = 8192;            // weights of one K step: 8 feature tiles x 1 KiB
 constexpr int NSLOT = 3;
-constexpr int RING0 = TILE_B;
-constexpr int IDX0 = RING0 + NSLOT * SLOT_B;   // int32 [256]: source row of every tile row
-constexpr int BIAS0 = IDX0 + 1024;             // f32 [256]
-constexpr int LDS_BYTES = BIAS0 + 1024;        // 157,696 B of the CU's 163,840
-constexpr int KSTEPS = 16;                     // 256 / 16
+constexpr int KSTEPS = 16;              // 256 / 16
+
+template <int NW_, int MI_> struct Geo {
+  static constexpr int NW = NW_, MI = MI_;
+  static constexpr int RG = NW / 4;                  // row groups (waves with the same feature slab)
+  static constexpr int BM = RG * MI * 32;            // rows per tile
+  static constexpr int NT = NW * 64;
+  static constexpr int TILE_B = BM * ROWB;
+  static constexpr int RING0 = TILE_B;
+  static constexpr int IDX0 = RING0 + NSLOT * SLOT_B;   // int32 [BM]: source row of every tile row
+  static constexpr int BIAS0 = IDX0 + 1024;             // f32 [256]
+  static constexpr int LDS_BYTES = BIAS0 + 1024;
+  static constexpr int PIECES = BM / 2;              // 1 KiB pieces (2 rows) of a tile
+  static constexpr int NCOPY = NW / 2;               // copy waves (w < NCOPY), each copies FPC feature tiles per K step
+  static constexpr int FPC = 8 / NCOPY;
+  static constexpr int OCC = 2;                      // waves per SIMD (launch bound): 1 x 8 or 2 x 4
+};
+typedef Geo<8, 4> G256;
+typedef Geo<4, 3> G96;
 
 struct Args {
   swn_chain_desc d;
@@ -104,28 +122,33 @@ struct Ctx {
   uint32_t e_base;       // ... of this lane's epilogue row incl. swizzle seed, half-wave and wave feature offset; ^ ((4 ni + g4) << 4)
   uint32_t e2_base;      // the same for the 16-byte writes after the half-wave exchange: chunk g4 + lhi, no 8-byte half offset
   uint32_t wf_base;      // RING0 + this wave's first feature tile + lane * 16 (add the slot offset)
-  uint32_t wo_base;      // write-out of the chain output (all 8 waves): LDS byte address of this lane's 16 bytes of piece j = 0; + j * 8192
-  uint32_t wos_base[2];  // write-out inside the K loop (store waves 4..7, two pieces per step): ... of piece (ks = 0, i); + ks * 8192
   int slot_off[3];       // byte offset of the ring slot of K step (16 L + j), j mod 3 - refreshed per layer
 };
+
+// LDS byte address of this lane's 16 bytes of write-out piece c (tile rows 2 c, 2 c + 1; lane -> row 2 c + lhi, 16-byte column l31)
+__device__ __forceinline__ uint32_t piece_addr(const Ctx& cx, int c) {
+  const int r = 2 * c + cx.lhi;
+  return (uint32_t)(r * ROWB + ((cx.l31 ^ (r & 15)) << 4));
+}
 
 // ---- the K loop of one layer ------------------------------------------------------------------------------------------------
 // Roles (vmcnt completes in order per wave, so a wave that both copies weights and stores activations can keep only ~2 stores in
 // flight behind the copy it waits for - far too few bytes to cover the HBM write latency):
-//   COPY  (waves 0..3): two weight copies per K step (feature tiles 2 w, 2 w + 1), counted wait for the copies of step ks + 1;
-//   STORE (waves 4..7): two 1 KiB pieces of the write-out per K step (SAVE: the input tile of this layer is a saved activation),
-//                       never waits for its stores - up to 63 of them in flight per wave.
-// One wave of each role per SIMD.
-template <typename E, bool SAVE>
-__device__ __forceinline__ void k_loop(f32x16_t (&acc)[4][2], const Ctx& cx, __amdgpu_buffer_rsrc_t rs_cur, __amdgpu_buffer_rsrc_t rs_nxt,
+//   COPY  (waves 0 .. NW/2 - 1): FPC weight copies per K step, counted wait for the copies of step ks + 1;
+//   STORE (the other waves):     two 1 KiB pieces of the write-out per K step (SAVE: the input tile of this layer is a saved
+//                                activation), never waits for its stores - up to 63 of them in flight per wave.
+// One wave of each role per SIMD (G256) / per SIMD pair (G96).
+template <typename E, typename G, bool SAVE>
+__device__ __forceinline__ void k_loop(f32x16_t (&acc)[G::MI][2], const Ctx& cx, __amdgpu_buffer_rsrc_t rs_cur, __amdgpu_buffer_rsrc_t rs_nxt,
                                        __amdgpu_buffer_rsrc_t rs_save, const bool COPY /* wave-uniform */, Timers& tm) {
+  constexpr int MI = G::MI;
   char* smem = cx.smem;
   const int lane16 = cx.lane * 16;
   const bool STORE = SAVE && !COPY;
-  u32x4_t fa[2][4], fw[2][2];
+  u32x4_t fa[2][MI], fw[2][2];
   u32x4_t wo[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
   // launder the per-lane bases: stops the compiler from hoisting the 16 swizzled fragment addresses (and friends) of the unrolled
-  // steps out of the layer loop into long-lived registers (spills next to 128 accumulators)
+  // steps out of the layer loop into long-lived registers (spills next to the accumulators)
   uint32_t a_base = cx.a_base, wf_base = cx.wf_base;
   asm volatile("" : "+v"(a_base), "+v"(wf_base));
   auto read_w = [&](int ks, int set, int ni) {
@@ -134,31 +157,52 @@ __device__ __forceinline__ void k_loop(f32x16_t (&acc)[4][2], const Ctx& cx, __a
   auto read_a = [&](int ks, int set, int mi) {
     fa[set][mi] = *(const u32x4_t*)(smem + (a_base ^ (uint32_t)(ks << 5)) + mi * (32 * ROWB));
   };
-  auto copy = [&](int ks, int i) {     // feature tile 2 w + i of K step ks + 3 of the stream -> the slot of step ks
-    const int nx = ks + 3, t = 2 * cx.w + i;
-    if (nx < KSTEPS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_cur, SWN_LDS(smem + RING0 + cx.slot_off[nx % 3] + t * 1024), 16, lane16, (t * KSTEPS + nx) * 1024, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_nxt, SWN_LDS(smem + RING0 + cx.slot_off[nx % 3] + t * 1024), 16, lane16, (t * KSTEPS + nx - KSTEPS) * 1024, 0, 0);
+  auto copy = [&](int ks, int i) {     // feature tile FPC w + i of K step ks + 3 of the stream -> the slot of step ks
+    const int nx = ks + 3, t = G::FPC * cx.w + i;
+    if (nx < KSTEPS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_cur, SWN_LDS(smem + G::RING0 + cx.slot_off[nx % 3] + t * 1024), 16, lane16, (t * KSTEPS + nx) * 1024, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_nxt, SWN_LDS(smem + G::RING0 + cx.slot_off[nx % 3] + t * 1024), 16, lane16, (t * KSTEPS + nx - KSTEPS) * 1024, 0, 0);
   };
-  auto store = [&](int ks, int i) {    // piece (ks, wave, i) of the write-out: rows 16 ks + 4 (w - 4) + 2 i + {0, 1}
-    __builtin_amdgcn_raw_buffer_store_b128(wo[i], rs_save, lane16, (ks * 8 + 2 * (cx.w - 4) + i) * 1024, SWN_BIG_STORE_AUX);
+  // write-out piece (ks, i) of this store wave: c = ks * NW + 2 (w - NW/2) + i.  G96 has 64 slots for 48 pieces: the surplus ones
+  // read piece 0 and their store falls outside the descriptor (dropped).
+  auto piece = [&](int ks, int i) -> int { return ks * G::NW + 2 * (cx.w - G::NCOPY) + i; };
+  auto store = [&](int ks, int i) {
+    __builtin_amdgcn_raw_buffer_store_b128(wo[i], rs_save, lane16, piece(ks, i) * 1024, SWN_BIG_STORE_AUX);
+  };
+  auto read_piece = [&](int ks, int i) {
+    const int c = piece(ks, i);
+    wo[i] = *(const u32x4_t*)(smem + piece_addr(cx, c < G::PIECES ? c : 0));
   };
   read_w(0, 0, 0); read_w(0, 0, 1);
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) read_a(0, 0, mi);
+  for (int mi = 0; mi < MI; ++mi) read_a(0, 0, mi);
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
     const int cur = ks & 1, nxt = cur ^ 1;
+#ifdef SWN_ABL_NOREAD
+    const bool more = false;
+#else
     const bool more = ks + 1 < KSTEPS;
+#endif
     SWN_TM(const long long q0 = TICK();)
     SWN_WAIT_LGKM0();                       // the fragments of step ks (and the write-out pieces read in step ks - 1) are in registers
-    if (COPY) SWN_WAIT_VM(2);               // this wave's copies of step ks + 1 have landed (younger: the two copies of step ks + 2)
+#ifndef SWN_ABL_NOCOPY
+    if (COPY) {                             // this wave's copies of step ks + 1 have landed (younger: the FPC copies of step ks + 2)
+      if constexpr (G::FPC == 2) SWN_WAIT_VM(2); else SWN_WAIT_VM(4);
+    }
+#endif
     SWN_TM(const long long q1 = TICK();)
+#ifndef SWN_ABL_NOBAR
     __builtin_amdgcn_s_barrier();           // ... and everybody else's; every wave is done reading the slot of step ks
+#endif
     SWN_TM(const long long q2 = TICK(); tm.wait += q1 - q0; tm.bar += q2 - q1;)
     SWN_PIN();
     // The matrix pipe starts at once; the LDS reads of the next step, the copies of step ks + 3 / the stores of the previous
     // write-out pieces and the reads of this step's pieces are spread between the MFMAs (order pinned).
+#ifdef SWN_ABL_NOMFMA
+#define SWN_MM(mi, ni) asm volatile("" :: "v"(fw[cur][ni]), "v"(fa[cur][mi]))
+#else
 #define SWN_MM(mi, ni) acc[mi][ni] = E::mfma(fw[cur][ni], fa[cur][mi], acc[mi][ni])
+#endif
     SWN_MM(0, 0);
     SWN_PIN();
     if (more) { read_w(ks + 1, nxt, 0); read_w(ks + 1, nxt, 1); }
@@ -166,13 +210,21 @@ __device__ __forceinline__ void k_loop(f32x16_t (&acc)[4][2], const Ctx& cx, __a
     SWN_MM(0, 1);
     SWN_PIN();
     if (more) read_a(ks + 1, nxt, 0);
-    if (COPY) copy(ks, 0);
+#ifndef SWN_ABL_NOCOPY
+    if (COPY) { copy(ks, 0); if constexpr (G::FPC == 4) copy(ks, 1); }
+#else
+    if (false) {}
+#endif
     else if (SAVE && ks >= 1) store(ks - 1, 0);
     SWN_PIN();
     SWN_MM(1, 0);
     SWN_PIN();
     if (more) read_a(ks + 1, nxt, 1);
-    if (COPY) copy(ks, 1);
+#ifndef SWN_ABL_NOCOPY
+    if (COPY) { copy(ks, G::FPC - 1); if constexpr (G::FPC == 4) copy(ks, 2); }
+#else
+    if (false) {}
+#endif
     else if (SAVE && ks >= 1) store(ks - 1, 1);
     SWN_PIN();
     SWN_MM(1, 1);
@@ -181,17 +233,22 @@ __device__ __forceinline__ void k_loop(f32x16_t (&acc)[4][2], const Ctx& cx, __a
     SWN_PIN();
     SWN_MM(2, 0);
     SWN_PIN();
-    if (more) read_a(ks + 1, nxt, 3);
+    if constexpr (MI == 4) { if (more) read_a(ks + 1, nxt, 3); }
+    else { if (STORE) read_piece(ks, 0); }
     SWN_PIN();
     SWN_MM(2, 1);
     SWN_PIN();
-    if (STORE) wo[0] = *(const u32x4_t*)(smem + cx.wos_base[0] + ks * 8192);
-    SWN_PIN();
-    SWN_MM(3, 0);
-    SWN_PIN();
-    if (STORE) wo[1] = *(const u32x4_t*)(smem + cx.wos_base[1] + ks * 8192);
-    SWN_PIN();
-    SWN_MM(3, 1);
+    if constexpr (MI == 4) {
+      if (STORE) read_piece(ks, 0);
+      SWN_PIN();
+      SWN_MM(3, 0);
+      SWN_PIN();
+      if (STORE) read_piece(ks, 1);
+      SWN_PIN();
+      SWN_MM(3, 1);
+    } else {
+      if (STORE) read_piece(ks, 1);
+    }
 #undef SWN_MM
     SWN_PIN();
   }
@@ -203,7 +260,7 @@ __device__ __forceinline__ void k_loop(f32x16_t (&acc)[4][2], const Ctx& cx, __a
 }
 
 // ---- epilogue of one layer: accumulators (+bias, +skip input) -> ReLU (recording the mask) / stored mask -> the tile, in place ----
-// A lane owns row 128 rg + 32 mi + l31 and, per (ni, g4), features 64 fg + 32 ni + 8 g4 + 4 lhi .. + 3.
+// A lane owns row (32 MI rg + 32 mi + l31) and, per (ni, g4), features 64 fg + 32 ni + 8 g4 + 4 lhi .. + 3.
 // A non-packed VALU instruction costs a wave 4 clocks on CDNA4 (16 lanes per clock), an MFMA 32: ~5 VALU per value were as
 // expensive as the K loop.  ReLU and its mask therefore work on the PACKED 16-bit results (two values per instruction; bf16 and
 // fp16 are sign-magnitude, so as int16 a negative value or -0 is < 0):
@@ -233,8 +290,8 @@ __device__ __forceinline__ uint32_t pk_mul16(uint32_t p, uint32_t t) {
   return q;
 }
 
-template <typename E, int RELU, bool BIAS, bool SKIP>
-__device__ __forceinline__ void epilogue(f32x16_t (&acc)[4][2], const Ctx& cx, u32x4_t& mk) {
+template <typename E, typename G, int RELU, bool BIAS, bool SKIP>
+__device__ __forceinline__ void epilogue(f32x16_t (&acc)[G::MI][2], const Ctx& cx, u32x4_t& mk) {
   char* smem = cx.smem;
   uint32_t e_base = cx.e_base, e2_base = cx.e2_base;      // laundered: keeps the swizzled addresses inside the layer loop (see k_loop)
   asm volatile("" : "+v"(e_base), "+v"(e2_base));
@@ -244,10 +301,10 @@ __device__ __forceinline__ void epilogue(f32x16_t (&acc)[4][2], const Ctx& cx, u
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4)
-        bias[ni][g4] = *(const f32x4_t*)(smem + BIAS0 + (((cx.w & 3) * 64 + 32 * ni + 8 * g4 + 4 * cx.lhi) << 2));
+        bias[ni][g4] = *(const f32x4_t*)(smem + G::BIAS0 + (((cx.w & 3) * 64 + 32 * ni + 8 * g4 + 4 * cx.lhi) << 2));
   }
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
+  for (int mi = 0; mi < G::MI; ++mi) {
     u32x2_t xv[2][4];
     if constexpr (SKIP) {
 #pragma unroll
@@ -302,25 +359,26 @@ __device__ __forceinline__ void epilogue(f32x16_t (&acc)[4][2], const Ctx& cx, u
   }
 }
 
-template <typename E>
-__device__ __forceinline__ void epilogue_dispatch(f32x16_t (&acc)[4][2], const Ctx& cx, u32x4_t& mk, int relu, bool bias, bool skip) {
+template <typename E, typename G>
+__device__ __forceinline__ void epilogue_dispatch(f32x16_t (&acc)[G::MI][2], const Ctx& cx, u32x4_t& mk, int relu, bool bias, bool skip) {
   if (relu == 1) {
-    if (skip) { if (bias) epilogue<E, 1, true, true>(acc, cx, mk); else epilogue<E, 1, false, true>(acc, cx, mk); }
-    else { if (bias) epilogue<E, 1, true, false>(acc, cx, mk); else epilogue<E, 1, false, false>(acc, cx, mk); }
+    if (skip) { if (bias) epilogue<E, G, 1, true, true>(acc, cx, mk); else epilogue<E, G, 1, false, true>(acc, cx, mk); }
+    else { if (bias) epilogue<E, G, 1, true, false>(acc, cx, mk); else epilogue<E, G, 1, false, false>(acc, cx, mk); }
   } else if (relu == 2) {
-    if (skip) epilogue<E, 2, false, true>(acc, cx, mk); else epilogue<E, 2, false, false>(acc, cx, mk);
+    if (skip) epilogue<E, G, 2, false, true>(acc, cx, mk); else epilogue<E, G, 2, false, false>(acc, cx, mk);
   } else {
-    if (skip) { if (bias) epilogue<E, 0, true, true>(acc, cx, mk); else epilogue<E, 0, false, true>(acc, cx, mk); }
-    else { if (bias) epilogue<E, 0, true, false>(acc, cx, mk); else epilogue<E, 0, false, false>(acc, cx, mk); }
+    if (skip) { if (bias) epilogue<E, G, 0, true, true>(acc, cx, mk); else epilogue<E, G, 0, false, true>(acc, cx, mk); }
+    else { if (bias) epilogue<E, G, 0, true, false>(acc, cx, mk); else epilogue<E, G, 0, false, false>(acc, cx, mk); }
   }
 }
 
-// the (gathered) chain input rows -> the swizzled tile: 128 pieces of 1 KiB (2 rows), 16 per wave, global_load ... lds
+// the (gathered) chain input rows -> the swizzled tile: 1 KiB pieces (2 rows), PIECES / NW per wave, global_load ... lds
+template <typename G>
 __device__ __forceinline__ void stage_input(const Ctx& cx, const char* x) {
-  const int* idx = (const int*)(cx.smem + IDX0);
+  const int* idx = (const int*)(cx.smem + G::IDX0);
 #pragma unroll 4
-  for (int j = 0; j < 16; ++j) {
-    const int c = j * 8 + cx.w;
+  for (int j = 0; j < G::PIECES / G::NW; ++j) {
+    const int c = j * G::NW + cx.w;
     const int r = 2 * c + cx.lhi;
     const long src = idx[r];
     const int q = cx.l31 ^ (r & 15);          // LDS position l31 of row r holds chunk q
@@ -328,9 +386,10 @@ __device__ __forceinline__ void stage_input(const Ctx& cx, const char* x) {
   }
 }
 
-template <typename E, int TAG>
-__global__ __launch_bounds__(NT, 2) void chainb_kernel(const Args args) {
+template <typename E, typename G, int TAG>
+__global__ __launch_bounds__(G::NT, G::OCC) void chainb_kernel(const Args args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = G::BM, MI = G::MI;
   const swn_chain_desc& d = args.d;
   Ctx cx;
   cx.smem = smem;
@@ -361,18 +420,13 @@ __global__ __launch_bounds__(NT, 2) void chainb_kernel(const Args args) {
   const int wset = g % d.n_wsets;
   const int n_layers = d.n_layers;
 
-  cx.a_base = (uint32_t)((128 * rg + cx.l31) * ROWB + ((cx.lhi ^ r15) << 4));
-  cx.e_base = (uint32_t)((128 * rg + cx.l31) * ROWB + (r15 << 4) + 8 * cx.lhi) ^ (uint32_t)(fg << 7);
-  cx.e2_base = (uint32_t)((128 * rg + cx.l31) * ROWB + (r15 << 4)) ^ (uint32_t)((fg << 7) | (cx.lhi << 4));
-  cx.wf_base = (uint32_t)(RING0 + (2 * fg) * 1024 + cx.lane * 16);
-  cx.wo_base = (uint32_t)((2 * cx.w + cx.lhi) * ROWB + ((cx.l31 ^ ((2 * cx.w + cx.lhi) & 15)) << 4));
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = 4 * (cx.w & 3) + 2 * i + cx.lhi;
-    cx.wos_base[i] = (uint32_t)(r * ROWB + ((cx.l31 ^ (r & 15)) << 4));
-  }
+  const int lrow = 32 * MI * rg + cx.l31;                 // this lane's tile row for mi = 0
+  cx.a_base = (uint32_t)(lrow * ROWB + ((cx.lhi ^ r15) << 4));
+  cx.e_base = (uint32_t)(lrow * ROWB + (r15 << 4) + 8 * cx.lhi) ^ (uint32_t)(fg << 7);
+  cx.e2_base = (uint32_t)(lrow * ROWB + (r15 << 4)) ^ (uint32_t)((fg << 7) | (cx.lhi << 4));
+  cx.wf_base = (uint32_t)(G::RING0 + (2 * fg) * 1024 + cx.lane * 16);
   const int lane16 = cx.lane * 16;
-  const bool copy_role = cx.w < 4;
+  const bool copy_role = cx.w < G::NCOPY;
 
   // the weight-fragment stream of layer L, weight set `wset`: 8 feature tiles x 16 K steps of 1 KiB
   auto wrs = [&](int L) -> __amdgpu_buffer_rsrc_t {
@@ -382,11 +436,11 @@ __global__ __launch_bounds__(NT, 2) void chainb_kernel(const Args args) {
   auto out_rs = [&](void* base) -> __amdgpu_buffer_rsrc_t {     // rows of this tile in a row-major [*, 256] tensor, clipped to the valid rows
     return uniform_rsrc((char*)base + grow0 * ROWB, rows_in_tile * ROWB);
   };
-  auto stage_bias = [&](int L) {        // 1 KiB, all waves issue (waves 4..7 repeat 0..3): keeps the per-wave vmcnt bookkeeping uniform
+  auto stage_bias = [&](int L) {        // 1 KiB: four waves copy 256 B each (further waves repeat them: uniform code)
     const float* b = d.layers[L].b;
     if (b) {
       const __amdgpu_buffer_rsrc_t rb = uniform_rsrc(b + (size_t)wset * 256, 1024);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, SWN_LDS(smem + BIAS0 + (cx.w & 3) * 256), 4, cx.lane * 4, (cx.w & 3) * 256, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, SWN_LDS(smem + G::BIAS0 + (cx.w & 3) * 256), 4, cx.lane * 4, (cx.w & 3) * 256, 0, 0);
     }
   };
 
@@ -396,23 +450,25 @@ __global__ __launch_bounds__(NT, 2) void chainb_kernel(const Args args) {
   {
     const __amdgpu_buffer_rsrc_t r0 = wrs(0);
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, SWN_LDS(smem + RING0 + s * SLOT_B + cx.w * 1024), 16, lane16, (cx.w * KSTEPS + s) * 1024, 0, 0);
+    for (int i = 0; i < 24 / G::NW; ++i) {      // 3 steps x 8 feature tiles, spread over the waves
+      const int f = i * G::NW + cx.w, s = f >> 3, t = f & 7;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, SWN_LDS(smem + G::RING0 + s * SLOT_B + t * 1024), 16, lane16, (t * KSTEPS + s) * 1024, 0, 0);
+    }
   }
   if (tid < BM) {
     const long gr = grow0 + (tid < rows_in_tile ? tid : 0);      // rows past the end repeat the first row (computed, never stored)
     long src = d.x_gather ? (long)d.x_gather[gr] : gr;
     if (src < 0) src = 0;
-    ((int*)(smem + IDX0))[tid] = (int)src;
+    ((int*)(smem + G::IDX0))[tid] = (int)src;
   }
   SWN_WAIT_LGKM0();
   __builtin_amdgcn_s_barrier();
-  stage_input(cx, (const char*)d.x);
+  stage_input<G>(cx, (const char*)d.x);
   stage_bias(0);
   SWN_WAIT_VM(0);
   __builtin_amdgcn_s_barrier();
 
-  f32x16_t acc[4][2];
+  f32x16_t acc[MI][2];
   Timers tm;
   SWN_TM(long long t_a = t_start;)
   for (int L = 0; L < n_layers; ++L) {
@@ -422,7 +478,7 @@ __global__ __launch_bounds__(NT, 2) void chainb_kernel(const Args args) {
     const __amdgpu_buffer_rsrc_t rs_nxt = has_next ? wrs(L + 1) : rs_cur;     // (end of chain: a valid stream, copied and never read)
     void* save_in = L > 0 ? d.layers[L - 1].save : nullptr;
     u32x4_t mk = {0u, 0u, 0u, 0u};
-    uint32_t* mkp = ly.mask ? ly.mask + ((size_t)(blockIdx.x * 8 + cx.w) * 64 + cx.lane) * 4 : nullptr;
+    uint32_t* mkp = ly.mask ? ly.mask + ((size_t)(blockIdx.x * G::NW + cx.w) * 64 + cx.lane) * 4 : nullptr;
     if (ly.relu == 2) mk = *(const u32x4_t*)mkp;
     {   // ring slots of this layer's K steps: step (16 L + j) -> slot (L + j) mod 3
       const int s0 = L % 3;
@@ -431,26 +487,26 @@ __global__ __launch_bounds__(NT, 2) void chainb_kernel(const Args args) {
       cx.slot_off[2] = ((s0 + 2) % 3) * SLOT_B;
     }
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     SWN_TM(const long long p0 = TICK(); if (L == 0) tm.pro = p0 - t_a;)
-    if (save_in) k_loop<E, true>(acc, cx, rs_cur, rs_nxt, out_rs(save_in), copy_role, tm);
-    else k_loop<E, false>(acc, cx, rs_cur, rs_nxt, rs_cur, copy_role, tm);
+    if (save_in) k_loop<E, G, true>(acc, cx, rs_cur, rs_nxt, out_rs(save_in), copy_role, tm);
+    else k_loop<E, G, false>(acc, cx, rs_cur, rs_nxt, rs_cur, copy_role, tm);
     SWN_TM(const long long p1 = TICK(); tm.kloop += p1 - p0;)
 
     SWN_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();       // every wave has finished reading the tile (fragments and write-out)
     if (ly.skip) {                      // the residual input: bring the chain input back into the (dead) tile; the epilogue reads it in place
-      stage_input(cx, (const char*)d.x);
+      stage_input<G>(cx, (const char*)d.x);
       SWN_WAIT_VM(0);
       __builtin_amdgcn_s_barrier();
     }
     SWN_TM(const long long p2 = TICK(); tm.mid += p2 - p1;)
-    epilogue_dispatch<E>(acc, cx, mk, ly.relu, ly.b != nullptr, ly.skip != 0);
+    epilogue_dispatch<E, G>(acc, cx, mk, ly.relu, ly.b != nullptr, ly.skip != 0);
     if (ly.relu == 1 && mkp) *(u32x4_t*)mkp = mk;
     SWN_WAIT_LGKM0();                   // the tile is rewritten
     if (copy_role) SWN_WAIT_VM(0);      // the copies of the next layer's first steps landed long ago (store waves: nothing to wait for,
@@ -466,15 +522,16 @@ __global__ __launch_bounds__(NT, 2) void chainb_kernel(const Args args) {
     const __amdgpu_buffer_rsrc_t ry = out_rs(d.y);
     const __amdgpu_buffer_rsrc_t ra = d.y_add ? out_rs((void*)d.y_add) : ry;
 #pragma unroll 4
-    for (int j = 0; j < 16; ++j) {
-      u32x4_t v = *(const u32x4_t*)(smem + cx.wo_base + j * 8192);
-      const int soff = (j * 8 + cx.w) * 1024;
+    for (int j = 0; j < G::PIECES / G::NW; ++j) {
+      const int c = j * G::NW + cx.w;
+      u32x4_t v = *(const u32x4_t*)(smem + piece_addr(cx, c));
+      const int soff = c * 1024;
       if (d.y_add) {
         const u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(ra, lane16, soff, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = E::pack2(E::lo(v[q]) + E::lo(a[q]), E::hi(v[q]) + E::hi(a[q]));
       }
-      __builtin_amdgcn_raw_buffer_store_b128(v, ry, lane16, soff, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(v, ry, lane16, soff, SWN_BIG_STORE_AUX);
     }
   }
   SWN_WAIT_VM(0);      // no LDS copy may be in flight when the workgroup retires
@@ -505,30 +562,39 @@ bool chain_big_eligible(const swn_chain_desc& d) {
   return true;
 }
 
-int chain_big_launch(const swn_chain_desc& d, void* stream) {
+int chain_big_tile_rows(int geometry) { return geometry == 3 ? swn_big::G96::BM : swn_big::G256::BM; }
+int chain_big_mask_words_per_tile(int geometry) { return (geometry == 3 ? swn_big::G96::NW : swn_big::G256::NW) * 256; }
+
+template <typename G>
+static int chain_big_launch_g(const swn_chain_desc& d, void* stream) {
   using namespace swn_big;
   Args a;
   a.d = d;
-  a.tiles_per_group = cdiv(d.group_rows ? (d.group_rows_clamp < d.group_stride ? d.group_rows_clamp : d.group_stride) : d.group_stride, BM);
+  a.tiles_per_group = cdiv(d.group_rows ? (d.group_rows_clamp < d.group_stride ? d.group_rows_clamp : d.group_stride) : d.group_stride, G::BM);
   if (!d.group_rows) a.d.group_rows_clamp = d.group_stride;
   const long grid = (long)a.tiles_per_group * d.n_groups;
   SWN_CHECK(grid > 0 && grid < (1L << 31), "swn_mlp_chain: grid %ld out of range", grid);
   const void* fn = nullptr;
 #define SWN_PICKB(TAGV)                                                                                                     \
   case TAGV:                                                                                                                \
-    fn = d.dtype == SWN_BF16 ? (const void*)chainb_kernel<Bf16, TAGV> : (const void*)chainb_kernel<Fp16, TAGV>;             \
+    fn = d.dtype == SWN_BF16 ? (const void*)chainb_kernel<Bf16, G, TAGV> : (const void*)chainb_kernel<Fp16, G, TAGV>;       \
     break;
   switch (d.tag) {
     SWN_PICKB(1) SWN_PICKB(2)
-    default: fn = d.dtype == SWN_BF16 ? (const void*)chainb_kernel<Bf16, 0> : (const void*)chainb_kernel<Fp16, 0>;
+    default: fn = d.dtype == SWN_BF16 ? (const void*)chainb_kernel<Bf16, G, 0> : (const void*)chainb_kernel<Fp16, G, 0>;
   }
 #undef SWN_PICKB
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
   SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   void* kargs[] = {(void*)&a};
-  e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(NT), kargs, LDS_BYTES, as_stream(stream));
-  SWN_CHECK(e == hipSuccess, "swn_mlp_chain (256-row geometry) launch: %s", hipGetErrorString(e));
+  e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(G::NT), kargs, G::LDS_BYTES, as_stream(stream));
+  SWN_CHECK(e == hipSuccess, "swn_mlp_chain (geometry %d) launch: %s", d.geometry, hipGetErrorString(e));
   return 0;
+}
+
+int chain_big_launch(const swn_chain_desc& d, void* stream) {
+  if (d.geometry == 3) return chain_big_launch_g<swn_big::G96>(d, stream);
+  return chain_big_launch_g<swn_big::G256>(d, stream);
 }
 
 }  // namespace swn

@@ -57,6 +57,8 @@ int chain_wide_tile_rows(int dtype);
 int chain_concat_launch(const swn_chain_desc& d, void* stream); // chain.hip compiled with -DSWN_CONCAT=1 (concat-skip layer mode)
 bool chain_big_eligible(const swn_chain_desc& d);                // chain_big.hip: the 256-row geometry
 int chain_big_launch(const swn_chain_desc& d, void* stream);
+int chain_big_tile_rows(int geometry);
+int chain_big_mask_words_per_tile(int geometry);
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -592,10 +592,11 @@ def test_chain_wide_512(dtype):
     assert report(f"chain512_d0_{dtype}", d0, g0) <= tolb * max(1.0, g0.abs().max().item())
 
 
+@pytest.mark.parametrize("geometry", [2, 3])
 @pytest.mark.parametrize("ng,cap,seed", [(16, 1000, 1), (8, 256, 2), (24, 700, 3), (8, 4096, 4)])
-def test_chain_256_row_geometry_bit_exact(ng, cap, seed):
-    """The 256-row chain geometry (chain_big.hip: one 512-thread workgroup per 256-row tile, weights shared through an LDS ring,
-    write-out interleaved into the next layer's K loop) against the 64-row kernels (chain.hip, pinned on the fp32 oracle above):
+def test_chain_256_row_geometry_bit_exact(ng, cap, seed, geometry):
+    """The chain_big.hip geometries (2: one 512-thread workgroup per 256-row tile, 3: two 256-thread workgroups per CU on 96-row
+    tiles; weights shared through an LDS ring, write-out interleaved into the next layer's K loop) against the 64-row kernels (chain.hip, pinned on the fp32 oracle above):
     the MFMA accumulation order and the epilogue arithmetic are the same, so every output, every saved activation and every dZ of
     the ExpertMLP forward and backward-data chains must be BIT-identical, on ragged (segment, expert) groups (empty, 1 row, one
     row past a tile, full), with gathered input rows; rows past a group's count must stay untouched."""
@@ -623,7 +624,7 @@ def test_chain_256_row_geometry_bit_exact(ng, cap, seed):
     dout = (torch.randn(P, M, generator=g) * 0.1).to(dev()).to(dt)
     skip_add = torch.randn(rows, M, generator=g).to(dev()).to(dt)
     res = {}
-    for geom in (1, 2):
+    for geom in (1, geometry):
         saves = [torch.zeros(rows, M, dtype=dt, device=dev()) for _ in range(L - 1)]
         masks = [torch.zeros(o.chain_mask_words(dt, ng, cap, M), dtype=torch.int32, device=dev()) for _ in range(L - 1)]
         y = torch.zeros(rows, M, dtype=dt, device=dev())
@@ -643,7 +644,7 @@ def test_chain_256_row_geometry_bit_exact(ng, cap, seed):
         torch.cuda.synchronize()
         res[geom] = [("y", y), ("y_inference", y_inf), ("dx", dx)] + [(f"save{l}", saves[l]) for l in range(L - 1)] + \
                     [(f"dz{l}", dz[l]) for l in range(L - 1)]
-    for (name, a), (_, b) in zip(res[1], res[2]):
+    for (name, a), (_, b) in zip(res[1], res[geometry]):
         assert torch.equal(a[vm], b[vm]), f"{name}: {(a[vm] != b[vm]).float().mean().item():.3g} of the valid elements differ"
         assert b[~vm].abs().sum().item() == 0, f"{name}: rows past a group's count were written"
-    assert (res[2][0][1][vm].float().abs().sum() > 0) and torch.isfinite(res[2][0][1].float()).all()
+    assert (res[geometry][0][1][vm].float().abs().sum() > 0) and torch.isfinite(res[geometry][0][1].float()).all()
