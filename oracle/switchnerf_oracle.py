@@ -95,7 +95,11 @@ def route_top1(gates: np.ndarray, capacity_factor: float, batch_prioritized: boo
         loc[sel] = np.arange(sel.shape[0], dtype=np.int32)
         counts[e] = sel.shape[0]
     cap = capacity_of(P, E, capacity_factor)
-    return dict(idx=idx, loc=loc, gate=gmax.astype(np.float32), capacity=cap, counts=counts.astype(np.int32))
+    # top-2 gap of every token (max - second max of its gate row): how close its expert choice is to a tie - parity tests only accept
+    # an index that differs from this oracle's where the gap is at rounding-noise level
+    part = np.partition(gates, E - 2, axis=1) if E > 1 else gates
+    gap = (part[:, E - 1] - part[:, E - 2]).astype(np.float32) if E > 1 else np.ones(P, np.float32)
+    return dict(idx=idx, loc=loc, gate=gmax.astype(np.float32), capacity=cap, counts=counts.astype(np.int32), top2_gap=gap)
 
 
 def load_balance_loss(gates: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
