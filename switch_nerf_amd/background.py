@@ -168,7 +168,7 @@ class BackgroundScene:
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX)
                 bg_present = bool(flag.item() > 0)
         for m in (nerf, bg):
-            scale = grad_allreduce(m.grad) if grad_allreduce is not None else 1.0
+            scale = grad_allreduce(m._allreduce_view()) if grad_allreduce is not None else 1.0
             if optimizer_step and (m is nerf or bg_present):
                 m.step_count += 1
                 ops.adam_step(m.flat, m.grad, m.m, m.v, None, m.step_count, m.lr, grad_scale=scale)

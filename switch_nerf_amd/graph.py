@@ -61,7 +61,7 @@ class GraphedTrainStep:
         self.graph.replay()
         scale = 1.0
         if grad_allreduce is not None:
-            scale = grad_allreduce(m.grad)
+            scale = grad_allreduce(m._allreduce_view())
         if optimizer_step:
             from . import ops
             m.step_count += 1

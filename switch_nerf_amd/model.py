@@ -47,11 +47,16 @@ class SwitchNeRF:
         self.base_lr = lr             # undecayed rate ('initial_lr' of the reference's ExponentialLR); self.lr = the current rate
         spec = self._configure(cfg)
         self.spec, off = {}, 0
-        for name, shape in spec:
+        self.n_dense = None           # elements of the flat buffer before the first expert parameter (all of it for dense models)
+        for i, (name, shape) in enumerate(spec):
+            if i == getattr(self, "_n_dense_spec", len(spec)):
+                self.n_dense = off
             n = int(np.prod(shape))
             self.spec[name] = (off, shape)
             off += _ceil_to(n, 64)
         self.n_flat = off
+        if self.n_dense is None:
+            self.n_dense = off
         z = lambda: torch.zeros(self.n_flat, dtype=torch.float32, device=self.dev)
         self.flat, self.grad, self.m, self.v = z(), z(), z(), z()
         self.p = {k: self.flat[o:o + int(np.prod(s))].view(s) for k, (o, s) in self.spec.items()}
@@ -83,18 +88,22 @@ class SwitchNeRF:
         self.n_ray_feat = self.in_dir + cfg["appearance_dim"]
         spec = [("xyz.w", (self.KP, M)), ("xyz.b", (M,)), ("gate0.w", (M, G)), ("gate0.b", (G,)),
                 ("gate1.w", (G, G)), ("gate1.b", (G,)), ("ln.w", (G,)), ("ln.b", (G,)), ("wg", (E, G))]
-        for l in range(L):
-            spec += [(f"exp{l}.w", (E, M, M)), (f"exp{l}.b", (E, M))]
         spec += [("l1.w", (M, M)), ("l1.b", (M,)), ("l2h.w", (M, H2)), ("l2r.w", (self.n_ray_feat, H2)), ("l2.b", (H2,)),
                  ("sigma.w", (M,)), ("sigma.b", (1,)), ("color.w", (3, H2)), ("color.b", (3,)),
                  ("emb", (cfg["appearance_count"], cfg["appearance_dim"]))]
+        # the expert parameters come LAST in the flat buffer: under expert parallelism only the dense prefix is all-reduced
+        # (the reference keeps the experts out of DDP, models/nerf_moe.py:139, 1037-1039); hash table: see below
+        self._expert_spec = []
+        for l in range(L):
+            self._expert_spec += [(f"exp{l}.w", (E, M, M)), (f"exp{l}.b", (E, M))]
         self.L, self.M, self.E, self.G, self.H2 = L, M, E, G, H2
         self._chain_weights = ["xyz", "gate0", "gate1", "l1", "l2h"] + [f"exp{l}" for l in range(L)]
         self._fwd_only_weights = {"xyz"}              # first layer: no input gradient, no transposed copy
         if self.hash is not None:                     # trainable encoding: the first layer's input gradient feeds the table
             spec.append(("hash.table", (self.hash["n_levels"], 1 << self.hash["log2_table"], 2)))
             self._fwd_only_weights = set()
-        return spec
+        self._n_dense_spec = len(spec)
+        return spec + self._expert_spec
 
     @contextlib.contextmanager
     def _timed(self, name):
@@ -248,10 +257,29 @@ class SwitchNeRF:
 
     def set_expert_parallel(self, ep):
         """Shard the experts over the ranks of `ep` (parallel.ExpertParallel) and exchange the dispatched rows instead of
-        computing every expert locally.  Parameters stay replicated: a rank only produces the gradients of its own experts
-        and the data-parallel all-reduce of the flat gradient buffer (a sum) distributes them."""
+        computing every expert locally.  Ownership is sharded like the reference's (models/nerf_moe.py:139, 1037-1039: expert
+        parameters are kept out of DDP): a rank computes the gradients of ITS experts from the rows of all ranks, only the dense
+        prefix of the flat gradient buffer is all-reduced, and Adam moves only the owner's copy of an expert (the other ranks'
+        copies see an exactly-zero gradient: their weights and moments never change and are never read).  The buffers keep
+        their full size (3.7 M expert parameters); gather_expert_shards() refreshes every rank's copy from the owners before a
+        checkpoint / evaluation without expert parallelism."""
         assert ep is None or ep.E == self.E
         self.ep = ep
+
+    def gather_expert_shards(self, include_optimizer=True):
+        """Every expert's parameters (and Adam moments) from its owner rank to all ranks (expert-parallel runs only)."""
+        import torch.distributed as dist
+        ep = self.ep
+        if ep is None or ep.world == 1:
+            return
+        bufs = [self.flat] + ([self.m, self.v] if include_optimizer else [])
+        for name, _shape in self._expert_spec:
+            off, shape = self.spec[name]
+            per = int(np.prod(shape)) // self.E
+            for r in range(ep.world):
+                for b in bufs:
+                    dist.broadcast(b[off + r * ep.El * per: off + (r + 1) * ep.El * per], src=r, group=ep.group)
+        self.refresh_compute_copies()
 
     def _local_experts(self, t, per_expert_leading=True):
         """Slice of a per-expert tensor / packed weight stream that belongs to this rank's experts."""
@@ -400,7 +428,7 @@ class SwitchNeRF:
         c["counts_flat"] = c["counts"].view(-1)
         c["eo"] = _b("eo", (rows, M), dt)
         c["saves"] = [_b(f"save{l}", (rows, M), dt) for l in range(L - 1)]
-        nw = o.chain_mask_words(dt, ng, cap, M)
+        nw = max(o.chain_mask_words(dt, ng, cap, M), n_seg * o.chain_mask_words(dt, E, cap, M))    # (expert parallel: one launch per segment)
         c["masks"] = [_b(f"mask{l}", (nw,), torch.int32) for l in range(L - 1)]
         skips = set(self.cfg["skips"])
         # expert chains (forward here, backward-data in backward_net - the pair shares its ReLU mask layout): the 256-row geometry
@@ -415,23 +443,43 @@ class SwitchNeRF:
                 o.mlp_chain(c["h0"], layers, c["eo"], n_groups=ng, n_wsets=E, group_stride=cap, group_rows=c["counts_flat"],
                             group_rows_clamp=cap, x_gather=c["perm"].view(-1), tag=1, geometry=c["geom"])
         else:
-            # expert parallel: rows in payload order (destination rank, segment, local expert, slot) -> all-to-all -> the
-            # local experts run on (source rank, segment, local expert) groups -> all-to-all back (parallel.ExpertParallel)
+            # expert parallel, pipelined per routing segment (parallel.ExpertParallel): the rows of segment s in native order
+            # (expert, slot) = payload order (destination rank, local expert, slot) -> all-to-all on the side stream -> the local
+            # experts run on the (source rank, local expert) groups -> all-to-all back into the native row space.  The dispatch of
+            # segment s + 1 and the return of segment s - 1 travel while the experts work on segment s.
             ep = self.ep
-            c["send_idx"] = ep.send_index(c["perm"].view(-1), n_seg, cap)
-            c["row_of_tok"] = ep.remap_rows(c["tok2row"], n_seg, cap)
-            cnt, cwait = ep.all_to_all(ep.send_counts(c["counts"], n_seg, cap), self.side)
-            xr, xwait = ep.all_to_all(o.gather_rows(c["h0"], c["send_idx"], _b("ep_send_x", (rows, M), dt)), self.side)
-            cwait()
-            xwait()
-            c["ep_counts"], c["ep_x"] = cnt.view(-1), xr
-            eo_r = _b("ep_eo", (rows, M), dt)
+            seg_rows = E * cap
+            c["row_of_tok"] = c["tok2row"]
+            cnt_wait = ep.exchange_counts(c["counts"], cap, self.side)
+            xr = _b("ep_x", (n_seg, seg_rows, M), dt)                       # received rows of all segments (also the first layer's
+            send = xr if ep.world == 1 else _b("ep_send_x", (n_seg, seg_rows, M), dt)      # weight-gradient operand)
+            eo_r = _b("ep_eo", (n_seg, seg_rows, M), dt)
+            eo = c["eo"].view(n_seg, seg_rows, M)
+            eo_send = eo if ep.world == 1 else eo_r
+            perm_s = c["perm"].view(n_seg, seg_rows)
+            wseg = o.chain_mask_words(dt, E, cap, M)
+            c["ep_mask_words"] = wseg
+
+            def issue(s_):
+                o.gather_rows(c["h0"], perm_s[s_], send[s_])
+                return ep.all_to_all(send[s_], self.side, out=xr[s_])
             with self._timed("expert_fwd"):
-                o.mlp_chain(xr, layers, eo_r, n_groups=ng, n_wsets=ep.El, group_stride=cap, group_rows=c["ep_counts"],
-                            group_rows_clamp=cap, tag=1, geometry=c["geom"])
-            eo, ewait = ep.all_to_all(eo_r, self.side)
-            ewait()
-            c["eo"] = eo
+                pend = issue(0)
+                c["ep_counts"] = cnt_wait()                                # [n_seg, W * E_local], group order of the expert kernels
+                returns = []
+                for s_ in range(n_seg):
+                    nxt = issue(s_ + 1) if s_ + 1 < n_seg else None
+                    pend[1]()
+                    rs = slice(s_ * seg_rows, (s_ + 1) * seg_rows)
+                    layers_s = [o.Layer(ly.w, ly.b, relu=ly.relu, skip=ly.skip, save=None if ly.save is None else ly.save[rs],
+                                        mask=None if ly.mask is None else ly.mask[s_ * wseg:(s_ + 1) * wseg]) for ly in layers]
+                    o.mlp_chain(xr[s_], layers_s, eo_send[s_], n_groups=E, n_wsets=ep.El, group_stride=cap, group_rows=c["ep_counts"][s_],
+                                group_rows_clamp=cap, tag=1, geometry=c["geom"])
+                    returns.append(ep.all_to_all(eo_send[s_], self.side, out=eo[s_]))
+                    pend = nxt
+                for _r, wait in returns:
+                    wait()
+            c["ep_x"] = xr.view(rows, M)
         # ---- per-ray part of layer "2": [PE(dir), appearance embedding] @ W2r + b2   (N_rays x 75, host-side torch)
         feat = torch.cat([pe_dir[:, : self.in_dir].float(), self.p["emb"][image_indices.long()]], 1)
         c["ray_feat"] = feat
@@ -489,8 +537,16 @@ class SwitchNeRF:
         # combine backward (adds the sigma head's rank-1 term, applies the ReLU mask, gate gradient)
         dout, dgmax = o.combine_bwd(dy, c["y"], dsig, self.p["sigma.w"], c["gmax"])
         ep = self.ep
-        if ep is not None:      # the rows travel to their experts while the tail's weight gradients run
-            dr, dr_wait = ep.all_to_all(o.gather_rows(dout, c["send_idx"], _b("ep_send_d", (rows, M), dt)), self.side)
+        if ep is not None:      # the rows of the first segment travel to their experts while the tail's weight gradients run
+            seg_rows = E * cap
+            dr = _b("ep_d", (n_seg, seg_rows, M), dt)
+            dsend = dr if ep.world == 1 else _b("ep_send_d", (n_seg, seg_rows, M), dt)
+            perm_s = c["perm"].view(n_seg, seg_rows)
+
+            def issue_b(s_):
+                o.gather_rows(dout, perm_s[s_], dsend[s_])
+                return ep.all_to_all(dsend[s_], self.side, out=dr[s_])
+            pend = issue_b(0)
         o.wgrad(c["h1"], dh2, g["l2h.w"].view(1, M, H2), None, n_splits=nsp)
         o.wgrad(c["y"], dh1, g["l1.w"].view(1, M, M), g["l1.b"].view(1, M), n_splits=nsp)
         # expert backward chain
@@ -507,16 +563,31 @@ class SwitchNeRF:
         if ep is None:
             perm = c["perm"].view(-1)
             x_first, dz_last = c["h0"], dout            # read through the routing permutation
+            with self._timed("expert_bwd"):
+                o.mlp_chain(dz_last, bl, dx, n_groups=ng, n_wsets=n_loc, group_stride=cap, group_rows=grp_rows,
+                            group_rows_clamp=cap, x_gather=perm, y_add=dz[skip_l] if skip_l is not None else None, tag=2,
+                            geometry=c["geom"])
         else:
+            # per segment like the forward pass: dispatch of segment s + 1 and return of segment s - 1 overlap the chain of segment s;
+            # the input gradients come home into the native row space (dx) that the front backward chain gathers from
             perm = None
-            dr_wait()
-            x_first, dz_last = c["ep_x"], dr            # the received rows, already in group order
-        with self._timed("expert_bwd"):
-            o.mlp_chain(dz_last, bl, dx, n_groups=ng, n_wsets=n_loc, group_stride=cap, group_rows=grp_rows,
-                        group_rows_clamp=cap, x_gather=perm, y_add=dz[skip_l] if skip_l is not None else None, tag=2,
-                        geometry=c["geom"])
-        if ep is not None:      # the input gradients travel home while the expert weight gradients / the router backward run
-            dx, dx_wait = ep.all_to_all(dx, self.side)
+            x_first, dz_last = c["ep_x"], dr.view(rows, M)       # the received rows, already in group order
+            grp_rows = c["ep_counts"].view(-1)
+            dxv = dx.view(n_seg, seg_rows, M)
+            dx_send = dxv if ep.world == 1 else _b("ep_dx", (n_seg, seg_rows, M), dt)
+            wseg = c["ep_mask_words"]
+            returns = []
+            with self._timed("expert_bwd"):
+                for s_ in range(n_seg):
+                    nxt = issue_b(s_ + 1) if s_ + 1 < n_seg else None
+                    pend[1]()
+                    rs = slice(s_ * seg_rows, (s_ + 1) * seg_rows)
+                    bl_s = [o.Layer(ly.w, None, relu=ly.relu, save=None if ly.save is None else ly.save[rs],
+                                    mask=None if ly.mask is None else ly.mask[s_ * wseg:(s_ + 1) * wseg]) for ly in bl]
+                    o.mlp_chain(dr[s_], bl_s, dx_send[s_], n_groups=E, n_wsets=n_loc, group_stride=cap, group_rows=c["ep_counts"][s_],
+                                group_rows_clamp=cap, y_add=dz[skip_l][rs] if skip_l is not None else None, tag=2, geometry=c["geom"])
+                    returns.append(ep.all_to_all(dx_send[s_], self.side, out=dxv[s_]))
+                    pend = nxt
 
         def expert_wgrads():
             # all layers in ONE launch: layer 0 reads its input rows, layer L-1 its dZ rows, through the routing permutation
@@ -550,8 +621,9 @@ class SwitchNeRF:
         # front backward chain: dg -> d(a1) -> d(h0), adding the expert path's input gradient through tok2row
         dza1 = _b("dza1", (P, G), dt)
         dh0 = _b("dh0", (P, M), dt)
-        if ep is not None:
-            dx_wait()
+        if ep is not None:      # (the input gradients travelled home under the expert weight gradients / the router backward)
+            for _r, wait in returns:
+                wait()
         o.mlp_chain(dg, [o.Layer(self.wb["gate1"], None, relu=2, mask=c["m_a1"], save=dza1), o.Layer(self.wb["gate0"], None)],
                     dh0, y_add=dx, y_add_gather=c["row_of_tok"], tag=6)
         o.wgrad(c["a1"], dg, g["gate1.w"].view(1, G, G), g["gate1.b"].view(1, G), n_splits=nsp)
@@ -615,11 +687,18 @@ class SwitchNeRF:
         """Gradient all-reduce (N > 1) + Adam (runner.py:486, 686) + refresh of the compute copies of the weights."""
         scale = 1.0
         if grad_allreduce is not None:
-            scale = grad_allreduce(self.grad)
+            scale = grad_allreduce(self._allreduce_view())
         if optimizer_step:
             self.step_count += 1
             ops.adam_step(self.flat, self.grad, self.m, self.v, None, self.step_count, self.lr, grad_scale=scale)
             self.refresh_compute_copies()
+
+    def _allreduce_view(self):
+        """What the data-parallel all-reduce sums: the whole flat gradient, or - experts sharded over the ranks - its dense
+        prefix (a local expert's gradient already holds the contributions of every rank's rows)."""
+        if self.ep is not None and self.ep.world > 1:
+            return self.grad[: self.n_dense]
+        return self.grad
 
     def forward_hier(self, rays, image_indices, n_samples, fine_samples, seg_tokens, perturb=0.0, perturb_rand=None,
                      fine_u=None, sigma_noise=None, sigma_noise_fine=None, routing_override=None, no_batch=False, training=True):
@@ -715,7 +794,7 @@ class SwitchNeRF:
             self.backward_net(lv, d_raw, d_laux)
         scale = 1.0
         if grad_allreduce is not None:
-            scale = grad_allreduce(self.grad)
+            scale = grad_allreduce(self._allreduce_view())
         if optimizer_step:
             self.step_count += 1
             ops.adam_step(self.flat, self.grad, self.m, self.v, None, self.step_count, self.lr, grad_scale=scale)

@@ -58,18 +58,17 @@ class ExpertParallel:
 
     Rank r owns experts [r * E_local, (r + 1) * E_local).  Every rank still routes ITS OWN points (capacity, ranking and
     l_aux stay rank-local exactly as in the data-parallel mode, so routing indices do not depend on the mode); only the
-    rows that enter the expert MLP travel.  Per MoE pass there are two exchanges of n_seg * E * C rows (dispatch and
-    return), forward and backward: four per train step.
+    rows that enter the expert MLP travel.
 
-    Payload order (a "row" = one capacity slot of 2 * M bytes): the sender lays its rows out as
-    [destination rank][segment][local expert][capacity slot]; all_to_all_single (equal splits) then delivers
-    [source rank][segment][local expert][capacity slot] - the group index g of the expert kernels, with
-    g % E_local = local expert, which is exactly how swn_mlp_chain / swn_wgrad pick a group's weight set (no kernel knows
-    about ranks).  The valid-row counts travel the same way.
-
-    RCCL over xGMI is point-to-point: an all-to-all sends (W - 1) / W of the payload over the 7 links in parallel, there
-    is nothing to gain from ring-style chunking; the exchange is issued on a side HIP stream (async_op + stream events)
-    so that whatever does not depend on it (dense weight gradients, the router backward) overlaps it.
+    The exchange is PER ROUTING SEGMENT (= the reference's per-model-chunk MoE call): the dispatched rows of one segment in their
+    native order (expert, capacity slot) ARE the payload order (destination rank, local expert, slot), so the send buffer is one
+    swn_gather_rows through the segment's routing permutation and the returned rows land in the native row space the combine
+    gathers from - no index remapping.  all_to_all_single (equal splits: capacity-padded like the reference's batched path)
+    delivers (source rank, local expert, slot) = the group order of the expert kernels with group % E_local = local expert (no
+    kernel knows about ranks).  The valid-row counts of all segments travel once, ahead of the rows.
+    Segments are pipelined: the exchange of segment s + 1 runs on a side HIP stream while the experts work on segment s, and the
+    return of segment s overlaps both (model.py).  RCCL over xGMI is point-to-point: an all-to-all sends (W - 1) / W of the payload
+    over the 7 links in parallel, there is nothing to gain from ring-style chunking.
     world == 1 degenerates to the identity (no process group needed): the single-GPU parity test runs this path.
     """
 
@@ -78,32 +77,33 @@ class ExpertParallel:
             raise ValueError(f"expert parallelism needs world ({world}) to divide the expert count ({n_experts})")
         self.rank, self.world, self.E, self.El, self.group = rank, world, n_experts, n_experts // world, group
 
-    # ---- index plumbing (tiny integer tensors; the 2 * M-byte rows are moved by swn_gather_rows / the collective) ----
-    def send_index(self, perm: torch.Tensor, n_seg: int, cap: int) -> torch.Tensor:
-        """perm [n_seg * E * cap] (native order (segment, expert, slot) -> source token, -1 = empty slot) -> the same
-        entries in payload order (destination rank, segment, local expert, slot)."""
-        return perm.view(n_seg, self.world, self.El, cap).permute(1, 0, 2, 3).contiguous().view(-1)
+    def exchange_counts(self, counts: torch.Tensor, cap: int, stream=None):
+        """counts [n_seg, E] (tokens routed per expert, before capacity) -> (recv, wait): recv [n_seg, W * E_local] int32 = valid
+        rows of every received group of every segment, in the expert kernels' group order (source rank, local expert)."""
+        n_seg = counts.shape[0]
+        send = counts.clamp(max=cap).view(n_seg, self.world, self.El).permute(1, 0, 2).contiguous()      # [dest rank, seg, el]
+        recv, wait = self.all_to_all(send, stream)
+        out = {}
 
-    def send_counts(self, counts: torch.Tensor, n_seg: int, cap: int) -> torch.Tensor:
-        """counts [n_seg, E] -> valid rows per payload group [world, n_seg, E_local] (clamped to the capacity)."""
-        return counts.clamp(max=cap).view(n_seg, self.world, self.El).permute(1, 0, 2).contiguous()
+        def wait_and_view():
+            wait()
+            out["v"] = recv.view(self.world, n_seg, self.El).permute(1, 0, 2).contiguous().view(n_seg, self.world * self.El)
+            return out["v"]
+        return wait_and_view
 
-    def remap_rows(self, tok2row: torch.Tensor, n_seg: int, cap: int) -> torch.Tensor:
-        """tok2row (token -> native row id (segment * E + expert) * cap + slot, -1 = dropped) -> payload row id."""
-        r = tok2row.long().clamp(min=0)
-        slot, g = r % cap, r // cap
-        e, s = g % self.E, g // self.E
-        out = (((e // self.El) * n_seg + s) * self.El + e % self.El) * cap + slot
-        return torch.where(tok2row < 0, torch.full_like(out, -1), out).to(torch.int32)
+    def owner_of(self, expert: int) -> int:
+        return expert // self.El
 
     # ---- the collective ----
-    def all_to_all(self, send: torch.Tensor, stream=None):
+    def all_to_all(self, send: torch.Tensor, stream=None, out: Optional[torch.Tensor] = None):
         """Equal-split all-to-all over dim 0 (world chunks).  Returns (recv, wait): call wait() on the stream that consumes
         recv.  With `stream` (a side HIP stream) the collective is ordered after the work already queued on the current
-        stream and runs concurrently with what the caller queues next."""
+        stream and runs concurrently with what the caller queues next.  out: receive buffer (same shape; world == 1: must be
+        `send` itself or None - nothing moves)."""
         if self.world == 1:
+            assert out is None or out.data_ptr() == send.data_ptr()
             return send, (lambda: None)
-        recv = torch.empty_like(send)
+        recv = torch.empty_like(send) if out is None else out
         if stream is None or not send.is_cuda:
             work = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
             return recv, work.wait

@@ -66,23 +66,24 @@ def _ep_worker(rank, world, port, out):
     P = n_seg * seg_tokens
     x = torch.from_numpy(rng.standard_normal((P, M)).astype(np.float32)) + 10.0 * rank
     perm_t, counts_t, t2r = torch.from_numpy(perm), torch.from_numpy(counts), torch.from_numpy(tok2row)
-    # dispatch
-    pe = ep.send_index(perm_t, n_seg, cap).long()
-    send = torch.where((pe >= 0)[:, None], x[pe.clamp(min=0)], torch.zeros(1, M))
-    recv, wait = ep.all_to_all(send)
-    wait()
-    crecv, cwait = ep.all_to_all(ep.send_counts(counts_t, n_seg, cap))
-    cwait()
-    crecv = crecv.view(-1)
-    # mock expert: y = x * (e + 1) + e on the valid rows of every received group; the group's local expert is g % E_local
-    y = torch.zeros_like(recv)
-    for g in range(world * n_seg * ep.El):
-        e = rank * ep.El + g % ep.El
-        n = int(crecv[g])
-        y[g * cap: g * cap + n] = recv[g * cap: g * cap + n] * (e + 1) + e
-    back, bwait = ep.all_to_all(y)
-    bwait()
-    rows = ep.remap_rows(t2r, n_seg, cap).long()
+    # per routing segment: the dispatched rows in native order (expert, slot) are the payload (destination rank, local expert, slot)
+    crecv = ep.exchange_counts(counts_t, cap)()                 # [n_seg, world * E_local] valid rows of every received group
+    seg_rows = E * cap
+    back = torch.zeros(n_seg * seg_rows, M)
+    for s_ in range(n_seg):
+        ps = perm_t[s_ * seg_rows:(s_ + 1) * seg_rows].long()
+        send = torch.where((ps >= 0)[:, None], x[ps.clamp(min=0)], torch.zeros(1, M))
+        recv, wait = ep.all_to_all(send)
+        wait()
+        # mock expert: y = x * (e + 1) + e on the valid rows of every received group; the group's local expert is g % E_local
+        y = torch.zeros_like(recv)
+        for g in range(world * ep.El):
+            e = rank * ep.El + g % ep.El
+            n = int(crecv[s_, g])
+            y[g * cap: g * cap + n] = recv[g * cap: g * cap + n] * (e + 1) + e
+        _, bwait = ep.all_to_all(y, out=back[s_ * seg_rows:(s_ + 1) * seg_rows])
+        bwait()
+    rows = t2r.long()                                           # the returned rows sit in the native row space: no remapping
     got = torch.where((rows >= 0)[:, None], back[rows.clamp(min=0)], torch.zeros(1, M))
     ref = torch.where(t2r[:, None] >= 0, x * (torch.from_numpy(idx)[:, None] + 1) + torch.from_numpy(idx)[:, None], torch.zeros(1, M))
     out[rank] = (bool(torch.equal(got, ref)), int((t2r >= 0).sum()), int(crecv.sum()))
@@ -90,8 +91,8 @@ def _ep_worker(rank, world, port, out):
 
 
 def test_expert_parallel_exchange_gloo():
-    """Tokens routed on 2 ranks reach the rank that owns their expert (payload order = the expert kernels' group order),
-    are processed by the right local expert, and come back to the row the combine gathers from."""
+    """Tokens routed on 2 ranks reach the rank that owns their expert (per-segment payload order = the expert kernels' group order),
+    are processed by the right local expert, and come back to the native row the combine gathers from."""
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
@@ -102,15 +103,11 @@ def test_expert_parallel_exchange_gloo():
 
 def test_expert_parallel_single_rank_is_identity():
     sys.path.insert(0, ROOT)
-    import numpy as np
     from switch_nerf_amd import parallel
     ep = parallel.ExpertParallel(0, 1, 8)
-    rng = np.random.default_rng(5)
-    idx, perm, counts, tok2row = _route(rng, 2, 64, 8, 8)
-    p = torch.from_numpy(perm)
-    assert torch.equal(ep.send_index(p, 2, 8), p)
-    assert torch.equal(ep.remap_rows(torch.from_numpy(tok2row), 2, 8), torch.from_numpy(tok2row))
+    counts = torch.tensor([[3, 9, 0, 8, 1, 2, 8, 30], [8, 8, 8, 8, 8, 8, 8, 8]], dtype=torch.int32)
+    assert torch.equal(ep.exchange_counts(counts, 8)(), counts.clamp(max=8))
     s = torch.zeros(4, 2)
-    r, w = ep.all_to_all(s)
+    r, w = ep.all_to_all(s, out=s)
     w()
     assert r is s
