@@ -80,8 +80,10 @@ int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const float* ln_b,
                  const float* gates, const int32_t* idx, const float* d_gmax, const float* stats,
                  const int32_t* counts, const float* laux_coef, int seg_tokens,
                  int n_tokens, int gate_dim, int n_experts,
-                 void* dg, float* dlogits /* scratch [P,E] f32, written */, float* d_wg, float* d_ln_w, float* d_ln_b,
+                 void* dg, float* dlogits /* scratch, written: swn_gate_bwd_scratch_floats() f32 = [P,E] logit gradients followed
+                 by the per-block partial sums of the router weight gradient */, float* d_wg, float* d_ln_w, float* d_ln_b,
                  void* stream);
+size_t swn_gate_bwd_scratch_floats(int n_tokens, int gate_dim, int n_experts);
 
 /* ---- routing: batch-prioritised top-1 capacity assignment ----------------------------------------------------
  * replaces extract_critical / compute_sorted_location / load_balance (tutel_fast_dispatch.py:136-217) and the
@@ -114,6 +116,25 @@ int swn_dispatch_bwd_data(const float* gates, const int32_t* indices, const int3
 int swn_dispatch_bwd_gate(float* grad_gates, const int32_t* indices, const int32_t* locations,
                           const void* reshaped_input, const void* dispatched, int dtype,
                           int samples, int hidden, int capacity, void* stream);
+
+/* ---- the no-batch (evaluation) variants: tutel_sparse_nobatch.py:24-133 as called from tutel_fast_dispatch_nobatch.py:36, :47,
+ * :53, :73, :87, :93 - the same argument order with `expert_locations_begin` (int32 [n_experts], exclusive prefix sum of
+ * expert_input_nums) as 4th argument: row(i) = expert_locations_begin[indices[i]] + locations[i], rows packed contiguously per
+ * expert, no capacity test (a token is skipped iff indices[i] < 0).  dispatched_rows = sum(expert_input_nums) (zero-filled first,
+ * like the reference's torch.zeros).                                                                                        */
+int swn_dispatch_nobatch_fwd(const float* gates, const int32_t* indices, const int32_t* locations,
+                             const int32_t* expert_locations_begin, const void* reshaped_input, void* dispatched, int dtype,
+                             int samples, int hidden, int capacity, int n_experts, long dispatched_rows, void* stream);
+int swn_dispatch_nobatch_bwd_data(const float* gates, const int32_t* indices, const int32_t* locations,
+                                  const int32_t* expert_locations_begin, void* grad_reshaped_input, const void* dispatched,
+                                  int dtype, int samples, int hidden, int capacity, int n_experts, void* stream);
+int swn_dispatch_nobatch_bwd_gate(float* grad_gates, const int32_t* indices, const int32_t* locations,
+                                  const int32_t* expert_locations_begin, const void* reshaped_input, const void* dispatched,
+                                  int dtype, int samples, int hidden, int capacity, int n_experts, void* stream);
+/* packed (no-batch) row space from a routing: begin[n_seg * E] = exclusive prefix sum of counts (= expert_locations_begin,
+ * per segment and expert), perm[n_tokens] row -> token, tok2row[n_tokens] token -> row (either may be NULL)                  */
+int swn_route_pack(const int32_t* idx, const int32_t* loc, const int32_t* counts, int n_tokens, int seg_tokens, int n_experts,
+                   int32_t* begin, int32_t* perm, int32_t* tok2row, void* stream);
 
 /* Fast-path combine (the reference's decode + the MoE layer's `act: relu`, models/nerf_moe.py:385-386):
  * y[i] = relu?(gate[i] * expert_out[seg(i)*E*C + idx*C + loc]), zero rows for dropped tokens.                 */
@@ -258,6 +279,8 @@ typedef struct swn_chain_desc {
   int32_t group_stride;         /* rows reserved per group in the row space                      */
   const int32_t* group_rows;    /* device [n_groups] valid rows per group, or NULL = group_stride (then clamp) */
   int32_t group_rows_clamp;     /* rows valid = min(group_rows[g], clamp)                         */
+  const int32_t* group_begin;   /* device [n_groups] first row of every group (packed / no-batch layout: exclusive prefix sum of
+                                   the group sizes, tutel_fast_dispatch_nobatch.py:24-36) or NULL = g * group_stride           */
   const void* x;                /* chain input, row-major [*, k0] dtype                           */
   const int32_t* x_gather;      /* device [n_groups*group_stride] row -> source row of x (-1 = zero row), or NULL */
   void* x_save;                 /* optional copy of the (gathered, scaled) input rows (row-major) or NULL */

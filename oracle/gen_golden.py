@@ -201,6 +201,42 @@ def gen_model_forward_nobatch():
          moe_gates=r["extras"]["moe_gates"][0].numpy().astype(np.int32))
 
 
+def gen_dispatch_nobatch():
+    """The reference's no-batch dispatcher on its own call sites: extract_critical (tutel_fast_dispatch_nobatch.py:205-251) ->
+    TutelMoeFastDispatcher.update / encode / decode (:98-160) with autograd through GatingEncoder / GatingDecoder (:16-96), i.e. the
+    three kernels of tutel_sparse_nobatch.py:24-133 with expert_locations_begin (run through the CPU stub of the JIT kernels, whose
+    row rule `begin[idx] + loc`, no capacity test, is the one of those CUDA strings)."""
+    print("[G10] no-batch dispatcher: extract_critical + encode / decode + gradients, S=768, E=8, M=32")
+    from switch_nerf.modules.tutel_moe_ext import tutel_fast_dispatch_nobatch as fdn
+    rng = np.random.default_rng(61)
+    S, E, M = 768, 8, 32
+    logits = torch.from_numpy((rng.standard_normal((S, E)) * 1.5).astype(np.float32))
+    gates = torch.softmax(logits, 1).requires_grad_(True)
+    x = torch.from_numpy(rng.standard_normal((S, M)).astype(np.float32)).requires_grad_(True)
+    # (position-order ranking only: with batch_prioritized_routing the reference's `expert_input_nums = locations1[-1, :] + 1`
+    #  is not the per-expert count and its own `sample_num * top_k == dispatched_input_numel` assertion fires; the reference's
+    #  evaluation recipe runs without it)
+    for tag, bpr in (("plain", False),):
+        crit, l_loss = fdn.extract_critical(gates, 1, 1.0, True, bpr)
+        n_exp, indices_s, locations_s, gates_s, expert_input_nums, capacity = crit
+        fdr = fdn.fast_dispatcher(num_global_experts=E, capacity=capacity, model_dim=M, dispatch_dtype=torch.float32)
+        fdr.update(indices_s, locations_s, gates_s, expert_input_nums, capacity=capacity, is_postscore=True, dispatcher_no_score=False)
+        disp = fdr.encode(x)                                     # [S, M] rows packed per expert
+        w = torch.from_numpy(rng.standard_normal((M, M)).astype(np.float32) / 8)
+        eo = torch.tanh(disp @ w)                                # a stand-in expert (row-wise, so the packing order matters)
+        eo.retain_grad()
+        y = fdr.decode(eo)
+        dy = torch.from_numpy(rng.standard_normal((S, M)).astype(np.float32))
+        gx, gg = torch.autograd.grad((y * dy).sum(), [x, gates], retain_graph=True)
+        begin = (torch.cumsum(expert_input_nums, 0) - expert_input_nums).to(torch.int32)
+        d_eo, = torch.autograd.grad((y * dy).sum(), [eo], retain_graph=True)
+        save(f"dispatch_nobatch_{tag}", bpr=int(bpr), gates=gates.detach().numpy(), x=x.detach().numpy(), w=w.numpy(), dy=dy.numpy(),
+             indices=indices_s[0].numpy().astype(np.int32), locations=locations_s[0].numpy().astype(np.int32),
+             expert_input_nums=expert_input_nums.numpy().astype(np.int32), expert_locations_begin=begin.numpy(), capacity=int(capacity),
+             dispatched=disp.detach().numpy(), y=y.detach().numpy(), dx=gx.numpy(), dgates=gg.numpy(), d_expert_out=d_eo.numpy(),
+             l_aux=l_loss.detach().numpy())
+
+
 # ------------------------------------------------------------------------------------------ G5 render + train step
 def gen_render(variants=(("unbalanced", 1.0, 1.0, True), ("balanced", 0.02, 1.0, True))):
     print("[G5] render_rays / training step (64 rays x 64 samples, chunk 1024 -> 4 chunks), fwd + grads")
@@ -471,7 +507,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    todo = dict(routing=gen_routing, pe=gen_pe, moe=gen_moe_layer, model=gen_model_forward, nobatch=gen_model_forward_nobatch,
+    todo = dict(routing=gen_routing, pe=gen_pe, moe=gen_moe_layer, model=gen_model_forward, nobatch=gen_model_forward_nobatch, dispatch_nobatch=gen_dispatch_nobatch,
                 render=gen_render, capacity=gen_render_capacity, fine=gen_render_fine, mip=gen_mip, ckpt=gen_checkpoint_layout, dense=gen_dense, composite=gen_composite, bg=gen_bg)
     for k, fn in todo.items():
         if a.only and k not in a.only.split(","):

@@ -132,6 +132,30 @@ def combine(d: torch.Tensor, idx: torch.Tensor, loc: torch.Tensor, gate: torch.T
     return torch.where(keep.unsqueeze(1), y, torch.zeros_like(y))
 
 
+def route_top1_nobatch(gates: np.ndarray):
+    """extract_critical of the no-batch path, tutel_fast_dispatch_nobatch.py:205-251, top_k = 1, position-order ranking
+    (fast_cumsum_sub_one): idx = argmax, loc = rank of the token among the earlier tokens of its expert, expert_input_nums =
+    tokens per expert (:222), expert_locations_begin = their exclusive prefix sum (:26-27).  Nothing is dropped."""
+    r = route_top1(gates, 1.0, False)
+    nums = r["counts"].astype(np.int32)
+    begin = (np.cumsum(nums) - nums).astype(np.int32)
+    return dict(idx=r["idx"], loc=r["loc"], gate=r["gate"], expert_input_nums=nums, expert_locations_begin=begin)
+
+
+def dispatch_nobatch(x: torch.Tensor, idx: torch.Tensor, loc: torch.Tensor, begin: torch.Tensor) -> torch.Tensor:
+    """GatingEncoder (tutel_fast_dispatch_nobatch.py:16-37) + the forward kernel tutel_sparse_nobatch.py:24-36, postscore (gate = 1):
+    D[begin[idx] + loc] += x, rows packed contiguously per expert, no capacity test.  Differentiable in x."""
+    rows = begin.long()[idx.long()] + loc.long()
+    return torch.zeros(x.shape[0], x.shape[1], dtype=x.dtype).index_add(0, rows, x)
+
+
+def combine_nobatch(d: torch.Tensor, idx: torch.Tensor, loc: torch.Tensor, begin: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
+    """GatingDecoder (:62-78) + the backward-data kernel tutel_sparse_nobatch.py:39-61: y[i] = gate[i] * D[begin[idx] + loc].
+    Differentiable in d and gate (the kernels :24-36 and :64-133 are its autograd backward)."""
+    rows = begin.long()[idx.long()] + loc.long()
+    return gate.unsqueeze(1) * d[rows]
+
+
 def expert_mlp(d: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
                skips: Sequence[int]) -> torch.Tensor:
     """ExpertMLP.forward, tutel_moe_layer_nobatch.py:887-924.  d: [E, C, M]; weights[l]: [E, in, out];

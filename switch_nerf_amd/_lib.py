@@ -32,7 +32,7 @@ class HashCfg(C.Structure):
 
 class ChainDesc(C.Structure):
     _fields_ = [("dtype", i32), ("n_layers", i32), ("n_groups", i32), ("n_wsets", i32), ("group_stride", i32),
-                ("group_rows", vp), ("group_rows_clamp", i32), ("x", vp), ("x_gather", vp), ("x_save", vp), ("x_scale", vp), ("x_relu", i32),
+                ("group_rows", vp), ("group_rows_clamp", i32), ("group_begin", vp), ("x", vp), ("x_gather", vp), ("x_save", vp), ("x_scale", vp), ("x_relu", i32),
                 ("y", vp), ("y_add", vp), ("y_add_gather", vp), ("geometry", i32), ("tag", i32), ("layers", ChainLayer * 12)]
 
 
@@ -51,6 +51,10 @@ SIGNATURES = {
     "swn_dispatch_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "swn_dispatch_bwd_data": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "swn_dispatch_bwd_gate": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "swn_dispatch_nobatch_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, vp],
+    "swn_dispatch_nobatch_bwd_data": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "swn_dispatch_nobatch_bwd_gate": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "swn_route_pack": [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp],
     "swn_combine_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "swn_combine_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp],
     "swn_heads_fwd": [vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp],
@@ -98,6 +102,8 @@ def load():
     lib.swn_last_error.argtypes = []
     lib.swn_route_workspace_bytes.restype = sz
     lib.swn_route_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.swn_gate_bwd_scratch_floats.restype = sz
+    lib.swn_gate_bwd_scratch_floats.argtypes = [i32, i32, i32]
     lib.swn_chain_mask_words.restype = i64
     lib.swn_chain_mask_words.argtypes = [i32, i32, i32, i32]
     for name, args in SIGNATURES.items():

@@ -440,7 +440,7 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
   const int row0 = tile * BM;
   if (row0 >= rows_valid) return;
   const int rows_in_tile = min(BM, rows_valid - row0);
-  const long grow0 = (long)g * d.group_stride + row0;
+  const long grow0 = (d.group_begin ? (long)d.group_begin[g] : (long)g * d.group_stride) + row0;
   const int wset = g % d.n_wsets;
 
   // per-lane LDS byte offsets of the activation fragments (the swizzle makes them non-affine in k: 8 (bf16) / 16

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(G::NT, G::OCC) void chainb_kernel(const Args args) 
   const int row0 = tile * BM;
   if (row0 >= rows_valid) return;
   const int rows_in_tile = min(BM, rows_valid - row0);
-  const long grow0 = (long)g * d.group_stride + row0;
+  const long grow0 = (d.group_begin ? (long)d.group_begin[g] : (long)g * d.group_stride) + row0;
   const int wset = g % d.n_wsets;
   const int n_layers = d.n_layers;
 

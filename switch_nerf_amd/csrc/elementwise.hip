@@ -415,7 +415,7 @@ template <typename T, int E, int G>
 __global__ __launch_bounds__(256) void gate_dwg_kernel(const T* __restrict__ g, const float* __restrict__ ln_w,
                                                        const float* __restrict__ ln_b, const float* __restrict__ stats,
                                                        const float* __restrict__ dlogits, int P, int tok_per_block,
-                                                       float* __restrict__ d_wg) {
+                                                       float* __restrict__ partial) {
   constexpr int VPT = 16 / (int)sizeof(T);     // columns per lane
   constexpr int LPT = G / VPT;                 // lanes per token
   constexpr int SG = 256 / LPT;                // token sub-groups per block
@@ -476,16 +476,33 @@ __global__ __launch_bounds__(256) void gate_dwg_kernel(const T* __restrict__ g, 
 #pragma unroll
     for (int v = 0; v < VPT; ++v) atomicAdd(red + e * G + c0 + v, acc[e][v]);
   __syncthreads();
-  for (int t = threadIdx.x; t < E * G; t += 256) unsafeAtomicAdd(d_wg + t, red[t]);
+  // the block's partial [E x G] goes to the workspace with plain stores; gate_dwg_reduce_kernel sums the blocks (a thousand blocks
+  // x 2048 device-scope atomics onto the same 2048 words took longer than reading the operands)
+  float* part = partial + (size_t)blockIdx.x * (E * G);
+  for (int t = threadIdx.x; t < E * G; t += 256) part[t] = red[t];
+}
+
+// d_wg[t] += sum over the blocks of partial[b][t]; grid = (E * G / 256, chunks of blocks)
+__global__ __launch_bounds__(256) void gate_dwg_reduce_kernel(const float* __restrict__ partial, int n_blocks, int blocks_per_chunk, int eg,
+                                                              float* __restrict__ d_wg) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= eg) return;
+  const int b0 = blockIdx.y * blocks_per_chunk, b1 = min(n_blocks, b0 + blocks_per_chunk);
+  float s = 0.f;
+  for (int b = b0; b < b1; ++b) s += partial[(size_t)b * eg + t];
+  unsafeAtomicAdd(d_wg + t, s);
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch / combine
 // Tutel batched sparse kernels: row(i) = seg(i)*E*C + idx[i]*C + loc[i], dropped iff loc >= C or idx < 0.
 template <typename T, int MODE>  // MODE 0: D[row] = g*x   1: out[i] = g*D[row] (+relu)   2: dgate[i] = <D[row], x[i]>
+// begin != NULL: the no-batch layout (tutel_sparse_nobatch.py:24-133): row(i) = begin[seg(i) * E + idx[i]] + loc[i], rows packed
+// contiguously per expert, NO capacity test (dropped iff idx < 0).
 __global__ __launch_bounds__(256) void sparse_kernel(const float* __restrict__ gates, const int32_t* __restrict__ idx,
                                                      const int32_t* __restrict__ loc, T* __restrict__ tok_buf,
                                                      T* __restrict__ disp, float* __restrict__ dgate, int samples,
-                                                     int hidden, int capacity, int seg_tokens, int n_experts, int relu) {
+                                                     int hidden, int capacity, int seg_tokens, int n_experts, int relu,
+                                                     const int32_t* __restrict__ begin) {
   const int lane = threadIdx.x & 63;
   const long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long nw = ((long)gridDim.x * blockDim.x) >> 6;
@@ -493,8 +510,9 @@ __global__ __launch_bounds__(256) void sparse_kernel(const float* __restrict__ g
   constexpr int EPC = 16 / (int)sizeof(T);
   for (long i = wid; i < samples; i += nw) {
     const int e = idx[i], l = loc[i];
-    const bool keep = (e >= 0) && (l < capacity) && (l >= 0);
-    const long row = (i / seg_tokens) * (long)n_experts * capacity + (long)e * capacity + l;
+    const bool keep = begin ? (e >= 0) : ((e >= 0) && (l < capacity) && (l >= 0));
+    const long row = begin ? (long)begin[(i / seg_tokens) * (long)n_experts + max(e, 0)] + l
+                           : (i / seg_tokens) * (long)n_experts * capacity + (long)e * capacity + l;
     const float gt = gates ? gates[i] : 1.f;
     if (MODE == 2) {
       float d = 0.f;
@@ -1031,7 +1049,7 @@ extern "C" int swn_gate_fwd(const void* g, int dtype, const float* ln_w, const f
 
 #define DWG_LAUNCH(T, EV, GV, GP)                                                                                  \
   hipLaunchKernelGGL((gate_dwg_kernel<T, EV, GV>), dim3(dwg_blocks), dim3(256), 0, as_stream(stream), GP, ln_w, ln_b, stats, \
-                     dlogits, n_tokens, tpb, d_wg)
+                     dlogits, n_tokens, tpb, dwg_partial)
 #define DWG_DISPATCH(T, GP)                                                                                         \
   do {                                                                                                              \
     if (gate_dim == 256 && n_experts == 8) DWG_LAUNCH(T, 8, 256, GP);                                               \
@@ -1043,6 +1061,15 @@ extern "C" int swn_gate_fwd(const void* g, int dtype, const float* ln_w, const f
     else if (gate_dim == 512 && n_experts == 8) DWG_LAUNCH(T, 8, 512, GP);                                          \
     else return swn::set_error("gate dW: unsupported gate_dim %d / experts %d", gate_dim, n_experts);              \
   } while (0)
+
+static int gate_dwg_tokens_per_block(int n_tokens) {
+  int tpb = cdiv(n_tokens, 1024);
+  return ((tpb < 256 ? 256 : (tpb > 4096 ? 4096 : tpb)) + 31) / 32 * 32;
+}
+
+extern "C" size_t swn_gate_bwd_scratch_floats(int n_tokens, int gate_dim, int n_experts) {
+  return (size_t)n_tokens * n_experts + (size_t)cdiv(n_tokens, gate_dwg_tokens_per_block(n_tokens)) * n_experts * gate_dim;
+}
 
 extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg,
                             const float* gates, const int32_t* idx, const float* d_gmax, const float* stats,
@@ -1056,9 +1083,9 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
   if (blocks > 2048) blocks = 2048;
   // router weight gradient: a block walks its tokens serially (32 per iteration), so its run time is set by tokens per block, not by
   // the batch - ~1024 blocks (4 per CU) whatever the batch size (4096 tokens per block took 0.5 ms for 2M and for 262144 tokens alike)
-  int tpb = cdiv(n_tokens, 1024);
-  tpb = ((tpb < 256 ? 256 : (tpb > 4096 ? 4096 : tpb)) + 31) / 32 * 32;
+  const int tpb = gate_dwg_tokens_per_block(n_tokens);
   const int dwg_blocks = cdiv(n_tokens, tpb);
+  float* dwg_partial = dlogits + (size_t)n_tokens * n_experts;          // second part of the scratch: [dwg_blocks][E * G]
   if (dtype == SWN_BF16) {
     const bf16_t* gp = (const bf16_t*)g;
     bf16_t* dgp = (bf16_t*)dg;
@@ -1074,6 +1101,11 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
     SWN_CHECK(n_experts == 4 || n_experts == 8 || n_experts == 16, "swn_gate_bwd: experts must be 4, 8 or 16");
     DWG_DISPATCH(float, gp);
   }
+  {
+    const int eg = n_experts * gate_dim, chunks = dwg_blocks < 16 ? dwg_blocks : 16, bpc = cdiv(dwg_blocks, chunks);
+    hipLaunchKernelGGL(gate_dwg_reduce_kernel, dim3(cdiv(eg, 256), cdiv(dwg_blocks, bpc)), dim3(256), 0, as_stream(stream), dwg_partial,
+                       dwg_blocks, bpc, eg, d_wg);
+  }
   SWN_LAUNCH_CHECK();
   return 0;
 }
@@ -1081,7 +1113,7 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
 template <int MODE>
 static int launch_sparse(const float* gates, const int32_t* idx, const int32_t* loc, void* tok, void* disp, float* dgate,
                          int dtype, int samples, int hidden, int capacity, int seg_tokens, int n_experts, int relu,
-                         void* stream) {
+                         void* stream, const int32_t* begin = nullptr) {
   SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "sparse: bad dtype");
   SWN_CHECK(idx && loc && tok && disp, "sparse: null pointer");
   SWN_CHECK(hidden * (dtype == SWN_BF16 ? 2 : 4) % 16 == 0, "sparse: hidden row must be a multiple of 16 bytes");
@@ -1089,10 +1121,10 @@ static int launch_sparse(const float* gates, const int32_t* idx, const int32_t* 
   const int blocks = ew_blocks(samples);
   if (dtype == SWN_BF16)
     hipLaunchKernelGGL((sparse_kernel<bf16_t, MODE>), dim3(blocks), dim3(256), 0, as_stream(stream), gates, idx, loc,
-                       (bf16_t*)tok, (bf16_t*)disp, dgate, samples, hidden, capacity, seg_tokens, n_experts, relu);
+                       (bf16_t*)tok, (bf16_t*)disp, dgate, samples, hidden, capacity, seg_tokens, n_experts, relu, begin);
   else
     hipLaunchKernelGGL((sparse_kernel<float, MODE>), dim3(blocks), dim3(256), 0, as_stream(stream), gates, idx, loc,
-                       (float*)tok, (float*)disp, dgate, samples, hidden, capacity, seg_tokens, n_experts, relu);
+                       (float*)tok, (float*)disp, dgate, samples, hidden, capacity, seg_tokens, n_experts, relu, begin);
   SWN_LAUNCH_CHECK();
   return 0;
 }
@@ -1119,6 +1151,33 @@ extern "C" int swn_dispatch_bwd_gate(float* grad_gates, const int32_t* indices, 
   SWN_CHECK(grad_gates, "swn_dispatch_bwd_gate: null");
   return launch_sparse<2>(nullptr, indices, locations, (void*)reshaped_input, (void*)dispatched, grad_gates, dtype,
                           samples, hidden, capacity, samples, 1 << 20, 0, stream);
+}
+
+// ---- no-batch (evaluation) kernel ABI: the reference's argument order with expert_locations_begin as 4th argument
+// (tutel_fast_dispatch_nobatch.py:36, :47, :53, :73, :87, :93).  n_experts: begin has n_experts entries per `samples` tokens.
+extern "C" int swn_dispatch_nobatch_fwd(const float* gates, const int32_t* indices, const int32_t* locations,
+                                        const int32_t* expert_locations_begin, const void* reshaped_input, void* dispatched, int dtype,
+                                        int samples, int hidden, int capacity, int n_experts, long dispatched_rows, void* stream) {
+  SWN_CHECK(dispatched && expert_locations_begin, "swn_dispatch_nobatch_fwd: null");
+  const size_t bytes = (size_t)dispatched_rows * hidden * (dtype == SWN_BF16 ? 2 : 4);
+  hipError_t e = hipMemsetAsync(dispatched, 0, bytes, as_stream(stream));  // torch.zeros at tutel_fast_dispatch_nobatch.py:34
+  SWN_CHECK(e == hipSuccess, "swn_dispatch_nobatch_fwd: memset failed: %s", hipGetErrorString(e));
+  return launch_sparse<0>(gates, indices, locations, (void*)reshaped_input, dispatched, nullptr, dtype, samples, hidden,
+                          capacity > 0 ? capacity : 1, samples, n_experts, 0, stream, expert_locations_begin);
+}
+extern "C" int swn_dispatch_nobatch_bwd_data(const float* gates, const int32_t* indices, const int32_t* locations,
+                                             const int32_t* expert_locations_begin, void* grad_reshaped_input, const void* dispatched,
+                                             int dtype, int samples, int hidden, int capacity, int n_experts, void* stream) {
+  SWN_CHECK(expert_locations_begin, "swn_dispatch_nobatch_bwd_data: null");
+  return launch_sparse<1>(gates, indices, locations, grad_reshaped_input, (void*)dispatched, nullptr, dtype, samples,
+                          hidden, capacity > 0 ? capacity : 1, samples, n_experts, 0, stream, expert_locations_begin);
+}
+extern "C" int swn_dispatch_nobatch_bwd_gate(float* grad_gates, const int32_t* indices, const int32_t* locations,
+                                             const int32_t* expert_locations_begin, const void* reshaped_input, const void* dispatched,
+                                             int dtype, int samples, int hidden, int capacity, int n_experts, void* stream) {
+  SWN_CHECK(grad_gates && expert_locations_begin, "swn_dispatch_nobatch_bwd_gate: null");
+  return launch_sparse<2>(nullptr, indices, locations, (void*)reshaped_input, (void*)dispatched, grad_gates, dtype,
+                          samples, hidden, capacity > 0 ? capacity : 1, samples, n_experts, 0, stream, expert_locations_begin);
 }
 
 extern "C" int swn_combine_fwd(const float* gates, const int32_t* indices, const int32_t* locations, void* y,

@@ -171,6 +171,37 @@ __global__ void route_finalize_kernel(const uint32_t* __restrict__ keys, const i
   }
 }
 
+// No-batch (evaluation) layout, tutel_fast_dispatch_nobatch.py:24-36: the rows of group g = (segment, expert) sit contiguously at
+// [begin[g], begin[g] + counts[g]), begin = exclusive prefix sum of the counts (expert_locations_begin), nothing is dropped.
+// One block computes begin (n_groups <= 4096); the tokens then scatter themselves.
+__global__ __launch_bounds__(256) void route_pack_begin_kernel(const int32_t* __restrict__ counts, int n_groups, int32_t* __restrict__ begin) {
+  __shared__ int32_t part[256];
+  const int per = (n_groups + 255) / 256;
+  const int g0 = threadIdx.x * per, g1 = min(n_groups, g0 + per);
+  int32_t s = 0;
+  for (int g = g0; g < g1; ++g) s += counts[g];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t run = 0;
+    for (int t = 0; t < 256; ++t) { const int32_t v = part[t]; part[t] = run; run += v; }
+  }
+  __syncthreads();
+  int32_t run = part[threadIdx.x];
+  for (int g = g0; g < g1; ++g) { begin[g] = run; run += counts[g]; }
+}
+__global__ void route_pack_scatter_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ loc,
+                                          const int32_t* __restrict__ begin, int n_tokens, int seg_tokens, int E,
+                                          int32_t* __restrict__ perm, int32_t* __restrict__ tok2row) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_tokens) return;
+  const int e = idx[i];
+  if (e < 0) { if (tok2row) tok2row[i] = -1; return; }
+  const int32_t row = begin[(i / seg_tokens) * E + e] + loc[i];
+  if (tok2row) tok2row[i] = row;
+  if (perm) perm[row] = (int32_t)i;
+}
+
 // me partial sums: grid (nblk, n_seg), block 256; partial[seg][blk][e]
 __global__ __launch_bounds__(256) void laux_partial_kernel(const float* __restrict__ gates, int seg_tokens, int E, int nblk,
                                                            float* __restrict__ partial) {
@@ -265,5 +296,18 @@ extern "C" int swn_route_top1(const int32_t* idx, const float* gmax, const float
     hipLaunchKernelGGL(laux_final_kernel, dim3(n_seg), dim3(64), 0, s, partial, counts, seg_tokens, n_experts, nblk, l_aux);
     SWN_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+extern "C" int swn_route_pack(const int32_t* idx, const int32_t* loc, const int32_t* counts, int n_tokens, int seg_tokens,
+                              int n_experts, int32_t* begin, int32_t* perm, int32_t* tok2row, void* stream) {
+  SWN_CHECK(idx && loc && counts && begin, "swn_route_pack: null pointer");
+  SWN_CHECK(n_tokens > 0 && seg_tokens > 0 && n_tokens % seg_tokens == 0, "swn_route_pack: n_tokens must be a multiple of seg_tokens");
+  const int n_groups = (n_tokens / seg_tokens) * n_experts;
+  SWN_CHECK(n_groups <= (1 << 20), "swn_route_pack: too many groups");
+  hipLaunchKernelGGL(route_pack_begin_kernel, dim3(1), dim3(256), 0, as_stream(stream), counts, n_groups, begin);
+  hipLaunchKernelGGL(route_pack_scatter_kernel, dim3(cdiv(n_tokens, 256)), dim3(256), 0, as_stream(stream), idx, loc, begin, n_tokens,
+                     seg_tokens, n_experts, perm, tok2row);
+  SWN_LAUNCH_CHECK();
   return 0;
 }

@@ -419,17 +419,26 @@ class SwitchNeRF:
         if routing_override is not None:     # tests: inject the oracle's expert choice (near-tie robustness)
             c["idx"] = routing_override.to(dev).int().contiguous()
             c["gmax"] = c["gates"].gather(1, c["idx"].long()[:, None])[:, 0].contiguous()
+        packed = bool(no_batch) and not sv and self.ep is None      # (see below: the no-batch row layout of the inference forward)
         c["loc"], c["counts"], c["perm"], c["tok2row"], c["l_aux"] = o.route_top1(c["idx"], c["gmax"], c["gates"], seg_tokens,
-                                                                                  E, cap, self.bpr)
+                                                                                  E, cap, self.bpr, want_perm=not packed)
         # ---- expert chain (gathers its rows through perm; ragged groups = (segment, expert))
         rows = n_seg * E * cap
         ng = n_seg * E
+        # evaluation without token dropping (apply_on_expert_fn_nobatch, tutel_moe_layer_nobatch.py:237-352): the reference packs the
+        # rows contiguously per expert (expert_locations_begin, tutel_fast_dispatch_nobatch.py:24-36).  Same layout here for the
+        # inference forward: P rows instead of n_seg * E * seg_tokens, groups addressed through their first row.
+        group_begin = None
+        if packed:
+            rows = P
+            group_begin, c["perm"], c["tok2row"] = o.route_pack(c["idx"], c["loc"], c["counts"], seg_tokens, E)
+            c["group_begin"] = group_begin
         c["rows"], c["ng"] = rows, ng
         c["counts_flat"] = c["counts"].view(-1)
         c["eo"] = _b("eo", (rows, M), dt)
-        c["saves"] = [_b(f"save{l}", (rows, M), dt) for l in range(L - 1)]
+        c["saves"] = [_b(f"save{l}", (rows, M), dt) if sv else None for l in range(L - 1)]
         nw = max(o.chain_mask_words(dt, ng, cap, M), n_seg * o.chain_mask_words(dt, E, cap, M))    # (expert parallel: one launch per segment)
-        c["masks"] = [_b(f"mask{l}", (nw,), torch.int32) for l in range(L - 1)]
+        c["masks"] = [_b(f"mask{l}", (nw,), torch.int32) if sv else None for l in range(L - 1)]
         skips = set(self.cfg["skips"])
         # expert chains (forward here, backward-data in backward_net - the pair shares its ReLU mask layout): the 256-row geometry
         # (chain_big.hip) for 256-feature experts in a 16-bit compute dtype once a group holds at least one full tile
@@ -437,11 +446,29 @@ class SwitchNeRF:
         layers = [o.Layer(self._local_experts(self.wf[f"exp{l}"]), self._local_experts(self.p[f"exp{l}.b"]),
                           relu=1 if l < L - 1 else 0, skip=(l in skips), save=c["saves"][l] if (sv and l < L - 1) else None,
                           mask=c["masks"][l] if (sv and l < L - 1) else None) for l in range(L)]
-        if self.ep is None:
+        if no_batch and not sv and self.ep is not None:
+            # evaluation without token dropping under expert parallelism (tutel_moe_layer_nobatch.py:308-335): the packed rows of a
+            # segment, expert-major = (destination rank, local expert), travel with UNEQUAL splits (the reference's list_all_to_all);
+            # the owner runs its experts on the (source rank, local expert) groups it received and sends the rows back
+            ep = self.ep
+            _gb, perm_p, c["tok2row"] = o.route_pack(c["idx"], c["loc"], c["counts"], seg_tokens, E)
+            c["row_of_tok"] = c["tok2row"]
+            c["eo"] = _b("eo_packed", (P, M), dt)
+            for s_ in range(n_seg):
+                rs = slice(s_ * seg_tokens, (s_ + 1) * seg_tokens)          # every segment holds exactly seg_tokens packed rows
+                recv, rc = ep.all_to_all_ragged(o.gather_rows(c["h0"], perm_p[rs]), c["counts"][s_].contiguous())
+                out = torch.empty_like(recv)
+                if recv.shape[0]:
+                    gb = (torch.cumsum(rc, 0) - rc).to(torch.int32)
+                    o.mlp_chain(recv, layers, out, n_groups=ep.world * ep.El, n_wsets=ep.El, group_stride=seg_tokens, group_rows=rc,
+                                group_rows_clamp=seg_tokens, tag=1, geometry=c["geom"], group_begin=gb)
+                back, _ = ep.all_to_all_ragged(out, rc, recv_counts=c["counts"][s_].contiguous())
+                c["eo"][rs] = back
+        elif self.ep is None:
             c["row_of_tok"] = c["tok2row"]
             with self._timed("expert_fwd"):
                 o.mlp_chain(c["h0"], layers, c["eo"], n_groups=ng, n_wsets=E, group_stride=cap, group_rows=c["counts_flat"],
-                            group_rows_clamp=cap, x_gather=c["perm"].view(-1), tag=1, geometry=c["geom"])
+                            group_rows_clamp=cap, x_gather=c["perm"].view(-1), tag=1, geometry=c["geom"], group_begin=group_begin)
         else:
             # expert parallel, pipelined per routing segment (parallel.ExpertParallel): the rows of segment s in native order
             # (expert, slot) = payload order (destination rank, local expert, slot) -> all-to-all on the side stream -> the local

@@ -114,7 +114,7 @@ def gate_bwd(g, ln_w, ln_b, wg, gates, idx, d_gmax, stats, counts, laux_coef, se
     P, G = g.shape
     E = wg.shape[0]
     dg = torch.empty_like(g)
-    dlogits = torch.empty(P, E, dtype=torch.float32, device=g.device)
+    dlogits = torch.empty(int(_lib.load().swn_gate_bwd_scratch_floats(P, G, E)), dtype=torch.float32, device=g.device)
     call("swn_gate_bwd", _p(g), _dt(g), _p(ln_w), _p(ln_b), _p(wg), _p(gates), _p(idx), _p(d_gmax), _p(stats), _p(counts),
          _p(laux_coef), int(seg_tokens), P, G, E, _p(dg), _p(dlogits), _p(d_wg), _p(d_ln_w), _p(d_ln_b), _stream())
     return dg
@@ -164,6 +164,46 @@ def dispatch_bwd_gate(indices, locations, x, dispatched, capacity: int):
     gg = torch.empty(S, dtype=torch.float32, device=x.device)
     call("swn_dispatch_bwd_gate", _p(gg), _p(indices), _p(locations), _p(x), _p(dispatched), _dt(x), S, H, capacity, _stream())
     return gg
+
+
+def dispatch_nobatch_fwd(gates, indices, locations, expert_locations_begin, x, dispatched_rows: int, capacity: int = 0):
+    """The no-batch encode kernel (tutel_fast_dispatch_nobatch.py:36): D[begin[idx] + loc] = g * x, rows packed per expert."""
+    S, H = x.shape
+    E = expert_locations_begin.numel()
+    d = torch.empty(int(dispatched_rows), H, dtype=x.dtype, device=x.device)
+    call("swn_dispatch_nobatch_fwd", _p(gates), _p(indices), _p(locations), _p(expert_locations_begin), _p(x), _p(d), _dt(x), S, H,
+         int(capacity), E, int(dispatched_rows), _stream())
+    return d
+
+
+def dispatch_nobatch_bwd_data(gates, indices, locations, expert_locations_begin, dispatched, capacity: int = 0):
+    """... :47 / :73 (also the decode forward): out[i] = g * D[begin[idx] + loc], zero rows for idx < 0."""
+    S, H = indices.shape[0], dispatched.shape[1]
+    out = torch.empty(S, H, dtype=dispatched.dtype, device=dispatched.device)
+    call("swn_dispatch_nobatch_bwd_data", _p(gates), _p(indices), _p(locations), _p(expert_locations_begin), _p(out), _p(dispatched),
+         _dt(out), S, H, int(capacity), expert_locations_begin.numel(), _stream())
+    return out
+
+
+def dispatch_nobatch_bwd_gate(indices, locations, expert_locations_begin, x, dispatched, capacity: int = 0):
+    """... :53 / :93: dgate[i] = <D[begin[idx] + loc], x[i]>."""
+    S, H = x.shape
+    gg = torch.empty(S, dtype=torch.float32, device=x.device)
+    call("swn_dispatch_nobatch_bwd_gate", _p(gg), _p(indices), _p(locations), _p(expert_locations_begin), _p(x), _p(dispatched), _dt(x),
+         S, H, int(capacity), expert_locations_begin.numel(), _stream())
+    return gg
+
+
+def route_pack(idx, loc, counts, seg_tokens: int, n_experts: int):
+    """Packed (no-batch) row space of a routing -> begin [n_seg * E] (expert_locations_begin per segment), perm [P] row -> token,
+    tok2row [P] token -> row."""
+    P = idx.shape[0]
+    n_groups = (P // seg_tokens) * n_experts
+    begin = torch.empty(n_groups, dtype=torch.int32, device=idx.device)
+    perm = torch.empty(P, dtype=torch.int32, device=idx.device)
+    tok2row = torch.empty(P, dtype=torch.int32, device=idx.device)
+    call("swn_route_pack", _p(idx), _p(loc), _p(counts), P, int(seg_tokens), int(n_experts), _p(begin), _p(perm), _p(tok2row), _stream())
+    return begin, perm, tok2row
 
 
 def combine_fwd(gates, indices, locations, expert_out, capacity: int, seg_tokens: int, n_experts: int, relu: bool):
@@ -385,8 +425,9 @@ def chain_mask_words(dtype, n_groups: int, group_stride: int, max_width: int = 2
 
 def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride=None, group_rows=None,
               group_rows_clamp=None, x_gather=None, x_save=None, y_add=None, y_add_gather=None, tag=0, x_scale=None,
-              x_relu=False, geometry=0):
-    """geometry: 0 automatic, 1 the 64-row tile kernels, 2 the 256-row kernel (include/swn.h)."""
+              x_relu=False, geometry=0, group_begin=None):
+    """geometry: 0 / 1 the 64-row tile kernels, 2 / 3 the chain_big.hip geometries (include/swn.h).  group_begin: first row of every
+    group (packed / no-batch layout) instead of g * group_stride."""
     d = ChainDesc()
     d.dtype = _dt(x)
     d.tag = int(tag)
@@ -396,6 +437,7 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
     d.group_stride = int(group_stride if group_stride is not None else y.shape[0])
     d.group_rows = _p(group_rows)
     d.group_rows_clamp = int(group_rows_clamp if group_rows_clamp is not None else d.group_stride)
+    d.group_begin = _p(group_begin)
     d.x, d.x_gather, d.x_save, d.y = _p(x), _p(x_gather), _p(x_save), _p(y)
     d.x_scale, d.x_relu = _p(x_scale), int(bool(x_relu))
     d.y_add, d.y_add_gather = _p(y_add), _p(y_add_gather)

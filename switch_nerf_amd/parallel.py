@@ -94,6 +94,28 @@ class ExpertParallel:
     def owner_of(self, expert: int) -> int:
         return expert // self.El
 
+    # ---- evaluation without token dropping: unequal splits ----
+    def all_to_all_ragged(self, rows: torch.Tensor, group_counts: torch.Tensor, recv_counts: Optional[torch.Tensor] = None):
+        """The reference's list_all_to_all (tutel_communicate_nobatch.py:18-51, used at tutel_moe_layer_nobatch.py:308-335): the
+        no-batch rows are packed, so every peer gets a different number of them.
+          rows          [sum(group_counts), M]: groups in (destination rank, local expert) order, each contiguous;
+          group_counts  int32 [W * E_local]: rows per group.
+        Forward direction (recv_counts None): the counts travel first (equal split), the split sizes are read on the host (the
+        reference's `.tolist()`, :312-313), then one all_to_all_single with unequal splits.  Returns (recv_rows, recv_counts): the rows
+        of the (source rank, local expert) groups, packed, and their sizes.  Way back: pass the counts received on the way in as
+        `recv_counts` - the split sizes are swapped and `group_counts` must be what this rank holds per (source rank, local expert)."""
+        W, El = self.world, self.El
+        if W == 1:
+            return rows, group_counts
+        if recv_counts is None:
+            recv_counts = torch.empty_like(group_counts)
+            dist.all_to_all_single(recv_counts, group_counts.contiguous(), group=self.group)
+        in_splits = group_counts.view(W, El).sum(1).tolist()
+        out_splits = recv_counts.view(W, El).sum(1).tolist()
+        out = torch.empty((int(sum(out_splits)),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+        dist.all_to_all_single(out, rows.contiguous(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+        return out, recv_counts
+
     # ---- the collective ----
     def all_to_all(self, send: torch.Tensor, stream=None, out: Optional[torch.Tensor] = None):
         """Equal-split all-to-all over dim 0 (world chunks).  Returns (recv, wait): call wait() on the stream that consumes

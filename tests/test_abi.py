@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/swn.h but not exported"
     declared = set(syms)
-    bound = set(_lib.SIGNATURES) | {"swn_last_error", "swn_route_workspace_bytes", "swn_chain_mask_words"}
+    bound = set(_lib.SIGNATURES) | {"swn_last_error", "swn_route_workspace_bytes", "swn_chain_mask_words", "swn_gate_bwd_scratch_floats"}
     assert bound == declared, (sorted(bound - declared), sorted(declared - bound))
     lib.swn_version.restype = ctypes.c_int
     assert lib.swn_version() >= 1

@@ -648,3 +648,46 @@ def test_chain_256_row_geometry_bit_exact(ng, cap, seed, geometry):
         assert torch.equal(a[vm], b[vm]), f"{name}: {(a[vm] != b[vm]).float().mean().item():.3g} of the valid elements differ"
         assert b[~vm].abs().sum().item() == 0, f"{name}: rows past a group's count were written"
     assert (res[geometry][0][1][vm].float().abs().sum() > 0) and torch.isfinite(res[geometry][0][1].float()).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_nobatch_sparse_abi_vs_reference_golden(dtype):
+    """The no-batch (evaluation) kernel ABI - swn_dispatch_nobatch_fwd / _bwd_data / _bwd_gate, the reference's argument order with
+    expert_locations_begin (tutel_sparse_nobatch.py:24-133) - on the tensors of the reference's own dispatcher run
+    (tests/golden/dispatch_nobatch_plain.npz): routing + packing bit-exact (swn_route_top1 + swn_route_pack), encode, decode and the
+    three backward products."""
+    o = ops()
+    g = np.load(os.path.join(G, "dispatch_nobatch_plain.npz"))
+    S, E = g["gates"].shape
+    M = g["x"].shape[1]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    gates = t(g["gates"])
+    idx = gates.argmax(1).int()
+    gmax = gates.gather(1, idx.long()[:, None])[:, 0].contiguous()
+    loc, counts, _perm, _t2r, _ = o.route_top1(idx, gmax, gates, S, E, S, False)          # position order, nothing dropped
+    begin, perm, tok2row = o.route_pack(idx, loc, counts, S, E)
+    assert np.array_equal(idx.cpu().numpy(), g["indices"]) and np.array_equal(loc.cpu().numpy(), g["locations"])
+    assert np.array_equal(counts.cpu().numpy().reshape(-1), g["expert_input_nums"])
+    assert np.array_equal(begin.cpu().numpy(), g["expert_locations_begin"])
+    rows = g["expert_locations_begin"][g["indices"]] + g["locations"]
+    assert np.array_equal(tok2row.cpu().numpy(), rows) and np.array_equal(perm.cpu().numpy()[rows], np.arange(S))
+    x = t(g["x"]).to(dtype)
+    tol = 0.0 if dtype == torch.float32 else 1e-2
+    # encode: func_fwd(gates = ones_helper -> NULL, indices, locations, begin, reshaped_input, dispatched)
+    d = o.dispatch_nobatch_fwd(None, idx, loc, begin, x, S)
+    assert report(f"nobatch_encode_{dtype}", d, t(g["dispatched"]).to(dtype)) <= tol
+    # decode: func_bwd_data(gates, indices, locations, begin, single_output, expert_output)
+    eo = torch.tanh(t(g["dispatched"]) @ t(g["w"])).to(dtype)
+    y = o.dispatch_nobatch_bwd_data(gmax, idx, loc, begin, eo)
+    assert report(f"nobatch_decode_{dtype}", y, t(g["y"])) <= (2e-6 if dtype == torch.float32 else 2e-2)
+    dy = t(g["dy"]).to(dtype)
+    # decode backward: d expert_out = func_fwd(gates, ..., combined_output, grad_expert_output); d gate = func_bwd_gate(...)
+    d_eo = o.dispatch_nobatch_fwd(gmax, idx, loc, begin, dy, S)
+    assert report(f"nobatch_d_expert_out_{dtype}", d_eo, t(g["d_expert_out"])) <= (2e-6 if dtype == torch.float32 else 2e-2)
+    dgate = o.dispatch_nobatch_bwd_gate(idx, loc, begin, dy, eo)
+    ref_dg = torch.from_numpy(g["dgates"]).gather(1, torch.from_numpy(g["indices"]).long()[:, None])[:, 0]      # the top-1 column carries it
+    assert report(f"nobatch_dgate_{dtype}", dgate, ref_dg) <= (2e-5 if dtype == torch.float32 else 0.15)
+    # encode backward: func_bwd_data(ones, ..., grad_data, d dispatched): d x = gather of the dispatched gradient
+    d_disp = ((1 - torch.tanh(t(g["dispatched"]) @ t(g["w"])) ** 2) * t(g["d_expert_out"])) @ t(g["w"]).t()
+    dx = o.dispatch_nobatch_bwd_data(None, idx, loc, begin, d_disp.to(dtype))
+    assert report(f"nobatch_dx_{dtype}", dx, t(g["dx"])) <= (5e-6 if dtype == torch.float32 else 5e-2)

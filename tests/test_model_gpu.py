@@ -602,3 +602,24 @@ def test_render_image_rays_loop_with_ragged_batches():
                          for i in range(0, R, pb)])
     np.testing.assert_allclose(res["rgb_coarse"].numpy(), ref.numpy(), rtol=0, atol=1e-4)
     assert res["gate_loss_coarse"].numel() == 6 + 6 + 4        # chunks per batch: 6, 6, 3 full + 1 ragged
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_nobatch_inference_runs_on_packed_rows(dtype):
+    """The evaluation forward without token dropping (Runner.set_no_batch): the rows of every (segment, expert) group are packed
+    contiguously like the reference's no-batch dispatcher (expert_locations_begin) - P rows, not n_seg * E * seg_tokens - and the
+    result is bit-identical to the capacity-padded layout (the same kernels on the same rows at other addresses; bf16 runs the
+    256-row chain geometry through group_begin)."""
+    N, S, chunk = 64, 128, 4096
+    m = _model(dtype, 97, 1.0, batch_prioritized=False)
+    rays, img, _ = synth.make_rays(98, N)
+    c_pack = m.forward_rays(_dev(rays), _dev(img), S, chunk, training=False, no_batch=True)
+    raw_pack = c_pack["raw"].clone()
+    c_pad = m.forward_rays(_dev(rays), _dev(img), S, chunk, training=True, no_batch=True)
+    P, n_seg, E = N * S, N * S // chunk, m.E
+    assert "group_begin" in c_pack and c_pack["eo"].shape[0] == P and c_pad["eo"].shape[0] == n_seg * E * chunk
+    assert int((c_pack["tok2row"] < 0).sum()) == 0 and torch.equal(c_pack["idx"], c_pad["idx"])
+    begin = c_pack["group_begin"].cpu().numpy()
+    counts = c_pack["counts"].cpu().numpy().reshape(-1)
+    assert np.array_equal(begin, np.cumsum(counts) - counts) and counts.sum() == P
+    assert torch.equal(raw_pack, c_pad["raw"])

@@ -399,3 +399,27 @@ def test_hash_encode_restatement_properties():
     a = O.hash_encode(torch.tensor([[0.5 - 1e-6, 0.3, 0.7]]), table, hc)
     b = O.hash_encode(torch.tensor([[0.5 + 1e-6, 0.3, 0.7]]), table, hc)
     assert (a - b).abs().max().item() < 1e-3
+
+
+def test_nobatch_dispatcher_vs_reference_golden():
+    """The evaluation path's dispatcher (tutel_fast_dispatch_nobatch.py: extract_critical, encode, decode with autograd) - the
+    oracle's restatement against tensors produced by the reference's own classes: indices / locations / expert_input_nums /
+    expert_locations_begin bit-exact, dispatched rows, decode output and the three gradients to fp32 rounding."""
+    g = np.load(os.path.join(G, "dispatch_nobatch_plain.npz"))
+    r = O.route_top1_nobatch(g["gates"])
+    assert np.array_equal(r["idx"], g["indices"]) and np.array_equal(r["loc"], g["locations"])
+    assert np.array_equal(r["expert_input_nums"], g["expert_input_nums"]) and np.array_equal(r["expert_locations_begin"], g["expert_locations_begin"])
+    gates = torch.from_numpy(g["gates"]).requires_grad_(True)
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    idx, loc, begin = (torch.from_numpy(r[k].astype(np.int64)) for k in ("idx", "loc", "expert_locations_begin"))
+    d = O.dispatch_nobatch(x, idx, loc, begin)
+    np.testing.assert_allclose(d.detach().numpy(), g["dispatched"], rtol=0, atol=0)
+    eo = torch.tanh(d @ torch.from_numpy(g["w"]))
+    eo.retain_grad()
+    gate_s = gates.gather(1, idx.unsqueeze(1)).squeeze(1)
+    y = O.combine_nobatch(eo, idx, loc, begin, gate_s)
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-6, atol=1e-7)
+    (y * torch.from_numpy(g["dy"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gates.grad.numpy(), g["dgates"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(eo.grad.numpy(), g["d_expert_out"], rtol=1e-6, atol=1e-7)

@@ -101,6 +101,45 @@ def test_expert_parallel_exchange_gloo():
     assert out[0][1] + out[1][1] == out[0][2] + out[1][2]      # every kept token is processed exactly once, somewhere
 
 
+def _ragged_worker(rank, world, port, out):
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from switch_nerf_amd import parallel
+    parallel.init_from_env(backend="gloo")
+    E, M = 4, 6
+    ep = parallel.ExpertParallel(rank, world, E)
+    rng = np.random.default_rng(300 + rank)
+    counts = torch.from_numpy(rng.integers(0, 9, E).astype(np.int32))               # tokens of this rank per (global) expert
+    counts[rank] = 0                                                                 # an empty group on the way
+    n = int(counts.sum())
+    # packed rows, expert-major: value = 1000 * source rank + 100 * expert + slot (so the receiver can check who sent what)
+    rows = torch.cat([torch.full((int(c), M), 1000.0 * rank + 100.0 * e) + torch.arange(int(c), dtype=torch.float32)[:, None]
+                      for e, c in enumerate(counts)]) if n else torch.zeros(0, M)
+    recv, rc = ep.all_to_all_ragged(rows, counts)
+    ok = recv.shape[0] == int(rc.sum())
+    pos = 0
+    for g in range(world * ep.El):                                                   # groups arrive as (source rank, local expert)
+        src, e = g // ep.El, rank * ep.El + g % ep.El
+        c = int(rc[g])
+        want = torch.full((c, M), 1000.0 * src + 100.0 * e) + torch.arange(c, dtype=torch.float32)[:, None]
+        ok = ok and torch.equal(recv[pos:pos + c], want)
+        pos += c
+    back, _ = ep.all_to_all_ragged(recv * 2.0, rc, recv_counts=counts)               # the way back: every row returns to its slot
+    out[rank] = bool(ok and torch.equal(back, rows * 2.0))
+    dist.destroy_process_group()
+
+
+def test_expert_parallel_ragged_exchange_gloo():
+    """The evaluation path's unequal-split exchange (the reference's list_all_to_all): packed rows reach the owner of their expert
+    grouped by (source rank, local expert) and come back to their own slot."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_ragged_worker, args=(world, 29731 + os.getpid() % 200, out), nprocs=world, join=True)
+    assert out[0] and out[1]
+
+
 def test_expert_parallel_single_rank_is_identity():
     sys.path.insert(0, ROOT)
     from switch_nerf_amd import parallel
