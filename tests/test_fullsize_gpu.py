@@ -144,3 +144,91 @@ def test_full_batch_bf16_properties():
     assert abs(kept16 - kept32) < 5e-3
     assert (rgb16 - c32["rgb"]).abs().max().item() < 5e-3             # measured 6.5e-4
     assert abs(st["loss"].item() - st32["loss"].item()) < 2e-2 * abs(st32["loss"].item())
+
+
+def test_mission_bay_recipe_mip_512_wide_16_experts_vs_oracle_fp32():
+    """BASELINE configs[3] as ONE workload (mission_bay.yaml's model block + the mip renderer): MipNeRFMoE-style two-level step
+    (frustum casting, integrated positional encoding, weights blur + level resampling, colour padding, loss = (fine + coarse) / 2)
+    through the 512-feature chain / block-wise weight-gradient kernels with 16 experts - against the oracle: routing of both levels
+    exact, rgb of both levels <= 1e-4, loss, every parameter gradient."""
+    cfg = dict(synth.BUILDING, model_dim=512, gate_hidden=512, num_experts=16)
+    N, S, Fn, chunk = 48, 33, 33, 512                      # 32 frustums per level and ray; 1536 points = 3 chunks per level
+    sd = synth.make_weights(351, cfg, gate_scale=0.05)
+    rays, img, rgbs = synth.make_rays(352, N)
+    rays[:, 6], rays[:, 7] = 0.01, 10.0                    # README.md:115 near / far of the Mission Bay recipe
+    rng = np.random.default_rng(353)
+    radii = np.full((N, 1), 1e-3, np.float32)
+    pr = rng.uniform(0, 1, (N, S)).astype(np.float32)
+    fu = rng.uniform(0, 1, (N, Fn)).astype(np.float32)
+    from switch_nerf_amd.model import SwitchNeRF
+    m = SwitchNeRF(cfg, dtype=torch.float32)
+    m.load_state_dict(sd)
+    st = m.train_step_mip(_dev(rgbs), _dev(rays), _dev(radii), _dev(img), S, Fn, chunk, perturb=1.0, perturb_rand=_dev(pr), fine_u=_dev(fu),
+                          optimizer_step=False)
+    c, cf = st["ctx"], st["ctx_fine"]
+    p = O.params_from_numpy(sd, requires_grad=True)
+    ost = O.training_step_mip(p, torch.from_numpy(rays), torch.from_numpy(radii), torch.from_numpy(img), torch.from_numpy(rgbs), cfg, S, Fn,
+                              chunk, perturb=1.0, perturb_rand=torch.from_numpy(pr), fine_u=torch.from_numpy(fu))
+    ost["loss"].backward()
+    res = ost["results"]
+    mis_c = int((c["idx"].cpu().numpy() != np.concatenate([r["idx"] for r in res["routings"]])).sum())
+    mis_f = int((cf["idx"].cpu().numpy() != np.concatenate([r["idx"] for r in res["routings_fine"]])).sum())
+    print(f"mission bay recipe (mip, 512 wide, 16 experts): routing mismatches coarse {mis_c}, fine {mis_f} of {N * (S - 1)} each")
+    assert mis_c == 0 and mis_f == 0
+    np.testing.assert_allclose(c["rgb"].cpu().numpy(), res["rgb_coarse"].detach().numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(cf["rgb"].cpu().numpy(), res["rgb_fine"].detach().numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(st["loss"].item(), ost["loss"].item(), rtol=2e-5)
+    worst = 0.0
+    for k, t in m.grad_dict().items():
+        ref = p[k].grad.numpy()
+        err = np.abs(t.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
+        worst = max(worst, err)
+        assert err <= (2e-3 if ref.size > 4 else 1e-2), (k, err)
+    print(f"mission bay recipe: worst relative parameter-gradient error {worst:.2e}")
+
+
+def test_mission_bay_per_gpu_share_bf16_properties():
+    """The per-GPU share of BASELINE configs[3] on 8 GPUs at full size: 1664 rays x (257 + 257) edges = 425,984 frustums per level,
+    model_chunk_size 212992 (two segments per level, capacity 13312), 512-wide layers, 16 experts, bf16.  Size-independent
+    properties: finite outputs and gradients, both levels route every point (counts add up, kept + dropped = all), the second level's
+    edges are sorted and inside [near, far], an Adam step lowers the loss on the same batch, and segment 0 of the coarse level is
+    routed exactly like the same rays processed alone."""
+    cfg = dict(synth.BUILDING, model_dim=512, gate_hidden=512, num_experts=16)
+    N, S, chunk = 1664, 257, 212992
+    sd = synth.make_weights(361, cfg, gate_scale=0.05)
+    rays, img, rgbs = synth.make_rays(362, N)
+    rays[:, 6], rays[:, 7] = 0.01, 10.0
+    radii = torch.full((N, 1), 1e-3, device="cuda")
+    g = torch.Generator().manual_seed(363)
+    pr, fu = torch.rand(N, S, generator=g).cuda(), torch.rand(N, S, generator=g).cuda()
+    from switch_nerf_amd.model import SwitchNeRF
+    m = SwitchNeRF(cfg, dtype=torch.bfloat16)
+    m.load_state_dict(sd)
+    kw = dict(perturb=1.0, perturb_rand=pr, fine_u=fu)
+    st = m.train_step_mip(_dev(rgbs), _dev(rays), radii, _dev(img), S, S, chunk, optimizer_step=True, **kw)
+    c, cf = st["ctx"], st["ctx_fine"]
+    P = N * (S - 1)
+    assert c["n_seg"] == 2 and cf["n_seg"] == 2 and c["cap"] == 13312 and c["P"] == P
+    idx0 = c["idx"][:chunk].clone()
+    loc0 = c["loc"][:chunk].clone()
+    for lv in (c, cf):
+        assert torch.isfinite(lv["rgb"]).all() and torch.isfinite(lv["raw"]).all()
+        assert int(lv["counts"].sum().item()) == P and (lv["counts"].sum(1) == chunk).all()
+        kept = (lv["tok2row"] >= 0)
+        assert torch.equal(kept, lv["loc"] < lv["cap"])
+    zf = cf["z_edges"]
+    assert (zf[:, 1:] >= zf[:, :-1]).all() and zf.min().item() >= 0.01 - 1e-6 and zf.max().item() <= 10.0 + 1e-4
+    assert torch.isfinite(st["loss"]) and torch.isfinite(m.grad).all()
+    l0 = st["loss"].item()
+    for _ in range(3):
+        st = m.train_step_mip(_dev(rgbs), _dev(rays), radii, _dev(img), S, S, chunk, optimizer_step=True, **kw)
+    assert st["loss"].item() < l0
+    # segment independence of the coarse level (fresh model: the weights above have moved)
+    m2 = SwitchNeRF(cfg, dtype=torch.bfloat16)
+    m2.load_state_dict(sd)
+    n0 = chunk // (S - 1)                                   # 832 rays = segment 0
+    c_all, _ = m2.forward_mip(_dev(rays), radii, _dev(img), S, 0, chunk, perturb=1.0, perturb_rand=pr)
+    c_one, _ = m2.forward_mip(_dev(rays[:n0]), radii[:n0], _dev(img[:n0]), S, 0, chunk, perturb=1.0, perturb_rand=pr[:n0].contiguous())
+    assert torch.equal(c_all["idx"][:chunk], c_one["idx"]) and torch.equal(c_all["loc"][:chunk], c_one["loc"])
+    assert torch.equal(c_all["idx"][:chunk], idx0) and torch.equal(c_all["loc"][:chunk], loc0)
+    print(f"mission bay share: loss {l0:.5f} -> {st['loss'].item():.5f}; kept coarse {float((c['tok2row'] >= 0).float().mean()):.3f}")
