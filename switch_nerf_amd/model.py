@@ -853,11 +853,36 @@ class SwitchNeRF:
         yield self
 
     def named_parameters(self):
-        """(reference key, tensor) pairs - views of the flat fp32 master buffer (count_parameters, runner.py:196-199)."""
+        """(reference key, tensor) pairs - the parameters in the reference's key layout, for inspection / count_parameters
+        (runner.py:196-199).  The trainable leaf an optimizer should be given is `flat_param` (trainable_parameters())."""
         return iter(self._to_ref_layout(self.p).items())
 
     def parameters(self):
         return (v for _, v in self.named_parameters())
+
+    # ---- torch.autograd bridge (autograd.py): the reference's Runner loop drives the HIP path unchanged
+    _flat_param = None
+    _packed_version = -1
+
+    @property
+    def flat_param(self):
+        """The model's whole parameter set as ONE leaf nn.Parameter sharing storage with the flat fp32 master buffer.  Give it to
+        torch.optim.Adam / DDP; rendering.render_rays(...) in training mode returns tensors whose backward fills its `.grad`."""
+        if self._flat_param is None:
+            self._flat_param = torch.nn.Parameter(self.flat, requires_grad=True)
+            self._packed_version = self._flat_param._version
+        return self._flat_param
+
+    def trainable_parameters(self):
+        return [self.flat_param]
+
+    def _sync_compute_copies(self):
+        """An optimizer outside this class moved the master weights in place (the Parameter's version counter tells): refresh the
+        packed compute copies the chain kernels read."""
+        fp = self._flat_param
+        if fp is not None and fp._version != self._packed_version:
+            self.refresh_compute_copies()
+            self._packed_version = fp._version
 
     def to(self, *_a, **_k):
         return self

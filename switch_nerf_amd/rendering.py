@@ -40,12 +40,37 @@ def render_rays(nerf, bg_nerf, rays: torch.Tensor, image_indices: Optional[torch
         noise = torch.randn(P, device=rays.device) * hparams.sigma_noise_std      # rendering.py:366
     if image_indices is None:
         image_indices = torch.zeros(N, dtype=torch.long, device=rays.device)
+    noise_f = None
     if F > 0:
-        noise_f = None
         if noise is not None:
             noise_f = torch.randn(N * F, device=rays.device) * hparams.sigma_noise_std
         if (N * F) % min(chunk, N * F) and nerf.training:
             raise ValueError(f"N_rays * fine_samples ({N * F}) must be a multiple of model_chunk_size ({chunk})")
+    if nerf.training and torch.is_grad_enabled() and hasattr(nerf, "flat_param") and getattr(nerf, "hash", None) is None:
+        # training under autograd (the reference's Runner loop: loss.backward() + torch optimizer, runner.py:679-693): one autograd
+        # node over the HIP forward; its backward runs the HIP backward and fills nerf.flat_param.grad (autograd.py)
+        from .autograd import RenderRaysFunction
+        rgb, gl_c, gl_f, depth, dvar = RenderRaysFunction.apply(nerf.flat_param, nerf, rays.contiguous(), image_indices, S, F, chunk,
+                                                                float(perturb), pr, noise, noise_f)
+        typ = "fine" if F > 0 else "coarse"
+        res = {f"rgb_{typ}": rgb, "gate_loss_coarse": gl_c}
+        if F > 0:
+            res["gate_loss_fine"] = gl_f
+        if get_depth:
+            res[f"depth_{typ}"] = depth
+        if get_depth_variance:
+            res[f"depth_variance_{typ}"] = dvar
+        st = nerf._last_ctx
+        if getattr(hparams, "moe_return_gates", False):
+            res["moe_gates_coarse"] = st[0]["idx"].long().view(N, S, 1, 1)
+            if F > 0:
+                res["moe_gates_fine"] = st[1]["idx"].long().view(N, F, 1, 1)
+        if getattr(hparams, "return_sigma", False):
+            res["sigma_coarse"] = st[0]["raw"][:, 3].view(N, S)
+            if F > 0:
+                res["sigma_fine"] = st[1]["raw"][:, 3].view(N, F)
+        return res, False
+    if F > 0:
         c, cf, out = nerf.forward_hier(rays.contiguous(), image_indices, S, F, chunk, float(perturb), pr, None, noise, noise_f,
                                        no_batch=nerf.moe_no_batch, training=nerf.training)
         res = {"rgb_fine": out["rgb"], "gate_loss_coarse": c["l_aux"], "gate_loss_fine": cf["l_aux"]}
