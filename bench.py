@@ -82,7 +82,8 @@ def main():
     ap.add_argument("--rays", type=int, default=8192)
     ap.add_argument("--samples", type=int, default=256)
     ap.add_argument("--chunk", type=int, default=131072)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="compute dtype: bf16 (headline, the reference's amp_use_bfloat16), fp16 (IEEE half + loss scaling: BASELINE configs[4]), fp32")
     ap.add_argument("--gate-scale", type=float, default=1.0, help="scale of the router weight (small => balanced routing)")
     ap.add_argument("--parallelism", default="dp", choices=["dp", "ep"],
                     help="dp (default): experts replicated, one gradient all-reduce per step; ep: experts sharded over the ranks, "
@@ -134,11 +135,11 @@ def main():
         parallel.init_from_env(os.environ.get("SWN_DIST_BACKEND", "nccl"), dev)       # "nccl" = RCCL; gloo only for single-GPU tests of this path
 
     from switch_nerf_amd.model import SwitchNeRF, BUILDING
-    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[a.dtype]
     cfg = dict(BUILDING, model_dim=a.model_dim, gate_hidden=a.model_dim, num_experts=a.experts)
     if a.hash:
         cfg["hash"] = dict(n_levels=16, log2_table=19, base_res=16, per_level_scale=1.3819, aabb_lo=(-1.2, -1.2, -1.2), aabb_hi=(1.2, 1.2, 1.2))
-    other = a.fine or a.mip or a.model_dim != 256 or a.experts != 8 or a.dense or a.bg or a.hash or a.capacity_factor != 1.0 or a.eval
+    other = a.dtype != "bf16" or a.fine or a.mip or a.model_dim != 256 or a.experts != 8 or a.dense or a.bg or a.hash or a.capacity_factor != 1.0 or a.eval
     if a.dense:
         from switch_nerf_amd.dense import DenseNeRF
         model = DenseNeRF(dtype=dtype, device=dev, seed=0)
@@ -250,7 +251,7 @@ def main():
 
     # ---- per-kernel accounting from the live HIP events
     L, M, E = model.L, model.M, model.E
-    esz = 2 if dtype == torch.bfloat16 else 4
+    esz = 4 if dtype == torch.float32 else 2
     traffic_tab = {}
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):

@@ -27,10 +27,14 @@ extern "C" {
 
 #define SWN_F32 0
 #define SWN_BF16 1
-#define SWN_F16 2   /* half precision compute copies (BASELINE configs[4]: fp16 MFMA); 256-row chain geometry */
+#define SWN_F16 2   /* IEEE half compute type (BASELINE configs[4]: fp16 MFMA) - libswn_hip_f16.so, see swn_half_dtype() */
 
 const char* swn_last_error(void);
 int swn_version(void);
+/* The library is built twice from the same sources: libswn_hip.so computes in fp32 and bfloat16 (dtype codes SWN_F32, SWN_BF16),
+ * libswn_hip_f16.so in fp32 and IEEE half (SWN_F32, SWN_F16; fp16 MFMA v_mfma_f32_32x32x16_f16) - identical entry points.  Returns
+ * the 16-bit dtype code this build accepts.                                                                                   */
+int swn_half_dtype(void);
 
 /* Diagnostic: dumps the lane->element maps of v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32 as used by the
  * kernels (out: 3*64*16 int32 = for each of A(8 used),B(8 used),C(16) slot the (row<<16|col) it addresses). */
@@ -294,7 +298,7 @@ typedef struct swn_chain_desc {
                                    workgroups per CU (chain_big.hip: chains of 256 x 256 layers, bf16 / fp16, no rowbias / x_scale /
                                    x_save / y_add_gather; swn_chain_big_ok).
                                    The ReLU masks of the two geometries are laid out differently: run a backward chain (relu = 2)
-                                   on the geometry of the forward chain that recorded its masks.  fp16 chains always use 2.   */
+                                   on the geometry of the forward chain that recorded its masks.                              */
   int32_t tag;                  /* profiling only: selects an identical kernel instantiation with its own symbol so that
                                    rocprofv3 reports the roles separately (0 generic, 1 expert fwd, 2 expert bwd,
                                    3 front fwd, 4 tail fwd, 5 tail bwd, 6 front bwd)                 */

@@ -6,6 +6,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SWN_LIB") or os.path.join(_HERE, "libswn_hip.so")      # (SWN_LIB: A/B builds of the library, experiments only)
+LIB_PATH_F16 = os.path.join(_HERE, "libswn_hip_f16.so")    # the same sources built with IEEE half as the 16-bit compute type
 
 F32, BF16, F16 = 0, 1, 2
 
@@ -86,18 +87,36 @@ SIGNATURES = {
 }
 
 _lib = None
+_libs = {}            # "bf16" / "f16" -> loaded library
+_half = "bf16"        # which build the process currently talks to
+
+
+def use_half(kind: str):
+    """Select the build of the library by its 16-bit compute type: "bf16" (libswn_hip.so, default) or "f16" (libswn_hip_f16.so).
+    Both carry the same entry points and both compute fp32; a model of compute dtype torch.float16 selects "f16" when it is built
+    and checks the selection on every step (the two 16-bit types share one dtype slot per build)."""
+    global _half, _lib
+    assert kind in ("bf16", "f16")
+    _half = kind
+    _lib = _libs.get(kind)
+    return load()
+
+
+def half_kind() -> str:
+    return _half
 
 
 def load():
-    """Load the HIP library (once).  No fallback: a missing library is an error."""
+    """Load the HIP library (once per build).  No fallback: a missing library is an error."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = LIB_PATH if _half == "bf16" else LIB_PATH_F16
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(switch_nerf_amd/build.sh).  There is no CPU fallback for the hot path.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     lib.swn_last_error.restype = C.c_char_p
     lib.swn_last_error.argtypes = []
     lib.swn_route_workspace_bytes.restype = sz
@@ -110,7 +129,10 @@ def load():
         fn = getattr(lib, name)
         fn.restype = i32
         fn.argtypes = args
-    _lib = lib
+    lib.swn_half_dtype.restype = i32
+    lib.swn_half_dtype.argtypes = []
+    assert lib.swn_half_dtype() == (BF16 if _half == "bf16" else F16), f"{path} is not the {_half} build"
+    _lib = _libs[_half] = lib
     return lib
 
 

@@ -200,16 +200,16 @@ extern "C" int swn_fg_bounds(const float* rays, const float* center_host, const 
 extern "C" int swn_bg_sample_pe(const float* rays, const float* center_host, const float* radius_host, const float* t_steps,
                                 const float* perturb_rand, float perturb, int n_rays, int n_samples, int l_xyz, int dtype,
                                 const float* z_in, float* z_out, float* depth_real, void* pe, int pe_stride, void* stream) {
-  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_bg_sample_pe: bad dtype");
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_bg_sample_pe: bad dtype");
   SWN_CHECK(rays && pe && (z_in || t_steps), "swn_bg_sample_pe: null pointer");
   SWN_CHECK((center_host == nullptr) == (radius_host == nullptr), "swn_bg_sample_pe: center / radius must both be given or both NULL");
   SWN_CHECK(l_xyz >= 0 && l_xyz <= 12, "swn_bg_sample_pe: frequencies must be <= 12");
-  const int epc = dtype == SWN_BF16 ? 8 : 4;
+  const int epc = dtype == SWN_HALF ? 8 : 4;
   SWN_CHECK(pe_stride >= 4 + 8 * l_xyz && pe_stride % epc == 0, "swn_bg_sample_pe: pe_stride %d too small / unaligned", pe_stride);
   if (n_rays <= 0) return 0;
   const long P = (long)n_rays * n_samples;
   const Bound b = make_bound(center_host, radius_host);
-  if (dtype == SWN_BF16)
+  if (dtype == SWN_HALF)
     hipLaunchKernelGGL((bg_sample_pe_kernel<bf16_t, 12>), dim3(cdiv(P, 128)), dim3(128), 0, as_stream(stream), rays, b, t_steps,
                        perturb_rand, perturb, n_rays, n_samples, l_xyz, z_in, z_out, depth_real, (bf16_t*)pe, pe_stride);
   else

@@ -251,7 +251,7 @@ __device__ __forceinline__ void k_loop(f32x16_t (&acc)[Cfg<T>::MI][NI], typename
       for (int mi = 0; mi < MI; ++mi) {
         const bf16x8_t a = aread(ks, mi);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][ni], a, acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = SWN_MFMA_32x32x16(ring[r][ni], a, acc[mi][ni]);
       }
       refill(ks, r);
     }
@@ -264,23 +264,23 @@ __device__ __forceinline__ void k_loop(f32x16_t (&acc)[Cfg<T>::MI][NI], typename
         const int r = ks % RING;
         a1 = aread(ks, 1);
         SWN_PIN();
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a0, acc[0][1], 0, 0, 0);
+        acc[0][0] = SWN_MFMA_32x32x16(ring[r][0], a0, acc[0][0]);
+        acc[0][1] = SWN_MFMA_32x32x16(ring[r][1], a0, acc[0][1]);
         SWN_PIN();
         a0 = aread(ks, 2);
         SWN_PIN();
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a1, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a1, acc[1][1], 0, 0, 0);
+        acc[1][0] = SWN_MFMA_32x32x16(ring[r][0], a1, acc[1][0]);
+        acc[1][1] = SWN_MFMA_32x32x16(ring[r][1], a1, acc[1][1]);
         SWN_PIN();
         a1 = aread(ks, 3);
         SWN_PIN();
-        acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a0, acc[2][0], 0, 0, 0);
-        acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a0, acc[2][1], 0, 0, 0);
+        acc[2][0] = SWN_MFMA_32x32x16(ring[r][0], a0, acc[2][0]);
+        acc[2][1] = SWN_MFMA_32x32x16(ring[r][1], a0, acc[2][1]);
         SWN_PIN();
         if (ks + 1 < NSTEPS) a0 = aread(ks + 1, 0);
         SWN_PIN();
-        acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a1, acc[3][0], 0, 0, 0);
-        acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a1, acc[3][1], 0, 0, 0);
+        acc[3][0] = SWN_MFMA_32x32x16(ring[r][0], a1, acc[3][0]);
+        acc[3][1] = SWN_MFMA_32x32x16(ring[r][1], a1, acc[3][1]);
         SWN_PIN();
         refill(ks, r);
         SWN_PIN();
@@ -291,13 +291,13 @@ __device__ __forceinline__ void k_loop(f32x16_t (&acc)[Cfg<T>::MI][NI], typename
         const int r = ks % RING;
         a1 = aread(ks, 1);
         SWN_PIN();
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a0, acc[0][1], 0, 0, 0);
+        acc[0][0] = SWN_MFMA_32x32x16(ring[r][0], a0, acc[0][0]);
+        acc[0][1] = SWN_MFMA_32x32x16(ring[r][1], a0, acc[0][1]);
         SWN_PIN();
         if (ks + 1 < NSTEPS) a0 = aread(ks + 1, 0);
         SWN_PIN();
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][0], a1, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[r][1], a1, acc[1][1], 0, 0, 0);
+        acc[1][0] = SWN_MFMA_32x32x16(ring[r][0], a1, acc[1][0]);
+        acc[1][1] = SWN_MFMA_32x32x16(ring[r][1], a1, acc[1][1]);
         SWN_PIN();
         refill(ks, r);
         SWN_PIN();
@@ -723,19 +723,19 @@ __global__ void pack_weights_batched_kernel(const PackTable tab) {
 static int chain_launch(const swn_chain_desc& d, void* stream) {
   ChainArgs a;
   a.d = d;
-  const int bm = d.dtype == SWN_BF16 ? Cfg<bf16_t>::BM : Cfg<float>::BM;
+  const int bm = d.dtype == SWN_HALF ? Cfg<bf16_t>::BM : Cfg<float>::BM;
   a.tiles_per_group = cdiv(d.group_rows ? (d.group_rows_clamp < d.group_stride ? d.group_rows_clamp : d.group_stride) : d.group_stride, bm);
   if (!d.group_rows) a.d.group_rows_clamp = d.group_stride;
   const long grid = (long)a.tiles_per_group * d.n_groups;
   SWN_CHECK(grid > 0 && grid < (1L << 31), "swn_mlp_chain: grid %ld out of range", grid);
-  int lds = (d.dtype == SWN_BF16 ? Cfg<bf16_t>::ACT : Cfg<float>::ACT) + ROW_ELEMS * 4;
+  int lds = (d.dtype == SWN_HALF ? Cfg<bf16_t>::ACT : Cfg<float>::ACT) + ROW_ELEMS * 4;
 #ifdef SWN_EXP_LDSPAD
   lds += SWN_EXP_LDSPAD;      // experiment: fewer resident workgroups per CU (scripts/chain_timing.py)
 #endif
   const void* fn = nullptr;
 #define SWN_PICK(TAGV)                                                                         \
   case TAGV:                                                                                   \
-    fn = d.dtype == SWN_BF16 ? (const void*)chain_kernel<bf16_t, TAGV> : (const void*)chain_kernel<float, TAGV>; \
+    fn = d.dtype == SWN_HALF ? (const void*)chain_kernel<bf16_t, TAGV> : (const void*)chain_kernel<float, TAGV>; \
     break;
   switch (d.tag) {
     SWN_PICK(0) SWN_PICK(1) SWN_PICK(2) SWN_PICK(3) SWN_PICK(4) SWN_PICK(5) SWN_PICK(6)
@@ -754,7 +754,7 @@ static int chain_launch(const swn_chain_desc& d, void* stream) {
 #if SWN_WIDE
 namespace swn {
 int chain_wide_launch(const swn_chain_desc& d, void* stream) { return swn_wide::chain_launch(d, stream); }
-int chain_wide_tile_rows(int dtype) { return dtype == SWN_BF16 ? swn_wide::Cfg<bf16_t>::BM : swn_wide::Cfg<float>::BM; }
+int chain_wide_tile_rows(int dtype) { return dtype == SWN_HALF ? swn_wide::Cfg<bf16_t>::BM : swn_wide::Cfg<float>::BM; }
 }  // namespace swn
 #elif SWN_CONCAT
 namespace swn {
@@ -767,14 +767,14 @@ using namespace swn;
 extern "C" int swn_pack_weights(const float* master, void* out, int dtype, int n_wsets, int in_dim, int out_dim,
                                 int transpose, void* stream) {
   SWN_CHECK(master && out, "swn_pack_weights: null pointer");
-  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_pack_weights: bad dtype");
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_pack_weights: bad dtype");
   const int N = transpose ? out_dim : in_dim, K = transpose ? in_dim : out_dim;
-  const int kstep = dtype == SWN_BF16 ? 16 : 8;
+  const int kstep = dtype == SWN_HALF ? 16 : 8;
   SWN_CHECK(N % 32 == 0 && K % kstep == 0 && n_wsets >= 1, "swn_pack_weights: N=%d must be a multiple of 32, K=%d of %d", N, K, kstep);
   const long chunks = (long)n_wsets * (N / 32) * (K / kstep) * 64;
   int blocks = cdiv(chunks, 256);
   if (blocks > 4096) blocks = 4096;
-  if (dtype == SWN_BF16)
+  if (dtype == SWN_HALF)
     hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(blocks), dim3(256), 0, as_stream(stream), master, (bf16_t*)out, in_dim,
                        out_dim, transpose, chunks);
   else
@@ -786,9 +786,9 @@ extern "C" int swn_pack_weights(const float* master, void* out, int dtype, int n
 
 extern "C" int swn_pack_weights_batched(const swn_pack_item* items, int n_items, int dtype, void* stream) {
   SWN_CHECK(items && n_items >= 1 && n_items <= SWN_MAX_PACK_ITEMS, "swn_pack_weights_batched: 1..%d items", SWN_MAX_PACK_ITEMS);
-  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_pack_weights_batched: bad dtype");
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_pack_weights_batched: bad dtype");
   PackTable tab;
-  const int kstep = dtype == SWN_BF16 ? 16 : 8;
+  const int kstep = dtype == SWN_HALF ? 16 : 8;
   long max_chunks = 0;
   for (int i = 0; i < n_items; ++i) {
     const swn_pack_item& q = items[i];
@@ -801,13 +801,13 @@ extern "C" int swn_pack_weights_batched(const swn_pack_item* items, int n_items,
   }
   int blocks = cdiv(max_chunks, 256);
   if (blocks > 512) blocks = 512;
-  if (dtype == SWN_BF16) hipLaunchKernelGGL((pack_weights_batched_kernel<bf16_t>), dim3(blocks, n_items), dim3(256), 0, as_stream(stream), tab);
+  if (dtype == SWN_HALF) hipLaunchKernelGGL((pack_weights_batched_kernel<bf16_t>), dim3(blocks, n_items), dim3(256), 0, as_stream(stream), tab);
   else hipLaunchKernelGGL((pack_weights_batched_kernel<float>), dim3(blocks, n_items), dim3(256), 0, as_stream(stream), tab);
   SWN_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int swn_chain_tile_rows(int dtype) { return dtype == SWN_BF16 ? Cfg<bf16_t>::BM : Cfg<float>::BM; }
+extern "C" int swn_chain_tile_rows(int dtype) { return dtype == SWN_HALF ? Cfg<bf16_t>::BM : Cfg<float>::BM; }
 
 /* uint32 words of one ReLU mask buffer for a chain over n_groups x group_stride rows whose widest layer has max_width features */
 extern "C" long swn_chain_mask_words(int dtype, int n_groups, int group_stride, int max_width) {
@@ -826,7 +826,7 @@ extern "C" long swn_chain_mask_words(int dtype, int n_groups, int group_stride, 
 extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   SWN_CHECK(desc != nullptr, "swn_mlp_chain: null descriptor");
   const swn_chain_desc& d = *desc;
-  SWN_CHECK(d.dtype == SWN_F32 || d.dtype == SWN_BF16 || d.dtype == SWN_F16, "swn_mlp_chain: bad dtype %d", d.dtype);
+  SWN_CHECK(d.dtype == SWN_F32 || d.dtype == SWN_HALF, "swn_mlp_chain: bad dtype %d (this build of the library computes in fp32 and %s)", d.dtype, SWN_HALF == SWN_F16 ? "fp16" : "bf16");
   SWN_CHECK(d.n_layers >= 1 && d.n_layers <= SWN_MAX_CHAIN_LAYERS, "swn_mlp_chain: n_layers %d not in [1,%d]", d.n_layers, SWN_MAX_CHAIN_LAYERS);
   SWN_CHECK(d.n_groups >= 1 && d.n_wsets >= 1 && d.group_stride >= 1, "swn_mlp_chain: bad group geometry");
   bool wide = false, concat = false;
@@ -857,8 +857,7 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
       // and a backward chain must run on the geometry of the forward chain that recorded its masks - the caller pairs them.
     const bool can = chain_big_eligible(d);
     SWN_CHECK(d.geometry < 2 || can, "swn_mlp_chain: geometry 2 / 3 needs bf16 / fp16 chains of 256 x 256 layers without rowbias / x_scale / x_save / y_add_gather");
-    SWN_CHECK(d.dtype != SWN_F16 || can, "swn_mlp_chain: fp16 chains run on the 256-row geometry only (256 x 256 layers)");
-    if (d.geometry >= 2 || d.dtype == SWN_F16) return chain_big_launch(d, stream);
+    if (d.geometry >= 2) return chain_big_launch(d, stream);
   }
   if (wide) return chain_wide_launch(d, stream);        // 512-feature geometry (this file compiled with -DSWN_WIDE=1)
   if (concat) return chain_concat_launch(d, stream);    // concat-skip layers (this file compiled with -DSWN_CONCAT=1)

@@ -549,7 +549,7 @@ __global__ __launch_bounds__(G::NT, G::OCC) void chainb_kernel(const Args args) 
 namespace swn {
 
 bool chain_big_eligible(const swn_chain_desc& d) {
-  if (d.dtype != SWN_BF16 && d.dtype != SWN_F16) return false;
+  if (d.dtype != SWN_HALF) return false;
 #ifdef SWN_BIG_TIMING
   if (d.x_save || d.x_scale) return false;
 #else
@@ -568,6 +568,11 @@ int chain_big_mask_words_per_tile(int geometry) { return (geometry == 3 ? swn_bi
 template <typename G>
 static int chain_big_launch_g(const swn_chain_desc& d, void* stream) {
   using namespace swn_big;
+#ifdef SWN_HALF_F16
+  typedef Fp16 HalfT;
+#else
+  typedef Bf16 HalfT;
+#endif
   Args a;
   a.d = d;
   a.tiles_per_group = cdiv(d.group_rows ? (d.group_rows_clamp < d.group_stride ? d.group_rows_clamp : d.group_stride) : d.group_stride, G::BM);
@@ -577,11 +582,11 @@ static int chain_big_launch_g(const swn_chain_desc& d, void* stream) {
   const void* fn = nullptr;
 #define SWN_PICKB(TAGV)                                                                                                     \
   case TAGV:                                                                                                                \
-    fn = d.dtype == SWN_BF16 ? (const void*)chainb_kernel<Bf16, G, TAGV> : (const void*)chainb_kernel<Fp16, G, TAGV>;       \
+    fn = (const void*)chainb_kernel<HalfT, G, TAGV>;       \
     break;
   switch (d.tag) {
     SWN_PICKB(1) SWN_PICKB(2)
-    default: fn = d.dtype == SWN_BF16 ? (const void*)chainb_kernel<Bf16, G, 0> : (const void*)chainb_kernel<Fp16, G, 0>;
+    default: fn = (const void*)chainb_kernel<HalfT, G, 0>;
   }
 #undef SWN_PICKB
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);

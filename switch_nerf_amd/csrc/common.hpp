@@ -22,11 +22,30 @@ int set_error(const char* fmt, ...);
     if (e__ != hipSuccess) return swn::set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
   } while (0)
 
+// The 16-bit compute type.  The library is built twice from the same sources (build.sh): libswn_hip.so with bfloat16 (dtype code
+// SWN_BF16, the reference's amp_use_bfloat16 recipes) and libswn_hip_f16.so (-DSWN_HALF_F16) with IEEE half (dtype code SWN_F16,
+// the reference's default fp16 autocast + GradScaler, runner.py:483, 679; BASELINE configs[4]).  Everything below the three
+// conversion helpers, the MFMA macro and the constants is type-agnostic: `bf16_t` reads "the 16-bit compute type, raw bits".
 typedef uint16_t bf16_t;  // raw bits
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#ifdef SWN_HALF_F16
+#define SWN_HALF SWN_F16
+#define SWN_HALF_ONE_X2 0x3C003C00u        /* two 1.0 */
+typedef _Float16 hwf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 swn_mfma16_t __attribute__((ext_vector_type(8)));
+#define SWN_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(swn_mfma16_t, a), __builtin_bit_cast(swn_mfma16_t, b), c, 0, 0, 0)
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {      // round to nearest even (v_cvt_f16_f32 x 2 + pack)
+  const hwf16x2_t v = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+#else
+#define SWN_HALF SWN_BF16
+#define SWN_HALF_ONE_X2 0x3F803F80u
 typedef __bf16 hwbf16x2_t __attribute__((ext_vector_type(2)));
-
+typedef short swn_mfma16_t __attribute__((ext_vector_type(8)));
+#define SWN_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(swn_mfma16_t, a), __builtin_bit_cast(swn_mfma16_t, b), c, 0, 0, 0)
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // round-to-nearest-even conversions: gfx950 has a packed hardware convert (v_cvt_pk_bf16_f32); going through the
 // __bf16 vector type lets hipcc emit it (one VALU op per two values instead of ~10 of integer rounding code).
@@ -34,6 +53,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   const f32x2_t v = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hwbf16x2_t));
 }
+#endif
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xFFFFu); }
 
 template <typename T> struct ElemIO;

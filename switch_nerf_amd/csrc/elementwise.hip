@@ -38,7 +38,7 @@ __global__ void probe_kernel(int32_t* out) {
   }
   f32x16_t c;
   for (int r = 0; r < 16; ++r) c[r] = 0.f;
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  c = SWN_MFMA_32x32x16(a, b, c);
   for (int r = 0; r < 16; ++r) out[lane * 16 + r] = (int)c[r];
   // Test 2 (f32 32x32x2): A[i][k] = (k == i % 2), B[k][j] = k + 2 * (j % 8)  ->  D[i][j] = (i % 2) + 2 * (j % 8)
   const int k2 = lane >> 5;
@@ -944,7 +944,8 @@ __global__ void gather_rows_kernel(const char* __restrict__ src, const int32_t* 
 using namespace swn;
 
 extern "C" const char* swn_last_error(void) { return g_err; }
-extern "C" int swn_version(void) { return 1; }
+extern "C" int swn_version(void) { return 2; }
+extern "C" int swn_half_dtype(void) { return SWN_HALF; }      /* the 16-bit compute type of this build: SWN_BF16 or SWN_F16 */
 
 extern "C" int swn_mfma_probe(int32_t* out, void* stream) {
   SWN_CHECK(out, "swn_mfma_probe: null");
@@ -963,13 +964,13 @@ static inline int ew_blocks(long waves_needed) {
 extern "C" int swn_sample_pe(const float* rays, const float* t_steps, const float* perturb_rand, float perturb,
                              int n_rays, int n_samples, int l_xyz, int l_dir, int dtype, float* z_out, void* pe_xyz,
                              int pe_stride, void* pe_dir, int dir_stride, void* stream) {
-  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_sample_pe: bad dtype");
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_sample_pe: bad dtype");
   SWN_CHECK(rays && t_steps && z_out && pe_xyz, "swn_sample_pe: null pointer");
   SWN_CHECK(l_xyz >= 0 && l_xyz <= 12 && l_dir >= 0 && l_dir <= 12, "swn_sample_pe: frequencies must be <= 12");
-  const int epc = dtype == SWN_BF16 ? 8 : 4;
+  const int epc = dtype == SWN_HALF ? 8 : 4;
   SWN_CHECK(pe_stride >= 3 + 6 * l_xyz && pe_stride % epc == 0, "swn_sample_pe: pe_stride %d too small / unaligned", pe_stride);
   const long P = (long)n_rays * n_samples;
-  if (dtype == SWN_BF16)
+  if (dtype == SWN_HALF)
     hipLaunchKernelGGL((sample_pe_kernel<bf16_t, 12>), dim3(cdiv(P, 128)), dim3(128), 0, as_stream(stream), rays, t_steps,
                        perturb_rand, perturb, n_rays, n_samples, l_xyz, z_out, (bf16_t*)pe_xyz, pe_stride, (const float*)nullptr);
   else
@@ -978,7 +979,7 @@ extern "C" int swn_sample_pe(const float* rays, const float* t_steps, const floa
   SWN_LAUNCH_CHECK();
   if (pe_dir) {
     SWN_CHECK(dir_stride >= 3 + 6 * l_dir, "swn_sample_pe: dir_stride too small");
-    if (dtype == SWN_BF16)
+    if (dtype == SWN_HALF)
       hipLaunchKernelGGL((dir_pe_kernel<bf16_t, 12>), dim3(cdiv(n_rays, 256)), dim3(256), 0, as_stream(stream), rays,
                          n_rays, l_dir, (bf16_t*)pe_dir, dir_stride);
     else
@@ -992,13 +993,13 @@ extern "C" int swn_sample_pe(const float* rays, const float* t_steps, const floa
 /* positional encoding of xyz = o + d * z for caller-supplied depths z[N,S] (the fine pass: rendering.py:246 xyz_fine_fn) */
 extern "C" int swn_pe_from_z(const float* rays, const float* z, int n_rays, int n_samples, int l_xyz, int dtype, void* pe_xyz,
                              int pe_stride, void* stream) {
-  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_pe_from_z: bad dtype");
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_pe_from_z: bad dtype");
   SWN_CHECK(rays && z && pe_xyz, "swn_pe_from_z: null pointer");
   SWN_CHECK(l_xyz >= 0 && l_xyz <= 12, "swn_pe_from_z: frequencies must be <= 12");
-  const int epc = dtype == SWN_BF16 ? 8 : 4;
+  const int epc = dtype == SWN_HALF ? 8 : 4;
   SWN_CHECK(pe_stride >= 3 + 6 * l_xyz && pe_stride % epc == 0, "swn_pe_from_z: pe_stride %d too small / unaligned", pe_stride);
   const long P = (long)n_rays * n_samples;
-  if (dtype == SWN_BF16)
+  if (dtype == SWN_HALF)
     hipLaunchKernelGGL((sample_pe_kernel<bf16_t, 12>), dim3(cdiv(P, 128)), dim3(128), 0, as_stream(stream), rays, (const float*)nullptr,
                        (const float*)nullptr, 0.f, n_rays, n_samples, l_xyz, (float*)nullptr, (bf16_t*)pe_xyz, pe_stride, z);
   else
@@ -1028,13 +1029,13 @@ static inline int row_blocks(long rows) {   // 16 rows per 256-thread block iter
 extern "C" int swn_gate_fwd(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg,
                             int n_tokens, int gate_dim, int n_experts, float* gates, int32_t* idx, float* gmax,
                             float* stats, void* stream) {
-  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_gate_fwd: bad dtype");
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_gate_fwd: bad dtype");
   SWN_CHECK(g && wg && gates && idx && gmax, "swn_gate_fwd: null pointer");
   SWN_CHECK(n_experts >= 1 && n_experts <= 16, "swn_gate_fwd: experts <= 16");
   SWN_CHECK((ln_w == nullptr) == (ln_b == nullptr), "swn_gate_fwd: ln_w / ln_b must both be given or both NULL");
   if (ln_w) SWN_CHECK(stats, "swn_gate_fwd: stats required with LayerNorm");
   const int blocks = row_blocks(n_tokens);
-  if (dtype == SWN_BF16) {
+  if (dtype == SWN_HALF) {
     const bf16_t* gp = (const bf16_t*)g;
     GATE_DISPATCH(bf16_t, gate_fwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, n_tokens, n_experts,
                   gates, idx, gmax, stats);
@@ -1075,7 +1076,7 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
                             const float* gates, const int32_t* idx, const float* d_gmax, const float* stats,
                             const int32_t* counts, const float* laux_coef, int seg_tokens, int n_tokens, int gate_dim,
                             int n_experts, void* dg, float* dlogits, float* d_wg, float* d_ln_w, float* d_ln_b, void* stream) {
-  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_gate_bwd: bad dtype");
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_gate_bwd: bad dtype");
   SWN_CHECK(g && wg && gates && idx && dg && d_wg && counts && dlogits, "swn_gate_bwd: null pointer");
   SWN_CHECK(n_experts >= 1 && n_experts <= 16 && seg_tokens > 0, "swn_gate_bwd: bad sizes");
   if (ln_w) SWN_CHECK(stats && d_ln_w && d_ln_b && ln_b, "swn_gate_bwd: LayerNorm buffers missing");
@@ -1086,7 +1087,7 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
   const int tpb = gate_dwg_tokens_per_block(n_tokens);
   const int dwg_blocks = cdiv(n_tokens, tpb);
   float* dwg_partial = dlogits + (size_t)n_tokens * n_experts;          // second part of the scratch: [dwg_blocks][E * G]
-  if (dtype == SWN_BF16) {
+  if (dtype == SWN_HALF) {
     const bf16_t* gp = (const bf16_t*)g;
     bf16_t* dgp = (bf16_t*)dg;
     GATE_DISPATCH(bf16_t, gate_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, gates, idx, d_gmax,
@@ -1114,12 +1115,12 @@ template <int MODE>
 static int launch_sparse(const float* gates, const int32_t* idx, const int32_t* loc, void* tok, void* disp, float* dgate,
                          int dtype, int samples, int hidden, int capacity, int seg_tokens, int n_experts, int relu,
                          void* stream, const int32_t* begin = nullptr) {
-  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "sparse: bad dtype");
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "sparse: bad dtype");
   SWN_CHECK(idx && loc && tok && disp, "sparse: null pointer");
-  SWN_CHECK(hidden * (dtype == SWN_BF16 ? 2 : 4) % 16 == 0, "sparse: hidden row must be a multiple of 16 bytes");
+  SWN_CHECK(hidden * (dtype == SWN_HALF ? 2 : 4) % 16 == 0, "sparse: hidden row must be a multiple of 16 bytes");
   SWN_CHECK(capacity > 0 && seg_tokens > 0 && n_experts > 0, "sparse: bad sizes");
   const int blocks = ew_blocks(samples);
-  if (dtype == SWN_BF16)
+  if (dtype == SWN_HALF)
     hipLaunchKernelGGL((sparse_kernel<bf16_t, MODE>), dim3(blocks), dim3(256), 0, as_stream(stream), gates, idx, loc,
                        (bf16_t*)tok, (bf16_t*)disp, dgate, samples, hidden, capacity, seg_tokens, n_experts, relu, begin);
   else
@@ -1133,7 +1134,7 @@ extern "C" int swn_dispatch_fwd(const float* gates, const int32_t* indices, cons
                                 const void* reshaped_input, void* dispatched, int dtype, int samples, int hidden,
                                 int capacity, int n_experts, void* stream) {
   SWN_CHECK(dispatched, "swn_dispatch_fwd: null");
-  const size_t bytes = (size_t)n_experts * capacity * hidden * (dtype == SWN_BF16 ? 2 : 4);
+  const size_t bytes = (size_t)n_experts * capacity * hidden * (dtype == SWN_HALF ? 2 : 4);
   hipError_t e = hipMemsetAsync(dispatched, 0, bytes, as_stream(stream));  // torch.zeros at tutel_fast_dispatch.py:25
   SWN_CHECK(e == hipSuccess, "swn_dispatch_fwd: memset failed: %s", hipGetErrorString(e));
   return launch_sparse<0>(gates, indices, locations, (void*)reshaped_input, dispatched, nullptr, dtype, samples, hidden,
@@ -1159,7 +1160,7 @@ extern "C" int swn_dispatch_nobatch_fwd(const float* gates, const int32_t* indic
                                         const int32_t* expert_locations_begin, const void* reshaped_input, void* dispatched, int dtype,
                                         int samples, int hidden, int capacity, int n_experts, long dispatched_rows, void* stream) {
   SWN_CHECK(dispatched && expert_locations_begin, "swn_dispatch_nobatch_fwd: null");
-  const size_t bytes = (size_t)dispatched_rows * hidden * (dtype == SWN_BF16 ? 2 : 4);
+  const size_t bytes = (size_t)dispatched_rows * hidden * (dtype == SWN_HALF ? 2 : 4);
   hipError_t e = hipMemsetAsync(dispatched, 0, bytes, as_stream(stream));  // torch.zeros at tutel_fast_dispatch_nobatch.py:34
   SWN_CHECK(e == hipSuccess, "swn_dispatch_nobatch_fwd: memset failed: %s", hipGetErrorString(e));
   return launch_sparse<0>(gates, indices, locations, (void*)reshaped_input, dispatched, nullptr, dtype, samples, hidden,
@@ -1189,13 +1190,13 @@ extern "C" int swn_combine_fwd(const float* gates, const int32_t* indices, const
 
 extern "C" int swn_combine_bwd(const void* dy_in, const void* y, const float* dsig, const float* wsig, const float* gate,
                                int dtype, int samples, int hidden, void* dout, float* dgate, void* stream) {
-  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_combine_bwd: bad dtype");
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_combine_bwd: bad dtype");
   SWN_CHECK(dy_in && y && gate && dout && dgate, "swn_combine_bwd: null pointer");
   SWN_CHECK(hidden == 256 || hidden == 128 || hidden == 512, "swn_combine_bwd: hidden must be 128, 256 or 512");
   int blocks = row_blocks(samples);
 #define SWN_CB(T, H) hipLaunchKernelGGL((combine_bwd_kernel<T, H>), dim3(blocks), dim3(256), 0, as_stream(stream), (const T*)dy_in, \
                                         (const T*)y, dsig, wsig, gate, samples, (T*)dout, dgate)
-  if (dtype == SWN_BF16) { if (hidden == 256) SWN_CB(bf16_t, 256); else if (hidden == 128) SWN_CB(bf16_t, 128); else SWN_CB(bf16_t, 512); }
+  if (dtype == SWN_HALF) { if (hidden == 256) SWN_CB(bf16_t, 256); else if (hidden == 128) SWN_CB(bf16_t, 128); else SWN_CB(bf16_t, 512); }
   else { if (hidden == 256) SWN_CB(float, 256); else if (hidden == 128) SWN_CB(float, 128); else SWN_CB(float, 512); }
 #undef SWN_CB
   SWN_LAUNCH_CHECK();
@@ -1205,13 +1206,13 @@ extern "C" int swn_combine_bwd(const void* dy_in, const void* y, const float* ds
 extern "C" int swn_heads_fwd(const void* y, const void* h2, int dtype, const float* w_sigma, const float* b_sigma,
                              const float* w_color, const float* b_color, const float* sigma_noise, int n_points,
                              int model_dim, int h2_dim, float* raw, void* stream) {
-  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_heads_fwd: bad dtype");
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_heads_fwd: bad dtype");
   SWN_CHECK(y && h2 && w_sigma && b_sigma && w_color && b_color && raw, "swn_heads_fwd: null pointer");
   SWN_CHECK((model_dim == 256 || model_dim == 512) && (h2_dim == 128 || h2_dim == 256), "swn_heads_fwd: model_dim in {256,512}, h2_dim in {128,256}");
   const int blocks = row_blocks(n_points);
 #define SWN_HF(T, M_, H_) hipLaunchKernelGGL((heads_fwd_kernel<T, M_, H_>), dim3(blocks), dim3(256), 0, as_stream(stream), (const T*)y, \
                                              (const T*)h2, w_sigma, b_sigma, w_color, b_color, sigma_noise, n_points, raw)
-  if (dtype == SWN_BF16) {
+  if (dtype == SWN_HALF) {
     if (model_dim == 256 && h2_dim == 128) SWN_HF(bf16_t, 256, 128); else if (model_dim == 512 && h2_dim == 256) SWN_HF(bf16_t, 512, 256);
     else if (model_dim == 256) SWN_HF(bf16_t, 256, 256); else SWN_HF(bf16_t, 512, 128);
   } else {
@@ -1226,7 +1227,7 @@ extern "C" int swn_heads_fwd(const void* y, const void* h2, int dtype, const flo
 extern "C" int swn_heads_bwd(const void* y, const void* h2, int dtype, const float* w_color, const float* raw,
                              const float* d_raw, int n_points, int model_dim, int h2_dim, void* dh2, float* dsig,
                              float* d_w_sigma, float* d_b_sigma, float* d_w_color, float* d_b_color, void* stream) {
-  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_heads_bwd: bad dtype");
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_heads_bwd: bad dtype");
   SWN_CHECK(y && h2 && w_color && raw && d_raw && dh2 && dsig && d_w_sigma && d_b_sigma && d_w_color && d_b_color,
             "swn_heads_bwd: null pointer");
   SWN_CHECK((model_dim == 256 || model_dim == 512) && (h2_dim == 128 || h2_dim == 256), "swn_heads_bwd: model_dim in {256,512}, h2_dim in {128,256}");
@@ -1234,7 +1235,7 @@ extern "C" int swn_heads_bwd(const void* y, const void* h2, int dtype, const flo
   if (blocks > 1024) blocks = 1024;
 #define SWN_HB(T, M_, H_) hipLaunchKernelGGL((heads_bwd_kernel<T, M_, H_>), dim3(blocks), dim3(256), 0, as_stream(stream), (const T*)y, \
                                              (const T*)h2, w_color, raw, d_raw, n_points, (T*)dh2, dsig, d_w_sigma, d_b_sigma, d_w_color, d_b_color)
-  if (dtype == SWN_BF16) {
+  if (dtype == SWN_HALF) {
     if (model_dim == 256 && h2_dim == 128) SWN_HB(bf16_t, 256, 128); else if (model_dim == 512 && h2_dim == 256) SWN_HB(bf16_t, 512, 256);
     else if (model_dim == 256) SWN_HB(bf16_t, 256, 256); else SWN_HB(bf16_t, 512, 128);
   } else {
@@ -1249,10 +1250,10 @@ extern "C" int swn_heads_bwd(const void* y, const void* h2, int dtype, const flo
 extern "C" int swn_group_colsum(const void* in, int dtype, int n_groups, int rows_per_group, int cols, float* out,
                                 void* stream) {
   SWN_CHECK(in && out, "swn_group_colsum: null pointer");
-  const int esz = dtype == SWN_BF16 ? 2 : 4;
+  const int esz = dtype == SWN_HALF ? 2 : 4;
   SWN_CHECK(cols > 0 && (cols * esz) % 16 == 0 && cols * esz <= 4096 && 256 % (cols * esz / 16) == 0,
             "swn_group_colsum: a row must be 16 * 2^k <= 4096 bytes (cols=%d)", cols);
-  if (dtype == SWN_BF16)
+  if (dtype == SWN_HALF)
     hipLaunchKernelGGL((group_colsum_kernel<bf16_t>), dim3(n_groups), dim3(256), 0, as_stream(stream), (const bf16_t*)in,
                        rows_per_group, cols, out);
   else
@@ -1321,7 +1322,7 @@ extern "C" int swn_adam_step(float* param, const float* grad, float* exp_avg, fl
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   int blocks = cdiv(n, 256);
   if (blocks > 4096) blocks = 4096;
-  if (shadow && dtype == SWN_BF16)
+  if (shadow && dtype == SWN_HALF)
     hipLaunchKernelGGL((adam_kernel<bf16_t>), dim3(blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg,
                        exp_avg_sq, (bf16_t*)shadow, n, lr, beta1, beta2, eps, bc1, bc2s, grad_scale);
   else
@@ -1335,7 +1336,7 @@ extern "C" int swn_cast(const float* in, void* out, int dtype, long n, void* str
   SWN_CHECK(in && out, "swn_cast: null pointer");
   int blocks = cdiv(n, 256);
   if (blocks > 4096) blocks = 4096;
-  if (dtype == SWN_BF16)
+  if (dtype == SWN_HALF)
     hipLaunchKernelGGL((cast_kernel<bf16_t>), dim3(blocks), dim3(256), 0, as_stream(stream), in, (bf16_t*)out, n);
   else
     hipLaunchKernelGGL((cast_kernel<float>), dim3(blocks), dim3(256), 0, as_stream(stream), in, (float*)out, n);
@@ -1346,7 +1347,7 @@ extern "C" int swn_cast(const float* in, void* out, int dtype, long n, void* str
 extern "C" int swn_cast_transpose(const float* in, void* out, int dtype, int batch, int rows, int cols, void* stream) {
   SWN_CHECK(in && out && batch >= 1 && rows >= 1 && cols >= 1, "swn_cast_transpose: bad arguments");
   dim3 grid(cdiv(cols, 32), cdiv(rows, 32), batch), block(32, 8);
-  if (dtype == SWN_BF16)
+  if (dtype == SWN_HALF)
     hipLaunchKernelGGL((cast_transpose_kernel<bf16_t>), grid, block, 0, as_stream(stream), in, (bf16_t*)out, rows, cols);
   else
     hipLaunchKernelGGL((cast_transpose_kernel<float>), grid, block, 0, as_stream(stream), in, (float*)out, rows, cols);

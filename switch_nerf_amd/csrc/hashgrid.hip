@@ -180,15 +180,15 @@ static int make_levels(const swn_hash_cfg* cfg, HashLevels* h) {
 
 extern "C" int swn_hash_encode_fwd(const float* rays, const float* z, int n_rays, int n_samples, const swn_hash_cfg* cfg,
                                    const float* table, int dtype, void* out, int out_stride, void* stream) {
-  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_hash_encode_fwd: bad dtype");
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_hash_encode_fwd: bad dtype");
   SWN_CHECK(rays && z && table && out, "swn_hash_encode_fwd: null pointer");
   HashLevels h;
   if (make_levels(cfg, &h)) return 1;
-  const int epc = dtype == SWN_BF16 ? 8 : 4;
+  const int epc = dtype == SWN_HALF ? 8 : 4;
   SWN_CHECK(out_stride >= 2 * h.n_levels && out_stride % epc == 0 && out_stride <= 128, "swn_hash_encode_fwd: out_stride %d", out_stride);
   if (n_rays <= 0 || n_samples <= 0) return 0;
   const long P = (long)n_rays * n_samples;
-  if (dtype == SWN_BF16)
+  if (dtype == SWN_HALF)
     hipLaunchKernelGGL((hash_encode_fwd_kernel<bf16_t>), dim3(cdiv(P, 128)), dim3(128), 0, as_stream(stream), rays, z, n_rays,
                        n_samples, h, table, (bf16_t*)out, out_stride);
   else
@@ -200,14 +200,14 @@ extern "C" int swn_hash_encode_fwd(const float* rays, const float* z, int n_rays
 
 extern "C" int swn_hash_encode_bwd(const float* rays, const float* z, int n_rays, int n_samples, const swn_hash_cfg* cfg,
                                    const void* d_out, int dtype, int d_stride, float* d_table, void* stream) {
-  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_hash_encode_bwd: bad dtype");
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_hash_encode_bwd: bad dtype");
   SWN_CHECK(rays && z && d_out && d_table, "swn_hash_encode_bwd: null pointer");
   HashLevels h;
   if (make_levels(cfg, &h)) return 1;
   SWN_CHECK(d_stride >= 2 * h.n_levels, "swn_hash_encode_bwd: d_stride %d", d_stride);
   if (n_rays <= 0 || n_samples <= 0) return 0;
   const long P = (long)n_rays * n_samples;
-  if (dtype == SWN_BF16)
+  if (dtype == SWN_HALF)
     hipLaunchKernelGGL((hash_encode_bwd_kernel<bf16_t>), dim3(cdiv(P, 256)), dim3(256), 0, as_stream(stream), rays, z, n_rays,
                        n_samples, h, (const bf16_t*)d_out, d_stride, d_table);
   else

@@ -231,13 +231,13 @@ extern "C" int swn_sample_z(const float* rays, const float* t_steps, const float
 
 extern "C" int swn_mip_encode(const float* rays, const float* radii, const float* z, int n_rays, int n_edges, int l_xyz, int dtype,
                               void* pe, int pe_stride, void* stream) {
-  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_mip_encode: bad dtype");
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_mip_encode: bad dtype");
   SWN_CHECK(rays && radii && z && pe, "swn_mip_encode: null pointer");
   SWN_CHECK(n_rays > 0 && n_edges >= 2 && l_xyz >= 0 && l_xyz <= 12, "swn_mip_encode: bad sizes");
-  const int epc = dtype == SWN_BF16 ? 8 : 4;
+  const int epc = dtype == SWN_HALF ? 8 : 4;
   SWN_CHECK(pe_stride >= 3 + 6 * l_xyz && pe_stride % epc == 0, "swn_mip_encode: pe_stride %d too small / unaligned", pe_stride);
   const long P = (long)n_rays * (n_edges - 1);
-  if (dtype == SWN_BF16)
+  if (dtype == SWN_HALF)
     hipLaunchKernelGGL((mip_encode_kernel<bf16_t, 12>), dim3(cdiv(P, 128)), dim3(128), 0, as_stream(stream), rays, radii, z, n_rays,
                        n_edges, l_xyz, (bf16_t*)pe, pe_stride);
   else

@@ -186,13 +186,13 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
             for (int q = 0; q < 4; ++q)
 #pragma unroll
               for (int qq = 0; qq < 2; ++qq)
-                acc[q][qq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q], fb[qq], acc[q][qq], 0, 0, 0);
+                acc[q][qq] = SWN_MFMA_32x32x16(fa[q], fb[qq], acc[q][qq]);
           }
           if (do_bias) {
-            const bf16x8_t ones = as_frag(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+            const bf16x8_t ones = as_frag(SWN_HALF_ONE_X2, SWN_HALF_ONE_X2, SWN_HALF_ONE_X2, SWN_HALF_ONE_X2);
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq)
-              accb[qq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fb[qq], accb[qq], 0, 0, 0);
+              accb[qq] = SWN_MFMA_32x32x16(ones, fb[qq], accb[qq]);
           }
         }
       } else {
@@ -312,7 +312,7 @@ static int wgrad_launch(const swn_wgrad_item* items, int n_items, int dtype, int
                         size_t dw_set_stride, size_t db_set_stride, int n_groups, int n_wsets, int group_stride,
                         const int32_t* group_rows, int group_rows_clamp, int n_splits, int tag, void* workspace,
                         size_t workspace_bytes, void* stream) {
-  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_BF16, "swn_wgrad: bad dtype %d", dtype);
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_wgrad: bad dtype %d", dtype);
   SWN_CHECK(m_dim >= 32 && m_dim <= 256 && m_dim % 32 == 0 && n_dim >= 32 && n_dim <= 256 && n_dim % 32 == 0,
             "swn_wgrad: m_dim=%d n_dim=%d must be multiples of 32 in [32,256]", m_dim, n_dim);
   SWN_CHECK(n_groups >= 1 && n_wsets >= 1 && group_stride >= 1 && n_splits >= 1, "swn_wgrad: bad geometry");
@@ -325,7 +325,7 @@ static int wgrad_launch(const swn_wgrad_item* items, int n_items, int dtype, int
     ra.db[i] = p.it[i].db;
     SWN_CHECK(p.it[i].a && p.it[i].b && p.it[i].dw, "swn_wgrad: null pointer in item %d", i);
   }
-  const int bkr = dtype == SWN_BF16 ? 32 : 16;
+  const int bkr = dtype == SWN_HALF ? 32 : 16;
   const int max_rows = group_rows ? (group_rows_clamp < group_stride ? group_rows_clamp : group_stride) : group_stride;
   int rps = cdiv(max_rows, n_splits);
   rps = cdiv(rps, bkr) * bkr;
@@ -341,10 +341,10 @@ static int wgrad_launch(const swn_wgrad_item* items, int n_items, int dtype, int
   const size_t need = (size_t)n_items * p.partial_stride * sizeof(float);
   p.partial = (workspace && workspace_bytes >= need) ? (float*)workspace : nullptr;
   if (workspace && !p.partial) return swn::set_error("swn_wgrad: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
-  const int lds = WG_NS * 2 * bkr * 256 * (dtype == SWN_BF16 ? 2 : 4);      // ring of WG_NS (A slab + B slab) slots: 128 KiB
+  const int lds = WG_NS * 2 * bkr * 256 * (dtype == SWN_HALF ? 2 : 4);      // ring of WG_NS (A slab + B slab) slots: 128 KiB
   SWN_CHECK(tag == 0 || tag == 1, "swn_wgrad: tag must be 0 or 1");
   const void* fn;
-  if (dtype == SWN_BF16) fn = tag ? (const void*)wgrad_kernel<bf16_t, 1> : (const void*)wgrad_kernel<bf16_t, 0>;
+  if (dtype == SWN_HALF) fn = tag ? (const void*)wgrad_kernel<bf16_t, 1> : (const void*)wgrad_kernel<bf16_t, 0>;
   else fn = tag ? (const void*)wgrad_kernel<float, 1> : (const void*)wgrad_kernel<float, 0>;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));

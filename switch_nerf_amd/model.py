@@ -29,7 +29,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 
 BUILDING = dict(model_dim=256, num_experts=8, expert_layers=7, skips=(3,), pos_xyz_dim=12, pos_dir_dim=4,
                 appearance_dim=48, appearance_count=10, gate_hidden=256, gate_layers=2, layer2_out=128)
@@ -39,10 +39,44 @@ def _ceil_to(x, m):
     return (x + m - 1) // m * m
 
 
+class LossScaler:
+    """torch.cuda.amp.GradScaler's contract (the reference trains fp16 with it: runner.py:483 `GradScaler(enabled=hparams.amp)`,
+    :679 `scaler.scale(loss).backward()`, scaler.step / update): the loss gradient is multiplied by `scale`, the optimizer step
+    is skipped when a gradient is not finite (scale *= backoff_factor), and after growth_interval clean steps scale *= growth_factor.
+    Same defaults as torch."""
+
+    def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.scale, self.growth_factor, self.backoff_factor, self.growth_interval = float(init_scale), growth_factor, backoff_factor, growth_interval
+        self._good = 0
+        self.skipped = 0
+
+    def update(self, found_inf: bool):
+        if found_inf:
+            self.scale *= self.backoff_factor
+            self._good = 0
+            self.skipped += 1
+        else:
+            self._good += 1
+            if self._good >= self.growth_interval:
+                self.scale *= self.growth_factor
+                self._good = 0
+
+    def state_dict(self):
+        return {"scale": self.scale, "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": self._good}
+
+
 class SwitchNeRF:
     def __init__(self, cfg: dict = BUILDING, dtype=torch.bfloat16, device="cuda", capacity_factor=1.0,
                  batch_prioritized=True, moe_l_aux_wt=5e-4, lr=5e-4, seed=0):
         self.cfg, self.dtype, self.dev = dict(cfg), dtype, torch.device(device)
+        # the 16-bit compute type selects the build of the library: bfloat16 (amp_use_bfloat16) or IEEE half (the reference's default
+        # autocast dtype; BASELINE configs[4] "fp16 MFMA") - see _lib.use_half.  fp16 trains with loss scaling like the reference.
+        if dtype == torch.float16:
+            _lib.use_half("f16")
+        elif dtype == torch.bfloat16:
+            _lib.use_half("bf16")
+        self.loss_scaler = LossScaler() if dtype == torch.float16 else None
         self.cf, self.bpr, self.wt, self.lr = capacity_factor, batch_prioritized, moe_l_aux_wt, lr
         self.base_lr = lr             # undecayed rate ('initial_lr' of the reference's ExponentialLR); self.lr = the current rate
         spec = self._configure(cfg)
@@ -695,15 +729,16 @@ class SwitchNeRF:
         diff = out["rgb"] - rgbs
         photo = (diff * diff).mean()                                      # F.mse_loss, runner.py:1099
         loss = photo + self.wt * gate_loss                                # runner.py:646-651
-        d_rgb = (diff * (2.0 / diff.numel())).contiguous()
+        ls = self.loss_scaler.scale if self.loss_scaler is not None else 1.0      # scaler.scale(loss).backward(), runner.py:679
+        d_rgb = (diff * (2.0 * ls / diff.numel())).contiguous()
         if not fine:
-            d_laux = torch.full((c["n_seg"],), self.wt / c["n_seg"], dtype=torch.float32, device=self.dev)
+            d_laux = torch.full((c["n_seg"],), ls * self.wt / c["n_seg"], dtype=torch.float32, device=self.dev)
             self.backward(c, d_rgb, d_laux)
         else:
             d_raw_m = ops.composite_bwd(out["raw"], out["z"], d_rgb)
             d_raw_f, d_raw_c = ops.unmerge_grad(d_raw_m, out["order"], fine_samples, n_samples)
-            self.backward_net(cf, d_raw_f, torch.full((cf["n_seg"],), 0.5 * self.wt / cf["n_seg"], dtype=torch.float32, device=self.dev))
-            self.backward_net(c, d_raw_c, torch.full((c["n_seg"],), 0.5 * self.wt / c["n_seg"], dtype=torch.float32, device=self.dev))
+            self.backward_net(cf, d_raw_f, torch.full((cf["n_seg"],), 0.5 * ls * self.wt / cf["n_seg"], dtype=torch.float32, device=self.dev))
+            self.backward_net(c, d_raw_c, torch.full((c["n_seg"],), 0.5 * ls * self.wt / c["n_seg"], dtype=torch.float32, device=self.dev))
         res = dict(loss=loss, photo_loss=photo, gate_loss=gate_loss, psnr=-10.0 * torch.log10(photo),
                    depth_variance=out["depth_variance"].mean(), ctx=c, rgb=out["rgb"], depth=out["depth"])
         if fine:
@@ -715,10 +750,22 @@ class SwitchNeRF:
         scale = 1.0
         if grad_allreduce is not None:
             scale = grad_allreduce(self._allreduce_view())
-        if optimizer_step:
+        if optimizer_step and self._unscale_ok():
+            if self.loss_scaler is not None:
+                scale /= self._applied_loss_scale
             self.step_count += 1
             ops.adam_step(self.flat, self.grad, self.m, self.v, None, self.step_count, self.lr, grad_scale=scale)
             self.refresh_compute_copies()
+
+    def _unscale_ok(self) -> bool:
+        """GradScaler.step / update (runner.py:686-690): with loss scaling on, skip the optimizer step when a gradient is not finite
+        (one device-to-host flag per step, like torch's found_inf) and adapt the scale.  Always True without loss scaling."""
+        if self.loss_scaler is None:
+            return True
+        self._applied_loss_scale = self.loss_scaler.scale
+        found_inf = not bool(torch.isfinite(self.grad).all().item())
+        self.loss_scaler.update(found_inf)
+        return not found_inf
 
     def _allreduce_view(self):
         """What the data-parallel all-reduce sums: the whole flat gradient, or - experts sharded over the ranks - its dense
@@ -811,18 +858,21 @@ class SwitchNeRF:
         photo, gate_loss = 0.0, 0.0
         for lv in levels:
             diff = lv["rgb"] - rgbs
-            lv["_d_rgb"] = (diff * (2.0 * share / diff.numel())).contiguous()
+            ls = self.loss_scaler.scale if self.loss_scaler is not None else 1.0
+            lv["_d_rgb"] = (diff * (2.0 * ls * share / diff.numel())).contiguous()
             photo = photo + share * (diff * diff).mean()
             gate_loss = gate_loss + share * lv["l_aux"].mean()
         loss = photo + self.wt * gate_loss
         for lv in levels:
             d_raw = ops.composite_bwd(lv["raw"], lv["z"], lv["_d_rgb"], rgb_padding=lv["rgb_padding"])
-            d_laux = torch.full((lv["n_seg"],), share * self.wt / lv["n_seg"], dtype=torch.float32, device=self.dev)
+            d_laux = torch.full((lv["n_seg"],), ls * share * self.wt / lv["n_seg"], dtype=torch.float32, device=self.dev)
             self.backward_net(lv, d_raw, d_laux)
         scale = 1.0
         if grad_allreduce is not None:
             scale = grad_allreduce(self._allreduce_view())
-        if optimizer_step:
+        if optimizer_step and self._unscale_ok():
+            if self.loss_scaler is not None:
+                scale /= self._applied_loss_scale
             self.step_count += 1
             ops.adam_step(self.flat, self.grad, self.m, self.v, None, self.step_count, self.lr, grad_scale=scale)
             self.refresh_compute_copies()

@@ -10,15 +10,27 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, ChainDesc, WgradItem, call
+from ._lib import BF16, F16, F32, ChainDesc, WgradItem, call
+
+
+def _code(dtype) -> int:
+    """torch dtype -> dtype code of the C ABI.  The 16-bit type must be the one the selected build of the library computes in
+    (_lib.use_half): bfloat16 -> libswn_hip.so, float16 -> libswn_hip_f16.so."""
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        if _lib.half_kind() != "bf16":
+            raise RuntimeError("bfloat16 tensor, but the fp16 build of the library is selected (_lib.use_half('bf16') first)")
+        return BF16
+    if dtype == torch.float16:
+        if _lib.half_kind() != "f16":
+            raise RuntimeError("float16 tensor, but the bf16 build of the library is selected (_lib.use_half('f16') first)")
+        return F16
+    raise TypeError(f"unsupported dtype {dtype}")
 
 
 def _dt(t: torch.Tensor) -> int:
-    if t.dtype == torch.float32:
-        return F32
-    if t.dtype == torch.bfloat16:
-        return BF16
-    raise TypeError(f"unsupported dtype {t.dtype}")
+    return _code(t.dtype)
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -33,7 +45,7 @@ def _stream():
 
 
 def torch_dtype(code: int):
-    return torch.float32 if code == F32 else torch.bfloat16
+    return {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[code]
 
 
 def mfma_probe() -> torch.Tensor:
@@ -270,7 +282,7 @@ def hash_encode_fwd(rays, z, table, hc: dict, dtype, out_stride: int):
     """Multiresolution hash-grid encoding of the points o + d z (include/swn.h swn_hash_encode_fwd) -> [N * S, out_stride]."""
     n, S = z.shape
     out = torch.empty(n * S, out_stride, dtype=dtype, device=rays.device)
-    call("swn_hash_encode_fwd", _p(rays), _p(z), n, S, C.byref(_hash_cfg(hc)), _p(table), BF16 if dtype == torch.bfloat16 else F32,
+    call("swn_hash_encode_fwd", _p(rays), _p(z), n, S, C.byref(_hash_cfg(hc)), _p(table), _code(dtype),
          _p(out), int(out_stride), _stream())
     return out
 
@@ -350,7 +362,7 @@ def bg_sample_pe(rays, center, radius, n_samples, l_xyz, dtype, pe_stride, pertu
     pe = pe_out if pe_out is not None else torch.empty(N * S, pe_stride, dtype=dtype, device=dev)
     t_steps = torch.linspace(0, 1, S, dtype=torch.float32).to(dev) if z_in is None else None
     call("swn_bg_sample_pe", _p(rays), _host3(center), _host3(radius), _p(t_steps), _p(perturb_rand), float(perturb), N, S, int(l_xyz),
-         BF16 if dtype == torch.bfloat16 else F32, _p(z_in), _p(z) if z_in is None else None, _p(dreal), _p(pe), int(pe_stride), _stream())
+         _code(dtype), _p(z_in), _p(z) if z_in is None else None, _p(dreal), _p(pe), int(pe_stride), _stream())
     return z, dreal, pe
 
 
@@ -414,13 +426,13 @@ class Layer:
 
 
 def chain_tile_rows(dtype) -> int:
-    return _lib.load().swn_chain_tile_rows(BF16 if dtype == torch.bfloat16 else F32)
+    return _lib.load().swn_chain_tile_rows(_code(dtype))
 
 
 def chain_mask_words(dtype, n_groups: int, group_stride: int, max_width: int = 256) -> int:
     """uint32 words per layer mask buffer for a chain launch with this geometry (1 bit per row x feature of the kernel's tile;
     max_width = the widest layer of the chain: > 256 selects the 512-feature kernels)."""
-    return int(_lib.load().swn_chain_mask_words(BF16 if dtype == torch.bfloat16 else F32, int(n_groups), int(group_stride), int(max_width)))
+    return int(_lib.load().swn_chain_mask_words(_code(dtype), int(n_groups), int(group_stride), int(max_width)))
 
 
 def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride=None, group_rows=None,

@@ -15,25 +15,41 @@ def header_symbols():
 
 
 def test_library_exports_every_declared_symbol():
+    """Both builds (bf16: libswn_hip.so, fp16: libswn_hip_f16.so) export exactly the declared entry points and say which 16-bit
+    compute type they carry."""
     from switch_nerf_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH):
+    if not (os.path.exists(_lib.LIB_PATH) and os.path.exists(_lib.LIB_PATH_F16)):
         import __graft_entry__
         __graft_entry__.build()
-    lib = ctypes.CDLL(_lib.LIB_PATH)
     syms = header_symbols()
     assert len(syms) >= 20
-    for s in syms:
-        assert hasattr(lib, s), f"{s} declared in include/swn.h but not exported"
     declared = set(syms)
-    bound = set(_lib.SIGNATURES) | {"swn_last_error", "swn_route_workspace_bytes", "swn_chain_mask_words", "swn_gate_bwd_scratch_floats"}
+    bound = set(_lib.SIGNATURES) | {"swn_last_error", "swn_route_workspace_bytes", "swn_chain_mask_words", "swn_gate_bwd_scratch_floats",
+                                    "swn_half_dtype"}
     assert bound == declared, (sorted(bound - declared), sorted(declared - bound))
-    lib.swn_version.restype = ctypes.c_int
-    assert lib.swn_version() >= 1
+    for path, half in ((_lib.LIB_PATH, _lib.BF16), (_lib.LIB_PATH_F16, _lib.F16)):
+        lib = ctypes.CDLL(path)
+        for s in syms:
+            assert hasattr(lib, s), f"{s} declared in include/swn.h but not exported by {os.path.basename(path)}"
+        lib.swn_version.restype = ctypes.c_int
+        lib.swn_half_dtype.restype = ctypes.c_int
+        assert lib.swn_version() >= 2 and lib.swn_half_dtype() == half
+
+
+def test_half_build_selection():
+    from switch_nerf_amd import _lib
+    try:
+        assert _lib.use_half("f16").swn_half_dtype() == _lib.F16 and _lib.half_kind() == "f16"
+        rc = _lib.load().swn_mlp_chain(None, None)
+        assert rc != 0
+    finally:
+        assert _lib.use_half("bf16").swn_half_dtype() == _lib.BF16 and _lib.half_kind() == "bf16"
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from switch_nerf_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_libs", {})
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()

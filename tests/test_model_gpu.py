@@ -210,6 +210,8 @@ def test_render_rays_mirror_hierarchical():
     m.train()
     res, bg = render_rays(m, None, _dev(rays), _dev(img), h, None, None, True, True, False)
     assert bg is False and "rgb_coarse" not in res
+    assert res["rgb_fine"].requires_grad             # training mode: the results carry a grad_fn like the reference's (autograd.py)
+    res = {k: v.detach() for k, v in res.items()}
     np.testing.assert_allclose(res["rgb_fine"].cpu().numpy(), g["rgb"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(res["depth_variance_fine"].cpu().numpy(), g["depth_variance"], rtol=1e-3, atol=1e-6)
     np.testing.assert_allclose(res["gate_loss_fine"].cpu().numpy(), g["gate_loss_fine"], rtol=1e-5)
