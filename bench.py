@@ -21,7 +21,7 @@ timed steps are the same computation (same routing, same kept-token fraction) wh
 Prints ONE JSON line (rank 0).  `roofline` describes the dominant expert kernel against the bf16 MFMA peak (the expert
 grouped GEMM is the MFMA-bound part), timed live with HIP events on the launch stream inside the timed region; `kernels` carries
 the MFMA fraction, the algorithmic HBM rate and the counter-measured HBM bytes (profiles/traffic.json) of all three expert kernels;
-`balanced` repeats the measurement with a near-uniform router (gate_scale 0.02, ~100 % of the tokens kept); `cpu_baseline` is the CPU
+`balanced` repeats the measurement with perfectly balanced routing (point i -> expert i mod E: every group full, 100 % of the tokens kept); `cpu_baseline` is the CPU
 oracle (a port of the reference's CPU path) timed on this box's host cores on a bounded sample (one 131072-point segment).
 """
 import argparse
@@ -108,7 +108,9 @@ def main():
                     help="replay the step's forward + backward launch sequence from a hipGraph (switch_nerf_amd/graph.py).  auto: on for "
                          "N > 1 data parallel (1024 rays per GPU are launch-bound from Python), off for N = 1 where the per-kernel HIP "
                          "events are recorded inside the timed region")
-    ap.add_argument("--no-balanced", action="store_true", help="skip the extra balanced-routing measurement (gate_scale 0.02)")
+    ap.add_argument("--no-balanced", action="store_true", help="skip the extra balanced-routing measurement")
+    ap.add_argument("--routing", choices=["router", "balanced"], default="router",
+                    help="balanced: the MAIN measurement runs with point i -> expert i mod E (used by the counter passes: bytes per kept row)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     a = ap.parse_args()
@@ -213,6 +215,8 @@ def main():
         torch.manual_seed(seed + rank)
         torch.cuda.manual_seed(seed + rank)
 
+    kept_acc = [None]             # mean kept rows per step of the last timed() call with events on
+
     def timed(steps, events):
         model.profile = events
         model.events = {}
@@ -221,8 +225,15 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         st = None
+        kept_acc[0] = None
         for _ in range(steps):
             st = step()
+            if events and not a.dense:       # work follows the kept rows and routing moves while training: average them like the events
+                c_ = st["ctx"]["c"] if a.bg else st["ctx"]
+                k_ = c_["counts"].clamp(max=c_["cap"]).sum()
+                kept_acc[0] = k_ if kept_acc[0] is None else kept_acc[0] + k_
+        if kept_acc[0] is not None:
+            kept_acc[0] = float(kept_acc[0].item()) / steps
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -234,10 +245,13 @@ def main():
         model.profile = False
         return dt, st
 
+    if a.routing == "balanced":
+        route_override[0] = (torch.arange(P, device=dev, dtype=torch.int32) % a.experts).contiguous()
     reset_state(4321)
     if use_graph:
         from switch_nerf_amd.graph import GraphedTrainStep
-        graphed[0] = GraphedTrainStep(model, rgbs, rays, idx, a.samples, a.chunk, perturb=1.0, noise_std=1.0)
+        graphed[0] = GraphedTrainStep(model, rgbs, rays, idx, a.samples, a.chunk, perturb=1.0, noise_std=1.0,
+                                      routing_override=route_override[0])
     for _ in range(a.warmup):
         st = step()
     reset_state(1234)
@@ -297,7 +311,8 @@ def main():
         return detail_
 
     kept = kept_of(st)
-    detail = {} if other else account(model.events, kept)          # (other recipes: headline number only)
+    kept_mean = kept_acc[0] if kept_acc[0] is not None else kept      # per-step mean over the steps the events cover
+    detail = {} if other else account(model.events, kept_mean)          # (other recipes: headline number only)
     roof = None
     if detail:
         # the expert grouped GEMM is priced against the bf16 MFMA peak; the dominant kernel = the slowest of its three
@@ -313,7 +328,7 @@ def main():
     #      router fills some experts to capacity and starves others).  Point i goes to expert i mod E - every (segment, expert) group
     #      is exactly full, nothing is dropped; gate values, ranking, dispatch and every kernel run as usual.
     balanced = None
-    if not other and not a.no_balanced and not a.fine:
+    if not other and not a.no_balanced and not a.fine and a.routing == "router":
         route_override[0] = (torch.arange(P, device=dev, dtype=torch.int32) % E).contiguous()
         reset_state(4321)
         for _ in range(2):
@@ -335,7 +350,8 @@ def main():
                                + ("dense NeRF 8 x 256 (configs[0] network, --no-use_moe)" if a.dense else f"{a.experts}-expert top-1 expertmlp, capacity_factor=1.0, BPR")
                                + f", {gb} rays x {a.samples} samples per step over {world} GPU(s) ({n_rays} rays per GPU)"
                                f", {P // a.chunk} segments of {a.chunk} points per GPU, building.yaml shapes, random-init weights,"
-                               f" gate_scale={a.gate_scale}" + (f", + {a.fine} fine samples (hierarchical)" if a.fine else "")
+                               f" gate_scale={a.gate_scale}" + (", ROUTING OVERRIDDEN: point i -> expert i mod E" if a.routing == "balanced" else "")
+                               + (f", + {a.fine} fine samples (hierarchical)" if a.fine else "")
                                + (", mip recipe (two levels)" if a.mip else "")
                                + (", INFERENCE ONLY (forward without saves; no backward / Adam)" if a.eval else "")
                                + (", hash-grid input encoding (16 levels x 2^19 x 2, table scaled to U(-1,1))" if a.hash else "")
@@ -343,7 +359,7 @@ def main():
                                + (f", + dense background model on {st['ctx']['Nb']} of {n_rays} rays x {a.samples // 2} samples" if a.bg else "")
                                + (f", model_dim {a.model_dim}, {a.experts} experts" if (a.model_dim != 256 or a.experts != 8) else ""),
                    "global_batch_rays": gb, "rays_per_gpu": n_rays, "samples": a.samples, "segment_points": a.chunk,
-                   "parallelism": f"{a.parallelism}{world}", "kept_token_fraction": round(kept / P, 4), "loss": round(loss_main, 6),
+                   "parallelism": f"{a.parallelism}{world}", "kept_token_fraction": round(kept / P, 4), "kept_token_fraction_mean": round(kept_mean / P, 4), "loss": round(loss_main, 6),
                    "timed_region": ("forward + backward replayed from a hipGraph, all-reduce + Adam eager; per-kernel events from 3 extra "
                                     "eager steps after the timed region" if use_graph else
                                     "per-kernel HIP events recorded inside it; expert weight gradients on the main stream (no side-stream "
