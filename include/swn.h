@@ -295,10 +295,14 @@ typedef struct swn_chain_desc {
   const void* y_add;            /* row-major [*, n_last] tensor added to the output rows (skip gradient) or NULL */
   const int32_t* y_add_gather;  /* row -> row of y_add (-1 = nothing to add), or NULL (identity)  */
   int32_t geometry;             /* 0 / 1 = the 64-row tile kernels (chain.hip); 2 = one 256-row workgroup per CU, 3 = two 96-row
-                                   workgroups per CU (chain_big.hip: chains of 256 x 256 layers, bf16 / fp16, no rowbias / x_scale /
-                                   x_save / y_add_gather; swn_chain_big_ok).
-                                   The ReLU masks of the two geometries are laid out differently: run a backward chain (relu = 2)
-                                   on the geometry of the forward chain that recorded its masks.                              */
+                                   workgroups per CU, 4 = the 256-row workgroup with its two row groups half a layer apart
+                                   (one group's epilogue beside the other's K loop; the accumulators start at the bias), 5 = the
+                                   same with the bias added in the epilogue like every other geometry (bit-identical to them)
+                                   (chain_big.hip: chains of 256 x 256 layers, bf16 / fp16, no rowbias / x_scale / x_save /
+                                   y_add_gather; swn_chain_big_ok).
+                                   The ReLU masks of the 64-row, 96-row and 256-row tiles are laid out differently (2, 4 and 5
+                                   share one layout): run a backward chain (relu = 2) on the tile geometry of the forward chain
+                                   that recorded its masks.                                                                   */
   int32_t tag;                  /* profiling only: selects an identical kernel instantiation with its own symbol so that
                                    rocprofv3 reports the roles separately (0 generic, 1 expert fwd, 2 expert bwd,
                                    3 front fwd, 4 tail fwd, 5 tail bwd, 6 front bwd)                 */

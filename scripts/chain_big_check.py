@@ -9,6 +9,7 @@ dev = torch.device('cuda')
 dt = torch.bfloat16
 M, E, L = 256, 8, 7
 mode = sys.argv[1] if len(sys.argv) > 1 else "all"
+GEOMS = tuple(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else (1, 2, 3, 4)      # the first one is the reference
 
 
 def build(ng, cap, counts, seed=0):
@@ -76,7 +77,7 @@ def check():
         Wb = [o.pack_weights(w, dt, False) for w in Wm]
         vm = valid_rows(ng, cap, counts)
         res = {}
-        for geom in (1, 2, 3):
+        for geom in GEOMS:
             y, saves, masks = run_fwd(geom, h0, perm, counts_t, Wf, B, ng, cap)
             dout = (torch.randn(h0.shape[0], M, generator=torch.Generator().manual_seed(seed + 7)).to(dev) * 0.1).to(dt)
             skip_add = torch.randn(ng * cap, M, generator=torch.Generator().manual_seed(seed + 9)).to(dev).to(dt)
@@ -95,7 +96,7 @@ def check():
             return same
         print(f"groups {ng} cap {cap} counts {counts.tolist()[:8]}...")
         allsame = True
-        for gg in (2, 3):
+        for gg in GEOMS[1:]:
             allsame &= cmp(f"g{gg} y", res[1]["y"], res[gg]["y"])
             for l in range(L - 1):
                 allsame &= cmp(f"g{gg} save{l}", res[1]["saves"][l], res[gg]["saves"][l])
@@ -109,8 +110,9 @@ def check():
                     ok = False
         # inference variant (no saves / masks)
         y1, _, _ = run_fwd(1, h0, perm, counts_t, Wf, B, ng, cap, save=False)
-        y2, _, _ = run_fwd(2, h0, perm, counts_t, Wf, B, ng, cap, save=False)
-        allsame &= cmp("y (no saves)", y1, y2)
+        for gg in GEOMS[1:]:
+            y2, _, _ = run_fwd(gg, h0, perm, counts_t, Wf, B, ng, cap, save=False)
+            allsame &= cmp(f"g{gg} y (no saves)", y1, y2)
         print("  bit-exact" if allsame else "  DIFFERENT")
     print("CHECK", "OK" if ok else "FAILED")
     return ok
@@ -149,7 +151,7 @@ def time_all():
             c[1::2] = int(CAP * (2 * frac - 1))
             counts = c.to(dev)
         kept = int(counts.sum().item())
-        for geom in (1, 2, 3):
+        for geom in GEOMS:
             def fwd(save=True, bare=False):
                 layers = [o.Layer(Wf[l], None if bare else B[l], relu=0 if bare else (1 if l < L - 1 else 0), skip=(l == 3 and not bare),
                                   save=saves[l] if (save and l < L - 1) else None, mask=masks[l] if (save and l < L - 1 and not bare) else None)

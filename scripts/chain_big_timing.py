@@ -19,6 +19,7 @@ masks = [torch.zeros(o.chain_mask_words(dt, NG, CAP, M), dtype=torch.int32, devi
 y = torch.empty(ROWS, M, dtype=dt, device=dev)
 counts = torch.full((NG,), CAP, dtype=torch.int32, device=dev)
 dbg = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
+GEOM = int(__import__("os").environ.get("GEOM", "2"))
 for mode in sys.argv[1:] or ["full", "nosave", "bare", "bwd"]:
     save, bare = mode in ("full", "bwd"), mode == "bare"
     if mode == "bwd":
@@ -28,11 +29,19 @@ for mode in sys.argv[1:] or ["full", "nosave", "bare", "bwd"]:
                           save=saves[l] if (save and l < L - 1) else None, mask=masks[l] if (save and l < L - 1) else None) for l in range(L)]
     def f():
         o.mlp_chain(h0, layers, y, n_groups=NG, n_wsets=E, group_stride=CAP, group_rows=counts, group_rows_clamp=CAP, x_gather=perm,
-                    y_add_gather=dbg.view(torch.int32), tag=1, geometry=2)
+                    y_add_gather=dbg.view(torch.int32), tag=1, geometry=GEOM)
     f(); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); f(); b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b)
+    if GEOM == 4:
+        wgs_per_cu = (ROWS // 256) / 256.0
+        for nm, sl in (("wave 0 (row group 0)", slice(0, 2048)), ("wave 4 (row group 1)", slice(2048, 4096))):
+            t = dbg.view(4096, 8)[sl].double().mean(0).tolist()
+            clk = t[7] * wgs_per_cu / (ms * 1e-3) / 1e9
+            print(f"{mode} {nm}: {ms:.3f} ms; implied clock {clk:.2f} GHz; per layer: K phase {t[0] / L:.0f}, wait+barrier after K {t[1] / L:.0f}, "
+                  f"E phase {t[2] / L:.0f} (of it bias/mask/write-out issue {t[4] / L:.0f}), barrier after E {t[3] / L:.0f}; prologue {t[5]:.0f}, tail {t[6]:.0f}, total {t[7]:.0f}")
+        continue
     t = dbg.view(4096, 8).double().mean(0).tolist()
     names = ["K wait", "K barrier", "K loop", "epilogue", "post-K barrier/restage", "prologue", "write-out", "total"]
     wgs_per_cu = (ROWS // 256) / 256.0

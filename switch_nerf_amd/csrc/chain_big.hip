@@ -72,9 +72,9 @@ struct Args {
 #ifdef SWN_BIG_TIMING
 #define TICK() __builtin_amdgcn_s_memtime()
 struct Timers { long long wait = 0, bar = 0, kloop = 0, epi = 0, mid = 0, pro = 0, wout = 0; };
-#define SWN_TM(x) x
+#define SWN_TM(...) __VA_ARGS__
 #else
-#define SWN_TM(x)
+#define SWN_TM(...)
 struct Timers {};
 #endif
 
@@ -290,21 +290,23 @@ __device__ __forceinline__ uint32_t pk_mul16(uint32_t p, uint32_t t) {
   return q;
 }
 
-template <typename E, typename G, int RELU, bool BIAS, bool SKIP>
-__device__ __forceinline__ void epilogue(f32x16_t (&acc)[G::MI][2], const Ctx& cx, u32x4_t& mk) {
+// bias_off: byte offset of the bias slot behind BIAS0 (geometry 4 double-buffers it); hook(mi) runs after the row tile mi is rewritten.
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+template <typename E, typename G, int RELU, bool BIAS, bool SKIP, typename HOOK = NoHook>
+__device__ __forceinline__ void epilogue(f32x16_t (&acc)[G::MI][2], const Ctx& cx, u32x4_t& mk, int bias_off = 0, HOOK hook = HOOK()) {
   char* smem = cx.smem;
   uint32_t e_base = cx.e_base, e2_base = cx.e2_base;      // laundered: keeps the swizzled addresses inside the layer loop (see k_loop)
   asm volatile("" : "+v"(e_base), "+v"(e2_base));
-  f32x4_t bias[2][4];
-  if constexpr (BIAS) {
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4)
-        bias[ni][g4] = *(const f32x4_t*)(smem + G::BIAS0 + (((cx.w & 3) * 64 + 32 * ni + 8 * g4 + 4 * cx.lhi) << 2));
-  }
 #pragma unroll
   for (int mi = 0; mi < G::MI; ++mi) {
+    f32x4_t bias[2][4];        // (re-read per row tile: 32 registers that would otherwise live through the whole epilogue; broadcast reads)
+    if constexpr (BIAS) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          bias[ni][g4] = *(const f32x4_t*)(smem + G::BIAS0 + bias_off + (((cx.w & 3) * 64 + 32 * ni + 8 * g4 + 4 * cx.lhi) << 2));
+    }
     u32x2_t xv[2][4];
     if constexpr (SKIP) {
 #pragma unroll
@@ -356,19 +358,21 @@ __device__ __forceinline__ void epilogue(f32x16_t (&acc)[G::MI][2], const Ctx& c
       }
     }
     SWN_PIN();                              // one row tile at a time: bounded register footprint
+    hook(mi);
   }
 }
 
-template <typename E, typename G>
-__device__ __forceinline__ void epilogue_dispatch(f32x16_t (&acc)[G::MI][2], const Ctx& cx, u32x4_t& mk, int relu, bool bias, bool skip) {
+template <typename E, typename G, typename HOOK = NoHook>
+__device__ __forceinline__ void epilogue_dispatch(f32x16_t (&acc)[G::MI][2], const Ctx& cx, u32x4_t& mk, int relu, bool bias, bool skip,
+                                                  int boff = 0, HOOK hook = HOOK()) {
   if (relu == 1) {
-    if (skip) { if (bias) epilogue<E, G, 1, true, true>(acc, cx, mk); else epilogue<E, G, 1, false, true>(acc, cx, mk); }
-    else { if (bias) epilogue<E, G, 1, true, false>(acc, cx, mk); else epilogue<E, G, 1, false, false>(acc, cx, mk); }
+    if (skip) { if (bias) epilogue<E, G, 1, true, true, HOOK>(acc, cx, mk, boff, hook); else epilogue<E, G, 1, false, true, HOOK>(acc, cx, mk, boff, hook); }
+    else { if (bias) epilogue<E, G, 1, true, false, HOOK>(acc, cx, mk, boff, hook); else epilogue<E, G, 1, false, false, HOOK>(acc, cx, mk, boff, hook); }
   } else if (relu == 2) {
-    if (skip) epilogue<E, G, 2, false, true>(acc, cx, mk); else epilogue<E, G, 2, false, false>(acc, cx, mk);
+    if (skip) epilogue<E, G, 2, false, true, HOOK>(acc, cx, mk, boff, hook); else epilogue<E, G, 2, false, false, HOOK>(acc, cx, mk, boff, hook);
   } else {
-    if (skip) { if (bias) epilogue<E, G, 0, true, true>(acc, cx, mk); else epilogue<E, G, 0, false, true>(acc, cx, mk); }
-    else { if (bias) epilogue<E, G, 0, true, false>(acc, cx, mk); else epilogue<E, G, 0, false, false>(acc, cx, mk); }
+    if (skip) { if (bias) epilogue<E, G, 0, true, true, HOOK>(acc, cx, mk, boff, hook); else epilogue<E, G, 0, false, true, HOOK>(acc, cx, mk, boff, hook); }
+    else { if (bias) epilogue<E, G, 0, true, false, HOOK>(acc, cx, mk, boff, hook); else epilogue<E, G, 0, false, false, HOOK>(acc, cx, mk, boff, hook); }
   }
 }
 
@@ -544,6 +548,477 @@ __global__ __launch_bounds__(G::NT, G::OCC) void chainb_kernel(const Args args) 
 #endif
 }
 
+// =================================================================================================================================
+// Geometry 4: the 256-row workgroup with its two row groups HALF A LAYER APART.
+//
+// In chainb_kernel all 8 waves run the K loop together and then the epilogue together: the matrix pipe idles for the epilogue's 5 k
+// clocks per layer and the K loop pays a workgroup barrier per step.  Here row group 0 (waves 0-3) and row group 1 (waves 4-7, the
+// SAME SIMDs: a workgroup's waves go to the SIMDs cyclically) alternate roles per PHASE:
+//     phase 2 l     : group 0 runs the K loop of layer l          | group 1 runs the epilogue of layer l - 1
+//     phase 2 l + 1 : group 0 runs the epilogue of layer l        | group 1 runs the K loop of layer l
+// so a SIMD always has one wave issuing MFMAs and one doing the VALU / LDS / store work.  One workgroup barrier per phase (two per
+// layer) instead of one per K step:
+//   * weights: wave (g, fg) copies the fragments of ITS two feature tiles itself (`buffer_load ... lds`, 2 x 1 KiB per K step) into
+//     the ring of its SIMD (3 slots x 2 KiB: the same LDS bytes as chainb's ring), three steps ahead, and waits for them with a
+//     counted vmcnt - no other wave reads them.  The two waves of a SIMD use the ring in turn; the last three steps of a K loop
+//     copy the first three steps of the ring's next user (the partner: same layer; or this group: next layer), landed before the
+//     phase barrier.  The weights pass the CU twice per 256 rows (the price of the phase shift: 2x chainb's weight copies);
+//   * an epilogue wave first writes out the PARTNER group's rows (the input tile of the K loop the partner is running = a saved
+//     activation: 16 x 1 KiB pieces per wave, non-temporal, never waited for inside the phase - the following K phase's first counted
+//     vmcnt is where a backlog of the store stream shows), then rewrites its own rows in place; bias and stored masks come straight
+//     from global memory into registers at the start of the phase;
+//   * the residual (skip) layer re-stages the chain input rows of the group into its own (dead) rows; the four waves of the group
+//     meet at an LDS counter (the only place where a group has to synchronise inside a phase).
+// Results and the ReLU mask layout are identical to chainb_kernel's (same K order per accumulator, same epilogue code).
+// =================================================================================================================================
+struct PhaseK {};
+
+#define SWN_WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+template <typename E>
+__device__ __forceinline__ void k_phase(f32x16_t (&acc)[4][2], const Ctx& cx, __amdgpu_buffer_rsrc_t rs_cur, __amdgpu_buffer_rsrc_t rs_nxt) {
+  typedef G256 G;
+  constexpr int MI = 4;
+  char* smem = cx.smem;
+  const int lane16 = cx.lane * 16;
+  const int fg = cx.w & 3;
+  u32x4_t fa[2][MI], fw[2][2];
+  uint32_t a_base = cx.a_base, wf_base = cx.wf_base;
+  asm volatile("" : "+v"(a_base), "+v"(wf_base));
+  auto read_w = [&](int ks, int set, int ni) {
+    fw[set][ni] = *(const u32x4_t*)(smem + wf_base + cx.slot_off[ks % 3] + ni * 1024);
+  };
+  auto read_a = [&](int ks, int set, int mi) {
+    fa[set][mi] = *(const u32x4_t*)(smem + (a_base ^ (uint32_t)(ks << 5)) + mi * (32 * ROWB));
+  };
+  auto copy = [&](int ks, int i) {     // feature tile 2 fg + i of step ks + 3 of the ring's stream -> the slot of step ks (its fragments are in registers)
+    const int nx = ks + 3, t = 2 * fg + i;
+    if (nx < KSTEPS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_cur, SWN_LDS(smem + G::RING0 + cx.slot_off[nx % 3] + t * 1024), 16, lane16, (t * KSTEPS + nx) * 1024, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_nxt, SWN_LDS(smem + G::RING0 + cx.slot_off[nx % 3] + t * 1024), 16, lane16, (t * KSTEPS + nx - KSTEPS) * 1024, 0, 0);
+  };
+  // The six fragment reads of step ks + 1 (w0 w1 a0 a1 a2 a3, in this order) are issued right behind the first MFMA of step ks and
+  // waited for ONE BY ONE (LDS returns in order: lgkmcnt(n) = all but the youngest n have landed) just before the MFMA that needs
+  // them: a lone wave has nobody to hide an lgkmcnt(0) behind.  Nothing else in the loop counts in lgkmcnt (the copies are vmcnt).
+  read_w(0, 0, 0); read_w(0, 0, 1);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) read_a(0, 0, mi);
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    const int cur = ks & 1, nxt = cur ^ 1;
+    const bool more = ks + 1 < KSTEPS;
+    if (ks >= 2) SWN_WAIT_VM(2);            // this wave's copies of step ks + 1 have landed (younger: the two copies of step ks + 2)
+    SWN_WAIT_LGKM(3);                       // w0 w1 a0 of this step
+    SWN_PIN();
+#ifdef SWN_ABL_NOMFMA
+#define SWN_MM(mi, ni) asm volatile("" :: "v"(fw[cur][ni]), "v"(fa[cur][mi]))
+#else
+#define SWN_MM(mi, ni) acc[mi][ni] = E::mfma(fw[cur][ni], fa[cur][mi], acc[mi][ni])
+#endif
+    SWN_MM(0, 0);
+    SWN_PIN();
+    if (more) {
+      read_w(ks + 1, nxt, 0); read_w(ks + 1, nxt, 1);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) read_a(ks + 1, nxt, mi);
+    }
+    SWN_PIN();
+    SWN_MM(0, 1);
+    SWN_PIN();
+    copy(ks, 0);
+    if (more) SWN_WAIT_LGKM(8); else SWN_WAIT_LGKM(2);      // a1
+    SWN_PIN();
+    SWN_MM(1, 0);
+    SWN_PIN();
+    copy(ks, 1);
+    SWN_PIN();
+    SWN_MM(1, 1);
+    SWN_PIN();
+    if (more) SWN_WAIT_LGKM(7); else SWN_WAIT_LGKM(1);      // a2
+    SWN_PIN();
+    SWN_MM(2, 0);
+    SWN_PIN();
+    SWN_MM(2, 1);
+    SWN_PIN();
+    if (more) SWN_WAIT_LGKM(6); else SWN_WAIT_LGKM(0);      // a3
+    SWN_PIN();
+    SWN_MM(3, 0);
+    SWN_PIN();
+    SWN_MM(3, 1);
+#undef SWN_MM
+    SWN_PIN();
+  }
+}
+
+// The epilogue of geometry 4.  Same arithmetic as epilogue() above, value for value - but an epilogue wave of chainp_kernel runs ALONE
+// beside its SIMD's MFMA wave: dependent VALU chains that two lockstep waves hide from each other (chainb) cost it ~8 clocks per
+// instruction.  The 16 packed pairs of a row tile therefore move through the stages together (16 independent instructions per
+// stage, order pinned), the mask accumulates in two registers, and the bias is read once per phase.
+template <typename E, int RELU, bool BIAS, bool SKIP, typename HOOK>
+__device__ __forceinline__ void epilogue_p(f32x16_t (&acc)[4][2], const Ctx& cx, u32x4_t& mk, int bias_off, HOOK hook) {
+  typedef G256 G;
+  char* smem = cx.smem;
+  uint32_t e_base = cx.e_base, e2_base = cx.e2_base;
+  asm volatile("" : "+v"(e_base), "+v"(e2_base));
+  f32x4_t bias[2][4];
+  if constexpr (BIAS) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+        bias[ni][g4] = *(const f32x4_t*)(smem + G::BIAS0 + bias_off + (((cx.w & 3) * 64 + 32 * ni + 8 * g4 + 4 * cx.lhi) << 2));
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    uint32_t m[4] = {0u, 0u, 0u, 0u};
+    const uint32_t mbits = (RELU == 2) ? mk[mi] : 0u;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {        // 8 packed pairs per stage: k = g4 * 2 + i, mask bit ni * 8 + k
+      u32x2_t xv[4];
+      if constexpr (SKIP) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) xv[g4] = *(const u32x2_t*)(smem + (e_base ^ (uint32_t)((4 * ni + g4) << 4)) + mi * (32 * ROWB));
+      }
+      f32x2_t_ v[8];
+      uint32_t pp[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int g4 = k >> 1, i = k & 1;
+        v[k] = f32x2_t_{acc[mi][ni][g4 * 4 + 2 * i], acc[mi][ni][g4 * 4 + 2 * i + 1]};
+        if constexpr (BIAS) v[k] += f32x2_t_{bias[ni][g4][2 * i], bias[ni][g4][2 * i + 1]};
+      }
+      SWN_PIN();
+      if constexpr (SKIP) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += f32x2_t_{E::lo(xv[k >> 1][k & 1]), E::hi(xv[k >> 1][k & 1])};
+        SWN_PIN();
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pp[k] = E::pack2(v[k][0], v[k][1]);
+      SWN_PIN();
+      if constexpr (RELU == 1) {
+        uint32_t q[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pp[k] = pk_relu16(pp[k]);
+        SWN_PIN();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = pk_nonzero16(pp[k]);
+        SWN_PIN();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k & 3] |= q[k] << (ni * 8 + k);
+      } else if constexpr (RELU == 2) {
+        uint32_t t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = mbits & (0x00010001u << (ni * 8 + k));
+        SWN_PIN();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = pk_nonzero16(t[k]);
+        SWN_PIN();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pp[k] = pk_mul16(pp[k], t[k]);
+      }
+      SWN_PIN();                            // (SKIP: the residual values of these chunks are consumed before the chunks are rewritten)
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        auto r0 = __builtin_amdgcn_permlane32_swap(pp[g * 2], pp[(g + 1) * 2], false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(pp[g * 2 + 1], pp[(g + 1) * 2 + 1], false, false);
+        const u32x4_t o = {(uint32_t)r0[0], (uint32_t)r1[0], (uint32_t)r0[1], (uint32_t)r1[1]};
+        *(u32x4_t*)(smem + (e2_base ^ (uint32_t)((4 * ni + g) << 4)) + mi * (32 * ROWB)) = o;
+      }
+      SWN_PIN();
+    }
+    if constexpr (RELU == 1) mk[mi] = (m[0] | m[1]) | (m[2] | m[3]);
+    hook(mi);
+  }
+}
+
+template <typename E, typename HOOK>
+__device__ __forceinline__ void epilogue_p_dispatch(f32x16_t (&acc)[4][2], const Ctx& cx, u32x4_t& mk, int relu, bool bias, bool skip, int boff, HOOK hook) {
+  if (relu == 1) {
+    if (skip) { if (bias) epilogue_p<E, 1, true, true, HOOK>(acc, cx, mk, boff, hook); else epilogue_p<E, 1, false, true, HOOK>(acc, cx, mk, boff, hook); }
+    else { if (bias) epilogue_p<E, 1, true, false, HOOK>(acc, cx, mk, boff, hook); else epilogue_p<E, 1, false, false, HOOK>(acc, cx, mk, boff, hook); }
+  } else if (relu == 2) {
+    if (skip) epilogue_p<E, 2, false, true, HOOK>(acc, cx, mk, boff, hook); else epilogue_p<E, 2, false, false, HOOK>(acc, cx, mk, boff, hook);
+  } else {
+    if (skip) { if (bias) epilogue_p<E, 0, true, true, HOOK>(acc, cx, mk, boff, hook); else epilogue_p<E, 0, false, true, HOOK>(acc, cx, mk, boff, hook); }
+    else { if (bias) epilogue_p<E, 0, true, false, HOOK>(acc, cx, mk, boff, hook); else epilogue_p<E, 0, false, false, HOOK>(acc, cx, mk, boff, hook); }
+  }
+}
+
+// 1 KiB pieces c0, c0 + stride, ... (n of them) of the (gathered) chain input -> the swizzled tile
+__device__ __forceinline__ void stage_pieces(const Ctx& cx, const char* x, int c0, int n, int stride) {
+  const int* idx = (const int*)(cx.smem + G256::IDX0);
+#pragma unroll 4
+  for (int j = 0; j < n; ++j) {
+    const int c = c0 + j * stride;
+    const int r = 2 * c + cx.lhi;
+    const long src = idx[r];
+    const int q = cx.l31 ^ (r & 15);
+    __builtin_amdgcn_global_load_lds(SWN_GLB(x + src * ROWB + q * 16), SWN_LDS(cx.smem + c * 1024), 16, 0, 0);
+  }
+}
+
+// pieces c0 + 4 j (j < 16) of the tile -> rows of a row-major tensor (descriptor clipped to the valid rows); batches of NB
+template <typename E, bool ADD, int NB>
+__device__ __forceinline__ void write_pieces16(const Ctx& cx, int c0, __amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t ra) {
+  const int lane16 = cx.lane * 16;
+#pragma unroll
+  for (int b = 0; b < 16 / NB; ++b) {
+    u32x4_t v[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) v[j] = *(const u32x4_t*)(cx.smem + piece_addr(cx, c0 + 4 * (NB * b + j)));
+    if constexpr (ADD) {
+      u32x4_t a[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) a[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, lane16, (c0 + 4 * (NB * b + j)) * 1024, 0);
+      SWN_WAIT_VM(0);
+      SWN_WAIT_LGKM0();
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[j][q] = E::pack2(E::lo(v[j][q]) + E::lo(a[j][q]), E::hi(v[j][q]) + E::hi(a[j][q]));
+    } else {
+      SWN_WAIT_LGKM0();
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rs, lane16, (c0 + 4 * (NB * b + j)) * 1024, SWN_BIG_STORE_AUX);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) asm volatile("s_nop 3" :: "v"(v[j]));     // (see the write-out hook in chainp_kernel)
+    SWN_PIN();
+  }
+}
+
+template <typename E, int TAG>
+__global__ __launch_bounds__(512, 2) void chainp_kernel(const Args args) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef G256 G;
+  constexpr int BM = G::BM, MI = 4;
+  const swn_chain_desc& d = args.d;
+  Ctx cx;
+  cx.smem = smem;
+  const int tid = threadIdx.x;
+  cx.lane = tid & 63;
+  cx.w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  cx.l31 = cx.lane & 31;
+  cx.lhi = cx.lane >> 5;
+  const int rg = cx.w >> 2, fg = cx.w & 3;
+  const int r15 = cx.lane & 15;
+
+  int g = blockIdx.x % d.n_groups;
+  int tile = blockIdx.x / d.n_groups;
+  if ((d.n_wsets & 7) == 0 && (d.n_groups & 7) == 0) {
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int s_ = q / args.tiles_per_group;
+    tile = q - s_ * args.tiles_per_group;
+    g = x + 8 * s_;
+  }
+  int rows_valid = d.group_stride;
+  if (d.group_rows) rows_valid = d.group_rows[g];
+  if (rows_valid > d.group_rows_clamp) rows_valid = d.group_rows_clamp;
+  const int row0 = tile * BM;
+  if (row0 >= rows_valid) return;
+  const int rows_in_tile = min(BM, rows_valid - row0);
+  const long grow0 = (d.group_begin ? (long)d.group_begin[g] : (long)g * d.group_stride) + row0;
+  const int wset = g % d.n_wsets;
+  const int n_layers = d.n_layers;
+
+  const int lrow = 32 * MI * rg + cx.l31;
+  cx.a_base = (uint32_t)(lrow * ROWB + ((cx.lhi ^ r15) << 4));
+  cx.e_base = (uint32_t)(lrow * ROWB + (r15 << 4) + 8 * cx.lhi) ^ (uint32_t)(fg << 7);
+  cx.e2_base = (uint32_t)(lrow * ROWB + (r15 << 4)) ^ (uint32_t)((fg << 7) | (cx.lhi << 4));
+  cx.wf_base = (uint32_t)(G::RING0 + (2 * fg) * 1024 + cx.lane * 16);
+  const int lane16 = cx.lane * 16;
+
+  auto wrs = [&](int L) -> __amdgpu_buffer_rsrc_t {
+    const char* p = (const char*)d.layers[L].w + (size_t)wset * 8 * (KSTEPS * 1024);
+    return uniform_rsrc(p, 8 * KSTEPS * 1024);
+  };
+  auto out_rs = [&](void* base) -> __amdgpu_buffer_rsrc_t {
+    return uniform_rsrc((char*)base + grow0 * ROWB, rows_in_tile * ROWB);
+  };
+  SWN_TM(const long long t_start = TICK(); long long tk = 0, tkb = 0, te = 0, teb = 0, two = 0, tpro = 0;)
+  int* gcount = (int*)(smem + G::BIAS0 + 3072);       // [2]: arrivals of the waves of a row group at the residual layer's meeting point
+
+  // ---- prologue: ring (steps 0..2 of layer 0), source rows, the rows of group 0 ----
+  {
+    const __amdgpu_buffer_rsrc_t r0 = wrs(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int f = i * 8 + cx.w, s = f >> 3, t = f & 7;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, SWN_LDS(smem + G::RING0 + s * SLOT_B + t * 1024), 16, lane16, (t * KSTEPS + s) * 1024, 0, 0);
+    }
+  }
+  if (tid < BM) {
+    const long gr = grow0 + (tid < rows_in_tile ? tid : 0);
+    long src = d.x_gather ? (long)d.x_gather[gr] : gr;
+    if (src < 0) src = 0;
+    ((int*)(smem + G::IDX0))[tid] = (int)src;
+  }
+  if (tid < 2) gcount[tid] = 0;
+  // bias of layer L lives in LDS slot L mod 3 from the K phase of layer L - 1 (group 0 copies it there) to the epilogues of layer L
+  auto stage_bias = [&](int L) {
+    const float* b = d.layers[L].b;
+    if (b) {
+      const __amdgpu_buffer_rsrc_t rb = uniform_rsrc(b + (size_t)wset * 256, 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, SWN_LDS(smem + G::BIAS0 + (L % 3) * 1024 + fg * 256), 4, cx.lane * 4, fg * 256, 0, 0);
+    }
+  };
+  if (rg == 0) stage_bias(0);
+  // geometry 4 starts the accumulators AT the bias (one packed add per pair less in the epilogue, which is the longer phase); geometry 5
+  // adds it in the epilogue like every other kernel of the library: bit-identical to them (the test of the phase machinery)
+  const bool bias_init = d.geometry == 4;
+  SWN_WAIT_LGKM0();
+  __builtin_amdgcn_s_barrier();
+  stage_pieces(cx, (const char*)d.x, cx.w, 8, 8);                 // rows of group 0: pieces 0..63, all waves
+  SWN_WAIT_VM(0);
+  __builtin_amdgcn_s_barrier();
+  if (rg == 1) {                                                  // phase 0 of group 1: its own rows
+    stage_pieces(cx, (const char*)d.x, 64 + fg, 16, 4);
+    SWN_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+  }
+
+  f32x16_t acc[MI][2];
+  int n_skip = 0;
+  auto load_mask = [&](int L) -> u32x4_t {      // the stored mask of this wave for the epilogue of layer L (backward chains)
+    const swn_chain_layer& l_ = d.layers[L];
+    if (l_.relu == 2) return *(const u32x4_t*)(l_.mask + ((size_t)(blockIdx.x * G::NW + cx.w) * 64 + cx.lane) * 4);
+    return u32x4_t{0u, 0u, 0u, 0u};
+  };
+  u32x4_t mk_next = load_mask(0);
+  SWN_TM(tpro = TICK() - t_start;)
+  for (int L = 0; L < n_layers; ++L) {
+    const swn_chain_layer& ly = d.layers[L];
+    u32x4_t mk = mk_next;
+    // ---- K phase ----
+    {
+      const int q = 2 * L + rg;                                   // this ring's q-th user: global K step 16 q + j -> slot (q + j) mod 3
+      const int s0 = q % 3;
+      cx.slot_off[0] = s0 * SLOT_B;
+      cx.slot_off[1] = ((s0 + 1) % 3) * SLOT_B;
+      cx.slot_off[2] = ((s0 + 2) % 3) * SLOT_B;
+      const __amdgpu_buffer_rsrc_t rs_cur = wrs(L);
+      const __amdgpu_buffer_rsrc_t rs_nxt = (rg == 0 || L + 1 >= n_layers) ? rs_cur : wrs(L + 1);      // the ring's next user
+      // what the coming epilogue needs from global memory, ahead of the weight copies (the K loop's counted waits cover them):
+      // the stored mask of this wave, and (group 0, for both groups) this layer's bias -> the LDS slot of the layer's parity
+      if (rg == 0 && L + 1 < n_layers) stage_bias(L + 1);
+      if (bias_init && ly.b) {
+        f32x4_t bv[2][4];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4)
+            bv[ni][g4] = *(const f32x4_t*)(smem + G::BIAS0 + (L % 3) * 1024 + ((fg * 64 + 32 * ni + 8 * g4 + 4 * cx.lhi) << 2));
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = bv[ni][r >> 2][r & 3];
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+      }
+      SWN_TM(const long long k0 = TICK();)
+      k_phase<E>(acc, cx, rs_cur, rs_nxt);
+      SWN_TM(const long long k1 = TICK();)
+      SWN_WAIT_VM(0);                   // the next user's first three steps have landed
+      __builtin_amdgcn_s_barrier();     // the group is done reading its rows; the partner has rewritten its own and written ours out
+      SWN_TM(const long long k2 = TICK(); tk += k1 - k0; tkb += k2 - k1;)
+    }
+    // ---- E phase ----
+    {
+      SWN_TM(const long long e0 = TICK();)
+      // per-lane addresses of this phase are re-derived from a laundered lane id: kept alive through the K phase they would spill
+      Ctx ce = cx;
+      asm volatile("" : "+v"(ce.lane));
+      ce.l31 = ce.lane & 31;
+      ce.lhi = ce.lane >> 5;
+      const int lane16e = ce.lane * 16;
+      uint32_t* mkp = ly.mask ? ly.mask + ((size_t)(blockIdx.x * G::NW + cx.w) * 64 + ce.lane) * 4 : nullptr;
+      if (L + 1 < n_layers) mk_next = load_mask(L + 1);      // a phase and a half ahead of its use: the next K loop's counted waits cover it
+      const bool bias_epi = ly.b != nullptr && !bias_init;
+      if (ly.skip) {                    // the residual input of this group -> its (dead) rows; the four waves stage 16 pieces each and meet
+        stage_pieces(ce, (const char*)d.x, 64 * rg + fg, 16, 4);
+        SWN_WAIT_VM(0);
+        ++n_skip;
+        if (ce.lane == 0) __hip_atomic_fetch_add(&gcount[rg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&gcount[rg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < 4 * n_skip)
+          __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      // the partner's rows = the input tile of the K loop it is running: group 1's hold the output of layer L - 1, group 0's that of layer L.
+      // Their write-out (16 pieces of 1 KiB per wave) is spread over the epilogue: 4 pieces after every row tile.
+      void* wo = rg == 0 ? (L >= 1 ? d.layers[L - 1].save : nullptr) : (L + 1 < n_layers ? ly.save : nullptr);
+      SWN_TM(two += TICK() - e0;)
+      if (wo) {
+        const __amdgpu_buffer_rsrc_t rs = out_rs(wo);
+        const int c0 = 64 * (1 - rg) + fg;
+        u32x4_t wv[4];
+        auto rd = [&](int b) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) wv[j] = *(const u32x4_t*)(smem + piece_addr(ce, c0 + 4 * (4 * b + j)));
+        };
+        rd(0);
+        auto hook = [&](int mi) {
+          SWN_WAIT_LGKM0();
+#pragma unroll
+          for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(wv[j], rs, lane16e, (c0 + 4 * (4 * mi + j)) * 1024, SWN_BIG_STORE_AUX);
+          // The registers of a 16-byte store must not be rewritten right behind it: with a VALU write two instructions after the
+          // store, single dwords of single lane groups reached memory with the NEW value (seen under store back-pressure; the
+          // documented hazard is one wait state).  Hold the four registers through a few idle issue slots.
+          asm volatile("s_nop 7\n\ts_nop 7" :: "v"(wv[0]), "v"(wv[1]), "v"(wv[2]), "v"(wv[3]));
+          if (mi < 3) rd(mi + 1);
+          SWN_PIN();
+        };
+        epilogue_p_dispatch<E, decltype(hook)>(acc, ce, mk, ly.relu, bias_epi, ly.skip != 0, (L % 3) * 1024, hook);
+      } else {
+        epilogue_p_dispatch<E, NoHook>(acc, ce, mk, ly.relu, bias_epi, ly.skip != 0, (L % 3) * 1024, NoHook());
+      }
+      if (ly.relu == 1 && mkp) *(u32x4_t*)mkp = mk;
+      SWN_WAIT_LGKM0();
+      SWN_TM(const long long e1 = TICK();)
+      __builtin_amdgcn_s_barrier();
+      SWN_TM(const long long e2 = TICK(); te += e1 - e0; teb += e2 - e1;)
+    }
+  }
+  SWN_TM(const long long t_tail = TICK();)
+
+  // ---- the chain output (+ y_add rows): group 0 writes its own rows while group 1 is in its last epilogue, then both write group 1's ----
+  const __amdgpu_buffer_rsrc_t ry = out_rs(d.y);
+  const __amdgpu_buffer_rsrc_t ra = d.y_add ? out_rs((void*)d.y_add) : ry;
+  if (rg == 0) {
+    if (d.y_add) write_pieces16<E, true, 8>(cx, fg, ry, ra); else write_pieces16<E, false, 8>(cx, fg, ry, ra);
+    SWN_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();
+  }
+  {
+    // pieces 64 + w + 8 j, j < 8
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = 64 + cx.w + 8 * j;
+      u32x4_t v = *(const u32x4_t*)(smem + piece_addr(cx, c));
+      if (d.y_add) {
+        const u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(ra, lane16, c * 1024, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = E::pack2(E::lo(v[q]) + E::lo(a[q]), E::hi(v[q]) + E::hi(a[q]));
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(v, ry, lane16, c * 1024, SWN_BIG_STORE_AUX);
+      asm volatile("s_nop 7\n\ts_nop 7" :: "v"(v));      // (see the write-out hook: keep the store's registers untouched for a few slots)
+    }
+  }
+  // (no LDS copy is in flight here - the last K phase waited for its own - and stores need no wait: the workgroup retires at once)
+#ifdef SWN_BIG_TIMING
+  if (d.y_add_gather && (tid == 0 || tid == 256) && blockIdx.x < 2048) {     // wave 0 -> row blockIdx.x, wave 4 -> row 2048 + blockIdx.x
+    long long* dbg = (long long*)d.y_add_gather + (long)(blockIdx.x + (tid ? 2048 : 0)) * 8;
+    const long long t_end = TICK();
+    dbg[0] = tk; dbg[1] = tkb; dbg[2] = te; dbg[3] = teb; dbg[4] = two; dbg[5] = tpro; dbg[6] = t_end - t_tail; dbg[7] = t_end - t_start;
+  }
+#endif
+}
+
 }  // namespace swn_big
 
 namespace swn {
@@ -597,7 +1072,32 @@ static int chain_big_launch_g(const swn_chain_desc& d, void* stream) {
   return 0;
 }
 
+static int chain_phase_launch(const swn_chain_desc& d, void* stream) {
+  using namespace swn_big;
+  typedef G256 G;
+#ifdef SWN_HALF_F16
+  typedef Fp16 HalfT;
+#else
+  typedef Bf16 HalfT;
+#endif
+  Args a;
+  a.d = d;
+  a.tiles_per_group = cdiv(d.group_rows ? (d.group_rows_clamp < d.group_stride ? d.group_rows_clamp : d.group_stride) : d.group_stride, G::BM);
+  if (!d.group_rows) a.d.group_rows_clamp = d.group_stride;
+  const long grid = (long)a.tiles_per_group * d.n_groups;
+  SWN_CHECK(grid > 0 && grid < (1L << 31), "swn_mlp_chain: grid %ld out of range", grid);
+  const void* fn = d.tag == 1 ? (const void*)chainp_kernel<HalfT, 1> : d.tag == 2 ? (const void*)chainp_kernel<HalfT, 2> : (const void*)chainp_kernel<HalfT, 0>;
+  constexpr int LDS_P = G::BIAS0 + 3072 + 64;        // three bias slots + the row groups' meeting counters
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_P);
+  SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  void* kargs[] = {(void*)&a};
+  e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(G::NT), kargs, LDS_P, as_stream(stream));
+  SWN_CHECK(e == hipSuccess, "swn_mlp_chain (geometry 4 / 5) launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
 int chain_big_launch(const swn_chain_desc& d, void* stream) {
+  if (d.geometry >= 4) return chain_phase_launch(d, stream);
   if (d.geometry == 3) return chain_big_launch_g<swn_big::G96>(d, stream);
   return chain_big_launch_g<swn_big::G256>(d, stream);
 }

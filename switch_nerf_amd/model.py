@@ -475,8 +475,9 @@ class SwitchNeRF:
         c["masks"] = [_b(f"mask{l}", (nw,), torch.int32) if sv else None for l in range(L - 1)]
         skips = set(self.cfg["skips"])
         # expert chains (forward here, backward-data in backward_net - the pair shares its ReLU mask layout): the 256-row geometry
-        # (chain_big.hip) for 256-feature experts in a 16-bit compute dtype once a group holds at least one full tile
-        c["geom"] = 2 if (M == 256 and dt != torch.float32 and cap >= 256 and os.environ.get("SWN_CHAIN_BIG", "1") != "0") else 1
+        # with phase-shifted row groups (chain_big.hip, geometry 4) for 256-feature experts in a 16-bit compute dtype once a group
+        # holds at least one full tile.  SWN_CHAIN_GEOM picks another one (1: the 64-row kernels, 2 / 5: see include/swn.h) - tests.
+        c["geom"] = int(os.environ.get("SWN_CHAIN_GEOM", "4")) if (M == 256 and dt != torch.float32 and cap >= 256) else 1
         layers = [o.Layer(self._local_experts(self.wf[f"exp{l}"]), self._local_experts(self.p[f"exp{l}.b"]),
                           relu=1 if l < L - 1 else 0, skip=(l in skips), save=c["saves"][l] if (sv and l < L - 1) else None,
                           mask=c["masks"][l] if (sv and l < L - 1) else None) for l in range(L)]
