@@ -1,0 +1,53 @@
+"""Router kernels against a torch fp64 reference + timing.  python scripts/gate_check.py   (SWN_GATE_VALU=1: the VALU kernels)"""
+import sys, os, torch
+sys.path.insert(0, '.')
+from switch_nerf_amd import ops as o
+dev = torch.device('cuda')
+torch.manual_seed(0)
+G, E = 256, 8
+which = "VALU" if os.environ.get("SWN_GATE_VALU") else "MFMA"
+
+
+def ref(g, ln_w, ln_b, wg):
+    x = g.double()
+    if ln_w is not None:
+        x = torch.nn.functional.layer_norm(x, (G,), ln_w.double(), ln_b.double(), 1e-5)
+    logits = x @ wg.double().t()
+    return torch.softmax(logits, 1)
+
+
+for P, mean_shift, E_ in ((5000, 0.0, 8), (32768, 0.7, 8), (33, 0.0, 8), (4097, 3.0, 5), (131072, 0.2, 8)):
+    g = (torch.randn(P, G, device=dev) * 1.3 + mean_shift).bfloat16()
+    ln_w = 1.0 + 0.2 * torch.randn(G, device=dev)
+    ln_b = 0.1 * torch.randn(G, device=dev)
+    wg = torch.randn(E_, G, device=dev) * 0.3
+    for ln in (True, False):
+        gates, idx, gmax, stats = o.gate_fwd(g, ln_w if ln else None, ln_b if ln else None, wg)
+        torch.cuda.synchronize()
+        pr = ref(g, ln_w if ln else None, ln_b if ln else None, wg)
+        err = (gates.double() - pr).abs().max().item()
+        ridx = pr.argmax(1)
+        mis = (idx.long() != ridx)
+        top2 = torch.topk(pr, 2, dim=1).values
+        gap = (top2[:, 0] - top2[:, 1])[mis]
+        gm_err = (gmax.double() - gates.double().gather(1, idx.long()[:, None])[:, 0]).abs().max().item()
+        st_err = 0.0
+        if ln:
+            mu = g.double().mean(1); var = g.double().var(1, unbiased=False)
+            st_err = max((stats[:, 0].double() - mu).abs().max().item(), ((stats[:, 1].double() - 1 / torch.sqrt(var + 1e-5)) * torch.sqrt(var + 1e-5)).abs().max().item())
+        print(f"{which} P {P:7d} E {E_} shift {mean_shift} ln {int(ln)}: max |prob err| {err:.2e}, idx mismatches {int(mis.sum())} (largest top-2 gap among them "
+              f"{gap.max().item() if mis.any() else 0:.1e}), gmax consistency {gm_err:.1e}, stats err {st_err:.1e}, sums {(gates.sum(1) - 1).abs().max().item():.1e}")
+
+P = 2097152
+g = (torch.randn(P, G, device=dev) * 1.3).bfloat16()
+ln_w = 1.0 + 0.2 * torch.randn(G, device=dev); ln_b = 0.1 * torch.randn(G, device=dev); wg = torch.randn(E, G, device=dev) * 0.3
+for _ in range(2):
+    o.gate_fwd(g, ln_w, ln_b, wg)
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(10):
+    o.gate_fwd(g, ln_w, ln_b, wg)
+b.record(); torch.cuda.synchronize()
+ms = a.elapsed_time(b) / 10
+print(f"{which} gate_fwd 2M tokens: {ms:.3f} ms = {P * G * 2 / ms / 1e9:.2f} TB/s of row reads")

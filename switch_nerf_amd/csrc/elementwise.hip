@@ -308,8 +308,9 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const T* __restrict__ g, 
   }
 }
 
-// backward: dlogits (softmax + l_aux), d(xn) = dlogits @ wg, LayerNorm backward -> dg; d_ln_w/d_ln_b accumulated per
-// lane; dlogits [P, E] written out for the router weight gradient (gate_dwg_kernel).
+// backward: dlogits (softmax + l_aux), d(xn) = dlogits @ wg, LayerNorm backward -> dg; dlogits [P, E] written out for the parameter
+// gradients: d_wg, d_ln_w and d_ln_b all follow from M[e][k] = sum_tok dlogits[tok][e] * xhat[tok][k] and DL[e] = sum_tok dlogits[tok][e]
+// (gate_dwg_kernel + gate_dwg_finalize_kernel), so this kernel keeps no per-column accumulators.
 template <typename T, int G, int EMAX>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ g, const float* __restrict__ ln_w,
                                                        const float* __restrict__ ln_b, const float* __restrict__ wg,
@@ -328,9 +329,9 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ g, 
     const int e = t / G, r = t % G, jj = r / VPL, v = r % VPL;
     swg[(e * 16 + jj) * LS + v] = e < E ? wg[(long)e * G + R::col(jj, v)] : 0.f;
   }
-  float w[VPL], aw[VPL], ab[VPL];
+  float w[VPL];
 #pragma unroll
-  for (int v = 0; v < VPL; ++v) { w[v] = 1.f; aw[v] = 0.f; ab[v] = 0.f; }
+  for (int v = 0; v < VPL; ++v) w[v] = 1.f;
   if (ln_w) R::loadf(ln_w, j, w);
   __syncthreads();
   const long gid = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
@@ -376,8 +377,6 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ g, 
         const float dxh = dxn[v] * w[v];
         s1 += dxh;
         s2 += dxh * xh[v];
-        aw[v] += dxn[v] * xh[v];
-        ab[v] += dxn[v];
       }
       s1 = sum16(s1) * (1.f / G);
       s2 = sum16(s2) * (1.f / G);
@@ -389,25 +388,11 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ g, 
     }
     R::store(dg + tok * G, j, dx);
   }
-  if (ln_w) {  // block-level reduction in LDS (16 row groups share each column), then one global atomic per column
-    __syncthreads();
-    float* red = swg;  // reuse: needs 2 * G floats <= EMAX * 16 * LS
-    for (int t = threadIdx.x; t < 2 * G; t += 256) red[t] = 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int v = 0; v < VPL; ++v) {
-      atomicAdd(red + R::col(j, v), aw[v]);
-      atomicAdd(red + G + R::col(j, v), ab[v]);
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < G; t += 256) {
-      unsafeAtomicAdd(d_ln_w + t, red[t]);
-      unsafeAtomicAdd(d_ln_b + t, red[G + t]);
-    }
-  }
 }
 
-// d_wg[e][c] += sum_tok dlogits[tok][e] * xn[tok][c]   (xn recomputed from g and the LayerNorm statistics)
+// M[e][c] = sum_tok dlogits[tok][e] * xhat[tok][c] (xhat = the normalised row before the LayerNorm's affine part, recomputed from g and
+// the statistics; without LayerNorm xhat = x), DL[e] = sum_tok dlogits[tok][e]; per block, finished by gate_dwg_finalize_kernel:
+//   d_wg[e][c] += ln_w[c] M[e][c] + ln_b[c] DL[e];   d_ln_w[c] += sum_e wg[e][c] M[e][c];   d_ln_b[c] += sum_e wg[e][c] DL[e]
 // block = 256 threads = SG token sub-groups x LPT lanes; a lane owns one 16-byte chunk of the row (8 bf16 / 4 fp32 columns), so a
 // sub-group reads a token's row as one contiguous run; each sub-group walks its tokens with UNR rows in flight and keeps
 // E x VPT accumulators; the sub-groups are summed with LDS atomics and the block issues one global atomic per (expert, column).
@@ -421,14 +406,13 @@ __global__ __launch_bounds__(256) void gate_dwg_kernel(const T* __restrict__ g, 
   constexpr int SG = 256 / LPT;                // token sub-groups per block
   constexpr int UNR = 4;
   static_assert(LPT <= 256 && 256 % LPT == 0, "gate width");
-  __shared__ float red[E * G];
+  __shared__ float red[E * G + E];
   const int lane = threadIdx.x % LPT, sg = threadIdx.x / LPT;
   const int c0 = lane * VPT;
-  float w[VPT], bb[VPT];
+  for (int t = threadIdx.x; t < E * G + E; t += 256) red[t] = 0.f;
+  float acc[E][VPT], dls[E];
 #pragma unroll
-  for (int v = 0; v < VPT; ++v) { w[v] = ln_w ? ln_w[c0 + v] : 1.f; bb[v] = ln_w ? ln_b[c0 + v] : 0.f; }
-  for (int t = threadIdx.x; t < E * G; t += 256) red[t] = 0.f;
-  float acc[E][VPT];
+  for (int e = 0; e < E; ++e) dls[e] = 0.f;
 #pragma unroll
   for (int e = 0; e < E; ++e)
 #pragma unroll
@@ -463,10 +447,14 @@ __global__ __launch_bounds__(256) void gate_dwg_kernel(const T* __restrict__ g, 
       }
 #pragma unroll
       for (int v = 0; v < VPT; ++v) {
-        float xn = ln_w ? (x[v] - mu[u]) * rs[u] * w[v] + bb[v] : x[v];
+        float xn = ln_w ? (x[v] - mu[u]) * rs[u] : x[v];
         xn = live ? xn : 0.f;
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[e][v] += dl[u][e] * xn;
+      }
+      if (lane == 0 && live) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) dls[e] += dl[u][e];
       }
     }
   }
@@ -475,22 +463,43 @@ __global__ __launch_bounds__(256) void gate_dwg_kernel(const T* __restrict__ g, 
   for (int e = 0; e < E; ++e)
 #pragma unroll
     for (int v = 0; v < VPT; ++v) atomicAdd(red + e * G + c0 + v, acc[e][v]);
+  if (lane == 0) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) atomicAdd(red + E * G + e, dls[e]);
+  }
   __syncthreads();
   // the block's partial [E x G] goes to the workspace with plain stores; gate_dwg_reduce_kernel sums the blocks (a thousand blocks
   // x 2048 device-scope atomics onto the same 2048 words took longer than reading the operands)
-  float* part = partial + (size_t)blockIdx.x * (E * G);
-  for (int t = threadIdx.x; t < E * G; t += 256) part[t] = red[t];
+  float* part = partial + (size_t)blockIdx.x * (E * G + E);
+  for (int t = threadIdx.x; t < E * G + E; t += 256) part[t] = red[t];
 }
 
-// d_wg[t] += sum over the blocks of partial[b][t]; grid = (E * G / 256, chunks of blocks)
+// msum[t] += sum over the blocks of partial[b][t], t < eg = E * G + E (msum zeroed by the caller); grid = (eg / 256, chunks of blocks)
 __global__ __launch_bounds__(256) void gate_dwg_reduce_kernel(const float* __restrict__ partial, int n_blocks, int blocks_per_chunk, int eg,
-                                                              float* __restrict__ d_wg) {
+                                                              float* __restrict__ msum) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= eg) return;
   const int b0 = blockIdx.y * blocks_per_chunk, b1 = min(n_blocks, b0 + blocks_per_chunk);
   float s = 0.f;
   for (int b = b0; b < b1; ++b) s += partial[(size_t)b * eg + t];
-  unsafeAtomicAdd(d_wg + t, s);
+  unsafeAtomicAdd(msum + t, s);
+}
+
+// the three parameter gradients from M = msum[0 .. E G) and DL = msum[E G .. E G + E): one block, thread = column
+__global__ void gate_dwg_finalize_kernel(const float* __restrict__ msum, int E, int G, const float* __restrict__ ln_w,
+                                         const float* __restrict__ ln_b, const float* __restrict__ wg, float* __restrict__ d_wg,
+                                         float* __restrict__ d_ln_w, float* __restrict__ d_ln_b) {
+  const int k = threadIdx.x;
+  if (k >= G) return;
+  const float w = ln_w ? ln_w[k] : 1.f, b = ln_w ? ln_b[k] : 0.f;
+  float lw = 0.f, lb = 0.f;
+  for (int e = 0; e < E; ++e) {
+    const float M = msum[e * G + k], DL = msum[E * G + e], wv = wg[(long)e * G + k];
+    d_wg[(long)e * G + k] += w * M + b * DL;
+    lw += wv * M;
+    lb += wv * DL;
+  }
+  if (ln_w) { d_ln_w[k] += lw; d_ln_b[k] += lb; }
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch / combine
@@ -1035,6 +1044,12 @@ extern "C" int swn_gate_fwd(const void* g, int dtype, const float* ln_w, const f
   SWN_CHECK((ln_w == nullptr) == (ln_b == nullptr), "swn_gate_fwd: ln_w / ln_b must both be given or both NULL");
   if (ln_w) SWN_CHECK(stats, "swn_gate_fwd: stats required with LayerNorm");
   const int blocks = row_blocks(n_tokens);
+#ifndef SWN_HALF_F16
+  // bf16 rows of 256, up to 8 experts: the contraction on the matrix pipe (gate_mfma.hip; SWN_GATE_VALU=1 keeps the VALU kernel: A/B runs)
+  static const bool valu_only = getenv("SWN_GATE_VALU") != nullptr;
+  if (dtype == SWN_HALF && gate_dim == 256 && n_experts <= 8 && !valu_only)
+    return swn::gate_fwd_mfma_launch(g, ln_w, ln_b, wg, n_tokens, n_experts, gates, idx, gmax, stats, stream);
+#endif
   if (dtype == SWN_HALF) {
     const bf16_t* gp = (const bf16_t*)g;
     GATE_DISPATCH(bf16_t, gate_fwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, n_tokens, n_experts,
@@ -1068,8 +1083,9 @@ static int gate_dwg_tokens_per_block(int n_tokens) {
   return ((tpb < 256 ? 256 : (tpb > 4096 ? 4096 : tpb)) + 31) / 32 * 32;
 }
 
-extern "C" size_t swn_gate_bwd_scratch_floats(int n_tokens, int gate_dim, int n_experts) {
-  return (size_t)n_tokens * n_experts + (size_t)cdiv(n_tokens, gate_dwg_tokens_per_block(n_tokens)) * n_experts * gate_dim;
+extern "C" size_t swn_gate_bwd_scratch_floats(int n_tokens, int gate_dim, int n_experts) {   // dlogits | per-block partials | their sum
+  const size_t ps = (size_t)n_experts * gate_dim + n_experts;
+  return (size_t)n_tokens * n_experts + ((size_t)cdiv(n_tokens, gate_dwg_tokens_per_block(n_tokens)) + 1) * ps;
 }
 
 extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg,
@@ -1086,7 +1102,9 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
   // the batch - ~1024 blocks (4 per CU) whatever the batch size (4096 tokens per block took 0.5 ms for 2M and for 262144 tokens alike)
   const int tpb = gate_dwg_tokens_per_block(n_tokens);
   const int dwg_blocks = cdiv(n_tokens, tpb);
-  float* dwg_partial = dlogits + (size_t)n_tokens * n_experts;          // second part of the scratch: [dwg_blocks][E * G]
+  float* dwg_partial = dlogits + (size_t)n_tokens * n_experts;          // second part of the scratch: [dwg_blocks][E * G + E]
+  const int ps = n_experts * gate_dim + n_experts;
+  float* msum = dwg_partial + (size_t)dwg_blocks * ps;                  // third part: [E * G + E]
   if (dtype == SWN_HALF) {
     const bf16_t* gp = (const bf16_t*)g;
     bf16_t* dgp = (bf16_t*)dg;
@@ -1103,9 +1121,13 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
     DWG_DISPATCH(float, gp);
   }
   {
-    const int eg = n_experts * gate_dim, chunks = dwg_blocks < 16 ? dwg_blocks : 16, bpc = cdiv(dwg_blocks, chunks);
-    hipLaunchKernelGGL(gate_dwg_reduce_kernel, dim3(cdiv(eg, 256), cdiv(dwg_blocks, bpc)), dim3(256), 0, as_stream(stream), dwg_partial,
-                       dwg_blocks, bpc, eg, d_wg);
+    const int chunks = dwg_blocks < 16 ? dwg_blocks : 16, bpc = cdiv(dwg_blocks, chunks);
+    hipError_t me = hipMemsetAsync(msum, 0, (size_t)ps * sizeof(float), as_stream(stream));
+    SWN_CHECK(me == hipSuccess, "swn_gate_bwd: memset: %s", hipGetErrorString(me));
+    hipLaunchKernelGGL(gate_dwg_reduce_kernel, dim3(cdiv(ps, 256), cdiv(dwg_blocks, bpc)), dim3(256), 0, as_stream(stream), dwg_partial,
+                       dwg_blocks, bpc, ps, msum);
+    hipLaunchKernelGGL(gate_dwg_finalize_kernel, dim3(1), dim3(gate_dim), 0, as_stream(stream), msum, n_experts, gate_dim, ln_w, ln_b, wg,
+                       d_wg, d_ln_w, d_ln_b);
   }
   SWN_LAUNCH_CHECK();
   return 0;
