@@ -51,3 +51,48 @@ for _ in range(10):
 b.record(); torch.cuda.synchronize()
 ms = a.elapsed_time(b) / 10
 print(f"{which} gate_fwd 2M tokens: {ms:.3f} ms = {P * G * 2 / ms / 1e9:.2f} TB/s of row reads")
+
+# ---------------------------------------------------------------- backward: against torch autograd in fp64
+print("backward")
+for P, seg, E_, ln in ((8192, 4096, 8, True), (8192, 8192, 8, False), (4099 * 2, 4099, 4, True), (65536, 16384, 8, True)):
+    g = (torch.randn(P, G, device=dev) * 1.3 + 0.3).bfloat16()
+    ln_w = (1.0 + 0.2 * torch.randn(G, device=dev)) if ln else None
+    ln_b = (0.1 * torch.randn(G, device=dev)) if ln else None
+    wg = torch.randn(E_, G, device=dev) * 0.3
+    gates, idx, gmax, stats = o.gate_fwd(g, ln_w, ln_b, wg)
+    n_seg = P // seg
+    counts = torch.randint(0, seg, (n_seg, E_), device=dev, dtype=torch.int32)
+    coef = torch.rand(n_seg, device=dev) * 1e-4
+    dgmax = torch.randn(P, device=dev)
+    d_wg = torch.zeros(E_, G, device=dev); d_lw = torch.zeros(G, device=dev); d_lb = torch.zeros(G, device=dev)
+    dg = o.gate_bwd(g, ln_w, ln_b, wg, gates, idx, dgmax, stats, counts, coef, seg, d_wg, d_lw if ln else None, d_lb if ln else None)
+    torch.cuda.synchronize()
+    x = g.double().requires_grad_(True)
+    W = wg.double().requires_grad_(True)
+    lw = ln_w.double().requires_grad_(True) if ln else None
+    lb = ln_b.double().requires_grad_(True) if ln else None
+    xn = torch.nn.functional.layer_norm(x, (G,), lw, lb, 1e-5) if ln else x
+    pr = torch.softmax(xn @ W.t(), 1)
+    dp = coef.double().repeat_interleave(seg)[:, None] * counts.double().repeat_interleave(seg, 0)
+    dp = dp + torch.nn.functional.one_hot(idx.long(), E_).double() * dgmax.double()[:, None]
+    (pr * dp).sum().backward()
+    def rel(a, b):
+        return ((a.double() - b).abs().max() / b.abs().max()).item()
+    line = f"{which} P {P} seg {seg} E {E_} ln {int(ln)}: dg rel err {rel(dg, x.grad):.2e}, d_wg {rel(d_wg, W.grad):.2e}"
+    if ln:
+        line += f", d_ln_w {rel(d_lw, lw.grad):.2e}, d_ln_b {rel(d_lb, lb.grad):.2e}"
+    print(line)
+
+P, seg = 2097152, 131072
+g = (torch.randn(P, G, device=dev) * 1.3).bfloat16()
+gates, idx, gmax, stats = o.gate_fwd(g, ln_w, ln_b, wg) if False else o.gate_fwd(g, 1.0 + 0.2 * torch.randn(G, device=dev), 0.1 * torch.randn(G, device=dev), torch.randn(E, G, device=dev) * 0.3)
+ln_w = 1.0 + 0.2 * torch.randn(G, device=dev); ln_b = 0.1 * torch.randn(G, device=dev); wg = torch.randn(E, G, device=dev) * 0.3
+counts = torch.randint(0, seg, (P // seg, E), device=dev, dtype=torch.int32); coef = torch.rand(P // seg, device=dev) * 1e-4; dgmax = torch.randn(P, device=dev)
+d_wg = torch.zeros(E, G, device=dev); d_lw = torch.zeros(G, device=dev); d_lb = torch.zeros(G, device=dev)
+f = lambda: o.gate_bwd(g, ln_w, ln_b, wg, gates, idx, dgmax, stats, counts, coef, seg, d_wg, d_lw, d_lb)
+f(); f(); torch.cuda.synchronize()
+a.record()
+for _ in range(10):
+    f()
+b.record(); torch.cuda.synchronize()
+print(f"{which} gate_bwd (data path + parameter gradients) 2M tokens: {a.elapsed_time(b) / 10:.3f} ms")

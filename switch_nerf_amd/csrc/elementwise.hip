@@ -1085,7 +1085,11 @@ static int gate_dwg_tokens_per_block(int n_tokens) {
 
 extern "C" size_t swn_gate_bwd_scratch_floats(int n_tokens, int gate_dim, int n_experts) {   // dlogits | per-block partials | their sum
   const size_t ps = (size_t)n_experts * gate_dim + n_experts;
-  return (size_t)n_tokens * n_experts + ((size_t)cdiv(n_tokens, gate_dwg_tokens_per_block(n_tokens)) + 1) * ps;
+  size_t blocks = (size_t)cdiv(n_tokens, gate_dwg_tokens_per_block(n_tokens));
+#ifndef SWN_HALF_F16
+  if ((size_t)swn::gate_bwd_mfma_blocks(n_tokens) > blocks) blocks = (size_t)swn::gate_bwd_mfma_blocks(n_tokens);
+#endif
+  return (size_t)n_tokens * n_experts + (blocks + 1) * ps;
 }
 
 extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg,
@@ -1101,17 +1105,33 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
   // router weight gradient: a block walks its tokens serially (32 per iteration), so its run time is set by tokens per block, not by
   // the batch - ~1024 blocks (4 per CU) whatever the batch size (4096 tokens per block took 0.5 ms for 2M and for 262144 tokens alike)
   const int tpb = gate_dwg_tokens_per_block(n_tokens);
-  const int dwg_blocks = cdiv(n_tokens, tpb);
+  int dwg_blocks = cdiv(n_tokens, tpb);
   float* dwg_partial = dlogits + (size_t)n_tokens * n_experts;          // second part of the scratch: [dwg_blocks][E * G + E]
   const int ps = n_experts * gate_dim + n_experts;
   float* msum = dwg_partial + (size_t)dwg_blocks * ps;                  // third part: [E * G + E]
+  bool mfma_path = false;
+#ifndef SWN_HALF_F16
+  static const bool valu_only = getenv("SWN_GATE_VALU") != nullptr;
+  mfma_path = dtype == SWN_HALF && gate_dim == 256 && n_experts <= 8 && !valu_only;
+#endif
   if (dtype == SWN_HALF) {
     const bf16_t* gp = (const bf16_t*)g;
     bf16_t* dgp = (bf16_t*)dg;
+#ifndef SWN_HALF_F16
+    if (mfma_path) {       // data path AND the per-block sums of the parameter gradients on the matrix pipe (gate_mfma.hip)
+      dwg_blocks = swn::gate_bwd_mfma_blocks(n_tokens);
+      msum = dwg_partial + (size_t)dwg_blocks * ps;
+      const int rc = swn::gate_bwd_mfma_launch(g, ln_w, wg, gates, idx, d_gmax, stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dg,
+                                               dlogits, dwg_partial, stream);
+      if (rc) return rc;
+    } else
+#endif
     GATE_DISPATCH(bf16_t, gate_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, gates, idx, d_gmax,
                   stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dgp, dlogits, d_ln_w, d_ln_b);
-    SWN_CHECK(n_experts == 4 || n_experts == 8 || n_experts == 16, "swn_gate_bwd: experts must be 4, 8 or 16");
-    DWG_DISPATCH(bf16_t, gp);
+    if (!mfma_path) {
+      SWN_CHECK(n_experts == 4 || n_experts == 8 || n_experts == 16, "swn_gate_bwd: experts must be 4, 8 or 16");
+      DWG_DISPATCH(bf16_t, gp);
+    }
   } else {
     const float* gp = (const float*)g;
     float* dgp = (float*)dg;

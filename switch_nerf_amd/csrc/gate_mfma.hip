@@ -194,5 +194,275 @@ int gate_fwd_mfma_launch(const void* g, const float* ln_w, const float* ln_b, co
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Router backward, data path: dlogits (softmax + l_aux, as gate_bwd_kernel) -> d(xhat w) = dlogits @ W' -> LayerNorm backward -> dg.
+// Same tiling as the forward kernel.  The contraction over the 8 experts is ONE K step of a 32x32x16 MFMA per 32 output columns: the
+// K slots 0-7 carry the bf16 head of dlogits, 8-15 its bf16 remainder, against the bf16 head of W' (and a second MFMA against the
+// remainder of W'): relative error 2^-17, far below the bf16 rounding of dg.  The row sums of the LayerNorm backward need every
+// column of the row before any column can be finished: two passes over the 8 column tiles (the MFMAs are recomputed - 32 per tile -
+// instead of holding 128 values per lane); the result replaces x in the LDS tile and leaves it in coalesced 1 KiB pieces.
+// The parameter gradients are not formed here (gate_dwg_kernel / gate_dwg_finalize_kernel from the dlogits written out).
+template <bool LN>
+__global__ __launch_bounds__(256, 2) void gate_bwd_mfma_kernel(const bf16_t* __restrict__ g, const float* __restrict__ ln_w,
+                                                               const float* __restrict__ wg, const float* __restrict__ gates,
+                                                               const int32_t* __restrict__ idx, const float* __restrict__ d_gmax,
+                                                               const float* __restrict__ stats, const int32_t* __restrict__ counts,
+                                                               const float* __restrict__ laux_coef, int seg_tokens, int P, int E,
+                                                               bf16_t* __restrict__ dg, float* __restrict__ dlogits, int n_tiles,
+                                                               float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5, r15 = lane & 15;
+
+  // ---- prologue: W' = ln_w (.) wg split into bf16 head / remainder, column-major: T[column][8 experts] (16 bytes per column) ----
+  char* wtab = smem + GM_CONST0 + 256 + 4096;        // behind the tiles and the dlr^T staging buffers: 2 x 4 KiB
+  {
+    const int k = tid;
+    const float lw = LN ? ln_w[k] : 1.f;
+    uint32_t hi[4] = {0u, 0u, 0u, 0u}, mid[4] = {0u, 0u, 0u, 0u};
+    for (int e = 0; e < E; ++e) {
+      const float wp = wg[(long)e * 256 + k] * lw;
+      const bf16_t h = f32_to_bf16(wp);
+      const bf16_t m = f32_to_bf16(wp - bf16_to_f32(h));
+      hi[e >> 1] |= (uint32_t)h << (16 * (e & 1));
+      mid[e >> 1] |= (uint32_t)m << (16 * (e & 1));
+    }
+    *(gm_u32x4_t*)(wtab + k * 16) = gm_u32x4_t{hi[0], hi[1], hi[2], hi[3]};
+    *(gm_u32x4_t*)(wtab + 4096 + k * 16) = gm_u32x4_t{mid[0], mid[1], mid[2], mid[3]};
+  }
+  __syncthreads();
+  // A fragments of column tile nt: row = column 32 nt + l31 of W', K slots = the 8 experts (both half-waves alike) - read from the table
+  // per use (64 registers otherwise)
+  const char* wrow = wtab + l31 * 16;
+
+  char* tile = smem + w * GM_TILE_B;
+  // this lane's 8-byte element group (row l31, columns 32 nt + 8 g4 + 4 lhi .. + 3): chunk 4 nt + g4, swizzled with the row
+  const uint32_t e_base = (uint32_t)(w * GM_TILE_B + l31 * 512 + (r15 << 4) + 8 * lhi);
+  // ---- the parameter-gradient side (see gate_dwg_kernel): M[e][k] = sum_tok dlogits[tok][e] xhat[tok][k] = sum_tok dlr[tok][e] x[tok][k]
+  //      - C[e], dlr = dlogits * rstd, C[e] = sum_tok dlr[tok][e] mean[tok]: a GEMM over the TOKENS with the exact bf16 rows as one operand.
+  //      v_mfma_f32_16x16x32_bf16 per 16 columns: A = dlr^T (rows: 8 experts x {bf16 head, remainder}; K = the tile's 32 tokens, staged
+  //      through a 1 KiB LDS buffer), B = x^T read straight from the row-major tile with the transposing LDS read (ds_read_b64_tr_b16:
+  //      the 16 lanes of a group address a [4 tokens][16 columns] block, 8 bytes each, and receive one column's 4 tokens).
+  typedef __attribute__((ext_vector_type(4))) float f32x4_t_;
+  f32x4_t_ macc[16];
+#pragma unroll
+  for (int nt = 0; nt < 16; ++nt) macc[nt] = f32x4_t_{0.f, 0.f, 0.f, 0.f};
+  float cacc[4] = {0.f, 0.f, 0.f, 0.f}, dlacc[4] = {0.f, 0.f, 0.f, 0.f};
+  char* dstage = smem + GM_CONST0 + 256 + w * 1024;            // [16 rows][32 tokens] bf16
+  const int kg = lane >> 4, n16 = lane & 15;
+  // transposing read of (tokens 8 kg + 4 h + (n16 >> 2), columns 16 nt + 4 (n16 & 3) .. + 3): row byte address + swizzled chunk
+  uint32_t tr_row[2], tr_sw[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = 8 * kg + 4 * h + (n16 >> 2);
+    tr_row[h] = (uint32_t)(w * GM_TILE_B + r * 512 + 8 * (n16 & 1));
+    tr_sw[h] = (uint32_t)(r & 15);
+  }
+  for (int t = blockIdx.x * 4 + w; t < n_tiles; t += gridDim.x * 4) {
+    const long tok0 = (long)t * 32;
+#pragma unroll 4
+    for (int c = 0; c < 16; ++c) {
+      const int r = 2 * c + lhi;
+      long tk = tok0 + r;
+      tk = tk < P ? tk : (long)P - 1;
+      const int q = l31 ^ (r & 15);
+      __builtin_amdgcn_global_load_lds(GM_GLB((const char*)g + tk * 512 + q * 16), GM_LDS(tile + c * 1024), 16, 0, 0);
+    }
+    // ---- per token (lane: token l31, experts 4 lhi + j): dlogits ----
+    long tok = tok0 + l31;
+    const bool live = tok < P;
+    tok = live ? tok : (long)P - 1;
+    const int seg = (int)(tok / seg_tokens);
+    const int my = idx[tok];
+    const float coef = laux_coef ? laux_coef[seg] : 0.f;
+    const float dgm = d_gmax ? d_gmax[tok] : 0.f;
+    float mean = 0.f, rstd = 1.f;
+    if (LN) { const float2 st = *(const float2*)(stats + tok * 2); mean = st.x; rstd = st.y; }
+    float pr[4], dp[4], dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = 4 * lhi + j;
+      pr[j] = e < E ? gates[tok * E + e] : 0.f;
+      dp[j] = e < E ? coef * (float)counts[seg * E + e] + ((e == my) ? dgm : 0.f) : 0.f;
+      dot += pr[j] * dp[j];
+    }
+    {
+      const float d_lo = __shfl(dot, l31), d_hi = __shfl(dot, l31 + 32);       // experts 0-3 first, like gate_bwd_kernel's loop
+      dot = d_lo + d_hi;
+    }
+    float dl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      dl[j] = pr[j] * (dp[j] - dot);     // softmax backward
+      if (live && 4 * lhi + j < E) dlogits[tok * E + 4 * lhi + j] = dl[j];
+    }
+    // the B fragment: all 8 dlogits of the token; the lower half-wave carries their bf16 heads, the upper one the remainders
+    float da[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float o = __shfl_xor(dl[j], 32);
+      da[j] = lhi ? o : dl[j];
+      da[4 + j] = lhi ? dl[j] : o;
+    }
+    gm_u32x4_t bfr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t v = 0u;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float x = da[2 * i + h];
+        const bf16_t hd = f32_to_bf16(x);
+        const bf16_t val = lhi ? f32_to_bf16(x - bf16_to_f32(hd)) : hd;
+        v |= (uint32_t)val << (16 * h);
+      }
+      bfr[i] = v;
+    }
+    if (partial) {          // dlr^T for the token GEMM: rows e (head) / 8 + e (remainder), column = this lane's token
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = live ? da[e] * rstd : 0.f;
+        const bf16_t hd = f32_to_bf16(x);
+        const bf16_t val = lhi ? f32_to_bf16(x - bf16_to_f32(hd)) : hd;
+        *(bf16_t*)(dstage + (8 * lhi + e) * 64 + l31 * 2) = val;
+      }
+      if (live) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { cacc[j] += dl[j] * rstd * mean; dlacc[j] += dl[j]; }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tile (and every load above) has landed
+    if (partial) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const gm_u32x4_t afr = *(const gm_u32x4_t*)(dstage + n16 * 64 + kg * 16);      // row n16, tokens 8 kg .. + 7
+#pragma unroll
+      for (int nt = 0; nt < 16; ++nt) {
+        // columns 16 nt + 4 (n16 & 3) ..: chunk 2 nt + ((n16 & 3) >> 1)
+        uint2 b0, b1;
+        const uint32_t ch = (uint32_t)(2 * nt + ((n16 & 3) >> 1));
+        const uint32_t a0 = tr_row[0] + ((ch ^ tr_sw[0]) << 4), a1 = tr_row[1] + ((ch ^ tr_sw[1]) << 4);
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b0) : "v"(a0) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b1) : "v"(a1) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const gm_u32x4_t bx = {b0.x, b0.y, b1.x, b1.y};
+        macc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gm_bf16x8_t, afr), __builtin_bit_cast(gm_bf16x8_t, bx), macc[nt], 0, 0, 0);
+      }
+    }
+
+    auto dxh_tile = [&](int nt) -> gm_f32x16_t {
+      gm_f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const gm_u32x4_t wh = *(const gm_u32x4_t*)(wrow + nt * 512), wm = *(const gm_u32x4_t*)(wrow + 4096 + nt * 512);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gm_bf16x8_t, wh), __builtin_bit_cast(gm_bf16x8_t, bfr), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gm_bf16x8_t, wm), __builtin_bit_cast(gm_bf16x8_t, bfr), acc, 0, 0, 0);
+      return acc;
+    };
+    const float mr = mean * rstd;
+    float s1 = 0.f, s2 = 0.f;
+    if (LN) {
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        const gm_f32x16_t acc = dxh_tile(nt);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const uint2 xv = *(const uint2*)(smem + (e_base ^ (uint32_t)((4 * nt + g4) << 4)));
+          const float x0 = __uint_as_float(xv.x << 16), x1 = __uint_as_float(xv.x & 0xFFFF0000u);
+          const float x2 = __uint_as_float(xv.y << 16), x3 = __uint_as_float(xv.y & 0xFFFF0000u);
+          const float d0 = acc[4 * g4], d1 = acc[4 * g4 + 1], d2 = acc[4 * g4 + 2], d3 = acc[4 * g4 + 3];
+          s1 += (d0 + d1) + (d2 + d3);
+          s2 += d0 * (x0 * rstd - mr) + d1 * (x1 * rstd - mr) + d2 * (x2 * rstd - mr) + d3 * (x3 * rstd - mr);
+        }
+      }
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      s1 *= (1.f / 256.f);
+      s2 *= (1.f / 256.f);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      const gm_f32x16_t acc = dxh_tile(nt);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const uint32_t a = e_base ^ (uint32_t)((4 * nt + g4) << 4);
+        float o[4];
+        if (LN) {
+          const uint2 xv = *(const uint2*)(smem + a);
+          const float xh0 = __uint_as_float(xv.x << 16) * rstd - mr, xh1 = __uint_as_float(xv.x & 0xFFFF0000u) * rstd - mr;
+          const float xh2 = __uint_as_float(xv.y << 16) * rstd - mr, xh3 = __uint_as_float(xv.y & 0xFFFF0000u) * rstd - mr;
+          o[0] = rstd * (acc[4 * g4] - s1 - xh0 * s2);
+          o[1] = rstd * (acc[4 * g4 + 1] - s1 - xh1 * s2);
+          o[2] = rstd * (acc[4 * g4 + 2] - s1 - xh2 * s2);
+          o[3] = rstd * (acc[4 * g4 + 3] - s1 - xh3 * s2);
+        } else {
+          o[0] = acc[4 * g4]; o[1] = acc[4 * g4 + 1]; o[2] = acc[4 * g4 + 2]; o[3] = acc[4 * g4 + 3];
+        }
+        *(uint2*)(smem + a) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+      }
+    }
+    // ---- dg rows out of the tile: 1 KiB pieces ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 4
+    for (int c = 0; c < 16; ++c) {
+      const int r = 2 * c + lhi;
+      const long tk = tok0 + r;
+      const int q = l31 ^ (r & 15);
+      const gm_u32x4_t v = *(const gm_u32x4_t*)(tile + c * 1024 + lane * 16);
+      if (tk < P) *(gm_u32x4_t*)((char*)dg + tk * 512 + q * 16) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the tile is free for the next copy
+  }
+  if (partial) {
+    // ---- block partial in gate_dwg_kernel's format: part[e * 256 + k] = M (this block's tokens), part[E * 256 + e] = DL ----
+    __syncthreads();
+    float* red = (float*)smem;                        // [16][256] + c[8] + dl[8]
+    for (int i = tid; i < 16 * 256 + 16; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < 16; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(red + (4 * kg + r) * 256 + 16 * nt + n16, macc[nt][r]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = cacc[j], b = dlacc[j];
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+      if (l31 == 0) { atomicAdd(red + 16 * 256 + 4 * lhi + j, a); atomicAdd(red + 16 * 256 + 8 + 4 * lhi + j, b); }
+    }
+    __syncthreads();
+    float* part = partial + (size_t)blockIdx.x * (E * 256 + E);
+    for (int i = tid; i < E * 256; i += 256) {
+      const int e = i >> 8, k = i & 255;
+      part[i] = (red[e * 256 + k] + red[(8 + e) * 256 + k]) - (LN ? red[16 * 256 + e] : 0.f);
+    }
+    if (tid < E) part[E * 256 + tid] = red[16 * 256 + 8 + tid];
+  }
+}
+
+int gate_bwd_mfma_blocks(int n_tokens) {
+  int blocks = cdiv(cdiv(n_tokens, 32), 4);
+  return blocks > 512 ? 512 : blocks;
+}
+
+// partial != NULL: the kernel also leaves its block's share of the parameter-gradient sums there ([blocks][E * 256 + E], the format
+// of gate_dwg_kernel): no separate pass over g for them
+int gate_bwd_mfma_launch(const void* g, const float* ln_w, const float* wg, const float* gates, const int32_t* idx, const float* d_gmax,
+                         const float* stats, const int32_t* counts, const float* laux_coef, int seg_tokens, int n_tokens, int n_experts,
+                         void* dg, float* dlogits, float* partial, void* stream) {
+  const int n_tiles = cdiv(n_tokens, 32);
+  const int blocks = gate_bwd_mfma_blocks(n_tokens);
+  const void* fn = ln_w ? (const void*)gate_bwd_mfma_kernel<true> : (const void*)gate_bwd_mfma_kernel<false>;
+  constexpr int LDS_B = GM_LDS_BYTES + 4096 + 8192;        // + dlr^T staging (4 x 1 KiB) + the W' table
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+  SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  const bf16_t* gp = (const bf16_t*)g;
+  bf16_t* dgp = (bf16_t*)dg;
+  void* kargs[] = {(void*)&gp, (void*)&ln_w, (void*)&wg, (void*)&gates, (void*)&idx, (void*)&d_gmax, (void*)&stats, (void*)&counts,
+                   (void*)&laux_coef, (void*)&seg_tokens, (void*)&n_tokens, (void*)&n_experts, (void*)&dgp, (void*)&dlogits, (void*)&n_tiles,
+                   (void*)&partial};
+  e = hipLaunchKernel(fn, dim3(blocks), dim3(256), kargs, LDS_B, as_stream(stream));
+  SWN_CHECK(e == hipSuccess, "swn_gate_bwd (mfma) launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
 }  // namespace swn
 #endif
