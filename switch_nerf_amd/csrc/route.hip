@@ -60,12 +60,23 @@ __global__ __launch_bounds__(256) void route_hist_kernel(const uint32_t* __restr
 }
 
 // exclusive scan of hist[seg][d][blk] in (d, blk) order; one block per segment, thread d owns row d.
+// NB > 0: the row (nblk <= NB counters) is held in registers - all its loads are in flight together; the serial form (NB = 0) pays
+// one memory round trip per counter, twice (25 us for 64 counters whatever the batch size).
+template <int NB>
 __global__ __launch_bounds__(256) void route_scan_kernel(int32_t* __restrict__ hist, int nblk) {
   __shared__ int32_t rowsum[256];
   const int seg = blockIdx.x, d = threadIdx.x;
   int32_t* row = hist + ((long)seg * 256 + d) * nblk;
   int32_t s = 0;
-  for (int b = 0; b < nblk; ++b) s += row[b];
+  int32_t c[NB > 0 ? NB : 1];
+  if constexpr (NB > 0) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) c[b] = b < nblk ? row[b] : 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) s += c[b];
+  } else {
+    for (int b = 0; b < nblk; ++b) s += row[b];
+  }
   rowsum[d] = s;
   __syncthreads();
   // exclusive scan over 256 row sums (serial in thread 0 would be 256 steps; do Hillis-Steele)
@@ -78,10 +89,18 @@ __global__ __launch_bounds__(256) void route_scan_kernel(int32_t* __restrict__ h
     __syncthreads();
   }
   int32_t run = v - s;  // exclusive prefix of this row
-  for (int b = 0; b < nblk; ++b) {
-    const int32_t c = row[b];
-    row[b] = run;
-    run += c;
+  if constexpr (NB > 0) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b < nblk) row[b] = run;
+      run += c[b];
+    }
+  } else {
+    for (int b = 0; b < nblk; ++b) {
+      const int32_t cc = row[b];
+      row[b] = run;
+      run += cc;
+    }
   }
 }
 
@@ -282,7 +301,9 @@ extern "C" int swn_route_top1(const int32_t* idx, const float* gmax, const float
   int32_t *vi = v0, *vo = v1;
   for (int shift = bpr ? 0 : 24; shift < 32; shift += 8) {
     hipLaunchKernelGGL(route_hist_kernel, dim3(nblk, n_seg), dim3(256), 0, s, ki, seg_tokens, shift, nblk, hist);
-    hipLaunchKernelGGL(route_scan_kernel, dim3(n_seg), dim3(256), 0, s, hist, nblk);
+    if (nblk <= 16) hipLaunchKernelGGL(route_scan_kernel<16>, dim3(n_seg), dim3(256), 0, s, hist, nblk);
+    else if (nblk <= 64) hipLaunchKernelGGL(route_scan_kernel<64>, dim3(n_seg), dim3(256), 0, s, hist, nblk);
+    else hipLaunchKernelGGL(route_scan_kernel<0>, dim3(n_seg), dim3(256), 0, s, hist, nblk);
     hipLaunchKernelGGL(route_scatter_kernel, dim3(nblk, n_seg), dim3(256), 0, s, ki, vi, seg_tokens, shift, nblk, hist, ko, vo);
     SWN_LAUNCH_CHECK();
     uint32_t* tk = ki; ki = ko; ko = tk;
