@@ -273,8 +273,8 @@ def main():
             traffic_tab = json.load(open(tp))
         except Exception:
             traffic_tab = {}
-    names = {"expert_fwd": "chainb_kernel<Bf16,1> (expert forward: 7 fused layers, 256-row tiles)",
-             "expert_bwd": "chainb_kernel<Bf16,2> (expert backward-data: 7 fused layers, 256-row tiles)",
+    names = {"expert_fwd": "chainp_kernel<Bf16,1> (expert forward: 7 fused layers, 256-row tiles, row groups half a layer apart)",
+             "expert_bwd": "chainp_kernel<Bf16,2> (expert backward-data: 7 fused layers, 256-row tiles, row groups half a layer apart)",
              "expert_wgrad": "wgrad_kernel<bf16,1> (expert weight gradients, 7 layers in one launch)"}
 
     def kept_of(st_):

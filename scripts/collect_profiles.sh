@@ -19,8 +19,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 # (c) SQ counters of the expert chains (one pass, 8 SQ slots)
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/p_sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --routing balanced --no-events > gpurun_out/p_sq.log 2>&1
-python scripts/pmc_summary.py gpurun_out/p_sq chainb > gpurun_out/r02_pmc_sq_chainb.txt
+python scripts/pmc_summary.py gpurun_out/p_sq chainp > gpurun_out/r02_pmc_sq_chainb.txt
 python scripts/pmc_summary.py gpurun_out/p_sq wgrad_kernel >> gpurun_out/r02_pmc_sq_chainb.txt
+python scripts/pmc_summary.py gpurun_out/p_sq gate_ >> gpurun_out/r02_pmc_sq_chainb.txt
 rm -rf gpurun_out/p_sq
 # (d) the bench lines
 python bench.py > gpurun_out/r02_bench_default.json 2> gpurun_out/r02_bench_default.err
