@@ -648,6 +648,69 @@ __device__ __forceinline__ void k_phase(f32x16_t (&acc)[4][2], const Ctx& cx, __
   }
 }
 
+// The K loop of geometry 4, second form: the wave's weight fragments come from global memory STRAIGHT INTO REGISTERS (nobody else reads
+// them, so the LDS ring of the first form was a detour): a 4-deep register ring, three K steps ahead, counted vmcnt.  The activation
+// fragments are read TWO steps ahead (three register sets): the LDS round trip of a lone wave's reads (~300 clocks with four waves
+// reading at once) no longer fits into one 256-clock step.  `wq` holds the fragments of steps 0..2 on entry (issued by the caller before
+// the phase barrier) - on exit nothing is in flight.
+template <typename E>
+__device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, __amdgpu_buffer_rsrc_t rs_cur, u32x4_t (&wq)[4][2]) {
+  constexpr int MI = 4;
+  char* smem = cx.smem;
+  const int lane16 = cx.lane * 16;
+  const int fg = cx.w & 3;
+  u32x4_t fa[3][MI];
+  uint32_t a_base = cx.a_base;
+  asm volatile("" : "+v"(a_base));
+  auto read_a = [&](int ks, int mi) {
+    fa[ks % 3][mi] = *(const u32x4_t*)(smem + (a_base ^ (uint32_t)(ks << 5)) + mi * (32 * ROWB));
+  };
+  auto load_w = [&](int ks) {          // the two feature tiles of this wave, K step ks
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      wq[ks & 3][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, lane16, ((2 * fg + i) * KSTEPS + ks) * 1024, 0);
+  };
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) read_a(0, mi);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) read_a(1, mi);
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    // weights of step ks: younger are the loads of steps ks + 1, ks + 2 (an older bias copy / mask load only makes the wait longer)
+    if (ks + 2 < KSTEPS) SWN_WAIT_VM(4); else if (ks + 1 < KSTEPS) SWN_WAIT_VM(2); else SWN_WAIT_VM(0);
+    if (ks + 1 < KSTEPS) SWN_WAIT_LGKM(4); else SWN_WAIT_LGKM(0);        // fragments of step ks (younger: those of step ks + 1)
+    SWN_PIN();
+#ifdef SWN_ABL_NOMFMA
+#define SWN_MM(mi, ni) asm volatile("" :: "v"(wq[ks & 3][ni]), "v"(fa[ks % 3][mi]))
+#else
+#define SWN_MM(mi, ni) acc[mi][ni] = E::mfma(wq[ks & 3][ni], fa[ks % 3][mi], acc[mi][ni])
+#endif
+    SWN_MM(0, 0);
+    SWN_PIN();
+    if (ks + 2 < KSTEPS) { read_a(ks + 2, 0); read_a(ks + 2, 1); }
+    SWN_PIN();
+    SWN_MM(0, 1);
+    SWN_PIN();
+    if (ks + 2 < KSTEPS) { read_a(ks + 2, 2); read_a(ks + 2, 3); }
+    SWN_PIN();
+    SWN_MM(1, 0);
+    SWN_PIN();
+    if (ks + 3 < KSTEPS) load_w(ks + 3);        // into the register set of step ks - 1, whose MFMAs were issued a step ago
+    SWN_PIN();
+    SWN_MM(1, 1);
+    SWN_PIN();
+    SWN_MM(2, 0);
+    SWN_PIN();
+    SWN_MM(2, 1);
+    SWN_PIN();
+    SWN_MM(3, 0);
+    SWN_PIN();
+    SWN_MM(3, 1);
+#undef SWN_MM
+    SWN_PIN();
+  }
+}
+
 // The epilogue of geometry 4.  Same arithmetic as epilogue() above, value for value - but an epilogue wave of chainp_kernel runs ALONE
 // beside its SIMD's MFMA wave: dependent VALU chains that two lockstep waves hide from each other (chainb) cost it ~8 clocks per
 // instruction.  The 16 packed pairs of a row tile therefore move through the stages together (16 independent instructions per
@@ -837,15 +900,15 @@ __global__ __launch_bounds__(512, 2) void chainp_kernel(const Args args) {
   SWN_TM(const long long t_start = TICK(); long long tk = 0, tkb = 0, te = 0, teb = 0, two = 0, tpro = 0;)
   int* gcount = (int*)(smem + G::BIAS0 + 3072);       // [2]: arrivals of the waves of a row group at the residual layer's meeting point
 
-  // ---- prologue: ring (steps 0..2 of layer 0), source rows, the rows of group 0 ----
-  {
-    const __amdgpu_buffer_rsrc_t r0 = wrs(0);
+  // ---- prologue: this wave's weight fragments of the first three K steps, source rows, the rows of group 0 ----
+  u32x4_t wq[4][2];
+  auto preload_w = [&](int L) {
+    const __amdgpu_buffer_rsrc_t r = wrs(L);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int f = i * 8 + cx.w, s = f >> 3, t = f & 7;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, SWN_LDS(smem + G::RING0 + s * SLOT_B + t * 1024), 16, lane16, (t * KSTEPS + s) * 1024, 0, 0);
-    }
-  }
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wq[ks][i] = __builtin_amdgcn_raw_buffer_load_b128(r, lane16, ((2 * fg + i) * KSTEPS + ks) * 1024, 0);
+  };
   if (tid < BM) {
     const long gr = grow0 + (tid < rows_in_tile ? tid : 0);
     long src = d.x_gather ? (long)d.x_gather[gr] : gr;
@@ -869,10 +932,14 @@ __global__ __launch_bounds__(512, 2) void chainp_kernel(const Args args) {
   __builtin_amdgcn_s_barrier();
   stage_pieces(cx, (const char*)d.x, cx.w, 8, 8);                 // rows of group 0: pieces 0..63, all waves
   SWN_WAIT_VM(0);
+  SWN_PIN();
+  if (rg == 0) preload_w(0);
+  SWN_PIN();
   __builtin_amdgcn_s_barrier();
   if (rg == 1) {                                                  // phase 0 of group 1: its own rows
     stage_pieces(cx, (const char*)d.x, 64 + fg, 16, 4);
     SWN_WAIT_VM(0);
+    preload_w(0);
     __builtin_amdgcn_s_barrier();
   }
 
@@ -890,15 +957,8 @@ __global__ __launch_bounds__(512, 2) void chainp_kernel(const Args args) {
     u32x4_t mk = mk_next;
     // ---- K phase ----
     {
-      const int q = 2 * L + rg;                                   // this ring's q-th user: global K step 16 q + j -> slot (q + j) mod 3
-      const int s0 = q % 3;
-      cx.slot_off[0] = s0 * SLOT_B;
-      cx.slot_off[1] = ((s0 + 1) % 3) * SLOT_B;
-      cx.slot_off[2] = ((s0 + 2) % 3) * SLOT_B;
       const __amdgpu_buffer_rsrc_t rs_cur = wrs(L);
-      const __amdgpu_buffer_rsrc_t rs_nxt = (rg == 0 || L + 1 >= n_layers) ? rs_cur : wrs(L + 1);      // the ring's next user
-      // what the coming epilogue needs from global memory, ahead of the weight copies (the K loop's counted waits cover them):
-      // the stored mask of this wave, and (group 0, for both groups) this layer's bias -> the LDS slot of the layer's parity
+      // (group 0, for both groups) the next layer's bias -> its LDS slot; the K loop's counted waits cover the copy
       if (rg == 0 && L + 1 < n_layers) stage_bias(L + 1);
       if (bias_init && ly.b) {
         f32x4_t bv[2][4];
@@ -922,9 +982,12 @@ __global__ __launch_bounds__(512, 2) void chainp_kernel(const Args args) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
       }
       SWN_TM(const long long k0 = TICK();)
-      k_phase<E>(acc, cx, rs_cur, rs_nxt);
+      k_phase2<E>(acc, cx, rs_cur, wq);
+#pragma unroll
+      for (int q_ = 0; q_ < 4; ++q_)          // the ring's registers are dead from here to the preload at the end of the epilogue phase:
+#pragma unroll
+        for (int i_ = 0; i_ < 2; ++i_) asm volatile("" : "=v"(wq[q_][i_]));      // say so (no code), or they are kept alive through it
       SWN_TM(const long long k1 = TICK();)
-      SWN_WAIT_VM(0);                   // the next user's first three steps have landed
       __builtin_amdgcn_s_barrier();     // the group is done reading its rows; the partner has rewritten its own and written ours out
       SWN_TM(const long long k2 = TICK(); tk += k1 - k0; tkb += k2 - k1;)
     }
@@ -962,8 +1025,7 @@ __global__ __launch_bounds__(512, 2) void chainp_kernel(const Args args) {
           for (int j = 0; j < 4; ++j) wv[j] = *(const u32x4_t*)(smem + piece_addr(ce, c0 + 4 * (4 * b + j)));
         };
         rd(0);
-        auto hook = [&](int mi) {
-          SWN_WAIT_LGKM0();
+        auto hook = [&](int mi) {      // (no explicit wait: the compiler counts the LDS operations behind the piece reads itself)
 #pragma unroll
           for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(wv[j], rs, lane16e, (c0 + 4 * (4 * mi + j)) * 1024, SWN_BIG_STORE_AUX);
           // The registers of a 16-byte store must not be rewritten right behind it: with a VALU write two instructions after the
@@ -978,6 +1040,9 @@ __global__ __launch_bounds__(512, 2) void chainp_kernel(const Args args) {
         epilogue_p_dispatch<E, NoHook>(acc, ce, mk, ly.relu, bias_epi, ly.skip != 0, (L % 3) * 1024, NoHook());
       }
       if (ly.relu == 1 && mkp) *(u32x4_t*)mkp = mk;
+      SWN_PIN();                                    // (the loads must not be scheduled up into the epilogue: 24 registers)
+      preload_w(L + 1 < n_layers ? L + 1 : L);     // the first three K steps of this wave's next K loop (end of chain: loaded, never used)
+      SWN_PIN();
       SWN_WAIT_LGKM0();
       SWN_TM(const long long e1 = TICK();)
       __builtin_amdgcn_s_barrier();
