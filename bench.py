@@ -105,9 +105,11 @@ def main():
                     help="N > 1: strong (default) = the --rays batch is split over the ranks like the reference (runner.py:573-575); "
                          "weak = --rays per rank")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="replay the step's forward + backward launch sequence from a hipGraph (switch_nerf_amd/graph.py).  auto: on for "
-                         "N > 1 data parallel (1024 rays per GPU are launch-bound from Python), off for N = 1 where the per-kernel HIP "
-                         "events are recorded inside the timed region")
+                    help="replay the step's forward + backward launch sequence from a hipGraph (switch_nerf_amd/graph.py).  auto = on for "
+                         "the headline recipe in data parallel: the FIRST process on a fresh box issues its ~150 launches per step 10 % "
+                         "slower than the GPU runs them (18.5-19.7 ms/step against 16.7 for every later process; 200 warm-up steps do not "
+                         "cure it), replay takes the host out of the step; per-kernel HIP events cannot be recorded inside a graph, they "
+                         "come from eager steps that follow the timed region.  off: eager launches, events inside the timed region")
     ap.add_argument("--no-balanced", action="store_true", help="skip the extra balanced-routing measurement")
     ap.add_argument("--routing", choices=["router", "balanced"], default="router",
                     help="balanced: the MAIN measurement runs with point i -> expert i mod E (used by the counter passes: bytes per kept row)")
@@ -175,8 +177,10 @@ def main():
 
     route_override = [None]       # [P] int32 expert of every point (the balanced-routing measurement) or None = the router's choice
     plain = not (a.eval or a.mip or a.bg or a.fine or a.dense)
-    use_graph = plain and a.parallelism == "dp" and (a.graph == "on" or (a.graph == "auto" and world > 1))
+    use_graph = plain and a.parallelism == "dp" and a.graph in ("on", "auto")
     graphed = [None]
+    if use_graph:
+        from switch_nerf_amd.graph import GraphedTrainStep
 
     def step():
         if a.eval:       # render_rays in eval mode (runner.py:2835-2885 render_image's inner call): forward only
@@ -249,7 +253,6 @@ def main():
         route_override[0] = (torch.arange(P, device=dev, dtype=torch.int32) % a.experts).contiguous()
     reset_state(4321)
     if use_graph:
-        from switch_nerf_amd.graph import GraphedTrainStep
         graphed[0] = GraphedTrainStep(model, rgbs, rays, idx, a.samples, a.chunk, perturb=1.0, noise_std=1.0,
                                       routing_override=route_override[0])
     for _ in range(a.warmup):
@@ -257,10 +260,11 @@ def main():
     reset_state(1234)
     dt, st = timed(a.steps, (not a.no_events) and not use_graph)
     ms = dt / a.steps * 1e3
-    if use_graph:                # per-kernel events cannot be recorded inside a graph: three more (eager, untimed) steps fill the table
-        graphed[0] = None
+    ev_steps = max(3, min(20, a.steps))
+    if use_graph:                # per-kernel events cannot be recorded inside a graph: eager steps right behind the timed region fill the
+        graphed[0] = None        # table (the same launches on the next steps of the same run)
         if not a.no_events:
-            _, st = timed(3, True)
+            _, st = timed(ev_steps, True)
     value = n_rays * world * a.steps / dt
 
     # ---- per-kernel accounting from the live HIP events
@@ -331,11 +335,18 @@ def main():
     if not other and not a.no_balanced and not a.fine and a.routing == "router":
         route_override[0] = (torch.arange(P, device=dev, dtype=torch.int32) % E).contiguous()
         reset_state(4321)
+        if use_graph:
+            graphed[0] = GraphedTrainStep(model, rgbs, rays, idx, a.samples, a.chunk, perturb=1.0, noise_std=1.0,
+                                          routing_override=route_override[0])
         for _ in range(2):
             step()
         reset_state(1234)
         bsteps = max(2, min(10, a.steps))
-        bdt, bst = timed(bsteps, not a.no_events)
+        bdt, bst = timed(bsteps, (not a.no_events) and not use_graph)
+        if use_graph:
+            graphed[0] = None
+            if not a.no_events:
+                _, bst = timed(bsteps, True)
         balanced = dict(routing="expert = point index mod E (every group full)", steps=bsteps, ms_per_step=round(bdt / bsteps * 1e3, 3),
                         value=round(n_rays * world * bsteps / bdt, 1), kept_token_fraction=round(kept_of(bst) / P, 4),
                         kernels=account(model.events, kept_of(bst)))
@@ -360,8 +371,8 @@ def main():
                                + (f", model_dim {a.model_dim}, {a.experts} experts" if (a.model_dim != 256 or a.experts != 8) else ""),
                    "global_batch_rays": gb, "rays_per_gpu": n_rays, "samples": a.samples, "segment_points": a.chunk,
                    "parallelism": f"{a.parallelism}{world}", "kept_token_fraction": round(kept / P, 4), "kept_token_fraction_mean": round(kept_mean / P, 4), "loss": round(loss_main, 6),
-                   "timed_region": ("forward + backward replayed from a hipGraph, all-reduce + Adam eager; per-kernel events from 3 extra "
-                                    "eager steps after the timed region" if use_graph else
+                   "timed_region": (f"forward + backward replayed from a hipGraph, all-reduce + Adam eager; per-kernel HIP events from {ev_steps} "
+                                    "eager steps right after the timed region (expert weight gradients on the main stream there)" if use_graph else
                                     "per-kernel HIP events recorded inside it; expert weight gradients on the main stream (no side-stream "
                                     "overlap) while events are on" if not a.no_events else "no per-kernel events; expert weight gradients "
                                     "overlapped on the side stream")},

@@ -431,7 +431,8 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
     const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int s_ = q / args.tiles_per_group;
     tile = q - s_ * args.tiles_per_group;
-    g = x + 8 * s_;
+    g = ((x + s_) & 7) + 8 * s_;     // rotated per 8 groups: every XCD meets every weight set - an expert that draws more rows than the
+                                     // others (unbalanced routing) would otherwise make ITS XCD the long pole of the launch
   }
 #endif
   int rows_valid = d.group_stride;

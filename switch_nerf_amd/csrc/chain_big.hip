@@ -412,7 +412,8 @@ __global__ __launch_bounds__(G::NT, G::OCC) void chainb_kernel(const Args args) 
     const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int s_ = q / args.tiles_per_group;
     tile = q - s_ * args.tiles_per_group;
-    g = x + 8 * s_;
+    g = ((x + s_) & 7) + 8 * s_;     // rotated per 8 groups: every XCD meets every weight set - an expert that draws more rows than the
+                                     // others (unbalanced routing) would otherwise make ITS XCD the long pole of the launch
   }
   int rows_valid = d.group_stride;
   if (d.group_rows) rows_valid = d.group_rows[g];
@@ -871,7 +872,8 @@ __global__ __launch_bounds__(512, 2) void chainp_kernel(const Args args) {
     const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int s_ = q / args.tiles_per_group;
     tile = q - s_ * args.tiles_per_group;
-    g = x + 8 * s_;
+    g = ((x + s_) & 7) + 8 * s_;     // rotated per 8 groups: every XCD meets every weight set - an expert that draws more rows than the
+                                     // others (unbalanced routing) would otherwise make ITS XCD the long pole of the launch
   }
   int rows_valid = d.group_stride;
   if (d.group_rows) rows_valid = d.group_rows[g];

@@ -70,7 +70,11 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int g = blockIdx.x, split = blockIdx.y;
+  // (blocks go to the XCDs round-robin: rotate the group index per 8 groups so that an XCD does not own one weight set - one expert -
+  //  of every segment: with unbalanced routing the XCD of the most popular expert would be the long pole of the launch)
+  int g = blockIdx.x;
+  if ((p.n_groups & 7) == 0) g = (((g & 7) + (g >> 3)) & 7) + (g & ~7);
+  const int split = blockIdx.y;
   const swn_wgrad_item& it = p.it[blockIdx.z];
   int rows_valid = p.group_stride;
   if (p.group_rows) rows_valid = min(p.group_rows[g], p.clamp);
