@@ -306,6 +306,16 @@ typedef struct swn_chain_desc {
   int32_t tag;                  /* profiling only: selects an identical kernel instantiation with its own symbol so that
                                    rocprofv3 reports the roles separately (0 generic, 1 expert fwd, 2 expert bwd,
                                    3 front fwd, 4 tail fwd, 5 tail bwd, 6 front bwd)                 */
+  /* Combine backward fused into the write-out of the LAST layer (comb_y != NULL; the tail backward chain): with z = the layer's
+     output row (the gradient of the decoded, gate-scaled, ReLU'd expert output y, tutel_fast_dispatch.py:50-63 + nerf_moe.py:385)
+       t = (z + comb_dsig[row] * comb_wsig) * (comb_y[row] > 0);   y[row] = t * comb_gate[row];   comb_dgate[row] = <comb_y[row], t> / comb_gate[row]
+     i.e. swn_combine_bwd without the round trip of z through memory.  comb_y: row-major [*, n_last] dtype; comb_dsig (NULL = 0),
+     comb_gate, comb_dgate: fp32 per row; comb_wsig: fp32 [n_last] (NULL = 0).  n_last must be 128, 256 or 512.                  */
+  const void* comb_y;
+  const float* comb_dsig;
+  const float* comb_wsig;
+  const float* comb_gate;
+  float* comb_dgate;
   swn_chain_layer layers[SWN_MAX_CHAIN_LAYERS];
 } swn_chain_desc;
 

@@ -1,0 +1,34 @@
+"""Expert weight-gradient launch (7 layers, 128 groups x 16384 rows) under different routing balances: ms and ns per kept row.
+python scripts/wgrad_check.py [splits ...]"""
+import sys, torch
+sys.path.insert(0, '.')
+from switch_nerf_amd import ops as o
+dev, dt = torch.device('cuda'), torch.bfloat16
+M, E, L, CAP, NSEG = 256, 8, 7, 16384, 16
+NG = NSEG * E
+ROWS = NG * CAP
+torch.manual_seed(0)
+acts = [torch.randn(ROWS, M, device=dev).to(dt) for _ in range(L)]
+dzs = [torch.randn(ROWS, M, device=dev).to(dt) for _ in range(L)]
+perm = torch.randperm(ROWS, device=dev).int()
+dw = [torch.zeros(E, M, M, device=dev) for _ in range(L)]
+db = [torch.zeros(E, M, device=dev) for _ in range(L)]
+items = [(acts[l], dzs[l], dw[l], db[l], perm if l == 0 else None, perm if l == L - 1 else None) for l in range(L)]
+pats = {"balanced": [CAP] * 8,
+        "all 79 %": [int(CAP * 0.79)] * 8,
+        "half full, half 58 %": [CAP, int(CAP * 0.58)] * 4,
+        "router-like (3 full, 5 x 66 %)": [CAP, CAP, CAP] + [int(CAP * 0.664)] * 5,
+        "2 full, 6 x 72 %": [CAP, CAP] + [int(CAP * 0.72)] * 6}
+for splits in [int(v) for v in sys.argv[1:]] or [2]:
+    for name, pe in pats.items():
+        counts = torch.tensor(pe * NSEG, dtype=torch.int32, device=dev)
+        kept = int(counts.sum())
+        f = lambda: o.wgrad_batched(items, n_groups=NG, n_wsets=E, group_stride=CAP, group_rows=counts, group_rows_clamp=CAP, n_splits=splits, tag=1)
+        f(); f(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5):
+            f()
+        b.record(); torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 5
+        print(f"splits {splits} {name:32s} kept {kept / ROWS:.3f}: {ms:.3f} ms, {ms * 1e6 / kept:.3f} ns per kept row, {kept * 7 * 1024 / ms / 1e9:.2f} TB/s of operand reads")

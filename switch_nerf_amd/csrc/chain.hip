@@ -126,6 +126,24 @@ __device__ __forceinline__ uint4 load_chunk_from_act(const char* act, int row, i
   }
 }
 
+// a 16-byte chunk of T <-> fp32 values
+template <typename T>
+__device__ __forceinline__ void chunk_to_f32(uint4 a, float* x) {
+  const uint32_t aa[4] = {a.x, a.y, a.z, a.w};
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { x[2 * j] = bf16_to_f32((bf16_t)(aa[j] & 0xFFFF)); x[2 * j + 1] = bf16_to_f32((bf16_t)(aa[j] >> 16)); }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = __uint_as_float(aa[j]);
+  }
+}
+template <typename T>
+__device__ __forceinline__ uint4 f32_to_chunk(const float* x) {
+  if constexpr (sizeof(T) == 2) return make_uint4(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7]));
+  else return make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
+}
+
 // out = a + b elementwise on a 16-byte chunk of T
 template <typename T>
 __device__ __forceinline__ uint4 add_chunks(uint4 a, uint4 b) {
@@ -623,6 +641,47 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
       const int cpr = row_bytes >> 4;
       const int sh = 31 - __builtin_clz(cpr);
       const int total = rows_in_tile * cpr;
+      if (last && d.comb_y) {
+        // Combine backward on the way out (include/swn.h).  A row's cpr chunks sit in cpr consecutive lanes (NT is a multiple of cpr:
+        // a thread keeps its chunk column).  The global operands of UB chunks are fetched together, ahead of the arithmetic.
+        constexpr int EPC = 16 / (int)sizeof(T), UB = 8;
+        const int ch = tidw & (cpr - 1);
+        float wv[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) wv[e] = d.comb_wsig ? d.comb_wsig[ch * EPC + e] : 0.f;
+        for (int c0 = tidw; c0 < total; c0 += UB * NT) {
+          uint4 yc[UB];
+          float gt[UB], ds[UB];
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            const int c = c0 + u * NT;
+            const long gr = grow0 + ((c < total ? c : c0) >> sh);
+            yc[u] = *(const uint4*)((const char*)d.comb_y + gr * row_bytes + ch * 16);
+            gt[u] = d.comb_gate[gr];
+            ds[u] = d.comb_dsig ? d.comb_dsig[gr] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            const int c = c0 + u * NT;
+            if (c < total) {
+              const int row = c >> sh;
+              float z[EPC], yv[EPC], dot = 0.f;
+              chunk_to_f32<T>(load_chunk_from_act<T>(act, row, ch), z);
+              chunk_to_f32<T>(yc[u], yv);
+#pragma unroll
+              for (int e = 0; e < EPC; ++e) {
+                float t = z[e] + ds[u] * wv[e];          // (one fma, like combine_bwd_kernel)
+                t = yv[e] > 0.f ? t : 0.f;
+                dot += yv[e] * t;
+                z[e] = t * gt[u];
+              }
+              for (int o = cpr >> 1; o >= 1; o >>= 1) dot += __shfl_xor(dot, o);
+              if (ch == 0) d.comb_dgate[grow0 + row] = dot / gt[u];
+              *(uint4*)((char*)outp + (grow0 + row) * row_bytes + ch * 16) = f32_to_chunk<T>(z);
+            }
+          }
+        }
+      } else
       for (int c = tidw; c < total; c += NT) {
         const int row = c >> sh, ch = c & (cpr - 1);
         uint4 v = load_chunk_from_act<T>(act, row, ch);
@@ -854,6 +913,13 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   SWN_CHECK(d.tag >= 0 && d.tag <= 6, "swn_mlp_chain: tag %d not in [0,6]", d.tag);
   SWN_CHECK(!(wide && concat), "swn_mlp_chain: concat-skip layers are built for the 256-feature kernels only");
   SWN_CHECK(d.geometry >= 0 && d.geometry <= 5, "swn_mlp_chain: geometry %d not in [0,5]", d.geometry);
+  if (d.comb_y) {
+    const int nl = d.layers[d.n_layers - 1].n;
+    SWN_CHECK(d.comb_gate && d.comb_dgate, "swn_mlp_chain: combine backward needs comb_gate and comb_dgate");
+    SWN_CHECK((nl == 128 || nl == 256 || nl == 512) && nl * (d.dtype == SWN_F32 ? 4 : 2) <= 1024,
+              "swn_mlp_chain: combine backward: last layer of 128 / 256 / 512 features, at most 1 KiB per row");
+    SWN_CHECK(d.geometry < 2, "swn_mlp_chain: combine backward runs on the 64-row kernels (geometry 0 / 1)");
+  }
   {   // 256-row geometry (chain_big.hip).  Never chosen silently for bf16: the ReLU mask layout differs between the geometries,
       // and a backward chain must run on the geometry of the forward chain that recorded its masks - the caller pairs them.
     const bool can = chain_big_eligible(d);

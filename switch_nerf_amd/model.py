@@ -591,13 +591,19 @@ class SwitchNeRF:
         d_feat_emb = dc_ray @ self.p["l2r.w"][self.in_dir:].t()
         g["emb"].index_add_(0, c["image_indices"].long(), d_feat_emb)
         # tail backward chain: dh2 -> dh1 -> dy
+        # ... with the combine backward (the sigma head's rank-1 term, the ReLU mask of y, the gate gradient, the gate scaling) applied
+        # in the write-out of the last layer: dy itself never reaches memory
         dh1 = _b("dh1", (P, M), dt)
-        dy = _b("dy", (P, M), dt)
-        o.mlp_chain(dh2, [o.Layer(self.wb["l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dy, tag=5)
+        dout = _b("dy", (P, M), dt)
+        if M * dout.element_size() <= 1024:      # (a row's 16-byte chunks must fit one wavefront: everything but fp32 rows of 512)
+            dgmax = _b("dgmax", (P,), torch.float32)
+            o.mlp_chain(dh2, [o.Layer(self.wb["l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dout, tag=5,
+                        combine=(c["y"], dsig, self.p["sigma.w"], c["gmax"], dgmax))
+        else:
+            o.mlp_chain(dh2, [o.Layer(self.wb["l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dout, tag=5)
+            dout, dgmax = o.combine_bwd(dout, c["y"], dsig, self.p["sigma.w"], c["gmax"])
         nsp = max(1, min(256, P // 1024))          # row splits of the dense weight-gradient GEMMs: one workgroup per CU also at the
                                                    # per-GPU batch of an 8-GPU run (262144 points)
-        # combine backward (adds the sigma head's rank-1 term, applies the ReLU mask, gate gradient)
-        dout, dgmax = o.combine_bwd(dy, c["y"], dsig, self.p["sigma.w"], c["gmax"])
         ep = self.ep
         if ep is not None:      # the rows of the first segment travel to their experts while the tail's weight gradients run
             seg_rows = E * cap

@@ -437,9 +437,10 @@ def chain_mask_words(dtype, n_groups: int, group_stride: int, max_width: int = 2
 
 def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride=None, group_rows=None,
               group_rows_clamp=None, x_gather=None, x_save=None, y_add=None, y_add_gather=None, tag=0, x_scale=None,
-              x_relu=False, geometry=0, group_begin=None):
-    """geometry: 0 / 1 the 64-row tile kernels, 2 / 3 the chain_big.hip geometries (include/swn.h).  group_begin: first row of every
-    group (packed / no-batch layout) instead of g * group_stride."""
+              x_relu=False, geometry=0, group_begin=None, combine=None):
+    """geometry: 0 / 1 the 64-row tile kernels, 2 - 5 the chain_big.hip geometries (include/swn.h).  group_begin: first row of every
+    group (packed / no-batch layout) instead of g * group_stride.  combine = (y_fwd, dsig, wsig, gate, dgate_out): the combine backward
+    (ops.combine_bwd) fused into the write-out of the last layer."""
     d = ChainDesc()
     d.dtype = _dt(x)
     d.tag = int(tag)
@@ -453,6 +454,10 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
     d.x, d.x_gather, d.x_save, d.y = _p(x), _p(x_gather), _p(x_save), _p(y)
     d.x_scale, d.x_relu = _p(x_scale), int(bool(x_relu))
     d.y_add, d.y_add_gather = _p(y_add), _p(y_add_gather)
+    if combine is not None:
+        cy, cds, cws, cg, cdg = combine
+        assert cy.dtype == x.dtype and cy.shape == y.shape and cg.dtype == torch.float32 and cdg.dtype == torch.float32
+        d.comb_y, d.comb_dsig, d.comb_wsig, d.comb_gate, d.comb_dgate = _p(cy), _p(cds), _p(cws), _p(cg), _p(cdg)
     for i, ly in enumerate(layers):
         L = d.layers[i]
         assert ly.w.dtype == x.dtype and hasattr(ly.w, "swn_nk"), "weights must come from ops.pack_weights (compute dtype)"

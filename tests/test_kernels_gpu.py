@@ -717,3 +717,35 @@ def test_nobatch_sparse_abi_vs_reference_golden(dtype):
     d_disp = ((1 - torch.tanh(t(g["dispatched"]) @ t(g["w"])) ** 2) * t(g["d_expert_out"])) @ t(g["w"]).t()
     dx = o.dispatch_nobatch_bwd_data(None, idx, loc, begin, d_disp.to(dtype))
     assert report(f"nobatch_dx_{dtype}", dx, t(g["dx"])) <= (5e-6 if dtype == torch.float32 else 5e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_chain_fused_combine_backward(dtype):
+    """The combine backward (ops.combine_bwd: sigma head's rank-1 term, ReLU mask of y, gate gradient, gate scaling) applied in the
+    write-out of the tail backward chain's last layer: the same numbers as the chain followed by swn_combine_bwd - the gradient rows
+    bit for bit (both read the chain's output after its rounding to the compute dtype), the gate gradient to summation order."""
+    o = ops()
+    g = torch.Generator().manual_seed(5)
+    P, M, H2 = 5000, 256, 128
+    dh2 = (torch.randn(P, H2, generator=g) * 0.1).to(dev()).to(dtype)
+    w2 = o.pack_weights((torch.randn(1, M, H2, generator=g) / 16).to(dev()), dtype, False)      # backward-data layouts [in, out]
+    w1 = o.pack_weights((torch.randn(1, M, M, generator=g) / 16).to(dev()), dtype, False)
+    y = torch.randn(P, M, generator=g).to(dev()).to(dtype)
+    dsig = torch.randn(P, generator=g).to(dev())
+    wsig = torch.randn(M, generator=g).to(dev())
+    gate = (torch.rand(P, generator=g) * 0.8 + 0.1).to(dev())
+    dh1a, dh1b = torch.zeros(P, M, dtype=dtype, device=dev()), torch.zeros(P, M, dtype=dtype, device=dev())
+    dy = torch.zeros(P, M, dtype=dtype, device=dev())
+    o.mlp_chain(dh2, [o.Layer(w2, None, save=dh1a), o.Layer(w1, None)], dy, tag=5)
+    ref_dout, ref_dgate = o.combine_bwd(dy, y, dsig, wsig, gate)
+    dout = torch.zeros(P, M, dtype=dtype, device=dev())
+    dgate = torch.zeros(P, device=dev())
+    o.mlp_chain(dh2, [o.Layer(w2, None, save=dh1b), o.Layer(w1, None)], dout, tag=5, combine=(y, dsig, wsig, gate, dgate))
+    torch.cuda.synchronize()
+    assert torch.equal(dh1a, dh1b) and torch.equal(dout, ref_dout)
+    assert (dgate - ref_dgate).abs().max().item() <= 1e-5 * ref_dgate.abs().max().item()
+    for none_case in (True,):                                    # without the sigma term
+        d2, g2 = torch.zeros_like(dout), torch.zeros_like(dgate)
+        o.mlp_chain(dh2, [o.Layer(w2, None), o.Layer(w1, None)], d2, tag=5, combine=(y, None, None, gate, g2))
+        r2, rg2 = o.combine_bwd(dy, y, None, None, gate)
+        assert torch.equal(d2, r2) and (g2 - rg2).abs().max().item() <= 1e-5 * rg2.abs().max().item()
