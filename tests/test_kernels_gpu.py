@@ -751,14 +751,15 @@ def test_chain_fused_combine_backward(dtype):
         assert torch.equal(d2, r2) and (g2 - rg2).abs().max().item() <= 1e-5 * rg2.abs().max().item()
 
 
+@pytest.mark.parametrize("P", [4096 + 37, 262144])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_chain_fused_heads(dtype):
+def test_chain_fused_heads(dtype, P):
     """The output heads (ops.heads_fwd: sigma = ShiftedSoftplus(<y, w_sigma> + b + noise), rgb = sigmoid(h2 Wc + bc)) computed inside the
     tail forward chain - sigma on the staged (gathered, gate-scaled, ReLU'd) input rows, the colours in the write-out of the last layer -
     against the chain followed by swn_heads_fwd on the tensors it wrote."""
     o = ops()
     g = torch.Generator().manual_seed(6)
-    P, M, H2, R = 4096 + 37, 256, 128, 6000
+    M, H2, R = 256, 128, 6000          # (262144 rows: a hazard of an earlier version showed up a few times per 10^5 rows only)
     eo = torch.randn(R, M, generator=g).to(dev()).to(dtype)
     row_of_tok = torch.randint(-1, R, (P,), generator=g).int().to(dev())
     gate = (torch.rand(P, generator=g) * 0.8 + 0.1).to(dev())
