@@ -310,18 +310,8 @@ typedef struct swn_chain_desc {
      output row (the gradient of the decoded, gate-scaled, ReLU'd expert output y, tutel_fast_dispatch.py:50-63 + nerf_moe.py:385)
        t = (z + comb_dsig[row] * comb_wsig) * (comb_y[row] > 0);   y[row] = t * comb_gate[row];   comb_dgate[row] = <comb_y[row], t> / comb_gate[row]
      i.e. swn_combine_bwd without the round trip of z through memory.  comb_y: row-major [*, n_last] dtype; comb_dsig (NULL = 0),
-     comb_gate, comb_dgate: fp32 per row; comb_wsig: fp32 [n_last] (NULL = 0).  n_last must be 128, 256 or 512.                  */
-  /* The output heads fused into the chain (heads_raw != NULL; the tail forward chain; swn_heads_fwd without reading y and h2 back):
-       heads_raw[row] = (sigmoid(<out row, heads_wc[c]> + heads_bc[c]) c < 3,  softplus(<in row, heads_ws> + heads_bs[0] + heads_noise[row] - 1))
-     with "in row" = the chain's input row after x_gather / x_scale / x_relu (what x_save receives: y) and "out row" = the last layer's
-     output (h2).  heads_ws: fp32 [k0], heads_wc: fp32 [3][n_last], heads_noise: fp32 per row or NULL, heads_raw: fp32 [rows][4].
-     Rows of at most 1 KiB on both ends.                                                                                          */
-  const float* heads_ws;
-  const float* heads_bs;
-  const float* heads_wc;
-  const float* heads_bc;
-  const float* heads_noise;
-  float* heads_raw;
+     comb_gate, comb_dgate: fp32 per row; comb_wsig: fp32 [n_last] (NULL = 0).  n_last must be 128, 256 or 512; tag must be 5 (only that kernel
+     instantiation carries the code).                                                                                              */
   const void* comb_y;
   const float* comb_dsig;
   const float* comb_wsig;

@@ -126,6 +126,24 @@ __device__ __forceinline__ uint4 load_chunk_from_act(const char* act, int row, i
   }
 }
 
+// a 16-byte chunk of T <-> fp32 values
+template <typename T>
+__device__ __forceinline__ void chunk_to_f32(uint4 a, float* x) {
+  const uint32_t aa[4] = {a.x, a.y, a.z, a.w};
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { x[2 * j] = bf16_to_f32((bf16_t)(aa[j] & 0xFFFF)); x[2 * j + 1] = bf16_to_f32((bf16_t)(aa[j] >> 16)); }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = __uint_as_float(aa[j]);
+  }
+}
+template <typename T>
+__device__ __forceinline__ uint4 f32_to_chunk(const float* x) {
+  if constexpr (sizeof(T) == 2) return make_uint4(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7]));
+  else return make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
+}
+
 // out = a + b elementwise on a 16-byte chunk of T
 template <typename T>
 __device__ __forceinline__ uint4 add_chunks(uint4 a, uint4 b) {
@@ -149,32 +167,13 @@ __device__ __forceinline__ uint4 add_chunks(uint4 a, uint4 b) {
   return r;
 }
 
-// a 16-byte chunk of T <-> fp32 values
-template <typename T>
-__device__ __forceinline__ void chunk_to_f32(uint4 a, float* x) {
-  const uint32_t aa[4] = {a.x, a.y, a.z, a.w};
-  if constexpr (sizeof(T) == 2) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { x[2 * j] = bf16_to_f32((bf16_t)(aa[j] & 0xFFFF)); x[2 * j + 1] = bf16_to_f32((bf16_t)(aa[j] >> 16)); }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) x[j] = __uint_as_float(aa[j]);
-  }
-}
-template <typename T>
-__device__ __forceinline__ uint4 f32_to_chunk(const float* x) {
-  if constexpr (sizeof(T) == 2) return make_uint4(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7]));
-  else return make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
-}
-
 // Load the (gathered) input rows of this tile into an LDS tile with the activation layout.
 // kfeat * sizeof(T) / 16 (chunks per row) is a power of two; all global loads of a batch are issued before any is
 // consumed (no per-load wait), out-of-range work is clamped to a valid address and masked at the store.
 template <typename T, int B = 4>
 __device__ __forceinline__ void load_rows_to_lds(char* dst, const void* src, const int32_t* gather, void* save,
                                                  long grow0, int rows_valid_in_tile, int kfeat, int tid,
-                                                 const float* scale = nullptr, int relu = 0, const float* dot_w = nullptr,
-                                                 float* dot_out = nullptr) {
+                                                 const float* scale = nullptr, int relu = 0) {
   constexpr int BM = Cfg<T>::BM;
   const int row_bytes = kfeat * (int)sizeof(T);
   const int cpr = row_bytes >> 4;  // 16-byte chunks per row (power of two)
@@ -225,16 +224,6 @@ __device__ __forceinline__ void load_rows_to_lds(char* dst, const void* src, con
       if (in[i]) {
         if (save && row[i] < rows_valid_in_tile) *(uint4*)((char*)save + (grow0 + row[i]) * row_bytes + ch[i] * 16) = v[i];
         store_chunk_to_act<T>(dst, row[i], ch[i], v[i]);
-      }
-      if (dot_w) {      // <staged row, dot_w> (the sigma head's pre-activation): a row's cpr chunks sit in cpr consecutive lanes
-        constexpr int EPC = 16 / (int)sizeof(T);
-        float xv[EPC], part = 0.f;
-        chunk_to_f32<T>(v[i], xv);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) part += xv[e] * dot_w[ch[i] * EPC + e];
-        part = in[i] ? part : 0.f;
-        for (int o = cpr >> 1; o >= 1; o >>= 1) part += __shfl_xor(part, o);
-        if (in[i] && ch[i] == 0) dot_out[row[i]] = part;
       }
     }
   }
@@ -443,7 +432,6 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
   const swn_chain_desc& d = args.d;
   char* act = smem;
   char* bias_lds = smem + Cfg<T>::ACT;  // ROW_ELEMS floats
-  float* sig_lds = (float*)(smem + Cfg<T>::ACT + ROW_ELEMS * 4);   // BM floats: <staged input row, heads_ws> (fused heads)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -516,8 +504,7 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
   }
   stage_bias(0);
   // ---- stage the chain input ----
-  load_rows_to_lds<T>(act, d.x, d.x_gather, d.x_save, grow0, rows_in_tile, d.layers[0].k, tid, d.x_scale, d.x_relu,
-                      d.heads_raw ? d.heads_ws : nullptr, sig_lds);
+  load_rows_to_lds<T>(act, d.x, d.x_gather, d.x_save, grow0, rows_in_tile, d.layers[0].k, tid, d.x_scale, d.x_relu);
   __syncthreads();
 
   f32x16_t acc[MI][NI];
@@ -654,7 +641,7 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
       const int cpr = row_bytes >> 4;
       const int sh = 31 - __builtin_clz(cpr);
       const int total = rows_in_tile * cpr;
-      if (last && d.comb_y) {
+      if (TAG == 5 && last && d.comb_y) {     // (only the tail-backward instantiation carries this code: registers)
         // Combine backward on the way out (include/swn.h).  A row's cpr chunks sit in cpr consecutive lanes (NT is a multiple of cpr:
         // a thread keeps its chunk column).  The global operands of UB chunks are fetched together, ahead of the arithmetic.
         constexpr int EPC = 16 / (int)sizeof(T), UB = 8;
@@ -694,15 +681,7 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
             }
           }
         }
-      } else {
-      constexpr int EPC_ = 16 / (int)sizeof(T);
-      float hwc[3][EPC_];          // fused heads: this thread's chunk column of the colour weights (NT is a multiple of cpr)
-      if (last && d.heads_raw) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-#pragma unroll
-          for (int e = 0; e < EPC_; ++e) hwc[q][e] = d.heads_wc[q * n + (tidw & (cpr - 1)) * EPC_ + e];
-      }
+      } else
       for (int c = tidw; c < total; c += NT) {
         const int row = c >> sh, ch = c & (cpr - 1);
         uint4 v = load_chunk_from_act<T>(act, row, ch);
@@ -714,33 +693,9 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
             v = add_chunks<T>(v, a);
           }
         }
-        if (last && d.heads_raw) {      // the output heads (include/swn.h): colour dots over the row's cpr lanes, sigma from the staging pass
-          constexpr int EPC = 16 / (int)sizeof(T);
-          float hv[EPC], c0 = 0.f, c1 = 0.f, c2 = 0.f;
-          chunk_to_f32<T>(v, hv);
-#pragma unroll
-          for (int e = 0; e < EPC; ++e) {
-            c0 = fmaf(hv[e], hwc[0][e], c0);
-            c1 = fmaf(hv[e], hwc[1][e], c1);
-            c2 = fmaf(hv[e], hwc[2][e], c2);
-          }
-          for (int o = cpr >> 1; o >= 1; o >>= 1) { c0 += __shfl_xor(c0, o); c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); }
-          // (every lane of the row evaluates the nonlinearities - the sums are the same in all of them after the butterfly - and one
-          //  stores: inside an `if (ch == 0)` region, with lanes 0 / 16 / 32 / 48 active, lane 48 returned a wrong FIRST sigmoid a few
-          //  times per 10^5 rows on gfx950; uniform control flow does not)
-          const long gr = grow0 + row;
-          const float u = sig_lds[row] + d.heads_bs[0] + (d.heads_noise ? d.heads_noise[gr] : 0.f) - 1.f;   // ShiftedSoftplus, models/nerf.py:68-69
-          float4 o4;
-          o4.x = 1.f / (1.f + expf(-(c0 + d.heads_bc[0])));
-          o4.y = 1.f / (1.f + expf(-(c1 + d.heads_bc[1])));
-          o4.z = 1.f / (1.f + expf(-(c2 + d.heads_bc[2])));
-          o4.w = u > 20.f ? u : log1pf(expf(u));
-          if (ch == 0) *(float4*)(d.heads_raw + gr * 4) = o4;
-        }
         // (plain stores: these tensors are read back by the next kernels while still on-die; non-temporal stores measured 5 % slower
         //  per step here - unlike the expert chains' seven write-only activation streams, chain_big.hip)
         *(uint4*)((char*)outp + (grow0 + row) * row_bytes + ch * 16) = v;
-      }
       }
     }
     // no barrier needed here: the next layer only reads `act` until its own post-K-loop barrier.
@@ -833,7 +788,7 @@ static int chain_launch(const swn_chain_desc& d, void* stream) {
   if (!d.group_rows) a.d.group_rows_clamp = d.group_stride;
   const long grid = (long)a.tiles_per_group * d.n_groups;
   SWN_CHECK(grid > 0 && grid < (1L << 31), "swn_mlp_chain: grid %ld out of range", grid);
-  int lds = (d.dtype == SWN_HALF ? Cfg<bf16_t>::ACT : Cfg<float>::ACT) + ROW_ELEMS * 4 + 256;      // tile + bias + the heads' 64 row sums
+  int lds = (d.dtype == SWN_HALF ? Cfg<bf16_t>::ACT : Cfg<float>::ACT) + ROW_ELEMS * 4;
 #ifdef SWN_EXP_LDSPAD
   lds += SWN_EXP_LDSPAD;      // experiment: fewer resident workgroups per CU (scripts/chain_timing.py)
 #endif
@@ -958,18 +913,12 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   SWN_CHECK(d.tag >= 0 && d.tag <= 6, "swn_mlp_chain: tag %d not in [0,6]", d.tag);
   SWN_CHECK(!(wide && concat), "swn_mlp_chain: concat-skip layers are built for the 256-feature kernels only");
   SWN_CHECK(d.geometry >= 0 && d.geometry <= 5, "swn_mlp_chain: geometry %d not in [0,5]", d.geometry);
-  if (d.heads_raw) {
-    const int nl = d.layers[d.n_layers - 1].n, esz = d.dtype == SWN_F32 ? 4 : 2;
-    SWN_CHECK(d.heads_ws && d.heads_bs && d.heads_wc && d.heads_bc, "swn_mlp_chain: fused heads need heads_ws / heads_bs / heads_wc / heads_bc");
-    SWN_CHECK(nl * esz <= 1024 && d.layers[0].k * esz <= 1024 && !d.comb_y && !d.y_add, "swn_mlp_chain: fused heads: rows of at most 1 KiB, no y_add / combine");
-    SWN_CHECK(d.geometry < 2, "swn_mlp_chain: fused heads run on the 64-row kernels (geometry 0 / 1)");
-  }
   if (d.comb_y) {
     const int nl = d.layers[d.n_layers - 1].n;
     SWN_CHECK(d.comb_gate && d.comb_dgate, "swn_mlp_chain: combine backward needs comb_gate and comb_dgate");
     SWN_CHECK((nl == 128 || nl == 256 || nl == 512) && nl * (d.dtype == SWN_F32 ? 4 : 2) <= 1024,
               "swn_mlp_chain: combine backward: last layer of 128 / 256 / 512 features, at most 1 KiB per row");
-    SWN_CHECK(d.geometry < 2, "swn_mlp_chain: combine backward runs on the 64-row kernels (geometry 0 / 1)");
+    SWN_CHECK(d.geometry < 2 && (d.tag & 0xFF) == 5, "swn_mlp_chain: combine backward runs on the 64-row kernels (geometry 0 / 1), tag 5");
   }
   {   // 256-row geometry (chain_big.hip).  Never chosen silently for bf16: the ReLU mask layout differs between the geometries,
       // and a backward chain must run on the geometry of the forward chain that recorded its masks - the caller pairs them.

@@ -1097,7 +1097,7 @@ bool chain_big_eligible(const swn_chain_desc& d) {
 #else
   if (d.x_save || d.x_scale || d.y_add_gather) return false;
 #endif
-  if (d.comb_y || d.heads_raw) return false;
+  if (d.comb_y) return false;
   for (int l = 0; l < d.n_layers; ++l) {
     const swn_chain_layer& ly = d.layers[l];
     if (ly.n != 256 || ly.k != 256 || ly.rowbias || ly.skip > 1) return false;

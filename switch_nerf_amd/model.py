@@ -102,7 +102,6 @@ class SwitchNeRF:
         self._init_random(seed)
         self._bufs = {}
         self.profile = False          # bench.py: record HIP events around the major launches
-        self.fuse_heads = False       # evaluate the output heads inside the tail forward chain (see forward_net)
         self.events: Dict[str, list] = {}
         # side HIP stream: the HBM-bound expert weight-gradient GEMMs overlap with the rest of the backward pass
         self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
@@ -556,21 +555,12 @@ class SwitchNeRF:
         if row_range is not None:  # a row range of the point grid: the rows' rays through an explicit per-row gather
             rowbias, rpb = c["c_ray"].index_select(0, torch.arange(r0, r1, device=dev) // S), 1
             c["ragged"] = True
-        # ---- ... and the heads.  swn_mlp_chain can evaluate them inside the chain (sigma on the staged input rows y, colours on the output
-        #      rows h2: self.fuse_heads); measured on the headline recipe it is a wash (the launch and 1.6 GB of reads saved against the
-        #      work added to the chain's staging / write-out), so the separate kernel stays the default
-        esz = c["h2"].element_size()
-        fuse_heads = self.fuse_heads and max(M, H2) * esz <= 1024
-        if fuse_heads:
-            c["raw"] = _b("raw", (P, 4), torch.float32)
         o.mlp_chain(c["eo"], [o.Layer(self.wf["l1"], self.p["l1.b"].view(1, M), save=c["h1"] if sv else None),
                               o.Layer(self.wf["l2h"], None, relu=1, rowbias=rowbias, rows_per_bias=rpb)], c["h2"],
-                    group_stride=P, x_gather=c["row_of_tok"], x_save=c["y"], x_scale=c["gmax"], x_relu=True, tag=4,
-                    heads=(self.p["sigma.w"], self.p["sigma.b"], self.p["color.w"], self.p["color.b"], sigma_noise, c["raw"])
-                    if fuse_heads else None)
-        if not fuse_heads:
-            c["raw"] = o.heads_fwd(c["y"], c["h2"], self.p["sigma.w"], self.p["sigma.b"], self.p["color.w"], self.p["color.b"],
-                                   sigma_noise)
+                    group_stride=P, x_gather=c["row_of_tok"], x_save=c["y"], x_scale=c["gmax"], x_relu=True, tag=4)
+        # ---- heads
+        c["raw"] = o.heads_fwd(c["y"], c["h2"], self.p["sigma.w"], self.p["sigma.b"], self.p["color.w"], self.p["color.b"],
+                               sigma_noise)
         return c
 
     # ------------------------------------------------------------------------------------------ backward
