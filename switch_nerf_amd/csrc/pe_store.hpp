@@ -24,26 +24,37 @@ __device__ __forceinline__ void store_vals(T* dst, const float* v, int n_pad) {
 // between lanes): stage the block's rows in LDS and write them out as one contiguous, fully coalesced region (the block's
 // rows are consecutive in memory).  Launch with 128 threads (bf16) / 64 threads (fp32) per block, row p = global thread id;
 // surplus threads of the last block pass live = false.
-template <typename T>
-__device__ __forceinline__ void pe_store_rows(const float* v, int used, T* __restrict__ pe, int pe_stride, long p, bool live,
+template <typename T, int VN>
+__device__ __forceinline__ void pe_store_rows(const float (&v)[VN], int used, T* __restrict__ pe, int pe_stride, long p, bool live,
                                               long total_rows) {
-  const int step = 16 / (int)sizeof(T);
+  constexpr int step = 16 / (int)sizeof(T);
   constexpr int NT = sizeof(T) == 2 ? 128 : 64;                  // threads per block (see the launchers)
   constexpr int ROWB = 128 * (int)sizeof(T) + 16;                // LDS row stride: <= 128 columns, +16 B against bank conflicts
   __shared__ __attribute__((aligned(16))) char stage[NT * ROWB];
   const bool staged = pe_stride <= 128;                          // (uniform) wider rows fall back to direct stores
   T* dst = staged ? (T*)(stage + threadIdx.x * ROWB) : pe + p * pe_stride;
-  float tmp[8];
   if (live) {
-    for (int c0 = 0; c0 < pe_stride; c0 += step) {
+    // v[] is indexed with COMPILE-TIME indices only (a runtime index would put the whole row into scratch memory: 368 bytes per lane
+    // and two waves per SIMD for the positional-encoding kernels)
+    constexpr int VPAD = (VN + step - 1) / step * step;
+#pragma unroll
+    for (int c0 = 0; c0 < VPAD; c0 += step) {
+      if (c0 < pe_stride) {
+        float tmp[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tmp[j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < step; ++j) {
+          const int c = c0 + j;
+          tmp[j] = (c < VN && c < used) ? v[c < VN ? c : 0] : 0.f;
+        }
+        store_vals<T>(dst + c0, tmp, step);
+      }
+    }
+    for (int c0 = VPAD; c0 < pe_stride; c0 += step) {            // zero padding beyond the row buffer
+      float tmp[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) tmp[j] = 0.f;
-      for (int j = 0; j < step; ++j) {
-        const int c = c0 + j;
-        float val = 0.f;
-        if (c < used) val = v[c];                                // v[] is indexed with a runtime index only here
-        tmp[j] = val;
-      }
       store_vals<T>(dst + c0, tmp, step);
     }
   }
