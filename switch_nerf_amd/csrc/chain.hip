@@ -451,6 +451,11 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
     tile = q - s_ * args.tiles_per_group;
     g = ((x + s_) & 7) + 8 * s_;     // rotated per 8 groups: every XCD meets every weight set - an expert that draws more rows than the
                                      // others (unbalanced routing) would otherwise make ITS XCD the long pole of the launch
+  } else if (d.n_groups == 1 && args.tiles_per_group >= 64) {
+    // one group (the dense chains): XCD x walks its own contiguous eighth of the rows - the workgroups resident together on an XCD
+    // write a few MB of consecutive rows instead of every eighth 32 KiB piece of a 32 MB window (grid = 8 * ceil(tiles / 8))
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    tile = x * ((args.tiles_per_group + 7) >> 3) + q;
   }
 #endif
   int rows_valid = d.group_stride;
@@ -616,7 +621,7 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
       int l31e = l31, lhie = lhi;
       asm volatile("" : "+v"(l31e), "+v"(lhie));
       const float* rbp = ly.rowbias ? ly.rowbias + (grow0 / ly.rows_per_bias) * (size_t)n : nullptr;   // tile-aligned per-ray bias
-      uint32_t* mk = ly.mask ? ly.mask + (size_t)(blockIdx.x * 4 + wn) * MI * 64 * (NI / 2) + lane : nullptr;
+      uint32_t* mk = ly.mask ? ly.mask + (size_t)((g * args.tiles_per_group + tile) * 4 + wn) * MI * 64 * (NI / 2) + lane : nullptr;
       const int nvalid = n - wn * 32 * NI;   // feature tiles of this wave that exist: nvalid >= 32 NI -> all
       epilogue_body<T, true, 0, false, false, false>(acc, act, bias_lds, rbp, mk, wn, l31e, lhie, nvalid, grow0, ly.rows_per_bias, n,
                                                      ly.relu, ly.skip == 1, ly.b != nullptr, rows_in_tile);
@@ -786,7 +791,10 @@ static int chain_launch(const swn_chain_desc& d, void* stream) {
   const int bm = d.dtype == SWN_HALF ? Cfg<bf16_t>::BM : Cfg<float>::BM;
   a.tiles_per_group = cdiv(d.group_rows ? (d.group_rows_clamp < d.group_stride ? d.group_rows_clamp : d.group_stride) : d.group_stride, bm);
   if (!d.group_rows) a.d.group_rows_clamp = d.group_stride;
-  const long grid = (long)a.tiles_per_group * d.n_groups;
+  long grid = (long)a.tiles_per_group * d.n_groups;
+#ifndef SWN_NO_SEQ_TILES
+  if (d.n_groups == 1 && a.tiles_per_group >= 64) grid = 8L * ((a.tiles_per_group + 7) >> 3);      // (see the tile mapping in the kernel)
+#endif
   SWN_CHECK(grid > 0 && grid < (1L << 31), "swn_mlp_chain: grid %ld out of range", grid);
   int lds = (d.dtype == SWN_HALF ? Cfg<bf16_t>::ACT : Cfg<float>::ACT) + ROW_ELEMS * 4;
 #ifdef SWN_EXP_LDSPAD
