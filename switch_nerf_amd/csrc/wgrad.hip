@@ -31,7 +31,12 @@ __device__ __attribute__((aligned(16))) uint32_t g_zero_page[256];   // 1 KiB of
 // queue (s_waitcnt vmcnt(0)) in front of it; the waits here are counted by hand.  M0 is saved / restored (cdna_hip_programming.md 5.7).
 __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
   uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+#if defined(SWN_WG_NT) && SWN_WG_NT
+#define SWN_WG_LOAD_POLICY " nt"      // experiment: non-temporal operand loads
+#else
+#define SWN_WG_LOAD_POLICY ""
+#endif
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" SWN_WG_LOAD_POLICY "\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
