@@ -1,11 +1,14 @@
 """Router kernels against a torch fp64 reference + timing.  python scripts/gate_check.py   (SWN_GATE_VALU=1: the VALU kernels)"""
 import sys, os, torch
 sys.path.insert(0, '.')
-from switch_nerf_amd import ops as o
+from switch_nerf_amd import ops as o, _lib
 dev = torch.device('cuda')
+HALF = torch.float16 if os.environ.get('GATE_DTYPE') == 'fp16' else torch.bfloat16
+if HALF == torch.float16:
+    _lib.use_half('f16')
 torch.manual_seed(0)
 G, E = 256, 8
-which = "VALU" if os.environ.get("SWN_GATE_VALU") else "MFMA"
+which = ("VALU" if os.environ.get("SWN_GATE_VALU") else "MFMA") + (" fp16" if os.environ.get("GATE_DTYPE") == "fp16" else "")
 
 
 def ref(g, ln_w, ln_b, wg):
@@ -17,7 +20,7 @@ def ref(g, ln_w, ln_b, wg):
 
 
 for P, mean_shift, E_ in ((5000, 0.0, 8), (32768, 0.7, 8), (33, 0.0, 8), (4097, 3.0, 5), (131072, 0.2, 8)):
-    g = (torch.randn(P, G, device=dev) * 1.3 + mean_shift).bfloat16()
+    g = (torch.randn(P, G, device=dev) * 1.3 + mean_shift).to(HALF)
     ln_w = 1.0 + 0.2 * torch.randn(G, device=dev)
     ln_b = 0.1 * torch.randn(G, device=dev)
     wg = torch.randn(E_, G, device=dev) * 0.3
@@ -39,7 +42,7 @@ for P, mean_shift, E_ in ((5000, 0.0, 8), (32768, 0.7, 8), (33, 0.0, 8), (4097, 
               f"{gap.max().item() if mis.any() else 0:.1e}), gmax consistency {gm_err:.1e}, stats err {st_err:.1e}, sums {(gates.sum(1) - 1).abs().max().item():.1e}")
 
 P = 2097152
-g = (torch.randn(P, G, device=dev) * 1.3).bfloat16()
+g = (torch.randn(P, G, device=dev) * 1.3).to(HALF)
 ln_w = 1.0 + 0.2 * torch.randn(G, device=dev); ln_b = 0.1 * torch.randn(G, device=dev); wg = torch.randn(E, G, device=dev) * 0.3
 for _ in range(2):
     o.gate_fwd(g, ln_w, ln_b, wg)
@@ -55,7 +58,7 @@ print(f"{which} gate_fwd 2M tokens: {ms:.3f} ms = {P * G * 2 / ms / 1e9:.2f} TB/
 # ---------------------------------------------------------------- backward: against torch autograd in fp64
 print("backward")
 for P, seg, E_, ln in ((8192, 4096, 8, True), (8192, 8192, 8, False), (4099 * 2, 4099, 4, True), (65536, 16384, 8, True)):
-    g = (torch.randn(P, G, device=dev) * 1.3 + 0.3).bfloat16()
+    g = (torch.randn(P, G, device=dev) * 1.3 + 0.3).to(HALF)
     ln_w = (1.0 + 0.2 * torch.randn(G, device=dev)) if ln else None
     ln_b = (0.1 * torch.randn(G, device=dev)) if ln else None
     wg = torch.randn(E_, G, device=dev) * 0.3
@@ -84,7 +87,7 @@ for P, seg, E_, ln in ((8192, 4096, 8, True), (8192, 8192, 8, False), (4099 * 2,
     print(line)
 
 P, seg = 2097152, 131072
-g = (torch.randn(P, G, device=dev) * 1.3).bfloat16()
+g = (torch.randn(P, G, device=dev) * 1.3).to(HALF)
 gates, idx, gmax, stats = o.gate_fwd(g, ln_w, ln_b, wg) if False else o.gate_fwd(g, 1.0 + 0.2 * torch.randn(G, device=dev), 0.1 * torch.randn(G, device=dev), torch.randn(E, G, device=dev) * 0.3)
 ln_w = 1.0 + 0.2 * torch.randn(G, device=dev); ln_b = 0.1 * torch.randn(G, device=dev); wg = torch.randn(E, G, device=dev) * 0.3
 counts = torch.randint(0, seg, (P // seg, E), device=dev, dtype=torch.int32); coef = torch.rand(P // seg, device=dev) * 1e-4; dgmax = torch.randn(P, device=dev)

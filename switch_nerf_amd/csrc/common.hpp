@@ -75,14 +75,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 int chain_wide_launch(const swn_chain_desc& d, void* stream);   // chain.hip compiled with -DSWN_WIDE=1
 int chain_wide_tile_rows(int dtype);
 int chain_concat_launch(const swn_chain_desc& d, void* stream); // chain.hip compiled with -DSWN_CONCAT=1 (concat-skip layer mode)
-#ifndef SWN_HALF_F16
 int gate_fwd_mfma_launch(const void* g, const float* ln_w, const float* ln_b, const float* wg, int n_tokens, int n_experts, float* gates,
                          int32_t* idx, float* gmax, float* stats, void* stream);
 int gate_bwd_mfma_launch(const void* g, const float* ln_w, const float* wg, const float* gates, const int32_t* idx, const float* d_gmax,
                          const float* stats, const int32_t* counts, const float* laux_coef, int seg_tokens, int n_tokens, int n_experts,
                          void* dg, float* dlogits, float* partial, void* stream);
 int gate_bwd_mfma_blocks(int n_tokens);
-#endif
 bool chain_big_eligible(const swn_chain_desc& d);                // chain_big.hip: the 256-row geometry
 int chain_big_launch(const swn_chain_desc& d, void* stream);
 int chain_big_tile_rows(int geometry);

@@ -1044,12 +1044,10 @@ extern "C" int swn_gate_fwd(const void* g, int dtype, const float* ln_w, const f
   SWN_CHECK((ln_w == nullptr) == (ln_b == nullptr), "swn_gate_fwd: ln_w / ln_b must both be given or both NULL");
   if (ln_w) SWN_CHECK(stats, "swn_gate_fwd: stats required with LayerNorm");
   const int blocks = row_blocks(n_tokens);
-#ifndef SWN_HALF_F16
-  // bf16 rows of 256, up to 8 experts: the contraction on the matrix pipe (gate_mfma.hip; SWN_GATE_VALU=1 keeps the VALU kernel: A/B runs)
+  // 16-bit rows of 256, up to 8 experts: the contraction on the matrix pipe (gate_mfma.hip; SWN_GATE_VALU=1 keeps the VALU kernel: A/B runs)
   static const bool valu_only = getenv("SWN_GATE_VALU") != nullptr;
   if (dtype == SWN_HALF && gate_dim == 256 && n_experts <= 8 && !valu_only)
     return swn::gate_fwd_mfma_launch(g, ln_w, ln_b, wg, n_tokens, n_experts, gates, idx, gmax, stats, stream);
-#endif
   if (dtype == SWN_HALF) {
     const bf16_t* gp = (const bf16_t*)g;
     GATE_DISPATCH(bf16_t, gate_fwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, n_tokens, n_experts,
@@ -1086,9 +1084,7 @@ static int gate_dwg_tokens_per_block(int n_tokens) {
 extern "C" size_t swn_gate_bwd_scratch_floats(int n_tokens, int gate_dim, int n_experts) {   // dlogits | per-block partials | their sum
   const size_t ps = (size_t)n_experts * gate_dim + n_experts;
   size_t blocks = (size_t)cdiv(n_tokens, gate_dwg_tokens_per_block(n_tokens));
-#ifndef SWN_HALF_F16
   if ((size_t)swn::gate_bwd_mfma_blocks(n_tokens) > blocks) blocks = (size_t)swn::gate_bwd_mfma_blocks(n_tokens);
-#endif
   return (size_t)n_tokens * n_experts + (blocks + 1) * ps;
 }
 
@@ -1109,15 +1105,11 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
   float* dwg_partial = dlogits + (size_t)n_tokens * n_experts;          // second part of the scratch: [dwg_blocks][E * G + E]
   const int ps = n_experts * gate_dim + n_experts;
   float* msum = dwg_partial + (size_t)dwg_blocks * ps;                  // third part: [E * G + E]
-  bool mfma_path = false;
-#ifndef SWN_HALF_F16
   static const bool valu_only = getenv("SWN_GATE_VALU") != nullptr;
-  mfma_path = dtype == SWN_HALF && gate_dim == 256 && n_experts <= 8 && !valu_only;
-#endif
+  const bool mfma_path = dtype == SWN_HALF && gate_dim == 256 && n_experts <= 8 && !valu_only;
   if (dtype == SWN_HALF) {
     const bf16_t* gp = (const bf16_t*)g;
     bf16_t* dgp = (bf16_t*)dg;
-#ifndef SWN_HALF_F16
     if (mfma_path) {       // data path AND the per-block sums of the parameter gradients on the matrix pipe (gate_mfma.hip)
       dwg_blocks = swn::gate_bwd_mfma_blocks(n_tokens);
       msum = dwg_partial + (size_t)dwg_blocks * ps;
@@ -1125,7 +1117,6 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
                                                dlogits, dwg_partial, stream);
       if (rc) return rc;
     } else
-#endif
     GATE_DISPATCH(bf16_t, gate_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, gates, idx, d_gmax,
                   stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dgp, dlogits, d_ln_w, d_ln_b);
     if (!mfma_path) {

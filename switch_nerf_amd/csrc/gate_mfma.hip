@@ -1,7 +1,7 @@
-// Router forward on the matrix pipe (bf16 gate input, gate_dim 256, up to 8 experts): the LayerNorm + fp32 router + softmax + top-1 of
+// Router forward on the matrix pipe (16-bit gate input, gate_dim 256, up to 8 experts): the LayerNorm + fp32 router + softmax + top-1 of
 // NeRFMoE.forward / TopKGate (/root/reference/switch_nerf/models/nerf_moe.py:370-372, modules/tutel_moe_ext/tutel_moe_layer_nobatch.py:
-// 105-126) - the same contract as gate_fwd_kernel in elementwise.hip, which stays the kernel of the fp32 (parity) mode, of the fp16
-// build and of the other shapes.
+// 105-126) - the same contract as gate_fwd_kernel in elementwise.hip, which stays the kernel of the fp32 (parity) mode and of the
+// other shapes.
 //
 // Why: gate_fwd_kernel spends ~225 VALU instructions per token on 2048 fp32 multiply-adds and their 16-lane reductions (0.68 ms per
 // 2M tokens against 0.25 ms for reading the rows).  Here the contraction runs as bf16 MFMAs WITHOUT giving up the fp32 router:
@@ -16,13 +16,25 @@
 // weight fragments live in registers for the whole kernel.  No workgroup barrier in the loop; two 4-wave workgroups per CU.
 #include "common.hpp"
 
-#ifndef SWN_HALF_F16
 namespace swn {
 
 typedef __attribute__((ext_vector_type(8))) short gm_bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float gm_f32x16_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t gm_u32x4_t;
 typedef __attribute__((ext_vector_type(2))) float gm_f32x2_t;
+// The 16-bit type of the build (bf16, or IEEE half in the -DSWN_HALF_F16 build): element access through common.hpp's bf16_to_f32 /
+// f32_to_bf16, which are the fp16 conversions there.  fp16 has 5 exponent bits: the split terms of a weight (w ~ 0.05: remainders
+// ~ 2e-5, ~ 1e-8) and small dlogits would land in its subnormals, so the fp16 build scales them by exact powers of two before the
+// split and scales the MFMA results back (GM_SW, GM_SD; 1 for bf16).
+#ifdef SWN_HALF_F16
+#define GM_MFMA16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(swn_mfma16_t, a), __builtin_bit_cast(swn_mfma16_t, b), c, 0, 0, 0)
+constexpr float GM_SW = 4096.f, GM_SD = 1024.f;
+#else
+#define GM_MFMA16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(swn_mfma16_t, a), __builtin_bit_cast(swn_mfma16_t, b), c, 0, 0, 0)
+constexpr float GM_SW = 1.f, GM_SD = 1.f;
+#endif
+__device__ __forceinline__ float gm_lo(uint32_t v) { return bf16_to_f32((bf16_t)(v & 0xFFFFu)); }
+__device__ __forceinline__ float gm_hi(uint32_t v) { return bf16_to_f32((bf16_t)(v >> 16)); }
 #define GM_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 #define GM_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
 
@@ -51,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_mfma_kernel(const bf16_t* __r
     const float lw = LN ? ln_w[k] : 1.f, lb = LN ? ln_b[k] : 0.f;
     for (int e = 0; e < E; ++e) {
       const float wv = wg[(long)e * 256 + k];
-      const float wp = wv * lw;
+      const float wp = wv * lw * GM_SW;
       const bf16_t hi = f32_to_bf16(wp);
       const float r1 = wp - bf16_to_f32(hi);
       const bf16_t mid = f32_to_bf16(r1);
@@ -61,14 +73,14 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_mfma_kernel(const bf16_t* __r
       *(bf16_t*)(smem + gm_elem(16 + e, k)) = lo;
       if (LN) {
         // c1 must be the sum of what the MFMA multiplies: hi + mid + lo (= wp to the last bit or two)
-        const float wq = bf16_to_f32(hi) + (bf16_to_f32(mid) + bf16_to_f32(lo));
+        const float wq = (bf16_to_f32(hi) + (bf16_to_f32(mid) + bf16_to_f32(lo))) * (1.f / GM_SW);
         float a = wq, b = lb * wv;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
         if (lane == 0) { cst[w * 16 + e] = a; cst[w * 16 + 8 + e] = b; }      // (summed below in a fixed order: every workgroup gets the same bits)
       }
     }
-    *(bf16_t*)(smem + gm_elem(24, k)) = (bf16_t)0x3F80;      // 1.0
+    *(bf16_t*)(smem + gm_elem(24, k)) = (bf16_t)(SWN_HALF_ONE_X2 & 0xFFFFu);      // 1.0
   }
   __syncthreads();
   gm_u32x4_t wfr[16];
@@ -110,12 +122,12 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_mfma_kernel(const bf16_t* __r
     for (int ks = 0; ks < 16; ++ks) {
       if (ks + 1 < 16) xf[(ks + 1) & 1] = *(const gm_u32x4_t*)(smem + (t_base ^ (uint32_t)((ks + 1) << 5)));
       const gm_u32x4_t x = xf[ks & 1];
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gm_bf16x8_t, wfr[ks]), __builtin_bit_cast(gm_bf16x8_t, x), acc, 0, 0, 0);
+      acc = SWN_MFMA_32x32x16(wfr[ks], x, acc);
       if (LN) {
 #pragma unroll
         for (int i = 0; i < 4; i += 2) {
-          const gm_f32x2_t u0 = {__uint_as_float(x[i] << 16), __uint_as_float(x[i] & 0xFFFF0000u)};
-          const gm_f32x2_t u1 = {__uint_as_float(x[i + 1] << 16), __uint_as_float(x[i + 1] & 0xFFFF0000u)};
+          const gm_f32x2_t u0 = {gm_lo(x[i]), gm_hi(x[i])};
+          const gm_f32x2_t u1 = {gm_lo(x[i + 1]), gm_hi(x[i + 1])};
           q2a += u0 * u0;
           q2b += u1 * u1;
         }
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void gate_fwd_mfma_kernel(const bf16_t* __r
     // ---- this lane: token l31, experts 4 lhi + j (accumulator rows 8 g4 + 4 lhi + j: g4 = 0 hi, 1 mid, 2 lo, 3: row 24 = sum x) ----
     float logit[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) logit[j] = (acc[j] + acc[4 + j]) + acc[8 + j];
+    for (int j = 0; j < 4; ++j) logit[j] = ((acc[j] + acc[4 + j]) + acc[8 + j]) * (1.f / GM_SW);
     float mean = 0.f, rstd = 1.f;
     if (LN) {
       const float sx = __shfl(acc[12], l31);                     // row 24 lives in the lower half-wave
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_mfma_kernel(const bf16_t* __r
     const float lw = LN ? ln_w[k] : 1.f;
     uint32_t hi[4] = {0u, 0u, 0u, 0u}, mid[4] = {0u, 0u, 0u, 0u};
     for (int e = 0; e < E; ++e) {
-      const float wp = wg[(long)e * 256 + k] * lw;
+      const float wp = wg[(long)e * 256 + k] * lw * GM_SW;
       const bf16_t h = f32_to_bf16(wp);
       const bf16_t m = f32_to_bf16(wp - bf16_to_f32(h));
       hi[e >> 1] |= (uint32_t)h << (16 * (e & 1));
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_mfma_kernel(const bf16_t* __r
       uint32_t v = 0u;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const float x = da[2 * i + h];
+        const float x = da[2 * i + h] * GM_SD;
         const bf16_t hd = f32_to_bf16(x);
         const bf16_t val = lhi ? f32_to_bf16(x - bf16_to_f32(hd)) : hd;
         v |= (uint32_t)val << (16 * h);
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_mfma_kernel(const bf16_t* __r
     if (partial) {          // dlr^T for the token GEMM: rows e (head) / 8 + e (remainder), column = this lane's token
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float x = live ? da[e] * rstd : 0.f;
+        const float x = live ? da[e] * rstd * GM_SD : 0.f;
         const bf16_t hd = f32_to_bf16(x);
         const bf16_t val = lhi ? f32_to_bf16(x - bf16_to_f32(hd)) : hd;
         *(bf16_t*)(dstage + (8 * lhi + e) * 64 + l31 * 2) = val;
@@ -344,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_mfma_kernel(const bf16_t* __r
         asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b1) : "v"(a1) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const gm_u32x4_t bx = {b0.x, b0.y, b1.x, b1.y};
-        macc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gm_bf16x8_t, afr), __builtin_bit_cast(gm_bf16x8_t, bx), macc[nt], 0, 0, 0);
+        macc[nt] = GM_MFMA16x16x32(afr, bx, macc[nt]);
       }
     }
 
@@ -353,8 +365,12 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_mfma_kernel(const bf16_t* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const gm_u32x4_t wh = *(const gm_u32x4_t*)(wrow + nt * 512), wm = *(const gm_u32x4_t*)(wrow + 4096 + nt * 512);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gm_bf16x8_t, wh), __builtin_bit_cast(gm_bf16x8_t, bfr), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gm_bf16x8_t, wm), __builtin_bit_cast(gm_bf16x8_t, bfr), acc, 0, 0, 0);
+      acc = SWN_MFMA_32x32x16(wh, bfr, acc);
+      acc = SWN_MFMA_32x32x16(wm, bfr, acc);
+#ifdef SWN_HALF_F16
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] *= 1.f / (GM_SW * GM_SD);
+#endif
       return acc;
     };
     const float mr = mean * rstd;
@@ -366,8 +382,8 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_mfma_kernel(const bf16_t* __r
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const uint2 xv = *(const uint2*)(smem + (e_base ^ (uint32_t)((4 * nt + g4) << 4)));
-          const float x0 = __uint_as_float(xv.x << 16), x1 = __uint_as_float(xv.x & 0xFFFF0000u);
-          const float x2 = __uint_as_float(xv.y << 16), x3 = __uint_as_float(xv.y & 0xFFFF0000u);
+          const float x0 = gm_lo(xv.x), x1 = gm_hi(xv.x);
+          const float x2 = gm_lo(xv.y), x3 = gm_hi(xv.y);
           const float d0 = acc[4 * g4], d1 = acc[4 * g4 + 1], d2 = acc[4 * g4 + 2], d3 = acc[4 * g4 + 3];
           s1 += (d0 + d1) + (d2 + d3);
           s2 += d0 * (x0 * rstd - mr) + d1 * (x1 * rstd - mr) + d2 * (x2 * rstd - mr) + d3 * (x3 * rstd - mr);
@@ -387,8 +403,8 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_mfma_kernel(const bf16_t* __r
         float o[4];
         if (LN) {
           const uint2 xv = *(const uint2*)(smem + a);
-          const float xh0 = __uint_as_float(xv.x << 16) * rstd - mr, xh1 = __uint_as_float(xv.x & 0xFFFF0000u) * rstd - mr;
-          const float xh2 = __uint_as_float(xv.y << 16) * rstd - mr, xh3 = __uint_as_float(xv.y & 0xFFFF0000u) * rstd - mr;
+          const float xh0 = gm_lo(xv.x) * rstd - mr, xh1 = gm_hi(xv.x) * rstd - mr;
+          const float xh2 = gm_lo(xv.y) * rstd - mr, xh3 = gm_hi(xv.y) * rstd - mr;
           o[0] = rstd * (acc[4 * g4] - s1 - xh0 * s2);
           o[1] = rstd * (acc[4 * g4 + 1] - s1 - xh1 * s2);
           o[2] = rstd * (acc[4 * g4 + 2] - s1 - xh2 * s2);
@@ -432,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_mfma_kernel(const bf16_t* __r
     float* part = partial + (size_t)blockIdx.x * (E * 256 + E);
     for (int i = tid; i < E * 256; i += 256) {
       const int e = i >> 8, k = i & 255;
-      part[i] = (red[e * 256 + k] + red[(8 + e) * 256 + k]) - (LN ? red[16 * 256 + e] : 0.f);
+      part[i] = (red[e * 256 + k] + red[(8 + e) * 256 + k]) * (1.f / GM_SD) - (LN ? red[16 * 256 + e] : 0.f);
     }
     if (tid < E) part[E * 256 + tid] = red[16 * 256 + 8 + tid];
   }
@@ -465,4 +481,3 @@ int gate_bwd_mfma_launch(const void* g, const float* ln_w, const float* wg, cons
 }
 
 }  // namespace swn
-#endif
