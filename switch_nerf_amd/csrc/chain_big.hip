@@ -559,11 +559,10 @@ __global__ __launch_bounds__(G::NT, G::OCC) void chainb_kernel(const Args args) 
 //     phase 2 l + 1 : group 0 runs the epilogue of layer l        | group 1 runs the K loop of layer l
 // so a SIMD always has one wave issuing MFMAs and one doing the VALU / LDS / store work.  One workgroup barrier per phase (two per
 // layer) instead of one per K step:
-//   * weights: wave (g, fg) copies the fragments of ITS two feature tiles itself (`buffer_load ... lds`, 2 x 1 KiB per K step) into
-//     the ring of its SIMD (3 slots x 2 KiB: the same LDS bytes as chainb's ring), three steps ahead, and waits for them with a
-//     counted vmcnt - no other wave reads them.  The two waves of a SIMD use the ring in turn; the last three steps of a K loop
-//     copy the first three steps of the ring's next user (the partner: same layer; or this group: next layer), landed before the
-//     phase barrier.  The weights pass the CU twice per 256 rows (the price of the phase shift: 2x chainb's weight copies);
+//   * weights: wave (g, fg) loads the fragments of ITS two feature tiles itself, straight into a 4-deep register ring (2 x 1 KiB per
+//     K step, three steps ahead, counted vmcnt; the first three steps of a K loop are requested at the end of the wave's preceding
+//     epilogue phase) - no other wave reads them, nothing is handed over.  The weights pass the CU twice per 256 rows (the price of
+//     the phase shift: 2x chainb's weight copies);
 //   * an epilogue wave first writes out the PARTNER group's rows (the input tile of the K loop the partner is running = a saved
 //     activation: 16 x 1 KiB pieces per wave, non-temporal, never waited for inside the phase - the following K phase's first counted
 //     vmcnt is where a backlog of the store stream shows), then rewrites its own rows in place; bias and stored masks come straight
@@ -572,85 +571,10 @@ __global__ __launch_bounds__(G::NT, G::OCC) void chainb_kernel(const Args args) 
 //     meet at an LDS counter (the only place where a group has to synchronise inside a phase).
 // Results and the ReLU mask layout are identical to chainb_kernel's (same K order per accumulator, same epilogue code).
 // =================================================================================================================================
-struct PhaseK {};
-
 #define SWN_WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
-template <typename E>
-__device__ __forceinline__ void k_phase(f32x16_t (&acc)[4][2], const Ctx& cx, __amdgpu_buffer_rsrc_t rs_cur, __amdgpu_buffer_rsrc_t rs_nxt) {
-  typedef G256 G;
-  constexpr int MI = 4;
-  char* smem = cx.smem;
-  const int lane16 = cx.lane * 16;
-  const int fg = cx.w & 3;
-  u32x4_t fa[2][MI], fw[2][2];
-  uint32_t a_base = cx.a_base, wf_base = cx.wf_base;
-  asm volatile("" : "+v"(a_base), "+v"(wf_base));
-  auto read_w = [&](int ks, int set, int ni) {
-    fw[set][ni] = *(const u32x4_t*)(smem + wf_base + cx.slot_off[ks % 3] + ni * 1024);
-  };
-  auto read_a = [&](int ks, int set, int mi) {
-    fa[set][mi] = *(const u32x4_t*)(smem + (a_base ^ (uint32_t)(ks << 5)) + mi * (32 * ROWB));
-  };
-  auto copy = [&](int ks, int i) {     // feature tile 2 fg + i of step ks + 3 of the ring's stream -> the slot of step ks (its fragments are in registers)
-    const int nx = ks + 3, t = 2 * fg + i;
-    if (nx < KSTEPS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_cur, SWN_LDS(smem + G::RING0 + cx.slot_off[nx % 3] + t * 1024), 16, lane16, (t * KSTEPS + nx) * 1024, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_nxt, SWN_LDS(smem + G::RING0 + cx.slot_off[nx % 3] + t * 1024), 16, lane16, (t * KSTEPS + nx - KSTEPS) * 1024, 0, 0);
-  };
-  // The six fragment reads of step ks + 1 (w0 w1 a0 a1 a2 a3, in this order) are issued right behind the first MFMA of step ks and
-  // waited for ONE BY ONE (LDS returns in order: lgkmcnt(n) = all but the youngest n have landed) just before the MFMA that needs
-  // them: a lone wave has nobody to hide an lgkmcnt(0) behind.  Nothing else in the loop counts in lgkmcnt (the copies are vmcnt).
-  read_w(0, 0, 0); read_w(0, 0, 1);
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) read_a(0, 0, mi);
-#pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks) {
-    const int cur = ks & 1, nxt = cur ^ 1;
-    const bool more = ks + 1 < KSTEPS;
-    if (ks >= 2) SWN_WAIT_VM(2);            // this wave's copies of step ks + 1 have landed (younger: the two copies of step ks + 2)
-    SWN_WAIT_LGKM(3);                       // w0 w1 a0 of this step
-    SWN_PIN();
-#ifdef SWN_ABL_NOMFMA
-#define SWN_MM(mi, ni) asm volatile("" :: "v"(fw[cur][ni]), "v"(fa[cur][mi]))
-#else
-#define SWN_MM(mi, ni) acc[mi][ni] = E::mfma(fw[cur][ni], fa[cur][mi], acc[mi][ni])
-#endif
-    SWN_MM(0, 0);
-    SWN_PIN();
-    if (more) {
-      read_w(ks + 1, nxt, 0); read_w(ks + 1, nxt, 1);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) read_a(ks + 1, nxt, mi);
-    }
-    SWN_PIN();
-    SWN_MM(0, 1);
-    SWN_PIN();
-    copy(ks, 0);
-    if (more) SWN_WAIT_LGKM(8); else SWN_WAIT_LGKM(2);      // a1
-    SWN_PIN();
-    SWN_MM(1, 0);
-    SWN_PIN();
-    copy(ks, 1);
-    SWN_PIN();
-    SWN_MM(1, 1);
-    SWN_PIN();
-    if (more) SWN_WAIT_LGKM(7); else SWN_WAIT_LGKM(1);      // a2
-    SWN_PIN();
-    SWN_MM(2, 0);
-    SWN_PIN();
-    SWN_MM(2, 1);
-    SWN_PIN();
-    if (more) SWN_WAIT_LGKM(6); else SWN_WAIT_LGKM(0);      // a3
-    SWN_PIN();
-    SWN_MM(3, 0);
-    SWN_PIN();
-    SWN_MM(3, 1);
-#undef SWN_MM
-    SWN_PIN();
-  }
-}
 
-// The K loop of geometry 4, second form: the wave's weight fragments come from global memory STRAIGHT INTO REGISTERS (nobody else reads
-// them, so the LDS ring of the first form was a detour): a 4-deep register ring, three K steps ahead, counted vmcnt.  The activation
+// The K loop of geometry 4: the wave's weight fragments come from global memory STRAIGHT INTO REGISTERS (nobody else reads them: the
+// LDS ring of chainb_kernel - and of this kernel's first version - would be a detour): a 4-deep register ring, three K steps ahead, counted vmcnt.  The activation
 // fragments are read TWO steps ahead (three register sets): the LDS round trip of a lone wave's reads (~300 clocks with four waves
 // reading at once) no longer fits into one 256-clock step.  `wq` holds the fragments of steps 0..2 on entry (issued by the caller before
 // the phase barrier) - on exit nothing is in flight.
