@@ -110,6 +110,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, in
 #ifndef SWN_BIG_STORE_AUX
 #define SWN_BIG_STORE_AUX 2       // cache policy of the activation stores (1 = sc0, 2 = nt, 16 = sc1)
 #endif
+#ifndef SWN_BIG_Y_AUX
+#define SWN_BIG_Y_AUX SWN_BIG_STORE_AUX      // ... of the chain OUTPUT (read back by the next kernel, unlike the saved activations)
+#endif
 #define SWN_PIN() __builtin_amdgcn_sched_barrier(0)
 #define SWN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define SWN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -767,7 +770,7 @@ __device__ __forceinline__ void write_pieces16(const Ctx& cx, int c0, __amdgpu_b
       SWN_WAIT_LGKM0();
     }
 #pragma unroll
-    for (int j = 0; j < NB; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rs, lane16, (c0 + 4 * (NB * b + j)) * 1024, SWN_BIG_STORE_AUX);
+    for (int j = 0; j < NB; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rs, lane16, (c0 + 4 * (NB * b + j)) * 1024, SWN_BIG_Y_AUX);
 #pragma unroll
     for (int j = 0; j < NB; ++j) asm volatile("s_nop 3" :: "v"(v[j]));     // (see the write-out hook in chainp_kernel)
     SWN_PIN();
@@ -996,7 +999,7 @@ __global__ __launch_bounds__(512, 2) void chainp_kernel(const Args args) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = E::pack2(E::lo(v[q]) + E::lo(a[q]), E::hi(v[q]) + E::hi(a[q]));
       }
-      __builtin_amdgcn_raw_buffer_store_b128(v, ry, lane16, c * 1024, SWN_BIG_STORE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(v, ry, lane16, c * 1024, SWN_BIG_Y_AUX);
       asm volatile("s_nop 7\n\ts_nop 7" :: "v"(v));      // (see the write-out hook: keep the store's registers untouched for a few slots)
     }
   }
