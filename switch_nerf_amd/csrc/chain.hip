@@ -686,6 +686,35 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
             }
           }
         }
+      } else if ((TAG == 6 || TAG == 2) && last && d.y_add) {
+        // The backward chains' output + the rows of another tensor (the expert input gradients through tok2row / the skip gradient):
+        // the row indices of UB chunks, then their 16-byte pieces, are fetched TOGETHER - one chunk at a time the loop paid two dependent
+        // global-load latencies per 16 bytes stored.  (Only these two instantiations carry the code: registers.)
+        constexpr int UB = 8;
+        const int ch = tidw & (cpr - 1);
+        for (int c0 = tidw; c0 < total; c0 += UB * NT) {
+          long ar[UB];
+          uint4 a[UB];
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            const int c = c0 + u * NT;
+            const long gr = grow0 + ((c < total ? c : c0) >> sh);
+            ar[u] = d.y_add_gather ? (long)d.y_add_gather[gr] : gr;
+          }
+#pragma unroll
+          for (int u = 0; u < UB; ++u)
+            a[u] = *(const uint4*)((const char*)d.y_add + (ar[u] >= 0 ? ar[u] : 0) * row_bytes + ch * 16);
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            const int c = c0 + u * NT;
+            if (c < total) {
+              const int row = c >> sh;
+              uint4 v = load_chunk_from_act<T>(act, row, ch);
+              if (ar[u] >= 0) v = add_chunks<T>(v, a[u]);
+              *(uint4*)((char*)outp + (grow0 + row) * row_bytes + ch * 16) = v;
+            }
+          }
+        }
       } else
       for (int c = tidw; c < total; c += NT) {
         const int row = c >> sh, ch = c & (cpr - 1);
