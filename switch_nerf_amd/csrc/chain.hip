@@ -509,7 +509,10 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
   }
   stage_bias(0);
   // ---- stage the chain input ----
-  load_rows_to_lds<T>(act, d.x, d.x_gather, d.x_save, grow0, rows_in_tile, d.layers[0].k, tid, d.x_scale, d.x_relu);
+  if constexpr (TAG == 4)      // the tail forward chain gathers its rows through tok2row: 8 chunks in flight per thread (one round trip per tile)
+    load_rows_to_lds<T, 8>(act, d.x, d.x_gather, d.x_save, grow0, rows_in_tile, d.layers[0].k, tid, d.x_scale, d.x_relu);
+  else
+    load_rows_to_lds<T>(act, d.x, d.x_gather, d.x_save, grow0, rows_in_tile, d.layers[0].k, tid, d.x_scale, d.x_relu);
   __syncthreads();
 
   f32x16_t acc[MI][NI];
