@@ -98,3 +98,30 @@ def test_adam_state_resumes_under_the_reference_scheduler():
     want = checkpoint.exponential_lr(5e-4, it, decay, total)
     assert abs(sch.get_last_lr()[0] - want) <= 5e-3 * want      # (whether the constructor takes one decay step varies with the torch version)
     assert torch.equal(opt.state[params[0]]["exp_avg"], m.m[order[0]])
+
+
+def test_loss_scaler_follows_gradscaler_schedule():
+    """model.LossScaler against torch's GradScaler bookkeeping (runner.py:483, 679-693): same scale after the same sequence of clean /
+    overflowing steps (GradScaler itself needs a CUDA device for its tensors - the schedule is restated from its documented contract:
+    backoff on inf, growth after growth_interval consecutive clean steps, the streak restarts after either)."""
+    from switch_nerf_amd.model import LossScaler
+    s = LossScaler(init_scale=1024.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=3)
+    seq = [False, False, True, False, False, False, False, True, True, False, False, False]
+    scale, good, want = 1024.0, 0, []
+    for inf in seq:
+        if inf:
+            scale, good = scale * 0.5, 0
+        else:
+            good += 1
+            if good == 3:
+                scale, good = scale * 2.0, 0
+        want.append(scale)
+    got = []
+    for inf in seq:
+        s.update(inf)
+        got.append(s.scale)
+    assert got == want and s.skipped == 3
+    sd = s.state_dict()
+    assert sd["scale"] == want[-1] and sd["growth_interval"] == 3 and sd["_growth_tracker"] == 0
+    d = LossScaler()
+    assert (d.scale, d.growth_factor, d.backoff_factor, d.growth_interval) == (65536.0, 2.0, 0.5, 2000)      # torch's defaults
