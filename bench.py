@@ -261,10 +261,12 @@ def main():
     dt, st = timed(a.steps, (not a.no_events) and not use_graph)
     ms = dt / a.steps * 1e3
     ev_steps = max(3, min(20, a.steps))
+    eager_ms = None
     if use_graph:                # per-kernel events cannot be recorded inside a graph: eager steps right behind the timed region fill the
         graphed[0] = None        # table (the same launches on the next steps of the same run)
         if not a.no_events:
-            _, st = timed(ev_steps, True)
+            edt, st = timed(ev_steps, True)
+            eager_ms = edt / ev_steps * 1e3      # the same steps launched eagerly with the events on (reported next to the replayed number)
     value = n_rays * world * a.steps / dt
 
     # ---- per-kernel accounting from the live HIP events
@@ -370,9 +372,9 @@ def main():
                                + (f", + dense background model on {st['ctx']['Nb']} of {n_rays} rays x {a.samples // 2} samples" if a.bg else "")
                                + (f", model_dim {a.model_dim}, {a.experts} experts" if (a.model_dim != 256 or a.experts != 8) else ""),
                    "global_batch_rays": gb, "rays_per_gpu": n_rays, "samples": a.samples, "segment_points": a.chunk,
-                   "parallelism": f"{a.parallelism}{world}", "kept_token_fraction": round(kept / P, 4), "kept_token_fraction_mean": round(kept_mean / P, 4), "loss": round(loss_main, 6),
+                   "parallelism": f"{a.parallelism}{world}", "kept_token_fraction": round(kept / P, 4), "kept_token_fraction_mean": round(kept_mean / P, 4), "loss": round(loss_main, 6), "eager_events_ms_per_step": None if eager_ms is None else round(eager_ms, 3),
                    "timed_region": (f"forward + backward replayed from a hipGraph, all-reduce + Adam eager; per-kernel HIP events from {ev_steps} "
-                                    "eager steps right after the timed region (expert weight gradients on the main stream there)" if use_graph else
+                                    "eager steps right after the timed region (expert weight gradients on the main stream there; their wall time = eager_events_ms_per_step: the first process on a fresh box is host-bound when it launches eagerly)" if use_graph else
                                     "per-kernel HIP events recorded inside it; expert weight gradients on the main stream (no side-stream "
                                     "overlap) while events are on" if not a.no_events else "no per-kernel events; expert weight gradients "
                                     "overlapped on the side stream")},
