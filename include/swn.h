@@ -378,6 +378,28 @@ int swn_wgrad_blocks(const swn_wgrad_item* items, int n_items, int dtype, int m_
                      size_t dw_set_stride, size_t db_set_stride, int n_groups, int n_wsets, int group_stride,
                      const int32_t* group_rows, int group_rows_clamp, int n_splits, int tag, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* Balanced form (round 3): up to 8 JOBS - one GEMM each, with its own operands, widths (multiples of 32 up to 256) and strides - over
+ * ONE common row grouping, in one launch whose work follows the valid rows: the rows of all jobs are cut into equal shares, one per
+ * CU, whatever the groups' fill (a full (segment, expert) group no longer is the long pole of the launch), a workgroup hands over one
+ * partial tile per (job, weight set) it touches and a second kernel adds them in a fixed order (deterministic, no atomics).
+ * Requires n_groups % n_wsets == 0 (group g uses weight set g % n_wsets), n_groups <= 2048, and a workspace of
+ * swn_wgrad_multi_workspace_bytes(n_jobs, n_wsets).  swn_wgrad / swn_wgrad_batched / swn_wgrad_blocks take this path themselves when
+ * their workspace is large enough (n_splits is ignored then).  dw / db: 16-byte aligned, ldw and the set strides multiples of 4.
+ * Replaces the backward of torch.baddbmm w.r.t. the expert weights for ALL layers of ExpertMLP (tutel_moe_layer_nobatch.py:887-924)
+ * and of F.linear for the dense Mlp layers (models/nerf_moe.py:30-49).                                                            */
+typedef struct swn_wgrad_job {
+  const void* a;             /* [rows, lda] dtype: layer input  */
+  const void* b;             /* [rows, ldb] dtype: dZ           */
+  const int32_t* a_gather;   /* or NULL (see swn_wgrad)         */
+  const int32_t* b_gather;
+  float* dw;                 /* [n_wsets][m_dim][ldw] f32, accumulated into */
+  float* db;                 /* [n_wsets][n_dim] f32 or NULL                */
+  size_t dw_set_stride, db_set_stride;   /* elements between weight sets    */
+  int32_t m_dim, n_dim, lda, ldb, ldw;
+} swn_wgrad_job;
+size_t swn_wgrad_multi_workspace_bytes(int n_jobs, int n_wsets);
+int swn_wgrad_multi(const swn_wgrad_job* jobs, int n_jobs, int dtype, int n_groups, int n_wsets, int group_stride,
+                    const int32_t* group_rows, int group_rows_clamp, int tag, void* workspace, size_t workspace_bytes, void* stream);
 /* workspace (optional, recommended): n_groups * n_splits * (m_dim*n_dim + n_dim) * 4 bytes.  With it every workgroup
  * stores its partial tile and a second kernel reduces them into dw/db (deterministic, no atomics); without it
  * (NULL) partial tiles are added with fp32 atomics.                                                               */

@@ -22,6 +22,11 @@ class WgradItem(C.Structure):
     _fields_ = [("a", vp), ("b", vp), ("a_gather", vp), ("b_gather", vp), ("dw", vp), ("db", vp)]
 
 
+class WgradJob(C.Structure):
+    _fields_ = [("a", vp), ("b", vp), ("a_gather", vp), ("b_gather", vp), ("dw", vp), ("db", vp), ("dw_set_stride", sz), ("db_set_stride", sz),
+                ("m_dim", i32), ("n_dim", i32), ("lda", i32), ("ldb", i32), ("ldw", i32)]
+
+
 class PackItem(C.Structure):
     _fields_ = [("master", vp), ("out", vp), ("n_wsets", i32), ("in_dim", i32), ("out_dim", i32), ("transpose", i32)]
 
@@ -81,6 +86,7 @@ SIGNATURES = {
     "swn_chain_tile_rows": [i32],
     "swn_wgrad_blocks": [C.POINTER(WgradItem), i32, i32, i32, i32, i32, i32, i32, sz, sz, i32, i32, i32, vp, i32, i32, i32, vp, sz, vp],
     "swn_wgrad_batched": [C.POINTER(WgradItem), i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, sz, vp],
+    "swn_wgrad_multi": [C.POINTER(WgradJob), i32, i32, i32, i32, i32, vp, i32, i32, vp, sz, vp],
     "swn_wgrad": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, vp, sz, vp],
     "swn_adam_step": [vp, vp, vp, vp, vp, i32, i64, f32, f32, f32, f32, i32, f32, vp],
     "swn_cast": [vp, vp, i32, i64, vp],
@@ -124,6 +130,8 @@ def load():
     lib.swn_route_workspace_bytes.argtypes = [i32, i32, i32]
     lib.swn_gate_bwd_scratch_floats.restype = sz
     lib.swn_gate_bwd_scratch_floats.argtypes = [i32, i32, i32]
+    lib.swn_wgrad_multi_workspace_bytes.restype = sz
+    lib.swn_wgrad_multi_workspace_bytes.argtypes = [i32, i32]
     lib.swn_chain_mask_words.restype = i64
     lib.swn_chain_mask_words.argtypes = [i32, i32, i32, i32]
     for name, args in SIGNATURES.items():

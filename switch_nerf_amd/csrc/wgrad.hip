@@ -313,9 +313,460 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+
+// =================================================================================================================================
+// Balanced stream kernel (round 3): the same slab pipeline, but the WORK - not the grid - follows the kept rows.
+//
+// The kernel above launches one workgroup per (group, row split, layer): with the router's own routing some (segment, expert) groups
+// are full and others hold a third of their capacity, the splits are sized by the capacity, the full groups are the long pole of the
+// launch (2.19 .. 6.21 ms per call in a training run, slower at 80 % kept rows than at 100 %), and every workgroup leaves a 257 KiB
+// partial tile behind (1792 of them: 0.9 GB written and read again per step).  Here a launch is a list of up to 8 JOBS (one GEMM
+// each: its own operands, widths and strides; one common row grouping).  All rows of all jobs form one line, measured in slabs of
+// BKR rows weighted by the bytes a slab moves ((m_dim + n_dim) / 32); the line is ordered job-major, then weight set, then group,
+// and cut into n_wg equal parts (n_wg = the CUs of the device: one 128 KiB workgroup per CU, every one resident from start to end).
+// A workgroup walks its part; whenever the (job, weight set) PAIR changes it stores the accumulators as one partial tile - so a
+// launch leaves n_wg + pairs partial tiles (312 for the 7 expert layers instead of 1792) and no workgroup runs longer than
+// its share of the kept rows plus one slab.  The cut depends on the row counts only: results are deterministic, the reduce kernel
+// recomputes the same cut and adds a pair's tiles in workgroup order (no atomics anywhere).
+constexpr int WS_MAX_JOBS = 8;
+constexpr int WS_MAX_GROUPS = 2048;
+constexpr int WS_MAX_PIECES = 512;            // (job, weight set) pairs of one launch: n_jobs * n_wsets
+constexpr int WS_LDS_INTS = 2 * WS_MAX_GROUPS + 1 + 8 + 1 + 4 * WS_MAX_PIECES;
+constexpr int WS_TILE = 256 * 256 + 256;      // floats per partial tile slot (dW tile + db row), whatever the job's widths
+constexpr int WS_HDR_INTS = 128;              // header in front of the partial tiles: [0] = slabs per job, [1 + e] = first slab of weight set e
+
+struct WsJob {
+  const void* a; const void* b; const int32_t* a_gather; const int32_t* b_gather; float* dw; float* db;
+  size_t dw_set_stride, db_set_stride;
+  int m_dim, n_dim, lda, ldb, ldw, weight;
+};
+struct WsArgs {
+  WsJob job[WS_MAX_JOBS];
+  const int32_t* group_rows;
+  float* partial;            // [WS_HDR_INTS ints][n_wg + n_jobs * n_wsets][WS_TILE]
+  int n_jobs, n_groups, n_wsets, group_stride, clamp, n_wg;
+};
+
+// first slab of a job (base = the job's offset on the weighted line, w = its weight, T = its slab count) whose start is >= x
+__device__ __forceinline__ int ws_first_slab(long x, long base, int w, int T) {
+  const long d = x - base;
+  if (d <= 0) return 0;
+  const long s = (d + w - 1) / w;
+  return s > T ? T : (int)s;
+}
+__device__ __forceinline__ long ws_cut(int k, long total, int n_wg) { return ((long)k * total) / n_wg; }
+
+template <typename T, int TAG>
+__global__ __launch_bounds__(WG_NT) void wgrad_stream_kernel(const WsArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BKR = WCfg<T>::BKR;
+  constexpr int RS = 256 * (int)sizeof(T);
+  constexpr int SLAB = BKR * RS;
+  constexpr int RING = WG_NS * 2 * SLAB;
+  int32_t* pre = (int32_t*)(smem + RING);                 // [n_groups + 1] slabs before ordered group i (i = wset * segs + segment)
+  int32_t* rws = pre + (WS_MAX_GROUPS + 1);               // [n_groups]     valid rows of ordered group i
+  int32_t* wtot = rws + WS_MAX_GROUPS;                    // [8]            scan scratch
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int n_groups = p.n_groups, n_wsets = p.n_wsets, segs = n_groups / n_wsets;
+
+  // ---- slabs per ordered group and their exclusive prefix (every workgroup computes the same table) ----
+  {
+    const int ipt = (n_groups + WG_NT - 1) / WG_NT;       // ordered groups per thread (<= 4)
+    const int i0 = tid * ipt;
+    int loc[4], run = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + q;
+      int sl = 0;
+      if (q < ipt && i < n_groups) {
+        const int g = (i % segs) * n_wsets + i / segs;
+        const int rows = p.group_rows ? min(p.group_rows[g], p.clamp) : p.group_stride;
+        rws[i] = rows;
+        sl = (rows + BKR - 1) / BKR;
+      }
+      loc[q] = run;
+      run += sl;
+    }
+    int inc = run;                                         // inclusive scan of the per-thread sums over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += v;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    int base = inc - run;
+    for (int w2 = 0; w2 < wave; ++w2) base += wtot[w2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + q;
+      if (q < ipt && i < n_groups) pre[i] = base + loc[q];
+    }
+    if (tid == WG_NT - 1) pre[n_groups] = base + run;
+    __syncthreads();
+  }
+  const int Tj = pre[n_groups];                           // slabs of one job
+  const int k = blockIdx.x;
+  if (k == 0 && tid <= n_wsets) {                         // header for the reduce kernel
+    int32_t* hdr = (int32_t*)p.partial;
+    if (tid == 0) hdr[0] = Tj;
+    hdr[1 + tid] = pre[tid * segs];
+  }
+  // ---- this workgroup's pieces: (job, weight set, first slab, end slab), listed by one thread (the cut needs 64-bit divisions: kept
+  //      out of the slab loop's register budget) ----
+  int32_t* plist = wtot + 8;                              // [1 + 4 * WS_MAX_PIECES]
+  if (tid == 0) {
+    long total = 0;
+    for (int j = 0; j < p.n_jobs; ++j) total += (long)p.job[j].weight * Tj;
+    int np = 0;
+    if (total > 0) {
+      const long x0 = ws_cut(k, total, p.n_wg), x1 = ws_cut(k + 1, total, p.n_wg);
+      long wbase = 0;                                     // the job's offset on the weighted line
+      for (int j = 0; j < p.n_jobs; ++j) {
+        const int w = p.job[j].weight;
+        const int s_lo = ws_first_slab(x0, wbase, w, Tj), s_hi = ws_first_slab(x1, wbase, w, Tj);
+        wbase += (long)w * Tj;
+        if (s_lo >= s_hi) continue;
+        for (int e = 0; e < n_wsets; ++e) {
+          const int pa = max(s_lo, pre[e * segs]), pb = min(s_hi, pre[(e + 1) * segs]);
+          if (pa >= pb) continue;
+          plist[1 + 4 * np] = j; plist[2 + 4 * np] = e; plist[3 + 4 * np] = pa; plist[4 + 4 * np] = pb;
+          ++np;
+        }
+      }
+    }
+    plist[0] = np;
+  }
+  __syncthreads();
+  const int n_pieces = __builtin_amdgcn_readfirstlane(plist[0]);
+  float* tiles = p.partial + WS_HDR_INTS;
+
+  // staging geometry (as in wgrad_kernel)
+  constexpr int RPP = 1024 / RS;
+  constexpr int LPR = RS / 16;
+  const int prow = lane / LPR, pcol = (lane % LPR) * 16;
+  const char* zero = (const char*)g_zero_page + (lane & 31) * 16;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  auto sa = [&](int b_) -> char* { return smem + b_ * 2 * SLAB; };
+  auto sb = [&](int b_) -> char* { return smem + b_ * 2 * SLAB + SLAB; };
+
+  for (int pi = 0; pi < n_pieces; ++pi) {
+    {
+      const int j = __builtin_amdgcn_readfirstlane(plist[1 + 4 * pi]), e = __builtin_amdgcn_readfirstlane(plist[2 + 4 * pi]);
+      const int pa = __builtin_amdgcn_readfirstlane(plist[3 + 4 * pi]), pb = __builtin_amdgcn_readfirstlane(plist[4 + 4 * pi]);
+      const WsJob& it = p.job[j];
+      const int m_dim = it.m_dim, n_dim = it.n_dim;
+      const int a_colb = pcol < m_dim * (int)sizeof(T) ? pcol : 0, b_colb = pcol < n_dim * (int)sizeof(T) ? pcol : 0;
+      const bool active = (wm * 128 < m_dim) && (wn * 64 < n_dim);
+      const bool do_bias = (it.db != nullptr) && wm == 0 && (wn * 64 < n_dim);
+      // ---------------------------------------------------------------- one piece: slabs [pa, pb) of (job j, weight set e)
+      f32x16_t acc[4][2];
+      f32x16_t accb[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[jj][r] = 0.f;
+
+      // producer cursor: ordered group ip (binary search for the group that holds slab pa), row offset rp, slabs left
+      int ip;
+      {
+        int lo = e * segs, hi = (e + 1) * segs - 1;        // last i with pre[i] <= pa
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (pre[mid] <= pa) lo = mid; else hi = mid - 1;
+        }
+        ip = lo;
+      }
+      int rp = (pa - pre[ip]) * BKR;
+      int rows_p = rws[ip];
+      int left = pb - pa;                                  // slabs not yet issued
+      ip = __builtin_amdgcn_readfirstlane(ip); rp = __builtin_amdgcn_readfirstlane(rp);
+      rows_p = __builtin_amdgcn_readfirstlane(rows_p); left = __builtin_amdgcn_readfirstlane(left);
+
+      auto produce = [&](int slot) {                       // next slab of the piece (or zeros past its end) -> ring slot
+        const bool live = left > 0;
+        const int g = (ip % segs) * n_wsets + e;
+        const long grow0 = (long)g * p.group_stride;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int piece = 2 * wave + i;
+          const int rf = rp + piece * RPP;
+          long asr[RPP], bsr[RPP];
+#pragma unroll
+          for (int q = 0; q < RPP; ++q) {
+            const long row = grow0 + max(min(rf + q, rows_p - 1), 0);
+            typedef const __attribute__((address_space(4))) int32_t* cidx_t;
+            asr[q] = (live && it.a_gather) ? (long)max(((cidx_t)it.a_gather)[row], 0) : row;
+            bsr[q] = (live && it.b_gather) ? (long)max(((cidx_t)it.b_gather)[row], 0) : row;
+          }
+          const bool ok = live && (rf + prow < rows_p);
+          const long as = RPP == 2 ? (prow ? asr[RPP - 1] : asr[0]) : asr[0];
+          const long bs = RPP == 2 ? (prow ? bsr[RPP - 1] : bsr[0]) : bsr[0];
+          const char* ap = ok ? (const char*)it.a + (as * (long)it.lda) * sizeof(T) + a_colb : zero;
+          const char* bp = ok ? (const char*)it.b + (bs * (long)it.ldb) * sizeof(T) + b_colb : zero;
+          dma16(ap, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(slot * 2 * SLAB + piece * 1024)));
+          dma16(bp, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(slot * 2 * SLAB + SLAB + piece * 1024)));
+        }
+        if (live) {                                        // advance (wave-uniform)
+          --left;
+          rp += BKR;
+          if (rp >= rows_p && left > 0) {
+            do { ++ip; rows_p = __builtin_amdgcn_readfirstlane(rws[ip]); } while (rows_p == 0);
+            rp = 0;
+          }
+        }
+      };
+
+      const int nsl = pb - pa;
+#pragma unroll
+      for (int s0 = 0; s0 < WG_NS - 1; ++s0) produce(s0);
+      int slot = 0;
+      for (int n = 0; n < nsl; ++n) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        produce((slot + WG_NS - 1) % WG_NS);
+        const char* A = sa(slot);
+        const char* B = sb(slot);
+        if (active || do_bias) {
+          if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int kk = 0; kk < BKR / 16; ++kk) {
+              const int rb0 = kk * 16 + lhi * 8;
+              uint2 pa_[8];
+              uint32_t pb_[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                pa_[q] = *(const uint2*)(A + (rb0 + q) * RS + (wm * 128 + 4 * l31) * 2);
+                pb_[q] = *(const uint32_t*)(B + (rb0 + q) * RS + (wn * 64 + 2 * l31) * 2);
+              }
+              bf16x8_t fa[4], fb[2];
+              {
+                uint32_t lo[4], hi[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                  lo[t] = (pa_[2 * t].x & 0xFFFFu) | (pa_[2 * t + 1].x << 16);
+                  hi[t] = (pa_[2 * t].x >> 16) | (pa_[2 * t + 1].x & 0xFFFF0000u);
+                }
+                fa[0] = as_frag(lo[0], lo[1], lo[2], lo[3]);
+                fa[1] = as_frag(hi[0], hi[1], hi[2], hi[3]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                  lo[t] = (pa_[2 * t].y & 0xFFFFu) | (pa_[2 * t + 1].y << 16);
+                  hi[t] = (pa_[2 * t].y >> 16) | (pa_[2 * t + 1].y & 0xFFFF0000u);
+                }
+                fa[2] = as_frag(lo[0], lo[1], lo[2], lo[3]);
+                fa[3] = as_frag(hi[0], hi[1], hi[2], hi[3]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                  lo[t] = (pb_[2 * t] & 0xFFFFu) | (pb_[2 * t + 1] << 16);
+                  hi[t] = (pb_[2 * t] >> 16) | (pb_[2 * t + 1] & 0xFFFF0000u);
+                }
+                fb[0] = as_frag(lo[0], lo[1], lo[2], lo[3]);
+                fb[1] = as_frag(hi[0], hi[1], hi[2], hi[3]);
+              }
+              if (active) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                  for (int qq = 0; qq < 2; ++qq)
+                    acc[q][qq] = SWN_MFMA_32x32x16(fa[q], fb[qq], acc[q][qq]);
+              }
+              if (do_bias) {
+                const bf16x8_t ones = as_frag(SWN_HALF_ONE_X2, SWN_HALF_ONE_X2, SWN_HALF_ONE_X2, SWN_HALF_ONE_X2);
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)
+                  accb[qq] = SWN_MFMA_32x32x16(ones, fb[qq], accb[qq]);
+              }
+            }
+          } else {
+#pragma unroll 2
+            for (int kk = 0; kk < BKR / 2; ++kk) {
+              const int row = kk * 2 + lhi;
+              float fa[4], fb[2];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) fa[q] = *(const float*)(A + row * RS + (wm * 128 + q * 32 + l31) * 4);
+#pragma unroll
+              for (int qq = 0; qq < 2; ++qq) fb[qq] = *(const float*)(B + row * RS + (wn * 64 + qq * 32 + l31) * 4);
+              if (active) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                  for (int qq = 0; qq < 2; ++qq)
+                    acc[q][qq] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q], fb[qq], acc[q][qq], 0, 0, 0);
+              }
+              if (do_bias) {
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)
+                  accb[qq] = __builtin_amdgcn_mfma_f32_32x32x2f32(1.0f, fb[qq], accb[qq], 0, 0, 0);
+              }
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        slot = (slot + 1) % WG_NS;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the zero copies issued past the end of the piece
+
+      // ---- the piece's partial tile: slot k + pair (unique: both the cut and the pair index grow along the line) ----
+      float* part = tiles + (size_t)(k + j * n_wsets + e) * WS_TILE;
+      if (active) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int i = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+              int m, n;
+              if constexpr (sizeof(T) == 2) {
+                m = wm * 128 + 4 * i + q;
+                n = wn * 64 + 2 * l31 + qq;
+              } else {
+                m = wm * 128 + q * 32 + i;
+                n = wn * 64 + qq * 32 + l31;
+              }
+              if (m < m_dim && n < n_dim) part[(size_t)m * n_dim + n] = acc[q][qq][r];
+            }
+      }
+      if (do_bias && lhi == 0) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          int n;
+          if constexpr (sizeof(T) == 2) n = wn * 64 + 2 * l31 + qq; else n = wn * 64 + qq * 32 + l31;
+          if (n < n_dim) part[(size_t)m_dim * n_dim + n] = accb[qq][0];
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (stores and copies share vmcnt: the next piece counts from zero)
+      __syncthreads();                                       // every wave has left the ring before the next piece refills it
+    }
+  }
+}
+
+// dw[pair] += the pair's partial tiles in workgroup order.  grid (tile blocks, pairs); a thread owns 4 consecutive elements.
+__global__ __launch_bounds__(256) void wgrad_stream_reduce_kernel(const WsArgs p) {
+  __shared__ int32_t flag[1024];
+  __shared__ int32_t krange[2];
+  const int pair = blockIdx.y, j = pair / p.n_wsets, e = pair % p.n_wsets;
+  const WsJob& it = p.job[j];
+  const int32_t* hdr = (const int32_t*)p.partial;
+  const int Tj = hdr[0], P0 = hdr[1 + e], P1 = hdr[2 + e];
+  long wpre = 0, total = 0;
+  for (int q = 0; q < p.n_jobs; ++q) {
+    if (q == j) wpre = total;
+    total += (long)p.job[q].weight * Tj;
+  }
+  if (threadIdx.x == 0) { krange[0] = p.n_wg; krange[1] = -1; }
+  __syncthreads();
+  if (total > 0 && P0 < P1) {
+    for (int k = threadIdx.x; k < p.n_wg; k += 256) {
+      const int s_lo = ws_first_slab(ws_cut(k, total, p.n_wg), wpre, it.weight, Tj);
+      const int s_hi = ws_first_slab(ws_cut(k + 1, total, p.n_wg), wpre, it.weight, Tj);
+      const int ok = max(s_lo, P0) < min(s_hi, P1);
+      flag[k] = ok;
+      if (ok) { atomicMin(&krange[0], k); atomicMax(&krange[1], k); }
+    }
+  }
+  __syncthreads();
+  const int k0 = krange[0], k1 = krange[1];
+  if (k1 < k0) return;
+  const int mn = it.m_dim * it.n_dim, tile_elems = mn + (it.db ? it.n_dim : 0);
+  const int el = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (el >= tile_elems) return;
+  const float* tiles = p.partial + WS_HDR_INTS + (size_t)pair * WS_TILE + el;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = k0; k <= k1; ++k) {
+    if (!flag[k]) continue;
+    const float4 v = *(const float4*)(tiles + (size_t)k * WS_TILE);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float* dst = el < mn ? it.dw + (size_t)e * it.dw_set_stride + (size_t)(el / it.n_dim) * it.ldw + el % it.n_dim
+                       : it.db + (size_t)e * it.db_set_stride + (el - mn);
+  float4 d = *(float4*)dst;
+  d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
+  *(float4*)dst = d;
+}
+
 }  // namespace swn
 
 using namespace swn;
+
+static int ws_n_wg() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    const char* ov = getenv("SWN_WGRAD_WGS");       // experiments: workgroups of the balanced kernel (default: one per CU)
+    if (ov && atoi(ov) > 0) cus = atoi(ov);
+    n = cus > 1024 ? 1024 : cus;
+  }
+  return n;
+}
+
+extern "C" size_t swn_wgrad_multi_workspace_bytes(int n_jobs, int n_wsets) {
+  return (size_t)WS_HDR_INTS * 4 + ((size_t)ws_n_wg() + (size_t)n_jobs * n_wsets) * WS_TILE * sizeof(float);
+}
+
+static bool ws_eligible(int n_groups, int n_wsets) {
+  static const bool legacy = getenv("SWN_WGRAD_LEGACY") != nullptr;
+  return !legacy && n_groups % n_wsets == 0 && n_groups <= WS_MAX_GROUPS && n_wsets <= WS_MAX_PIECES / WS_MAX_JOBS && n_wsets + 2 <= WS_HDR_INTS;
+}
+
+extern "C" int swn_wgrad_multi(const swn_wgrad_job* jobs, int n_jobs, int dtype, int n_groups, int n_wsets, int group_stride,
+                               const int32_t* group_rows, int group_rows_clamp, int tag, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_wgrad_multi: bad dtype %d", dtype);
+  SWN_CHECK(jobs && n_jobs >= 1 && n_jobs <= WS_MAX_JOBS, "swn_wgrad_multi: 1..%d jobs", WS_MAX_JOBS);
+  SWN_CHECK(n_groups >= 1 && n_wsets >= 1 && group_stride >= 1, "swn_wgrad_multi: bad geometry");
+  SWN_CHECK(ws_eligible(n_groups, n_wsets) || getenv("SWN_WGRAD_LEGACY"), "swn_wgrad_multi: n_groups (%d) must be a multiple of n_wsets (%d) and <= %d", n_groups,
+            n_wsets, WS_MAX_GROUPS);
+  SWN_CHECK(tag == 0 || tag == 1, "swn_wgrad_multi: tag must be 0 or 1");
+  WsArgs p;
+  memset(&p, 0, sizeof(p));
+  for (int i = 0; i < n_jobs; ++i) {
+    const swn_wgrad_job& s = jobs[i];
+    SWN_CHECK(s.a && s.b && s.dw, "swn_wgrad_multi: null pointer in job %d", i);
+    SWN_CHECK(s.m_dim >= 32 && s.m_dim <= 256 && s.m_dim % 32 == 0 && s.n_dim >= 32 && s.n_dim <= 256 && s.n_dim % 32 == 0,
+              "swn_wgrad_multi: job %d: m_dim=%d n_dim=%d must be multiples of 32 in [32,256]", i, s.m_dim, s.n_dim);
+    SWN_CHECK(s.lda >= s.m_dim && s.ldb >= s.n_dim && s.ldw >= s.n_dim && s.ldw % 4 == 0, "swn_wgrad_multi: job %d: bad leading dimensions", i);
+    SWN_CHECK(((uintptr_t)s.dw & 15) == 0 && (!s.db || ((uintptr_t)s.db & 15) == 0) && s.dw_set_stride % 4 == 0 && s.db_set_stride % 4 == 0,
+              "swn_wgrad_multi: job %d: dw / db must be 16-byte aligned", i);
+    WsJob& d = p.job[i];
+    d.a = s.a; d.b = s.b; d.a_gather = s.a_gather; d.b_gather = s.b_gather; d.dw = s.dw; d.db = s.db;
+    d.dw_set_stride = s.dw_set_stride; d.db_set_stride = s.db_set_stride;
+    d.m_dim = s.m_dim; d.n_dim = s.n_dim; d.lda = s.lda; d.ldb = s.ldb; d.ldw = s.ldw; d.weight = (s.m_dim + s.n_dim) / 32;
+  }
+  p.group_rows = group_rows;
+  p.n_jobs = n_jobs; p.n_groups = n_groups; p.n_wsets = n_wsets; p.group_stride = group_stride;
+  p.clamp = group_rows ? group_rows_clamp : group_stride;
+  p.n_wg = ws_n_wg();
+  const size_t need = swn_wgrad_multi_workspace_bytes(n_jobs, n_wsets);
+  SWN_CHECK(workspace && workspace_bytes >= need, "swn_wgrad_multi: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
+  p.partial = (float*)workspace;
+  const int bkr = dtype == SWN_HALF ? 32 : 16;
+  const int lds = WG_NS * 2 * bkr * 256 * (dtype == SWN_HALF ? 2 : 4) + WS_LDS_INTS * 4;
+  const void* fn;
+  if (dtype == SWN_HALF) fn = tag ? (const void*)wgrad_stream_kernel<bf16_t, 1> : (const void*)wgrad_stream_kernel<bf16_t, 0>;
+  else fn = tag ? (const void*)wgrad_stream_kernel<float, 1> : (const void*)wgrad_stream_kernel<float, 0>;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  void* kargs[] = {(void*)&p};
+  e = hipLaunchKernel(fn, dim3(p.n_wg), dim3(WG_NT), kargs, lds, as_stream(stream));
+  SWN_CHECK(e == hipSuccess, "swn_wgrad_multi launch: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(wgrad_stream_reduce_kernel, dim3(cdiv(WS_TILE, 1024), n_jobs * n_wsets), dim3(256), 0, as_stream(stream), p);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}
 
 static int wgrad_launch(const swn_wgrad_item* items, int n_items, int dtype, int m_dim, int n_dim, int lda, int ldb, int ldw,
                         size_t dw_set_stride, size_t db_set_stride, int n_groups, int n_wsets, int group_stride,
@@ -326,6 +777,18 @@ static int wgrad_launch(const swn_wgrad_item* items, int n_items, int dtype, int
             "swn_wgrad: m_dim=%d n_dim=%d must be multiples of 32 in [32,256]", m_dim, n_dim);
   SWN_CHECK(n_groups >= 1 && n_wsets >= 1 && group_stride >= 1 && n_splits >= 1, "swn_wgrad: bad geometry");
   SWN_CHECK(items && n_items >= 1 && n_items <= 8, "swn_wgrad: 1..8 items");
+  if (workspace && ws_eligible(n_groups, n_wsets) && workspace_bytes >= swn_wgrad_multi_workspace_bytes(n_items, n_wsets)) {
+    // the balanced stream kernel (work follows the kept rows; n_splits is irrelevant there)
+    swn_wgrad_job jobs[8];
+    for (int i = 0; i < n_items; ++i) {
+      jobs[i].a = items[i].a; jobs[i].b = items[i].b; jobs[i].a_gather = items[i].a_gather; jobs[i].b_gather = items[i].b_gather;
+      jobs[i].dw = items[i].dw; jobs[i].db = items[i].db;
+      jobs[i].m_dim = m_dim; jobs[i].n_dim = n_dim; jobs[i].lda = lda; jobs[i].ldb = ldb; jobs[i].ldw = ldw;
+      jobs[i].dw_set_stride = dw_set_stride; jobs[i].db_set_stride = db_set_stride;
+    }
+    return swn_wgrad_multi(jobs, n_items, dtype, n_groups, n_wsets, group_stride, group_rows, group_rows_clamp, tag, workspace,
+                           workspace_bytes, stream);
+  }
   WgradArgs p;
   WgradReduceArgs ra;
   for (int i = 0; i < 8; ++i) {

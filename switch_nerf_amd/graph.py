@@ -68,3 +68,59 @@ class GraphedTrainStep:
             ops.adam_step(m.flat, m.grad, m.m, m.v, None, m.step_count, m.lr, grad_scale=scale)
             self.copies.replay()
         return self.res
+
+
+class GraphedRender:
+    """The inference forward of ONE ray-batch shape (render_rays in eval mode: no jitter, no noise, no activation saves), captured
+    once and replayed: Runner.render_image (runner.py:2835-2885) calls render_rays for every image_pixel_batch_size rays of every
+    image with the same shapes - ~60 launches per call that the host otherwise enqueues slower than the GPU runs them.
+
+        g = GraphedRender(model, rays, image_indices, n_samples, seg_tokens, fine_samples=F, no_batch=model.moe_no_batch)
+        out = g(rays, image_indices)     # dict: rgb, depth, depth_variance, l_aux_coarse, idx_coarse, sigma_coarse (+ *_fine)
+
+    The returned tensors live in the graph's static memory: consume (or clone) them before the next call.  Expert-parallel
+    evaluation reads split sizes on the host (list_all_to_all) and cannot be captured."""
+
+    def __init__(self, model, rays, image_indices, n_samples: int, seg_tokens: int, fine_samples: int = 0, no_batch: bool = False,
+                 warmup: int = 2):
+        if model.ep is not None and model.ep.world > 1:
+            raise ValueError("GraphedRender: expert-parallel evaluation exchanges host-sized splits and cannot be captured")
+        self.model = model
+        dev = model.dev
+        self.rays, self.idx = rays.clone().contiguous(), image_indices.clone().contiguous()
+        N, S, F = rays.shape[0], int(n_samples), int(fine_samples)
+        self.key = (N, S, F, int(seg_tokens), bool(no_batch))
+
+        def run():
+            with torch.no_grad():
+                chunk = min(int(seg_tokens), N * S)
+                if F > 0:
+                    c, cf, o = model.forward_hier(self.rays, self.idx, S, F, chunk, 0.0, None, None, None, None, no_batch=no_batch,
+                                                  training=False)
+                    return dict(rgb=o["rgb"], depth=o["depth"], depth_variance=o["depth_variance"], l_aux_coarse=c["l_aux"],
+                                l_aux_fine=cf["l_aux"], idx_coarse=c["idx"], idx_fine=cf["idx"], sigma_coarse=c["raw"][:, 3],
+                                sigma_fine=cf["raw"][:, 3])
+                c = model.forward_rays(self.rays, self.idx, S, chunk, 0.0, None, None, training=False, no_batch=no_batch)
+                return dict(rgb=c["rgb"], depth=c["depth"], depth_variance=c["depth_variance"], l_aux_coarse=c["l_aux"],
+                            idx_coarse=c["idx"], sigma_coarse=c["raw"][:, 3])
+
+        was_profile, model.profile = model.profile, False
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up on the capture stream: allocates every cached buffer / workspace
+            for _ in range(max(1, warmup)):
+                run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self.out = run()
+        model.profile = was_profile
+
+    def __call__(self, rays=None, image_indices=None):
+        if rays is not None:
+            self.rays.copy_(rays)
+        if image_indices is not None:
+            self.idx.copy_(image_indices)
+        self.graph.replay()
+        return self.out

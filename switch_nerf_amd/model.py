@@ -288,6 +288,8 @@ class SwitchNeRF:
                     pairs.append((w3, self.wb[n], False))
         if pairs:
             ops.repack_weights_batched(pairs)      # one launch (was 23 of ~5 us each: a tenth of the step at 1024 rays per GPU)
+        if self._flat_param is not None:           # the copies now match the master weights as of this version of flat_param
+            self._packed_version = self._flat_param._version
 
     def set_expert_parallel(self, ep):
         """Shard the experts over the ranks of `ep` (parallel.ExpertParallel) and exchange the dispatched rows instead of
@@ -366,6 +368,7 @@ class SwitchNeRF:
         Returns a context dict holding every tensor the backward needs and the rendered results."""
         o, dt, dev = ops, self.dtype, self.dev
         N, S = rays.shape[0], n_samples
+        self._sync_compute_copies()       # (an optimizer outside this class may have stepped flat_param since the last forward)
         if self.hash is not None:         # hash-grid encoding of the sample positions (BASELINE configs[4])
             z = z_in if z_in is not None else o.sample_z(rays, self._linspace(S), perturb_rand,
                                                          perturb, S)
@@ -615,8 +618,8 @@ class SwitchNeRF:
                 o.gather_rows(dout, perm_s[s_], dsend[s_])
                 return ep.all_to_all(dsend[s_], self.side, out=dr[s_])
             pend = issue_b(0)
-        o.wgrad(c["h1"], dh2, g["l2h.w"].view(1, M, H2), None, n_splits=nsp)
-        o.wgrad(c["y"], dh1, g["l1.w"].view(1, M, M), g["l1.b"].view(1, M), n_splits=nsp)
+        self._dense_wgrads([(c["h1"], dh2, g["l2h.w"].view(1, M, H2), None),
+                            (c["y"], dh1, g["l1.w"].view(1, M, M), g["l1.b"].view(1, M))], nsp)
         # expert backward chain
         dz = [_b(f"dz{l}", (rows, M), dt) for l in range(L - 1)]     # dz[L-1] = dout through perm: never materialised
         dx = _b("dx", (rows, M), dt)
@@ -694,15 +697,24 @@ class SwitchNeRF:
                 wait()
         o.mlp_chain(dg, [o.Layer(self.wb["gate1"], None, relu=2, mask=c["m_a1"], save=dza1), o.Layer(self.wb["gate0"], None)],
                     dh0, y_add=dx, y_add_gather=c["row_of_tok"], tag=6)
-        o.wgrad(c["a1"], dg, g["gate1.w"].view(1, G, G), g["gate1.b"].view(1, G), n_splits=nsp)
-        o.wgrad(c["h0"], dza1, g["gate0.w"].view(1, M, G), g["gate0.b"].view(1, G), n_splits=nsp)
-        o.wgrad(c["pe"], dh0, g["xyz.w"].view(1, self.KP, M), g["xyz.b"].view(1, M), n_splits=nsp)
+        self._dense_wgrads([(c["a1"], dg, g["gate1.w"].view(1, G, G), g["gate1.b"].view(1, G)),
+                            (c["h0"], dza1, g["gate0.w"].view(1, M, G), g["gate0.b"].view(1, G)),
+                            (c["pe"], dh0, g["xyz.w"].view(1, self.KP, M), g["xyz.b"].view(1, M))], nsp)
         if self.hash is not None:          # dL/d encoding = dh0 W_xyz^T, scattered into the hash table's gradient
             d_enc = _b("d_enc", (P, self.KP), dt)
             o.mlp_chain(dh0, [o.Layer(self.wb["xyz"], None)], d_enc, tag=0)
             o.hash_encode_bwd(c["rays"], c["z"], d_enc, self.hash, g["hash.table"])
         if side_done is not None:
             torch.cuda.current_stream().wait_event(side_done)
+
+    def _dense_wgrads(self, jobs, n_splits):
+        """Weight gradients of dense layers that are ready together, (a, dz, dw, db) each: ONE balanced launch and one reduction
+        (swn_wgrad_multi) for layers of up to 256 features, per-layer block launches for wider ones."""
+        if all(a.shape[1] <= 256 and b.shape[1] <= 256 for a, b, _w, _b in jobs):
+            ops.wgrad_multi([(a, b, dw, db, None, None) for a, b, dw, db in jobs])
+        else:
+            for a, b, dw, db in jobs:
+                ops.wgrad(a, b, dw, db, n_splits=n_splits)
 
     # ------------------------------------------------------------------------------------------ training step
     def train_step(self, rgbs, rays, image_indices, n_samples, seg_tokens, perturb=1.0, perturb_rand=None,
@@ -810,6 +822,7 @@ class SwitchNeRF:
         NeRFMoE.forward behind MipEmbedder, nerf_moe.py:675-810) -> compositing at the frustum mid points with the colour
         padding of :383-386."""
         N, S1 = rays.shape[0], z.shape[1] - 1
+        self._sync_compute_copies()
         pe = ops.mip_encode(rays, radii, z, self.cfg["pos_xyz_dim"], self.dtype, self.KP)
         if pe_dir is None:
             pe_dir = self._dir_pe(rays)

@@ -10,7 +10,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import BF16, F16, F32, ChainDesc, WgradItem, call
+from ._lib import BF16, F16, F32, ChainDesc, WgradItem, WgradJob, call
 
 
 def _code(dtype) -> int:
@@ -472,10 +472,26 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
 _wgrad_ws = {}
 
 
+def _wgrad_workspace(dev, nbytes: int):
+    """One workspace per (device, stream) - launches on different streams may overlap -, grown to the largest request."""
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        _wgrad_ws[key] = ws
+    return ws
+
+
+def _multi_ws_bytes(n_jobs: int, n_wsets: int) -> int:
+    return int(_lib.load().swn_wgrad_multi_workspace_bytes(int(n_jobs), int(n_wsets)))
+
+
 def wgrad(a, b, dw, db=None, n_groups=1, n_wsets=1, group_stride=None, group_rows=None, group_rows_clamp=None, n_splits=8,
           tag=0, use_workspace=True, a_gather=None, b_gather=None):
     """dw [n_wsets, m_dim, n_dim] f32 += a^T b per group; db [n_wsets, n_dim] += colsum(b).
-    a_gather / b_gather: read the rows of a / b through an index (the routing permutation) instead of a dispatched copy."""
+    a_gather / b_gather: read the rows of a / b through an index (the routing permutation) instead of a dispatched copy.
+    With a workspace (default) the launch is the balanced stream kernel (swn_wgrad_multi: n_splits is ignored) whenever
+    n_groups % n_wsets == 0; use_workspace=False adds the partial tiles with fp32 atomics (the row-split kernel)."""
     m_dim, n_dim = a.shape[1], b.shape[1]
     assert group_stride is not None or (a_gather is None and b_gather is None)
     if m_dim > 256 or n_dim > 256:      # wider than one 256 x 256 tile: column blocks of the operands, one launch
@@ -484,15 +500,30 @@ def wgrad(a, b, dw, db=None, n_groups=1, n_wsets=1, group_stride=None, group_row
     gs = int(group_stride if group_stride is not None else a.shape[0])
     ws, ws_bytes = None, 0
     if use_workspace:
-        ws_bytes = int(n_groups) * int(n_splits) * (m_dim * n_dim + n_dim) * 4
-        key = (a.device, torch.cuda.current_stream().cuda_stream)     # one workspace per stream: launches may overlap
-        ws = _wgrad_ws.get(key)
-        if ws is None or ws.numel() < ws_bytes:
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
-            _wgrad_ws[key] = ws
+        ws = _wgrad_workspace(a.device, max(int(n_groups) * int(n_splits) * (m_dim * n_dim + n_dim) * 4, _multi_ws_bytes(1, n_wsets)))
         ws_bytes = ws.numel()
     call("swn_wgrad", _p(a), _p(b), _p(a_gather), _p(b_gather), _dt(a), m_dim, n_dim, int(n_groups), int(n_wsets), gs, _p(group_rows),
          int(group_rows_clamp if group_rows_clamp is not None else gs), _p(dw), _p(db), int(n_splits), int(tag), _p(ws), ws_bytes, _stream())
+
+
+def wgrad_multi(jobs, n_groups=1, n_wsets=1, group_stride=None, group_rows=None, group_rows_clamp=None, tag=0):
+    """jobs: tuples (a, b, dw, db, a_gather, b_gather) over ONE row grouping, each with its own widths (multiples of 32 up to 256):
+    the balanced stream launch (swn_wgrad_multi, include/swn.h) - up to 8 jobs per launch, the work cut into equal shares of the
+    valid rows, deterministic reduction.  dw [n_wsets, m, n] f32 (accumulated into), db [n_wsets, n] or None."""
+    a0 = jobs[0][0]
+    gs = int(group_stride if group_stride is not None else a0.shape[0])
+    for i0 in range(0, len(jobs), 8):
+        chunk = jobs[i0:i0 + 8]
+        arr = (WgradJob * len(chunk))()
+        for jb, (a, b, dw, db, ag, bg) in zip(arr, chunk):
+            m, n = a.shape[1], b.shape[1]
+            assert a.dtype == a0.dtype and b.dtype == a0.dtype and dw.shape[-2:] == (m, n) and dw.dtype == torch.float32
+            jb.a, jb.b, jb.a_gather, jb.b_gather, jb.dw, jb.db = _p(a), _p(b), _p(ag), _p(bg), _p(dw), _p(db)
+            jb.m_dim, jb.n_dim, jb.lda, jb.ldb, jb.ldw = m, n, m, n, n
+            jb.dw_set_stride, jb.db_set_stride = m * n, n
+        ws = _wgrad_workspace(a0.device, _multi_ws_bytes(len(chunk), n_wsets))
+        call("swn_wgrad_multi", arr, len(chunk), _dt(a0), int(n_groups), int(n_wsets), gs, _p(group_rows),
+             int(group_rows_clamp if group_rows_clamp is not None else gs), int(tag), _p(ws), ws.numel(), _stream())
 
 
 def wgrad_batched(items, n_groups=1, n_wsets=1, group_stride=None, group_rows=None, group_rows_clamp=None, n_splits=8, tag=0):
@@ -511,11 +542,7 @@ def wgrad_batched(items, n_groups=1, n_wsets=1, group_stride=None, group_rows=No
                 blocks.append((a.data_ptr() + i * esz, b.data_ptr() + j * esz, _p(ag), _p(bg), dw.data_ptr() + (i * N + j) * 4,
                                (db.data_ptr() + j * 4) if (db is not None and i == 0) else None))
     per = int(n_groups) * int(n_splits) * (bm * bn + bn) * 4
-    key = (a0.device, torch.cuda.current_stream().cuda_stream)
-    ws = _wgrad_ws.get(key)
-    if ws is None or ws.numel() < 8 * per:
-        ws = torch.empty(8 * per, dtype=torch.uint8, device=a0.device)
-        _wgrad_ws[key] = ws
+    ws = _wgrad_workspace(a0.device, max(8 * per, _multi_ws_bytes(8, n_wsets)))
     for i0 in range(0, len(blocks), 8):
         chunk = blocks[i0:i0 + 8]
         arr = (WgradItem * len(chunk))()

@@ -70,6 +70,8 @@ def render_rays(nerf, bg_nerf, rays: torch.Tensor, image_indices: Optional[torch
             if F > 0:
                 res["sigma_fine"] = st[1]["raw"][:, 3].view(N, F)
         return res, False
+    if not nerf.training and getattr(nerf, "graph_eval", False) and getattr(nerf, "ep", None) is None:
+        return _render_rays_graphed(nerf, rays, image_indices, hparams, N, S, F, chunk, get_depth, get_depth_variance), False
     if F > 0:
         c, cf, out = nerf.forward_hier(rays.contiguous(), image_indices, S, F, chunk, float(perturb), pr, None, noise, noise_f,
                                        no_batch=nerf.moe_no_batch, training=nerf.training)
@@ -97,6 +99,37 @@ def render_rays(nerf, bg_nerf, rays: torch.Tensor, image_indices: Optional[torch
     if getattr(hparams, "return_sigma", False):
         res["sigma_coarse"] = c["raw"][:, 3].view(N, S)
     return res, False
+
+
+def _render_rays_graphed(nerf, rays, image_indices, hparams, N, S, F, chunk, get_depth, get_depth_variance):
+    """Evaluation with `nerf.graph_eval = True`: the forward of this batch shape is captured once (graph.GraphedRender, cached on the
+    model per (rays, samples, fine samples, chunk, no_batch)) and replayed - Runner.render_image's pixel-batch loop
+    (runner.py:2835-2885) is ~60 launches per call otherwise.  Results are cloned out of the graph's static memory."""
+    from .graph import GraphedRender
+    cache = nerf.__dict__.setdefault("_render_graphs", {})
+    key = (N, S, F, int(chunk), bool(nerf.moe_no_batch), nerf.dtype)
+    nerf._sync_compute_copies()
+    g = cache.get(key)
+    if g is None:
+        g = cache[key] = GraphedRender(nerf, rays.contiguous(), image_indices, S, chunk, F, nerf.moe_no_batch)
+    o = g(rays, image_indices)
+    typ = "fine" if F > 0 else "coarse"
+    res = {f"rgb_{typ}": o["rgb"].clone(), "gate_loss_coarse": o["l_aux_coarse"].clone()}
+    if F > 0:
+        res["gate_loss_fine"] = o["l_aux_fine"].clone()
+    if get_depth:
+        res[f"depth_{typ}"] = o["depth"].clone()
+    if get_depth_variance:
+        res[f"depth_variance_{typ}"] = o["depth_variance"].clone()
+    if getattr(hparams, "moe_return_gates", False):
+        res["moe_gates_coarse"] = o["idx_coarse"].long().view(N, S, 1, 1)
+        if F > 0:
+            res["moe_gates_fine"] = o["idx_fine"].long().view(N, F, 1, 1)
+    if getattr(hparams, "return_sigma", False):
+        res["sigma_coarse"] = o["sigma_coarse"].reshape(N, S).clone()
+        if F > 0:
+            res["sigma_fine"] = o["sigma_fine"].reshape(N, F).clone()
+    return res
 
 
 def _render_rays_bg(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sphere_radius, get_depth, get_depth_variance,

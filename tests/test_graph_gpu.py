@@ -44,3 +44,63 @@ def test_graphed_train_step_equals_eager(dtype):
     d = (ma.flat - mb.flat).abs().max().item() / mb.flat.abs().max().item()
     assert d <= tol, d
     assert ma.step_count == mb.step_count == 3
+
+
+def _probe(*args, env=None, timeout=400):
+    """scripts/graph_probe.py in its own process (a GPU fault must not take the test session down) -> its result dict."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "graph_probe.py")] + list(args), capture_output=True, text=True,
+                       timeout=timeout, env=dict(os.environ, **(env or {})))
+    assert p.returncode == 0, (p.returncode, p.stderr[-800:])
+    line = [l for l in p.stdout.splitlines() if l.startswith("PROBE ")]
+    assert line, p.stdout[-400:]
+    return json.loads(line[-1][6:])
+
+
+@pytest.mark.parametrize("variant", [("--rays", "2048"), ("--rays", "1024", "--no-batch"), ("--rays", "1024", "--fine", "128")])
+def test_graphed_render_50_replays_equal_eager(variant):
+    """The inference forward (matrix-pipe router kernel inside) replayed 50 times from one hipGraph on alternating ray batches: every
+    checked replay equals the eager forward bit for bit (rgb and top-1 indices) - round 2's fault on the second replay of such a graph
+    does not occur."""
+    r = _probe("render", "--replays", "50", *variant)
+    assert r["ok"] and r["routing_mismatches"] == 0 and r["rgb_max_diff"] == 0.0, r
+
+
+def test_graphed_train_50_replays_equal_eager():
+    r = _probe("train", "--replays", "50", "--rays", "1024")
+    assert r["ok"], r
+    assert r["routing_mismatches"] <= 8, r          # (atomically ordered router gradient sums may flip a near-tie late in the run)
+
+
+def test_expert_chain_200_back_to_back_launches_bit_exact():
+    """200 full-size (2,097,152-row) launches of the phase-shifted expert chain: geometry 5 is bit-identical to the 64-row kernels on
+    every launch (outputs and all six saved activations) - the store-data hazard of round 2 (a later register value stored a few times
+    per 1e5 stores) would show here -, geometry 4 stays within its bias-first accumulation bound."""
+    r = _probe("chain", "--launches", "200", timeout=900)
+    assert r["ok"] and r["geometry5_launches_with_a_difference"] == 0, r
+
+
+def test_render_rays_graph_eval_matches_eager():
+    """rendering.render_rays with nerf.graph_eval = True (the path Runner.render_image's pixel-batch loop takes): same results as
+    the eager evaluation, for two different batches through the same cached graph, after an optimizer moved the weights."""
+    import argparse
+    from switch_nerf_amd import rendering
+    m = _model(torch.bfloat16, 43)
+    hp = argparse.Namespace(coarse_samples=64, fine_samples=32, model_chunk_size=8192, perturb=1.0, use_sigma_noise=True,
+                            sigma_noise_std=1.0, moe_return_gates=True, return_sigma=True)
+    m.eval()
+    m.set_no_batch(True)
+    for seed in (600, 601):
+        rays, img, _ = synth.make_rays(seed, 256)
+        m.graph_eval = False
+        a, _ = rendering.render_rays(m, None, _dev(rays), _dev(img), hp, None, None, True, True)
+        m.graph_eval = True
+        b, _ = rendering.render_rays(m, None, _dev(rays), _dev(img), hp, None, None, True, True)
+        assert set(a) == set(b)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    assert len(m._render_graphs) == 1

@@ -440,6 +440,75 @@ def test_wgrad_shapes(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", ["ragged", "tiny", "dense"])
+def test_wgrad_balanced_multi(dtype, shape):
+    """swn_wgrad_multi (the balanced stream launch): jobs of different widths over one ragged row grouping - empty groups, groups
+    past the capacity clamp, a row count that is no multiple of the slab, gathered operands, accumulation into a non-zero dW -
+    against an fp64 reference; two launches give the same bits (the cut and the reduction order depend on the row counts only)."""
+    o = ops()
+    rng = np.random.default_rng(77)
+    if shape == "ragged":
+        n_seg, E, cap = 3, 4, 700
+        counts = rng.integers(0, cap + 150, (n_seg, E))
+        counts[0, 1] = 0
+        counts[2, 3] = 0
+        counts[1, 2] = cap + 100
+    elif shape == "tiny":           # fewer slabs than workgroups: most shares are empty
+        n_seg, E, cap = 2, 2, 40
+        counts = np.array([[3, 0], [33, 40]])
+    else:                           # one group = a dense layer over all points
+        n_seg, E, cap = 1, 1, 9000
+        counts = None
+    ng, rows = n_seg * E, n_seg * E * cap
+    gr = None if counts is None else torch.from_numpy(counts.reshape(-1).astype(np.int32)).to(dev())
+    valid = np.full(ng, cap) if counts is None else np.minimum(counts.reshape(-1), cap)
+    dims = [(256, 256, True), (128, 256, True), (256, 64, False)]
+    perm = torch.from_numpy(rng.permutation(rows).astype(np.int32))
+    jobs, refs = [], []
+    for ji, (m, n, bias) in enumerate(dims):
+        a = _round(torch.from_numpy(rng.standard_normal((rows, m)).astype(np.float32)), dtype)
+        b = _round(torch.from_numpy(rng.standard_normal((rows, n)).astype(np.float32)), dtype)
+        dw = torch.full((E, m, n), 1.0, device=dev())
+        db = torch.full((E, n), -2.0, device=dev()) if bias else None
+        ag = None
+        a_dev = a.to(dev()).to(dtype)
+        if ji == 1:                 # this job reads its A rows through an index: store them shuffled
+            src = torch.empty_like(a_dev)
+            src[perm.long().to(dev())] = a_dev
+            a_dev, ag = src, perm.to(dev())
+        jobs.append((a_dev, b.to(dev()).to(dtype), dw, db, ag, None))
+        rw = torch.ones(E, m, n, dtype=torch.float64)
+        rb = torch.full((E, n), -2.0, dtype=torch.float64)
+        for g in range(ng):
+            r0, r1 = g * cap, g * cap + int(valid[g])
+            rw[g % E] += a[r0:r1].double().t() @ b[r0:r1].double()
+            rb[g % E] += b[r0:r1].double().sum(0)
+        refs.append((rw.float(), rb.float()))
+    kw = dict(n_groups=ng, n_wsets=E, group_stride=cap, group_rows=gr, group_rows_clamp=cap, tag=1)
+    o.wgrad_multi(jobs, **kw)
+    tol = 2e-5 * max(1, int(valid.max())) ** 0.5 * 8
+    for ji, ((a, b, dw, db, _ag, _bg), (rw, rb)) in enumerate(zip(jobs, refs)):
+        assert report(f"wgrad_multi_{shape}_{ji}_{dtype}", dw, rw) <= tol
+        if db is not None:
+            assert report(f"wgrad_multi_db_{shape}_{ji}_{dtype}", db, rb) <= tol
+    first = [(j[2].clone(), None if j[3] is None else j[3].clone()) for j in jobs]
+    for j in jobs:
+        j[2].fill_(1.0)
+        if j[3] is not None:
+            j[3].fill_(-2.0)
+    o.wgrad_multi(jobs, **kw)
+    for j, (w1, b1) in zip(jobs, first):
+        assert torch.equal(j[2], w1) and (b1 is None or torch.equal(j[3], b1))
+    # the single-GEMM entry point takes the same path and gives the same bits as a one-job launch
+    a, b, dw, db, ag, _ = jobs[0]
+    w_single, b_single = torch.zeros_like(dw), torch.zeros_like(db)
+    o.wgrad(a, b, w_single, b_single, n_groups=ng, n_wsets=E, group_stride=cap, group_rows=gr, group_rows_clamp=cap, n_splits=2)
+    w_multi, b_multi = torch.zeros_like(dw), torch.zeros_like(db)
+    o.wgrad_multi([(a, b, w_multi, b_multi, None, None)], **dict(kw, tag=0))
+    assert torch.equal(w_single, w_multi) and torch.equal(b_single, b_multi)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_heads_and_combine_bwd(dtype):
     rng = np.random.default_rng(61)
     P, M, H2 = 2500, 256, 128
