@@ -32,3 +32,33 @@ for splits in [int(v) for v in sys.argv[1:]] or [2]:
         b.record(); torch.cuda.synchronize()
         ms = a.elapsed_time(b) / 5
         print(f"splits {splits} {name:32s} kept {kept / ROWS:.3f}: {ms:.3f} ms, {ms * 1e6 / kept:.3f} ns per kept row, {kept * 7 * 1024 / ms / 1e9:.2f} TB/s of operand reads")
+
+# ---- the five dense-layer weight gradients of the step (2,097,152 points): per-layer launches vs the two batched launches
+P, KP, H2 = 8192 * 256, 128, 128
+t = lambda c: torch.randn(P, c, device=dev).to(dt)
+h1, dh2, y, dh1, a1, dg, h0, dza1, pe, dh0 = t(M), t(H2), t(M), t(M), t(M), t(M), t(M), t(M), t(KP), t(M)
+z = lambda *s: torch.zeros(*s, device=dev)
+tail = [(h1, dh2, z(1, M, H2), None), (y, dh1, z(1, M, M), z(1, M))]
+front = [(a1, dg, z(1, M, M), z(1, M)), (h0, dza1, z(1, M, M), z(1, M)), (pe, dh0, z(1, KP, M), z(1, M))]
+nbytes = sum((a.shape[1] + b.shape[1]) * 2 * P for a, b, _w, _b in tail + front)
+
+
+def per_layer():
+    for a, b, w, bb in tail + front:
+        o.wgrad(a, b, w, bb, n_splits=256)
+
+
+def batched():
+    o.wgrad_multi([(a, b, w, bb, None, None) for a, b, w, bb in tail])
+    o.wgrad_multi([(a, b, w, bb, None, None) for a, b, w, bb in front])
+
+
+for name, f in (("dense per-layer launches", per_layer), ("dense 2 batched launches", batched)):
+    f(); f(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5):
+        f()
+    b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 5
+    print(f"{name}: {ms:.3f} ms, {nbytes / ms / 1e9:.2f} TB/s of operand reads")

@@ -155,21 +155,30 @@ class BackgroundScene:
         diff = ctx["rgb"] - rgbs
         photo = (diff * diff).mean()
         loss = photo + nerf.wt * gate_loss
-        d_rgb = (diff * (2.0 / diff.numel())).contiguous()
-        self.backward(ctx, d_rgb, nerf.wt * (0.5 if fine else 1.0), nerf.wt * 0.5)
+        # fp16 (the reference's single GradScaler over both optimizers, runner.py:483, 679-690): one loss scale - the foreground model's
+        # scaler - multiplies the loss gradient; both models unscale by it, and a non-finite gradient in either skips that model's step
+        ls = 1.0
+        if nerf.loss_scaler is not None:
+            ls = float(nerf.loss_scaler.scale)
+            nerf._loss_scale_tensor()                     # (records the scale this backward uses: _unscale_ok divides by it)
+            if bg.loss_scaler is not None:
+                bg.loss_scaler.scale = nerf.loss_scaler.scale
+                bg._loss_scale_tensor()
+        d_rgb = (diff * (2.0 * ls / diff.numel())).contiguous()
+        self.backward(ctx, d_rgb, ls * nerf.wt * (0.5 if fine else 1.0), ls * nerf.wt * 0.5)
         # the reference skips the background optimizer on batches without background rays (runner.py:683: `if key == 'bg_nerf'
-        # and not bg_nerf_rays_present: continue`): no Adam step, no moment decay, no step-counter increment.  Under data
-        # parallelism the flag is the OR over the ranks (every rank still joins the gradient all-reduce).
-        bg_present = ctx["Nb"] > 0
-        if grad_allreduce is not None:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized():
-                flag = torch.tensor([1.0 if bg_present else 0.0], device=self.dev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                bg_present = bool(flag.item() > 0)
+        # and not bg_nerf_rays_present: continue`): no Adam step, no moment decay, no step-counter increment - in a SINGLE-process
+        # run.  In a distributed run ('RANK' in os.environ) render_rays makes a dummy background forward on a rank without background
+        # rays and reports bg_nerf_rays_present = True (rendering.py:162-194), so there the background Adam steps on EVERY iteration
+        # (with a zero gradient when no rank had background rays: moments decay, step count grows).  Same rule here.
+        import torch.distributed as dist
+        distributed = grad_allreduce is not None or (dist.is_available() and dist.is_initialized())
+        bg_present = True if distributed else ctx["Nb"] > 0
         for m in (nerf, bg):
             scale = grad_allreduce(m._allreduce_view()) if grad_allreduce is not None else 1.0
-            if optimizer_step and (m is nerf or bg_present):
+            if optimizer_step and (m is nerf or bg_present) and m._unscale_ok():
+                if m.loss_scaler is not None:            # fp16: the gradient carries the loss scale (backward above)
+                    scale /= m._applied_loss_scale
                 m.step_count += 1
                 ops.adam_step(m.flat, m.grad, m.m, m.v, None, m.step_count, m.lr, grad_scale=scale)
                 m.refresh_compute_copies()

@@ -162,9 +162,12 @@ def exponential_lr(base_lr: float, iteration: int, lr_decay_factor: float = 0.1,
 def save_checkpoint(path, nerf, bg_nerf=None, iteration: int = 0, dataset_index: int = 0, module_prefix: bool = True) -> dict:
     """Writes (and returns) the reference's checkpoint dict; module_prefix reproduces the DDP-wrapped key names."""
     pre = "module." if module_prefix else ""
+    if getattr(nerf, "ep", None) is not None:      # expert-parallel run: a rank holds trained weights only for the experts it owns;
+        nerf.gather_expert_shards()                # collective - every rank must call save_checkpoint (any rank may then write the file)
+    scaler = getattr(nerf, "loss_scaler", None)
     ck = {"model_state_dict": {pre + k: v.detach().cpu() for k, v in nerf.state_dict().items()},
           "optimizers": {"nerf": adam_state_dict(nerf)}, "iteration": int(iteration), "dataset_index": int(dataset_index),
-          "scaler": {}, "torch_random_state": torch.get_rng_state()}
+          "scaler": scaler.state_dict() if scaler is not None else {}, "torch_random_state": torch.get_rng_state()}
     if bg_nerf is not None:
         ck["bg_model_state_dict"] = {pre + k: v.detach().cpu() for k, v in bg_nerf.state_dict().items()}
         ck["optimizers"]["bg_nerf"] = adam_state_dict(bg_nerf)
@@ -181,6 +184,10 @@ def load_checkpoint(path_or_dict, nerf, bg_nerf=None) -> int:
     nerf.load_state_dict(ck["model_state_dict"])
     if "optimizers" in ck and "nerf" in ck["optimizers"]:
         load_adam_state_dict(nerf, ck["optimizers"]["nerf"])
+    if getattr(nerf, "loss_scaler", None) is not None and ck.get("scaler"):     # GradScaler state (runner.py:2806): the scale survives a resume
+        nerf.loss_scaler.load_state_dict(ck["scaler"])
+        if getattr(nerf, "_ls_dev", None) is not None:
+            nerf._loss_scale_tensor()
     if bg_nerf is not None:
         bg_nerf.load_state_dict(ck["bg_model_state_dict"])
         if "optimizers" in ck and "bg_nerf" in ck["optimizers"]:

@@ -89,4 +89,22 @@ int chain_big_mask_words_per_tile(int geometry);
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Device fills are KERNELS in this library, never hipMemsetAsync: captured into a hipGraph a hipMemsetAsync becomes a memset NODE, and
+// with ROCm 7.2 such a node leaves wrong memory contents from the SECOND replay of the graph on (scripts/memset_graph_repro.py: torch +
+// libamdhip64 only; first replay correct, every later one wrong, with or without freeing the target during the capture; the same
+// graph with fill kernels is correct).  That was the "GPU fault on the second replay" of round 2's inference graph: the per-segment
+// counts were not zero on the second replay, route_finalize_kernel computed negative slots from them and wrote perm[] out of bounds.
+static __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t* __restrict__ p, uint32_t v, long n) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+static inline hipError_t fill_u32_async(void* p, uint32_t v, size_t bytes, hipStream_t s) {   // bytes: a multiple of 4
+  const long n = (long)(bytes / 4);
+  if (n <= 0) return hipSuccess;
+  int blocks = cdiv(n, 256 * 8);
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipLaunchKernelGGL(fill_u32_kernel, dim3(blocks), dim3(256), 0, s, (uint32_t*)p, v, n);
+  return hipGetLastError();
+}
+
 }  // namespace swn

@@ -1133,7 +1133,7 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
   }
   {
     const int chunks = dwg_blocks < 16 ? dwg_blocks : 16, bpc = cdiv(dwg_blocks, chunks);
-    hipError_t me = hipMemsetAsync(msum, 0, (size_t)ps * sizeof(float), as_stream(stream));
+    hipError_t me = fill_u32_async(msum, 0u, (size_t)ps * sizeof(float), as_stream(stream));
     SWN_CHECK(me == hipSuccess, "swn_gate_bwd: memset: %s", hipGetErrorString(me));
     hipLaunchKernelGGL(gate_dwg_reduce_kernel, dim3(cdiv(ps, 256), cdiv(dwg_blocks, bpc)), dim3(256), 0, as_stream(stream), dwg_partial,
                        dwg_blocks, bpc, ps, msum);
@@ -1168,7 +1168,7 @@ extern "C" int swn_dispatch_fwd(const float* gates, const int32_t* indices, cons
                                 int capacity, int n_experts, void* stream) {
   SWN_CHECK(dispatched, "swn_dispatch_fwd: null");
   const size_t bytes = (size_t)n_experts * capacity * hidden * (dtype == SWN_HALF ? 2 : 4);
-  hipError_t e = hipMemsetAsync(dispatched, 0, bytes, as_stream(stream));  // torch.zeros at tutel_fast_dispatch.py:25
+  hipError_t e = fill_u32_async(dispatched, 0u, bytes, as_stream(stream));  // torch.zeros at tutel_fast_dispatch.py:25
   SWN_CHECK(e == hipSuccess, "swn_dispatch_fwd: memset failed: %s", hipGetErrorString(e));
   return launch_sparse<0>(gates, indices, locations, (void*)reshaped_input, dispatched, nullptr, dtype, samples, hidden,
                           capacity, samples, n_experts, 0, stream);
@@ -1194,7 +1194,7 @@ extern "C" int swn_dispatch_nobatch_fwd(const float* gates, const int32_t* indic
                                         int samples, int hidden, int capacity, int n_experts, long dispatched_rows, void* stream) {
   SWN_CHECK(dispatched && expert_locations_begin, "swn_dispatch_nobatch_fwd: null");
   const size_t bytes = (size_t)dispatched_rows * hidden * (dtype == SWN_HALF ? 2 : 4);
-  hipError_t e = hipMemsetAsync(dispatched, 0, bytes, as_stream(stream));  // torch.zeros at tutel_fast_dispatch_nobatch.py:34
+  hipError_t e = fill_u32_async(dispatched, 0u, bytes, as_stream(stream));  // torch.zeros at tutel_fast_dispatch_nobatch.py:34
   SWN_CHECK(e == hipSuccess, "swn_dispatch_nobatch_fwd: memset failed: %s", hipGetErrorString(e));
   return launch_sparse<0>(gates, indices, locations, (void*)reshaped_input, dispatched, nullptr, dtype, samples, hidden,
                           capacity > 0 ? capacity : 1, samples, n_experts, 0, stream, expert_locations_begin);

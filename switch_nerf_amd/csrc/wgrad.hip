@@ -493,48 +493,59 @@ __global__ __launch_bounds__(WG_NT) void wgrad_stream_kernel(const WsArgs p) {
       ip = __builtin_amdgcn_readfirstlane(ip); rp = __builtin_amdgcn_readfirstlane(rp);
       rows_p = __builtin_amdgcn_readfirstlane(rows_p); left = __builtin_amdgcn_readfirstlane(left);
 
-      auto produce = [&](int slot) {                       // next slab of the piece (or zeros past its end) -> ring slot
+      // The producer in two halves: prepare() works out the four source addresses of the next slab (scalar row arithmetic, the gather
+      // indices by scalar loads, one 64-bit multiply-add per address) and advances the cursor; issue() is the four LDS copies alone.
+      // The loop prepares BEFORE it waits for the current slab and the barrier, so the copies go out right behind the barrier
+      // (the address arithmetic used to sit between the barrier and the copies: ~300 instructions per slab on every wave).
+      int gp = (ip % segs) * n_wsets + e;                  // group of the cursor (ordered group ip + 1 = group gp + n_wsets)
+      const char* a_lane = (const char*)it.a + a_colb;
+      const char* b_lane = (const char*)it.b + b_colb;
+      const uint32_t a_rb = (uint32_t)it.lda * (uint32_t)sizeof(T), b_rb = (uint32_t)it.ldb * (uint32_t)sizeof(T);
+      typedef const __attribute__((address_space(4))) int32_t* cidx_t;
+      const cidx_t ag = (cidx_t)it.a_gather, bg = (cidx_t)it.b_gather;
+      const char* src[4];                                  // [2 pieces] x (A, B)
+      auto prepare = [&]() {
         const bool live = left > 0;
-        const int g = (ip % segs) * n_wsets + e;
-        const long grow0 = (long)g * p.group_stride;
+        const long grow0 = (long)gp * p.group_stride;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int piece = 2 * wave + i;
-          const int rf = rp + piece * RPP;
-          long asr[RPP], bsr[RPP];
-#pragma unroll
-          for (int q = 0; q < RPP; ++q) {
-            const long row = grow0 + max(min(rf + q, rows_p - 1), 0);
-            typedef const __attribute__((address_space(4))) int32_t* cidx_t;
-            asr[q] = (live && it.a_gather) ? (long)max(((cidx_t)it.a_gather)[row], 0) : row;
-            bsr[q] = (live && it.b_gather) ? (long)max(((cidx_t)it.b_gather)[row], 0) : row;
-          }
+          const int rf = rp + (2 * wave + i) * RPP;        // first row of this wave's piece (wave-uniform)
+          const long r0 = grow0 + max(min(rf, rows_p - 1), 0), r1 = grow0 + max(min(rf + RPP - 1, rows_p - 1), 0);
+          long a0 = r0, a1 = r1, b0 = r0, b1 = r1;
+          if (live && ag) { a0 = max(ag[r0], 0); if (RPP == 2) a1 = max(ag[r1], 0); }
+          if (live && bg) { b0 = max(bg[r0], 0); if (RPP == 2) b1 = max(bg[r1], 0); }
           const bool ok = live && (rf + prow < rows_p);
-          const long as = RPP == 2 ? (prow ? asr[RPP - 1] : asr[0]) : asr[0];
-          const long bs = RPP == 2 ? (prow ? bsr[RPP - 1] : bsr[0]) : bsr[0];
-          const char* ap = ok ? (const char*)it.a + (as * (long)it.lda) * sizeof(T) + a_colb : zero;
-          const char* bp = ok ? (const char*)it.b + (bs * (long)it.ldb) * sizeof(T) + b_colb : zero;
-          dma16(ap, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(slot * 2 * SLAB + piece * 1024)));
-          dma16(bp, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(slot * 2 * SLAB + SLAB + piece * 1024)));
+          const uint32_t as = (uint32_t)((RPP == 2 && prow) ? a1 : a0), bs = (uint32_t)((RPP == 2 && prow) ? b1 : b0);
+          src[2 * i] = ok ? a_lane + (uint64_t)as * a_rb : zero;
+          src[2 * i + 1] = ok ? b_lane + (uint64_t)bs * b_rb : zero;
         }
         if (live) {                                        // advance (wave-uniform)
           --left;
           rp += BKR;
           if (rp >= rows_p && left > 0) {
-            do { ++ip; rows_p = __builtin_amdgcn_readfirstlane(rws[ip]); } while (rows_p == 0);
+            do { ++ip; gp += n_wsets; rows_p = __builtin_amdgcn_readfirstlane(rws[ip]); } while (rows_p == 0);
             rp = 0;
           }
+        }
+      };
+      auto issue = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int piece = 2 * wave + i;
+          dma16(src[2 * i], __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(slot * 2 * SLAB + piece * 1024)));
+          dma16(src[2 * i + 1], __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(slot * 2 * SLAB + SLAB + piece * 1024)));
         }
       };
 
       const int nsl = pb - pa;
 #pragma unroll
-      for (int s0 = 0; s0 < WG_NS - 1; ++s0) produce(s0);
+      for (int s0 = 0; s0 < WG_NS - 1; ++s0) { prepare(); issue(s0); }
       int slot = 0;
       for (int n = 0; n < nsl; ++n) {
+        prepare();
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        produce((slot + WG_NS - 1) % WG_NS);
+        issue((slot + WG_NS - 1) % WG_NS);
         const char* A = sa(slot);
         const char* B = sb(slot);
         if (active || do_bias) {

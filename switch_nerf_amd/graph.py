@@ -21,11 +21,16 @@ class GraphedTrainStep:
 
     def __init__(self, model, rgbs, rays, image_indices, n_samples: int, seg_tokens: int, perturb: float = 1.0, noise_std: float = 1.0,
                  routing_override=None, warmup: int = 2):
+        if model.ep is not None and model.ep.world > 1:
+            raise ValueError("GraphedTrainStep: the expert-parallel step issues RCCL collectives between its kernels and is not captured; "
+                             "use SwitchNeRF.train_step")
         self.model = model
         dev = model.dev
         self.rgbs, self.rays, self.idx = rgbs.clone(), rays.clone(), image_indices.clone()
         N, S = rays.shape[0], int(n_samples)
         P = N * S
+        if model.loss_scaler is not None:
+            model._loss_scale_tensor()                     # exists before the capture (it is read, not created, inside the graph)
         ro = None if routing_override is None else routing_override.to(dev).int().contiguous()
 
         def run():
@@ -59,14 +64,9 @@ class GraphedTrainStep:
         if image_indices is not None:
             self.idx.copy_(image_indices)
         self.graph.replay()
-        scale = 1.0
-        if grad_allreduce is not None:
-            scale = grad_allreduce(m._allreduce_view())
-        if optimizer_step:
-            from . import ops
-            m.step_count += 1
-            ops.adam_step(m.flat, m.grad, m.m, m.v, None, m.step_count, m.lr, grad_scale=scale)
-            self.copies.replay()
+        # all-reduce, loss-scale handling (fp16: inf check, skipped step, scale update - the captured step reads the scale from a
+        # device scalar), Adam and the refresh of the compute copies (a second small graph): SwitchNeRF.apply_step
+        m.apply_step(grad_allreduce, optimizer_step, refresh=self.copies.replay)
         return self.res
 
 

@@ -65,6 +65,16 @@ class LossScaler:
         return {"scale": self.scale, "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
                 "growth_interval": self.growth_interval, "_growth_tracker": self._good}
 
+    def load_state_dict(self, sd):
+        """GradScaler.load_state_dict's keys (the reference saves scaler.state_dict() under 'scaler', runner.py:2806)."""
+        if not sd:
+            return
+        self.scale = float(sd.get("scale", self.scale))
+        self.growth_factor = float(sd.get("growth_factor", self.growth_factor))
+        self.backoff_factor = float(sd.get("backoff_factor", self.backoff_factor))
+        self.growth_interval = int(sd.get("growth_interval", self.growth_interval))
+        self._good = int(sd.get("_growth_tracker", 0))
+
 
 class SwitchNeRF:
     def __init__(self, cfg: dict = BUILDING, dtype=torch.bfloat16, device="cuda", capacity_factor=1.0,
@@ -300,21 +310,35 @@ class SwitchNeRF:
         their full size (3.7 M expert parameters); gather_expert_shards() refreshes every rank's copy from the owners before a
         checkpoint / evaluation without expert parallelism."""
         assert ep is None or ep.E == self.E
+        if ep is None and self.ep is not None:       # leaving expert parallelism: every rank needs every expert's trained weights
+            self.gather_expert_shards()
         self.ep = ep
 
     def gather_expert_shards(self, include_optimizer=True):
-        """Every expert's parameters (and Adam moments) from its owner rank to all ranks (expert-parallel runs only)."""
+        """Every expert's parameters (and Adam moments) from its owner rank to all ranks (expert-parallel runs only): called by
+        checkpoint.save_checkpoint and before leaving expert parallelism, so a checkpoint written by ANY rank holds every expert's
+        trained weights.  The expert block is the contiguous tail of the flat buffers: per buffer, the owners' slices are packed
+        rank-major, exchanged with ONE all_gather, and scattered back per tensor."""
         import torch.distributed as dist
         ep = self.ep
         if ep is None or ep.world == 1:
             return
+        W, El, r = ep.world, ep.El, ep.rank
         bufs = [self.flat] + ([self.m, self.v] if include_optimizer else [])
+        spans = []                                   # (offset of the tensor in the flat buffer, elements per expert)
         for name, _shape in self._expert_spec:
             off, shape = self.spec[name]
-            per = int(np.prod(shape)) // self.E
-            for r in range(ep.world):
-                for b in bufs:
-                    dist.broadcast(b[off + r * ep.El * per: off + (r + 1) * ep.El * per], src=r, group=ep.group)
+            spans.append((off, int(np.prod(shape)) // self.E))
+        per_rank = sum(El * per for _o, per in spans)
+        for b in bufs:
+            mine = torch.cat([b[off + r * El * per: off + (r + 1) * El * per] for off, per in spans])
+            full = torch.empty(W * per_rank, dtype=b.dtype, device=b.device)
+            dist.all_gather_into_tensor(full, mine, group=ep.group)
+            full = full.view(W, per_rank)
+            q = 0
+            for off, per in spans:
+                b[off: off + self.E * per].view(W, El * per).copy_(full[:, q:q + El * per])
+                q += El * per
         self.refresh_compute_copies()
 
     def _local_experts(self, t, per_expert_leading=True):
@@ -405,8 +429,8 @@ class SwitchNeRF:
     def _net_forward(self, pe, pe_dir, image_indices, N, S, seg_tokens, sigma_noise, routing_override, no_batch, tag):
         """NeRFMoE.forward over the N*S points whose encodings are in `pe`, evaluated in model chunks of seg_tokens points like
         the reference's loop (rendering.py:354-383): routing, capacity and l_aux are per chunk.  A ragged last chunk
-        (N*S not a multiple of seg_tokens - evaluation batches) is routed on its own with its own capacity, exactly as the
-        reference does; that case is inference-only here (no backward through a ragged context)."""
+        (N*S not a multiple of seg_tokens) is routed on its own with its own capacity, exactly as the reference does - in
+        evaluation and in training (backward_net walks the two parts)."""
         P = N * S
         seg_tokens = min(seg_tokens, P)
         if P % seg_tokens == 0:
@@ -557,7 +581,7 @@ class SwitchNeRF:
         rowbias, rpb = c["c_ray"], S
         if row_range is not None:  # a row range of the point grid: the rows' rays through an explicit per-row gather
             rowbias, rpb = c["c_ray"].index_select(0, torch.arange(r0, r1, device=dev) // S), 1
-            c["ragged"] = True
+            c["ragged"], c["row0"] = True, r0
         o.mlp_chain(c["eo"], [o.Layer(self.wf["l1"], self.p["l1.b"].view(1, M), save=c["h1"] if sv else None),
                               o.Layer(self.wf["l2h"], None, relu=1, rowbias=rowbias, rows_per_bias=rpb)], c["h2"],
                     group_stride=P, x_gather=c["row_of_tok"], x_save=c["y"], x_scale=c["gmax"], x_relu=True, tag=4)
@@ -577,9 +601,16 @@ class SwitchNeRF:
         o, dt = ops, self.dtype
         if c.get("no_grad"):
             raise RuntimeError("this context comes from an inference forward (training=False): nothing was saved for the backward")
-        if c.get("ragged"):
-            raise NotImplementedError("backward through a ragged last model chunk: training batches must be a multiple of "
-                                      "model_chunk_size points (evaluation handles any size)")
+        if c.get("parts") is not None:
+            # a ragged last model chunk (rendering.py:354-383 trains any batch size): the whole chunks and the short last chunk were
+            # routed as two contexts with their own capacities; each runs its own backward on its rows of dL/d raw and its chunks'
+            # share of the l_aux gradient
+            if self.hash is not None:
+                raise NotImplementedError("hash-grid encoding with a ragged last model chunk: make N_rays * samples a multiple of model_chunk_size")
+            a, b = c["parts"]
+            self.backward_net(a, d_raw[: a["P"]], d_laux[: a["n_seg"]].contiguous())
+            self.backward_net(b, d_raw[a["P"]:], d_laux[a["n_seg"]:].contiguous())
+            return
         N, S, P, n_seg, cap, seg_tokens = c["N"], c["S"], c["P"], c["n_seg"], c["cap"], c["seg_tokens"]
         M, E, L, G, H2 = self.M, self.E, self.L, self.G, self.H2
         g = self.g
@@ -588,7 +619,11 @@ class SwitchNeRF:
         dh2, dsig = o.heads_bwd(c["y"], c["h2"], self.p["color.w"], c["raw"], d_raw, g["sigma.w"], g["sigma.b"], g["color.w"],
                                 g["color.b"])
         # per-ray bias gradient and the tiny per-ray GEMM's parameters
-        dc_ray = o.group_colsum(dh2, S)
+        if c.get("ragged"):      # a row range of the point grid: rays may be cut at either end - per-ray sums through the rows' ray index
+            ray_of_row = torch.arange(c["row0"], c["row0"] + P, device=self.dev) // S
+            dc_ray = torch.zeros(N, H2, dtype=torch.float32, device=self.dev).index_add_(0, ray_of_row, dh2.float())
+        else:
+            dc_ray = o.group_colsum(dh2, S)
         g["l2r.w"].addmm_(c["ray_feat"].t(), dc_ray)
         g["l2.b"].add_(dc_ray.sum(0))
         d_feat_emb = dc_ray @ self.p["l2r.w"][self.in_dir:].t()
@@ -748,24 +783,27 @@ class SwitchNeRF:
         diff = out["rgb"] - rgbs
         photo = (diff * diff).mean()                                      # F.mse_loss, runner.py:1099
         loss = photo + self.wt * gate_loss                                # runner.py:646-651
-        ls = self.loss_scaler.scale if self.loss_scaler is not None else 1.0      # scaler.scale(loss).backward(), runner.py:679
-        d_rgb = (diff * (2.0 * ls / diff.numel())).contiguous()
+        # scaler.scale(loss).backward(), runner.py:679: the scale is read from a DEVICE scalar (kept equal to loss_scaler.scale by
+        # _unscale_ok), so a captured step (graph.GraphedTrainStep) follows the scale as it adapts between replays
+        ls = self._loss_scale_tensor() if self.loss_scaler is not None else 1.0
+        d_rgb = (diff * (2.0 / diff.numel()) * ls).contiguous()
         if not fine:
-            d_laux = torch.full((c["n_seg"],), ls * self.wt / c["n_seg"], dtype=torch.float32, device=self.dev)
+            d_laux = torch.full((c["n_seg"],), self.wt / c["n_seg"], dtype=torch.float32, device=self.dev) * ls
             self.backward(c, d_rgb, d_laux)
         else:
             d_raw_m = ops.composite_bwd(out["raw"], out["z"], d_rgb)
             d_raw_f, d_raw_c = ops.unmerge_grad(d_raw_m, out["order"], fine_samples, n_samples)
-            self.backward_net(cf, d_raw_f, torch.full((cf["n_seg"],), 0.5 * ls * self.wt / cf["n_seg"], dtype=torch.float32, device=self.dev))
-            self.backward_net(c, d_raw_c, torch.full((c["n_seg"],), 0.5 * ls * self.wt / c["n_seg"], dtype=torch.float32, device=self.dev))
+            self.backward_net(cf, d_raw_f, torch.full((cf["n_seg"],), 0.5 * self.wt / cf["n_seg"], dtype=torch.float32, device=self.dev) * ls)
+            self.backward_net(c, d_raw_c, torch.full((c["n_seg"],), 0.5 * self.wt / c["n_seg"], dtype=torch.float32, device=self.dev) * ls)
         res = dict(loss=loss, photo_loss=photo, gate_loss=gate_loss, psnr=-10.0 * torch.log10(photo),
                    depth_variance=out["depth_variance"].mean(), ctx=c, rgb=out["rgb"], depth=out["depth"])
         if fine:
             res["ctx_fine"] = cf
         return res
 
-    def apply_step(self, grad_allreduce=None, optimizer_step=True):
-        """Gradient all-reduce (N > 1) + Adam (runner.py:486, 686) + refresh of the compute copies of the weights."""
+    def apply_step(self, grad_allreduce=None, optimizer_step=True, refresh=None):
+        """Gradient all-reduce (N > 1) + Adam (runner.py:486, 686) + refresh of the compute copies of the weights (`refresh`: a
+        replacement for refresh_compute_copies, e.g. the replay of its captured graph)."""
         scale = 1.0
         if grad_allreduce is not None:
             scale = grad_allreduce(self._allreduce_view())
@@ -774,16 +812,37 @@ class SwitchNeRF:
                 scale /= self._applied_loss_scale
             self.step_count += 1
             ops.adam_step(self.flat, self.grad, self.m, self.v, None, self.step_count, self.lr, grad_scale=scale)
-            self.refresh_compute_copies()
+            (refresh or self.refresh_compute_copies)()
+
+    _ls_dev = None
+    _ls_dev_val = None
+
+    def _loss_scale_tensor(self):
+        """The current loss scale as a device scalar (see grad_step), refreshed whenever the host value has changed since the last
+        call (after _unscale_ok adapted it, after a checkpoint load, after a caller set loss_scaler.scale)."""
+        v = float(self.loss_scaler.scale)
+        if self._ls_dev is None:
+            self._ls_dev = torch.full((1,), v, dtype=torch.float32, device=self.dev)
+        elif self._ls_dev_val != v:
+            self._ls_dev.fill_(v)
+        self._ls_dev_val = v
+        return self._ls_dev
 
     def _unscale_ok(self) -> bool:
         """GradScaler.step / update (runner.py:686-690): with loss scaling on, skip the optimizer step when a gradient is not finite
-        (one device-to-host flag per step, like torch's found_inf) and adapt the scale.  Always True without loss scaling."""
+        (one device-to-host flag per step, like torch's found_inf) and adapt the scale.  Always True without loss scaling.
+        Under expert parallelism the expert part of the gradient is rank-local (never all-reduced), so the flag is agreed over the
+        ranks (MAX): every rank skips - or takes - the same steps and holds the same scale."""
         if self.loss_scaler is None:
             return True
-        self._applied_loss_scale = self.loss_scaler.scale
-        found_inf = not bool(torch.isfinite(self.grad).all().item())
+        self._applied_loss_scale = self._ls_dev_val if self._ls_dev_val is not None else self.loss_scaler.scale   # what the backward used
+        bad = (~torch.isfinite(self.grad).all()).to(torch.float32).view(1)
+        if self.ep is not None and self.ep.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.ep.group)
+        found_inf = bool(bad.item() > 0)
         self.loss_scaler.update(found_inf)
+        self._loss_scale_tensor()           # the device copy follows (a captured step reads it on its next replay)
         return not found_inf
 
     def _allreduce_view(self):
@@ -876,26 +935,18 @@ class SwitchNeRF:
         levels = [c] if cf is None else [cf, c]
         share = 1.0 / len(levels)
         photo, gate_loss = 0.0, 0.0
+        ls = self._loss_scale_tensor() if self.loss_scaler is not None else 1.0
         for lv in levels:
             diff = lv["rgb"] - rgbs
-            ls = self.loss_scaler.scale if self.loss_scaler is not None else 1.0
-            lv["_d_rgb"] = (diff * (2.0 * ls * share / diff.numel())).contiguous()
+            lv["_d_rgb"] = (diff * (2.0 * share / diff.numel()) * ls).contiguous()
             photo = photo + share * (diff * diff).mean()
             gate_loss = gate_loss + share * lv["l_aux"].mean()
         loss = photo + self.wt * gate_loss
         for lv in levels:
             d_raw = ops.composite_bwd(lv["raw"], lv["z"], lv["_d_rgb"], rgb_padding=lv["rgb_padding"])
-            d_laux = torch.full((lv["n_seg"],), ls * share * self.wt / lv["n_seg"], dtype=torch.float32, device=self.dev)
+            d_laux = torch.full((lv["n_seg"],), share * self.wt / lv["n_seg"], dtype=torch.float32, device=self.dev) * ls
             self.backward_net(lv, d_raw, d_laux)
-        scale = 1.0
-        if grad_allreduce is not None:
-            scale = grad_allreduce(self._allreduce_view())
-        if optimizer_step and self._unscale_ok():
-            if self.loss_scaler is not None:
-                scale /= self._applied_loss_scale
-            self.step_count += 1
-            ops.adam_step(self.flat, self.grad, self.m, self.v, None, self.step_count, self.lr, grad_scale=scale)
-            self.refresh_compute_copies()
+        self.apply_step(grad_allreduce, optimizer_step)
         top = levels[0]
         return dict(loss=loss, photo_loss=photo, gate_loss=gate_loss, psnr=-10.0 * torch.log10(((top["rgb"] - rgbs) ** 2).mean()),
                     depth_variance=top["depth_variance"].mean(), ctx=c, ctx_fine=cf, rgb=top["rgb"], depth=top["depth"])

@@ -31,8 +31,8 @@ def render_rays(nerf, bg_nerf, rays: torch.Tensor, image_indices: Optional[torch
                                get_depth_variance, get_bg_fg_rgb)
     P = N * S
     chunk = min(hparams.model_chunk_size, P)
-    if P % chunk and nerf.training:     # evaluation handles a ragged last chunk like the reference's loop (rendering.py:354-383)
-        raise ValueError(f"training: N_rays * samples ({P}) must be a multiple of model_chunk_size ({chunk})")
+    # (a ragged last model chunk - P % chunk != 0 - is routed on its own like the reference's loop, rendering.py:354-383, in
+    #  evaluation and in training)
     perturb = hparams.perturb if nerf.training else 0
     pr = torch.rand(N, S, device=rays.device) if perturb > 0 else None
     noise = None
@@ -44,8 +44,6 @@ def render_rays(nerf, bg_nerf, rays: torch.Tensor, image_indices: Optional[torch
     if F > 0:
         if noise is not None:
             noise_f = torch.randn(N * F, device=rays.device) * hparams.sigma_noise_std
-        if (N * F) % min(chunk, N * F) and nerf.training:
-            raise ValueError(f"N_rays * fine_samples ({N * F}) must be a multiple of model_chunk_size ({chunk})")
     if nerf.training and torch.is_grad_enabled() and hasattr(nerf, "flat_param") and getattr(nerf, "hash", None) is None:
         # training under autograd (the reference's Runner loop: loss.backward() + torch optimizer, runner.py:679-693): one autograd
         # node over the HIP forward; its backward runs the HIP backward and fills nerf.flat_param.grad (autograd.py)

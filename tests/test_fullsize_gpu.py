@@ -50,8 +50,10 @@ def test_full_segment_fp32_vs_oracle():
     gaps = r0["top2_gap"][mis]
     print(f"full segment: {int(mis.sum())} of {mis.size} top-1 indices differ from the oracle; largest oracle top-2 gap among them "
           f"{gaps.max() if gaps.size else 0.0:.3e}; kept {float((loc < c['cap']).mean()):.4f}")
-    assert mis.mean() < 1e-3
+    near_ties = int((r0["top2_gap"] < 1e-5).sum())      # tokens whose two best gate values the ORACLE itself separates by < 1e-5
     assert (gaps < 1e-5).all(), "an expert index may only differ from the oracle's at a near-tie of the oracle's gate values"
+    assert int(mis.sum()) <= near_ties, f"{int(mis.sum())} expert indices differ but the oracle has only {near_ties} near-ties"
+    assert int(mis.sum()) <= 8, "more flips than fp32 summation order explains at this size (0 observed in rounds 2-3)"
     # (2) ranking on identical inputs: the oracle's integer routing fed with the HIP gate values
     gates_hip = c["gates"].cpu().numpy()
     r_same = O.route_top1(gates_hip, 1.0, True)

@@ -72,8 +72,7 @@ def test_graphed_render_50_replays_equal_eager(variant):
 
 def test_graphed_train_50_replays_equal_eager():
     r = _probe("train", "--replays", "50", "--rays", "1024")
-    assert r["ok"], r
-    assert r["routing_mismatches"] <= 8, r          # (atomically ordered router gradient sums may flip a near-tie late in the run)
+    assert r["ok"] and r["routing_mismatches_first3"] == 0, r
 
 
 def test_expert_chain_200_back_to_back_launches_bit_exact():
