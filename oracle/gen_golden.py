@@ -267,6 +267,65 @@ def gen_render(variants=(("unbalanced", 1.0, 1.0, True), ("balanced", 0.02, 1.0,
         save(f"render_train_{tag}", **out)
 
 
+class _CpuAutocastShim:
+    """Stands in for torch.cuda.amp.autocast while the reference runs on the CPU: the reference opens
+    `torch.cuda.amp.autocast(enabled=..., dtype=...)` regions by name (runner.py:598; the fp32 islands of the router,
+    tutel_moe_layer_nobatch.py:109, and of the sigma head, nerf_moe.py:399), which only toggle the CUDA autocast state - a no-op on
+    a CPU-only build.  Mapped onto torch.autocast("cpu") the same regions toggle the state that actually governs CPU tensors, so the
+    reference's own code decides where the 16-bit type is used.  (Generator-side harness; nothing of the reference is modified.)"""
+
+    def __init__(self, enabled=True, dtype=torch.bfloat16, cache_enabled=True):
+        self.ctx = torch.autocast("cpu", dtype=dtype if dtype is not None else torch.bfloat16, enabled=enabled)
+
+    def __enter__(self):
+        return self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        return self.ctx.__exit__(*a)
+
+
+def gen_render_autocast():
+    """[G5b] the training step of G5 under bf16 autocast (the reference's amp_use_bfloat16 recipes, runner.py:593-598), run on
+    the CPU backend's autocast: pins oracle.Autocast(policy="cpu") - i.e. WHERE the reference's code uses the 16-bit type - on the
+    reference itself.  (The CUDA backend's operator table differs for layer_norm and softplus only; see oracle.Autocast.)"""
+    print("[G5b] render_rays / training step under torch.autocast('cpu', bfloat16)")
+    cfg = synth.BUILDING
+    real = torch.cuda.amp.autocast
+    torch.cuda.amp.autocast = _CpuAutocastShim
+    try:
+        for tag, gate_scale in (("unbalanced", 1.0), ("balanced", 0.02)):
+            sd = synth.make_weights(51, cfg, gate_scale=gate_scale)
+            N, S, chunk = 64, 64, 1024
+            nerf, h = build_reference_model(cfg, sd, coarse=S, chunk=chunk, perturb=0.0, sigma_noise=True)
+            h.amp_use_bfloat16 = True
+            nerf.args.amp_use_bfloat16 = True
+            rays, img, rgbs = synth.make_rays(52, N)
+            nerf.train()
+            # sigma noise on (rendering.py:366 draws randn per chunk): replay the draws from the seed and hand them to the oracle
+            torch.manual_seed(1234)
+            noise = torch.cat([torch.randn(chunk, 1) for _ in range(N * S // chunk)], 0)
+            torch.manual_seed(1234)
+            with torch.cuda.amp.autocast(enabled=True, dtype=torch.bfloat16):               # runner.py:598
+                res, _ = rendering.render_rays(nerf, None, torch.from_numpy(rays), torch.from_numpy(img), h, None, None,
+                                               get_depth=True, get_depth_variance=True, get_bg_fg_rgb=False)
+                photo = torch.nn.functional.mse_loss(res["rgb_coarse"], torch.from_numpy(rgbs))
+                gate_loss = res["gate_loss_coarse"].mean()
+                loss = photo + 5e-4 * gate_loss
+            loss.backward()
+            out = dict(seed=51, gate_scale=gate_scale, N=N, S=S, chunk=chunk, sigma_noise=noise.numpy(), rgb=res["rgb_coarse"].detach().float().numpy(),
+                       sigma=res["sigma_coarse"].detach().float().numpy(), sigma_is_bf16=int(res["sigma_coarse"].dtype == torch.bfloat16),
+                       gate_loss=res["gate_loss_coarse"].detach().float().numpy(),
+                       moe_gates=res["moe_gates_coarse"].numpy().astype(np.int32).reshape(N, S),
+                       loss=loss.detach().float().numpy(), photo=photo.detach().float().numpy())
+            for n, p_ in nerf.named_parameters():
+                g_ = p_.grad.float()
+                out["gsum__" + n] = synth.checksum(g_.numpy())
+                out["gslice__" + n] = g_.numpy().reshape(-1)[:: max(1, g_.numel() // 499)][:499]
+            save(f"render_train_bf16cpu_{tag}", **out)
+    finally:
+        torch.cuda.amp.autocast = real
+
+
 def gen_render_capacity():
     """Other capacity factors / ranking modes (BASELINE configs[4]: capacity_factor 1.25 with token dropping; no BPR =
     position-order ranking, tutel_fast_dispatch.py:177-191)."""
@@ -508,7 +567,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     todo = dict(routing=gen_routing, pe=gen_pe, moe=gen_moe_layer, model=gen_model_forward, nobatch=gen_model_forward_nobatch, dispatch_nobatch=gen_dispatch_nobatch,
-                render=gen_render, capacity=gen_render_capacity, fine=gen_render_fine, mip=gen_mip, ckpt=gen_checkpoint_layout, dense=gen_dense, composite=gen_composite, bg=gen_bg)
+                render=gen_render, autocast=gen_render_autocast, capacity=gen_render_capacity, fine=gen_render_fine, mip=gen_mip, ckpt=gen_checkpoint_layout, dense=gen_dense, composite=gen_composite, bg=gen_bg)
     for k, fn in todo.items():
         if a.only and k not in a.only.split(","):
             continue

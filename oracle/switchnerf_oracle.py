@@ -32,6 +32,74 @@ import torch
 import torch.nn.functional as F
 
 # --------------------------------------------------------------------------------------------
+# the reference's mixed-precision mode (torch autocast), restated
+# --------------------------------------------------------------------------------------------
+
+
+class Autocast:
+    """The dtype policy the reference TRAINS under: runner.py:593-598 wraps the training step in
+    `torch.cuda.amp.autocast(enabled=hparams.amp, dtype=bfloat16 if hparams.amp_use_bfloat16 else float16)` (rendering: :2845-2846).
+    torch's autocast is a per-operator table; the operators on this path and what the table does to them:
+
+      * lower-precision list (inputs cast to the autocast dtype, output in it): linear, baddbmm  -> every nn.Linear of NeRFMoE
+        (models/nerf_moe.py:30-49, 330-441) and ExpertMLP's baddbmm (tutel_moe_layer_nobatch.py:908) - weights AND biases are
+        rounded to the 16-bit type, products accumulate in fp32, the result is rounded once;
+      * fp32 list of the CUDA backend (inputs cast up, fp32 output): layer_norm (the gate-input norm, nerf_moe.py:370-372),
+        softplus (the sigma activation :416), softmax, cumprod, sum, exp, pow, mse_loss.  The CPU backend's fp32 list holds NEITHER
+        layer_norm NOR softplus: there both run - and round - in the 16-bit type of their input.  That is the only difference
+        between the two backends on this path (`policy`);
+      * everything else (relu, sigmoid, add, sub, mul, cat, indexing) runs in the promoted type of its inputs: relu / the skip add
+        on 16-bit activations stay 16-bit, sigmoid of the 16-bit colour logits is 16-bit (rounded), `sigma += sigma_noise` is an
+        in-place add on a 16-bit tensor (stays 16-bit), cat([h (16-bit), dir encoding, appearance (fp32)]) promotes to fp32 and the
+        next Linear rounds it again, cat([rgb (16-bit), sigma]) promotes to fp32 under CUDA.
+    Explicit islands in the reference's code (independent of the table): the router runs with autocast OFF on `.float()` inputs
+    (tutel_moe_layer_nobatch.py:105-113, fp32_gate), the dispatcher encodes / decodes in fp32 and casts the result back to the
+    activation dtype (tutel_fast_dispatch.py:89-93, 119-127), the sigma head runs in the autocast dtype only with
+    amp_use_bfloat16, otherwise in an autocast-off fp32 island (nerf_moe.py:396-400).
+
+    policy "cuda" is what the reference's GPU training computes (the benchmarked dtype).  policy "cpu" exists to PIN this
+    restatement: oracle/gen_golden.py runs the reference itself under torch.autocast("cpu", bfloat16) (its torch.cuda.amp.autocast
+    islands mapped onto the CPU autocast state) and tests/test_oracle_golden.py checks this class against those outputs; the
+    operator table of either backend is checked against torch itself (tests/test_oracle_golden.py on the CPU,
+    tests/test_fullsize_gpu.py under torch.autocast("cuda") on the GPU box).
+    Matrix products are evaluated as fp32 products of the ROUNDED operands (products of two 16-bit floats are exact in fp32,
+    the sums run in fp32, one final rounding) - what cuBLAS / hipBLASLt / oneDNN kernels do, up to the order of the sums."""
+
+    FP32_OPS = {"cuda": ("layer_norm", "softplus", "softmax", "cumprod", "sum", "exp", "mse_loss"),
+                "cpu": ("mse_loss",)}
+
+    def __init__(self, dtype=torch.bfloat16, policy: str = "cuda", sigma_head_lowp: Optional[bool] = None):
+        assert policy in ("cuda", "cpu") and dtype in (torch.bfloat16, torch.float16)
+        self.dtype, self.policy = dtype, policy
+        # nerf_moe.py:396-400: the sigma Linear is autocast only with amp_use_bfloat16 (= the bf16 recipes)
+        self.sigma_head_lowp = (dtype == torch.bfloat16) if sigma_head_lowp is None else bool(sigma_head_lowp)
+
+    def lp(self, t: torch.Tensor) -> torch.Tensor:
+        return t.to(self.dtype)
+
+    def linear(self, x, w, b=None):
+        y = F.linear(self.lp(x).float(), self.lp(w).float(), None if b is None else self.lp(b).float())
+        return y.to(self.dtype)
+
+    def baddbmm(self, b, x, w):
+        return torch.baddbmm(self.lp(b).float(), self.lp(x).float(), self.lp(w).float()).to(self.dtype)
+
+    def fp32_op(self, name: str) -> bool:
+        return name in self.FP32_OPS[self.policy]
+
+    def layer_norm(self, x, w, b, eps):
+        if self.fp32_op("layer_norm"):
+            return F.layer_norm(x.float(), (x.shape[1],), w, b, eps)
+        # CPU backend: not in any list -> the kernel runs on the 16-bit input (fp32 statistics inside), output rounded to 16 bits
+        return F.layer_norm(x.float(), (x.shape[1],), w, b, eps).to(x.dtype)
+
+    def softplus(self, x, beta, threshold):
+        if self.fp32_op("softplus"):
+            return F.softplus(x.float(), beta, threshold)
+        return F.softplus(x.float(), beta, threshold).to(x.dtype)
+
+
+# --------------------------------------------------------------------------------------------
 # positional encoding / sampling
 # --------------------------------------------------------------------------------------------
 
@@ -157,7 +225,7 @@ def combine_nobatch(d: torch.Tensor, idx: torch.Tensor, loc: torch.Tensor, begin
 
 
 def expert_mlp(d: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
-               skips: Sequence[int]) -> torch.Tensor:
+               skips: Sequence[int], autocast: Optional[Autocast] = None) -> torch.Tensor:
     """ExpertMLP.forward, tutel_moe_layer_nobatch.py:887-924.  d: [E, C, M]; weights[l]: [E, in, out];
     biases[l]: [E, 1, out].  ReLU after every layer but the last; at a skip layer the layer input saved
     at the previous skip (initially the expert input) is added before the ReLU."""
@@ -165,7 +233,7 @@ def expert_mlp(d: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequenc
     x = d
     h = d
     for l in range(L):
-        h = torch.baddbmm(biases[l], h, weights[l])
+        h = torch.baddbmm(biases[l], h, weights[l]) if autocast is None else autocast.baddbmm(biases[l], h, weights[l])
         if l in skips:
             h = h + x
             if l < L - 1:
@@ -177,7 +245,8 @@ def expert_mlp(d: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequenc
 
 
 def moe_layer(h: torch.Tensor, gate_input: torch.Tensor, wg: torch.Tensor, weights, biases, skips,
-              capacity_factor: float, batch_prioritized: bool, routing: Optional[dict] = None, no_batch: bool = False):
+              capacity_factor: float, batch_prioritized: bool, routing: Optional[dict] = None, no_batch: bool = False,
+              autocast: Optional[Autocast] = None):
     """TopKGate.apply_on_expert_fn, tutel_moe_layer_nobatch.py:98-235 (k=1, fp32 gate, postscore).
     Returns (y [P,M], l_aux, routing dict, gates [P,E]).  `routing` may be injected (idx/loc numpy) to
     decouple numerics tests from near-tie routing flips."""
@@ -195,9 +264,16 @@ def moe_layer(h: torch.Tensor, gate_input: torch.Tensor, wg: torch.Tensor, weigh
     cap = int(routing["capacity"])
     gate_s = gates.gather(1, idx.unsqueeze(1)).squeeze(1)                      # differentiable gates_s, :182
     l_aux = load_balance_loss(gates, idx)                                      # :184
-    d = dispatch(h, idx, loc, E, cap).view(E, cap, -1)                         # :146
-    o = expert_mlp(d, weights, biases, skips).reshape(E * cap, -1)             # :174
-    y = combine(o, idx, loc, gate_s, cap)                                      # :225
+    if autocast is None:
+        d = dispatch(h, idx, loc, E, cap).view(E, cap, -1)                     # :146
+        o = expert_mlp(d, weights, biases, skips).reshape(E * cap, -1)         # :174
+        y = combine(o, idx, loc, gate_s, cap)                                  # :225
+    else:
+        # the dispatcher works in fp32 and hands back the activation dtype (tutel_fast_dispatch.py:89-93, 119-127: data.to(fp32),
+        # ....to(original_dtype)); the experts' baddbmm is an autocast operator (tutel_moe_layer_nobatch.py:908)
+        d = dispatch(h.float(), idx, loc, E, cap).to(h.dtype).view(E, cap, -1)
+        o = expert_mlp(d, weights, biases, skips, autocast).reshape(E * cap, -1)
+        y = combine(o.float(), idx, loc, gate_s, cap).to(h.dtype)
     return y, l_aux, routing, gates
 
 
@@ -222,7 +298,7 @@ def params_from_numpy(sd: Dict[str, np.ndarray], requires_grad: bool = False) ->
 
 def nerf_moe_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: dict, capacity_factor: float = 1.0,
                      batch_prioritized: bool = True, sigma_noise: Optional[torch.Tensor] = None,
-                     routing: Optional[dict] = None, no_batch: bool = False, encoded=None):
+                     routing: Optional[dict] = None, no_batch: bool = False, encoded=None, autocast: Optional[Autocast] = None):
     """NeRFMoE.forward, models/nerf_moe.py:320-455, with building.yaml's layer wiring.
     x: [P, 7] = xyz(3) dir(3) image_index(1).  Returns dict(outputs [P,4], moe_loss [1], routing, gates).
     encoded = (xyz encoding [P, 3 + 6 L], dirs [P,3], image index [P]): MipNeRFMoE.forward (:675-810), which is the same
@@ -233,6 +309,9 @@ def nerf_moe_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: dict, cap
         enc = positional_encoding(xyz, cfg["pos_xyz_dim"])
     else:
         enc, dirs, img = encoded[0], encoded[1], encoded[2].long()
+    if autocast is not None:
+        return _nerf_moe_forward_autocast(p, enc, dirs, img, cfg, capacity_factor, batch_prioritized, sigma_noise, routing, no_batch,
+                                          autocast)
     h = F.linear(enc, p["layers.xyz.fcs.0.weight"], p["layers.xyz.fcs.0.bias"])  # :330-333
     g = F.linear(h, p["layers.moe_external_gate.fcs.0.weight"], p["layers.moe_external_gate.fcs.0.bias"])
     g = F.linear(torch.relu(g), p["layers.moe_external_gate.fcs.1.weight"], p["layers.moe_external_gate.fcs.1.bias"])  # :347-348, Mlp :30-49
@@ -251,6 +330,33 @@ def nerf_moe_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: dict, cap
     h2 = torch.relu(F.linear(feat, p["layers.2.fcs.0.weight"], p["layers.2.fcs.0.bias"]))
     rgb = torch.sigmoid(F.linear(h2, p["layers.color.fcs.0.weight"], p["layers.color.fcs.0.bias"]))  # :431-441
     return dict(outputs=torch.cat([rgb, sigma], -1), moe_loss=l_aux.reshape(1), routing=routing, gates=gates)
+
+
+def _nerf_moe_forward_autocast(p, enc, dirs, img, cfg, capacity_factor, batch_prioritized, sigma_noise, routing, no_batch, ac: Autocast):
+    """nerf_moe_forward under the reference's autocast (class Autocast: which operator rounds where).  Same wiring, same citations."""
+    L = cfg["expert_layers"]
+    h = ac.linear(enc, p["layers.xyz.fcs.0.weight"], p["layers.xyz.fcs.0.bias"])               # 16-bit
+    g = ac.linear(h, p["layers.moe_external_gate.fcs.0.weight"], p["layers.moe_external_gate.fcs.0.bias"])
+    g = ac.linear(torch.relu(g), p["layers.moe_external_gate.fcs.1.weight"], p["layers.moe_external_gate.fcs.1.bias"])
+    g = ac.layer_norm(g, p["layers.gate_input_norm.weight"], p["layers.gate_input_norm.bias"], 1e-5)   # fp32 (CUDA) / 16-bit (CPU)
+    weights = [p[f"layers.0.experts.0.weights.{l}"] for l in range(L)]
+    biases = [p[f"layers.0.experts.0.bias.{l}"] for l in range(L)]
+    y, l_aux, routing, gates = moe_layer(h, g, p["layers.0.gates.0.wg.weight"], weights, biases, cfg["skips"],
+                                         capacity_factor, batch_prioritized, routing, no_batch, autocast=ac)
+    y = torch.relu(y)                                                                            # 16-bit
+    if ac.sigma_head_lowp:                                                                       # :396-397
+        sigma = ac.linear(y, p["layers.sigma.fcs.0.weight"], p["layers.sigma.fcs.0.bias"])
+    else:                                                                                        # :398-400: autocast off, fp32
+        sigma = F.linear(y.float(), p["layers.sigma.fcs.0.weight"], p["layers.sigma.fcs.0.bias"])
+    if sigma_noise is not None:
+        sigma = (sigma.float() + sigma_noise).to(sigma.dtype)                                    # :414-415 `sigma += noise`: in place
+    sigma = ac.softplus(sigma - 1, 1, 20)                                                        # nerf.py:68-69; `x - 1` in x's dtype
+    h1 = ac.linear(y, p["layers.1.fcs.0.weight"], p["layers.1.fcs.0.bias"])
+    feat = torch.cat([h1.float(), positional_encoding(dirs, cfg["pos_dir_dim"]), p["embedding_a.weight"][img]], -1)   # cat promotes to fp32
+    h2 = torch.relu(ac.linear(feat, p["layers.2.fcs.0.weight"], p["layers.2.fcs.0.bias"]))
+    rgb = torch.sigmoid(ac.linear(h2, p["layers.color.fcs.0.weight"], p["layers.color.fcs.0.bias"]).float()).to(ac.dtype)   # sigmoid: 16-bit
+    outputs = torch.cat([rgb, sigma], -1) if rgb.dtype == sigma.dtype else torch.cat([rgb.float(), sigma.float()], -1)
+    return dict(outputs=outputs, moe_loss=l_aux.reshape(1), routing=routing, gates=gates)
 
 
 # --------------------------------------------------------------------------------------------
@@ -298,7 +404,8 @@ def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_fine: int, u: Option
     return bin_b + (u - cdf_b) / denom * (bin_a - bin_b)
 
 
-def _eval_points(p, rays, image_indices, z, cfg, chunk, capacity_factor, batch_prioritized, sigma_noise, routings, hash_cfg=None):
+def _eval_points(p, rays, image_indices, z, cfg, chunk, capacity_factor, batch_prioritized, sigma_noise, routings, hash_cfg=None,
+                 autocast: Optional[Autocast] = None):
     """The chunked network evaluation of _inference (rendering.py:311-383): routing (capacity, ranking, l_aux) is per chunk.
     hash_cfg: the positions enter through the hash-grid encoding (p["embedding_xyz.table"]) instead of the frequency one."""
     N, S = z.shape
@@ -312,7 +419,8 @@ def _eval_points(p, rays, image_indices, z, cfg, chunk, capacity_factor, batch_p
         sn = None if sigma_noise is None else sigma_noise[i:i + chunk]
         r = nerf_moe_forward(p, pts[i:i + chunk], cfg, capacity_factor, batch_prioritized, sn,
                              None if routings is None else routings[ci],
-                             encoded=None if enc is None else (enc[i:i + chunk], pts[i:i + chunk, 3:6], pts[i:i + chunk, 6]))
+                             encoded=None if enc is None else (enc[i:i + chunk], pts[i:i + chunk, 3:6], pts[i:i + chunk, 6]),
+                             autocast=autocast)
         outs.append(r["outputs"])
         losses.append(r["moe_loss"])
         routes.append(r["routing"])
@@ -323,8 +431,11 @@ def render_rays(p, rays: torch.Tensor, image_indices: torch.Tensor, cfg: dict, n
                 capacity_factor: float = 1.0, batch_prioritized: bool = True, perturb: float = 0.0,
                 perturb_rand: Optional[torch.Tensor] = None, sigma_noise: Optional[torch.Tensor] = None,
                 routings: Optional[list] = None, fine_samples: int = 0, fine_u: Optional[torch.Tensor] = None,
-                sigma_noise_fine: Optional[torch.Tensor] = None, hash_cfg: Optional[dict] = None):
+                sigma_noise_fine: Optional[torch.Tensor] = None, hash_cfg: Optional[dict] = None,
+                autocast: Optional[Autocast] = None):
     """render_rays + _get_results + _inference, rendering.py:15-196, :199-274, :277-494 (no background model, no cascade).
+    autocast: the reference's mixed-precision training mode (class Autocast); the renderer itself stays fp32 - its inputs are
+    (z fp32) x (network outputs), which type promotion lifts to fp32 (under the CPU policy sigma and rgb arrive rounded to 16 bits).
     Points are evaluated in chunks of `chunk` (= model_chunk_size) and the routing (capacity, ranking, l_aux) is per
     chunk, exactly as the reference's loop :354-383.
     fine_samples > 0: the hierarchical pass :236-268 - fine depths drawn from the detached coarse weights (fine_u = the
@@ -333,7 +444,8 @@ def render_rays(p, rays: torch.Tensor, image_indices: torch.Tensor, cfg: dict, n
     near, far = rays[:, 6:7], rays[:, 7:8]
     z = sample_z(near, far, n_samples, perturb, perturb_rand)
     out, gl, routes = _eval_points(p, rays, image_indices, z, cfg, chunk, capacity_factor, batch_prioritized, sigma_noise,
-                                   routings, hash_cfg)
+                                   routings, hash_cfg, autocast)
+    out = out.float()
     comp = composite(out[..., :3], out[..., 3], z)
     res = dict(rgb_coarse=comp["rgb"], depth_variance_coarse=comp["depth_variance"], depth_coarse=comp["depth"],
                weights_coarse=comp["weights"], gate_loss_coarse=gl, sigma_coarse=out[..., 3], raw=out, z_vals=z,
@@ -342,7 +454,8 @@ def render_rays(p, rays: torch.Tensor, image_indices: torch.Tensor, cfg: dict, n
         z_mid = 0.5 * (z[:, :-1] + z[:, 1:])                                                 # :238
         z_fine = sample_pdf(z_mid, comp["weights"][:, 1:-1].detach(), fine_samples, fine_u)  # :240
         out_f, gl_f, routes_f = _eval_points(p, rays, image_indices, z_fine, cfg, min(chunk, z_fine.numel()), capacity_factor,
-                                             batch_prioritized, sigma_noise_fine, None, hash_cfg)
+                                             batch_prioritized, sigma_noise_fine, None, hash_cfg, autocast)
+        out_f = out_f.float()
         z_all, order = torch.sort(torch.cat([z_fine, z], -1), dim=-1, stable=True)              # :421
         raw_all = torch.gather(torch.cat([out_f, out], 1), 1, order[:, :, None].expand(-1, -1, 4))   # :422-430
         comp_f = composite(raw_all[..., :3], raw_all[..., 3], z_all)

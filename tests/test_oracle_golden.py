@@ -164,6 +164,79 @@ def test_render_and_training_step(tag):
         np.testing.assert_allclose(sl, g["gslice__" + k], rtol=1e-3, atol=1e-7 + 1e-4 * np.abs(g["gslice__" + k]).max(), err_msg=k)
 
 
+@pytest.mark.parametrize("tag", ["unbalanced", "balanced"])
+def test_training_step_bf16_autocast_vs_reference_cpu_autocast(tag):
+    """oracle.Autocast (which operator of the path rounds to bf16, which runs in an fp32 island) against the REFERENCE run under
+    bf16 autocast - on the CPU backend's autocast, the one this container can execute (gen_golden.gen_render_autocast), sigma noise
+    on.  Same rounding points, same operator order => the forward agrees to the bit: top-1 indices equal, rgb and sigma equal
+    (asserted <= 1e-6), loss 1e-6 relative."""
+    g = load(f"render_train_bf16cpu_{tag}")
+    cfg = synth.BUILDING
+    p = O.params_from_numpy(synth.make_weights(int(g["seed"]), cfg, gate_scale=float(g["gate_scale"])), requires_grad=True)
+    N, S, chunk = int(g["N"]), int(g["S"]), int(g["chunk"])
+    rays, img, rgbs = synth.make_rays(52, N)
+    ac = O.Autocast(torch.bfloat16, policy="cpu")
+    st = O.training_step(p, torch.from_numpy(rays), torch.from_numpy(img), torch.from_numpy(rgbs), cfg, S, chunk,
+                         sigma_noise=torch.from_numpy(g["sigma_noise"]), autocast=ac)
+    res = st["results"]
+    assert int(g["sigma_is_bf16"]) == 1      # the CPU backend leaves softplus in the 16-bit type (oracle.Autocast.FP32_OPS["cpu"])
+    got_idx = np.concatenate([r["idx"] for r in res["routings"]]).reshape(N, S)
+    gaps = np.concatenate([r["top2_gap"] for r in res["routings"]]).reshape(N, S)
+    mis = got_idx != g["moe_gates"]
+    print(f"{tag}: {int(mis.sum())} of {mis.size} top-1 indices differ from the reference's bf16 run; loss {float(st['loss']):.8f} vs {float(g['loss']):.8f}")
+    assert int(mis.sum()) == 0, "same rounding points, same operator order: the forward is bit-identical (observed)"
+    d_rgb = np.abs(res["rgb_coarse"].detach().numpy() - g["rgb"]).max()
+    sig, sig_ref = res["sigma_coarse"].detach().float().numpy(), g["sigma"]
+    ok = ~mis                                  # (a flipped token went through another expert)
+    d_sig = (np.abs(sig - sig_ref)[ok] / np.maximum(np.abs(sig_ref)[ok], 1e-3)).max()
+    print(f"{tag}: max |rgb diff| {d_rgb:.2e}, max relative sigma diff {d_sig:.2e}")
+    assert d_rgb <= 1e-6 and d_sig <= 1e-6          # (observed: 0.0 and 0.0)
+    np.testing.assert_allclose(res["gate_loss_coarse"].detach().numpy(), g["gate_loss"], rtol=1e-4)
+    np.testing.assert_allclose(st["loss"].detach().numpy(), g["loss"], rtol=1e-6)
+    # gradients: the reference's autocast backward forms dW = x^T dZ and the bias sums with bf16 OUTPUTS (observed: single entries
+    # off by up to 20 % of the tensor's largest entry for a bias row summed in bf16), the oracle's autograd keeps them in fp32:
+    # the tensors' absolute sums agree to 1 %, entries to a quarter of the largest entry
+    st["loss"].backward()
+    for k, t in p.items():
+        ref_sum = g["gsum__" + k]
+        got = t.grad.numpy()
+        scale = max(1e-12, float(ref_sum[1]))
+        assert abs(synth.checksum(got)[1] - ref_sum[1]) <= 1e-2 * scale + 1e-9, k
+        sl = got.reshape(-1)[:: max(1, got.size // 499)][:499]
+        ref = g["gslice__" + k]
+        assert np.abs(sl - ref).max() <= 0.25 * np.abs(ref).max() + 1e-9, k
+
+
+def test_autocast_operator_table_matches_torch_cpu():
+    """oracle.Autocast.FP32_OPS["cpu"] / the lower-precision list against torch's own CPU autocast: output dtypes of the operators on
+    the path for bf16 inputs.  (The CUDA table is checked the same way on the GPU box: tests/test_fullsize_gpu.py.)"""
+    import torch.nn.functional as F
+    x = torch.randn(4, 8).bfloat16()
+    w, b = torch.randn(8), torch.randn(8)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        got = dict(layer_norm=F.layer_norm(x, (8,), w, b).dtype, softplus=F.softplus(x - 1, 1, 20).dtype, sigmoid=torch.sigmoid(x).dtype,
+                   relu=torch.relu(x).dtype, linear=F.linear(torch.randn(4, 8), torch.randn(3, 8), torch.randn(3)).dtype,
+                   baddbmm=torch.baddbmm(torch.randn(2, 1, 3), torch.randn(2, 4, 8), torch.randn(2, 8, 3)).dtype,
+                   cat=torch.cat([x, torch.randn(4, 2)], 1).dtype, softmax=torch.softmax(x.float(), 1).dtype,
+                   mse_loss=F.mse_loss(x, torch.randn(4, 8)).dtype)
+        y = x.clone()
+        y += torch.randn(4, 8)
+        got["iadd"] = y.dtype
+    ac = O.Autocast(torch.bfloat16, policy="cpu")
+    lo, f32 = torch.bfloat16, torch.float32
+    want = dict(layer_norm=f32 if ac.fp32_op("layer_norm") else lo, softplus=f32 if ac.fp32_op("softplus") else lo, sigmoid=lo, relu=lo,
+                linear=lo, baddbmm=lo, cat=f32, softmax=f32, mse_loss=f32, iadd=lo)
+    assert got == want, (got, want)
+    # the emulated matrix product (fp32 product of rounded operands, one rounding) equals torch's own bf16 linear to one ulp
+    xi, wi, bi = torch.randn(64, 256), torch.randn(32, 256) / 16, torch.randn(32)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ref = F.linear(xi, wi, bi)
+    em = ac.linear(xi, wi, bi)
+    assert ref.dtype == em.dtype == torch.bfloat16
+    assert ((ref.float() - em.float()).abs() <= 2.0 ** -7 * ref.float().abs() + 1e-6).all()
+    assert (ref != em).float().mean().item() < 0.02
+
+
 @pytest.mark.parametrize("tag", ["det", "perturbed"])
 def test_hierarchical_training_step(tag):
     """Coarse pass -> _sample_pdf -> fine pass -> sort-merge -> compositing, forward and every parameter gradient, against
