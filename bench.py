@@ -175,6 +175,11 @@ def main():
         scene = BackgroundScene(model, bg, [0.02, -0.03, 0.01], [0.6, 0.8, 0.7])
         rays[:, 7] = torch.rand(n_rays, device=dev) * 1.2 + 0.3          # about half of the rays leave the bound
 
+    eval_counts = [None, None]
+    if a.eval:                    # (the kept-token fraction of the JSON line: one eager forward's routing)
+        with torch.no_grad():
+            c0_ = model.forward_rays(rays, idx, a.samples, a.chunk, 0.0, None, None, training=False)
+        eval_counts = [c0_["counts"].clone(), c0_["cap"]]
     route_override = [None]       # [P] int32 expert of every point (the balanced-routing measurement) or None = the router's choice
     plain = not (a.eval or a.mip or a.bg or a.fine or a.dense)
     use_graph = plain and a.parallelism == "dp" and a.graph in ("on", "auto")
@@ -184,6 +189,12 @@ def main():
 
     def step():
         if a.eval:       # render_rays in eval mode (runner.py:2835-2885 render_image's inner call): forward only
+            if a.graph != "off":      # replayed from a hipGraph (graph.GraphedRender = rendering.render_rays with nerf.graph_eval)
+                if graphed[0] is None:
+                    from switch_nerf_amd.graph import GraphedRender
+                    graphed[0] = GraphedRender(model, rays, idx, a.samples, a.chunk)
+                o_ = graphed[0](rays, idx)
+                return dict(ctx=dict(counts=eval_counts[0], cap=eval_counts[1]), loss=o_["rgb"].sum() * 0)
             with torch.no_grad():
                 c = model.forward_rays(rays, idx, a.samples, a.chunk, 0.0, None, None, training=False)
             return dict(ctx=c, loss=c["rgb"].sum() * 0)
@@ -249,6 +260,32 @@ def main():
         model.profile = False
         return dt, st
 
+    def kernel_times(reps=5):
+        """Per-kernel durations that do not depend on how fast the host enqueues a step: ONE eager step with the relaunch hooks on
+        (SwitchNeRF.profile), then every expert kernel `reps` times back to back on that step's live buffers between two HIP events
+        on the launch stream.  Returns ({name: ms}, kept rows of that step)."""
+        model.profile = True
+        st_ = step()
+        model.profile = False
+        c_ = st_["ctx"]["c"] if a.bg else st_["ctx"]
+        hooks = c_.get("_relaunch", {})
+        out_ = {}
+        for name in ("expert_fwd", "expert_bwd", "expert_wgrad", "expert_fwd_nosave"):
+            fn = hooks.get(name)
+            if fn is None:
+                continue
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            out_[name] = e0.elapsed_time(e1) / reps
+        kept_ = int(torch.minimum(c_["counts"], torch.tensor(c_["cap"], device=dev)).sum().item())
+        return out_, kept_
+
     if a.routing == "balanced":
         route_override[0] = (torch.arange(P, device=dev, dtype=torch.int32) % a.experts).contiguous()
     reset_state(4321)
@@ -258,15 +295,17 @@ def main():
     for _ in range(a.warmup):
         st = step()
     reset_state(1234)
-    dt, st = timed(a.steps, (not a.no_events) and not use_graph)
+    dt, st = timed(a.steps, False)
     ms = dt / a.steps * 1e3
-    ev_steps = max(3, min(20, a.steps))
+    ev_steps = max(3, min(10, a.steps))
     eager_ms = None
-    if use_graph:                # per-kernel events cannot be recorded inside a graph: eager steps right behind the timed region fill the
-        graphed[0] = None        # table (the same launches on the next steps of the same run)
-        if not a.no_events:
-            edt, st = timed(ev_steps, True)
-            eager_ms = edt / ev_steps * 1e3      # the same steps launched eagerly with the events on (reported next to the replayed number)
+    ktimes, kkept = {}, None
+    if use_graph:
+        graphed[0] = None
+    if plain and not a.no_events:
+        edt, st = timed(ev_steps, False)     # the same steps launched eagerly (reported next to the replayed number)
+        eager_ms = edt / ev_steps * 1e3
+        ktimes, kkept = kernel_times()       # back-to-back relaunches of the expert kernels on the next step's live buffers
     value = n_rays * world * a.steps / dt
 
     # ---- per-kernel accounting from the live HIP events
@@ -281,7 +320,9 @@ def main():
             traffic_tab = {}
     names = {"expert_fwd": "chainp_kernel<Bf16,1> (expert forward: 7 fused layers, 256-row tiles, row groups half a layer apart)",
              "expert_bwd": "chainp_kernel<Bf16,2> (expert backward-data: 7 fused layers, 256-row tiles, row groups half a layer apart)",
-             "expert_wgrad": "wgrad_kernel<bf16,1> (expert weight gradients, 7 layers in one launch)"}
+             "expert_wgrad": "wgrad_stream_kernel<bf16,1> (expert weight gradients, 7 layers in one balanced launch)",
+             "expert_fwd_nosave": "chainp_kernel<Bf16,1> without activation saves (the inference / --eval expert chain on the same rows: "
+                                  "the grouped GEMM alone)"}
 
     def kept_of(st_):
         c_ = st_["ctx"]["c"] if a.bg else st_["ctx"]
@@ -296,13 +337,10 @@ def main():
         detail_ = {}
         flops = 2.0 * L * M * M * kept_
         alg = {"expert_fwd": kept_ * M * esz * (1 + (L - 1) + 1), "expert_bwd": kept_ * M * esz * (1 + (L - 1) + 1 + 1),
-               "expert_wgrad": kept_ * M * esz * 2 * L}
-        for name in ("expert_fwd", "expert_bwd", "expert_wgrad"):
-            evs = events.get(name)
-            if not evs:
-                continue
-            ms_ = sum(x.elapsed_time(y) for x, y in evs) / len(evs)
-            if ms_ <= 0:
+               "expert_wgrad": kept_ * M * esz * 2 * L, "expert_fwd_nosave": kept_ * M * esz * 2}
+        for name in ("expert_fwd", "expert_bwd", "expert_wgrad", "expert_fwd_nosave"):
+            ms_ = events.get(name)
+            if not ms_ or ms_ <= 0:
                 continue
             tf = flops / (ms_ * 1e-3) / 1e12
             gbs = alg[name] / (ms_ * 1e-3) / 1e9
@@ -317,13 +355,14 @@ def main():
         return detail_
 
     kept = kept_of(st)
-    kept_mean = kept_acc[0] if kept_acc[0] is not None else kept      # per-step mean over the steps the events cover
-    detail = {} if other else account(model.events, kept_mean)          # (other recipes: headline number only)
+    kept_mean = kkept if kkept is not None else kept                   # kept rows of the step whose buffers the kernels were timed on
+    detail = {} if other else account(ktimes, kept_mean)               # (other recipes: headline number only)
     roof = None
     if detail:
         # the expert grouped GEMM is priced against the bf16 MFMA peak; the dominant kernel = the slowest of its three
-        # launches.  (Their HBM side - a training chain must save every activation for the weight gradients - is in `kernels`.)
-        dom = max(detail, key=lambda k: detail[k]["ms"])
+        # training launches.  (Their HBM side - a training chain must save every activation for the weight gradients - is in `kernels`;
+        # `expert_fwd_nosave` is the same grouped GEMM without the saves.)
+        dom = max((k for k in detail if k != "expert_fwd_nosave"), key=lambda k: detail[k]["ms"])
         d = detail[dom]
         roof = dict(kernel=names[dom], bound="mfma", achieved=d["tflops"], peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=d["mfma_frac"], traffic=d.get("hbm_measured_bytes"), alg_gbs=d["alg_gbs"],
@@ -344,15 +383,47 @@ def main():
             step()
         reset_state(1234)
         bsteps = max(2, min(10, a.steps))
-        bdt, bst = timed(bsteps, (not a.no_events) and not use_graph)
+        bdt, bst = timed(bsteps, False)
         if use_graph:
             graphed[0] = None
-            if not a.no_events:
-                _, bst = timed(bsteps, True)
+        bk, bkept = kernel_times() if not a.no_events else ({}, kept_of(bst))
         balanced = dict(routing="expert = point index mod E (every group full)", steps=bsteps, ms_per_step=round(bdt / bsteps * 1e3, 3),
-                        value=round(n_rays * world * bsteps / bdt, 1), kept_token_fraction=round(kept_of(bst) / P, 4),
-                        kernels=account(model.events, kept_of(bst)))
+                        value=round(n_rays * world * bsteps / bdt, 1), kept_token_fraction=round(bkept / P, 4),
+                        kernels=account(bk, bkept))
         route_override[0] = None
+
+    # ---- the loop a maintainer of the reference would run (runner.py:604-693): rendering.render_rays under autograd, loss.backward(),
+    #      torch.optim.Adam on the flat parameter, ExponentialLR - forward / backward replayed from captured graphs (nerf.graph_train)
+    runner_ms = None
+    if plain and world == 1 and not a.no_events and a.dtype != "fp16":
+        from argparse import Namespace
+        from switch_nerf_amd import rendering
+        reset_state(1234)
+        hp = Namespace(coarse_samples=a.samples, fine_samples=0, model_chunk_size=a.chunk, perturb=1.0, use_sigma_noise=True,
+                       sigma_noise_std=1.0, use_cascade=False)
+        model.graph_train = True
+        model.train()
+        opt = torch.optim.Adam(model.trainable_parameters(), lr=5e-4)
+        sch = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.1 ** (1 / 500000))
+
+        def runner_step():
+            res, _ = rendering.render_rays(model, None, rays, idx, hp, None, None, True, True, False)
+            loss = torch.nn.functional.mse_loss(res["rgb_coarse"], rgbs) + model.wt * res["gate_loss_coarse"].mean()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            sch.step()
+            return loss
+        for _ in range(3):
+            runner_step()
+        torch.cuda.synchronize()
+        rsteps = max(3, min(20, a.steps))
+        t0 = time.perf_counter()
+        for _ in range(rsteps):
+            runner_step()
+        torch.cuda.synchronize()
+        runner_ms = (time.perf_counter() - t0) / rsteps * 1e3
+        model.graph_train = False
 
     gb = a.rays if scaling == "strong" else a.rays * world
     out = {
@@ -366,18 +437,20 @@ def main():
                                f" gate_scale={a.gate_scale}" + (", ROUTING OVERRIDDEN: point i -> expert i mod E" if a.routing == "balanced" else "")
                                + (f", + {a.fine} fine samples (hierarchical)" if a.fine else "")
                                + (", mip recipe (two levels)" if a.mip else "")
-                               + (", INFERENCE ONLY (forward without saves; no backward / Adam)" if a.eval else "")
+                               + ((", INFERENCE ONLY (forward without saves; no backward / Adam" + ("; replayed from a hipGraph)" if a.graph != "off" else "; eager launches)")) if a.eval else "")
                                + (", hash-grid input encoding (16 levels x 2^19 x 2, table scaled to U(-1,1))" if a.hash else "")
                                + (f", capacity_factor {a.capacity_factor}" if a.capacity_factor != 1.0 else "")
                                + (f", + dense background model on {st['ctx']['Nb']} of {n_rays} rays x {a.samples // 2} samples" if a.bg else "")
                                + (f", model_dim {a.model_dim}, {a.experts} experts" if (a.model_dim != 256 or a.experts != 8) else ""),
                    "global_batch_rays": gb, "rays_per_gpu": n_rays, "samples": a.samples, "segment_points": a.chunk,
-                   "parallelism": f"{a.parallelism}{world}", "kept_token_fraction": round(kept / P, 4), "kept_token_fraction_mean": round(kept_mean / P, 4), "loss": round(loss_main, 6), "eager_events_ms_per_step": None if eager_ms is None else round(eager_ms, 3),
-                   "timed_region": (f"forward + backward replayed from a hipGraph, all-reduce + Adam eager; per-kernel HIP events from {ev_steps} "
-                                    "eager steps right after the timed region (expert weight gradients on the main stream there; their wall time = eager_events_ms_per_step: the first process on a fresh box is host-bound when it launches eagerly)" if use_graph else
-                                    "per-kernel HIP events recorded inside it; expert weight gradients on the main stream (no side-stream "
-                                    "overlap) while events are on" if not a.no_events else "no per-kernel events; expert weight gradients "
-                                    "overlapped on the side stream")},
+                   "parallelism": f"{a.parallelism}{world}", "kept_token_fraction": round(kept / P, 4), "kept_token_fraction_mean": round(kept_mean / P, 4), "loss": round(loss_main, 6), "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 3),
+                   "runner_loop_ms_per_step": None if runner_ms is None else round(runner_ms, 3),
+                   "timed_region": ((("forward + backward replayed from a hipGraph, all-reduce + Adam eager" if use_graph else "eager launches")
+                                     + f"; eager_ms_per_step = the same step launched eagerly ({ev_steps} steps); runner_loop_ms_per_step = the "
+                                     "reference's loop (render_rays under autograd + loss.backward() + torch.optim.Adam + ExponentialLR) with the "
+                                     "forward and backward graphs of nerf.graph_train; `kernels`: every expert kernel relaunched 5 x back to back "
+                                     "on one step's live buffers between two HIP events on the launch stream (independent of the host's launch rate)")
+                                    if not a.no_events else "no per-kernel timing")},
         "roofline": roof, "kernels": detail, "balanced": balanced,
     }
     if rank == 0:

@@ -19,13 +19,26 @@ from . import ops
 
 class RenderRaysFunction(torch.autograd.Function):
     """(flat_param, nerf, rays, image_indices, S, F, chunk, perturb, perturb_rand, sigma_noise, sigma_noise_fine)
-    -> (rgb [N,3], gate_loss_coarse [n_seg], gate_loss_fine [n_seg_f] or empty, depth [N], depth_variance [N])."""
+    -> (rgb [N,3], gate_loss_coarse [n_seg], gate_loss_fine [n_seg_f] or empty, depth [N], depth_variance [N]).
+    perturb_rand = "graph" (with sigma_noise = the noise std): the forward and the backward are replayed from the captured graphs of
+    graph.GraphedRenderTrain (`nerf.graph_train = True`), which draw the jitter and the noise on the device themselves."""
 
     @staticmethod
     def forward(ctx, flat_param, nerf, rays, image_indices, S, F, chunk, perturb, perturb_rand, sigma_noise, sigma_noise_fine):
         nerf._sync_compute_copies()
         ctx.nerf, ctx.fine = nerf, F > 0
-        if F > 0:
+        ctx.graph = None
+        if isinstance(perturb_rand, str) and perturb_rand == "graph":
+            from .graph import GraphedRenderTrain
+            cache = nerf.__dict__.setdefault("_train_graphs", {})
+            key = (rays.shape[0], S, F, int(chunk), float(perturb), float(sigma_noise or 0.0), bool(nerf.moe_no_batch), nerf.dtype)
+            g = cache.get(key)
+            if g is None:
+                g = cache[key] = GraphedRenderTrain(nerf, rays, image_indices, S, F, chunk, float(perturb), float(sigma_noise or 0.0))
+            state, outs = g.forward(rays, image_indices)
+            ctx.graph, ctx.state = g, state
+            res = (outs[0].clone(), outs[1].clone(), outs[2].clone(), outs[3].clone(), outs[4].clone())
+        elif F > 0:
             c, cf, out = nerf.forward_hier(rays, image_indices, S, F, chunk, perturb, perturb_rand, None, sigma_noise, sigma_noise_fine,
                                            no_batch=nerf.moe_no_batch, training=True)
             ctx.state = (c, cf, out, S, F)
@@ -41,6 +54,13 @@ class RenderRaysFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_rgb, d_laux_c, d_laux_f, _d_depth, _d_var):
         nerf = ctx.nerf
+        if ctx.graph is not None:
+            if nerf._last_ctx is not ctx.state:
+                raise RuntimeError("graph_train: backward() must follow the forward it belongs to (the captured graphs share one set of "
+                                   "static activation buffers per batch shape)")
+            g = ctx.graph.backward(d_rgb.to(torch.float32), d_laux_c.to(torch.float32), d_laux_f.to(torch.float32))
+            ctx.state = None
+            return (g.clone(),) + (None,) * 10
         nerf.grad.zero_()
         d_rgb = d_rgb.to(torch.float32).contiguous()
         if ctx.fine:

@@ -124,3 +124,84 @@ class GraphedRender:
             self.idx.copy_(image_indices)
         self.graph.replay()
         return self.out
+
+
+class GraphedRenderTrain:
+    """The TRAINING render of one ray-batch shape as two captured graphs - forward and backward - behind autograd.RenderRaysFunction,
+    so that the reference's own loop (runner.py:604-693: `render_rays` under autograd, `scaler.scale(loss).backward()`, torch.optim.Adam,
+    ExponentialLR) runs the hot path with two host calls per step instead of ~150 launches:
+
+        forward graph : [jitter / sigma noise drawn on the device] -> forward_rays / forward_hier (training=True, activations saved
+                        into static buffers) -> rgb, gate losses, depth, depth variance
+        backward graph: static d_rgb, d_gate_loss -> grad.zero_() + compositing backward + backward_net -> the flat gradient
+
+    Enabled per model with `nerf.graph_train = True` (rendering.render_rays then takes this path in training mode; one instance is
+    cached per batch shape).  The loss itself, the optimizer and the scheduler stay ordinary torch code between the two replays.
+    Not for expert-parallel models (their step issues collectives between its kernels)."""
+
+    def __init__(self, model, rays, image_indices, n_samples: int, fine_samples: int, seg_tokens: int, perturb: float, noise_std: float,
+                 warmup: int = 2):
+        if model.ep is not None and model.ep.world > 1:
+            raise ValueError("GraphedRenderTrain: expert-parallel training is not captured")
+        from . import ops
+        self.model = model
+        dev = model.dev
+        N, S, F = rays.shape[0], int(n_samples), int(fine_samples)
+        self.rays, self.idx = rays.clone().contiguous(), image_indices.clone().contiguous()
+        self.d_rgb = torch.zeros(N, 3, dtype=torch.float32, device=dev)
+        chunk = min(int(seg_tokens), N * S)
+
+        def fwd():
+            pr = torch.rand(N, S, device=dev) if perturb > 0 else None                                   # rendering.py:582
+            noise = torch.randn(N * S, device=dev) * noise_std if noise_std > 0 else None                # rendering.py:366
+            if F > 0:
+                noise_f = torch.randn(N * F, device=dev) * noise_std if noise_std > 0 else None
+                c, cf, out = model.forward_hier(self.rays, self.idx, S, F, chunk, perturb, pr, None, noise, noise_f,
+                                                no_batch=model.moe_no_batch, training=True)
+                return (c, cf, out), (out["rgb"], c["l_aux"], cf["l_aux"], out["depth"], out["depth_variance"])
+            c = model.forward_rays(self.rays, self.idx, S, chunk, perturb, pr, noise, training=True, no_batch=model.moe_no_batch)
+            return (c,), (c["rgb"], c["l_aux"], torch.zeros(0, device=dev), c["depth"], c["depth_variance"])
+
+        def bwd(state):
+            model.grad.zero_()
+            if F > 0:
+                c, cf, out = state
+                d_raw_m = ops.composite_bwd(out["raw"], out["z"], self.d_rgb)
+                d_raw_f, d_raw_c = ops.unmerge_grad(d_raw_m, out["order"], F, S)
+                model.backward_net(cf, d_raw_f, self.d_laux_f)
+                model.backward_net(c, d_raw_c, self.d_laux_c)
+            else:
+                model.backward(state[0], self.d_rgb, self.d_laux_c)
+
+        was_profile, model.profile = model.profile, False
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up on the capture stream: allocates every cached buffer / workspace
+            for _ in range(max(1, warmup)):
+                st, outs = fwd()
+                self.d_laux_c = torch.zeros_like(outs[1])
+                self.d_laux_f = torch.zeros_like(outs[2])
+                bwd(st)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.fwd_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.fwd_graph, stream=side):
+            self.state, self.outs = fwd()
+        self.bwd_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.bwd_graph, stream=side, pool=self.fwd_graph.pool()):
+            bwd(self.state)
+        model.profile = was_profile
+
+    def forward(self, rays, image_indices):
+        self.rays.copy_(rays)
+        self.idx.copy_(image_indices)
+        self.fwd_graph.replay()
+        return self.state, self.outs
+
+    def backward(self, d_rgb, d_laux_c, d_laux_f):
+        self.d_rgb.copy_(d_rgb)
+        self.d_laux_c.copy_(d_laux_c)
+        if self.d_laux_f.numel():
+            self.d_laux_f.copy_(d_laux_f)
+        self.bwd_graph.replay()
+        return self.model.grad

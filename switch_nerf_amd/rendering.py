@@ -34,17 +34,18 @@ def render_rays(nerf, bg_nerf, rays: torch.Tensor, image_indices: Optional[torch
     # (a ragged last model chunk - P % chunk != 0 - is routed on its own like the reference's loop, rendering.py:354-383, in
     #  evaluation and in training)
     perturb = hparams.perturb if nerf.training else 0
-    pr = torch.rand(N, S, device=rays.device) if perturb > 0 else None
-    noise = None
-    if getattr(hparams, "use_sigma_noise", False) and hparams.sigma_noise_std > 0 and nerf.training:
-        noise = torch.randn(P, device=rays.device) * hparams.sigma_noise_std      # rendering.py:366
+    use_noise = bool(getattr(hparams, "use_sigma_noise", False) and hparams.sigma_noise_std > 0 and nerf.training)
+    under_autograd = nerf.training and torch.is_grad_enabled() and hasattr(nerf, "flat_param") and getattr(nerf, "hash", None) is None
     if image_indices is None:
         image_indices = torch.zeros(N, dtype=torch.long, device=rays.device)
-    noise_f = None
-    if F > 0:
-        if noise is not None:
-            noise_f = torch.randn(N * F, device=rays.device) * hparams.sigma_noise_std
-    if nerf.training and torch.is_grad_enabled() and hasattr(nerf, "flat_param") and getattr(nerf, "hash", None) is None:
+    if under_autograd and getattr(nerf, "graph_train", False) and getattr(nerf, "ep", None) is None:
+        # forward / backward replayed from captured graphs (graph.GraphedRenderTrain); jitter and sigma noise are drawn inside them
+        pr, noise, noise_f = "graph", (float(hparams.sigma_noise_std) if use_noise else 0.0), None
+    else:
+        pr = torch.rand(N, S, device=rays.device) if perturb > 0 else None
+        noise = torch.randn(P, device=rays.device) * hparams.sigma_noise_std if use_noise else None      # rendering.py:366
+        noise_f = torch.randn(N * F, device=rays.device) * hparams.sigma_noise_std if (F > 0 and noise is not None) else None
+    if under_autograd:
         # training under autograd (the reference's Runner loop: loss.backward() + torch optimizer, runner.py:679-693): one autograd
         # node over the HIP forward; its backward runs the HIP backward and fills nerf.flat_param.grad (autograd.py)
         from .autograd import RenderRaysFunction

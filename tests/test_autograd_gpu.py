@@ -93,3 +93,61 @@ def test_runner_style_loop_with_torch_adam_scheduler_and_gradscaler():
     d = (a.flat - b.flat).abs().max().item()
     print(f"runner-style loop: max parameter difference after 3 steps {d:.2e}")
     assert d < 2e-5
+
+
+def test_eval_after_external_optimizer_step_uses_fresh_weights():
+    """after torch.optim.Adam moved flat_param, an evaluation / no_grad render must read the NEW weights in every
+    kernel (the packed compute copies are refreshed at the top of each forward, not only inside the autograd Function)."""
+    from switch_nerf_amd.rendering import render_rays
+    N, S, chunk = 64, 64, 1024
+    rays, img, rgbs = synth.make_rays(422, N)
+    m = _model(torch.bfloat16, 421)
+    opt = torch.optim.Adam(m.trainable_parameters(), lr=1e-2)
+    res, _ = render_rays(m, None, _dev(rays), _dev(img), _hp(S, 0, chunk), None, None, True, True, False)
+    opt.zero_grad(set_to_none=True)
+    _runner_loss(res, _dev(rgbs), m.wt).backward()
+    opt.step()
+    m.eval()
+    with torch.no_grad():
+        got, _ = render_rays(m, None, _dev(rays), _dev(img), _hp(S, 0, chunk), None, None, True, True, False)
+    ref_model = _model(torch.bfloat16, 421)
+    ref_model.flat.copy_(m.flat)
+    ref_model.refresh_compute_copies()
+    ref_model.eval()
+    with torch.no_grad():
+        ref, _ = render_rays(ref_model, None, _dev(rays), _dev(img), _hp(S, 0, chunk), None, None, True, True, False)
+    assert torch.equal(got["rgb_coarse"], ref["rgb_coarse"])
+
+
+@pytest.mark.parametrize("fine", [0, 32])
+def test_graph_train_runner_loop_matches_eager_bridge(fine):
+    """nerf.graph_train = True: the Runner-style loop (render_rays under autograd, GradScaler, torch Adam, ExponentialLR) with the
+    forward and the backward replayed from captured graphs (graph.GraphedRenderTrain) against the same loop on the eager bridge:
+    same losses and the same parameters after four optimizer steps on changing ray batches (deterministic sampling)."""
+    from torch.optim.lr_scheduler import ExponentialLR
+    from switch_nerf_amd.rendering import render_rays
+    N, S, chunk = 128, 64, 2048
+    batches = [synth.make_rays(430 + i, N) for i in range(4)]
+    models = [_model(torch.float32, 431), _model(torch.float32, 431)]
+    models[1].graph_train = True
+    losses = [[], []]
+    for k, m in enumerate(models):
+        opt = torch.optim.Adam(m.trainable_parameters(), lr=5e-4)
+        sch = ExponentialLR(opt, gamma=0.1 ** (1 / 50))
+        scaler = torch.amp.GradScaler("cuda", enabled=True, init_scale=1024.0)
+        m.train()
+        for rays, img, rgbs in batches:
+            res, _ = render_rays(m, None, _dev(rays), _dev(img), _hp(S, fine, chunk), None, None, True, True, False)
+            loss = _runner_loss(res, _dev(rgbs), m.wt)
+            opt.zero_grad(set_to_none=True)
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            sch.step()
+            losses[k].append(loss.item())
+    assert len(models[1]._train_graphs) == 1
+    for la, lb in zip(*losses):
+        assert abs(la - lb) <= 2e-5 * abs(la), losses
+    d = (models[0].flat - models[1].flat).abs().max().item()
+    print(f"graph_train vs eager bridge (fine={fine}): max parameter difference after 4 steps {d:.2e}")
+    assert d < 2e-5
