@@ -425,6 +425,30 @@ def main():
         runner_ms = (time.perf_counter() - t0) / rsteps * 1e3
         model.graph_train = False
 
+    # ---- expert parallel: what travelled, and how much of the exchange was hidden behind the expert kernels
+    ep_info = None
+    if a.parallelism == "ep" and model.ep is not None:
+        ep_ = model.ep
+        ep_.profile, ep_.bytes_sent = True, 0
+        ep_.overlap_report()
+        psteps = 3
+        for _ in range(psteps):
+            st = step()
+        torch.cuda.synchronize()
+        rep = ep_.overlap_report()
+        ep_.profile = False
+        c_ = st["ctx"]
+        kept_rows = int(c_["counts"].clamp(max=c_["cap"]).sum().item())
+        ep_info = dict(exchange="kept rows only, unequal-split all_to_all_single per routing segment on a side HIP stream; 4 exchanges per "
+                                "segment and step (dispatch / return, forward / backward)",
+                       segments=int(c_["n_seg"]), kept_rows_per_step=kept_rows,
+                       bytes_leaving_this_gpu_per_step=int(ep_.bytes_sent // psteps),
+                       bytes_per_segment_exchange=int(ep_.bytes_sent // psteps // max(1, 4 * int(c_["n_seg"]))),
+                       capacity_padded_bytes_per_step=int(4 * c_["n_seg"] * model.E * c_["cap"] * model.M * esz * (world - 1) // world),
+                       collectives_per_step=rep["collectives"] // psteps, collective_ms_per_step=round(rep["collective_ms"] / psteps, 3),
+                       wait_ms_per_step=round(rep["wait_ms"] / psteps, 3),
+                       hidden_fraction=None if rep["hidden_fraction"] is None else round(rep["hidden_fraction"], 4))
+
     gb = a.rays if scaling == "strong" else a.rays * world
     out = {
         "metric": "train rays/sec (8192-ray batch, 256 samples, 8 experts)", "value": round(value, 1), "unit": "rays/s",
@@ -453,6 +477,8 @@ def main():
                                     if not a.no_events else "no per-kernel timing")},
         "roofline": roof, "kernels": detail, "balanced": balanced,
     }
+    if ep_info is not None:
+        out["config"]["expert_parallel"] = ep_info
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline and not other:
             try:

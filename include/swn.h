@@ -398,8 +398,11 @@ typedef struct swn_wgrad_job {
   int32_t m_dim, n_dim, lda, ldb, ldw;
 } swn_wgrad_job;
 size_t swn_wgrad_multi_workspace_bytes(int n_jobs, int n_wsets);
+/* group_begin (device int32 [n_groups], or NULL): first row of every group - packed row layouts (the rows an expert-parallel rank
+ * received: swn_route_pack's layout, as in swn_chain_desc.group_begin); NULL = group g starts at row g * group_stride.          */
 int swn_wgrad_multi(const swn_wgrad_job* jobs, int n_jobs, int dtype, int n_groups, int n_wsets, int group_stride,
-                    const int32_t* group_rows, int group_rows_clamp, int tag, void* workspace, size_t workspace_bytes, void* stream);
+                    const int32_t* group_rows, int group_rows_clamp, const int32_t* group_begin, int tag, void* workspace,
+                    size_t workspace_bytes, void* stream);
 /* workspace (optional, recommended): n_groups * n_splits * (m_dim*n_dim + n_dim) * 4 bytes.  With it every workgroup
  * stores its partial tile and a second kernel reduces them into dw/db (deterministic, no atomics); without it
  * (NULL) partial tiles are added with fp32 atomics.                                                               */

@@ -86,7 +86,7 @@ SIGNATURES = {
     "swn_chain_tile_rows": [i32],
     "swn_wgrad_blocks": [C.POINTER(WgradItem), i32, i32, i32, i32, i32, i32, i32, sz, sz, i32, i32, i32, vp, i32, i32, i32, vp, sz, vp],
     "swn_wgrad_batched": [C.POINTER(WgradItem), i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, sz, vp],
-    "swn_wgrad_multi": [C.POINTER(WgradJob), i32, i32, i32, i32, i32, vp, i32, i32, vp, sz, vp],
+    "swn_wgrad_multi": [C.POINTER(WgradJob), i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, sz, vp],
     "swn_wgrad": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, vp, sz, vp],
     "swn_adam_step": [vp, vp, vp, vp, vp, i32, i64, f32, f32, f32, f32, i32, f32, vp],
     "swn_cast": [vp, vp, i32, i64, vp],

@@ -343,6 +343,7 @@ struct WsJob {
 struct WsArgs {
   WsJob job[WS_MAX_JOBS];
   const int32_t* group_rows;
+  const int32_t* group_begin;    // first row of every group (packed layouts), or NULL: group g starts at row g * group_stride
   float* partial;            // [WS_HDR_INTS ints][n_wg + n_jobs * n_wsets][WS_TILE]
   int n_jobs, n_groups, n_wsets, group_stride, clamp, n_wg;
 };
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(WG_NT) void wgrad_stream_kernel(const WsArgs p) {
       const char* src[4];                                  // [2 pieces] x (A, B)
       auto prepare = [&]() {
         const bool live = left > 0;
-        const long grow0 = (long)gp * p.group_stride;
+        const long grow0 = p.group_begin ? (long)((cidx_t)p.group_begin)[gp] : (long)gp * p.group_stride;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int rf = rp + (2 * wave + i) * RPP;        // first row of this wave's piece (wave-uniform)
@@ -734,8 +735,8 @@ static bool ws_eligible(int n_groups, int n_wsets) {
 }
 
 extern "C" int swn_wgrad_multi(const swn_wgrad_job* jobs, int n_jobs, int dtype, int n_groups, int n_wsets, int group_stride,
-                               const int32_t* group_rows, int group_rows_clamp, int tag, void* workspace, size_t workspace_bytes,
-                               void* stream) {
+                               const int32_t* group_rows, int group_rows_clamp, const int32_t* group_begin, int tag, void* workspace,
+                               size_t workspace_bytes, void* stream) {
   SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_wgrad_multi: bad dtype %d", dtype);
   SWN_CHECK(jobs && n_jobs >= 1 && n_jobs <= WS_MAX_JOBS, "swn_wgrad_multi: 1..%d jobs", WS_MAX_JOBS);
   SWN_CHECK(n_groups >= 1 && n_wsets >= 1 && group_stride >= 1, "swn_wgrad_multi: bad geometry");
@@ -758,6 +759,7 @@ extern "C" int swn_wgrad_multi(const swn_wgrad_job* jobs, int n_jobs, int dtype,
     d.m_dim = s.m_dim; d.n_dim = s.n_dim; d.lda = s.lda; d.ldb = s.ldb; d.ldw = s.ldw; d.weight = (s.m_dim + s.n_dim) / 32;
   }
   p.group_rows = group_rows;
+  p.group_begin = group_begin;
   p.n_jobs = n_jobs; p.n_groups = n_groups; p.n_wsets = n_wsets; p.group_stride = group_stride;
   p.clamp = group_rows ? group_rows_clamp : group_stride;
   p.n_wg = ws_n_wg();
@@ -797,7 +799,7 @@ static int wgrad_launch(const swn_wgrad_item* items, int n_items, int dtype, int
       jobs[i].m_dim = m_dim; jobs[i].n_dim = n_dim; jobs[i].lda = lda; jobs[i].ldb = ldb; jobs[i].ldw = ldw;
       jobs[i].dw_set_stride = dw_set_stride; jobs[i].db_set_stride = db_set_stride;
     }
-    return swn_wgrad_multi(jobs, n_items, dtype, n_groups, n_wsets, group_stride, group_rows, group_rows_clamp, tag, workspace,
+    return swn_wgrad_multi(jobs, n_items, dtype, n_groups, n_wsets, group_stride, group_rows, group_rows_clamp, nullptr, tag, workspace,
                            workspace_bytes, stream);
   }
   WgradArgs p;

@@ -332,9 +332,9 @@ class SwitchNeRF:
         per_rank = sum(El * per for _o, per in spans)
         for b in bufs:
             mine = torch.cat([b[off + r * El * per: off + (r + 1) * El * per] for off, per in spans])
-            full = torch.empty(W * per_rank, dtype=b.dtype, device=b.device)
-            dist.all_gather_into_tensor(full, mine, group=ep.group)
-            full = full.view(W, per_rank)
+            parts = [torch.empty_like(mine) for _ in range(W)]
+            dist.all_gather(parts, mine, group=ep.group)       # (the list form: every backend implements it, gloo included)
+            full = torch.stack(parts, 0)
             q = 0
             for off, per in spans:
                 b[off: off + self.E * per].view(W, El * per).copy_(full[:, q:q + El * per])
@@ -538,43 +538,50 @@ class SwitchNeRF:
                 c["_relaunch"] = {"expert_fwd": run_experts,
                                   "expert_fwd_nosave": lambda: run_experts([o.Layer(ly.w, ly.b, relu=ly.relu, skip=ly.skip) for ly in layers])}
         else:
-            # expert parallel, pipelined per routing segment (parallel.ExpertParallel): the rows of segment s in native order
-            # (expert, slot) = payload order (destination rank, local expert, slot) -> all-to-all on the side stream -> the local
-            # experts run on the (source rank, local expert) groups -> all-to-all back into the native row space.  The dispatch of
-            # segment s + 1 and the return of segment s - 1 travel while the experts work on segment s.
+            # expert parallel, pipelined per routing segment (parallel.ExpertParallel), KEPT ROWS ONLY: the kept rows of segment s, packed in
+            # (expert, slot) order = payload order (destination rank, local expert, slot) -> unequal-split all-to-all on the side stream ->
+            # the local experts run on the (source rank, local expert) groups (first rows from a device prefix sum) -> all-to-all back into
+            # the packed row space the combine gathers from.  The dispatch of segment s + 1 and the return of segment s - 1 travel while
+            # the experts work on segment s.  One host read of the counts per forward pass (ExpertParallel.plan).
             ep = self.ep
-            seg_rows = E * cap
-            c["row_of_tok"] = c["tok2row"]
-            cnt_wait = ep.exchange_counts(c["counts"], cap, self.side)
-            xr = _b("ep_x", (n_seg, seg_rows, M), dt)                       # received rows of all segments (also the first layer's
-            send = xr if ep.world == 1 else _b("ep_send_x", (n_seg, seg_rows, M), dt)      # weight-gradient operand)
-            eo_r = _b("ep_eo", (n_seg, seg_rows, M), dt)
-            eo = c["eo"].view(n_seg, seg_rows, M)
-            eo_send = eo if ep.world == 1 else eo_r
-            perm_s = c["perm"].view(n_seg, seg_rows)
+            W, El = ep.world, ep.El
+            kept = c["counts"].clamp(max=cap)
+            idx_kept = torch.where(c["loc"] < cap, c["idx"], torch.full_like(c["idx"], -1))
+            _gb, perm_p, c["row_of_tok"] = o.route_pack(idx_kept, c["loc"], kept, seg_tokens, E)     # packed row space of this rank's rows
+            c["ep_perm"] = perm_p
+            recv_counts = ep.exchange_counts(c["counts"], cap, self.side)()            # [n_seg, W * E_local], the expert kernels' group order
+            c["ep_counts"] = recv_counts
+            pl = c["ep_plan"] = ep.plan(kept, recv_counts)
+            so, ro = pl["send_off"], pl["recv_off"]
+            flat_rc = recv_counts.reshape(-1)
+            c["ep_begin"] = (torch.cumsum(flat_rc, 0, dtype=torch.int32) - flat_rc).contiguous()      # first row of every received group
+            xr = _b("ep_x", (rows, M), dt)                                  # received rows of all segments (also the first layer's
+            send = xr if W == 1 else _b("ep_send_x", (rows, M), dt)         # weight-gradient operand)
+            eo_r = c["eo"] if W == 1 else _b("ep_eo", (rows, M), dt)        # expert outputs in the received row space
+            ngs = W * El
             wseg = o.chain_mask_words(dt, E, cap, M)
             c["ep_mask_words"] = wseg
 
             def issue(s_):
-                o.gather_rows(c["h0"], perm_s[s_], send[s_])
-                return ep.all_to_all(send[s_], self.side, out=xr[s_])
+                o.gather_rows(c["h0"], perm_p[so[s_]:so[s_ + 1]], send[so[s_]:so[s_ + 1]])
+                return ep.all_to_all_v(send[so[s_]:so[s_ + 1]], pl["in_splits"][s_], xr[ro[s_]:ro[s_ + 1]], pl["out_splits"][s_], self.side)
             with self._timed("expert_fwd"):
                 pend = issue(0)
-                c["ep_counts"] = cnt_wait()                                # [n_seg, W * E_local], group order of the expert kernels
                 returns = []
                 for s_ in range(n_seg):
                     nxt = issue(s_ + 1) if s_ + 1 < n_seg else None
-                    pend[1]()
-                    rs = slice(s_ * seg_rows, (s_ + 1) * seg_rows)
-                    layers_s = [o.Layer(ly.w, ly.b, relu=ly.relu, skip=ly.skip, save=None if ly.save is None else ly.save[rs],
+                    pend()
+                    layers_s = [o.Layer(ly.w, ly.b, relu=ly.relu, skip=ly.skip, save=ly.save,
                                         mask=None if ly.mask is None else ly.mask[s_ * wseg:(s_ + 1) * wseg]) for ly in layers]
-                    o.mlp_chain(xr[s_], layers_s, eo_send[s_], n_groups=E, n_wsets=ep.El, group_stride=cap, group_rows=c["ep_counts"][s_],
-                                group_rows_clamp=cap, tag=1, geometry=c["geom"])
-                    returns.append(ep.all_to_all(eo_send[s_], self.side, out=eo[s_]))
+                    if ro[s_ + 1] > ro[s_]:
+                        o.mlp_chain(xr, layers_s, eo_r, n_groups=ngs, n_wsets=El, group_stride=cap, group_rows=recv_counts[s_],
+                                    group_rows_clamp=cap, tag=1, geometry=c["geom"], group_begin=c["ep_begin"][s_ * ngs:(s_ + 1) * ngs])
+                    returns.append(ep.all_to_all_v(eo_r[ro[s_]:ro[s_ + 1]], pl["out_splits"][s_], c["eo"][so[s_]:so[s_ + 1]],
+                                                   pl["in_splits"][s_], self.side))
                     pend = nxt
-                for _r, wait in returns:
+                for wait in returns:
                     wait()
-            c["ep_x"] = xr.view(rows, M)
+            c["ep_x"] = xr
         # ---- per-ray part of layer "2": [PE(dir), appearance embedding] @ W2r + b2   (N_rays x 75, host-side torch)
         feat = torch.cat([pe_dir[:, : self.in_dir].float(), self.p["emb"][image_indices.long()]], 1)
         c["ray_feat"] = feat
@@ -650,14 +657,14 @@ class SwitchNeRF:
                                                    # per-GPU batch of an 8-GPU run (262144 points)
         ep = self.ep
         if ep is not None:      # the rows of the first segment travel to their experts while the tail's weight gradients run
-            seg_rows = E * cap
-            dr = _b("ep_d", (n_seg, seg_rows, M), dt)
-            dsend = dr if ep.world == 1 else _b("ep_send_d", (n_seg, seg_rows, M), dt)
-            perm_s = c["perm"].view(n_seg, seg_rows)
+            pl, perm_p = c["ep_plan"], c["ep_perm"]
+            so, ro = pl["send_off"], pl["recv_off"]
+            dr = _b("ep_d", (rows, M), dt)
+            dsend = dr if ep.world == 1 else _b("ep_send_d", (rows, M), dt)
 
             def issue_b(s_):
-                o.gather_rows(dout, perm_s[s_], dsend[s_])
-                return ep.all_to_all(dsend[s_], self.side, out=dr[s_])
+                o.gather_rows(dout, perm_p[so[s_]:so[s_ + 1]], dsend[so[s_]:so[s_ + 1]])
+                return ep.all_to_all_v(dsend[so[s_]:so[s_ + 1]], pl["in_splits"][s_], dr[ro[s_]:ro[s_ + 1]], pl["out_splits"][s_], self.side)
             pend = issue_b(0)
         self._dense_wgrads([(c["h1"], dh2, g["l2h.w"].view(1, M, H2), None),
                             (c["y"], dh1, g["l1.w"].view(1, M, M), g["l1.b"].view(1, M))], nsp)
@@ -685,24 +692,26 @@ class SwitchNeRF:
                 c["_relaunch"]["expert_bwd"] = run_expert_bwd
         else:
             # per segment like the forward pass: dispatch of segment s + 1 and return of segment s - 1 overlap the chain of segment s;
-            # the input gradients come home into the native row space (dx) that the front backward chain gathers from
+            # the input gradients come home into the packed row space (dx) that the front backward chain gathers from
             perm = None
-            x_first, dz_last = c["ep_x"], dr.view(rows, M)       # the received rows, already in group order
-            grp_rows = c["ep_counts"].view(-1)
-            dxv = dx.view(n_seg, seg_rows, M)
-            dx_send = dxv if ep.world == 1 else _b("ep_dx", (n_seg, seg_rows, M), dt)
+            x_first, dz_last = c["ep_x"], dr                     # the received rows, already in group order
+            grp_rows = c["ep_counts"].reshape(-1)
+            ngs = ep.world * ep.El
+            dx_r = dx if ep.world == 1 else _b("ep_dx", (rows, M), dt)
             wseg = c["ep_mask_words"]
             returns = []
             with self._timed("expert_bwd"):
                 for s_ in range(n_seg):
                     nxt = issue_b(s_ + 1) if s_ + 1 < n_seg else None
-                    pend[1]()
-                    rs = slice(s_ * seg_rows, (s_ + 1) * seg_rows)
-                    bl_s = [o.Layer(ly.w, None, relu=ly.relu, save=None if ly.save is None else ly.save[rs],
+                    pend()
+                    bl_s = [o.Layer(ly.w, None, relu=ly.relu, save=ly.save,
                                     mask=None if ly.mask is None else ly.mask[s_ * wseg:(s_ + 1) * wseg]) for ly in bl]
-                    o.mlp_chain(dr[s_], bl_s, dx_send[s_], n_groups=E, n_wsets=n_loc, group_stride=cap, group_rows=c["ep_counts"][s_],
-                                group_rows_clamp=cap, y_add=dz[skip_l][rs] if skip_l is not None else None, tag=2, geometry=c["geom"])
-                    returns.append(ep.all_to_all(dx_send[s_], self.side, out=dxv[s_]))
+                    if ro[s_ + 1] > ro[s_]:
+                        o.mlp_chain(dr, bl_s, dx_r, n_groups=ngs, n_wsets=n_loc, group_stride=cap, group_rows=c["ep_counts"][s_],
+                                    group_rows_clamp=cap, y_add=dz[skip_l] if skip_l is not None else None, tag=2, geometry=c["geom"],
+                                    group_begin=c["ep_begin"][s_ * ngs:(s_ + 1) * ngs])
+                    returns.append(ep.all_to_all_v(dx_r[ro[s_]:ro[s_ + 1]], pl["out_splits"][s_], dx[so[s_]:so[s_ + 1]], pl["in_splits"][s_],
+                                                   self.side))
                     pend = nxt
 
         def expert_wgrads():
@@ -713,6 +722,10 @@ class SwitchNeRF:
                 bz = dz_last if l == L - 1 else dz[l]
                 items.append((a, bz, self._local_experts(g[f"exp{l}.w"]), self._local_experts(g[f"exp{l}.b"]),
                               perm if l == 0 else None, perm if l == L - 1 else None))
+            if ep is not None and M <= 256:      # received rows are packed: groups through their first rows
+                o.wgrad_multi(items, n_groups=ng, n_wsets=n_loc, group_stride=cap, group_rows=grp_rows, group_rows_clamp=cap, tag=1,
+                              group_begin=c["ep_begin"])
+                return
             for i0 in range(0, L, 8):
                 o.wgrad_batched(items[i0:i0 + 8], n_groups=ng, n_wsets=n_loc, group_stride=cap, group_rows=grp_rows,
                                 group_rows_clamp=cap, n_splits=self.expert_wgrad_splits or max(1, min(256 // ng, cap // 2048)), tag=1)
@@ -740,7 +753,7 @@ class SwitchNeRF:
         dza1 = _b("dza1", (P, G), dt)
         dh0 = _b("dh0", (P, M), dt)
         if ep is not None:      # (the input gradients travelled home under the expert weight gradients / the router backward)
-            for _r, wait in returns:
+            for wait in returns:
                 wait()
         o.mlp_chain(dg, [o.Layer(self.wb["gate1"], None, relu=2, mask=c["m_a1"], save=dza1), o.Layer(self.wb["gate0"], None)],
                     dh0, y_add=dx, y_add_gather=c["row_of_tok"], tag=6)

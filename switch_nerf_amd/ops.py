@@ -105,6 +105,8 @@ def gather_rows(src, index, out=None):
     R, Cc = index.numel(), src.shape[1]
     if out is None:
         out = torch.empty(R, Cc, dtype=src.dtype, device=src.device)
+    if R == 0:
+        return out
     call("swn_gather_rows", _p(src), _p(index), R, Cc * src.element_size(), _p(out), _stream())
     return out
 
@@ -506,7 +508,7 @@ def wgrad(a, b, dw, db=None, n_groups=1, n_wsets=1, group_stride=None, group_row
          int(group_rows_clamp if group_rows_clamp is not None else gs), _p(dw), _p(db), int(n_splits), int(tag), _p(ws), ws_bytes, _stream())
 
 
-def wgrad_multi(jobs, n_groups=1, n_wsets=1, group_stride=None, group_rows=None, group_rows_clamp=None, tag=0):
+def wgrad_multi(jobs, n_groups=1, n_wsets=1, group_stride=None, group_rows=None, group_rows_clamp=None, tag=0, group_begin=None):
     """jobs: tuples (a, b, dw, db, a_gather, b_gather) over ONE row grouping, each with its own widths (multiples of 32 up to 256):
     the balanced stream launch (swn_wgrad_multi, include/swn.h) - up to 8 jobs per launch, the work cut into equal shares of the
     valid rows, deterministic reduction.  dw [n_wsets, m, n] f32 (accumulated into), db [n_wsets, n] or None."""
@@ -523,7 +525,7 @@ def wgrad_multi(jobs, n_groups=1, n_wsets=1, group_stride=None, group_rows=None,
             jb.dw_set_stride, jb.db_set_stride = m * n, n
         ws = _wgrad_workspace(a0.device, _multi_ws_bytes(len(chunk), n_wsets))
         call("swn_wgrad_multi", arr, len(chunk), _dt(a0), int(n_groups), int(n_wsets), gs, _p(group_rows),
-             int(group_rows_clamp if group_rows_clamp is not None else gs), int(tag), _p(ws), ws.numel(), _stream())
+             int(group_rows_clamp if group_rows_clamp is not None else gs), _p(group_begin), int(tag), _p(ws), ws.numel(), _stream())
 
 
 def wgrad_batched(items, n_groups=1, n_wsets=1, group_stride=None, group_rows=None, group_rows_clamp=None, n_splits=8, tag=0):

@@ -60,12 +60,16 @@ class ExpertParallel:
     l_aux stay rank-local exactly as in the data-parallel mode, so routing indices do not depend on the mode); only the
     rows that enter the expert MLP travel.
 
-    The exchange is PER ROUTING SEGMENT (= the reference's per-model-chunk MoE call): the dispatched rows of one segment in their
-    native order (expert, capacity slot) ARE the payload order (destination rank, local expert, slot), so the send buffer is one
-    swn_gather_rows through the segment's routing permutation and the returned rows land in the native row space the combine
-    gathers from - no index remapping.  all_to_all_single (equal splits: capacity-padded like the reference's batched path)
-    delivers (source rank, local expert, slot) = the group order of the expert kernels with group % E_local = local expert (no
-    kernel knows about ranks).  The valid-row counts of all segments travel once, ahead of the rows.
+    The exchange is PER ROUTING SEGMENT (= the reference's per-model-chunk MoE call) and carries KEPT ROWS ONLY: the rows of a
+    segment that fit their expert's capacity, PACKED in (expert, capacity slot) order (swn_route_pack's layout: group g = (segment,
+    expert) starts at the exclusive prefix sum of the kept counts), are the payload in (destination rank, local expert, slot) order;
+    the send buffer is one swn_gather_rows through the packed permutation and the returned rows land in the packed row space the
+    combine gathers from - no index remapping.  all_to_all_single with UNEQUAL splits (the reference pads to capacity,
+    tutel_moe_layer_nobatch.py:157; padding rows cost 20 % of the bytes at 80 % kept rows) delivers (source rank, local expert, slot)
+    = the group order of the expert kernels with group % E_local = local expert (no kernel knows about ranks; the groups' first rows
+    come from a device prefix sum, swn_chain_desc.group_begin / swn_wgrad_multi's group_begin).  The valid-row counts of ALL segments
+    travel once, ahead of the rows, and are read on the host ONCE per forward pass (plan()): the split sizes of every segment's
+    exchange, forward and backward.
     Segments are pipelined: the exchange of segment s + 1 runs on a side HIP stream while the experts work on segment s, and the
     return of segment s overlaps both (model.py).  RCCL over xGMI is point-to-point: an all-to-all sends (W - 1) / W of the payload
     over the 7 links in parallel, there is nothing to gain from ring-style chunking.
@@ -115,6 +119,73 @@ class ExpertParallel:
         out = torch.empty((int(sum(out_splits)),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
         dist.all_to_all_single(out, rows.contiguous(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
         return out, recv_counts
+
+    # ---- the training exchange: kept rows only ----
+    def plan(self, kept: torch.Tensor, recv_counts: torch.Tensor):
+        """ONE host read per forward pass (not one per segment): kept [n_seg, E] = rows this rank sends per (segment, expert),
+        recv_counts [n_seg, W * E_local] = rows it receives per (segment, source rank, local expert).  Returns the per-segment split
+        sizes and row offsets of the packed send / receive spaces: dict(in_splits, out_splits [n_seg][W], send_off, recv_off [n_seg + 1])."""
+        n_seg = kept.shape[0]
+        both = torch.cat([kept.view(n_seg, self.world, self.El).sum(2), recv_counts.view(n_seg, self.world, self.El).sum(2)], 1)
+        host = both.to("cpu", torch.int64).tolist()          # the one synchronisation point of the expert-parallel step
+        ins = [row[: self.world] for row in host]
+        outs = [row[self.world:] for row in host]
+        so, ro = [0], [0]
+        for s_ in range(n_seg):
+            so.append(so[-1] + sum(ins[s_]))
+            ro.append(ro[-1] + sum(outs[s_]))
+        return dict(in_splits=ins, out_splits=outs, send_off=so, recv_off=ro)
+
+    profile = False          # bench.py --parallelism ep: record HIP events around the collectives and the waits for them
+
+    def all_to_all_v(self, send: torch.Tensor, in_splits, recv: torch.Tensor, out_splits, stream=None):
+        """Unequal-split all-to-all of packed rows (dim 0): chunk r of `send` (in_splits[r] rows) goes to rank r, `recv` receives
+        out_splits[w] rows from rank w.  Only rows that exist travel (20 % fewer bytes than the capacity-padded payload at 80 % kept
+        rows).  Same stream semantics as all_to_all; returns wait()."""
+        if self.world == 1:
+            assert recv.data_ptr() == send.data_ptr()
+            return lambda: None
+        row_bytes = (send.numel() // max(1, send.shape[0])) * send.element_size()
+        self.bytes_sent = getattr(self, "bytes_sent", 0) + (sum(in_splits) - in_splits[self.rank]) * row_bytes     # rows that leave this GPU
+        if stream is None or not send.is_cuda:
+            work = dist.all_to_all_single(recv, send, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits), group=self.group,
+                                          async_op=True)
+            return work.wait
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(stream):
+            stream.wait_event(ready)
+            ev = None
+            if self.profile:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            work = dist.all_to_all_single(recv, send, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits), group=self.group,
+                                          async_op=True)
+            if ev is not None:
+                work.wait()
+                ev[1].record()
+                self.__dict__.setdefault("ev_coll", []).append(ev)
+
+        def wait():
+            wv = None
+            if self.profile:
+                wv = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                wv[0].record()
+            work.wait()                       # orders the consumer's (current) stream after the collective
+            if wv is not None:
+                wv[1].record()
+                self.__dict__.setdefault("ev_wait", []).append(wv)
+            send.record_stream(torch.cuda.current_stream())
+        return wait
+
+    def overlap_report(self):
+        """(after a synchronize) total time of the profiled collectives on the side stream, total time the consumer stream spent
+        waiting for them, and the fraction of the exchange that was hidden behind compute: 1 - wait / collective."""
+        coll = sum(a.elapsed_time(b) for a, b in self.__dict__.get("ev_coll", []))
+        wait = sum(a.elapsed_time(b) for a, b in self.__dict__.get("ev_wait", []))
+        n = len(self.__dict__.get("ev_coll", []))
+        self.__dict__["ev_coll"], self.__dict__["ev_wait"] = [], []
+        return dict(collectives=n, collective_ms=coll, wait_ms=wait, hidden_fraction=(1.0 - wait / coll) if coll > 0 else None)
 
     # ---- the collective ----
     def all_to_all(self, send: torch.Tensor, stream=None, out: Optional[torch.Tensor] = None):

@@ -1,6 +1,7 @@
 """bench.py's multi-rank flow on a real GPU: two ranks share cuda:0 and talk over gloo (RCCL needs one GPU per rank; the
-collectives are backend-agnostic torch.distributed calls).  Data parallel and expert parallel must train identically:
-routing is rank-local and the parameters stay replicated, so after two optimizer steps both modes report the same loss."""
+collectives are backend-agnostic torch.distributed calls).  Data parallel and expert parallel must train identically: routing is
+rank-local in both modes; under expert parallelism the experts are SHARDED (a rank owns, updates and check-points E / W of them, the
+dense parameters stay replicated and all-reduced) and only kept rows travel - after two optimizer steps both modes report the same loss."""
 import json
 import os
 import subprocess
@@ -34,6 +35,12 @@ def test_two_ranks_dp_and_ep_agree():
     assert abs(dp["config"]["loss"] - ep["config"]["loss"]) <= 5e-4 * abs(dp["config"]["loss"])
     assert abs(dp["config"]["kept_token_fraction"] - ep["config"]["kept_token_fraction"]) < 1e-3
     assert dp["value"] > 0 and ep["value"] > 0
+    x = ep["config"]["expert_parallel"]
+    # kept rows only: what leaves a GPU is (W - 1) / W of 4 exchanges of the kept rows, not of the capacity-padded payload
+    assert x["segments"] >= 1 and 0 < x["bytes_leaving_this_gpu_per_step"] < x["capacity_padded_bytes_per_step"]
+    full = 4 * x["kept_rows_per_step"] * 256 * 2          # every kept row, four exchanges, bf16 rows of 256 features
+    assert 0.1 * full <= x["bytes_leaving_this_gpu_per_step"] <= 0.9 * full      # ~ (W - 1) / W of it, depending on where the experts sit
+    assert x["collectives_per_step"] == 4 * x["segments"] and x["hidden_fraction"] is not None
 
 
 def test_bench_launches_its_own_ranks():
@@ -65,3 +72,14 @@ def test_expert_parallel_evaluation_unequal_splits(dtype):
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
     assert out.stdout.count("EP_EVAL rank") == 2 and "MISMATCH" not in out.stdout
+
+
+def test_expert_parallel_checkpoint_equals_data_parallel_checkpoint():
+    """Two ranks, two optimizer steps with sharded experts, checkpoint.save_checkpoint on every rank (which gathers the expert shards
+    from their owners): parameters and Adam moments equal the data-parallel run's on both ranks."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29573", os.path.join(ROOT, "tests", "ep_ckpt_worker.py")]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    assert out.stdout.count("EP_CKPT rank") == 2 and "MISMATCH" not in out.stdout
