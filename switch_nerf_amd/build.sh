@@ -22,5 +22,8 @@ build_one() {   # $1 = object directory, $2 = extra flags, $3 = output library
   $HIPCC --offload-arch=gfx950 -shared -fPIC "$OBJ"/{elementwise,gate_mfma,route,chain,chain_big,chain_wide,chain_cat,wgrad,sampling,mip,bounds,hashgrid}.o -o "$OUT"
   echo "built $OUT"
 }
+# SWN_VARIANT=name (experiments): the bf16 library built with SWN_DEFS into libswn_hip_<name>.so / build_<name>/ - select it at run time
+# with SWN_LIB=switch_nerf_amd/libswn_hip_<name>.so; the default libraries are left alone
+if [ -n "${SWN_VARIANT:-}" ]; then build_one "build_${SWN_VARIANT}" "" "libswn_hip_${SWN_VARIANT}.so"; exit 0; fi
 build_one build "" libswn_hip.so
 if [ "${SWN_ONLY:-}" != "bf16" ]; then build_one build_f16 "-DSWN_HALF_F16" libswn_hip_f16.so; fi

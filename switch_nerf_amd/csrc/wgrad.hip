@@ -664,9 +664,11 @@ __global__ __launch_bounds__(WG_NT) void wgrad_stream_kernel(const WsArgs p) {
   }
 }
 
-// dw[pair] += the pair's partial tiles in workgroup order.  grid (tile blocks, pairs); a thread owns 4 consecutive elements.
+// dw[pair] += the pair's partial tiles in workgroup order.  grid (tile blocks, pairs); a thread owns 4 consecutive elements and adds
+// the tiles in ascending workgroup order (deterministic); the loads of 8 tiles are in flight together (one at a time the loop paid a
+// memory round trip per tile: 130 us for a dense layer's 256 tiles).
 __global__ __launch_bounds__(256) void wgrad_stream_reduce_kernel(const WsArgs p) {
-  __shared__ int32_t flag[1024];
+  __shared__ int32_t flag[1024 + 8];
   __shared__ int32_t krange[2];
   const int pair = blockIdx.y, j = pair / p.n_wsets, e = pair % p.n_wsets;
   const WsJob& it = p.job[j];
@@ -678,6 +680,7 @@ __global__ __launch_bounds__(256) void wgrad_stream_reduce_kernel(const WsArgs p
     total += (long)p.job[q].weight * Tj;
   }
   if (threadIdx.x == 0) { krange[0] = p.n_wg; krange[1] = -1; }
+  for (int k = threadIdx.x; k < 1024 + 8; k += 256) flag[k] = 0;
   __syncthreads();
   if (total > 0 && P0 < P1) {
     for (int k = threadIdx.x; k < p.n_wg; k += 256) {
@@ -696,10 +699,16 @@ __global__ __launch_bounds__(256) void wgrad_stream_reduce_kernel(const WsArgs p
   if (el >= tile_elems) return;
   const float* tiles = p.partial + WS_HDR_INTS + (size_t)pair * WS_TILE + el;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k = k0; k <= k1; ++k) {
-    if (!flag[k]) continue;
-    const float4 v = *(const float4*)(tiles + (size_t)k * WS_TILE);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  for (int k = k0; k <= k1; k += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {            // (flag[] is zero past n_wg: the tail of the last batch reads nothing)
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (flag[k + u]) v[u] = *(const float4*)(tiles + (size_t)(k + u) * WS_TILE);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (flag[k + u]) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
   }
   float* dst = el < mn ? it.dw + (size_t)e * it.dw_set_stride + (size_t)(el / it.n_dim) * it.ldw + el % it.n_dim
                        : it.db + (size_t)e * it.db_set_stride + (el - mn);
