@@ -1,31 +1,40 @@
 #!/bin/bash
 # Collects the round's rocprofv3 evidence on a GPU box into gpurun_out/ (summaries only; raw databases are deleted).
-#   bash scripts/collect_profiles.sh
+#   bash scripts/collect_profiles.sh [round tag, default r03]
 set -x
+R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-balanced --graph off"
-# (a) per-kernel time of the step (events on: expert weight gradients on the main stream, like the default timed region)
-rocprofv3 --kernel-trace --stats -d gpurun_out/p_step -o step -- $B > gpurun_out/p_step.log 2>&1
-python scripts/prof_summary.py $(find gpurun_out/p_step -name "*.db" | head -1) 40 > gpurun_out/r02_kernel_stats_step.md
-tail -1 gpurun_out/p_step.log | grep '^{' >> gpurun_out/r02_kernel_stats_step.md
+mkdir -p gpurun_out/$R
+O=gpurun_out/$R
+B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-balanced --graph off --no-events"
+# (a) per-kernel time of the step, eager launches (side-stream overlap of the expert weight gradients on, as in the timed region)
+rocprofv3 --kernel-trace --stats -d gpurun_out/p_step -o step -- $B > $O/p_step.log 2>&1
+python scripts/prof_summary.py $(find gpurun_out/p_step -name "*.db" | head -1) 45 > $O/${R}_kernel_stats_step.md
+tail -1 $O/p_step.log | grep '^{' >> $O/${R}_kernel_stats_step.md
 rm -rf gpurun_out/p_step
+# ... and without the side-stream overlap (kernel durations undisturbed by concurrent kernels)
+SWN_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d gpurun_out/p_step2 -o step -- $B > $O/p_step_noov.log 2>&1
+python scripts/prof_summary.py $(find gpurun_out/p_step2 -name "*.db" | head -1) 45 > $O/${R}_kernel_stats_step_no_overlap.md
+tail -1 $O/p_step_noov.log | grep '^{' >> $O/${R}_kernel_stats_step_no_overlap.md
+rm -rf gpurun_out/p_step2
 # (b) HBM traffic: two counter-only passes
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/p_$c -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --routing balanced --no-events --graph off > gpurun_out/p_$c.log 2>&1
-  python scripts/pmc_summary.py gpurun_out/p_$c > gpurun_out/r02_pmc_$c.txt
-  tail -1 gpurun_out/p_$c.log | grep '^{' >> gpurun_out/r02_pmc_$c.txt
+  SWN_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/p_$c -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --routing balanced --no-events --graph off > $O/p_$c.log 2>&1
+  python scripts/pmc_summary.py gpurun_out/p_$c > $O/${R}_pmc_$c.txt
+  tail -1 $O/p_$c.log | grep '^{' >> $O/${R}_pmc_$c.txt
   rm -rf gpurun_out/p_$c
 done
-# (c) SQ counters of the expert chains (one pass, 8 SQ slots)
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/p_sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --routing balanced --no-events --graph off > gpurun_out/p_sq.log 2>&1
-python scripts/pmc_summary.py gpurun_out/p_sq chainp > gpurun_out/r02_pmc_sq_chainb.txt
-python scripts/pmc_summary.py gpurun_out/p_sq wgrad_kernel >> gpurun_out/r02_pmc_sq_chainb.txt
-python scripts/pmc_summary.py gpurun_out/p_sq gate_ >> gpurun_out/r02_pmc_sq_chainb.txt
+# (c) SQ counters of the expert kernels (one pass, 8 SQ slots)
+SWN_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/p_sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --routing balanced --no-events --graph off > $O/p_sq.log 2>&1
+python scripts/pmc_summary.py gpurun_out/p_sq chainp > $O/${R}_pmc_sq_experts.txt
+python scripts/pmc_summary.py gpurun_out/p_sq wgrad_stream >> $O/${R}_pmc_sq_experts.txt
 rm -rf gpurun_out/p_sq
 # (d) the bench lines
-python bench.py > gpurun_out/r02_bench_default.json 2> gpurun_out/r02_bench_default.err
-python bench.py --steps 20 --warmup 5 > gpurun_out/r02_bench_20_5.json 2>/dev/null
-python bench.py --rays 1024 --steps 100 --warmup 20 --no-cpu-baseline --no-balanced --graph on > gpurun_out/r02_bench_1024rays_graph.json 2>/dev/null
-python bench.py --rays 1024 --steps 100 --warmup 20 --no-cpu-baseline --no-balanced --graph off --no-events > gpurun_out/r02_bench_1024rays_eager.json 2>/dev/null
-ls -la gpurun_out | head -30
+python bench.py > $O/${R}_bench_default.json 2> $O/${R}_bench_default.err
+python bench.py --steps 20 --warmup 5 > $O/${R}_bench_20_5.json 2>/dev/null
+SWN_NO_OVERLAP=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-balanced --no-events > $O/${R}_bench_no_overlap.json 2>/dev/null
+python bench.py --rays 1024 --steps 100 --warmup 20 --no-cpu-baseline --no-balanced --graph on > $O/${R}_bench_1024rays_graph.json 2>/dev/null
+python bench.py --rays 1024 --steps 100 --warmup 20 --no-cpu-baseline --no-balanced --graph off --no-events > $O/${R}_bench_1024rays_eager.json 2>/dev/null
+python bench.py --eval --steps 50 --warmup 10 --no-cpu-baseline > $O/${R}_bench_eval_graph.json 2>/dev/null
+python bench.py --eval --graph off --steps 50 --warmup 10 --no-cpu-baseline > $O/${R}_bench_eval_eager.json 2>/dev/null
+ls -la $O | head -40
