@@ -444,7 +444,7 @@ def main():
     # ---- the loop a maintainer of the reference would run (runner.py:604-693): rendering.render_rays under autograd, loss.backward(),
     #      torch.optim.Adam on the flat parameter, ExponentialLR - forward / backward replayed from captured graphs (nerf.graph_train)
     runner_ms = None
-    if plain and world == 1 and not a.no_events and a.dtype != "fp16":
+    if plain and not other and world == 1 and not a.no_events:        # (the headline recipe only)
         from argparse import Namespace
         from switch_nerf_amd import rendering
         reset_state(1234)
