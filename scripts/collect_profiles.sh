@@ -29,6 +29,10 @@ SWN_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY
 python scripts/pmc_summary.py gpurun_out/p_sq chainp > $O/${R}_pmc_sq_experts.txt
 python scripts/pmc_summary.py gpurun_out/p_sq wgrad_stream >> $O/${R}_pmc_sq_experts.txt
 rm -rf gpurun_out/p_sq
+# ... and of the SAVE-FREE expert chain (the inference forward: the grouped GEMM alone - north_star's MFMA figure)
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/p_sq2 -- python bench.py --eval --graph off --steps 3 --warmup 1 --no-cpu-baseline --gate-scale 0.02 > $O/p_sq_eval.log 2>&1
+python scripts/pmc_summary.py gpurun_out/p_sq2 chainp > $O/${R}_pmc_sq_eval_chain.txt
+rm -rf gpurun_out/p_sq2
 # (d) the bench lines
 python bench.py > $O/${R}_bench_default.json 2> $O/${R}_bench_default.err
 python bench.py --steps 20 --warmup 5 > $O/${R}_bench_20_5.json 2>/dev/null

@@ -112,3 +112,35 @@ def test_fp16_expert_chain_and_wgrad_vs_fp32_math(geometry):
         c = int(counts[gi])
         ref[gi % E] += a16[gi * cap: gi * cap + c].float().cpu().t() @ b16[gi * cap: gi * cap + c].float().cpu()
     assert (dw.cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
+def test_graphed_fp16_step_follows_the_loss_scale():
+    """graph.GraphedTrainStep on a float16 model.  The captured step reads the loss scale from a device scalar, the
+    step after the replay goes through SwitchNeRF.apply_step (inf check, unscale, skipped step, scale update): three replays equal three
+    eager steps of a twin model; a scale beyond the fp16 range is detected (step skipped, parameters untouched, scale halved) and the
+    NEXT replay already runs with the halved scale."""
+    from switch_nerf_amd import _lib
+    from switch_nerf_amd.graph import GraphedTrainStep
+    N, S, chunk = 256, 64, 4096
+    rays, img, rgbs = synth.make_rays(522, N)
+    try:
+        ma, mb = _model(torch.float16, 521), _model(torch.float16, 521)
+        step = GraphedTrainStep(ma, _dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0, noise_std=0.0)
+        ma.load_state_dict(synth.make_weights(521, synth.BUILDING, gate_scale=0.05))
+        ma.m.zero_(); ma.v.zero_(); ma.step_count = 0
+        ma.refresh_compute_copies()
+        for _ in range(3):
+            ra = step()
+            rb = mb.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0)
+            assert abs(ra["loss"].item() - rb["loss"].item()) <= 1e-3 * abs(rb["loss"].item())
+        assert ma.step_count == mb.step_count == 3 and ma.loss_scaler.skipped == 0
+        d = (ma.flat - mb.flat).abs().max().item() / mb.flat.abs().max().item()
+        assert d <= 5e-3, d                       # Adam actually consumed UNSCALED gradients (65536 x would move the weights by lr each)
+        before = ma.flat.clone()
+        ma.loss_scaler.scale = 2.0 ** 40
+        ma._loss_scale_tensor()                   # (a caller that sets the scale by hand syncs the device copy; _unscale_ok does it itself)
+        step()
+        assert ma.step_count == 3 and ma.loss_scaler.skipped == 1 and ma.loss_scaler.scale == 2.0 ** 39 and torch.equal(before, ma.flat)
+        assert float(ma._ls_dev.item()) == 2.0 ** 39
+    finally:
+        _lib.use_half("bf16")
