@@ -407,6 +407,27 @@ int swn_wgrad_multi(const swn_wgrad_job* jobs, int n_jobs, int dtype, int n_grou
  * stores its partial tile and a second kernel reduces them into dw/db (deterministic, no atomics); without it
  * (NULL) partial tiles are added with fp32 atomics.                                                               */
 
+/* ---- per-ray work of the step as single launches (round 3) ----------------------------------------------------------
+ * The direction / appearance half of layer "2" is constant along a ray (models/nerf_moe.py:419-429: cat([h, embedding_dir(d),
+ * embedding_a(idx)]) -> Linear "2"):  feat[n] = [pe_dir[n][0..in_dir), emb[idx[n]]] (fp32, [N, in_dir + app_dim]),
+ * c_ray[n] = feat[n] @ w2r + b2 ([N, h2] fp32, the per-ray bias of the tail chain's last layer).  w2r [in_dir + app_dim][h2] f32.
+ * image_indices: int32 or int64 (indices_are_int64).  Replaces torch cat / embedding / addmm.                             */
+int swn_ray_feat_fwd(const void* pe_dir, int dtype, int dir_stride, int in_dir, const float* emb, int app_dim,
+                     const void* image_indices, int indices_are_int64, const float* w2r, const float* b2, int n_rays, int h2,
+                     float* feat, float* c_ray, void* stream);
+/* ... and its backward given dc_ray [N, h2] f32 (the per-ray column sums of the layer's pre-activation gradient):
+ * g_w2r += feat^T dc_ray, g_b2 += colsum(dc_ray), g_emb[idx[n]] += dc_ray[n] @ w2r[in_dir:]^T  (fp32 atomics per block).
+ * in_dir + app_dim <= 96, h2 <= 256.                                                                                      */
+int swn_ray_feat_bwd(const float* dc_ray, const float* feat, const float* w2r, const void* image_indices, int indices_are_int64,
+                     int n_rays, int h2, int in_dir, int app_dim, float* g_w2r, float* g_b2, float* g_emb, void* stream);
+/* The loss of the training step (runner.py:1099-1111, 646-658) and its gradient seeds in one launch:
+ *   photo = mean((rgb - target)^2) over n_values = 3 N_rays;  gate_loss = mean(l_aux_a)  or, with l_aux_b (hierarchical: fine /
+ *   coarse), (mean(a) + mean(b)) / 2;  loss = photo + l_aux_weight * gate_loss;  psnr = -10 log10(photo)   -> out4 (device, 4 floats)
+ *   d_rgb = 2 (rgb - target) / n_values * s,  d_l_aux_x = l_aux_weight * share / n_x * s,  s = *loss_scale_dev (fp16 training) or 1. */
+int swn_step_loss(const float* rgb, const float* target, int n_values, const float* l_aux_a, int n_a, const float* l_aux_b, int n_b,
+                  float l_aux_weight, const float* loss_scale_dev, float* d_rgb, float* d_l_aux_a, float* d_l_aux_b, float* out4,
+                  void* stream);
+
 /* ---- optimiser -------------------------------------------------------------------------------------------------
  * torch.optim.Adam (runner.py:486) over one flat fp32 parameter buffer; grad_scale multiplies the gradient
  * (1/world_size after a sum all-reduce).  Also refreshes the compute copies: shadow (dtype) same layout.         */

@@ -88,6 +88,9 @@ SIGNATURES = {
     "swn_wgrad_batched": [C.POINTER(WgradItem), i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, sz, vp],
     "swn_wgrad_multi": [C.POINTER(WgradJob), i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, sz, vp],
     "swn_wgrad": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, vp, sz, vp],
+    "swn_ray_feat_fwd": [vp, i32, i32, i32, vp, i32, vp, i32, vp, vp, i32, i32, vp, vp, vp],
+    "swn_ray_feat_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp],
+    "swn_step_loss": [vp, vp, i32, vp, i32, vp, i32, f32, vp, vp, vp, vp, vp, vp],
     "swn_adam_step": [vp, vp, vp, vp, vp, i32, i64, f32, f32, f32, f32, i32, f32, vp],
     "swn_cast": [vp, vp, i32, i64, vp],
     "swn_cast_transpose": [vp, vp, i32, i32, i32, i32, vp],

@@ -1,0 +1,155 @@
+// Per-RAY work of the training step as three kernels (round 3).  The direction / appearance half of layer "2" is constant along a ray
+// (models/nerf_moe.py:419-429: cat([h, embedding_dir(d), embedding_a(idx)]) feeds Linear "2"); model.py folds it into a per-ray bias
+//     c_ray[n] = [PE(dir_n), emb[idx_n]] @ W2r + b2                       (N_rays x 75 x 128)
+// and the loss of the step (runner.py:1099-1111, 646-658) is a reduction over N_rays x 3 values.  Both were ~20 small torch kernels
+// (cat, index, addmm, sub, mul, mean, full, index_add ...) - nothing at 8192 x 256 points, 7 % of the step at the 1024 rays per GPU of
+// an 8-GPU strong-scaling run, where every launch gap counts.
+#include "common.hpp"
+
+namespace swn {
+
+// feat[n] = [pe_dir[n][0..in_dir), emb[idx[n]][0..app_dim)] (fp32), c_ray[n][j] = b2[j] + sum_k feat[n][k] w2r[k][j].  One block per ray.
+template <typename T>
+__global__ __launch_bounds__(256) void ray_feat_fwd_kernel(const T* __restrict__ pe_dir, int dir_stride, int in_dir, const float* __restrict__ emb,
+                                                           int app_dim, const void* __restrict__ image_indices, int idx64, const float* __restrict__ w2r,
+                                                           const float* __restrict__ b2, int n_rays, int h2, float* __restrict__ feat,
+                                                           float* __restrict__ c_ray) {
+  __shared__ float f[256];
+  const int n = blockIdx.x, F = in_dir + app_dim;
+  const long img = idx64 ? (long)((const long long*)image_indices)[n] : (long)((const int32_t*)image_indices)[n];
+  for (int k = threadIdx.x; k < F; k += blockDim.x) {
+    const float v = k < in_dir ? ElemIO<T>::ld(pe_dir + (long)n * dir_stride + k) : emb[img * app_dim + (k - in_dir)];
+    f[k] = v;
+    feat[(long)n * F + k] = v;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < h2; j += blockDim.x) {
+    float acc = b2[j];
+    for (int k = 0; k < F; ++k) acc = fmaf(f[k], w2r[(long)k * h2 + j], acc);
+    c_ray[(long)n * h2 + j] = acc;
+  }
+}
+
+// Backward of the above given dc_ray [N, h2] (= per-ray column sums of dh2): g_w2r += feat^T dc_ray, g_b2 += colsum(dc_ray),
+// g_emb[idx[n]] += dc_ray[n] @ w2r[in_dir:]^T.  A block takes RPB rays; thread j owns column j of the weight gradient (F accumulators),
+// one fp32 atomic per element and block at the end.
+constexpr int RF_RPB = 32, RF_MAXF = 96;
+__global__ __launch_bounds__(256) void ray_feat_bwd_kernel(const float* __restrict__ dc_ray, const float* __restrict__ feat,
+                                                           const float* __restrict__ w2r, const void* __restrict__ image_indices, int idx64,
+                                                           int n_rays, int h2, int in_dir, int app_dim, float* __restrict__ g_w2r,
+                                                           float* __restrict__ g_b2, float* __restrict__ g_emb) {
+  __shared__ float fs[RF_MAXF];
+  __shared__ float ds[256];
+  const int F = in_dir + app_dim, j = threadIdx.x;
+  const int r0 = blockIdx.x * RF_RPB, r1 = min(n_rays, r0 + RF_RPB);
+  float acc[RF_MAXF];
+#pragma unroll
+  for (int k = 0; k < RF_MAXF; ++k) acc[k] = 0.f;
+  float bsum = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    __syncthreads();
+    if (j < F) fs[j] = feat[(long)r * F + j];
+    const float d = j < h2 ? dc_ray[(long)r * h2 + j] : 0.f;
+    ds[j] = d;
+    __syncthreads();
+    bsum += d;
+#pragma unroll
+    for (int k = 0; k < RF_MAXF; ++k)
+      if (k < F) acc[k] = fmaf(fs[k], d, acc[k]);
+    if (j < app_dim) {            // gradient of this ray's appearance embedding row
+      float e = 0.f;
+      const float* wr = w2r + (long)(in_dir + j) * h2;
+      for (int q = 0; q < h2; ++q) e = fmaf(ds[q], wr[q], e);
+      const long img = idx64 ? (long)((const long long*)image_indices)[r] : (long)((const int32_t*)image_indices)[r];
+      unsafeAtomicAdd(g_emb + img * app_dim + j, e);
+    }
+  }
+  if (j < h2) {
+#pragma unroll
+    for (int k = 0; k < RF_MAXF; ++k)
+      if (k < F) unsafeAtomicAdd(g_w2r + (long)k * h2 + j, acc[k]);
+    unsafeAtomicAdd(g_b2 + j, bsum);
+  }
+}
+
+// The loss of the step in ONE block: photo = mean((rgb - target)^2), gate_loss = mean(l_aux_a) [or the mean of both means],
+// loss = photo + wt * gate_loss, psnr = -10 log10(photo); d_rgb = 2 (rgb - target) / (3 N) * scale, d_laux_* = wt * share / n_* * scale
+// (scale = the loss scale of fp16 training, read from a device scalar, or 1).  out4 = {photo, gate_loss, loss, psnr}.
+__global__ __launch_bounds__(1024) void step_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ target, int n_vals,
+                                                         const float* __restrict__ la, int na, const float* __restrict__ lb, int nb, float wt,
+                                                         const float* __restrict__ scale_dev, float* __restrict__ d_rgb,
+                                                         float* __restrict__ d_la, float* __restrict__ d_lb, float* __restrict__ out4) {
+  __shared__ double red[1024];
+  const float sc = scale_dev ? scale_dev[0] : 1.f;
+  const float k = 2.0f / (float)n_vals * sc;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n_vals; i += 1024) {
+    const float d = rgb[i] - target[i];
+    s += (double)d * (double)d;
+    d_rgb[i] = d * k;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o >= 1; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float share = nb > 0 ? 0.5f : 1.f;
+  for (int i = threadIdx.x; i < na; i += 1024) d_la[i] = wt * share / (float)na * sc;
+  for (int i = threadIdx.x; i < nb; i += 1024) d_lb[i] = wt * share / (float)nb * sc;
+  if (threadIdx.x == 0) {
+    const float photo = (float)(red[0] / (double)n_vals);
+    double ga = 0.0, gb = 0.0;
+    for (int i = 0; i < na; ++i) ga += la[i];
+    for (int i = 0; i < nb; ++i) gb += lb[i];
+    float gate = (float)(ga / (double)na);
+    if (nb > 0) gate = 0.5f * ((float)(gb / (double)nb) + gate);      // runner.py:1104-1111: (mean(fine) + mean(coarse)) / 2
+    out4[0] = photo;
+    out4[1] = gate;
+    out4[2] = photo + wt * gate;
+    out4[3] = -10.0f * log10f(photo);
+  }
+}
+
+}  // namespace swn
+
+using namespace swn;
+
+extern "C" int swn_ray_feat_fwd(const void* pe_dir, int dtype, int dir_stride, int in_dir, const float* emb, int app_dim,
+                                const void* image_indices, int indices_are_int64, const float* w2r, const float* b2, int n_rays, int h2,
+                                float* feat, float* c_ray, void* stream) {
+  SWN_CHECK(pe_dir && emb && image_indices && w2r && b2 && feat && c_ray, "swn_ray_feat_fwd: null pointer");
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_ray_feat_fwd: bad dtype %d", dtype);
+  SWN_CHECK(n_rays > 0 && h2 > 0 && in_dir >= 0 && app_dim >= 0 && in_dir + app_dim > 0 && in_dir + app_dim <= 256,
+            "swn_ray_feat_fwd: bad sizes (rays %d, h2 %d, features %d + %d)", n_rays, h2, in_dir, app_dim);
+  if (dtype == SWN_HALF)
+    hipLaunchKernelGGL((ray_feat_fwd_kernel<bf16_t>), dim3(n_rays), dim3(128), 0, as_stream(stream), (const bf16_t*)pe_dir, dir_stride, in_dir, emb,
+                       app_dim, image_indices, indices_are_int64, w2r, b2, n_rays, h2, feat, c_ray);
+  else
+    hipLaunchKernelGGL((ray_feat_fwd_kernel<float>), dim3(n_rays), dim3(128), 0, as_stream(stream), (const float*)pe_dir, dir_stride, in_dir, emb,
+                       app_dim, image_indices, indices_are_int64, w2r, b2, n_rays, h2, feat, c_ray);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int swn_ray_feat_bwd(const float* dc_ray, const float* feat, const float* w2r, const void* image_indices, int indices_are_int64,
+                                int n_rays, int h2, int in_dir, int app_dim, float* g_w2r, float* g_b2, float* g_emb, void* stream) {
+  SWN_CHECK(dc_ray && feat && w2r && image_indices && g_w2r && g_b2 && g_emb, "swn_ray_feat_bwd: null pointer");
+  SWN_CHECK(n_rays > 0 && h2 > 0 && h2 <= 256 && in_dir + app_dim > 0 && in_dir + app_dim <= RF_MAXF && app_dim <= 256,
+            "swn_ray_feat_bwd: bad sizes (rays %d, h2 %d <= 256, features %d + %d <= %d)", n_rays, h2, in_dir, app_dim, RF_MAXF);
+  hipLaunchKernelGGL(ray_feat_bwd_kernel, dim3(cdiv(n_rays, RF_RPB)), dim3(256), 0, as_stream(stream), dc_ray, feat, w2r, image_indices,
+                     indices_are_int64, n_rays, h2, in_dir, app_dim, g_w2r, g_b2, g_emb);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int swn_step_loss(const float* rgb, const float* target, int n_values, const float* l_aux_a, int n_a, const float* l_aux_b,
+                             int n_b, float l_aux_weight, const float* loss_scale_dev, float* d_rgb, float* d_l_aux_a, float* d_l_aux_b,
+                             float* out4, void* stream) {
+  SWN_CHECK(rgb && target && l_aux_a && d_rgb && d_l_aux_a && out4, "swn_step_loss: null pointer");
+  SWN_CHECK(n_values > 0 && n_a > 0 && n_b >= 0 && (n_b == 0 || (l_aux_b && d_l_aux_b)), "swn_step_loss: bad sizes");
+  hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, as_stream(stream), rgb, target, n_values, l_aux_a, n_a, l_aux_b, n_b,
+                     l_aux_weight, loss_scale_dev, d_rgb, d_l_aux_a, d_l_aux_b, out4);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}

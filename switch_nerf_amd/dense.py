@@ -173,9 +173,7 @@ class DenseNeRF(SwitchNeRF):
             o.mlp_chain(pe, layers, c["acts"][L - 1], tag=1)
         c["y"] = c["acts"][L - 1]
         # ---- per-ray part of dir_a_encoding: [PE(dir), appearance embedding] @ W2r + b2 (nerf.py:173-181)
-        feat = torch.cat([pe_dir[:, : self.in_dir].float(), self.p["emb"][image_indices.long()]], 1)
-        c["ray_feat"] = feat
-        c["c_ray"] = torch.addmm(self.p["l2.b"], feat, self.p["l2r.w"]).contiguous()
+        c["ray_feat"], c["c_ray"] = o.ray_feat_fwd(pe_dir, self.in_dir, self.p["emb"], image_indices.contiguous(), self.p["l2r.w"], self.p["l2.b"])
         c["h1"] = _b("h1", (P, W), dt)
         c["h2"] = _b("h2", (P, H2), dt)
         o.mlp_chain(c["y"], [o.Layer(self.wf["l1"], self.p["l1.b"].view(1, W), save=c["h1"] if sv else None),
@@ -198,9 +196,7 @@ class DenseNeRF(SwitchNeRF):
         dh2, dsig = o.heads_bwd(c["y"], c["h2"], self.p["color.w"], c["raw"], d_raw, g["sigma.w"], g["sigma.b"], g["color.w"],
                                 g["color.b"])
         dc_ray = o.group_colsum(dh2, S)
-        g["l2r.w"].addmm_(c["ray_feat"].t(), dc_ray)
-        g["l2.b"].add_(dc_ray.sum(0))
-        g["emb"].index_add_(0, c["image_indices"].long(), dc_ray @ self.p["l2r.w"][self.in_dir:].t())
+        o.ray_feat_bwd(dc_ray, c["ray_feat"], self.p["l2r.w"], c["image_indices"].contiguous(), self.in_dir, g["l2r.w"], g["l2.b"], g["emb"])
         dh1 = _b("dh1", (P, W), dt)
         dy = _b("dy", (P, W), dt)
         o.mlp_chain(dh2, [o.Layer(self.wb["l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dy, tag=5)

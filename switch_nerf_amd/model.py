@@ -583,9 +583,8 @@ class SwitchNeRF:
                     wait()
             c["ep_x"] = xr
         # ---- per-ray part of layer "2": [PE(dir), appearance embedding] @ W2r + b2   (N_rays x 75, host-side torch)
-        feat = torch.cat([pe_dir[:, : self.in_dir].float(), self.p["emb"][image_indices.long()]], 1)
-        c["ray_feat"] = feat
-        c["c_ray"] = torch.addmm(self.p["l2.b"], feat, self.p["l2r.w"]).contiguous()
+        # (one launch: swn_ray_feat_fwd - was cat / embedding lookup / addmm in torch)
+        c["ray_feat"], c["c_ray"] = o.ray_feat_fwd(pe_dir, self.in_dir, self.p["emb"], image_indices.contiguous(), self.p["l2r.w"], self.p["l2.b"])
         # ---- tail chain.  Its input load IS the combine: rows gathered from the expert output through tok2row, scaled by
         # the gate value, ReLU'd (dropped tokens -> zero rows) and saved as y;  then layer "1" -> layer "2" (+ per-ray bias)
         c["y"] = _b("y", (P, M), dt)
@@ -637,10 +636,8 @@ class SwitchNeRF:
             dc_ray = torch.zeros(N, H2, dtype=torch.float32, device=self.dev).index_add_(0, ray_of_row, dh2.float())
         else:
             dc_ray = o.group_colsum(dh2, S)
-        g["l2r.w"].addmm_(c["ray_feat"].t(), dc_ray)
-        g["l2.b"].add_(dc_ray.sum(0))
-        d_feat_emb = dc_ray @ self.p["l2r.w"][self.in_dir:].t()
-        g["emb"].index_add_(0, c["image_indices"].long(), d_feat_emb)
+        # (one launch: swn_ray_feat_bwd - was addmm_ / sum / matmul / index_add_ in torch)
+        o.ray_feat_bwd(dc_ray, c["ray_feat"], self.p["l2r.w"], c["image_indices"].contiguous(), self.in_dir, g["l2r.w"], g["l2.b"], g["emb"])
         # tail backward chain: dh2 -> dh1 -> dy
         # ... with the combine backward (the sigma head's rank-1 term, the ReLU mask of y, the gate gradient, the gate scaling) applied
         # in the write-out of the last layer: dy itself never reaches memory
@@ -800,27 +797,24 @@ class SwitchNeRF:
         if not fine:
             c = out = self.forward_rays(rays, image_indices, n_samples, seg_tokens, perturb, perturb_rand, sigma_noise, True,
                                         routing_override)
-            gate_loss = c["l_aux"].mean()                                 # runner.py:1104
         else:
             c, cf, out = self.forward_hier(rays, image_indices, n_samples, fine_samples, seg_tokens, perturb, perturb_rand,
                                            fine_u, sigma_noise, sigma_noise_fine, routing_override)
-            gate_loss = (cf["l_aux"].mean() + c["l_aux"].mean()) / 2.0    # runner.py:1104-1111
-        diff = out["rgb"] - rgbs
-        photo = (diff * diff).mean()                                      # F.mse_loss, runner.py:1099
-        loss = photo + self.wt * gate_loss                                # runner.py:646-651
-        # scaler.scale(loss).backward(), runner.py:679: the scale is read from a DEVICE scalar (kept equal to loss_scaler.scale by
-        # _unscale_ok), so a captured step (graph.GraphedTrainStep) follows the scale as it adapts between replays
-        ls = self._loss_scale_tensor() if self.loss_scaler is not None else 1.0
-        d_rgb = (diff * (2.0 / diff.numel()) * ls).contiguous()
+        # loss (F.mse_loss runner.py:1099, + wt * gate loss :646-651, :1104-1111), psnr and the gradient seeds in ONE launch
+        # (swn_step_loss); scaler.scale(loss).backward() (runner.py:679): the scale is read from a DEVICE scalar (kept equal to
+        # loss_scaler.scale by _unscale_ok), so a captured step (graph.GraphedTrainStep) follows the scale as it adapts between replays
+        ls = self._loss_scale_tensor() if self.loss_scaler is not None else None
+        out4, d_rgb, d_la, d_lb = ops.step_loss(out["rgb"], rgbs.to(torch.float32).contiguous(), cf["l_aux"] if fine else c["l_aux"],
+                                                c["l_aux"] if fine else None, self.wt, ls)
+        photo, gate_loss, loss, psnr = out4[0], out4[1], out4[2], out4[3]
         if not fine:
-            d_laux = torch.full((c["n_seg"],), self.wt / c["n_seg"], dtype=torch.float32, device=self.dev) * ls
-            self.backward(c, d_rgb, d_laux)
+            self.backward(c, d_rgb, d_la)
         else:
             d_raw_m = ops.composite_bwd(out["raw"], out["z"], d_rgb)
             d_raw_f, d_raw_c = ops.unmerge_grad(d_raw_m, out["order"], fine_samples, n_samples)
-            self.backward_net(cf, d_raw_f, torch.full((cf["n_seg"],), 0.5 * self.wt / cf["n_seg"], dtype=torch.float32, device=self.dev) * ls)
-            self.backward_net(c, d_raw_c, torch.full((c["n_seg"],), 0.5 * self.wt / c["n_seg"], dtype=torch.float32, device=self.dev) * ls)
-        res = dict(loss=loss, photo_loss=photo, gate_loss=gate_loss, psnr=-10.0 * torch.log10(photo),
+            self.backward_net(cf, d_raw_f, d_la)
+            self.backward_net(c, d_raw_c, d_lb)
+        res = dict(loss=loss, photo_loss=photo, gate_loss=gate_loss, psnr=psnr,
                    depth_variance=out["depth_variance"].mean(), ctx=c, rgb=out["rgb"], depth=out["depth"])
         if fine:
             res["ctx_fine"] = cf

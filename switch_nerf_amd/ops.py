@@ -264,6 +264,41 @@ def group_colsum(x, rows_per_group: int):
     return out
 
 
+def _idx_arg(image_indices):
+    assert image_indices.dtype in (torch.int32, torch.int64) and image_indices.is_contiguous()
+    return _p(image_indices), int(image_indices.dtype == torch.int64)
+
+
+def ray_feat_fwd(pe_dir, in_dir: int, emb, image_indices, w2r, b2):
+    """-> feat [N, in_dir + app_dim] f32, c_ray [N, h2] f32 (include/swn.h swn_ray_feat_fwd)."""
+    N, h2, app = pe_dir.shape[0], w2r.shape[1], emb.shape[1]
+    feat = torch.empty(N, in_dir + app, dtype=torch.float32, device=pe_dir.device)
+    c_ray = torch.empty(N, h2, dtype=torch.float32, device=pe_dir.device)
+    ip, i64 = _idx_arg(image_indices)
+    call("swn_ray_feat_fwd", _p(pe_dir), _dt(pe_dir), pe_dir.shape[1], int(in_dir), _p(emb), app, ip, i64, _p(w2r), _p(b2), N, h2,
+         _p(feat), _p(c_ray), _stream())
+    return feat, c_ray
+
+
+def ray_feat_bwd(dc_ray, feat, w2r, image_indices, in_dir: int, g_w2r, g_b2, g_emb):
+    N, h2 = dc_ray.shape
+    ip, i64 = _idx_arg(image_indices)
+    call("swn_ray_feat_bwd", _p(dc_ray), _p(feat), _p(w2r), ip, i64, N, h2, int(in_dir), feat.shape[1] - int(in_dir), _p(g_w2r), _p(g_b2),
+         _p(g_emb), _stream())
+
+
+def step_loss(rgb, target, l_aux_a, l_aux_b, wt: float, loss_scale_dev=None):
+    """-> (out4 = [photo, gate_loss, loss, psnr] on the device, d_rgb, d_l_aux_a, d_l_aux_b or None)."""
+    dev = rgb.device
+    d_rgb = torch.empty_like(rgb)
+    d_a = torch.empty_like(l_aux_a)
+    d_b = torch.empty_like(l_aux_b) if l_aux_b is not None else None
+    out4 = torch.empty(4, dtype=torch.float32, device=dev)
+    call("swn_step_loss", _p(rgb), _p(target), rgb.numel(), _p(l_aux_a), l_aux_a.numel(), _p(l_aux_b), 0 if l_aux_b is None else l_aux_b.numel(),
+         float(wt), _p(loss_scale_dev), _p(d_rgb), _p(d_a), _p(d_b), _p(out4), _stream())
+    return out4, d_rgb, d_a, d_b
+
+
 def sample_z(rays, t_steps, perturb_rand, perturb: float, n_samples: int):
     n = rays.shape[0]
     z = torch.empty(n, n_samples, dtype=torch.float32, device=rays.device)

@@ -509,6 +509,50 @@ def test_wgrad_balanced_multi(dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
+def test_ray_feat_fwd_bwd_and_step_loss(dtype, idx_dtype):
+    """The per-ray launches of round 3 against the torch ops they replace: [PE(dir), emb[idx]] @ W2r + b2 (models/nerf_moe.py:419-429
+    folded per ray) forward and backward, and the loss / psnr / gradient seeds of the step (runner.py:1099-1111, 646-658) incl. the
+    hierarchical gate-loss average and the fp16 loss scale."""
+    o = ops()
+    rng = np.random.default_rng(91)
+    N, in_dir, app, A, H2, DP = 1000, 27, 48, 10, 128, 32
+    pe = torch.from_numpy(rng.standard_normal((N, DP)).astype(np.float32)).to(dev()).to(dtype)
+    emb = torch.from_numpy(rng.standard_normal((A, app)).astype(np.float32)).to(dev())
+    idx = torch.from_numpy(rng.integers(0, A, N)).to(dev()).to(idx_dtype)
+    w = torch.from_numpy((rng.standard_normal((in_dir + app, H2)) / 8).astype(np.float32)).to(dev())
+    b = torch.from_numpy(rng.standard_normal(H2).astype(np.float32)).to(dev())
+    feat, c_ray = o.ray_feat_fwd(pe, in_dir, emb, idx, w, b)
+    feat_ref = torch.cat([pe[:, :in_dir].float(), emb[idx.long()]], 1)
+    assert torch.equal(feat, feat_ref)
+    ref = torch.addmm(b.double(), feat_ref.double(), w.double()).float()
+    assert report(f"ray_feat_fwd_{dtype}", c_ray, ref) <= 2e-5
+    dc = torch.from_numpy(rng.standard_normal((N, H2)).astype(np.float32)).to(dev())
+    gw, gb, ge = torch.full_like(w, 0.5), torch.full_like(b, -1.0), torch.zeros_like(emb)
+    o.ray_feat_bwd(dc, feat, w, idx, in_dir, gw, gb, ge)
+    assert report(f"ray_feat_bwd_w_{dtype}", gw, 0.5 + (feat_ref.double().t() @ dc.double()).float()) <= 2e-4
+    assert report(f"ray_feat_bwd_b_{dtype}", gb, -1.0 + dc.double().sum(0).float()) <= 2e-4
+    ge_ref = torch.zeros_like(emb).double().index_add_(0, idx.long(), dc.double() @ w[in_dir:].double().t()).float()
+    assert report(f"ray_feat_bwd_emb_{dtype}", ge, ge_ref) <= 5e-4
+    # the step's loss
+    rgb = torch.rand(N, 3, device=dev())
+    tgt = torch.rand(N, 3, device=dev())
+    la, lb = torch.rand(5, device=dev()), torch.rand(3, device=dev())
+    scale = torch.tensor([1024.0], device=dev())
+    for use_b, sc in ((False, None), (True, scale)):
+        out4, d_rgb, d_a, d_b = o.step_loss(rgb, tgt, la, lb if use_b else None, 5e-4, sc)
+        s_ = 1.0 if sc is None else 1024.0
+        photo = ((rgb.double() - tgt.double()) ** 2).mean()
+        gate = (lb.double().mean() + la.double().mean()) / 2 if use_b else la.double().mean()
+        want = torch.stack([photo, gate, photo + 5e-4 * gate, -10 * torch.log10(photo)]).float()
+        assert (out4 - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item())
+        assert (d_rgb - (rgb - tgt) * (2.0 * s_ / (3 * N))).abs().max().item() <= 1e-9 * s_ + 1e-7 * (d_rgb.abs().max().item())
+        share = 0.5 if use_b else 1.0
+        assert torch.allclose(d_a, torch.full_like(la, 5e-4 * share / 5 * s_), rtol=1e-6)
+        assert (d_b is None) == (not use_b) and (d_b is None or torch.allclose(d_b, torch.full_like(lb, 5e-4 * 0.5 / 3 * s_), rtol=1e-6))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_heads_and_combine_bwd(dtype):
     rng = np.random.default_rng(61)
     P, M, H2 = 2500, 256, 128

@@ -150,3 +150,67 @@ def test_expert_parallel_single_rank_is_identity():
     r, w = ep.all_to_all(s, out=s)
     w()
     assert r is s
+
+
+def _ep_packed_worker(rank, world, port, out):
+    """Round 3 protocol: kept rows only, packed per (segment, expert), unequal-split exchange planned from ONE host read of the counts."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from switch_nerf_amd import parallel
+    parallel.init_from_env(backend="gloo")
+    E, n_seg, seg_tokens, cap, M = 4, 3, 40, 10, 8
+    ep = parallel.ExpertParallel(rank, world, E)
+    rng = np.random.default_rng(300 + rank)
+    idx, perm, counts, tok2row = _route(rng, n_seg, seg_tokens, E, cap)
+    P = n_seg * seg_tokens
+    x = torch.from_numpy(rng.standard_normal((P, M)).astype(np.float32)) + 10.0 * rank
+    counts_t = torch.from_numpy(counts)
+    kept = counts_t.clamp(max=cap)                                                  # [n_seg, E]
+    # the packed row space of swn_route_pack on the kept rows: group (segment, expert) starts at the exclusive prefix sum of `kept`
+    begin = (torch.cumsum(kept.reshape(-1), 0) - kept.reshape(-1)).long()
+    perm_c = torch.from_numpy(perm).view(n_seg, E, cap)
+    packed_perm = torch.cat([perm_c[s_, e, : int(kept[s_, e])] for s_ in range(n_seg) for e in range(E)]).long()      # packed row -> token
+    recv_counts = ep.exchange_counts(counts_t, cap)()                               # [n_seg, W * E_local]
+    pl = ep.plan(kept, recv_counts)
+    so, ro = pl["send_off"], pl["recv_off"]
+    assert so[-1] == int(kept.sum()) and ro[-1] == int(recv_counts.sum())
+    send = x[packed_perm]                                                           # swn_gather_rows through the packed permutation
+    xr = torch.zeros(ro[-1], M)
+    back = torch.zeros(so[-1], M)
+    rbeg = (torch.cumsum(recv_counts.reshape(-1), 0) - recv_counts.reshape(-1)).long()
+    ngs = world * ep.El
+    for s_ in range(n_seg):
+        ep.all_to_all_v(send[so[s_]:so[s_ + 1]], pl["in_splits"][s_], xr[ro[s_]:ro[s_ + 1]], pl["out_splits"][s_])()
+        y = torch.zeros(ro[s_ + 1] - ro[s_], M)
+        for g in range(ngs):                        # received groups in (source rank, local expert) order, first rows from a prefix sum
+            e = rank * ep.El + g % ep.El
+            b0, n = int(rbeg[s_ * ngs + g]), int(recv_counts[s_, g])
+            y[b0 - ro[s_]: b0 - ro[s_] + n] = xr[b0: b0 + n] * (e + 1) + e
+        ep.all_to_all_v(y, pl["out_splits"][s_], back[so[s_]:so[s_ + 1]], pl["in_splits"][s_])()
+    # the returned rows sit in the packed row space: token -> begin[(segment, expert)] + slot
+    t2r = torch.from_numpy(tok2row).long()
+    slot = t2r % cap
+    grp = t2r // cap
+    rows = begin[grp.clamp(min=0)] + slot
+    keep = t2r >= 0
+    got = torch.where(keep[:, None], back[rows.clamp(0, max(so[-1] - 1, 0))], torch.zeros(1, M))
+    ie = torch.from_numpy(idx)[:, None]
+    ref = torch.where(keep[:, None], x * (ie + 1) + ie, torch.zeros(1, M))
+    sent_rows = sum(sum(r) - r[rank] for r in pl["in_splits"])
+    out[rank] = (bool(torch.equal(got, ref)), int(keep.sum()), ro[-1], sent_rows, n_seg * E * cap)
+    dist.destroy_process_group()
+
+
+def test_expert_parallel_kept_rows_only_exchange_gloo():
+    """The round-3 exchange on 2 ranks: packed kept rows, unequal splits from one host read of the counts, received groups addressed by
+    a prefix sum, the way back with swapped splits - every kept token is processed by its expert's owner and returns to its packed row;
+    no padding row travels (rows leaving a rank <= its kept rows < the capacity-padded payload)."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_ep_packed_worker, args=(world, 29431 + os.getpid() % 200, out), nprocs=world, join=True)
+    assert out[0][0] and out[1][0]
+    assert out[0][1] + out[1][1] == out[0][2] + out[1][2]
+    for r in range(world):
+        assert out[r][3] <= out[r][1] < out[r][4]
