@@ -149,9 +149,10 @@ def route_top1(idx, gmax, gates, seg_tokens: int, n_experts: int, capacity: int,
     nbytes = _lib.load().swn_route_workspace_bytes(P, n_seg, n_experts)
     key = (dev, nbytes)
     ws = _route_ws.get(key)
-    if ws is None:
+    if ws is None:      # one workspace per size, kept: a captured hipGraph may hold its address (coarse / fine passes alternate two sizes)
+        if len(_route_ws) >= 16:
+            _route_ws.pop(next(iter(_route_ws)))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _route_ws.clear()
         _route_ws[key] = ws
     call("swn_route_top1", _p(idx), _p(gmax), _p(gates), P, int(seg_tokens), n_experts, int(capacity), int(bool(bpr)),
          _p(loc), _p(counts), _p(perm), _p(tok2row), _p(l_aux), _p(ws), nbytes, _stream())
@@ -283,8 +284,10 @@ def ray_feat_fwd(pe_dir, in_dir: int, emb, image_indices, w2r, b2):
 def ray_feat_bwd(dc_ray, feat, w2r, image_indices, in_dir: int, g_w2r, g_b2, g_emb):
     N, h2 = dc_ray.shape
     ip, i64 = _idx_arg(image_indices)
-    call("swn_ray_feat_bwd", _p(dc_ray), _p(feat), _p(w2r), ip, i64, N, h2, int(in_dir), feat.shape[1] - int(in_dir), _p(g_w2r), _p(g_b2),
-         _p(g_emb), _stream())
+    app = feat.shape[1] - int(in_dir)
+    ws = torch.empty(int(_lib.load().swn_ray_feat_bwd_workspace_floats(N, h2, int(in_dir), app)), dtype=torch.float32, device=dc_ray.device)
+    call("swn_ray_feat_bwd", _p(dc_ray), _p(feat), _p(w2r), ip, i64, N, h2, int(in_dir), app, g_emb.shape[0], _p(g_w2r), _p(g_b2),
+         _p(g_emb), _p(ws), _stream())
 
 
 def step_loss(rgb, target, l_aux_a, l_aux_b, wt: float, loss_scale_dev=None):
@@ -512,10 +515,15 @@ _wgrad_ws = {}
 def _wgrad_workspace(dev, nbytes: int):
     """One workspace per (device, stream) - launches on different streams may overlap -, grown to the largest request."""
     key = (dev, torch.cuda.current_stream().cuda_stream)
-    ws = _wgrad_ws.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
-        _wgrad_ws[key] = ws
+    held = _wgrad_ws.setdefault(key, [])
+    for ws in held:
+        if ws.numel() >= nbytes:
+            return ws
+    # a larger request: a NEW buffer next to the old ones (a captured hipGraph may still hold an old one's address; a handful of growth
+    # steps at most - the sizes depend on the job count and the weight sets only)
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+    held.insert(0, ws)
+    del held[4:]
     return ws
 
 

@@ -38,13 +38,13 @@ worst = 0.0
 for k, v in cks["dp"]["model_state_dict"].items():
     d = (v - cks["ep"]["model_state_dict"][k]).abs().max().item() / (v.abs().max().item() + 1e-12)
     worst = max(worst, d)
-    ok &= d <= 2e-5
+    ok &= d <= 5e-5
 sd, se = cks["dp"]["optimizers"]["nerf"]["state"], cks["ep"]["optimizers"]["nerf"]["state"]
 for i in sd:
     for key in ("exp_avg", "exp_avg_sq"):
         d = (sd[i][key] - se[i][key]).abs().max().item() / (sd[i][key].abs().max().item() + 1e-20)
         worst = max(worst, d)
-        ok &= d <= 1e-4
+        ok &= d <= 5e-4
 moved = (cks["ep"]["model_state_dict"]["module.layers.0.experts.0.weights.3"] - torch.from_numpy(
     synth.make_weights(701, synth.BUILDING, gate_scale=1.0)["layers.0.experts.0.weights.3"])).abs().amax(dim=(1, 2))
 ok &= bool((moved > 0).all())                                          # every expert - also the other rank's - carries trained weights
