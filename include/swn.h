@@ -415,14 +415,6 @@ int swn_wgrad_multi(const swn_wgrad_job* jobs, int n_jobs, int dtype, int n_grou
 int swn_ray_feat_fwd(const void* pe_dir, int dtype, int dir_stride, int in_dir, const float* emb, int app_dim,
                      const void* image_indices, int indices_are_int64, const float* w2r, const float* b2, int n_rays, int h2,
                      float* feat, float* c_ray, void* stream);
-/* ... and its backward given dc_ray [N, h2] f32 (the per-ray column sums of the layer's pre-activation gradient):
- * g_w2r += feat^T dc_ray, g_b2 += colsum(dc_ray), g_emb[idx[n]] += dc_ray[n] @ w2r[in_dir:]^T for the n_emb_rows rows of the embedding
- * table.  Deterministic: block partials + per-ray embedding gradients in `workspace` (swn_ray_feat_bwd_workspace_floats floats), added
- * in a fixed order by a second kernel.  in_dir + app_dim <= 96, h2 <= 256.                                                 */
-size_t swn_ray_feat_bwd_workspace_floats(int n_rays, int h2, int in_dir, int app_dim);
-int swn_ray_feat_bwd(const float* dc_ray, const float* feat, const float* w2r, const void* image_indices, int indices_are_int64,
-                     int n_rays, int h2, int in_dir, int app_dim, int n_emb_rows, float* g_w2r, float* g_b2, float* g_emb,
-                     float* workspace, void* stream);
 /* The loss of the training step (runner.py:1099-1111, 646-658) and its gradient seeds in one launch:
  *   photo = mean((rgb - target)^2) over n_values = 3 N_rays;  gate_loss = mean(l_aux_a)  or, with l_aux_b (hierarchical: fine /
  *   coarse), (mean(a) + mean(b)) / 2;  loss = photo + l_aux_weight * gate_loss;  psnr = -10 log10(photo)   -> out4 (device, 4 floats)

@@ -89,7 +89,6 @@ SIGNATURES = {
     "swn_wgrad_multi": [C.POINTER(WgradJob), i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, sz, vp],
     "swn_wgrad": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, vp, sz, vp],
     "swn_ray_feat_fwd": [vp, i32, i32, i32, vp, i32, vp, i32, vp, vp, i32, i32, vp, vp, vp],
-    "swn_ray_feat_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "swn_step_loss": [vp, vp, i32, vp, i32, vp, i32, f32, vp, vp, vp, vp, vp, vp],
     "swn_adam_step": [vp, vp, vp, vp, vp, i32, i64, f32, f32, f32, f32, i32, f32, vp],
     "swn_cast": [vp, vp, i32, i64, vp],
@@ -133,8 +132,6 @@ def load():
     lib.swn_route_workspace_bytes.argtypes = [i32, i32, i32]
     lib.swn_gate_bwd_scratch_floats.restype = sz
     lib.swn_gate_bwd_scratch_floats.argtypes = [i32, i32, i32]
-    lib.swn_ray_feat_bwd_workspace_floats.restype = sz
-    lib.swn_ray_feat_bwd_workspace_floats.argtypes = [i32, i32, i32, i32]
     lib.swn_wgrad_multi_workspace_bytes.restype = sz
     lib.swn_wgrad_multi_workspace_bytes.argtypes = [i32, i32]
     lib.swn_chain_mask_words.restype = i64

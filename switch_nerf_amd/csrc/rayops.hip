@@ -1,9 +1,11 @@
-// Per-RAY work of the training step as three kernels (round 3).  The direction / appearance half of layer "2" is constant along a ray
+// Per-RAY work of the training step as single launches (round 3).  The direction / appearance half of layer "2" is constant along a ray
 // (models/nerf_moe.py:419-429: cat([h, embedding_dir(d), embedding_a(idx)]) feeds Linear "2"); model.py folds it into a per-ray bias
 //     c_ray[n] = [PE(dir_n), emb[idx_n]] @ W2r + b2                       (N_rays x 75 x 128)
-// and the loss of the step (runner.py:1099-1111, 646-658) is a reduction over N_rays x 3 values.  Both were ~20 small torch kernels
-// (cat, index, addmm, sub, mul, mean, full, index_add ...) - nothing at 8192 x 256 points, 7 % of the step at the 1024 rays per GPU of
-// an 8-GPU strong-scaling run, where every launch gap counts.
+// and the loss of the step (runner.py:1099-1111, 646-658) is a reduction over N_rays x 3 values.  Both were ~15 small torch kernels
+// (cat, index, addmm, sub, mul, mean, full ...) - nothing at 8192 x 256 points, but launches that the host pays for one by one when it
+// is the bottleneck (the first process on a fresh box, the 1024 rays per GPU of an 8-GPU run).  The BACKWARD of the per-ray part stays
+// in torch (addmm_ / sum / matmul / index_add_, ~35 us): a fused deterministic version measured 0.8 ms (an ordered reduction over 800
+// rays per embedding row is a latency chain), an atomic one 0.12 ms - profiles/r03_experiments.md.
 #include "common.hpp"
 
 namespace swn {
@@ -28,80 +30,6 @@ __global__ __launch_bounds__(256) void ray_feat_fwd_kernel(const T* __restrict__
     for (int k = 0; k < F; ++k) acc = fmaf(f[k], w2r[(long)k * h2 + j], acc);
     c_ray[(long)n * h2 + j] = acc;
   }
-}
-
-// Backward of the above given dc_ray [N, h2] (= per-ray column sums of dh2): g_w2r += feat^T dc_ray, g_b2 += colsum(dc_ray),
-// g_emb[idx[n]] += dc_ray[n] @ w2r[in_dir:]^T.  Deterministic (no atomics): a block takes RPB rays, thread j owns column j of the weight
-// gradient (F accumulators) and the block stores its partial [F * h2 + h2]; it also stores every ray's embedding-row gradient.  The
-// reduce kernel adds the block partials in block order and, per embedding row, the rays that use it in ray order.
-constexpr int RF_RPB = 32, RF_MAXF = 96;
-__global__ __launch_bounds__(256) void ray_feat_bwd_kernel(const float* __restrict__ dc_ray, const float* __restrict__ feat,
-                                                           const float* __restrict__ w2r, int n_rays, int h2, int in_dir, int app_dim,
-                                                           float* __restrict__ partial, float* __restrict__ d_emb_ray) {
-  __shared__ float fs[RF_MAXF];
-  __shared__ float ds[256];
-  const int F = in_dir + app_dim, j = threadIdx.x;
-  const int r0 = blockIdx.x * RF_RPB, r1 = min(n_rays, r0 + RF_RPB);
-  float acc[RF_MAXF];
-#pragma unroll
-  for (int k = 0; k < RF_MAXF; ++k) acc[k] = 0.f;
-  float bsum = 0.f;
-  for (int r = r0; r < r1; ++r) {
-    __syncthreads();
-    if (j < F) fs[j] = feat[(long)r * F + j];
-    const float d = j < h2 ? dc_ray[(long)r * h2 + j] : 0.f;
-    ds[j] = d;
-    __syncthreads();
-    bsum += d;
-#pragma unroll
-    for (int k = 0; k < RF_MAXF; ++k)
-      if (k < F) acc[k] = fmaf(fs[k], d, acc[k]);
-    if (j < app_dim) {            // gradient of this ray's appearance embedding row
-      float e = 0.f;
-      const float* wr = w2r + (long)(in_dir + j) * h2;
-      for (int q = 0; q < h2; ++q) e = fmaf(ds[q], wr[q], e);
-      d_emb_ray[(long)r * app_dim + j] = e;
-    }
-  }
-  if (j < h2) {
-    float* part = partial + (size_t)blockIdx.x * ((size_t)F * h2 + h2);
-#pragma unroll
-    for (int k = 0; k < RF_MAXF; ++k)
-      if (k < F) part[(long)k * h2 + j] = acc[k];
-    part[(long)F * h2 + j] = bsum;
-  }
-}
-
-// blocks [0, nb_w): g_w2r / g_b2 element e += sum over the nblk block partials (block order); blocks [nb_w, nb_w + n_emb): embedding row
-// a += the gradients of the rays with image index a, in ray order (thread t < app_dim owns one column).
-__global__ __launch_bounds__(256) void ray_feat_reduce_kernel(const float* __restrict__ partial, int nblk, int n_w, int n_wb,
-                                                              const float* __restrict__ d_emb_ray, const void* __restrict__ image_indices,
-                                                              int idx64, int n_rays, int app_dim, int nb_w, float* __restrict__ g_w2r,
-                                                              float* __restrict__ g_b2, float* __restrict__ g_emb) {
-  if ((int)blockIdx.x < nb_w) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n_wb) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * n_wb + e];
-    if (e < n_w) g_w2r[e] += s; else g_b2[e - n_w] += s;
-    return;
-  }
-  const int a = blockIdx.x - nb_w;
-  __shared__ int32_t hit[256];
-  float s = 0.f;
-  for (int r0 = 0; r0 < n_rays; r0 += 256) {
-    const int r = r0 + threadIdx.x;
-    long img = -1;
-    if (r < n_rays) img = idx64 ? (long)((const long long*)image_indices)[r] : (long)((const int32_t*)image_indices)[r];
-    __syncthreads();
-    hit[threadIdx.x] = (img == a) ? 1 : 0;
-    __syncthreads();
-    if ((int)threadIdx.x < app_dim) {
-      for (int q = 0; q < 256 && r0 + q < n_rays; ++q)
-        if (hit[q]) s += d_emb_ray[(long)(r0 + q) * app_dim + threadIdx.x];
-    }
-  }
-  if ((int)threadIdx.x < app_dim) g_emb[(long)a * app_dim + threadIdx.x] += s;
 }
 
 // The loss of the step in ONE block: photo = mean((rgb - target)^2), gate_loss = mean(l_aux_a) [or the mean of both means],
@@ -160,28 +88,6 @@ extern "C" int swn_ray_feat_fwd(const void* pe_dir, int dtype, int dir_stride, i
   else
     hipLaunchKernelGGL((ray_feat_fwd_kernel<float>), dim3(n_rays), dim3(128), 0, as_stream(stream), (const float*)pe_dir, dir_stride, in_dir, emb,
                        app_dim, image_indices, indices_are_int64, w2r, b2, n_rays, h2, feat, c_ray);
-  SWN_LAUNCH_CHECK();
-  return 0;
-}
-
-extern "C" size_t swn_ray_feat_bwd_workspace_floats(int n_rays, int h2, int in_dir, int app_dim) {
-  return (size_t)cdiv(n_rays, RF_RPB) * ((size_t)(in_dir + app_dim) * h2 + h2) + (size_t)n_rays * app_dim;
-}
-
-extern "C" int swn_ray_feat_bwd(const float* dc_ray, const float* feat, const float* w2r, const void* image_indices, int indices_are_int64,
-                                int n_rays, int h2, int in_dir, int app_dim, int n_emb_rows, float* g_w2r, float* g_b2, float* g_emb,
-                                float* workspace, void* stream) {
-  SWN_CHECK(dc_ray && feat && w2r && image_indices && g_w2r && g_b2 && g_emb && workspace, "swn_ray_feat_bwd: null pointer");
-  SWN_CHECK(n_rays > 0 && h2 > 0 && h2 <= 256 && in_dir + app_dim > 0 && in_dir + app_dim <= RF_MAXF && app_dim <= 256 && n_emb_rows > 0,
-            "swn_ray_feat_bwd: bad sizes (rays %d, h2 %d <= 256, features %d + %d <= %d)", n_rays, h2, in_dir, app_dim, RF_MAXF);
-  const int nblk = cdiv(n_rays, RF_RPB), F = in_dir + app_dim;
-  const int n_w = F * h2, n_wb = n_w + h2, nb_w = cdiv(n_wb, 256);
-  float* partial = workspace;
-  float* d_emb_ray = workspace + (size_t)nblk * n_wb;
-  hipLaunchKernelGGL(ray_feat_bwd_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), dc_ray, feat, w2r, n_rays, h2, in_dir, app_dim, partial,
-                     d_emb_ray);
-  hipLaunchKernelGGL(ray_feat_reduce_kernel, dim3(nb_w + n_emb_rows), dim3(256), 0, as_stream(stream), (const float*)partial, nblk, n_w, n_wb,
-                     (const float*)d_emb_ray, image_indices, indices_are_int64, n_rays, app_dim, nb_w, g_w2r, g_b2, g_emb);
   SWN_LAUNCH_CHECK();
   return 0;
 }

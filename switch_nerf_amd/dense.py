@@ -196,7 +196,9 @@ class DenseNeRF(SwitchNeRF):
         dh2, dsig = o.heads_bwd(c["y"], c["h2"], self.p["color.w"], c["raw"], d_raw, g["sigma.w"], g["sigma.b"], g["color.w"],
                                 g["color.b"])
         dc_ray = o.group_colsum(dh2, S)
-        o.ray_feat_bwd(dc_ray, c["ray_feat"], self.p["l2r.w"], c["image_indices"].contiguous(), self.in_dir, g["l2r.w"], g["l2.b"], g["emb"])
+        g["l2r.w"].addmm_(c["ray_feat"].t(), dc_ray)
+        g["l2.b"].add_(dc_ray.sum(0))
+        g["emb"].index_add_(0, c["image_indices"].long(), dc_ray @ self.p["l2r.w"][self.in_dir:].t())
         dh1 = _b("dh1", (P, W), dt)
         dy = _b("dy", (P, W), dt)
         o.mlp_chain(dh2, [o.Layer(self.wb["l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dy, tag=5)

@@ -636,8 +636,10 @@ class SwitchNeRF:
             dc_ray = torch.zeros(N, H2, dtype=torch.float32, device=self.dev).index_add_(0, ray_of_row, dh2.float())
         else:
             dc_ray = o.group_colsum(dh2, S)
-        # (one launch: swn_ray_feat_bwd - was addmm_ / sum / matmul / index_add_ in torch)
-        o.ray_feat_bwd(dc_ray, c["ray_feat"], self.p["l2r.w"], c["image_indices"].contiguous(), self.in_dir, g["l2r.w"], g["l2.b"], g["emb"])
+        g["l2r.w"].addmm_(c["ray_feat"].t(), dc_ray)
+        g["l2.b"].add_(dc_ray.sum(0))
+        d_feat_emb = dc_ray @ self.p["l2r.w"][self.in_dir:].t()
+        g["emb"].index_add_(0, c["image_indices"].long(), d_feat_emb)
         # tail backward chain: dh2 -> dh1 -> dy
         # ... with the combine backward (the sigma head's rank-1 term, the ReLU mask of y, the gate gradient, the gate scaling) applied
         # in the write-out of the last layer: dy itself never reaches memory

@@ -281,15 +281,6 @@ def ray_feat_fwd(pe_dir, in_dir: int, emb, image_indices, w2r, b2):
     return feat, c_ray
 
 
-def ray_feat_bwd(dc_ray, feat, w2r, image_indices, in_dir: int, g_w2r, g_b2, g_emb):
-    N, h2 = dc_ray.shape
-    ip, i64 = _idx_arg(image_indices)
-    app = feat.shape[1] - int(in_dir)
-    ws = torch.empty(int(_lib.load().swn_ray_feat_bwd_workspace_floats(N, h2, int(in_dir), app)), dtype=torch.float32, device=dc_ray.device)
-    call("swn_ray_feat_bwd", _p(dc_ray), _p(feat), _p(w2r), ip, i64, N, h2, int(in_dir), app, g_emb.shape[0], _p(g_w2r), _p(g_b2),
-         _p(g_emb), _p(ws), _stream())
-
-
 def step_loss(rgb, target, l_aux_a, l_aux_b, wt: float, loss_scale_dev=None):
     """-> (out4 = [photo, gate_loss, loss, psnr] on the device, d_rgb, d_l_aux_a, d_l_aux_b or None)."""
     dev = rgb.device

@@ -510,9 +510,9 @@ def test_wgrad_balanced_multi(dtype, shape):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
-def test_ray_feat_fwd_bwd_and_step_loss(dtype, idx_dtype):
+def test_ray_feat_fwd_and_step_loss(dtype, idx_dtype):
     """The per-ray launches of round 3 against the torch ops they replace: [PE(dir), emb[idx]] @ W2r + b2 (models/nerf_moe.py:419-429
-    folded per ray) forward and backward, and the loss / psnr / gradient seeds of the step (runner.py:1099-1111, 646-658) incl. the
+    folded per ray), and the loss / psnr / gradient seeds of the step (runner.py:1099-1111, 646-658) incl. the
     hierarchical gate-loss average and the fp16 loss scale."""
     o = ops()
     rng = np.random.default_rng(91)
@@ -527,13 +527,6 @@ def test_ray_feat_fwd_bwd_and_step_loss(dtype, idx_dtype):
     assert torch.equal(feat, feat_ref)
     ref = torch.addmm(b.double(), feat_ref.double(), w.double()).float()
     assert report(f"ray_feat_fwd_{dtype}", c_ray, ref) <= 2e-5
-    dc = torch.from_numpy(rng.standard_normal((N, H2)).astype(np.float32)).to(dev())
-    gw, gb, ge = torch.full_like(w, 0.5), torch.full_like(b, -1.0), torch.zeros_like(emb)
-    o.ray_feat_bwd(dc, feat, w, idx, in_dir, gw, gb, ge)
-    assert report(f"ray_feat_bwd_w_{dtype}", gw, 0.5 + (feat_ref.double().t() @ dc.double()).float()) <= 2e-4
-    assert report(f"ray_feat_bwd_b_{dtype}", gb, -1.0 + dc.double().sum(0).float()) <= 2e-4
-    ge_ref = torch.zeros_like(emb).double().index_add_(0, idx.long(), dc.double() @ w[in_dir:].double().t()).float()
-    assert report(f"ray_feat_bwd_emb_{dtype}", ge, ge_ref) <= 5e-4
     # the step's loss
     rgb = torch.rand(N, 3, device=dev())
     tgt = torch.rand(N, 3, device=dev())
