@@ -33,12 +33,17 @@ def test_graphed_train_step_equals_eager(dtype):
     ma.load_state_dict(synth.make_weights(41, synth.BUILDING))          # (the capture's warm-up steps did not touch the parameters,
     ma.m.zero_(); ma.v.zero_(); ma.step_count = 0                      #  but be explicit) - same start as the eager model
     ma.refresh_compute_copies()
-    for rays, img, rgbs in batches:
+    for it, (rays, img, rgbs) in enumerate(batches):
         ra = step(_dev(rgbs), _dev(rays), _dev(img))
         la, idx_a = float(ra["loss"].item()), ra["ctx"]["idx"].clone()
         rb = mb.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0)
         lb = float(rb["loss"].item())
-        assert torch.equal(idx_a, rb["ctx"]["idx"]), "routing"
+        mis = int((idx_a != rb["ctx"]["idx"]).sum().item())
+        # Steps 0 and 1 are the same computation bit for bit wherever it is deterministic.  The head / embedding / router parameter
+        # gradients are sums ordered by atomics: their last bits differ from run to run (two EAGER runs differ the same way,
+        # scripts/graph_flake_probe.py), Adam carries that into every parameter by the second step, and in bf16 a 1e-7 parameter
+        # difference moves ~1e3 activations across a rounding boundary - a handful of near-tie expert choices may flip at step 2.
+        assert mis == 0 if it < 2 else mis <= 64, (it, mis)
         assert abs(la - lb) <= 2e-5 * max(1.0, abs(lb)), (la, lb)
     tol = 2e-3 if dtype == torch.bfloat16 else 2e-5
     d = (ma.flat - mb.flat).abs().max().item() / mb.flat.abs().max().item()
@@ -72,7 +77,7 @@ def test_graphed_render_50_replays_equal_eager(variant):
 
 def test_graphed_train_50_replays_equal_eager():
     r = _probe("train", "--replays", "50", "--rays", "1024")
-    assert r["ok"] and r["routing_mismatches_first3"] == 0, r
+    assert r["ok"] and r["routing_mismatches_first2"] == 0, r
 
 
 def test_expert_chain_200_back_to_back_launches_bit_exact():
