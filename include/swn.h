@@ -157,9 +157,14 @@ int swn_combine_bwd(const void* dy_in, const void* y, const float* dsig, const f
 int swn_heads_fwd(const void* y, const void* h2, int dtype, const float* w_sigma, const float* b_sigma,
                   const float* w_color, const float* b_color, const float* sigma_noise, int n_points,
                   int model_dim, int h2_dim, float* raw, void* stream);
+/* Backward: dh2, dsig (per point) and the four parameter gradients ACCUMULATED (+=) into d_w_sigma[M], d_b_sigma[1], d_w_color[3,H2],
+ * d_b_color[3].  The parameter gradients are block partial sums in `workspace` (swn_heads_bwd_workspace_bytes) added in a fixed order:
+ * the same bits on every run.                                                                                       */
+size_t swn_heads_bwd_workspace_bytes(int n_points, int model_dim, int h2_dim);
 int swn_heads_bwd(const void* y, const void* h2, int dtype, const float* w_color, const float* raw,
                   const float* d_raw, int n_points, int model_dim, int h2_dim, void* dh2, float* dsig,
-                  float* d_w_sigma, float* d_b_sigma, float* d_w_color, float* d_b_color, void* stream);
+                  float* d_w_sigma, float* d_b_sigma, float* d_w_color, float* d_b_color, void* workspace,
+                  size_t workspace_bytes, void* stream);
 /* out[g][c] = sum_r in[g*rows_per_group + r][c]  (per-ray bias gradient) */
 int swn_group_colsum(const void* in, int dtype, int n_groups, int rows_per_group, int cols, float* out, void* stream);
 
@@ -422,6 +427,10 @@ int swn_ray_feat_fwd(const void* pe_dir, int dtype, int dir_stride, int in_dir, 
 int swn_step_loss(const float* rgb, const float* target, int n_values, const float* l_aux_a, int n_a, const float* l_aux_b, int n_b,
                   float l_aux_weight, const float* loss_scale_dev, float* d_rgb, float* d_l_aux_a, float* d_l_aux_b, float* out4,
                   void* stream);
+/* d_emb[n_images, app_dim] f32 += the rows d_feat[n] (n-th ray, leading dimension ld) of the rays with image_indices[n] == row, added in
+ * ascending ray order with a fixed association: nn.Embedding's backward (models/nerf_moe.py:215-222) with run-to-run identical bits. */
+int swn_emb_grad(const float* d_feat, int ld, const void* image_indices, int indices_are_int64, int n_rays, int app_dim,
+                 int n_images, float* d_emb, void* stream);
 
 /* ---- optimiser -------------------------------------------------------------------------------------------------
  * torch.optim.Adam (runner.py:486) over one flat fp32 parameter buffer; grad_scale multiplies the gradient

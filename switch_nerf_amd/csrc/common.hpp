@@ -107,4 +107,45 @@ static inline hipError_t fill_u32_async(void* p, uint32_t v, size_t bytes, hipSt
   return hipGetLastError();
 }
 
+// Ordered reduction of per-block partial sums: out[t] (+)= sum_b partial[b * n + t], the blocks in ascending order with a FIXED two-level
+// association (16 runs of consecutive blocks, then the 16 run sums) - the same bits on every run, unlike one atomic per block.  The n
+// values go to up to four destination arrays laid end to end (d.n[i] values each).  256 threads = 16 values x 16 runs.
+struct OrdDst { float* p[4]; int n[4]; };
+static __global__ __launch_bounds__(256) void ordered_reduce_kernel(const float* __restrict__ partial, int n_blocks, int n, OrdDst d,
+                                                                    int accumulate) {
+  __shared__ float red[16][17];
+  const int pl = threadIdx.x & 15, c = threadIdx.x >> 4;
+  const int t = blockIdx.x * 16 + pl;
+  const int bpc = (n_blocks + 15) / 16;
+  const int b0 = c * bpc, b1 = n_blocks < b0 + bpc ? n_blocks : b0 + bpc;
+  float s = 0.f;
+  if (t < n) {
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(b + u) * n + t];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < b1; ++b) s += partial[(size_t)b * n + t];
+  }
+  red[c][pl] = s;
+  __syncthreads();
+  if (c == 0 && t < n) {
+    float a = red[0][pl];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) a += red[k][pl];
+    int q = t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (q < d.n[i]) { float* o = d.p[i] + q; *o = accumulate ? *o + a : a; break; }
+      q -= d.n[i];
+    }
+  }
+}
+static inline void ordered_reduce_async(const float* partial, int n_blocks, int n, const OrdDst& d, bool accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(ordered_reduce_kernel, dim3(cdiv(n, 16)), dim3(256), 0, s, partial, n_blocks, n, d, accumulate ? 1 : 0);
+}
+
 }  // namespace swn

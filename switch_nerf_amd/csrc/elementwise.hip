@@ -459,30 +459,25 @@ __global__ __launch_bounds__(256) void gate_dwg_kernel(const T* __restrict__ g, 
     }
   }
   __syncthreads();
+  // the sub-groups add their sums one after the other (a fixed order: the result has the same bits on every run; LDS atomics would
+  // add them in arrival order)
+  for (int s = 0; s < SG; ++s) {
+    if (sg == s) {
 #pragma unroll
-  for (int e = 0; e < E; ++e)
+      for (int e = 0; e < E; ++e)
 #pragma unroll
-    for (int v = 0; v < VPT; ++v) atomicAdd(red + e * G + c0 + v, acc[e][v]);
-  if (lane == 0) {
+        for (int v = 0; v < VPT; ++v) red[e * G + c0 + v] += acc[e][v];
+      if (lane == 0) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) atomicAdd(red + E * G + e, dls[e]);
+        for (int e = 0; e < E; ++e) red[E * G + e] += dls[e];
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  // the block's partial [E x G] goes to the workspace with plain stores; gate_dwg_reduce_kernel sums the blocks (a thousand blocks
-  // x 2048 device-scope atomics onto the same 2048 words took longer than reading the operands)
+  // the block's partial [E x G] goes to the workspace with plain stores; ordered_reduce_kernel sums the blocks (a thousand blocks
+  // x 2048 device-scope atomics onto the same 2048 words took longer than reading the operands, and their order is not fixed)
   float* part = partial + (size_t)blockIdx.x * (E * G + E);
   for (int t = threadIdx.x; t < E * G + E; t += 256) part[t] = red[t];
-}
-
-// msum[t] += sum over the blocks of partial[b][t], t < eg = E * G + E (msum zeroed by the caller); grid = (eg / 256, chunks of blocks)
-__global__ __launch_bounds__(256) void gate_dwg_reduce_kernel(const float* __restrict__ partial, int n_blocks, int blocks_per_chunk, int eg,
-                                                              float* __restrict__ msum) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= eg) return;
-  const int b0 = blockIdx.y * blocks_per_chunk, b1 = min(n_blocks, b0 + blocks_per_chunk);
-  float s = 0.f;
-  for (int b = b0; b < b1; ++b) s += partial[(size_t)b * eg + t];
-  unsafeAtomicAdd(msum + t, s);
 }
 
 // the three parameter gradients from M = msum[0 .. E G) and DL = msum[E G .. E G + E): one block, thread = column
@@ -638,14 +633,12 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const T* __restrict__ y,
   }
 }
 
-// d_raw -> dh2 (masked by h2 > 0), dsig_pre; accumulates d_wc, d_bc, d_ws, d_bs.
+// d_raw -> dh2 (masked by h2 > 0), dsig_pre; the block's sums for d_ws, d_wc, d_bs, d_bc -> partial[block].
 template <typename T, int M, int H2>
 __global__ __launch_bounds__(256) void heads_bwd_kernel(const T* __restrict__ y, const T* __restrict__ h2,
                                                         const float* __restrict__ wc, const float* __restrict__ raw,
                                                         const float* __restrict__ d_raw, int P, T* __restrict__ dh2,
-                                                        float* __restrict__ dsig, float* __restrict__ d_ws,
-                                                        float* __restrict__ d_bs, float* __restrict__ d_wc,
-                                                        float* __restrict__ d_bc) {
+                                                        float* __restrict__ dsig, float* __restrict__ partial) {
   using RY = Row16<T, M>;
   using RH = Row16<T, H2>;
   const int j = threadIdx.x & 15;
@@ -682,31 +675,31 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const T* __restrict__ y,
     }
     RH::store(dh2 + i * H2, j, o);
   }
-  // block-level reduction in LDS, then one global atomic per parameter per block
+  // block-level reduction in LDS: the 16 row groups add their sums one after the other (fixed order); the block's partial goes to the
+  // workspace with plain stores and ordered_reduce_kernel adds the blocks in order - the same bits on every run (one atomic per
+  // parameter per block, as in rounds 1-2, made the head gradients differ in the last bits from run to run)
   __shared__ float red[M + 3 * H2 + 4];
   for (int t = threadIdx.x; t < M + 3 * H2 + 4; t += 256) red[t] = 0.f;
   __syncthreads();
+  for (int gq = 0; gq < 16; ++gq) {
+    if ((int)(threadIdx.x >> 4) == gq) {
 #pragma unroll
-  for (int v = 0; v < RY::VPL; ++v) atomicAdd(red + RY::col(j, v), aws[v]);
+      for (int v = 0; v < RY::VPL; ++v) red[RY::col(j, v)] += aws[v];
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
+      for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int v = 0; v < RH::VPL; ++v) atomicAdd(red + M + c * H2 + RH::col(j, v), awc[c][v]);
-  if (j == 0) {
-    atomicAdd(red + M + 3 * H2 + 0, abs_);
-    atomicAdd(red + M + 3 * H2 + 1, abc[0]);
-    atomicAdd(red + M + 3 * H2 + 2, abc[1]);
-    atomicAdd(red + M + 3 * H2 + 3, abc[2]);
+        for (int v = 0; v < RH::VPL; ++v) red[M + c * H2 + RH::col(j, v)] += awc[c][v];
+      if (j == 0) {
+        red[M + 3 * H2 + 0] += abs_;
+        red[M + 3 * H2 + 1] += abc[0];
+        red[M + 3 * H2 + 2] += abc[1];
+        red[M + 3 * H2 + 3] += abc[2];
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  for (int t = threadIdx.x; t < M; t += 256) unsafeAtomicAdd(d_ws + t, red[t]);
-  for (int t = threadIdx.x; t < 3 * H2; t += 256) unsafeAtomicAdd(d_wc + t, red[M + t]);
-  if (threadIdx.x == 0) {
-    unsafeAtomicAdd(d_bs, red[M + 3 * H2]);
-    unsafeAtomicAdd(d_bc + 0, red[M + 3 * H2 + 1]);
-    unsafeAtomicAdd(d_bc + 1, red[M + 3 * H2 + 2]);
-    unsafeAtomicAdd(d_bc + 2, red[M + 3 * H2 + 3]);
-  }
+  float* part = partial + (size_t)blockIdx.x * (M + 3 * H2 + 4);     // [M | 3 H2 | b_sigma | b_color(3)]
+  for (int t = threadIdx.x; t < M + 3 * H2 + 4; t += 256) part[t] = red[t];
 }
 
 // out[g][c] = sum over the group's rows of in[g*R + r][c]
@@ -1132,11 +1125,8 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
     DWG_DISPATCH(float, gp);
   }
   {
-    const int chunks = dwg_blocks < 16 ? dwg_blocks : 16, bpc = cdiv(dwg_blocks, chunks);
-    hipError_t me = fill_u32_async(msum, 0u, (size_t)ps * sizeof(float), as_stream(stream));
-    SWN_CHECK(me == hipSuccess, "swn_gate_bwd: memset: %s", hipGetErrorString(me));
-    hipLaunchKernelGGL(gate_dwg_reduce_kernel, dim3(cdiv(ps, 256), cdiv(dwg_blocks, bpc)), dim3(256), 0, as_stream(stream), dwg_partial,
-                       dwg_blocks, bpc, ps, msum);
+    OrdDst od{{msum, nullptr, nullptr, nullptr}, {ps, 0, 0, 0}};
+    ordered_reduce_async(dwg_partial, dwg_blocks, ps, od, false, as_stream(stream));
     hipLaunchKernelGGL(gate_dwg_finalize_kernel, dim3(1), dim3(gate_dim), 0, as_stream(stream), msum, n_experts, gate_dim, ln_w, ln_b, wg,
                        d_wg, d_ln_w, d_ln_b);
   }
@@ -1257,17 +1247,30 @@ extern "C" int swn_heads_fwd(const void* y, const void* h2, int dtype, const flo
   return 0;
 }
 
+static int heads_bwd_blocks(int n_points) {
+  const int blocks = row_blocks(n_points);
+  return blocks > 1024 ? 1024 : blocks;
+}
+
+extern "C" size_t swn_heads_bwd_workspace_bytes(int n_points, int model_dim, int h2_dim) {
+  return (size_t)heads_bwd_blocks(n_points) * (size_t)(model_dim + 3 * h2_dim + 4) * sizeof(float);
+}
+
 extern "C" int swn_heads_bwd(const void* y, const void* h2, int dtype, const float* w_color, const float* raw,
                              const float* d_raw, int n_points, int model_dim, int h2_dim, void* dh2, float* dsig,
-                             float* d_w_sigma, float* d_b_sigma, float* d_w_color, float* d_b_color, void* stream) {
+                             float* d_w_sigma, float* d_b_sigma, float* d_w_color, float* d_b_color, void* workspace,
+                             size_t workspace_bytes, void* stream) {
   SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_heads_bwd: bad dtype");
-  SWN_CHECK(y && h2 && w_color && raw && d_raw && dh2 && dsig && d_w_sigma && d_b_sigma && d_w_color && d_b_color,
+  SWN_CHECK(y && h2 && w_color && raw && d_raw && dh2 && dsig && d_w_sigma && d_b_sigma && d_w_color && d_b_color && workspace,
             "swn_heads_bwd: null pointer");
   SWN_CHECK((model_dim == 256 || model_dim == 512) && (h2_dim == 128 || h2_dim == 256), "swn_heads_bwd: model_dim in {256,512}, h2_dim in {128,256}");
-  int blocks = row_blocks(n_points);
-  if (blocks > 1024) blocks = 1024;
+  SWN_CHECK(workspace_bytes >= swn_heads_bwd_workspace_bytes(n_points, model_dim, h2_dim), "swn_heads_bwd: workspace of %zu bytes, need %zu",
+            workspace_bytes, swn_heads_bwd_workspace_bytes(n_points, model_dim, h2_dim));
+  if (n_points <= 0) return 0;
+  const int blocks = heads_bwd_blocks(n_points);
+  float* partial = (float*)workspace;
 #define SWN_HB(T, M_, H_) hipLaunchKernelGGL((heads_bwd_kernel<T, M_, H_>), dim3(blocks), dim3(256), 0, as_stream(stream), (const T*)y, \
-                                             (const T*)h2, w_color, raw, d_raw, n_points, (T*)dh2, dsig, d_w_sigma, d_b_sigma, d_w_color, d_b_color)
+                                             (const T*)h2, w_color, raw, d_raw, n_points, (T*)dh2, dsig, partial)
   if (dtype == SWN_HALF) {
     if (model_dim == 256 && h2_dim == 128) SWN_HB(bf16_t, 256, 128); else if (model_dim == 512 && h2_dim == 256) SWN_HB(bf16_t, 512, 256);
     else if (model_dim == 256) SWN_HB(bf16_t, 256, 256); else SWN_HB(bf16_t, 512, 128);
@@ -1276,6 +1279,8 @@ extern "C" int swn_heads_bwd(const void* y, const void* h2, int dtype, const flo
     else if (model_dim == 256) SWN_HB(float, 256, 256); else SWN_HB(float, 512, 128);
   }
 #undef SWN_HB
+  OrdDst od{{d_w_sigma, d_w_color, d_b_sigma, d_b_color}, {model_dim, 3 * h2_dim, 1, 3}};
+  ordered_reduce_async(partial, blocks, model_dim + 3 * h2_dim + 4, od, true, as_stream(stream));
   SWN_LAUNCH_CHECK();
   return 0;
 }

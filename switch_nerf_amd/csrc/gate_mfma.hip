@@ -433,18 +433,28 @@ __global__ __launch_bounds__(256, 2) void gate_bwd_mfma_kernel(const bf16_t* __r
     float* red = (float*)smem;                        // [16][256] + c[8] + dl[8]
     for (int i = tid; i < 16 * 256 + 16; i += 256) red[i] = 0.f;
     __syncthreads();
-#pragma unroll
-    for (int nt = 0; nt < 16; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(red + (4 * kg + r) * 256 + 16 * nt + n16, macc[nt][r]);
+    float cs[4], dls[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float a = cacc[j], b = dlacc[j];
 #pragma unroll
       for (int o = 16; o >= 1; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-      if (l31 == 0) { atomicAdd(red + 16 * 256 + 4 * lhi + j, a); atomicAdd(red + 16 * 256 + 8 + 4 * lhi + j, b); }
+      cs[j] = a; dls[j] = b;
     }
-    __syncthreads();
+    // the four waves add their sums one after the other: a fixed order, the same bits on every run (a wave's lanes own distinct words)
+    for (int wq = 0; wq < 4; ++wq) {
+      if (w == wq) {
+#pragma unroll
+        for (int nt = 0; nt < 16; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[(4 * kg + r) * 256 + 16 * nt + n16] += macc[nt][r];
+        if (l31 == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { red[16 * 256 + 4 * lhi + j] += cs[j]; red[16 * 256 + 8 + 4 * lhi + j] += dls[j]; }
+        }
+      }
+      __syncthreads();
+    }
     float* part = partial + (size_t)blockIdx.x * (E * 256 + E);
     for (int i = tid; i < E * 256; i += 256) {
       const int e = i >> 8, k = i & 255;

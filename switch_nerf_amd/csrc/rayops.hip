@@ -71,6 +71,58 @@ __global__ __launch_bounds__(1024) void step_loss_kernel(const float* __restrict
   }
 }
 
+// d_emb[a][:] += sum over the rays n with image_indices[n] == a, in ascending n, of d_feat[n][:]   (the appearance embedding's gradient,
+// nn.Embedding's backward: models/nerf_moe.py:215-222).  One block per embedding row: the block walks the ray indices in tiles of 1024,
+// compacts the matching rays IN ORDER (wave scan of the per-thread match counts), and sums their rows with a fixed association
+// (256 / app_dim interleaved partial sums per column, added in order) - the same bits on every run; an index_add with atomics adds in
+// arrival order.  A training batch holds a few rays per image, so almost all the time is the scan of the (L2-resident) index array.
+template <typename IT>
+__global__ __launch_bounds__(256) void emb_grad_kernel(const float* __restrict__ d_feat, int ld, const IT* __restrict__ idx, int n_rays,
+                                                       int app_dim, float* __restrict__ d_emb) {
+  __shared__ int list[1024];
+  __shared__ int wcnt[4];
+  __shared__ float red[256];
+  const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nsub = 256 / app_dim, sub = tid / app_dim, col = tid - sub * app_dim;
+  float tot = 0.f;
+  for (int base = 0; base < n_rays; base += 1024) {
+    bool m[4];
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = base + 4 * tid + u;
+      m[u] = n < n_rays && (long)idx[n < n_rays ? n : 0] == (long)a;
+      cnt += m[u] ? 1 : 0;
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) wcnt[w] = incl;
+    __syncthreads();
+    int off = incl - cnt;
+    for (int q = 0; q < w; ++q) off += wcnt[q];
+    const int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (m[u]) list[off++] = base + 4 * tid + u;
+    __syncthreads();
+    if (total) {                                            // (the same for every thread)
+      float s = 0.f;
+      if (sub < nsub)
+        for (int k = sub; k < total; k += nsub) s += d_feat[(size_t)list[k] * ld + col];
+      red[tid] = s;
+      __syncthreads();
+      if (tid < app_dim)
+        for (int q = 0; q < nsub; ++q) tot += red[q * app_dim + tid];
+    }
+    __syncthreads();
+  }
+  if (tid < app_dim) d_emb[(size_t)a * app_dim + tid] += tot;
+}
+
 }  // namespace swn
 
 using namespace swn;
@@ -99,6 +151,22 @@ extern "C" int swn_step_loss(const float* rgb, const float* target, int n_values
   SWN_CHECK(n_values > 0 && n_a > 0 && n_b >= 0 && (n_b == 0 || (l_aux_b && d_l_aux_b)), "swn_step_loss: bad sizes");
   hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1024), 0, as_stream(stream), rgb, target, n_values, l_aux_a, n_a, l_aux_b, n_b,
                      l_aux_weight, loss_scale_dev, d_rgb, d_l_aux_a, d_l_aux_b, out4);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int swn_emb_grad(const float* d_feat, int ld, const void* image_indices, int indices_are_int64, int n_rays, int app_dim,
+                            int n_images, float* d_emb, void* stream) {
+  SWN_CHECK(d_feat && image_indices && d_emb, "swn_emb_grad: null pointer");
+  SWN_CHECK(n_rays >= 0 && n_images > 0 && app_dim > 0 && app_dim <= 256 && ld >= app_dim, "swn_emb_grad: bad sizes (rays %d, images %d, width %d)",
+            n_rays, n_images, app_dim);
+  if (n_rays == 0) return 0;
+  if (indices_are_int64)
+    hipLaunchKernelGGL((emb_grad_kernel<int64_t>), dim3(n_images), dim3(256), 0, as_stream(stream), d_feat, ld, (const int64_t*)image_indices,
+                       n_rays, app_dim, d_emb);
+  else
+    hipLaunchKernelGGL((emb_grad_kernel<int32_t>), dim3(n_images), dim3(256), 0, as_stream(stream), d_feat, ld, (const int32_t*)image_indices,
+                       n_rays, app_dim, d_emb);
   SWN_LAUNCH_CHECK();
   return 0;
 }

@@ -198,7 +198,7 @@ class DenseNeRF(SwitchNeRF):
         dc_ray = o.group_colsum(dh2, S)
         g["l2r.w"].addmm_(c["ray_feat"].t(), dc_ray)
         g["l2.b"].add_(dc_ray.sum(0))
-        g["emb"].index_add_(0, c["image_indices"].long(), dc_ray @ self.p["l2r.w"][self.in_dir:].t())
+        o.emb_grad(dc_ray @ self.p["l2r.w"][self.in_dir:].t(), c["image_indices"].contiguous(), g["emb"])
         dh1 = _b("dh1", (P, W), dt)
         dy = _b("dy", (P, W), dt)
         o.mlp_chain(dh2, [o.Layer(self.wb["l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dy, tag=5)

@@ -639,7 +639,7 @@ class SwitchNeRF:
         g["l2r.w"].addmm_(c["ray_feat"].t(), dc_ray)
         g["l2.b"].add_(dc_ray.sum(0))
         d_feat_emb = dc_ray @ self.p["l2r.w"][self.in_dir:].t()
-        g["emb"].index_add_(0, c["image_indices"].long(), d_feat_emb)
+        o.emb_grad(d_feat_emb, c["image_indices"].contiguous(), g["emb"])        # (rays added in order: torch's index_add_ uses atomics)
         # tail backward chain: dh2 -> dh1 -> dy
         # ... with the combine backward (the sigma head's rank-1 term, the ReLU mask of y, the gate gradient, the gate scaling) applied
         # in the write-out of the last layer: dy itself never reaches memory

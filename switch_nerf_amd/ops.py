@@ -252,8 +252,10 @@ def heads_bwd(y, h2, w_color, raw, d_raw, d_w_sigma, d_b_sigma, d_w_color, d_b_c
     H2 = h2.shape[1]
     dh2 = torch.empty_like(h2)
     dsig = torch.empty(P, dtype=torch.float32, device=y.device)
+    nb = int(_lib.load().swn_heads_bwd_workspace_bytes(int(P), int(M), int(H2)))
+    ws = torch.empty(max(nb, 4) // 4, dtype=torch.float32, device=y.device)     # block partial sums (added in a fixed order)
     call("swn_heads_bwd", _p(y), _p(h2), _dt(y), _p(w_color), _p(raw), _p(d_raw), P, M, H2, _p(dh2), _p(dsig), _p(d_w_sigma),
-         _p(d_b_sigma), _p(d_w_color), _p(d_b_color), _stream())
+         _p(d_b_sigma), _p(d_w_color), _p(d_b_color), _p(ws), nb, _stream())
     return dh2, dsig
 
 
@@ -279,6 +281,13 @@ def ray_feat_fwd(pe_dir, in_dir: int, emb, image_indices, w2r, b2):
     call("swn_ray_feat_fwd", _p(pe_dir), _dt(pe_dir), pe_dir.shape[1], int(in_dir), _p(emb), app, ip, i64, _p(w2r), _p(b2), N, h2,
          _p(feat), _p(c_ray), _stream())
     return feat, c_ray
+
+
+def emb_grad(d_feat, image_indices, d_emb):
+    """d_emb[image_indices[n]] += d_feat[n], rays in ascending order with a fixed association (deterministic nn.Embedding backward)."""
+    assert d_feat.dtype == torch.float32 and d_emb.dtype == torch.float32 and d_feat.stride(1) == 1 and d_emb.is_contiguous()
+    ip, i64 = _idx_arg(image_indices)
+    call("swn_emb_grad", _p(d_feat), d_feat.stride(0), ip, i64, d_feat.shape[0], d_feat.shape[1], d_emb.shape[0], _p(d_emb), _stream())
 
 
 def step_loss(rgb, target, l_aux_a, l_aux_b, wt: float, loss_scale_dev=None):

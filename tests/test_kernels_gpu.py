@@ -545,6 +545,33 @@ def test_ray_feat_fwd_and_step_loss(dtype, idx_dtype):
         assert (d_b is None) == (not use_b) and (d_b is None or torch.allclose(d_b, torch.full_like(lb, 5e-4 * 0.5 / 3 * s_), rtol=1e-6))
 
 
+@pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
+@pytest.mark.parametrize("shape", [(8192, 48, 1940, 1940), (3000, 48, 7, 3), (1, 16, 5, 5), (5000, 256, 4, 1)])
+def test_emb_grad_is_an_ordered_index_add(shape, idx_dtype):
+    """swn_emb_grad (nn.Embedding's backward, models/nerf_moe.py:215-222): equals index_add_ in float64 to fp32 rounding, accumulates into
+    the existing gradient, leaves rows without rays untouched, and gives the same bits on every launch (rays are added in ascending order
+    with a fixed association; shapes: a training batch, a few images with thousands of rays each, one ray, ALL rays on one image)."""
+    o = ops()
+    N, app, A, used = shape
+    rng = np.random.default_rng(92)
+    d_feat = torch.from_numpy(rng.standard_normal((N, app)).astype(np.float32)).to(dev())
+    idx = torch.from_numpy(rng.integers(0, used, N)).to(dev()).to(idx_dtype)
+    base = torch.from_numpy(rng.standard_normal((A, app)).astype(np.float32)).to(dev())
+    outs = []
+    for _ in range(3):
+        g = base.clone()
+        o.emb_grad(d_feat, idx, g)
+        outs.append(g)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    ref = base.double().index_add_(0, idx.long(), d_feat.double())
+    err = (outs[0].double() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"emb_grad {shape}: max rel err {err:.2e}")
+    assert err <= 2e-6
+    hit = torch.zeros(A, dtype=torch.bool, device=dev())
+    hit[idx.long()] = True
+    assert torch.equal(outs[0][~hit], base[~hit])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_heads_and_combine_bwd(dtype):
     rng = np.random.default_rng(61)
@@ -577,6 +604,14 @@ def test_heads_and_combine_bwd(dtype):
     assert report(f"heads_dbs_{dtype}", dbs, bsr.grad) <= 1e-3
     assert report(f"heads_dwc_{dtype}", dwc, wcr.grad) <= 1e-3
     assert report(f"heads_dbc_{dtype}", dbc, bcr.grad) <= 1e-3
+    # the parameter gradients ACCUMULATE, and every launch gives the same bits (block partial sums added in a fixed order)
+    first = [t.clone() for t in (dws, dbs, dwc, dbc)]
+    for _ in range(3):
+        acc = [torch.zeros_like(t) for t in first]
+        o.heads_bwd(yd, h2d, wc.to(dev()), raw, d_raw.to(dev()), *acc)
+        assert all(torch.equal(a, f) for a, f in zip(acc, first))
+    o.heads_bwd(yd, h2d, wc.to(dev()), raw, d_raw.to(dev()), dws, dbs, dwc, dbc)
+    assert all(torch.allclose(t, 2 * f, rtol=1e-6, atol=0) for t, f in zip((dws, dbs, dwc, dbc), first))
     # combine backward: y = relu(g * o); given dy_in and the sigma head's rank-1 term
     gate = torch.from_numpy(rng.uniform(0.125, 1, P).astype(np.float32)).requires_grad_(True)
     oo = torch.from_numpy(rng.standard_normal((P, M)).astype(np.float32))
