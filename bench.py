@@ -361,6 +361,34 @@ def main():
                          "activations through HBM between the layers, no saves)", rows_per_expert=rows, ms=round(ms_, 4), tflops=round(tf, 1),
                     mfma_frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4))
 
+    def gemm_yardsticks(kept_):
+        """What the matrix pipe and the library deliver on THIS box (clocks under load are 1.3-1.9 GHz, the 2.5 PFLOP/s peak is quoted at
+        2.4 GHz): (a) one large square bf16 GEMM - the practical ceiling of any MFMA kernel here; (b) ONE layer of the expert MLP as a
+        plain [rows, 256] x [256, 256] GEMM over all kept rows - what a layer-by-layer (unfused) grouped GEMM is bounded by: it reads
+        and writes every activation through HBM."""
+        def timed(fn, n=5):
+            fn(); fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n
+        n = 8192
+        a_, b_ = torch.randn(n, n, device=dev).to(torch.bfloat16), torch.randn(n, n, device=dev).to(torch.bfloat16)
+        ms_sq = timed(lambda: torch.matmul(a_, b_))
+        tf_sq = 2.0 * n * n * n / (ms_sq * 1e-3) / 1e12
+        del a_, b_
+        rows = int(kept_) // 256 * 256
+        x_, w_ = torch.randn(rows, M, device=dev).to(torch.bfloat16), (torch.randn(M, M, device=dev) / 16).to(torch.bfloat16)
+        ms_l = timed(lambda: torch.matmul(x_, w_))
+        tf_l = 2.0 * rows * M * M / (ms_l * 1e-3) / 1e12
+        return dict(square_gemm_8192=dict(ms=round(ms_sq, 4), tflops=round(tf_sq, 1), mfma_frac=round(tf_sq / MFMA_BF16_PEAK_TFLOPS, 4)),
+                    one_layer_gemm=dict(rows=rows, ms=round(ms_l, 4), tflops=round(tf_l, 1), mfma_frac=round(tf_l / MFMA_BF16_PEAK_TFLOPS, 4),
+                                        gbs=round(rows * M * 2 * 2 / (ms_l * 1e-3) / 1e9, 1)))
+
     def account(events, kept_):
         """Expert kernels against both rooflines.  flops: 2 L M^2 per KEPT row for each of forward, backward-data and weight
         gradients.  Algorithmic HBM bytes per launch: fwd reads x, writes L-1 activations +
@@ -416,6 +444,10 @@ def main():
             detail["reference_style_library_gemms"] = library_yardstick(kept_mean)
         except Exception as e:      # informational only
             detail["reference_style_library_gemms"] = dict(error=str(e))
+        try:
+            detail["library_gemm_yardsticks"] = gemm_yardsticks(kept_mean)
+        except Exception as e:
+            detail["library_gemm_yardsticks"] = dict(error=str(e))
     loss_main = float(st["loss"].item())
 
     # ---- the same measurement with perfectly balanced routing (GEMM work follows the kept tokens; the random-init

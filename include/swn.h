@@ -322,6 +322,18 @@ typedef struct swn_chain_desc {
   const float* comb_wsig;
   const float* comb_gate;
   float* comb_dgate;
+  /* Sigma / colour heads fused into the tail FORWARD chain (heads_raw != NULL; tag must be 4, geometry 0 / 1): with y = the staged
+     chain input row (gathered, gate-scaled, ReLU'd: what x_save would hold) and h2 = the last layer's output row,
+       heads_raw[row] = (sigmoid(<h2, heads_wc[c]> + heads_bc[c]) c < 3, softplus(<y, heads_ws> + heads_bs[0] + heads_noise[row] - 1))
+     i.e. swn_heads_fwd (models/nerf_moe.py:393-441) without reading y and h2 back from memory.  heads_ws fp32 [k0], heads_wc fp32
+     [3][n_last], heads_noise fp32 per row or NULL; chain input of 256 / 512 features, last layer of 128 / 256.  With the heads fused
+     `y` (and x_save) may be NULL: an inference forward then writes nothing but raw.                                             */
+  const float* heads_ws;
+  const float* heads_bs;
+  const float* heads_wc;
+  const float* heads_bc;
+  const float* heads_noise;
+  float* heads_raw;
   swn_chain_layer layers[SWN_MAX_CHAIN_LAYERS];
 } swn_chain_desc;
 

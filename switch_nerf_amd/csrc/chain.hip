@@ -515,6 +515,31 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
     load_rows_to_lds<T>(act, d.x, d.x_gather, d.x_save, grow0, rows_in_tile, d.layers[0].k, tid, d.x_scale, d.x_relu);
   __syncthreads();
 
+  // ---- fused sigma / colour heads (tail forward chain only: include/swn.h, heads_raw) ----
+  // The sigma head reads the chain INPUT row y (the decoded, gate-scaled, ReLU'd expert output): its dot product is taken from the
+  // staged tile now and parked in LDS until the colour head's turn after the last layer.  Neither y nor h2 is read back from memory
+  // (swn_heads_fwd: 768 B per point at 256 / 128 features).  Lane = row (BM = 64), wave = a quarter of the columns: the weights are
+  // wave-uniform (scalar loads), no cross-lane reduction - the four quarter sums of a row meet in LDS.  (A first version with a
+  // shuffle reduction per row cost the chain as much as the separate heads launch had: these 64-row chains are latency chains.)
+  float* heads_part = (float*)(smem + Cfg<T>::ACT + ROW_ELEMS * 4);       // [16][64]: sigma quarters 0..3, colour c quarters 4 + 4 c ..
+  if constexpr (TAG == 4 && BM == 64) {
+    if (d.heads_raw) {
+      constexpr int EPC = 16 / (int)sizeof(T);
+      const int cq = d.layers[0].k / EPC / 4;                // chunks per quarter row
+      const float* wq = d.heads_ws + wn * cq * EPC;
+      int ln = lane;
+      asm volatile("" : "+v"(ln));                           // (own copy of the lane index: nothing of this block stays live across the layers)
+      float sg = 0.f;
+      for (int c = 0; c < cq; ++c) {
+        float yv[EPC];
+        chunk_to_f32<T>(load_chunk_from_act<T>(act, ln, wn * cq + c), yv);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) sg += yv[e] * wq[c * EPC + e];
+      }
+      heads_part[wn * 64 + ln] = sg;
+    }
+  }
+
   f32x16_t acc[MI][NI];
 #if SWN_TIMING_ON
   long long tk = 0, tb1 = 0, tep = 0, tb2 = 0, two = 0, tstart = __builtin_amdgcn_s_memtime();
@@ -644,6 +669,44 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
     asm volatile("" : "+v"(tidw));     // same reason: keep the write-out index math inside the loop
     const bool last = (L == d.n_layers - 1);
     void* outp = last ? d.y : ly.save;
+    if constexpr (TAG == 4 && BM == 64) {
+      if (last && d.heads_raw) {      // colour head from the h2 tile, sigma from the parked quarter sums -> raw[row] = (rgb, sigma)
+        constexpr int EPC = 16 / (int)sizeof(T);
+        const int cq = n / EPC / 4;
+        const float* w0 = d.heads_wc + wn * cq * EPC;
+        const int lane = tidw & 63;                          // (from the laundered thread index: see above)
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        for (int c = 0; c < cq; ++c) {
+          float hv[EPC];
+          chunk_to_f32<T>(load_chunk_from_act<T>(act, lane, wn * cq + c), hv);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            c0 += hv[e] * w0[c * EPC + e];
+            c1 += hv[e] * w0[n + c * EPC + e];
+            c2 += hv[e] * w0[2 * n + c * EPC + e];
+          }
+        }
+        heads_part[(4 + wn) * 64 + lane] = c0;
+        heads_part[(8 + wn) * 64 + lane] = c1;
+        heads_part[(12 + wn) * 64 + lane] = c2;
+        __syncthreads();
+        if (wn == 0 && lane < rows_in_tile) {
+          float v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            v[q] = (heads_part[(4 * q) * 64 + lane] + heads_part[(4 * q + 1) * 64 + lane]) +
+                   (heads_part[(4 * q + 2) * 64 + lane] + heads_part[(4 * q + 3) * 64 + lane]);
+          const long gr = grow0 + lane;
+          const float u = v[0] + d.heads_bs[0] + (d.heads_noise ? d.heads_noise[gr] : 0.f) - 1.f;   // ShiftedSoftplus, models/nerf.py:68-69
+          float4 o;
+          o.x = 1.f / (1.f + expf(-(v[1] + d.heads_bc[0])));
+          o.y = 1.f / (1.f + expf(-(v[2] + d.heads_bc[1])));
+          o.z = 1.f / (1.f + expf(-(v[3] + d.heads_bc[2])));
+          o.w = u > 20.f ? u : log1pf(expf(u));
+          *(float4*)(d.heads_raw + gr * 4) = o;
+        }
+      }
+    }
     if (outp) {
       const int row_bytes = n * (int)sizeof(T);
       const int cpr = row_bytes >> 4;
@@ -828,7 +891,7 @@ static int chain_launch(const swn_chain_desc& d, void* stream) {
   if (d.n_groups == 1 && a.tiles_per_group >= 64) grid = 8L * ((a.tiles_per_group + 7) >> 3);      // (see the tile mapping in the kernel)
 #endif
   SWN_CHECK(grid > 0 && grid < (1L << 31), "swn_mlp_chain: grid %ld out of range", grid);
-  int lds = (d.dtype == SWN_HALF ? Cfg<bf16_t>::ACT : Cfg<float>::ACT) + ROW_ELEMS * 4;
+  int lds = (d.dtype == SWN_HALF ? Cfg<bf16_t>::ACT : Cfg<float>::ACT) + ROW_ELEMS * 4 + 4096;     // tile, bias row, the fused heads' quarter sums
 #ifdef SWN_EXP_LDSPAD
   lds += SWN_EXP_LDSPAD;      // experiment: fewer resident workgroups per CU (scripts/chain_timing.py)
 #endif
@@ -949,7 +1012,15 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
     SWN_CHECK(ly.relu >= 0 && ly.relu <= 2, "swn_mlp_chain: relu mode %d", ly.relu);
     if (ly.relu == 2) SWN_CHECK(ly.mask != nullptr, "swn_mlp_chain: relu=2 (apply stored mask) needs a mask");
   }
-  SWN_CHECK(d.x != nullptr && d.y != nullptr, "swn_mlp_chain: x / y must not be null");
+  SWN_CHECK(d.x != nullptr && (d.y != nullptr || d.heads_raw != nullptr), "swn_mlp_chain: x / y must not be null");
+  if (d.heads_raw) {
+    const int nl = d.layers[d.n_layers - 1].n, k0 = d.layers[0].k;
+    SWN_CHECK(d.heads_ws && d.heads_bs && d.heads_wc && d.heads_bc, "swn_mlp_chain: fused heads need heads_ws / heads_bs / heads_wc / heads_bc");
+    SWN_CHECK(d.geometry < 2 && d.tag == 4, "swn_mlp_chain: the fused heads run on the 64-row kernels (geometry 0 / 1), tag 4");
+    SWN_CHECK((nl == 128 || nl == 256) && (k0 == 256 || k0 == 512) && k0 * (d.dtype == SWN_F32 ? 4 : 2) <= 1024,
+              "swn_mlp_chain: fused heads: chain input of 256 / 512 features in rows of at most 1 KiB, last layer of 128 / 256 (k0=%d, n=%d)", k0, nl);
+    for (int l = 0; l < d.n_layers; ++l) SWN_CHECK(d.layers[l].skip != 2, "swn_mlp_chain: fused heads: no concat-skip layers");
+  }
   SWN_CHECK(d.tag >= 0 && d.tag <= 6, "swn_mlp_chain: tag %d not in [0,6]", d.tag);
   SWN_CHECK(!(wide && concat), "swn_mlp_chain: concat-skip layers are built for the 256-feature kernels only");
   SWN_CHECK(d.geometry >= 0 && d.geometry <= 5, "swn_mlp_chain: geometry %d not in [0,5]", d.geometry);

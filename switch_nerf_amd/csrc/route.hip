@@ -44,29 +44,35 @@ __global__ __launch_bounds__(256) void route_keys_kernel(const int32_t* __restri
   }
 }
 
+// One LSD pass sorts by the BITS-bit digit (key >> shift) & (2^BITS - 1).  BITS = 8: four passes over the 32-bit key (the default).
+// The key only has 26 + ceil(log2 E) significant bits, so for E <= 16 three passes of <= 10 bits would do - an experiment that lost
+// (see swn_route_top1).
+template <int BITS>
 __global__ __launch_bounds__(256) void route_hist_kernel(const uint32_t* __restrict__ keys, int seg_tokens, int shift,
                                                          int nblk, int32_t* __restrict__ hist) {
-  __shared__ int32_t h[256];
+  constexpr int BINS = 1 << BITS;
+  __shared__ int32_t h[BINS];
   const int seg = blockIdx.y, blk = blockIdx.x;
-  h[threadIdx.x] = 0;
+  for (int d = threadIdx.x; d < BINS; d += 256) h[d] = 0;
   __syncthreads();
   const uint32_t* k = keys + (long)seg * seg_tokens;
   for (int j = 0; j < KPB / 256; ++j) {
     const int p = blk * KPB + j * 256 + threadIdx.x;
-    if (p < seg_tokens) atomicAdd(&h[(k[p] >> shift) & 255], 1);
+    if (p < seg_tokens) atomicAdd(&h[(k[p] >> shift) & (BINS - 1)], 1);
   }
   __syncthreads();
-  hist[((long)seg * 256 + threadIdx.x) * nblk + blk] = h[threadIdx.x];
+  for (int d = threadIdx.x; d < BINS; d += 256) hist[((long)seg * BINS + d) * nblk + blk] = h[d];
 }
 
-// exclusive scan of hist[seg][d][blk] in (d, blk) order; one block per segment, thread d owns row d.
+// exclusive scan of hist[seg][d][blk] in (d, blk) order; one block of 2^BITS threads per segment, thread d owns row d.
 // NB > 0: the row (nblk <= NB counters) is held in registers - all its loads are in flight together; the serial form (NB = 0) pays
 // one memory round trip per counter, twice (25 us for 64 counters whatever the batch size).
-template <int NB>
-__global__ __launch_bounds__(256) void route_scan_kernel(int32_t* __restrict__ hist, int nblk) {
-  __shared__ int32_t rowsum[256];
+template <int BITS, int NB>
+__global__ __launch_bounds__(1 << BITS) void route_scan_kernel(int32_t* __restrict__ hist, int nblk) {
+  constexpr int BINS = 1 << BITS, NW = BINS / 64;
+  __shared__ int32_t rowsum[NW];
   const int seg = blockIdx.x, d = threadIdx.x;
-  int32_t* row = hist + ((long)seg * 256 + d) * nblk;
+  int32_t* row = hist + ((long)seg * BINS + d) * nblk;
   int32_t s = 0;
   int32_t c[NB > 0 ? NB : 1];
   if constexpr (NB > 0) {
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(256) void route_scan_kernel(int32_t* __restrict__ h
   } else {
     for (int b = 0; b < nblk; ++b) s += row[b];
   }
-  // exclusive scan over the 256 row sums: inclusive scan inside each wave (shuffles, no barrier), then the totals of the waves before
+  // exclusive scan over the row sums: inclusive scan inside each wave (shuffles, no barrier), then the totals of the waves before
   // (the Hillis-Steele form over LDS paid 16 workgroup barriers: 17 us per pass for 64 counters)
   int32_t v = s;
 #pragma unroll
@@ -104,10 +110,11 @@ __global__ __launch_bounds__(256) void route_scan_kernel(int32_t* __restrict__ h
   }
 }
 
+template <int BITS>
 __device__ __forceinline__ unsigned long long match_digit(int d, bool valid) {
   unsigned long long m = __ballot(valid);
 #pragma unroll
-  for (int b = 0; b < 8; ++b) {
+  for (int b = 0; b < BITS; ++b) {
     const bool bit = (d >> b) & 1;
     const unsigned long long bal = __ballot(bit);
     m &= bit ? bal : ~bal;
@@ -115,30 +122,31 @@ __device__ __forceinline__ unsigned long long match_digit(int d, bool valid) {
   return valid ? m : 0ull;
 }
 
+template <int BITS>
 __global__ __launch_bounds__(256) void route_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                             const int32_t* __restrict__ vals_in, int seg_tokens, int shift,
                                                             int nblk, const int32_t* __restrict__ hist,
                                                             uint32_t* __restrict__ keys_out, int32_t* __restrict__ vals_out) {
-  __shared__ int32_t wh[4][256];
+  constexpr int BINS = 1 << BITS;
+  __shared__ int32_t wh[4][BINS];
   const int seg = blockIdx.y, blk = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long sbase = (long)seg * seg_tokens;
-  for (int j = threadIdx.x; j < 1024; j += 256) (&wh[0][0])[j] = 0;
+  for (int j = threadIdx.x; j < 4 * BINS; j += 256) (&wh[0][0])[j] = 0;
   __syncthreads();
   const int p0 = blk * KPB + w * (KPB / 4);
   // phase 1: per-wave digit counts
   for (int r = 0; r < KPB / 4 / 64; ++r) {
     const int p = p0 + r * 64 + lane;
     const bool valid = p < seg_tokens;
-    const int d = valid ? (int)((keys_in[sbase + p] >> shift) & 255) : 0;
-    const unsigned long long m = match_digit(d, valid);
+    const int d = valid ? (int)((keys_in[sbase + p] >> shift) & (BINS - 1)) : 0;
+    const unsigned long long m = match_digit<BITS>(d, valid);
     if (valid && lane == __ffsll((long long)m) - 1) wh[w][d] += __popcll(m);
   }
   __syncthreads();
   // phase 2: per-wave bases
-  {
-    const int d = threadIdx.x;
-    int32_t base = hist[((long)seg * 256 + d) * nblk + blk];
+  for (int d = threadIdx.x; d < BINS; d += 256) {
+    int32_t base = hist[((long)seg * BINS + d) * nblk + blk];
 #pragma unroll
     for (int ww = 0; ww < 4; ++ww) {
       const int32_t c = wh[ww][d];
@@ -154,8 +162,8 @@ __global__ __launch_bounds__(256) void route_scatter_kernel(const uint32_t* __re
     uint32_t key = 0;
     int32_t val = 0;
     if (valid) { key = keys_in[sbase + p]; val = vals_in[sbase + p]; }
-    const int d = (int)((key >> shift) & 255);
-    const unsigned long long m = match_digit(d, valid);
+    const int d = (int)((key >> shift) & (BINS - 1));
+    const unsigned long long m = match_digit<BITS>(d, valid);
     if (valid) {
       const int rank = __popcll(m & ((1ull << lane) - 1ull));
       const int32_t pos = wh[w][d] + rank;
@@ -166,6 +174,16 @@ __global__ __launch_bounds__(256) void route_scatter_kernel(const uint32_t* __re
     if (valid && lane == __ffsll((long long)m) - 1) wh[w][d] += __popcll(m);
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+template <int BITS>
+static void route_pass(const uint32_t* ki, const int32_t* vi, uint32_t* ko, int32_t* vo, int seg_tokens, int n_seg, int nblk, int shift,
+                       int32_t* hist, hipStream_t s) {
+  hipLaunchKernelGGL((route_hist_kernel<BITS>), dim3(nblk, n_seg), dim3(256), 0, s, ki, seg_tokens, shift, nblk, hist);
+  if (nblk <= 16) hipLaunchKernelGGL((route_scan_kernel<BITS, 16>), dim3(n_seg), dim3(1 << BITS), 0, s, hist, nblk);
+  else if (nblk <= 64) hipLaunchKernelGGL((route_scan_kernel<BITS, 64>), dim3(n_seg), dim3(1 << BITS), 0, s, hist, nblk);
+  else hipLaunchKernelGGL((route_scan_kernel<BITS, 0>), dim3(n_seg), dim3(1 << BITS), 0, s, hist, nblk);
+  hipLaunchKernelGGL((route_scatter_kernel<BITS>), dim3(nblk, n_seg), dim3(256), 0, s, ki, vi, seg_tokens, shift, nblk, hist, ko, vo);
 }
 
 __global__ void route_finalize_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ vals,
@@ -275,7 +293,7 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" size_t swn_route_workspace_bytes(int n_tokens, int n_seg, int n_experts) {
   const int seg_tokens = n_seg > 0 ? (n_tokens + n_seg - 1) / n_seg : n_tokens;
   const int nblk = (seg_tokens + KPB - 1) / KPB;
-  return 4 * align256((size_t)n_tokens * 4) + align256((size_t)n_seg * 256 * nblk * 4) +
+  return 4 * align256((size_t)n_tokens * 4) + align256((size_t)n_seg * 1024 * nblk * 4) +
          align256((size_t)n_seg * nblk * n_experts * 4) + 1024;
 }
 
@@ -297,7 +315,7 @@ extern "C" int swn_route_top1(const int32_t* idx, const float* gmax, const float
   int32_t* v0 = (int32_t*)(ws + 2 * tb);
   int32_t* v1 = (int32_t*)(ws + 3 * tb);
   int32_t* hist = (int32_t*)(ws + 4 * tb);
-  float* partial = (float*)(ws + 4 * tb + align256((size_t)n_seg * 256 * nblk * 4));
+  float* partial = (float*)(ws + 4 * tb + align256((size_t)n_seg * 1024 * nblk * 4));
   hipStream_t s = as_stream(stream);
   // counts = 0, perm = -1: fill KERNELS (common.hpp: memset nodes of a captured graph go wrong from the second replay on).
   // SWN_ROUTE_HIP_MEMSET=1 restores the hipMemsetAsync calls of rounds 1-2 (scripts/graph_probe.py demonstrates the fault with it).
@@ -315,13 +333,29 @@ extern "C" int swn_route_top1(const int32_t* idx, const float* gmax, const float
   SWN_LAUNCH_CHECK();
   uint32_t *ki = k0, *ko = k1;
   int32_t *vi = v0, *vo = v1;
-  for (int shift = bpr ? 0 : 24; shift < 32; shift += 8) {
-    hipLaunchKernelGGL(route_hist_kernel, dim3(nblk, n_seg), dim3(256), 0, s, ki, seg_tokens, shift, nblk, hist);
-    if (nblk <= 16) hipLaunchKernelGGL(route_scan_kernel<16>, dim3(n_seg), dim3(256), 0, s, hist, nblk);
-    else if (nblk <= 64) hipLaunchKernelGGL(route_scan_kernel<64>, dim3(n_seg), dim3(256), 0, s, hist, nblk);
-    else hipLaunchKernelGGL(route_scan_kernel<0>, dim3(n_seg), dim3(256), 0, s, hist, nblk);
-    hipLaunchKernelGGL(route_scatter_kernel, dim3(nblk, n_seg), dim3(256), 0, s, ki, vi, seg_tokens, shift, nblk, hist, ko, vo);
+  // pass plan: the key has 26 + ceil(log2 E) significant bits (without BPR only the expert bits differ: one pass)
+  int ebits = 0;
+  while ((1 << ebits) < n_experts) ++ebits;
+  // Default: four 8-bit passes.  SWN_ROUTE_3PASS=1: three passes of 9 / 10 bits for E <= 16 - measured SLOWER (15.20 vs 14.98 ms per
+  // step, 2.49 vs 2.41 ms at 1024 rays: with 2048 keys per block a 1024-bin histogram per block is as much traffic as the keys, the scan
+  // kernel has four times the rows, and the per-wave match takes 10 ballots) - kept for the record (profiles/r03_experiments.md).
+  static const bool three_pass = getenv("SWN_ROUTE_3PASS") != nullptr;
+  int widths[4] = {8, 8, 8, 8}, n_pass = 4, shift = 0;
+  if (!bpr) { n_pass = 1; shift = 24; }
+  else if (26 + ebits <= 30 && three_pass) {
+    const int tot = 26 + ebits;                 // 27 .. 30 bits in three passes of 9 or 10 bits
+    n_pass = 3;
+    widths[0] = (tot + 2) / 3; widths[1] = (tot + 1) / 3; widths[2] = tot / 3;
+    for (int q = 0; q < 3; ++q) if (widths[q] < 8) widths[q] = 8;
+  }
+  for (int q = 0; q < n_pass; ++q) {
+    switch (widths[q]) {
+      case 8: route_pass<8>(ki, vi, ko, vo, seg_tokens, n_seg, nblk, shift, hist, s); break;
+      case 9: route_pass<9>(ki, vi, ko, vo, seg_tokens, n_seg, nblk, shift, hist, s); break;
+      default: route_pass<10>(ki, vi, ko, vo, seg_tokens, n_seg, nblk, shift, hist, s); break;
+    }
     SWN_LAUNCH_CHECK();
+    shift += widths[q];
     uint32_t* tk = ki; ki = ko; ko = tk;
     int32_t* tv = vi; vi = vo; vo = tv;
   }

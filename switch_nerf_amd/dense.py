@@ -174,12 +174,17 @@ class DenseNeRF(SwitchNeRF):
         c["y"] = c["acts"][L - 1]
         # ---- per-ray part of dir_a_encoding: [PE(dir), appearance embedding] @ W2r + b2 (nerf.py:173-181)
         c["ray_feat"], c["c_ray"] = o.ray_feat_fwd(pe_dir, self.in_dir, self.p["emb"], image_indices.contiguous(), self.p["l2r.w"], self.p["l2.b"])
-        c["h1"] = _b("h1", (P, W), dt)
-        c["h2"] = _b("h2", (P, H2), dt)
+        from .model import _FUSED_HEADS, c_esz
+        fused = _FUSED_HEADS and W in (256, 512) and H2 in (128, 256) and W * c_esz(dt) <= 1024      # heads inside the tail chain's launch (swn.h: heads_raw)
+        c["h1"] = _b("h1", (P, W), dt) if sv else None
+        c["h2"] = _b("h2", (P, H2), dt) if (sv or not fused) else None      # an inference forward writes nothing but raw
+        c["raw"] = torch.empty(P, 4, dtype=torch.float32, device=self.dev) if fused else None
         o.mlp_chain(c["y"], [o.Layer(self.wf["l1"], self.p["l1.b"].view(1, W), save=c["h1"] if sv else None),
-                             o.Layer(self.wf["l2h"], None, relu=1, rowbias=c["c_ray"], rows_per_bias=S)], c["h2"], tag=4)
-        c["raw"] = o.heads_fwd(c["y"], c["h2"], self.p["sigma.w"], self.p["sigma.b"], self.p["color.w"], self.p["color.b"],
-                               sigma_noise)
+                             o.Layer(self.wf["l2h"], None, relu=1, rowbias=c["c_ray"], rows_per_bias=S)], c["h2"], tag=4, group_stride=P,
+                    heads=(self.p["sigma.w"], self.p["sigma.b"], self.p["color.w"], self.p["color.b"], sigma_noise, c["raw"]) if fused else None)
+        if not fused:
+            c["raw"] = o.heads_fwd(c["y"], c["h2"], self.p["sigma.w"], self.p["sigma.b"], self.p["color.w"], self.p["color.b"],
+                                   sigma_noise)
         c["l_aux"] = torch.zeros(c["n_seg"], dtype=torch.float32, device=self.dev)     # no gate loss (runner.py:1104 guards on use_moe)
         c["idx"] = None
         return c

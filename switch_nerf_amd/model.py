@@ -39,6 +39,12 @@ def _ceil_to(x, m):
     return (x + m - 1) // m * m
 
 
+_FUSED_HEADS = os.environ.get("SWN_NO_FUSED_HEADS") is None      # sigma / colour heads inside the tail forward chain (swn.h: heads_raw)
+
+
+def c_esz(dtype) -> int:
+    return 4 if dtype == torch.float32 else 2
+
 class LossScaler:
     """torch.cuda.amp.GradScaler's contract (the reference trains fp16 with it: runner.py:483 `GradScaler(enabled=hparams.amp)`,
     :679 `scaler.scale(loss).backward()`, scaler.step / update): the loss gradient is multiplied by `scale`, the optimizer step
@@ -587,19 +593,25 @@ class SwitchNeRF:
         c["ray_feat"], c["c_ray"] = o.ray_feat_fwd(pe_dir, self.in_dir, self.p["emb"], image_indices.contiguous(), self.p["l2r.w"], self.p["l2.b"])
         # ---- tail chain.  Its input load IS the combine: rows gathered from the expert output through tok2row, scaled by
         # the gate value, ReLU'd (dropped tokens -> zero rows) and saved as y;  then layer "1" -> layer "2" (+ per-ray bias)
-        c["y"] = _b("y", (P, M), dt)
-        c["h1"] = _b("h1", (P, M), dt)
-        c["h2"] = _b("h2", (P, H2), dt)
+        # The sigma / colour heads run inside that launch (swn.h: heads_raw): sigma from the staged y tile, colour from the h2 tile.  A
+        # training forward still writes y, h1 and h2 (the backward reads them); an inference forward writes nothing but raw.
+        fused = _FUSED_HEADS and M in (256, 512) and H2 in (128, 256) and M * c_esz(dt) <= 1024      # (rows of at most 1 KiB)
+        keep = sv or not fused
+        c["y"] = _b("y", (P, M), dt) if keep else None
+        c["h1"] = _b("h1", (P, M), dt) if sv else None
+        c["h2"] = _b("h2", (P, H2), dt) if keep else None
+        c["raw"] = torch.empty(P, 4, dtype=torch.float32, device=dev) if fused else None
         rowbias, rpb = c["c_ray"], S
         if row_range is not None:  # a row range of the point grid: the rows' rays through an explicit per-row gather
             rowbias, rpb = c["c_ray"].index_select(0, torch.arange(r0, r1, device=dev) // S), 1
             c["ragged"], c["row0"] = True, r0
         o.mlp_chain(c["eo"], [o.Layer(self.wf["l1"], self.p["l1.b"].view(1, M), save=c["h1"] if sv else None),
                               o.Layer(self.wf["l2h"], None, relu=1, rowbias=rowbias, rows_per_bias=rpb)], c["h2"],
-                    group_stride=P, x_gather=c["row_of_tok"], x_save=c["y"], x_scale=c["gmax"], x_relu=True, tag=4)
-        # ---- heads
-        c["raw"] = o.heads_fwd(c["y"], c["h2"], self.p["sigma.w"], self.p["sigma.b"], self.p["color.w"], self.p["color.b"],
-                               sigma_noise)
+                    group_stride=P, x_gather=c["row_of_tok"], x_save=c["y"], x_scale=c["gmax"], x_relu=True, tag=4,
+                    heads=(self.p["sigma.w"], self.p["sigma.b"], self.p["color.w"], self.p["color.b"], sigma_noise, c["raw"]) if fused else None)
+        if not fused:      # ---- heads as their own launch (SWN_NO_FUSED_HEADS=1: rounds 1-2)
+            c["raw"] = o.heads_fwd(c["y"], c["h2"], self.p["sigma.w"], self.p["sigma.b"], self.p["color.w"], self.p["color.b"],
+                                   sigma_noise)
         return c
 
     # ------------------------------------------------------------------------------------------ backward

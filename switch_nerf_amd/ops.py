@@ -477,17 +477,18 @@ def chain_mask_words(dtype, n_groups: int, group_stride: int, max_width: int = 2
 
 def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride=None, group_rows=None,
               group_rows_clamp=None, x_gather=None, x_save=None, y_add=None, y_add_gather=None, tag=0, x_scale=None,
-              x_relu=False, geometry=0, group_begin=None, combine=None):
+              x_relu=False, geometry=0, group_begin=None, combine=None, heads=None):
     """geometry: 0 / 1 the 64-row tile kernels, 2 - 5 the chain_big.hip geometries (include/swn.h).  group_begin: first row of every
     group (packed / no-batch layout) instead of g * group_stride.  combine = (y_fwd, dsig, wsig, gate, dgate_out): the combine backward
-    (ops.combine_bwd) fused into the write-out of the last layer."""
+    (ops.combine_bwd) fused into the write-out of the last layer.  heads = (w_sigma, b_sigma, w_color, b_color, sigma_noise or None, raw):
+    the sigma / colour heads (ops.heads_fwd) fused into the tail forward chain (tag 4) - y may then be None (nothing but raw is written)."""
     d = ChainDesc()
     d.dtype = _dt(x)
     d.tag = int(tag)
     d.geometry = int(geometry)
     d.n_layers = len(layers)
     d.n_groups, d.n_wsets = int(n_groups), int(n_wsets)
-    d.group_stride = int(group_stride if group_stride is not None else y.shape[0])
+    d.group_stride = int(group_stride if group_stride is not None else (y if y is not None else heads[5]).shape[0])
     d.group_rows = _p(group_rows)
     d.group_rows_clamp = int(group_rows_clamp if group_rows_clamp is not None else d.group_stride)
     d.group_begin = _p(group_begin)
@@ -498,6 +499,11 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
         cy, cds, cws, cg, cdg = combine
         assert cy.dtype == x.dtype and cy.shape == y.shape and cg.dtype == torch.float32 and cdg.dtype == torch.float32
         d.comb_y, d.comb_dsig, d.comb_wsig, d.comb_gate, d.comb_dgate = _p(cy), _p(cds), _p(cws), _p(cg), _p(cdg)
+    if heads is not None:
+        hws, hbs, hwc, hbc, hnoise, hraw = heads
+        assert all(t.dtype == torch.float32 and t.is_contiguous() for t in (hws, hbs, hwc, hbc, hraw)) and hraw.shape[1] == 4
+        assert hnoise is None or (hnoise.dtype == torch.float32 and hnoise.is_contiguous())
+        d.heads_ws, d.heads_bs, d.heads_wc, d.heads_bc, d.heads_noise, d.heads_raw = _p(hws), _p(hbs), _p(hwc), _p(hbc), _p(hnoise), _p(hraw)
     for i, ly in enumerate(layers):
         L = d.layers[i]
         assert ly.w.dtype == x.dtype and hasattr(ly.w, "swn_nk"), "weights must come from ops.pack_weights (compute dtype)"

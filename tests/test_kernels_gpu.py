@@ -890,3 +890,50 @@ def test_chain_fused_combine_backward(dtype):
         o.mlp_chain(dh2, [o.Layer(w2, None), o.Layer(w1, None)], d2, tag=5, combine=(y, None, None, gate, g2))
         r2, rg2 = o.combine_bwd(dy, y, None, None, gate)
         assert torch.equal(d2, r2) and (g2 - rg2).abs().max().item() <= 1e-5 * rg2.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("widths", [(256, 128), (512, 256)])
+def test_chain_fused_heads_forward(dtype, widths):
+    """The sigma / colour heads inside the tail forward chain (swn.h: heads_raw) against the chain followed by swn_heads_fwd: the same
+    raw (rgb, sigma) to summation order, with gathered / gate-scaled / ReLU'd input rows (dropped tokens = zero rows), sigma noise,
+    a row count that is not a multiple of the tile; saves (y, h1, h2) unchanged bit for bit; and the inference form (no y, no saves:
+    nothing but raw is written) gives the same raw."""
+    o = ops()
+    g = torch.Generator().manual_seed(6)
+    M, H2 = widths
+    if dtype == torch.float32 and M == 512:
+        pytest.skip("fused heads take rows of at most 1 KiB (the caller falls back to swn_heads_fwd)")
+    P, R, S = 4992 + 37, 6000, 1
+    eo = torch.randn(R, M, generator=g).to(dev()).to(dtype)
+    t2r = torch.randint(0, R, (P,), generator=g).int()
+    t2r[::9] = -1
+    t2r = t2r.to(dev())
+    gate = (torch.rand(P, generator=g) * 0.8 + 0.1).to(dev())
+    w1 = o.pack_weights((torch.randn(1, M, M, generator=g) / 16).to(dev()), dtype, True)
+    w2 = o.pack_weights((torch.randn(1, M, H2, generator=g) / 16).to(dev()), dtype, True)
+    b1 = (torch.randn(1, M, generator=g) * 0.1).to(dev())
+    rowb = (torch.randn(P, H2, generator=g) * 0.1).to(dev())
+    ws, bs = (torch.randn(M, generator=g) / 16).to(dev()), torch.randn(1, generator=g).to(dev())
+    wc, bc = (torch.randn(3, H2, generator=g) / 8).to(dev()), torch.randn(3, generator=g).to(dev())
+    noise = torch.randn(P, generator=g).to(dev())
+
+    def run(heads, keep=True):
+        y = torch.zeros(P, M, dtype=dtype, device=dev()) if keep else None
+        h1 = torch.zeros(P, M, dtype=dtype, device=dev()) if keep else None
+        h2 = torch.zeros(P, H2, dtype=dtype, device=dev()) if keep else None
+        o.mlp_chain(eo, [o.Layer(w1, b1, save=h1), o.Layer(w2, None, relu=1, rowbias=rowb, rows_per_bias=1)], h2, group_stride=P,
+                    x_gather=t2r, x_save=y, x_scale=gate, x_relu=True, tag=4, heads=heads)
+        return y, h1, h2
+    for nz in (noise, None):
+        y, h1, h2 = run(None)
+        ref = o.heads_fwd(y, h2, ws, bs, wc, bc, nz)
+        raw = torch.full((P, 4), -7.0, device=dev())
+        y2, h12, h22 = run((ws, bs, wc, bc, nz, raw))
+        assert torch.equal(y, y2) and torch.equal(h1, h12) and torch.equal(h2, h22)
+        err = (raw - ref).abs().max().item()
+        print(f"fused heads {dtype} {widths} noise={nz is not None}: max abs diff {err:.2e}")
+        assert err <= 2e-5
+        raw3 = torch.full((P, 4), -7.0, device=dev())
+        run((ws, bs, wc, bc, nz, raw3), keep=False)
+        assert torch.equal(raw3, raw)
