@@ -424,6 +424,31 @@ __device__ __forceinline__ void epilogue_body(f32x16_t (&acc)[Cfg<T>::MI][NI], c
     }
   }
 }
+// Fused heads (chain_kernel, TAG 4): acc[s] += <tile row `row`, chunks [chunk0, chunk0 + NC)> . w[s * wstride + ...] for NSETS weight
+// rows.  The weights are wave-uniform: all their scalar loads are issued together, ahead of the LDS reads (one s_load per loop
+// iteration, as the first version had it, is a ~300-clock round trip each: +0.26 ms on the tail forward chain).
+template <typename T, int NC, int NSETS>
+__device__ __forceinline__ void heads_dot(const char* act, int row, int chunk0, const float* __restrict__ w, int wstride, float (&acc)[NSETS]) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  float wv[NSETS][NC * EPC];
+#pragma unroll
+  for (int s_ = 0; s_ < NSETS; ++s_)
+#pragma unroll
+    for (int i = 0; i < NC * EPC; ++i) wv[s_][i] = w[s_ * wstride + i];
+  uint4 raw[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) raw[c] = load_chunk_from_act<T>(act, row, chunk0 + c);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    float v[EPC];
+    chunk_to_f32<T>(raw[c], v);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e)
+#pragma unroll
+      for (int s_ = 0; s_ < NSETS; ++s_) acc[s_] += v[e] * wv[s_][c * EPC + e];
+  }
+}
+
 template <typename T, int TAG>
 __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -529,14 +554,10 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
       const float* wq = d.heads_ws + wn * cq * EPC;
       int ln = lane;
       asm volatile("" : "+v"(ln));                           // (own copy of the lane index: nothing of this block stays live across the layers)
-      float sg = 0.f;
-      for (int c = 0; c < cq; ++c) {
-        float yv[EPC];
-        chunk_to_f32<T>(load_chunk_from_act<T>(act, ln, wn * cq + c), yv);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) sg += yv[e] * wq[c * EPC + e];
-      }
-      heads_part[wn * 64 + ln] = sg;
+      float sg[1] = {0.f};
+      constexpr int NCS = 64 / EPC;                          // chunks per call: 64 weights in scalar registers
+      for (int c = 0; c < cq; c += NCS) heads_dot<T, NCS, 1>(act, ln, wn * cq + c, wq + c * EPC, 0, sg);
+      heads_part[wn * 64 + ln] = sg[0];
     }
   }
 
@@ -675,20 +696,12 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
         const int cq = n / EPC / 4;
         const float* w0 = d.heads_wc + wn * cq * EPC;
         const int lane = tidw & 63;                          // (from the laundered thread index: see above)
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-        for (int c = 0; c < cq; ++c) {
-          float hv[EPC];
-          chunk_to_f32<T>(load_chunk_from_act<T>(act, lane, wn * cq + c), hv);
-#pragma unroll
-          for (int e = 0; e < EPC; ++e) {
-            c0 += hv[e] * w0[c * EPC + e];
-            c1 += hv[e] * w0[n + c * EPC + e];
-            c2 += hv[e] * w0[2 * n + c * EPC + e];
-          }
-        }
-        heads_part[(4 + wn) * 64 + lane] = c0;
-        heads_part[(8 + wn) * 64 + lane] = c1;
-        heads_part[(12 + wn) * 64 + lane] = c2;
+        float cc[3] = {0.f, 0.f, 0.f};
+        constexpr int NCC = 16 / EPC;                        // 3 x 16 weights in scalar registers per call
+        for (int c = 0; c < cq; c += NCC) heads_dot<T, NCC, 3>(act, lane, wn * cq + c, w0 + c * EPC, n, cc);
+        heads_part[(4 + wn) * 64 + lane] = cc[0];
+        heads_part[(8 + wn) * 64 + lane] = cc[1];
+        heads_part[(12 + wn) * 64 + lane] = cc[2];
         __syncthreads();
         if (wn == 0 && lane < rows_in_tile) {
           float v[4];
