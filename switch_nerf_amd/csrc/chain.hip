@@ -690,36 +690,6 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
     asm volatile("" : "+v"(tidw));     // same reason: keep the write-out index math inside the loop
     const bool last = (L == d.n_layers - 1);
     void* outp = last ? d.y : ly.save;
-    if constexpr (TAG == 4 && BM == 64) {
-      if (last && d.heads_raw) {      // colour head from the h2 tile, sigma from the parked quarter sums -> raw[row] = (rgb, sigma)
-        constexpr int EPC = 16 / (int)sizeof(T);
-        const int cq = n / EPC / 4;
-        const float* w0 = d.heads_wc + wn * cq * EPC;
-        const int lane = tidw & 63;                          // (from the laundered thread index: see above)
-        float cc[3] = {0.f, 0.f, 0.f};
-        constexpr int NCC = 16 / EPC;                        // 3 x 16 weights in scalar registers per call
-        for (int c = 0; c < cq; c += NCC) heads_dot<T, NCC, 3>(act, lane, wn * cq + c, w0 + c * EPC, n, cc);
-        heads_part[(4 + wn) * 64 + lane] = cc[0];
-        heads_part[(8 + wn) * 64 + lane] = cc[1];
-        heads_part[(12 + wn) * 64 + lane] = cc[2];
-        __syncthreads();
-        if (wn == 0 && lane < rows_in_tile) {
-          float v[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            v[q] = (heads_part[(4 * q) * 64 + lane] + heads_part[(4 * q + 1) * 64 + lane]) +
-                   (heads_part[(4 * q + 2) * 64 + lane] + heads_part[(4 * q + 3) * 64 + lane]);
-          const long gr = grow0 + lane;
-          const float u = v[0] + d.heads_bs[0] + (d.heads_noise ? d.heads_noise[gr] : 0.f) - 1.f;   // ShiftedSoftplus, models/nerf.py:68-69
-          float4 o;
-          o.x = 1.f / (1.f + expf(-(v[1] + d.heads_bc[0])));
-          o.y = 1.f / (1.f + expf(-(v[2] + d.heads_bc[1])));
-          o.z = 1.f / (1.f + expf(-(v[3] + d.heads_bc[2])));
-          o.w = u > 20.f ? u : log1pf(expf(u));
-          *(float4*)(d.heads_raw + gr * 4) = o;
-        }
-      }
-    }
     if (outp) {
       const int row_bytes = n * (int)sizeof(T);
       const int cpr = row_bytes >> 4;
@@ -815,6 +785,42 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
 #if SWN_TIMING_ON
     two += TICK() - q4;
 #endif
+  }
+  // ---- fused heads, second half (after the layer loop: the tile holds the last layer's output h2; kept out of the loop body, where its
+  //      kernel-argument loads were hoisted and cost 9 more spilled registers - 0.4 GB of scratch traffic per launch; the barrier
+  //      behind the last epilogue already ordered the tile) ----
+  if constexpr (TAG == 4 && BM == 64) {
+    if (d.heads_raw) {      // colour head from the h2 tile, sigma from the parked quarter sums -> raw[row] = (rgb, sigma)
+      constexpr int EPC = 16 / (int)sizeof(T);
+      const int n = d.layers[d.n_layers - 1].n;
+      const int cq = n / EPC / 4;
+      const float* w0 = d.heads_wc + wn * cq * EPC;
+      int lane_ = tid & 63;
+      asm volatile("" : "+v"(lane_));                      // (own copy of the lane index)
+      const int lane = lane_;
+      float cc[3] = {0.f, 0.f, 0.f};
+      constexpr int NCC = 16 / EPC;                        // 3 x 16 weights in scalar registers per call
+      for (int c = 0; c < cq; c += NCC) heads_dot<T, NCC, 3>(act, lane, wn * cq + c, w0 + c * EPC, n, cc);
+      heads_part[(4 + wn) * 64 + lane] = cc[0];
+      heads_part[(8 + wn) * 64 + lane] = cc[1];
+      heads_part[(12 + wn) * 64 + lane] = cc[2];
+      __syncthreads();
+      if (wn == 0 && lane < rows_in_tile) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          v[q] = (heads_part[(4 * q) * 64 + lane] + heads_part[(4 * q + 1) * 64 + lane]) +
+                 (heads_part[(4 * q + 2) * 64 + lane] + heads_part[(4 * q + 3) * 64 + lane]);
+        const long gr = grow0 + lane;
+        const float u = v[0] + d.heads_bs[0] + (d.heads_noise ? d.heads_noise[gr] : 0.f) - 1.f;   // ShiftedSoftplus, models/nerf.py:68-69
+        float4 o;
+        o.x = 1.f / (1.f + expf(-(v[1] + d.heads_bc[0])));
+        o.y = 1.f / (1.f + expf(-(v[2] + d.heads_bc[1])));
+        o.z = 1.f / (1.f + expf(-(v[3] + d.heads_bc[2])));
+        o.w = u > 20.f ? u : log1pf(expf(u));
+        *(float4*)(d.heads_raw + gr * 4) = o;
+      }
+    }
   }
 #if SWN_TIMING_ON
   if (d.y_add_gather && tid == 0 && blockIdx.x < 4096) {

@@ -85,40 +85,47 @@ __global__ __launch_bounds__(256) void emb_grad_kernel(const float* __restrict__
   const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int nsub = 256 / app_dim, sub = tid / app_dim, col = tid - sub * app_dim;
   float tot = 0.f;
-  for (int base = 0; base < n_rays; base += 1024) {
-    bool m[4];
-    int cnt = 0;
+  for (int sbase = 0; sbase < n_rays; sbase += 8192) {      // the index loads of 8 tiles are in flight together (one L2 round trip)
+    uint32_t mbits = 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int n = base + 4 * tid + u;
-      m[u] = n < n_rays && (long)idx[n < n_rays ? n : 0] == (long)a;
-      cnt += m[u] ? 1 : 0;
-    }
-    int incl = cnt;
+    for (int t8 = 0; t8 < 8; ++t8)
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(incl, o);
-      if (lane >= o) incl += v;
-    }
-    if (lane == 63) wcnt[w] = incl;
-    __syncthreads();
-    int off = incl - cnt;
-    for (int q = 0; q < w; ++q) off += wcnt[q];
-    const int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+      for (int u = 0; u < 4; ++u) {
+        const int n = sbase + t8 * 1024 + 4 * tid + u;
+        const bool hit = n < n_rays && (long)idx[n < n_rays ? n : 0] == (long)a;
+        mbits |= (hit ? 1u : 0u) << (t8 * 4 + u);
+      }
+    for (int t8 = 0; t8 < 8; ++t8) {
+      const int base = sbase + t8 * 1024;
+      if (base >= n_rays) break;
+      const uint32_t m4 = (mbits >> (t8 * 4)) & 15u;
+      const int cnt = __popc(m4);
+      int incl = cnt;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (m[u]) list[off++] = base + 4 * tid + u;
-    __syncthreads();
-    if (total) {                                            // (the same for every thread)
-      float s = 0.f;
-      if (sub < nsub)
-        for (int k = sub; k < total; k += nsub) s += d_feat[(size_t)list[k] * ld + col];
-      red[tid] = s;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+      }
+      if (lane == 63) wcnt[w] = incl;
       __syncthreads();
-      if (tid < app_dim)
-        for (int q = 0; q < nsub; ++q) tot += red[q * app_dim + tid];
+      int off = incl - cnt;
+      for (int q = 0; q < w; ++q) off += wcnt[q];
+      const int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if ((m4 >> u) & 1u) list[off++] = base + 4 * tid + u;
+      __syncthreads();
+      if (total) {                                            // (the same for every thread)
+        float s = 0.f;
+        if (sub < nsub)
+          for (int k = sub; k < total; k += nsub) s += d_feat[(size_t)list[k] * ld + col];
+        red[tid] = s;
+        __syncthreads();
+        if (tid < app_dim)
+          for (int q = 0; q < nsub; ++q) tot += red[q * app_dim + tid];
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   if (tid < app_dim) d_emb[(size_t)a * app_dim + tid] += tot;
 }
