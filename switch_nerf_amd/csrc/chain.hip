@@ -690,52 +690,13 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
     asm volatile("" : "+v"(tidw));     // same reason: keep the write-out index math inside the loop
     const bool last = (L == d.n_layers - 1);
     void* outp = last ? d.y : ly.save;
+    if (TAG == 5 && last && d.comb_y) outp = nullptr;       // the fused combine backward writes the last layer out behind the loop
     if (outp) {
       const int row_bytes = n * (int)sizeof(T);
       const int cpr = row_bytes >> 4;
       const int sh = 31 - __builtin_clz(cpr);
       const int total = rows_in_tile * cpr;
-      if (TAG == 5 && last && d.comb_y) {     // (only the tail-backward instantiation carries this code: registers)
-        // Combine backward on the way out (include/swn.h).  A row's cpr chunks sit in cpr consecutive lanes (NT is a multiple of cpr:
-        // a thread keeps its chunk column).  The global operands of UB chunks are fetched together, ahead of the arithmetic.
-        constexpr int EPC = 16 / (int)sizeof(T), UB = 8;
-        const int ch = tidw & (cpr - 1);
-        float wv[EPC];
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) wv[e] = d.comb_wsig ? d.comb_wsig[ch * EPC + e] : 0.f;
-        for (int c0 = tidw; c0 < total; c0 += UB * NT) {
-          uint4 yc[UB];
-          float gt[UB], ds[UB];
-#pragma unroll
-          for (int u = 0; u < UB; ++u) {
-            const int c = c0 + u * NT;
-            const long gr = grow0 + ((c < total ? c : c0) >> sh);
-            yc[u] = *(const uint4*)((const char*)d.comb_y + gr * row_bytes + ch * 16);
-            gt[u] = d.comb_gate[gr];
-            ds[u] = d.comb_dsig ? d.comb_dsig[gr] : 0.f;
-          }
-#pragma unroll
-          for (int u = 0; u < UB; ++u) {
-            const int c = c0 + u * NT;
-            if (c < total) {
-              const int row = c >> sh;
-              float z[EPC], yv[EPC], dot = 0.f;
-              chunk_to_f32<T>(load_chunk_from_act<T>(act, row, ch), z);
-              chunk_to_f32<T>(yc[u], yv);
-#pragma unroll
-              for (int e = 0; e < EPC; ++e) {
-                float t = z[e] + ds[u] * wv[e];          // (one fma, like combine_bwd_kernel)
-                t = yv[e] > 0.f ? t : 0.f;
-                dot += yv[e] * t;
-                z[e] = t * gt[u];
-              }
-              for (int o = cpr >> 1; o >= 1; o >>= 1) dot += __shfl_xor(dot, o);
-              if (ch == 0) d.comb_dgate[grow0 + row] = dot / gt[u];
-              *(uint4*)((char*)outp + (grow0 + row) * row_bytes + ch * 16) = f32_to_chunk<T>(z);
-            }
-          }
-        }
-      } else if ((TAG == 6 || TAG == 2) && last && d.y_add) {
+      if ((TAG == 6 || TAG == 2) && last && d.y_add) {
         // The backward chains' output + the rows of another tensor (the expert input gradients through tok2row / the skip gradient):
         // the row indices of UB chunks, then their 16-byte pieces, are fetched TOGETHER - one chunk at a time the loop paid two dependent
         // global-load latencies per 16 bytes stored.  (Only these two instantiations carry the code: registers.)
@@ -785,6 +746,59 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
 #if SWN_TIMING_ON
     two += TICK() - q4;
 #endif
+  }
+  // ---- combine backward fused into the write-out of the LAST layer (tail backward chain; behind the layer loop for the same reason
+  //      as the fused heads: inside the loop body its operand loads were hoisted across the K loops) ----
+  if constexpr (TAG == 5) {
+    if (d.comb_y) {
+      int tidw = tid;
+      asm volatile("" : "+v"(tidw));
+      const int n = d.layers[d.n_layers - 1].n;
+      void* outp = d.y;
+      const int row_bytes = n * (int)sizeof(T);
+      const int cpr = row_bytes >> 4;
+      const int sh = 31 - __builtin_clz(cpr);
+      const int total = rows_in_tile * cpr;
+    // Combine backward on the way out (include/swn.h).  A row's cpr chunks sit in cpr consecutive lanes (NT is a multiple of cpr:
+    // a thread keeps its chunk column).  The global operands of UB chunks are fetched together, ahead of the arithmetic.
+    constexpr int EPC = 16 / (int)sizeof(T), UB = 8;
+    const int ch = tidw & (cpr - 1);
+    float wv[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) wv[e] = d.comb_wsig ? d.comb_wsig[ch * EPC + e] : 0.f;
+    for (int c0 = tidw; c0 < total; c0 += UB * NT) {
+      uint4 yc[UB];
+      float gt[UB], ds[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int c = c0 + u * NT;
+        const long gr = grow0 + ((c < total ? c : c0) >> sh);
+        yc[u] = *(const uint4*)((const char*)d.comb_y + gr * row_bytes + ch * 16);
+        gt[u] = d.comb_gate[gr];
+        ds[u] = d.comb_dsig ? d.comb_dsig[gr] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int c = c0 + u * NT;
+        if (c < total) {
+          const int row = c >> sh;
+          float z[EPC], yv[EPC], dot = 0.f;
+          chunk_to_f32<T>(load_chunk_from_act<T>(act, row, ch), z);
+          chunk_to_f32<T>(yc[u], yv);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            float t = z[e] + ds[u] * wv[e];          // (one fma, like combine_bwd_kernel)
+            t = yv[e] > 0.f ? t : 0.f;
+            dot += yv[e] * t;
+            z[e] = t * gt[u];
+          }
+          for (int o = cpr >> 1; o >= 1; o >>= 1) dot += __shfl_xor(dot, o);
+          if (ch == 0) d.comb_dgate[grow0 + row] = dot / gt[u];
+          *(uint4*)((char*)outp + (grow0 + row) * row_bytes + ch * 16) = f32_to_chunk<T>(z);
+        }
+      }
+    }
+    }
   }
   // ---- fused heads, second half (after the layer loop: the tile holds the last layer's output h2; kept out of the loop body, where its
   //      kernel-argument loads were hoisted and cost 9 more spilled registers - 0.4 GB of scratch traffic per launch; the barrier
