@@ -163,8 +163,11 @@ int swn_heads_fwd(const void* y, const void* h2, int dtype, const float* w_sigma
 size_t swn_heads_bwd_workspace_bytes(int n_points, int model_dim, int h2_dim);
 int swn_heads_bwd(const void* y, const void* h2, int dtype, const float* w_color, const float* raw,
                   const float* d_raw, int n_points, int model_dim, int h2_dim, void* dh2, float* dsig,
-                  float* d_w_sigma, float* d_b_sigma, float* d_w_color, float* d_b_color, void* workspace,
-                  size_t workspace_bytes, void* stream);
+                  float* d_w_sigma, float* d_b_sigma, float* d_w_color, float* d_b_color, int rows_per_group,
+                  float* group_colsum, void* workspace, size_t workspace_bytes, void* stream);
+/* rows_per_group > 0 (the samples per ray; must divide n_points): also group_colsum[n_points / rows_per_group][h2_dim] f32 = the column
+ * sums of each group's dh2 rows as stored - what swn_group_colsum(dh2, ...) returns (the per-ray bias gradient, nerf_moe.py:419-429)
+ * without reading dh2 back.  0: group_colsum is not touched.                                                          */
 /* out[g][c] = sum_r in[g*rows_per_group + r][c]  (per-ray bias gradient) */
 int swn_group_colsum(const void* in, int dtype, int n_groups, int rows_per_group, int cols, float* out, void* stream);
 

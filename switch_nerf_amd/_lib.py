@@ -67,7 +67,7 @@ SIGNATURES = {
     "swn_combine_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "swn_combine_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp],
     "swn_heads_fwd": [vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp],
-    "swn_heads_bwd": [vp, vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp],
+    "swn_heads_bwd": [vp, vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, sz, vp],
     "swn_group_colsum": [vp, i32, i32, i32, i32, vp, vp],
     "swn_composite_fwd": [vp, vp, f32, f32, i32, i32, vp, vp, vp, vp, vp],
     "swn_composite_bwd": [vp, vp, f32, f32, vp, i32, i32, vp, vp],

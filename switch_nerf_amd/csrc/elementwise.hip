@@ -634,11 +634,14 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const T* __restrict__ y,
 }
 
 // d_raw -> dh2 (masked by h2 > 0), dsig_pre; the block's sums for d_ws, d_wc, d_bs, d_bc -> partial[block].
+// rows_per_group > 0 (P a multiple of it; the samples of a ray): a block walks whole groups and also leaves rowsum[group][:] = the
+// column sums of the group's dh2 rows AS STORED (rounded to T) - the per-ray bias gradient (swn_group_colsum) without reading dh2 back.
 template <typename T, int M, int H2>
 __global__ __launch_bounds__(256) void heads_bwd_kernel(const T* __restrict__ y, const T* __restrict__ h2,
                                                         const float* __restrict__ wc, const float* __restrict__ raw,
                                                         const float* __restrict__ d_raw, int P, T* __restrict__ dh2,
-                                                        float* __restrict__ dsig, float* __restrict__ partial) {
+                                                        float* __restrict__ dsig, float* __restrict__ partial, int rows_per_group,
+                                                        float* __restrict__ rowsum) {
   using RY = Row16<T, M>;
   using RH = Row16<T, H2>;
   const int j = threadIdx.x & 15;
@@ -651,9 +654,8 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const T* __restrict__ y,
   }
 #pragma unroll
   for (int v = 0; v < RY::VPL; ++v) aws[v] = 0.f;
-  const long gid = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
-  const long ngr = ((long)gridDim.x * 256) >> 4;
-  for (long i = gid; i < P; i += ngr) {
+  float o[RH::VPL];
+  auto row = [&](long i) {
     const float4 r = *(const float4*)(raw + i * 4);
     const float4 d = *(const float4*)(d_raw + i * 4);
     const float dc0 = d.x * r.x * (1.f - r.x), dc1 = d.y * r.y * (1.f - r.y), dc2 = d.z * r.z * (1.f - r.z);
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const T* __restrict__ y,
       dsig[i] = dsp;
       abs_ += dsp; abc[0] += dc0; abc[1] += dc1; abc[2] += dc2;
     }
-    float yv[RY::VPL], hv[RH::VPL], o[RH::VPL];
+    float yv[RY::VPL], hv[RH::VPL];
     RY::load(y + i * M, j, yv);
     RH::load(h2 + i * H2, j, hv);
 #pragma unroll
@@ -674,6 +676,45 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const T* __restrict__ y,
       o[v] = hv[v] > 0.f ? gg : 0.f;
     }
     RH::store(dh2 + i * H2, j, o);
+  };
+  // ONE instance of the row body for both walks (two inlined copies were contracted differently by the compiler: last-bit differences
+  // in fp32): plain = one unit of P rows, 16-lane group q of block b takes rows 16 b + q, + 16 gridDim, ...; grouped = block b takes
+  // the units b, b + gridDim, ..., its 16-lane groups the unit's rows q, q + 16, ...
+  __shared__ float cs_lds[16][H2];
+  const bool grouped = rows_per_group > 0;
+  const int grp = threadIdx.x >> 4;
+  const long rows = grouped ? rows_per_group : P, n_units = grouped ? P / rows_per_group : 1;
+  const long r0 = grouped ? grp : (((long)blockIdx.x * 256 + threadIdx.x) >> 4), rstep = grouped ? 16 : (((long)gridDim.x * 256) >> 4);
+  for (long u = grouped ? blockIdx.x : 0; u < n_units; u += grouped ? gridDim.x : 1) {
+    float cs[RH::VPL];
+#pragma unroll
+    for (int v = 0; v < RH::VPL; ++v) cs[v] = 0.f;
+    for (long r = r0; r < rows; r += rstep) {
+      row(u * rows + r);
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int v = 0; v < RH::VPL; v += 2) {           // what the store kept: the values rounded to T
+          const uint32_t pk = pack_bf16x2(o[v], o[v + 1]);
+          cs[v] += bf16_to_f32((bf16_t)(pk & 0xFFFF));
+          cs[v + 1] += bf16_to_f32((bf16_t)(pk >> 16));
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < RH::VPL; ++v) cs[v] += o[v];
+      }
+    }
+    if (grouped) {
+#pragma unroll
+      for (int v = 0; v < RH::VPL; ++v) cs_lds[grp][RH::col(j, v)] = cs[v];
+      __syncthreads();
+      for (int c = threadIdx.x; c < H2; c += 256) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s_ += cs_lds[q][c];   // the 16 row stripes in a fixed order
+        rowsum[u * H2 + c] = s_;
+      }
+      __syncthreads();
+    }
   }
   // block-level reduction in LDS: the 16 row groups add their sums one after the other (fixed order); the block's partial goes to the
   // workspace with plain stores and ordered_reduce_kernel adds the blocks in order - the same bits on every run (one atomic per
@@ -1258,19 +1299,22 @@ extern "C" size_t swn_heads_bwd_workspace_bytes(int n_points, int model_dim, int
 
 extern "C" int swn_heads_bwd(const void* y, const void* h2, int dtype, const float* w_color, const float* raw,
                              const float* d_raw, int n_points, int model_dim, int h2_dim, void* dh2, float* dsig,
-                             float* d_w_sigma, float* d_b_sigma, float* d_w_color, float* d_b_color, void* workspace,
-                             size_t workspace_bytes, void* stream) {
+                             float* d_w_sigma, float* d_b_sigma, float* d_w_color, float* d_b_color, int rows_per_group,
+                             float* group_colsum, void* workspace, size_t workspace_bytes, void* stream) {
   SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_heads_bwd: bad dtype");
   SWN_CHECK(y && h2 && w_color && raw && d_raw && dh2 && dsig && d_w_sigma && d_b_sigma && d_w_color && d_b_color && workspace,
             "swn_heads_bwd: null pointer");
   SWN_CHECK((model_dim == 256 || model_dim == 512) && (h2_dim == 128 || h2_dim == 256), "swn_heads_bwd: model_dim in {256,512}, h2_dim in {128,256}");
   SWN_CHECK(workspace_bytes >= swn_heads_bwd_workspace_bytes(n_points, model_dim, h2_dim), "swn_heads_bwd: workspace of %zu bytes, need %zu",
             workspace_bytes, swn_heads_bwd_workspace_bytes(n_points, model_dim, h2_dim));
+  SWN_CHECK(rows_per_group >= 0 && (rows_per_group == 0 || (group_colsum && n_points % rows_per_group == 0)),
+            "swn_heads_bwd: rows_per_group %d must divide n_points %d (and group_colsum be given)", rows_per_group, n_points);
   if (n_points <= 0) return 0;
-  const int blocks = heads_bwd_blocks(n_points);
+  int blocks = heads_bwd_blocks(n_points);
+  if (rows_per_group > 0 && n_points / rows_per_group < blocks) blocks = n_points / rows_per_group;     // (never more than the workspace was sized for)
   float* partial = (float*)workspace;
 #define SWN_HB(T, M_, H_) hipLaunchKernelGGL((heads_bwd_kernel<T, M_, H_>), dim3(blocks), dim3(256), 0, as_stream(stream), (const T*)y, \
-                                             (const T*)h2, w_color, raw, d_raw, n_points, (T*)dh2, dsig, partial)
+                                             (const T*)h2, w_color, raw, d_raw, n_points, (T*)dh2, dsig, partial, rows_per_group, group_colsum)
   if (dtype == SWN_HALF) {
     if (model_dim == 256 && h2_dim == 128) SWN_HB(bf16_t, 256, 128); else if (model_dim == 512 && h2_dim == 256) SWN_HB(bf16_t, 512, 256);
     else if (model_dim == 256) SWN_HB(bf16_t, 256, 256); else SWN_HB(bf16_t, 512, 128);

@@ -198,9 +198,8 @@ class DenseNeRF(SwitchNeRF):
         W, L, H2, s = self.M, self.L, self.H2, self.skip_l
         g, acts, masks = self.g, c["acts"], c["masks"]
         _b = lambda name, shape, dtype: self._buf(c["tag"] + ":" + name, shape, dtype)
-        dh2, dsig = o.heads_bwd(c["y"], c["h2"], self.p["color.w"], c["raw"], d_raw, g["sigma.w"], g["sigma.b"], g["color.w"],
-                                g["color.b"])
-        dc_ray = o.group_colsum(dh2, S)
+        dh2, dsig, dc_ray = o.heads_bwd(c["y"], c["h2"], self.p["color.w"], c["raw"], d_raw, g["sigma.w"], g["sigma.b"], g["color.w"],
+                                        g["color.b"], rows_per_group=S)
         g["l2r.w"].addmm_(c["ray_feat"].t(), dc_ray)
         g["l2.b"].add_(dc_ray.sum(0))
         o.emb_grad(dc_ray @ self.p["l2r.w"][self.in_dir:].t(), c["image_indices"].contiguous(), g["emb"])

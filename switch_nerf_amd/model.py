@@ -640,14 +640,15 @@ class SwitchNeRF:
         g = self.g
         rows, ng = c["rows"], c["ng"]
         _b = lambda name, shape, dtype: self._buf(c["tag"] + ":" + name, shape, dtype)
-        dh2, dsig = o.heads_bwd(c["y"], c["h2"], self.p["color.w"], c["raw"], d_raw, g["sigma.w"], g["sigma.b"], g["color.w"],
-                                g["color.b"])
-        # per-ray bias gradient and the tiny per-ray GEMM's parameters
+        # per-ray bias gradient (the column sums of a ray's dh2 rows: from the heads' launch) and the tiny per-ray GEMM's parameters
         if c.get("ragged"):      # a row range of the point grid: rays may be cut at either end - per-ray sums through the rows' ray index
+            dh2, dsig = o.heads_bwd(c["y"], c["h2"], self.p["color.w"], c["raw"], d_raw, g["sigma.w"], g["sigma.b"], g["color.w"],
+                                    g["color.b"])
             ray_of_row = torch.arange(c["row0"], c["row0"] + P, device=self.dev) // S
             dc_ray = torch.zeros(N, H2, dtype=torch.float32, device=self.dev).index_add_(0, ray_of_row, dh2.float())
         else:
-            dc_ray = o.group_colsum(dh2, S)
+            dh2, dsig, dc_ray = o.heads_bwd(c["y"], c["h2"], self.p["color.w"], c["raw"], d_raw, g["sigma.w"], g["sigma.b"], g["color.w"],
+                                            g["color.b"], rows_per_group=S)
         g["l2r.w"].addmm_(c["ray_feat"].t(), dc_ray)
         g["l2.b"].add_(dc_ray.sum(0))
         d_feat_emb = dc_ray @ self.p["l2r.w"][self.in_dir:].t()

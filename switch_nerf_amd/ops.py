@@ -247,16 +247,19 @@ def heads_fwd(y, h2, w_sigma, b_sigma, w_color, b_color, sigma_noise):
     return raw
 
 
-def heads_bwd(y, h2, w_color, raw, d_raw, d_w_sigma, d_b_sigma, d_w_color, d_b_color):
+def heads_bwd(y, h2, w_color, raw, d_raw, d_w_sigma, d_b_sigma, d_w_color, d_b_color, rows_per_group: int = 0):
+    """-> (dh2, dsig) or, with rows_per_group > 0 (the samples per ray, dividing P), (dh2, dsig, colsum [P / rows_per_group, H2] f32 =
+    group_colsum(dh2, rows_per_group) from the same launch)."""
     P, M = y.shape
     H2 = h2.shape[1]
     dh2 = torch.empty_like(h2)
     dsig = torch.empty(P, dtype=torch.float32, device=y.device)
     nb = int(_lib.load().swn_heads_bwd_workspace_bytes(int(P), int(M), int(H2)))
     ws = torch.empty(max(nb, 4) // 4, dtype=torch.float32, device=y.device)     # block partial sums (added in a fixed order)
+    cs = torch.empty(P // rows_per_group, H2, dtype=torch.float32, device=y.device) if rows_per_group else None
     call("swn_heads_bwd", _p(y), _p(h2), _dt(y), _p(w_color), _p(raw), _p(d_raw), P, M, H2, _p(dh2), _p(dsig), _p(d_w_sigma),
-         _p(d_b_sigma), _p(d_w_color), _p(d_b_color), _p(ws), nb, _stream())
-    return dh2, dsig
+         _p(d_b_sigma), _p(d_w_color), _p(d_b_color), int(rows_per_group), _p(cs), _p(ws), nb, _stream())
+    return (dh2, dsig, cs) if rows_per_group else (dh2, dsig)
 
 
 def group_colsum(x, rows_per_group: int):

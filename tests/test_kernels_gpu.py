@@ -612,6 +612,20 @@ def test_heads_and_combine_bwd(dtype):
         assert all(torch.equal(a, f) for a, f in zip(acc, first))
     o.heads_bwd(yd, h2d, wc.to(dev()), raw, d_raw.to(dev()), dws, dbs, dwc, dbc)
     assert all(torch.allclose(t, 2 * f, rtol=1e-6, atol=0) for t, f in zip((dws, dbs, dwc, dbc), first))
+    # rows_per_group: the same launch also leaves the per-group column sums of dh2 (= swn_group_colsum of the stored rows); a block
+    # then walks whole groups - dh2 / dsig identical, the parameter gradients equal to summation order, run-to-run identical bits
+    for S in (25, 100, 2500):
+        outs = []
+        for _ in range(2):
+            acc = [torch.zeros_like(t) for t in first]
+            dh2g, dsigg, cs = o.heads_bwd(yd, h2d, wc.to(dev()), raw, d_raw.to(dev()), *acc, rows_per_group=S)
+            outs.append((cs, acc))
+        assert torch.equal(dh2g, dh2) and torch.equal(dsigg, dsig)
+        ref_cs = o.group_colsum(dh2, S)
+        assert cs.shape == ref_cs.shape and (cs - ref_cs).abs().max().item() <= 2e-5 * max(1.0, ref_cs.abs().max().item())
+        assert torch.equal(outs[0][0], outs[1][0]) and all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+        for a, f in zip(outs[0][1], first):
+            assert (a - f).abs().max().item() <= 1e-4 * max(1e-6, f.abs().max().item())      # (sums with cancellation, another order)
     # combine backward: y = relu(g * o); given dy_in and the sigma head's rank-1 term
     gate = torch.from_numpy(rng.uniform(0.125, 1, P).astype(np.float32)).requires_grad_(True)
     oo = torch.from_numpy(rng.standard_normal((P, M)).astype(np.float32))
