@@ -63,3 +63,47 @@ def test_error_reporting_without_gpu():
     assert rc != 0 and b"null descriptor" in lib.swn_last_error()
     rc = lib.swn_route_top1(None, None, None, 10, 3, 8, 1, 1, None, None, None, None, None, None, 0, None)
     assert rc != 0 and b"null pointer" in lib.swn_last_error()
+
+
+def test_round3_entry_points_validate_before_launch():
+    """The entry points added in round 3 (ordered heads backward with its workspace / per-ray sums, ordered embedding gradient, the
+    balanced weight-gradient launch, the heads fused into the tail forward chain) reject bad arguments with a message and launch
+    nothing - exercised without a GPU (fake non-null pointers are never dereferenced on the host)."""
+    import ctypes as C
+    from switch_nerf_amd import _lib
+    lib = _lib.load()
+    p = C.c_void_p(0x1000)                                   # any non-null address: validation only
+    err = lambda: lib.swn_last_error().decode()
+    # heads backward: workspace size, rows_per_group must divide the point count and come with an output
+    need = lib.swn_heads_bwd_workspace_bytes(1000, 256, 128)
+    assert need >= (256 + 3 * 128 + 4) * 4
+    args = [p, p, _lib.F32, p, p, p, 1000, 256, 128, p, p, p, p, p, p]
+    assert lib.swn_heads_bwd(*args, 0, None, p, need - 4, None) != 0 and "workspace" in err()
+    assert lib.swn_heads_bwd(*args, 7, p, p, need, None) != 0 and "rows_per_group" in err()
+    assert lib.swn_heads_bwd(*args, 10, None, p, need, None) != 0 and "rows_per_group" in err()
+    assert lib.swn_heads_bwd(*args, 0, None, None, need, None) != 0 and "null pointer" in err()
+    # embedding gradient
+    assert lib.swn_emb_grad(p, 48, p, 1, 100, 48, 0, p, None) != 0 and "bad sizes" in err()
+    assert lib.swn_emb_grad(p, 40, p, 1, 100, 48, 10, p, None) != 0 and "bad sizes" in err()
+    assert lib.swn_emb_grad(None, 48, p, 1, 100, 48, 10, p, None) != 0 and "null pointer" in err()
+    assert lib.swn_emb_grad(p, 48, p, 1, 0, 48, 10, p, None) == 0            # no rays: nothing to do, nothing launched
+    # balanced weight-gradient launch: job count, workspace
+    assert lib.swn_wgrad_multi_workspace_bytes(7, 8) > 0
+    jobs = (_lib.WgradJob * 1)()
+    assert lib.swn_wgrad_multi(jobs, 0, _lib.BF16, 1, 1, 256, None, 256, None, 0, p, 1 << 30, None) != 0
+    assert lib.swn_wgrad_multi(jobs, 9, _lib.BF16, 1, 1, 256, None, 256, None, 0, p, 1 << 30, None) != 0
+    # fused heads: only on the 64-row kernels with tag 4, with all four parameter arrays, rows of at most 1 KiB
+    d = _lib.ChainDesc()
+    d.dtype, d.n_layers, d.n_groups, d.n_wsets, d.group_stride, d.group_rows_clamp = _lib.BF16, 2, 1, 1, 640, 640
+    d.x, d.y = p, None
+    for i, (n, k) in enumerate(((256, 256), (128, 256))):
+        d.layers[i].w, d.layers[i].n, d.layers[i].k = p, n, k
+    assert lib.swn_mlp_chain(C.byref(d), None) != 0 and "x / y" in err()      # no y and no fused heads
+    d.heads_raw = p
+    assert lib.swn_mlp_chain(C.byref(d), None) != 0 and "fused heads need" in err()
+    d.heads_ws = d.heads_bs = d.heads_wc = d.heads_bc = p
+    d.tag = 3
+    assert lib.swn_mlp_chain(C.byref(d), None) != 0 and "tag 4" in err()
+    d.tag, d.dtype = 4, _lib.F32
+    d.layers[0].n = d.layers[0].k = d.layers[1].k = 512
+    assert lib.swn_mlp_chain(C.byref(d), None) != 0 and "1 KiB" in err()
