@@ -951,3 +951,18 @@ def test_chain_fused_heads_forward(dtype, widths):
         raw3 = torch.full((P, 4), -7.0, device=dev())
         run((ws, bs, wc, bc, nz, raw3), keep=False)
         assert torch.equal(raw3, raw)
+
+
+def test_route_three_pass_variant_is_bit_exact_too():
+    """SWN_ROUTE_3PASS=1 (three radix passes of 9 / 10 bits instead of four of 8: measured slower, kept selectable - profiles/
+    r03_experiments.md section 7) passes the same bit-exact routing tests against the reference's goldens; the switch is read once
+    per process, hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-q", "-x", "-k",
+                        "test_route_golden or test_route_ragged"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, SWN_ROUTE_3PASS="1"), cwd=root)
+    assert p.returncode == 0, p.stdout[-1500:]
+    assert " passed" in p.stdout and "failed" not in p.stdout
