@@ -61,27 +61,29 @@ __global__ __launch_bounds__(256) void route_hist_kernel(const uint32_t* __restr
     if (p < seg_tokens) atomicAdd(&h[(k[p] >> shift) & (BINS - 1)], 1);
   }
   __syncthreads();
-  for (int d = threadIdx.x; d < BINS; d += 256) hist[((long)seg * BINS + d) * nblk + blk] = h[d];
+  for (int d = threadIdx.x; d < BINS; d += 256) hist[((long)seg * nblk + blk) * BINS + d] = h[d];      // [segment][block][digit]: coalesced
 }
 
-// exclusive scan of hist[seg][d][blk] in (d, blk) order; one block of 2^BITS threads per segment, thread d owns row d.
-// NB > 0: the row (nblk <= NB counters) is held in registers - all its loads are in flight together; the serial form (NB = 0) pays
-// one memory round trip per counter, twice (25 us for 64 counters whatever the batch size).
+// exclusive scan of the counters hist[seg][blk][d] in (d, blk) order; one block of 2^BITS threads per segment, thread d owns digit d.
+// NB > 0: the digit's nblk <= NB counters are held in registers - all their loads are in flight together; the serial form (NB = 0) pays
+// one memory round trip per counter, twice (25 us for 64 counters whatever the batch size).  The digit is the fastest index: the
+// threads of a wave read / write consecutive words (with the block index fastest - rounds 1-2 - every one of a wave's 64 x 64 loads was
+// its own cache line: 17 us per pass for a kilobyte of counters).
 template <int BITS, int NB>
 __global__ __launch_bounds__(1 << BITS) void route_scan_kernel(int32_t* __restrict__ hist, int nblk) {
   constexpr int BINS = 1 << BITS, NW = BINS / 64;
   __shared__ int32_t rowsum[NW];
   const int seg = blockIdx.x, d = threadIdx.x;
-  int32_t* row = hist + ((long)seg * BINS + d) * nblk;
+  int32_t* row = hist + (long)seg * nblk * BINS + d;       // counter of block b: row[b * BINS]
   int32_t s = 0;
   int32_t c[NB > 0 ? NB : 1];
   if constexpr (NB > 0) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) c[b] = b < nblk ? row[b] : 0;
+    for (int b = 0; b < NB; ++b) c[b] = b < nblk ? row[(long)b * BINS] : 0;
 #pragma unroll
     for (int b = 0; b < NB; ++b) s += c[b];
   } else {
-    for (int b = 0; b < nblk; ++b) s += row[b];
+    for (int b = 0; b < nblk; ++b) s += row[(long)b * BINS];
   }
   // exclusive scan over the row sums: inclusive scan inside each wave (shuffles, no barrier), then the totals of the waves before
   // (the Hillis-Steele form over LDS paid 16 workgroup barriers: 17 us per pass for 64 counters)
@@ -98,13 +100,13 @@ __global__ __launch_bounds__(1 << BITS) void route_scan_kernel(int32_t* __restri
   if constexpr (NB > 0) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      if (b < nblk) row[b] = run;
+      if (b < nblk) row[(long)b * BINS] = run;
       run += c[b];
     }
   } else {
     for (int b = 0; b < nblk; ++b) {
-      const int32_t cc = row[b];
-      row[b] = run;
+      const int32_t cc = row[(long)b * BINS];
+      row[(long)b * BINS] = run;
       run += cc;
     }
   }
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void route_scatter_kernel(const uint32_t* __re
   __syncthreads();
   // phase 2: per-wave bases
   for (int d = threadIdx.x; d < BINS; d += 256) {
-    int32_t base = hist[((long)seg * BINS + d) * nblk + blk];
+    int32_t base = hist[((long)seg * nblk + blk) * BINS + d];
 #pragma unroll
     for (int ww = 0; ww < 4; ++ww) {
       const int32_t c = wh[ww][d];
@@ -249,7 +251,15 @@ __global__ __launch_bounds__(256) void laux_partial_kernel(const float* __restri
   const int e = threadIdx.x % E, t0 = threadIdx.x / E, tstep = 256 / E;
   float s = 0.f;
   const int pbeg = blk * KPB, pend = min(seg_tokens, pbeg + KPB);
-  for (int p = pbeg + t0; p < pend; p += tstep) s += gp[(long)p * E + e];
+  int p = pbeg + t0;
+  for (; p + 7 * tstep < pend; p += 8 * tstep) {      // 8 loads in flight, added in the same order as one at a time (same bits)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = gp[(long)(p + u * tstep) * E + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; p < pend; p += tstep) s += gp[(long)p * E + e];
   red[threadIdx.x] = s;
   __syncthreads();
   if (threadIdx.x < E) {
