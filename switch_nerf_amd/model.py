@@ -678,8 +678,14 @@ class SwitchNeRF:
                 o.gather_rows(dout, perm_p[so[s_]:so[s_ + 1]], dsend[so[s_]:so[s_ + 1]])
                 return ep.all_to_all_v(dsend[so[s_]:so[s_ + 1]], pl["in_splits"][s_], dr[ro[s_]:ro[s_ + 1]], pl["out_splits"][s_], self.side)
             pend = issue_b(0)
-        self._dense_wgrads([(c["h1"], dh2, g["l2h.w"].view(1, M, H2), None),
-                            (c["y"], dh1, g["l1.w"].view(1, M, M), g["l1.b"].view(1, M))], nsp)
+        # The weight gradients of the two tail layers: at small batches (the per-GPU share of a strong-scaling run) they go out together
+        # with the front layers' at the end - one balanced launch + one reduction for all five dense layers (2.39 against 2.42 ms per
+        # step at 1024 rays); at the full batch two launches are faster (15.15 against 15.30 ms: the tail operands are the most recently
+        # written tensors when their launch follows the tail backward directly).  Measured on one box, scripts/ab_env.sh.
+        tail_jobs = [(c["h1"], dh2, g["l2h.w"].view(1, M, H2), None), (c["y"], dh1, g["l1.w"].view(1, M, M), g["l1.b"].view(1, M))]
+        if P > (1 << 19):
+            self._dense_wgrads(tail_jobs, nsp)
+            tail_jobs = []
         # expert backward chain
         dz = [_b(f"dz{l}", (rows, M), dt) for l in range(L - 1)]     # dz[L-1] = dout through perm: never materialised
         dx = _b("dx", (rows, M), dt)
@@ -769,9 +775,9 @@ class SwitchNeRF:
                 wait()
         o.mlp_chain(dg, [o.Layer(self.wb["gate1"], None, relu=2, mask=c["m_a1"], save=dza1), o.Layer(self.wb["gate0"], None)],
                     dh0, y_add=dx, y_add_gather=c["row_of_tok"], tag=6)
-        self._dense_wgrads([(c["a1"], dg, g["gate1.w"].view(1, G, G), g["gate1.b"].view(1, G)),
-                            (c["h0"], dza1, g["gate0.w"].view(1, M, G), g["gate0.b"].view(1, G)),
-                            (c["pe"], dh0, g["xyz.w"].view(1, self.KP, M), g["xyz.b"].view(1, M))], nsp)
+        self._dense_wgrads(tail_jobs + [(c["a1"], dg, g["gate1.w"].view(1, G, G), g["gate1.b"].view(1, G)),
+                                        (c["h0"], dza1, g["gate0.w"].view(1, M, G), g["gate0.b"].view(1, G)),
+                                        (c["pe"], dh0, g["xyz.w"].view(1, self.KP, M), g["xyz.b"].view(1, M))], nsp)
         if self.hash is not None:          # dL/d encoding = dh0 W_xyz^T, scattered into the hash table's gradient
             d_enc = _b("d_enc", (P, self.KP), dt)
             o.mlp_chain(dh0, [o.Layer(self.wb["xyz"], None)], d_enc, tag=0)
