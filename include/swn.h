@@ -446,6 +446,12 @@ int swn_step_loss(const float* rgb, const float* target, int n_values, const flo
  * ascending ray order with a fixed association: nn.Embedding's backward (models/nerf_moe.py:215-222) with run-to-run identical bits. */
 int swn_emb_grad(const float* d_feat, int ld, const void* image_indices, int indices_are_int64, int n_rays, int app_dim,
                  int n_images, float* d_emb, void* stream);
+/* Parameter gradients of the per-ray half of layer "2" (models/nerf_moe.py:419-429, the backward of cat([.., PE(dir), emb]) @ W):
+ * d_w2r[n_feat, h2] += feat[n_rays, n_feat]^T dc_ray[n_rays, h2], d_b2[h2] += column sums of dc_ray (all fp32, row-major, dense).
+ * Block partial sums in `workspace` added in a fixed order: the same bits on every run.  n_feat <= 256, h2 in {64, 128, 256}.       */
+size_t swn_ray_feat_wgrad_workspace_bytes(int n_rays, int n_feat, int h2);
+int swn_ray_feat_wgrad(const float* feat, const float* dc_ray, int n_rays, int n_feat, int h2, float* d_w2r, float* d_b2,
+                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- optimiser -------------------------------------------------------------------------------------------------
  * torch.optim.Adam (runner.py:486) over one flat fp32 parameter buffer; grad_scale multiplies the gradient

@@ -93,6 +93,7 @@ SIGNATURES = {
     "swn_ray_feat_fwd": [vp, i32, i32, i32, vp, i32, vp, i32, vp, vp, i32, i32, vp, vp, vp],
     "swn_step_loss": [vp, vp, i32, vp, i32, vp, i32, f32, vp, vp, vp, vp, vp, vp],
     "swn_emb_grad": [vp, i32, vp, i32, i32, i32, i32, vp, vp],
+    "swn_ray_feat_wgrad": [vp, vp, i32, i32, i32, vp, vp, vp, sz, vp],
     "swn_adam_step": [vp, vp, vp, vp, vp, i32, i64, f32, f32, f32, f32, i32, f32, vp],
     "swn_cast": [vp, vp, i32, i64, vp],
     "swn_cast_transpose": [vp, vp, i32, i32, i32, i32, vp],
@@ -139,6 +140,8 @@ def load():
     lib.swn_wgrad_multi_workspace_bytes.argtypes = [i32, i32]
     lib.swn_heads_bwd_workspace_bytes.restype = sz
     lib.swn_heads_bwd_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.swn_ray_feat_wgrad_workspace_bytes.restype = sz
+    lib.swn_ray_feat_wgrad_workspace_bytes.argtypes = [i32, i32, i32]
     lib.swn_chain_mask_words.restype = i64
     lib.swn_chain_mask_words.argtypes = [i32, i32, i32, i32]
     for name, args in SIGNATURES.items():

@@ -200,8 +200,11 @@ class DenseNeRF(SwitchNeRF):
         _b = lambda name, shape, dtype: self._buf(c["tag"] + ":" + name, shape, dtype)
         dh2, dsig, dc_ray = o.heads_bwd(c["y"], c["h2"], self.p["color.w"], c["raw"], d_raw, g["sigma.w"], g["sigma.b"], g["color.w"],
                                         g["color.b"], rows_per_group=S)
-        g["l2r.w"].addmm_(c["ray_feat"].t(), dc_ray)
-        g["l2.b"].add_(dc_ray.sum(0))
+        if dc_ray.shape[1] in (64, 128, 256) and c["ray_feat"].shape[1] <= 256:      # split over the rays + ordered reduce (one launch)
+            o.ray_feat_wgrad(c["ray_feat"], dc_ray, g["l2r.w"], g["l2.b"])
+        else:
+            g["l2r.w"].addmm_(c["ray_feat"].t(), dc_ray)
+            g["l2.b"].add_(dc_ray.sum(0))
         o.emb_grad(dc_ray @ self.p["l2r.w"][self.in_dir:].t(), c["image_indices"].contiguous(), g["emb"])
         dh1 = _b("dh1", (P, W), dt)
         dy = _b("dy", (P, W), dt)

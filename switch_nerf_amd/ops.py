@@ -293,6 +293,17 @@ def emb_grad(d_feat, image_indices, d_emb):
     call("swn_emb_grad", _p(d_feat), d_feat.stride(0), ip, i64, d_feat.shape[0], d_feat.shape[1], d_emb.shape[0], _p(d_emb), _stream())
 
 
+def ray_feat_wgrad(feat, dc_ray, d_w2r, d_b2):
+    """d_w2r [F, H2] += feat^T dc_ray, d_b2 [H2] += dc_ray.sum(0) (fp32): block partial sums added in a fixed order, one launch + reduce."""
+    N, F = feat.shape
+    H2 = dc_ray.shape[1]
+    assert all(t.dtype == torch.float32 and t.is_contiguous() for t in (feat, dc_ray, d_w2r, d_b2)) and dc_ray.shape[0] == N
+    assert d_w2r.numel() == F * H2 and d_b2.numel() == H2
+    nb = int(_lib.load().swn_ray_feat_wgrad_workspace_bytes(int(N), int(F), int(H2)))
+    ws = torch.empty(max(nb, 4) // 4, dtype=torch.float32, device=feat.device)
+    call("swn_ray_feat_wgrad", _p(feat), _p(dc_ray), N, F, H2, _p(d_w2r), _p(d_b2), _p(ws), nb, _stream())
+
+
 def step_loss(rgb, target, l_aux_a, l_aux_b, wt: float, loss_scale_dev=None):
     """-> (out4 = [photo, gate_loss, loss, psnr] on the device, d_rgb, d_l_aux_a, d_l_aux_b or None)."""
     dev = rgb.device

@@ -545,6 +545,31 @@ def test_ray_feat_fwd_and_step_loss(dtype, idx_dtype):
         assert (d_b is None) == (not use_b) and (d_b is None or torch.allclose(d_b, torch.full_like(lb, 5e-4 * 0.5 / 3 * s_), rtol=1e-6))
 
 
+@pytest.mark.parametrize("shape", [(8192, 75, 128), (1000, 75, 128), (1, 27, 64), (300, 256, 256)])
+def test_ray_feat_wgrad(shape):
+    """swn_ray_feat_wgrad: d_w2r += feat^T dc_ray and d_b2 += colsum(dc_ray) (the backward of the per-ray half of layer "2",
+    models/nerf_moe.py:419-429) against float64, accumulating, with the same bits on every launch."""
+    o = ops()
+    N, F, H2 = shape
+    rng = np.random.default_rng(93)
+    feat = torch.from_numpy(rng.standard_normal((N, F)).astype(np.float32)).to(dev())
+    dc = torch.from_numpy(rng.standard_normal((N, H2)).astype(np.float32)).to(dev())
+    w0 = torch.from_numpy(rng.standard_normal((F, H2)).astype(np.float32)).to(dev())
+    b0 = torch.from_numpy(rng.standard_normal(H2).astype(np.float32)).to(dev())
+    outs = []
+    for _ in range(3):
+        w, b = w0.clone(), b0.clone()
+        o.ray_feat_wgrad(feat, dc, w, b)
+        outs.append((w, b))
+    assert all(torch.equal(outs[0][0], q[0]) and torch.equal(outs[0][1], q[1]) for q in outs[1:])
+    rw = w0.double() + feat.double().t() @ dc.double()
+    rb = b0.double() + dc.double().sum(0)
+    ew = (outs[0][0].double() - rw).abs().max().item() / rw.abs().max().item()
+    eb = (outs[0][1].double() - rb).abs().max().item() / rb.abs().max().item()
+    print(f"ray_feat_wgrad {shape}: dW {ew:.2e} db {eb:.2e}")
+    assert ew <= 2e-6 and eb <= 2e-6
+
+
 @pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
 @pytest.mark.parametrize("shape", [(8192, 48, 1940, 1940), (3000, 48, 7, 3), (1, 16, 5, 5), (5000, 256, 4, 1)])
 def test_emb_grad_is_an_ordered_index_add(shape, idx_dtype):
