@@ -132,39 +132,52 @@ __global__ __launch_bounds__(256) void emb_grad_kernel(const float* __restrict__
 
 // Parameter gradients of the per-ray half of layer "2": d_w2r[k][j] += sum_n feat[n][k] dc_ray[n][j], d_b2[j] += sum_n dc_ray[n][j]
 // (N_rays x (F = 75) x (H2 = 128): a GEMM whose only long dimension is the reduction - the library ran it on a handful of tiles, 57 us
-// at 8192 rays, + 14 us for the column sums).  Split over the rays: block b sums RB rays into partial[b] (thread = column j, rows
-// k = kg, kg + KG, ...; the block's feat rows in LDS, read as broadcasts), ordered_reduce_kernel adds the blocks in a fixed order.
-constexpr int RFW_RB = 64;       // rays per block
-constexpr int RFW_KC = 32;       // accumulators per thread and pass
+// at 8192 rays, + 14 us for the column sums).  Split over the rays: block b sums RB rays into partial[b] (thread = column j and a
+// contiguous range of rows k; the block's feat rows in LDS, zero-padded, read as 16-byte broadcasts; the thread's dc column in
+// LDS too), ordered_reduce_kernel adds the blocks in a fixed order.  (First version: a guard per FMA on a per-thread row index and a
+// dynamically indexed register array - 2000 exec-mask branches and scratch: 166 us.)
+constexpr int RFW_RB = 16;       // rays per block
+constexpr int RFW_KC = 8;        // rows (accumulators) per thread and pass
 __global__ __launch_bounds__(256) void ray_feat_wgrad_kernel(const float* __restrict__ feat, const float* __restrict__ dc_ray, int n_rays, int F,
-                                                             int H2, float* __restrict__ partial) {
-  extern __shared__ float fs[];                        // [RB][F]
+                                                             int F_pad, int H2, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float fs[];      // [RB][F_pad], zero beyond the valid rays / features: no guards in the loop
   const int b = blockIdx.x, r0 = b * RFW_RB, nr = min(RFW_RB, n_rays - r0);
-  for (int i = threadIdx.x; i < nr * F; i += 256) fs[i] = feat[(long)r0 * F + i];
+  for (int i = threadIdx.x; i < RFW_RB * F_pad; i += 256) {
+    const int r = i / F_pad, k = i - r * F_pad;
+    fs[i] = (r < nr && k < F) ? feat[(long)(r0 + r) * F + k] : 0.f;
+  }
   __syncthreads();
-  const int KG = 256 / H2;                             // row groups (H2 = 128: 2, 256: 1)
-  const int j = threadIdx.x % H2, kg = threadIdx.x / H2;
+  const int KG = 256 / H2;                             // row groups (H2 = 64: 4, 128: 2, 256: 1); a wave lies inside one group
+  const int j = threadIdx.x % H2, kg = __builtin_amdgcn_readfirstlane(threadIdx.x / H2);
+  const int rpk = F_pad / KG;                          // rows of this group: [kg rpk, (kg + 1) rpk), a multiple of RFW_KC
   float* part = partial + (size_t)b * ((size_t)F * H2 + H2);
-  if (kg >= KG) return;
-  const float* dcp = dc_ray + (long)r0 * H2 + j;
-  for (int k0 = kg; k0 < F; k0 += KG * RFW_KC) {       // rows k0, k0 + KG, ... (at most RFW_KC of them per pass)
+  // the block's dc rows go to LDS as well ([RB][H2] behind the feature rows; a register array would have to be indexed by constants,
+  // i.e. a fully unrolled ray loop whose 128 hoisted LDS reads spill: measured 96 us): thread j reads its own column
+  float* dcs = fs + RFW_RB * F_pad;
+  for (int i = threadIdx.x; i < RFW_RB * H2; i += 256) {
+    const int r = i / H2;
+    dcs[i] = r < nr ? dc_ray[(long)r0 * H2 + i] : 0.f;
+  }
+  __syncthreads();
+  for (int k0 = kg * rpk; k0 < (kg + 1) * rpk; k0 += RFW_KC) {
     float acc[RFW_KC];
 #pragma unroll
     for (int i = 0; i < RFW_KC; ++i) acc[i] = 0.f;
-    for (int r = 0; r < nr; ++r) {
-      const float dc = dcp[(long)r * H2];
-      const float* fr = fs + r * F + k0;
-#pragma unroll
-      for (int i = 0; i < RFW_KC; ++i)
-        if (k0 + i * KG < F) acc[i] = fmaf(fr[i * KG], dc, acc[i]);
+#pragma unroll 8
+    for (int r = 0; r < RFW_RB; ++r) {
+      const float4 f0 = *(const float4*)(fs + r * F_pad + k0), f1 = *(const float4*)(fs + r * F_pad + k0 + 4);      // wave-uniform: broadcasts
+      const float dc = dcs[r * H2 + j];
+      acc[0] = fmaf(f0.x, dc, acc[0]); acc[1] = fmaf(f0.y, dc, acc[1]); acc[2] = fmaf(f0.z, dc, acc[2]); acc[3] = fmaf(f0.w, dc, acc[3]);
+      acc[4] = fmaf(f1.x, dc, acc[4]); acc[5] = fmaf(f1.y, dc, acc[5]); acc[6] = fmaf(f1.z, dc, acc[6]); acc[7] = fmaf(f1.w, dc, acc[7]);
     }
 #pragma unroll
     for (int i = 0; i < RFW_KC; ++i)
-      if (k0 + i * KG < F) part[(size_t)(k0 + i * KG) * H2 + j] = acc[i];
+      if (k0 + i < F) part[(size_t)(k0 + i) * H2 + j] = acc[i];
   }
   if (kg == 0) {
     float sb = 0.f;
-    for (int r = 0; r < nr; ++r) sb += dcp[(long)r * H2];
+#pragma unroll 8
+    for (int r = 0; r < RFW_RB; ++r) sb += dcs[r * H2 + j];
     part[(size_t)F * H2 + j] = sb;
   }
 }
@@ -230,10 +243,11 @@ extern "C" int swn_ray_feat_wgrad(const float* feat, const float* dc_ray, int n_
             workspace_bytes, swn_ray_feat_wgrad_workspace_bytes(n_rays, n_feat, h2));
   if (n_rays == 0) return 0;
   const int nb = cdiv(n_rays, RFW_RB);
-  const size_t lds = (size_t)RFW_RB * n_feat * sizeof(float);
+  const int unit = (256 / h2) * RFW_KC, f_pad = cdiv(n_feat, unit) * unit;      // every row group gets a whole number of passes
+  const size_t lds = (size_t)RFW_RB * (f_pad + h2) * sizeof(float);
   hipError_t e = hipFuncSetAttribute((const void*)ray_feat_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   SWN_CHECK(e == hipSuccess, "swn_ray_feat_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(ray_feat_wgrad_kernel, dim3(nb), dim3(256), lds, as_stream(stream), feat, dc_ray, n_rays, n_feat, h2, (float*)workspace);
+  hipLaunchKernelGGL(ray_feat_wgrad_kernel, dim3(nb), dim3(256), lds, as_stream(stream), feat, dc_ray, n_rays, n_feat, f_pad, h2, (float*)workspace);
   OrdDst od{{d_w2r, d_b2, nullptr, nullptr}, {n_feat * h2, h2, 0, 0}};
   ordered_reduce_async((const float*)workspace, nb, n_feat * h2 + h2, od, true, as_stream(stream));
   SWN_LAUNCH_CHECK();

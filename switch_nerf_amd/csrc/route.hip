@@ -16,37 +16,42 @@ __global__ __launch_bounds__(256) void route_keys_kernel(const int32_t* __restri
                                                          int n_tokens, int seg_tokens, int E, int bpr,
                                                          uint32_t* __restrict__ keys, int32_t* __restrict__ vals,
                                                          int32_t* __restrict__ counts) {
-  // per-block (LDS) expert histogram, then one global atomic per (segment, expert) touched by the block; a block
-  // spans at most two segments (seg_tokens >= 256 is not required: generic two-slot handling below)
+  // A block takes KPB = 2048 consecutive tokens (8 per thread): per-block (LDS) expert histogram, then one global atomic per
+  // (segment, expert) touched by the block; a block spans at most two segments (seg_tokens >= KPB is not required: generic two-slot
+  // handling below).  With 256 tokens per block (rounds 1-2) 512 blocks per segment queued up on each of the E counters of the
+  // segment: the kernel took 40 us for 2M tokens, 5x its traffic.
   __shared__ int32_t h[2][64];
   if (threadIdx.x < 128) (&h[0][0])[threadIdx.x] = 0;
   __syncthreads();
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int seg0 = (int)(((long)blockIdx.x * blockDim.x) / seg_tokens);
-  int e = -1, seg = seg0;
-  if (i < n_tokens) {
-    e = idx[i];
-    uint32_t inv = 0;
-    if (bpr) {
-      const int32_t b = (int32_t)0x3F800000 - (int32_t)__float_as_uint(gmax[i]);
-      inv = b < 0 ? 0u : (b > 0x03FFFFFF ? 0x03FFFFFFu : (uint32_t)b);
+  const long b0 = (long)blockIdx.x * KPB;
+  const int seg0 = (int)(b0 / seg_tokens);
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int u = 0; u < KPB / 256; ++u) {
+    const long i = b0 + u * 256 + threadIdx.x;
+    int e = -1, seg = seg0;
+    if (i < n_tokens) {
+      e = idx[i];
+      uint32_t inv = 0;
+      if (bpr) {
+        const int32_t b = (int32_t)0x3F800000 - (int32_t)__float_as_uint(gmax[i]);
+        inv = b < 0 ? 0u : (b > 0x03FFFFFF ? 0x03FFFFFFu : (uint32_t)b);
+      }
+      keys[i] = ((uint32_t)e << 26) | inv;
+      seg = (int)(i / seg_tokens);
+      vals[i] = (int32_t)(i - (long)seg * seg_tokens);
     }
-    keys[i] = ((uint32_t)e << 26) | inv;
-    seg = (int)(i / seg_tokens);
-    vals[i] = (int32_t)(i - (long)seg * seg_tokens);
-  }
-  // Expert counts.  A wave that lies inside one segment (the usual case) counts with one ballot per expert and adds once per expert -
-  // 256 threads hitting 8 LDS words with one atomic each took most of this kernel's time (40 us for 2M tokens: 5x its traffic).
-  const int seg_first = __shfl(seg, 0), seg_last = __shfl(seg, 63);
-  if (seg_first == seg_last && seg_first - seg0 < 2) {
-    const int lane = threadIdx.x & 63;
-    for (int q = 0; q < E; ++q) {
-      const unsigned long long m = __ballot(e == q);
-      if (lane == 0 && m) atomicAdd(&h[seg_first - seg0][q], (int)__popcll(m));
+    // a wave inside one segment (the usual case) counts with one ballot per expert and adds once per expert
+    const int seg_first = __shfl(seg, 0), seg_last = __shfl(seg, 63);
+    if (seg_first == seg_last && seg_first - seg0 < 2) {
+      for (int q = 0; q < E; ++q) {
+        const unsigned long long m = __ballot(e == q);
+        if (lane == 0 && m) atomicAdd(&h[seg_first - seg0][q], (int)__popcll(m));
+      }
+    } else if (e >= 0) {
+      if (seg - seg0 < 2) atomicAdd(&h[seg - seg0][e], 1);
+      else atomicAdd(counts + seg * E + e, 1);   // tiny segments: fall back to a direct atomic
     }
-  } else if (e >= 0) {
-    if (seg - seg0 < 2) atomicAdd(&h[seg - seg0][e], 1);
-    else atomicAdd(counts + seg * E + e, 1);   // tiny segments: fall back to a direct atomic
   }
   __syncthreads();
   if (threadIdx.x < 128) {
@@ -350,7 +355,7 @@ extern "C" int swn_route_top1(const int32_t* idx, const float* gmax, const float
                    : fill_u32_async(perm, 0xFFFFFFFFu, (size_t)n_seg * n_experts * capacity * 4, s);
     SWN_CHECK(e == hipSuccess, "fill: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(route_keys_kernel, dim3(cdiv(n_tokens, 256)), dim3(256), 0, s, idx, gmax, n_tokens, seg_tokens,
+  hipLaunchKernelGGL(route_keys_kernel, dim3(cdiv(n_tokens, KPB)), dim3(256), 0, s, idx, gmax, n_tokens, seg_tokens,
                      n_experts, bpr, k0, v0, counts);
   SWN_LAUNCH_CHECK();
   uint32_t *ki = k0, *ko = k1;
