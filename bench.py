@@ -276,13 +276,17 @@ def main():
                 continue
             fn()
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            out_[name] = e0.elapsed_time(e1) / reps
+            best = None
+            for _batch in range(3):      # the fastest of three batches of `reps` launches (a batch right behind an eager step can sit
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)      # in a clock ramp: seen once as +20 %)
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                t_ = e0.elapsed_time(e1) / reps
+                best = t_ if best is None else min(best, t_)
+            out_[name] = best
         kept_ = int(torch.minimum(c_["counts"], torch.tensor(c_["cap"], device=dev)).sum().item())
         return out_, kept_
 
