@@ -11,8 +11,15 @@ torch.manual_seed(0)
 acts = [torch.randn(ROWS, M, device=dev).to(dt) for _ in range(L)]
 dzs = [torch.randn(ROWS, M, device=dev).to(dt) for _ in range(L)]
 perm = torch.randperm(ROWS, device=dev).int()
+import os
+if os.environ.get("PERM") == "identity":        # gather order experiments: the two gathered operands read in row order ...
+    perm = torch.arange(ROWS, device=dev, dtype=torch.int32)
+elif os.environ.get("PERM") == "sorted":        # ... or ascending inside every (segment, expert) group (what a token-ordered row layout would give)
+    perm = perm.view(NG, CAP).sort(dim=1).values.reshape(-1).contiguous()
 dw = [torch.zeros(E, M, M, device=dev) for _ in range(L)]
 db = [torch.zeros(E, M, device=dev) for _ in range(L)]
+if os.environ.get("PERM") == "none":            # no gathered operand at all (what the index loads of the two gathered streams cost)
+    perm = None
 items = [(acts[l], dzs[l], dw[l], db[l], perm if l == 0 else None, perm if l == L - 1 else None) for l in range(L)]
 pats = {"balanced": [CAP] * 8,
         "all 79 %": [int(CAP * 0.79)] * 8,

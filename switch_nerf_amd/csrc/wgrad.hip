@@ -505,16 +505,34 @@ __global__ __launch_bounds__(WG_NT) void wgrad_stream_kernel(const WsArgs p) {
       typedef const __attribute__((address_space(4))) int32_t* cidx_t;
       const cidx_t ag = (cidx_t)it.a_gather, bg = (cidx_t)it.b_gather;
       const char* src[4];                                  // [2 pieces] x (A, B)
-      auto prepare = [&]() {
-        const bool live = left > 0;
+      // Gather indices of the slab the cursor points to, fetched ONE slab ahead: fetch() only issues the scalar loads (behind the
+      // cursor's advance, at the end of prepare()); their values are first looked at in the next prepare(), a whole slab of MFMA work
+      // later.  With the loads at the top of prepare() every wave sat through two scalar-load round trips per slab in the two gathered
+      // jobs of the expert launch: 2.93 ms against 2.49 without any gather (scripts/wgrad_check.py, PERM=none), whatever the order
+      // of the gathered rows.
+      // (The loads are unconditional straight-line code - without a gather they read a zero word - and the choice between the loaded
+      //  index and the row itself is made where the value is used: a load inside `if (gather)` is waited for at the end of its branch.)
+      const cidx_t agp = ag ? ag : (cidx_t)g_zero_page, bgp = bg ? bg : (cidx_t)g_zero_page;
+      long rr0[2], rr1[2];
+      int ia0[2], ia1[2], ib0[2], ib1[2];
+      auto fetch = [&]() {
         const long grow0 = p.group_begin ? (long)((cidx_t)p.group_begin)[gp] : (long)gp * p.group_stride;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int rf = rp + (2 * wave + i) * RPP;        // first row of this wave's piece (wave-uniform)
           const long r0 = grow0 + max(min(rf, rows_p - 1), 0), r1 = grow0 + max(min(rf + RPP - 1, rows_p - 1), 0);
-          long a0 = r0, a1 = r1, b0 = r0, b1 = r1;
-          if (live && ag) { a0 = max(ag[r0], 0); if (RPP == 2) a1 = max(ag[r1], 0); }
-          if (live && bg) { b0 = max(bg[r0], 0); if (RPP == 2) b1 = max(bg[r1], 0); }
+          rr0[i] = r0; rr1[i] = r1;
+          ia0[i] = agp[ag ? r0 : 0]; ia1[i] = agp[ag ? r1 : 0];
+          ib0[i] = bgp[bg ? r0 : 0]; ib1[i] = bgp[bg ? r1 : 0];
+        }
+      };
+      auto prepare = [&]() {
+        const bool live = left > 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int rf = rp + (2 * wave + i) * RPP;
+          const long a0 = ag ? (long)max(ia0[i], 0) : rr0[i], a1 = ag ? (long)max(ia1[i], 0) : rr1[i];      // (-1 = an empty slot of the permutation)
+          const long b0 = bg ? (long)max(ib0[i], 0) : rr0[i], b1 = bg ? (long)max(ib1[i], 0) : rr1[i];
           const bool ok = live && (rf + prow < rows_p);
           const uint32_t as = (uint32_t)((RPP == 2 && prow) ? a1 : a0), bs = (uint32_t)((RPP == 2 && prow) ? b1 : b0);
           src[2 * i] = ok ? a_lane + (uint64_t)as * a_rb : zero;
@@ -528,6 +546,7 @@ __global__ __launch_bounds__(WG_NT) void wgrad_stream_kernel(const WsArgs p) {
             rp = 0;
           }
         }
+        fetch();
       };
       auto issue = [&](int slot) {
 #pragma unroll
@@ -539,6 +558,7 @@ __global__ __launch_bounds__(WG_NT) void wgrad_stream_kernel(const WsArgs p) {
       };
 
       const int nsl = pb - pa;
+      fetch();
 #pragma unroll
       for (int s0 = 0; s0 < WG_NS - 1; ++s0) { prepare(); issue(s0); }
       int slot = 0;
