@@ -513,6 +513,7 @@ __global__ __launch_bounds__(WG_NT) void wgrad_stream_kernel(const WsArgs p) {
       // (The loads are unconditional straight-line code - without a gather they read a zero word - and the choice between the loaded
       //  index and the row itself is made where the value is used: a load inside `if (gather)` is waited for at the end of its branch.)
       const cidx_t agp = ag ? ag : (cidx_t)g_zero_page, bgp = bg ? bg : (cidx_t)g_zero_page;
+      const bool gathered = ag != nullptr || bg != nullptr;
       long rr0[2], rr1[2];
       int ia0[2], ia1[2], ib0[2], ib1[2];
       auto fetch = [&]() {
@@ -520,10 +521,14 @@ __global__ __launch_bounds__(WG_NT) void wgrad_stream_kernel(const WsArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int rf = rp + (2 * wave + i) * RPP;        // first row of this wave's piece (wave-uniform)
-          const long r0 = grow0 + max(min(rf, rows_p - 1), 0), r1 = grow0 + max(min(rf + RPP - 1, rows_p - 1), 0);
-          rr0[i] = r0; rr1[i] = r1;
-          ia0[i] = agp[ag ? r0 : 0]; ia1[i] = agp[ag ? r1 : 0];
-          ib0[i] = bgp[bg ? r0 : 0]; ib1[i] = bgp[bg ? r1 : 0];
+          rr0[i] = grow0 + max(min(rf, rows_p - 1), 0);
+          rr1[i] = grow0 + max(min(rf + RPP - 1, rows_p - 1), 0);
+        }
+        if (gathered) {                                    // (jobs without a gathered operand - five of the expert launch's seven, all dense
+          ia0[0] = agp[ag ? rr0[0] : 0]; ia1[0] = agp[ag ? rr1[0] : 0];      //  ones - skip the loads; ia / ib are then never looked at)
+          ia0[1] = agp[ag ? rr0[1] : 0]; ia1[1] = agp[ag ? rr1[1] : 0];
+          ib0[0] = bgp[bg ? rr0[0] : 0]; ib1[0] = bgp[bg ? rr1[0] : 0];
+          ib0[1] = bgp[bg ? rr0[1] : 0]; ib1[1] = bgp[bg ? rr1[1] : 0];
         }
       };
       auto prepare = [&]() {
