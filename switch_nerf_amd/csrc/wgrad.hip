@@ -516,8 +516,9 @@ __global__ __launch_bounds__(WG_NT) void wgrad_stream_kernel(const WsArgs p) {
       const bool gathered = ag != nullptr || bg != nullptr;
       long rr0[2], rr1[2];
       int ia0[2], ia1[2], ib0[2], ib1[2];
+      auto group_row0 = [&]() -> long { return p.group_begin ? (long)((cidx_t)p.group_begin)[gp] : (long)gp * p.group_stride; };
+      long grow0 = group_row0();                           // first row of the cursor's group: re-read only when the cursor changes group
       auto fetch = [&]() {
-        const long grow0 = p.group_begin ? (long)((cidx_t)p.group_begin)[gp] : (long)gp * p.group_stride;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int rf = rp + (2 * wave + i) * RPP;        // first row of this wave's piece (wave-uniform)
@@ -549,6 +550,7 @@ __global__ __launch_bounds__(WG_NT) void wgrad_stream_kernel(const WsArgs p) {
           if (rp >= rows_p && left > 0) {
             do { ++ip; gp += n_wsets; rows_p = __builtin_amdgcn_readfirstlane(rws[ip]); } while (rows_p == 0);
             rp = 0;
+            grow0 = group_row0();
           }
         }
         fetch();
