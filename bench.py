@@ -18,11 +18,17 @@ buffer per step) or, with --parallelism ep, expert-parallel (dispatched rows exc
 Reproducibility: the device RNG is seeded, and after the warm-up steps the parameters, the Adam state and the RNG are reset, so the
 timed steps are the same computation (same routing, same kept-token fraction) whatever the warm-up count.
 
-Prints ONE JSON line (rank 0).  `roofline` describes the dominant expert kernel against the bf16 MFMA peak (the expert
-grouped GEMM is the MFMA-bound part), timed live with HIP events on the launch stream inside the timed region; `kernels` carries
-the MFMA fraction, the algorithmic HBM rate and the counter-measured HBM bytes (profiles/traffic.json) of all three expert kernels;
-`balanced` repeats the measurement with perfectly balanced routing (point i -> expert i mod E: every group full, 100 % of the tokens kept); `cpu_baseline` is the CPU
-oracle (a port of the reference's CPU path) timed on this box's host cores on a bounded sample (one 131072-point segment).
+Prints ONE JSON line (rank 0).  `roofline` describes the DOMINANT expert kernel (the slowest of the three expert launches of a training
+step: the weight-gradient launch) on the roofline its arithmetic intensity puts it under - `bound` "hbm" when its flop per algorithmic
+byte are below the ridge MFMA peak / HBM peak = 312 flop/B (the weight gradients read every operand once: 128 flop/B), else "mfma";
+`achieved` / `peak` / `frac` are on that scale, `attainable` = min(MFMA peak, flop_per_byte x HBM peak) in TFLOP/s and `mfma_frac` put the
+same launch on the matrix-pipe scale, `traffic` = HBM bytes per launch from the PMC counters (profiles/traffic.json).  Timed live:
+every expert kernel is relaunched back to back on one step's live buffers between two HIP events on the launch stream.  `kernels`
+carries the MFMA fraction, the algorithmic HBM rate and the counter-measured HBM bytes of all three expert kernels plus the save-free
+forward chain (the grouped GEMM alone); `balanced` repeats the measurement with perfectly balanced routing (point i -> expert i mod E:
+every group full, 100 % of the tokens kept; its rays/s is also in `config.balanced_value`); `cpu_baseline` is the CPU oracle (a port of
+the reference's CPU path) timed on this box's host cores on a bounded sample (one 131072-point segment): `cores` = the cores this
+process may run on (os.sched_getaffinity), `threads` = torch's intra-op threads (what the oracle actually used).
 """
 import argparse
 import json
@@ -50,6 +56,14 @@ def synth_batch(n_rays, seed, device):
     return rays.to(device), idx.to(device), rgbs.to(device)
 
 
+def _host_cores():
+    """Cores this process may run on (len(os.sched_getaffinity(0)))."""
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(seconds_budget=30.0):
     """The CPU oracle's training step (fwd + bwd, fp32) on one routing segment; returns rays/s on the host cores."""
     import numpy as np
@@ -69,7 +83,7 @@ def cpu_baseline(seconds_budget=30.0):
         dt = time.time() - t0
         t_best = dt if t_best is None else min(t_best, dt)
         reps += 1
-    return dict(value=n_rays / t_best, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+    return dict(value=n_rays / t_best, unit="rays/s", cores=_host_cores(), threads=torch.get_num_threads(), kind="port",
                 sample=f"oracle fwd+bwd fp32 on 1 of 16 segments (512 rays x 256 samples = 131072 points), best of {reps}; "
                        f"{t_best:.2f} s/segment => {16 * t_best:.1f} s per 8192-ray step")
 
@@ -110,6 +124,8 @@ def main():
                          "slower than the GPU runs them (18.5-19.7 ms/step against 16.7 for every later process; 200 warm-up steps do not "
                          "cure it), replay takes the host out of the step; per-kernel HIP events cannot be recorded inside a graph, they "
                          "come from eager steps that follow the timed region.  off: eager launches, events inside the timed region")
+    ap.add_argument("--no-split-backward", action="store_true", help="N > 1: one backward graph and one all-reduce behind it (default: two "
+                    "graphs, the expert block's all-reduce on the side stream under the second one)")
     ap.add_argument("--no-balanced", action="store_true", help="skip the extra balanced-routing measurement")
     ap.add_argument("--routing", choices=["router", "balanced"], default="router",
                     help="balanced: the MAIN measurement runs with point i -> expert i mod E (used by the counter passes: bytes per kept row)")
@@ -295,7 +311,7 @@ def main():
     reset_state(4321)
     if use_graph:
         graphed[0] = GraphedTrainStep(model, rgbs, rays, idx, a.samples, a.chunk, perturb=1.0, noise_std=1.0,
-                                      routing_override=route_override[0])
+                                      routing_override=route_override[0], split_backward=False if a.no_split_backward else None)
     for _ in range(a.warmup):
         st = step()
     reset_state(1234)
@@ -433,6 +449,7 @@ def main():
         # 312 flop/B.  The weight-gradient launch (reads every operand once: 128 flop/B) is HBM-bound; the chains that save every
         # activation sit at ~220 flop/B (HBM side as well), the save-free forward at 1790 flop/B (MFMA side).  Both fractions are reported.
         intensity = flops_of(kept_mean) / d["alg_bytes"]
+        attainable = min(MFMA_BF16_PEAK_TFLOPS, intensity * HBM_PEAK_GBS * 1e9 / 1e12)      # TFLOP/s: both rooflines in one number
         if intensity < MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
             roof = dict(kernel=names[dom], bound="hbm", achieved=d["alg_gbs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=d["hbm_frac_alg"],
                         traffic=d.get("hbm_measured_bytes"), flop_per_byte=round(intensity, 1), mfma_frac=d["mfma_frac"], tflops=d["tflops"],
@@ -441,6 +458,8 @@ def main():
             roof = dict(kernel=names[dom], bound="mfma", achieved=d["tflops"], peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=d["mfma_frac"], traffic=d.get("hbm_measured_bytes"), flop_per_byte=round(intensity, 1), alg_gbs=d["alg_gbs"],
                         hbm_frac_measured=d.get("hbm_frac_measured"))
+        roof["attainable"] = dict(tflops=round(attainable, 1), frac_of_attainable=round(d["tflops"] / attainable, 4),
+                                  what="min(MFMA peak, flop_per_byte x HBM peak) for this launch's algorithmic flops and bytes")
         if "expert_fwd_nosave" in detail:      # north_star: the grouped GEMM against the MFMA peak = the chain without the training saves
             roof["grouped_gemm_mfma_frac_nosave"] = detail["expert_fwd_nosave"]["mfma_frac"]
     if detail and world == 1 and a.dtype == "bf16":
@@ -534,6 +553,29 @@ def main():
                        wait_ms_per_step=round(rep["wait_ms"] / psteps, 3),
                        hidden_fraction=None if rep["hidden_fraction"] is None else round(rep["hidden_fraction"], 4))
 
+    # ---- data parallel: the gradient all-reduce - its time and how much of it ran under the second backward graph
+    ar_info = None
+    if world > 1 and a.parallelism == "dp" and hasattr(allreduce, "report"):
+        if use_graph and graphed[0] is None:
+            graphed[0] = GraphedTrainStep(model, rgbs, rays, idx, a.samples, a.chunk, perturb=1.0, noise_std=1.0,
+                                          split_backward=False if a.no_split_backward else None)
+        allreduce.profile = True
+        allreduce.report()
+        psteps = 5
+        for _ in range(psteps):
+            step()
+        torch.cuda.synchronize()
+        rep = allreduce.report()
+        allreduce.profile = False
+        ar_info = dict(what="flat fp32 gradient, RCCL all-reduce; the expert block (behind n_dense) is issued on the side stream between the "
+                            "two backward graphs, the dense prefix behind the second one" if (graphed[0] is not None and graphed[0].split)
+                       else "flat fp32 gradient, one RCCL all-reduce behind the backward",
+                       bytes=int(model.grad.numel() * 4), expert_block_bytes=int((model.grad.numel() - model.n_dense) * 4),
+                       collectives_per_step=rep["collectives"] // psteps, allreduce_ms=round(rep["allreduce_ms"] / psteps, 4),
+                       wait_ms=round(rep["wait_ms"] / psteps, 4),
+                       allreduce_hidden_fraction=None if rep["hidden_fraction"] is None else round(rep["hidden_fraction"], 4))
+        graphed[0] = None
+
     gb = a.rays if scaling == "strong" else a.rays * world
     out = {
         "metric": "train rays/sec (8192-ray batch, 256 samples, 8 experts)", "value": round(value, 1), "unit": "rays/s",
@@ -552,7 +594,8 @@ def main():
                                + (f", + dense background model on {st['ctx']['Nb']} of {n_rays} rays x {a.samples // 2} samples" if a.bg else "")
                                + (f", model_dim {a.model_dim}, {a.experts} experts" if (a.model_dim != 256 or a.experts != 8) else ""),
                    "global_batch_rays": gb, "rays_per_gpu": n_rays, "samples": a.samples, "segment_points": a.chunk,
-                   "parallelism": f"{a.parallelism}{world}", "kept_token_fraction": round(kept / P, 4), "kept_token_fraction_mean": round(kept_mean / P, 4), "loss": round(loss_main, 6), "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 3),
+                   "parallelism": f"{a.parallelism}{world}", "balanced_value": None if balanced is None else balanced["value"],
+                   "kept_token_fraction": round(kept / P, 4), "kept_token_fraction_mean": round(kept_mean / P, 4), "loss": round(loss_main, 6), "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 3),
                    "runner_loop_ms_per_step": None if runner_ms is None else round(runner_ms, 3),
                    "timed_region": ((("forward + backward replayed from a hipGraph, all-reduce + Adam eager" if use_graph else "eager launches")
                                      + f"; eager_ms_per_step = the same step launched eagerly ({ev_steps} steps); runner_loop_ms_per_step = the "
@@ -564,12 +607,16 @@ def main():
     }
     if ep_info is not None:
         out["config"]["expert_parallel"] = ep_info
+    if ar_info is not None:
+        out["config"]["allreduce"] = ar_info
+        out["allreduce_ms"], out["allreduce_hidden_fraction"] = ar_info["allreduce_ms"], ar_info["allreduce_hidden_fraction"]
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline and not other:
             try:
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:      # the baseline must never take the bench line down
-                out["cpu_baseline"] = dict(value=None, unit="rays/s", cores=torch.get_num_threads(), kind="port", sample=f"failed: {e}")
+                out["cpu_baseline"] = dict(value=None, unit="rays/s", cores=_host_cores(), threads=torch.get_num_threads(), kind="port",
+                                           sample=f"failed: {e}")
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

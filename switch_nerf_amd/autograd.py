@@ -29,14 +29,13 @@ class RenderRaysFunction(torch.autograd.Function):
         ctx.nerf, ctx.fine = nerf, F > 0
         ctx.graph = None
         if isinstance(perturb_rand, str) and perturb_rand == "graph":
-            from .graph import GraphedRenderTrain
+            from .graph import GraphedRenderTrain, cached_graph
             cache = nerf.__dict__.setdefault("_train_graphs", {})
             key = (rays.shape[0], S, F, int(chunk), float(perturb), float(sigma_noise or 0.0), bool(nerf.moe_no_batch), nerf.dtype)
-            g = cache.get(key)
-            if g is None:
-                g = cache[key] = GraphedRenderTrain(nerf, rays, image_indices, S, F, chunk, float(perturb), float(sigma_noise or 0.0))
+            g = cached_graph(cache, key, lambda: GraphedRenderTrain(nerf, rays, image_indices, S, F, chunk, float(perturb),
+                                                                    float(sigma_noise or 0.0)))
             state, outs = g.forward(rays, image_indices)
-            ctx.graph, ctx.state = g, state
+            ctx.graph, ctx.state, ctx.generation = g, state, g.generation
             res = (outs[0].clone(), outs[1].clone(), outs[2].clone(), outs[3].clone(), outs[4].clone())
         elif F > 0:
             c, cf, out = nerf.forward_hier(rays, image_indices, S, F, chunk, perturb, perturb_rand, None, sigma_noise, sigma_noise_fine,
@@ -55,7 +54,9 @@ class RenderRaysFunction(torch.autograd.Function):
     def backward(ctx, d_rgb, d_laux_c, d_laux_f, _d_depth, _d_var):
         nerf = ctx.nerf
         if ctx.graph is not None:
-            if nerf._last_ctx is not ctx.state:
+            # every replay of the forward graph returns the SAME state object (static buffers): the replay counter tells whether the
+            # buffers still hold this node's activations
+            if ctx.graph.generation != ctx.generation or nerf._last_ctx is not ctx.state:
                 raise RuntimeError("graph_train: backward() must follow the forward it belongs to (the captured graphs share one set of "
                                    "static activation buffers per batch shape)")
             g = ctx.graph.backward(d_rgb.to(torch.float32), d_laux_c.to(torch.float32), d_laux_f.to(torch.float32))

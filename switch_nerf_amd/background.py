@@ -174,13 +174,28 @@ class BackgroundScene:
         import torch.distributed as dist
         distributed = grad_allreduce is not None or (dist.is_available() and dist.is_initialized())
         bg_present = True if distributed else ctx["Nb"] > 0
-        for m in (nerf, bg):
-            scale = grad_allreduce(m._allreduce_view()) if grad_allreduce is not None else 1.0
-            if optimizer_step and (m is nerf or bg_present) and m._unscale_ok():
+        models = [nerf] + ([bg] if bg_present else [])
+        scale = {id(m): (grad_allreduce(m._allreduce_view()) if grad_allreduce is not None else 1.0) for m in (nerf, bg)}
+        # fp16: the reference holds ONE GradScaler over both optimizers (runner.py:483, 686-690).  GradScaler.step skips an optimizer on
+        # ITS OWN non-finite gradient; GradScaler.update backs the shared scale off when EITHER optimizer found one (and only then
+        # resets the growth tracker).  The foreground model's LossScaler is that shared scaler; the background's mirrors its scale.
+        found = {id(m): False for m in (nerf, bg)}
+        if optimizer_step and nerf.loss_scaler is not None:
+            for m in models:
+                if m.loss_scaler is not None:
+                    found[id(m)] = m._found_inf()
+            nerf.loss_scaler.update(any(found.values()))
+            nerf._loss_scale_tensor()
+            if bg.loss_scaler is not None:
+                bg.loss_scaler.scale = nerf.loss_scaler.scale
+                bg._loss_scale_tensor()
+        for m in models:
+            if optimizer_step and not found[id(m)]:
+                sc = scale[id(m)]
                 if m.loss_scaler is not None:            # fp16: the gradient carries the loss scale (backward above)
-                    scale /= m._applied_loss_scale
+                    sc /= m._applied_loss_scale
                 m.step_count += 1
-                ops.adam_step(m.flat, m.grad, m.m, m.v, None, m.step_count, m.lr, grad_scale=scale)
+                ops.adam_step(m.flat, m.grad, m.m, m.v, None, m.step_count, m.lr, grad_scale=sc)
                 m.refresh_compute_copies()
         return dict(loss=loss, photo_loss=photo, gate_loss=gate_loss, psnr=-10.0 * torch.log10(photo), rgb=ctx["rgb"],
                     depth=ctx["depth"], depth_variance=ctx["depth_variance"].mean(), ctx=ctx, bg_nerf_rays_present=bg_present)

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void route_keys_kernel(const int32_t* __restri
 #pragma unroll
   for (int u = 0; u < KPB / 256; ++u) {
     const long i = b0 + u * 256 + threadIdx.x;
-    int e = -1, seg = seg0;
+    int e = -1, seg = -1;            // (lanes past the last token: no expert, no segment)
     if (i < n_tokens) {
       e = idx[i];
       uint32_t inv = 0;
@@ -41,9 +41,11 @@ __global__ __launch_bounds__(256) void route_keys_kernel(const int32_t* __restri
       seg = (int)(i / seg_tokens);
       vals[i] = (int32_t)(i - (long)seg * seg_tokens);
     }
-    // a wave inside one segment (the usual case) counts with one ballot per expert and adds once per expert
-    const int seg_first = __shfl(seg, 0), seg_last = __shfl(seg, 63);
-    if (seg_first == seg_last && seg_first - seg0 < 2) {
+    // a wave inside one segment (the usual case) counts with one ballot per expert and adds once per expert.  Every VALID lane must
+    // agree on the segment: with segments shorter than a wave, lanes 0 and 63 alone (lane 63 past the last token) can sit in one
+    // segment while the lanes between them are in the next - those tokens would be credited to the wrong segment's counts.
+    const int seg_first = __shfl(seg, 0);
+    if (seg_first >= 0 && __all(e < 0 || seg == seg_first) && seg_first - seg0 < 2) {
       for (int q = 0; q < E; ++q) {
         const unsigned long long m = __ballot(e == q);
         if (lane == 0 && m) atomicAdd(&h[seg_first - seg0][q], (int)__popcll(m));

@@ -765,9 +765,14 @@ extern "C" size_t swn_wgrad_multi_workspace_bytes(int n_jobs, int n_wsets) {
   return (size_t)WS_HDR_INTS * 4 + ((size_t)ws_n_wg() + (size_t)n_jobs * n_wsets) * WS_TILE * sizeof(float);
 }
 
+// the groupings the stream kernel's LDS tables hold (checked on EVERY swn_wgrad_multi call: an oversized grouping would overrun them)
+static bool ws_geometry_ok(int n_groups, int n_wsets) {
+  return n_groups % n_wsets == 0 && n_groups <= WS_MAX_GROUPS && n_wsets <= WS_MAX_PIECES / WS_MAX_JOBS && n_wsets + 2 <= WS_HDR_INTS;
+}
+// ... and whether swn_wgrad / swn_wgrad_blocks route to it (SWN_WGRAD_LEGACY keeps them on the row-split kernel: experiments)
 static bool ws_eligible(int n_groups, int n_wsets) {
   static const bool legacy = getenv("SWN_WGRAD_LEGACY") != nullptr;
-  return !legacy && n_groups % n_wsets == 0 && n_groups <= WS_MAX_GROUPS && n_wsets <= WS_MAX_PIECES / WS_MAX_JOBS && n_wsets + 2 <= WS_HDR_INTS;
+  return !legacy && ws_geometry_ok(n_groups, n_wsets);
 }
 
 extern "C" int swn_wgrad_multi(const swn_wgrad_job* jobs, int n_jobs, int dtype, int n_groups, int n_wsets, int group_stride,
@@ -776,7 +781,7 @@ extern "C" int swn_wgrad_multi(const swn_wgrad_job* jobs, int n_jobs, int dtype,
   SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_wgrad_multi: bad dtype %d", dtype);
   SWN_CHECK(jobs && n_jobs >= 1 && n_jobs <= WS_MAX_JOBS, "swn_wgrad_multi: 1..%d jobs", WS_MAX_JOBS);
   SWN_CHECK(n_groups >= 1 && n_wsets >= 1 && group_stride >= 1, "swn_wgrad_multi: bad geometry");
-  SWN_CHECK(ws_eligible(n_groups, n_wsets) || getenv("SWN_WGRAD_LEGACY"), "swn_wgrad_multi: n_groups (%d) must be a multiple of n_wsets (%d) and <= %d", n_groups,
+  SWN_CHECK(ws_geometry_ok(n_groups, n_wsets), "swn_wgrad_multi: n_groups (%d) must be a multiple of n_wsets (%d) and <= %d", n_groups,
             n_wsets, WS_MAX_GROUPS);
   SWN_CHECK(tag == 0 || tag == 1, "swn_wgrad_multi: tag must be 0 or 1");
   WsArgs p;

@@ -11,24 +11,50 @@ from __future__ import annotations
 
 import torch
 
+MAX_CACHED_GRAPHS = 8
+
+
+def cached_graph(cache: dict, key, make):
+    """cache[key], created with make() on a miss; the cache holds at most MAX_CACHED_GRAPHS captured graphs (least recently used one
+    dropped: a graph owns a private memory pool with every activation of its batch shape).  Dropping a graph is safe - the buffers a
+    capture bakes in besides its own pool (the model's cached buffers, the library workspaces of ops.py) are never freed."""
+    g = cache.pop(key, None)
+    if g is None:
+        while len(cache) >= MAX_CACHED_GRAPHS:
+            cache.pop(next(iter(cache)))
+        g = make()
+    cache[key] = g              # (re-inserted: dict order = recency)
+    return g
+
 
 class GraphedTrainStep:
     """step = GraphedTrainStep(model, rgbs, rays, image_indices, n_samples, seg_tokens, ...); res = step(rgbs, rays, image_indices)
 
     Same result dict as SwitchNeRF.train_step (tensors live in static graph memory: read them before the next call).  The inputs
     are copied into static buffers; stratified jitter (perturb > 0) and the sigma noise (noise_std > 0) are drawn inside the
-    graph from the device generator, like rendering.py:582 / :366.  Only the plain (non-hierarchical, non-mip) step is graphed."""
+    graph from the device generator, like rendering.py:582 / :366.  Only the plain (non-hierarchical, non-mip) step is graphed.
+
+    split_backward (default: on when torch.distributed runs more than one rank): the step is captured as TWO graphs cut behind the
+    expert weight gradients (SwitchNeRF.backward_net_a / _b).  Between the replays the all-reduce of the expert block of the flat
+    gradient - final at that point, 14.7 of 15.8 MB - is issued on the model's side stream and travels while the second graph (router
+    backward, front backward chain, dense weight gradients: a quarter of the step) runs; the dense prefix follows behind it.  This is
+    the overlap DDP's buckets give the reference (runner.py:203-207); with one all-reduce behind the whole backward nothing hides it
+    at 1024 rays per GPU.  Results are bit-identical to the single-graph step (same sums over the same ranks)."""
 
     def __init__(self, model, rgbs, rays, image_indices, n_samples: int, seg_tokens: int, perturb: float = 1.0, noise_std: float = 1.0,
-                 routing_override=None, warmup: int = 2):
-        if model.ep is not None and model.ep.world > 1:
-            raise ValueError("GraphedTrainStep: the expert-parallel step issues RCCL collectives between its kernels and is not captured; "
-                             "use SwitchNeRF.train_step")
+                 routing_override=None, warmup: int = 2, split_backward=None):
+        if model.ep is not None and model.ep.world > 1 and not getattr(model.ep, "capturable", False):
+            raise ValueError("GraphedTrainStep: the expert-parallel step with unequal (host-sized) splits issues RCCL collectives between "
+                             "its kernels and is not captured; use SwitchNeRF.train_step, or ExpertParallel(..., padded=True)")
         self.model = model
         dev = model.dev
         self.rgbs, self.rays, self.idx = rgbs.clone(), rays.clone(), image_indices.clone()
         N, S = rays.shape[0], int(n_samples)
         P = N * S
+        if split_backward is None:
+            import torch.distributed as dist
+            split_backward = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.split = bool(split_backward) and model.ep is None
         if model.loss_scaler is not None:
             model._loss_scale_tensor()                     # exists before the capture (it is read, not created, inside the graph)
         ro = None if routing_override is None else routing_override.to(dev).int().contiguous()
@@ -37,19 +63,26 @@ class GraphedTrainStep:
             pr = torch.rand(N, S, device=dev) if perturb > 0 else None
             noise = torch.randn(P, device=dev) * noise_std if noise_std > 0 else None
             return model.grad_step(self.rgbs, self.rays, self.idx, S, min(int(seg_tokens), P), perturb=perturb, perturb_rand=pr,
-                                   sigma_noise=noise, routing_override=ro)
+                                   sigma_noise=noise, routing_override=ro, split=self.split)
 
         was_profile, model.profile = model.profile, False
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up on a side stream: allocates every cached buffer / workspace
             for _ in range(max(1, warmup)):
-                run()
+                r_ = run()
+                if self.split:
+                    model.backward_net_b(r_["bwd_b"])
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=side):
             self.res = run()
+        self.graph_b = None
+        if self.split:
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b, stream=side, pool=self.graph.pool()):
+                model.backward_net_b(self.res["bwd_b"])
         self.copies = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.copies, stream=side):
             model.refresh_compute_copies()
@@ -64,9 +97,15 @@ class GraphedTrainStep:
         if image_indices is not None:
             self.idx.copy_(image_indices)
         self.graph.replay()
+        ar = grad_allreduce
+        if self.graph_b is not None:
+            if ar is not None and hasattr(ar, "begin"):
+                ar.begin(m.grad[m.n_dense:], m.side)       # the expert block is final: it travels under the second backward graph
+                ar = lambda _view, f=grad_allreduce: f.finish(m.grad[: m.n_dense])
+            self.graph_b.replay()
         # all-reduce, loss-scale handling (fp16: inf check, skipped step, scale update - the captured step reads the scale from a
         # device scalar), Adam and the refresh of the compute copies (a second small graph): SwitchNeRF.apply_step
-        m.apply_step(grad_allreduce, optimizer_step, refresh=self.copies.replay)
+        m.apply_step(ar, optimizer_step, refresh=self.copies.replay)
         return self.res
 
 
@@ -192,10 +231,13 @@ class GraphedRenderTrain:
             bwd(self.state)
         model.profile = was_profile
 
+    generation = 0           # forward replays so far: the static activation buffers belong to the LAST one (autograd.py checks it)
+
     def forward(self, rays, image_indices):
         self.rays.copy_(rays)
         self.idx.copy_(image_indices)
         self.fwd_graph.replay()
+        self.generation += 1
         return self.state, self.outs
 
     def backward(self, d_rgb, d_laux_c, d_laux_f):

@@ -621,10 +621,10 @@ class SwitchNeRF:
         self.backward_net(c, d_raw, d_laux)
 
     def backward_net(self, c, d_raw, d_laux):
-        """Backward of _net_forward given dL/d raw [N*S, 4] and dL/d l_aux[seg]; accumulates into self.grad."""
-        o, dt = ops, self.dtype
-        if c.get("no_grad"):
-            raise RuntimeError("this context comes from an inference forward (training=False): nothing was saved for the backward")
+        """Backward of _net_forward given dL/d raw [N*S, 4] and dL/d l_aux[seg]; accumulates into self.grad.
+        = backward_net_a (heads, tail, expert chain, expert weight gradients: after it the EXPERT block of the flat gradient - 93 % of
+        its bytes - is final) + backward_net_b (router, front chain, dense weight gradients).  A data-parallel step replayed from
+        graphs cuts there: the all-reduce of the expert block travels while the second half runs (graph.GraphedTrainStep)."""
         if c.get("parts") is not None:
             # a ragged last model chunk (rendering.py:354-383 trains any batch size): the whole chunks and the short last chunk were
             # routed as two contexts with their own capacities; each runs its own backward on its rows of dL/d raw and its chunks'
@@ -635,6 +635,16 @@ class SwitchNeRF:
             self.backward_net(a, d_raw[: a["P"]], d_laux[: a["n_seg"]].contiguous())
             self.backward_net(b, d_raw[a["P"]:], d_laux[a["n_seg"]:].contiguous())
             return
+        self.backward_net_b(self.backward_net_a(c, d_raw, d_laux))
+
+    def backward_net_a(self, c, d_raw, d_laux, join_side=False):
+        """First half of backward_net (see there); returns the state backward_net_b continues from.  join_side: the launch stream
+        waits for the expert weight gradients before returning (they run on the side stream otherwise and are joined at the end of
+        the second half)."""
+        o, dt = ops, self.dtype
+        if c.get("no_grad"):
+            raise RuntimeError("this context comes from an inference forward (training=False): nothing was saved for the backward")
+        assert c.get("parts") is None, "ragged contexts go through backward_net"
         N, S, P, n_seg, cap, seg_tokens = c["N"], c["S"], c["P"], c["n_seg"], c["cap"], c["seg_tokens"]
         M, E, L, G, H2 = self.M, self.E, self.L, self.G, self.H2
         g = self.g
@@ -743,15 +753,15 @@ class SwitchNeRF:
                 bz = dz_last if l == L - 1 else dz[l]
                 items.append((a, bz, self._local_experts(g[f"exp{l}.w"]), self._local_experts(g[f"exp{l}.b"]),
                               perm if l == 0 else None, perm if l == L - 1 else None))
-            if ep is not None and M <= 256:      # received rows are packed: groups through their first rows
+            if ep is not None:      # received rows are packed: groups through their first rows (any width: wgrad_multi cuts 512-feature
                 o.wgrad_multi(items, n_groups=ng, n_wsets=n_loc, group_stride=cap, group_rows=grp_rows, group_rows_clamp=cap, tag=1,
-                              group_begin=c["ep_begin"])
+                              group_begin=c["ep_begin"])      # operands into 256-column GEMMs of the same launch)
                 return
             for i0 in range(0, L, 8):
                 o.wgrad_batched(items[i0:i0 + 8], n_groups=ng, n_wsets=n_loc, group_stride=cap, group_rows=grp_rows,
                                 group_rows_clamp=cap, n_splits=self.expert_wgrad_splits or max(1, min(256 // ng, cap // 2048)), tag=1)
         side_done = None
-        if self.overlap and self.side is not None and not self.profile:
+        if self.overlap and self.side is not None and not self.profile and not join_side:
             # independent of everything that follows (they only read the saved activations / dZ and write their own
             # gradient slices): run them on the side stream, join before Adam
             ready = torch.cuda.Event()
@@ -766,6 +776,18 @@ class SwitchNeRF:
                 expert_wgrads()
             if self.profile and "_relaunch" in c:
                 c["_relaunch"]["expert_wgrad"] = expert_wgrads        # (accumulates into the gradient buffer again: timing only)
+        return dict(c=c, d_laux=d_laux, dgmax=dgmax, dx=dx, dout=dout, returns=returns if ep is not None else None, tail_jobs=tail_jobs,
+                    nsp=nsp, side_done=side_done)
+
+    def backward_net_b(self, st):
+        """Second half of backward_net: router backward, front backward chain, dense weight gradients (+ the hash table's)."""
+        o, dt = ops, self.dtype
+        c, d_laux, dgmax, dx, returns, tail_jobs, nsp, side_done = (st[k] for k in ("c", "d_laux", "dgmax", "dx", "returns", "tail_jobs",
+                                                                                   "nsp", "side_done"))
+        P, seg_tokens = c["P"], c["seg_tokens"]
+        M, E, G = self.M, self.E, self.G
+        g, ep = self.g, self.ep
+        _b = lambda name, shape, dtype: self._buf(c["tag"] + ":" + name, shape, dtype)
         # gate backward (softmax / router / LayerNorm) including the l_aux term
         coef = (d_laux * (E / float(seg_tokens * seg_tokens))).to(torch.float32).contiguous()
         dg = o.gate_bwd(c["g"], self.p["ln.w"], self.p["ln.b"], self.p["wg"], c["gates"], c["idx"], dgmax, c["stats"],
@@ -808,10 +830,11 @@ class SwitchNeRF:
         return res
 
     def grad_step(self, rgbs, rays, image_indices, n_samples, seg_tokens, perturb=1.0, perturb_rand=None, sigma_noise=None,
-                  routing_override=None, fine_samples=0, fine_u=None, sigma_noise_fine=None):
+                  routing_override=None, fine_samples=0, fine_u=None, sigma_noise_fine=None, split=False):
         """Forward + loss + backward of one training step: fills self.grad (zeroed first) and returns the metrics.  Nothing here
         depends on host state that changes from step to step, so the whole launch sequence can be captured into a hipGraph
-        (graph.GraphedTrainStep).
+        (graph.GraphedTrainStep).  split=True (plain step only) stops after backward_net_a - the expert block of the gradient is final,
+        the launch stream has waited for it - and returns the second half's state as res["bwd_b"] (finish with backward_net_b).
         fine_samples > 0 adds the hierarchical pass (rendering.py:236-268): importance-sample fine depths from the coarse
         weights (detached), evaluate the network on them, sort-merge with the coarse samples, composite the union;
         loss = mse(rgb_fine) + wt * (mean(gate_loss_fine) + mean(gate_loss_coarse)) / 2."""
@@ -831,7 +854,12 @@ class SwitchNeRF:
         out4, d_rgb, d_la, d_lb = ops.step_loss(out["rgb"], rgbs.to(torch.float32).contiguous(), cf["l_aux"] if fine else c["l_aux"],
                                                 c["l_aux"] if fine else None, self.wt, ls)
         photo, gate_loss, loss, psnr = out4[0], out4[1], out4[2], out4[3]
-        if not fine:
+        bwd_b = None
+        if split:
+            if fine or c.get("parts") is not None or type(self).backward_net is not SwitchNeRF.backward_net:
+                raise ValueError("grad_step(split=True): the plain single-context step of a SwitchNeRF only")
+            bwd_b = self.backward_net_a(c, ops.composite_bwd(c["raw"], c["z"], d_rgb), d_la, join_side=True)
+        elif not fine:
             self.backward(c, d_rgb, d_la)
         else:
             d_raw_m = ops.composite_bwd(out["raw"], out["z"], d_rgb)
@@ -842,6 +870,8 @@ class SwitchNeRF:
                    depth_variance=out["depth_variance"].mean(), ctx=c, rgb=out["rgb"], depth=out["depth"])
         if fine:
             res["ctx_fine"] = cf
+        if split:
+            res["bwd_b"] = bwd_b
         return res
 
     def apply_step(self, grad_allreduce=None, optimizer_step=True, refresh=None):
@@ -871,19 +901,24 @@ class SwitchNeRF:
         self._ls_dev_val = v
         return self._ls_dev
 
-    def _unscale_ok(self) -> bool:
-        """GradScaler.step / update (runner.py:686-690): with loss scaling on, skip the optimizer step when a gradient is not finite
-        (one device-to-host flag per step, like torch's found_inf) and adapt the scale.  Always True without loss scaling.
-        Under expert parallelism the expert part of the gradient is rank-local (never all-reduced), so the flag is agreed over the
-        ranks (MAX): every rank skips - or takes - the same steps and holds the same scale."""
-        if self.loss_scaler is None:
-            return True
+    def _found_inf(self) -> bool:
+        """GradScaler's found_inf for THIS model's gradient (one device-to-host flag, like torch's): records the scale the backward
+        used (`_applied_loss_scale`, what the Adam step divides by).  Under expert parallelism the expert part of the gradient is
+        rank-local (never all-reduced), so the flag is agreed over the ranks (MAX): every rank skips - or takes - the same steps and
+        holds the same scale."""
         self._applied_loss_scale = self._ls_dev_val if self._ls_dev_val is not None else self.loss_scaler.scale   # what the backward used
         bad = (~torch.isfinite(self.grad).all()).to(torch.float32).view(1)
         if self.ep is not None and self.ep.world > 1:
             import torch.distributed as dist
             dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.ep.group)
-        found_inf = bool(bad.item() > 0)
+        return bool(bad.item() > 0)
+
+    def _unscale_ok(self) -> bool:
+        """GradScaler.step / update (runner.py:686-690): with loss scaling on, skip the optimizer step when a gradient is not finite
+        and adapt the scale.  Always True without loss scaling."""
+        if self.loss_scaler is None:
+            return True
+        found_inf = self._found_inf()
         self.loss_scaler.update(found_inf)
         self._loss_scale_tensor()           # the device copy follows (a captured step reads it on its next replay)
         return not found_inf

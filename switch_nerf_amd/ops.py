@@ -149,10 +149,8 @@ def route_top1(idx, gmax, gates, seg_tokens: int, n_experts: int, capacity: int,
     nbytes = _lib.load().swn_route_workspace_bytes(P, n_seg, n_experts)
     key = (dev, nbytes)
     ws = _route_ws.get(key)
-    if ws is None:      # one workspace per size, kept: a captured hipGraph may hold its address (coarse / fine passes alternate two sizes)
-        if len(_route_ws) >= 16:
-            _route_ws.pop(next(iter(_route_ws)))
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if ws is None:      # one workspace per size, kept for good: a captured hipGraph may hold its address (coarse / fine passes alternate
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)      # two sizes; a size follows the batch shape: a handful per process)
         _route_ws[key] = ws
     call("swn_route_top1", _p(idx), _p(gmax), _p(gates), P, int(seg_tokens), n_experts, int(capacity), int(bool(bpr)),
          _p(loc), _p(counts), _p(perm), _p(tok2row), _p(l_aux), _p(ws), nbytes, _stream())
@@ -539,11 +537,10 @@ def _wgrad_workspace(dev, nbytes: int):
     for ws in held:
         if ws.numel() >= nbytes:
             return ws
-    # a larger request: a NEW buffer next to the old ones (a captured hipGraph may still hold an old one's address; a handful of growth
-    # steps at most - the sizes depend on the job count and the weight sets only)
+    # a larger request: a NEW buffer next to the old ones, which are NEVER freed (a captured hipGraph may hold an old one's address
+    # for as long as the process lives; a handful of growth steps at most - the sizes depend on the job count and the weight sets only)
     ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
     held.insert(0, ws)
-    del held[4:]
     return ws
 
 
@@ -572,20 +569,31 @@ def wgrad(a, b, dw, db=None, n_groups=1, n_wsets=1, group_stride=None, group_row
 
 
 def wgrad_multi(jobs, n_groups=1, n_wsets=1, group_stride=None, group_rows=None, group_rows_clamp=None, tag=0, group_begin=None):
-    """jobs: tuples (a, b, dw, db, a_gather, b_gather) over ONE row grouping, each with its own widths (multiples of 32 up to 256):
-    the balanced stream launch (swn_wgrad_multi, include/swn.h) - up to 8 jobs per launch, the work cut into equal shares of the
-    valid rows, deterministic reduction.  dw [n_wsets, m, n] f32 (accumulated into), db [n_wsets, n] or None."""
+    """jobs: tuples (a, b, dw, db, a_gather, b_gather) over ONE row grouping, each with its own widths (multiples of 32):
+    the balanced stream launch (swn_wgrad_multi, include/swn.h) - up to 8 GEMMs per launch, the work cut into equal shares of the
+    valid rows, deterministic reduction.  dw [n_wsets, m, n] f32 (accumulated into), db [n_wsets, n] or None.  Operands wider than
+    256 features (the Mission Bay widths) are cut into 256-column blocks - one GEMM per (row block of dw, column block of dw) through
+    the per-job leading dimensions - so packed row spaces (group_begin: the rows an expert-parallel rank received) work at any width."""
     a0 = jobs[0][0]
     gs = int(group_stride if group_stride is not None else a0.shape[0])
-    for i0 in range(0, len(jobs), 8):
-        chunk = jobs[i0:i0 + 8]
+    esz = a0.element_size()
+    gemms = []              # (a ptr, b ptr, a_gather, b_gather, dw ptr, db ptr, m, n, lda, ldb, ldw, dw_set_stride, db_set_stride)
+    for (a, b, dw, db, ag, bg) in jobs:
+        m, n = a.shape[1], b.shape[1]
+        assert a.dtype == a0.dtype and b.dtype == a0.dtype and dw.shape[-2:] == (m, n) and dw.dtype == torch.float32
+        bm, bn = min(m, 256), min(n, 256)
+        assert m % bm == 0 and n % bn == 0, "operand widths above 256 must be multiples of 256"
+        for i in range(0, m, bm):
+            for j in range(0, n, bn):
+                gemms.append((a.data_ptr() + i * esz, b.data_ptr() + j * esz, _p(ag), _p(bg), dw.data_ptr() + (i * n + j) * 4,
+                              (db.data_ptr() + j * 4) if (db is not None and i == 0) else None, bm, bn, m, n, n, m * n, n))
+    for i0 in range(0, len(gemms), 8):
+        chunk = gemms[i0:i0 + 8]
         arr = (WgradJob * len(chunk))()
-        for jb, (a, b, dw, db, ag, bg) in zip(arr, chunk):
-            m, n = a.shape[1], b.shape[1]
-            assert a.dtype == a0.dtype and b.dtype == a0.dtype and dw.shape[-2:] == (m, n) and dw.dtype == torch.float32
-            jb.a, jb.b, jb.a_gather, jb.b_gather, jb.dw, jb.db = _p(a), _p(b), _p(ag), _p(bg), _p(dw), _p(db)
-            jb.m_dim, jb.n_dim, jb.lda, jb.ldb, jb.ldw = m, n, m, n, n
-            jb.dw_set_stride, jb.db_set_stride = m * n, n
+        for jb, (pa, pb, ag, bg, pdw, pdb, m, n, lda, ldb, ldw, dws, dbs) in zip(arr, chunk):
+            jb.a, jb.b, jb.a_gather, jb.b_gather, jb.dw, jb.db = pa, pb, ag, bg, pdw, pdb
+            jb.m_dim, jb.n_dim, jb.lda, jb.ldb, jb.ldw = m, n, lda, ldb, ldw
+            jb.dw_set_stride, jb.db_set_stride = dws, dbs
         ws = _wgrad_workspace(a0.device, _multi_ws_bytes(len(chunk), n_wsets))
         call("swn_wgrad_multi", arr, len(chunk), _dt(a0), int(n_groups), int(n_wsets), gs, _p(group_rows),
              int(group_rows_clamp if group_rows_clamp is not None else gs), _p(group_begin), int(tag), _p(ws), ws.numel(), _stream())

@@ -38,16 +38,93 @@ def shard_rays(n_rays: int, rank: int, world: int) -> Tuple[int, int]:
     return rank * per, (rank + 1) * per
 
 
-def make_grad_allreduce(group=None) -> Callable[[torch.Tensor], float]:
-    """Returns f(flat_grad) -> grad_scale: sums the flat gradient buffer over ranks in place (one bucket) and returns
-    the 1/world factor that swn_adam_step applies."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+class GradAllReduce:
+    """The data-parallel gradient all-reduce (RCCL over xGMI with backend "nccl").
 
-    def f(flat: torch.Tensor) -> float:
-        if world > 1:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        return 1.0 / world
-    return f
+        f = GradAllReduce(group);  scale = f(flat_grad)          # one bucket, in place; returns the 1 / world factor Adam applies
+
+    Overlapped form - what DDP's buckets do in the reference (runner.py:203-207: gradients are reduced while the backward still
+    runs) - for a backward pass that is cut in two (SwitchNeRF.backward_net_a / _b, graph.GraphedTrainStep with two backward graphs):
+
+        f.begin(grad[n_dense:], side_stream)     # after the first half: the expert block (93 % of the bytes) is final and travels on
+                                                 # the side stream while the second half (router, front chain, dense weight
+                                                 # gradients) runs on the launch stream
+        scale = f.finish(grad[:n_dense])         # after the second half: the dense prefix, then the launch stream joins the side stream
+
+    Both forms sum the same elements over the same ranks: results are bit-identical.  profile = True records HIP events around the
+    collectives and the launch stream's waits (report())."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.profile = False
+        self._pending = None
+        self._ev = []            # (kind, start, end)
+
+    def _timed(self, kind, fn):
+        if not self.profile or not torch.cuda.is_available():
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = fn()
+        b.record()
+        self._ev.append((kind, a, b))
+        return out
+
+    def __call__(self, flat: torch.Tensor) -> float:
+        if self.world > 1:
+            self._timed("coll", lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group))
+        return 1.0 / self.world
+
+    def begin(self, part: torch.Tensor, stream=None):
+        """Start the all-reduce of `part` (final already) on `stream`, ordered after the work queued on the current stream."""
+        assert self._pending is None, "GradAllReduce.begin: the previous overlapped all-reduce was not finished"
+        if self.world == 1:
+            self._pending = (None, part)
+            return
+        if stream is None or not part.is_cuda:
+            self._pending = (dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True), part)
+            return
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(stream):
+            stream.wait_event(ready)
+
+            def issue():
+                w = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.profile:
+                    w.wait()         # (orders `stream` after the collective so that the closing event times it)
+                return w
+            work = self._timed("coll", issue)
+        self._pending = (work, part)
+
+    def finish(self, rest: torch.Tensor) -> float:
+        """All-reduce `rest` on the current stream, then make the current stream wait for the part begin() sent."""
+        assert self._pending is not None, "GradAllReduce.finish without begin"
+        work, part = self._pending
+        self._pending = None
+        if self.world > 1:
+            if rest.numel():
+                self._timed("coll", lambda: dist.all_reduce(rest, op=dist.ReduceOp.SUM, group=self.group))
+            self._timed("wait", work.wait)
+            if part.is_cuda:
+                part.record_stream(torch.cuda.current_stream())
+        return 1.0 / self.world
+
+    def report(self):
+        """(after a synchronize) per profiled step set: total time of the collectives, time the launch stream waited for the early part,
+        and the hidden fraction 1 - wait / (time of the early collective)."""
+        coll = sum(a.elapsed_time(b) for k, a, b in self._ev if k == "coll")
+        wait = sum(a.elapsed_time(b) for k, a, b in self._ev if k == "wait")
+        n = sum(1 for k, _a, _b in self._ev if k == "coll")
+        self._ev = []
+        return dict(collectives=n, allreduce_ms=coll, wait_ms=wait, hidden_fraction=(1.0 - wait / coll) if coll > 0 else None)
+
+
+def make_grad_allreduce(group=None) -> GradAllReduce:
+    """Returns f(flat_grad) -> grad_scale: sums the flat gradient buffer over ranks in place (one bucket) and returns
+    the 1/world factor that swn_adam_step applies; f.begin / f.finish: the overlapped two-part form (GradAllReduce)."""
+    return GradAllReduce(group)
 
 
 

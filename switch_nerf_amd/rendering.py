@@ -104,13 +104,11 @@ def _render_rays_graphed(nerf, rays, image_indices, hparams, N, S, F, chunk, get
     """Evaluation with `nerf.graph_eval = True`: the forward of this batch shape is captured once (graph.GraphedRender, cached on the
     model per (rays, samples, fine samples, chunk, no_batch)) and replayed - Runner.render_image's pixel-batch loop
     (runner.py:2835-2885) is ~60 launches per call otherwise.  Results are cloned out of the graph's static memory."""
-    from .graph import GraphedRender
+    from .graph import GraphedRender, cached_graph
     cache = nerf.__dict__.setdefault("_render_graphs", {})
     key = (N, S, F, int(chunk), bool(nerf.moe_no_batch), nerf.dtype)
     nerf._sync_compute_copies()
-    g = cache.get(key)
-    if g is None:
-        g = cache[key] = GraphedRender(nerf, rays.contiguous(), image_indices, S, chunk, F, nerf.moe_no_batch)
+    g = cached_graph(cache, key, lambda: GraphedRender(nerf, rays.contiguous(), image_indices, S, chunk, F, nerf.moe_no_batch))
     o = g(rays, image_indices)
     typ = "fine" if F > 0 else "coarse"
     res = {f"rgb_{typ}": o["rgb"].clone(), "gate_loss_coarse": o["l_aux_coarse"].clone()}

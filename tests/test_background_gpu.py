@@ -214,6 +214,36 @@ def test_background_bf16_step_close_to_fp32_and_adam_updates_both():
     assert abs(out[torch.float32][1] - out[torch.bfloat16][1]) < 2e-2 * out[torch.float32][1]
 
 
+def test_background_fp16_one_shared_grad_scaler():
+    """The reference holds ONE GradScaler over both optimizers (runner.py:483, 686-690): GradScaler.step skips an optimizer on ITS OWN
+    non-finite gradient, GradScaler.update backs the shared scale off when EITHER found one.  An overflow in the background gradient
+    alone must therefore halve the shared scale, skip the background step only, and reset the growth tracker."""
+    from switch_nerf_amd.background import BackgroundScene
+    N, S = 256, 64
+    rays, img, rgbs = synth.make_bg_rays(131, N)
+    m, b = _models(torch.float16, 133, 134)
+    scene = BackgroundScene(m, b, CENTER, RADIUS)
+    m.loss_scaler.scale = 1024.0
+    m.loss_scaler._good = 7
+    st = scene.train_step(_dev(rgbs), _dev(rays), _dev(img), S, 4096, perturb=0.0)
+    assert st["ctx"]["Nb"] > 0 and m.step_count == 1 and b.step_count == 1
+    assert m.loss_scaler.scale == 1024.0 and b.loss_scaler.scale == 1024.0 and m.loss_scaler._good == 8
+    # poison the BACKGROUND gradient only: its backward accumulates into bg.grad, so a non-finite value planted in a parameter the
+    # foreground never reads (the background's own first-layer bias) makes bg.grad non-finite and leaves nerf.grad finite
+    fg_before, bg_before = m.flat.clone(), b.flat.clone()
+    orig_backward = scene.backward
+
+    def poisoned(*a, **k):
+        orig_backward(*a, **k)
+        b.grad[0] = float("inf")
+    scene.backward = poisoned
+    scene.train_step(_dev(rgbs), _dev(rays), _dev(img), S, 4096, perturb=0.0)
+    scene.backward = orig_backward
+    assert m.step_count == 2 and b.step_count == 1                      # each optimizer skips on ITS OWN found_inf
+    assert (m.flat != fg_before).any() and torch.equal(b.flat, bg_before)
+    assert m.loss_scaler.scale == 512.0 and b.loss_scaler.scale == 512.0 and m.loss_scaler._good == 0      # ONE scaler: backed off for both
+
+
 def test_background_model_call_mirror_on_explicit_points():
     """NeRF.forward of the xyz_dim = 4 background model on explicit inverted-sphere points (nerf.py:143-190)."""
     from switch_nerf_amd.dense import DenseNeRF

@@ -236,22 +236,33 @@ def test_full_segment_bf16_vs_autocast_oracle():
     assert d_rgb <= 2.0 ** -7
     assert abs(st["loss"].item() - o2["loss"].item()) <= 1e-2 * abs(o2["loss"].item())
     np.testing.assert_allclose(c["l_aux"].cpu().numpy(), res["gate_loss_coarse"].numpy(), rtol=2e-3)
-    # the backward of the benchmarked dtype: every parameter gradient against the autocast oracle's autograd (activation gradients
-    # rounded to bf16 on both sides, in slightly different places: the oracle - like the reference's autocast backward - also rounds
-    # the dW products' inputs; the HIP weight-gradient GEMMs accumulate bf16 operands in fp32).  Tensors agree in norm to a few %.
+    # The backward of the benchmarked dtype, THREE-WAY: the fp32 oracle (same routing, same inputs) is the truth both 16-bit paths
+    # approximate.  Per parameter tensor:  e_hip = ||g_HIP_bf16 - g_fp32||,  e_ac = ||g_autocast - g_fp32||  (Frobenius).  The HIP path
+    # rounds where the reference's autocast rounds and is MORE precise in four places (docstring), so its gradient must sit at least as
+    # close to the fp32 gradient as the autocast oracle's does: e_hip <= 1.1 e_ac for EVERY tensor, the sigma head included (its
+    # gradient is a sum of cancelling per-point terms: the two 16-bit results differ from each other by ~0.8 of its norm - round 3
+    # could only bound it to "the same order of magnitude" - but both are compared with the truth here).
+    p32 = O.params_from_numpy(sd, requires_grad=True)
+    kw32 = dict(kw)
+    kw32.pop("autocast")
+    o3 = O.training_step(p32, torch.from_numpy(rays), torch.from_numpy(img), torch.from_numpy(rgbs), synth.BUILDING, S, chunk,
+                         routings=[dict(idx=idx, loc=loc, capacity=c["cap"])], **kw32)
+    o3["loss"].backward()
     gd = m.grad_dict()
-    worst, worst_k = 0.0, ""
+    worst, worst_k, lines = 0.0, "", []
     for k, t in p.items():
-        ref = t.grad.numpy()
-        got = gd[k].cpu().numpy()
-        fro = np.linalg.norm((got - ref).ravel()) / (np.linalg.norm(ref.ravel()) + 1e-20)
-        if fro > worst and "sigma" not in k:
-            worst, worst_k = fro, k
-        if "sigma" in k:      # a sum of cancelling per-point terms (relative difference 0.77 observed): same order of magnitude only
-            assert 0.2 <= np.linalg.norm(got.ravel()) / (np.linalg.norm(ref.ravel()) + 1e-20) <= 5.0, (k, fro)
-            continue
-        assert fro <= 0.15, (k, fro)       # (observed: ~0.08 on the first expert layer)
-    print(f"bf16 full segment vs autocast oracle: worst relative (Frobenius) parameter-gradient difference {worst:.3e} ({worst_k})")
+        g32 = p32[k].grad.numpy().ravel().astype(np.float64)
+        g_ac = t.grad.numpy().ravel().astype(np.float64)
+        g_hip = gd[k].cpu().numpy().ravel().astype(np.float64)
+        n32 = np.linalg.norm(g32) + 1e-30
+        e_hip, e_ac = np.linalg.norm(g_hip - g32) / n32, np.linalg.norm(g_ac - g32) / n32
+        ratio = e_hip / max(e_ac, 1e-30)
+        lines.append(f"    {k}: e_hip {e_hip:.3e}  e_autocast {e_ac:.3e}  ratio {ratio:.3f}")
+        if ratio > worst:
+            worst, worst_k = ratio, k
+    print("bf16 full segment, parameter gradients against the fp32 oracle (relative Frobenius distance):\n" + "\n".join(lines))
+    print(f"bf16 full segment: worst e_hip / e_autocast = {worst:.3f} ({worst_k})")
+    assert worst <= 1.1, (worst_k, worst)
 
 
 def test_mission_bay_recipe_mip_512_wide_16_experts_vs_oracle_fp32():

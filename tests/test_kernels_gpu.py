@@ -150,6 +150,11 @@ def test_route_ragged_and_ties_and_scale():
     _route_check(synth.make_gates(104, 4 * 131072, 8, 3.0), 131072, 8, 1.0, True)               # BASELINE size, 4 segments
     _route_check(synth.make_gates(105, 2 * 2000, 4, 1.0), 2000, 4, 1.0, False)
     _route_check(np.full((512, 8), 0.125, np.float32), 512, 8, 1.0, True)                       # everything ties
+    # segments shorter than a wavefront, the tokens ending inside a wave: lanes 0 and 63 of a wave alone do not tell its segments
+    # (route_keys_kernel's wave-uniform fast path must look at every valid lane)
+    _route_check(synth.make_gates(106, 3 * 40, 8, 1.0), 40, 8, 1.0, True)
+    _route_check(synth.make_gates(107, 5 * 24, 4, 2.0), 24, 4, 1.0, False)
+    _route_check(synth.make_gates(108, 2 * 70, 8, 1.0), 70, 8, 1.25, True)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -260,6 +260,38 @@ def test_expert_parallel_path_single_rank_equals_local_experts(dtype):
         assert (a - b).abs().max().item() <= 1e-5 * max(a.abs().max().item(), 1e-12), name
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_expert_parallel_path_512_wide_equals_local_experts(dtype):
+    """the expert-parallel path keeps the received rows PACKED (groups addressed through ep_begin); with 512-feature
+    experts (mission_bay.yaml widths) the expert weight gradients must honour that packing too (ops.wgrad_multi cuts the 512-wide
+    operands into 256-column GEMMs of the balanced launch, group_begin included).  World = 1 against the default path, unbalanced
+    routing (gate_scale 1: the groups are far from full, so packed rows and capacity slots differ)."""
+    from switch_nerf_amd.model import SwitchNeRF
+    from switch_nerf_amd.parallel import ExpertParallel
+    cfg = dict(synth.BUILDING, model_dim=512, gate_hidden=512, num_experts=16)
+    N, S, chunk = 64, 64, 2048
+    sd = synth.make_weights(161, cfg, gate_scale=1.0)
+    rays, img, rgbs = synth.make_rays(162, N)
+    outs = []
+    for use_ep in (False, True):
+        m = SwitchNeRF(cfg, dtype=dtype)
+        m.load_state_dict(sd)
+        if use_ep:
+            m.set_expert_parallel(ExpertParallel(0, 1, m.E))
+        st = m.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0, optimizer_step=False)
+        kept = int(st["ctx"]["counts"].clamp(max=st["ctx"]["cap"]).sum().item())
+        assert 0 < kept < N * S                       # tokens are dropped and groups are ragged: the layouts really differ
+        outs.append((st["rgb"].clone(), st["loss"].clone(), m.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    g0, g1 = outs[0][2], outs[1][2]
+    for name, (off, shape) in m.spec.items():
+        n = int(np.prod(shape))
+        a, b = g0[off:off + n], g1[off:off + n]
+        assert (a - b).abs().max().item() <= 1e-5 * max(a.abs().max().item(), 1e-12), name
+    off, shape = m.spec["exp3.w"]
+    assert g0[off:off + int(np.prod(shape))].abs().sum().item() > 0
+
+
 @pytest.mark.parametrize("tag", ["det", "perturbed"])
 def test_mip_train_step_vs_reference_golden_fp32(tag):
     """Two-level mip training step (frustum casting + integrated encoding, weights blur + resampling, colour padding,

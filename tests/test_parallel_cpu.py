@@ -35,6 +35,42 @@ def test_dp_allreduce_and_sharding_gloo():
         assert head == [102.0, 101.0, 3.0] and mid == 3.0     # identical summed buffer on both ranks
 
 
+def _overlap_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from switch_nerf_amd import parallel
+    parallel.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(5 + rank)
+    flat = torch.randn(1000, generator=g)
+    ref = flat.clone()
+    f = parallel.make_grad_allreduce()
+    s0 = f(ref)                                          # one bucket
+    n_dense = 300                                        # overlapped form: the tail ("expert block") first, the prefix behind it
+    f.begin(flat[n_dense:])
+    flat[:n_dense] += 0.0                                # (the second half of the backward would run here)
+    s1 = f.finish(flat[:n_dense])
+    out[rank] = (s0, s1, bool(torch.equal(flat, ref)), ref[:4].tolist())
+    try:
+        f.finish(flat[:n_dense])
+        out[rank] += (False,)
+    except AssertionError:
+        out[rank] += (True,)
+    dist.destroy_process_group()
+
+
+def test_overlapped_two_part_allreduce_equals_one_bucket_gloo():
+    """GradAllReduce.begin / finish (the expert block travels between the two backward graphs, the dense prefix behind the second:
+    graph.GraphedTrainStep) sums the same elements over the same ranks as the one-bucket call: bit-identical buffers on every rank."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_overlap_worker, args=(world, 29331 + os.getpid() % 200, out), nprocs=world, join=True)
+    assert out[0][3] == out[1][3]
+    for r in range(world):
+        s0, s1, same, _head, guarded = out[r]
+        assert s0 == s1 == 0.5 and same and guarded
+
+
 def _route(rng, n_seg, seg_tokens, E, cap):
     """Random top-1 routing with capacity in the native layout of swn_route_top1: perm, counts, tok2row."""
     import numpy as np
