@@ -306,10 +306,13 @@ typedef struct swn_chain_desc {
                                    workgroups per CU, 4 = the 256-row workgroup with its two row groups half a layer apart
                                    (one group's epilogue beside the other's K loop; the accumulators start at the bias), 5 = the
                                    same with the bias added in the epilogue like every other geometry (bit-identical to them)
+                                   6 / 7 = geometry 5 / 4 as a PERSISTENT launch: one resident workgroup per CU walks a queue of
+                                   256-row tiles, a row group stages its next tile and writes its last one out while its partner
+                                   computes (no per-tile prologue / tail / fill phase; `sched` below)
                                    (chain_big.hip: chains of 256 x 256 layers, bf16 / fp16, no rowbias / x_scale / x_save /
                                    y_add_gather; swn_chain_big_ok).
-                                   The ReLU masks of the 64-row, 96-row and 256-row tiles are laid out differently (2, 4 and 5
-                                   share one layout): run a backward chain (relu = 2) on the tile geometry of the forward chain
+                                   The ReLU masks of the 64-row, 96-row and 256-row tiles are laid out differently (2, 4, 5, 6 and
+                                   7 share one layout): run a backward chain (relu = 2) on the tile geometry of the forward chain
                                    that recorded its masks.                                                                   */
   int32_t tag;                  /* profiling only: selects an identical kernel instantiation with its own symbol so that
                                    rocprofv3 reports the roles separately (0 generic, 1 expert fwd, 2 expert bwd,
@@ -337,6 +340,9 @@ typedef struct swn_chain_desc {
   const float* heads_bc;
   const float* heads_noise;
   float* heads_raw;
+  int32_t* sched;               /* geometry 6 / 7: device int32 [16] tile-queue counters, ZERO before the first launch that uses them
+                                   (the kernel leaves them zero); launches that may run concurrently need their own.  NULL: the tiles
+                                   are dealt round-robin over the resident workgroups (no balancing of ragged groups)          */
   swn_chain_layer layers[SWN_MAX_CHAIN_LAYERS];
 } swn_chain_desc;
 

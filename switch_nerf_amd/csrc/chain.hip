@@ -1056,7 +1056,7 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   }
   SWN_CHECK(d.tag >= 0 && d.tag <= 6, "swn_mlp_chain: tag %d not in [0,6]", d.tag);
   SWN_CHECK(!(wide && concat), "swn_mlp_chain: concat-skip layers are built for the 256-feature kernels only");
-  SWN_CHECK(d.geometry >= 0 && d.geometry <= 5, "swn_mlp_chain: geometry %d not in [0,5]", d.geometry);
+  SWN_CHECK(d.geometry >= 0 && d.geometry <= 7, "swn_mlp_chain: geometry %d not in [0,7]", d.geometry);
   if (d.comb_y) {
     const int nl = d.layers[d.n_layers - 1].n;
     SWN_CHECK(d.comb_gate && d.comb_dgate, "swn_mlp_chain: combine backward needs comb_gate and comb_dgate");
@@ -1067,7 +1067,7 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   {   // 256-row geometry (chain_big.hip).  Never chosen silently for bf16: the ReLU mask layout differs between the geometries,
       // and a backward chain must run on the geometry of the forward chain that recorded its masks - the caller pairs them.
     const bool can = chain_big_eligible(d);
-    SWN_CHECK(d.geometry < 2 || can, "swn_mlp_chain: geometry 2 / 3 / 4 needs bf16 / fp16 chains of 256 x 256 layers without rowbias / x_scale / x_save / y_add_gather");
+    SWN_CHECK(d.geometry < 2 || can, "swn_mlp_chain: geometries 2 - 7 need bf16 / fp16 chains of 256 x 256 layers without rowbias / x_scale / x_save / y_add_gather");
     if (d.geometry >= 2) return chain_big_launch(d, stream);
   }
   if (wide) return chain_wide_launch(d, stream);        // 512-feature geometry (this file compiled with -DSWN_WIDE=1)

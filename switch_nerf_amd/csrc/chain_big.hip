@@ -1013,6 +1013,390 @@ __global__ __launch_bounds__(512, 2) void chainp_kernel(const Args args) {
 #endif
 }
 
+
+// =================================================================================================================================
+// Geometry 6 / 7: the phase-shifted 256-row workgroup of geometry 4 / 5 made PERSISTENT.
+//
+// chainp_kernel pays a fixed price per 256-row tile around its 2 x n_layers phases: the prologue (source rows -> staging of both row
+// groups' input, two barriers and an HBM round trip that nothing overlaps: one workgroup per CU), the fill / drain phase of the
+// half-layer shift, and the tail (write-out of both row groups) - 14-23 k of ~110 k clocks on the 7-layer expert chain
+// (profiles/r03_experiments.md section 9), and as much as the useful phases themselves on a 2-3 layer chain.  Here ONE workgroup per CU
+// stays resident and walks a queue of tiles; the two row groups keep their half-layer offset ACROSS tiles:
+//     phase (per tile, 2 n + 1 of them):   S    K0   E0   K1   ...  K(n-1)  E(n-1) | S'   K0' ...
+//     row group 0                          S    K0   E0   K1        K(n-1)  E(n-1) | S'   K0'
+//     row group 1 (one phase behind)     E(n-1)'' S   K0   E0  ...  E(n-2)  K(n-1) | E(n-1) S'
+//   * S (stage) = a row group writes ITS output rows of the previous tile out (coalesced 1 KiB pieces) and brings the (gathered) input
+//     rows of its next tile into the same LDS rows by LDS-DMA - while its partner is in a K or E phase on the same SIMDs: the HBM round
+//     trip of the staging and the write-out are hidden behind the partner's work, there is no fill / drain phase any more;
+//   * the tile queue: per XCD x (workgroups b = x mod 8) one atomic counter q -> virtual block 8 q + x of chainp_kernel's grid, i.e. the
+//     SAME tile -> (group, rows) mapping (rotated expert per XCD), the same ReLU-mask layout - masks recorded by geometry 4 / 5 serve a
+//     geometry 6 / 7 backward and vice versa - but tiles past a ragged group's end cost one atomic instead of a workgroup launch slot, and
+//     the queue balances unequal groups by itself.  Wave 0 claims the tile AFTER next while the current one is staged and leaves its
+//     (group, first row, valid rows, weight set) in LDS for both row groups; the source rows of the next tile are fetched during the
+//     last epilogue phase.  The counters are left zeroed by the last workgroup (swn_chain_desc.sched: 16 ints, zero before the first
+//     launch); without them the tiles are dealt round-robin (b, b + grid, ...);
+//   * biases live in a 3-slot ring indexed by a running layer counter (the bias of the next tile's first layer arrives during the
+//     last K phase of this one), weight fragments as in geometry 4 (register ring, preloaded at the end of the preceding phase).
+// Arithmetic, rounding points and masks are chainp_kernel's: geometry 6 is bit-identical to geometry 5 (and to the 64-row kernels),
+// geometry 7 to geometry 4 (accumulators start at the bias).
+// =================================================================================================================================
+struct ArgsQ {
+  swn_chain_desc d;
+  int tiles_per_group;
+  int n_vb;            // virtual blocks = chainp_kernel's grid
+  int n_queues;        // 8: one queue per XCD (rotated mapping), 1: a single queue
+  int stagger;         // start offset between the workgroups of an XCD in units of ~1 k clocks (0: all start together)
+};
+
+constexpr int Q_IDX1 = G256::BIAS0 + 3072 + 64;      // second source-row table (int32 [256]); the first one is G256::IDX0
+constexpr int Q_TINFO = Q_IDX1 + 1024;               // int32 [2][8]: vb (-1 = none), group, first tile row, valid rows, first row (lo, hi), weight set
+constexpr int Q_LDS = Q_TINFO + 64;
+
+__device__ __forceinline__ void stage_pieces_q(const Ctx& cx, const char* x, int c0, int n, int stride, int idx_off) {
+  const int* idx = (const int*)(cx.smem + idx_off);
+#pragma unroll 4
+  for (int j = 0; j < n; ++j) {
+    const int c = c0 + j * stride;
+    const int r = 2 * c + cx.lhi;
+    const long src = idx[r];
+    const int q = cx.l31 ^ (r & 15);
+    __builtin_amdgcn_global_load_lds(SWN_GLB(x + src * ROWB + q * 16), SWN_LDS(cx.smem + c * 1024), 16, 0, 0);
+  }
+}
+
+template <typename E, int TAG, bool BIAS_INIT>
+__global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef G256 G;
+  constexpr int BM = G::BM, MI = 4;
+  const swn_chain_desc& d = args.d;
+  Ctx cx;
+  cx.smem = smem;
+  const int tid = threadIdx.x;
+  cx.lane = tid & 63;
+  cx.w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  cx.l31 = cx.lane & 31;
+  cx.lhi = cx.lane >> 5;
+  const int rg = cx.w >> 2, fg = cx.w & 3;
+  const int r15 = cx.lane & 15;
+  const int n_layers = d.n_layers;
+
+  // The per-lane LDS bases of a phase (fragment rows of the K loop, epilogue rows) are derived INSIDE the phase from a laundered lane
+  // id: nothing but the lane id itself lives across the phases (the K phase holds 208 registers of accumulators and fragment rings).
+  cx.a_base = cx.e_base = cx.e2_base = cx.wf_base = 0;
+  auto phase_ctx = [&](bool k_phase) -> Ctx {
+    Ctx c = cx;
+    asm volatile("" : "+v"(c.lane), "+s"(c.w));
+    c.l31 = c.lane & 31;
+    c.lhi = c.lane >> 5;
+    const int r15_ = c.lane & 15, rg_ = c.w >> 2, fg_ = c.w & 3;
+    const int lrow = 32 * MI * rg_ + c.l31;
+    if (k_phase) {
+      c.a_base = (uint32_t)(lrow * ROWB + ((c.lhi ^ r15_) << 4));
+    } else {
+      c.e_base = (uint32_t)(lrow * ROWB + (r15_ << 4) + 8 * c.lhi) ^ (uint32_t)(fg_ << 7);
+      c.e2_base = (uint32_t)(lrow * ROWB + (r15_ << 4)) ^ (uint32_t)((fg_ << 7) | (c.lhi << 4));
+    }
+    return c;
+  };
+  int* gcount = (int*)(smem + G::BIAS0 + 3072);
+  const int* tinfo = (const int*)(smem + Q_TINFO);      // (every reader sits behind a barrier that follows an asm memory clobber)
+
+  // ---- the tile queue (wave 0 only) ----
+  const int xq = args.n_queues == 8 ? (int)(blockIdx.x & 7) : 0;
+  int kq = 0;                                    // (no counters: the kq-th tile of this workgroup is block b + kq * grid)
+  auto grab = [&](int slot) {                    // the next tile with at least one valid row -> tinfo[slot] (vb = -1: the queue is empty)
+    int vb, g = 0, tile = 0, rows_valid = 0;
+    int n_groups = d.n_groups, tpg = args.tiles_per_group, n_wsets = d.n_wsets;
+    asm volatile("" : "+s"(n_groups), "+s"(tpg), "+s"(n_wsets));      // (divisors re-read here: their reciprocals must not live - in
+                                                                      //  vector registers - through the phases of the tile loop)
+    for (;;) {
+      int q;
+      if (d.sched) {
+        q = 0;
+        if (cx.lane == 0) q = __hip_atomic_fetch_add(d.sched + xq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        q = __builtin_amdgcn_readfirstlane(q);
+        vb = args.n_queues == 8 ? q * 8 + xq : q;
+      } else {
+        vb = (int)blockIdx.x + kq * (int)gridDim.x;
+        ++kq;
+      }
+      if (vb >= args.n_vb) { vb = -1; break; }
+      if ((n_wsets & 7) == 0 && (n_groups & 7) == 0) {           // chainp_kernel's mapping: XCD x meets every weight set in turn
+        const int x = vb & 7, qq = vb >> 3;
+        const int s_ = qq / tpg;
+        tile = qq - s_ * tpg;
+        g = ((x + s_) & 7) + 8 * s_;
+      } else {
+        tile = vb / n_groups;
+        g = vb - tile * n_groups;
+      }
+      rows_valid = d.group_stride;
+      if (d.group_rows) rows_valid = d.group_rows[g];
+      if (rows_valid > d.group_rows_clamp) rows_valid = d.group_rows_clamp;
+      if (tile * BM < rows_valid) break;
+    }
+    if (cx.lane == 0) {
+      int* t = (int*)(smem + Q_TINFO) + slot * 8;
+      t[0] = vb;
+      if (vb >= 0) {
+        const long grow0 = (d.group_begin ? (long)d.group_begin[g] : (long)g * d.group_stride) + (long)tile * BM;
+        t[1] = g;
+        t[2] = min(BM, rows_valid - tile * BM);
+        t[3] = (int)(uint32_t)(grow0 & 0xFFFFFFFFl);
+        t[4] = (int)(grow0 >> 32);
+        t[5] = g % n_wsets;
+      }
+    }
+  };
+  struct Tile { int vb, rows; long grow0; int wset; };
+  auto read_tile = [&](int slot) -> Tile {
+    Tile t;
+    t.vb = __builtin_amdgcn_readfirstlane(tinfo[slot * 8 + 0]);
+    t.rows = __builtin_amdgcn_readfirstlane(tinfo[slot * 8 + 2]);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane(tinfo[slot * 8 + 3]);
+    const int hi = __builtin_amdgcn_readfirstlane(tinfo[slot * 8 + 4]);
+    t.grow0 = ((long)hi << 32) | (long)lo;
+    t.wset = __builtin_amdgcn_readfirstlane(tinfo[slot * 8 + 5]);
+    return t;
+  };
+  auto finish = [&]() {                          // the last workgroup to leave zeroes the counters for the next launch
+    if (d.sched && cx.w == 0 && cx.lane == 0) {
+      const int done = __hip_atomic_fetch_add(d.sched + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (done == (int)gridDim.x - 1) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) __hip_atomic_store(d.sched + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  // source rows of the tile's rows of THIS row group (threads 0..127 of the row group: one row each): load, and - later - store into
+  // the idx table `idx_off` (two steps: the gather-index load of the NEXT tile is issued at the top of the last epilogue phase and
+  // looked at behind it)
+  auto load_row = [&](const Tile& t) -> int {
+    const int lt = fg * 64 + cx.lane;
+    int src = 0;
+    if (lt < 128) {
+      const int r = 128 * rg + lt;
+      const long gr = t.grow0 + (r < t.rows ? r : 0);          // rows past the end repeat the first row (computed, never stored)
+      src = d.x_gather ? d.x_gather[gr] : (int)gr;
+    }
+    return src;
+  };
+  auto store_row = [&](int src, int idx_off) {
+    const int lt = fg * 64 + cx.lane;
+    if (lt < 128) ((int*)(smem + idx_off))[128 * rg + lt] = src < 0 ? 0 : src;
+  };
+  auto wrs = [&](int L, int wset) -> __amdgpu_buffer_rsrc_t {
+    const char* p = (const char*)d.layers[L].w + (size_t)wset * 8 * (KSTEPS * 1024);
+    return uniform_rsrc(p, 8 * KSTEPS * 1024);
+  };
+  auto out_rs = [&](void* base, const Tile& t) -> __amdgpu_buffer_rsrc_t {
+    return uniform_rsrc((char*)base + t.grow0 * ROWB, t.rows * ROWB);
+  };
+  u32x4_t wq[4][2];
+  auto preload_w = [&](int L, int wset, int lane_) {
+    const __amdgpu_buffer_rsrc_t r = wrs(L, wset);
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wq[ks][i] = __builtin_amdgcn_raw_buffer_load_b128(r, lane_ * 16, ((2 * fg + i) * KSTEPS + ks) * 1024, 0);
+  };
+  auto stage_bias = [&](int L, int wset, int slot) {     // (the four waves of row group 0: 256 B each)
+    const float* b = d.layers[L].b;
+    if (b) {
+      const __amdgpu_buffer_rsrc_t rb = uniform_rsrc(b + (size_t)wset * 256, 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, SWN_LDS(smem + G::BIAS0 + slot * 1024 + fg * 256), 4, cx.lane * 4, fg * 256, 0, 0);
+    } else if constexpr (BIAS_INIT) {                    // the accumulators ALWAYS start at the slot's contents: no bias = zeros
+      *(float*)(smem + G::BIAS0 + slot * 1024 + fg * 256 + cx.lane * 4) = 0.f;
+    }
+  };
+  auto load_mask = [&](int L, int vb) -> u32x4_t {
+    const swn_chain_layer& l_ = d.layers[L];
+    if (l_.relu == 2) return *(const u32x4_t*)(l_.mask + ((size_t)(vb * G::NW + cx.w) * 64 + cx.lane) * 4);
+    return u32x4_t{0u, 0u, 0u, 0u};
+  };
+  constexpr bool bias_init = BIAS_INIT;
+
+  // Workgroups that start together on equal tiles reach their S phases together - every CU bursts its 64 KiB out and 64 KiB in at the
+  // same moment and the phase is as long as the whole chip's burst takes through HBM (measured: 7-9 k clocks).  A start offset
+  // per workgroup spreads the S phases of the CUs over the tile period.
+  for (int i = ((int)(blockIdx.x >> 3) & 15) * args.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(16);
+  // ---- prologue: the first tile, its source rows ----
+  if (cx.w == 0 && cx.lane < 2) gcount[cx.lane] = 0;
+  if (cx.w == 0) grab(0);
+  SWN_WAIT_LGKM0();
+  __builtin_amdgcn_s_barrier();
+  Tile cur = read_tile(0);
+  if (cur.vb < 0) { finish(); return; }          // (nothing for this workgroup: every wave sees the same)
+  store_row(load_row(cur), G::IDX0);
+  SWN_WAIT_LGKM0();
+  __builtin_amdgcn_s_barrier();
+  if (rg == 1) __builtin_amdgcn_s_barrier();     // row group 1 runs one phase behind from here on
+
+  f32x16_t acc[MI][2];
+  SWN_TM(const long long t_start = TICK(); long long tS = 0, tSb = 0, tK = 0, tKb = 0, tE = 0, tEb = 0, tSw = 0, tSi = 0;)
+  int n_skip = 0;
+  int it = 0;                                    // tiles this row group has started
+  int bc = 0;                                    // running layer counter: the bias of this row group's layer lives in slot bc % 3
+  Tile prev = cur;
+  for (;;) {
+    const int idx_cur = (it & 1) ? Q_IDX1 : G::IDX0, idx_nxt = (it & 1) ? G::IDX0 : Q_IDX1;
+    SWN_TM(const long long s0 = TICK();)
+    // ================= S phase: write-out of the previous tile's rows of this group, staging of this tile's =================
+    {
+      // (per-lane / per-wave coordinates re-derived from laundered ids: computed once outside the tile loop, the ~50 swizzled piece
+      //  addresses and scalar piece offsets of this phase would live - spilled - through every other phase)
+      Ctx cs = cx;
+      asm volatile("" : "+v"(cs.lane), "+s"(cs.w));
+      cs.l31 = cs.lane & 31;
+      cs.lhi = cs.lane >> 5;
+      const int rgs = cs.w >> 2, fgs = cs.w & 3;
+      if (it > 0) {
+        const __amdgpu_buffer_rsrc_t ry = out_rs(d.y, prev);
+        const __amdgpu_buffer_rsrc_t ra = d.y_add ? out_rs((void*)d.y_add, prev) : ry;
+        if (d.y_add) write_pieces16<E, true, 8>(cs, 64 * rgs + fgs, ry, ra); else write_pieces16<E, false, 8>(cs, 64 * rgs + fgs, ry, ra);
+        SWN_WAIT_LGKM0();                        // (every piece is in registers / on its way: the rows may be overwritten)
+      }
+      SWN_TM(const long long sw = TICK(); tSw += sw - s0;)
+      stage_pieces_q(cs, (const char*)d.x, 64 * rgs + fgs, 16, 4, idx_cur);
+    }
+    if (rg == 0 && it == 0) stage_bias(0, cur.wset, 0);
+    u32x4_t mk_next = load_mask(0, cur.vb);
+    if (cx.w == 0) grab((it + 1) & 1);           // the tile after this one (both row groups read it during their last epilogue phase)
+    SWN_TM(const long long si = TICK(); tSi += si - s0;)
+    SWN_WAIT_VM(0);                              // the rows have landed (and the stores / the claim before them have retired)
+    SWN_PIN();
+    preload_w(0, cur.wset, cx.lane);
+    SWN_PIN();
+    SWN_WAIT_LGKM0();
+    SWN_TM(const long long s1 = TICK();)
+    __builtin_amdgcn_s_barrier();
+    SWN_TM(const long long s2 = TICK(); tS += s1 - s0; tSb += s2 - s1;)
+    Tile nxt = cur;
+    for (int L = 0; L < n_layers; ++L) {
+      const swn_chain_layer& ly = d.layers[L];
+      const bool last = L + 1 == n_layers;
+      u32x4_t mk = mk_next;
+      if (last) nxt = read_tile((it + 1) & 1);   // (written by wave 0 during row group 0's S phase of this tile, barriers ago)
+      // ---- K phase ----
+      {
+        SWN_TM(const long long k0 = TICK();)
+        const __amdgpu_buffer_rsrc_t rs_cur = wrs(L, cur.wset);
+        // (row group 0, for both groups) the NEXT layer's bias -> its slot; the K loop's counted waits cover the copy
+        if (rg == 0) {
+          if (!last) stage_bias(L + 1, cur.wset, (bc + 1) % 3);
+          else if (nxt.vb >= 0) stage_bias(0, nxt.wset, (bc + 1) % 3);
+        }
+        if constexpr (bias_init) {
+          // accumulators start at the bias (zeros for a layer without one: stage_bias).  Written as plain copies of two 16-register
+          // tuples: the compiler feeds the tuples to the first K step's MFMAs as their C operand - no copy is executed
+          f32x4_t bv[2][4];
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+              bv[ni][g4] = *(const f32x4_t*)(smem + G::BIAS0 + (bc % 3) * 1024 + ((fg * 64 + 32 * ni + 8 * g4 + 4 * cx.lhi) << 2));
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[mi][ni][r] = bv[ni][r >> 2][r & 3];
+        } else {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        }
+        {
+          const Ctx ck = phase_ctx(true);
+          k_phase2<E>(acc, ck, rs_cur, wq);
+        }
+#pragma unroll
+        for (int q_ = 0; q_ < 4; ++q_)
+#pragma unroll
+          for (int i_ = 0; i_ < 2; ++i_) asm volatile("" : "=v"(wq[q_][i_]));
+        SWN_TM(const long long k1 = TICK();)
+        __builtin_amdgcn_s_barrier();
+        SWN_TM(const long long k2 = TICK(); tK += k1 - k0; tKb += k2 - k1;)
+      }
+      // ---- E phase ----
+      {
+        SWN_TM(const long long e0 = TICK();)
+        const Ctx ce = phase_ctx(false);
+        const int rge = ce.w >> 2, fge = ce.w & 3;
+        const int lane16e = ce.lane * 16;
+        uint32_t* mkp = ly.mask ? ly.mask + ((size_t)(cur.vb * G::NW + ce.w) * 64 + ce.lane) * 4 : nullptr;
+        if (!last) mk_next = load_mask(L + 1, cur.vb);
+        int row_nxt = 0;
+        if (last && nxt.vb >= 0) row_nxt = load_row(nxt);      // (consumed behind the epilogue)
+        const bool bias_epi = ly.b != nullptr && !bias_init;
+        if (ly.skip) {
+          stage_pieces_q(ce, (const char*)d.x, 64 * rge + fge, 16, 4, idx_cur);
+          SWN_WAIT_VM(0);
+          ++n_skip;
+          if (ce.lane == 0) __hip_atomic_fetch_add(&gcount[rge], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&gcount[rge], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < 4 * n_skip)
+            __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        // the partner's rows = the input tile of the K loop it is running (same tile: the groups are one phase apart)
+        void* wo = rge == 0 ? (L >= 1 ? d.layers[L - 1].save : nullptr) : (!last ? ly.save : nullptr);
+        if (wo) {
+          const __amdgpu_buffer_rsrc_t rs = out_rs(wo, cur);
+          const int c0 = 64 * (1 - rge) + fge;
+          u32x4_t wv[4];
+          auto rd = [&](int b) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wv[j] = *(const u32x4_t*)(smem + piece_addr(ce, c0 + 4 * (4 * b + j)));
+          };
+          rd(0);
+          auto hook = [&](int mi) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(wv[j], rs, lane16e, (c0 + 4 * (4 * mi + j)) * 1024, SWN_BIG_STORE_AUX);
+            asm volatile("s_nop 7\n\ts_nop 7" :: "v"(wv[0]), "v"(wv[1]), "v"(wv[2]), "v"(wv[3]));      // (store-data hold: see chainp_kernel)
+            if (mi < 3) rd(mi + 1);
+            SWN_PIN();
+          };
+          epilogue_p_dispatch<E, decltype(hook)>(acc, ce, mk, ly.relu, bias_epi, ly.skip != 0, (bc % 3) * 1024, hook);
+        } else {
+          epilogue_p_dispatch<E, NoHook>(acc, ce, mk, ly.relu, bias_epi, ly.skip != 0, (bc % 3) * 1024, NoHook());
+        }
+        if (ly.relu == 1 && mkp) *(u32x4_t*)mkp = mk;
+        SWN_PIN();
+        if (!last) preload_w(L + 1, cur.wset, ce.lane);      // (last layer: the S phase that follows loads the next tile's first fragments)
+        else if (nxt.vb >= 0) store_row(row_nxt, idx_nxt);
+        SWN_PIN();
+        SWN_WAIT_LGKM0();
+        SWN_TM(const long long e1 = TICK();)
+        __builtin_amdgcn_s_barrier();
+        SWN_TM(const long long e2 = TICK(); tE += e1 - e0; tEb += e2 - e1;)
+      }
+      ++bc;
+    }
+    prev = cur;
+    cur = nxt;
+    ++it;
+    if (cur.vb < 0) break;
+  }
+  // ---- the rows of the last tile ----
+  {
+    const __amdgpu_buffer_rsrc_t ry = out_rs(d.y, prev);
+    const __amdgpu_buffer_rsrc_t ra = d.y_add ? out_rs((void*)d.y_add, prev) : ry;
+    if (d.y_add) write_pieces16<E, true, 8>(cx, 64 * rg + fg, ry, ra); else write_pieces16<E, false, 8>(cx, 64 * rg + fg, ry, ra);
+  }
+  if (rg == 0) __builtin_amdgcn_s_barrier();      // (row group 1's last phase boundary)
+#ifdef SWN_BIG_TIMING
+  if (d.y_add_gather && cx.lane == 0 && (cx.w == 0 || cx.w == 4) && blockIdx.x < 2048) {   // wave 0 -> row b, wave 4 -> row 2048 + b
+    long long* dbg = (long long*)d.y_add_gather + (long)(blockIdx.x + (cx.w ? 2048 : 0)) * 8;
+    dbg[0] = tS; dbg[1] = tSw; dbg[2] = tK; dbg[3] = tKb; dbg[4] = tE; dbg[5] = tEb + tSb; dbg[6] = it | (tSi << 16); dbg[7] = TICK() - t_start;
+  }
+#endif
+  finish();
+}
+
 }  // namespace swn_big
 
 namespace swn {
@@ -1091,7 +1475,54 @@ static int chain_phase_launch(const swn_chain_desc& d, void* stream) {
   return 0;
 }
 
+
+static int n_compute_units() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    n = cus;
+  }
+  return n;
+}
+
+static int chain_persistent_launch(const swn_chain_desc& d, void* stream) {
+  using namespace swn_big;
+  typedef G256 G;
+#ifdef SWN_HALF_F16
+  typedef Fp16 HalfT;
+#else
+  typedef Bf16 HalfT;
+#endif
+  ArgsQ a;
+  a.d = d;
+  a.tiles_per_group = cdiv(d.group_rows ? (d.group_rows_clamp < d.group_stride ? d.group_rows_clamp : d.group_stride) : d.group_stride, G::BM);
+  if (!d.group_rows) a.d.group_rows_clamp = d.group_stride;
+  const long n_vb = (long)a.tiles_per_group * d.n_groups;
+  SWN_CHECK(n_vb > 0 && n_vb < (1L << 28), "swn_mlp_chain: %ld tiles out of range", n_vb);
+  a.n_vb = (int)n_vb;
+  int grid = n_compute_units();                         // one resident workgroup per CU (157 KiB of LDS each)
+  const char* ov = getenv("SWN_CHAINQ_WGS");            // experiments
+  if (ov && atoi(ov) > 0) grid = atoi(ov);
+  if (grid > n_vb) grid = (int)n_vb;
+  const bool rotated = (d.n_wsets & 7) == 0 && (d.n_groups & 7) == 0;
+  a.n_queues = (rotated && grid % 8 == 0 && d.sched) ? 8 : 1;
+  a.stagger = 0;
+  if (const char* sv = getenv("SWN_CHAINQ_STAGGER")) a.stagger = atoi(sv);
+  if (n_vb < 4L * grid) a.stagger = 0;                  // (short launches: the offset would be most of the run)
+  const void* fn;
+  if (d.geometry == 7) fn = d.tag == 1 ? (const void*)chainq_kernel<HalfT, 1, true> : d.tag == 2 ? (const void*)chainq_kernel<HalfT, 2, true> : (const void*)chainq_kernel<HalfT, 0, true>;
+  else fn = d.tag == 1 ? (const void*)chainq_kernel<HalfT, 1, false> : d.tag == 2 ? (const void*)chainq_kernel<HalfT, 2, false> : (const void*)chainq_kernel<HalfT, 0, false>;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
+  SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  void* kargs[] = {(void*)&a};
+  e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(G::NT), kargs, Q_LDS, as_stream(stream));
+  SWN_CHECK(e == hipSuccess, "swn_mlp_chain (geometry 6 / 7) launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
 int chain_big_launch(const swn_chain_desc& d, void* stream) {
+  if (d.geometry >= 6) return chain_persistent_launch(d, stream);
   if (d.geometry >= 4) return chain_phase_launch(d, stream);
   if (d.geometry == 3) return chain_big_launch_g<swn_big::G96>(d, stream);
   return chain_big_launch_g<swn_big::G256>(d, stream);

@@ -4,6 +4,8 @@ Every function enqueues HIP kernels from libswn_hip.so on torch's current stream
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import List, Optional, Sequence
 
@@ -489,11 +491,12 @@ def chain_mask_words(dtype, n_groups: int, group_stride: int, max_width: int = 2
 
 def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride=None, group_rows=None,
               group_rows_clamp=None, x_gather=None, x_save=None, y_add=None, y_add_gather=None, tag=0, x_scale=None,
-              x_relu=False, geometry=0, group_begin=None, combine=None, heads=None):
+              x_relu=False, geometry=0, group_begin=None, combine=None, heads=None, sched=None):
     """geometry: 0 / 1 the 64-row tile kernels, 2 - 5 the chain_big.hip geometries (include/swn.h).  group_begin: first row of every
     group (packed / no-batch layout) instead of g * group_stride.  combine = (y_fwd, dsig, wsig, gate, dgate_out): the combine backward
     (ops.combine_bwd) fused into the write-out of the last layer.  heads = (w_sigma, b_sigma, w_color, b_color, sigma_noise or None, raw):
-    the sigma / colour heads (ops.heads_fwd) fused into the tail forward chain (tag 4) - y may then be None (nothing but raw is written)."""
+    the sigma / colour heads (ops.heads_fwd) fused into the tail forward chain (tag 4) - y may then be None (nothing but raw is written).
+    sched: int32 [16] zero-initialised tile-queue counters of the persistent geometries 6 / 7 (chain_sched(); left zero by the kernel)."""
     d = ChainDesc()
     d.dtype = _dt(x)
     d.tag = int(tag)
@@ -507,6 +510,11 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
     d.x, d.x_gather, d.x_save, d.y = _p(x), _p(x_gather), _p(x_save), _p(y)
     d.x_scale, d.x_relu = _p(x_scale), int(bool(x_relu))
     d.y_add, d.y_add_gather = _p(y_add), _p(y_add_gather)
+    if sched is None and d.geometry >= 6 and os.environ.get("SWN_CHAINQ_STATIC") is None:
+        sched = chain_sched(x.device, d.tag)       # (launches of one role on one stream are ordered: they can share the counters)
+    if sched is not None:
+        assert sched.dtype == torch.int32 and sched.numel() >= 16
+        d.sched = _p(sched)
     if combine is not None:
         cy, cds, cws, cg, cdg = combine
         assert cy.dtype == x.dtype and cy.shape == y.shape and cg.dtype == torch.float32 and cdg.dtype == torch.float32
@@ -525,6 +533,20 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
         L.relu, L.skip = ly.relu, int(ly.skip)
     call("swn_mlp_chain", C.byref(d), _stream())
     return y
+
+
+_chain_sched = {}
+
+
+def chain_sched(dev, key):
+    """The tile-queue counters of a persistent chain launch (geometry 6 / 7): int32 [16], zero at creation and left zero by every launch.
+    One tensor per (device, stream, key): launches that share one are ordered on their stream; give launches that may overlap on
+    different streams different keys.  Never freed (a captured hipGraph holds the address)."""
+    k = (dev, torch.cuda.current_stream().cuda_stream if dev.type == "cuda" else 0, key)
+    t = _chain_sched.get(k)
+    if t is None:
+        t = _chain_sched[k] = torch.zeros(16, dtype=torch.int32, device=dev)
+    return t
 
 
 _wgrad_ws = {}

@@ -777,12 +777,13 @@ def test_chain_wide_512(dtype):
     assert report(f"chain512_d0_{dtype}", d0, g0) <= tolb * max(1.0, g0.abs().max().item())
 
 
-@pytest.mark.parametrize("geometry", [2, 3, 5, 4])
+@pytest.mark.parametrize("geometry", [2, 3, 5, 4, 6, 7])
 @pytest.mark.parametrize("ng,cap,seed", [(16, 1000, 1), (8, 256, 2), (24, 700, 3), (8, 4096, 4)])
 def test_chain_256_row_geometry_bit_exact(ng, cap, seed, geometry):
     """The chain_big.hip geometries (2: one 512-thread workgroup per 256-row tile, 3: two 256-thread workgroups per CU on 96-row
     tiles; weights shared through an LDS ring, write-out interleaved into the next layer's K loop; 5 / 4: the 256-row workgroup with its
-    row groups half a layer apart) against the 64-row kernels (chain.hip, pinned on the fp32 oracle above):
+    row groups half a layer apart; 6 / 7: the same as a PERSISTENT launch - resident workgroups walking a tile queue, a row group
+    staging its next tile while its partner computes) against the 64-row kernels (chain.hip, pinned on the fp32 oracle above):
     the MFMA accumulation order and the epilogue arithmetic are the same, so every output, every saved activation and every dZ of
     the ExpertMLP forward and backward-data chains must be BIT-identical, on ragged (segment, expert) groups (empty, 1 row, one
     row past a tile, full), with gathered input rows; rows past a group's count must stay untouched."""
@@ -832,19 +833,45 @@ def test_chain_256_row_geometry_bit_exact(ng, cap, seed, geometry):
                 [(f"dz{l}", dz[l]) for l in range(L - 1)]), masks
 
     ref, _ = run(1)
-    if geometry != 4:
-        for rep in range(3 if geometry == 5 else 1):        # (the phase-shifted kernel: repeated - a race would not repeat itself)
-            got, _ = run(geometry)
+    if geometry not in (4, 7):
+        masks5 = run(5)[1] if geometry == 6 else None
+        for rep in range(3 if geometry >= 5 else 1):        # (the phase-shifted kernels: repeated - a race would not repeat itself)
+            if geometry == 6:       # the persistent launch in its three scheduling modes: per-XCD queues, static round-robin, few workgroups
+                os.environ.pop("SWN_CHAINQ_STATIC", None)
+                os.environ.pop("SWN_CHAINQ_WGS", None)
+                if rep == 1:
+                    os.environ["SWN_CHAINQ_STATIC"] = "1"
+                if rep == 2:
+                    os.environ["SWN_CHAINQ_WGS"] = "5"
+            try:
+                got, masks_g = run(geometry)
+            finally:
+                os.environ.pop("SWN_CHAINQ_STATIC", None)
+                os.environ.pop("SWN_CHAINQ_WGS", None)
             for (name, a), (_, b) in zip(ref, got):
                 assert torch.equal(a[vm], b[vm]), f"{name} (run {rep}): {(a[vm] != b[vm]).float().mean().item():.3g} of the valid elements differ"
                 assert b[~vm].abs().sum().item() == 0, f"{name}: rows past a group's count were written"
+            if geometry == 6:       # same tile -> mask-word mapping as geometry 4 / 5: the masks are interchangeable
+                for a, b in zip(masks5, masks_g):
+                    assert torch.equal(a, b), f"run {rep}: the ReLU masks of geometry 6 differ from geometry 5's"
+                for t in o._chain_sched.values():
+                    assert int(t.abs().sum().item()) == 0, "the tile-queue counters must be left zeroed"
         assert (got[0][1][vm].float().abs().sum() > 0) and torch.isfinite(got[0][1].float()).all()
         return
     # geometry 4 = geometry 5 with the accumulators started at the bias: the same sums in a different fp32 order - single 16-bit
     # roundings may differ (and what they feed), nothing more.  Its backward pass has no bias: on the SAME masks it is bit-identical.
+    # geometry 7 = the persistent form of geometry 4: bit-identical to it (same arithmetic), checked like it against geometry 5.
     exact, masks5 = run(5)
+    if geometry == 7:
+        g4, m4 = run(4)
+        g7, m7 = run(7)
+        for (name, a), (_, b) in zip(g4, g7):
+            assert torch.equal(a[vm], b[vm]), f"{name}: geometry 7 differs from geometry 4 ({(a[vm] != b[vm]).float().mean().item():.3g} of the elements)"
+            assert b[~vm].abs().sum().item() == 0, f"{name}: rows past a group's count were written"
+        for a, b in zip(m4, m7):
+            assert torch.equal(a, b), "the ReLU masks of geometry 7 differ from geometry 4's"
     for rep in range(3):
-        got, _ = run(4, masks_in=masks5)
+        got, _ = run(geometry, masks_in=masks5)
         for (name, a), (_, b) in zip(exact, got):
             a_, b_ = a[vm].float(), b[vm].float()
             if name == "dx" or name.startswith("dz"):
@@ -854,7 +881,7 @@ def test_chain_256_row_geometry_bit_exact(ng, cap, seed, geometry):
                 err = (a_ - b_).abs().max().item() / max(1.0, a_.abs().max().item())
                 assert frac < 0.03 and err < 2.0 ** -6, f"{name} (run {rep}): {frac:.3g} of the elements differ, max difference {err:.3g} of the largest value"
             assert b[~vm].abs().sum().item() == 0, f"{name}: rows past a group's count were written"
-    own, _ = run(4)                                             # with its own masks: against the 64-row kernels, bf16-level tolerance
+    own, _ = run(geometry)                                      # with its own masks: against the 64-row kernels, bf16-level tolerance
     for (name, a), (_, b) in zip(ref, own):                     # (a pre-activation within rounding of zero may flip its mask bit: a
         a_, b_ = a[vm].float(), b[vm].float()                   #  single dZ entry then differs by its whole value - counted, not bounded)
         off = ((a_ - b_).abs() > 0.02 * max(1.0, a_.abs().max().item())).float().mean().item()
