@@ -338,10 +338,10 @@ def main():
             traffic_tab = json.load(open(tp))
         except Exception:
             traffic_tab = {}
-    names = {"expert_fwd": "chainp_kernel<Bf16,1> (expert forward: 7 fused layers, 256-row tiles, row groups half a layer apart)",
-             "expert_bwd": "chainp_kernel<Bf16,2> (expert backward-data: 7 fused layers, 256-row tiles, row groups half a layer apart)",
+    names = {"expert_fwd": "chainq_kernel<Bf16,1,true> (expert forward: 7 fused layers, persistent 256-row workgroups on a tile queue, row groups half a layer apart)",
+             "expert_bwd": "chainq_kernel<Bf16,2,true> (expert backward-data: 7 fused layers, persistent 256-row workgroups on a tile queue, row groups half a layer apart)",
              "expert_wgrad": "wgrad_stream_kernel<bf16,1> (expert weight gradients, 7 layers in one balanced launch)",
-             "expert_fwd_nosave": "chainp_kernel<Bf16,1> without activation saves (the inference / --eval expert chain on the same rows: "
+             "expert_fwd_nosave": "chainq_kernel<Bf16,1,true> without activation saves (the inference / --eval expert chain on the same rows: "
                                   "the grouped GEMM alone)"}
 
     def kept_of(st_):

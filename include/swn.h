@@ -343,6 +343,9 @@ typedef struct swn_chain_desc {
   int32_t* sched;               /* geometry 6 / 7: device int32 [16] tile-queue counters, ZERO before the first launch that uses them
                                    (the kernel leaves them zero); launches that may run concurrently need their own.  NULL: the tiles
                                    are dealt round-robin over the resident workgroups (no balancing of ragged groups)          */
+  int32_t x_features;           /* geometry 6 / 7: features per row of x when fewer than layers[0].k: 128 under a first layer whose packed
+                                   weights are zero-padded from k = 128 to k = 256 (the rows of x are 128 features wide; the kernel zeroes
+                                   the other half of its input tile).  0 = layers[0].k                                         */
   swn_chain_layer layers[SWN_MAX_CHAIN_LAYERS];
 } swn_chain_desc;
 
@@ -369,6 +372,8 @@ typedef struct swn_pack_item {
   const float* master;  /* [n_wsets][in_dim][out_dim] f32 */
   void* out;            /* packed compute copy (dtype of the call) */
   int32_t n_wsets, in_dim, out_dim, transpose;
+  int32_t in_rows;      /* rows of `master` actually stored when fewer than in_dim ([n_wsets][in_rows][out_dim]): the packed copy is
+                           zero-padded to in_dim (a 128-feature first layer under the K = 256 kernels of geometry 6 / 7); 0 = in_dim */
 } swn_pack_item;
 int swn_pack_weights_batched(const swn_pack_item* items, int n_items, int dtype, void* stream);
 

@@ -28,7 +28,7 @@ class WgradJob(C.Structure):
 
 
 class PackItem(C.Structure):
-    _fields_ = [("master", vp), ("out", vp), ("n_wsets", i32), ("in_dim", i32), ("out_dim", i32), ("transpose", i32)]
+    _fields_ = [("master", vp), ("out", vp), ("n_wsets", i32), ("in_dim", i32), ("out_dim", i32), ("transpose", i32), ("in_rows", i32)]
 
 
 class HashCfg(C.Structure):
@@ -41,7 +41,7 @@ class ChainDesc(C.Structure):
                 ("group_rows", vp), ("group_rows_clamp", i32), ("group_begin", vp), ("x", vp), ("x_gather", vp), ("x_save", vp), ("x_scale", vp), ("x_relu", i32),
                 ("y", vp), ("y_add", vp), ("y_add_gather", vp), ("geometry", i32), ("tag", i32),
                 ("comb_y", vp), ("comb_dsig", vp), ("comb_wsig", vp), ("comb_gate", vp), ("comb_dgate", vp),
-                ("heads_ws", vp), ("heads_bs", vp), ("heads_wc", vp), ("heads_bc", vp), ("heads_noise", vp), ("heads_raw", vp), ("sched", vp),
+                ("heads_ws", vp), ("heads_bs", vp), ("heads_wc", vp), ("heads_bc", vp), ("heads_noise", vp), ("heads_raw", vp), ("sched", vp), ("x_features", i32),
                 ("layers", ChainLayer * 12)]
 
 

@@ -886,6 +886,7 @@ __global__ void pack_weights_batched_kernel(const PackTable tab) {
   constexpr int KSTEP = Cfg<T>::KSTEP;
   const swn_pack_item& q = tab.it[blockIdx.y];
   const int in_dim = q.in_dim, out_dim = q.out_dim, transpose = q.transpose;
+  const int in_rows = q.in_rows > 0 ? q.in_rows : in_dim;          // rows of the master that exist (the rest of in_dim packs as zeros)
   const int N = transpose ? out_dim : in_dim, K = transpose ? in_dim : out_dim;
   const long per_set = (long)(N / 32) * (K / KSTEP) * 64;
   const long total_chunks = per_set * q.n_wsets;
@@ -898,13 +899,14 @@ __global__ void pack_weights_batched_kernel(const PackTable tab) {
     r >>= 6;
     const int ks = (int)(r % (K / KSTEP)), nt = (int)(r / (K / KSTEP));
     const int n = nt * 32 + (lane & 31);
-    const float* m = master + ws * (long)in_dim * out_dim;
+    const float* m = master + ws * (long)in_rows * out_dim;
     T* o = out + c * EPC;
 #pragma unroll
     for (int j = 0; j < EPC; ++j) {
       int kk;
       if constexpr (sizeof(T) == 2) kk = ks * 16 + (lane >> 5) * 8 + j; else kk = ks * 8 + 2 * j + (lane >> 5);
-      const float v = transpose ? m[(long)kk * out_dim + n] : m[(long)n * out_dim + kk];
+      const int row = transpose ? kk : n;
+      const float v = row < in_rows ? (transpose ? m[(long)kk * out_dim + n] : m[(long)n * out_dim + kk]) : 0.f;
       ElemIO<T>::st(o + j, v);
     }
   }
@@ -989,6 +991,7 @@ extern "C" int swn_pack_weights_batched(const swn_pack_item* items, int n_items,
   for (int i = 0; i < n_items; ++i) {
     const swn_pack_item& q = items[i];
     SWN_CHECK(q.master && q.out && q.n_wsets >= 1, "swn_pack_weights_batched: item %d: null pointer / no weight sets", i);
+    SWN_CHECK(q.in_rows >= 0 && q.in_rows <= q.in_dim, "swn_pack_weights_batched: item %d: in_rows %d not in [0, in_dim = %d]", i, q.in_rows, q.in_dim);
     const int N = q.transpose ? q.out_dim : q.in_dim, K = q.transpose ? q.in_dim : q.out_dim;
     SWN_CHECK(N % 32 == 0 && K % kstep == 0, "swn_pack_weights_batched: item %d: N=%d must be a multiple of 32, K=%d of %d", i, N, K, kstep);
     const long chunks = (long)q.n_wsets * (N / 32) * (K / kstep) * 64;
@@ -1055,6 +1058,8 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
     for (int l = 0; l < d.n_layers; ++l) SWN_CHECK(d.layers[l].skip != 2, "swn_mlp_chain: fused heads: no concat-skip layers");
   }
   SWN_CHECK(d.tag >= 0 && d.tag <= 6, "swn_mlp_chain: tag %d not in [0,6]", d.tag);
+  SWN_CHECK(d.x_features == 0 || d.x_features == d.layers[0].k || (d.x_features == 128 && d.layers[0].k == 256 && d.geometry >= 6),
+            "swn_mlp_chain: x_features = %d: only 128-feature rows under a zero-padded k = 256 first layer on geometry 6 / 7", d.x_features);
   SWN_CHECK(!(wide && concat), "swn_mlp_chain: concat-skip layers are built for the 256-feature kernels only");
   SWN_CHECK(d.geometry >= 0 && d.geometry <= 7, "swn_mlp_chain: geometry %d not in [0,7]", d.geometry);
   if (d.comb_y) {
@@ -1066,7 +1071,7 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   }
   {   // 256-row geometry (chain_big.hip).  Never chosen silently for bf16: the ReLU mask layout differs between the geometries,
       // and a backward chain must run on the geometry of the forward chain that recorded its masks - the caller pairs them.
-    const bool can = chain_big_eligible(d);
+    const bool can = d.geometry >= 6 ? chain_persistent_eligible(d) : chain_big_eligible(d);
     SWN_CHECK(d.geometry < 2 || can, "swn_mlp_chain: geometries 2 - 7 need bf16 / fp16 chains of 256 x 256 layers without rowbias / x_scale / x_save / y_add_gather");
     if (d.geometry >= 2) return chain_big_launch(d, stream);
   }

@@ -581,9 +581,9 @@ __global__ __launch_bounds__(G::NT, G::OCC) void chainb_kernel(const Args args) 
 // fragments are read TWO steps ahead (three register sets): the LDS round trip of a lone wave's reads (~300 clocks with four waves
 // reading at once) no longer fits into one 256-clock step.  `wq` holds the fragments of steps 0..2 on entry (issued by the caller before
 // the phase barrier) - on exit nothing is in flight.
-template <typename E>
+template <typename E, int NS = KSTEPS>
 __device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, __amdgpu_buffer_rsrc_t rs_cur, u32x4_t (&wq)[4][2]) {
-  constexpr int MI = 4;
+  constexpr int MI = 4;           // NS = K steps of this layer (K / 16): 16, or 8 for a 128-feature chain input (geometries 6 / 7)
   char* smem = cx.smem;
   const int lane16 = cx.lane * 16;
   const int fg = cx.w & 3;
@@ -596,17 +596,17 @@ __device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, _
   auto load_w = [&](int ks) {          // the two feature tiles of this wave, K step ks
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      wq[ks & 3][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, lane16, ((2 * fg + i) * KSTEPS + ks) * 1024, 0);
+      wq[ks & 3][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, lane16, ((2 * fg + i) * NS + ks) * 1024, 0);
   };
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) read_a(0, mi);
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) read_a(1, mi);
 #pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks) {
+  for (int ks = 0; ks < NS; ++ks) {
     // weights of step ks: younger are the loads of steps ks + 1, ks + 2 (an older bias copy / mask load only makes the wait longer)
-    if (ks + 2 < KSTEPS) SWN_WAIT_VM(4); else if (ks + 1 < KSTEPS) SWN_WAIT_VM(2); else SWN_WAIT_VM(0);
-    if (ks + 1 < KSTEPS) SWN_WAIT_LGKM(4); else SWN_WAIT_LGKM(0);        // fragments of step ks (younger: those of step ks + 1)
+    if (ks + 2 < NS) SWN_WAIT_VM(4); else if (ks + 1 < NS) SWN_WAIT_VM(2); else SWN_WAIT_VM(0);
+    if (ks + 1 < NS) SWN_WAIT_LGKM(4); else SWN_WAIT_LGKM(0);        // fragments of step ks (younger: those of step ks + 1)
     SWN_PIN();
 #ifdef SWN_ABL_NOMFMA
 #define SWN_MM(mi, ni) asm volatile("" :: "v"(wq[ks & 3][ni]), "v"(fa[ks % 3][mi]))
@@ -615,15 +615,15 @@ __device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, _
 #endif
     SWN_MM(0, 0);
     SWN_PIN();
-    if (ks + 2 < KSTEPS) { read_a(ks + 2, 0); read_a(ks + 2, 1); }
+    if (ks + 2 < NS) { read_a(ks + 2, 0); read_a(ks + 2, 1); }
     SWN_PIN();
     SWN_MM(0, 1);
     SWN_PIN();
-    if (ks + 2 < KSTEPS) { read_a(ks + 2, 2); read_a(ks + 2, 3); }
+    if (ks + 2 < NS) { read_a(ks + 2, 2); read_a(ks + 2, 3); }
     SWN_PIN();
     SWN_MM(1, 0);
     SWN_PIN();
-    if (ks + 3 < KSTEPS) load_w(ks + 3);        // into the register set of step ks - 1, whose MFMAs were issued a step ago
+    if (ks + 3 < NS) load_w(ks + 3);        // into the register set of step ks - 1, whose MFMAs were issued a step ago
     SWN_PIN();
     SWN_MM(1, 1);
     SWN_PIN();
@@ -1046,21 +1046,80 @@ struct ArgsQ {
   int n_vb;            // virtual blocks = chainp_kernel's grid
   int n_queues;        // 8: one queue per XCD (rotated mapping), 1: a single queue
   int stagger;         // start offset between the workgroups of an XCD in units of ~1 k clocks (0: all start together)
+  int per_queue;       // 8 queues over ONE group (dense chains): queue x walks the tiles [x * per_queue, (x + 1) * per_queue) - the
+                       // workgroups of an XCD write consecutive rows (as the 64-row kernels' dense mapping does)
 };
 
 constexpr int Q_IDX1 = G256::BIAS0 + 3072 + 64;      // second source-row table (int32 [256]); the first one is G256::IDX0
 constexpr int Q_TINFO = Q_IDX1 + 1024;               // int32 [2][8]: vb (-1 = none), group, first tile row, valid rows, first row (lo, hi), weight set
 constexpr int Q_LDS = Q_TINFO + 64;
 
+// NARROW: the chain input has 128 features (256-byte rows) under a first layer whose weights are zero-padded to K = 256 (one K-loop
+// instantiation for every layer: a second, 8-step one beside it cost 160 spilled registers): the first 16 chunk positions of a tile row
+// receive the row - position p of row r holds chunk p ^ (r & 15) < 16, copied by the lanes that own them (an inactive lane of an
+// LDS-DMA writes nothing) - and the other lanes ZERO the upper 16 positions (what is left there from the previous tile would meet zero
+// weights, but 0 x inf is not 0)
+template <bool NARROW>
 __device__ __forceinline__ void stage_pieces_q(const Ctx& cx, const char* x, int c0, int n, int stride, int idx_off) {
   const int* idx = (const int*)(cx.smem + idx_off);
-#pragma unroll 4
-  for (int j = 0; j < n; ++j) {
-    const int c = c0 + j * stride;
-    const int r = 2 * c + cx.lhi;
-    const long src = idx[r];
-    const int q = cx.l31 ^ (r & 15);
-    __builtin_amdgcn_global_load_lds(SWN_GLB(x + src * ROWB + q * 16), SWN_LDS(cx.smem + c * 1024), 16, 0, 0);
+  constexpr int XRB = NARROW ? 256 : ROWB;
+  // all source rows first (one LDS round trip), then the copies back to back: with the index read in front of every copy the 16 copies of
+  // a wave took ~6 k clocks to ISSUE (16 dependent LDS round trips beside the partner group's LDS traffic)
+  int src[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) src[j] = j < n ? idx[2 * (c0 + j * stride) + cx.lhi] : 0;
+  if constexpr (NARROW) {       // the zero half FIRST: behind an LDS-DMA every LDS write waits for the copy to land (one HBM round trip each)
+    if (cx.l31 >= 16) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (j < n) *(u32x4_t*)(cx.smem + (c0 + j * stride) * 1024 + cx.lane * 16) = u32x4_t{0u, 0u, 0u, 0u};
+    }
+  }
+  SWN_WAIT_LGKM0();
+  if (!NARROW || cx.l31 < 16) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j < n) {
+        const int c = c0 + j * stride;
+        const int r = 2 * c + cx.lhi;
+        const int q = cx.l31 ^ (r & 15);
+        __builtin_amdgcn_global_load_lds(SWN_GLB(x + (long)src[j] * XRB + q * 16), SWN_LDS(cx.smem + c * 1024), 16, 0, 0);
+      }
+    }
+  }
+}
+
+// write_pieces16 with the rows of y_add fetched through an index (the front backward chain adds the expert path's input gradient through
+// tok2row: -1 = nothing to add): pieces c0 + 4 j (j < 16) in two batches of 8 - the 8 row indices, then the 8 x 16 bytes, together
+template <typename E>
+__device__ __forceinline__ void write_pieces16_gather(const Ctx& cx, int c0, __amdgpu_buffer_rsrc_t rs, const char* y_add, const int32_t* gather,
+                                                      long grow0, int rows) {
+  const int lane16 = cx.lane * 16;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    int ar[8];
+    u32x4_t v[8], a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = 2 * (c0 + 4 * (8 * b + j)) + cx.lhi;
+      ar[j] = gather[grow0 + (r < rows ? r : 0)];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *(const u32x4_t*)(cx.smem + piece_addr(cx, c0 + 4 * (8 * b + j)));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = *(const u32x4_t*)(y_add + (long)(ar[j] < 0 ? 0 : ar[j]) * ROWB + cx.l31 * 16);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (ar[j] >= 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[j][q] = E::pack2(E::lo(v[j][q]) + E::lo(a[j][q]), E::hi(v[j][q]) + E::hi(a[j][q]));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rs, lane16, (c0 + 4 * (8 * b + j)) * 1024, SWN_BIG_Y_AUX);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("s_nop 3" :: "v"(v[j]));
+    SWN_PIN();
   }
 }
 
@@ -1105,18 +1164,27 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
   // ---- the tile queue (wave 0 only) ----
   const int xq = args.n_queues == 8 ? (int)(blockIdx.x & 7) : 0;
   int kq = 0;                                    // (no counters: the kq-th tile of this workgroup is block b + kq * grid)
-  auto grab = [&](int slot) {                    // the next tile with at least one valid row -> tinfo[slot] (vb = -1: the queue is empty)
+  auto claim = [&]() -> int {                    // one ticket of this workgroup's queue (lane 0; NOT waited for: consume with grab)
+    int q = 0;
+    if (d.sched && cx.lane == 0) q = __hip_atomic_fetch_add(d.sched + xq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return q;
+  };
+  auto grab = [&](int slot, int ticket) {        // the next tile with at least one valid row -> tinfo[slot] (vb = -1: the queue is empty);
+                                                 // `ticket`: a claim issued earlier (its round trip hidden behind other work)
     int vb, g = 0, tile = 0, rows_valid = 0;
+    bool first = true;
     int n_groups = d.n_groups, tpg = args.tiles_per_group, n_wsets = d.n_wsets;
     asm volatile("" : "+s"(n_groups), "+s"(tpg), "+s"(n_wsets));      // (divisors re-read here: their reciprocals must not live - in
                                                                       //  vector registers - through the phases of the tile loop)
     for (;;) {
       int q;
       if (d.sched) {
-        q = 0;
-        if (cx.lane == 0) q = __hip_atomic_fetch_add(d.sched + xq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        q = first ? ticket : claim();
+        first = false;
         q = __builtin_amdgcn_readfirstlane(q);
-        vb = args.n_queues == 8 ? q * 8 + xq : q;
+        if (args.n_queues != 8) vb = q;
+        else if (args.per_queue == 0) vb = q * 8 + xq;
+        else vb = q < args.per_queue ? xq * args.per_queue + q : args.n_vb;
       } else {
         vb = (int)blockIdx.x + kq * (int)gridDim.x;
         ++kq;
@@ -1186,9 +1254,11 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     const int lt = fg * 64 + cx.lane;
     if (lt < 128) ((int*)(smem + idx_off))[128 * rg + lt] = src < 0 ? 0 : src;
   };
+  const bool narrow = d.x_features == 128;                  // 128-feature chain input (256-byte rows) under a K = 256 zero-padded first layer
   auto wrs = [&](int L, int wset) -> __amdgpu_buffer_rsrc_t {
-    const char* p = (const char*)d.layers[L].w + (size_t)wset * 8 * (KSTEPS * 1024);
-    return uniform_rsrc(p, 8 * KSTEPS * 1024);
+    const int bytes = 8 * (d.layers[L].k >> 4) * 1024;      // 8 feature tiles x K / 16 steps of 1 KiB
+    const char* p = (const char*)d.layers[L].w + (size_t)wset * bytes;
+    return uniform_rsrc(p, bytes);
   };
   auto out_rs = [&](void* base, const Tile& t) -> __amdgpu_buffer_rsrc_t {
     return uniform_rsrc((char*)base + t.grow0 * ROWB, t.rows * ROWB);
@@ -1199,7 +1269,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) wq[ks][i] = __builtin_amdgcn_raw_buffer_load_b128(r, lane_ * 16, ((2 * fg + i) * KSTEPS + ks) * 1024, 0);
+      for (int i = 0; i < 2; ++i) wq[ks][i] = __builtin_amdgcn_raw_buffer_load_b128(r, lane_ * 16, ((2 * fg + i) * (d.layers[L].k >> 4) + ks) * 1024, 0);
   };
   auto stage_bias = [&](int L, int wset, int slot) {     // (the four waves of row group 0: 256 B each)
     const float* b = d.layers[L].b;
@@ -1223,7 +1293,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
   for (int i = ((int)(blockIdx.x >> 3) & 15) * args.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(16);
   // ---- prologue: the first tile, its source rows ----
   if (cx.w == 0 && cx.lane < 2) gcount[cx.lane] = 0;
-  if (cx.w == 0) grab(0);
+  if (cx.w == 0) grab(0, claim());
   SWN_WAIT_LGKM0();
   __builtin_amdgcn_s_barrier();
   Tile cur = read_tile(0);
@@ -1251,20 +1321,28 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
       cs.l31 = cs.lane & 31;
       cs.lhi = cs.lane >> 5;
       const int rgs = cs.w >> 2, fgs = cs.w & 3;
+      int ticket = 0;
+      if (cs.w == 0) ticket = claim();           // (the claim of the tile after this one travels under the write-out and the staging)
       if (it > 0) {
         const __amdgpu_buffer_rsrc_t ry = out_rs(d.y, prev);
         const __amdgpu_buffer_rsrc_t ra = d.y_add ? out_rs((void*)d.y_add, prev) : ry;
-        if (d.y_add) write_pieces16<E, true, 8>(cs, 64 * rgs + fgs, ry, ra); else write_pieces16<E, false, 8>(cs, 64 * rgs + fgs, ry, ra);
+        if (d.y_add && d.y_add_gather) write_pieces16_gather<E>(cs, 64 * rgs + fgs, ry, (const char*)d.y_add, d.y_add_gather, prev.grow0, prev.rows);
+        else if (d.y_add) write_pieces16<E, true, 8>(cs, 64 * rgs + fgs, ry, ra);
+        else write_pieces16<E, false, 8>(cs, 64 * rgs + fgs, ry, ra);
         SWN_WAIT_LGKM0();                        // (every piece is in registers / on its way: the rows may be overwritten)
       }
       SWN_TM(const long long sw = TICK(); tSw += sw - s0;)
-      stage_pieces_q(cs, (const char*)d.x, 64 * rgs + fgs, 16, 4, idx_cur);
+      if (narrow) stage_pieces_q<true>(cs, (const char*)d.x, 64 * rgs + fgs, 16, 4, idx_cur);
+      else stage_pieces_q<false>(cs, (const char*)d.x, 64 * rgs + fgs, 16, 4, idx_cur);
+      if (cs.w == 0) grab((it + 1) & 1, ticket);   // the tile after this one (both row groups read it during their last epilogue phase)
+      SWN_TM(const long long si = TICK(); tSi += si - s0;)
+      // The rows have landed (and the stores before them have retired).  Measured (profiles/r04_experiments.md): the 32 vector memory
+      // operations of this phase take 6-9 k clocks to ISSUE whatever their order (copies first and a counted wait: no gain) - the CU's
+      // vector memory path carries the partner group's weight stream at the same time and is the bound of this kernel family.
+      SWN_WAIT_VM(0);
     }
-    if (rg == 0 && it == 0) stage_bias(0, cur.wset, 0);
+    if (rg == 0 && it == 0) { stage_bias(0, cur.wset, 0); SWN_WAIT_VM(0); }
     u32x4_t mk_next = load_mask(0, cur.vb);
-    if (cx.w == 0) grab((it + 1) & 1);           // the tile after this one (both row groups read it during their last epilogue phase)
-    SWN_TM(const long long si = TICK(); tSi += si - s0;)
-    SWN_WAIT_VM(0);                              // the rows have landed (and the stores / the claim before them have retired)
     SWN_PIN();
     preload_w(0, cur.wset, cx.lane);
     SWN_PIN();
@@ -1334,7 +1412,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         if (last && nxt.vb >= 0) row_nxt = load_row(nxt);      // (consumed behind the epilogue)
         const bool bias_epi = ly.b != nullptr && !bias_init;
         if (ly.skip) {
-          stage_pieces_q(ce, (const char*)d.x, 64 * rge + fge, 16, 4, idx_cur);
+          stage_pieces_q<false>(ce, (const char*)d.x, 64 * rge + fge, 16, 4, idx_cur);      // (a residual layer has n = k0 = 256)
           SWN_WAIT_VM(0);
           ++n_skip;
           if (ce.lane == 0) __hip_atomic_fetch_add(&gcount[rge], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1385,11 +1463,13 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
   {
     const __amdgpu_buffer_rsrc_t ry = out_rs(d.y, prev);
     const __amdgpu_buffer_rsrc_t ra = d.y_add ? out_rs((void*)d.y_add, prev) : ry;
-    if (d.y_add) write_pieces16<E, true, 8>(cx, 64 * rg + fg, ry, ra); else write_pieces16<E, false, 8>(cx, 64 * rg + fg, ry, ra);
+    if (d.y_add && d.y_add_gather) write_pieces16_gather<E>(cx, 64 * rg + fg, ry, (const char*)d.y_add, d.y_add_gather, prev.grow0, prev.rows);
+    else if (d.y_add) write_pieces16<E, true, 8>(cx, 64 * rg + fg, ry, ra);
+    else write_pieces16<E, false, 8>(cx, 64 * rg + fg, ry, ra);
   }
   if (rg == 0) __builtin_amdgcn_s_barrier();      // (row group 1's last phase boundary)
 #ifdef SWN_BIG_TIMING
-  if (d.y_add_gather && cx.lane == 0 && (cx.w == 0 || cx.w == 4) && blockIdx.x < 2048) {   // wave 0 -> row b, wave 4 -> row 2048 + b
+  if (d.y_add_gather && !d.y_add && cx.lane == 0 && (cx.w == 0 || cx.w == 4) && blockIdx.x < 2048) {   // wave 0 -> row b, wave 4 -> row 2048 + b
     long long* dbg = (long long*)d.y_add_gather + (long)(blockIdx.x + (cx.w ? 2048 : 0)) * 8;
     dbg[0] = tS; dbg[1] = tSw; dbg[2] = tK; dbg[3] = tKb; dbg[4] = tE; dbg[5] = tEb + tSb; dbg[6] = it | (tSi << 16); dbg[7] = TICK() - t_start;
   }
@@ -1414,6 +1494,21 @@ bool chain_big_eligible(const swn_chain_desc& d) {
     if (ly.n != 256 || ly.k != 256 || ly.rowbias || ly.skip > 1) return false;
   }
   return true;
+}
+
+// geometries 6 / 7 (chainq_kernel) also take the dense front chains: a 128-feature chain input (x_features = 128 under a first layer
+// whose weights are zero-padded to k = 256) and a gathered y_add
+bool chain_persistent_eligible(const swn_chain_desc& d) {
+  if (d.dtype != SWN_HALF || d.x_save || d.x_scale || d.comb_y || d.heads_raw) return false;
+#ifndef SWN_BIG_TIMING
+  if (d.y_add_gather && !d.y_add) return false;
+#endif
+  for (int l = 0; l < d.n_layers; ++l) {
+    const swn_chain_layer& ly = d.layers[l];
+    if (ly.n != 256 || ly.k != 256 || ly.rowbias || ly.skip > 1) return false;
+    if (ly.skip && d.x_features == 128) return false;
+  }
+  return d.x_features == 0 || d.x_features == 256 || d.x_features == 128;
 }
 
 int chain_big_tile_rows(int geometry) { return geometry == 3 ? swn_big::G96::BM : swn_big::G256::BM; }
@@ -1507,12 +1602,24 @@ static int chain_persistent_launch(const swn_chain_desc& d, void* stream) {
   if (grid > n_vb) grid = (int)n_vb;
   const bool rotated = (d.n_wsets & 7) == 0 && (d.n_groups & 7) == 0;
   a.n_queues = (rotated && grid % 8 == 0 && d.sched) ? 8 : 1;
+  a.per_queue = 0;
+  if (!rotated && d.n_groups == 1 && grid % 8 == 0 && d.sched && n_vb >= 64) {      // one group (dense chains): XCD x walks its own eighth
+    a.n_queues = 8;
+    a.per_queue = (int)cdiv(n_vb, 8);
+  }
   a.stagger = 0;
   if (const char* sv = getenv("SWN_CHAINQ_STAGGER")) a.stagger = atoi(sv);
   if (n_vb < 4L * grid) a.stagger = 0;                  // (short launches: the offset would be most of the run)
   const void* fn;
-  if (d.geometry == 7) fn = d.tag == 1 ? (const void*)chainq_kernel<HalfT, 1, true> : d.tag == 2 ? (const void*)chainq_kernel<HalfT, 2, true> : (const void*)chainq_kernel<HalfT, 0, true>;
-  else fn = d.tag == 1 ? (const void*)chainq_kernel<HalfT, 1, false> : d.tag == 2 ? (const void*)chainq_kernel<HalfT, 2, false> : (const void*)chainq_kernel<HalfT, 0, false>;
+#define SWN_PICKQ(TAGV)                                                                                                       \
+  case TAGV:                                                                                                                  \
+    fn = d.geometry == 7 ? (const void*)chainq_kernel<HalfT, TAGV, true> : (const void*)chainq_kernel<HalfT, TAGV, false>;    \
+    break;
+  switch (d.tag) {
+    SWN_PICKQ(1) SWN_PICKQ(2) SWN_PICKQ(3) SWN_PICKQ(6)
+    default: fn = d.geometry == 7 ? (const void*)chainq_kernel<HalfT, 0, true> : (const void*)chainq_kernel<HalfT, 0, false>;
+  }
+#undef SWN_PICKQ
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
   SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   void* kargs[] = {(void*)&a};

@@ -82,6 +82,7 @@ int gate_bwd_mfma_launch(const void* g, const float* ln_w, const float* wg, cons
                          void* dg, float* dlogits, float* partial, void* stream);
 int gate_bwd_mfma_blocks(int n_tokens);
 bool chain_big_eligible(const swn_chain_desc& d);                // chain_big.hip: the 256-row geometry
+bool chain_persistent_eligible(const swn_chain_desc& d);         // chain_big.hip: geometries 6 / 7 (persistent; also the dense front chains)
 int chain_big_launch(const swn_chain_desc& d, void* stream);
 int chain_big_tile_rows(int geometry);
 int chain_big_mask_words_per_tile(int geometry);

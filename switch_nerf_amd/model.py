@@ -302,10 +302,24 @@ class SwitchNeRF:
                 pairs.append((w3, self.wf[n], True))
                 if n in self.wb:
                     pairs.append((w3, self.wb[n], False))
+        # the front chains on the persistent 256-row geometry (chain_big.hip, geometry 7) run every layer with K = 256: the first layer's
+        # 128-row weight (75 -> 256, PE padded to 128) is packed zero-padded to 256 rows
+        if self._front_big():
+            w3 = self.p["xyz.w"].unsqueeze(0)
+            if "xyz_pad" not in self.wf:
+                self.wf["xyz_pad"] = ops.pack_weights_padded(w3, self.dtype, True, 256)
+            else:
+                pairs.append((w3, self.wf["xyz_pad"], True, 256))
         if pairs:
             ops.repack_weights_batched(pairs)      # one launch (was 23 of ~5 us each: a tenth of the step at 1024 rays per GPU)
         if self._flat_param is not None:           # the copies now match the master weights as of this version of flat_param
             self._packed_version = self._flat_param._version
+
+    def _front_big(self) -> bool:
+        """The dense front chains (PE -> xyz -> gate MLP, and their backward) on the persistent 256-row geometry: 256-feature layers over
+        a 128-feature encoding in a 16-bit compute dtype (building.yaml).  SWN_FRONT_GEOM=1 keeps them on the 64-row kernels."""
+        return ("xyz.w" in self.spec and self.M == 256 and self.G == 256 and self.KP == 128 and self.dtype != torch.float32
+                and self.hash is None and os.environ.get("SWN_FRONT_GEOM", "7") != "1")
 
     def set_expert_parallel(self, ep):
         """Shard the experts over the ranks of `ep` (parallel.ExpertParallel) and exchange the dispatched rows instead of
@@ -477,10 +491,15 @@ class SwitchNeRF:
         c["m_a1"] = _b("m_a1", (o.chain_mask_words(dt, 1, P, max(M, G, self.KP)),), torch.int32)
         sv = self._saving
         c["no_grad"] = not sv
-        o.mlp_chain(c["pe"], [o.Layer(self.wf["xyz"], self.p["xyz.b"].view(1, M), save=c["h0"]),
+        # (the 64-row kernels re-stream the 320 KB of weights from L2 for every 64 rows - 11.8 GB of L2 reads per 2M-point launch against
+        #  0.5 GB of input, the CU's L2 -> L1 path is what bounds them - the persistent 256-row geometry a quarter of that)
+        c["front_geom"] = int(os.environ.get("SWN_FRONT_GEOM", "7")) if self._front_big() else 1
+        big = c["front_geom"] >= 6
+        o.mlp_chain(c["pe"], [o.Layer(self.wf["xyz_pad" if big else "xyz"], self.p["xyz.b"].view(1, M), save=c["h0"]),
                               o.Layer(self.wf["gate0"], self.p["gate0.b"].view(1, G), relu=1, mask=c["m_a1"] if sv else None,
                                       save=c["a1"] if sv else None),
-                              o.Layer(self.wf["gate1"], self.p["gate1.b"].view(1, G))], c["g"], tag=3)
+                              o.Layer(self.wf["gate1"], self.p["gate1.b"].view(1, G))], c["g"], tag=3, geometry=c["front_geom"] if big else 0,
+                    x_features=self.KP if big else 0)
         # ---- gate + routing
         c["gates"], c["idx"], c["gmax"], c["stats"] = o.gate_fwd(c["g"], self.p["ln.w"], self.p["ln.b"], self.p["wg"])
         if routing_override is not None:     # tests: inject the oracle's expert choice (near-tie robustness)
@@ -508,9 +527,10 @@ class SwitchNeRF:
         c["masks"] = [_b(f"mask{l}", (nw,), torch.int32) if sv else None for l in range(L - 1)]
         skips = set(self.cfg["skips"])
         # expert chains (forward here, backward-data in backward_net - the pair shares its ReLU mask layout): the 256-row geometry
-        # with phase-shifted row groups (chain_big.hip, geometry 4) for 256-feature experts in a 16-bit compute dtype once a group
-        # holds at least one full tile.  SWN_CHAIN_GEOM picks another one (1: the 64-row kernels, 2 / 5: see include/swn.h) - tests.
-        c["geom"] = int(os.environ.get("SWN_CHAIN_GEOM", "4")) if (M == 256 and dt != torch.float32 and cap >= 256) else 1
+        # with phase-shifted row groups as a persistent launch (chain_big.hip, geometry 7 = geometry 4 walking a tile queue) for 256-feature
+        # experts in a 16-bit compute dtype once a group holds at least one full tile.  SWN_CHAIN_GEOM picks another one (1: the 64-row
+        # kernels, 2 / 4 / 5 / 6: see include/swn.h) - tests.
+        c["geom"] = int(os.environ.get("SWN_CHAIN_GEOM", "7")) if (M == 256 and dt != torch.float32 and cap >= 256) else 1
         layers = [o.Layer(self._local_experts(self.wf[f"exp{l}"]), self._local_experts(self.p[f"exp{l}.b"]),
                           relu=1 if l < L - 1 else 0, skip=(l in skips), save=c["saves"][l] if (sv and l < L - 1) else None,
                           mask=c["masks"][l] if (sv and l < L - 1) else None) for l in range(L)]
@@ -799,7 +819,7 @@ class SwitchNeRF:
             for wait in returns:
                 wait()
         o.mlp_chain(dg, [o.Layer(self.wb["gate1"], None, relu=2, mask=c["m_a1"], save=dza1), o.Layer(self.wb["gate0"], None)],
-                    dh0, y_add=dx, y_add_gather=c["row_of_tok"], tag=6)
+                    dh0, y_add=dx, y_add_gather=c["row_of_tok"], tag=6, geometry=c["front_geom"] if c["front_geom"] >= 6 else 0)
         self._dense_wgrads(tail_jobs + [(c["a1"], dg, g["gate1.w"].view(1, G, G), g["gate1.b"].view(1, G)),
                                         (c["h0"], dza1, g["gate0.w"].view(1, M, G), g["gate0.b"].view(1, G)),
                                         (c["pe"], dh0, g["xyz.w"].view(1, self.KP, M), g["xyz.b"].view(1, M))], nsp)

@@ -74,7 +74,7 @@ class _MoEFunction(torch.autograd.Function):
                           mask=masks[l] if l < L - 1 else None) for l in range(L)]
         eo = torch.empty(rows, M, dtype=dt, device=xs.device)
         cnt = counts.view(-1)
-        geom = 4 if (M == 256 and dt != torch.float32 and cap >= 256) else 1       # 256-row geometry (forward and backward alike)
+        geom = 7 if (M == 256 and dt != torch.float32 and cap >= 256) else 1       # persistent 256-row geometry (forward and backward alike)
         o.mlp_chain(xs, layers, eo, n_groups=E, n_wsets=E, group_stride=cap, group_rows=cnt, group_rows_clamp=cap,
                     x_gather=perm.view(-1), tag=1, geometry=geom)
         y = o.combine_fwd(gmax, idx, loc, eo, cap, P, E, False)                                # decode: gate * row, 0 if dropped
@@ -110,7 +110,7 @@ class _MoEFunction(torch.autograd.Function):
               for l in range(L - 1, -1, -1)]
         o.mlp_chain(dout, bl, dxr, n_groups=E, n_wsets=E, group_stride=cap, group_rows=cnt, group_rows_clamp=cap,
                     y_add=dz[skip_l] if skip_l is not None else None, tag=2,
-                    geometry=4 if (M == 256 and dt != torch.float32 and cap >= 256) else 1)
+                    geometry=7 if (M == 256 and dt != torch.float32 and cap >= 256) else 1)
         dx = o.dispatch_bwd_data(None, idx, loc, dxr, cap)                                     # encode backward (no score)
         # expert weight / bias gradients, all layers in one launch (layer 0 reads its input rows through the permutation)
         dws = [torch.zeros(E, M, M, dtype=torch.float32, device=dev) for _ in range(L)]

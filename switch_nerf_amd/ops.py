@@ -460,15 +460,30 @@ def repack_weights(master, packed, transpose: bool):
 
 
 def repack_weights_batched(pairs):
-    """pairs: (master [ws, in, out] f32, packed, transpose) of one compute dtype -> one launch per 32 weights."""
+    """pairs: (master [ws, in, out] f32, packed, transpose[, in_padded]) of one compute dtype -> one launch per 32 weights.  in_padded:
+    the packed copy's in dimension when larger than the master's (zero-padded: pack_weights_padded)."""
     from ._lib import PackItem
     for i0 in range(0, len(pairs), 32):
         chunk = pairs[i0:i0 + 32]
         arr = (PackItem * len(chunk))()
-        for it, (master, packed, transpose) in zip(arr, chunk):
+        for it, pr in zip(arr, chunk):
+            master, packed, transpose = pr[:3]
             ws, i, o_ = master.shape
-            it.master, it.out, it.n_wsets, it.in_dim, it.out_dim, it.transpose = _p(master), _p(packed), ws, i, o_, int(bool(transpose))
+            ipad = int(pr[3]) if len(pr) > 3 and pr[3] else i
+            it.master, it.out, it.n_wsets, it.in_dim, it.out_dim, it.transpose = _p(master), _p(packed), ws, ipad, o_, int(bool(transpose))
+            it.in_rows = i if ipad != i else 0
         call("swn_pack_weights_batched", arr, len(chunk), _dt(chunk[0][1]), _stream())
+
+
+def pack_weights_padded(master, dtype, transpose: bool, in_padded: int):
+    """pack_weights with the master's in dimension zero-padded to in_padded: a 128-feature first layer for the K = 256 kernels of chain
+    geometries 6 / 7 (mlp_chain(..., x_features=128)).  Refresh with repack_weights_batched([(master, packed, transpose, in_padded)])."""
+    assert master.dim() == 3 and master.dtype == torch.float32 and in_padded >= master.shape[1]
+    ws, i, o_ = master.shape
+    out = torch.empty(ws * in_padded * o_, dtype=dtype, device=master.device)
+    out.swn_nk = (o_, in_padded) if transpose else (in_padded, o_)
+    repack_weights_batched([(master, out, transpose, in_padded)])
+    return out
 
 
 class Layer:
@@ -491,7 +506,7 @@ def chain_mask_words(dtype, n_groups: int, group_stride: int, max_width: int = 2
 
 def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride=None, group_rows=None,
               group_rows_clamp=None, x_gather=None, x_save=None, y_add=None, y_add_gather=None, tag=0, x_scale=None,
-              x_relu=False, geometry=0, group_begin=None, combine=None, heads=None, sched=None):
+              x_relu=False, geometry=0, group_begin=None, combine=None, heads=None, sched=None, x_features=0):
     """geometry: 0 / 1 the 64-row tile kernels, 2 - 5 the chain_big.hip geometries (include/swn.h).  group_begin: first row of every
     group (packed / no-batch layout) instead of g * group_stride.  combine = (y_fwd, dsig, wsig, gate, dgate_out): the combine backward
     (ops.combine_bwd) fused into the write-out of the last layer.  heads = (w_sigma, b_sigma, w_color, b_color, sigma_noise or None, raw):
@@ -510,6 +525,7 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
     d.x, d.x_gather, d.x_save, d.y = _p(x), _p(x_gather), _p(x_save), _p(y)
     d.x_scale, d.x_relu = _p(x_scale), int(bool(x_relu))
     d.y_add, d.y_add_gather = _p(y_add), _p(y_add_gather)
+    d.x_features = int(x_features)                 # (geometry 6 / 7: 128-feature rows under a zero-padded K = 256 first layer)
     if sched is None and d.geometry >= 6 and os.environ.get("SWN_CHAINQ_STATIC") is None:
         sched = chain_sched(x.device, d.tag)       # (launches of one role on one stream are ordered: they can share the counters)
     if sched is not None:

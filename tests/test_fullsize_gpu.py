@@ -100,7 +100,7 @@ def test_full_batch_bf16_properties():
     m16 = _model(torch.bfloat16, 277)
     st = m16.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=1.0, perturb_rand=pr, sigma_noise=noise, optimizer_step=False)
     c = st["ctx"]
-    assert c["n_seg"] == 16 and c["cap"] == 16384 and c["geom"] == 4
+    assert c["n_seg"] == 16 and c["cap"] == 16384 and c["geom"] == 7 and c["front_geom"] == 7
     rgb16, idx16, loc16 = c["rgb"].clone(), c["idx"].clone(), c["loc"].clone()
     grad16 = m16.grad.clone()
     assert torch.isfinite(rgb16).all() and torch.isfinite(st["loss"]) and torch.isfinite(grad16).all()
@@ -119,11 +119,12 @@ def test_full_batch_bf16_properties():
     print(f"full batch bf16: segment 5 alone vs inside the 16-segment launch: routing identical, max |rgb difference| {d5:.2e}")
     assert d5 < 2e-3
     # the same batch on the other expert-chain geometries (SWN_CHAIN_GEOM is read per forward).  5 = the phase-shifted 256-row
-    # workgroup with the bias added in the epilogue and 2 = the lockstep 256-row workgroup are BIT-identical to the 64-row kernels (1);
-    # the default (4) starts its accumulators at the bias: same sums, a different fp32 rounding order.
+    # workgroup with the bias added in the epilogue, 6 = its persistent form and 2 = the lockstep 256-row workgroup are BIT-identical to
+    # the 64-row kernels (1); the default (7: persistent) and 4 start their accumulators at the bias: same sums, a different fp32
+    # rounding order - and are bit-identical to each other, gradients included.
     import os
     runs = {}
-    for geom in ("1", "5", "2"):
+    for geom in ("1", "5", "2", "6", "4"):
         os.environ["SWN_CHAIN_GEOM"] = geom
         try:
             stg = m16.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=1.0, perturb_rand=pr, sigma_noise=noise, optimizer_step=False)
@@ -131,7 +132,9 @@ def test_full_batch_bf16_properties():
             os.environ.pop("SWN_CHAIN_GEOM")
         assert stg["ctx"]["geom"] == int(geom)
         runs[geom] = (stg["ctx"]["idx"].clone(), stg["ctx"]["rgb"].clone(), m16.grad.clone())
-    for geom in ("5", "2"):
+    assert torch.equal(runs["4"][0], idx16) and torch.equal(runs["4"][1], rgb16) and torch.equal(runs["4"][2], grad16), \
+        "geometry 4 and its persistent form (7, the default) are bit-identical"
+    for geom in ("5", "2", "6"):
         assert torch.equal(runs[geom][0], runs["1"][0]) and torch.equal(runs[geom][1], runs["1"][1]), f"geometry {geom}: the forward pass is bit-identical"
         gd = (runs[geom][2] - runs["1"][2]).abs().max().item() / runs["1"][2].abs().max().item()
         print(f"full batch bf16: geometry {geom} vs 64-row expert chains: max relative gradient difference {gd:.2e} (atomics order only)")
@@ -209,7 +212,7 @@ def test_full_segment_bf16_vs_autocast_oracle():
     st = m.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=1.0, perturb_rand=_dev(pr),
                       sigma_noise=_dev(noise.reshape(-1)), optimizer_step=False)
     c = st["ctx"]
-    assert c["n_seg"] == 1 and c["cap"] == 16384 and c["geom"] == 4
+    assert c["n_seg"] == 1 and c["cap"] == 16384 and c["geom"] == 7
     ac = O.Autocast(torch.bfloat16, policy="cuda")
     p = O.params_from_numpy(sd)
     kw = dict(sigma_noise=torch.from_numpy(noise), perturb_rand=torch.from_numpy(pr), perturb=1.0, autocast=ac)

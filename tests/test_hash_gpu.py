@@ -216,7 +216,7 @@ def test_configs4_full_size_share_fp16_hash_cf125_properties():
         noise = torch.randn(N * S, generator=g).cuda()
         st = m.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=1.0, perturb_rand=pr, sigma_noise=noise, optimizer_step=False)
         c = st["ctx"]
-        assert c["n_seg"] == 2 and c["cap"] == int(1.25 * 16384) and c["geom"] == 4
+        assert c["n_seg"] == 2 and c["cap"] == int(1.25 * 16384) and c["geom"] == 7
         assert torch.isfinite(c["rgb"]).all() and torch.isfinite(st["loss"]) and torch.isfinite(m.grad).all()
         assert (c["counts"].sum(1) == chunk).all()
         kept = float((c["loc"] < c["cap"]).float().mean())

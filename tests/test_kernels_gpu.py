@@ -888,6 +888,66 @@ def test_chain_256_row_geometry_bit_exact(ng, cap, seed, geometry):
         assert off < 1e-4, f"{name}: {off:.3g} of the elements are off"
 
 
+@pytest.mark.parametrize("P", [1000, 256 * 37 + 5, 70000])
+def test_front_chains_on_the_persistent_geometry(P):
+    """The dense FRONT chains of the model on the persistent 256-row geometry (chain_big.hip, geometries 6 / 7): forward = 128-feature
+    encoding rows under a first layer whose packed weights are zero-padded to K = 256 (x_features = 128), two more 256 x 256 layers, every
+    output saved, a ReLU mask; backward = two layers through the stored mask with the rows of another tensor added through an index (-1 =
+    nothing: the expert path's input gradient through tok2row).  Geometry 6 (bias in the epilogue) must be BIT-identical to the 64-row
+    kernels - the zero-padded K steps add exact zeros - geometry 7 (accumulators start at the bias) to a bf16 rounding, and its backward on
+    the same masks bit-identical again; a ragged last tile, rows past the end untouched."""
+    o = ops()
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(P)
+    pe = torch.randn(P, 128, generator=g).to(dev()).to(dt)
+    W0 = (torch.randn(1, 128, 256, generator=g) / 11).to(dev())
+    W1 = (torch.randn(1, 256, 256, generator=g) / 16).to(dev())
+    W2 = (torch.randn(1, 256, 256, generator=g) / 16).to(dev())
+    b = [(torch.randn(1, 256, generator=g) * 0.1).to(dev()) for _ in range(3)]
+    w0, w0p = o.pack_weights(W0, dt, True), o.pack_weights_padded(W0, dt, True, 256)
+    w1, w2 = o.pack_weights(W1, dt, True), o.pack_weights(W2, dt, True)
+    w1b, w2b = o.pack_weights(W1, dt, False), o.pack_weights(W2, dt, False)
+    assert w0p.numel() == 2 * w0.numel()
+    dg = (torch.randn(P, 256, generator=g) * 0.1).to(dev()).to(dt)
+    R = P // 2 + 3
+    dx = torch.randn(R, 256, generator=g).to(dev()).to(dt)
+    t2r = torch.randint(-1, R, (P,), generator=g).int().to(dev())
+    pad = 300
+
+    def run(geom, mask_in=None):
+        big = geom >= 6
+        h0, a1, gg = (torch.zeros(P + pad, 256, dtype=dt, device=dev()) for _ in range(3))
+        mask = torch.zeros(o.chain_mask_words(dt, 1, P, 256), dtype=torch.int32, device=dev())
+        o.mlp_chain(pe, [o.Layer(w0p if big else w0, b[0], save=h0), o.Layer(w1, b[1], relu=1, mask=mask, save=a1), o.Layer(w2, b[2])], gg[:P],
+                    tag=3, geometry=geom, x_features=128 if big else 0)
+        dza1, dh0 = (torch.zeros(P + pad, 256, dtype=dt, device=dev()) for _ in range(2))
+        o.mlp_chain(dg, [o.Layer(w2b, None, relu=2, mask=mask if mask_in is None else mask_in, save=dza1), o.Layer(w1b, None)], dh0[:P],
+                    y_add=dx, y_add_gather=t2r, tag=6, geometry=geom)
+        torch.cuda.synchronize()
+        return dict(h0=h0, a1=a1, g=gg, dza1=dza1, dh0=dh0), mask
+
+    ref, _ = run(0)
+    # against fp32 math on the rounded operands (the 64-row kernels are pinned elsewhere; this pins THIS test's reference)
+    h0_ref = pe.float() @ W0[0].to(dt).float() + b[0]
+    assert (ref["h0"][:P].float() - h0_ref).abs().max().item() <= 2.0 ** -7 * max(1.0, h0_ref.abs().max().item())
+    for rep in range(2):
+        got, m6 = run(6)
+        for k in ref:
+            assert torch.equal(ref[k][:P], got[k][:P]), f"{k} (run {rep}): {(ref[k][:P] != got[k][:P]).float().mean().item():.3g} of the elements differ"
+            assert got[k][P:].abs().sum().item() == 0, f"{k}: rows past the end were written"
+    got7, m7 = run(7)
+    for k in ("h0", "a1", "g"):
+        a_, b_ = ref[k][:P].float(), got7[k][:P].float()
+        frac, err = (a_ != b_).float().mean().item(), (a_ - b_).abs().max().item() / max(1.0, a_.abs().max().item())
+        assert frac < 0.03 and err < 2.0 ** -6, f"{k}: {frac:.3g} of the elements differ, max difference {err:.3g}"
+    got7b, _ = run(7, mask_in=m6)          # backward has no bias: on the same masks geometry 7 is bit-identical
+    for k in ("dza1", "dh0"):
+        assert torch.equal(ref[k][:P], got7b[k][:P]), k
+        assert got7b[k][P:].abs().sum().item() == 0
+    for t in o._chain_sched.values():
+        assert int(t.abs().sum().item()) == 0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_nobatch_sparse_abi_vs_reference_golden(dtype):
     """The no-batch (evaluation) kernel ABI - swn_dispatch_nobatch_fwd / _bwd_data / _bwd_gate, the reference's argument order with
