@@ -372,8 +372,10 @@ typedef struct swn_pack_item {
   const float* master;  /* [n_wsets][in_dim][out_dim] f32 */
   void* out;            /* packed compute copy (dtype of the call) */
   int32_t n_wsets, in_dim, out_dim, transpose;
-  int32_t in_rows;      /* rows of `master` actually stored when fewer than in_dim ([n_wsets][in_rows][out_dim]): the packed copy is
-                           zero-padded to in_dim (a 128-feature first layer under the K = 256 kernels of geometry 6 / 7); 0 = in_dim */
+  int32_t in_rows;      /* rows / columns of `master` actually stored when fewer than in_dim / out_dim: master is                     */
+  int32_t out_cols;     /* [n_wsets][in_rows][out_cols] and the packed copy is zero-padded to (in_dim, out_dim) - a 128-feature first
+                           layer (forward: in_rows = 128 under in_dim = 256; backward-data of a 128-output layer: out_cols = 128 under
+                           out_dim = 256) for the K = 256 kernels of chain geometries 6 / 7.  0 = in_dim / out_dim                   */
 } swn_pack_item;
 int swn_pack_weights_batched(const swn_pack_item* items, int n_items, int dtype, void* stream);
 

@@ -28,7 +28,7 @@ class WgradJob(C.Structure):
 
 
 class PackItem(C.Structure):
-    _fields_ = [("master", vp), ("out", vp), ("n_wsets", i32), ("in_dim", i32), ("out_dim", i32), ("transpose", i32), ("in_rows", i32)]
+    _fields_ = [("master", vp), ("out", vp), ("n_wsets", i32), ("in_dim", i32), ("out_dim", i32), ("transpose", i32), ("in_rows", i32), ("out_cols", i32)]
 
 
 class HashCfg(C.Structure):

@@ -886,7 +886,8 @@ __global__ void pack_weights_batched_kernel(const PackTable tab) {
   constexpr int KSTEP = Cfg<T>::KSTEP;
   const swn_pack_item& q = tab.it[blockIdx.y];
   const int in_dim = q.in_dim, out_dim = q.out_dim, transpose = q.transpose;
-  const int in_rows = q.in_rows > 0 ? q.in_rows : in_dim;          // rows of the master that exist (the rest of in_dim packs as zeros)
+  const int in_rows = q.in_rows > 0 ? q.in_rows : in_dim;          // rows / columns of the master that exist (the rest packs as zeros)
+  const int out_cols = q.out_cols > 0 ? q.out_cols : out_dim;
   const int N = transpose ? out_dim : in_dim, K = transpose ? in_dim : out_dim;
   const long per_set = (long)(N / 32) * (K / KSTEP) * 64;
   const long total_chunks = per_set * q.n_wsets;
@@ -899,14 +900,14 @@ __global__ void pack_weights_batched_kernel(const PackTable tab) {
     r >>= 6;
     const int ks = (int)(r % (K / KSTEP)), nt = (int)(r / (K / KSTEP));
     const int n = nt * 32 + (lane & 31);
-    const float* m = master + ws * (long)in_rows * out_dim;
+    const float* m = master + ws * (long)in_rows * out_cols;
     T* o = out + c * EPC;
 #pragma unroll
     for (int j = 0; j < EPC; ++j) {
       int kk;
       if constexpr (sizeof(T) == 2) kk = ks * 16 + (lane >> 5) * 8 + j; else kk = ks * 8 + 2 * j + (lane >> 5);
-      const int row = transpose ? kk : n;
-      const float v = row < in_rows ? (transpose ? m[(long)kk * out_dim + n] : m[(long)n * out_dim + kk]) : 0.f;
+      const int row = transpose ? kk : n, col = transpose ? n : kk;          // master[row][col]
+      const float v = (row < in_rows && col < out_cols) ? m[(long)row * out_cols + col] : 0.f;
       ElemIO<T>::st(o + j, v);
     }
   }
@@ -991,7 +992,8 @@ extern "C" int swn_pack_weights_batched(const swn_pack_item* items, int n_items,
   for (int i = 0; i < n_items; ++i) {
     const swn_pack_item& q = items[i];
     SWN_CHECK(q.master && q.out && q.n_wsets >= 1, "swn_pack_weights_batched: item %d: null pointer / no weight sets", i);
-    SWN_CHECK(q.in_rows >= 0 && q.in_rows <= q.in_dim, "swn_pack_weights_batched: item %d: in_rows %d not in [0, in_dim = %d]", i, q.in_rows, q.in_dim);
+    SWN_CHECK(q.in_rows >= 0 && q.in_rows <= q.in_dim && q.out_cols >= 0 && q.out_cols <= q.out_dim,
+              "swn_pack_weights_batched: item %d: in_rows %d / out_cols %d not in [0, in_dim = %d] / [0, out_dim = %d]", i, q.in_rows, q.out_cols, q.in_dim, q.out_dim);
     const int N = q.transpose ? q.out_dim : q.in_dim, K = q.transpose ? q.in_dim : q.out_dim;
     SWN_CHECK(N % 32 == 0 && K % kstep == 0, "swn_pack_weights_batched: item %d: N=%d must be a multiple of 32, K=%d of %d", i, N, K, kstep);
     const long chunks = (long)q.n_wsets * (N / 32) * (K / kstep) * 64;
@@ -1067,7 +1069,9 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
     SWN_CHECK(d.comb_gate && d.comb_dgate, "swn_mlp_chain: combine backward needs comb_gate and comb_dgate");
     SWN_CHECK((nl == 128 || nl == 256 || nl == 512) && nl * (d.dtype == SWN_F32 ? 4 : 2) <= 1024,
               "swn_mlp_chain: combine backward: last layer of 128 / 256 / 512 features, at most 1 KiB per row");
-    SWN_CHECK(d.geometry < 2 && (d.tag & 0xFF) == 5, "swn_mlp_chain: combine backward runs on the 64-row kernels (geometry 0 / 1), tag 5");
+    SWN_CHECK((d.geometry < 2 || d.geometry >= 6) && (d.tag & 0xFF) == 5,
+              "swn_mlp_chain: combine backward runs on the 64-row kernels (geometry 0 / 1) or the persistent ones (6 / 7), tag 5");
+    SWN_CHECK(d.geometry < 2 || nl == 256, "swn_mlp_chain: combine backward on geometry 6 / 7: last layer of 256 features");
   }
   {   // 256-row geometry (chain_big.hip).  Never chosen silently for bf16: the ReLU mask layout differs between the geometries,
       // and a backward chain must run on the geometry of the forward chain that recorded its masks - the caller pairs them.

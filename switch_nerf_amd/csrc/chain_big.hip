@@ -1089,6 +1089,60 @@ __device__ __forceinline__ void stage_pieces_q(const Ctx& cx, const char* x, int
   }
 }
 
+// write_pieces16 with the COMBINE BACKWARD applied on the way out (the tail backward chain; include/swn.h, comb_*; the arithmetic of
+// chain_kernel's fused write-out, value for value and in its summation order): with z = the output row,
+//   t = (z + dsig[row] * wsig) * (y[row] > 0);   out[row] = t * gate[row];   dgate[row] = <y[row], t> / gate[row]
+// A half-wave holds one row (lane l31 = its 8 features 8 l31 ..): the row's dot product is 8 sequential fmas per lane, then the
+// xor butterfly over the 32 lanes (16, 8, 4, 2, 1) like the 64-row kernel's 32 chunk lanes.
+template <typename E>
+__device__ __forceinline__ void write_pieces16_comb(const Ctx& cx, int c0, __amdgpu_buffer_rsrc_t rs, const swn_chain_desc& d, long grow0, int rows) {
+  const int lane16 = cx.lane * 16;
+  float wv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) wv[e] = d.comb_wsig ? d.comb_wsig[cx.l31 * 8 + e] : 0.f;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    u32x4_t v[8], yc[8];
+    float gt[8], ds[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = 2 * (c0 + 4 * (8 * b + j)) + cx.lhi;
+      const long gr = grow0 + (r < rows ? r : 0);
+      yc[j] = *(const u32x4_t*)((const char*)d.comb_y + gr * ROWB + cx.l31 * 16);
+      gt[j] = d.comb_gate[gr];
+      ds[j] = d.comb_dsig ? d.comb_dsig[gr] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *(const u32x4_t*)(cx.smem + piece_addr(cx, c0 + 4 * (8 * b + j)));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = 2 * (c0 + 4 * (8 * b + j)) + cx.lhi;
+      float z[8], yv[8], dot = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        z[2 * q] = E::lo(v[j][q]); z[2 * q + 1] = E::hi(v[j][q]);
+        yv[2 * q] = E::lo(yc[j][q]); yv[2 * q + 1] = E::hi(yc[j][q]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = z[e] + ds[j] * wv[e];          // (one fma, like combine_bwd_kernel)
+        t = yv[e] > 0.f ? t : 0.f;
+        dot += yv[e] * t;
+        z[e] = t * gt[j];
+      }
+      for (int o = 16; o >= 1; o >>= 1) dot += __shfl_xor(dot, o);
+      if (cx.l31 == 0 && r < rows) d.comb_dgate[grow0 + r] = dot / gt[j];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[j][q] = E::pack2(z[2 * q], z[2 * q + 1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rs, lane16, (c0 + 4 * (8 * b + j)) * 1024, SWN_BIG_Y_AUX);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("s_nop 3" :: "v"(v[j]));
+    SWN_PIN();
+  }
+}
+
 // write_pieces16 with the rows of y_add fetched through an index (the front backward chain adds the expert path's input gradient through
 // tok2row: -1 = nothing to add): pieces c0 + 4 j (j < 16) in two batches of 8 - the 8 row indices, then the 8 x 16 bytes, together
 template <typename E>
@@ -1326,7 +1380,10 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
       if (it > 0) {
         const __amdgpu_buffer_rsrc_t ry = out_rs(d.y, prev);
         const __amdgpu_buffer_rsrc_t ra = d.y_add ? out_rs((void*)d.y_add, prev) : ry;
-        if (d.y_add && d.y_add_gather) write_pieces16_gather<E>(cs, 64 * rgs + fgs, ry, (const char*)d.y_add, d.y_add_gather, prev.grow0, prev.rows);
+        if constexpr (TAG == 5) {      // (only this instantiation carries the fused combine backward)
+          if (d.comb_y) write_pieces16_comb<E>(cs, 64 * rgs + fgs, ry, d, prev.grow0, prev.rows);
+          else write_pieces16<E, false, 8>(cs, 64 * rgs + fgs, ry, ra);
+        } else if (d.y_add && d.y_add_gather) write_pieces16_gather<E>(cs, 64 * rgs + fgs, ry, (const char*)d.y_add, d.y_add_gather, prev.grow0, prev.rows);
         else if (d.y_add) write_pieces16<E, true, 8>(cs, 64 * rgs + fgs, ry, ra);
         else write_pieces16<E, false, 8>(cs, 64 * rgs + fgs, ry, ra);
         SWN_WAIT_LGKM0();                        // (every piece is in registers / on its way: the rows may be overwritten)
@@ -1463,7 +1520,10 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
   {
     const __amdgpu_buffer_rsrc_t ry = out_rs(d.y, prev);
     const __amdgpu_buffer_rsrc_t ra = d.y_add ? out_rs((void*)d.y_add, prev) : ry;
-    if (d.y_add && d.y_add_gather) write_pieces16_gather<E>(cx, 64 * rg + fg, ry, (const char*)d.y_add, d.y_add_gather, prev.grow0, prev.rows);
+    if constexpr (TAG == 5) {
+      if (d.comb_y) write_pieces16_comb<E>(cx, 64 * rg + fg, ry, d, prev.grow0, prev.rows);
+      else write_pieces16<E, false, 8>(cx, 64 * rg + fg, ry, ra);
+    } else if (d.y_add && d.y_add_gather) write_pieces16_gather<E>(cx, 64 * rg + fg, ry, (const char*)d.y_add, d.y_add_gather, prev.grow0, prev.rows);
     else if (d.y_add) write_pieces16<E, true, 8>(cx, 64 * rg + fg, ry, ra);
     else write_pieces16<E, false, 8>(cx, 64 * rg + fg, ry, ra);
   }
@@ -1499,7 +1559,8 @@ bool chain_big_eligible(const swn_chain_desc& d) {
 // geometries 6 / 7 (chainq_kernel) also take the dense front chains: a 128-feature chain input (x_features = 128 under a first layer
 // whose weights are zero-padded to k = 256) and a gathered y_add
 bool chain_persistent_eligible(const swn_chain_desc& d) {
-  if (d.dtype != SWN_HALF || d.x_save || d.x_scale || d.comb_y || d.heads_raw) return false;
+  if (d.dtype != SWN_HALF || d.x_save || d.x_scale || d.heads_raw) return false;
+  if (d.comb_y && (d.tag != 5 || d.y_add)) return false;      // (the fused combine backward: the tail backward instantiation only)
 #ifndef SWN_BIG_TIMING
   if (d.y_add_gather && !d.y_add) return false;
 #endif
@@ -1616,7 +1677,7 @@ static int chain_persistent_launch(const swn_chain_desc& d, void* stream) {
     fn = d.geometry == 7 ? (const void*)chainq_kernel<HalfT, TAGV, true> : (const void*)chainq_kernel<HalfT, TAGV, false>;    \
     break;
   switch (d.tag) {
-    SWN_PICKQ(1) SWN_PICKQ(2) SWN_PICKQ(3) SWN_PICKQ(6)
+    SWN_PICKQ(1) SWN_PICKQ(2) SWN_PICKQ(3) SWN_PICKQ(5) SWN_PICKQ(6)
     default: fn = d.geometry == 7 ? (const void*)chainq_kernel<HalfT, 0, true> : (const void*)chainq_kernel<HalfT, 0, false>;
   }
 #undef SWN_PICKQ

@@ -310,6 +310,12 @@ class SwitchNeRF:
                 self.wf["xyz_pad"] = ops.pack_weights_padded(w3, self.dtype, True, 256)
             else:
                 pairs.append((w3, self.wf["xyz_pad"], True, 256))
+        if self._tail_big():      # the tail BACKWARD chain likewise: dh2 (128 features) under the backward-data copy of layer "2" padded in K
+            w3 = self.p["l2h.w"].unsqueeze(0)
+            if "l2h_pad" not in self.wb:
+                self.wb["l2h_pad"] = ops.pack_weights_padded(w3, self.dtype, False, 0, 256)
+            else:
+                pairs.append((w3, self.wb["l2h_pad"], False, 0, 256))
         if pairs:
             ops.repack_weights_batched(pairs)      # one launch (was 23 of ~5 us each: a tenth of the step at 1024 rays per GPU)
         if self._flat_param is not None:           # the copies now match the master weights as of this version of flat_param
@@ -320,6 +326,15 @@ class SwitchNeRF:
         a 128-feature encoding in a 16-bit compute dtype (building.yaml).  SWN_FRONT_GEOM=1 keeps them on the 64-row kernels."""
         return ("xyz.w" in self.spec and self.M == 256 and self.G == 256 and self.KP == 128 and self.dtype != torch.float32
                 and self.hash is None and os.environ.get("SWN_FRONT_GEOM", "7") != "1")
+
+    def _tail_big(self) -> bool:
+        """The tail backward chain (dh2 -> dh1 -> dy with the combine backward in its write-out) on the persistent 256-row geometry:
+        built and bit-exact (tests/test_kernels_gpu.py::test_chain_fused_combine_backward), but OFF by default - measured 0.23 ms per
+        step SLOWER than the 64-row kernel (14.42 against 14.19 ms on one box): a two-layer chain is 5 phases, and the staging phase
+        with the combine backward in it (three more operand streams behind the write-out) is the longest of them.  SWN_TAIL_GEOM=7
+        turns it on (profiles/r04_experiments.md)."""
+        return ("l2h.w" in self.spec and "l1.w" in self.spec and self.M == 256 and self.H2 == 128 and self.dtype != torch.float32
+                and os.environ.get("SWN_TAIL_GEOM", "1") in ("6", "7"))
 
     def set_expert_parallel(self, ep):
         """Shard the experts over the ranks of `ep` (parallel.ExpertParallel) and exchange the dispatched rows instead of
@@ -693,8 +708,9 @@ class SwitchNeRF:
         dout = _b("dy", (P, M), dt)
         if M * dout.element_size() <= 1024:      # (a row's 16-byte chunks must fit one wavefront: everything but fp32 rows of 512)
             dgmax = _b("dgmax", (P,), torch.float32)
-            o.mlp_chain(dh2, [o.Layer(self.wb["l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dout, tag=5,
-                        combine=(c["y"], dsig, self.p["sigma.w"], c["gmax"], dgmax))
+            tg = int(os.environ.get("SWN_TAIL_GEOM", "1")) if self._tail_big() else 0
+            o.mlp_chain(dh2, [o.Layer(self.wb["l2h_pad" if tg >= 6 else "l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dout, tag=5,
+                        combine=(c["y"], dsig, self.p["sigma.w"], c["gmax"], dgmax), geometry=tg, x_features=H2 if tg >= 6 else 0)
         else:
             o.mlp_chain(dh2, [o.Layer(self.wb["l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dout, tag=5)
             dout, dgmax = o.combine_bwd(dout, c["y"], dsig, self.p["sigma.w"], c["gmax"])

@@ -460,8 +460,8 @@ def repack_weights(master, packed, transpose: bool):
 
 
 def repack_weights_batched(pairs):
-    """pairs: (master [ws, in, out] f32, packed, transpose[, in_padded]) of one compute dtype -> one launch per 32 weights.  in_padded:
-    the packed copy's in dimension when larger than the master's (zero-padded: pack_weights_padded)."""
+    """pairs: (master [ws, in, out] f32, packed, transpose[, in_padded[, out_padded]]) of one compute dtype -> one launch per 32 weights.
+    in_padded / out_padded: the packed copy's in / out dimension when larger than the master's (zero-padded: pack_weights_padded)."""
     from ._lib import PackItem
     for i0 in range(0, len(pairs), 32):
         chunk = pairs[i0:i0 + 32]
@@ -470,19 +470,23 @@ def repack_weights_batched(pairs):
             master, packed, transpose = pr[:3]
             ws, i, o_ = master.shape
             ipad = int(pr[3]) if len(pr) > 3 and pr[3] else i
-            it.master, it.out, it.n_wsets, it.in_dim, it.out_dim, it.transpose = _p(master), _p(packed), ws, ipad, o_, int(bool(transpose))
-            it.in_rows = i if ipad != i else 0
+            opad = int(pr[4]) if len(pr) > 4 and pr[4] else o_
+            it.master, it.out, it.n_wsets, it.in_dim, it.out_dim, it.transpose = _p(master), _p(packed), ws, ipad, opad, int(bool(transpose))
+            it.in_rows, it.out_cols = (i if ipad != i else 0), (o_ if opad != o_ else 0)
         call("swn_pack_weights_batched", arr, len(chunk), _dt(chunk[0][1]), _stream())
 
 
-def pack_weights_padded(master, dtype, transpose: bool, in_padded: int):
-    """pack_weights with the master's in dimension zero-padded to in_padded: a 128-feature first layer for the K = 256 kernels of chain
-    geometries 6 / 7 (mlp_chain(..., x_features=128)).  Refresh with repack_weights_batched([(master, packed, transpose, in_padded)])."""
-    assert master.dim() == 3 and master.dtype == torch.float32 and in_padded >= master.shape[1]
+def pack_weights_padded(master, dtype, transpose: bool, in_padded: int = 0, out_padded: int = 0):
+    """pack_weights with the master's in / out dimension zero-padded: a 128-feature first layer for the K = 256 kernels of chain
+    geometries 6 / 7 (mlp_chain(..., x_features=128)) - forward (transpose): in 128 -> 256; backward-data of a 128-output layer: out 128 ->
+    256.  Refresh with repack_weights_batched([(master, packed, transpose, in_padded, out_padded)])."""
+    assert master.dim() == 3 and master.dtype == torch.float32
     ws, i, o_ = master.shape
-    out = torch.empty(ws * in_padded * o_, dtype=dtype, device=master.device)
-    out.swn_nk = (o_, in_padded) if transpose else (in_padded, o_)
-    repack_weights_batched([(master, out, transpose, in_padded)])
+    ipad, opad = in_padded or i, out_padded or o_
+    assert ipad >= i and opad >= o_
+    out = torch.empty(ws * ipad * opad, dtype=dtype, device=master.device)
+    out.swn_nk = (opad, ipad) if transpose else (ipad, opad)
+    repack_weights_batched([(master, out, transpose, ipad, opad)])
     return out
 
 

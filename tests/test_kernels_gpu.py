@@ -1021,6 +1021,29 @@ def test_chain_fused_combine_backward(dtype):
         o.mlp_chain(dh2, [o.Layer(w2, None), o.Layer(w1, None)], d2, tag=5, combine=(y, None, None, gate, g2))
         r2, rg2 = o.combine_bwd(dy, y, None, None, gate)
         assert torch.equal(d2, r2) and (g2 - rg2).abs().max().item() <= 1e-5 * rg2.abs().max().item()
+    if dtype == torch.float32:
+        return
+    # the same chain on the persistent 256-row geometry (dh2's 128 features under the K-padded backward-data copy of layer "2", the
+    # combine backward in the S phase's write-out): no bias in a backward chain, so geometries 6 and 7 are both bit-identical to the
+    # 64-row kernels - rows, saved dh1, and the gate gradient (same fma chain per lane, same butterfly over the row's 32 lanes)
+    w2p = o.pack_weights_padded((torch.randn(1, M, H2, generator=torch.Generator().manual_seed(5)) * 0).to(dev()), dtype, False, 0, 256)
+    g = torch.Generator().manual_seed(5)
+    _ = torch.randn(P, H2, generator=g)
+    w2m = (torch.randn(1, M, H2, generator=g) / 16).to(dev())        # (the same draws as w2 above)
+    w2p = o.pack_weights_padded(w2m, dtype, False, 0, 256)
+    for geom in (6, 7):
+        for comb in ((y, dsig, wsig, gate), (y, None, None, gate)):
+            dh1c = torch.zeros(P + 300, M, dtype=dtype, device=dev())
+            doutc = torch.zeros(P + 300, M, dtype=dtype, device=dev())
+            dgc = torch.zeros(P, device=dev())
+            o.mlp_chain(dh2, [o.Layer(w2p, None, save=dh1c), o.Layer(w1, None)], doutc[:P], tag=5, combine=comb + (dgc,), geometry=geom,
+                        x_features=H2)
+            dref, gref = (dout, dgate) if comb[1] is not None else (d2, g2)
+            torch.cuda.synchronize()
+            assert torch.equal(dh1c[:P], dh1b), f"geometry {geom}: dh1"
+            assert torch.equal(doutc[:P], dref), f"geometry {geom}: {(doutc[:P] != dref).float().mean().item():.3g} of the output elements differ"
+            assert torch.equal(dgc, gref), f"geometry {geom}: gate gradient {(dgc - gref).abs().max().item():.3g}"
+            assert dh1c[P:].abs().sum().item() == 0 and doutc[P:].abs().sum().item() == 0
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
