@@ -295,6 +295,13 @@ __device__ __forceinline__ uint32_t pk_mul16(uint32_t p, uint32_t t) {
 
 // bias_off: byte offset of the bias slot behind BIAS0 (geometry 4 double-buffers it); hook(mi) runs after the row tile mi is rewritten.
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+// HalfHook<F>: a hook that epilogue_p calls after every HALF row tile (h = 2 mi + ni, 8 calls) instead of after every row tile
+template <typename F> struct HalfHook {
+  F f;
+  __device__ __forceinline__ void operator()(int h) const { f(h); }
+};
+template <typename T> struct hook_halves { static constexpr bool value = false; };
+template <typename F> struct hook_halves<HalfHook<F>> { static constexpr bool value = true; };
 template <typename E, typename G, int RELU, bool BIAS, bool SKIP, typename HOOK = NoHook>
 __device__ __forceinline__ void epilogue(f32x16_t (&acc)[G::MI][2], const Ctx& cx, u32x4_t& mk, int bias_off = 0, HOOK hook = HOOK()) {
   char* smem = cx.smem;
@@ -715,9 +722,10 @@ __device__ __forceinline__ void epilogue_p(f32x16_t (&acc)[4][2], const Ctx& cx,
         *(u32x4_t*)(smem + (e2_base ^ (uint32_t)((4 * ni + g) << 4)) + mi * (32 * ROWB)) = o;
       }
       SWN_PIN();
+      if constexpr (hook_halves<HOOK>::value) hook(2 * mi + ni);
     }
     if constexpr (RELU == 1) mk[mi] = (m[0] | m[1]) | (m[2] | m[3]);
-    hook(mi);
+    if constexpr (!hook_halves<HOOK>::value) hook(mi);
   }
 }
 
@@ -1482,20 +1490,31 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         if (wo) {
           const __amdgpu_buffer_rsrc_t rs = out_rs(wo, cur);
           const int c0 = 64 * (1 - rge) + fge;
-          u32x4_t wv[4];
-          auto rd = [&](int b) {
+          // 16 pieces in 8 half steps of 2 (one behind every half row tile of the epilogue) through TWO alternating register sets: the
+          // LDS reads that refill a set are issued a half step after ITS stores - hundreds of clocks - never right behind them.  (On
+          // this part a 16-byte store whose registers were rewritten two instructions later reached memory with single dwords of the
+          // NEW value under store back-pressure; chainp_kernel holds that off with 16 idle issue slots behind every store batch,
+          // here the distance is structural.)
+          u32x4_t wv[2][2];
+          auto rd = [&](int h) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wv[j] = *(const u32x4_t*)(smem + piece_addr(ce, c0 + 4 * (4 * b + j)));
+            for (int j = 0; j < 2; ++j) wv[h & 1][j] = *(const u32x4_t*)(smem + piece_addr(ce, c0 + 4 * (2 * h + j)));
           };
           rd(0);
-          auto hook = [&](int mi) {
+          auto hook_f = [&](int h) {
+            // the set stored a half step ago stays ALLOCATED up to here (an empty statement that reads it): a value is dead behind its
+            // store, and the compiler would hand its registers to the very next epilogue temporaries - the VALU write two instructions
+            // behind the store that the hazard is about.  The next write to them is the refill below.
+            asm volatile("" :: "v"(wv[(h + 1) & 1][0]), "v"(wv[(h + 1) & 1][1]));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(wv[j], rs, lane16e, (c0 + 4 * (4 * mi + j)) * 1024, SWN_BIG_STORE_AUX);
-            asm volatile("s_nop 7\n\ts_nop 7" :: "v"(wv[0]), "v"(wv[1]), "v"(wv[2]), "v"(wv[3]));      // (store-data hold: see chainp_kernel)
-            if (mi < 3) rd(mi + 1);
+            for (int j = 0; j < 2; ++j) __builtin_amdgcn_raw_buffer_store_b128(wv[h & 1][j], rs, lane16e, (c0 + 4 * (2 * h + j)) * 1024, SWN_BIG_STORE_AUX);
+            if (h < 7) rd(h + 1);                  // (into the OTHER set: stored from a half step ago)
             SWN_PIN();
           };
-          epilogue_p_dispatch<E, decltype(hook)>(acc, ce, mk, ly.relu, bias_epi, ly.skip != 0, (bc % 3) * 1024, hook);
+          const HalfHook<decltype(hook_f)> hook{hook_f};
+          epilogue_p_dispatch<E, HalfHook<decltype(hook_f)>>(acc, ce, mk, ly.relu, bias_epi, ly.skip != 0, (bc % 3) * 1024, hook);
+          SWN_PIN();
+          asm volatile("s_nop 7\n\ts_nop 7" :: "v"(wv[0][0]), "v"(wv[0][1]), "v"(wv[1][0]), "v"(wv[1][1]));      // (the last two sets)
         } else {
           epilogue_p_dispatch<E, NoHook>(acc, ce, mk, ly.relu, bias_epi, ly.skip != 0, (bc % 3) * 1024, NoHook());
         }

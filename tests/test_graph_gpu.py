@@ -75,11 +75,12 @@ def test_graphed_train_50_replays_equal_eager():
 
 
 def test_expert_chain_200_back_to_back_launches_bit_exact():
-    """200 full-size (2,097,152-row) launches of the phase-shifted expert chain: geometry 5 is bit-identical to the 64-row kernels on
-    every launch (outputs and all six saved activations) - the store-data hazard of round 2 (a later register value stored a few times
-    per 1e5 stores) would show here -, geometry 4 stays within its bias-first accumulation bound."""
+    """200 full-size (2,097,152-row) launches of the phase-shifted expert chains: geometries 5 and 6 (the persistent form, in turn) are
+    bit-identical to the 64-row kernels on every launch (outputs and all six saved activations) - the store-data hazard of round 2 (a
+    later register value stored a few times per 1e5 stores) would show here -, geometry 7 (the model's default) is bit-identical to
+    geometry 4 and within the bias-first accumulation bound."""
     r = _probe("chain", "--launches", "200", timeout=900)
-    assert r["ok"] and r["geometry5_launches_with_a_difference"] == 0, r
+    assert r["ok"] and r["geometry5_launches_with_a_difference"] == 0 and r["geometry7_launches_that_differ_from_geometry4"] == 0, r
 
 
 def test_render_rays_graph_eval_matches_eager():
