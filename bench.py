@@ -102,6 +102,10 @@ def main():
     ap.add_argument("--parallelism", default="dp", choices=["dp", "ep"],
                     help="dp (default): experts replicated, one gradient all-reduce per step; ep: experts sharded over the ranks, "
                          "dispatched rows exchanged with RCCL all-to-all (BASELINE.json configs[2]; needs gpus | 8)")
+    ap.add_argument("--ep-padded", default="off", choices=["off", "on", "auto"],
+                    help="expert parallel: off = kept rows only, unequal splits (one host read per forward pass, eager launches); on = the "
+                         "reference's capacity-padded equal splits (nothing read on the host: the step can be replayed from a hipGraph with "
+                         "--graph on); auto = padded when a segment's payload is at most 64 MiB")
     ap.add_argument("--fine", type=int, default=0, help="hierarchical sampling: fine samples per ray on top of --samples (other recipes; "
                                                         "the headline metric is --fine 0)")
     ap.add_argument("--mip", action="store_true", help="mip recipe: --samples edges per level (frustums = edges - 1), two levels")
@@ -180,7 +184,7 @@ def main():
         allreduce = parallel.make_grad_allreduce()     # RCCL all-reduce over xGMI, one 16 MB bucket
     if a.parallelism == "ep":
         from switch_nerf_amd.parallel import ExpertParallel
-        model.set_expert_parallel(ExpertParallel(rank, world, model.E))
+        model.set_expert_parallel(ExpertParallel(rank, world, model.E, padded={"off": False, "on": True, "auto": "auto"}[a.ep_padded]))
 
     radii = torch.full((n_rays, 1), 1e-3, device=dev)
     scene = None
@@ -198,7 +202,10 @@ def main():
         eval_counts = [c0_["counts"].clone(), c0_["cap"]]
     route_override = [None]       # [P] int32 expert of every point (the balanced-routing measurement) or None = the router's choice
     plain = not (a.eval or a.mip or a.bg or a.fine or a.dense)
-    use_graph = plain and a.parallelism == "dp" and a.graph in ("on", "auto")
+    # (expert parallel: only the padded mode is capturable, and only on request - RCCL collectives inside a captured graph have not
+    #  run on hardware yet)
+    use_graph = plain and ((a.parallelism == "dp" and a.graph in ("on", "auto")) or
+                           (a.parallelism == "ep" and a.ep_padded != "off" and a.graph == "on"))
     graphed = [None]
     if use_graph:
         from switch_nerf_amd.graph import GraphedTrainStep
@@ -543,8 +550,9 @@ def main():
         ep_.profile = False
         c_ = st["ctx"]
         kept_rows = int(c_["counts"].clamp(max=c_["cap"]).sum().item())
-        ep_info = dict(exchange="kept rows only, unequal-split all_to_all_single per routing segment on a side HIP stream; 4 exchanges per "
-                                "segment and step (dispatch / return, forward / backward)",
+        ep_info = dict(exchange=("capacity-padded equal-split" if c_.get("ep_padded") else "kept rows only, unequal-split") +
+                                " all_to_all_single per routing segment on a side HIP stream; 4 exchanges per segment and step (dispatch / "
+                                "return, forward / backward)", padded=bool(c_.get("ep_padded")),
                        segments=int(c_["n_seg"]), kept_rows_per_step=kept_rows,
                        bytes_leaving_this_gpu_per_step=int(ep_.bytes_sent // psteps),
                        bytes_per_segment_exchange=int(ep_.bytes_sent // psteps // max(1, 4 * int(c_["n_seg"]))),

@@ -43,13 +43,15 @@ class GraphedTrainStep:
 
     def __init__(self, model, rgbs, rays, image_indices, n_samples: int, seg_tokens: int, perturb: float = 1.0, noise_std: float = 1.0,
                  routing_override=None, warmup: int = 2, split_backward=None):
-        if model.ep is not None and model.ep.world > 1 and not getattr(model.ep, "capturable", False):
-            raise ValueError("GraphedTrainStep: the expert-parallel step with unequal (host-sized) splits issues RCCL collectives between "
-                             "its kernels and is not captured; use SwitchNeRF.train_step, or ExpertParallel(..., padded=True)")
+        N, S = rays.shape[0], int(n_samples)
+        if model.ep is not None:
+            seg_payload = model.E * int(model.cf * ((min(int(seg_tokens), N * S) + model.E - 1) // model.E)) * model.M * (4 if model.dtype == torch.float32 else 2)
+            if not (model.ep.capturable and model.ep.use_padded(seg_payload)):
+                raise ValueError("GraphedTrainStep: the expert-parallel step with unequal splits reads their sizes on the host and cannot be "
+                                 "captured; use SwitchNeRF.train_step, or ExpertParallel(..., padded=True) (equal, capacity-padded splits)")
         self.model = model
         dev = model.dev
         self.rgbs, self.rays, self.idx = rgbs.clone(), rays.clone(), image_indices.clone()
-        N, S = rays.shape[0], int(n_samples)
         P = N * S
         if split_backward is None:
             import torch.distributed as dist

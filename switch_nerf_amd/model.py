@@ -586,20 +586,34 @@ class SwitchNeRF:
             # the experts work on segment s.  One host read of the counts per forward pass (ExpertParallel.plan).
             ep = self.ep
             W, El = ep.world, ep.El
-            kept = c["counts"].clamp(max=cap)
-            idx_kept = torch.where(c["loc"] < cap, c["idx"], torch.full_like(c["idx"], -1))
-            _gb, perm_p, c["row_of_tok"] = o.route_pack(idx_kept, c["loc"], kept, seg_tokens, E)     # packed row space of this rank's rows
-            c["ep_perm"] = perm_p
+            ngs = W * El
             recv_counts = ep.exchange_counts(c["counts"], cap, self.side)()            # [n_seg, W * E_local], the expert kernels' group order
             c["ep_counts"] = recv_counts
-            pl = c["ep_plan"] = ep.plan(kept, recv_counts)
+            c["ep_padded"] = ep.use_padded(E * cap * M * c_esz(dt))
+            if c["ep_padded"]:
+                # the reference's layout (tutel_moe_layer_nobatch.py:157): every (expert, capacity slot) of a segment travels - empty slots
+                # as zero rows - with EQUAL splits.  The row spaces are the standard ones (perm / tok2row of swn_route_top1, group g at row
+                # g * cap), nothing is read on the host: the step can be captured into a hipGraph, collectives included.
+                perm_p, c["row_of_tok"] = c["perm"].view(-1), c["tok2row"]
+                seg_rows = E * cap
+                pl = dict(in_splits=[[El * cap] * W] * n_seg, out_splits=[[El * cap] * W] * n_seg,
+                          send_off=[s_ * seg_rows for s_ in range(n_seg + 1)], recv_off=[s_ * seg_rows for s_ in range(n_seg + 1)])
+                key = ("ep_begin_padded", n_seg * ngs, cap)
+                if key not in self._bufs:
+                    self._bufs[key] = (torch.arange(n_seg * ngs, device=dev, dtype=torch.int32) * cap).contiguous()
+                c["ep_begin"] = self._bufs[key]
+            else:
+                kept = c["counts"].clamp(max=cap)
+                idx_kept = torch.where(c["loc"] < cap, c["idx"], torch.full_like(c["idx"], -1))
+                _gb, perm_p, c["row_of_tok"] = o.route_pack(idx_kept, c["loc"], kept, seg_tokens, E)     # packed row space of this rank's rows
+                pl = ep.plan(kept, recv_counts)
+                flat_rc = recv_counts.reshape(-1)
+                c["ep_begin"] = (torch.cumsum(flat_rc, 0, dtype=torch.int32) - flat_rc).contiguous()      # first row of every received group
+            c["ep_perm"], c["ep_plan"] = perm_p, pl
             so, ro = pl["send_off"], pl["recv_off"]
-            flat_rc = recv_counts.reshape(-1)
-            c["ep_begin"] = (torch.cumsum(flat_rc, 0, dtype=torch.int32) - flat_rc).contiguous()      # first row of every received group
             xr = _b("ep_x", (rows, M), dt)                                  # received rows of all segments (also the first layer's
             send = xr if W == 1 else _b("ep_send_x", (rows, M), dt)         # weight-gradient operand)
             eo_r = c["eo"] if W == 1 else _b("ep_eo", (rows, M), dt)        # expert outputs in the received row space
-            ngs = W * El
             wseg = o.chain_mask_words(dt, E, cap, M)
             c["ep_mask_words"] = wseg
 

@@ -153,10 +153,29 @@ class ExpertParallel:
     world == 1 degenerates to the identity (no process group needed): the single-GPU parity test runs this path.
     """
 
-    def __init__(self, rank: int, world: int, n_experts: int, group=None):
+    def __init__(self, rank: int, world: int, n_experts: int, group=None, padded=False):
+        """padded: False = kept rows only, unequal splits sized on the host (one device-to-host read per forward pass: the step cannot
+        be captured into a hipGraph); True = the reference's own layout (tutel_moe_layer_nobatch.py:157: every (expert, capacity slot)
+        travels, empty slots as zero rows) with EQUAL splits - nothing is read on the host, so the whole step, collectives included,
+        can be replayed from a graph (graph.GraphedTrainStep); "auto" = padded when one segment's payload is at most PAD_AUTO_BYTES
+        (the small per-GPU batches of a strong-scaling run, where ~150 eager launches cost more than the padding)."""
         if n_experts % world:
             raise ValueError(f"expert parallelism needs world ({world}) to divide the expert count ({n_experts})")
         self.rank, self.world, self.E, self.El, self.group = rank, world, n_experts, n_experts // world, group
+        self.padded = padded
+
+    PAD_AUTO_BYTES = 64 << 20
+
+    def use_padded(self, segment_payload_bytes: int) -> bool:
+        """Whether a step whose per-segment exchange carries this many capacity-padded bytes runs in the padded (host-free) mode."""
+        if self.padded == "auto":
+            return segment_payload_bytes <= self.PAD_AUTO_BYTES
+        return bool(self.padded)
+
+    @property
+    def capturable(self) -> bool:
+        """True when no forward pass of this mode reads split sizes on the host (see `padded`; "auto": the caller asks use_padded)."""
+        return self.padded is True or self.padded == "auto"
 
     def exchange_counts(self, counts: torch.Tensor, cap: int, stream=None):
         """counts [n_seg, E] (tokens routed per expert, before capacity) -> (recv, wait): recv [n_seg, W * E_local] int32 = valid

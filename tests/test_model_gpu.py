@@ -261,6 +261,50 @@ def test_expert_parallel_path_single_rank_equals_local_experts(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_expert_parallel_padded_mode_is_host_free_and_graph_capturable(dtype):
+    """ExpertParallel(padded=True): the reference's capacity-padded equal-split exchange (tutel_moe_layer_nobatch.py:157) - standard row
+    spaces, nothing read on the host.  World = 1: (a) forward / loss bit-identical to the default path and gradients to summation order,
+    unbalanced routing with dropped tokens; (b) the whole step captured into hipGraphs (graph.GraphedTrainStep: a host read of split
+    sizes would abort the capture) replays bit-identically to the eager padded step over three optimizer steps."""
+    from switch_nerf_amd.graph import GraphedTrainStep
+    from switch_nerf_amd.parallel import ExpertParallel
+    N, S, chunk = 128, 64, 2048
+    rays, img, rgbs = synth.make_rays(128, N)
+    outs = []
+    for mode in ("default", "padded"):
+        m = _model(dtype, 127, 1.0)
+        if mode == "padded":
+            ep = ExpertParallel(0, 1, m.E, padded=True)
+            assert ep.capturable and ep.use_padded(1 << 40)
+            m.set_expert_parallel(ep)
+        st = m.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0, optimizer_step=False)
+        assert st["ctx"].get("ep_padded", None) in (None, True)
+        outs.append((st["rgb"].clone(), st["loss"].clone(), m.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for name, (off, shape) in m.spec.items():
+        n = int(np.prod(shape))
+        a, b = outs[0][2][off:off + n], outs[1][2][off:off + n]
+        assert (a - b).abs().max().item() <= 1e-5 * max(a.abs().max().item(), 1e-12), name
+    auto = ExpertParallel(0, 1, m.E, padded="auto")
+    assert auto.use_padded(1 << 20) and not auto.use_padded(1 << 30)
+    with pytest.raises(ValueError, match="cannot be captured"):
+        mp = _model(dtype, 127, 1.0)
+        mp.set_expert_parallel(ExpertParallel(0, 1, mp.E))          # unequal splits: host-sized
+        GraphedTrainStep(mp, _dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0, noise_std=0.0)
+    if dtype == torch.float32:
+        return
+    ma, mb = _model(dtype, 129, 1.0), _model(dtype, 129, 1.0)
+    for mm in (ma, mb):
+        mm.set_expert_parallel(ExpertParallel(0, 1, mm.E, padded=True))
+    step = GraphedTrainStep(ma, _dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0, noise_std=0.0)
+    for it in range(3):
+        ra = step(_dev(rgbs), _dev(rays), _dev(img))
+        rb = mb.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0)
+        assert torch.equal(ra["loss"], rb["loss"]), it
+    assert torch.equal(ma.flat, mb.flat) and ma.step_count == mb.step_count == 3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_expert_parallel_path_512_wide_equals_local_experts(dtype):
     """the expert-parallel path keeps the received rows PACKED (groups addressed through ep_begin); with 512-feature
     experts (mission_bay.yaml widths) the expert weight gradients must honour that packing too (ops.wgrad_multi cuts the 512-wide

@@ -13,11 +13,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(parallelism, port):
+def _run(parallelism, port, extra=()):
     env = dict(os.environ, SWN_DIST_BACKEND="gloo", SWN_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--rays", "1024",
-           "--parallelism", parallelism, "--no-events"]
+           "--parallelism", parallelism, "--no-events"] + list(extra)
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -44,6 +44,12 @@ def test_two_ranks_dp_and_ep_agree():
     full = 4 * x["kept_rows_per_step"] * 256 * 2          # every kept row, four exchanges, bf16 rows of 256 features
     assert 0.1 * full <= x["bytes_leaving_this_gpu_per_step"] <= 0.9 * full      # ~ (W - 1) / W of it, depending on where the experts sit
     assert x["collectives_per_step"] == 4 * x["segments"] and x["hidden_fraction"] is not None
+    # the padded (host-free, capturable) mode of the exchange: capacity-padded equal splits like the reference - same training, the
+    # capacity-padded payload on the wire
+    pad = _run("ep", 29563, ("--ep-padded", "on"))
+    assert abs(dp["config"]["loss"] - pad["config"]["loss"]) <= 5e-5 * abs(dp["config"]["loss"])
+    xp = pad["config"]["expert_parallel"]
+    assert xp["bytes_leaving_this_gpu_per_step"] == xp["capacity_padded_bytes_per_step"] and xp["collectives_per_step"] == 4 * xp["segments"]
 
 
 def test_bench_launches_its_own_ranks():
