@@ -644,6 +644,11 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
 #if SWN_TIMING_ON
     long long q0 = TICK();
 #endif
+    // (a wave beyond the width of the LAST layer has nothing to compute and nothing to prefetch for: it skips the K loop - for the
+    //  128-feature last layer of the tail forward chain that is half the waves, a quarter of the launch's weight stream through the
+    //  CU's L2 -> L1 path, which bounds these kernels)
+    if (!wave_active && !has_next) {}
+    else
     if (steps == 256 / KSTEP) k_loop<T, 256 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
     else if (steps == 128 / KSTEP) k_loop<T, 128 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
     else k_loop<T, 64 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
