@@ -2,7 +2,7 @@
 # Collects the round's rocprofv3 evidence on a GPU box into gpurun_out/ (summaries only; raw databases are deleted).
 #   bash scripts/collect_profiles.sh [round tag, default r03]
 set -x
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$R
 O=gpurun_out/$R
@@ -26,13 +26,21 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 # (c) SQ counters of the expert kernels (one pass, 8 SQ slots)
 SWN_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/p_sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --routing balanced --no-events --graph off > $O/p_sq.log 2>&1
-python scripts/pmc_summary.py gpurun_out/p_sq chainp > $O/${R}_pmc_sq_experts.txt
+python scripts/pmc_summary.py gpurun_out/p_sq chainq > $O/${R}_pmc_sq_experts.txt
 python scripts/pmc_summary.py gpurun_out/p_sq wgrad_stream >> $O/${R}_pmc_sq_experts.txt
 rm -rf gpurun_out/p_sq
 # ... and of the SAVE-FREE expert chain (the inference forward: the grouped GEMM alone - north_star's MFMA figure)
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/p_sq2 -- python bench.py --eval --graph off --steps 3 --warmup 1 --no-cpu-baseline --gate-scale 0.02 > $O/p_sq_eval.log 2>&1
-python scripts/pmc_summary.py gpurun_out/p_sq2 chainp > $O/${R}_pmc_sq_eval_chain.txt
+python scripts/pmc_summary.py gpurun_out/p_sq2 chainq > $O/${R}_pmc_sq_eval_chain.txt
 rm -rf gpurun_out/p_sq2
+# (c2) L2 -> L1 requests of the chains (the weight stream through the CU's vector memory path: what bounds the dense chains)
+SWN_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/p_l2 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --routing balanced --no-events --graph off > $O/p_l2.log 2>&1
+python scripts/pmc_summary.py gpurun_out/p_l2 chain > $O/${R}_pmc_l2_chains.txt
+rm -rf gpurun_out/p_l2
+# (c3) kernel table of the 1024-rays-per-GPU share (8-GPU strong scaling)
+SWN_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d gpurun_out/p_1024 -o step -- python bench.py --rays 1024 --steps 30 --warmup 5 --no-cpu-baseline --no-balanced --graph off --no-events > $O/p_1024.log 2>&1
+python scripts/prof_summary.py $(find gpurun_out/p_1024 -name "*.db" | head -1) 45 > $O/${R}_kernel_stats_1024rays.md
+rm -rf gpurun_out/p_1024
 # (d) the bench lines
 python bench.py > $O/${R}_bench_default.json 2> $O/${R}_bench_default.err
 python bench.py --steps 20 --warmup 5 > $O/${R}_bench_20_5.json 2>/dev/null

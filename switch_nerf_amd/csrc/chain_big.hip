@@ -1060,7 +1060,8 @@ struct ArgsQ {
 
 constexpr int Q_IDX1 = G256::BIAS0 + 3072 + 64;      // second source-row table (int32 [256]); the first one is G256::IDX0
 constexpr int Q_TINFO = Q_IDX1 + 1024;               // int32 [2][8]: vb (-1 = none), group, first tile row, valid rows, first row (lo, hi), weight set
-constexpr int Q_LDS = Q_TINFO + 64;
+constexpr int Q_YIDX = Q_TINFO + 64;                 // int32 [2][256]: rows of y_add for the output rows of a tile (y_add_gather), by tile parity
+constexpr int Q_LDS = Q_YIDX + 2048;
 
 // NARROW: the chain input has 128 features (256-byte rows) under a first layer whose weights are zero-padded to K = 256 (one K-loop
 // instantiation for every layer: a second, 8-step one beside it cost 160 spilled registers): the first 16 chunk positions of a tile row
@@ -1152,29 +1153,30 @@ __device__ __forceinline__ void write_pieces16_comb(const Ctx& cx, int c0, __amd
 }
 
 // write_pieces16 with the rows of y_add fetched through an index (the front backward chain adds the expert path's input gradient through
-// tok2row: -1 = nothing to add): pieces c0 + 4 j (j < 16) in two batches of 8 - the 8 row indices, then the 8 x 16 bytes, together
+// tok2row: -1 = nothing to add).  The indices of the tile's rows were put into an LDS table during its last epilogue phase (yidx_off), so
+// the 16 row pieces of a wave are requested together: ONE global round trip in the staging phase (index and row fetched back to back
+// in two batches of 8 were four: the front backward chain's S phase was twice as long as its other phases)
 template <typename E>
-__device__ __forceinline__ void write_pieces16_gather(const Ctx& cx, int c0, __amdgpu_buffer_rsrc_t rs, const char* y_add, const int32_t* gather,
-                                                      long grow0, int rows) {
+__device__ __forceinline__ void write_pieces16_gather(const Ctx& cx, int c0, __amdgpu_buffer_rsrc_t rs, const char* y_add, int yidx_off) {
   const int lane16 = cx.lane * 16;
+  const int* yidx = (const int*)(cx.smem + yidx_off);
+  int ar[16];
+  u32x4_t a[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) ar[j] = yidx[2 * (c0 + 4 * j) + cx.lhi];
+  SWN_WAIT_LGKM0();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) a[j] = *(const u32x4_t*)(y_add + (long)(ar[j] < 0 ? 0 : ar[j]) * ROWB + cx.l31 * 16);
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
-    int ar[8];
-    u32x4_t v[8], a[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int r = 2 * (c0 + 4 * (8 * b + j)) + cx.lhi;
-      ar[j] = gather[grow0 + (r < rows ? r : 0)];
-    }
+    u32x4_t v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = *(const u32x4_t*)(cx.smem + piece_addr(cx, c0 + 4 * (8 * b + j)));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = *(const u32x4_t*)(y_add + (long)(ar[j] < 0 ? 0 : ar[j]) * ROWB + cx.l31 * 16);
-#pragma unroll
     for (int j = 0; j < 8; ++j) {
-      if (ar[j] >= 0) {
+      if (ar[8 * b + j] >= 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[j][q] = E::pack2(E::lo(v[j][q]) + E::lo(a[j][q]), E::hi(v[j][q]) + E::hi(a[j][q]));
+        for (int q = 0; q < 4; ++q) v[j][q] = E::pack2(E::lo(v[j][q]) + E::lo(a[8 * b + j][q]), E::hi(v[j][q]) + E::hi(a[8 * b + j][q]));
       }
     }
 #pragma unroll
@@ -1391,7 +1393,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         if constexpr (TAG == 5) {      // (only this instantiation carries the fused combine backward)
           if (d.comb_y) write_pieces16_comb<E>(cs, 64 * rgs + fgs, ry, d, prev.grow0, prev.rows);
           else write_pieces16<E, false, 8>(cs, 64 * rgs + fgs, ry, ra);
-        } else if (d.y_add && d.y_add_gather) write_pieces16_gather<E>(cs, 64 * rgs + fgs, ry, (const char*)d.y_add, d.y_add_gather, prev.grow0, prev.rows);
+        } else if (d.y_add && d.y_add_gather) write_pieces16_gather<E>(cs, 64 * rgs + fgs, ry, (const char*)d.y_add, ((it - 1) & 1) ? Q_YIDX + 1024 : Q_YIDX);
         else if (d.y_add) write_pieces16<E, true, 8>(cs, 64 * rgs + fgs, ry, ra);
         else write_pieces16<E, false, 8>(cs, 64 * rgs + fgs, ry, ra);
         SWN_WAIT_LGKM0();                        // (every piece is in registers / on its way: the rows may be overwritten)
@@ -1473,8 +1475,12 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         const int lane16e = ce.lane * 16;
         uint32_t* mkp = ly.mask ? ly.mask + ((size_t)(cur.vb * G::NW + ce.w) * 64 + ce.lane) * 4 : nullptr;
         if (!last) mk_next = load_mask(L + 1, cur.vb);
-        int row_nxt = 0;
+        int row_nxt = 0, yrow = -1;
         if (last && nxt.vb >= 0) row_nxt = load_row(nxt);      // (consumed behind the epilogue)
+        if (last && d.y_add_gather && d.y_add) {               // the y_add row of this thread's output row of THIS tile (write_pieces16_gather)
+          const int lt = fg * 64 + cx.lane;
+          if (lt < 128) { const int r = 128 * rg + lt; yrow = d.y_add_gather[cur.grow0 + (r < cur.rows ? r : 0)]; }
+        }
         const bool bias_epi = ly.b != nullptr && !bias_init;
         if (ly.skip) {
           stage_pieces_q<false>(ce, (const char*)d.x, 64 * rge + fge, 16, 4, idx_cur);      // (a residual layer has n = k0 = 256)
@@ -1522,6 +1528,10 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         SWN_PIN();
         if (!last) preload_w(L + 1, cur.wset, ce.lane);      // (last layer: the S phase that follows loads the next tile's first fragments)
         else if (nxt.vb >= 0) store_row(row_nxt, idx_nxt);
+        if (last && d.y_add_gather && d.y_add) {
+          const int lt = fg * 64 + cx.lane;
+          if (lt < 128) ((int*)(smem + ((it & 1) ? Q_YIDX + 1024 : Q_YIDX)))[128 * rg + lt] = yrow;
+        }
         SWN_PIN();
         SWN_WAIT_LGKM0();
         SWN_TM(const long long e1 = TICK();)
@@ -1542,7 +1552,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     if constexpr (TAG == 5) {
       if (d.comb_y) write_pieces16_comb<E>(cx, 64 * rg + fg, ry, d, prev.grow0, prev.rows);
       else write_pieces16<E, false, 8>(cx, 64 * rg + fg, ry, ra);
-    } else if (d.y_add && d.y_add_gather) write_pieces16_gather<E>(cx, 64 * rg + fg, ry, (const char*)d.y_add, d.y_add_gather, prev.grow0, prev.rows);
+    } else if (d.y_add && d.y_add_gather) write_pieces16_gather<E>(cx, 64 * rg + fg, ry, (const char*)d.y_add, ((it - 1) & 1) ? Q_YIDX + 1024 : Q_YIDX);
     else if (d.y_add) write_pieces16<E, true, 8>(cx, 64 * rg + fg, ry, ra);
     else write_pieces16<E, false, 8>(cx, 64 * rg + fg, ry, ra);
   }
