@@ -73,14 +73,17 @@ template <typename T> struct Cfg;
 #ifndef SWN_BF16_BM
 #define SWN_BF16_BM 64
 #endif
+#ifndef SWN_WIDE_BM
+#define SWN_WIDE_BM 64      // rows per tile of the 512-feature build (128: one workgroup per CU, 256 accumulator registers per wave - experiment)
+#endif
 template <> struct Cfg<bf16_t> {
-  static constexpr int BM = SWN_WIDE ? 64 : SWN_BF16_BM, MI = BM / 32, KSTEP = 16;   // one ring step = K 16: one 16-byte fragment load per feature tile
+  static constexpr int BM = SWN_WIDE ? SWN_WIDE_BM : SWN_BF16_BM, MI = BM / 32, KSTEP = 16;   // one ring step = K 16: one 16-byte fragment load per feature tile
   static constexpr int ROWB = ROW_ELEMS * 2;           // LDS tile row stride in bytes
   static constexpr int ACT = BM * ROWB;                // LDS tile bytes
 #ifndef SWN_OCC
 #define SWN_OCC 4
 #endif
-  static constexpr int OCC = SWN_WIDE ? 2 : (BM == 128 ? 2 : (SWN_CONCAT ? 3 : SWN_OCC));   // workgroups per CU (= waves per SIMD) the register budget must allow
+  static constexpr int OCC = SWN_WIDE ? (SWN_WIDE_BM == 128 ? 1 : 2) : (BM == 128 ? 2 : (SWN_CONCAT ? 3 : SWN_OCC));   // workgroups per CU (= waves per SIMD) the register budget must allow
   typedef bf16x8_t wfrag_t;
 };
 template <> struct Cfg<float> {

@@ -31,9 +31,9 @@ __device__ __attribute__((aligned(16))) uint32_t g_zero_page[256];   // 1 KiB of
 // queue (s_waitcnt vmcnt(0)) in front of it; the waits here are counted by hand.  M0 is saved / restored (cdna_hip_programming.md 5.7).
 __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
   uint32_t keep;
-#if defined(SWN_WG_NT) && SWN_WG_NT
-#define SWN_WG_LOAD_POLICY " nt"      // experiment: non-temporal operand loads
-#else
+#if !defined(SWN_WG_NT) || SWN_WG_NT
+#define SWN_WG_LOAD_POLICY " nt"      // non-temporal operand loads (every operand row is read exactly once): 2.555 -> 2.49-2.50 ms for the expert
+#else                                 // launch, 2.04 -> 2.01 ms for the dense ones (round 4, scripts/wgrad_check.py); -DSWN_WG_NT=0: default policy
 #define SWN_WG_LOAD_POLICY ""
 #endif
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" SWN_WG_LOAD_POLICY "\n\ts_mov_b32 m0, %0"
