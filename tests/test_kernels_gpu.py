@@ -888,6 +888,58 @@ def test_chain_256_row_geometry_bit_exact(ng, cap, seed, geometry):
         assert off < 1e-4, f"{name}: {off:.3g} of the elements are off"
 
 
+@pytest.mark.parametrize("L,skip_at,ng,nws,packed", [(1, None, 3, 1, False), (2, None, 5, 5, True), (5, 2, 16, 8, False), (12, 3, 7, 1, True),
+                                                     (3, None, 1, 1, False)])
+def test_persistent_chain_shapes(L, skip_at, ng, nws, packed):
+    """chainq_kernel (geometry 6) on the shapes the model does not exercise: 1 / 2 / 5 / 12 layers, a residual layer anywhere, group
+    counts that are not a multiple of 8 (single tile queue), one weight set for many groups, PACKED row spaces (group_begin = exclusive
+    prefix sums: the no-batch / expert-parallel layout), every layer saved, with and without the output add - bit-identical to the
+    64-row kernels, rows past the end untouched, the queue counters left zeroed."""
+    o = ops()
+    dt = torch.bfloat16
+    M, cap = 256, 700
+    g = torch.Generator().manual_seed(100 * L + ng)
+    counts = torch.randint(0, cap + 1, (ng,), generator=g)
+    counts[0] = cap
+    if ng > 2:
+        counts[1], counts[2] = 0, 257
+    begin = None
+    if packed:
+        begin = (torch.cumsum(counts, 0) - counts).int()
+        rows = int(counts.sum())
+        starts = begin.tolist()
+    else:
+        rows = ng * cap
+        starts = [gi * cap for gi in range(ng)]
+    vm = torch.zeros(rows + 64, dtype=torch.bool)
+    for gi in range(ng):
+        vm[starts[gi]: starts[gi] + int(counts[gi])] = True
+    x = torch.randn(rows + 64, M, generator=g).to(dev()).to(dt)
+    W = [(torch.randn(nws, M, M, generator=g) / 16).to(dev()) for _ in range(L)]
+    B = [(torch.randn(nws, M, generator=g) * 0.1).to(dev()) for _ in range(L)]
+    wf = [o.pack_weights(w, dt, True) for w in W]
+    add = torch.randn(rows + 64, M, generator=g).to(dev()).to(dt)
+    kw = dict(n_groups=ng, n_wsets=nws, group_stride=cap, group_rows=counts.int().to(dev()), group_rows_clamp=cap,
+              group_begin=None if begin is None else begin.to(dev()))
+
+    def run(geom, with_add):
+        saves = [torch.zeros(rows + 64, M, dtype=dt, device=dev()) for _ in range(L - 1)]
+        masks = [torch.zeros(o.chain_mask_words(dt, ng, cap, M), dtype=torch.int32, device=dev()) for _ in range(L - 1)]
+        y = torch.zeros(rows + 64, M, dtype=dt, device=dev())
+        layers = [o.Layer(wf[l], B[l], relu=1 if l < L - 1 else 0, skip=(l == skip_at), save=saves[l] if l < L - 1 else None,
+                          mask=masks[l] if l < L - 1 else None) for l in range(L)]
+        o.mlp_chain(x, layers, y, tag=0, geometry=geom, y_add=add if with_add else None, **kw)
+        torch.cuda.synchronize()
+        return [y] + saves
+    for with_add in (False, True):
+        ref, got = run(1, with_add), run(6, with_add)
+        for i, (a, b) in enumerate(zip(ref, got)):
+            assert torch.equal(a[vm.to(dev())], b[vm.to(dev())]), f"tensor {i} (add {with_add}): {(a[vm.to(dev())] != b[vm.to(dev())]).float().mean().item():.3g} differ"
+            assert b[~vm.to(dev())].abs().sum().item() == 0, f"tensor {i}: rows outside the groups were written"
+    for t in o._chain_sched.values():
+        assert int(t.abs().sum().item()) == 0
+
+
 @pytest.mark.parametrize("P", [1000, 256 * 37 + 5, 70000])
 def test_front_chains_on_the_persistent_geometry(P):
     """The dense FRONT chains of the model on the persistent 256-row geometry (chain_big.hip, geometries 6 / 7): forward = 128-feature
