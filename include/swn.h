@@ -135,6 +135,12 @@ int swn_dispatch_nobatch_bwd_data(const float* gates, const int32_t* indices, co
 int swn_dispatch_nobatch_bwd_gate(float* grad_gates, const int32_t* indices, const int32_t* locations,
                                   const int32_t* expert_locations_begin, const void* reshaped_input, const void* dispatched,
                                   int dtype, int samples, int hidden, int capacity, int n_experts, void* stream);
+/* The tokens no expert kept (locations >= capacity), listed per (segment, expert) in location order: drop_begin [n_groups + 1] receives
+ * the exclusive prefix of max(counts - capacity, 0) over the groups (drop_begin[n_groups] = the number of dropped tokens), dropped
+ * [n_tokens] the tokens (entries past the count are not written).  Input of the fused tail of swn_mlp_chain (tail_dropped).  */
+int swn_route_dropped(const int32_t* idx, const int32_t* loc, const int32_t* counts, int n_tokens, int seg_tokens, int n_experts,
+                      int capacity, int32_t* drop_begin, int32_t* dropped, void* stream);
+
 /* packed (no-batch) row space from a routing: begin[n_seg * E] = exclusive prefix sum of counts (= expert_locations_begin,
  * per segment and expert), perm[n_tokens] row -> token, tok2row[n_tokens] token -> row (either may be NULL)                  */
 int swn_route_pack(const int32_t* idx, const int32_t* loc, const int32_t* counts, int n_tokens, int seg_tokens, int n_experts,
@@ -316,7 +322,7 @@ typedef struct swn_chain_desc {
                                    that recorded its masks.                                                                   */
   int32_t tag;                  /* profiling only: selects an identical kernel instantiation with its own symbol so that
                                    rocprofv3 reports the roles separately (0 generic, 1 expert fwd, 2 expert bwd,
-                                   3 front fwd, 4 tail fwd, 5 tail bwd, 6 front bwd)                 */
+                                   3 front fwd, 4 tail fwd, 5 tail bwd, 6 front bwd; 7 = the expert forward chain WITH the fused tail, tail_first below)                 */
   /* Combine backward fused into the write-out of the LAST layer (comb_y != NULL; the tail backward chain): with z = the layer's
      output row (the gradient of the decoded, gate-scaled, ReLU'd expert output y, tutel_fast_dispatch.py:50-63 + nerf_moe.py:385)
        t = (z + comb_dsig[row] * comb_wsig) * (comb_y[row] > 0);   y[row] = t * comb_gate[row];   comb_dgate[row] = <comb_y[row], t> / comb_gate[row]
@@ -346,6 +352,28 @@ typedef struct swn_chain_desc {
   int32_t x_features;           /* geometry 6 / 7: features per row of x when fewer than layers[0].k: 128 under a first layer whose packed
                                    weights are zero-padded from k = 128 to k = 256 (the rows of x are 128 features wide; the kernel zeroes
                                    the other half of its input tile).  0 = layers[0].k                                         */
+  /* The dense TAIL of the network folded into the expert FORWARD chain (tail_first > 0; geometry 7, tag 7, x_gather required): the
+     expert output never travels to memory and back between the MoE layer and the layers behind it (models/nerf_moe.py:385-441:
+     GatingDecoder -> act relu -> sigma head, Linear "1", Linear "2" over cat([h, PE(dir), embedding_a]), colour head).
+       * x_gather maps a row to its TOKEN (= its source row of x, swn_route_top1's perm); tokens are the row index of everything below;
+       * behind layer tail_first - 1 (the last expert layer) a row becomes z = relu(tail_gate[token] * z) - rounded to dtype before and
+         after the scaling, the arithmetic of x_scale / x_relu on the 64-row tail chain - and that is what layers[tail_first - 1].save
+         receives;
+       * layers[tail_first ..] are SHARED layers (weight set 0 for every group); the LAST layer may carry a rowbias (fp32
+         [tail_tokens / rows_per_bias][y_features], indexed by token / rows_per_bias) and be narrower than 256 features: y_features = 128
+         with its packed weights zero-padded to n = 256 (swn_pack_item.out_cols);
+       * layers[l].save for l >= tail_first - 1, y ([tail_tokens][y_features]), heads_raw and heads_noise are in TOKEN order;
+       * tail_dropped[0 .. *tail_n_dropped) (swn_route_dropped) lists the tokens no expert kept: they enter at layer tail_first as zero
+         rows (and are saved as zero rows of layers[tail_first - 1].save);
+       * heads_* as for tag 4 (optional), y / the saves may be NULL (an inference forward writes nothing but heads_raw);
+       * tail_tokens * 512 bytes must stay below 4 GiB (the scattered stores carry 32-bit offsets).                                 */
+  int32_t tail_first;
+  int32_t y_features;           /* real width of the last layer (tail mode): 128 or 256; 0 = layers[n_layers - 1].n              */
+  const float* tail_gate;       /* fp32 [tail_tokens]                                                                              */
+  const int32_t* tail_dropped;  /* device int32 [tail_dropped_max]                                                                  */
+  const int32_t* tail_n_dropped;/* device int32 scalar                                                                              */
+  int32_t tail_dropped_max;
+  int32_t tail_tokens;
   swn_chain_layer layers[SWN_MAX_CHAIN_LAYERS];
 } swn_chain_desc;
 

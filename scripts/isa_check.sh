@@ -8,4 +8,4 @@ B=$(basename $F .hip)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-variable -Wno-unused-but-set-variable -ffp-contract=fast-honor-pragmas "$@" --cuda-device-only -S /root/repo/switch_nerf_amd/csrc/$B.hip -o /tmp/isa/$B.s 2>&1 | grep -v "hip-link" | head -30
 grep -n "\.name:\|\.vgpr_count\|vgpr_spill_count\|sgpr_spill_count" /tmp/isa/$B.s | paste - - - - | sed 's/ \+/ /g' | grep "$PAT" | sed 's/^[0-9]*: //'
 N=$(grep "\.name:" /tmp/isa/$B.s | grep "$PAT" | head -1 | awk '{print $2}')
-[ -f /tmp/isa/phases.py ] && python3 /tmp/isa/phases.py /tmp/isa/$B.s $N
+python3 /root/repo/scripts/isa_phases.py /tmp/isa/$B.s $N

@@ -42,6 +42,8 @@ class ChainDesc(C.Structure):
                 ("y", vp), ("y_add", vp), ("y_add_gather", vp), ("geometry", i32), ("tag", i32),
                 ("comb_y", vp), ("comb_dsig", vp), ("comb_wsig", vp), ("comb_gate", vp), ("comb_dgate", vp),
                 ("heads_ws", vp), ("heads_bs", vp), ("heads_wc", vp), ("heads_bc", vp), ("heads_noise", vp), ("heads_raw", vp), ("sched", vp), ("x_features", i32),
+                ("tail_first", i32), ("y_features", i32), ("tail_gate", vp), ("tail_dropped", vp), ("tail_n_dropped", vp),
+                ("tail_dropped_max", i32), ("tail_tokens", i32),
                 ("layers", ChainLayer * 12)]
 
 
@@ -64,6 +66,7 @@ SIGNATURES = {
     "swn_dispatch_nobatch_bwd_data": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "swn_dispatch_nobatch_bwd_gate": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "swn_route_pack": [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp],
+    "swn_route_dropped": [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp],
     "swn_combine_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "swn_combine_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp],
     "swn_heads_fwd": [vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp],

@@ -1062,12 +1062,15 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   if (d.heads_raw) {
     const int nl = d.layers[d.n_layers - 1].n, k0 = d.layers[0].k;
     SWN_CHECK(d.heads_ws && d.heads_bs && d.heads_wc && d.heads_bc, "swn_mlp_chain: fused heads need heads_ws / heads_bs / heads_wc / heads_bc");
-    SWN_CHECK(d.geometry < 2 && d.tag == 4, "swn_mlp_chain: the fused heads run on the 64-row kernels (geometry 0 / 1), tag 4");
+    SWN_CHECK((d.geometry < 2 && d.tag == 4) || (d.tail_first > 0 && d.geometry == 7 && d.tag == 7),
+              "swn_mlp_chain: the fused heads run on the 64-row kernels (geometry 0 / 1, tag 4) or inside a fused tail (geometry 7, tag 7)");
     SWN_CHECK((nl == 128 || nl == 256) && (k0 == 256 || k0 == 512) && k0 * (d.dtype == SWN_F32 ? 4 : 2) <= 1024,
               "swn_mlp_chain: fused heads: chain input of 256 / 512 features in rows of at most 1 KiB, last layer of 128 / 256 (k0=%d, n=%d)", k0, nl);
     for (int l = 0; l < d.n_layers; ++l) SWN_CHECK(d.layers[l].skip != 2, "swn_mlp_chain: fused heads: no concat-skip layers");
   }
-  SWN_CHECK(d.tag >= 0 && d.tag <= 6, "swn_mlp_chain: tag %d not in [0,6]", d.tag);
+  SWN_CHECK(d.tag >= 0 && d.tag <= 7, "swn_mlp_chain: tag %d not in [0,7]", d.tag);
+  SWN_CHECK(d.tail_first == 0 || (d.geometry == 7 && d.tag == 7), "swn_mlp_chain: a fused tail (tail_first > 0) runs on geometry 7 with tag 7");
+  SWN_CHECK(d.tag != 7 || d.tail_first > 0, "swn_mlp_chain: tag 7 is the fused-tail forward chain (tail_first > 0)");
   SWN_CHECK(d.x_features == 0 || d.x_features == d.layers[0].k || (d.x_features == 128 && d.layers[0].k == 256 && d.geometry >= 6),
             "swn_mlp_chain: x_features = %d: only 128-feature rows under a zero-padded k = 256 first layer on geometry 6 / 7", d.x_features);
   SWN_CHECK(!(wide && concat), "swn_mlp_chain: concat-skip layers are built for the 256-feature kernels only");

@@ -1056,6 +1056,7 @@ struct ArgsQ {
   int stagger;         // start offset between the workgroups of an XCD in units of ~1 k clocks (0: all start together)
   int per_queue;       // 8 queues over ONE group (dense chains): queue x walks the tiles [x * per_queue, (x + 1) * per_queue) - the
                        // workgroups of an XCD write consecutive rows (as the 64-row kernels' dense mapping does)
+  int n_vb_e;          // fused tail (tag 7): virtual blocks [n_vb_e, n_vb) are the tiles of the dropped tokens (= n_vb otherwise)
 };
 
 constexpr int Q_IDX1 = G256::BIAS0 + 3072 + 64;      // second source-row table (int32 [256]); the first one is G256::IDX0
@@ -1187,11 +1188,194 @@ __device__ __forceinline__ void write_pieces16_gather(const Ctx& cx, int c0, __a
   }
 }
 
+// ---- the dense tail folded into the expert forward chain (TAG 7; include/swn.h, tail_first) ------------------------------------------
+// LDS tables of that instantiation, in the 24 KiB that chainb_kernel's weight ring occupies (chainq_kernel streams its weights
+// straight into registers):
+constexpr int T_GATE = G256::RING0;        // f32 [256]: gate value of every tile row
+constexpr int T_WS = T_GATE + 1024;        // f32 [256]: sigma head weights
+constexpr int T_SIGP = T_WS + 1024;        // f32 [8][256]: partial sums of the sigma head, [wave quarter * 2 + half-wave][tile row]
+constexpr int T_COL = T_SIGP + 8192;       // f32 [3][256]: the colour head's dot products of every tile row
+static_assert(T_COL + 3072 <= G256::IDX0, "tail tables must fit the ring region");
+
+// Epilogue of the LAST EXPERT layer of a fused chain: the row becomes relu(gate[row] * z) - z rounded to the 16-bit type first, the
+// product rounded again: GatingDecoder's fp32 multiply on the 16-bit expert output, cast back, act relu (tutel_fast_dispatch.py:119-127,
+// nerf_moe.py:385; value for value the x_scale / x_relu staging of the 64-row tail chain) - and, with the heads, leaves the lane's share
+// of the sigma head's dot product <row, w_sigma> in T_SIGP (a lane holds 32 features of each of its 4 rows).
+template <typename E, typename HOOK>
+__device__ __forceinline__ void epilogue_q_gate(f32x16_t (&acc)[4][2], const Ctx& cx, bool heads, HOOK hook) {
+  char* smem = cx.smem;
+  uint32_t e2_base = cx.e2_base;
+  asm volatile("" : "+v"(e2_base));
+  const int fg = cx.w & 3;
+  const int row0 = 128 * (cx.w >> 2) + cx.l31;
+  float gt[4], sg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) gt[mi] = *(const float*)(smem + T_GATE + (row0 + 32 * mi) * 4);
+  int h = 0;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    f32x4_t ws[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) ws[g4] = *(const f32x4_t*)(smem + T_WS + ((fg * 64 + 32 * ni + 8 * g4 + 4 * cx.lhi) << 2));
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      uint32_t pp[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pp[k] = E::pack2(acc[mi][ni][(k >> 1) * 4 + 2 * (k & 1)], acc[mi][ni][(k >> 1) * 4 + 2 * (k & 1) + 1]);
+      SWN_PIN();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pp[k] = pk_relu16(E::pack2(E::lo(pp[k]) * gt[mi], E::hi(pp[k]) * gt[mi]));
+      SWN_PIN();
+      if (heads) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          sg[mi] = __builtin_fmaf(E::lo(pp[k]), ws[k >> 1][2 * (k & 1)], sg[mi]);
+          sg[mi] = __builtin_fmaf(E::hi(pp[k]), ws[k >> 1][2 * (k & 1) + 1], sg[mi]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        auto r0 = __builtin_amdgcn_permlane32_swap(pp[g * 2], pp[(g + 1) * 2], false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(pp[g * 2 + 1], pp[(g + 1) * 2 + 1], false, false);
+        const u32x4_t o = {(uint32_t)r0[0], (uint32_t)r1[0], (uint32_t)r0[1], (uint32_t)r1[1]};
+        *(u32x4_t*)(smem + (e2_base ^ (uint32_t)((4 * ni + g) << 4)) + mi * (32 * ROWB)) = o;
+      }
+      SWN_PIN();
+      if constexpr (hook_halves<HOOK>::value) hook(h);
+      else if (h & 1) hook(h >> 1);
+      ++h;
+    }
+  }
+  if (heads) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) *(float*)(smem + T_SIGP + (((fg * 2 + cx.lhi) * 256 + row0 + 32 * mi) << 2)) = sg[mi];
+  }
+}
+
+// Epilogue of the LAST layer of a fused chain (Linear "2" over cat([h, PE(dir), embedding_a]), nerf_moe.py:419-429): the per-ray half
+// of the layer arrives as a row bias (fp32 [rays][nf], the row of token / rpb), then ReLU.  nf = 128: the wave quarters beyond the
+// layer's width (zero-padded weights) only run the hooks.
+template <typename E, typename HOOK>
+__device__ __forceinline__ void epilogue_q_rowbias(f32x16_t (&acc)[4][2], const Ctx& cx, const float* rowbias, int rpb, int nf, int idx_off,
+                                                   HOOK hook) {
+  char* smem = cx.smem;
+  const int fg = cx.w & 3;
+  if (fg * 64 >= nf) {
+    if constexpr (hook_halves<HOOK>::value) {
+#pragma unroll
+      for (int h = 0; h < 8; ++h) hook(h);
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) hook(mi);
+    }
+    return;
+  }
+  uint32_t e2_base = cx.e2_base;
+  asm volatile("" : "+v"(e2_base));
+  const int row0 = 128 * (cx.w >> 2) + cx.l31;
+  const float* rb[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const uint32_t tok = (uint32_t)((const int*)(smem + idx_off))[row0 + 32 * mi];
+    rb[mi] = rowbias ? rowbias + (size_t)(tok / (uint32_t)rpb) * nf + fg * 64 + 4 * cx.lhi : nullptr;
+  }
+  f32x4_t bq[2][4];
+  auto fetch = [&](int t) {                 // the bias chunks of half step t = 4 ni + mi, one half step ahead of their use
+    const int ni = t >> 2, mi = t & 3;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      bq[t & 1][g4] = rb[mi] ? *(const f32x4_t*)(rb[mi] + 32 * ni + 8 * g4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+  };
+  fetch(0);
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int t = 4 * ni + mi;
+      if (t + 1 < 8) fetch(t + 1);
+      uint32_t pp[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int g4 = k >> 1, i = k & 1;
+        pp[k] = pk_relu16(E::pack2(acc[mi][ni][g4 * 4 + 2 * i] + bq[t & 1][g4][2 * i], acc[mi][ni][g4 * 4 + 2 * i + 1] + bq[t & 1][g4][2 * i + 1]));
+      }
+      SWN_PIN();
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        auto r0 = __builtin_amdgcn_permlane32_swap(pp[g * 2], pp[(g + 1) * 2], false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(pp[g * 2 + 1], pp[(g + 1) * 2 + 1], false, false);
+        const u32x4_t o = {(uint32_t)r0[0], (uint32_t)r1[0], (uint32_t)r0[1], (uint32_t)r1[1]};
+        *(u32x4_t*)(smem + (e2_base ^ (uint32_t)((4 * ni + g) << 4)) + mi * (32 * ROWB)) = o;
+      }
+      SWN_PIN();
+      if constexpr (hook_halves<HOOK>::value) hook(t);
+      else if (t & 1) hook(t >> 1);
+    }
+  }
+}
+
+// The rows of a finished tile whose last layer is 128 features wide -> y[token] (256-byte rows), with the colour head on the way.  A wave
+// handles the rows it STAGES (pieces fg + 4 j of its row group: rows 8 j + 2 fg, + 1 - nobody else's copy may land on a row that is
+// still to be read), four at a time (lane -> row 8 (2 i + lane / 32) + 2 fg + (lane / 16 & 1), 16-byte chunk lane % 16: every lane
+// carries data, 8 stores per wave instead of the 16 half-empty ones of the 512-byte pieces); a lane multiplies its 8 features by the
+// three colour rows, a butterfly over the row's 16 lanes (quad swaps, half mirror, mirror) gives <h2, w_c> -> T_COL[c][row].
+template <typename E>
+__device__ __forceinline__ void write_rows128_tok(const Ctx& cx, void* y, uint32_t oob, const float* wc, int idx_off, int rows, bool heads) {
+  char* smem = cx.smem;
+  const int* idx = (const int*)(smem + idx_off);
+  const int l15 = cx.lane & 15, rq = cx.lane >> 4;
+  const int rbase = 128 * (cx.w >> 2) + 2 * (cx.w & 3) + 8 * (rq >> 1) + (rq & 1);      // row of step i: rbase + 16 i
+  const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(y ? y : (void*)wc, y ? (int)oob : 0);
+  f32x4_t w[3][2];
+  if (heads) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) w[c][q] = *(const f32x4_t*)(wc + c * 128 + l15 * 8 + 4 * q);
+  }
+  u32x4_t v[8];
+  int tk[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = rbase + 16 * i;
+    v[i] = *(const u32x4_t*)(smem + r * ROWB + ((l15 ^ (r & 15)) << 4));
+    tk[i] = idx[r];
+  }
+  SWN_WAIT_LGKM0();
+  if (y) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_raw_buffer_store_b128(v[i], rs, rbase + 16 * i < rows ? (uint32_t)tk[i] * 256u + (uint32_t)(l15 * 16) : oob, 0, SWN_BIG_Y_AUX);
+  }
+  if (heads) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float f[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { f[2 * q] = E::lo(v[i][q]); f[2 * q + 1] = E::hi(v[i][q]); }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a = __builtin_fmaf(f[e], w[c][e >> 2][e & 3], a);
+        a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+        a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+        a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x141, 0xF, 0xF, true));     // row_half_mirror
+        a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x140, 0xF, 0xF, true));     // row_mirror
+        if (l15 == c) ((float*)(smem + T_COL))[c * 256 + rbase + 16 * i] = a;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) asm volatile("s_nop 1" :: "v"(v[i]));      // (store operands stay allocated behind their stores: see the write-out hook)
+}
+
 template <typename E, int TAG, bool BIAS_INIT>
 __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef G256 G;
   constexpr int BM = G::BM, MI = 4;
+  constexpr bool TAIL = TAG == 7;               // the dense tail folded into the expert forward chain (include/swn.h, tail_first)
   const swn_chain_desc& d = args.d;
   Ctx cx;
   cx.smem = smem;
@@ -1254,6 +1438,15 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         ++kq;
       }
       if (vb >= args.n_vb) { vb = -1; break; }
+      if constexpr (TAIL) {
+        if (vb >= args.n_vb_e) {                 // a tile of dropped tokens (they enter at the first shared layer as zero rows)
+          rows_valid = min(*d.tail_n_dropped, d.tail_dropped_max);
+          tile = vb - args.n_vb_e;
+          g = -1;
+          if (tile * BM >= rows_valid) vb = -1;  // (a queue hands its tiles out in order: everything behind this one is empty too)
+          break;
+        }
+      }
       if ((n_wsets & 7) == 0 && (n_groups & 7) == 0) {           // chainp_kernel's mapping: XCD x meets every weight set in turn
         const int x = vb & 7, qq = vb >> 3;
         const int s_ = qq / tpg;
@@ -1272,16 +1465,18 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
       int* t = (int*)(smem + Q_TINFO) + slot * 8;
       t[0] = vb;
       if (vb >= 0) {
-        const long grow0 = (d.group_begin ? (long)d.group_begin[g] : (long)g * d.group_stride) + (long)tile * BM;
+        long grow0 = (long)tile * BM;
+        if (g >= 0) grow0 += d.group_begin ? (long)d.group_begin[g] : (long)g * d.group_stride;
         t[1] = g;
         t[2] = min(BM, rows_valid - tile * BM);
         t[3] = (int)(uint32_t)(grow0 & 0xFFFFFFFFl);
         t[4] = (int)(grow0 >> 32);
-        t[5] = g % n_wsets;
+        t[5] = g >= 0 ? g % n_wsets : 0;
+        if constexpr (TAIL) t[6] = g >= 0 ? 0 : d.tail_first;      // first layer of the tile
       }
     }
   };
-  struct Tile { int vb, rows; long grow0; int wset; };
+  struct Tile { int vb, rows; long grow0; int wset, l0; };
   auto read_tile = [&](int slot) -> Tile {
     Tile t;
     t.vb = __builtin_amdgcn_readfirstlane(tinfo[slot * 8 + 0]);
@@ -1290,6 +1485,8 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     const int hi = __builtin_amdgcn_readfirstlane(tinfo[slot * 8 + 4]);
     t.grow0 = ((long)hi << 32) | (long)lo;
     t.wset = __builtin_amdgcn_readfirstlane(tinfo[slot * 8 + 5]);
+    t.l0 = 0;
+    if constexpr (TAIL) t.l0 = __builtin_amdgcn_readfirstlane(tinfo[slot * 8 + 6]);
     return t;
   };
   auto finish = [&]() {                          // the last workgroup to leave zeroes the counters for the next launch
@@ -1310,7 +1507,8 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     if (lt < 128) {
       const int r = 128 * rg + lt;
       const long gr = t.grow0 + (r < t.rows ? r : 0);          // rows past the end repeat the first row (computed, never stored)
-      src = d.x_gather ? d.x_gather[gr] : (int)gr;
+      if (TAIL && t.l0) src = d.tail_dropped[gr];
+      else src = d.x_gather ? d.x_gather[gr] : (int)gr;
     }
     return src;
   };
@@ -1324,6 +1522,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     const char* p = (const char*)d.layers[L].w + (size_t)wset * bytes;
     return uniform_rsrc(p, bytes);
   };
+  auto ws_of = [&](int L, const Tile& t) -> int { return (TAIL && L >= d.tail_first) ? 0 : t.wset; };      // (shared layers: one weight set)
   auto out_rs = [&](void* base, const Tile& t) -> __amdgpu_buffer_rsrc_t {
     return uniform_rsrc((char*)base + t.grow0 * ROWB, t.rows * ROWB);
   };
@@ -1355,6 +1554,64 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
   // same moment and the phase is as long as the whole chip's burst takes through HBM (measured: 7-9 k clocks).  A start offset
   // per workgroup spreads the S phases of the CUs over the tile period.
   for (int i = ((int)(blockIdx.x >> 3) & 15) * args.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(16);
+  // ---- fused tail: what a row group does with the rows of a finished tile, and how a tile of dropped tokens is staged ----
+  const int yf = TAIL ? (d.y_features ? d.y_features : 256) : 256;           // real width of the last layer
+  const uint32_t oob_y = (uint32_t)d.tail_tokens * (uint32_t)(yf * 2), oob_s = (uint32_t)d.tail_tokens * (uint32_t)ROWB;
+  auto tail_out = [&](const Ctx& c_, const Tile& t, int idx_off) {
+    // the last layer's rows -> y[token] (128 features), and the heads: raw[token] = (sigmoid(colour sums + b), softplus(sigma sum + b - 1));
+    // a wave finishes the 32 rows it wrote out itself (lanes 0 .. 31: one row each, rows 8 j + 2 fg + {0, 1}) - no one else's LDS
+    // writes are involved
+    const bool hd = d.heads_raw != nullptr;
+    write_rows128_tok<E>(c_, d.y, oob_y, d.heads_wc, idx_off, t.rows, hd);
+    if (hd) {
+      SWN_WAIT_LGKM0();
+      const int r = 128 * (c_.w >> 2) + 8 * (c_.l31 >> 1) + 2 * (c_.w & 3) + (c_.l31 & 1);
+      if (c_.lhi == 0 && r < t.rows) {
+        const long tok = ((const int*)(smem + idx_off))[r];
+        const float* sp = (const float*)(smem + T_SIGP) + r;
+        const float* cp = (const float*)(smem + T_COL) + r;
+        const float sg = ((sp[0] + sp[256]) + (sp[512] + sp[768])) + ((sp[1024] + sp[1280]) + (sp[1536] + sp[1792]));
+        const float u = sg + d.heads_bs[0] + (d.heads_noise ? d.heads_noise[tok] : 0.f) - 1.f;      // ShiftedSoftplus, models/nerf.py:68-69
+        f32x4_t o;
+        o[0] = 1.f / (1.f + expf(-(cp[0] + d.heads_bc[0])));
+        o[1] = 1.f / (1.f + expf(-(cp[256] + d.heads_bc[1])));
+        o[2] = 1.f / (1.f + expf(-(cp[512] + d.heads_bc[2])));
+        o[3] = u > 20.f ? u : log1pf(expf(u));
+        *(f32x4_t*)(d.heads_raw + tok * 4) = o;
+      }
+    }
+  };
+  auto stage_dropped = [&](const Ctx& c_, const Tile& t, int idx_off) {
+    // dropped tokens: zero rows into the tile (they meet the shared layers' biases only), zero sigma sums, zero rows of the saved y
+    const int rg_ = c_.w >> 2, fg_ = c_.w & 3;
+    const u32x4_t z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) *(u32x4_t*)(smem + (64 * rg_ + fg_ + 4 * j) * 1024 + c_.lane * 16) = z;
+    if (c_.lhi == 0) {      // (the wave's own rows: the ones its tail_out has just read)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ((float*)(smem + T_SIGP))[q * 256 + 128 * rg_ + 8 * (c_.l31 >> 1) + 2 * fg_ + (c_.l31 & 1)] = 0.f;
+    }
+    void* ys = d.layers[d.tail_first - 1].save;
+    if (ys) {
+      const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(ys, (int)oob_s);
+      const int* idx = (const int*)(smem + idx_off);
+      uint32_t off[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) off[j] = (uint32_t)idx[2 * (64 * rg_ + fg_ + 4 * j) + c_.lhi];
+      SWN_WAIT_LGKM0();
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int r = 2 * (64 * rg_ + fg_ + 4 * j) + c_.lhi;
+        __builtin_amdgcn_raw_buffer_store_b128(z, rs, r < t.rows ? off[j] * (uint32_t)ROWB + (uint32_t)(c_.l31 * 16) : oob_s, 0, SWN_BIG_STORE_AUX);
+      }
+      asm volatile("s_nop 7" :: "v"(z));
+    }
+  };
+  if constexpr (TAIL) {
+    if (d.heads_raw) {      // the heads' weights (fp32) for the epilogues of the gate layer and of the last layer
+      if (tid < 256) ((float*)(smem + T_WS))[tid] = d.heads_ws[tid];
+    }
+  }
   // ---- prologue: the first tile, its source rows ----
   if (cx.w == 0 && cx.lane < 2) gcount[cx.lane] = 0;
   if (cx.w == 0) grab(0, claim());
@@ -1388,18 +1645,31 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
       int ticket = 0;
       if (cs.w == 0) ticket = claim();           // (the claim of the tile after this one travels under the write-out and the staging)
       if (it > 0) {
-        const __amdgpu_buffer_rsrc_t ry = out_rs(d.y, prev);
-        const __amdgpu_buffer_rsrc_t ra = d.y_add ? out_rs((void*)d.y_add, prev) : ry;
-        if constexpr (TAG == 5) {      // (only this instantiation carries the fused combine backward)
-          if (d.comb_y) write_pieces16_comb<E>(cs, 64 * rgs + fgs, ry, d, prev.grow0, prev.rows);
+        if constexpr (TAIL) {
+          tail_out(cs, prev, idx_nxt);           // (the other table still holds the previous tile's tokens)
+        } else {
+          const __amdgpu_buffer_rsrc_t ry = out_rs(d.y, prev);
+          const __amdgpu_buffer_rsrc_t ra = d.y_add ? out_rs((void*)d.y_add, prev) : ry;
+          if constexpr (TAG == 5) {      // (only this instantiation carries the fused combine backward)
+            if (d.comb_y) write_pieces16_comb<E>(cs, 64 * rgs + fgs, ry, d, prev.grow0, prev.rows);
+            else write_pieces16<E, false, 8>(cs, 64 * rgs + fgs, ry, ra);
+          } else if (d.y_add && d.y_add_gather) write_pieces16_gather<E>(cs, 64 * rgs + fgs, ry, (const char*)d.y_add, ((it - 1) & 1) ? Q_YIDX + 1024 : Q_YIDX);
+          else if (d.y_add) write_pieces16<E, true, 8>(cs, 64 * rgs + fgs, ry, ra);
           else write_pieces16<E, false, 8>(cs, 64 * rgs + fgs, ry, ra);
-        } else if (d.y_add && d.y_add_gather) write_pieces16_gather<E>(cs, 64 * rgs + fgs, ry, (const char*)d.y_add, ((it - 1) & 1) ? Q_YIDX + 1024 : Q_YIDX);
-        else if (d.y_add) write_pieces16<E, true, 8>(cs, 64 * rgs + fgs, ry, ra);
-        else write_pieces16<E, false, 8>(cs, 64 * rgs + fgs, ry, ra);
+        }
         SWN_WAIT_LGKM0();                        // (every piece is in registers / on its way: the rows may be overwritten)
       }
       SWN_TM(const long long sw = TICK(); tSw += sw - s0;)
-      if (narrow) stage_pieces_q<true>(cs, (const char*)d.x, 64 * rgs + fgs, 16, 4, idx_cur);
+      float gate_v = 0.f;
+      const int lts = fgs * 64 + cs.lane;
+      if constexpr (TAIL) {
+        if (cur.l0) {
+          stage_dropped(cs, cur, idx_cur);
+        } else {
+          if (lts < 128) gate_v = d.tail_gate[((const int*)(smem + idx_cur))[128 * rgs + lts]];      // the rows' gate values -> T_GATE below
+          stage_pieces_q<false>(cs, (const char*)d.x, 64 * rgs + fgs, 16, 4, idx_cur);
+        }
+      } else if (narrow) stage_pieces_q<true>(cs, (const char*)d.x, 64 * rgs + fgs, 16, 4, idx_cur);
       else stage_pieces_q<false>(cs, (const char*)d.x, 64 * rgs + fgs, 16, 4, idx_cur);
       if (cs.w == 0) grab((it + 1) & 1, ticket);   // the tile after this one (both row groups read it during their last epilogue phase)
       SWN_TM(const long long si = TICK(); tSi += si - s0;)
@@ -1407,18 +1677,21 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
       // operations of this phase take 6-9 k clocks to ISSUE whatever their order (copies first and a counted wait: no gain) - the CU's
       // vector memory path carries the partner group's weight stream at the same time and is the bound of this kernel family.
       SWN_WAIT_VM(0);
+      if constexpr (TAIL) {
+        if (!cur.l0 && lts < 128) ((float*)(smem + T_GATE))[128 * rgs + lts] = gate_v;
+      }
     }
-    if (rg == 0 && it == 0) { stage_bias(0, cur.wset, 0); SWN_WAIT_VM(0); }
-    u32x4_t mk_next = load_mask(0, cur.vb);
+    if (rg == 0 && it == 0) { stage_bias(cur.l0, ws_of(cur.l0, cur), 0); SWN_WAIT_VM(0); }
+    u32x4_t mk_next = load_mask(cur.l0, cur.vb);
     SWN_PIN();
-    preload_w(0, cur.wset, cx.lane);
+    preload_w(cur.l0, ws_of(cur.l0, cur), cx.lane);
     SWN_PIN();
     SWN_WAIT_LGKM0();
     SWN_TM(const long long s1 = TICK();)
     __builtin_amdgcn_s_barrier();
     SWN_TM(const long long s2 = TICK(); tS += s1 - s0; tSb += s2 - s1;)
     Tile nxt = cur;
-    for (int L = 0; L < n_layers; ++L) {
+    for (int L = cur.l0; L < n_layers; ++L) {
       const swn_chain_layer& ly = d.layers[L];
       const bool last = L + 1 == n_layers;
       u32x4_t mk = mk_next;
@@ -1426,11 +1699,11 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
       // ---- K phase ----
       {
         SWN_TM(const long long k0 = TICK();)
-        const __amdgpu_buffer_rsrc_t rs_cur = wrs(L, cur.wset);
+        const __amdgpu_buffer_rsrc_t rs_cur = wrs(L, ws_of(L, cur));
         // (row group 0, for both groups) the NEXT layer's bias -> its slot; the K loop's counted waits cover the copy
         if (rg == 0) {
-          if (!last) stage_bias(L + 1, cur.wset, (bc + 1) % 3);
-          else if (nxt.vb >= 0) stage_bias(0, nxt.wset, (bc + 1) % 3);
+          if (!last) stage_bias(L + 1, ws_of(L + 1, cur), (bc + 1) % 3);
+          else if (nxt.vb >= 0) stage_bias(nxt.l0, ws_of(nxt.l0, nxt), (bc + 1) % 3);
         }
         if constexpr (bias_init) {
           // accumulators start at the bias (zeros for a layer without one: stage_bias).  Written as plain copies of two 16-register
@@ -1492,9 +1765,29 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         // the partner's rows = the input tile of the K loop it is running (same tile: the groups are one phase apart)
-        void* wo = rge == 0 ? (L >= 1 ? d.layers[L - 1].save : nullptr) : (!last ? ly.save : nullptr);
+        void* wo = rge == 0 ? (L > cur.l0 ? d.layers[L - 1].save : nullptr) : (!last ? ly.save : nullptr);
+        // fused tail: the saves from the gate layer on go to TOKEN order; the gate layer and the last layer have their own epilogues
+        const bool wo_tok = TAIL && (rge == 0 ? L - 1 : L) >= d.tail_first - 1;
+        const bool gate_l = TAIL && L + 1 == d.tail_first, rb_l = TAIL && last;
+        auto run_epi = [&](auto hook) {
+          typedef decltype(hook) HK;
+          if constexpr (TAIL) {
+#ifdef SWN_T7_NOHEADS
+            const bool hd = false;
+#else
+            const bool hd = d.heads_raw != nullptr;
+#endif
+#ifndef SWN_T7_NOGATE
+            if (gate_l) { epilogue_q_gate<E, HK>(acc, ce, hd, hook); return; }
+#endif
+#ifndef SWN_T7_NORB
+            if (rb_l) { epilogue_q_rowbias<E, HK>(acc, ce, ly.rowbias, ly.rows_per_bias, yf, idx_cur, hook); return; }
+#endif
+          }
+          epilogue_p_dispatch<E, HK>(acc, ce, mk, ly.relu, bias_epi, ly.skip != 0, (bc % 3) * 1024, hook);
+        };
         if (wo) {
-          const __amdgpu_buffer_rsrc_t rs = out_rs(wo, cur);
+          const __amdgpu_buffer_rsrc_t rs = wo_tok ? uniform_rsrc(wo, (int)oob_s) : out_rs(wo, cur);
           const int c0 = 64 * (1 - rge) + fge;
           // 16 pieces in 8 half steps of 2 (one behind every half row tile of the epilogue) through TWO alternating register sets: the
           // LDS reads that refill a set are issued a half step after ITS stores - hundreds of clocks - never right behind them.  (On
@@ -1502,9 +1795,13 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
           // NEW value under store back-pressure; chainp_kernel holds that off with 16 idle issue slots behind every store batch,
           // here the distance is structural.)
           u32x4_t wv[2][2];
+          int tk[2][2];                            // (fused tail: the tokens of the pieces' rows)
           auto rd = [&](int h) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) wv[h & 1][j] = *(const u32x4_t*)(smem + piece_addr(ce, c0 + 4 * (2 * h + j)));
+            for (int j = 0; j < 2; ++j) {
+              wv[h & 1][j] = *(const u32x4_t*)(smem + piece_addr(ce, c0 + 4 * (2 * h + j)));
+              if constexpr (TAIL) tk[h & 1][j] = ((const int*)(smem + idx_cur))[2 * (c0 + 4 * (2 * h + j)) + ce.lhi];
+            }
           };
           rd(0);
           auto hook_f = [&](int h) {
@@ -1513,20 +1810,30 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
             // behind the store that the hazard is about.  The next write to them is the refill below.
             asm volatile("" :: "v"(wv[(h + 1) & 1][0]), "v"(wv[(h + 1) & 1][1]));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) __builtin_amdgcn_raw_buffer_store_b128(wv[h & 1][j], rs, lane16e, (c0 + 4 * (2 * h + j)) * 1024, SWN_BIG_STORE_AUX);
+            for (int j = 0; j < 2; ++j) {
+              const int c = c0 + 4 * (2 * h + j);
+              if constexpr (TAIL) {      // one form for both row spaces: row index = the token, or the tile row under a descriptor of the tile's rows
+                const int r = 2 * c + ce.lhi;
+                const uint32_t ri = wo_tok ? (uint32_t)tk[h & 1][j] : (uint32_t)r;
+                const uint32_t off = r < cur.rows ? ri * (uint32_t)ROWB + (uint32_t)(ce.l31 * 16) : oob_s;
+                __builtin_amdgcn_raw_buffer_store_b128(wv[h & 1][j], rs, off, 0, SWN_BIG_STORE_AUX);
+              } else {
+                __builtin_amdgcn_raw_buffer_store_b128(wv[h & 1][j], rs, lane16e, c * 1024, SWN_BIG_STORE_AUX);
+              }
+            }
             if (h < 7) rd(h + 1);                  // (into the OTHER set: stored from a half step ago)
             SWN_PIN();
           };
           const HalfHook<decltype(hook_f)> hook{hook_f};
-          epilogue_p_dispatch<E, HalfHook<decltype(hook_f)>>(acc, ce, mk, ly.relu, bias_epi, ly.skip != 0, (bc % 3) * 1024, hook);
+          run_epi(hook);
           SWN_PIN();
           asm volatile("s_nop 7\n\ts_nop 7" :: "v"(wv[0][0]), "v"(wv[0][1]), "v"(wv[1][0]), "v"(wv[1][1]));      // (the last two sets)
         } else {
-          epilogue_p_dispatch<E, NoHook>(acc, ce, mk, ly.relu, bias_epi, ly.skip != 0, (bc % 3) * 1024, NoHook());
+          run_epi(NoHook());
         }
         if (ly.relu == 1 && mkp) *(u32x4_t*)mkp = mk;
         SWN_PIN();
-        if (!last) preload_w(L + 1, cur.wset, ce.lane);      // (last layer: the S phase that follows loads the next tile's first fragments)
+        if (!last) preload_w(L + 1, ws_of(L + 1, cur), ce.lane);      // (last layer: the S phase that follows loads the next tile's first fragments)
         else if (nxt.vb >= 0) store_row(row_nxt, idx_nxt);
         if (last && d.y_add_gather && d.y_add) {
           const int lt = fg * 64 + cx.lane;
@@ -1546,7 +1853,9 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     if (cur.vb < 0) break;
   }
   // ---- the rows of the last tile ----
-  {
+  if constexpr (TAIL) {
+    tail_out(cx, prev, ((it - 1) & 1) ? Q_IDX1 : G::IDX0);
+  } else {
     const __amdgpu_buffer_rsrc_t ry = out_rs(d.y, prev);
     const __amdgpu_buffer_rsrc_t ra = d.y_add ? out_rs((void*)d.y_add, prev) : ry;
     if constexpr (TAG == 5) {
@@ -1588,6 +1897,24 @@ bool chain_big_eligible(const swn_chain_desc& d) {
 // geometries 6 / 7 (chainq_kernel) also take the dense front chains: a 128-feature chain input (x_features = 128 under a first layer
 // whose weights are zero-padded to k = 256) and a gathered y_add
 bool chain_persistent_eligible(const swn_chain_desc& d) {
+  if (d.tail_first > 0) {      // the dense tail folded into the expert forward chain: chainq_kernel<., 7, true> only
+    if (d.dtype != SWN_HALF || d.geometry != 7 || d.tag != 7 || d.x_save || d.x_scale || d.y_add || d.comb_y || !d.x_gather || d.group_begin) return false;
+    if (d.tail_first >= d.n_layers || !d.tail_gate || !d.tail_dropped || !d.tail_n_dropped || d.tail_tokens <= 0) return false;
+    if ((long)d.tail_tokens * 512 >= (1L << 32) - 64) return false;
+    if (d.x_features != 0 && d.x_features != 256) return false;
+    if (d.y_features != 128) return false;
+    for (int l = 0; l < d.n_layers; ++l) {
+      const swn_chain_layer& ly = d.layers[l];
+      const bool last = l + 1 == d.n_layers;
+      if (ly.n != 256 || ly.k != 256 || ly.skip > 1 || ly.relu == 2) return false;
+      if (ly.rowbias && (!last || ly.rows_per_bias <= 0)) return false;
+      if (l >= d.tail_first - 1 && (ly.skip || ly.mask)) return false;
+      if (l == d.tail_first - 1 && ly.relu) return false;      // (the gate layer: ReLU comes with the scaling)
+      if (last && ly.relu != 1) return false;                  // (the last layer's epilogue: row bias, then ReLU)
+    }
+    return true;
+  }
+  if (d.tag == 7) return false;
   if (d.dtype != SWN_HALF || d.x_save || d.x_scale || d.heads_raw) return false;
   if (d.comb_y && (d.tag != 5 || d.y_add)) return false;      // (the fused combine backward: the tail backward instantiation only)
 #ifndef SWN_BIG_TIMING
@@ -1685,7 +2012,9 @@ static int chain_persistent_launch(const swn_chain_desc& d, void* stream) {
   if (!d.group_rows) a.d.group_rows_clamp = d.group_stride;
   const long n_vb = (long)a.tiles_per_group * d.n_groups;
   SWN_CHECK(n_vb > 0 && n_vb < (1L << 28), "swn_mlp_chain: %ld tiles out of range", n_vb);
-  a.n_vb = (int)n_vb;
+  a.n_vb = a.n_vb_e = (int)n_vb;
+  if (d.tail_first > 0) a.n_vb += cdiv(d.tail_dropped_max, G::BM);      // tiles of the dropped tokens behind the experts' (the count is a
+                                                                        // device scalar: tiles beyond it end the queue)
   int grid = n_compute_units();                         // one resident workgroup per CU (157 KiB of LDS each)
   const char* ov = getenv("SWN_CHAINQ_WGS");            // experiments
   if (ov && atoi(ov) > 0) grid = atoi(ov);
@@ -1707,6 +2036,7 @@ static int chain_persistent_launch(const swn_chain_desc& d, void* stream) {
     break;
   switch (d.tag) {
     SWN_PICKQ(1) SWN_PICKQ(2) SWN_PICKQ(3) SWN_PICKQ(5) SWN_PICKQ(6)
+    case 7: fn = (const void*)chainq_kernel<HalfT, 7, true>; break;
     default: fn = d.geometry == 7 ? (const void*)chainq_kernel<HalfT, 0, true> : (const void*)chainq_kernel<HalfT, 0, false>;
   }
 #undef SWN_PICKQ

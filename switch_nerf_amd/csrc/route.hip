@@ -399,6 +399,57 @@ extern "C" int swn_route_top1(const int32_t* idx, const float* gmax, const float
   return 0;
 }
 
+// ---- the tokens no expert kept (the fused tail of swn_mlp_chain runs them as zero rows) -------------------------------------
+// drop_begin[g] = dropped tokens of the groups before g (group = (segment, expert)); one workgroup: the counts go through LDS, the
+// prefix is a serial walk of one thread over at most a few thousand words
+__global__ __launch_bounds__(256) void route_drop_begin_kernel(const int32_t* __restrict__ counts, int n_groups, int capacity,
+                                                               int32_t* __restrict__ drop_begin) {
+  __shared__ int32_t part[256];
+  const int per = (n_groups + 255) / 256;
+  const int g0 = threadIdx.x * per;
+  int run = 0;
+  for (int q = 0; q < per; ++q) {
+    const int g = g0 + q;
+    if (g < n_groups) run += max(counts[g] - capacity, 0);
+  }
+  part[threadIdx.x] = run;
+  __syncthreads();
+  int base = 0;
+  for (int t = 0; t < (int)threadIdx.x; ++t) base += part[t];
+  for (int q = 0; q < per; ++q) {
+    const int g = g0 + q;
+    if (g < n_groups) {
+      drop_begin[g] = base;
+      base += max(counts[g] - capacity, 0);
+    }
+  }
+  if (threadIdx.x == 255) drop_begin[n_groups] = base;
+}
+
+__global__ __launch_bounds__(256) void route_drop_list_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ loc,
+                                                              const int32_t* __restrict__ drop_begin, int n_tokens, int seg_tokens, int E,
+                                                              int capacity, int32_t* __restrict__ dropped) {
+  const long tok = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tok >= n_tokens) return;
+  const int l = loc[tok];
+  if (l < capacity) return;
+  const int g = (int)(tok / seg_tokens) * E + idx[tok];
+  dropped[drop_begin[g] + (l - capacity)] = (int32_t)tok;
+}
+
+extern "C" int swn_route_dropped(const int32_t* idx, const int32_t* loc, const int32_t* counts, int n_tokens, int seg_tokens, int n_experts,
+                                 int capacity, int32_t* drop_begin, int32_t* dropped, void* stream) {
+  SWN_CHECK(idx && loc && counts && drop_begin && dropped, "swn_route_dropped: null pointer");
+  SWN_CHECK(n_tokens > 0 && seg_tokens > 0 && n_tokens % seg_tokens == 0, "swn_route_dropped: n_tokens must be a multiple of seg_tokens");
+  const int n_groups = (n_tokens / seg_tokens) * n_experts;
+  SWN_CHECK(n_groups <= (1 << 20), "swn_route_dropped: too many groups");
+  hipLaunchKernelGGL(route_drop_begin_kernel, dim3(1), dim3(256), 0, as_stream(stream), counts, n_groups, capacity, drop_begin);
+  hipLaunchKernelGGL(route_drop_list_kernel, dim3(cdiv(n_tokens, 256)), dim3(256), 0, as_stream(stream), idx, loc, drop_begin, n_tokens,
+                     seg_tokens, n_experts, capacity, dropped);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int swn_route_pack(const int32_t* idx, const int32_t* loc, const int32_t* counts, int n_tokens, int seg_tokens,
                               int n_experts, int32_t* begin, int32_t* perm, int32_t* tok2row, void* stream) {
   SWN_CHECK(idx && loc && counts && begin, "swn_route_pack: null pointer");

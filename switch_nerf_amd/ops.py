@@ -159,6 +159,18 @@ def route_top1(idx, gmax, gates, seg_tokens: int, n_experts: int, capacity: int,
     return loc, counts, perm, tok2row, l_aux
 
 
+def route_dropped(idx, loc, counts, seg_tokens: int, n_experts: int, capacity: int):
+    """-> (drop_begin int32 [n_groups + 1], dropped int32 [P]): the tokens no expert kept, per (segment, expert) in location order;
+    drop_begin[-1] = their number (a device scalar: nothing is read on the host).  Input of the fused tail (mlp_chain(tail=...))."""
+    P = idx.shape[0]
+    n_groups = (P // seg_tokens) * n_experts
+    drop_begin = torch.empty(n_groups + 1, dtype=torch.int32, device=idx.device)
+    dropped = torch.empty(P, dtype=torch.int32, device=idx.device)
+    call("swn_route_dropped", _p(idx), _p(loc), _p(counts), P, int(seg_tokens), int(n_experts), int(capacity), _p(drop_begin), _p(dropped),
+         _stream())
+    return drop_begin, dropped
+
+
 def dispatch_fwd(gates, indices, locations, x, n_experts: int, capacity: int):
     S, H = x.shape
     d = torch.empty(n_experts * capacity, H, dtype=x.dtype, device=x.device)
@@ -510,12 +522,15 @@ def chain_mask_words(dtype, n_groups: int, group_stride: int, max_width: int = 2
 
 def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride=None, group_rows=None,
               group_rows_clamp=None, x_gather=None, x_save=None, y_add=None, y_add_gather=None, tag=0, x_scale=None,
-              x_relu=False, geometry=0, group_begin=None, combine=None, heads=None, sched=None, x_features=0):
+              x_relu=False, geometry=0, group_begin=None, combine=None, heads=None, sched=None, x_features=0, tail=None):
     """geometry: 0 / 1 the 64-row tile kernels, 2 - 5 the chain_big.hip geometries (include/swn.h).  group_begin: first row of every
     group (packed / no-batch layout) instead of g * group_stride.  combine = (y_fwd, dsig, wsig, gate, dgate_out): the combine backward
     (ops.combine_bwd) fused into the write-out of the last layer.  heads = (w_sigma, b_sigma, w_color, b_color, sigma_noise or None, raw):
     the sigma / colour heads (ops.heads_fwd) fused into the tail forward chain (tag 4) - y may then be None (nothing but raw is written).
-    sched: int32 [16] zero-initialised tile-queue counters of the persistent geometries 6 / 7 (chain_sched(); left zero by the kernel)."""
+    sched: int32 [16] zero-initialised tile-queue counters of the persistent geometries 6 / 7 (chain_sched(); left zero by the kernel).
+    tail = (tail_first, gate [P] f32, drop_begin, dropped, y_features): the dense tail folded into the expert forward chain (include/swn.h,
+    tail_first: geometry 7, tag 7) - layers[tail_first:] are shared layers, the saves from layer tail_first - 1 on, y and the heads'
+    raw are in token order (P rows), x_gather maps rows to tokens."""
     d = ChainDesc()
     d.dtype = _dt(x)
     d.tag = int(tag)
@@ -523,6 +538,12 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
     d.n_layers = len(layers)
     d.n_groups, d.n_wsets = int(n_groups), int(n_wsets)
     d.group_stride = int(group_stride if group_stride is not None else (y if y is not None else heads[5]).shape[0])
+    if tail is not None:
+        t_first, t_gate, t_begin, t_dropped, t_yf = tail
+        assert t_gate.dtype == torch.float32 and t_begin.dtype == torch.int32 and t_dropped.dtype == torch.int32 and x_gather is not None
+        d.tail_first, d.y_features, d.tail_gate, d.tail_dropped = int(t_first), int(t_yf), _p(t_gate), _p(t_dropped)
+        d.tail_n_dropped = t_begin.data_ptr() + 4 * (t_begin.numel() - 1)
+        d.tail_dropped_max, d.tail_tokens = int(t_dropped.numel()), int(t_gate.numel())
     d.group_rows = _p(group_rows)
     d.group_rows_clamp = int(group_rows_clamp if group_rows_clamp is not None else d.group_stride)
     d.group_begin = _p(group_begin)
