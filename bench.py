@@ -283,6 +283,8 @@ def main():
         model.profile = False
         return dt, st
 
+    fused_tail = [False]      # the step's expert forward launch carries the dense tail (SwitchNeRF._tail_fused)
+
     def kernel_times(reps=5):
         """Per-kernel durations that do not depend on how fast the host enqueues a step: ONE eager step with the relaunch hooks on
         (SwitchNeRF.profile), then every expert kernel `reps` times back to back on that step's live buffers between two HIP events
@@ -311,6 +313,7 @@ def main():
                 best = t_ if best is None else min(best, t_)
             out_[name] = best
         kept_ = int(torch.minimum(c_["counts"], torch.tensor(c_["cap"], device=dev)).sum().item())
+        fused_tail[0] = bool(c_.get("tail_fused"))
         return out_, kept_
 
     if a.routing == "balanced":
@@ -423,18 +426,32 @@ def main():
         hbm_measured_*: bytes from the FETCH_SIZE / WRITE_SIZE counters of a separate profiling pass (profiles/traffic.json,
         stored per kept row), i.e. what actually crossed the memory-side fabric."""
         detail_ = {}
-        flops = 2.0 * L * M * M * kept_
+        flops_e = 2.0 * L * M * M * kept_
         alg = {"expert_fwd": kept_ * M * esz * (1 + (L - 1) + 1), "expert_bwd": kept_ * M * esz * (1 + (L - 1) + 1 + 1),
                "expert_wgrad": kept_ * M * esz * 2 * L, "expert_fwd_nosave": kept_ * M * esz * 2}
+        fl = {k: flops_e for k in alg}
+        if fused_tail[0]:
+            # the forward launch also runs the dense tail on EVERY point (kept or not): Linear "1" (M x M) and Linear "2" (M x H2); it
+            # reads the kept rows and the per-ray bias (fp32, one row per point), writes the L - 1 expert activations (kept rows), y / h1
+            # (M) and h2 (H2) per point for the backward and raw (16 B per point) - the save-free form writes raw only
+            H2_ = model.H2
+            tail_fl = 2.0 * (M * M + M * H2_) * P
+            fl["expert_fwd"] += tail_fl
+            fl["expert_fwd_nosave"] += tail_fl
+            alg["expert_fwd"] = kept_ * M * esz * (1 + (L - 1)) + P * (2 * M * esz + H2_ * esz + H2_ * 4 + 16)
+            alg["expert_fwd_nosave"] = kept_ * M * esz + P * (H2_ * 4 + 16)
         for name in ("expert_fwd", "expert_bwd", "expert_wgrad", "expert_fwd_nosave"):
             ms_ = events.get(name)
             if not ms_ or ms_ <= 0:
                 continue
+            flops = fl[name]
             tf = flops / (ms_ * 1e-3) / 1e12
             gbs = alg[name] / (ms_ * 1e-3) / 1e9
             d_ = dict(ms=round(ms_, 4), tflops=round(tf, 1), mfma_frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4), alg_bytes=int(alg[name]),
-                      alg_gbs=round(gbs, 1), hbm_frac_alg=round(gbs / HBM_PEAK_GBS, 4))
+                      alg_flops=float(flops), alg_gbs=round(gbs, 1), hbm_frac_alg=round(gbs / HBM_PEAK_GBS, 4))
             per_row = traffic_tab.get(name + "_bytes_per_kept_row")
+            if fused_tail[0] and name.startswith("expert_fwd"):      # (measured on the launch that carries the tail: its own key)
+                per_row = traffic_tab.get(name + "_tail_bytes_per_kept_row")
             if per_row:
                 tb = per_row * kept_
                 d_.update(hbm_measured_bytes=int(tb), hbm_measured_gbs=round(tb / (ms_ * 1e-3) / 1e9, 1),
@@ -442,6 +459,10 @@ def main():
             detail_[name] = d_
         return detail_
 
+    if fused_tail[0]:
+        names["expert_fwd"] = ("chainq_kernel<Bf16,7,true> (expert forward, 7 fused layers, AND the dense tail behind it - gate scaling, Linear 1, "
+                               "Linear 2 + per-ray bias, sigma / colour heads - on every point: persistent 256-row workgroups on a tile queue)")
+        names["expert_fwd_nosave"] = "chainq_kernel<Bf16,7,true> without activation saves (the inference / --eval launch: experts + tail, raw is all it writes)"
     kept = kept_of(st)
     kept_mean = kkept if kkept is not None else kept                   # kept rows of the step whose buffers the kernels were timed on
     detail = {} if other else account(ktimes, kept_mean)               # (other recipes: headline number only)
@@ -455,7 +476,7 @@ def main():
         # which roofline bounds it: arithmetic intensity (algorithmic flops / algorithmic bytes) against the ridge 2.5 PFLOP/s / 8 TB/s =
         # 312 flop/B.  The weight-gradient launch (reads every operand once: 128 flop/B) is HBM-bound; the chains that save every
         # activation sit at ~220 flop/B (HBM side as well), the save-free forward at 1790 flop/B (MFMA side).  Both fractions are reported.
-        intensity = flops_of(kept_mean) / d["alg_bytes"]
+        intensity = d["alg_flops"] / d["alg_bytes"]
         attainable = min(MFMA_BF16_PEAK_TFLOPS, intensity * HBM_PEAK_GBS * 1e9 / 1e12)      # TFLOP/s: both rooflines in one number
         if intensity < MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
             roof = dict(kernel=names[dom], bound="hbm", achieved=d["alg_gbs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=d["hbm_frac_alg"],

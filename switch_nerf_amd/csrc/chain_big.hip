@@ -1898,7 +1898,7 @@ bool chain_big_eligible(const swn_chain_desc& d) {
 // whose weights are zero-padded to k = 256) and a gathered y_add
 bool chain_persistent_eligible(const swn_chain_desc& d) {
   if (d.tail_first > 0) {      // the dense tail folded into the expert forward chain: chainq_kernel<., 7, true> only
-    if (d.dtype != SWN_HALF || d.geometry != 7 || d.tag != 7 || d.x_save || d.x_scale || d.y_add || d.comb_y || !d.x_gather || d.group_begin) return false;
+    if (d.dtype != SWN_HALF || d.geometry != 7 || d.tag != 7 || d.x_save || d.x_scale || d.y_add || d.comb_y || !d.x_gather) return false;
     if (d.tail_first >= d.n_layers || !d.tail_gate || !d.tail_dropped || !d.tail_n_dropped || d.tail_tokens <= 0) return false;
     if ((long)d.tail_tokens * 512 >= (1L << 32) - 64) return false;
     if (d.x_features != 0 && d.x_features != 256) return false;

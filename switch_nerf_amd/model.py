@@ -316,6 +316,12 @@ class SwitchNeRF:
                 self.wb["l2h_pad"] = ops.pack_weights_padded(w3, self.dtype, False, 0, 256)
             else:
                 pairs.append((w3, self.wb["l2h_pad"], False, 0, 256))
+        if self._tail_fused():    # the tail folded into the expert forward chain: layer "2" (256 -> 128) zero-padded to 256 outputs
+            w3 = self.p["l2h.w"].unsqueeze(0)
+            if "l2h_pad" not in self.wf:
+                self.wf["l2h_pad"] = ops.pack_weights_padded(w3, self.dtype, True, 0, 256)
+            else:
+                pairs.append((w3, self.wf["l2h_pad"], True, 0, 256))
         if pairs:
             ops.repack_weights_batched(pairs)      # one launch (was 23 of ~5 us each: a tenth of the step at 1024 rays per GPU)
         if self._flat_param is not None:           # the copies now match the master weights as of this version of flat_param
@@ -335,6 +341,13 @@ class SwitchNeRF:
         turns it on (profiles/r04_experiments.md)."""
         return ("l2h.w" in self.spec and "l1.w" in self.spec and self.M == 256 and self.H2 == 128 and self.dtype != torch.float32
                 and os.environ.get("SWN_TAIL_GEOM", "1") in ("6", "7"))
+
+    def _tail_fused(self) -> bool:
+        """The dense tail (gate scaling + ReLU, Linear "1", Linear "2" + per-ray bias, sigma / colour heads) inside the expert forward
+        launch (swn_chain_desc.tail_first, chain_big.hip tag 7): 256-feature experts, 128-feature layer "2", 16-bit compute dtype,
+        experts local.  SWN_FUSED_TAIL=0 keeps the 64-row tail chain as its own launch."""
+        return ("l2h.w" in self.spec and "l1.w" in self.spec and self.M == 256 and self.H2 == 128 and self.dtype != torch.float32
+                and _FUSED_HEADS and self.L + 2 <= 12 and os.environ.get("SWN_FUSED_TAIL", "1") != "0")
 
     def set_expert_parallel(self, ep):
         """Shard the experts over the ranks of `ep` (parallel.ExpertParallel) and exchange the dispatched rows instead of
@@ -536,7 +549,6 @@ class SwitchNeRF:
             c["group_begin"] = group_begin
         c["rows"], c["ng"] = rows, ng
         c["counts_flat"] = c["counts"].view(-1)
-        c["eo"] = _b("eo", (rows, M), dt)
         c["saves"] = [_b(f"save{l}", (rows, M), dt) if sv else None for l in range(L - 1)]
         nw = max(o.chain_mask_words(dt, ng, cap, M), n_seg * o.chain_mask_words(dt, E, cap, M))    # (expert parallel: one launch per segment)
         c["masks"] = [_b(f"mask{l}", (nw,), torch.int32) if sv else None for l in range(L - 1)]
@@ -549,6 +561,10 @@ class SwitchNeRF:
         layers = [o.Layer(self._local_experts(self.wf[f"exp{l}"]), self._local_experts(self.p[f"exp{l}.b"]),
                           relu=1 if l < L - 1 else 0, skip=(l in skips), save=c["saves"][l] if (sv and l < L - 1) else None,
                           mask=c["masks"][l] if (sv and l < L - 1) else None) for l in range(L)]
+        # the tail inside the expert launch (local experts, standard row space, whole point grid): the expert output never reaches memory
+        c["tail_fused"] = (self._tail_fused() and self.ep is None and c["geom"] == 7 and row_range is None
+                           and P * M * c_esz(dt) < (1 << 32) - 64 and os.environ.get("SWN_CHAIN_GEOM", "7") == "7")
+        c["eo"] = None if c["tail_fused"] else _b("eo", (rows, M), dt)
         if no_batch and not sv and self.ep is not None:
             # evaluation without token dropping under expert parallelism (tutel_moe_layer_nobatch.py:308-335): the packed rows of a
             # segment, expert-major = (destination rank, local expert), travel with UNEQUAL splits (the reference's list_all_to_all);
@@ -567,6 +583,35 @@ class SwitchNeRF:
                                 group_rows_clamp=seg_tokens, tag=1, geometry=c["geom"], group_begin=gb)
                 back, _ = ep.all_to_all_ragged(out, rc, recv_counts=c["counts"][s_].contiguous())
                 c["eo"][rs] = back
+        elif self.ep is None and c["tail_fused"]:
+            # ---- experts + tail in ONE launch (chain_big.hip, tag 7): behind the last expert layer a row is scaled by its gate value and
+            # ReLU'd (the decoded MoE output y), runs through layer "1" and layer "2" (+ the per-ray bias below) and the two heads; y, h1
+            # and h2 are saved in TOKEN order for the backward (a training forward), raw is written in token order; the tokens no expert
+            # kept enter at layer "1" as zero rows (swn_route_dropped).  Replaces: the expert output's round trip through memory, the
+            # 64-row tail chain (which re-streams its 192 KiB of weights from L2 for every 64 rows) and its launch.
+            c["row_of_tok"] = c["tok2row"]
+            c["ray_feat"], c["c_ray"] = o.ray_feat_fwd(pe_dir, self.in_dir, self.p["emb"], image_indices.contiguous(), self.p["l2r.w"], self.p["l2.b"])
+            c["drop_begin"], c["dropped"] = o.route_dropped(c["idx"], c["loc"], c["counts"], seg_tokens, E, cap)
+            c["y"] = _b("y", (P, M), dt) if sv else None
+            c["h1"] = _b("h1", (P, M), dt) if sv else None
+            c["h2"] = _b("h2", (P, H2), dt) if sv else None
+            c["raw"] = torch.empty(P, 4, dtype=torch.float32, device=dev)
+            heads = (self.p["sigma.w"], self.p["sigma.b"], self.p["color.w"], self.p["color.b"], sigma_noise, c["raw"])
+
+            def run_experts(save=sv):
+                lys = [o.Layer(ly.w, ly.b, relu=ly.relu, skip=ly.skip, save=ly.save if save else None, mask=ly.mask if save else None)
+                       for ly in layers]
+                lys[-1].save = c["y"] if save else None
+                lys += [o.Layer(self.wf["l1"], self.p["l1.b"].view(1, M), save=c["h1"] if save else None),
+                        o.Layer(self.wf["l2h_pad"], None, relu=1, rowbias=c["c_ray"], rows_per_bias=S)]
+                o.mlp_chain(c["h0"], lys, c["h2"] if save else None, n_groups=ng, n_wsets=E, group_stride=cap, group_rows=c["counts_flat"],
+                            group_rows_clamp=cap, x_gather=c["perm"].view(-1), tag=7, geometry=7, heads=heads, group_begin=group_begin,
+                            tail=(L, c["gmax"], c["drop_begin"], c["dropped"], H2))
+            with self._timed("expert_fwd"):
+                run_experts()
+            if self.profile:
+                c["_relaunch"] = {"expert_fwd": run_experts, "expert_fwd_nosave": lambda: run_experts(False)}
+            return c
         elif self.ep is None:
             c["row_of_tok"] = c["tok2row"]
 

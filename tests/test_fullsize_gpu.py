@@ -100,7 +100,7 @@ def test_full_batch_bf16_properties():
     m16 = _model(torch.bfloat16, 277)
     st = m16.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=1.0, perturb_rand=pr, sigma_noise=noise, optimizer_step=False)
     c = st["ctx"]
-    assert c["n_seg"] == 16 and c["cap"] == 16384 and c["geom"] == 7 and c["front_geom"] == 7
+    assert c["n_seg"] == 16 and c["cap"] == 16384 and c["geom"] == 7 and c["front_geom"] == 7 and c["tail_fused"]
     rgb16, idx16, loc16 = c["rgb"].clone(), c["idx"].clone(), c["loc"].clone()
     grad16 = m16.grad.clone()
     assert torch.isfinite(rgb16).all() and torch.isfinite(st["loss"]) and torch.isfinite(grad16).all()
@@ -121,19 +121,28 @@ def test_full_batch_bf16_properties():
     # the same batch on the other expert-chain geometries (SWN_CHAIN_GEOM is read per forward).  5 = the phase-shifted 256-row
     # workgroup with the bias added in the epilogue, 6 = its persistent form and 2 = the lockstep 256-row workgroup are BIT-identical to
     # the 64-row kernels (1); the default (7: persistent) and 4 start their accumulators at the bias: same sums, a different fp32
-    # rounding order - and are bit-identical to each other, gradients included.
+    # rounding order - and are bit-identical to each other, gradients included.  The DEFAULT launch also carries the dense tail (layer
+    # "1", layer "2", the heads: SwitchNeRF._tail_fused); "7" below is geometry 7 with the tail as its own 64-row launch
+    # (SWN_FUSED_TAIL=0): the fused tail starts layer "1"'s accumulators at the bias too - same sums, one more rounding-order difference.
     import os
     runs = {}
-    for geom in ("1", "5", "2", "6", "4"):
+    for geom in ("1", "5", "2", "6", "4", "7"):
         os.environ["SWN_CHAIN_GEOM"] = geom
+        os.environ["SWN_FUSED_TAIL"] = "0"
         try:
             stg = m16.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=1.0, perturb_rand=pr, sigma_noise=noise, optimizer_step=False)
         finally:
             os.environ.pop("SWN_CHAIN_GEOM")
-        assert stg["ctx"]["geom"] == int(geom)
+            os.environ.pop("SWN_FUSED_TAIL")
+        assert stg["ctx"]["geom"] == int(geom) and not stg["ctx"]["tail_fused"]
         runs[geom] = (stg["ctx"]["idx"].clone(), stg["ctx"]["rgb"].clone(), m16.grad.clone())
-    assert torch.equal(runs["4"][0], idx16) and torch.equal(runs["4"][1], rgb16) and torch.equal(runs["4"][2], grad16), \
-        "geometry 4 and its persistent form (7, the default) are bit-identical"
+    assert torch.equal(runs["4"][0], runs["7"][0]) and torch.equal(runs["4"][1], runs["7"][1]) and torch.equal(runs["4"][2], runs["7"][2]), \
+        "geometry 4 and its persistent form (7) are bit-identical"
+    assert torch.equal(runs["7"][0], idx16), "routing does not see the tail"
+    d7 = (runs["7"][1] - rgb16).abs().max().item()
+    g7 = (runs["7"][2] - grad16).abs().max().item() / grad16.abs().max().item()
+    print(f"full batch bf16: the tail inside the expert launch vs its own 64-row launch: max |rgb difference| {d7:.2e}, max relative gradient difference {g7:.2e}")
+    assert d7 < 2e-3 and g7 < 5e-3
     for geom in ("5", "2", "6"):
         assert torch.equal(runs[geom][0], runs["1"][0]) and torch.equal(runs[geom][1], runs["1"][1]), f"geometry {geom}: the forward pass is bit-identical"
         gd = (runs[geom][2] - runs["1"][2]).abs().max().item() / runs["1"][2].abs().max().item()
