@@ -2,7 +2,7 @@
 # the GPU suite + the bench lines: bash scripts/r04_suite.sh <tag>
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 T=${1:-s}; O=gpurun_out/r04; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -25 > $O/${T}_pytest.log
+timeout 1500 python -m pytest tests -m gpu -q ${PYTEST_X--x} 2>&1 | tail -25 > $O/${T}_pytest.log
 tail -6 $O/${T}_pytest.log
 timeout 400 python bench.py --steps 20 --warmup 5 > $O/${T}_bench.json 2> $O/${T}_bench.err
 python - <<PY

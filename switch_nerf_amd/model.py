@@ -316,7 +316,7 @@ class SwitchNeRF:
                 self.wb["l2h_pad"] = ops.pack_weights_padded(w3, self.dtype, False, 0, 256)
             else:
                 pairs.append((w3, self.wb["l2h_pad"], False, 0, 256))
-        if self._tail_fused():    # the tail folded into the expert forward chain: layer "2" (256 -> 128) zero-padded to 256 outputs
+        if self._tail_fused() or "l2h_pad" in self.wf:    # the tail folded into the expert forward chain: layer "2" (256 -> 128) zero-padded to 256 outputs
             w3 = self.p["l2h.w"].unsqueeze(0)
             if "l2h_pad" not in self.wf:
                 self.wf["l2h_pad"] = ops.pack_weights_padded(w3, self.dtype, True, 0, 256)
@@ -592,6 +592,8 @@ class SwitchNeRF:
             c["row_of_tok"] = c["tok2row"]
             c["ray_feat"], c["c_ray"] = o.ray_feat_fwd(pe_dir, self.in_dir, self.p["emb"], image_indices.contiguous(), self.p["l2r.w"], self.p["l2.b"])
             c["drop_begin"], c["dropped"] = o.route_dropped(c["idx"], c["loc"], c["counts"], seg_tokens, E, cap)
+            if "l2h_pad" not in self.wf:      # (SWN_FUSED_TAIL switched on after the compute copies were made)
+                self.wf["l2h_pad"] = o.pack_weights_padded(self.p["l2h.w"].unsqueeze(0), dt, True, 0, 256)
             c["y"] = _b("y", (P, M), dt) if sv else None
             c["h1"] = _b("h1", (P, M), dt) if sv else None
             c["h2"] = _b("h2", (P, H2), dt) if sv else None

@@ -235,12 +235,14 @@ def test_hierarchical_bf16_runs_at_odd_sizes():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_expert_parallel_path_single_rank_equals_local_experts(dtype):
+def test_expert_parallel_path_single_rank_equals_local_experts(dtype, monkeypatch):
     """The expert-parallel code path (send buffer in payload order, counts exchange, local-expert groups, return path,
     remapped combine index) with world = 1, where the exchange is the identity: must reproduce the default path - forward
     and loss bit for bit, every gradient up to the summation-order noise of the fp32 atomics that both paths share.
-    (World > 1 plumbing: tests/test_parallel_cpu.py, gloo.)"""
+    (World > 1 plumbing: tests/test_parallel_cpu.py, gloo.)  The local path runs its tail as the 64-row launch the expert-parallel
+    path uses (SWN_FUSED_TAIL=0: inside the expert launch - local experts only - layer "1" sums in another fp32 order)."""
     from switch_nerf_amd.parallel import ExpertParallel
+    monkeypatch.setenv("SWN_FUSED_TAIL", "0")
     N, S, chunk = 128, 64, 2048
     rays, img, rgbs = synth.make_rays(118, N)
     outs = []
@@ -261,13 +263,14 @@ def test_expert_parallel_path_single_rank_equals_local_experts(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_expert_parallel_padded_mode_is_host_free_and_graph_capturable(dtype):
+def test_expert_parallel_padded_mode_is_host_free_and_graph_capturable(dtype, monkeypatch):
     """ExpertParallel(padded=True): the reference's capacity-padded equal-split exchange (tutel_moe_layer_nobatch.py:157) - standard row
     spaces, nothing read on the host.  World = 1: (a) forward / loss bit-identical to the default path and gradients to summation order,
     unbalanced routing with dropped tokens; (b) the whole step captured into hipGraphs (graph.GraphedTrainStep: a host read of split
     sizes would abort the capture) replays bit-identically to the eager padded step over three optimizer steps."""
     from switch_nerf_amd.graph import GraphedTrainStep
     from switch_nerf_amd.parallel import ExpertParallel
+    monkeypatch.setenv("SWN_FUSED_TAIL", "0")      # (the default path with its tail as the 64-row launch the expert-parallel path uses)
     N, S, chunk = 128, 64, 2048
     rays, img, rgbs = synth.make_rays(128, N)
     outs = []
@@ -744,7 +747,7 @@ def test_nobatch_inference_runs_on_packed_rows(dtype):
     raw_pack = c_pack["raw"].clone()
     c_pad = m.forward_rays(_dev(rays), _dev(img), S, chunk, training=True, no_batch=True)
     P, n_seg, E = N * S, N * S // chunk, m.E
-    assert "group_begin" in c_pack and c_pack["eo"].shape[0] == P and c_pad["eo"].shape[0] == n_seg * E * chunk
+    assert "group_begin" in c_pack and c_pack["rows"] == P and c_pad["rows"] == n_seg * E * chunk
     assert int((c_pack["tok2row"] < 0).sum()) == 0 and torch.equal(c_pack["idx"], c_pad["idx"])
     begin = c_pack["group_begin"].cpu().numpy()
     counts = c_pack["counts"].cpu().numpy().reshape(-1)

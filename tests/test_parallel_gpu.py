@@ -74,8 +74,9 @@ def test_bench_launches_its_own_ranks():
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_expert_parallel_evaluation_unequal_splits(dtype):
     """Evaluation without token dropping, experts sharded over two ranks: the packed rows travel with unequal splits (the reference's
-    list_all_to_all, tutel_communicate_nobatch.py:18-51) and the result equals the single-rank forward bit for bit."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    list_all_to_all, tutel_communicate_nobatch.py:18-51) and the result equals the single-rank forward bit for bit (its tail as the
+    64-row launch the expert-parallel path uses: SWN_FUSED_TAIL=0)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SWN_FUSED_TAIL="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29571", os.path.join(ROOT, "tests", "ep_eval_worker.py"), dtype]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
