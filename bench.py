@@ -283,7 +283,7 @@ def main():
         model.profile = False
         return dt, st
 
-    fused_tail = [False]      # the step's expert forward launch carries the dense tail (SwitchNeRF._tail_fused)
+    fused_tail = [False, False]      # the step's expert forward / backward launches carry the dense tail (SwitchNeRF._tail_fused)
 
     def kernel_times(reps=5):
         """Per-kernel durations that do not depend on how fast the host enqueues a step: ONE eager step with the relaunch hooks on
@@ -314,6 +314,7 @@ def main():
             out_[name] = best
         kept_ = int(torch.minimum(c_["counts"], torch.tensor(c_["cap"], device=dev)).sum().item())
         fused_tail[0] = bool(c_.get("tail_fused"))
+        fused_tail[1] = fused_tail[0] and os.environ.get("SWN_FUSED_TAIL_BWD", "1") != "0"
         return out_, kept_
 
     if a.routing == "balanced":
@@ -440,6 +441,11 @@ def main():
             fl["expert_fwd_nosave"] += tail_fl
             alg["expert_fwd"] = kept_ * M * esz * (1 + (L - 1)) + P * (2 * M * esz + H2_ * esz + H2_ * 4 + 16)
             alg["expert_fwd_nosave"] = kept_ * M * esz + P * (H2_ * 4 + 16)
+        if fused_tail[1]:
+            # ... and the backward launch runs the tail's two backward layers and the combine backward in front of the experts': reads dh2
+            # (H2) and y (M) per point and the skip layer's dZ, writes dh1 (M) per point, L dZ (the last expert layer's included) + dx per kept row
+            fl["expert_bwd"] += 2.0 * (M * M + M * model.H2) * P
+            alg["expert_bwd"] = kept_ * M * esz * (L + 1 + 1) + P * (model.H2 * esz + 2 * M * esz + 12)
         for name in ("expert_fwd", "expert_bwd", "expert_wgrad", "expert_fwd_nosave"):
             ms_ = events.get(name)
             if not ms_ or ms_ <= 0:
@@ -463,6 +469,9 @@ def main():
         names["expert_fwd"] = ("chainq_kernel<Bf16,7,true> (expert forward, 7 fused layers, AND the dense tail behind it - gate scaling, Linear 1, "
                                "Linear 2 + per-ray bias, sigma / colour heads - on every point: persistent 256-row workgroups on a tile queue)")
         names["expert_fwd_nosave"] = "chainq_kernel<Bf16,7,true> without activation saves (the inference / --eval launch: experts + tail, raw is all it writes)"
+    if fused_tail[1]:
+        names["expert_bwd"] = ("chainq_kernel<Bf16,8,true> (the tail's two backward layers + the combine backward on every point, then the expert "
+                               "backward-data chain, 7 fused layers: persistent 256-row workgroups on a tile queue)")
     kept = kept_of(st)
     kept_mean = kkept if kkept is not None else kept                   # kept rows of the step whose buffers the kernels were timed on
     detail = {} if other else account(ktimes, kept_mean)               # (other recipes: headline number only)

@@ -322,7 +322,7 @@ typedef struct swn_chain_desc {
                                    that recorded its masks.                                                                   */
   int32_t tag;                  /* profiling only: selects an identical kernel instantiation with its own symbol so that
                                    rocprofv3 reports the roles separately (0 generic, 1 expert fwd, 2 expert bwd,
-                                   3 front fwd, 4 tail fwd, 5 tail bwd, 6 front bwd; 7 = the expert forward chain WITH the fused tail, tail_first below)                 */
+                                   3 front fwd, 4 tail fwd, 5 tail bwd, 6 front bwd; 7 = the expert forward chain WITH the fused tail, tail_first below; 8 = the expert backward chain behind the tail's backward layers, head_layers below)                 */
   /* Combine backward fused into the write-out of the LAST layer (comb_y != NULL; the tail backward chain): with z = the layer's
      output row (the gradient of the decoded, gate-scaled, ReLU'd expert output y, tutel_fast_dispatch.py:50-63 + nerf_moe.py:385)
        t = (z + comb_dsig[row] * comb_wsig) * (comb_y[row] > 0);   y[row] = t * comb_gate[row];   comb_dgate[row] = <comb_y[row], t> / comb_gate[row]
@@ -367,6 +367,15 @@ typedef struct swn_chain_desc {
          rows (and are saved as zero rows of layers[tail_first - 1].save);
        * heads_* as for tag 4 (optional), y / the saves may be NULL (an inference forward writes nothing but heads_raw);
        * tail_tokens * 512 bytes must stay below 4 GiB (the scattered stores carry 32-bit offsets).                                 */
+  /* The mirror image for the BACKWARD-DATA pass (head_layers > 0; geometry 7, tag 8, x_gather required, x_features = 128): the tail's
+     backward layers in FRONT of the expert backward chain.  x = dh2 in TOKEN order (128 features under a first layer zero-padded in K),
+     layers[0 .. head_layers) are shared layers (weight set 0), layers[l].save for l < head_layers - 1 is in TOKEN order (dh1); behind
+     layer head_layers - 1 the combine backward runs on the row (comb_* above, all indexed by TOKEN here: comb_y [tail_tokens][256],
+     comb_dsig, comb_gate, comb_dgate per token - the tokens tail_dropped lists get comb_dgate = 0), whose result is what
+     layers[head_layers - 1].save receives in the ROW space (the last expert layer's dZ for the weight gradients) and what the expert
+     layers behind it consume; y / y_add / the other saves are the expert backward chain's (row space).  The dropped tokens run the
+     head layers only.                                                                                                              */
+  int32_t head_layers;
   int32_t tail_first;
   int32_t y_features;           /* real width of the last layer (tail mode): 128 or 256; 0 = layers[n_layers - 1].n              */
   const float* tail_gate;       /* fp32 [tail_tokens]                                                                              */

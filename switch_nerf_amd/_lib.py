@@ -42,7 +42,7 @@ class ChainDesc(C.Structure):
                 ("y", vp), ("y_add", vp), ("y_add_gather", vp), ("geometry", i32), ("tag", i32),
                 ("comb_y", vp), ("comb_dsig", vp), ("comb_wsig", vp), ("comb_gate", vp), ("comb_dgate", vp),
                 ("heads_ws", vp), ("heads_bs", vp), ("heads_wc", vp), ("heads_bc", vp), ("heads_noise", vp), ("heads_raw", vp), ("sched", vp), ("x_features", i32),
-                ("tail_first", i32), ("y_features", i32), ("tail_gate", vp), ("tail_dropped", vp), ("tail_n_dropped", vp),
+                ("head_layers", i32), ("tail_first", i32), ("y_features", i32), ("tail_gate", vp), ("tail_dropped", vp), ("tail_n_dropped", vp),
                 ("tail_dropped_max", i32), ("tail_tokens", i32),
                 ("layers", ChainLayer * 12)]
 

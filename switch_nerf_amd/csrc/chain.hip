@@ -1068,14 +1068,16 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
               "swn_mlp_chain: fused heads: chain input of 256 / 512 features in rows of at most 1 KiB, last layer of 128 / 256 (k0=%d, n=%d)", k0, nl);
     for (int l = 0; l < d.n_layers; ++l) SWN_CHECK(d.layers[l].skip != 2, "swn_mlp_chain: fused heads: no concat-skip layers");
   }
-  SWN_CHECK(d.tag >= 0 && d.tag <= 7, "swn_mlp_chain: tag %d not in [0,7]", d.tag);
+  SWN_CHECK(d.tag >= 0 && d.tag <= 8, "swn_mlp_chain: tag %d not in [0,8]", d.tag);
+  SWN_CHECK(d.head_layers == 0 || (d.geometry == 7 && d.tag == 8), "swn_mlp_chain: head layers (head_layers > 0) run on geometry 7 with tag 8");
+  SWN_CHECK(d.tag != 8 || d.head_layers > 0, "swn_mlp_chain: tag 8 is the expert backward chain behind the tail's backward layers (head_layers > 0)");
   SWN_CHECK(d.tail_first == 0 || (d.geometry == 7 && d.tag == 7), "swn_mlp_chain: a fused tail (tail_first > 0) runs on geometry 7 with tag 7");
   SWN_CHECK(d.tag != 7 || d.tail_first > 0, "swn_mlp_chain: tag 7 is the fused-tail forward chain (tail_first > 0)");
   SWN_CHECK(d.x_features == 0 || d.x_features == d.layers[0].k || (d.x_features == 128 && d.layers[0].k == 256 && d.geometry >= 6),
             "swn_mlp_chain: x_features = %d: only 128-feature rows under a zero-padded k = 256 first layer on geometry 6 / 7", d.x_features);
   SWN_CHECK(!(wide && concat), "swn_mlp_chain: concat-skip layers are built for the 256-feature kernels only");
   SWN_CHECK(d.geometry >= 0 && d.geometry <= 7, "swn_mlp_chain: geometry %d not in [0,7]", d.geometry);
-  if (d.comb_y) {
+  if (d.comb_y && d.head_layers == 0) {      // (head_layers > 0: the combine backward sits behind the head layers - chain_persistent_eligible)
     const int nl = d.layers[d.n_layers - 1].n;
     SWN_CHECK(d.comb_gate && d.comb_dgate, "swn_mlp_chain: combine backward needs comb_gate and comb_dgate");
     SWN_CHECK((nl == 128 || nl == 256 || nl == 512) && nl * (d.dtype == SWN_F32 ? 4 : 2) <= 1024,

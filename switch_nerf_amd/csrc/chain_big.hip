@@ -1196,6 +1196,7 @@ constexpr int T_WS = T_GATE + 1024;        // f32 [256]: sigma head weights
 constexpr int T_SIGP = T_WS + 1024;        // f32 [8][256]: partial sums of the sigma head, [wave quarter * 2 + half-wave][tile row]
 constexpr int T_COL = T_SIGP + 8192;       // f32 [3][256]: the colour head's dot products of every tile row
 static_assert(T_COL + 3072 <= G256::IDX0, "tail tables must fit the ring region");
+constexpr int T_DSIG = T_COL;              // (tag 8) f32 [256]: the sigma head's gradient of every tile row
 
 // Epilogue of the LAST EXPERT layer of a fused chain: the row becomes relu(gate[row] * z) - z rounded to the 16-bit type first, the
 // product rounded again: GatingDecoder's fp32 multiply on the 16-bit expert output, cast back, act relu (tutel_fast_dispatch.py:119-127,
@@ -1232,6 +1233,7 @@ __device__ __forceinline__ void epilogue_q_gate(f32x16_t (&acc)[4][2], const Ctx
           sg[mi] = __builtin_fmaf(E::lo(pp[k]), ws[k >> 1][2 * (k & 1)], sg[mi]);
           sg[mi] = __builtin_fmaf(E::hi(pp[k]), ws[k >> 1][2 * (k & 1) + 1], sg[mi]);
         }
+        asm volatile("" : "+v"(sg[mi]));     // (computed here, not sunk to the store at the end: see epilogue_q_comb)
       }
 #pragma unroll
       for (int g = 0; g < 4; g += 2) {
@@ -1250,6 +1252,77 @@ __device__ __forceinline__ void epilogue_q_gate(f32x16_t (&acc)[4][2], const Ctx
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) *(float*)(smem + T_SIGP + (((fg * 2 + cx.lhi) * 256 + row0 + 32 * mi) << 2)) = sg[mi];
   }
+}
+
+// Epilogue of the last HEAD layer of a fused backward chain (tag 8): the COMBINE BACKWARD on the row (include/swn.h comb_*; the arithmetic
+// of write_pieces16_comb / combine_bwd_kernel value for value): with z = the layer's output rounded to the 16-bit type (the gradient of
+// the decoded, gate-scaled, ReLU'd expert output y),  t = (z + dsig[row] * wsig) * (y[row] > 0);  the row becomes t * gate[row] (the
+// gradient of the expert output: the next layer's input and layers[head_layers - 1].save);  the lane's share of <y[row], t> goes to
+// T_SIGP for the gate gradient.  y is read from memory through the rows' tokens (8 bytes per lane, row and 8-feature group), one half
+// step ahead of its use.
+template <typename E, typename HOOK>
+__device__ __forceinline__ void epilogue_q_comb(f32x16_t (&acc)[4][2], const Ctx& cx, const char* y, uint32_t y_bytes, int idx_off, HOOK hook) {
+  char* smem = cx.smem;
+  uint32_t e2_base = cx.e2_base;
+  asm volatile("" : "+v"(e2_base));
+  const int fg = cx.w & 3;
+  const int row0 = 128 * (cx.w >> 2) + cx.l31;
+  const __amdgpu_buffer_rsrc_t ry = uniform_rsrc(y, (int)y_bytes);
+  uint32_t yo[4];                           // byte offset of the lane's first 4 features of its row mi in y
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+    yo[mi] = (uint32_t)((const int*)(smem + idx_off))[row0 + 32 * mi] * (uint32_t)ROWB + (uint32_t)((fg * 64 + 4 * cx.lhi) * 2);
+  float dot[4] = {0.f, 0.f, 0.f, 0.f};
+  u32x2_t yq[4];
+  auto fetch = [&](int t) {                 // (into the ONE buffer, right behind its last use: the loads travel under the half step's
+    const int ni = t >> 2, mi = t & 3;      //  exchange, LDS writes and write-out hook)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) yq[g4] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(ry, yo[mi], (32 * ni + 8 * g4) * 2, 0));
+  };
+  fetch(0);
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    f32x4_t ws[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) ws[g4] = *(const f32x4_t*)(smem + T_WS + ((fg * 64 + 32 * ni + 8 * g4 + 4 * cx.lhi) << 2));
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int t = 4 * ni + mi;
+      const float gt = *(const float*)(smem + T_GATE + (row0 + 32 * mi) * 4), ds = *(const float*)(smem + T_DSIG + (row0 + 32 * mi) * 4);
+      uint32_t pp[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pp[k] = E::pack2(acc[mi][ni][(k >> 1) * 4 + 2 * (k & 1)], acc[mi][ni][(k >> 1) * 4 + 2 * (k & 1) + 1]);
+      SWN_PIN();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int g4 = k >> 1, i = k & 1;
+        const float y0 = E::lo(yq[g4][i]), y1 = E::hi(yq[g4][i]);
+        float t0 = __builtin_fmaf(ds, ws[g4][2 * i], E::lo(pp[k])), t1 = __builtin_fmaf(ds, ws[g4][2 * i + 1], E::hi(pp[k]));
+        t0 = y0 > 0.f ? t0 : 0.f;
+        t1 = y1 > 0.f ? t1 : 0.f;
+        dot[mi] = __builtin_fmaf(y0, t0, dot[mi]);
+        dot[mi] = __builtin_fmaf(y1, t1, dot[mi]);
+        pp[k] = E::pack2(t0 * gt, t1 * gt);
+      }
+      asm volatile("" : "+v"(dot[mi]));      // (the sum is wanted HERE: left alone the compiler sinks the whole fma chain to the store at the
+                                             //  end of the epilogue and keeps - spills - every y and t value until then)
+      SWN_PIN();
+      if (t + 1 < 8) fetch(t + 1);
+      SWN_PIN();
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        auto r0 = __builtin_amdgcn_permlane32_swap(pp[g * 2], pp[(g + 1) * 2], false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(pp[g * 2 + 1], pp[(g + 1) * 2 + 1], false, false);
+        const u32x4_t o = {(uint32_t)r0[0], (uint32_t)r1[0], (uint32_t)r0[1], (uint32_t)r1[1]};
+        *(u32x4_t*)(smem + (e2_base ^ (uint32_t)((4 * ni + g) << 4)) + mi * (32 * ROWB)) = o;
+      }
+      SWN_PIN();
+      if constexpr (hook_halves<HOOK>::value) hook(t);
+      else if (t & 1) hook(t >> 1);
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) *(float*)(smem + T_SIGP + (((fg * 2 + cx.lhi) * 256 + row0 + 32 * mi) << 2)) = dot[mi];
 }
 
 // Epilogue of the LAST layer of a fused chain (Linear "2" over cat([h, PE(dir), embedding_a]), nerf_moe.py:419-429): the per-ray half
@@ -1376,6 +1449,8 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
   typedef G256 G;
   constexpr int BM = G::BM, MI = 4;
   constexpr bool TAIL = TAG == 7;               // the dense tail folded into the expert forward chain (include/swn.h, tail_first)
+  constexpr bool HEAD = TAG == 8;               // the tail's backward layers in front of the expert backward chain (head_layers)
+  constexpr bool DROPS = TAIL || HEAD;          // tiles of dropped tokens behind the experts' tiles
   const swn_chain_desc& d = args.d;
   Ctx cx;
   cx.smem = smem;
@@ -1438,8 +1513,9 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         ++kq;
       }
       if (vb >= args.n_vb) { vb = -1; break; }
-      if constexpr (TAIL) {
-        if (vb >= args.n_vb_e) {                 // a tile of dropped tokens (they enter at the first shared layer as zero rows)
+      if constexpr (DROPS) {
+        if (vb >= args.n_vb_e) {                 // a tile of dropped tokens (forward: they enter at the first shared layer as zero rows;
+                                                 // backward: they run the shared head layers only)
           rows_valid = min(*d.tail_n_dropped, d.tail_dropped_max);
           tile = vb - args.n_vb_e;
           g = -1;
@@ -1473,10 +1549,11 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         t[4] = (int)(grow0 >> 32);
         t[5] = g >= 0 ? g % n_wsets : 0;
         if constexpr (TAIL) t[6] = g >= 0 ? 0 : d.tail_first;      // first layer of the tile
+        if constexpr (HEAD) t[7] = g >= 0 ? d.n_layers : d.head_layers;      // ... one past its last layer
       }
     }
   };
-  struct Tile { int vb, rows; long grow0; int wset, l0; };
+  struct Tile { int vb, rows; long grow0; int wset, l0, l1; };
   auto read_tile = [&](int slot) -> Tile {
     Tile t;
     t.vb = __builtin_amdgcn_readfirstlane(tinfo[slot * 8 + 0]);
@@ -1487,6 +1564,8 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     t.wset = __builtin_amdgcn_readfirstlane(tinfo[slot * 8 + 5]);
     t.l0 = 0;
     if constexpr (TAIL) t.l0 = __builtin_amdgcn_readfirstlane(tinfo[slot * 8 + 6]);
+    t.l1 = n_layers;
+    if constexpr (HEAD) t.l1 = __builtin_amdgcn_readfirstlane(tinfo[slot * 8 + 7]);
     return t;
   };
   auto finish = [&]() {                          // the last workgroup to leave zeroes the counters for the next launch
@@ -1507,7 +1586,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     if (lt < 128) {
       const int r = 128 * rg + lt;
       const long gr = t.grow0 + (r < t.rows ? r : 0);          // rows past the end repeat the first row (computed, never stored)
-      if (TAIL && t.l0) src = d.tail_dropped[gr];
+      if ((TAIL && t.l0) || (HEAD && t.l1 < n_layers)) src = d.tail_dropped[gr];
       else src = d.x_gather ? d.x_gather[gr] : (int)gr;
     }
     return src;
@@ -1522,7 +1601,9 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     const char* p = (const char*)d.layers[L].w + (size_t)wset * bytes;
     return uniform_rsrc(p, bytes);
   };
-  auto ws_of = [&](int L, const Tile& t) -> int { return (TAIL && L >= d.tail_first) ? 0 : t.wset; };      // (shared layers: one weight set)
+  auto ws_of = [&](int L, const Tile& t) -> int {      // (shared layers: one weight set)
+    return ((TAIL && L >= d.tail_first) || (HEAD && L < d.head_layers)) ? 0 : t.wset;
+  };
   auto out_rs = [&](void* base, const Tile& t) -> __amdgpu_buffer_rsrc_t {
     return uniform_rsrc((char*)base + t.grow0 * ROWB, t.rows * ROWB);
   };
@@ -1612,6 +1693,20 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
       if (tid < 256) ((float*)(smem + T_WS))[tid] = d.heads_ws[tid];
     }
   }
+  auto head_out = [&](const Ctx& c_, const Tile& t, int idx_off) {
+    // backward: the gate gradient of the finished tile's rows, dgate[token] = <y, t> / gate (the eight partial sums of the combine
+    // epilogue; a wave finishes the rows it stages: 8 j + 2 fg + {0, 1})
+    const int r = 128 * (c_.w >> 2) + 8 * (c_.l31 >> 1) + 2 * (c_.w & 3) + (c_.l31 & 1);
+    if (c_.lhi == 0 && r < t.rows) {
+      const long tok = ((const int*)(smem + idx_off))[r];
+      const float* sp = (const float*)(smem + T_SIGP) + r;
+      const float dot = ((sp[0] + sp[256]) + (sp[512] + sp[768])) + ((sp[1024] + sp[1280]) + (sp[1536] + sp[1792]));
+      d.comb_dgate[tok] = dot / d.comb_gate[tok];      // (the gate value from memory: the LDS table may already hold the next tile's)
+    }
+  };
+  if constexpr (HEAD) {
+    if (tid < 256) ((float*)(smem + T_WS))[tid] = d.comb_wsig ? d.comb_wsig[tid] : 0.f;
+  }
   // ---- prologue: the first tile, its source rows ----
   if (cx.w == 0 && cx.lane < 2) gcount[cx.lane] = 0;
   if (cx.w == 0) grab(0, claim());
@@ -1647,7 +1742,10 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
       if (it > 0) {
         if constexpr (TAIL) {
           tail_out(cs, prev, idx_nxt);           // (the other table still holds the previous tile's tokens)
+        } else if (HEAD && prev.l1 < n_layers) {
+          // (a tile of dropped tokens has no output rows; its gate gradients were zeroed when it was staged)
         } else {
+          if constexpr (HEAD) head_out(cs, prev, idx_nxt);
           const __amdgpu_buffer_rsrc_t ry = out_rs(d.y, prev);
           const __amdgpu_buffer_rsrc_t ra = d.y_add ? out_rs((void*)d.y_add, prev) : ry;
           if constexpr (TAG == 5) {      // (only this instantiation carries the fused combine backward)
@@ -1660,9 +1758,21 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         SWN_WAIT_LGKM0();                        // (every piece is in registers / on its way: the rows may be overwritten)
       }
       SWN_TM(const long long sw = TICK(); tSw += sw - s0;)
-      float gate_v = 0.f;
+      float gate_v = 0.f, dsig_v = 0.f;
       const int lts = fgs * 64 + cs.lane;
-      if constexpr (TAIL) {
+      if constexpr (HEAD) {
+        if (lts < 128) {
+          const int r_ = 128 * rgs + lts;
+          const long tok = ((const int*)(smem + idx_cur))[r_];
+          if (cur.l1 < n_layers) {               // dropped tokens: no expert saw them - their gate gradient is zero
+            if (r_ < cur.rows) d.comb_dgate[tok] = 0.f;
+          } else {
+            gate_v = d.comb_gate[tok];
+            dsig_v = d.comb_dsig ? d.comb_dsig[tok] : 0.f;
+          }
+        }
+        stage_pieces_q<true>(cs, (const char*)d.x, 64 * rgs + fgs, 16, 4, idx_cur);
+      } else if constexpr (TAIL) {
         if (cur.l0) {
           stage_dropped(cs, cur, idx_cur);
         } else {
@@ -1680,6 +1790,12 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
       if constexpr (TAIL) {
         if (!cur.l0 && lts < 128) ((float*)(smem + T_GATE))[128 * rgs + lts] = gate_v;
       }
+      if constexpr (HEAD) {
+        if (cur.l1 == n_layers && lts < 128) {
+          ((float*)(smem + T_GATE))[128 * rgs + lts] = gate_v;
+          ((float*)(smem + T_DSIG))[128 * rgs + lts] = dsig_v;
+        }
+      }
     }
     if (rg == 0 && it == 0) { stage_bias(cur.l0, ws_of(cur.l0, cur), 0); SWN_WAIT_VM(0); }
     u32x4_t mk_next = load_mask(cur.l0, cur.vb);
@@ -1691,9 +1807,10 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     __builtin_amdgcn_s_barrier();
     SWN_TM(const long long s2 = TICK(); tS += s1 - s0; tSb += s2 - s1;)
     Tile nxt = cur;
-    for (int L = cur.l0; L < n_layers; ++L) {
+    const int l_end = HEAD ? cur.l1 : n_layers;
+    for (int L = cur.l0; L < l_end; ++L) {
       const swn_chain_layer& ly = d.layers[L];
-      const bool last = L + 1 == n_layers;
+      const bool last = L + 1 == l_end;
       u32x4_t mk = mk_next;
       if (last) nxt = read_tile((it + 1) & 1);   // (written by wave 0 during row group 0's S phase of this tile, barriers ago)
       // ---- K phase ----
@@ -1767,10 +1884,13 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         // the partner's rows = the input tile of the K loop it is running (same tile: the groups are one phase apart)
         void* wo = rge == 0 ? (L > cur.l0 ? d.layers[L - 1].save : nullptr) : (!last ? ly.save : nullptr);
         // fused tail: the saves from the gate layer on go to TOKEN order; the gate layer and the last layer have their own epilogues
-        const bool wo_tok = TAIL && (rge == 0 ? L - 1 : L) >= d.tail_first - 1;
+        const bool wo_tok = (TAIL && (rge == 0 ? L - 1 : L) >= d.tail_first - 1) || (HEAD && (rge == 0 ? L - 1 : L) < d.head_layers - 1);
         const bool gate_l = TAIL && L + 1 == d.tail_first, rb_l = TAIL && last;
         auto run_epi = [&](auto hook) {
           typedef decltype(hook) HK;
+          if constexpr (HEAD) {
+            if (L + 1 == d.head_layers && cur.l1 == n_layers) { epilogue_q_comb<E, HK>(acc, ce, (const char*)d.comb_y, oob_s, idx_cur, hook); return; }
+          }
           if constexpr (TAIL) {
 #ifdef SWN_T7_NOHEADS
             const bool hd = false;
@@ -1800,7 +1920,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               wv[h & 1][j] = *(const u32x4_t*)(smem + piece_addr(ce, c0 + 4 * (2 * h + j)));
-              if constexpr (TAIL) tk[h & 1][j] = ((const int*)(smem + idx_cur))[2 * (c0 + 4 * (2 * h + j)) + ce.lhi];
+              if constexpr (DROPS) tk[h & 1][j] = ((const int*)(smem + idx_cur))[2 * (c0 + 4 * (2 * h + j)) + ce.lhi];
             }
           };
           rd(0);
@@ -1812,7 +1932,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               const int c = c0 + 4 * (2 * h + j);
-              if constexpr (TAIL) {      // one form for both row spaces: row index = the token, or the tile row under a descriptor of the tile's rows
+              if constexpr (DROPS) {     // one form for both row spaces: row index = the token, or the tile row under a descriptor of the tile's rows
                 const int r = 2 * c + ce.lhi;
                 const uint32_t ri = wo_tok ? (uint32_t)tk[h & 1][j] : (uint32_t)r;
                 const uint32_t off = r < cur.rows ? ri * (uint32_t)ROWB + (uint32_t)(ce.l31 * 16) : oob_s;
@@ -1855,7 +1975,9 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
   // ---- the rows of the last tile ----
   if constexpr (TAIL) {
     tail_out(cx, prev, ((it - 1) & 1) ? Q_IDX1 : G::IDX0);
+  } else if (HEAD && prev.l1 < n_layers) {
   } else {
+    if constexpr (HEAD) head_out(cx, prev, ((it - 1) & 1) ? Q_IDX1 : G::IDX0);
     const __amdgpu_buffer_rsrc_t ry = out_rs(d.y, prev);
     const __amdgpu_buffer_rsrc_t ra = d.y_add ? out_rs((void*)d.y_add, prev) : ry;
     if constexpr (TAG == 5) {
@@ -1914,7 +2036,18 @@ bool chain_persistent_eligible(const swn_chain_desc& d) {
     }
     return true;
   }
-  if (d.tag == 7) return false;
+  if (d.head_layers > 0) {     // the tail's backward layers in front of the expert backward chain: chainq_kernel<., 8, true> only
+    if (d.dtype != SWN_HALF || d.geometry != 7 || d.tag != 8 || d.tail_first || d.x_save || d.x_scale || d.heads_raw || d.y_add_gather || !d.x_gather) return false;
+    if (d.head_layers >= d.n_layers || !d.comb_y || !d.comb_gate || !d.comb_dgate || !d.tail_dropped || !d.tail_n_dropped || d.tail_tokens <= 0) return false;
+    if ((long)d.tail_tokens * 512 >= (1L << 32) - 64 || d.x_features != 128) return false;
+    for (int l = 0; l < d.n_layers; ++l) {
+      const swn_chain_layer& ly = d.layers[l];
+      if (ly.n != 256 || ly.k != 256 || ly.rowbias || ly.skip || ly.b || ly.relu == 1) return false;
+      if (l < d.head_layers && (ly.relu || ly.mask)) return false;
+    }
+    return true;
+  }
+  if (d.tag == 7 || d.tag == 8) return false;
   if (d.dtype != SWN_HALF || d.x_save || d.x_scale || d.heads_raw) return false;
   if (d.comb_y && (d.tag != 5 || d.y_add)) return false;      // (the fused combine backward: the tail backward instantiation only)
 #ifndef SWN_BIG_TIMING
@@ -2013,7 +2146,7 @@ static int chain_persistent_launch(const swn_chain_desc& d, void* stream) {
   const long n_vb = (long)a.tiles_per_group * d.n_groups;
   SWN_CHECK(n_vb > 0 && n_vb < (1L << 28), "swn_mlp_chain: %ld tiles out of range", n_vb);
   a.n_vb = a.n_vb_e = (int)n_vb;
-  if (d.tail_first > 0) a.n_vb += cdiv(d.tail_dropped_max, G::BM);      // tiles of the dropped tokens behind the experts' (the count is a
+  if (d.tail_first > 0 || d.head_layers > 0) a.n_vb += cdiv(d.tail_dropped_max, G::BM);      // tiles of the dropped tokens behind the experts' (the count is a
                                                                         // device scalar: tiles beyond it end the queue)
   int grid = n_compute_units();                         // one resident workgroup per CU (157 KiB of LDS each)
   const char* ov = getenv("SWN_CHAINQ_WGS");            // experiments
@@ -2037,6 +2170,7 @@ static int chain_persistent_launch(const swn_chain_desc& d, void* stream) {
   switch (d.tag) {
     SWN_PICKQ(1) SWN_PICKQ(2) SWN_PICKQ(3) SWN_PICKQ(5) SWN_PICKQ(6)
     case 7: fn = (const void*)chainq_kernel<HalfT, 7, true>; break;
+    case 8: fn = (const void*)chainq_kernel<HalfT, 8, true>; break;
     default: fn = d.geometry == 7 ? (const void*)chainq_kernel<HalfT, 0, true> : (const void*)chainq_kernel<HalfT, 0, false>;
   }
 #undef SWN_PICKQ

@@ -310,7 +310,7 @@ class SwitchNeRF:
                 self.wf["xyz_pad"] = ops.pack_weights_padded(w3, self.dtype, True, 256)
             else:
                 pairs.append((w3, self.wf["xyz_pad"], True, 256))
-        if self._tail_big():      # the tail BACKWARD chain likewise: dh2 (128 features) under the backward-data copy of layer "2" padded in K
+        if self._tail_big() or self._tail_fused() or "l2h_pad" in self.wb:      # the tail BACKWARD layers likewise: dh2 (128 features) under the backward-data copy of layer "2" padded in K
             w3 = self.p["l2h.w"].unsqueeze(0)
             if "l2h_pad" not in self.wb:
                 self.wb["l2h_pad"] = ops.pack_weights_padded(w3, self.dtype, False, 0, 256)
@@ -766,8 +766,15 @@ class SwitchNeRF:
         # ... with the combine backward (the sigma head's rank-1 term, the ReLU mask of y, the gate gradient, the gate scaling) applied
         # in the write-out of the last layer: dy itself never reaches memory
         dh1 = _b("dh1", (P, M), dt)
-        dout = _b("dy", (P, M), dt)
-        if M * dout.element_size() <= 1024:      # (a row's 16-byte chunks must fit one wavefront: everything but fp32 rows of 512)
+        # the tail's two backward layers and the combine backward in FRONT of the expert backward chain, one launch (chain_big.hip, tag 8):
+        # pairs with the fused forward (its list of dropped tokens); SWN_FUSED_TAIL_BWD=0 keeps the two launches
+        fused_bwd = bool(c.get("tail_fused")) and self.ep is None and os.environ.get("SWN_FUSED_TAIL_BWD", "1") != "0"
+        dout = None if fused_bwd else _b("dy", (P, M), dt)
+        if fused_bwd:
+            dgmax = _b("dgmax", (P,), torch.float32)
+            if "l2h_pad" not in self.wb:
+                self.wb["l2h_pad"] = o.pack_weights_padded(self.p["l2h.w"].unsqueeze(0), dt, False, 0, 256)
+        elif M * dout.element_size() <= 1024:      # (a row's 16-byte chunks must fit one wavefront: everything but fp32 rows of 512)
             dgmax = _b("dgmax", (P,), torch.float32)
             tg = int(os.environ.get("SWN_TAIL_GEOM", "1")) if self._tail_big() else 0
             o.mlp_chain(dh2, [o.Layer(self.wb["l2h_pad" if tg >= 6 else "l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dout, tag=5,
@@ -793,7 +800,7 @@ class SwitchNeRF:
         # step at 1024 rays); at the full batch two launches are faster (15.15 against 15.30 ms: the tail operands are the most recently
         # written tensors when their launch follows the tail backward directly).  Measured on one box, scripts/ab_env.sh.
         tail_jobs = [(c["h1"], dh2, g["l2h.w"].view(1, M, H2), None), (c["y"], dh1, g["l1.w"].view(1, M, M), g["l1.b"].view(1, M))]
-        if P > (1 << 19):
+        if P > (1 << 19) and not fused_bwd:      # (fused backward: dh1 comes out of the expert launch - the tail's weight gradients follow it)
             self._dense_wgrads(tail_jobs, nsp)
             tail_jobs = []
         # expert backward chain
@@ -807,7 +814,24 @@ class SwitchNeRF:
                               mask=c["masks"][l - 1] if l > 0 else None, save=dz[l - 1] if l > 0 else None))
         n_loc = E if ep is None else ep.El
         grp_rows = c["counts_flat"] if ep is None else c["ep_counts"]
-        if ep is None:
+        if ep is None and fused_bwd:
+            perm = c["perm"].view(-1)
+            x_first, dz_last = c["h0"], _b("dz_last", (rows, M), dt)      # the last expert layer's dZ in the row space (the combine's output)
+
+            def run_expert_bwd():
+                o.mlp_chain(dh2, [o.Layer(self.wb["l2h_pad"], None, save=dh1), o.Layer(self.wb["l1"], None, save=dz_last)] + bl, dx, n_groups=ng,
+                            n_wsets=n_loc, group_stride=cap, group_rows=grp_rows, group_rows_clamp=cap, x_gather=perm,
+                            y_add=dz[skip_l] if skip_l is not None else None, tag=8, geometry=7, x_features=H2,
+                            combine=(c["y"], dsig, self.p["sigma.w"], c["gmax"], dgmax), head=(2, c["drop_begin"], c["dropped"]),
+                            group_begin=c.get("group_begin"))
+            with self._timed("expert_bwd"):
+                run_expert_bwd()
+            if self.profile and "_relaunch" in c:
+                c["_relaunch"]["expert_bwd"] = run_expert_bwd
+            if P > (1 << 19):
+                self._dense_wgrads(tail_jobs, nsp)
+                tail_jobs = []
+        elif ep is None:
             perm = c["perm"].view(-1)
             x_first, dz_last = c["h0"], dout            # read through the routing permutation
             def run_expert_bwd():
@@ -849,7 +873,7 @@ class SwitchNeRF:
                 a = x_first if l == 0 else c["saves"][l - 1]
                 bz = dz_last if l == L - 1 else dz[l]
                 items.append((a, bz, self._local_experts(g[f"exp{l}.w"]), self._local_experts(g[f"exp{l}.b"]),
-                              perm if l == 0 else None, perm if l == L - 1 else None))
+                              perm if l == 0 else None, perm if (l == L - 1 and not fused_bwd) else None))
             if ep is not None:      # received rows are packed: groups through their first rows (any width: wgrad_multi cuts 512-feature
                 o.wgrad_multi(items, n_groups=ng, n_wsets=n_loc, group_stride=cap, group_rows=grp_rows, group_rows_clamp=cap, tag=1,
                               group_begin=c["ep_begin"])      # operands into 256-column GEMMs of the same launch)

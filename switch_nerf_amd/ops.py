@@ -522,7 +522,7 @@ def chain_mask_words(dtype, n_groups: int, group_stride: int, max_width: int = 2
 
 def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride=None, group_rows=None,
               group_rows_clamp=None, x_gather=None, x_save=None, y_add=None, y_add_gather=None, tag=0, x_scale=None,
-              x_relu=False, geometry=0, group_begin=None, combine=None, heads=None, sched=None, x_features=0, tail=None):
+              x_relu=False, geometry=0, group_begin=None, combine=None, heads=None, sched=None, x_features=0, tail=None, head=None):
     """geometry: 0 / 1 the 64-row tile kernels, 2 - 5 the chain_big.hip geometries (include/swn.h).  group_begin: first row of every
     group (packed / no-batch layout) instead of g * group_stride.  combine = (y_fwd, dsig, wsig, gate, dgate_out): the combine backward
     (ops.combine_bwd) fused into the write-out of the last layer.  heads = (w_sigma, b_sigma, w_color, b_color, sigma_noise or None, raw):
@@ -530,7 +530,9 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
     sched: int32 [16] zero-initialised tile-queue counters of the persistent geometries 6 / 7 (chain_sched(); left zero by the kernel).
     tail = (tail_first, gate [P] f32, drop_begin, dropped, y_features): the dense tail folded into the expert forward chain (include/swn.h,
     tail_first: geometry 7, tag 7) - layers[tail_first:] are shared layers, the saves from layer tail_first - 1 on, y and the heads'
-    raw are in token order (P rows), x_gather maps rows to tokens."""
+    raw are in token order (P rows), x_gather maps rows to tokens.
+    head = (head_layers, drop_begin, dropped): the mirror image for the backward pass (include/swn.h, head_layers: geometry 7, tag 8) -
+    x = dh2 in token order, layers[:head_layers] shared, `combine` (token order) applied behind them, the expert backward layers after."""
     d = ChainDesc()
     d.dtype = _dt(x)
     d.tag = int(tag)
@@ -544,6 +546,12 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
         d.tail_first, d.y_features, d.tail_gate, d.tail_dropped = int(t_first), int(t_yf), _p(t_gate), _p(t_dropped)
         d.tail_n_dropped = t_begin.data_ptr() + 4 * (t_begin.numel() - 1)
         d.tail_dropped_max, d.tail_tokens = int(t_dropped.numel()), int(t_gate.numel())
+    if head is not None:
+        h_layers, h_begin, h_dropped = head
+        assert h_begin.dtype == torch.int32 and h_dropped.dtype == torch.int32 and x_gather is not None and combine is not None
+        d.head_layers, d.tail_dropped = int(h_layers), _p(h_dropped)
+        d.tail_n_dropped = h_begin.data_ptr() + 4 * (h_begin.numel() - 1)
+        d.tail_dropped_max, d.tail_tokens = int(h_dropped.numel()), int(x.shape[0])
     d.group_rows = _p(group_rows)
     d.group_rows_clamp = int(group_rows_clamp if group_rows_clamp is not None else d.group_stride)
     d.group_begin = _p(group_begin)
@@ -558,7 +566,7 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
         d.sched = _p(sched)
     if combine is not None:
         cy, cds, cws, cg, cdg = combine
-        assert cy.dtype == x.dtype and cy.shape == y.shape and cg.dtype == torch.float32 and cdg.dtype == torch.float32
+        assert cy.dtype == x.dtype and (cy.shape == y.shape or head is not None) and cg.dtype == torch.float32 and cdg.dtype == torch.float32
         d.comb_y, d.comb_dsig, d.comb_wsig, d.comb_gate, d.comb_dgate = _p(cy), _p(cds), _p(cws), _p(cg), _p(cdg)
     if heads is not None:
         hws, hbs, hwc, hbc, hnoise, hraw = heads
