@@ -8,8 +8,10 @@ M, E, L, CAP, NSEG = 256, 8, 7, 16384, 16
 NG = NSEG * E
 ROWS = NG * CAP
 torch.manual_seed(0)
-acts = [torch.randn(ROWS, M, device=dev).to(dt) for _ in range(L)]
-dzs = [torch.randn(ROWS, M, device=dev).to(dt) for _ in range(L)]
+import os
+_mk = (lambda: torch.zeros(ROWS, M, device=dev, dtype=dt)) if os.environ.get("ZERO") else (lambda: torch.randn(ROWS, M, device=dev).to(dt))
+acts = [_mk() for _ in range(L)]      # ZERO=1: all-zero operands (what the matrix pipe's POWER costs: zeros toggle nothing)
+dzs = [_mk() for _ in range(L)]
 perm = torch.randperm(ROWS, device=dev).int()
 import os
 if os.environ.get("PERM") == "identity":        # gather order experiments: the two gathered operands read in row order ...

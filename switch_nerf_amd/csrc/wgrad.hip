@@ -576,55 +576,92 @@ __global__ __launch_bounds__(WG_NT) void wgrad_stream_kernel(const WsArgs p) {
         issue((slot + WG_NS - 1) % WG_NS);
         const char* A = sa(slot);
         const char* B = sb(slot);
+#ifdef SWN_WG_ABL_STREAM      // (experiment: the staging pipeline alone - no LDS reads, no MFMAs; profiles/r04_experiments.md)
+        if (false) {
+#else
         if (active || do_bias) {
+#endif
           if constexpr (sizeof(T) == 2) {
+            // One slab = two K steps of 16 rows.  The 32 LDS reads of BOTH steps go out first (one round trip per slab), an operand
+            // fragment (8 consecutive rows of one column) is put together from the row-major dwords with one v_perm_b32 per dword, and
+            // the permutes of step 1 sit BETWEEN the matrix instructions of step 0: the workgroup's eight waves leave the slab's barrier
+            // together, and with reads -> permutes -> MFMAs in sequence per step they all read, then all permute, then all multiply
+            // (LDS, VALU and the matrix pipe busy one after the other: 4.9 TB/s against the 6.2 the staging pipeline alone sustains,
+            // profiles/r04_experiments.md).  Same products in the same order per accumulator: results unchanged bit for bit.
+            static_assert(BKR == 32, "two K steps per slab");
+            uint2 pa_[2][8];
+            uint32_t pb_[2][8];
 #pragma unroll
-            for (int kk = 0; kk < BKR / 16; ++kk) {
-              const int rb0 = kk * 16 + lhi * 8;
-              uint2 pa_[8];
-              uint32_t pb_[8];
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
               for (int q = 0; q < 8; ++q) {
-                pa_[q] = *(const uint2*)(A + (rb0 + q) * RS + (wm * 128 + 4 * l31) * 2);
-                pb_[q] = *(const uint32_t*)(B + (rb0 + q) * RS + (wn * 64 + 2 * l31) * 2);
+                pa_[kk][q] = *(const uint2*)(A + (kk * 16 + lhi * 8 + q) * RS + (wm * 128 + 4 * l31) * 2);
+                pb_[kk][q] = *(const uint32_t*)(B + (kk * 16 + lhi * 8 + q) * RS + (wn * 64 + 2 * l31) * 2);
               }
-              bf16x8_t fa[4], fb[2];
-              {
-                uint32_t lo[4], hi[4];
+            // dword t of a fragment = (row 2 t, row 2 t + 1) of one column: low halves 0x05040100, high halves 0x07060302
+            auto plo = [](uint32_t r0, uint32_t r1) -> uint32_t { return __builtin_amdgcn_perm(r1, r0, 0x05040100u); };
+            auto phi = [](uint32_t r0, uint32_t r1) -> uint32_t { return __builtin_amdgcn_perm(r1, r0, 0x07060302u); };
+            bf16x8_t fa[2][4], fb[2][2];
+            auto frag_a = [&](int kk, int q) {      // column 4 l31 + q of the A slab
+              const bool y = q >= 2, h = q & 1;
+              uint32_t d[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                  lo[t] = (pa_[2 * t].x & 0xFFFFu) | (pa_[2 * t + 1].x << 16);
-                  hi[t] = (pa_[2 * t].x >> 16) | (pa_[2 * t + 1].x & 0xFFFF0000u);
-                }
-                fa[0] = as_frag(lo[0], lo[1], lo[2], lo[3]);
-                fa[1] = as_frag(hi[0], hi[1], hi[2], hi[3]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                  lo[t] = (pa_[2 * t].y & 0xFFFFu) | (pa_[2 * t + 1].y << 16);
-                  hi[t] = (pa_[2 * t].y >> 16) | (pa_[2 * t + 1].y & 0xFFFF0000u);
-                }
-                fa[2] = as_frag(lo[0], lo[1], lo[2], lo[3]);
-                fa[3] = as_frag(hi[0], hi[1], hi[2], hi[3]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                  lo[t] = (pb_[2 * t] & 0xFFFFu) | (pb_[2 * t + 1] << 16);
-                  hi[t] = (pb_[2 * t] >> 16) | (pb_[2 * t + 1] & 0xFFFF0000u);
-                }
-                fb[0] = as_frag(lo[0], lo[1], lo[2], lo[3]);
-                fb[1] = as_frag(hi[0], hi[1], hi[2], hi[3]);
+              for (int t = 0; t < 4; ++t) {
+                const uint32_t r0 = y ? pa_[kk][2 * t].y : pa_[kk][2 * t].x, r1 = y ? pa_[kk][2 * t + 1].y : pa_[kk][2 * t + 1].x;
+                d[t] = h ? phi(r0, r1) : plo(r0, r1);
               }
-              if (active) {
+              fa[kk][q] = as_frag(d[0], d[1], d[2], d[3]);
+            };
+            auto frag_b = [&](int kk, int qq) {     // column 2 l31 + qq of the B slab
+              uint32_t d[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+              for (int t = 0; t < 4; ++t) d[t] = qq ? phi(pb_[kk][2 * t], pb_[kk][2 * t + 1]) : plo(pb_[kk][2 * t], pb_[kk][2 * t + 1]);
+              fb[kk][qq] = as_frag(d[0], d[1], d[2], d[3]);
+            };
 #pragma unroll
-                  for (int qq = 0; qq < 2; ++qq)
-                    acc[q][qq] = SWN_MFMA_32x32x16(fa[q], fb[qq], acc[q][qq]);
+            for (int q = 0; q < 4; ++q) frag_a(0, q);
+            frag_b(0, 0);
+            frag_b(0, 1);
+            const bf16x8_t ones = as_frag(SWN_HALF_ONE_X2, SWN_HALF_ONE_X2, SWN_HALF_ONE_X2, SWN_HALF_ONE_X2);
+            __builtin_amdgcn_sched_barrier(0);
+#if defined(SWN_WG_ABL) && SWN_WG_ABL == 2      // (experiment: staging + the LDS reads, nothing else)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+              for (int q = 0; q < 8; ++q) asm volatile("" :: "v"(pa_[kk][q]), "v"(pb_[kk][q]));
+            if (false) {
+#elif defined(SWN_WG_ABL) && SWN_WG_ABL == 3    // (experiment: ... + the fragment permutes, no matrix instructions)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { frag_a(1, q); asm volatile("" :: "v"(fa[0][q]), "v"(fa[1][q])); }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { frag_b(1, q); asm volatile("" :: "v"(fb[0][q]), "v"(fb[1][q])); }
+            if (false) {
+#else
+            if (active) {      // (a wave outside the job's widths only takes part in the staging; do_bias implies active)
+#endif
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                  acc[q][qq] = SWN_MFMA_32x32x16(fa[0][q], fb[0][qq], acc[q][qq]);
+                  __builtin_amdgcn_sched_barrier(0);
+                  const int j = 2 * q + qq;      // six fragments of step 1 behind the first six matrix instructions of step 0
+                  if (j < 4) { frag_a(1, j); asm volatile("" : "+v"(fa[1][j])); }      // (HERE: pure code is otherwise sunk to its use)
+                  else if (j < 6) { frag_b(1, j - 4); asm volatile("" : "+v"(fb[1][j - 4])); }
+                  __builtin_amdgcn_sched_barrier(0);
+                }
               }
               if (do_bias) {
-                const bf16x8_t ones = as_frag(SWN_HALF_ONE_X2, SWN_HALF_ONE_X2, SWN_HALF_ONE_X2, SWN_HALF_ONE_X2);
 #pragma unroll
-                for (int qq = 0; qq < 2; ++qq)
-                  accb[qq] = SWN_MFMA_32x32x16(ones, fb[qq], accb[qq]);
+                for (int qq = 0; qq < 2; ++qq) accb[qq] = SWN_MFMA_32x32x16(ones, fb[0][qq], accb[qq]);
+              }
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) acc[q][qq] = SWN_MFMA_32x32x16(fa[1][q], fb[1][qq], acc[q][qq]);
+              if (do_bias) {
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) accb[qq] = SWN_MFMA_32x32x16(ones, fb[1][qq], accb[qq]);
               }
             }
           } else {
