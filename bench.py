@@ -295,7 +295,7 @@ def main():
         c_ = st_["ctx"]["c"] if a.bg else st_["ctx"]
         hooks = c_.get("_relaunch", {})
         out_ = {}
-        for name in ("expert_fwd", "expert_bwd", "expert_wgrad", "expert_fwd_nosave"):
+        for name in ("expert_fwd", "expert_bwd", "expert_wgrad", "expert_fwd_nosave", "expert_gemm_nosave"):
             fn = hooks.get(name)
             if fn is None:
                 continue
@@ -429,7 +429,7 @@ def main():
         detail_ = {}
         flops_e = 2.0 * L * M * M * kept_
         alg = {"expert_fwd": kept_ * M * esz * (1 + (L - 1) + 1), "expert_bwd": kept_ * M * esz * (1 + (L - 1) + 1 + 1),
-               "expert_wgrad": kept_ * M * esz * 2 * L, "expert_fwd_nosave": kept_ * M * esz * 2}
+               "expert_wgrad": kept_ * M * esz * 2 * L, "expert_fwd_nosave": kept_ * M * esz * 2, "expert_gemm_nosave": kept_ * M * esz * 2}
         fl = {k: flops_e for k in alg}
         if fused_tail[0]:
             # the forward launch also runs the dense tail on EVERY point (kept or not): Linear "1" (M x M) and Linear "2" (M x H2); it
@@ -446,7 +446,7 @@ def main():
             # (H2) and y (M) per point and the skip layer's dZ, writes dh1 (M) per point, L dZ (the last expert layer's included) + dx per kept row
             fl["expert_bwd"] += 2.0 * (M * M + M * model.H2) * P
             alg["expert_bwd"] = kept_ * M * esz * (L + 1 + 1) + P * (model.H2 * esz + 2 * M * esz + 12)
-        for name in ("expert_fwd", "expert_bwd", "expert_wgrad", "expert_fwd_nosave"):
+        for name in ("expert_fwd", "expert_bwd", "expert_wgrad", "expert_fwd_nosave", "expert_gemm_nosave"):
             ms_ = events.get(name)
             if not ms_ or ms_ <= 0:
                 continue
@@ -497,7 +497,9 @@ def main():
                         hbm_frac_measured=d.get("hbm_frac_measured"))
         roof["attainable"] = dict(tflops=round(attainable, 1), frac_of_attainable=round(d["tflops"] / attainable, 4),
                                   what="min(MFMA peak, flop_per_byte x HBM peak) for this launch's algorithmic flops and bytes")
-        if "expert_fwd_nosave" in detail:      # north_star: the grouped GEMM against the MFMA peak = the chain without the training saves
+        if "expert_gemm_nosave" in detail:     # north_star: the grouped GEMM against the MFMA peak = the expert layers alone, without saves
+            roof["grouped_gemm_mfma_frac_nosave"] = detail["expert_gemm_nosave"]["mfma_frac"]
+        elif "expert_fwd_nosave" in detail:
             roof["grouped_gemm_mfma_frac_nosave"] = detail["expert_fwd_nosave"]["mfma_frac"]
     if detail and world == 1 and a.dtype == "bf16":
         try:

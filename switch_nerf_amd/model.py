@@ -611,8 +611,12 @@ class SwitchNeRF:
                             tail=(L, c["gmax"], c["drop_begin"], c["dropped"], H2))
             with self._timed("expert_fwd"):
                 run_experts()
-            if self.profile:
-                c["_relaunch"] = {"expert_fwd": run_experts, "expert_fwd_nosave": lambda: run_experts(False)}
+            if self.profile:      # bench.py: the launch again on this step's live buffers, its save-free form, and the expert layers ALONE
+                def expert_gemm():    # (the grouped GEMM without the tail: tag 1, into a scratch output - what round 1-3's figure measured)
+                    o.mlp_chain(c["h0"], [o.Layer(ly.w, ly.b, relu=ly.relu, skip=ly.skip) for ly in layers], _b("eo_probe", (rows, M), dt),
+                                n_groups=ng, n_wsets=E, group_stride=cap, group_rows=c["counts_flat"], group_rows_clamp=cap,
+                                x_gather=c["perm"].view(-1), tag=1, geometry=7, group_begin=group_begin)
+                c["_relaunch"] = {"expert_fwd": run_experts, "expert_fwd_nosave": lambda: run_experts(False), "expert_gemm_nosave": expert_gemm}
             return c
         elif self.ep is None:
             c["row_of_tok"] = c["tok2row"]
