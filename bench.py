@@ -455,11 +455,14 @@ def main():
             gbs = alg[name] / (ms_ * 1e-3) / 1e9
             d_ = dict(ms=round(ms_, 4), tflops=round(tf, 1), mfma_frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4), alg_bytes=int(alg[name]),
                       alg_flops=float(flops), alg_gbs=round(gbs, 1), hbm_frac_alg=round(gbs / HBM_PEAK_GBS, 4))
-            per_row = traffic_tab.get(name + "_bytes_per_kept_row")
-            if fused_tail[0] and name.startswith("expert_fwd"):      # (measured on the launch that carries the tail: its own key)
-                per_row = traffic_tab.get(name + "_tail_bytes_per_kept_row")
+            per_row, per_pt = traffic_tab.get(name + "_bytes_per_kept_row"), 0.0
+            if (fused_tail[0] and name == "expert_fwd") or (fused_tail[1] and name == "expert_bwd"):      # (the launches that carry the tail:
+                per_row = traffic_tab.get(name + "_tail_bytes_per_kept_row")                             #  measured on their own)
+                per_pt = traffic_tab.get(name + "_tail_bytes_per_point", 0.0)
+            elif fused_tail[0] and name == "expert_fwd_nosave":
+                per_row = None
             if per_row:
-                tb = per_row * kept_
+                tb = per_row * kept_ + per_pt * P
                 d_.update(hbm_measured_bytes=int(tb), hbm_measured_gbs=round(tb / (ms_ * 1e-3) / 1e9, 1),
                           hbm_frac_measured=round(tb / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
             detail_[name] = d_
