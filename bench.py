@@ -19,13 +19,16 @@ Reproducibility: the device RNG is seeded, and after the warm-up steps the param
 timed steps are the same computation (same routing, same kept-token fraction) whatever the warm-up count.
 
 Prints ONE JSON line (rank 0).  `roofline` describes the DOMINANT expert kernel (the slowest of the three expert launches of a training
-step: the weight-gradient launch) on the roofline its arithmetic intensity puts it under - `bound` "hbm" when its flop per algorithmic
-byte are below the ridge MFMA peak / HBM peak = 312 flop/B (the weight gradients read every operand once: 128 flop/B), else "mfma";
+step - forward + dense tail + heads, tail backward + combine backward + expert backward-data, weight gradients: within 15 % of each
+other; `roofline.kernel` names it) on the roofline its arithmetic intensity puts it under - `bound` "hbm" when its flop per algorithmic
+byte are below the ridge MFMA peak / HBM peak = 312 flop/B (the training chains save every activation: ~250 flop/B; the weight gradients
+read every operand once: 128 flop/B), else "mfma";
 `achieved` / `peak` / `frac` are on that scale, `attainable` = min(MFMA peak, flop_per_byte x HBM peak) in TFLOP/s and `mfma_frac` put the
 same launch on the matrix-pipe scale, `traffic` = HBM bytes per launch from the PMC counters (profiles/traffic.json).  Timed live:
 every expert kernel is relaunched back to back on one step's live buffers between two HIP events on the launch stream.  `kernels`
-carries the MFMA fraction, the algorithmic HBM rate and the counter-measured HBM bytes of all three expert kernels plus the save-free
-forward chain (the grouped GEMM alone); `balanced` repeats the measurement with perfectly balanced routing (point i -> expert i mod E:
+carries the MFMA fraction, the algorithmic HBM rate and the counter-measured HBM bytes of all three expert launches plus the save-free
+forward launch (`expert_fwd_nosave`: what an inference forward runs) and the seven expert layers alone (`expert_gemm_nosave`: the grouped
+GEMM of north_star, also `roofline.grouped_gemm_mfma_frac_nosave`); `balanced` repeats the measurement with perfectly balanced routing (point i -> expert i mod E:
 every group full, 100 % of the tokens kept; its rays/s is also in `config.balanced_value`); `cpu_baseline` is the CPU oracle (a port of
 the reference's CPU path) timed on this box's host cores on a bounded sample (one 131072-point segment): `cores` = the cores this
 process may run on (os.sched_getaffinity), `threads` = torch's intra-op threads (what the oracle actually used).
