@@ -1089,6 +1089,10 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   {   // 256-row geometry (chain_big.hip).  Never chosen silently for bf16: the ReLU mask layout differs between the geometries,
       // and a backward chain must run on the geometry of the forward chain that recorded its masks - the caller pairs them.
     const bool can = d.geometry >= 6 ? chain_persistent_eligible(d) : chain_big_eligible(d);
+    if (d.tail_first > 0 || d.head_layers > 0)
+      SWN_CHECK(can, "swn_mlp_chain: a fused tail (tail_first / head_layers) needs bf16 / fp16 layers of 256 x 256 (the last tail layer zero-padded "
+                "from y_features = 128; x_features = 128 under the head layers), x_gather, the gate values / combine operands, the dropped-token "
+                "list, tail_tokens * 512 bytes below 4 GiB, no ReLU on the gate layer and ReLU on the last tail layer (include/swn.h)");
     SWN_CHECK(d.geometry < 2 || can, "swn_mlp_chain: geometries 2 - 7 need bf16 / fp16 chains of 256 x 256 layers without rowbias / x_scale / x_save / y_add_gather");
     if (d.geometry >= 2) return chain_big_launch(d, stream);
   }

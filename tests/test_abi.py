@@ -107,3 +107,47 @@ def test_round3_entry_points_validate_before_launch():
     d.tag, d.dtype = 4, _lib.F32
     d.layers[0].n = d.layers[0].k = d.layers[1].k = 512
     assert lib.swn_mlp_chain(C.byref(d), None) != 0 and "1 KiB" in err()
+
+
+def test_fused_tail_descriptors_validate_before_launch():
+    """swn_chain_desc.tail_first / head_layers (round 4: the dense tail inside the expert launches) are tied to geometry 7 and their own
+    tags, and a descriptor that the persistent kernel cannot run (a relu on the gate layer, a missing drop list, a token count whose
+    rows do not fit 32-bit offsets) is rejected with a message - nothing is launched (no GPU needed)."""
+    import ctypes as C
+    from switch_nerf_amd import _lib
+    lib = _lib.load()
+    p = C.c_void_p(0x1000)
+    err = lambda: lib.swn_last_error().decode()
+
+    def desc(n_layers):
+        d = _lib.ChainDesc()
+        d.dtype, d.n_layers, d.n_groups, d.n_wsets, d.group_stride, d.group_rows_clamp = _lib.BF16, n_layers, 8, 8, 512, 512
+        d.x, d.y, d.x_gather = p, p, p
+        for i in range(n_layers):
+            d.layers[i].w, d.layers[i].n, d.layers[i].k = p, 256, 256
+        return d
+    d = desc(9)
+    d.tail_first, d.geometry, d.tag = 7, 1, 7
+    assert lib.swn_mlp_chain(C.byref(d), None) != 0 and "geometry 7 with tag 7" in err()
+    d.geometry, d.tag = 7, 1
+    assert lib.swn_mlp_chain(C.byref(d), None) != 0 and "geometry 7 with tag 7" in err()
+    d.tag, d.tail_first = 7, 0
+    assert lib.swn_mlp_chain(C.byref(d), None) != 0 and "tag 7 is the fused-tail" in err()
+    d.tail_first = 7                                          # no gate values / drop list / token count yet
+    assert lib.swn_mlp_chain(C.byref(d), None) != 0 and "a fused tail" in err()
+    d.tail_gate = d.tail_dropped = d.tail_n_dropped = p
+    d.tail_tokens, d.tail_dropped_max, d.y_features = 4096, 4096, 128
+    d.layers[8].relu = 1
+    d.layers[6].relu = 1                                      # the gate layer's ReLU comes with the scaling
+    assert lib.swn_mlp_chain(C.byref(d), None) != 0 and "a fused tail" in err()
+    d.layers[6].relu = 0
+    d.tail_tokens = 1 << 23                                   # 2^23 rows of 512 bytes: past the 32-bit store offsets
+    assert lib.swn_mlp_chain(C.byref(d), None) != 0 and "a fused tail" in err()
+    # backward: head layers
+    b = desc(9)
+    b.head_layers, b.geometry, b.tag = 2, 7, 2
+    assert lib.swn_mlp_chain(C.byref(b), None) != 0 and "geometry 7 with tag 8" in err()
+    b.tag, b.head_layers = 8, 0
+    assert lib.swn_mlp_chain(C.byref(b), None) != 0 and "tag 8 is the expert backward" in err()
+    b.head_layers = 2                                         # no combine operands, no 128-feature input
+    assert lib.swn_mlp_chain(C.byref(b), None) != 0 and "a fused tail" in err()
