@@ -588,8 +588,12 @@ __global__ __launch_bounds__(G::NT, G::OCC) void chainb_kernel(const Args args) 
 // fragments are read TWO steps ahead (three register sets): the LDS round trip of a lone wave's reads (~300 clocks with four waves
 // reading at once) no longer fits into one 256-clock step.  `wq` holds the fragments of steps 0..2 on entry (issued by the caller before
 // the phase barrier) - on exit nothing is in flight.
+#ifndef SWN_WQ_DEPTH
+#define SWN_WQ_DEPTH 4            // weight-fragment register sets of a wave's K loop: SWN_WQ_DEPTH - 1 K steps in flight
+#endif
+constexpr int WQD = SWN_WQ_DEPTH, WQA = SWN_WQ_DEPTH - 1;
 template <typename E, int NS = KSTEPS>
-__device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, __amdgpu_buffer_rsrc_t rs_cur, u32x4_t (&wq)[4][2]) {
+__device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, __amdgpu_buffer_rsrc_t rs_cur, u32x4_t (&wq)[WQD][2]) {
   constexpr int MI = 4;           // NS = K steps of this layer (K / 16): 16, or 8 for a 128-feature chain input (geometries 6 / 7)
   char* smem = cx.smem;
   const int lane16 = cx.lane * 16;
@@ -603,7 +607,7 @@ __device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, _
   auto load_w = [&](int ks) {          // the two feature tiles of this wave, K step ks
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      wq[ks & 3][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, lane16, ((2 * fg + i) * NS + ks) * 1024, 0);
+      wq[ks % WQD][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, lane16, ((2 * fg + i) * NS + ks) * 1024, 0);
   };
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) read_a(0, mi);
@@ -612,13 +616,17 @@ __device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, _
 #pragma unroll
   for (int ks = 0; ks < NS; ++ks) {
     // weights of step ks: younger are the loads of steps ks + 1, ks + 2 (an older bias copy / mask load only makes the wait longer)
-    if (ks + 2 < NS) SWN_WAIT_VM(4); else if (ks + 1 < NS) SWN_WAIT_VM(2); else SWN_WAIT_VM(0);
+    {   // weights of step ks have landed: younger are the loads of the next min(WQA - 1, NS - 1 - ks) steps, two each
+      const int younger = (NS - 1 - ks < WQA - 1 ? NS - 1 - ks : WQA - 1) * 2;
+      if (younger >= 8) SWN_WAIT_VM(8); else if (younger == 6) SWN_WAIT_VM(6); else if (younger == 4) SWN_WAIT_VM(4);
+      else if (younger == 2) SWN_WAIT_VM(2); else SWN_WAIT_VM(0);
+    }
     if (ks + 1 < NS) SWN_WAIT_LGKM(4); else SWN_WAIT_LGKM(0);        // fragments of step ks (younger: those of step ks + 1)
     SWN_PIN();
 #ifdef SWN_ABL_NOMFMA
-#define SWN_MM(mi, ni) asm volatile("" :: "v"(wq[ks & 3][ni]), "v"(fa[ks % 3][mi]))
+#define SWN_MM(mi, ni) asm volatile("" :: "v"(wq[ks % WQD][ni]), "v"(fa[ks % 3][mi]))
 #else
-#define SWN_MM(mi, ni) acc[mi][ni] = E::mfma(wq[ks & 3][ni], fa[ks % 3][mi], acc[mi][ni])
+#define SWN_MM(mi, ni) acc[mi][ni] = E::mfma(wq[ks % WQD][ni], fa[ks % 3][mi], acc[mi][ni])
 #endif
     SWN_MM(0, 0);
     SWN_PIN();
@@ -630,7 +638,7 @@ __device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, _
     SWN_PIN();
     SWN_MM(1, 0);
     SWN_PIN();
-    if (ks + 3 < NS) load_w(ks + 3);        // into the register set of step ks - 1, whose MFMAs were issued a step ago
+    if (ks + WQA < NS) load_w(ks + WQA);    // into the register set of step ks - 1, whose MFMAs were issued a step ago
     SWN_PIN();
     SWN_MM(1, 1);
     SWN_PIN();
@@ -838,11 +846,11 @@ __global__ __launch_bounds__(512, 2) void chainp_kernel(const Args args) {
   int* gcount = (int*)(smem + G::BIAS0 + 3072);       // [2]: arrivals of the waves of a row group at the residual layer's meeting point
 
   // ---- prologue: this wave's weight fragments of the first three K steps, source rows, the rows of group 0 ----
-  u32x4_t wq[4][2];
+  u32x4_t wq[WQD][2];
   auto preload_w = [&](int L) {
     const __amdgpu_buffer_rsrc_t r = wrs(L);
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks)
+    for (int ks = 0; ks < WQA; ++ks)
 #pragma unroll
       for (int i = 0; i < 2; ++i) wq[ks][i] = __builtin_amdgcn_raw_buffer_load_b128(r, lane16, ((2 * fg + i) * KSTEPS + ks) * 1024, 0);
   };
@@ -921,7 +929,7 @@ __global__ __launch_bounds__(512, 2) void chainp_kernel(const Args args) {
       SWN_TM(const long long k0 = TICK();)
       k_phase2<E>(acc, cx, rs_cur, wq);
 #pragma unroll
-      for (int q_ = 0; q_ < 4; ++q_)          // the ring's registers are dead from here to the preload at the end of the epilogue phase:
+      for (int q_ = 0; q_ < WQD; ++q_)        // the ring's registers are dead from here to the preload at the end of the epilogue phase:
 #pragma unroll
         for (int i_ = 0; i_ < 2; ++i_) asm volatile("" : "=v"(wq[q_][i_]));      // say so (no code), or they are kept alive through it
       SWN_TM(const long long k1 = TICK();)
@@ -1607,11 +1615,11 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
   auto out_rs = [&](void* base, const Tile& t) -> __amdgpu_buffer_rsrc_t {
     return uniform_rsrc((char*)base + t.grow0 * ROWB, t.rows * ROWB);
   };
-  u32x4_t wq[4][2];
+  u32x4_t wq[WQD][2];
   auto preload_w = [&](int L, int wset, int lane_) {
     const __amdgpu_buffer_rsrc_t r = wrs(L, wset);
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks)
+    for (int ks = 0; ks < WQA; ++ks)
 #pragma unroll
       for (int i = 0; i < 2; ++i) wq[ks][i] = __builtin_amdgcn_raw_buffer_load_b128(r, lane_ * 16, ((2 * fg + i) * (d.layers[L].k >> 4) + ks) * 1024, 0);
   };
@@ -1850,7 +1858,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
           k_phase2<E>(acc, ck, rs_cur, wq);
         }
 #pragma unroll
-        for (int q_ = 0; q_ < 4; ++q_)
+        for (int q_ = 0; q_ < WQD; ++q_)
 #pragma unroll
           for (int i_ = 0; i_ < 2; ++i_) asm volatile("" : "=v"(wq[q_][i_]));
         SWN_TM(const long long k1 = TICK();)
