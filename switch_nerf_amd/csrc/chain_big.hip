@@ -588,6 +588,7 @@ __global__ __launch_bounds__(G::NT, G::OCC) void chainb_kernel(const Args args) 
 // fragments are read TWO steps ahead (three register sets): the LDS round trip of a lone wave's reads (~300 clocks with four waves
 // reading at once) no longer fits into one 256-clock step.  `wq` holds the fragments of steps 0..2 on entry (issued by the caller before
 // the phase barrier) - on exit nothing is in flight.
+// -DSWN_KPRIO=n: s_setprio n for a wave of chainq_kernel in its K phase (measured: no change at 1 or 3, profiles/r04_experiments.md 12)
 #ifndef SWN_WQ_DEPTH
 #define SWN_WQ_DEPTH 4            // weight-fragment register sets of a wave's K loop: SWN_WQ_DEPTH - 1 K steps in flight
 #endif
@@ -1855,7 +1856,13 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         }
         {
           const Ctx ck = phase_ctx(true);
+#ifdef SWN_KPRIO
+          __builtin_amdgcn_s_setprio(SWN_KPRIO);      // the K phase's wave ahead of its SIMD partner (in an E or S phase: VALU, LDS, stores)
+#endif
           k_phase2<E>(acc, ck, rs_cur, wq);
+#ifdef SWN_KPRIO
+          __builtin_amdgcn_s_setprio(0);
+#endif
         }
 #pragma unroll
         for (int q_ = 0; q_ < WQD; ++q_)
