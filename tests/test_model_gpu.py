@@ -753,3 +753,44 @@ def test_nobatch_inference_runs_on_packed_rows(dtype):
     counts = c_pack["counts"].cpu().numpy().reshape(-1)
     assert np.array_equal(begin, np.cumsum(counts) - counts) and counts.sum() == P
     assert torch.equal(raw_pack, c_pad["raw"])
+
+
+@pytest.mark.parametrize("cf,fine,chunk", [(1.0, 0, 2048), (0.5, 0, 4096), (1.25, 64, 2048)])
+def test_fused_tail_step_equals_separate_tail_launches_bf16(cf, fine, chunk, monkeypatch):
+    """The default bf16 step runs the dense tail inside the two expert launches (SwitchNeRF._tail_fused: chain_big.hip tags 7 / 8); with
+    SWN_FUSED_TAIL=0 the tail is its own pair of 64-row launches (the step of the first half of round 4).  Same weights, same batch:
+    identical routing and gate values, the saved y bit-identical, rgb / loss / every gradient equal to the rounding order of layer "1"
+    (the fused launch starts its accumulators at the bias) - with half the tokens dropped (capacity factor 0.5: the dropped-token
+    tiles), with spare capacity (1.25: ragged last tiles) and through the hierarchical step (coarse + fine contexts); the backward alone
+    (SWN_FUSED_TAIL_BWD=0) is bit-identical to the fused forward's own two-launch backward except for the gate gradient's sum order."""
+    N, S = 128, 64
+    rays, img, rgbs = synth.make_rays(141, N)
+    pr = torch.rand(N, S, generator=torch.Generator().manual_seed(7)).cuda()
+    outs = {}
+    for mode in ("fused", "fwd_only", "separate"):
+        if mode == "separate":
+            monkeypatch.setenv("SWN_FUSED_TAIL", "0")
+        elif mode == "fwd_only":
+            monkeypatch.setenv("SWN_FUSED_TAIL_BWD", "0")
+        m = _model(torch.bfloat16, 140, 1.0, capacity_factor=cf)
+        kw = dict(fine_samples=fine, fine_u=torch.rand(N, fine, generator=torch.Generator().manual_seed(8)).cuda()) if fine else {}
+        st = m.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=1.0, perturb_rand=pr, optimizer_step=False, **kw)
+        c = st["ctx"]
+        assert c["geom"] == 7 and c["tail_fused"] == (mode != "separate")
+        outs[mode] = dict(idx=c["idx"].clone(), gmax=c["gmax"].clone(), y=c["y"].clone(), rgb=st["rgb"].clone(), loss=st["loss"].item(),
+                          grad=m.grad.clone(), dropped=int((c["tok2row"] < 0).sum()))
+        monkeypatch.delenv("SWN_FUSED_TAIL", raising=False)
+        monkeypatch.delenv("SWN_FUSED_TAIL_BWD", raising=False)
+    a, b, s_ = outs["fused"], outs["fwd_only"], outs["separate"]
+    assert (a["dropped"] > 0) == (cf < 1.25 or a["dropped"] > 0)
+    if cf == 0.5:
+        assert a["dropped"] >= N * S // 2 - 8 * (N * S // chunk)
+    for o in (b, s_):
+        assert torch.equal(a["idx"], o["idx"]) and torch.equal(a["gmax"], o["gmax"]) and torch.equal(a["y"], o["y"])
+    assert torch.equal(a["rgb"], b["rgb"]) and a["loss"] == b["loss"]          # the same forward launch
+    gscale = a["grad"].abs().max().item()
+    assert (a["grad"] - b["grad"]).abs().max().item() <= 2e-4 * gscale         # (the gate gradient's eight partial sums)
+    d_rgb = (a["rgb"] - s_["rgb"]).abs().max().item()
+    d_g = (a["grad"] - s_["grad"]).abs().max().item() / gscale
+    print(f"fused tail vs separate launches (cf {cf}, fine {fine}, {a['dropped']} dropped): rgb {d_rgb:.2e}, loss {abs(a['loss'] - s_['loss']):.2e}, gradients {d_g:.2e}")
+    assert d_rgb < 3e-3 and abs(a["loss"] - s_["loss"]) < 1e-3 * abs(s_["loss"]) and d_g < 1e-2
