@@ -1639,6 +1639,16 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     return u32x4_t{0u, 0u, 0u, 0u};
   };
   constexpr bool bias_init = BIAS_INIT;
+  f32x4_t bv[2][4];                              // the bias values of this wave's next K phase (BIAS_INIT: the accumulators start there)
+  auto load_bv = [&](int slot) {
+    if constexpr (BIAS_INIT) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          bv[ni][g4] = *(const f32x4_t*)(smem + G::BIAS0 + slot * 1024 + ((fg * 64 + 32 * ni + 8 * g4 + 4 * cx.lhi) << 2));
+    }
+  };
 
   // Workgroups that start together on equal tiles reach their S phases together - every CU bursts its 64 KiB out and 64 KiB in at the
   // same moment and the phase is as long as the whole chip's burst takes through HBM (measured: 7-9 k clocks).  A start offset
@@ -1811,15 +1821,19 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     SWN_PIN();
     preload_w(cur.l0, ws_of(cur.l0, cur), cx.lane);
     SWN_PIN();
-    SWN_WAIT_LGKM0();
-    SWN_TM(const long long s1 = TICK();)
-    __builtin_amdgcn_s_barrier();
-    SWN_TM(const long long s2 = TICK(); tS += s1 - s0; tSb += s2 - s1;)
+    SWN_TM(const long long s1 = TICK(); tS += s1 - s0;)
     Tile nxt = cur;
     const int l_end = HEAD ? cur.l1 : n_layers;
     for (int L = cur.l0; L < l_end; ++L) {
       const swn_chain_layer& ly = d.layers[L];
       const bool last = L + 1 == l_end;
+      // The phase boundary in front of every K phase (behind the S phase or the preceding E phase) sits HERE, with the bias values of
+      // the K phase read right before it: one program point for them (read at the top of the K phase their LDS round trip was on its
+      // critical path; read in the two preceding phases they were carried around the loop's back edge through scratch)
+      load_bv(bc % 3);                             // (first tile: a wave reads the quarter of the slot its own copy has just filled)
+      SWN_PIN();
+      SWN_WAIT_LGKM0();
+      __builtin_amdgcn_s_barrier();
       u32x4_t mk = mk_next;
       if (last) nxt = read_tile((it + 1) & 1);   // (written by wave 0 during row group 0's S phase of this tile, barriers ago)
       // ---- K phase ----
@@ -1833,13 +1847,8 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         }
         if constexpr (bias_init) {
           // accumulators start at the bias (zeros for a layer without one: stage_bias).  Written as plain copies of two 16-register
-          // tuples: the compiler feeds the tuples to the first K step's MFMAs as their C operand - no copy is executed
-          f32x4_t bv[2][4];
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-              bv[ni][g4] = *(const f32x4_t*)(smem + G::BIAS0 + (bc % 3) * 1024 + ((fg * 64 + 32 * ni + 8 * g4 + 4 * cx.lhi) << 2));
+          // tuples: the compiler feeds the tuples to the first K step's MFMAs as their C operand - no copy is executed.  The values were
+          // read at the end of the preceding phase (load_bv: their LDS round trip is not on this phase's critical path)
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -1975,9 +1984,11 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
           if (lt < 128) ((int*)(smem + ((it & 1) ? Q_YIDX + 1024 : Q_YIDX)))[128 * rg + lt] = yrow;
         }
         SWN_PIN();
-        SWN_WAIT_LGKM0();
         SWN_TM(const long long e1 = TICK();)
-        __builtin_amdgcn_s_barrier();
+        if (last) {                                // (behind the other layers the boundary is the one at the top of the next layer)
+          SWN_WAIT_LGKM0();
+          __builtin_amdgcn_s_barrier();
+        }
         SWN_TM(const long long e2 = TICK(); tE += e1 - e0; tEb += e2 - e1;)
       }
       ++bc;
