@@ -230,11 +230,15 @@ template <typename T, int COLS> struct Row16 {
 };
 
 // ------------------------------------------------------------------------------------------------ gate
-template <typename T, int G, int EMAX>
+template <typename T, int G, int EMAX, int TB = 1>
 __global__ __launch_bounds__(256) void gate_fwd_kernel(const T* __restrict__ g, const float* __restrict__ ln_w,
                                                        const float* __restrict__ ln_b, const float* __restrict__ wg,
                                                        int P, int E, float* __restrict__ gates, int32_t* __restrict__ idx,
                                                        float* __restrict__ gmax, float* __restrict__ stats) {
+  // TB tokens per 16-lane group and pass (consecutive rows): every router weight read from LDS serves TB rows; the arithmetic of a row
+  // is unchanged, value for value (TB = 1, the default everywhere: the kernel of rounds 1-3).  What made the 512-feature x 16-expert
+  // instantiation slow (2.0 ms per 852 k rows, a tenth of the rate its row reads allow) was not the LDS traffic but the scheduler
+  // hoisting all 128 weight reads of the unrolled expert loop: 512 registers + 168 spilled - see the sched_barrier below (0.74 ms).
   using R = Row16<T, G>;
   constexpr int VPL = R::VPL;
   constexpr int LS = VPL + 4;       // lane segment stride (floats): +16 B keeps the 16 lanes of a b128 read on distinct banks
@@ -247,63 +251,82 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const T* __restrict__ g, 
   float w[VPL], b[VPL];
   if (ln_w) { R::loadf(ln_w, j, w); R::loadf(ln_b, j, b); }
   __syncthreads();
-  const long gid = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
-  const long ngr = ((long)gridDim.x * 256) >> 4;
-  uint4 nxt[R::NCH];
-  if (gid < P) R::load_raw(g + gid * G, j, nxt);
-  for (long tok = gid; tok < P; tok += ngr) {
-    float x[VPL];
-    R::unpack(nxt, x);
-    if (tok + ngr < P) R::load_raw(g + (tok + ngr) * G, j, nxt);     // next row in flight during this row's arithmetic
-    float mean = 0.f, rstd = 1.f;
-    if (ln_w) {  // torch.nn.LayerNorm, eps 1e-5 (models/nerf_moe.py:301-302)
-      float s = 0.f;
+  const long gid = (((long)blockIdx.x * 256 + threadIdx.x) >> 4) * TB;
+  const long ngr = (((long)gridDim.x * 256) >> 4) * TB;
+  uint4 nxt[TB][R::NCH];
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) s += x[v];
-      mean = sum16(s) * (1.f / G);
-      float q = 0.f;
+  for (int t = 0; t < TB; ++t)
+    if (gid + t < P) R::load_raw(g + (gid + t) * G, j, nxt[t]);
+  for (long tok0 = gid; tok0 < P; tok0 += ngr) {
+    float x[TB][VPL];
+    float mean[TB], rstd[TB];
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) q += (x[v] - mean) * (x[v] - mean);
-      rstd = 1.f / sqrtf(sum16(q) * (1.f / G) + 1e-5f);
+    for (int t = 0; t < TB; ++t) {
+      R::unpack(nxt[t], x[t]);
+      if (tok0 + ngr + t < P) R::load_raw(g + (tok0 + ngr + t) * G, j, nxt[t]);     // next rows in flight during these rows' arithmetic
+      mean[t] = 0.f; rstd[t] = 1.f;
+      if (ln_w) {  // torch.nn.LayerNorm, eps 1e-5 (models/nerf_moe.py:301-302)
+        float s = 0.f;
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) x[v] = (x[v] - mean) * rstd * w[v] + b[v];
+        for (int v = 0; v < VPL; ++v) s += x[t][v];
+        mean[t] = sum16(s) * (1.f / G);
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) q += (x[t][v] - mean[t]) * (x[t][v] - mean[t]);
+        rstd[t] = 1.f / sqrtf(sum16(q) * (1.f / G) + 1e-5f);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) x[t][v] = (x[t][v] - mean[t]) * rstd[t] * w[v] + b[v];
+      }
     }
-    float logit[EMAX];
+    float logit[TB][EMAX];
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) {
-      float d = 0.f;
+      float d[TB];
+#pragma unroll
+      for (int t = 0; t < TB; ++t) d[t] = 0.f;
       const float4* wp = (const float4*)(swg + (e * 16 + j) * LS);
 #pragma unroll
       for (int v4 = 0; v4 < VPL / 4; ++v4) {
         const float4 ww = wp[v4];
-        d += x[4 * v4] * ww.x + x[4 * v4 + 1] * ww.y + x[4 * v4 + 2] * ww.z + x[4 * v4 + 3] * ww.w;
+#pragma unroll
+        for (int t = 0; t < TB; ++t)
+          d[t] += x[t][4 * v4] * ww.x + x[t][4 * v4 + 1] * ww.y + x[t][4 * v4 + 2] * ww.z + x[t][4 * v4 + 3] * ww.w;
       }
-      logit[e] = sum16(d);
-    }
-    float mx = logit[0];
 #pragma unroll
-    for (int e = 1; e < EMAX; ++e)
-      if (e < E) mx = fmaxf(mx, logit[e]);
-    float den = 0.f, pr[EMAX];
-#pragma unroll
-    for (int e = 0; e < EMAX; ++e) {
-      pr[e] = (e < E) ? expf(logit[e] - mx) : 0.f;
-      den += pr[e];
-    }
-    int best = 0;
-    float bv = -1.f;
-#pragma unroll
-    for (int e = 0; e < EMAX; ++e) {
-      pr[e] = pr[e] / den;
-      if (e < E && pr[e] > bv) { bv = pr[e]; best = e; }  // first maximum
+      for (int t = 0; t < TB; ++t) logit[t][e] = sum16(d[t]);
+      // (wide rows: one expert's weights at a time - left alone the scheduler hoists the LDS reads of all 16 experts to the top of the
+      //  unrolled loop: 512 registers and 170-480 spilled ones at 512 features)
+      if constexpr (G >= 512) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int e = 0; e < EMAX; ++e)
-      if (j == (e & 15) && e < E) gates[tok * E + e] = pr[e];
-    if (j == 0) {
-      idx[tok] = best;
-      gmax[tok] = bv;
-      if (stats) { stats[tok * 2] = mean; stats[tok * 2 + 1] = rstd; }
+    for (int t = 0; t < TB; ++t) {
+      const long tok = tok0 + t;
+      if (tok >= P) break;
+      float mx = logit[t][0];
+#pragma unroll
+      for (int e = 1; e < EMAX; ++e)
+        if (e < E) mx = fmaxf(mx, logit[t][e]);
+      float den = 0.f, pr[EMAX];
+#pragma unroll
+      for (int e = 0; e < EMAX; ++e) {
+        pr[e] = (e < E) ? expf(logit[t][e] - mx) : 0.f;
+        den += pr[e];
+      }
+      int best = 0;
+      float bv = -1.f;
+#pragma unroll
+      for (int e = 0; e < EMAX; ++e) {
+        pr[e] = pr[e] / den;
+        if (e < E && pr[e] > bv) { bv = pr[e]; best = e; }  // first maximum
+      }
+#pragma unroll
+      for (int e = 0; e < EMAX; ++e)
+        if (j == (e & 15) && e < E) gates[tok * E + e] = pr[e];
+      if (j == 0) {
+        idx[tok] = best;
+        gmax[tok] = bv;
+        if (stats) { stats[tok * 2] = mean[t]; stats[tok * 2 + 1] = rstd[t]; }
+      }
     }
   }
 }
@@ -311,7 +334,7 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const T* __restrict__ g, 
 // backward: dlogits (softmax + l_aux), d(xn) = dlogits @ wg, LayerNorm backward -> dg; dlogits [P, E] written out for the parameter
 // gradients: d_wg, d_ln_w and d_ln_b all follow from M[e][k] = sum_tok dlogits[tok][e] * xhat[tok][k] and DL[e] = sum_tok dlogits[tok][e]
 // (gate_dwg_kernel + gate_dwg_finalize_kernel), so this kernel keeps no per-column accumulators.
-template <typename T, int G, int EMAX>
+template <typename T, int G, int EMAX, int TB = 1>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ g, const float* __restrict__ ln_w,
                                                        const float* __restrict__ ln_b, const float* __restrict__ wg,
                                                        const float* __restrict__ gates, const int32_t* __restrict__ idx,
@@ -320,6 +343,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ g, 
                                                        int seg_tokens, int P, int E, T* __restrict__ dg,
                                                        float* __restrict__ dlogits, float* __restrict__ d_ln_w,
                                                        float* __restrict__ d_ln_b) {
+  // (TB rows per 16-lane group and pass: see gate_fwd_kernel)
   using R = Row16<T, G>;
   constexpr int VPL = R::VPL;
   constexpr int LS = VPL + 4;
@@ -334,59 +358,77 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ g, 
   for (int v = 0; v < VPL; ++v) w[v] = 1.f;
   if (ln_w) R::loadf(ln_w, j, w);
   __syncthreads();
-  const long gid = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
-  const long ngr = ((long)gridDim.x * 256) >> 4;
-  for (long tok = gid; tok < P; tok += ngr) {
-    float xh[VPL];
-    R::load(g + tok * G, j, xh);
-    const float mean = ln_w ? stats[tok * 2] : 0.f, rstd = ln_w ? stats[tok * 2 + 1] : 1.f;
-    if (ln_w) {
+  const long gid = (((long)blockIdx.x * 256 + threadIdx.x) >> 4) * TB;
+  const long ngr = (((long)gridDim.x * 256) >> 4) * TB;
+  for (long tok0 = gid; tok0 < P; tok0 += ngr) {
+    float xh[TB][VPL], dl[TB][EMAX], rstd[TB];
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) xh[v] = (xh[v] - mean) * rstd;
+    for (int t = 0; t < TB; ++t) {
+      const long tok = tok0 + t < P ? tok0 + t : (long)P - 1;      // (rows past the end repeat the last row: computed, never stored)
+      R::load(g + tok * G, j, xh[t]);
+      const float mean = ln_w ? stats[tok * 2] : 0.f;
+      rstd[t] = ln_w ? stats[tok * 2 + 1] : 1.f;
+      if (ln_w) {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) xh[t][v] = (xh[t][v] - mean) * rstd[t];
+      }
+      const int seg = (int)(tok / seg_tokens);
+      const int my = idx[tok];
+      const float coef = laux_coef ? laux_coef[seg] : 0.f;
+      const float dgm = d_gmax ? d_gmax[tok] : 0.f;
+      float pr[EMAX], dp[EMAX], dot = 0.f;
+#pragma unroll
+      for (int e = 0; e < EMAX; ++e) {
+        pr[e] = (e < E) ? gates[tok * E + e] : 0.f;
+        dp[e] = (e < E) ? coef * (float)counts[seg * E + e] + ((e == my) ? dgm : 0.f) : 0.f;
+        dot += pr[e] * dp[e];
+      }
+#pragma unroll
+      for (int e = 0; e < EMAX; ++e) {
+        dl[t][e] = pr[e] * (dp[e] - dot);  // softmax backward
+        if (e < E && j == (e & 15) && tok0 + t < P) dlogits[tok * E + e] = dl[t][e];
+      }
     }
-    const int seg = (int)(tok / seg_tokens);
-    const int my = idx[tok];
-    const float coef = laux_coef ? laux_coef[seg] : 0.f;
-    const float dgm = d_gmax ? d_gmax[tok] : 0.f;
-    float pr[EMAX], dp[EMAX], dot = 0.f;
+    float dxn[TB][VPL];
+#pragma unroll
+    for (int t = 0; t < TB; ++t)
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) dxn[t][v] = 0.f;
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) {
-      pr[e] = (e < E) ? gates[tok * E + e] : 0.f;
-      dp[e] = (e < E) ? coef * (float)counts[seg * E + e] + ((e == my) ? dgm : 0.f) : 0.f;
-      dot += pr[e] * dp[e];
-    }
-    float dxn[VPL];
-#pragma unroll
-    for (int v = 0; v < VPL; ++v) dxn[v] = 0.f;
-#pragma unroll
-    for (int e = 0; e < EMAX; ++e) {
-      const float dl = pr[e] * (dp[e] - dot);  // softmax backward
-      if (e < E && j == (e & 15)) dlogits[tok * E + e] = dl;
       const float4* wp = (const float4*)(swg + (e * 16 + j) * LS);
 #pragma unroll
       for (int v4 = 0; v4 < VPL / 4; ++v4) {
         const float4 ww = wp[v4];
-        dxn[4 * v4] += dl * ww.x; dxn[4 * v4 + 1] += dl * ww.y; dxn[4 * v4 + 2] += dl * ww.z; dxn[4 * v4 + 3] += dl * ww.w;
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+          dxn[t][4 * v4] += dl[t][e] * ww.x; dxn[t][4 * v4 + 1] += dl[t][e] * ww.y;
+          dxn[t][4 * v4 + 2] += dl[t][e] * ww.z; dxn[t][4 * v4 + 3] += dl[t][e] * ww.w;
+        }
       }
+      if constexpr (G >= 512) __builtin_amdgcn_sched_barrier(0);      // (one expert's weights at a time: see gate_fwd_kernel)
     }
-    float dx[VPL];
-    if (ln_w) {
-      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) {
-        const float dxh = dxn[v] * w[v];
-        s1 += dxh;
-        s2 += dxh * xh[v];
+    for (int t = 0; t < TB; ++t) {
+      float dx[VPL];
+      if (ln_w) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const float dxh = dxn[t][v] * w[v];
+          s1 += dxh;
+          s2 += dxh * xh[t][v];
+        }
+        s1 = sum16(s1) * (1.f / G);
+        s2 = sum16(s2) * (1.f / G);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) dx[v] = rstd[t] * (dxn[t][v] * w[v] - s1 - xh[t][v] * s2);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) dx[v] = dxn[t][v];
       }
-      s1 = sum16(s1) * (1.f / G);
-      s2 = sum16(s2) * (1.f / G);
-#pragma unroll
-      for (int v = 0; v < VPL; ++v) dx[v] = rstd * (dxn[v] * w[v] - s1 - xh[v] * s2);
-    } else {
-#pragma unroll
-      for (int v = 0; v < VPL; ++v) dx[v] = dxn[v];
+      if (tok0 + t < P) R::store(dg + (tok0 + t) * G, j, dx);
     }
-    R::store(dg + tok * G, j, dx);
   }
 }
 
@@ -1052,13 +1094,16 @@ extern "C" int swn_pe_from_z(const float* rays, const float* z, int n_rays, int 
   return 0;
 }
 
-#define GATE_DISPATCH(T, KERNEL, ...)                                                                        \
+#ifndef SWN_GATE_TB512
+#define SWN_GATE_TB512 1          // rows per 16-lane group and pass of the 512-feature router FORWARD kernel (LDS weight reads per row / TB).
+#endif                            // Measured on 852 k rows x 16 experts: 1 = 0.74 ms (163 registers, 3 waves per SIMD), 2 = 1.07, 4 = 1.02
+#define GATE_DISPATCH_TB(T, KERNEL, TBV, ...)                                                                      \
   do {                                                                                                       \
     const bool e8 = n_experts <= 8;                                                                          \
     if (gate_dim == 256 && e8) hipLaunchKernelGGL((KERNEL<T, 256, 8>), __VA_ARGS__);                         \
     else if (gate_dim == 256) hipLaunchKernelGGL((KERNEL<T, 256, 16>), __VA_ARGS__);                         \
     else if (gate_dim == 128 && e8) hipLaunchKernelGGL((KERNEL<T, 128, 8>), __VA_ARGS__);                    \
-    else if (gate_dim == 512) hipLaunchKernelGGL((KERNEL<T, 512, 16>), __VA_ARGS__);                         \
+    else if (gate_dim == 512) hipLaunchKernelGGL((KERNEL<T, 512, 16, TBV>), __VA_ARGS__);                    \
     else return swn::set_error("gate: unsupported gate_dim %d / experts %d", gate_dim, n_experts);          \
   } while (0)
 
@@ -1084,11 +1129,11 @@ extern "C" int swn_gate_fwd(const void* g, int dtype, const float* ln_w, const f
     return swn::gate_fwd_mfma_launch(g, ln_w, ln_b, wg, n_tokens, n_experts, gates, idx, gmax, stats, stream);
   if (dtype == SWN_HALF) {
     const bf16_t* gp = (const bf16_t*)g;
-    GATE_DISPATCH(bf16_t, gate_fwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, n_tokens, n_experts,
+    GATE_DISPATCH_TB(bf16_t, gate_fwd_kernel, SWN_GATE_TB512, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, n_tokens, n_experts,
                   gates, idx, gmax, stats);
   } else {
     const float* gp = (const float*)g;
-    GATE_DISPATCH(float, gate_fwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, n_tokens, n_experts,
+    GATE_DISPATCH_TB(float, gate_fwd_kernel, 1, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, n_tokens, n_experts,
                   gates, idx, gmax, stats);
   }
   SWN_LAUNCH_CHECK();
@@ -1151,7 +1196,7 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
                                                dlogits, dwg_partial, stream);
       if (rc) return rc;
     } else
-    GATE_DISPATCH(bf16_t, gate_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, gates, idx, d_gmax,
+    GATE_DISPATCH_TB(bf16_t, gate_bwd_kernel, 1, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, gates, idx, d_gmax,
                   stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dgp, dlogits, d_ln_w, d_ln_b);
     if (!mfma_path) {
       SWN_CHECK(n_experts == 4 || n_experts == 8 || n_experts == 16, "swn_gate_bwd: experts must be 4, 8 or 16");
@@ -1160,7 +1205,7 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
   } else {
     const float* gp = (const float*)g;
     float* dgp = (float*)dg;
-    GATE_DISPATCH(float, gate_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, gates, idx, d_gmax,
+    GATE_DISPATCH_TB(float, gate_bwd_kernel, 1, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, gates, idx, d_gmax,
                   stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dgp, dlogits, d_ln_w, d_ln_b);
     SWN_CHECK(n_experts == 4 || n_experts == 8 || n_experts == 16, "swn_gate_bwd: experts must be 4, 8 or 16");
     DWG_DISPATCH(float, gp);
