@@ -911,21 +911,25 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
   float prod = 1.f;
 #pragma unroll
   for (int j = 0; j < SPL; ++j) {
+    // (branch-free: with the per-sample values assigned inside `if (s < S)` the 16-sample instantiation - merged coarse + fine rays -
+    //  carried its five arrays through every branch as whole vectors: 1900 accumulator-register moves, 842 spilled registers, 373 us
+    //  per 8192 x 768 samples against 96 for the forward kernel)
     const int s = lane * SPL + j;
-    al[j] = 0.f; dl[j] = 0.f; cg[j] = 0.f;
-    if (s < S) {
-      const float zc = zr[s];
-      dl[j] = (s + 1 < S) ? zsign * (zr[s + 1] - zc) : last_delta;
-      float4 c = rr[s];
-      if (rgb_pad != 0.f) {
-        c.x = c.x * (1.f + 2.f * rgb_pad) - rgb_pad;
-        c.y = c.y * (1.f + 2.f * rgb_pad) - rgb_pad;
-        c.z = c.z * (1.f + 2.f * rgb_pad) - rgb_pad;
-      }
-      al[j] = 1.f - expf(-dl[j] * c.w);
-      cg[j] = c.x * g0 + c.y * g1 + c.z * g2;
-      prod *= (1.f - al[j] + 1e-8f);
+    const bool ok = s < S;
+    const int sc = ok ? s : S - 1;
+    const float zc = zr[sc];
+    const float dlj = (sc + 1 < S) ? zsign * (zr[sc + 1] - zc) : last_delta;
+    float4 c = rr[sc];
+    if (rgb_pad != 0.f) {
+      c.x = c.x * (1.f + 2.f * rgb_pad) - rgb_pad;
+      c.y = c.y * (1.f + 2.f * rgb_pad) - rgb_pad;
+      c.z = c.z * (1.f + 2.f * rgb_pad) - rgb_pad;
     }
+    const float alj = 1.f - expf(-dlj * c.w);
+    dl[j] = ok ? dlj : 0.f;
+    al[j] = ok ? alj : 0.f;
+    cg[j] = ok ? c.x * g0 + c.y * g1 + c.z * g2 : 0.f;
+    prod *= ok ? (1.f - alj + 1e-8f) : 1.f;
   }
   float incl = prod;
 #pragma unroll
@@ -965,6 +969,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
       *(float4*)(d_raw + (ray * S + s) * 4) = make_float4(wj * g0, wj * g1, wj * g2, dsigma);
     }
     suffix += u[j];
+    if constexpr (SPL >= 16) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
