@@ -227,6 +227,10 @@ int swn_hash_encode_fwd(const float* rays, const float* z, int n_rays, int n_sam
                         const float* table, int dtype, void* out, int out_stride, void* stream);
 int swn_hash_encode_bwd(const float* rays, const float* z, int n_rays, int n_samples, const swn_hash_cfg* cfg,
                         const void* d_out, int dtype, int d_stride, float* d_table, void* stream);
+/* The same with one private copy of the gradient table per XCD (xcd_tables: fp32 [8][n_levels][T][2], ZERO on entry and left zero): a
+ * workgroup's atomics go to the copy of the XCD it runs on (HW_REG_XCC_ID) and a second kernel adds the copies into d_table.        */
+int swn_hash_encode_bwd_xcd(const float* rays, const float* z, int n_rays, int n_samples, const swn_hash_cfg* cfg,
+                            const void* d_out, int dtype, int d_stride, float* d_table, float* xcd_tables, void* stream);
 
 /* ---- background model + foreground bound (render_rays' bg_nerf branch, /root/reference/switch_nerf/rendering.py:32-159) ---
  * swn_fg_bounds: _intersect_sphere (:497-518) per ray against the ellipsoid (center, radius: 3 floats each in HOST memory,

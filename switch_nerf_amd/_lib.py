@@ -83,6 +83,7 @@ SIGNATURES = {
     "swn_composite_bounded_bwd": [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp],
     "swn_hash_encode_fwd": [vp, vp, i32, i32, C.POINTER(HashCfg), vp, i32, vp, i32, vp],
     "swn_hash_encode_bwd": [vp, vp, i32, i32, C.POINTER(HashCfg), vp, i32, i32, vp, vp],
+    "swn_hash_encode_bwd_xcd": [vp, vp, i32, i32, C.POINTER(HashCfg), vp, i32, i32, vp, vp, vp],
     "swn_gather_rows": [vp, vp, i64, i32, vp, vp],
     "swn_mlp_chain": [C.POINTER(ChainDesc), vp],
     "swn_chain_big_ok": [C.POINTER(ChainDesc)],

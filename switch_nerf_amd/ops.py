@@ -353,10 +353,18 @@ def hash_encode_fwd(rays, z, table, hc: dict, dtype, out_stride: int):
     return out
 
 
+_hash_xcd_tables = {}
+
+
 def hash_encode_bwd(rays, z, d_out, hc: dict, d_table):
     """d_table [L, T, 2] fp32 += the table gradient for dL/d encoding d_out [N * S, stride]."""
     n, S = z.shape
-    call("swn_hash_encode_bwd", _p(rays), _p(z), n, S, C.byref(_hash_cfg(hc)), _p(d_out), _dt(d_out), d_out.shape[1], _p(d_table), _stream())
+    key = (d_table.device, d_table.numel())
+    ws = _hash_xcd_tables.get(key)
+    if ws is None:      # one private copy of the gradient table per XCD: zero once, left zero by every launch; never freed (graphs)
+        ws = _hash_xcd_tables[key] = torch.zeros(8 * d_table.numel(), dtype=torch.float32, device=d_table.device)
+    call("swn_hash_encode_bwd_xcd", _p(rays), _p(z), n, S, C.byref(_hash_cfg(hc)), _p(d_out), _dt(d_out), d_out.shape[1], _p(d_table), _p(ws),
+         _stream())
 
 
 def mip_encode(rays, radii, z, l_xyz: int, dtype, pe_stride: int):
