@@ -17,9 +17,10 @@ build_one() {   # $1 = object directory, $2 = extra flags, $3 = output library
   # chain.hip a second time: the 512-feature geometry; a third time: the concat-skip layer mode of the dense NeRF trunk (kept out of
   # the default build's register budget)
   if newer chain.hip "$OBJ/chain_wide.o"; then $HIPCC $FLAGS -DSWN_WIDE=1 -c chain.hip -o "$OBJ/chain_wide.o" & pids+=($!); fi
+  if newer chain.hip "$OBJ/chain_wide2.o"; then $HIPCC $FLAGS -DSWN_WIDE=2 -c chain.hip -o "$OBJ/chain_wide2.o" & pids+=($!); fi
   if newer chain.hip "$OBJ/chain_cat.o"; then $HIPCC $FLAGS -DSWN_CONCAT=1 -c chain.hip -o "$OBJ/chain_cat.o" & pids+=($!); fi
   for p in "${pids[@]}"; do wait $p; done
-  $HIPCC --offload-arch=gfx950 -shared -fPIC "$OBJ"/{elementwise,gate_mfma,route,chain,chain_big,chain_wide,chain_cat,wgrad,sampling,mip,bounds,hashgrid,rayops}.o -o "$OUT"
+  $HIPCC --offload-arch=gfx950 -shared -fPIC "$OBJ"/{elementwise,gate_mfma,route,chain,chain_big,chain_wide,chain_wide2,chain_cat,wgrad,sampling,mip,bounds,hashgrid,rayops}.o -o "$OUT"
   echo "built $OUT"
 }
 # SWN_VARIANT=name (experiments): the bf16 library built with SWN_DEFS into libswn_hip_<name>.so / build_<name>/ - select it at run time

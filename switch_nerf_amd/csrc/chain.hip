@@ -28,7 +28,9 @@
 #ifndef SWN_CONCAT
 #define SWN_CONCAT 0     // 1: third build of this file with the concat-skip layer mode (skip = 2) enabled, namespace swn_cat
 #endif
-#if SWN_WIDE
+#if SWN_WIDE == 2
+#define SWN_NS swn_wide2
+#elif SWN_WIDE
 #define SWN_NS swn_wide
 #elif SWN_CONCAT
 #define SWN_NS swn_cat
@@ -56,14 +58,18 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 // -DSWN_WIDE=1 into a second set of kernels for layers up to 512 features (the Mission Bay recipe's model width): a wave then owns
 // 128 output features (4 MFMA feature tiles, 128 accumulator VGPRs), the LDS tile is 64 rows x 1 KiB (bf16; two workgroups per CU)
 // or 2 KiB (fp32; one), and the K loop is left to the compiler's scheduler.
-constexpr int NT = 256;         // threads per workgroup (4 waves)
-constexpr int NI = SWN_WIDE ? 4 : 2;        // 32-wide feature tiles per wave (4 waves * NI * 32 = max features)
-constexpr int ROW_ELEMS = 128 * NI;         // features per LDS tile row: 256 / 512
+// -DSWN_WIDE=2 (round 4): a third geometry for 512-feature layers in the 16-bit types - EIGHT waves (512 threads), one workgroup per CU
+// on a 128-row x 1 KiB tile, a wave owns 64 output features of all 128 rows (4 x 2 MFMA tiles, 128 accumulators, the hand-scheduled
+// MI = 4 K loop): a layer's 512 KiB of weights are streamed once per 128 rows instead of once per 64 - these chains are bound by the
+// CU's L2 -> L1 path like every other one (profiles/r04_experiments.md 1, 15).  Chains with the fused heads stay on -DSWN_WIDE=1.
+constexpr int NT = SWN_WIDE == 2 ? 512 : 256;         // threads per workgroup (4 waves; 8 in the SWN_WIDE = 2 build)
+constexpr int NI = SWN_WIDE == 1 ? 4 : 2;   // 32-wide feature tiles per wave (waves * NI * 32 = max features)
+constexpr int ROW_ELEMS = (NT / 64) * 32 * NI;        // features per LDS tile row: 256 / 512
 #ifndef SWN_RING
 #define SWN_RING 2
 #endif
 constexpr int RING = SWN_RING;  // weight-fragment steps in flight
-#if SWN_WIDE
+#if SWN_WIDE == 1
 typedef uint64_t mbits_t;
 #else
 typedef uint32_t mbits_t;
@@ -77,13 +83,13 @@ template <typename T> struct Cfg;
 #define SWN_WIDE_BM 64      // rows per tile of the 512-feature build (128: one workgroup per CU, 256 accumulator registers per wave - experiment)
 #endif
 template <> struct Cfg<bf16_t> {
-  static constexpr int BM = SWN_WIDE ? SWN_WIDE_BM : SWN_BF16_BM, MI = BM / 32, KSTEP = 16;   // one ring step = K 16: one 16-byte fragment load per feature tile
+  static constexpr int BM = SWN_WIDE == 2 ? 128 : (SWN_WIDE ? SWN_WIDE_BM : SWN_BF16_BM), MI = BM / 32, KSTEP = 16;   // one ring step = K 16: one 16-byte fragment load per feature tile
   static constexpr int ROWB = ROW_ELEMS * 2;           // LDS tile row stride in bytes
   static constexpr int ACT = BM * ROWB;                // LDS tile bytes
 #ifndef SWN_OCC
 #define SWN_OCC 4
 #endif
-  static constexpr int OCC = SWN_WIDE ? (SWN_WIDE_BM == 128 ? 1 : 2) : (BM == 128 ? 2 : (SWN_CONCAT ? 3 : SWN_OCC));   // workgroups per CU (= waves per SIMD) the register budget must allow
+  static constexpr int OCC = SWN_WIDE == 2 ? 1 : SWN_WIDE ? (SWN_WIDE_BM == 128 ? 1 : 2) : (BM == 128 ? 2 : (SWN_CONCAT ? 3 : SWN_OCC));   // workgroups per CU (= waves per SIMD) the register budget must allow
   typedef bf16x8_t wfrag_t;
 };
 template <> struct Cfg<float> {
@@ -264,7 +270,7 @@ __device__ __forceinline__ void k_loop(f32x16_t (&acc)[Cfg<T>::MI][NI], typename
     auto aread = [&](int ks, int mi) -> bf16x8_t {
       return *(const bf16x8_t*)(act + aoff[ks & 7] + mi * (32 * Cfg<T>::ROWB) + (ks >> 3) * 256);
     };
-#if SWN_WIDE
+#if SWN_WIDE == 1
 #pragma unroll
     for (int ks = 0; ks < NSTEPS; ++ks) {
       const int r = ks % RING;
@@ -678,7 +684,7 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
       int l31e = l31, lhie = lhi;
       asm volatile("" : "+v"(l31e), "+v"(lhie));
       const float* rbp = ly.rowbias ? ly.rowbias + (grow0 / ly.rows_per_bias) * (size_t)n : nullptr;   // tile-aligned per-ray bias
-      uint32_t* mk = ly.mask ? ly.mask + (size_t)((g * args.tiles_per_group + tile) * 4 + wn) * MI * 64 * (NI / 2) + lane : nullptr;
+      uint32_t* mk = ly.mask ? ly.mask + (size_t)((g * args.tiles_per_group + tile) * (NT / 64) + wn) * MI * 64 * (NI / 2) + lane : nullptr;
       const int nvalid = n - wn * 32 * NI;   // feature tiles of this wave that exist: nvalid >= 32 NI -> all
       epilogue_body<T, true, 0, false, false, false>(acc, act, bias_lds, rbp, mk, wn, l31e, lhie, nvalid, grow0, ly.rows_per_bias, n,
                                                      ly.relu, ly.skip == 1, ly.b != nullptr, rows_in_tile);
@@ -958,7 +964,12 @@ static int chain_launch(const swn_chain_desc& d, void* stream) {
 
 }  // namespace SWN_NS
 
-#if SWN_WIDE
+#if SWN_WIDE == 2
+namespace swn {
+int chain_wide2_launch(const swn_chain_desc& d, void* stream) { return swn_wide2::chain_launch(d, stream); }
+int chain_wide2_tile_rows() { return swn_wide2::Cfg<bf16_t>::BM; }
+}  // namespace swn
+#elif SWN_WIDE
 namespace swn {
 int chain_wide_launch(const swn_chain_desc& d, void* stream) { return swn_wide::chain_launch(d, stream); }
 int chain_wide_tile_rows(int dtype) { return dtype == SWN_HALF ? swn_wide::Cfg<bf16_t>::BM : swn_wide::Cfg<float>::BM; }
@@ -1023,6 +1034,11 @@ extern "C" long swn_chain_mask_words(int dtype, int n_groups, int group_stride, 
   const bool wide = max_width > 256;
   const int bm = wide ? chain_wide_tile_rows(dtype) : swn_chain_tile_rows(dtype);
   long words = (long)cdiv(group_stride, bm) * n_groups * bm * (wide ? 16 : 8);
+  if (wide && dtype != SWN_F32) {              // ... or the 8-wave 128-row geometry of the 512-feature chains (same words per row)
+    const int bm2 = chain_wide2_tile_rows();
+    const long w2 = (long)cdiv(group_stride, bm2) * n_groups * bm2 * 16;
+    if (w2 > words) words = w2;
+  }
   if (!wide && dtype != SWN_F32) {             // ... or any of the chain_big.hip geometries (one buffer size fits all)
     for (int geo = 2; geo <= 3; ++geo) {
       const long w = (long)cdiv(group_stride, chain_big_tile_rows(geo)) * n_groups * chain_big_mask_words_per_tile(geo);
@@ -1096,7 +1112,11 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
     SWN_CHECK(d.geometry < 2 || can, "swn_mlp_chain: geometries 2 - 7 need bf16 / fp16 chains of 256 x 256 layers without rowbias / x_scale / x_save / y_add_gather");
     if (d.geometry >= 2) return chain_big_launch(d, stream);
   }
-  if (wide) return chain_wide_launch(d, stream);        // 512-feature geometry (this file compiled with -DSWN_WIDE=1)
+  if (wide) {      // 512-feature geometries: this file compiled with -DSWN_WIDE=2 (16-bit types, no fused heads: 128-row tiles, 8 waves) / =1
+    static const bool no_w2 = getenv("SWN_NO_WIDE2") != nullptr;
+    if (d.dtype == SWN_HALF && !d.heads_raw && !no_w2) return chain_wide2_launch(d, stream);
+    return chain_wide_launch(d, stream);
+  }
   if (concat) return chain_concat_launch(d, stream);    // concat-skip layers (this file compiled with -DSWN_CONCAT=1)
   return chain_launch(d, stream);
 }

@@ -74,6 +74,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 int chain_wide_launch(const swn_chain_desc& d, void* stream);   // chain.hip compiled with -DSWN_WIDE=1
 int chain_wide_tile_rows(int dtype);
+int chain_wide2_launch(const swn_chain_desc& d, void* stream);  // chain.hip compiled with -DSWN_WIDE=2 (16-bit types: 128-row tiles, 8 waves)
+int chain_wide2_tile_rows();
 int chain_concat_launch(const swn_chain_desc& d, void* stream); // chain.hip compiled with -DSWN_CONCAT=1 (concat-skip layer mode)
 int gate_fwd_mfma_launch(const void* g, const float* ln_w, const float* ln_b, const float* wg, int n_tokens, int n_experts, float* gates,
                          int32_t* idx, float* gmax, float* stats, void* stream);
