@@ -65,8 +65,11 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int NT = SWN_WIDE == 2 ? 512 : 256;         // threads per workgroup (4 waves; 8 in the SWN_WIDE = 2 build)
 constexpr int NI = SWN_WIDE == 1 ? 4 : 2;   // 32-wide feature tiles per wave (waves * NI * 32 = max features)
 constexpr int ROW_ELEMS = (NT / 64) * 32 * NI;        // features per LDS tile row: 256 / 512
+#ifndef SWN_RING_W2
+#define SWN_RING_W2 4      // ... of the 8-wave 512-feature build (one workgroup per CU, fewer waves to hide the L2 round trip behind: 4 measured best - 39.5 ms at 2, 40.5 at 3, 38.8 at 4 on the Mission Bay recipe; 6 spills 42 registers)
+#endif
 #ifndef SWN_RING
-#define SWN_RING 2
+#define SWN_RING (SWN_WIDE == 2 ? SWN_RING_W2 : 2)
 #endif
 constexpr int RING = SWN_RING;  // weight-fragment steps in flight
 #if SWN_WIDE == 1
