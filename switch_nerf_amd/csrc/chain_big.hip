@@ -1452,6 +1452,14 @@ __device__ __forceinline__ void write_rows128_tok(const Ctx& cx, void* y, uint32
   for (int i = 0; i < 8; ++i) asm volatile("s_nop 1" :: "v"(v[i]));      // (store operands stay allocated behind their stores: see the write-out hook)
 }
 
+// The lane id, re-derived where it is used (two VALU instructions, nothing to keep alive): a lane id that lives across the phases of
+// chainq_kernel is SPILLED, and its reloads sat in front of the K loop with a full vmcnt(0) wait each (four per K phase of row group 0)
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 template <typename E, int TAG, bool BIAS_INIT>
 __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1477,7 +1485,8 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
   cx.a_base = cx.e_base = cx.e2_base = cx.wf_base = 0;
   auto phase_ctx = [&](bool k_phase) -> Ctx {
     Ctx c = cx;
-    asm volatile("" : "+v"(c.lane), "+s"(c.w));
+    c.lane = fresh_lane();
+    asm volatile("" : "+s"(c.w));
     c.l31 = c.lane & 31;
     c.lhi = c.lane >> 5;
     const int r15_ = c.lane & 15, rg_ = c.w >> 2, fg_ = c.w & 3;
@@ -1498,7 +1507,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
   int kq = 0;                                    // (no counters: the kq-th tile of this workgroup is block b + kq * grid)
   auto claim = [&]() -> int {                    // one ticket of this workgroup's queue (lane 0; NOT waited for: consume with grab)
     int q = 0;
-    if (d.sched && cx.lane == 0) q = __hip_atomic_fetch_add(d.sched + xq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d.sched && fresh_lane() == 0) q = __hip_atomic_fetch_add(d.sched + xq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return q;
   };
   auto grab = [&](int slot, int ticket) {        // the next tile with at least one valid row -> tinfo[slot] (vb = -1: the queue is empty);
@@ -1546,7 +1555,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
       if (rows_valid > d.group_rows_clamp) rows_valid = d.group_rows_clamp;
       if (tile * BM < rows_valid) break;
     }
-    if (cx.lane == 0) {
+    if (fresh_lane() == 0) {
       int* t = (int*)(smem + Q_TINFO) + slot * 8;
       t[0] = vb;
       if (vb >= 0) {
@@ -1578,7 +1587,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     return t;
   };
   auto finish = [&]() {                          // the last workgroup to leave zeroes the counters for the next launch
-    if (d.sched && cx.w == 0 && cx.lane == 0) {
+    if (d.sched && cx.w == 0 && fresh_lane() == 0) {
       const int done = __hip_atomic_fetch_add(d.sched + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (done == (int)gridDim.x - 1) {
 #pragma unroll
@@ -1590,7 +1599,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
   // the idx table `idx_off` (two steps: the gather-index load of the NEXT tile is issued at the top of the last epilogue phase and
   // looked at behind it)
   auto load_row = [&](const Tile& t) -> int {
-    const int lt = fg * 64 + cx.lane;
+    const int lt = fg * 64 + fresh_lane();
     int src = 0;
     if (lt < 128) {
       const int r = 128 * rg + lt;
@@ -1601,7 +1610,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     return src;
   };
   auto store_row = [&](int src, int idx_off) {
-    const int lt = fg * 64 + cx.lane;
+    const int lt = fg * 64 + fresh_lane();
     if (lt < 128) ((int*)(smem + idx_off))[128 * rg + lt] = src < 0 ? 0 : src;
   };
   const bool narrow = d.x_features == 128;                  // 128-feature chain input (256-byte rows) under a K = 256 zero-padded first layer
@@ -1628,25 +1637,26 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     const float* b = d.layers[L].b;
     if (b) {
       const __amdgpu_buffer_rsrc_t rb = uniform_rsrc(b + (size_t)wset * 256, 1024);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, SWN_LDS(smem + G::BIAS0 + slot * 1024 + fg * 256), 4, cx.lane * 4, fg * 256, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, SWN_LDS(smem + G::BIAS0 + slot * 1024 + fg * 256), 4, fresh_lane() * 4, fg * 256, 0, 0);
     } else if constexpr (BIAS_INIT) {                    // the accumulators ALWAYS start at the slot's contents: no bias = zeros
-      *(float*)(smem + G::BIAS0 + slot * 1024 + fg * 256 + cx.lane * 4) = 0.f;
+      *(float*)(smem + G::BIAS0 + slot * 1024 + fg * 256 + fresh_lane() * 4) = 0.f;
     }
   };
   auto load_mask = [&](int L, int vb) -> u32x4_t {
     const swn_chain_layer& l_ = d.layers[L];
-    if (l_.relu == 2) return *(const u32x4_t*)(l_.mask + ((size_t)(vb * G::NW + cx.w) * 64 + cx.lane) * 4);
+    if (l_.relu == 2) return *(const u32x4_t*)(l_.mask + ((size_t)(vb * G::NW + cx.w) * 64 + fresh_lane()) * 4);
     return u32x4_t{0u, 0u, 0u, 0u};
   };
   constexpr bool bias_init = BIAS_INIT;
   f32x4_t bv[2][4];                              // the bias values of this wave's next K phase (BIAS_INIT: the accumulators start there)
   auto load_bv = [&](int slot) {
     if constexpr (BIAS_INIT) {
+      const int lh_ = fresh_lane() >> 5;
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4)
-          bv[ni][g4] = *(const f32x4_t*)(smem + G::BIAS0 + slot * 1024 + ((fg * 64 + 32 * ni + 8 * g4 + 4 * cx.lhi) << 2));
+          bv[ni][g4] = *(const f32x4_t*)(smem + G::BIAS0 + slot * 1024 + ((fg * 64 + 32 * ni + 8 * g4 + 4 * lh_) << 2));
     }
   };
 
@@ -1752,7 +1762,8 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
       // (per-lane / per-wave coordinates re-derived from laundered ids: computed once outside the tile loop, the ~50 swizzled piece
       //  addresses and scalar piece offsets of this phase would live - spilled - through every other phase)
       Ctx cs = cx;
-      asm volatile("" : "+v"(cs.lane), "+s"(cs.w));
+      cs.lane = fresh_lane();
+      asm volatile("" : "+s"(cs.w));
       cs.l31 = cs.lane & 31;
       cs.lhi = cs.lane >> 5;
       const int rgs = cs.w >> 2, fgs = cs.w & 3;
@@ -1819,7 +1830,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     if (rg == 0 && it == 0) { stage_bias(cur.l0, ws_of(cur.l0, cur), 0); SWN_WAIT_VM(0); }
     u32x4_t mk_next = load_mask(cur.l0, cur.vb);
     SWN_PIN();
-    preload_w(cur.l0, ws_of(cur.l0, cur), cx.lane);
+    preload_w(cur.l0, ws_of(cur.l0, cur), fresh_lane());
     SWN_PIN();
     SWN_TM(const long long s1 = TICK(); tS += s1 - s0;)
     Tile nxt = cur;
@@ -1892,7 +1903,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         int row_nxt = 0, yrow = -1;
         if (last && nxt.vb >= 0) row_nxt = load_row(nxt);      // (consumed behind the epilogue)
         if (last && d.y_add_gather && d.y_add) {               // the y_add row of this thread's output row of THIS tile (write_pieces16_gather)
-          const int lt = fg * 64 + cx.lane;
+          const int lt = fg * 64 + fresh_lane();
           if (lt < 128) { const int r = 128 * rg + lt; yrow = d.y_add_gather[cur.grow0 + (r < cur.rows ? r : 0)]; }
         }
         const bool bias_epi = ly.b != nullptr && !bias_init;
@@ -1980,7 +1991,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         if (!last) preload_w(L + 1, ws_of(L + 1, cur), ce.lane);      // (last layer: the S phase that follows loads the next tile's first fragments)
         else if (nxt.vb >= 0) store_row(row_nxt, idx_nxt);
         if (last && d.y_add_gather && d.y_add) {
-          const int lt = fg * 64 + cx.lane;
+          const int lt = fg * 64 + fresh_lane();
           if (lt < 128) ((int*)(smem + ((it & 1) ? Q_YIDX + 1024 : Q_YIDX)))[128 * rg + lt] = yrow;
         }
         SWN_PIN();
@@ -1999,19 +2010,23 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     if (cur.vb < 0) break;
   }
   // ---- the rows of the last tile ----
+  Ctx cf = cx;                                   // (lane coordinates re-derived: nothing of them lives through the tile loop)
+  cf.lane = fresh_lane();
+  cf.l31 = cf.lane & 31;
+  cf.lhi = cf.lane >> 5;
   if constexpr (TAIL) {
-    tail_out(cx, prev, ((it - 1) & 1) ? Q_IDX1 : G::IDX0);
+    tail_out(cf, prev, ((it - 1) & 1) ? Q_IDX1 : G::IDX0);
   } else if (HEAD && prev.l1 < n_layers) {
   } else {
-    if constexpr (HEAD) head_out(cx, prev, ((it - 1) & 1) ? Q_IDX1 : G::IDX0);
+    if constexpr (HEAD) head_out(cf, prev, ((it - 1) & 1) ? Q_IDX1 : G::IDX0);
     const __amdgpu_buffer_rsrc_t ry = out_rs(d.y, prev);
     const __amdgpu_buffer_rsrc_t ra = d.y_add ? out_rs((void*)d.y_add, prev) : ry;
     if constexpr (TAG == 5) {
-      if (d.comb_y) write_pieces16_comb<E>(cx, 64 * rg + fg, ry, d, prev.grow0, prev.rows);
-      else write_pieces16<E, false, 8>(cx, 64 * rg + fg, ry, ra);
-    } else if (d.y_add && d.y_add_gather) write_pieces16_gather<E>(cx, 64 * rg + fg, ry, (const char*)d.y_add, ((it - 1) & 1) ? Q_YIDX + 1024 : Q_YIDX);
-    else if (d.y_add) write_pieces16<E, true, 8>(cx, 64 * rg + fg, ry, ra);
-    else write_pieces16<E, false, 8>(cx, 64 * rg + fg, ry, ra);
+      if (d.comb_y) write_pieces16_comb<E>(cf, 64 * rg + fg, ry, d, prev.grow0, prev.rows);
+      else write_pieces16<E, false, 8>(cf, 64 * rg + fg, ry, ra);
+    } else if (d.y_add && d.y_add_gather) write_pieces16_gather<E>(cf, 64 * rg + fg, ry, (const char*)d.y_add, ((it - 1) & 1) ? Q_YIDX + 1024 : Q_YIDX);
+    else if (d.y_add) write_pieces16<E, true, 8>(cf, 64 * rg + fg, ry, ra);
+    else write_pieces16<E, false, 8>(cf, 64 * rg + fg, ry, ra);
   }
   if (rg == 0) __builtin_amdgcn_s_barrier();      // (row group 1's last phase boundary)
 #ifdef SWN_BIG_TIMING
