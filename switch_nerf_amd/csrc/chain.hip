@@ -92,7 +92,10 @@ template <> struct Cfg<bf16_t> {
 #ifndef SWN_OCC
 #define SWN_OCC 4
 #endif
-  static constexpr int OCC = SWN_WIDE == 2 ? 1 : SWN_WIDE ? (SWN_WIDE_BM == 128 ? 1 : 2) : (BM == 128 ? 2 : (SWN_CONCAT ? 3 : SWN_OCC));   // workgroups per CU (= waves per SIMD) the register budget must allow
+#ifndef SWN_CAT_OCC
+#define SWN_CAT_OCC 3      // workgroups per CU of the concat-skip build (dense NeRF trunk)
+#endif
+  static constexpr int OCC = SWN_WIDE == 2 ? 1 : SWN_WIDE ? (SWN_WIDE_BM == 128 ? 1 : 2) : (BM == 128 ? 2 : (SWN_CONCAT ? SWN_CAT_OCC : SWN_OCC));   // workgroups per CU (= waves per SIMD) the register budget must allow
   typedef bf16x8_t wfrag_t;
 };
 template <> struct Cfg<float> {
