@@ -1927,17 +1927,8 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
             if (L + 1 == d.head_layers && cur.l1 == n_layers) { epilogue_q_comb<E, HK>(acc, ce, (const char*)d.comb_y, oob_s, idx_cur, hook); return; }
           }
           if constexpr (TAIL) {
-#ifdef SWN_T7_NOHEADS
-            const bool hd = false;
-#else
-            const bool hd = d.heads_raw != nullptr;
-#endif
-#ifndef SWN_T7_NOGATE
-            if (gate_l) { epilogue_q_gate<E, HK>(acc, ce, hd, hook); return; }
-#endif
-#ifndef SWN_T7_NORB
+            if (gate_l) { epilogue_q_gate<E, HK>(acc, ce, d.heads_raw != nullptr, hook); return; }
             if (rb_l) { epilogue_q_rowbias<E, HK>(acc, ce, ly.rowbias, ly.rows_per_bias, yf, idx_cur, hook); return; }
-#endif
           }
           epilogue_p_dispatch<E, HK>(acc, ce, mk, ly.relu, bias_epi, ly.skip != 0, (bc % 3) * 1024, hook);
         };
