@@ -9,7 +9,8 @@ dev, dt = torch.device('cuda'), torch.bfloat16
 M, E, L, CAP = 256, 8, 7, 16384
 geoms = [int(a) for a in sys.argv[1:]] or [4, 7]
 torch.manual_seed(0)
-Wm = [torch.randn(E, M, M, device=dev).mul_(1 / 16) for _ in range(L)]
+ZERO = bool(os.environ.get("ZERO"))      # all-zero weights and inputs: what the matrix pipe's POWER costs (nothing toggles)
+Wm = [torch.randn(E, M, M, device=dev).mul_(0.0 if ZERO else 1 / 16) for _ in range(L)]
 Wf = [o.pack_weights(w, dt, True) for w in Wm]
 Wb = [o.pack_weights(w, dt, False) for w in Wm]
 B = [torch.randn(E, M, device=dev).mul_(0.1) for _ in range(L)]
@@ -37,7 +38,7 @@ for nseg, pattern in ((16, "full"), (16, "router"), (2, "full"), (2, "router")):
     fill = {"full": [1.0] * 8, "router": [1.0, 1.0, 1.0, 0.66, 0.66, 0.66, 0.66, 0.66]}[pattern]
     counts = torch.tensor([int(CAP * fill[g % E]) for g in range(NG)], dtype=torch.int32, device=dev)
     kept = int(counts.sum().item())
-    h0 = torch.randn(ROWS, M, device=dev).to(dt)
+    h0 = torch.randn(ROWS, M, device=dev).mul_(0.0 if ZERO else 1.0).to(dt)
     perm = torch.randperm(ROWS, device=dev).int()
     saves = [torch.empty(ROWS, M, dtype=dt, device=dev) for _ in range(L - 1)]
     dz = [torch.empty(ROWS, M, dtype=dt, device=dev) for _ in range(L - 1)]
