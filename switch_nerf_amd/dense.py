@@ -207,15 +207,20 @@ class DenseNeRF(SwitchNeRF):
             g["l2.b"].add_(dc_ray.sum(0))
         o.emb_grad(dc_ray @ self.p["l2r.w"][self.in_dir:].t(), c["image_indices"].contiguous(), g["emb"])
         dh1 = _b("dh1", (P, W), dt)
-        dy = _b("dy", (P, W), dt)
-        o.mlp_chain(dh2, [o.Layer(self.wb["l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dy, tag=5)
         nsp = max(1, min(256, P // 1024))
         # d(pre-activation of the last trunk layer) = (dy + dsigma * w_sigma) * (xyz_ > 0): the combine backward with a unit gate
         if getattr(self, "_ones", None) is None or self._ones.numel() < P:
             self._ones = torch.ones(P, dtype=torch.float32, device=self.dev)
         ones = self._ones[:P]
         dz = [_b(f"dz{i}", (P, W), dt) for i in range(L - 1)]
-        dz.append(o.combine_bwd(dy, c["y"], dsig, self.p["sigma.w"], ones)[0])
+        if W * dh1.element_size() <= 1024:      # ... applied in the write-out of the tail backward chain (swn.h comb_*: swn_combine_bwd's
+            dz.append(_b(f"dz{L - 1}", (P, W), dt))                      # arithmetic, value for value): dy never reaches memory
+            o.mlp_chain(dh2, [o.Layer(self.wb["l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dz[L - 1], tag=5,
+                        combine=(c["y"], dsig, self.p["sigma.w"], ones, _b("dgate_unused", (P,), torch.float32)))
+        else:
+            dy = _b("dy", (P, W), dt)
+            o.mlp_chain(dh2, [o.Layer(self.wb["l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dy, tag=5)
+            dz.append(o.combine_bwd(dy, c["y"], dsig, self.p["sigma.w"], ones)[0])
         o.wgrad(c["h1"], dh2, g["l2h.w"].view(1, W, H2), None, n_splits=nsp)
         o.wgrad(c["y"], dh1, g["l1.w"].view(1, W, W), g["l1.b"].view(1, W), n_splits=nsp)
         with self._timed("trunk_bwd"):
