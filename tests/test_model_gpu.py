@@ -794,3 +794,26 @@ def test_fused_tail_step_equals_separate_tail_launches_bf16(cf, fine, chunk, mon
     d_g = (a["grad"] - s_["grad"]).abs().max().item() / gscale
     print(f"fused tail vs separate launches (cf {cf}, fine {fine}, {a['dropped']} dropped): rgb {d_rgb:.2e}, loss {abs(a['loss'] - s_['loss']):.2e}, gradients {d_g:.2e}")
     assert d_rgb < 3e-3 and abs(a["loss"] - s_["loss"]) < 1e-3 * abs(s_["loss"]) and d_g < 1e-2
+
+
+def test_fused_tail_inference_on_packed_rows_equals_separate_launches_bf16(monkeypatch):
+    """The evaluation forward without token dropping (packed row space: `group_begin`, nothing dropped, no saves) through the fused
+    launch - raw is all it writes - against the expert chain + 64-row tail chain (SWN_FUSED_TAIL=0): the same experts, raw to the
+    rounding order of layer "1"; and the capacity-limited inference forward (dropped tokens) likewise."""
+    N, S, chunk = 96, 128, 4096
+    rays, img, _ = synth.make_rays(151, N)
+    for no_batch in (True, False):
+        outs = []
+        for fused in (True, False):
+            if not fused:
+                monkeypatch.setenv("SWN_FUSED_TAIL", "0")
+            m = _model(torch.bfloat16, 150, 1.0, capacity_factor=0.75)
+            c = m.forward_rays(_dev(rays), _dev(img), S, chunk, training=False, no_batch=no_batch)
+            assert c["tail_fused"] == fused and c["geom"] == 7 and ("group_begin" in c) == no_batch
+            outs.append((c["idx"].clone(), c["raw"].clone(), c["rgb"].clone(), int((c["tok2row"] < 0).sum())))
+            monkeypatch.delenv("SWN_FUSED_TAIL", raising=False)
+        assert torch.equal(outs[0][0], outs[1][0]) and outs[0][3] == outs[1][3] and (outs[0][3] == 0) == no_batch
+        d_raw = (outs[0][1] - outs[1][1]).abs().max().item()
+        d_rgb = (outs[0][2] - outs[1][2]).abs().max().item()
+        print(f"fused inference (no_batch={no_batch}, {outs[0][3]} dropped): raw {d_raw:.2e}, rgb {d_rgb:.2e}")
+        assert d_raw < 5e-3 and d_rgb < 2e-3
