@@ -467,6 +467,7 @@ __global__ __launch_bounds__(WG_NT) void wgrad_stream_kernel(const WsArgs p) {
       // ---------------------------------------------------------------- one piece: slabs [pa, pb) of (job j, weight set e)
       f32x16_t acc[4][2];
       f32x16_t accb[2];
+      float dbv[2] = {0.f, 0.f};                 // 16-bit operands: this lane's share of the bias gradient (its two columns, its 8 rows per step)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -622,7 +623,16 @@ __global__ __launch_bounds__(WG_NT) void wgrad_stream_kernel(const WsArgs p) {
             for (int q = 0; q < 4; ++q) frag_a(0, q);
             frag_b(0, 0);
             frag_b(0, 1);
-            const bf16x8_t ones = as_frag(SWN_HALF_ONE_X2, SWN_HALF_ONE_X2, SWN_HALF_ONE_X2, SWN_HALF_ONE_X2);
+            // db = the column sums of the B slab, from the raw row dwords (low half: column 2 l31, high half: 2 l31 + 1): 32 VALU
+            // instructions per K step instead of two more matrix instructions against a fragment of ones - the launch is bound by the
+            // chip's power budget (profiles/r04_experiments.md 10) and an MFMA costs what ~500 such additions do
+            auto dbsum = [&](int kk) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                dbv[0] += bf16_to_f32((bf16_t)(pb_[kk][q] & 0xFFFFu));
+                dbv[1] += bf16_to_f32((bf16_t)(pb_[kk][q] >> 16));
+              }
+            };
             __builtin_amdgcn_sched_barrier(0);
 #if defined(SWN_WG_ABL) && SWN_WG_ABL == 2      // (experiment: staging + the LDS reads, nothing else)
 #pragma unroll
@@ -651,18 +661,12 @@ __global__ __launch_bounds__(WG_NT) void wgrad_stream_kernel(const WsArgs p) {
                   __builtin_amdgcn_sched_barrier(0);
                 }
               }
-              if (do_bias) {
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq) accb[qq] = SWN_MFMA_32x32x16(ones, fb[0][qq], accb[qq]);
-              }
+              if (do_bias) dbsum(0);
 #pragma unroll
               for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) acc[q][qq] = SWN_MFMA_32x32x16(fa[1][q], fb[1][qq], acc[q][qq]);
-              if (do_bias) {
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq) accb[qq] = SWN_MFMA_32x32x16(ones, fb[1][qq], accb[qq]);
-              }
+              if (do_bias) dbsum(1);
             }
           } else {
 #pragma unroll 2
@@ -714,12 +718,18 @@ __global__ __launch_bounds__(WG_NT) void wgrad_stream_kernel(const WsArgs p) {
               if (m < m_dim && n < n_dim) part[(size_t)m * n_dim + n] = acc[q][qq][r];
             }
       }
+      if constexpr (sizeof(T) == 2) {          // the two half-waves hold the two halves of every K step's rows
+        if (do_bias) {
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) dbv[qq] += __shfl_xor(dbv[qq], 32);
+        }
+      }
       if (do_bias && lhi == 0) {
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
           int n;
           if constexpr (sizeof(T) == 2) n = wn * 64 + 2 * l31 + qq; else n = wn * 64 + qq * 32 + l31;
-          if (n < n_dim) part[(size_t)m_dim * n_dim + n] = accb[qq][0];
+          if (n < n_dim) part[(size_t)m_dim * n_dim + n] = sizeof(T) == 2 ? dbv[qq] : accb[qq][0];
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (stores and copies share vmcnt: the next piece counts from zero)
