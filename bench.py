@@ -503,6 +503,9 @@ def main():
                         hbm_frac_measured=d.get("hbm_frac_measured"))
         roof["attainable"] = dict(tflops=round(attainable, 1), frac_of_attainable=round(d["tflops"] / attainable, 4),
                                   what="min(MFMA peak, flop_per_byte x HBM peak) for this launch's algorithmic flops and bytes")
+        # the three training launches side by side (the dominant one changes with the box and the router's fill: they are within 15 %)
+        roof["launches"] = {k: dict(ms=detail[k]["ms"], hbm_frac_alg=detail[k]["hbm_frac_alg"], hbm_frac_measured=detail[k].get("hbm_frac_measured"),
+                                    mfma_frac=detail[k]["mfma_frac"]) for k in ("expert_fwd", "expert_bwd", "expert_wgrad") if k in detail}
         if "expert_gemm_nosave" in detail:     # north_star: the grouped GEMM against the MFMA peak = the expert layers alone, without saves
             roof["grouped_gemm_mfma_frac_nosave"] = detail["expert_gemm_nosave"]["mfma_frac"]
         elif "expert_fwd_nosave" in detail:
