@@ -1263,75 +1263,64 @@ __device__ __forceinline__ void epilogue_q_gate(f32x16_t (&acc)[4][2], const Ctx
   }
 }
 
-// Epilogue of the last HEAD layer of a fused backward chain (tag 8): the COMBINE BACKWARD on the row (include/swn.h comb_*; the arithmetic
-// of write_pieces16_comb / combine_bwd_kernel value for value): with z = the layer's output rounded to the 16-bit type (the gradient of
-// the decoded, gate-scaled, ReLU'd expert output y),  t = (z + dsig[row] * wsig) * (y[row] > 0);  the row becomes t * gate[row] (the
-// gradient of the expert output: the next layer's input and layers[head_layers - 1].save);  the lane's share of <y[row], t> goes to
-// T_SIGP for the gate gradient.  y is read from memory through the rows' tokens (8 bytes per lane, row and 8-feature group), one half
-// step ahead of its use.
-template <typename E, typename HOOK>
-__device__ __forceinline__ void epilogue_q_comb(f32x16_t (&acc)[4][2], const Ctx& cx, const char* y, uint32_t y_bytes, int idx_off, HOOK hook) {
+// The COMBINE BACKWARD of a fused backward chain (tag 8), in place on a row group's rows of the LDS tile behind the last head layer
+// (include/swn.h comb_*; write_pieces16_comb's arithmetic value for value and in its summation order - the result, the gate gradient
+// included, is bit-identical to the separate launches): with z = the row (the gradient of the decoded, gate-scaled, ReLU'd expert output y),
+//   t = (z + dsig[row] * wsig) * (y[row] > 0);   row <- t * gate[row];   dgate[token] = <y[row], t> / gate[row]
+// A wave takes the pieces it stages (fg + 4 j: tile rows 2 c + lhi); a half-wave holds one row, lane l31 its 8 features 8 l31 ..: y is
+// read from memory in whole 512-byte rows through the rows' tokens.  (A first version applied the combine in the accumulator layout of
+// the layer's epilogue and read y in 8-byte pieces - 32 rows per load instruction: 0.33 ms of the launch, profiles/r04_experiments.md 19.)
+template <typename E>
+__device__ __forceinline__ void comb_pieces16_inplace(const Ctx& cx, int c0, const swn_chain_desc& d, int idx_off, int rows) {
   char* smem = cx.smem;
-  uint32_t e2_base = cx.e2_base;
-  asm volatile("" : "+v"(e2_base));
-  const int fg = cx.w & 3;
-  const int row0 = 128 * (cx.w >> 2) + cx.l31;
-  const __amdgpu_buffer_rsrc_t ry = uniform_rsrc(y, (int)y_bytes);
-  uint32_t yo[4];                           // byte offset of the lane's first 4 features of its row mi in y
+  const int* idx = (const int*)(smem + idx_off);
+  float wv[8];
+  {
+    const f32x4_t w0 = *(const f32x4_t*)(smem + T_WS + cx.l31 * 32), w1 = *(const f32x4_t*)(smem + T_WS + cx.l31 * 32 + 16);
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-    yo[mi] = (uint32_t)((const int*)(smem + idx_off))[row0 + 32 * mi] * (uint32_t)ROWB + (uint32_t)((fg * 64 + 4 * cx.lhi) * 2);
-  float dot[4] = {0.f, 0.f, 0.f, 0.f};
-  u32x2_t yq[4];
-  auto fetch = [&](int t) {                 // (into the ONE buffer, right behind its last use: the loads travel under the half step's
-    const int ni = t >> 2, mi = t & 3;      //  exchange, LDS writes and write-out hook)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) yq[g4] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(ry, yo[mi], (32 * ni + 8 * g4) * 2, 0));
-  };
-  fetch(0);
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    f32x4_t ws[4];
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) ws[g4] = *(const f32x4_t*)(smem + T_WS + ((fg * 64 + 32 * ni + 8 * g4 + 4 * cx.lhi) << 2));
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int t = 4 * ni + mi;
-      const float gt = *(const float*)(smem + T_GATE + (row0 + 32 * mi) * 4), ds = *(const float*)(smem + T_DSIG + (row0 + 32 * mi) * 4);
-      uint32_t pp[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) pp[k] = E::pack2(acc[mi][ni][(k >> 1) * 4 + 2 * (k & 1)], acc[mi][ni][(k >> 1) * 4 + 2 * (k & 1) + 1]);
-      SWN_PIN();
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int g4 = k >> 1, i = k & 1;
-        const float y0 = E::lo(yq[g4][i]), y1 = E::hi(yq[g4][i]);
-        float t0 = __builtin_fmaf(ds, ws[g4][2 * i], E::lo(pp[k])), t1 = __builtin_fmaf(ds, ws[g4][2 * i + 1], E::hi(pp[k]));
-        t0 = y0 > 0.f ? t0 : 0.f;
-        t1 = y1 > 0.f ? t1 : 0.f;
-        dot[mi] = __builtin_fmaf(y0, t0, dot[mi]);
-        dot[mi] = __builtin_fmaf(y1, t1, dot[mi]);
-        pp[k] = E::pack2(t0 * gt, t1 * gt);
-      }
-      asm volatile("" : "+v"(dot[mi]));      // (the sum is wanted HERE: left alone the compiler sinks the whole fma chain to the store at the
-                                             //  end of the epilogue and keeps - spills - every y and t value until then)
-      SWN_PIN();
-      if (t + 1 < 8) fetch(t + 1);
-      SWN_PIN();
-#pragma unroll
-      for (int g = 0; g < 4; g += 2) {
-        auto r0 = __builtin_amdgcn_permlane32_swap(pp[g * 2], pp[(g + 1) * 2], false, false);
-        auto r1 = __builtin_amdgcn_permlane32_swap(pp[g * 2 + 1], pp[(g + 1) * 2 + 1], false, false);
-        const u32x4_t o = {(uint32_t)r0[0], (uint32_t)r1[0], (uint32_t)r0[1], (uint32_t)r1[1]};
-        *(u32x4_t*)(smem + (e2_base ^ (uint32_t)((4 * ni + g) << 4)) + mi * (32 * ROWB)) = o;
-      }
-      SWN_PIN();
-      if constexpr (hook_halves<HOOK>::value) hook(t);
-      else if (t & 1) hook(t >> 1);
-    }
+    for (int e = 0; e < 4; ++e) { wv[e] = w0[e]; wv[4 + e] = w1[e]; }
   }
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) *(float*)(smem + T_SIGP + (((fg * 2 + cx.lhi) * 256 + row0 + 32 * mi) << 2)) = dot[mi];
+  for (int b = 0; b < 2; ++b) {
+    u32x4_t v[8], yc[8];
+    float gt[8], ds[8];
+    long tok[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = 2 * (c0 + 4 * (8 * b + j)) + cx.lhi;
+      tok[j] = idx[r];
+      gt[j] = *(const float*)(smem + T_GATE + r * 4);
+      ds[j] = *(const float*)(smem + T_DSIG + r * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) yc[j] = *(const u32x4_t*)((const char*)d.comb_y + tok[j] * ROWB + cx.l31 * 16);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *(const u32x4_t*)(smem + piece_addr(cx, c0 + 4 * (8 * b + j)));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = 2 * (c0 + 4 * (8 * b + j)) + cx.lhi;
+      float z[8], yv[8], dot = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        z[2 * q] = E::lo(v[j][q]); z[2 * q + 1] = E::hi(v[j][q]);
+        yv[2 * q] = E::lo(yc[j][q]); yv[2 * q + 1] = E::hi(yc[j][q]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = z[e] + ds[j] * wv[e];          // (one fma, like combine_bwd_kernel)
+        t = yv[e] > 0.f ? t : 0.f;
+        dot += yv[e] * t;
+        z[e] = t * gt[j];
+      }
+      for (int o = 16; o >= 1; o >>= 1) dot += __shfl_xor(dot, o);
+      if (cx.l31 == 0 && r < rows) d.comb_dgate[tok[j]] = dot / gt[j];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[j][q] = E::pack2(z[2 * q], z[2 * q + 1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *(u32x4_t*)(smem + piece_addr(cx, c0 + 4 * (8 * b + j))) = v[j];
+    SWN_PIN();
+  }
 }
 
 // Epilogue of the LAST layer of a fused chain (Linear "2" over cat([h, PE(dir), embedding_a]), nerf_moe.py:419-429): the per-ray half
@@ -1366,7 +1355,11 @@ __device__ __forceinline__ void epilogue_q_rowbias(f32x16_t (&acc)[4][2], const 
     const int ni = t >> 2, mi = t & 3;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4)
+#ifdef SWN_ABL_NORB     // (experiment: what the per-ray bias gather of the last layer's epilogue costs)
+      bq[t & 1][g4] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#else
       bq[t & 1][g4] = rb[mi] ? *(const f32x4_t*)(rb[mi] + 32 * ni + 8 * g4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+#endif
   };
   fetch(0);
 #pragma unroll
@@ -1722,17 +1715,6 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
       if (tid < 256) ((float*)(smem + T_WS))[tid] = d.heads_ws[tid];
     }
   }
-  auto head_out = [&](const Ctx& c_, const Tile& t, int idx_off) {
-    // backward: the gate gradient of the finished tile's rows, dgate[token] = <y, t> / gate (the eight partial sums of the combine
-    // epilogue; a wave finishes the rows it stages: 8 j + 2 fg + {0, 1})
-    const int r = 128 * (c_.w >> 2) + 8 * (c_.l31 >> 1) + 2 * (c_.w & 3) + (c_.l31 & 1);
-    if (c_.lhi == 0 && r < t.rows) {
-      const long tok = ((const int*)(smem + idx_off))[r];
-      const float* sp = (const float*)(smem + T_SIGP) + r;
-      const float dot = ((sp[0] + sp[256]) + (sp[512] + sp[768])) + ((sp[1024] + sp[1280]) + (sp[1536] + sp[1792]));
-      d.comb_dgate[tok] = dot / d.comb_gate[tok];      // (the gate value from memory: the LDS table may already hold the next tile's)
-    }
-  };
   if constexpr (HEAD) {
     if (tid < 256) ((float*)(smem + T_WS))[tid] = d.comb_wsig ? d.comb_wsig[tid] : 0.f;
   }
@@ -1775,7 +1757,6 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         } else if (HEAD && prev.l1 < n_layers) {
           // (a tile of dropped tokens has no output rows; its gate gradients were zeroed when it was staged)
         } else {
-          if constexpr (HEAD) head_out(cs, prev, idx_nxt);
           const __amdgpu_buffer_rsrc_t ry = out_rs(d.y, prev);
           const __amdgpu_buffer_rsrc_t ra = d.y_add ? out_rs((void*)d.y_add, prev) : ry;
           if constexpr (TAG == 5) {      // (only this instantiation carries the fused combine backward)
@@ -1923,9 +1904,6 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         const bool gate_l = TAIL && L + 1 == d.tail_first, rb_l = TAIL && last;
         auto run_epi = [&](auto hook) {
           typedef decltype(hook) HK;
-          if constexpr (HEAD) {
-            if (L + 1 == d.head_layers && cur.l1 == n_layers) { epilogue_q_comb<E, HK>(acc, ce, (const char*)d.comb_y, oob_s, idx_cur, hook); return; }
-          }
           if constexpr (TAIL) {
             if (gate_l) { epilogue_q_gate<E, HK>(acc, ce, d.heads_raw != nullptr, hook); return; }
             if (rb_l) { epilogue_q_rowbias<E, HK>(acc, ce, ly.rowbias, ly.rows_per_bias, yf, idx_cur, hook); return; }
@@ -1979,6 +1957,22 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         }
         if (ly.relu == 1 && mkp) *(u32x4_t*)mkp = mk;
         SWN_PIN();
+        if constexpr (HEAD) {
+          if (L + 1 == d.head_layers && cur.l1 == n_layers) {
+            // ---- the combine backward on this row group's rows, in place (see comb_pieces16_inplace): the four waves have written the
+            //      layer's output rows - meet (the row groups' own counter: no workgroup barrier inside a phase), then every wave takes
+            //      the rows it stages ----
+            ++n_skip;
+            SWN_WAIT_LGKM0();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (ce.lane == 0) __hip_atomic_fetch_add(&gcount[rge], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&gcount[rge], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < 4 * n_skip)
+              __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            comb_pieces16_inplace<E>(ce, 64 * rge + fge, d, idx_cur, cur.rows);
+          }
+        }
+        SWN_PIN();
         if (!last) preload_w(L + 1, ws_of(L + 1, cur), ce.lane);      // (last layer: the S phase that follows loads the next tile's first fragments)
         else if (nxt.vb >= 0) store_row(row_nxt, idx_nxt);
         if (last && d.y_add_gather && d.y_add) {
@@ -2009,7 +2003,6 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     tail_out(cf, prev, ((it - 1) & 1) ? Q_IDX1 : G::IDX0);
   } else if (HEAD && prev.l1 < n_layers) {
   } else {
-    if constexpr (HEAD) head_out(cf, prev, ((it - 1) & 1) ? Q_IDX1 : G::IDX0);
     const __amdgpu_buffer_rsrc_t ry = out_rs(d.y, prev);
     const __amdgpu_buffer_rsrc_t ra = d.y_add ? out_rs((void*)d.y_add, prev) : ry;
     if constexpr (TAG == 5) {
