@@ -1204,7 +1204,9 @@ constexpr int T_GATE = G256::RING0;        // f32 [256]: gate value of every til
 constexpr int T_WS = T_GATE + 1024;        // f32 [256]: sigma head weights
 constexpr int T_SIGP = T_WS + 1024;        // f32 [8][256]: partial sums of the sigma head, [wave quarter * 2 + half-wave][tile row]
 constexpr int T_COL = T_SIGP + 8192;       // f32 [3][256]: the colour head's dot products of every tile row
-static_assert(T_COL + 3072 <= G256::IDX0, "tail tables must fit the ring region");
+constexpr int T_WC = T_COL + 3072;         // f32 [3][128]: colour head weights
+constexpr int T_HB = T_WC + 1536;          // f32 [4]: the heads' biases (colour 0..2, sigma)
+static_assert(T_HB + 16 <= G256::IDX0, "tail tables must fit the ring region");
 constexpr int T_DSIG = T_COL;              // (tag 8) f32 [256]: the sigma head's gradient of every tile row
 
 // Epilogue of the LAST EXPERT layer of a fused chain: the row becomes relu(gate[row] * z) - z rounded to the 16-bit type first, the
@@ -1394,8 +1396,8 @@ __device__ __forceinline__ void epilogue_q_rowbias(f32x16_t (&acc)[4][2], const 
 // still to be read), four at a time (lane -> row 8 (2 i + lane / 32) + 2 fg + (lane / 16 & 1), 16-byte chunk lane % 16: every lane
 // carries data, 8 stores per wave instead of the 16 half-empty ones of the 512-byte pieces); a lane multiplies its 8 features by the
 // three colour rows, a butterfly over the row's 16 lanes (quad swaps, half mirror, mirror) gives <h2, w_c> -> T_COL[c][row].
-template <typename E>
-__device__ __forceinline__ void write_rows128_tok(const Ctx& cx, void* y, uint32_t oob, const float* wc, int idx_off, int rows, bool heads) {
+template <typename E, typename PRE>
+__device__ __forceinline__ void write_rows128_tok(const Ctx& cx, void* y, uint32_t oob, const float* wc, int idx_off, int rows, bool heads, PRE pre) {
   char* smem = cx.smem;
   const int* idx = (const int*)(smem + idx_off);
   const int l15 = cx.lane & 15, rq = cx.lane >> 4;
@@ -1406,7 +1408,7 @@ __device__ __forceinline__ void write_rows128_tok(const Ctx& cx, void* y, uint32
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int q = 0; q < 2; ++q) w[c][q] = *(const f32x4_t*)(wc + c * 128 + l15 * 8 + 4 * q);
+      for (int q = 0; q < 2; ++q) w[c][q] = *(const f32x4_t*)(smem + T_WC + ((c * 128 + l15 * 8 + 4 * q) << 2));
   }
   u32x4_t v[8];
   int tk[8];
@@ -1417,11 +1419,11 @@ __device__ __forceinline__ void write_rows128_tok(const Ctx& cx, void* y, uint32
     tk[i] = idx[r];
   }
   SWN_WAIT_LGKM0();
-  if (y) {
+  pre();                 // (the caller's loads go in front of the stores: one in-order counter for both)
+  // (no y: a descriptor of 0 bytes drops the stores - unconditional, so that the wait for the caller's load counts them on every path)
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      __builtin_amdgcn_raw_buffer_store_b128(v[i], rs, rbase + 16 * i < rows ? (uint32_t)tk[i] * 256u + (uint32_t)(l15 * 16) : oob, 0, SWN_BIG_Y_AUX);
-  }
+  for (int i = 0; i < 8; ++i)
+    __builtin_amdgcn_raw_buffer_store_b128(v[i], rs, rbase + 16 * i < rows ? (uint32_t)tk[i] * 256u + (uint32_t)(l15 * 16) : oob, 0, SWN_BIG_Y_AUX);
   if (heads) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -1665,21 +1667,31 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     // a wave finishes the 32 rows it wrote out itself (lanes 0 .. 31: one row each, rows 8 j + 2 fg + {0, 1}) - no one else's LDS
     // writes are involved
     const bool hd = d.heads_raw != nullptr;
-    write_rows128_tok<E>(c_, d.y, oob_y, d.heads_wc, idx_off, t.rows, hd);
+    // (the finalizing lane's token and its sigma noise are fetched BEFORE the write-out's stores: loads and stores retire through one
+    //  in-order counter on this part - a load issued behind the stores is waited for with all of them, the round trip of the tile's
+    //  write-out in front of the staging; issued first it costs a wait that leaves the 8 stores in flight)
+    const int r = 128 * (c_.w >> 2) + 8 * (c_.l31 >> 1) + 2 * (c_.w & 3) + (c_.l31 & 1);
+    const bool fin = hd && c_.lhi == 0 && r < t.rows;
+    const long tok = fin ? ((const int*)(smem + idx_off))[r] : 0;
+    float nz = 0.f;
+    write_rows128_tok<E>(c_, d.y, oob_y, d.heads_wc, idx_off, t.rows, hd, [&]() { if (hd && d.heads_noise) nz = d.heads_noise[tok]; });
     if (hd) {
       SWN_WAIT_LGKM0();
-      const int r = 128 * (c_.w >> 2) + 8 * (c_.l31 >> 1) + 2 * (c_.w & 3) + (c_.l31 & 1);
-      if (c_.lhi == 0 && r < t.rows) {
-        const long tok = ((const int*)(smem + idx_off))[r];
+      if (fin) {
         const float* sp = (const float*)(smem + T_SIGP) + r;
         const float* cp = (const float*)(smem + T_COL) + r;
         const float sg = ((sp[0] + sp[256]) + (sp[512] + sp[768])) + ((sp[1024] + sp[1280]) + (sp[1536] + sp[1792]));
-        const float u = sg + d.heads_bs[0] + (d.heads_noise ? d.heads_noise[tok] : 0.f) - 1.f;      // ShiftedSoftplus, models/nerf.py:68-69
+        const f32x4_t hb = *(const f32x4_t*)(smem + T_HB);
+        const float u = sg + hb[3] + nz - 1.f;      // ShiftedSoftplus, models/nerf.py:68-69
         f32x4_t o;
-        o[0] = 1.f / (1.f + expf(-(cp[0] + d.heads_bc[0])));
-        o[1] = 1.f / (1.f + expf(-(cp[256] + d.heads_bc[1])));
-        o[2] = 1.f / (1.f + expf(-(cp[512] + d.heads_bc[2])));
-        o[3] = u > 20.f ? u : log1pf(expf(u));
+        // (hardware exp2 / log2 / rcp: ~2 ulp each, far inside the 16-bit rows they are computed from; the library forms keep
+        //  a dozen constants alive across the whole tile loop - spilled, and reloaded here behind a wait for the stores above)
+        o[0] = __builtin_amdgcn_rcpf(1.f + __expf(-(cp[0] + hb[0])));
+        o[1] = __builtin_amdgcn_rcpf(1.f + __expf(-(cp[256] + hb[1])));
+        o[2] = __builtin_amdgcn_rcpf(1.f + __expf(-(cp[512] + hb[2])));
+        const float eu = __expf(fminf(u, 20.f));
+        const float lp = eu < 1e-3f ? eu * (1.f - eu * (0.5f - eu * (1.f / 3.f))) : __logf(1.f + eu);     // log1p(e^u)
+        o[3] = u > 20.f ? u : lp;
         *(f32x4_t*)(d.heads_raw + tok * 4) = o;
       }
     }
@@ -1713,6 +1725,8 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
   if constexpr (TAIL) {
     if (d.heads_raw) {      // the heads' weights (fp32) for the epilogues of the gate layer and of the last layer
       if (tid < 256) ((float*)(smem + T_WS))[tid] = d.heads_ws[tid];
+      if (tid < 384) ((float*)(smem + T_WC))[tid] = d.heads_wc[tid];
+      if (tid < 4) ((float*)(smem + T_HB))[tid] = tid < 3 ? d.heads_bc[tid] : d.heads_bs[0];
     }
   }
   if constexpr (HEAD) {

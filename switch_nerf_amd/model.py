@@ -729,11 +729,14 @@ class SwitchNeRF:
             # a ragged last model chunk (rendering.py:354-383 trains any batch size): the whole chunks and the short last chunk were
             # routed as two contexts with their own capacities; each runs its own backward on its rows of dL/d raw and its chunks'
             # share of the l_aux gradient
-            if self.hash is not None:
-                raise NotImplementedError("hash-grid encoding with a ragged last model chunk: make N_rays * samples a multiple of model_chunk_size")
             a, b = c["parts"]
+            if self.hash is not None:      # the parts leave dL/d encoding in their rows of one [P, KP] buffer; the table's gradient is
+                d_enc = self._buf(c["tag"] + ":d_enc", (c["P"], self.KP), self.dtype)       # one launch over the whole rays behind them
+                a["d_enc_out"], b["d_enc_out"] = d_enc[: a["P"]], d_enc[a["P"]:]
             self.backward_net(a, d_raw[: a["P"]], d_laux[: a["n_seg"]].contiguous())
             self.backward_net(b, d_raw[a["P"]:], d_laux[a["n_seg"]:].contiguous())
+            if self.hash is not None:
+                ops.hash_encode_bwd(c["rays"], c["z"], d_enc, self.hash, self.g["hash.table"])
             return
         self.backward_net_b(self.backward_net_a(c, d_raw, d_laux))
 
@@ -929,9 +932,13 @@ class SwitchNeRF:
                                         (c["h0"], dza1, g["gate0.w"].view(1, M, G), g["gate0.b"].view(1, G)),
                                         (c["pe"], dh0, g["xyz.w"].view(1, self.KP, M), g["xyz.b"].view(1, M))], nsp)
         if self.hash is not None:          # dL/d encoding = dh0 W_xyz^T, scattered into the hash table's gradient
-            d_enc = _b("d_enc", (P, self.KP), dt)
+            d_enc = c.get("d_enc_out")     # (a part of a ragged batch: its rows of the batch's buffer - backward_net scatters them)
+            part = d_enc is not None
+            if not part:
+                d_enc = _b("d_enc", (P, self.KP), dt)
             o.mlp_chain(dh0, [o.Layer(self.wb["xyz"], None)], d_enc, tag=0)
-            o.hash_encode_bwd(c["rays"], c["z"], d_enc, self.hash, g["hash.table"])
+            if not part:
+                o.hash_encode_bwd(c["rays"], c["z"], d_enc, self.hash, g["hash.table"])
         if side_done is not None:
             torch.cuda.current_stream().wait_event(side_done)
 
