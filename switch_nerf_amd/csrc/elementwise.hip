@@ -687,19 +687,40 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const T* __restrict__ y,
   using RY = Row16<T, M>;
   using RH = Row16<T, H2>;
   const int j = threadIdx.x & 15;
-  float wcv[3][RH::VPL], aws[RY::VPL], awc[3][RH::VPL], abs_ = 0.f, abc[3] = {0.f, 0.f, 0.f};
+  float aws[RY::VPL], awc[3][RH::VPL], abs_ = 0.f, abc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    RH::loadf(wc + c * H2, j, wcv[c]);
 #pragma unroll
     for (int v = 0; v < RH::VPL; ++v) awc[c][v] = 0.f;
   }
+  // the colour weights live in LDS and are read per row: in registers (24 per lane) they cost the kernel its fourth wave per SIMD -
+  // one row per 16-lane group is 3 KB in flight per wave, and 12 waves per CU do not cover the memory latency (496 -> 444 us)
+  __shared__ float wc_lds[3][16][RH::VPL];      // [colour][lane of the row's 16][value]: the lane's weights in its own value order
+  if (threadIdx.x < 16) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float t_[RH::VPL];
+      RH::loadf(wc + c * H2, threadIdx.x, t_);
+#pragma unroll
+      for (int v = 0; v < RH::VPL; ++v) wc_lds[c][threadIdx.x][v] = t_[v];
+    }
+  }
+  __syncthreads();
 #pragma unroll
   for (int v = 0; v < RY::VPL; ++v) aws[v] = 0.f;
   float o[RH::VPL];
-  auto row = [&](long i) {
-    const float4 r = *(const float4*)(raw + i * 4);
-    const float4 d = *(const float4*)(d_raw + i * 4);
+  // a row's operands as loaded (all loads of a row issued before the first is unpacked; fetching the NEXT row ahead as well was
+  // measured: 174-198 registers, two waves per SIMD, 457 us against 444)
+  struct RowIn { float4 r, d; uint4 yr[RY::NCH], hr[RH::NCH]; };
+  auto fetch = [&](long i, RowIn& in) {
+    in.r = *(const float4*)(raw + i * 4);
+    in.d = *(const float4*)(d_raw + i * 4);
+    RY::load_raw(y + i * M, j, in.yr);
+    RH::load_raw(h2 + i * H2, j, in.hr);
+  };
+  auto row = [&](long i, const RowIn& in) {
+    const float4 r = in.r;
+    const float4 d = in.d;
     const float dc0 = d.x * r.x * (1.f - r.x), dc1 = d.y * r.y * (1.f - r.y), dc2 = d.z * r.z * (1.f - r.z);
     const float dsp = d.w * -expm1f(-r.w);  // softplus'(u) = sigmoid(u) = 1 - exp(-softplus(u)); expm1: no cancellation for near-empty samples
     if (j == 0) {
@@ -707,14 +728,15 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const T* __restrict__ y,
       abs_ += dsp; abc[0] += dc0; abc[1] += dc1; abc[2] += dc2;
     }
     float yv[RY::VPL], hv[RH::VPL];
-    RY::load(y + i * M, j, yv);
-    RH::load(h2 + i * H2, j, hv);
+    asm volatile("" ::: "memory");        // (keeps the LDS reads of the colour weights inside the row loop: hoisted they are registers again)
+    RY::unpack(in.yr, yv);
+    RH::unpack(in.hr, hv);
 #pragma unroll
     for (int v = 0; v < RY::VPL; ++v) aws[v] += dsp * yv[v];
 #pragma unroll
     for (int v = 0; v < RH::VPL; ++v) {
       awc[0][v] += dc0 * hv[v]; awc[1][v] += dc1 * hv[v]; awc[2][v] += dc2 * hv[v];
-      const float gg = dc0 * wcv[0][v] + dc1 * wcv[1][v] + dc2 * wcv[2][v];
+      const float gg = dc0 * wc_lds[0][j][v] + dc1 * wc_lds[1][j][v] + dc2 * wc_lds[2][j][v];
       o[v] = hv[v] > 0.f ? gg : 0.f;
     }
     RH::store(dh2 + i * H2, j, o);
@@ -732,7 +754,9 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const T* __restrict__ y,
 #pragma unroll
     for (int v = 0; v < RH::VPL; ++v) cs[v] = 0.f;
     for (long r = r0; r < rows; r += rstep) {
-      row(u * rows + r);
+      RowIn cur_in;
+      fetch(u * rows + r, cur_in);
+      row(u * rows + r, cur_in);
       if constexpr (sizeof(T) == 2) {
 #pragma unroll
         for (int v = 0; v < RH::VPL; v += 2) {           // what the store kept: the values rounded to T
