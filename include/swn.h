@@ -165,7 +165,8 @@ int swn_heads_fwd(const void* y, const void* h2, int dtype, const float* w_sigma
                   int model_dim, int h2_dim, float* raw, void* stream);
 /* Backward: dh2, dsig (per point) and the four parameter gradients ACCUMULATED (+=) into d_w_sigma[M], d_b_sigma[1], d_w_color[3,H2],
  * d_b_color[3].  The parameter gradients are block partial sums in `workspace` (swn_heads_bwd_workspace_bytes) added in a fixed order:
- * the same bits on every run.                                                                                       */
+ * the same bits on every run.  y == NULL: the sigma weight gradient is not formed here (d_w_sigma receives + 0; a fused backward
+ * chain forms it where y is read anyway: swn_chain_desc.comb_dwsig) - the launch then reads 512 bytes per point less.           */
 size_t swn_heads_bwd_workspace_bytes(int n_points, int model_dim, int h2_dim);
 int swn_heads_bwd(const void* y, const void* h2, int dtype, const float* w_color, const float* raw,
                   const float* d_raw, int n_points, int model_dim, int h2_dim, void* dh2, float* dsig,
@@ -338,6 +339,15 @@ typedef struct swn_chain_desc {
   const float* comb_wsig;
   const float* comb_gate;
   float* comb_dgate;
+  /* (head_layers > 0 only) The sigma head's WEIGHT gradient from the same pass - the combine backward holds comb_y[row] and
+     comb_dsig[row] of every kept token in registers:  comb_dwsig[f] += sum over the tokens of comb_dsig[token] * comb_y[token][f]
+     (fp32 [256]; nerf_moe.py:393-400 sigma = Linear(256, 1): its weight.grad; the dropped tokens' y is zero).  Summed in a FIXED order
+     whatever workgroup ran a tile: a wave leaves the sum of its 32 rows in comb_dwsig_ws[(tile * 8 + wave)][256], the launch then adds
+     the rows up in order (two small kernels behind the chain kernel).  comb_dwsig_ws: fp32 workspace of
+     swn_chain_dwsig_workspace_bytes(n_groups, group_rows_clamp) bytes (zeroed by the launch); both NULL = not computed (swn_heads_bwd
+     forms the gradient from y then).                                                                                              */
+  float* comb_dwsig;
+  float* comb_dwsig_ws;
   /* Sigma / colour heads fused into the tail FORWARD chain (heads_raw != NULL; tag must be 4, geometry 0 / 1): with y = the staged
      chain input row (gathered, gate-scaled, ReLU'd: what x_save would hold) and h2 = the last layer's output row,
        heads_raw[row] = (sigmoid(<h2, heads_wc[c]> + heads_bc[c]) c < 3, softplus(<y, heads_ws> + heads_bs[0] + heads_noise[row] - 1))
@@ -391,6 +401,8 @@ typedef struct swn_chain_desc {
 } swn_chain_desc;
 
 int swn_mlp_chain(const swn_chain_desc* desc, void* stream);
+/* bytes of swn_chain_desc.comb_dwsig_ws for a fused backward chain over n_groups groups of at most group_rows_clamp rows */
+size_t swn_chain_dwsig_workspace_bytes(int n_groups, int group_rows_clamp);
 /* 1 if the chain can run on the 256-row geometry (geometry = 2) */
 int swn_chain_big_ok(const swn_chain_desc* desc);
 /* rows per workgroup tile for dtype (sizes the ReLU mask buffers: ceil(group_stride / rows) * n_groups * rows * 8 words) */

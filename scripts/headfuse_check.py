@@ -71,6 +71,20 @@ print("dgate max rel diff:", ((a[2] - b[2]).abs().max() / a[2].abs().max()).item
 for l in range(L - 1):
     print(f"dz{l} identical:", torch.equal(a[3][l], b[3][l]))
 print("dx identical:", torch.equal(a[4], b[4]))
+# the sigma head's weight gradient from the same launch (comb_dwsig): += into a vector holding 1.0, twice (fixed order: identical bits)
+dws = [torch.ones(M, device=dev) for _ in range(2)]
+for t_ in dws:
+    dgm2 = torch.zeros(P, device=dev); dz2 = [torch.zeros(rows, M, dtype=dt, device=dev) for _ in range(L - 1)]
+    o.mlp_chain(dh2, [o.Layer(w2bpad, None, save=torch.zeros(P, M, dtype=dt, device=dev)), o.Layer(w1b, None, save=torch.zeros(rows, M, dtype=dt, device=dev))]
+                + expert_bwd(dz2), torch.zeros(rows, M, dtype=dt, device=dev), y_add=dz2[3], tag=8, geometry=7, x_features=H2,
+                combine=(y, dsig, wsig, gmax, dgm2, t_), head=(2, drop_begin, dropped), **kw)
+kept = (tok2row >= 0)
+ref = 1.0 + (dsig.double()[:, None] * y.double() * kept[:, None]).sum(0)
+err = ((dws[0].double() - ref).abs().max() / ref.abs().max()).item()
+print("dwsig rel err vs fp64:", err, " two launches identical:", torch.equal(dws[0], dws[1]), " dgate identical to the launch without it:", torch.equal(dgm2, b[2]))
+assert err < 1e-5 and torch.equal(dws[0], dws[1]) and torch.equal(dgm2, b[2])
+if timing:
+    print("with comb_dwsig:", end=" ")
 if timing:
     def bench(fn, n=5):
         fn(); torch.cuda.synchronize()
@@ -90,4 +104,7 @@ if timing:
     t_exp = bench(lambda: o.mlp_chain(dout, expert_bwd(dz), dx, y_add=dz[3], tag=2, geometry=7, **kw))
     t_fus = bench(lambda: o.mlp_chain(dh2, [o.Layer(w2bpad, None, save=dh1), o.Layer(w1b, None, save=dzl)] + expert_bwd(dz), dx, y_add=dz[3], tag=8,
                                       geometry=7, x_features=H2, combine=(y, dsig, wsig, gmax, dgm), head=(2, drop_begin, dropped), **kw))
-    print(f"tail backward {t_tail:.3f} ms + expert backward {t_exp:.3f} ms = {t_tail + t_exp:.3f};  fused {t_fus:.3f} ms")
+    dwt = torch.zeros(M, device=dev)
+    t_fus2 = bench(lambda: o.mlp_chain(dh2, [o.Layer(w2bpad, None, save=dh1), o.Layer(w1b, None, save=dzl)] + expert_bwd(dz), dx, y_add=dz[3], tag=8,
+                                       geometry=7, x_features=H2, combine=(y, dsig, wsig, gmax, dgm, dwt), head=(2, drop_begin, dropped), **kw))
+    print(f"tail backward {t_tail:.3f} ms + expert backward {t_exp:.3f} ms = {t_tail + t_exp:.3f};  fused {t_fus:.3f} ms;  fused + comb_dwsig (fill, run sums, reduce included) {t_fus2:.3f} ms")

@@ -40,7 +40,7 @@ class ChainDesc(C.Structure):
     _fields_ = [("dtype", i32), ("n_layers", i32), ("n_groups", i32), ("n_wsets", i32), ("group_stride", i32),
                 ("group_rows", vp), ("group_rows_clamp", i32), ("group_begin", vp), ("x", vp), ("x_gather", vp), ("x_save", vp), ("x_scale", vp), ("x_relu", i32),
                 ("y", vp), ("y_add", vp), ("y_add_gather", vp), ("geometry", i32), ("tag", i32),
-                ("comb_y", vp), ("comb_dsig", vp), ("comb_wsig", vp), ("comb_gate", vp), ("comb_dgate", vp),
+                ("comb_y", vp), ("comb_dsig", vp), ("comb_wsig", vp), ("comb_gate", vp), ("comb_dgate", vp), ("comb_dwsig", vp), ("comb_dwsig_ws", vp),
                 ("heads_ws", vp), ("heads_bs", vp), ("heads_wc", vp), ("heads_bc", vp), ("heads_noise", vp), ("heads_raw", vp), ("sched", vp), ("x_features", i32),
                 ("head_layers", i32), ("tail_first", i32), ("y_features", i32), ("tail_gate", vp), ("tail_dropped", vp), ("tail_n_dropped", vp),
                 ("tail_dropped_max", i32), ("tail_tokens", i32),
@@ -146,6 +146,8 @@ def load():
     lib.swn_heads_bwd_workspace_bytes.argtypes = [i32, i32, i32]
     lib.swn_ray_feat_wgrad_workspace_bytes.restype = sz
     lib.swn_ray_feat_wgrad_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.swn_chain_dwsig_workspace_bytes.restype = sz
+    lib.swn_chain_dwsig_workspace_bytes.argtypes = [i32, i32]
     lib.swn_chain_mask_words.restype = i64
     lib.swn_chain_mask_words.argtypes = [i32, i32, i32, i32]
     for name, args in SIGNATURES.items():

@@ -1092,6 +1092,8 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
   }
   SWN_CHECK(d.tag >= 0 && d.tag <= 8, "swn_mlp_chain: tag %d not in [0,8]", d.tag);
   SWN_CHECK(d.head_layers == 0 || (d.geometry == 7 && d.tag == 8), "swn_mlp_chain: head layers (head_layers > 0) run on geometry 7 with tag 8");
+  SWN_CHECK(!d.comb_dwsig == !d.comb_dwsig_ws && (!d.comb_dwsig || (d.head_layers > 0 && d.comb_y && d.comb_dsig)),
+            "swn_mlp_chain: comb_dwsig and comb_dwsig_ws come together, with the combine backward of a fused backward chain (head_layers > 0, comb_y, comb_dsig)");
   SWN_CHECK(d.tag != 8 || d.head_layers > 0, "swn_mlp_chain: tag 8 is the expert backward chain behind the tail's backward layers (head_layers > 0)");
   SWN_CHECK(d.tail_first == 0 || (d.geometry == 7 && d.tag == 7), "swn_mlp_chain: a fused tail (tail_first > 0) runs on geometry 7 with tag 7");
   SWN_CHECK(d.tag != 7 || d.tail_first > 0, "swn_mlp_chain: tag 7 is the fused-tail forward chain (tail_first > 0)");

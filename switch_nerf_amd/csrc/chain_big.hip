@@ -1272,10 +1272,14 @@ __device__ __forceinline__ void epilogue_q_gate(f32x16_t (&acc)[4][2], const Ctx
 // A wave takes the pieces it stages (fg + 4 j: tile rows 2 c + lhi); a half-wave holds one row, lane l31 its 8 features 8 l31 ..: y is
 // read from memory in whole 512-byte rows through the rows' tokens.  (A first version applied the combine in the accumulator layout of
 // the layer's epilogue and read y in 8-byte pieces - 32 rows per load instruction: 0.33 ms of the launch, profiles/r04_experiments.md 19.)
+// dws_part != NULL: the wave also leaves the sum over ITS 32 rows of dsig[row] * y[row][:] (the sigma head's weight gradient,
+// include/swn.h comb_dwsig) in dws_part[256] - a lane adds its 8 features over its 16 rows in loop order, then the two half-waves'
+// sums: the same bits whoever runs the tile.
 template <typename E>
-__device__ __forceinline__ void comb_pieces16_inplace(const Ctx& cx, int c0, const swn_chain_desc& d, int idx_off, int rows) {
+__device__ __forceinline__ void comb_pieces16_inplace(const Ctx& cx, int c0, const swn_chain_desc& d, int idx_off, int rows, float* dws_part) {
   char* smem = cx.smem;
   const int* idx = (const int*)(smem + idx_off);
+  float aw[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float wv[8];
   {
     const f32x4_t w0 = *(const f32x4_t*)(smem + T_WS + cx.l31 * 32), w1 = *(const f32x4_t*)(smem + T_WS + cx.l31 * 32 + 16);
@@ -1307,6 +1311,11 @@ __device__ __forceinline__ void comb_pieces16_inplace(const Ctx& cx, int c0, con
         z[2 * q] = E::lo(v[j][q]); z[2 * q + 1] = E::hi(v[j][q]);
         yv[2 * q] = E::lo(yc[j][q]); yv[2 * q + 1] = E::hi(yc[j][q]);
       }
+      if (dws_part) {                            // (rows past the tile's end repeat its first row: not counted)
+        const float dsm = r < rows ? ds[j] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) aw[e] = __builtin_fmaf(dsm, yv[e], aw[e]);
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float t = z[e] + ds[j] * wv[e];          // (one fma, like combine_bwd_kernel)
@@ -1322,6 +1331,14 @@ __device__ __forceinline__ void comb_pieces16_inplace(const Ctx& cx, int c0, con
 #pragma unroll
     for (int j = 0; j < 8; ++j) *(u32x4_t*)(smem + piece_addr(cx, c0 + 4 * (8 * b + j))) = v[j];
     SWN_PIN();
+  }
+  if (dws_part) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) aw[e] += __shfl_xor(aw[e], 32);
+    if (cx.lhi == 0) {
+      *(f32x4_t*)(dws_part + cx.l31 * 8) = f32x4_t{aw[0], aw[1], aw[2], aw[3]};
+      *(f32x4_t*)(dws_part + cx.l31 * 8 + 4) = f32x4_t{aw[4], aw[5], aw[6], aw[7]};
+    }
   }
 }
 
@@ -1983,7 +2000,8 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
             while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&gcount[rge], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < 4 * n_skip)
               __builtin_amdgcn_s_sleep(2);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            comb_pieces16_inplace<E>(ce, 64 * rge + fge, d, idx_cur, cur.rows);
+            comb_pieces16_inplace<E>(ce, 64 * rge + fge, d, idx_cur, cur.rows,
+                                     d.comb_dwsig_ws ? d.comb_dwsig_ws + ((long)cur.vb * 8 + ce.w) * 256 : nullptr);
           }
         }
         SWN_PIN();
@@ -2170,6 +2188,27 @@ static int n_compute_units() {
   return n;
 }
 
+// comb_dwsig (include/swn.h): the per-wave sums of a fused backward launch, [n_rows][256] fp32, added up in a fixed order - runs of
+// consecutive rows first (this kernel: one column per thread), then the runs (ordered_reduce_kernel).
+__global__ __launch_bounds__(256) void dwsig_runs_kernel(const float* __restrict__ partial, long n_rows, int rows_per_block, float* __restrict__ out) {
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
+  const int t = threadIdx.x;
+  float s = 0.f;
+  long r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(partial + (r + u) * 256 + t);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; r < r1; ++r) s += partial[r * 256 + t];
+  out[(long)blockIdx.x * 256 + t] = s;
+}
+constexpr int DWSIG_RUNS = 1024;
+static long dwsig_ws_rows(int n_groups, int group_rows_clamp) { return (long)cdiv(group_rows_clamp, 256) * n_groups * 8; }
+
 static int chain_persistent_launch(const swn_chain_desc& d, void* stream) {
   using namespace swn_big;
   typedef G256 G;
@@ -2215,9 +2254,24 @@ static int chain_persistent_launch(const swn_chain_desc& d, void* stream) {
 #undef SWN_PICKQ
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
   SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  const long dws_rows = d.comb_dwsig_ws ? (long)a.n_vb_e * 8 : 0;      // (tiles without rows are never visited: their slots stay zero)
+  if (dws_rows) {
+    e = fill_u32_async(d.comb_dwsig_ws, 0u, (size_t)dws_rows * 1024, as_stream(stream));
+    SWN_CHECK(e == hipSuccess, "swn_mlp_chain: comb_dwsig_ws fill: %s", hipGetErrorString(e));
+  }
   void* kargs[] = {(void*)&a};
   e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(G::NT), kargs, Q_LDS, as_stream(stream));
   SWN_CHECK(e == hipSuccess, "swn_mlp_chain (geometry 6 / 7) launch: %s", hipGetErrorString(e));
+  if (dws_rows) {
+    int rpb = cdiv(dws_rows, DWSIG_RUNS);
+    rpb = (rpb + 7) & ~7;
+    const int runs = cdiv(dws_rows, rpb);
+    float* run_sums = d.comb_dwsig_ws + dws_rows * 256;
+    hipLaunchKernelGGL(dwsig_runs_kernel, dim3(runs), dim3(256), 0, as_stream(stream), (const float*)d.comb_dwsig_ws, dws_rows, rpb, run_sums);
+    OrdDst od{{d.comb_dwsig, nullptr, nullptr, nullptr}, {256, 0, 0, 0}};
+    ordered_reduce_async(run_sums, runs, 256, od, true, as_stream(stream));
+    SWN_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -2229,5 +2283,10 @@ int chain_big_launch(const swn_chain_desc& d, void* stream) {
 }
 
 }  // namespace swn
+
+extern "C" size_t swn_chain_dwsig_workspace_bytes(int n_groups, int group_rows_clamp) {
+  if (n_groups <= 0 || group_rows_clamp <= 0) return 0;
+  return (size_t)(swn::dwsig_ws_rows(n_groups, group_rows_clamp) + swn::DWSIG_RUNS) * 1024;
+}
 
 extern "C" int swn_chain_big_ok(const swn_chain_desc* desc) { return desc != nullptr && swn::chain_big_eligible(*desc) ? 1 : 0; }

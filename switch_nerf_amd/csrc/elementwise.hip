@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const T* __restrict__ y,
 // d_raw -> dh2 (masked by h2 > 0), dsig_pre; the block's sums for d_ws, d_wc, d_bs, d_bc -> partial[block].
 // rows_per_group > 0 (P a multiple of it; the samples of a ray): a block walks whole groups and also leaves rowsum[group][:] = the
 // column sums of the group's dh2 rows AS STORED (rounded to T) - the per-ray bias gradient (swn_group_colsum) without reading dh2 back.
-template <typename T, int M, int H2>
+template <typename T, int M, int H2, bool HASY>      // HASY = false: no y, no sigma weight gradient (its 16+ registers are a fifth wave per SIMD)
 __global__ __launch_bounds__(256) void heads_bwd_kernel(const T* __restrict__ y, const T* __restrict__ h2,
                                                         const float* __restrict__ wc, const float* __restrict__ raw,
                                                         const float* __restrict__ d_raw, int P, T* __restrict__ dh2,
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const T* __restrict__ y,
   auto fetch = [&](long i, RowIn& in) {
     in.r = *(const float4*)(raw + i * 4);
     in.d = *(const float4*)(d_raw + i * 4);
-    RY::load_raw(y + i * M, j, in.yr);
+    if constexpr (HASY) RY::load_raw(y + i * M, j, in.yr);      // (y == NULL: d_ws is formed elsewhere - swn_chain_desc.comb_dwsig - and stays untouched here)
     RH::load_raw(h2 + i * H2, j, in.hr);
   };
   auto row = [&](long i, const RowIn& in) {
@@ -727,12 +727,15 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const T* __restrict__ y,
       dsig[i] = dsp;
       abs_ += dsp; abc[0] += dc0; abc[1] += dc1; abc[2] += dc2;
     }
-    float yv[RY::VPL], hv[RH::VPL];
+    float hv[RH::VPL];
     asm volatile("" ::: "memory");        // (keeps the LDS reads of the colour weights inside the row loop: hoisted they are registers again)
-    RY::unpack(in.yr, yv);
-    RH::unpack(in.hr, hv);
+    if constexpr (HASY) {
+      float yv[RY::VPL];
+      RY::unpack(in.yr, yv);
 #pragma unroll
-    for (int v = 0; v < RY::VPL; ++v) aws[v] += dsp * yv[v];
+      for (int v = 0; v < RY::VPL; ++v) aws[v] += dsp * yv[v];
+    }
+    RH::unpack(in.hr, hv);
 #pragma unroll
     for (int v = 0; v < RH::VPL; ++v) {
       awc[0][v] += dc0 * hv[v]; awc[1][v] += dc1 * hv[v]; awc[2][v] += dc2 * hv[v];
@@ -753,10 +756,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const T* __restrict__ y,
     float cs[RH::VPL];
 #pragma unroll
     for (int v = 0; v < RH::VPL; ++v) cs[v] = 0.f;
-    for (long r = r0; r < rows; r += rstep) {
-      RowIn cur_in;
-      fetch(u * rows + r, cur_in);
-      row(u * rows + r, cur_in);
+    auto colsum = [&]() {
       if constexpr (sizeof(T) == 2) {
 #pragma unroll
         for (int v = 0; v < RH::VPL; v += 2) {           // what the store kept: the values rounded to T
@@ -767,6 +767,28 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const T* __restrict__ y,
       } else {
 #pragma unroll
         for (int v = 0; v < RH::VPL; ++v) cs[v] += o[v];
+      }
+    };
+    if constexpr (HASY) {
+      for (long r = r0; r < rows; r += rstep) {
+        RowIn cur_in;
+        fetch(u * rows + r, cur_in);
+        row(u * rows + r, cur_in);
+        colsum();
+      }
+    } else {       // a row is 288 bytes here: two rows' loads in flight per 16-lane group (same rows, same order: the same bits;
+                   // 307 -> 261 us at full size)
+      for (long r = r0; r < rows; r += 2 * rstep) {
+        RowIn in0, in1;
+        const bool two = r + rstep < rows;
+        fetch(u * rows + r, in0);
+        if (two) fetch(u * rows + r + rstep, in1);
+        row(u * rows + r, in0);
+        colsum();
+        if (two) {
+          row(u * rows + r + rstep, in1);
+          colsum();
+        }
       }
     }
     if (grouped) {
@@ -1376,8 +1398,8 @@ extern "C" int swn_heads_bwd(const void* y, const void* h2, int dtype, const flo
                              float* d_w_sigma, float* d_b_sigma, float* d_w_color, float* d_b_color, int rows_per_group,
                              float* group_colsum, void* workspace, size_t workspace_bytes, void* stream) {
   SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_heads_bwd: bad dtype");
-  SWN_CHECK(y && h2 && w_color && raw && d_raw && dh2 && dsig && d_w_sigma && d_b_sigma && d_w_color && d_b_color && workspace,
-            "swn_heads_bwd: null pointer");
+  SWN_CHECK(h2 && w_color && raw && d_raw && dh2 && dsig && d_w_sigma && d_b_sigma && d_w_color && d_b_color && workspace,
+            "swn_heads_bwd: null pointer");      // (y may be NULL: d_w_sigma is left as it is - swn_chain_desc.comb_dwsig forms it)
   SWN_CHECK((model_dim == 256 || model_dim == 512) && (h2_dim == 128 || h2_dim == 256), "swn_heads_bwd: model_dim in {256,512}, h2_dim in {128,256}");
   SWN_CHECK(workspace_bytes >= swn_heads_bwd_workspace_bytes(n_points, model_dim, h2_dim), "swn_heads_bwd: workspace of %zu bytes, need %zu",
             workspace_bytes, swn_heads_bwd_workspace_bytes(n_points, model_dim, h2_dim));
@@ -1387,8 +1409,9 @@ extern "C" int swn_heads_bwd(const void* y, const void* h2, int dtype, const flo
   int blocks = heads_bwd_blocks(n_points);
   if (rows_per_group > 0 && n_points / rows_per_group < blocks) blocks = n_points / rows_per_group;     // (never more than the workspace was sized for)
   float* partial = (float*)workspace;
-#define SWN_HB(T, M_, H_) hipLaunchKernelGGL((heads_bwd_kernel<T, M_, H_>), dim3(blocks), dim3(256), 0, as_stream(stream), (const T*)y, \
+#define SWN_HB1(T, M_, H_, Y_) hipLaunchKernelGGL((heads_bwd_kernel<T, M_, H_, Y_>), dim3(blocks), dim3(256), 0, as_stream(stream), (const T*)y, \
                                              (const T*)h2, w_color, raw, d_raw, n_points, (T*)dh2, dsig, partial, rows_per_group, group_colsum)
+#define SWN_HB(T, M_, H_) do { if (y) SWN_HB1(T, M_, H_, true); else SWN_HB1(T, M_, H_, false); } while (0)
   if (dtype == SWN_HALF) {
     if (model_dim == 256 && h2_dim == 128) SWN_HB(bf16_t, 256, 128); else if (model_dim == 512 && h2_dim == 256) SWN_HB(bf16_t, 512, 256);
     else if (model_dim == 256) SWN_HB(bf16_t, 256, 256); else SWN_HB(bf16_t, 512, 128);
@@ -1397,6 +1420,7 @@ extern "C" int swn_heads_bwd(const void* y, const void* h2, int dtype, const flo
     else if (model_dim == 256) SWN_HB(float, 256, 256); else SWN_HB(float, 512, 128);
   }
 #undef SWN_HB
+#undef SWN_HB1
   OrdDst od{{d_w_sigma, d_w_color, d_b_sigma, d_b_color}, {model_dim, 3 * h2_dim, 1, 3}};
   ordered_reduce_async(partial, blocks, model_dim + 3 * h2_dim + 4, od, true, as_stream(stream));
   SWN_LAUNCH_CHECK();

@@ -753,14 +753,21 @@ class SwitchNeRF:
         g = self.g
         rows, ng = c["rows"], c["ng"]
         _b = lambda name, shape, dtype: self._buf(c["tag"] + ":" + name, shape, dtype)
+        # the tail's two backward layers and the combine backward in FRONT of the expert backward chain, one launch (chain_big.hip, tag 8):
+        # pairs with the fused forward (its list of dropped tokens); SWN_FUSED_TAIL_BWD=0 keeps the two launches
+        fused_bwd = bool(c.get("tail_fused")) and self.ep is None and os.environ.get("SWN_FUSED_TAIL_BWD", "1") != "0"
+        # ... which also forms the sigma head's weight gradient where it reads y anyway (swn_chain_desc.comb_dwsig): the heads' backward
+        # launch then runs without y - 512 bytes per point less (SWN_FUSED_DWSIG=0: from y in the heads' launch, as before)
+        fused_dws = fused_bwd and M == 256 and os.environ.get("SWN_FUSED_DWSIG", "1") != "0"
+        y_heads = None if fused_dws else c["y"]
         # per-ray bias gradient (the column sums of a ray's dh2 rows: from the heads' launch) and the tiny per-ray GEMM's parameters
         if c.get("ragged"):      # a row range of the point grid: rays may be cut at either end - per-ray sums through the rows' ray index
-            dh2, dsig = o.heads_bwd(c["y"], c["h2"], self.p["color.w"], c["raw"], d_raw, g["sigma.w"], g["sigma.b"], g["color.w"],
+            dh2, dsig = o.heads_bwd(y_heads, c["h2"], self.p["color.w"], c["raw"], d_raw, g["sigma.w"], g["sigma.b"], g["color.w"],
                                     g["color.b"])
             ray_of_row = torch.arange(c["row0"], c["row0"] + P, device=self.dev) // S
             dc_ray = torch.zeros(N, H2, dtype=torch.float32, device=self.dev).index_add_(0, ray_of_row, dh2.float())
         else:
-            dh2, dsig, dc_ray = o.heads_bwd(c["y"], c["h2"], self.p["color.w"], c["raw"], d_raw, g["sigma.w"], g["sigma.b"], g["color.w"],
+            dh2, dsig, dc_ray = o.heads_bwd(y_heads, c["h2"], self.p["color.w"], c["raw"], d_raw, g["sigma.w"], g["sigma.b"], g["color.w"],
                                             g["color.b"], rows_per_group=S)
         if dc_ray.shape[1] in (64, 128, 256) and c["ray_feat"].shape[1] <= 256:      # split over the rays + ordered reduce (one launch)
             o.ray_feat_wgrad(c["ray_feat"], dc_ray, g["l2r.w"], g["l2.b"])
@@ -773,9 +780,6 @@ class SwitchNeRF:
         # ... with the combine backward (the sigma head's rank-1 term, the ReLU mask of y, the gate gradient, the gate scaling) applied
         # in the write-out of the last layer: dy itself never reaches memory
         dh1 = _b("dh1", (P, M), dt)
-        # the tail's two backward layers and the combine backward in FRONT of the expert backward chain, one launch (chain_big.hip, tag 8):
-        # pairs with the fused forward (its list of dropped tokens); SWN_FUSED_TAIL_BWD=0 keeps the two launches
-        fused_bwd = bool(c.get("tail_fused")) and self.ep is None and os.environ.get("SWN_FUSED_TAIL_BWD", "1") != "0"
         dout = None if fused_bwd else _b("dy", (P, M), dt)
         if fused_bwd:
             dgmax = _b("dgmax", (P,), torch.float32)
@@ -825,15 +829,19 @@ class SwitchNeRF:
             perm = c["perm"].view(-1)
             x_first, dz_last = c["h0"], _b("dz_last", (rows, M), dt)      # the last expert layer's dZ in the row space (the combine's output)
 
+            dws_dst = [g["sigma.w"].view(-1) if fused_dws else None]
+
             def run_expert_bwd():
                 o.mlp_chain(dh2, [o.Layer(self.wb["l2h_pad"], None, save=dh1), o.Layer(self.wb["l1"], None, save=dz_last)] + bl, dx, n_groups=ng,
                             n_wsets=n_loc, group_stride=cap, group_rows=grp_rows, group_rows_clamp=cap, x_gather=perm,
                             y_add=dz[skip_l] if skip_l is not None else None, tag=8, geometry=7, x_features=H2,
-                            combine=(c["y"], dsig, self.p["sigma.w"], c["gmax"], dgmax), head=(2, c["drop_begin"], c["dropped"]),
+                            combine=(c["y"], dsig, self.p["sigma.w"], c["gmax"], dgmax, dws_dst[0]), head=(2, c["drop_begin"], c["dropped"]),
                             group_begin=c.get("group_begin"))
             with self._timed("expert_bwd"):
                 run_expert_bwd()
             if self.profile and "_relaunch" in c:
+                if fused_dws:      # (a relaunch for timing adds into a scratch vector, not into the gradient)
+                    dws_dst[0] = torch.zeros(M, dtype=torch.float32, device=self.dev)
                 c["_relaunch"]["expert_bwd"] = run_expert_bwd
             if P > (1 << 19):
                 self._dense_wgrads(tail_jobs, nsp)

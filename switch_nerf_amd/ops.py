@@ -262,14 +262,14 @@ def heads_fwd(y, h2, w_sigma, b_sigma, w_color, b_color, sigma_noise):
 def heads_bwd(y, h2, w_color, raw, d_raw, d_w_sigma, d_b_sigma, d_w_color, d_b_color, rows_per_group: int = 0):
     """-> (dh2, dsig) or, with rows_per_group > 0 (the samples per ray, dividing P), (dh2, dsig, colsum [P / rows_per_group, H2] f32 =
     group_colsum(dh2, rows_per_group) from the same launch)."""
-    P, M = y.shape
-    H2 = h2.shape[1]
+    P, H2 = h2.shape
+    M = d_w_sigma.numel()          # (y may be None: the sigma weight gradient comes from the fused backward chain, mlp_chain(combine=(..., dws)))
     dh2 = torch.empty_like(h2)
-    dsig = torch.empty(P, dtype=torch.float32, device=y.device)
+    dsig = torch.empty(P, dtype=torch.float32, device=h2.device)
     nb = int(_lib.load().swn_heads_bwd_workspace_bytes(int(P), int(M), int(H2)))
-    ws = torch.empty(max(nb, 4) // 4, dtype=torch.float32, device=y.device)     # block partial sums (added in a fixed order)
-    cs = torch.empty(P // rows_per_group, H2, dtype=torch.float32, device=y.device) if rows_per_group else None
-    call("swn_heads_bwd", _p(y), _p(h2), _dt(y), _p(w_color), _p(raw), _p(d_raw), P, M, H2, _p(dh2), _p(dsig), _p(d_w_sigma),
+    ws = torch.empty(max(nb, 4) // 4, dtype=torch.float32, device=h2.device)     # block partial sums (added in a fixed order)
+    cs = torch.empty(P // rows_per_group, H2, dtype=torch.float32, device=h2.device) if rows_per_group else None
+    call("swn_heads_bwd", _p(y), _p(h2), _dt(h2), _p(w_color), _p(raw), _p(d_raw), P, M, H2, _p(dh2), _p(dsig), _p(d_w_sigma),
          _p(d_b_sigma), _p(d_w_color), _p(d_b_color), int(rows_per_group), _p(cs), _p(ws), nb, _stream())
     return (dh2, dsig, cs) if rows_per_group else (dh2, dsig)
 
@@ -573,9 +573,17 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
         assert sched.dtype == torch.int32 and sched.numel() >= 16
         d.sched = _p(sched)
     if combine is not None:
-        cy, cds, cws, cg, cdg = combine
+        cy, cds, cws, cg, cdg = combine[:5]
         assert cy.dtype == x.dtype and (cy.shape == y.shape or head is not None) and cg.dtype == torch.float32 and cdg.dtype == torch.float32
         d.comb_y, d.comb_dsig, d.comb_wsig, d.comb_gate, d.comb_dgate = _p(cy), _p(cds), _p(cws), _p(cg), _p(cdg)
+        if len(combine) > 5 and combine[5] is not None:      # the sigma head's weight gradient += from the same pass (fused backward only)
+            dws = combine[5]
+            assert head is not None and dws.dtype == torch.float32 and dws.numel() == 256 and dws.is_contiguous()
+            nb = int(_lib.load().swn_chain_dwsig_workspace_bytes(int(n_groups), int(d.group_rows_clamp)))
+            ws = _dwsig_ws.get((x.device, nb))
+            if ws is None:           # per-wave partial sums (zeroed and added up in a fixed order by the launch); never freed (graphs)
+                ws = _dwsig_ws[(x.device, nb)] = torch.empty(nb // 4, dtype=torch.float32, device=x.device)
+            d.comb_dwsig, d.comb_dwsig_ws = _p(dws), _p(ws)
     if heads is not None:
         hws, hbs, hwc, hbc, hnoise, hraw = heads
         assert all(t.dtype == torch.float32 and t.is_contiguous() for t in (hws, hbs, hwc, hbc, hraw)) and hraw.shape[1] == 4
@@ -593,6 +601,7 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
 
 
 _chain_sched = {}
+_dwsig_ws = {}
 
 
 def chain_sched(dev, key):

@@ -602,6 +602,22 @@ def test_emb_grad_is_an_ordered_index_add(shape, idx_dtype):
     assert torch.equal(outs[0][~hit], base[~hit])
 
 
+def test_fused_backward_chain_against_its_two_launches_and_sigma_weight_gradient():
+    """scripts/headfuse_check.py small: the fused backward launch (chain_big.hip tag 8: the tail's two backward layers + the combine
+    backward in front of the expert backward chain, dropped-token tiles behind the experts') against the two launches it replaces -
+    every save, the gate gradient and dx bit-identical - and swn_chain_desc.comb_dwsig, the sigma head's weight gradient from the same
+    pass: 1e-5 of an fp64 sum, accumulated (+=), two launches the same bits (per-wave sums added in a fixed order whatever workgroup
+    ran a tile), the other outputs unchanged by it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "headfuse_check.py"), "small"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if "identical" in ln]
+    assert len(lines) >= 10 and all("False" not in ln for ln in lines), r.stdout[-2000:]
+    assert any(ln.startswith("dwsig rel err") for ln in lines)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_heads_and_combine_bwd(dtype):
     rng = np.random.default_rng(61)
@@ -656,6 +672,15 @@ def test_heads_and_combine_bwd(dtype):
         assert torch.equal(outs[0][0], outs[1][0]) and all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
         for a, f in zip(outs[0][1], first):
             assert (a - f).abs().max().item() <= 1e-4 * max(1e-6, f.abs().max().item())      # (sums with cancellation, another order)
+    # without y (the sigma weight gradient is formed by the fused backward chain, swn_chain_desc.comb_dwsig): d_w_sigma untouched,
+    # everything else the same bits - plain walk and grouped walk (two rows in flight per 16-lane group, the rows in the same order)
+    for S in (0, 100):
+        acc = [torch.full_like(t, 3.0) if i == 0 else torch.zeros_like(t) for i, t in enumerate(first)]
+        acc_y = [torch.zeros_like(t) for t in first]
+        out_n = o.heads_bwd(None, h2d, wc.to(dev()), raw, d_raw.to(dev()), *acc, rows_per_group=S)
+        out_y = o.heads_bwd(yd, h2d, wc.to(dev()), raw, d_raw.to(dev()), *acc_y, rows_per_group=S)
+        assert all(torch.equal(a, b) for a, b in zip(out_n, out_y))
+        assert torch.equal(acc[0], torch.full_like(acc[0], 3.0)) and all(torch.equal(a, b) for a, b in zip(acc[1:], acc_y[1:]))
     # combine backward: y = relu(g * o); given dy_in and the sigma head's rank-1 term
     gate = torch.from_numpy(rng.uniform(0.125, 1, P).astype(np.float32)).requires_grad_(True)
     oo = torch.from_numpy(rng.standard_normal((P, M)).astype(np.float32))
