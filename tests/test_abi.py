@@ -151,3 +151,14 @@ def test_fused_tail_descriptors_validate_before_launch():
     assert lib.swn_mlp_chain(C.byref(b), None) != 0 and "tag 8 is the expert backward" in err()
     b.head_layers = 2                                         # no combine operands, no 128-feature input
     assert lib.swn_mlp_chain(C.byref(b), None) != 0 and "a fused tail" in err()
+    # the sigma head's weight gradient from the fused backward launch: destination and workspace come together, with the combine operands
+    b.comb_dwsig = p
+    assert lib.swn_mlp_chain(C.byref(b), None) != 0 and "comb_dwsig and comb_dwsig_ws come together" in err()
+    b.comb_dwsig_ws = p
+    assert lib.swn_mlp_chain(C.byref(b), None) != 0 and "comb_dwsig and comb_dwsig_ws come together" in err()      # (no comb_y / comb_dsig)
+    f = desc(2)
+    f.comb_dwsig = f.comb_dwsig_ws = f.comb_y = f.comb_dsig = p                                                     # (no head layers)
+    assert lib.swn_mlp_chain(C.byref(f), None) != 0 and "comb_dwsig and comb_dwsig_ws come together" in err()
+    # its workspace: 8 wave slots of 256 floats per 256-row tile of every group + 1024 run sums
+    assert lib.swn_chain_dwsig_workspace_bytes(128, 16384) == (128 * 64 * 8 + 1024) * 1024
+    assert lib.swn_chain_dwsig_workspace_bytes(16, 500) == (16 * 2 * 8 + 1024) * 1024 and lib.swn_chain_dwsig_workspace_bytes(0, 500) == 0
