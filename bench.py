@@ -477,7 +477,8 @@ def main():
         names["expert_fwd_nosave"] = "chainq_kernel<Bf16,7,true> without activation saves (the inference / --eval launch: experts + tail, raw is all it writes)"
     if fused_tail[1]:
         names["expert_bwd"] = ("chainq_kernel<Bf16,8,true> (the tail's two backward layers + the combine backward on every point, then the expert "
-                               "backward-data chain, 7 fused layers: persistent 256-row workgroups on a tile queue)")
+                               "backward-data chain, 7 fused layers: persistent 256-row workgroups on a tile queue; timed with the three small launches "
+                               "around it that finish the sigma head's weight gradient - workspace fill, run sums, ordered reduce: ~0.04 ms)")
     kept = kept_of(st)
     kept_mean = kkept if kkept is not None else kept                   # kept rows of the step whose buffers the kernels were timed on
     detail = {} if other else account(ktimes, kept_mean)               # (other recipes: headline number only)
