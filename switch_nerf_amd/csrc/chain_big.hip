@@ -593,6 +593,59 @@ __global__ __launch_bounds__(G::NT, G::OCC) void chainb_kernel(const Args args) 
 #define SWN_WQ_DEPTH 4            // weight-fragment register sets of a wave's K loop: SWN_WQ_DEPTH - 1 K steps in flight
 #endif
 constexpr int WQD = SWN_WQ_DEPTH, WQA = SWN_WQ_DEPTH - 1;
+#ifdef SWN_ROLLED_K
+// (experiment, NOT in the default build - profiles/r04_experiments.md 24: the same K loop rolled to four steps per trip + the last four
+//  peeled, the step count a run-time argument: the same loads, waits and MFMA order per accumulator; the same spill counts as the
+//  unrolled loop in every chainq instantiation, all chain tests bit-exact - and 3-4 % slower in the K-bound launches.  What it was
+//  for: ONE loop that can run a 128-feature first layer in 8 steps over unpadded weights - a second unrolled instantiation spilled
+//  96-122 registers, section 23 - but the half K phase that would save is about what the rolled loop costs.)
+template <typename E, int NS_UNUSED = KSTEPS>
+__device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, __amdgpu_buffer_rsrc_t rs_cur, u32x4_t (&wq)[WQD][2], int NS = KSTEPS) {
+  static_assert(WQD == 4, "rolled K loop: ring of 4");
+  constexpr int MI = 4;
+  char* smem = cx.smem;
+  const int lane16 = cx.lane * 16;
+  const int fg = cx.w & 3;
+  u32x4_t fa[4][MI];             // (four sets so that the set index is static in a body of 4 steps: ks % 4)
+  uint32_t a_base = cx.a_base;
+  asm volatile("" : "+v"(a_base));
+#define RD_A(ks_, set_, mi_) fa[set_][mi_] = *(const u32x4_t*)(smem + (a_base ^ (uint32_t)((ks_) << 5)) + (mi_) * (32 * ROWB))
+#define LD_W(ks_, set_) { _Pragma("unroll") for (int i = 0; i < 2; ++i) wq[set_][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, lane16, ((2 * fg + i) * NS + (ks_)) * 1024, 0); }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) RD_A(0, 0, mi);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) RD_A(1, 1, mi);
+#define SWN_MM(set_, mi, ni) acc[mi][ni] = E::mfma(wq[set_][ni], fa[set_][mi], acc[mi][ni])
+#define STEP(ks_, u_, W_VM, W_LGKM, HAS2, HAS3)                                        \
+  {                                                                                    \
+    W_VM; W_LGKM; SWN_PIN();                                                           \
+    SWN_MM(u_, 0, 0); SWN_PIN();                                                       \
+    if (HAS2) { RD_A((ks_) + 2, (u_ + 2) & 3, 0); RD_A((ks_) + 2, (u_ + 2) & 3, 1); }  \
+    SWN_PIN(); SWN_MM(u_, 0, 1); SWN_PIN();                                            \
+    if (HAS2) { RD_A((ks_) + 2, (u_ + 2) & 3, 2); RD_A((ks_) + 2, (u_ + 2) & 3, 3); }  \
+    SWN_PIN(); SWN_MM(u_, 1, 0); SWN_PIN();                                            \
+    if (HAS3) LD_W((ks_) + 3, (u_ + 3) & 3);                                           \
+    SWN_PIN(); SWN_MM(u_, 1, 1); SWN_PIN(); SWN_MM(u_, 2, 0); SWN_PIN(); SWN_MM(u_, 2, 1); SWN_PIN(); \
+    SWN_MM(u_, 3, 0); SWN_PIN(); SWN_MM(u_, 3, 1); SWN_PIN();                          \
+  }
+  int ks = 0;
+  for (; ks + 4 < NS; ks += 4) {       // steady state: four steps per trip, every wait the same
+    STEP(ks, 0, SWN_WAIT_VM(4), SWN_WAIT_LGKM(4), true, true)
+    STEP(ks + 1, 1, SWN_WAIT_VM(4), SWN_WAIT_LGKM(4), true, true)
+    STEP(ks + 2, 2, SWN_WAIT_VM(4), SWN_WAIT_LGKM(4), true, true)
+    STEP(ks + 3, 3, SWN_WAIT_VM(4), SWN_WAIT_LGKM(4), true, true)
+  }
+  // the last four steps
+  STEP(ks, 0, SWN_WAIT_VM(4), SWN_WAIT_LGKM(4), true, true)
+  STEP(ks + 1, 1, SWN_WAIT_VM(4), SWN_WAIT_LGKM(4), true, false)
+  STEP(ks + 2, 2, SWN_WAIT_VM(2), SWN_WAIT_LGKM(4), false, false)
+  STEP(ks + 3, 3, SWN_WAIT_VM(0), SWN_WAIT_LGKM(0), false, false)
+#undef STEP
+#undef SWN_MM
+#undef RD_A
+#undef LD_W
+}
+#else
 template <typename E, int NS = KSTEPS>
 __device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, __amdgpu_buffer_rsrc_t rs_cur, u32x4_t (&wq)[WQD][2]) {
   constexpr int MI = 4;           // NS = K steps of this layer (K / 16): 16, or 8 for a 128-feature chain input (geometries 6 / 7)
@@ -654,6 +707,7 @@ __device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, _
     SWN_PIN();
   }
 }
+#endif
 
 // The epilogue of geometry 4.  Same arithmetic as epilogue() above, value for value - but an epilogue wave of chainp_kernel runs ALONE
 // beside its SIMD's MFMA wave: dependent VALU chains that two lockstep waves hide from each other (chainb) cost it ~8 clocks per
