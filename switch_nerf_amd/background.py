@@ -32,6 +32,12 @@ class BackgroundScene:
         self.center, self.radius = sphere_center, sphere_radius
         bg_nerf._grow_bufs = True           # the number of background rays changes every batch
         self.dev = nerf.dev
+        # ONE loss scaler over both models (the reference's single GradScaler over both optimizers, runner.py:483, 679-690): when either
+        # model computes in fp16, both hold the SAME LossScaler object - one scale multiplies the loss gradient, both unscale by it, one
+        # growth tracker is checkpointed whichever model's state_dict is asked (a 16-bit-float foreground beside an fp16 background included)
+        self.loss_scaler = nerf.loss_scaler if nerf.loss_scaler is not None else bg_nerf.loss_scaler
+        if self.loss_scaler is not None:
+            nerf.loss_scaler = bg_nerf.loss_scaler = self.loss_scaler
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, rays, image_indices, n_samples, seg_tokens, perturb=0.0, perturb_rand=None, perturb_rand_bg=None,
@@ -158,12 +164,10 @@ class BackgroundScene:
         # fp16 (the reference's single GradScaler over both optimizers, runner.py:483, 679-690): one loss scale - the foreground model's
         # scaler - multiplies the loss gradient; both models unscale by it, and a non-finite gradient in either skips that model's step
         ls = 1.0
-        if nerf.loss_scaler is not None:
-            ls = float(nerf.loss_scaler.scale)
-            nerf._loss_scale_tensor()                     # (records the scale this backward uses: _unscale_ok divides by it)
-            if bg.loss_scaler is not None:
-                bg.loss_scaler.scale = nerf.loss_scaler.scale
-                bg._loss_scale_tensor()
+        if self.loss_scaler is not None:
+            ls = float(self.loss_scaler.scale)
+            for m in (nerf, bg):
+                m._loss_scale_tensor()                    # (records the scale this backward uses: _found_inf divides by it)
         d_rgb = (diff * (2.0 * ls / diff.numel())).contiguous()
         self.backward(ctx, d_rgb, ls * nerf.wt * (0.5 if fine else 1.0), ls * nerf.wt * 0.5)
         # the reference skips the background optimizer on batches without background rays (runner.py:683: `if key == 'bg_nerf'
@@ -180,19 +184,16 @@ class BackgroundScene:
         # ITS OWN non-finite gradient; GradScaler.update backs the shared scale off when EITHER optimizer found one (and only then
         # resets the growth tracker).  The foreground model's LossScaler is that shared scaler; the background's mirrors its scale.
         found = {id(m): False for m in (nerf, bg)}
-        if optimizer_step and nerf.loss_scaler is not None:
+        if optimizer_step and self.loss_scaler is not None:
             for m in models:
-                if m.loss_scaler is not None:
-                    found[id(m)] = m._found_inf()
-            nerf.loss_scaler.update(any(found.values()))
-            nerf._loss_scale_tensor()
-            if bg.loss_scaler is not None:
-                bg.loss_scaler.scale = nerf.loss_scaler.scale
-                bg._loss_scale_tensor()
+                found[id(m)] = m._found_inf()
+            self.loss_scaler.update(any(found.values()))
+            for m in (nerf, bg):
+                m._loss_scale_tensor()
         for m in models:
             if optimizer_step and not found[id(m)]:
                 sc = scale[id(m)]
-                if m.loss_scaler is not None:            # fp16: the gradient carries the loss scale (backward above)
+                if self.loss_scaler is not None:         # fp16: the gradient carries the loss scale (backward above)
                     sc /= m._applied_loss_scale
                 m.step_count += 1
                 ops.adam_step(m.flat, m.grad, m.m, m.v, None, m.step_count, m.lr, grad_scale=sc)

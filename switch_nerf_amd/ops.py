@@ -354,15 +354,29 @@ def hash_encode_fwd(rays, z, table, hc: dict, dtype, out_stride: int):
 
 
 _hash_xcd_tables = {}
+HASH_XCD_COPIES = 8          # XCDs of an MI300X / MI355X (the kernel picks its copy by HW_REG_XCC_ID & 7: hashgrid.hip)
+
+
+def hash_xcd_budget_bytes() -> int:
+    """Upper bound on the per-XCD gradient-table workspace of hash_encode_bwd (SWN_HASH_XCD_MB, default 1024 MiB; 0 = never)."""
+    return int(os.environ.get("SWN_HASH_XCD_MB", "1024")) << 20
 
 
 def hash_encode_bwd(rays, z, d_out, hc: dict, d_table):
-    """d_table [L, T, 2] fp32 += the table gradient for dL/d encoding d_out [N * S, stride]."""
+    """d_table [L, T, 2] fp32 += the table gradient for dL/d encoding d_out [N * S, stride].
+
+    Default: one private fp32 copy of the gradient table per XCD (HASH_XCD_COPIES x the table: 512 MiB at 16 levels x 2^19, zeroed once,
+    left zero by every launch, never freed - a captured hipGraph holds its address) - the atomics of an XCD stay in its own L2.  A table
+    whose copies would exceed hash_xcd_budget_bytes() (2^22 entries: 4 GiB) takes the plain path: atomics straight into d_table."""
     n, S = z.shape
+    ws_bytes = HASH_XCD_COPIES * d_table.numel() * 4
+    if ws_bytes > hash_xcd_budget_bytes():
+        call("swn_hash_encode_bwd", _p(rays), _p(z), n, S, C.byref(_hash_cfg(hc)), _p(d_out), _dt(d_out), d_out.shape[1], _p(d_table), _stream())
+        return
     key = (d_table.device, d_table.numel())
     ws = _hash_xcd_tables.get(key)
-    if ws is None:      # one private copy of the gradient table per XCD: zero once, left zero by every launch; never freed (graphs)
-        ws = _hash_xcd_tables[key] = torch.zeros(8 * d_table.numel(), dtype=torch.float32, device=d_table.device)
+    if ws is None:
+        ws = _hash_xcd_tables[key] = torch.zeros(HASH_XCD_COPIES * d_table.numel(), dtype=torch.float32, device=d_table.device)
     call("swn_hash_encode_bwd_xcd", _p(rays), _p(z), n, S, C.byref(_hash_cfg(hc)), _p(d_out), _dt(d_out), d_out.shape[1], _p(d_table), _p(ws),
          _stream())
 
@@ -608,7 +622,7 @@ def chain_sched(dev, key):
     """The tile-queue counters of a persistent chain launch (geometry 6 / 7): int32 [16], zero at creation and left zero by every launch.
     One tensor per (device, stream, key): launches that share one are ordered on their stream; give launches that may overlap on
     different streams different keys.  Never freed (a captured hipGraph holds the address)."""
-    k = (dev, torch.cuda.current_stream().cuda_stream if dev.type == "cuda" else 0, key)
+    k = (dev, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0, key)
     t = _chain_sched.get(k)
     if t is None:
         t = _chain_sched[k] = torch.zeros(16, dtype=torch.int32, device=dev)

@@ -71,14 +71,24 @@ class GradAllReduce:
         self._ev.append((kind, a, b))
         return out
 
+    def _drain(self):
+        """A pending early part whose finish() never ran (an exception between the two backward halves): wait for it and forget it, so
+        that the next step starts clean instead of dying on a stale handle."""
+        if self._pending is not None:
+            work, _part = self._pending
+            self._pending = None
+            if work is not None:
+                work.wait()
+
     def __call__(self, flat: torch.Tensor) -> float:
+        self._drain()
         if self.world > 1:
             self._timed("coll", lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group))
         return 1.0 / self.world
 
     def begin(self, part: torch.Tensor, stream=None):
         """Start the all-reduce of `part` (final already) on `stream`, ordered after the work queued on the current stream."""
-        assert self._pending is None, "GradAllReduce.begin: the previous overlapped all-reduce was not finished"
+        self._drain()
         if self.world == 1:
             self._pending = (None, part)
             return

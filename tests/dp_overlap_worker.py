@@ -26,9 +26,12 @@ for it in range(3):
     rays, img, rgbs = synth.make_rays(800 + 10 * it + rank, N)         # every rank trains on its own rays
     batches.append(tuple(torch.from_numpy(x).to(dev) for x in (rays, img, rgbs)))
 out = {}
+flat0 = None
 for mode in ("eager", "one_graph", "split"):
     m = SwitchNeRF(synth.BUILDING, dtype=torch.bfloat16, device=dev)
     m.load_state_dict(synth.make_weights(801, synth.BUILDING, gate_scale=1.0))
+    if flat0 is None:
+        flat0 = m.flat.clone()                                         # the initial parameters (the same in every mode)
     step = None
     if mode != "eager":         # (perturb / noise off: the three modes must see the same draws)
         step = GraphedTrainStep(m, batches[0][2], batches[0][0], batches[0][1], S, chunk, perturb=0.0, noise_std=0.0,
@@ -50,8 +53,8 @@ for mode in ("one_graph", "split"):
     for a, b in zip(out["eager"][:3], out[mode][:3]):
         ok &= bool(torch.equal(a, b))
     ok &= out[mode][3] == out["eager"][3] == 3
-moved = (out["split"][0] - torch.zeros_like(out["split"][0])).abs().sum().item() > 0
+moved = all(bool((out[mode][0] != flat0).any()) for mode in out)       # the optimizer steps changed the parameters in every mode
 print(f"DP_OVERLAP rank {rank}: {'OK' if ok and moved else 'MISMATCH'}", flush=True)
 torch.distributed.barrier()
 torch.distributed.destroy_process_group()
-sys.exit(0 if ok else 1)
+sys.exit(0 if ok and moved else 1)

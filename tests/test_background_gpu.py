@@ -223,6 +223,7 @@ def test_background_fp16_one_shared_grad_scaler():
     rays, img, rgbs = synth.make_bg_rays(131, N)
     m, b = _models(torch.float16, 133, 134)
     scene = BackgroundScene(m, b, CENTER, RADIUS)
+    assert m.loss_scaler is b.loss_scaler is scene.loss_scaler          # ONE object: one scale, one growth tracker to checkpoint
     m.loss_scaler.scale = 1024.0
     m.loss_scaler._good = 7
     st = scene.train_step(_dev(rgbs), _dev(rays), _dev(img), S, 4096, perturb=0.0)
@@ -242,6 +243,7 @@ def test_background_fp16_one_shared_grad_scaler():
     assert m.step_count == 2 and b.step_count == 1                      # each optimizer skips on ITS OWN found_inf
     assert (m.flat != fg_before).any() and torch.equal(b.flat, bg_before)
     assert m.loss_scaler.scale == 512.0 and b.loss_scaler.scale == 512.0 and m.loss_scaler._good == 0      # ONE scaler: backed off for both
+    assert b.loss_scaler.state_dict()["_growth_tracker"] == 0 and b.loss_scaler.skipped == 1               # ... whichever model is asked
 
 
 def test_background_model_call_mirror_on_explicit_points():
