@@ -161,6 +161,7 @@ def main():
         from switch_nerf_amd import parallel
         parallel.init_from_env(os.environ.get("SWN_DIST_BACKEND", "nccl"), dev)       # "nccl" = RCCL; gloo only for single-GPU tests of this path
 
+    from switch_nerf_amd import _lib
     from switch_nerf_amd.model import SwitchNeRF, BUILDING
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[a.dtype]
     cfg = dict(BUILDING, model_dim=a.model_dim, gate_hidden=a.model_dim, num_experts=a.experts)
@@ -352,6 +353,16 @@ def main():
             traffic_tab = json.load(open(tp))
         except Exception:
             traffic_tab = {}
+    csrc_sha = _lib.source_hash()
+    traffic_ok, traffic_note = False, "profiles/traffic.json missing"
+    if traffic_tab:
+        if traffic_tab.get("csrc_sha256") != csrc_sha:
+            traffic_note = ("profiles/traffic.json was collected on other kernel sources (csrc_sha256 "
+                            f"{str(traffic_tab.get('csrc_sha256'))[:12]} != {csrc_sha[:12]}): traffic not reported")
+        elif traffic_tab.get("points") != P:
+            traffic_note = f"profiles/traffic.json was collected at {traffic_tab.get('points')} points per launch, this run has {P}"
+        else:
+            traffic_ok, traffic_note = True, traffic_tab.get("_how")
     names = {"expert_fwd": "chainq_kernel<Bf16,1,true> (expert forward: 7 fused layers, persistent 256-row workgroups on a tile queue, row groups half a layer apart)",
              "expert_bwd": "chainq_kernel<Bf16,2,true> (expert backward-data: 7 fused layers, persistent 256-row workgroups on a tile queue, row groups half a layer apart)",
              "expert_wgrad": "wgrad_stream_kernel<bf16,1> (expert weight gradients, 7 layers in one balanced launch)",
@@ -423,13 +434,8 @@ def main():
                     one_layer_gemm=dict(rows=rows, ms=round(ms_l, 4), tflops=round(tf_l, 1), mfma_frac=round(tf_l / MFMA_BF16_PEAK_TFLOPS, 4),
                                         gbs=round(rows * M * 2 * 2 / (ms_l * 1e-3) / 1e9, 1)))
 
-    def account(events, kept_):
-        """Expert kernels against both rooflines.  flops: 2 L M^2 per KEPT row for each of forward, backward-data and weight
-        gradients (SURVEY 8(d)).  Algorithmic HBM bytes per launch (DESIGN.md section 5): fwd reads x, writes L-1 activations +
-        the output; bwd reads dout and the skip layer's dZ, writes L-1 dZ + dx; the weight gradients read L layer inputs and L dZ.
-        hbm_measured_*: bytes from the FETCH_SIZE / WRITE_SIZE counters of a separate profiling pass (profiles/traffic.json,
-        stored per kept row), i.e. what actually crossed the memory-side fabric."""
-        detail_ = {}
+    def alg_of(kept_):
+        """(algorithmic HBM bytes, algorithmic flops) per launch name for `kept_` kept rows."""
         flops_e = 2.0 * L * M * M * kept_
         alg = {"expert_fwd": kept_ * M * esz * (1 + (L - 1) + 1), "expert_bwd": kept_ * M * esz * (1 + (L - 1) + 1 + 1),
                "expert_wgrad": kept_ * M * esz * 2 * L, "expert_fwd_nosave": kept_ * M * esz * 2, "expert_gemm_nosave": kept_ * M * esz * 2}
@@ -449,6 +455,33 @@ def main():
             # (H2) and y (M) per point and the skip layer's dZ, writes dh1 (M) per point, L dZ (the last expert layer's included) + dx per kept row
             fl["expert_bwd"] += 2.0 * (M * M + M * model.H2) * P
             alg["expert_bwd"] = kept_ * M * esz * (L + 1 + 1) + P * (model.H2 * esz + 2 * M * esz + 12)
+        return alg, fl
+
+    def traffic_of(name, kept_):
+        """HBM bytes of launch `name` from the counter passes (profiles/traffic.json, scripts/make_traffic.py): measured on the timed
+        workload at traffic_tab['kept_rows'] kept rows, scaled to this run's kept rows by the ratio of the algorithmic bytes (a few
+        percent: routing moves while training).  None when the table was collected on other kernel sources, another kernel set or
+        another problem size."""
+        if not traffic_ok:
+            return None
+        t_ = traffic_tab.get("launches", {}).get(name)
+        if not t_:
+            return None
+        ks_t, ks_now = traffic_tab.get("kernel_set") or {}, model.kernel_set()
+        if any(ks_t.get(k) != ks_now.get(k) for k in ("geom", "front_geom", "tail_fused", "fused_backward", "comb_dwsig") if k in ks_t):
+            return None
+        a_now, _ = alg_of(kept_)
+        a_pmc, _ = alg_of(traffic_tab["kept_rows"])
+        return t_["hbm_bytes"] * a_now[name] / a_pmc[name]
+
+    def account(events, kept_):
+        """Expert kernels against both rooflines.  flops: 2 L M^2 per KEPT row for each of forward, backward-data and weight
+        gradients (SURVEY 8(d)).  Algorithmic HBM bytes per launch (DESIGN.md section 5): fwd reads x, writes L-1 activations +
+        the output; bwd reads dout and the skip layer's dZ, writes L-1 dZ + dx; the weight gradients read L layer inputs and L dZ.
+        hbm_measured_*: bytes from the FETCH_SIZE / WRITE_SIZE counters of a separate profiling pass (profiles/traffic.json,
+        stored per kept row), i.e. what actually crossed the memory-side fabric."""
+        detail_ = {}
+        alg, fl = alg_of(kept_)
         for name in ("expert_fwd", "expert_bwd", "expert_wgrad", "expert_fwd_nosave", "expert_gemm_nosave"):
             ms_ = events.get(name)
             if not ms_ or ms_ <= 0:
@@ -458,16 +491,10 @@ def main():
             gbs = alg[name] / (ms_ * 1e-3) / 1e9
             d_ = dict(ms=round(ms_, 4), tflops=round(tf, 1), mfma_frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4), alg_bytes=int(alg[name]),
                       alg_flops=float(flops), alg_gbs=round(gbs, 1), hbm_frac_alg=round(gbs / HBM_PEAK_GBS, 4))
-            per_row, per_pt = traffic_tab.get(name + "_bytes_per_kept_row"), 0.0
-            if (fused_tail[0] and name == "expert_fwd") or (fused_tail[1] and name == "expert_bwd"):      # (the launches that carry the tail:
-                per_row = traffic_tab.get(name + "_tail_bytes_per_kept_row")                             #  measured on their own)
-                per_pt = traffic_tab.get(name + "_tail_bytes_per_point", 0.0)
-            elif fused_tail[0] and name == "expert_fwd_nosave":
-                per_row = None
-            if per_row:
-                tb = per_row * kept_ + per_pt * P
+            tb = traffic_of(name, kept_)
+            if tb:
                 d_.update(hbm_measured_bytes=int(tb), hbm_measured_gbs=round(tb / (ms_ * 1e-3) / 1e9, 1),
-                          hbm_frac_measured=round(tb / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+                          hbm_frac_measured=round(tb / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), hbm_measured_over_alg=round(tb / alg[name], 4))
             detail_[name] = d_
         return detail_
 
@@ -502,6 +529,7 @@ def main():
             roof = dict(kernel=names[dom], bound="mfma", achieved=d["tflops"], peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=d["mfma_frac"], traffic=d.get("hbm_measured_bytes"), flop_per_byte=round(intensity, 1), alg_gbs=d["alg_gbs"],
                         hbm_frac_measured=d.get("hbm_frac_measured"))
+        roof["traffic_source"] = traffic_note
         roof["attainable"] = dict(tflops=round(attainable, 1), frac_of_attainable=round(d["tflops"] / attainable, 4),
                                   what="min(MFMA peak, flop_per_byte x HBM peak) for this launch's algorithmic flops and bytes")
         # the three training launches side by side (the dominant one changes with the box and the router's fill: they are within 15 %)
@@ -644,6 +672,7 @@ def main():
                                + (f", + dense background model on {st['ctx']['Nb']} of {n_rays} rays x {a.samples // 2} samples" if a.bg else "")
                                + (f", model_dim {a.model_dim}, {a.experts} experts" if (a.model_dim != 256 or a.experts != 8) else ""),
                    "global_batch_rays": gb, "rays_per_gpu": n_rays, "samples": a.samples, "segment_points": a.chunk,
+                   "kernel_set": None if a.dense else model.kernel_set(), "csrc_sha256": csrc_sha,
                    "parallelism": f"{a.parallelism}{world}", "balanced_value": None if balanced is None else balanced["value"],
                    "kept_token_fraction": round(kept / P, 4), "kept_token_fraction_mean": round(kept_mean / P, 4), "loss": round(loss_main, 6), "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 3),
                    "runner_loop_ms_per_step": None if runner_ms is None else round(runner_ms, 3),

@@ -10,6 +10,21 @@ LIB_PATH_F16 = os.path.join(_HERE, "libswn_hip_f16.so")    # the same sources bu
 
 F32, BF16, F16 = 0, 1, 2
 
+
+def source_hash() -> str:
+    """sha256 over the kernel sources (csrc/*, include/swn.h, build.sh: names and contents, sorted) - the identity of the kernels a
+    measurement ran.  profiles/traffic.json records the hash of the build its counter passes ran; bench.py reports HBM traffic from
+    the table only when the sources it runs hash the same."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(_HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(_HERE, "csrc")))]
+    files += [os.path.join(os.path.dirname(_HERE), "include", "swn.h"), os.path.join(_HERE, "build.sh")]
+    for f in files:
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode() + b"\0")
+            h.update(open(f, "rb").read())
+    return h.hexdigest()
+
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
 

@@ -114,6 +114,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, in
 #define SWN_BIG_Y_AUX SWN_BIG_STORE_AUX      // ... of the chain OUTPUT (read back by the next kernel, unlike the saved activations)
 #endif
 #define SWN_PIN() __builtin_amdgcn_sched_barrier(0)
+// Store-operand hold.  The registers of a 16-byte store must stay ALLOCATED behind it: the value is dead behind its store, the compiler
+// hands the registers to the next temporaries, and with a VALU write two instructions behind the store single dwords reached memory with
+// the NEW value under store back-pressure (profiles/r04_experiments.md section 5; the documented hazard is one wait state).  An empty asm
+// statement that READS the operands keeps them allocated up to the program point where it stands - put it where the next write to the
+// registers is structurally far: behind the s_waitcnt vmcnt(0) that retires the stores (S phase, end of kernel), or at the refill of an
+// alternating register set a half epilogue step later (E phase).  No idle issue slots anywhere.
+#define SWN_KEEP4(a) asm volatile("" :: "v"((a)[0]), "v"((a)[1]), "v"((a)[2]), "v"((a)[3]))
+#define SWN_KEEP8(a) asm volatile("" :: "v"((a)[0]), "v"((a)[1]), "v"((a)[2]), "v"((a)[3]), "v"((a)[4]), "v"((a)[5]), "v"((a)[6]), "v"((a)[7]))
+#define SWN_KEEP16(a) do { SWN_KEEP8(a); SWN_KEEP8((a) + 8); } while (0)
 #define SWN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define SWN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
@@ -818,13 +827,14 @@ __device__ __forceinline__ void stage_pieces(const Ctx& cx, const char* x, int c
   }
 }
 
-// pieces c0 + 4 j (j < 16) of the tile -> rows of a row-major tensor (descriptor clipped to the valid rows); batches of NB
+// pieces c0 + 4 j (j < 16) of the tile -> rows of a row-major tensor (descriptor clipped to the valid rows); batches of NB.  The store
+// operands live in the CALLER's keep[16] (SWN_KEEP: allocated until the caller has waited for the stores)
 template <typename E, bool ADD, int NB>
-__device__ __forceinline__ void write_pieces16(const Ctx& cx, int c0, __amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t ra) {
+__device__ __forceinline__ void write_pieces16(const Ctx& cx, int c0, __amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t ra, u32x4_t (&keep)[16]) {
   const int lane16 = cx.lane * 16;
 #pragma unroll
   for (int b = 0; b < 16 / NB; ++b) {
-    u32x4_t v[NB];
+    u32x4_t* v = keep + NB * b;
 #pragma unroll
     for (int j = 0; j < NB; ++j) v[j] = *(const u32x4_t*)(cx.smem + piece_addr(cx, c0 + 4 * (NB * b + j)));
     if constexpr (ADD) {
@@ -842,8 +852,6 @@ __device__ __forceinline__ void write_pieces16(const Ctx& cx, int c0, __amdgpu_b
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rs, lane16, (c0 + 4 * (NB * b + j)) * 1024, SWN_BIG_Y_AUX);
-#pragma unroll
-    for (int j = 0; j < NB; ++j) asm volatile("s_nop 3" :: "v"(v[j]));     // (see the write-out hook in chainp_kernel)
     SWN_PIN();
   }
 }
@@ -1016,22 +1024,21 @@ __global__ __launch_bounds__(512, 2) void chainp_kernel(const Args args) {
       // Their write-out (16 pieces of 1 KiB per wave) is spread over the epilogue: 4 pieces after every row tile.
       void* wo = rg == 0 ? (L >= 1 ? d.layers[L - 1].save : nullptr) : (L + 1 < n_layers ? ly.save : nullptr);
       SWN_TM(two += TICK() - e0;)
+      // the write-out's store operands - two alternating register sets: the set stored at row tile mi stays allocated (SWN_KEEP4) until
+      // its refill a row tile later, the last two to the end of the phase (behind the mask store and the next K loop's preloads)
+      u32x4_t wv[2][4];
       if (wo) {
         const __amdgpu_buffer_rsrc_t rs = out_rs(wo);
         const int c0 = 64 * (1 - rg) + fg;
-        u32x4_t wv[4];
         auto rd = [&](int b) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) wv[j] = *(const u32x4_t*)(smem + piece_addr(ce, c0 + 4 * (4 * b + j)));
+          for (int j = 0; j < 4; ++j) wv[b & 1][j] = *(const u32x4_t*)(smem + piece_addr(ce, c0 + 4 * (4 * b + j)));
         };
         rd(0);
         auto hook = [&](int mi) {      // (no explicit wait: the compiler counts the LDS operations behind the piece reads itself)
+          if (mi > 0) SWN_KEEP4(wv[(mi + 1) & 1]);       // (the set stored a row tile ago: its next write is the refill below)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(wv[j], rs, lane16e, (c0 + 4 * (4 * mi + j)) * 1024, SWN_BIG_STORE_AUX);
-          // The registers of a 16-byte store must not be rewritten right behind it: with a VALU write two instructions after the
-          // store, single dwords of single lane groups reached memory with the NEW value (seen under store back-pressure; the
-          // documented hazard is one wait state).  Hold the four registers through a few idle issue slots.
-          asm volatile("s_nop 7\n\ts_nop 7" :: "v"(wv[0]), "v"(wv[1]), "v"(wv[2]), "v"(wv[3]));
+          for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(wv[mi & 1][j], rs, lane16e, (c0 + 4 * (4 * mi + j)) * 1024, SWN_BIG_STORE_AUX);
           if (mi < 3) rd(mi + 1);
           SWN_PIN();
         };
@@ -1043,6 +1050,7 @@ __global__ __launch_bounds__(512, 2) void chainp_kernel(const Args args) {
       SWN_PIN();                                    // (the loads must not be scheduled up into the epilogue: 24 registers)
       preload_w(L + 1 < n_layers ? L + 1 : L);     // the first three K steps of this wave's next K loop (end of chain: loaded, never used)
       SWN_PIN();
+      if (wo) { SWN_KEEP4(wv[0]); SWN_KEEP4(wv[1]); }
       SWN_WAIT_LGKM0();
       SWN_TM(const long long e1 = TICK();)
       __builtin_amdgcn_s_barrier();
@@ -1054,8 +1062,9 @@ __global__ __launch_bounds__(512, 2) void chainp_kernel(const Args args) {
   // ---- the chain output (+ y_add rows): group 0 writes its own rows while group 1 is in its last epilogue, then both write group 1's ----
   const __amdgpu_buffer_rsrc_t ry = out_rs(d.y);
   const __amdgpu_buffer_rsrc_t ra = d.y_add ? out_rs((void*)d.y_add) : ry;
+  u32x4_t keep[16], keep2[8];                      // store operands, allocated until the stores have retired (SWN_KEEP)
   if (rg == 0) {
-    if (d.y_add) write_pieces16<E, true, 8>(cx, fg, ry, ra); else write_pieces16<E, false, 8>(cx, fg, ry, ra);
+    if (d.y_add) write_pieces16<E, true, 8>(cx, fg, ry, ra, keep); else write_pieces16<E, false, 8>(cx, fg, ry, ra, keep);
     SWN_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();
   }
@@ -1070,11 +1079,13 @@ __global__ __launch_bounds__(512, 2) void chainp_kernel(const Args args) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = E::pack2(E::lo(v[q]) + E::lo(a[q]), E::hi(v[q]) + E::hi(a[q]));
       }
-      __builtin_amdgcn_raw_buffer_store_b128(v, ry, lane16, c * 1024, SWN_BIG_Y_AUX);
-      asm volatile("s_nop 7\n\ts_nop 7" :: "v"(v));      // (see the write-out hook: keep the store's registers untouched for a few slots)
+      keep2[j] = v;
+      __builtin_amdgcn_raw_buffer_store_b128(keep2[j], ry, lane16, c * 1024, SWN_BIG_Y_AUX);
     }
   }
-  // (no LDS copy is in flight here - the last K phase waited for its own - and stores need no wait: the workgroup retires at once)
+  SWN_WAIT_VM(0);                                  // (the tile's last stores have retired: their operands may go)
+  if (rg == 0) SWN_KEEP16(keep);
+  SWN_KEEP8(keep2);
 #ifdef SWN_BIG_TIMING
   if (d.y_add_gather && (tid == 0 || tid == 256) && blockIdx.x < 2048) {     // wave 0 -> row blockIdx.x, wave 4 -> row 2048 + blockIdx.x
     long long* dbg = (long long*)d.y_add_gather + (long)(blockIdx.x + (tid ? 2048 : 0)) * 8;
@@ -1168,14 +1179,16 @@ __device__ __forceinline__ void stage_pieces_q(const Ctx& cx, const char* x, int
 // A half-wave holds one row (lane l31 = its 8 features 8 l31 ..): the row's dot product is 8 sequential fmas per lane, then the
 // xor butterfly over the 32 lanes (16, 8, 4, 2, 1) like the 64-row kernel's 32 chunk lanes.
 template <typename E>
-__device__ __forceinline__ void write_pieces16_comb(const Ctx& cx, int c0, __amdgpu_buffer_rsrc_t rs, const swn_chain_desc& d, long grow0, int rows) {
+__device__ __forceinline__ void write_pieces16_comb(const Ctx& cx, int c0, __amdgpu_buffer_rsrc_t rs, const swn_chain_desc& d, long grow0, int rows,
+                                                    u32x4_t (&keep)[16]) {
   const int lane16 = cx.lane * 16;
   float wv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) wv[e] = d.comb_wsig ? d.comb_wsig[cx.l31 * 8 + e] : 0.f;
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
-    u32x4_t v[8], yc[8];
+    u32x4_t* v = keep + 8 * b;        // (store operands: the caller keeps them allocated until the stores have retired)
+    u32x4_t yc[8];
     float gt[8], ds[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1210,8 +1223,6 @@ __device__ __forceinline__ void write_pieces16_comb(const Ctx& cx, int c0, __amd
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rs, lane16, (c0 + 4 * (8 * b + j)) * 1024, SWN_BIG_Y_AUX);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) asm volatile("s_nop 3" :: "v"(v[j]));
     SWN_PIN();
   }
 }
@@ -1221,7 +1232,8 @@ __device__ __forceinline__ void write_pieces16_comb(const Ctx& cx, int c0, __amd
 // the 16 row pieces of a wave are requested together: ONE global round trip in the staging phase (index and row fetched back to back
 // in two batches of 8 were four: the front backward chain's S phase was twice as long as its other phases)
 template <typename E>
-__device__ __forceinline__ void write_pieces16_gather(const Ctx& cx, int c0, __amdgpu_buffer_rsrc_t rs, const char* y_add, int yidx_off) {
+__device__ __forceinline__ void write_pieces16_gather(const Ctx& cx, int c0, __amdgpu_buffer_rsrc_t rs, const char* y_add, int yidx_off,
+                                                      u32x4_t (&keep)[16]) {
   const int lane16 = cx.lane * 16;
   const int* yidx = (const int*)(cx.smem + yidx_off);
   int ar[16];
@@ -1233,7 +1245,7 @@ __device__ __forceinline__ void write_pieces16_gather(const Ctx& cx, int c0, __a
   for (int j = 0; j < 16; ++j) a[j] = *(const u32x4_t*)(y_add + (long)(ar[j] < 0 ? 0 : ar[j]) * ROWB + cx.l31 * 16);
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
-    u32x4_t v[8];
+    u32x4_t* v = keep + 8 * b;        // (store operands: the caller keeps them allocated until the stores have retired)
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = *(const u32x4_t*)(cx.smem + piece_addr(cx, c0 + 4 * (8 * b + j)));
 #pragma unroll
@@ -1245,8 +1257,6 @@ __device__ __forceinline__ void write_pieces16_gather(const Ctx& cx, int c0, __a
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rs, lane16, (c0 + 4 * (8 * b + j)) * 1024, SWN_BIG_Y_AUX);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) asm volatile("s_nop 3" :: "v"(v[j]));
     SWN_PIN();
   }
 }
@@ -1468,7 +1478,8 @@ __device__ __forceinline__ void epilogue_q_rowbias(f32x16_t (&acc)[4][2], const 
 // carries data, 8 stores per wave instead of the 16 half-empty ones of the 512-byte pieces); a lane multiplies its 8 features by the
 // three colour rows, a butterfly over the row's 16 lanes (quad swaps, half mirror, mirror) gives <h2, w_c> -> T_COL[c][row].
 template <typename E, typename PRE>
-__device__ __forceinline__ void write_rows128_tok(const Ctx& cx, void* y, uint32_t oob, const float* wc, int idx_off, int rows, bool heads, PRE pre) {
+__device__ __forceinline__ void write_rows128_tok(const Ctx& cx, void* y, uint32_t oob, const float* wc, int idx_off, int rows, bool heads, PRE pre,
+                                                  u32x4_t (&keep)[16]) {
   char* smem = cx.smem;
   const int* idx = (const int*)(smem + idx_off);
   const int l15 = cx.lane & 15, rq = cx.lane >> 4;
@@ -1481,7 +1492,7 @@ __device__ __forceinline__ void write_rows128_tok(const Ctx& cx, void* y, uint32
 #pragma unroll
       for (int q = 0; q < 2; ++q) w[c][q] = *(const f32x4_t*)(smem + T_WC + ((c * 128 + l15 * 8 + 4 * q) << 2));
   }
-  u32x4_t v[8];
+  u32x4_t* v = keep;                // (8 store operands: the caller keeps them allocated until the stores have retired)
   int tk[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -1514,8 +1525,6 @@ __device__ __forceinline__ void write_rows128_tok(const Ctx& cx, void* y, uint32
       }
     }
   }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) asm volatile("s_nop 1" :: "v"(v[i]));      // (store operands stay allocated behind their stores: see the write-out hook)
 }
 
 // The lane id, re-derived where it is used (two VALU instructions, nothing to keep alive): a lane id that lives across the phases of
@@ -1733,7 +1742,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
   // ---- fused tail: what a row group does with the rows of a finished tile, and how a tile of dropped tokens is staged ----
   const int yf = TAIL ? (d.y_features ? d.y_features : 256) : 256;           // real width of the last layer
   const uint32_t oob_y = (uint32_t)d.tail_tokens * (uint32_t)(yf * 2), oob_s = (uint32_t)d.tail_tokens * (uint32_t)ROWB;
-  auto tail_out = [&](const Ctx& c_, const Tile& t, int idx_off) {
+  auto tail_out = [&](const Ctx& c_, const Tile& t, int idx_off, u32x4_t (&keep)[16]) {
     // the last layer's rows -> y[token] (128 features), and the heads: raw[token] = (sigmoid(colour sums + b), softplus(sigma sum + b - 1));
     // a wave finishes the 32 rows it wrote out itself (lanes 0 .. 31: one row each, rows 8 j + 2 fg + {0, 1}) - no one else's LDS
     // writes are involved
@@ -1745,7 +1754,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     const bool fin = hd && c_.lhi == 0 && r < t.rows;
     const long tok = fin ? ((const int*)(smem + idx_off))[r] : 0;
     float nz = 0.f;
-    write_rows128_tok<E>(c_, d.y, oob_y, d.heads_wc, idx_off, t.rows, hd, [&]() { if (hd && d.heads_noise) nz = d.heads_noise[tok]; });
+    write_rows128_tok<E>(c_, d.y, oob_y, d.heads_wc, idx_off, t.rows, hd, [&]() { if (hd && d.heads_noise) nz = d.heads_noise[tok]; }, keep);
     if (hd) {
       SWN_WAIT_LGKM0();
       if (fin) {
@@ -1767,10 +1776,12 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
       }
     }
   };
-  auto stage_dropped = [&](const Ctx& c_, const Tile& t, int idx_off) {
+  auto stage_dropped = [&](const Ctx& c_, const Tile& t, int idx_off, u32x4_t& z) {
     // dropped tokens: zero rows into the tile (they meet the shared layers' biases only), zero sigma sums, zero rows of the saved y
+    // (z: the zero store operand, in a register set of the caller's - SWN_KEEP)
     const int rg_ = c_.w >> 2, fg_ = c_.w & 3;
-    const u32x4_t z = {0u, 0u, 0u, 0u};
+    z = u32x4_t{0u, 0u, 0u, 0u};
+    asm volatile("" : "+v"(z));           // (one register set for all 16 stores, not a constant re-materialised beside each)
 #pragma unroll
     for (int j = 0; j < 16; ++j) *(u32x4_t*)(smem + (64 * rg_ + fg_ + 4 * j) * 1024 + c_.lane * 16) = z;
     if (c_.lhi == 0) {      // (the wave's own rows: the ones its tail_out has just read)
@@ -1790,7 +1801,6 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         const int r = 2 * (64 * rg_ + fg_ + 4 * j) + c_.lhi;
         __builtin_amdgcn_raw_buffer_store_b128(z, rs, r < t.rows ? off[j] * (uint32_t)ROWB + (uint32_t)(c_.l31 * 16) : oob_s, 0, SWN_BIG_STORE_AUX);
       }
-      asm volatile("s_nop 7" :: "v"(z));
     }
   };
   if constexpr (TAIL) {
@@ -1836,20 +1846,25 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
       const int rgs = cs.w >> 2, fgs = cs.w & 3;
       int ticket = 0;
       if (cs.w == 0) ticket = claim();           // (the claim of the tile after this one travels under the write-out and the staging)
+      // the store operands of this phase's write-out: allocated (SWN_KEEP) until the s_waitcnt vmcnt(0) at the end of the phase has
+      // retired the stores - no register of a store is handed to the staging's temporaries behind it
+      u32x4_t keep[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) keep[i] = u32x4_t{0u, 0u, 0u, 0u};
       if (it > 0) {
         if constexpr (TAIL) {
-          tail_out(cs, prev, idx_nxt);           // (the other table still holds the previous tile's tokens)
+          tail_out(cs, prev, idx_nxt, keep);     // (the other table still holds the previous tile's tokens)
         } else if (HEAD && prev.l1 < n_layers) {
           // (a tile of dropped tokens has no output rows; its gate gradients were zeroed when it was staged)
         } else {
           const __amdgpu_buffer_rsrc_t ry = out_rs(d.y, prev);
           const __amdgpu_buffer_rsrc_t ra = d.y_add ? out_rs((void*)d.y_add, prev) : ry;
           if constexpr (TAG == 5) {      // (only this instantiation carries the fused combine backward)
-            if (d.comb_y) write_pieces16_comb<E>(cs, 64 * rgs + fgs, ry, d, prev.grow0, prev.rows);
-            else write_pieces16<E, false, 8>(cs, 64 * rgs + fgs, ry, ra);
-          } else if (d.y_add && d.y_add_gather) write_pieces16_gather<E>(cs, 64 * rgs + fgs, ry, (const char*)d.y_add, ((it - 1) & 1) ? Q_YIDX + 1024 : Q_YIDX);
-          else if (d.y_add) write_pieces16<E, true, 8>(cs, 64 * rgs + fgs, ry, ra);
-          else write_pieces16<E, false, 8>(cs, 64 * rgs + fgs, ry, ra);
+            if (d.comb_y) write_pieces16_comb<E>(cs, 64 * rgs + fgs, ry, d, prev.grow0, prev.rows, keep);
+            else write_pieces16<E, false, 8>(cs, 64 * rgs + fgs, ry, ra, keep);
+          } else if (d.y_add && d.y_add_gather) write_pieces16_gather<E>(cs, 64 * rgs + fgs, ry, (const char*)d.y_add, ((it - 1) & 1) ? Q_YIDX + 1024 : Q_YIDX, keep);
+          else if (d.y_add) write_pieces16<E, true, 8>(cs, 64 * rgs + fgs, ry, ra, keep);
+          else write_pieces16<E, false, 8>(cs, 64 * rgs + fgs, ry, ra, keep);
         }
         SWN_WAIT_LGKM0();                        // (every piece is in registers / on its way: the rows may be overwritten)
       }
@@ -1870,7 +1885,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         stage_pieces_q<true>(cs, (const char*)d.x, 64 * rgs + fgs, 16, 4, idx_cur);
       } else if constexpr (TAIL) {
         if (cur.l0) {
-          stage_dropped(cs, cur, idx_cur);
+          stage_dropped(cs, cur, idx_cur, keep[15]);     // (tail_out holds keep[0..7])
         } else {
           if (lts < 128) gate_v = d.tail_gate[((const int*)(smem + idx_cur))[128 * rgs + lts]];      // the rows' gate values -> T_GATE below
           stage_pieces_q<false>(cs, (const char*)d.x, 64 * rgs + fgs, 16, 4, idx_cur);
@@ -1883,6 +1898,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
       // operations of this phase take 6-9 k clocks to ISSUE whatever their order (copies first and a counted wait: no gain) - the CU's
       // vector memory path carries the partner group's weight stream at the same time and is the bound of this kernel family.
       SWN_WAIT_VM(0);
+      SWN_KEEP16(keep);                          // (the write-out's stores have retired)
       if constexpr (TAIL) {
         if (!cur.l0 && lts < 128) ((float*)(smem + T_GATE))[128 * rgs + lts] = gate_v;
       }
@@ -1965,6 +1981,24 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         const int rge = ce.w >> 2, fge = ce.w & 3;
         const int lane16e = ce.lane * 16;
         uint32_t* mkp = ly.mask ? ly.mask + ((size_t)(cur.vb * G::NW + ce.w) * 64 + ce.lane) * 4 : nullptr;
+        // The partner's rows = the input tile of the K loop it is running (same tile: the groups are one phase apart) -> their save
+        // tensor: 16 pieces in 8 batches of 2 through TWO alternating register sets.  Batch 0 is stored in front of the epilogue, batch
+        // h + 1 behind its half row tile h (h < 7); the LDS reads that refill a set are issued a half step after ITS stores, behind the
+        // statement that keeps it allocated (SWN_KEEP) - hundreds of clocks - and the last batch is stored a half step before the phase ends.
+        void* wo = rge == 0 ? (L > cur.l0 ? d.layers[L - 1].save : nullptr) : (!last ? ly.save : nullptr);
+        // fused tail: the saves from the gate layer on go to TOKEN order; the gate layer and the last layer have their own epilogues
+        const bool wo_tok = (TAIL && (rge == 0 ? L - 1 : L) >= d.tail_first - 1) || (HEAD && (rge == 0 ? L - 1 : L) < d.head_layers - 1);
+        const int c0 = 64 * (1 - rge) + fge;
+        u32x4_t wv[2][2];
+        int tk[2][2];                              // (fused tail: the tokens of the pieces' rows)
+        auto rd = [&](int b) {                     // the two pieces of batch b -> set b & 1
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            wv[b & 1][j] = *(const u32x4_t*)(smem + piece_addr(ce, c0 + 4 * (2 * b + j)));
+            if constexpr (DROPS) tk[b & 1][j] = ((const int*)(smem + idx_cur))[2 * (c0 + 4 * (2 * b + j)) + ce.lhi];
+          }
+        };
+        if (wo) rd(0);
         if (!last) mk_next = load_mask(L + 1, cur.vb);
         int row_nxt = 0, yrow = -1;
         if (last && nxt.vb >= 0) row_nxt = load_row(nxt);      // (consumed behind the epilogue)
@@ -1982,10 +2016,6 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
             __builtin_amdgcn_s_sleep(2);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        // the partner's rows = the input tile of the K loop it is running (same tile: the groups are one phase apart)
-        void* wo = rge == 0 ? (L > cur.l0 ? d.layers[L - 1].save : nullptr) : (!last ? ly.save : nullptr);
-        // fused tail: the saves from the gate layer on go to TOKEN order; the gate layer and the last layer have their own epilogues
-        const bool wo_tok = (TAIL && (rge == 0 ? L - 1 : L) >= d.tail_first - 1) || (HEAD && (rge == 0 ? L - 1 : L) < d.head_layers - 1);
         const bool gate_l = TAIL && L + 1 == d.tail_first, rb_l = TAIL && last;
         auto run_epi = [&](auto hook) {
           typedef decltype(hook) HK;
@@ -1997,46 +2027,35 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         };
         if (wo) {
           const __amdgpu_buffer_rsrc_t rs = wo_tok ? uniform_rsrc(wo, (int)oob_s) : out_rs(wo, cur);
-          const int c0 = 64 * (1 - rge) + fge;
-          // 16 pieces in 8 half steps of 2 (one behind every half row tile of the epilogue) through TWO alternating register sets: the
-          // LDS reads that refill a set are issued a half step after ITS stores - hundreds of clocks - never right behind them.  (On
-          // this part a 16-byte store whose registers were rewritten two instructions later reached memory with single dwords of the
-          // NEW value under store back-pressure; chainp_kernel holds that off with 16 idle issue slots behind every store batch,
-          // here the distance is structural.)
-          u32x4_t wv[2][2];
-          int tk[2][2];                            // (fused tail: the tokens of the pieces' rows)
-          auto rd = [&](int h) {
+          auto st = [&](int b) {                   // the two pieces of batch b, from set b & 1
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-              wv[h & 1][j] = *(const u32x4_t*)(smem + piece_addr(ce, c0 + 4 * (2 * h + j)));
-              if constexpr (DROPS) tk[h & 1][j] = ((const int*)(smem + idx_cur))[2 * (c0 + 4 * (2 * h + j)) + ce.lhi];
-            }
-          };
-          rd(0);
-          auto hook_f = [&](int h) {
-            // the set stored a half step ago stays ALLOCATED up to here (an empty statement that reads it): a value is dead behind its
-            // store, and the compiler would hand its registers to the very next epilogue temporaries - the VALU write two instructions
-            // behind the store that the hazard is about.  The next write to them is the refill below.
-            asm volatile("" :: "v"(wv[(h + 1) & 1][0]), "v"(wv[(h + 1) & 1][1]));
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const int c = c0 + 4 * (2 * h + j);
+              const int c = c0 + 4 * (2 * b + j);
               if constexpr (DROPS) {     // one form for both row spaces: row index = the token, or the tile row under a descriptor of the tile's rows
                 const int r = 2 * c + ce.lhi;
-                const uint32_t ri = wo_tok ? (uint32_t)tk[h & 1][j] : (uint32_t)r;
+                const uint32_t ri = wo_tok ? (uint32_t)tk[b & 1][j] : (uint32_t)r;
                 const uint32_t off = r < cur.rows ? ri * (uint32_t)ROWB + (uint32_t)(ce.l31 * 16) : oob_s;
-                __builtin_amdgcn_raw_buffer_store_b128(wv[h & 1][j], rs, off, 0, SWN_BIG_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(wv[b & 1][j], rs, off, 0, SWN_BIG_STORE_AUX);
               } else {
-                __builtin_amdgcn_raw_buffer_store_b128(wv[h & 1][j], rs, lane16e, c * 1024, SWN_BIG_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(wv[b & 1][j], rs, lane16e, c * 1024, SWN_BIG_STORE_AUX);
               }
             }
-            if (h < 7) rd(h + 1);                  // (into the OTHER set: stored from a half step ago)
+          };
+          st(0);                                   // (read at the top of the phase)
+          rd(1);
+          SWN_PIN();
+          auto hook_f = [&](int h) {
+            // the set stored a half step ago (batch h) stays ALLOCATED up to here (an empty statement that reads it): a value is dead
+            // behind its store, and the compiler would hand its registers to the very next epilogue temporaries - the VALU write two
+            // instructions behind the store that the hazard is about.  The next write to them is the refill below.
+            asm volatile("" :: "v"(wv[h & 1][0]), "v"(wv[h & 1][1]));
+            if (h < 7) st(h + 1);                  // (from the OTHER set: read a half step ago)
+            if (h < 6) rd(h + 2);
             SWN_PIN();
           };
           const HalfHook<decltype(hook_f)> hook{hook_f};
           run_epi(hook);
           SWN_PIN();
-          asm volatile("s_nop 7\n\ts_nop 7" :: "v"(wv[0][0]), "v"(wv[0][1]), "v"(wv[1][0]), "v"(wv[1][1]));      // (the last two sets)
         } else {
           run_epi(NoHook());
         }
@@ -2085,19 +2104,24 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
   cf.lane = fresh_lane();
   cf.l31 = cf.lane & 31;
   cf.lhi = cf.lane >> 5;
+  u32x4_t keep[16];                               // (store operands: allocated until the stores have retired - SWN_KEEP)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) keep[i] = u32x4_t{0u, 0u, 0u, 0u};
   if constexpr (TAIL) {
-    tail_out(cf, prev, ((it - 1) & 1) ? Q_IDX1 : G::IDX0);
+    tail_out(cf, prev, ((it - 1) & 1) ? Q_IDX1 : G::IDX0, keep);
   } else if (HEAD && prev.l1 < n_layers) {
   } else {
     const __amdgpu_buffer_rsrc_t ry = out_rs(d.y, prev);
     const __amdgpu_buffer_rsrc_t ra = d.y_add ? out_rs((void*)d.y_add, prev) : ry;
     if constexpr (TAG == 5) {
-      if (d.comb_y) write_pieces16_comb<E>(cf, 64 * rg + fg, ry, d, prev.grow0, prev.rows);
-      else write_pieces16<E, false, 8>(cf, 64 * rg + fg, ry, ra);
-    } else if (d.y_add && d.y_add_gather) write_pieces16_gather<E>(cf, 64 * rg + fg, ry, (const char*)d.y_add, ((it - 1) & 1) ? Q_YIDX + 1024 : Q_YIDX);
-    else if (d.y_add) write_pieces16<E, true, 8>(cf, 64 * rg + fg, ry, ra);
-    else write_pieces16<E, false, 8>(cf, 64 * rg + fg, ry, ra);
+      if (d.comb_y) write_pieces16_comb<E>(cf, 64 * rg + fg, ry, d, prev.grow0, prev.rows, keep);
+      else write_pieces16<E, false, 8>(cf, 64 * rg + fg, ry, ra, keep);
+    } else if (d.y_add && d.y_add_gather) write_pieces16_gather<E>(cf, 64 * rg + fg, ry, (const char*)d.y_add, ((it - 1) & 1) ? Q_YIDX + 1024 : Q_YIDX, keep);
+    else if (d.y_add) write_pieces16<E, true, 8>(cf, 64 * rg + fg, ry, ra, keep);
+    else write_pieces16<E, false, 8>(cf, 64 * rg + fg, ry, ra, keep);
   }
+  SWN_WAIT_VM(0);
+  SWN_KEEP16(keep);
   if (rg == 0) __builtin_amdgcn_s_barrier();      // (row group 1's last phase boundary)
 #ifdef SWN_BIG_TIMING
   if (d.y_add_gather && !d.y_add && cx.lane == 0 && (cx.w == 0 || cx.w == 4) && blockIdx.x < 2048) {   // wave 0 -> row b, wave 4 -> row 2048 + b

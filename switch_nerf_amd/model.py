@@ -122,6 +122,7 @@ class SwitchNeRF:
         # side HIP stream: the HBM-bound expert weight-gradient GEMMs overlap with the rest of the backward pass
         self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self.overlap = os.environ.get("SWN_NO_OVERLAP", "0") != "1"   # side-stream overlap of the expert weight gradients
+        self._kernel_sel = {}         # kernel_set(): what the last forward / backward selected
         self.ep = None                # parallel.ExpertParallel: experts sharded over ranks, tokens exchanged (set_expert_parallel)
         self.expert_wgrad_splits = int(os.environ.get("SWN_EXPERT_WGRAD_SPLITS", "0"))   # 0 = heuristic
 
@@ -326,6 +327,21 @@ class SwitchNeRF:
             ops.repack_weights_batched(pairs)      # one launch (was 23 of ~5 us each: a tenth of the step at 1024 rays per GPU)
         if self._flat_param is not None:           # the copies now match the master weights as of this version of flat_param
             self._packed_version = self._flat_param._version
+
+    def kernel_set(self) -> dict:
+        """The kernel selection the LAST forward / backward of this model resolved to (what the SWN_* environment switches and the
+        shapes added up to): expert chain geometry (7 = persistent phase-shifted 256-row tiles, accumulators start at the bias), front
+        chain geometry, the dense tail inside the expert forward launch (tag 7), its backward + combine backward in front of the expert
+        backward chain (tag 8), the sigma head's weight gradient from that launch's combine pass, side-stream overlap of the expert
+        weight gradients, expert parallelism, and every SWN_* variable that is set.  bench.py prints it in its line's `config`;
+        tests/test_fullsize_gpu.py pins the default set."""
+        sel = dict(self._kernel_sel)
+        sel["wgrad_overlap"] = bool(self.overlap)
+        sel["expert_parallel"] = int(self.ep.world) if self.ep is not None else 0
+        sel["env_overrides"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("SWN_")}
+        return sel
+
+    DEFAULT_KERNEL_SET = dict(geom=7, front_geom=7, tail_fused=True, fused_backward=True, comb_dwsig=True, wgrad_overlap=True)
 
     def _front_big(self) -> bool:
         """The dense front chains (PE -> xyz -> gate MLP, and their backward) on the persistent 256-row geometry: 256-feature layers over
@@ -565,6 +581,7 @@ class SwitchNeRF:
         c["tail_fused"] = (self._tail_fused() and self.ep is None and c["geom"] == 7 and row_range is None
                            and P * M * c_esz(dt) < (1 << 32) - 64 and os.environ.get("SWN_CHAIN_GEOM", "7") == "7")
         c["eo"] = None if c["tail_fused"] else _b("eo", (rows, M), dt)
+        self._kernel_sel.update(geom=c["geom"], front_geom=c["front_geom"], tail_fused=bool(c["tail_fused"]))
         if no_batch and not sv and self.ep is not None:
             # evaluation without token dropping under expert parallelism (tutel_moe_layer_nobatch.py:308-335): the packed rows of a
             # segment, expert-major = (destination rank, local expert), travel with UNEQUAL splits (the reference's list_all_to_all);
@@ -760,6 +777,7 @@ class SwitchNeRF:
         # launch then runs without y - 512 bytes per point less (SWN_FUSED_DWSIG=0: from y in the heads' launch, as before)
         fused_dws = fused_bwd and M == 256 and os.environ.get("SWN_FUSED_DWSIG", "1") != "0"
         y_heads = None if fused_dws else c["y"]
+        self._kernel_sel.update(fused_backward=fused_bwd, comb_dwsig=fused_dws)
         # per-ray bias gradient (the column sums of a ray's dh2 rows: from the heads' launch) and the tiny per-ray GEMM's parameters
         if c.get("ragged"):      # a row range of the point grid: rays may be cut at either end - per-ray sums through the rows' ray index
             dh2, dsig = o.heads_bwd(y_heads, c["h2"], self.p["color.w"], c["raw"], d_raw, g["sigma.w"], g["sigma.b"], g["color.w"],

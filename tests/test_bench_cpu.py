@@ -18,3 +18,33 @@ def test_bench_refuses_without_a_gpu():
     assert one.returncode != 0 and "visible" in one.stderr and not any(l.startswith("{") for l in one.stdout.splitlines())
     many = _run("--gpus", "4", "--steps", "1", "--warmup", "0")
     assert many.returncode != 0 and "GPU(s) are visible" in many.stderr and not any(l.startswith("{") for l in many.stdout.splitlines())
+
+
+def test_traffic_table_is_made_by_script_and_tied_to_the_kernel_sources(tmp_path):
+    """scripts/make_traffic.py turns the two PMC summaries (+ the bench line of each pass) into profiles/traffic.json: corrected bytes
+    = 2 x FETCH + WRITE KiB per launch, the kept rows and the source hash of the pass; _lib.source_hash() is stable and changes with
+    the sources (bench.py reports traffic only when the hashes agree)."""
+    import importlib.util
+    import json
+    import shutil
+    sys.path.insert(0, ROOT)
+    from switch_nerf_amd import _lib
+    h = _lib.source_hash()
+    assert len(h) == 64 and h == _lib.source_hash()
+    spec = importlib.util.spec_from_file_location("make_traffic", os.path.join(ROOT, "scripts", "make_traffic.py"))
+    mt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mt)
+    line = json.dumps({"config": {"rays_per_gpu": 8192, "samples": 256, "kept_token_fraction": 0.78, "csrc_sha256": h, "kernel_set": {"geom": 7}}})
+    (tmp_path / "profiles").mkdir()
+    for c, v7, v8 in (("FETCH_SIZE", 1.0e6, 2.0e6), ("WRITE_SIZE", 9.0e6, 9.5e6)):
+        (tmp_path / "profiles" / f"rXX_pmc_{c}.txt").write_text(
+            f"void swn_big::chainq_kernel<swn_big::Bf16, 7, true>(swn_big::ArgsQ)\n   {c}   {v7:.4e}  (n=3)\n"
+            f"void swn_big::chainq_kernel<swn_big::Bf16, 8, true>(swn_big::ArgsQ)\n   {c}   {v8:.4e}  (n=3)\n"
+            f"swn::dwsig_runs_kernel(float const*, long, int, float*)\n   {c}   1.0000e+02  (n=3)\n" + line + "\n")
+    mt.ROOT = str(tmp_path)
+    sys.argv = ["make_traffic.py", "rXX"]
+    mt.main()
+    t = json.load(open(tmp_path / "profiles" / "traffic.json"))
+    assert t["csrc_sha256"] == h and t["points"] == 8192 * 256 and t["kept_rows"] == round(0.78 * 8192 * 256)
+    assert t["launches"]["expert_fwd"]["hbm_bytes"] == int((2 * 1.0e6 + 9.0e6) * 1024)
+    assert t["launches"]["expert_bwd"]["hbm_bytes"] == int((2 * (2.0e6 + 100) + 9.5e6 + 100) * 1024)

@@ -101,6 +101,12 @@ def test_full_batch_bf16_properties():
     st = m16.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=1.0, perturb_rand=pr, sigma_noise=noise, optimizer_step=False)
     c = st["ctx"]
     assert c["n_seg"] == 16 and c["cap"] == 16384 and c["geom"] == 7 and c["front_geom"] == 7 and c["tail_fused"]
+    # the production path = these defaults (hygiene 13): whatever the environment switches are for, an unset
+    # environment must resolve to exactly this kernel set - the one bench.py times and prints in its line's config.kernel_set
+    ks = m16.kernel_set()
+    unset = {k: v for k, v in ks["env_overrides"].items() if k not in ("SWN_LIB",)}
+    if not unset:
+        assert {k: ks[k] for k in type(m16).DEFAULT_KERNEL_SET} == type(m16).DEFAULT_KERNEL_SET, ks
     rgb16, idx16, loc16 = c["rgb"].clone(), c["idx"].clone(), c["loc"].clone()
     grad16 = m16.grad.clone()
     assert torch.isfinite(rgb16).all() and torch.isfinite(st["loss"]) and torch.isfinite(grad16).all()

@@ -83,6 +83,19 @@ def test_expert_chain_200_back_to_back_launches_bit_exact():
     assert r["ok"] and r["geometry5_launches_with_a_difference"] == 0 and r["geometry7_launches_that_differ_from_geometry4"] == 0, r
 
 
+@pytest.mark.parametrize("env,launches", [({}, 200), ({"SWN_FUSED_TAIL": "0"}, 100)])
+def test_full_step_back_to_back_bit_exact(env, launches):
+    """The launches the step actually runs, 200 full-size steps (8192 rays x 256 samples) back to back: the fused expert forward /
+    backward launches (chainq tags 7 / 8), the front chains (tags 3 / 6) and the weight-gradient kernels that read what they stored;
+    with SWN_FUSED_TAIL=0 the plain expert chains (tags 1 / 2) and the tail chains as their own launches.  Every repetition's gradient,
+    rgb and saved tensors equal the first one's bit for bit, and the tile-queue counters are left at zero."""
+    r = _probe("step", "--launches", str(launches), "--rays", "8192", env=env, timeout=900)
+    assert r["ok"] and r["steps_that_differ_from_the_first"] == 0 and r["tile_queue_counters_left_nonzero"] == 0, r
+    if not env:
+        ks = r["kernel_set"]
+        assert ks["geom"] == 7 and ks["front_geom"] == 7 and ks["tail_fused"] and ks["fused_backward"] and ks["comb_dwsig"], ks
+
+
 def test_render_rays_graph_eval_matches_eager():
     """rendering.render_rays with nerf.graph_eval = True (the path Runner.render_image's pixel-batch loop takes): same results as
     the eager evaluation, for two different batches through the same cached graph, after an optimizer moved the weights."""
