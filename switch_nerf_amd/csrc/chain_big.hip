@@ -656,7 +656,9 @@ __device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, _
 }
 #else
 template <typename E, int NS = KSTEPS>
-__device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, __amdgpu_buffer_rsrc_t rs_cur, u32x4_t (&wq)[WQD][2]) {
+__device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, __amdgpu_buffer_rsrc_t rs_cur, u32x4_t (&wq)[WQD][2], bool skip_w = false) {
+  // (skip_w: -DSWN_ABL_SHAREW only - the wave leaves its weight fragments as they are: what the chain would cost if row group 1 got
+  //  row group 0's weight stream for free, the upper bound of ANY weight-sharing scheme; results are wrong)
   constexpr int MI = 4;           // NS = K steps of this layer (K / 16): 16, or 8 for a 128-feature chain input (geometries 6 / 7)
   char* smem = cx.smem;
   const int lane16 = cx.lane * 16;
@@ -701,7 +703,11 @@ __device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, _
     SWN_PIN();
     SWN_MM(1, 0);
     SWN_PIN();
+#ifdef SWN_ABL_SHAREW
+    if (ks + WQA < NS && !skip_w) load_w(ks + WQA);
+#else
     if (ks + WQA < NS) load_w(ks + WQA);    // into the register set of step ks - 1, whose MFMAs were issued a step ago
+#endif
     SWN_PIN();
     SWN_MM(1, 1);
     SWN_PIN();
@@ -1701,8 +1707,14 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     return uniform_rsrc((char*)base + t.grow0 * ROWB, t.rows * ROWB);
   };
   u32x4_t wq[WQD][2];
+#ifdef SWN_ABL_SHAREW
+  const bool skip_w = rg == 1 && TAG != 3 && TAG != 6;      // (the expert launches only: the front chains still route correctly)
+#else
+  constexpr bool skip_w = false;
+#endif
   auto preload_w = [&](int L, int wset, int lane_) {
     const __amdgpu_buffer_rsrc_t r = wrs(L, wset);
+    if (skip_w) return;
 #pragma unroll
     for (int ks = 0; ks < WQA; ++ks)
 #pragma unroll
@@ -1961,7 +1973,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
 #ifdef SWN_KPRIO
           __builtin_amdgcn_s_setprio(SWN_KPRIO);      // the K phase's wave ahead of its SIMD partner (in an E or S phase: VALU, LDS, stores)
 #endif
-          k_phase2<E>(acc, ck, rs_cur, wq);
+          k_phase2<E>(acc, ck, rs_cur, wq, skip_w);
 #ifdef SWN_KPRIO
           __builtin_amdgcn_s_setprio(0);
 #endif
