@@ -138,6 +138,10 @@ def main():
                     help="balanced: the MAIN measurement runs with point i -> expert i mod E (used by the counter passes: bytes per kept row)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--no-ep-probe", action="store_true",
+                    help="N > 1, data parallel: skip the expert-parallel measurement that otherwise follows the headline in the same line")
+    ap.add_argument("--ep-probe-limit", type=float, default=180.0,
+                    help="seconds the expert-parallel probe may take before the line is printed without it (a collective that never returns)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -607,29 +611,45 @@ def main():
         model.graph_train = False
 
     # ---- expert parallel: what travelled, and how much of the exchange was hidden behind the expert kernels
-    ep_info = None
-    if a.parallelism == "ep" and model.ep is not None:
+    def ep_report(psteps=3):
+        """A few profiled expert-parallel steps -> what left this GPU, the collectives' time on the side stream, the time the launch
+        stream waited for them, and the rows every rank's experts received (the GPU-level load imbalance of one expert per GPU)."""
         ep_ = model.ep
         ep_.profile, ep_.bytes_sent = True, 0
         ep_.overlap_report()
-        psteps = 3
+        st_ = None
         for _ in range(psteps):
-            st = step()
+            st_ = step()
         torch.cuda.synchronize()
         rep = ep_.overlap_report()
         ep_.profile = False
-        c_ = st["ctx"]
+        c_ = st_["ctx"]
         kept_rows = int(c_["counts"].clamp(max=c_["cap"]).sum().item())
-        ep_info = dict(exchange=("capacity-padded equal-split" if c_.get("ep_padded") else "kept rows only, unequal-split") +
-                                " all_to_all_single per routing segment on a side HIP stream; 4 exchanges per segment and step (dispatch / "
-                                "return, forward / backward)", padded=bool(c_.get("ep_padded")),
-                       segments=int(c_["n_seg"]), kept_rows_per_step=kept_rows,
-                       bytes_leaving_this_gpu_per_step=int(ep_.bytes_sent // psteps),
-                       bytes_per_segment_exchange=int(ep_.bytes_sent // psteps // max(1, 4 * int(c_["n_seg"]))),
-                       capacity_padded_bytes_per_step=int(4 * c_["n_seg"] * model.E * c_["cap"] * model.M * esz * (world - 1) // world),
-                       collectives_per_step=rep["collectives"] // psteps, collective_ms_per_step=round(rep["collective_ms"] / psteps, 3),
-                       wait_ms_per_step=round(rep["wait_ms"] / psteps, 3),
-                       hidden_fraction=None if rep["hidden_fraction"] is None else round(rep["hidden_fraction"], 4))
+        mine = torch.tensor([int(c_["ep_counts"].sum().item())], device=dev, dtype=torch.int64)      # rows this rank's experts ran
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        if dist:
+            dist.all_gather(per_rank, mine)
+        else:
+            per_rank = [mine]
+        per_rank = [int(t.item()) for t in per_rank]
+        mean_rows = sum(per_rank) / max(1, len(per_rank))
+        return dict(exchange=("capacity-padded equal-split" if c_.get("ep_padded") else "kept rows only, unequal-split") +
+                             " all_to_all_single per routing segment on a side HIP stream; 4 exchanges per segment and step (dispatch / "
+                             "return, forward / backward)", padded=bool(c_.get("ep_padded")),
+                    segments=int(c_["n_seg"]), kept_rows_per_step=kept_rows,
+                    bytes_leaving_this_gpu_per_step=int(ep_.bytes_sent // psteps),
+                    bytes_per_segment_exchange=int(ep_.bytes_sent // psteps // max(1, 4 * int(c_["n_seg"]))),
+                    capacity_padded_bytes_per_step=int(4 * c_["n_seg"] * model.E * c_["cap"] * model.M * esz * (world - 1) // world),
+                    collectives_per_step=rep["collectives"] // psteps, collective_ms_per_step=round(rep["collective_ms"] / psteps, 3),
+                    wait_ms_per_step=round(rep["wait_ms"] / psteps, 3),
+                    hidden_fraction=None if rep["hidden_fraction"] is None else round(rep["hidden_fraction"], 4),
+                    expert_rows_per_rank=per_rank,
+                    load_imbalance_max_over_mean=None if mean_rows <= 0 else round(max(per_rank) / mean_rows, 4),
+                    tail="64-row tail launches (the fused tail rides the expert launch of LOCAL experts only: INTEGRATION.md section 5)")
+
+    ep_info = None
+    if a.parallelism == "ep" and model.ep is not None:
+        ep_info = ep_report()
 
     # ---- data parallel: the gradient all-reduce - its time and how much of it ran under the second backward graph
     ar_info = None
@@ -689,6 +709,40 @@ def main():
     if ar_info is not None:
         out["config"]["allreduce"] = ar_info
         out["allreduce_ms"], out["allreduce_hidden_fraction"] = ar_info["allreduce_ms"], ar_info["allreduce_hidden_fraction"]
+
+    # ---- N > 1, data parallel (the driver's scaling run): the expert-parallel step of the SAME batch right behind the headline, in the
+    #      same line (north_star: RCCL all-to-all over xGMI in place of Tutel's; BASELINE configs[2]) - experts sharded E / N per GPU, kept
+    #      rows exchanged per routing segment on a side stream, eager launches (the kept-rows mode reads split sizes on the host).
+    #      A watchdog prints the line without it if a collective never returns: the headline must not depend on the probe.
+    if world > 1 and a.parallelism == "dp" and plain and not other and not a.no_ep_probe and model.E % world == 0:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["config"]["expert_parallel"] = dict(error=f"the expert-parallel probe did not finish within {a.ep_probe_limit:.0f} s")
+                out["cpu_baseline"] = None
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog = threading.Timer(a.ep_probe_limit + (0.0 if rank == 0 else 5.0), give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            from switch_nerf_amd.parallel import ExpertParallel
+            graphed[0] = None
+            model.set_expert_parallel(ExpertParallel(rank, world, model.E, padded=False))
+            reset_state(4321)
+            for _ in range(3):
+                step()
+            reset_state(1234)
+            esteps = max(3, min(10, a.steps))
+            edt_, est_ = timed(esteps, False)
+            x = ep_report()
+            x.update(steps=esteps, ms_per_step=round(edt_ / esteps * 1e3, 3), value=round(n_rays * world * esteps / edt_, 1), unit="rays/s",
+                     launches="eager (compare with config.eager_ms_per_step of the data-parallel step)", loss=round(float(est_["loss"].item()), 6))
+            out["config"]["expert_parallel"] = x
+        except Exception as e:      # (the same exception on every rank: a one-sided failure ends in the watchdog)
+            out["config"]["expert_parallel"] = dict(error=f"{type(e).__name__}: {e}"[:400])
+        dog.cancel()
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline and not other:
             try:

@@ -38,6 +38,14 @@ def test_two_ranks_dp_and_ep_agree():
     assert abs(dp["config"]["loss"] - ep["config"]["loss"]) <= 5e-5 * abs(dp["config"]["loss"])
     assert abs(dp["config"]["kept_token_fraction"] - ep["config"]["kept_token_fraction"]) < 1e-3
     assert dp["value"] > 0 and ep["value"] > 0
+    # the data-parallel line carries the expert-parallel measurement of the same batch (the driver's scaling run gets one invocation per
+    # N: north_star's all-to-all must not need a second one) - rays/s, bytes per GPU, hidden fraction, the rows every rank's experts ran
+    xd = dp["config"]["expert_parallel"]
+    assert "error" not in xd, xd
+    assert xd["value"] > 0 and xd["ms_per_step"] > 0 and xd["collectives_per_step"] == 4 * xd["segments"] and xd["hidden_fraction"] is not None
+    assert len(xd["expert_rows_per_rank"]) == 2 and min(xd["expert_rows_per_rank"]) > 0 and xd["load_imbalance_max_over_mean"] >= 1.0
+    assert 0 < xd["bytes_leaving_this_gpu_per_step"] < xd["capacity_padded_bytes_per_step"]
+    assert dp["config"]["kernel_set"]["expert_parallel"] in (0, 2) and len(dp["config"]["csrc_sha256"]) == 64
     x = ep["config"]["expert_parallel"]
     # kept rows only: what leaves a GPU is (W - 1) / W of 4 exchanges of the kept rows, not of the capacity-padded payload
     assert x["segments"] >= 1 and 0 < x["bytes_leaving_this_gpu_per_step"] < x["capacity_padded_bytes_per_step"]
