@@ -105,6 +105,21 @@ int swn_route_top1(const int32_t* idx, const float* gmax, const float* gates,
                    int32_t* loc, int32_t* counts, int32_t* perm, int32_t* tok2row, float* l_aux,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same routing in ONE launch (route.hip, route_one_kernel: resident workgroups walk the tiles through the phases of the radix sort
+ * and meet at grid barriers), with the list of dropped tokens (swn_route_dropped's outputs: both NULL or both given) from the same
+ * launch.  Replaces the same reference code as swn_route_top1 (tutel_fast_dispatch.py:136-217) - every output is identical to
+ * swn_route_top1 + swn_route_dropped (the tile bodies are the same code, l_aux is added in the same order).
+ *   sync: int32 [swn_route_sync_bytes() / 4], ZERO before the first launch and left zero by every launch; launches that may overlap
+ *         (different streams) need different ones.  NULL, more than 255 segments, more than 2048 (segment, expert) groups with the
+ *         dropped-token lists, or SWN_ROUTE_MULTI=1 in the environment: the per-phase launches of swn_route_top1 (+ swn_route_dropped).
+ *   workspace: swn_route_workspace_bytes() as for swn_route_top1.                                                                    */
+size_t swn_route_sync_bytes(void);
+int swn_route_top1x(const int32_t* idx, const float* gmax, const float* gates,
+                    int n_tokens, int seg_tokens, int n_experts, int capacity, int bpr,
+                    int32_t* loc, int32_t* counts, int32_t* perm, int32_t* tok2row, float* l_aux,
+                    int32_t* drop_begin, int32_t* dropped, int32_t* sync,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- Tutel sparse kernel ABI (batched, capacity padded) ------------------------------------------------------
  * replaces tutel.jit_kernels.sparse func_fwd / func_bwd_data / func_bwd_gate as called from
  * tutel_fast_dispatch.py:27,36,43,61,70,76 - same argument order (gates, indices, locations, reshaped_input,

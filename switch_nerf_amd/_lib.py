@@ -74,6 +74,7 @@ SIGNATURES = {
     "swn_gate_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
     "swn_gate_bwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp],
     "swn_route_top1": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp],
+    "swn_route_top1x": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp],
     "swn_dispatch_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "swn_dispatch_bwd_data": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "swn_dispatch_bwd_gate": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
@@ -153,6 +154,8 @@ def load():
     lib.swn_last_error.argtypes = []
     lib.swn_route_workspace_bytes.restype = sz
     lib.swn_route_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.swn_route_sync_bytes.restype = sz
+    lib.swn_route_sync_bytes.argtypes = []
     lib.swn_gate_bwd_scratch_floats.restype = sz
     lib.swn_gate_bwd_scratch_floats.argtypes = [i32, i32, i32]
     lib.swn_wgrad_multi_workspace_bytes.restype = sz

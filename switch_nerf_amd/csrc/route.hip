@@ -313,6 +313,357 @@ __global__ __launch_bounds__(256) void laux_final_kernel(const float* __restrict
   }
 }
 
+
+// =================================================================================================================================
+// The whole routing in ONE launch (swn_route_top1x; VERDICT round 4, missing 5).
+//
+// The multi-launch form above is 20 launches per call (2 fills, keys, 4 x (histogram, scan, scatter), finalize, 2 for l_aux, 2 for the
+// dropped-token lists): 0.27 ms at 2M tokens for ~200 MB of traffic, 0.13 ms of the 2.16 ms step at 1024 rays per GPU - launch gaps and
+// tails, not bytes.  Here a grid of resident 256-thread workgroups (at most two per CU: always co-resident) walks the SAME tiles through the
+// SAME phases - the tile bodies are the per-phase kernels' code, so every integer output is identical by construction and l_aux is added
+// in the same order - and meets at a grid barrier between the phases:
+//     A   per tile: keys / values, the tile's expert histogram, its digit histogram of pass 0, its l_aux partial sums;
+//         the LAST tile of a segment to arrive (a per-segment ticket) adds up the segment's counts and scans its histogram
+//     B   scatter pass 0
+//     B   per pass q = 1 .. n_pass - 1:  histogram (+ scan by the last tile of the segment)   B   scatter   B
+//     F   per tile: loc / perm / tok2row and the list of dropped tokens from the sorted order; empty capacity slots of perm = -1 (no
+//         fill launch); l_aux per segment
+// 8 grid barriers with batch-prioritised routing (4 passes of 8 bits), 2 without.  A barrier is one agent-scope atomic add + a spin
+// on it by one lane per workgroup behind a release fence, an acquire fence in front of the next phase.  `sync`: int32 [SYNC_WORDS],
+// zero before the first launch, left zero by every launch (the last workgroup out resets it), one per stream that may run a routing
+// (ops.route_sync()).
+// =================================================================================================================================
+constexpr int ROUTE_SYNC_WORDS = 1024;      // [0] barrier arrivals, [1] workgroups that left, [2 + pass * n_seg + seg] tiles of (pass, segment) done
+constexpr int ROUTE_ONE_MAX_GROUPS = 2048;  // (segment, expert) groups whose dropped-token prefix fits the workgroup's LDS table
+
+struct RouteOne {
+  const int32_t* idx; const float* gmax; const float* gates;
+  int n_tokens, seg_tokens, E, capacity, bpr, n_seg, nblk, n_pass, shift0;
+  int32_t* loc; int32_t* counts; int32_t* perm; int32_t* tok2row; float* l_aux; int32_t* drop_begin; int32_t* dropped;
+  uint32_t* k0; uint32_t* k1; int32_t* v0; int32_t* v1; int32_t* hist; int32_t* ehist; float* partial; int32_t* sync;
+};
+
+__device__ __forceinline__ void route_grid_barrier(int32_t* ctr, int& epoch) {
+  // (the form of the device library's grid sync: EVERY wave releases at agent scope - its stores are out of this XCD's L2 - before the
+  //  workgroup barrier, one lane signals and spins, every wave acquires behind the second workgroup barrier)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ++epoch;
+    __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int target = epoch * (int)gridDim.x;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// the exclusive scan of one segment's tile histograms in (digit, tile) order: route_scan_kernel's body for 256 bins on 256 threads
+template <int NB>
+__device__ __forceinline__ void route_scan_seg(int32_t* __restrict__ hist, int seg, int nblk, int32_t* rowsum /* LDS [4] */) {
+  constexpr int BINS = 256;
+  const int d = threadIdx.x;
+  int32_t* row = hist + (long)seg * nblk * BINS + d;
+  int32_t s = 0;
+  int32_t c[NB > 0 ? NB : 1];
+  if constexpr (NB > 0) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) c[b] = b < nblk ? row[(long)b * BINS] : 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) s += c[b];
+  } else {
+    for (int b = 0; b < nblk; ++b) s += row[(long)b * BINS];
+  }
+  int32_t v = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int32_t t = __shfl_up(v, o, 64);
+    if ((d & 63) >= o) v += t;
+  }
+  __syncthreads();                                     // (rowsum may still be read by the previous use)
+  if ((d & 63) == 63) rowsum[d >> 6] = v;
+  __syncthreads();
+  for (int w = 0; w < (d >> 6); ++w) v += rowsum[w];
+  int32_t run = v - s;
+  if constexpr (NB > 0) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b < nblk) row[(long)b * BINS] = run;
+      run += c[b];
+    }
+  } else {
+    for (int b = 0; b < nblk; ++b) {
+      const int32_t cc = row[(long)b * BINS];
+      row[(long)b * BINS] = run;
+      run += cc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
+  constexpr int BITS = 8, BINS = 256;
+  __shared__ int32_t h[BINS];             // a tile's digit histogram
+  __shared__ int32_t wh[4][BINS];         // scatter: per-wave digit counts / bases
+  __shared__ int32_t eh[64];              // a tile's expert histogram
+  __shared__ float red[256];              // l_aux partial sums
+  __shared__ int32_t rowsum[4];
+  __shared__ int32_t flag;
+  __shared__ int32_t dbeg[ROUTE_ONE_MAX_GROUPS + 1];      // F: dropped tokens of the groups before g
+  __shared__ int32_t gstart[65];                          // F: first sorted position of every expert of the tile's segment
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int E = a.E, nblk = a.nblk, n_seg = a.n_seg, seg_tokens = a.seg_tokens;
+  const int n_tiles = n_seg * nblk;
+  int epoch = 0;
+  int32_t* bar = a.sync;
+  int32_t* arrive = a.sync + 2;
+
+  // the last tile of (pass, segment) to finish: adds up the counts (pass 0) and scans the segment's histogram
+  auto tile_done = [&](int pass, int seg) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) {
+      const int old = __hip_atomic_fetch_add(arrive + pass * n_seg + seg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      flag = old == nblk - 1;
+    }
+    __syncthreads();
+    if (!flag) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (pass == 0 && tid < E) {
+      int32_t c = 0;
+      for (int b = 0; b < nblk; ++b) c += a.ehist[((long)seg * nblk + b) * E + tid];
+      a.counts[seg * E + tid] = c;
+    }
+    if (nblk <= 16) route_scan_seg<16>(a.hist, seg, nblk, rowsum);
+    else if (nblk <= 64) route_scan_seg<64>(a.hist, seg, nblk, rowsum);
+    else route_scan_seg<0>(a.hist, seg, nblk, rowsum);
+  };
+
+  // ================= phase A: keys, values, expert / digit histograms, l_aux partial sums =================
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int seg = t / nblk, blk = t - seg * nblk;
+    const long sbase = (long)seg * seg_tokens;
+    for (int d = tid; d < BINS; d += 256) h[d] = 0;
+    if (tid < 64) eh[tid] = 0;
+    __syncthreads();
+    for (int j = 0; j < KPB / 256; ++j) {
+      const int p = blk * KPB + j * 256 + tid;
+      int e = -1;
+      uint32_t key = 0;
+      if (p < seg_tokens) {
+        const long i = sbase + p;
+        e = a.idx[i];
+        uint32_t inv = 0;
+        if (a.bpr) {
+          const int32_t b = (int32_t)0x3F800000 - (int32_t)__float_as_uint(a.gmax[i]);
+          inv = b < 0 ? 0u : (b > 0x03FFFFFF ? 0x03FFFFFFu : (uint32_t)b);
+        }
+        key = ((uint32_t)e << 26) | inv;
+        a.k0[i] = key;
+        a.v0[i] = p;
+        atomicAdd(&h[(key >> a.shift0) & (BINS - 1)], 1);
+      }
+      for (int q = 0; q < E; ++q) {                    // one ballot per expert, one LDS add per wave and expert
+        const unsigned long long m = __ballot(e == q);
+        if (lane == 0 && m) atomicAdd(&eh[q], (int)__popcll(m));
+      }
+    }
+    __syncthreads();
+    for (int d = tid; d < BINS; d += 256) a.hist[((long)seg * nblk + blk) * BINS + d] = h[d];
+    if (tid < E) a.ehist[((long)seg * nblk + blk) * E + tid] = eh[tid];
+    if (a.gates && a.l_aux) {                          // laux_partial_kernel's body (same tile, same order of additions)
+      const float* gp = a.gates + sbase * E;
+      const int e = tid % E, t0 = tid / E, tstep = 256 / E;
+      float s = 0.f;
+      const int pbeg = blk * KPB, pend = min(seg_tokens, pbeg + KPB);
+      int p = pbeg + t0;
+      for (; p + 7 * tstep < pend; p += 8 * tstep) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = gp[(long)(p + u * tstep) * E + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; p < pend; p += tstep) s += gp[(long)p * E + e];
+      red[tid] = s;
+      __syncthreads();
+      if (tid < E) {
+        float acc = 0.f;
+        for (int q = tid; q < 256; q += E) acc += red[q];
+        a.partial[((long)seg * nblk + blk) * E + tid] = acc;
+      }
+    }
+    tile_done(0, seg);
+  }
+  route_grid_barrier(bar, epoch);
+
+  // ================= the passes =================
+  const uint32_t* ki = a.k0;
+  const int32_t* vi = a.v0;
+  uint32_t* ko = a.k1;
+  int32_t* vo = a.v1;
+  int shift = a.shift0;
+  for (int pass = 0; pass < a.n_pass; ++pass) {
+    if (pass > 0) {      // histogram of this pass's digit in the order the previous pass left (route_hist_kernel's body)
+      for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int seg = t / nblk, blk = t - seg * nblk;
+        for (int d = tid; d < BINS; d += 256) h[d] = 0;
+        __syncthreads();
+        const uint32_t* k = ki + (long)seg * seg_tokens;
+        for (int j = 0; j < KPB / 256; ++j) {
+          const int p = blk * KPB + j * 256 + tid;
+          if (p < seg_tokens) atomicAdd(&h[(k[p] >> shift) & (BINS - 1)], 1);
+        }
+        __syncthreads();
+        for (int d = tid; d < BINS; d += 256) a.hist[((long)seg * nblk + blk) * BINS + d] = h[d];
+        tile_done(pass, seg);
+      }
+      route_grid_barrier(bar, epoch);
+    }
+    // stable scatter (route_scatter_kernel's body)
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+      const int seg = t / nblk, blk = t - seg * nblk;
+      const long sbase = (long)seg * seg_tokens;
+      __syncthreads();
+      for (int j = tid; j < 4 * BINS; j += 256) (&wh[0][0])[j] = 0;
+      __syncthreads();
+      const int p0 = blk * KPB + w * (KPB / 4);
+      for (int r = 0; r < KPB / 4 / 64; ++r) {
+        const int p = p0 + r * 64 + lane;
+        const bool valid = p < seg_tokens;
+        const int d = valid ? (int)((ki[sbase + p] >> shift) & (BINS - 1)) : 0;
+        const unsigned long long m = match_digit<BITS>(d, valid);
+        if (valid && lane == __ffsll((long long)m) - 1) wh[w][d] += __popcll(m);
+      }
+      __syncthreads();
+      for (int d = tid; d < BINS; d += 256) {
+        int32_t base = a.hist[((long)seg * nblk + blk) * BINS + d];
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+          const int32_t c = wh[ww][d];
+          wh[ww][d] = base;
+          base += c;
+        }
+      }
+      __syncthreads();
+      for (int r = 0; r < KPB / 4 / 64; ++r) {
+        const int p = p0 + r * 64 + lane;
+        const bool valid = p < seg_tokens;
+        uint32_t key = 0;
+        int32_t val = 0;
+        if (valid) { key = ki[sbase + p]; val = vi[sbase + p]; }
+        const int d = (int)((key >> shift) & (BINS - 1));
+        const unsigned long long m = match_digit<BITS>(d, valid);
+        if (valid) {
+          const int rank = __popcll(m & ((1ull << lane) - 1ull));
+          const int32_t pos = wh[w][d] + rank;
+          ko[sbase + pos] = key;
+          vo[sbase + pos] = val;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valid && lane == __ffsll((long long)m) - 1) wh[w][d] += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    route_grid_barrier(bar, epoch);
+    shift += BITS;
+    const uint32_t* tk = ki; ki = ko; ko = (uint32_t*)tk;
+    const int32_t* tv = vi; vi = vo; vo = (int32_t*)tv;
+  }
+
+  // ================= phase F: locations, row spaces, dropped tokens, l_aux =================
+  const int n_groups = n_seg * E, cap = a.capacity;
+  if (a.drop_begin) {      // every workgroup: the prefix of the dropped-token counts over all groups (LDS; workgroup 0 also writes it out)
+    int32_t* part = wh[0];
+    const int per = (n_groups + 255) / 256;
+    const int g0 = tid * per;
+    int run = 0;
+    for (int q = 0; q < per; ++q) {
+      const int g = g0 + q;
+      if (g < n_groups) run += max(a.counts[g] - cap, 0);
+    }
+    __syncthreads();
+    part[tid] = run;
+    __syncthreads();
+    int base = 0;
+    for (int t = 0; t < tid; ++t) base += part[t];
+    for (int q = 0; q < per; ++q) {
+      const int g = g0 + q;
+      if (g < n_groups) {
+        dbeg[g] = base;
+        base += max(a.counts[g] - cap, 0);
+      }
+    }
+    if (tid == 255) dbeg[n_groups] = base;
+    __syncthreads();
+    if (blockIdx.x == 0)
+      for (int g = tid; g <= n_groups; g += 256) a.drop_begin[g] = dbeg[g];
+  }
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int seg = t / nblk, blk = t - seg * nblk;
+    const long sbase = (long)seg * seg_tokens;
+    __syncthreads();
+    if (tid == 0) {
+      int s_ = 0;
+      for (int q = 0; q < E; ++q) { gstart[q] = s_; s_ += a.counts[seg * E + q]; }
+    }
+    __syncthreads();
+    for (int j = 0; j < KPB / 256; ++j) {
+      const int pos = blk * KPB + j * 256 + tid;
+      if (pos >= seg_tokens) continue;
+      const int e = (int)(ki[sbase + pos] >> 26);
+      const int l = pos - gstart[e];
+      const long tok = sbase + vi[sbase + pos];
+      a.loc[tok] = l;
+      const long row = ((long)seg * E + e) * cap + l;
+      if (l < cap) {
+        if (a.perm) a.perm[row] = (int32_t)tok;
+        if (a.tok2row) a.tok2row[tok] = (int32_t)row;
+      } else {
+        if (a.tok2row) a.tok2row[tok] = -1;
+        if (a.dropped) a.dropped[dbeg[seg * E + e] + (l - cap)] = (int32_t)tok;
+      }
+    }
+  }
+  if (a.perm) {            // the capacity slots no token took: -1 (the multi-launch form fills the whole tensor first)
+    const long rows = (long)n_groups * cap;
+    for (long r = (long)blockIdx.x * 256 + tid; r < rows; r += (long)gridDim.x * 256) {
+      const int g = (int)(r / cap);
+      const int l = (int)(r - (long)g * cap);
+      if (l >= a.counts[g]) a.perm[r] = -1;
+    }
+  }
+  if (a.gates && a.l_aux) {      // laux_final_kernel's body, one workgroup per segment
+    for (int seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
+      const int e = tid % E, sub = tid / E, nsub = 256 / E;
+      float me = 0.f;
+      for (int b = sub; b < nblk; b += nsub) me += a.partial[((long)seg * nblk + b) * E + e];
+      __syncthreads();
+      red[tid] = me;
+      __syncthreads();
+      if (tid < E) {
+        float acc = 0.f;
+        for (int q = 0; q < nsub; ++q) acc += red[q * E + tid];
+        red[tid] = acc * (float)a.counts[seg * E + tid];
+      }
+      __syncthreads();
+      if (tid == 0) {
+        float tot = 0.f;
+        for (int q = 0; q < E; ++q) tot += red[q];
+        const float scale = (float)((double)E / ((double)seg_tokens * (double)seg_tokens));
+        a.l_aux[seg] = tot * scale;
+      }
+    }
+  }
+  // ---- leave the synchronisation words at zero for the next launch: the last workgroup out (everyone has passed every barrier) ----
+  __syncthreads();
+  if (tid == 0) {
+    const int old = __hip_atomic_fetch_add(a.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (int)gridDim.x - 1) {
+      for (int i = 0; i < 2 + a.n_pass * n_seg; ++i) __hip_atomic_store(a.sync + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 }  // namespace swn
 
 using namespace swn;
@@ -323,7 +674,61 @@ extern "C" size_t swn_route_workspace_bytes(int n_tokens, int n_seg, int n_exper
   const int seg_tokens = n_seg > 0 ? (n_tokens + n_seg - 1) / n_seg : n_tokens;
   const int nblk = (seg_tokens + KPB - 1) / KPB;
   return 4 * align256((size_t)n_tokens * 4) + align256((size_t)n_seg * 1024 * nblk * 4) +
-         align256((size_t)n_seg * nblk * n_experts * 4) + 1024;
+         2 * align256((size_t)n_seg * nblk * n_experts * 4) + 1024;
+}
+
+extern "C" size_t swn_route_sync_bytes(void) { return (size_t)ROUTE_SYNC_WORDS * 4; }
+
+static int route_compute_units() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    n = cus;
+  }
+  return n;
+}
+
+extern "C" int swn_route_top1x(const int32_t* idx, const float* gmax, const float* gates, int n_tokens, int seg_tokens,
+                               int n_experts, int capacity, int bpr, int32_t* loc, int32_t* counts, int32_t* perm,
+                               int32_t* tok2row, float* l_aux, int32_t* drop_begin, int32_t* dropped, int32_t* sync,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  SWN_CHECK(idx && gmax && loc && counts && workspace, "swn_route_top1x: null pointer");
+  SWN_CHECK(n_tokens > 0 && seg_tokens > 0 && n_tokens % seg_tokens == 0,
+            "swn_route_top1x: n_tokens (%d) must be a positive multiple of seg_tokens (%d)", n_tokens, seg_tokens);
+  SWN_CHECK(n_experts >= 1 && n_experts <= 64 && (256 % n_experts) == 0, "swn_route_top1x: experts must divide 256 (<= 64)");
+  SWN_CHECK(capacity >= 1, "swn_route_top1x: capacity must be >= 1");
+  SWN_CHECK((drop_begin == nullptr) == (dropped == nullptr), "swn_route_top1x: drop_begin and dropped come together");
+  const int n_seg = n_tokens / seg_tokens;
+  SWN_CHECK(workspace_bytes >= swn_route_workspace_bytes(n_tokens, n_seg, n_experts), "swn_route_top1x: workspace too small");
+  // the one-launch form needs its synchronisation words, a ticket per (pass, segment) and - for the dropped-token lists - the group
+  // prefix in LDS; anything else (and SWN_ROUTE_MULTI=1: tests compare the two forms) takes the per-phase launches
+  static const bool multi = getenv("SWN_ROUTE_MULTI") != nullptr;
+  const bool one = !multi && sync != nullptr && 2 + 4 * n_seg <= ROUTE_SYNC_WORDS && (!drop_begin || n_seg * n_experts <= ROUTE_ONE_MAX_GROUPS);
+  if (!one) {
+    int rc = swn_route_top1(idx, gmax, gates, n_tokens, seg_tokens, n_experts, capacity, bpr, loc, counts, perm, tok2row, l_aux, workspace,
+                            workspace_bytes, stream);
+    if (rc == 0 && drop_begin) rc = swn_route_dropped(idx, loc, counts, n_tokens, seg_tokens, n_experts, capacity, drop_begin, dropped, stream);
+    return rc;
+  }
+  const int nblk = cdiv(seg_tokens, KPB);
+  char* ws = (char*)workspace;
+  const size_t tb = align256((size_t)n_tokens * 4), hb = align256((size_t)n_seg * 1024 * nblk * 4), pb = align256((size_t)n_seg * nblk * n_experts * 4);
+  RouteOne a;
+  a.idx = idx; a.gmax = gmax; a.gates = gates;
+  a.n_tokens = n_tokens; a.seg_tokens = seg_tokens; a.E = n_experts; a.capacity = capacity; a.bpr = bpr; a.n_seg = n_seg; a.nblk = nblk;
+  a.n_pass = bpr ? 4 : 1;                  // the key has 26 + ceil(log2 E) significant bits; without BPR only the expert bits differ
+  a.shift0 = bpr ? 0 : 24;
+  a.loc = loc; a.counts = counts; a.perm = perm; a.tok2row = tok2row; a.l_aux = l_aux; a.drop_begin = drop_begin; a.dropped = dropped;
+  a.k0 = (uint32_t*)ws; a.k1 = (uint32_t*)(ws + tb); a.v0 = (int32_t*)(ws + 2 * tb); a.v1 = (int32_t*)(ws + 3 * tb);
+  a.hist = (int32_t*)(ws + 4 * tb); a.partial = (float*)(ws + 4 * tb + hb); a.ehist = (int32_t*)(ws + 4 * tb + hb + pb);
+  a.sync = sync;
+  const int n_tiles = n_seg * nblk;
+  int grid = 2 * route_compute_units();    // at most two 256-thread workgroups per CU: always co-resident (the grid barrier's condition)
+  if (grid > n_tiles) grid = n_tiles;
+  hipLaunchKernelGGL(route_one_kernel, dim3(grid), dim3(256), 0, as_stream(stream), a);
+  SWN_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int swn_route_top1(const int32_t* idx, const float* gmax, const float* gates, int n_tokens, int seg_tokens,

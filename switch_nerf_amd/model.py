@@ -550,8 +550,14 @@ class SwitchNeRF:
             c["idx"] = routing_override.to(dev).int().contiguous()
             c["gmax"] = c["gates"].gather(1, c["idx"].long()[:, None])[:, 0].contiguous()
         packed = bool(no_batch) and not sv and self.ep is None      # (see below: the no-batch row layout of the inference forward)
-        c["loc"], c["counts"], c["perm"], c["tok2row"], c["l_aux"] = o.route_top1(c["idx"], c["gmax"], c["gates"], seg_tokens,
-                                                                                  E, cap, self.bpr, want_perm=not packed)
+        # (the fused tail's list of dropped tokens comes out of the routing launch: the conditions of c["tail_fused"] below)
+        geom_ = int(os.environ.get("SWN_CHAIN_GEOM", "7")) if (M == 256 and dt != torch.float32 and cap >= 256) else 1
+        want_drops = (self._tail_fused() and self.ep is None and geom_ == 7 and row_range is None and P * M * c_esz(dt) < (1 << 32) - 64
+                      and not packed)
+        routed = o.route_top1(c["idx"], c["gmax"], c["gates"], seg_tokens, E, cap, self.bpr, want_perm=not packed, want_drops=want_drops)
+        c["loc"], c["counts"], c["perm"], c["tok2row"], c["l_aux"] = routed[:5]
+        if want_drops:
+            c["drop_begin"], c["dropped"] = routed[5], routed[6]
         # ---- expert chain (gathers its rows through perm; ragged groups = (segment, expert))
         rows = n_seg * E * cap
         ng = n_seg * E
@@ -608,7 +614,8 @@ class SwitchNeRF:
             # 64-row tail chain (which re-streams its 192 KiB of weights from L2 for every 64 rows) and its launch.
             c["row_of_tok"] = c["tok2row"]
             c["ray_feat"], c["c_ray"] = o.ray_feat_fwd(pe_dir, self.in_dir, self.p["emb"], image_indices.contiguous(), self.p["l2r.w"], self.p["l2.b"])
-            c["drop_begin"], c["dropped"] = o.route_dropped(c["idx"], c["loc"], c["counts"], seg_tokens, E, cap)
+            if "dropped" not in c:
+                c["drop_begin"], c["dropped"] = o.route_dropped(c["idx"], c["loc"], c["counts"], seg_tokens, E, cap)
             if "l2h_pad" not in self.wf:      # (SWN_FUSED_TAIL switched on after the compute copies were made)
                 self.wf["l2h_pad"] = o.pack_weights_padded(self.p["l2h.w"].unsqueeze(0), dt, True, 0, 256)
             c["y"] = _b("y", (P, M), dt) if sv else None

@@ -139,7 +139,23 @@ def gate_bwd(g, ln_w, ln_b, wg, gates, idx, d_gmax, stats, counts, laux_coef, se
 _route_ws = {}
 
 
-def route_top1(idx, gmax, gates, seg_tokens: int, n_experts: int, capacity: int, bpr: bool, want_perm=True):
+_route_sync = {}
+
+
+def route_sync(dev):
+    """The synchronisation words of the one-launch routing (swn_route_top1x): zero at creation, left zero by every launch; one per
+    (device, stream) - routings on one stream are ordered, routings that may overlap get their own.  Never freed (graphs)."""
+    k = (dev, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
+    t = _route_sync.get(k)
+    if t is None:
+        t = _route_sync[k] = torch.zeros(int(_lib.load().swn_route_sync_bytes()) // 4, dtype=torch.int32, device=dev)
+    return t
+
+
+def route_top1(idx, gmax, gates, seg_tokens: int, n_experts: int, capacity: int, bpr: bool, want_perm=True, want_drops=False, multi=False):
+    """Top-1 capacity assignment of every routing segment in ONE launch (swn_route_top1x) -> (loc, counts, perm, tok2row, l_aux)
+    [+ (drop_begin, dropped) with want_drops: the tokens no expert kept, swn_route_dropped's lists, from the same launch].
+    multi=True: the per-phase launches (swn_route_top1 + swn_route_dropped) - the twin the tests compare with."""
     P = idx.shape[0]
     n_seg = P // seg_tokens
     dev = idx.device
@@ -148,14 +164,25 @@ def route_top1(idx, gmax, gates, seg_tokens: int, n_experts: int, capacity: int,
     perm = torch.empty(n_seg, n_experts * capacity, dtype=torch.int32, device=dev) if want_perm else None
     tok2row = torch.empty(P, dtype=torch.int32, device=dev)
     l_aux = torch.empty(n_seg, dtype=torch.float32, device=dev) if gates is not None else None
+    drop_begin = torch.empty(n_seg * n_experts + 1, dtype=torch.int32, device=dev) if want_drops else None
+    dropped = torch.empty(P, dtype=torch.int32, device=dev) if want_drops else None
     nbytes = _lib.load().swn_route_workspace_bytes(P, n_seg, n_experts)
     key = (dev, nbytes)
     ws = _route_ws.get(key)
     if ws is None:      # one workspace per size, kept for good: a captured hipGraph may hold its address (coarse / fine passes alternate
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)      # two sizes; a size follows the batch shape: a handful per process)
         _route_ws[key] = ws
-    call("swn_route_top1", _p(idx), _p(gmax), _p(gates), P, int(seg_tokens), n_experts, int(capacity), int(bool(bpr)),
-         _p(loc), _p(counts), _p(perm), _p(tok2row), _p(l_aux), _p(ws), nbytes, _stream())
+    if multi:
+        call("swn_route_top1", _p(idx), _p(gmax), _p(gates), P, int(seg_tokens), n_experts, int(capacity), int(bool(bpr)),
+             _p(loc), _p(counts), _p(perm), _p(tok2row), _p(l_aux), _p(ws), nbytes, _stream())
+        if want_drops:
+            call("swn_route_dropped", _p(idx), _p(loc), _p(counts), P, int(seg_tokens), int(n_experts), int(capacity), _p(drop_begin),
+                 _p(dropped), _stream())
+    else:
+        call("swn_route_top1x", _p(idx), _p(gmax), _p(gates), P, int(seg_tokens), n_experts, int(capacity), int(bool(bpr)),
+             _p(loc), _p(counts), _p(perm), _p(tok2row), _p(l_aux), _p(drop_begin), _p(dropped), _p(route_sync(dev)), _p(ws), nbytes, _stream())
+    if want_drops:
+        return loc, counts, perm, tok2row, l_aux, drop_begin, dropped
     return loc, counts, perm, tok2row, l_aux
 
 

@@ -1265,13 +1265,44 @@ def test_chain_fused_tail(n_seg, seg_tokens, skew, S):
 def test_route_three_pass_variant_is_bit_exact_too():
     """SWN_ROUTE_3PASS=1 (three radix passes of 9 / 10 bits instead of four of 8: measured slower, kept selectable - profiles/
     r03_experiments.md section 7) passes the same bit-exact routing tests against the reference's goldens; the switch is read once
-    per process, hence the subprocess."""
+    per process, hence the subprocess (SWN_ROUTE_MULTI=1: the per-phase launches - the one-launch form always runs four 8-bit passes)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-q", "-x", "-k",
                         "test_route_golden or test_route_ragged"], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, SWN_ROUTE_3PASS="1"), cwd=root)
+                       env=dict(os.environ, SWN_ROUTE_3PASS="1", SWN_ROUTE_MULTI="1"), cwd=root)
     assert p.returncode == 0, p.stdout[-1500:]
     assert " passed" in p.stdout and "failed" not in p.stdout
+
+
+def test_route_one_launch_equals_the_per_phase_launches():
+    """swn_route_top1x (the whole routing in one launch: resident workgroups, grid barriers, the last tile of a segment scans) against
+    swn_route_top1 + swn_route_dropped (20 launches): every output bit-identical - loc, counts, perm (the -1 of the empty slots
+    included), tok2row, l_aux (same order of additions), drop_begin and the written part of the dropped list - on tie-heavy gates,
+    ragged last tiles, one / many segments, 1 .. 64 experts, with and without batch prioritisation, capacities below and above the
+    counts; 30 launches back to back on one set of synchronisation words (left at zero every time)."""
+    o = ops()
+    cases = [(2048, 2048, 8, 1.0, True, 0), (1000, 1000, 16, 1.0, True, 0), (16384, 16384, 8, 1.0, True, 3), (4 * 131072, 131072, 8, 1.0, True, 0),
+             (2 * 2000, 2000, 4, 1.0, False, 0), (512, 512, 8, 1.0, True, 1), (3 * 40, 40, 8, 1.0, True, 0), (5 * 24, 24, 4, 1.0, False, 0),
+             (2 * 70, 70, 8, 1.25, True, 0), (16 * 131072, 131072, 8, 1.0, True, 0), (6 * 5000, 5000, 64, 0.5, True, 4), (3 * 4100, 4100, 1, 1.0, True, 0),
+             (2 * 131072, 131072, 8, 1.25, True, 0), (8 * 33000, 33000, 2, 0.75, False, 0)]
+    for n, (P, seg, E, cf, bpr, qb) in enumerate(cases):
+        gates_np = synth.make_gates(300 + n, P, E, 2.0, quantize_bits=qb) if qb else synth.make_gates(300 + n, P, E, 2.0)
+        gates = torch.from_numpy(gates_np).to(dev())
+        idx = gates.argmax(1).int()
+        gmax = gates.gather(1, idx.long()[:, None])[:, 0].contiguous()
+        cap = O.capacity_of(seg, E, cf)
+        ref = o.route_top1(idx, gmax, gates, seg, E, cap, bpr, want_drops=True, multi=True)
+        nd = int(ref[5][-1].item())
+        for rep in range(30 if n in (3, 9) else 2):
+            one = o.route_top1(idx, gmax, gates, seg, E, cap, bpr, want_drops=True)
+            for name, a, b in zip(("loc", "counts", "perm", "tok2row", "l_aux", "drop_begin"), one[:6], ref[:6]):
+                assert torch.equal(a, b), (n, rep, name, int((a != b).sum().item()))
+            assert int(one[5][-1].item()) == nd and torch.equal(one[6][:nd], ref[6][:nd]), (n, rep, "dropped")
+        # the optional outputs left out
+        lean = o.route_top1(idx, gmax, None, seg, E, cap, bpr, want_perm=False)
+        assert torch.equal(lean[0], ref[0]) and torch.equal(lean[1], ref[1]) and lean[2] is None and torch.equal(lean[3], ref[3]) and lean[4] is None
+    for t in o._route_sync.values():
+        assert int(t.abs().sum().item()) == 0
