@@ -328,8 +328,8 @@ __global__ __launch_bounds__(256) void laux_final_kernel(const float* __restrict
 //     B   per pass q = 1 .. n_pass - 1:  histogram (+ scan by the last tile of the segment)   B   scatter   B
 //     F   per tile: loc / perm / tok2row and the list of dropped tokens from the sorted order; empty capacity slots of perm = -1 (no
 //         fill launch); l_aux per segment
-// 8 grid barriers with batch-prioritised routing (4 passes of 8 bits), 2 without.  A barrier is one agent-scope atomic add + a spin
-// on it by one lane per workgroup behind a release fence, an acquire fence in front of the next phase.  `sync`: int32 [SYNC_WORDS],
+// 8 grid barriers with batch-prioritised routing (4 passes of 8 bits), 2 without.  A barrier is a wait for the wave's own stores, one
+// agent-scope atomic add and a spin on it by one lane per workgroup; the data that crosses it is coherent by itself (ldc / stc below).  `sync`: int32 [SYNC_WORDS],
 // zero before the first launch, left zero by every launch (the last workgroup out resets it), one per stream that may run a routing
 // (ops.route_sync()).
 // =================================================================================================================================
@@ -343,10 +343,21 @@ struct RouteOne {
   uint32_t* k0; uint32_t* k1; int32_t* v0; int32_t* v1; int32_t* hist; int32_t* ehist; float* partial; int32_t* sync;
 };
 
+// Everything one workgroup writes for another to read in a later phase (keys / values, histograms, counts, l_aux partial sums) moves
+// through RELAXED AGENT-SCOPE ATOMIC loads and stores (`sc1`: written through to, and read from, the memory side - the eight XCDs' L2s
+// are not coherent with each other for plain accesses inside a kernel).  A first version used plain accesses and agent-scope release /
+// acquire fences at the barriers: every fence wrote back / invalidated a whole L2 (buffer_wbl2 / buffer_inv sc1, four waves of 512
+// workgroups at each of 8 barriers) - 246 us per call at 1024 rays and 1.2 ms at full size against 0.13 / 0.27 ms of the 20 launches
+// (profiles/r05_experiments.md 3).  With the data itself coherent a barrier is a wait for the wave's own stores, one atomic add and a spin.
+__device__ __forceinline__ uint32_t ldc(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int32_t ldc(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ldc(const float* p) { return __uint_as_float(__hip_atomic_load((const uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ void stc(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stc(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stc(float* p, float v) { __hip_atomic_store((uint32_t*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ void route_grid_barrier(int32_t* ctr, int& epoch) {
-  // (the form of the device library's grid sync: EVERY wave releases at agent scope - its stores are out of this XCD's L2 - before the
-  //  workgroup barrier, one lane signals and spins, every wave acquires behind the second workgroup barrier)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have reached the memory side
   __syncthreads();
   if (threadIdx.x == 0) {
     ++epoch;
@@ -355,7 +366,6 @@ __device__ __forceinline__ void route_grid_barrier(int32_t* ctr, int& epoch) {
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 // the exclusive scan of one segment's tile histograms in (digit, tile) order: route_scan_kernel's body for 256 bins on 256 threads
@@ -368,11 +378,11 @@ __device__ __forceinline__ void route_scan_seg(int32_t* __restrict__ hist, int s
   int32_t c[NB > 0 ? NB : 1];
   if constexpr (NB > 0) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) c[b] = b < nblk ? row[(long)b * BINS] : 0;
+    for (int b = 0; b < NB; ++b) c[b] = b < nblk ? ldc(row + (long)b * BINS) : 0;
 #pragma unroll
     for (int b = 0; b < NB; ++b) s += c[b];
   } else {
-    for (int b = 0; b < nblk; ++b) s += row[(long)b * BINS];
+    for (int b = 0; b < nblk; ++b) s += ldc(row + (long)b * BINS);
   }
   int32_t v = s;
 #pragma unroll
@@ -388,13 +398,13 @@ __device__ __forceinline__ void route_scan_seg(int32_t* __restrict__ hist, int s
   if constexpr (NB > 0) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      if (b < nblk) row[(long)b * BINS] = run;
+      if (b < nblk) stc(row + (long)b * BINS, run);
       run += c[b];
     }
   } else {
     for (int b = 0; b < nblk; ++b) {
-      const int32_t cc = row[(long)b * BINS];
-      row[(long)b * BINS] = run;
+      const int32_t cc = ldc(row + (long)b * BINS);
+      stc(row + (long)b * BINS, run);
       run += cc;
     }
   }
@@ -419,7 +429,7 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
 
   // the last tile of (pass, segment) to finish: adds up the counts (pass 0) and scans the segment's histogram
   auto tile_done = [&](int pass, int seg) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
       const int old = __hip_atomic_fetch_add(arrive + pass * n_seg + seg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -427,11 +437,10 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
     }
     __syncthreads();
     if (!flag) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (pass == 0 && tid < E) {
       int32_t c = 0;
-      for (int b = 0; b < nblk; ++b) c += a.ehist[((long)seg * nblk + b) * E + tid];
-      a.counts[seg * E + tid] = c;
+      for (int b = 0; b < nblk; ++b) c += ldc(a.ehist + ((long)seg * nblk + b) * E + tid);
+      stc(a.counts + seg * E + tid, c);
     }
     if (nblk <= 16) route_scan_seg<16>(a.hist, seg, nblk, rowsum);
     else if (nblk <= 64) route_scan_seg<64>(a.hist, seg, nblk, rowsum);
@@ -458,8 +467,8 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
           inv = b < 0 ? 0u : (b > 0x03FFFFFF ? 0x03FFFFFFu : (uint32_t)b);
         }
         key = ((uint32_t)e << 26) | inv;
-        a.k0[i] = key;
-        a.v0[i] = p;
+        stc(a.k0 + i, key);
+        stc(a.v0 + i, p);
         atomicAdd(&h[(key >> a.shift0) & (BINS - 1)], 1);
       }
       for (int q = 0; q < E; ++q) {                    // one ballot per expert, one LDS add per wave and expert
@@ -468,8 +477,8 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
       }
     }
     __syncthreads();
-    for (int d = tid; d < BINS; d += 256) a.hist[((long)seg * nblk + blk) * BINS + d] = h[d];
-    if (tid < E) a.ehist[((long)seg * nblk + blk) * E + tid] = eh[tid];
+    for (int d = tid; d < BINS; d += 256) stc(a.hist + ((long)seg * nblk + blk) * BINS + d, h[d]);
+    if (tid < E) stc(a.ehist + ((long)seg * nblk + blk) * E + tid, eh[tid]);
     if (a.gates && a.l_aux) {                          // laux_partial_kernel's body (same tile, same order of additions)
       const float* gp = a.gates + sbase * E;
       const int e = tid % E, t0 = tid / E, tstep = 256 / E;
@@ -489,7 +498,7 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
       if (tid < E) {
         float acc = 0.f;
         for (int q = tid; q < 256; q += E) acc += red[q];
-        a.partial[((long)seg * nblk + blk) * E + tid] = acc;
+        stc(a.partial + ((long)seg * nblk + blk) * E + tid, acc);
       }
     }
     tile_done(0, seg);
@@ -511,10 +520,10 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
         const uint32_t* k = ki + (long)seg * seg_tokens;
         for (int j = 0; j < KPB / 256; ++j) {
           const int p = blk * KPB + j * 256 + tid;
-          if (p < seg_tokens) atomicAdd(&h[(k[p] >> shift) & (BINS - 1)], 1);
+          if (p < seg_tokens) atomicAdd(&h[(ldc(k + p) >> shift) & (BINS - 1)], 1);
         }
         __syncthreads();
-        for (int d = tid; d < BINS; d += 256) a.hist[((long)seg * nblk + blk) * BINS + d] = h[d];
+        for (int d = tid; d < BINS; d += 256) stc(a.hist + ((long)seg * nblk + blk) * BINS + d, h[d]);
         tile_done(pass, seg);
       }
       route_grid_barrier(bar, epoch);
@@ -530,13 +539,13 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
       for (int r = 0; r < KPB / 4 / 64; ++r) {
         const int p = p0 + r * 64 + lane;
         const bool valid = p < seg_tokens;
-        const int d = valid ? (int)((ki[sbase + p] >> shift) & (BINS - 1)) : 0;
+        const int d = valid ? (int)((ldc(ki + sbase + p) >> shift) & (BINS - 1)) : 0;
         const unsigned long long m = match_digit<BITS>(d, valid);
         if (valid && lane == __ffsll((long long)m) - 1) wh[w][d] += __popcll(m);
       }
       __syncthreads();
       for (int d = tid; d < BINS; d += 256) {
-        int32_t base = a.hist[((long)seg * nblk + blk) * BINS + d];
+        int32_t base = ldc(a.hist + ((long)seg * nblk + blk) * BINS + d);
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) {
           const int32_t c = wh[ww][d];
@@ -550,14 +559,14 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
         const bool valid = p < seg_tokens;
         uint32_t key = 0;
         int32_t val = 0;
-        if (valid) { key = ki[sbase + p]; val = vi[sbase + p]; }
+        if (valid) { key = ldc(ki + sbase + p); val = ldc(vi + sbase + p); }
         const int d = (int)((key >> shift) & (BINS - 1));
         const unsigned long long m = match_digit<BITS>(d, valid);
         if (valid) {
           const int rank = __popcll(m & ((1ull << lane) - 1ull));
           const int32_t pos = wh[w][d] + rank;
-          ko[sbase + pos] = key;
-          vo[sbase + pos] = val;
+          stc(ko + sbase + pos, key);
+          stc(vo + sbase + pos, val);
         }
         __builtin_amdgcn_wave_barrier();
         if (valid && lane == __ffsll((long long)m) - 1) wh[w][d] += __popcll(m);
@@ -579,7 +588,7 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
     int run = 0;
     for (int q = 0; q < per; ++q) {
       const int g = g0 + q;
-      if (g < n_groups) run += max(a.counts[g] - cap, 0);
+      if (g < n_groups) run += max(ldc(a.counts + g) - cap, 0);
     }
     __syncthreads();
     part[tid] = run;
@@ -590,7 +599,7 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
       const int g = g0 + q;
       if (g < n_groups) {
         dbeg[g] = base;
-        base += max(a.counts[g] - cap, 0);
+        base += max(ldc(a.counts + g) - cap, 0);
       }
     }
     if (tid == 255) dbeg[n_groups] = base;
@@ -604,15 +613,15 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
     __syncthreads();
     if (tid == 0) {
       int s_ = 0;
-      for (int q = 0; q < E; ++q) { gstart[q] = s_; s_ += a.counts[seg * E + q]; }
+      for (int q = 0; q < E; ++q) { gstart[q] = s_; s_ += ldc(a.counts + seg * E + q); }
     }
     __syncthreads();
     for (int j = 0; j < KPB / 256; ++j) {
       const int pos = blk * KPB + j * 256 + tid;
       if (pos >= seg_tokens) continue;
-      const int e = (int)(ki[sbase + pos] >> 26);
+      const int e = (int)(ldc(ki + sbase + pos) >> 26);
       const int l = pos - gstart[e];
-      const long tok = sbase + vi[sbase + pos];
+      const long tok = sbase + ldc(vi + sbase + pos);
       a.loc[tok] = l;
       const long row = ((long)seg * E + e) * cap + l;
       if (l < cap) {
@@ -629,21 +638,21 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
     for (long r = (long)blockIdx.x * 256 + tid; r < rows; r += (long)gridDim.x * 256) {
       const int g = (int)(r / cap);
       const int l = (int)(r - (long)g * cap);
-      if (l >= a.counts[g]) a.perm[r] = -1;
+      if (l >= ldc(a.counts + g)) a.perm[r] = -1;
     }
   }
   if (a.gates && a.l_aux) {      // laux_final_kernel's body, one workgroup per segment
     for (int seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
       const int e = tid % E, sub = tid / E, nsub = 256 / E;
       float me = 0.f;
-      for (int b = sub; b < nblk; b += nsub) me += a.partial[((long)seg * nblk + b) * E + e];
+      for (int b = sub; b < nblk; b += nsub) me += ldc(a.partial + ((long)seg * nblk + b) * E + e);
       __syncthreads();
       red[tid] = me;
       __syncthreads();
       if (tid < E) {
         float acc = 0.f;
         for (int q = 0; q < nsub; ++q) acc += red[q * E + tid];
-        red[tid] = acc * (float)a.counts[seg * E + tid];
+        red[tid] = acc * (float)ldc(a.counts + seg * E + tid);
       }
       __syncthreads();
       if (tid == 0) {
