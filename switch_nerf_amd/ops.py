@@ -152,10 +152,18 @@ def route_sync(dev):
     return t
 
 
-def route_top1(idx, gmax, gates, seg_tokens: int, n_experts: int, capacity: int, bpr: bool, want_perm=True, want_drops=False, multi=False):
-    """Top-1 capacity assignment of every routing segment in ONE launch (swn_route_top1x) -> (loc, counts, perm, tok2row, l_aux)
-    [+ (drop_begin, dropped) with want_drops: the tokens no expert kept, swn_route_dropped's lists, from the same launch].
-    multi=True: the per-phase launches (swn_route_top1 + swn_route_dropped) - the twin the tests compare with."""
+_ROUTE_ONE = os.environ.get("SWN_ROUTE_ONE", "0") == "1"
+
+
+def route_top1(idx, gmax, gates, seg_tokens: int, n_experts: int, capacity: int, bpr: bool, want_perm=True, want_drops=False, multi=False,
+               one=None):
+    """Top-1 capacity assignment of every routing segment (swn_route_top1x) -> (loc, counts, perm, tok2row, l_aux)
+    [+ (drop_begin, dropped) with want_drops: the tokens no expert kept, swn_route_dropped's lists].
+    one: True = the whole routing in ONE launch (route_one_kernel: resident workgroups + grid barriers; built and bit-identical, but
+    SLOWER than the per-phase launches on this part - the data that crosses a barrier has to go through the memory side, the eight
+    XCDs' L2s are not coherent with each other: profiles/r05_experiments.md 3); None = the SWN_ROUTE_ONE environment switch (default
+    off: swn_route_top1x without its synchronisation words runs the per-phase launches).  multi=True: the round 1-4 entry points
+    (swn_route_top1 + swn_route_dropped) - the twin the tests compare with."""
     P = idx.shape[0]
     n_seg = P // seg_tokens
     dev = idx.device
@@ -180,7 +188,8 @@ def route_top1(idx, gmax, gates, seg_tokens: int, n_experts: int, capacity: int,
                  _p(dropped), _stream())
     else:
         call("swn_route_top1x", _p(idx), _p(gmax), _p(gates), P, int(seg_tokens), n_experts, int(capacity), int(bool(bpr)),
-             _p(loc), _p(counts), _p(perm), _p(tok2row), _p(l_aux), _p(drop_begin), _p(dropped), _p(route_sync(dev)), _p(ws), nbytes, _stream())
+             _p(loc), _p(counts), _p(perm), _p(tok2row), _p(l_aux), _p(drop_begin), _p(dropped),
+             _p(route_sync(dev)) if (one if one is not None else _ROUTE_ONE) else None, _p(ws), nbytes, _stream())
     if want_drops:
         return loc, counts, perm, tok2row, l_aux, drop_begin, dropped
     return loc, counts, perm, tok2row, l_aux

@@ -1278,7 +1278,8 @@ def test_route_three_pass_variant_is_bit_exact_too():
 
 
 def test_route_one_launch_equals_the_per_phase_launches():
-    """swn_route_top1x (the whole routing in one launch: resident workgroups, grid barriers, the last tile of a segment scans) against
+    """swn_route_top1x with its synchronisation words (the whole routing in one launch: resident workgroups, grid barriers, the last tile
+    of a segment scans - built, bit-identical and slower than the launches it replaces: opt-in, profiles/r05_experiments.md 3) against
     swn_route_top1 + swn_route_dropped (20 launches): every output bit-identical - loc, counts, perm (the -1 of the empty slots
     included), tok2row, l_aux (same order of additions), drop_begin and the written part of the dropped list - on tie-heavy gates,
     ragged last tiles, one / many segments, 1 .. 64 experts, with and without batch prioritisation, capacities below and above the
@@ -1297,12 +1298,12 @@ def test_route_one_launch_equals_the_per_phase_launches():
         ref = o.route_top1(idx, gmax, gates, seg, E, cap, bpr, want_drops=True, multi=True)
         nd = int(ref[5][-1].item())
         for rep in range(30 if n in (3, 9) else 2):
-            one = o.route_top1(idx, gmax, gates, seg, E, cap, bpr, want_drops=True)
+            one = o.route_top1(idx, gmax, gates, seg, E, cap, bpr, want_drops=True, one=True)
             for name, a, b in zip(("loc", "counts", "perm", "tok2row", "l_aux", "drop_begin"), one[:6], ref[:6]):
                 assert torch.equal(a, b), (n, rep, name, int((a != b).sum().item()))
             assert int(one[5][-1].item()) == nd and torch.equal(one[6][:nd], ref[6][:nd]), (n, rep, "dropped")
         # the optional outputs left out
-        lean = o.route_top1(idx, gmax, None, seg, E, cap, bpr, want_perm=False)
+        lean = o.route_top1(idx, gmax, None, seg, E, cap, bpr, want_perm=False, one=True)
         assert torch.equal(lean[0], ref[0]) and torch.equal(lean[1], ref[1]) and lean[2] is None and torch.equal(lean[3], ref[3]) and lean[4] is None
     for t in o._route_sync.values():
         assert int(t.abs().sum().item()) == 0
