@@ -107,9 +107,9 @@ __global__ __launch_bounds__(256) void hash_encode_bwd_kernel(const float* __res
                                                               int n_rays, int S, HashLevels h, const T* __restrict__ d_out,
                                                               int d_stride, float* __restrict__ d_table, long xcd_stride, int level_major) {
 #pragma clang fp contract(off)
-  // level_major: blockIdx.y = the level this workgroup adds (grid = point blocks x levels, the levels dispatched one after the other):
-  // the workgroups in flight at any moment work on ONE level's 4 MiB slice of the gradient table (2^19 entries) - it stays in the
-  // XCD's L2 - instead of all 16 levels' 64 MiB per point block (every atomic a miss that goes to the memory side)
+  // level_major (experiment): blockIdx.y = the level this workgroup adds (grid = point blocks x levels, the levels dispatched one after
+  // the other): the workgroups in flight at any moment work on ONE level's 4 MiB slice of the gradient table instead of all 16 levels'
+  // 64 MiB - no faster (15.9 against 15.0 ms per 2M points): the atomics are not bound by where their lines live
   // xcd_stride != 0: d_table is one PRIVATE copy of the gradient table per XCD (copy x at d_table + x * xcd_stride, x = the XCC_ID the
   // workgroup runs on): every atomic of the launch meets its partners in ONE L2 (hash_reduce_kernel adds the copies afterwards)
   if (xcd_stride) {
@@ -242,9 +242,10 @@ extern "C" int swn_hash_encode_bwd_xcd(const float* rays, const float* z, int n_
   const long table_elems = (long)h.n_levels * h.level_stride;
   float* target = xcd_tables ? xcd_tables : d_table;
   const long xs = xcd_tables ? table_elems : 0;
-  // SWN_HASH_POINT_MAJOR=1: one workgroup per point block walks all levels (rounds 1-4; experiments)
-  static const bool point_major = getenv("SWN_HASH_POINT_MAJOR") != nullptr;
-  const int lm = point_major ? 0 : 1;
+  // SWN_HASH_LEVEL_MAJOR=1 (experiment, NOT the default - measured 2 % slower: profiles/r05_experiments.md 4): grid = point blocks x
+  // levels; default: one workgroup per point block walks all levels
+  static const bool level_major = getenv("SWN_HASH_LEVEL_MAJOR") != nullptr;
+  const int lm = level_major ? 1 : 0;
   const dim3 grid(cdiv(P, 256), lm ? h.n_levels : 1);
   if (dtype == SWN_HALF)
     hipLaunchKernelGGL((hash_encode_bwd_kernel<bf16_t>), grid, dim3(256), 0, as_stream(stream), rays, z, n_rays,
