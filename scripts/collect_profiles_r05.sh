@@ -1,0 +1,44 @@
+#!/bin/bash
+# Round 5: the round's rocprofv3 evidence on a GPU box -> gpurun_out/r05/ (summaries only; raw databases are deleted), every table from
+# ONE build (bench.py stamps config.csrc_sha256; scripts/make_traffic.py ties profiles/traffic.json to it).
+#   bash scripts/collect_profiles_r05.sh
+set -x
+R=r05
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/$R; mkdir -p $O
+B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-balanced --graph off --no-events"
+# (a) per-kernel time of the step, eager launches, without the side-stream overlap (kernel durations undisturbed by concurrent kernels)
+SWN_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d gpurun_out/p_step2 -o step -- $B > $O/p_step_noov.log 2>&1
+python scripts/prof_summary.py $(find gpurun_out/p_step2 -name "*.db" | head -1) 45 > $O/${R}_kernel_stats_step_no_overlap.md
+tail -1 $O/p_step_noov.log | grep '^{' >> $O/${R}_kernel_stats_step_no_overlap.md
+rm -rf gpurun_out/p_step2
+# (b) HBM traffic of the TIMED workload (the router's own routing): two counter-only passes, each followed by its bench line
+P="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-balanced --no-events --graph off"
+for c in FETCH_SIZE WRITE_SIZE; do
+  SWN_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/p_$c -- $P > $O/p_$c.log 2>&1
+  python scripts/pmc_summary.py gpurun_out/p_$c > $O/${R}_pmc_$c.txt
+  tail -1 $O/p_$c.log | grep '^{' >> $O/${R}_pmc_$c.txt
+  rm -rf gpurun_out/p_$c
+done
+mkdir -p profiles; cp $O/${R}_pmc_FETCH_SIZE.txt $O/${R}_pmc_WRITE_SIZE.txt profiles/
+python scripts/make_traffic.py $R > $O/make_traffic.log 2>&1; cp profiles/traffic.json $O/traffic.json
+# (c) SQ counters of the expert kernels (one pass, 8 SQ slots) and of the save-free expert chain (inference forward)
+SWN_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/p_sq -- $P > $O/p_sq.log 2>&1
+python scripts/pmc_summary.py gpurun_out/p_sq chainq > $O/${R}_pmc_sq_experts.txt
+python scripts/pmc_summary.py gpurun_out/p_sq wgrad_stream >> $O/${R}_pmc_sq_experts.txt
+rm -rf gpurun_out/p_sq
+# (c2) L2 -> L1 requests of the chains (the weight stream through the CU's vector memory path)
+SWN_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/p_l2 -- $P > $O/p_l2.log 2>&1
+python scripts/pmc_summary.py gpurun_out/p_l2 chain > $O/${R}_pmc_l2_chains.txt
+rm -rf gpurun_out/p_l2
+# (c3) kernel table of the 1024-rays-per-GPU share (8-GPU strong scaling)
+SWN_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d gpurun_out/p_1024 -o step -- python bench.py --rays 1024 --steps 30 --warmup 5 --no-cpu-baseline --no-balanced --graph off --no-events > $O/p_1024.log 2>&1
+python scripts/prof_summary.py $(find gpurun_out/p_1024 -name "*.db" | head -1) 45 > $O/${R}_kernel_stats_1024rays.md
+rm -rf gpurun_out/p_1024
+# (d) the bench lines (traffic.json of THIS build is in place: roofline.traffic is reported)
+python bench.py > $O/${R}_bench_default.json 2> $O/${R}_bench_default.err
+python bench.py --steps 20 --warmup 5 > $O/${R}_bench_20_5.json 2>/dev/null
+python bench.py --rays 1024 --steps 100 --warmup 20 --no-cpu-baseline --no-balanced --graph on > $O/${R}_bench_1024rays_graph.json 2>/dev/null
+python bench.py --rays 1024 --steps 100 --warmup 20 --no-cpu-baseline --no-balanced --graph off --no-events > $O/${R}_bench_1024rays_eager.json 2>/dev/null
+python bench.py --eval --steps 50 --warmup 10 --no-cpu-baseline > $O/${R}_bench_eval_graph.json 2>/dev/null
+ls -la $O | head -60
