@@ -10,14 +10,17 @@ B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-balanced --graph
 # (a) per-kernel time of the step, eager launches, without the side-stream overlap (kernel durations undisturbed by concurrent kernels)
 SWN_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d gpurun_out/p_step2 -o step -- $B > $O/p_step_noov.log 2>&1
 python scripts/prof_summary.py $(find gpurun_out/p_step2 -name "*.db" | head -1) 45 > $O/${R}_kernel_stats_step_no_overlap.md
-tail -1 $O/p_step_noov.log | grep '^{' >> $O/${R}_kernel_stats_step_no_overlap.md
+grep '^{' $O/p_step_noov.log | tail -1 >> $O/${R}_kernel_stats_step_no_overlap.md
 rm -rf gpurun_out/p_step2
 # (b) HBM traffic of the TIMED workload (the router's own routing): two counter-only passes, each followed by its bench line
+# ONE step per pass (no warm-up): every dispatch of a kernel in the pass has the same kept rows - the router's kept fraction moves from
+# step to step (0.52 at the first step, ~0.8 after twenty), and the table stores bytes per launch AT the pass's kept rows
+P1="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-balanced --no-events --graph off"
 P="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-balanced --no-events --graph off"
 for c in FETCH_SIZE WRITE_SIZE; do
-  SWN_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/p_$c -- $P > $O/p_$c.log 2>&1
+  SWN_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/p_$c -- $P1 > $O/p_$c.log 2>&1
   python scripts/pmc_summary.py gpurun_out/p_$c > $O/${R}_pmc_$c.txt
-  tail -1 $O/p_$c.log | grep '^{' >> $O/${R}_pmc_$c.txt
+  grep '^{' $O/p_$c.log | tail -1 >> $O/${R}_pmc_$c.txt
   rm -rf gpurun_out/p_$c
 done
 mkdir -p profiles; cp $O/${R}_pmc_FETCH_SIZE.txt $O/${R}_pmc_WRITE_SIZE.txt profiles/
