@@ -527,6 +527,19 @@ class SwitchNeRF:
             cap = seg_tokens
         c = dict(N=N, S=S, P=P, n_seg=n_seg, cap=cap, seg_tokens=seg_tokens, tag=tag, image_indices=image_indices)
         c["pe"], c["pe_dir"] = pe, pe_dir
+        # the per-ray half of layer "2" (gather + a 75 x 128 GEMM per ray: one small launch) only needs the direction encoding: on the side
+        # stream it runs under the front chain / the router instead of between the routing and the expert launch
+        ray_feat_ev = None
+        if (self.overlap and self.side is not None and not self.profile and self.ep is None and row_range is None and self._tail_fused()
+                and "l2r.w" in self.p):
+            ev0 = torch.cuda.Event()
+            ev0.record()
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev0)
+                c["ray_feat"], c["c_ray"] = ops.ray_feat_fwd(pe_dir, self.in_dir, self.p["emb"], image_indices.contiguous(), self.p["l2r.w"],
+                                                             self.p["l2.b"])
+                ray_feat_ev = torch.cuda.Event()
+                ray_feat_ev.record()
         _b = lambda name, shape, dtype: self._buf(tag + ":" + name, shape, dtype)
         # ---- front chain: PE -> xyz -> gate MLP
         c["h0"] = _b("h0", (P, M), dt)
@@ -613,7 +626,10 @@ class SwitchNeRF:
             # kept enter at layer "1" as zero rows (swn_route_dropped).  Replaces: the expert output's round trip through memory, the
             # 64-row tail chain (which re-streams its 192 KiB of weights from L2 for every 64 rows) and its launch.
             c["row_of_tok"] = c["tok2row"]
-            c["ray_feat"], c["c_ray"] = o.ray_feat_fwd(pe_dir, self.in_dir, self.p["emb"], image_indices.contiguous(), self.p["l2r.w"], self.p["l2.b"])
+            if ray_feat_ev is not None:
+                torch.cuda.current_stream().wait_event(ray_feat_ev)
+            else:
+                c["ray_feat"], c["c_ray"] = o.ray_feat_fwd(pe_dir, self.in_dir, self.p["emb"], image_indices.contiguous(), self.p["l2r.w"], self.p["l2.b"])
             if "dropped" not in c:
                 c["drop_begin"], c["dropped"] = o.route_dropped(c["idx"], c["loc"], c["counts"], seg_tokens, E, cap)
             if "l2h_pad" not in self.wf:      # (SWN_FUSED_TAIL switched on after the compute copies were made)
@@ -714,7 +730,10 @@ class SwitchNeRF:
             c["ep_x"] = xr
         # ---- per-ray part of layer "2": [PE(dir), appearance embedding] @ W2r + b2   (N_rays x 75, host-side torch)
         # (one launch: swn_ray_feat_fwd - was cat / embedding lookup / addmm in torch)
-        c["ray_feat"], c["c_ray"] = o.ray_feat_fwd(pe_dir, self.in_dir, self.p["emb"], image_indices.contiguous(), self.p["l2r.w"], self.p["l2.b"])
+        if ray_feat_ev is not None:        # (issued on the side stream above; this branch: the fused tail was not taken after all)
+            torch.cuda.current_stream().wait_event(ray_feat_ev)
+        else:
+            c["ray_feat"], c["c_ray"] = o.ray_feat_fwd(pe_dir, self.in_dir, self.p["emb"], image_indices.contiguous(), self.p["l2r.w"], self.p["l2.b"])
         # ---- tail chain.  Its input load IS the combine: rows gathered from the expert output through tok2row, scaled by
         # the gate value, ReLU'd (dropped tokens -> zero rows) and saved as y;  then layer "1" -> layer "2" (+ per-ray bias)
         # The sigma / colour heads run inside that launch (swn.h: heads_raw): sigma from the staged y tile, colour from the h2 tile.  A
@@ -794,13 +813,29 @@ class SwitchNeRF:
         else:
             dh2, dsig, dc_ray = o.heads_bwd(y_heads, c["h2"], self.p["color.w"], c["raw"], d_raw, g["sigma.w"], g["sigma.b"], g["color.w"],
                                             g["color.b"], rows_per_group=S)
-        if dc_ray.shape[1] in (64, 128, 256) and c["ray_feat"].shape[1] <= 256:      # split over the rays + ordered reduce (one launch)
-            o.ray_feat_wgrad(c["ray_feat"], dc_ray, g["l2r.w"], g["l2.b"])
+        def ray_level():
+            if dc_ray.shape[1] in (64, 128, 256) and c["ray_feat"].shape[1] <= 256:      # split over the rays + ordered reduce (one launch)
+                o.ray_feat_wgrad(c["ray_feat"], dc_ray, g["l2r.w"], g["l2.b"])
+            else:
+                g["l2r.w"].addmm_(c["ray_feat"].t(), dc_ray)
+                g["l2.b"].add_(dc_ray.sum(0))
+            d_feat_emb = dc_ray @ self.p["l2r.w"][self.in_dir:].t()
+            o.emb_grad(d_feat_emb, c["image_indices"].contiguous(), g["emb"])        # (rays added in order: torch's index_add_ uses atomics)
+        # The per-ray work (layer "2"'s ray half and the appearance embedding: three small launches + a reduce, ~0.1 ms in which 10-30
+        # workgroups hold the chip) goes to the SIDE stream: it only needs dc_ray and writes gradient slices nobody else touches, so it
+        # runs under the expert backward launch that follows (whose resident workgroups pick the few late CUs up through the tile queue);
+        # joined with the expert weight gradients (same stream) or at the end of this half.  SWN_NO_OVERLAP=1: on the launch stream.
+        side_small = None
+        if self.overlap and self.side is not None and not self.profile and not c.get("ragged") and self.ep is None:
+            ready_small = torch.cuda.Event()
+            ready_small.record()
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ready_small)
+                ray_level()
+                side_small = torch.cuda.Event()
+                side_small.record()
         else:
-            g["l2r.w"].addmm_(c["ray_feat"].t(), dc_ray)
-            g["l2.b"].add_(dc_ray.sum(0))
-        d_feat_emb = dc_ray @ self.p["l2r.w"][self.in_dir:].t()
-        o.emb_grad(d_feat_emb, c["image_indices"].contiguous(), g["emb"])        # (rays added in order: torch's index_add_ uses atomics)
+            ray_level()
         # tail backward chain: dh2 -> dh1 -> dy
         # ... with the combine backward (the sigma head's rank-1 term, the ReLU mask of y, the gate gradient, the gate scaling) applied
         # in the write-out of the last layer: dy itself never reaches memory
@@ -937,8 +972,10 @@ class SwitchNeRF:
                 expert_wgrads()
             if self.profile and "_relaunch" in c:
                 c["_relaunch"]["expert_wgrad"] = expert_wgrads        # (accumulates into the gradient buffer again: timing only)
+        if side_small is not None and side_done is None:      # (no expert weight gradients behind it on the side stream: join here)
+            torch.cuda.current_stream().wait_event(side_small)
         return dict(c=c, d_laux=d_laux, dgmax=dgmax, dx=dx, dout=dout, returns=returns if ep is not None else None, tail_jobs=tail_jobs,
-                    nsp=nsp, side_done=side_done)
+                    nsp=nsp, side_done=side_done, keep=(dc_ray, dh2, dsig))      # (keep: tensors the side stream reads stay allocated to the join)
 
     def backward_net_b(self, st):
         """Second half of backward_net: router backward, front backward chain, dense weight gradients (+ the hash table's)."""
