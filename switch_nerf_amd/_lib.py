@@ -74,7 +74,7 @@ SIGNATURES = {
     "swn_gate_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
     "swn_gate_bwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp],
     "swn_route_top1": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp],
-    "swn_route_top1x": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp],
+    "swn_route_top1x": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, sz, vp],
     "swn_dispatch_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "swn_dispatch_bwd_data": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "swn_dispatch_bwd_gate": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],

@@ -105,11 +105,8 @@ __device__ __forceinline__ float run_inclusive_scan(float v, int lane, int start
 template <typename T>
 __global__ __launch_bounds__(256) void hash_encode_bwd_kernel(const float* __restrict__ rays, const float* __restrict__ z,
                                                               int n_rays, int S, HashLevels h, const T* __restrict__ d_out,
-                                                              int d_stride, float* __restrict__ d_table, long xcd_stride, int level_major) {
+                                                              int d_stride, float* __restrict__ d_table, long xcd_stride) {
 #pragma clang fp contract(off)
-  // level_major (experiment): blockIdx.y = the level this workgroup adds (grid = point blocks x levels, the levels dispatched one after
-  // the other): the workgroups in flight at any moment work on ONE level's 4 MiB slice of the gradient table instead of all 16 levels'
-  // 64 MiB - no faster (15.9 against 15.0 ms per 2M points): the atomics are not bound by where their lines live
   // xcd_stride != 0: d_table is one PRIVATE copy of the gradient table per XCD (copy x at d_table + x * xcd_stride, x = the XCC_ID the
   // workgroup runs on): every atomic of the launch meets its partners in ONE L2 (hash_reduce_kernel adds the copies afterwards)
   if (xcd_stride) {
@@ -125,8 +122,7 @@ __global__ __launch_bounds__(256) void hash_encode_bwd_kernel(const float* __res
   float x[3];
   point_of(rays, z, p, S, h, x);
   const T* dr = d_out + p * d_stride;
-  const int l_begin = level_major ? (int)blockIdx.y : 0, l_end = level_major ? (int)blockIdx.y + 1 : h.n_levels;
-  for (int l = l_begin; l < l_end; ++l) {
+  for (int l = 0; l < h.n_levels; ++l) {
     const float g0 = live ? ElemIO<T>::ld(dr + 2 * l) : 0.f, g1 = live ? ElemIO<T>::ld(dr + 2 * l + 1) : 0.f;
     uint32_t c0[3];
     float w[3];
@@ -242,17 +238,14 @@ extern "C" int swn_hash_encode_bwd_xcd(const float* rays, const float* z, int n_
   const long table_elems = (long)h.n_levels * h.level_stride;
   float* target = xcd_tables ? xcd_tables : d_table;
   const long xs = xcd_tables ? table_elems : 0;
-  // SWN_HASH_LEVEL_MAJOR=1 (experiment, NOT the default - measured 2 % slower: profiles/r05_experiments.md 4): grid = point blocks x
-  // levels; default: one workgroup per point block walks all levels
-  static const bool level_major = getenv("SWN_HASH_LEVEL_MAJOR") != nullptr;
-  const int lm = level_major ? 1 : 0;
-  const dim3 grid(cdiv(P, 256), lm ? h.n_levels : 1);
+  // (one workgroup per point block walks all levels; the level as the slow grid dimension - one 4 MiB table slice in flight - was
+  //  measured 2 % slower, profiles/r05_experiments.md 4: the atomics are not bound by where their lines live)
   if (dtype == SWN_HALF)
-    hipLaunchKernelGGL((hash_encode_bwd_kernel<bf16_t>), grid, dim3(256), 0, as_stream(stream), rays, z, n_rays,
-                       n_samples, h, (const bf16_t*)d_out, d_stride, target, xs, lm);
+    hipLaunchKernelGGL((hash_encode_bwd_kernel<bf16_t>), dim3(cdiv(P, 256)), dim3(256), 0, as_stream(stream), rays, z, n_rays,
+                       n_samples, h, (const bf16_t*)d_out, d_stride, target, xs);
   else
-    hipLaunchKernelGGL((hash_encode_bwd_kernel<float>), grid, dim3(256), 0, as_stream(stream), rays, z, n_rays,
-                       n_samples, h, (const float*)d_out, d_stride, target, xs, lm);
+    hipLaunchKernelGGL((hash_encode_bwd_kernel<float>), dim3(cdiv(P, 256)), dim3(256), 0, as_stream(stream), rays, z, n_rays,
+                       n_samples, h, (const float*)d_out, d_stride, target, xs);
   if (xcd_tables)
     hipLaunchKernelGGL(hash_reduce_kernel, dim3(cdiv(table_elems / 4, 256)), dim3(256), 0, as_stream(stream), xcd_tables, table_elems, 8,
                        table_elems, d_table);

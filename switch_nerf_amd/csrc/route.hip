@@ -341,6 +341,8 @@ struct RouteOne {
   int n_tokens, seg_tokens, E, capacity, bpr, n_seg, nblk, n_pass, shift0;
   int32_t* loc; int32_t* counts; int32_t* perm; int32_t* tok2row; float* l_aux; int32_t* drop_begin; int32_t* dropped;
   uint32_t* k0; uint32_t* k1; int32_t* v0; int32_t* v1; int32_t* hist; int32_t* ehist; float* partial; int32_t* sync;
+  int ph_lo, ph_hi;        // the phases this launch runs (0 = A, 2 q = histogram of pass q >= 1, 2 q + 1 = scatter of pass q, 2 n_pass = F)
+  int kv_plain;            // keys / values with plain loads and stores: every scatter and its readers are in different launches
 };
 
 // Everything one workgroup writes for another to read in a later phase (keys / values, histograms, counts, l_aux partial sums) moves
@@ -426,6 +428,12 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
   int epoch = 0;
   int32_t* bar = a.sync;
   int32_t* arrive = a.sync + 2;
+  auto runs = [&](int ph) { return ph >= a.ph_lo && ph <= a.ph_hi; };
+  auto after = [&](int ph) { if (runs(ph) && ph < a.ph_hi) route_grid_barrier(bar, epoch); };      // (a launch boundary is the barrier otherwise)
+  auto ldk = [&](const uint32_t* p) { return a.kv_plain ? *p : ldc(p); };
+  auto ldv = [&](const int32_t* p) { return a.kv_plain ? *p : ldc(p); };
+  auto stk = [&](uint32_t* p, uint32_t v) { if (a.kv_plain) *p = v; else stc(p, v); };
+  auto stv = [&](int32_t* p, int32_t v) { if (a.kv_plain) *p = v; else stc(p, v); };
 
   // the last tile of (pass, segment) to finish: adds up the counts (pass 0) and scans the segment's histogram
   auto tile_done = [&](int pass, int seg) {
@@ -448,7 +456,7 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
   };
 
   // ================= phase A: keys, values, expert / digit histograms, l_aux partial sums =================
-  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+  for (int t = blockIdx.x; t < (runs(0) ? n_tiles : 0); t += gridDim.x) {
     const int seg = t / nblk, blk = t - seg * nblk;
     const long sbase = (long)seg * seg_tokens;
     for (int d = tid; d < BINS; d += 256) h[d] = 0;
@@ -467,8 +475,8 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
           inv = b < 0 ? 0u : (b > 0x03FFFFFF ? 0x03FFFFFFu : (uint32_t)b);
         }
         key = ((uint32_t)e << 26) | inv;
-        stc(a.k0 + i, key);
-        stc(a.v0 + i, p);
+        stk(a.k0 + i, key);
+        stv(a.v0 + i, p);
         atomicAdd(&h[(key >> a.shift0) & (BINS - 1)], 1);
       }
       for (int q = 0; q < E; ++q) {                    // one ballot per expert, one LDS add per wave and expert
@@ -503,7 +511,7 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
     }
     tile_done(0, seg);
   }
-  route_grid_barrier(bar, epoch);
+  after(0);
 
   // ================= the passes =================
   const uint32_t* ki = a.k0;
@@ -513,23 +521,23 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
   int shift = a.shift0;
   for (int pass = 0; pass < a.n_pass; ++pass) {
     if (pass > 0) {      // histogram of this pass's digit in the order the previous pass left (route_hist_kernel's body)
-      for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+      for (int t = blockIdx.x; t < (runs(2 * pass) ? n_tiles : 0); t += gridDim.x) {
         const int seg = t / nblk, blk = t - seg * nblk;
         for (int d = tid; d < BINS; d += 256) h[d] = 0;
         __syncthreads();
         const uint32_t* k = ki + (long)seg * seg_tokens;
         for (int j = 0; j < KPB / 256; ++j) {
           const int p = blk * KPB + j * 256 + tid;
-          if (p < seg_tokens) atomicAdd(&h[(ldc(k + p) >> shift) & (BINS - 1)], 1);
+          if (p < seg_tokens) atomicAdd(&h[(ldk(k + p) >> shift) & (BINS - 1)], 1);
         }
         __syncthreads();
         for (int d = tid; d < BINS; d += 256) stc(a.hist + ((long)seg * nblk + blk) * BINS + d, h[d]);
         tile_done(pass, seg);
       }
-      route_grid_barrier(bar, epoch);
+      after(2 * pass);
     }
     // stable scatter (route_scatter_kernel's body)
-    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    for (int t = blockIdx.x; t < (runs(2 * pass + 1) ? n_tiles : 0); t += gridDim.x) {
       const int seg = t / nblk, blk = t - seg * nblk;
       const long sbase = (long)seg * seg_tokens;
       __syncthreads();
@@ -539,7 +547,7 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
       for (int r = 0; r < KPB / 4 / 64; ++r) {
         const int p = p0 + r * 64 + lane;
         const bool valid = p < seg_tokens;
-        const int d = valid ? (int)((ldc(ki + sbase + p) >> shift) & (BINS - 1)) : 0;
+        const int d = valid ? (int)((ldk(ki + sbase + p) >> shift) & (BINS - 1)) : 0;
         const unsigned long long m = match_digit<BITS>(d, valid);
         if (valid && lane == __ffsll((long long)m) - 1) wh[w][d] += __popcll(m);
       }
@@ -559,27 +567,28 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
         const bool valid = p < seg_tokens;
         uint32_t key = 0;
         int32_t val = 0;
-        if (valid) { key = ldc(ki + sbase + p); val = ldc(vi + sbase + p); }
+        if (valid) { key = ldk(ki + sbase + p); val = ldv(vi + sbase + p); }
         const int d = (int)((key >> shift) & (BINS - 1));
         const unsigned long long m = match_digit<BITS>(d, valid);
         if (valid) {
           const int rank = __popcll(m & ((1ull << lane) - 1ull));
           const int32_t pos = wh[w][d] + rank;
-          stc(ko + sbase + pos, key);
-          stc(vo + sbase + pos, val);
+          stk(ko + sbase + pos, key);
+          stv(vo + sbase + pos, val);
         }
         __builtin_amdgcn_wave_barrier();
         if (valid && lane == __ffsll((long long)m) - 1) wh[w][d] += __popcll(m);
         __builtin_amdgcn_wave_barrier();
       }
     }
-    route_grid_barrier(bar, epoch);
+    after(2 * pass + 1);
     shift += BITS;
     const uint32_t* tk = ki; ki = ko; ko = (uint32_t*)tk;
     const int32_t* tv = vi; vi = vo; vo = (int32_t*)tv;
   }
 
   // ================= phase F: locations, row spaces, dropped tokens, l_aux =================
+  if (!runs(2 * a.n_pass)) return;
   const int n_groups = n_seg * E, cap = a.capacity;
   if (a.drop_begin) {      // every workgroup: the prefix of the dropped-token counts over all groups (LDS; workgroup 0 also writes it out)
     int32_t* part = wh[0];
@@ -619,9 +628,9 @@ __global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
     for (int j = 0; j < KPB / 256; ++j) {
       const int pos = blk * KPB + j * 256 + tid;
       if (pos >= seg_tokens) continue;
-      const int e = (int)(ldc(ki + sbase + pos) >> 26);
+      const int e = (int)(ldk(ki + sbase + pos) >> 26);
       const int l = pos - gstart[e];
-      const long tok = sbase + ldc(vi + sbase + pos);
+      const long tok = sbase + ldv(vi + sbase + pos);
       a.loc[tok] = l;
       const long row = ((long)seg * E + e) * cap + l;
       if (l < cap) {
@@ -700,7 +709,7 @@ static int route_compute_units() {
 
 extern "C" int swn_route_top1x(const int32_t* idx, const float* gmax, const float* gates, int n_tokens, int seg_tokens,
                                int n_experts, int capacity, int bpr, int32_t* loc, int32_t* counts, int32_t* perm,
-                               int32_t* tok2row, float* l_aux, int32_t* drop_begin, int32_t* dropped, int32_t* sync,
+                               int32_t* tok2row, float* l_aux, int32_t* drop_begin, int32_t* dropped, int32_t* sync, int mode,
                                void* workspace, size_t workspace_bytes, void* stream) {
   SWN_CHECK(idx && gmax && loc && counts && workspace, "swn_route_top1x: null pointer");
   SWN_CHECK(n_tokens > 0 && seg_tokens > 0 && n_tokens % seg_tokens == 0,
@@ -711,9 +720,9 @@ extern "C" int swn_route_top1x(const int32_t* idx, const float* gmax, const floa
   const int n_seg = n_tokens / seg_tokens;
   SWN_CHECK(workspace_bytes >= swn_route_workspace_bytes(n_tokens, n_seg, n_experts), "swn_route_top1x: workspace too small");
   // the one-launch form needs its synchronisation words, a ticket per (pass, segment) and - for the dropped-token lists - the group
-  // prefix in LDS; anything else (and SWN_ROUTE_MULTI=1: tests compare the two forms) takes the per-phase launches
-  static const bool multi = getenv("SWN_ROUTE_MULTI") != nullptr;
-  const bool one = !multi && sync != nullptr && 2 + 4 * n_seg <= ROUTE_SYNC_WORDS && (!drop_begin || n_seg * n_experts <= ROUTE_ONE_MAX_GROUPS);
+  // prefix in LDS; anything else takes the per-phase launches
+  SWN_CHECK(mode >= 0 && mode <= 2, "swn_route_top1x: mode %d (0 = per-phase kernels, 1 = fused phases, 2 = one launch)", mode);
+  const bool one = mode > 0 && sync != nullptr && 2 + 4 * n_seg <= ROUTE_SYNC_WORDS && (!drop_begin || n_seg * n_experts <= ROUTE_ONE_MAX_GROUPS);
   if (!one) {
     int rc = swn_route_top1(idx, gmax, gates, n_tokens, seg_tokens, n_experts, capacity, bpr, loc, counts, perm, tok2row, l_aux, workspace,
                             workspace_bytes, stream);
@@ -733,9 +742,18 @@ extern "C" int swn_route_top1x(const int32_t* idx, const float* gmax, const floa
   a.hist = (int32_t*)(ws + 4 * tb); a.partial = (float*)(ws + 4 * tb + hb); a.ehist = (int32_t*)(ws + 4 * tb + hb + pb);
   a.sync = sync;
   const int n_tiles = n_seg * nblk;
-  int grid = 2 * route_compute_units();    // at most two 256-thread workgroups per CU: always co-resident (the grid barrier's condition)
-  if (grid > n_tiles) grid = n_tiles;
-  hipLaunchKernelGGL(route_one_kernel, dim3(grid), dim3(256), 0, as_stream(stream), a);
+  if (mode == 2) {       // every phase in one launch, grid barriers between them
+    a.ph_lo = 0; a.ph_hi = 2 * a.n_pass; a.kv_plain = 0;
+    int grid = 2 * route_compute_units();    // at most two 256-thread workgroups per CU: always co-resident (the grid barrier's condition)
+    if (grid > n_tiles) grid = n_tiles;
+    hipLaunchKernelGGL(route_one_kernel, dim3(grid), dim3(256), 0, as_stream(stream), a);
+  } else {               // one launch per phase (9 with batch prioritisation, 3 without): the launch boundary is the barrier, one tile per workgroup
+    a.kv_plain = 1;
+    for (int ph = 0; ph <= 2 * a.n_pass; ++ph) {
+      a.ph_lo = a.ph_hi = ph;
+      hipLaunchKernelGGL(route_one_kernel, dim3(n_tiles), dim3(256), 0, as_stream(stream), a);
+    }
+  }
   SWN_LAUNCH_CHECK();
   return 0;
 }

@@ -152,18 +152,17 @@ def route_sync(dev):
     return t
 
 
-_ROUTE_ONE = os.environ.get("SWN_ROUTE_ONE", "0") == "1"
+_ROUTE_MODE = int(os.environ.get("SWN_ROUTE_MODE", "0"))
 
 
 def route_top1(idx, gmax, gates, seg_tokens: int, n_experts: int, capacity: int, bpr: bool, want_perm=True, want_drops=False, multi=False,
-               one=None):
+               mode=None):
     """Top-1 capacity assignment of every routing segment (swn_route_top1x) -> (loc, counts, perm, tok2row, l_aux)
-    [+ (drop_begin, dropped) with want_drops: the tokens no expert kept, swn_route_dropped's lists].
-    one: True = the whole routing in ONE launch (route_one_kernel: resident workgroups + grid barriers; built and bit-identical, but
-    SLOWER than the per-phase launches on this part - the data that crosses a barrier has to go through the memory side, the eight
-    XCDs' L2s are not coherent with each other: profiles/r05_experiments.md 3); None = the SWN_ROUTE_ONE environment switch (default
-    off: swn_route_top1x without its synchronisation words runs the per-phase launches).  multi=True: the round 1-4 entry points
-    (swn_route_top1 + swn_route_dropped) - the twin the tests compare with."""
+    [+ (drop_begin, dropped) with want_drops: the tokens no expert kept, swn_route_dropped's lists, from the same call].
+    mode (include/swn.h): 0 = the 20 per-phase kernels of rounds 1-4 (the default - still the fastest; SWN_ROUTE_MODE overrides);
+    1 = route_one_kernel launched once per phase (9 launches: no faster), 2 = ONE launch with grid barriers (slower); both bit-identical
+    and kept under their twin test (profiles/r05_experiments.md 3).
+    multi=True: the round 1-4 entry points themselves (swn_route_top1 + swn_route_dropped) - the twin the tests compare with."""
     P = idx.shape[0]
     n_seg = P // seg_tokens
     dev = idx.device
@@ -189,7 +188,7 @@ def route_top1(idx, gmax, gates, seg_tokens: int, n_experts: int, capacity: int,
     else:
         call("swn_route_top1x", _p(idx), _p(gmax), _p(gates), P, int(seg_tokens), n_experts, int(capacity), int(bool(bpr)),
              _p(loc), _p(counts), _p(perm), _p(tok2row), _p(l_aux), _p(drop_begin), _p(dropped),
-             _p(route_sync(dev)) if (one if one is not None else _ROUTE_ONE) else None, _p(ws), nbytes, _stream())
+             _p(route_sync(dev)), int(_ROUTE_MODE if mode is None else mode), _p(ws), nbytes, _stream())
     if want_drops:
         return loc, counts, perm, tok2row, l_aux, drop_begin, dropped
     return loc, counts, perm, tok2row, l_aux

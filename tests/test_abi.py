@@ -63,7 +63,7 @@ def test_error_reporting_without_gpu():
     assert rc != 0 and b"null descriptor" in lib.swn_last_error()
     rc = lib.swn_route_top1(None, None, None, 10, 3, 8, 1, 1, None, None, None, None, None, None, 0, None)
     assert rc != 0 and b"null pointer" in lib.swn_last_error()
-    rc = lib.swn_route_top1x(None, None, None, 10, 3, 8, 1, 1, None, None, None, None, None, None, None, None, None, 0, None)
+    rc = lib.swn_route_top1x(None, None, None, 10, 3, 8, 1, 1, None, None, None, None, None, None, None, None, 1, None, 0, None)
     assert rc != 0 and b"swn_route_top1x: null pointer" in lib.swn_last_error()
     assert lib.swn_route_sync_bytes() == 4096
 

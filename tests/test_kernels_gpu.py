@@ -1265,21 +1265,21 @@ def test_chain_fused_tail(n_seg, seg_tokens, skew, S):
 def test_route_three_pass_variant_is_bit_exact_too():
     """SWN_ROUTE_3PASS=1 (three radix passes of 9 / 10 bits instead of four of 8: measured slower, kept selectable - profiles/
     r03_experiments.md section 7) passes the same bit-exact routing tests against the reference's goldens; the switch is read once
-    per process, hence the subprocess (SWN_ROUTE_MULTI=1: the per-phase launches - the one-launch form always runs four 8-bit passes)."""
+    per process, hence the subprocess (SWN_ROUTE_MODE=0: the per-phase kernels - the fused phases always run four 8-bit passes)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-q", "-x", "-k",
                         "test_route_golden or test_route_ragged"], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, SWN_ROUTE_3PASS="1", SWN_ROUTE_MULTI="1"), cwd=root)
+                       env=dict(os.environ, SWN_ROUTE_3PASS="1", SWN_ROUTE_MODE="0"), cwd=root)
     assert p.returncode == 0, p.stdout[-1500:]
     assert " passed" in p.stdout and "failed" not in p.stdout
 
 
-def test_route_one_launch_equals_the_per_phase_launches():
-    """swn_route_top1x with its synchronisation words (the whole routing in one launch: resident workgroups, grid barriers, the last tile
-    of a segment scans - built, bit-identical and slower than the launches it replaces: opt-in, profiles/r05_experiments.md 3) against
+def test_route_fused_phases_and_one_launch_equal_the_per_phase_kernels():
+    """swn_route_top1x in mode 1 (route_one_kernel launched once per phase: 9 launches, the default) and mode 2 (the same phases in ONE
+    launch of resident workgroups with grid barriers: built, bit-identical, slower - opt-in, profiles/r05_experiments.md 3) against
     swn_route_top1 + swn_route_dropped (20 launches): every output bit-identical - loc, counts, perm (the -1 of the empty slots
     included), tok2row, l_aux (same order of additions), drop_begin and the written part of the dropped list - on tie-heavy gates,
     ragged last tiles, one / many segments, 1 .. 64 experts, with and without batch prioritisation, capacities below and above the
@@ -1298,12 +1298,14 @@ def test_route_one_launch_equals_the_per_phase_launches():
         ref = o.route_top1(idx, gmax, gates, seg, E, cap, bpr, want_drops=True, multi=True)
         nd = int(ref[5][-1].item())
         for rep in range(30 if n in (3, 9) else 2):
-            one = o.route_top1(idx, gmax, gates, seg, E, cap, bpr, want_drops=True, one=True)
-            for name, a, b in zip(("loc", "counts", "perm", "tok2row", "l_aux", "drop_begin"), one[:6], ref[:6]):
-                assert torch.equal(a, b), (n, rep, name, int((a != b).sum().item()))
-            assert int(one[5][-1].item()) == nd and torch.equal(one[6][:nd], ref[6][:nd]), (n, rep, "dropped")
+            for mode in (1, 2):
+                one = o.route_top1(idx, gmax, gates, seg, E, cap, bpr, want_drops=True, mode=mode)
+                for name, a, b in zip(("loc", "counts", "perm", "tok2row", "l_aux", "drop_begin"), one[:6], ref[:6]):
+                    assert torch.equal(a, b), (n, rep, mode, name, int((a != b).sum().item()))
+                assert int(one[5][-1].item()) == nd and torch.equal(one[6][:nd], ref[6][:nd]), (n, rep, mode, "dropped")
         # the optional outputs left out
-        lean = o.route_top1(idx, gmax, None, seg, E, cap, bpr, want_perm=False, one=True)
-        assert torch.equal(lean[0], ref[0]) and torch.equal(lean[1], ref[1]) and lean[2] is None and torch.equal(lean[3], ref[3]) and lean[4] is None
+        for mode in (0, 1, 2):
+            lean = o.route_top1(idx, gmax, None, seg, E, cap, bpr, want_perm=False, mode=mode)
+            assert torch.equal(lean[0], ref[0]) and torch.equal(lean[1], ref[1]) and lean[2] is None and torch.equal(lean[3], ref[3]) and lean[4] is None
     for t in o._route_sync.values():
         assert int(t.abs().sum().item()) == 0
