@@ -2327,9 +2327,7 @@ static int chain_persistent_launch(const swn_chain_desc& d, void* stream) {
     a.n_queues = 8;
     a.per_queue = (int)cdiv(n_vb, 8);
   }
-  a.stagger = 0;
-  if (const char* sv = getenv("SWN_CHAINQ_STAGGER")) a.stagger = atoi(sv);
-  if (n_vb < 4L * grid) a.stagger = 0;                  // (short launches: the offset would be most of the run)
+  a.stagger = 0;                                        // (a start offset between the workgroups of an XCD: measured, no effect - r04_experiments.md 2)
   const void* fn;
 #define SWN_PICKQ(TAGV)                                                                                                       \
   case TAGV:                                                                                                                  \

@@ -795,28 +795,15 @@ extern "C" int swn_route_top1(const int32_t* idx, const float* gmax, const float
   uint32_t *ki = k0, *ko = k1;
   int32_t *vi = v0, *vo = v1;
   // pass plan: the key has 26 + ceil(log2 E) significant bits (without BPR only the expert bits differ: one pass)
-  int ebits = 0;
-  while ((1 << ebits) < n_experts) ++ebits;
-  // Default: four 8-bit passes.  SWN_ROUTE_3PASS=1: three passes of 9 / 10 bits for E <= 16 - measured SLOWER (15.20 vs 14.98 ms per
-  // step, 2.49 vs 2.41 ms at 1024 rays: with 2048 keys per block a 1024-bin histogram per block is as much traffic as the keys, the scan
-  // kernel has four times the rows, and the per-wave match takes 10 ballots) - kept for the record (profiles/r03_experiments.md).
-  static const bool three_pass = getenv("SWN_ROUTE_3PASS") != nullptr;
-  int widths[4] = {8, 8, 8, 8}, n_pass = 4, shift = 0;
+  // Four 8-bit passes.  (Three passes of 9 / 10 bits for E <= 16 were measured SLOWER in round 3 - 15.20 vs 14.98 ms per step: with 2048
+  // keys per block a 1024-bin histogram per block is as much traffic as the keys, the scan kernel has four times the rows, the per-wave
+  // match takes 10 ballots - profiles/r03_experiments.md 7; the variant and its switch were removed in round 5.)
+  int n_pass = 4, shift = 0;
   if (!bpr) { n_pass = 1; shift = 24; }
-  else if (26 + ebits <= 30 && three_pass) {
-    const int tot = 26 + ebits;                 // 27 .. 30 bits in three passes of 9 or 10 bits
-    n_pass = 3;
-    widths[0] = (tot + 2) / 3; widths[1] = (tot + 1) / 3; widths[2] = tot / 3;
-    for (int q = 0; q < 3; ++q) if (widths[q] < 8) widths[q] = 8;
-  }
   for (int q = 0; q < n_pass; ++q) {
-    switch (widths[q]) {
-      case 8: route_pass<8>(ki, vi, ko, vo, seg_tokens, n_seg, nblk, shift, hist, s); break;
-      case 9: route_pass<9>(ki, vi, ko, vo, seg_tokens, n_seg, nblk, shift, hist, s); break;
-      default: route_pass<10>(ki, vi, ko, vo, seg_tokens, n_seg, nblk, shift, hist, s); break;
-    }
+    route_pass<8>(ki, vi, ko, vo, seg_tokens, n_seg, nblk, shift, hist, s);
     SWN_LAUNCH_CHECK();
-    shift += widths[q];
+    shift += 8;
     uint32_t* tk = ki; ki = ko; ko = tk;
     int32_t* tv = vi; vi = vo; vo = tv;
   }

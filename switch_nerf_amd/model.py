@@ -124,7 +124,7 @@ class SwitchNeRF:
         self.overlap = os.environ.get("SWN_NO_OVERLAP", "0") != "1"   # side-stream overlap of the expert weight gradients
         self._kernel_sel = {}         # kernel_set(): what the last forward / backward selected
         self.ep = None                # parallel.ExpertParallel: experts sharded over ranks, tokens exchanged (set_expert_parallel)
-        self.expert_wgrad_splits = int(os.environ.get("SWN_EXPERT_WGRAD_SPLITS", "0"))   # 0 = heuristic
+        self.expert_wgrad_splits = 0         # row splits of the legacy expert weight-gradient launch (0 = heuristic)
 
     def _configure(self, cfg):
         """Sets the network dimensions and returns the flat parameter layout [(name, shape)]; Linear weights are [in, out]."""

@@ -1262,21 +1262,6 @@ def test_chain_fused_tail(n_seg, seg_tokens, skew, S):
         assert int(t.abs().sum().item()) == 0
 
 
-def test_route_three_pass_variant_is_bit_exact_too():
-    """SWN_ROUTE_3PASS=1 (three radix passes of 9 / 10 bits instead of four of 8: measured slower, kept selectable - profiles/
-    r03_experiments.md section 7) passes the same bit-exact routing tests against the reference's goldens; the switch is read once
-    per process, hence the subprocess (SWN_ROUTE_MODE=0: the per-phase kernels - the fused phases always run four 8-bit passes)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-q", "-x", "-k",
-                        "test_route_golden or test_route_ragged"], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, SWN_ROUTE_3PASS="1", SWN_ROUTE_MODE="0"), cwd=root)
-    assert p.returncode == 0, p.stdout[-1500:]
-    assert " passed" in p.stdout and "failed" not in p.stdout
-
-
 def test_route_fused_phases_and_one_launch_equal_the_per_phase_kernels():
     """swn_route_top1x in mode 1 (route_one_kernel launched once per phase: 9 launches, the default) and mode 2 (the same phases in ONE
     launch of resident workgroups with grid barriers: built, bit-identical, slower - opt-in, profiles/r05_experiments.md 3) against
