@@ -717,7 +717,11 @@ def main():
     if world > 1 and a.parallelism == "dp" and plain and not other and not a.no_ep_probe and model.E % world == 0:
         import threading
 
+        probe_done = threading.Event()
+
         def give_up():
+            if probe_done.is_set():
+                return
             if rank == 0:
                 out["config"]["expert_parallel"] = dict(error=f"the expert-parallel probe did not finish within {a.ep_probe_limit:.0f} s")
                 out["cpu_baseline"] = None
@@ -742,6 +746,7 @@ def main():
             out["config"]["expert_parallel"] = x
         except Exception as e:      # (the same exception on every rank: a one-sided failure ends in the watchdog)
             out["config"]["expert_parallel"] = dict(error=f"{type(e).__name__}: {e}"[:400])
+        probe_done.set()
         dog.cancel()
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline and not other:

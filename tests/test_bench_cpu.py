@@ -42,8 +42,12 @@ def test_traffic_table_is_made_by_script_and_tied_to_the_kernel_sources(tmp_path
             f"void swn_big::chainq_kernel<swn_big::Bf16, 8, true>(swn_big::ArgsQ)\n   {c}   {v8:.4e}  (n=3)\n"
             f"swn::dwsig_runs_kernel(float const*, long, int, float*)\n   {c}   1.0000e+02  (n=3)\n" + line + "\n")
     mt.ROOT = str(tmp_path)
-    sys.argv = ["make_traffic.py", "rXX"]
-    mt.main()
+    argv = sys.argv
+    try:
+        sys.argv = ["make_traffic.py", "rXX"]
+        mt.main()
+    finally:
+        sys.argv = argv
     t = json.load(open(tmp_path / "profiles" / "traffic.json"))
     assert t["csrc_sha256"] == h and t["points"] == 8192 * 256 and t["kept_rows"] == round(0.78 * 8192 * 256)
     assert t["launches"]["expert_fwd"]["hbm_bytes"] == int((2 * 1.0e6 + 9.0e6) * 1024)
