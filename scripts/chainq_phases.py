@@ -1,7 +1,7 @@
 """Phase timers of the persistent expert chain (geometry 7; library variant built with SWN_DEFS=-DSWN_BIG_TIMING):
    SWN_VARIANT=timing SWN_DEFS=-DSWN_BIG_TIMING bash switch_nerf_amd/build.sh
    SWN_LIB=switch_nerf_amd/libswn_hip_timing.so python scripts/chainq_phases.py [full|nosave|bwd]
-mean shader clocks of wave 0 (row group 0) / wave 4 (row group 1) per tile and per layer."""
+mean shader clocks of each of the 8 waves per tile and per layer."""
 import sys
 import torch
 sys.path.insert(0, '.')
@@ -35,7 +35,7 @@ for mode in sys.argv[1:] or ["full", "nosave", "bwd"]:
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); f(); b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b)
-    for nm, sl in (("wave 0 (row group 0)", slice(0, 256)), ("wave 4 (row group 1)", slice(2048, 2048 + 256))):
+    for nm, sl in [(f"wave {w_} (row group {w_ >> 2})", slice(512 * w_, 512 * w_ + 256)) for w_ in range(8)]:
         raw = dbg.view(4096, 8)[sl]
         t = raw.double().mean(0).tolist()
         tiles = (raw[:, 6] & 0xFFFF).double().mean().item()

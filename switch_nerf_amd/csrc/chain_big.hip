@@ -2136,8 +2136,8 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
   SWN_KEEP16(keep);
   if (rg == 0) __builtin_amdgcn_s_barrier();      // (row group 1's last phase boundary)
 #ifdef SWN_BIG_TIMING
-  if (d.y_add_gather && !d.y_add && cx.lane == 0 && (cx.w == 0 || cx.w == 4) && blockIdx.x < 2048) {   // wave 0 -> row b, wave 4 -> row 2048 + b
-    long long* dbg = (long long*)d.y_add_gather + (long)(blockIdx.x + (cx.w ? 2048 : 0)) * 8;
+  if (d.y_add_gather && !d.y_add && cx.lane == 0 && blockIdx.x < 512) {   // wave w of workgroup b -> row 512 w + b
+    long long* dbg = (long long*)d.y_add_gather + (long)(cx.w * 512 + blockIdx.x) * 8;
     dbg[0] = tS; dbg[1] = tSw; dbg[2] = tK; dbg[3] = tKb; dbg[4] = tE; dbg[5] = tEb + tSb; dbg[6] = it | (tSi << 16); dbg[7] = TICK() - t_start;
   }
 #endif
