@@ -75,6 +75,13 @@ int swn_unmerge_grad(const float* d_raw, const int32_t* order, int n_rays, int n
 int swn_gate_fwd(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg,
                  int n_tokens, int gate_dim, int n_experts,
                  float* gates, int32_t* idx, float* gmax, float* stats, void* stream);
+/* The same with gate noise (a TRAINING forward under --gate_noise > 0: opts.py:208, tutel_moe_layer_nobatch.py:119-122,
+ * `logits + gate_noise * randn_like(logits) / E`): logits += noise_scale * noise[token][expert] (fp32 [n_tokens][n_experts], drawn by the
+ * caller; noise_scale = gate_noise / n_experts) before the softmax.  The backward (swn_gate_bwd) is unchanged - it starts from the
+ * probabilities this call wrote.  Runs on the VALU kernel for every shape.                                                          */
+int swn_gate_fwd_noise(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg, const float* noise,
+                       float noise_scale, int n_tokens, int gate_dim, int n_experts, float* gates, int32_t* idx, float* gmax,
+                       float* stats, void* stream);
 
 /* backward of the above + the l_aux gradient.  d_gates[s,e] = laux_coef[seg(s)] * counts[seg(s),e]
  * + (e==idx[s]) * d_gmax[s];  then softmax bwd, router bwd (d_wg accumulated with atomics into fp32 [E,G]),

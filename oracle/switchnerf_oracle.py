@@ -246,12 +246,14 @@ def expert_mlp(d: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequenc
 
 def moe_layer(h: torch.Tensor, gate_input: torch.Tensor, wg: torch.Tensor, weights, biases, skips,
               capacity_factor: float, batch_prioritized: bool, routing: Optional[dict] = None, no_batch: bool = False,
-              autocast: Optional[Autocast] = None):
+              autocast: Optional[Autocast] = None, gate_noise: float = 0.0, noise: Optional[torch.Tensor] = None):
     """TopKGate.apply_on_expert_fn, tutel_moe_layer_nobatch.py:98-235 (k=1, fp32 gate, postscore).
     Returns (y [P,M], l_aux, routing dict, gates [P,E]).  `routing` may be injected (idx/loc numpy) to
-    decouple numerics tests from near-tie routing flips."""
+    decouple numerics tests from near-tie routing flips.  gate_noise / noise: the gate-noise branch of a training forward."""
     E = wg.shape[0]
     logits = gate_input.float() @ wg.float().t()                               # :105-113
+    if gate_noise > 0 and noise is not None:                                   # training, --gate_noise > 0 (:119-122): `noise` stands for
+        logits = logits + gate_noise * noise / E                               # the layer's torch.randn_like(logits) draw
     gates = torch.softmax(logits, dim=1)                                       # :126
     if routing is None:
         routing = route_top1(gates.detach().numpy(), capacity_factor, batch_prioritized)
@@ -298,8 +300,10 @@ def params_from_numpy(sd: Dict[str, np.ndarray], requires_grad: bool = False) ->
 
 def nerf_moe_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: dict, capacity_factor: float = 1.0,
                      batch_prioritized: bool = True, sigma_noise: Optional[torch.Tensor] = None,
-                     routing: Optional[dict] = None, no_batch: bool = False, encoded=None, autocast: Optional[Autocast] = None):
+                     routing: Optional[dict] = None, no_batch: bool = False, encoded=None, autocast: Optional[Autocast] = None,
+                     gate_noise: float = 0.0, gate_noise_draw: Optional[torch.Tensor] = None):
     """NeRFMoE.forward, models/nerf_moe.py:320-455, with building.yaml's layer wiring.
+    gate_noise / gate_noise_draw [P, E]: the gate-noise branch of a training forward (moe_layer; fp32 path only).
     x: [P, 7] = xyz(3) dir(3) image_index(1).  Returns dict(outputs [P,4], moe_loss [1], routing, gates).
     encoded = (xyz encoding [P, 3 + 6 L], dirs [P,3], image index [P]): MipNeRFMoE.forward (:675-810), which is the same
     network behind a different position encoder (MipEmbedder)."""
@@ -310,6 +314,7 @@ def nerf_moe_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: dict, cap
     else:
         enc, dirs, img = encoded[0], encoded[1], encoded[2].long()
     if autocast is not None:
+        assert gate_noise_draw is None, "gate noise: fp32 path only"
         return _nerf_moe_forward_autocast(p, enc, dirs, img, cfg, capacity_factor, batch_prioritized, sigma_noise, routing, no_batch,
                                           autocast)
     h = F.linear(enc, p["layers.xyz.fcs.0.weight"], p["layers.xyz.fcs.0.bias"])  # :330-333
@@ -319,7 +324,7 @@ def nerf_moe_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: dict, cap
     weights = [p[f"layers.0.experts.0.weights.{l}"] for l in range(L)]
     biases = [p[f"layers.0.experts.0.bias.{l}"] for l in range(L)]
     y, l_aux, routing, gates = moe_layer(h, g, p["layers.0.gates.0.wg.weight"], weights, biases, cfg["skips"],
-                                         capacity_factor, batch_prioritized, routing, no_batch)
+                                         capacity_factor, batch_prioritized, routing, no_batch, gate_noise=gate_noise, noise=gate_noise_draw)
     y = torch.relu(y)                                                          # act: relu, :385-386
     sigma = F.linear(y, p["layers.sigma.fcs.0.weight"], p["layers.sigma.fcs.0.bias"])  # :393-400
     if sigma_noise is not None:
@@ -405,7 +410,7 @@ def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_fine: int, u: Option
 
 
 def _eval_points(p, rays, image_indices, z, cfg, chunk, capacity_factor, batch_prioritized, sigma_noise, routings, hash_cfg=None,
-                 autocast: Optional[Autocast] = None):
+                 autocast: Optional[Autocast] = None, gate_noise: float = 0.0, gate_noise_draw: Optional[torch.Tensor] = None):
     """The chunked network evaluation of _inference (rendering.py:311-383): routing (capacity, ranking, l_aux) is per chunk.
     hash_cfg: the positions enter through the hash-grid encoding (p["embedding_xyz.table"]) instead of the frequency one."""
     N, S = z.shape
@@ -420,7 +425,8 @@ def _eval_points(p, rays, image_indices, z, cfg, chunk, capacity_factor, batch_p
         r = nerf_moe_forward(p, pts[i:i + chunk], cfg, capacity_factor, batch_prioritized, sn,
                              None if routings is None else routings[ci],
                              encoded=None if enc is None else (enc[i:i + chunk], pts[i:i + chunk, 3:6], pts[i:i + chunk, 6]),
-                             autocast=autocast)
+                             autocast=autocast, gate_noise=gate_noise,
+                             gate_noise_draw=None if gate_noise_draw is None else gate_noise_draw[i:i + chunk])
         outs.append(r["outputs"])
         losses.append(r["moe_loss"])
         routes.append(r["routing"])
@@ -432,8 +438,9 @@ def render_rays(p, rays: torch.Tensor, image_indices: torch.Tensor, cfg: dict, n
                 perturb_rand: Optional[torch.Tensor] = None, sigma_noise: Optional[torch.Tensor] = None,
                 routings: Optional[list] = None, fine_samples: int = 0, fine_u: Optional[torch.Tensor] = None,
                 sigma_noise_fine: Optional[torch.Tensor] = None, hash_cfg: Optional[dict] = None,
-                autocast: Optional[Autocast] = None):
+                autocast: Optional[Autocast] = None, gate_noise: float = 0.0, gate_noise_draw: Optional[torch.Tensor] = None):
     """render_rays + _get_results + _inference, rendering.py:15-196, :199-274, :277-494 (no background model, no cascade).
+    gate_noise / gate_noise_draw [N * n_samples, E]: --gate_noise in a training forward (coarse pass only here).
     autocast: the reference's mixed-precision training mode (class Autocast); the renderer itself stays fp32 - its inputs are
     (z fp32) x (network outputs), which type promotion lifts to fp32 (under the CPU policy sigma and rgb arrive rounded to 16 bits).
     Points are evaluated in chunks of `chunk` (= model_chunk_size) and the routing (capacity, ranking, l_aux) is per
@@ -443,8 +450,9 @@ def render_rays(p, rays: torch.Tensor, image_indices: torch.Tensor, cfg: dict, n
     sets sort-merged :419-433 (stable sort here; the reference's torch.sort is only defined up to ties) and composited."""
     near, far = rays[:, 6:7], rays[:, 7:8]
     z = sample_z(near, far, n_samples, perturb, perturb_rand)
+    assert gate_noise_draw is None or fine_samples == 0
     out, gl, routes = _eval_points(p, rays, image_indices, z, cfg, chunk, capacity_factor, batch_prioritized, sigma_noise,
-                                   routings, hash_cfg, autocast)
+                                   routings, hash_cfg, autocast, gate_noise, gate_noise_draw)
     out = out.float()
     comp = composite(out[..., :3], out[..., 3], z)
     res = dict(rgb_coarse=comp["rgb"], depth_variance_coarse=comp["depth_variance"], depth_coarse=comp["depth"],

@@ -72,6 +72,7 @@ SIGNATURES = {
     "swn_merge_samples": [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp],
     "swn_unmerge_grad": [vp, vp, i32, i32, i32, vp, vp, vp],
     "swn_gate_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
+    "swn_gate_fwd_noise": [vp, i32, vp, vp, vp, vp, f32, i32, i32, i32, vp, vp, vp, vp, vp],
     "swn_gate_bwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp],
     "swn_route_top1": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp],
     "swn_route_top1x": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, sz, vp],

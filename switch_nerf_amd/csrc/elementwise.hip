@@ -234,7 +234,10 @@ template <typename T, int G, int EMAX, int TB = 1>
 __global__ __launch_bounds__(256) void gate_fwd_kernel(const T* __restrict__ g, const float* __restrict__ ln_w,
                                                        const float* __restrict__ ln_b, const float* __restrict__ wg,
                                                        int P, int E, float* __restrict__ gates, int32_t* __restrict__ idx,
-                                                       float* __restrict__ gmax, float* __restrict__ stats) {
+                                                       float* __restrict__ gmax, float* __restrict__ stats,
+                                                       const float* __restrict__ noise, float noise_scale) {
+  // noise != NULL: logits += noise_scale * noise[token][expert] before the softmax - the gate-noise branch of a training forward
+  // (--gate_noise > 0: tutel_moe_layer_nobatch.py:119-122, noise_scale = gate_noise / E; swn_gate_fwd_noise).  NULL: nothing is added.
   // TB tokens per 16-lane group and pass (consecutive rows): every router weight read from LDS serves TB rows; the arithmetic of a row
   // is unchanged, value for value (TB = 1, the default everywhere: the kernel of rounds 1-3).  What made the 512-feature x 16-expert
   // instantiation slow (2.0 ms per 852 k rows, a tenth of the rate its row reads allow) was not the LDS traffic but the scheduler
@@ -302,6 +305,11 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const T* __restrict__ g, 
     for (int t = 0; t < TB; ++t) {
       const long tok = tok0 + t;
       if (tok >= P) break;
+      if (noise) {
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e)
+          if (e < E) logit[t][e] = logit[t][e] + noise_scale * noise[tok * E + e];
+      }
       float mx = logit[t][0];
 #pragma unroll
       for (int e = 1; e < EMAX; ++e)
@@ -1165,30 +1173,43 @@ static inline int row_blocks(long rows) {   // 16 rows per 256-thread block iter
   return (int)b;
 }
 
-extern "C" int swn_gate_fwd(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg,
-                            int n_tokens, int gate_dim, int n_experts, float* gates, int32_t* idx, float* gmax,
-                            float* stats, void* stream) {
+static int gate_fwd_impl(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg, const float* noise, float noise_scale,
+                         int n_tokens, int gate_dim, int n_experts, float* gates, int32_t* idx, float* gmax, float* stats, void* stream) {
   SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_gate_fwd: bad dtype");
   SWN_CHECK(g && wg && gates && idx && gmax, "swn_gate_fwd: null pointer");
   SWN_CHECK(n_experts >= 1 && n_experts <= 16, "swn_gate_fwd: experts <= 16");
   SWN_CHECK((ln_w == nullptr) == (ln_b == nullptr), "swn_gate_fwd: ln_w / ln_b must both be given or both NULL");
   if (ln_w) SWN_CHECK(stats, "swn_gate_fwd: stats required with LayerNorm");
   const int blocks = row_blocks(n_tokens);
-  // 16-bit rows of 256, up to 8 experts: the contraction on the matrix pipe (gate_mfma.hip; SWN_GATE_VALU=1 keeps the VALU kernel: A/B runs)
+  // 16-bit rows of 256, up to 8 experts: the contraction on the matrix pipe (gate_mfma.hip; SWN_GATE_VALU=1 keeps the VALU kernel: A/B runs;
+  // a forward with gate noise runs on the VALU kernel)
   static const bool valu_only = getenv("SWN_GATE_VALU") != nullptr;
-  if (dtype == SWN_HALF && gate_dim == 256 && n_experts <= 8 && !valu_only)
+  if (dtype == SWN_HALF && gate_dim == 256 && n_experts <= 8 && !valu_only && !noise)
     return swn::gate_fwd_mfma_launch(g, ln_w, ln_b, wg, n_tokens, n_experts, gates, idx, gmax, stats, stream);
   if (dtype == SWN_HALF) {
     const bf16_t* gp = (const bf16_t*)g;
     GATE_DISPATCH_TB(bf16_t, gate_fwd_kernel, SWN_GATE_TB512, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, n_tokens, n_experts,
-                  gates, idx, gmax, stats);
+                  gates, idx, gmax, stats, noise, noise_scale);
   } else {
     const float* gp = (const float*)g;
     GATE_DISPATCH_TB(float, gate_fwd_kernel, 1, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, n_tokens, n_experts,
-                  gates, idx, gmax, stats);
+                  gates, idx, gmax, stats, noise, noise_scale);
   }
   SWN_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int swn_gate_fwd(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg,
+                            int n_tokens, int gate_dim, int n_experts, float* gates, int32_t* idx, float* gmax,
+                            float* stats, void* stream) {
+  return gate_fwd_impl(g, dtype, ln_w, ln_b, wg, nullptr, 0.f, n_tokens, gate_dim, n_experts, gates, idx, gmax, stats, stream);
+}
+
+extern "C" int swn_gate_fwd_noise(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg, const float* noise,
+                                  float noise_scale, int n_tokens, int gate_dim, int n_experts, float* gates, int32_t* idx, float* gmax,
+                                  float* stats, void* stream) {
+  SWN_CHECK(noise, "swn_gate_fwd_noise: null noise");
+  return gate_fwd_impl(g, dtype, ln_w, ln_b, wg, noise, noise_scale, n_tokens, gate_dim, n_experts, gates, idx, gmax, stats, stream);
 }
 
 #define DWG_LAUNCH(T, EV, GV, GP)                                                                                  \

@@ -84,7 +84,7 @@ class LossScaler:
 
 class SwitchNeRF:
     def __init__(self, cfg: dict = BUILDING, dtype=torch.bfloat16, device="cuda", capacity_factor=1.0,
-                 batch_prioritized=True, moe_l_aux_wt=5e-4, lr=5e-4, seed=0):
+                 batch_prioritized=True, moe_l_aux_wt=5e-4, lr=5e-4, seed=0, gate_noise=-1.0):
         self.cfg, self.dtype, self.dev = dict(cfg), dtype, torch.device(device)
         # the 16-bit compute type selects the build of the library: bfloat16 (amp_use_bfloat16) or IEEE half (the reference's default
         # autocast dtype; BASELINE configs[4] "fp16 MFMA") - see _lib.use_half.  fp16 trains with loss scaling like the reference.
@@ -94,6 +94,9 @@ class SwitchNeRF:
             _lib.use_half("bf16")
         self.loss_scaler = LossScaler() if dtype == torch.float16 else None
         self.cf, self.bpr, self.wt, self.lr = capacity_factor, batch_prioritized, moe_l_aux_wt, lr
+        # --gate_noise (opts.py:208, default -1 = off): a TRAINING forward adds gate_noise * randn / E to the router's logits
+        # (tutel_moe_layer_nobatch.py:119-122).  gate_noise_draw: a [P, E] tensor to use as that draw (tests), else drawn per forward.
+        self.gate_noise, self.gate_noise_draw = float(gate_noise), None
         self.base_lr = lr             # undecayed rate ('initial_lr' of the reference's ExponentialLR); self.lr = the current rate
         spec = self._configure(cfg)
         self.spec, off = {}, 0
@@ -558,7 +561,12 @@ class SwitchNeRF:
                               o.Layer(self.wf["gate1"], self.p["gate1.b"].view(1, G))], c["g"], tag=3, geometry=c["front_geom"] if big else 0,
                     x_features=self.KP if big else 0)
         # ---- gate + routing
-        c["gates"], c["idx"], c["gmax"], c["stats"] = o.gate_fwd(c["g"], self.p["ln.w"], self.p["ln.b"], self.p["wg"])
+        gnoise = None
+        if sv and self.gate_noise > 0:       # (training only, like `self.training and self.gate_noise > 0`)
+            gnoise = (self.gate_noise_draw.to(dev, torch.float32).reshape(P, E).contiguous() if self.gate_noise_draw is not None
+                      else torch.randn(P, E, device=dev, dtype=torch.float32))
+        c["gates"], c["idx"], c["gmax"], c["stats"] = o.gate_fwd(c["g"], self.p["ln.w"], self.p["ln.b"], self.p["wg"], noise=gnoise,
+                                                                 noise_scale=self.gate_noise / E)
         if routing_override is not None:     # tests: inject the oracle's expert choice (near-tie robustness)
             c["idx"] = routing_override.to(dev).int().contiguous()
             c["gmax"] = c["gates"].gather(1, c["idx"].long()[:, None])[:, 0].contiguous()

@@ -7,7 +7,7 @@
 
 Mirrors `moe_layer` / `MOELayer` of /root/reference/switch_nerf/modules/tutel_moe_ext/tutel_moe_layer_nobatch.py (ctor
 :443-460, forward :733-797, TopKGate.apply_on_expert_fn :98-235, ExpertMLP :836-924) for the configuration the reference's
-NeRFMoE builds (models/nerf_moe.py:278-292): top-1 gate with fp32 router, post-score dispatch (the gate value is applied on
+NeRFMoE builds (models/nerf_moe.py:278-292): top-1 gate with fp32 router (optionally with gate noise in training), post-score dispatch (the gate value is applied on
 the way back), capacity `int(cf * ceil(P / E))` with optional batch-prioritised ranking, `expertmlp` experts with the
 residual skip, one routing problem per call (the P tokens of the call), no expert parallelism (`parallel.ExpertParallel`
 covers that inside SwitchNeRF).  Parameter names equal the reference's (`gates.0.wg.weight`, `experts.0.weights.{l}`
@@ -51,14 +51,15 @@ class _Gate(nn.Module):
 
 class _MoEFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, layer, x, gate_in, wg, *wb):
+    def forward(ctx, layer, x, gate_in, wg, gate_noise, *wb):
         o, dt = ops, layer.dtype
         L, E, M = layer.layer_num, layer.n_experts, layer.model_dim
         P = x.shape[0]
         xs = x.detach().to(dt).contiguous()
         gs = gate_in.detach().to(dt).contiguous()
         wg32 = wg.detach().float().contiguous()
-        gates, idx, gmax, stats = o.gate_fwd(gs, None, None, wg32)
+        # gate_noise: the [P, E] draw of a training forward under gate_noise > 0 (tutel_moe_layer_nobatch.py:119-122) or None
+        gates, idx, gmax, stats = o.gate_fwd(gs, None, None, wg32, noise=gate_noise, noise_scale=layer.gate_noise / E if gate_noise is not None else 0.0)
         cap = int(layer.capacity_factor * ((P + E - 1) // E))                                  # tutel_fast_dispatch.py:211
         if layer.moe_no_batch:
             cap = P
@@ -125,7 +126,7 @@ class _MoEFunction(torch.autograd.Function):
         d_wg = torch.zeros_like(wg32)
         coef = (d_laux.reshape(1).float() * (E / float(P * P))).contiguous()
         dg = o.gate_bwd(gs, None, None, wg32, gates, idx, dgmax, stats, counts, coef, P, d_wg, None, None)
-        return (None, dx.to(ctx.x_dtype), dg.to(ctx.g_dtype), d_wg, *dws, *[b.view(E, 1, M) for b in dbs])
+        return (None, dx.to(ctx.x_dtype), dg.to(ctx.g_dtype), d_wg, None, *dws, *[b.view(E, 1, M) for b in dbs])
 
 
 class MoELayer(nn.Module):
@@ -146,6 +147,11 @@ class MoELayer(nn.Module):
         self.capacity_factor = float(gate_type.get("capacity_factor", 1.0))
         self.bpr = bool(gate_type.get("batch_prioritized_routing", False))
         self.gate_dim = int(gate_type.get("gate_dim", model_dim))
+        # gate noise (--gate_noise, opts.py:208; <= 0 = off like the shipped configs' -1): in TRAINING the router's logits get
+        # gate_noise * randn / E before the softmax (tutel_moe_layer_nobatch.py:119-122)
+        self.gate_noise = float(gate_type.get("gate_noise", 0.0) or 0.0)
+        if gate_type.get("use_load_importance_loss") or gate_type.get("use_normal_noise"):
+            raise NotImplementedError("use_load_importance_loss / use_normal_noise (tutel_fast_dispatch.py:152-174; no shipped config uses them)")
         self.moe_no_batch, self.return_gates, self.dtype = bool(moe_no_batch), bool(return_gates), dtype
         gen = None
         if seeds is not None:                      # gate under seeds[0], experts under seeds[1] (tutel_moe_layer_nobatch.py:654-703)
@@ -153,7 +159,9 @@ class MoELayer(nn.Module):
         self.gates = nn.ModuleList([_Gate(self.gate_dim, self.n_experts)])
         self.experts = nn.ModuleList([_ExpertParams(self.n_experts, self.model_dim, self.layer_num, gen)])
 
-    def forward(self, input: torch.Tensor, gate_input: Optional[torch.Tensor] = None):
+    def forward(self, input: torch.Tensor, gate_input: Optional[torch.Tensor] = None, gate_noise_draw: Optional[torch.Tensor] = None):
+        """gate_noise_draw: the [P, E] standard-normal tensor to use as the layer's noise draw (tests replay the reference's); None =
+        drawn here (torch.randn on the device) when the layer trains with gate_noise > 0."""
         if not input.is_cuda:
             raise RuntimeError("MoELayer runs on the HIP library only (no CPU fallback)")
         gi = input if gate_input is None else gate_input
@@ -161,7 +169,11 @@ class MoELayer(nn.Module):
         x = input.reshape(-1, self.model_dim)
         g = gi.reshape(-1, self.gate_dim)
         ex = self.experts[0]
-        y, l_aux, idx = _MoEFunction.apply(self, x, g, self.gates[0].wg.weight, *ex.weights, *ex.bias)
+        noise = None
+        if self.training and self.gate_noise > 0:
+            noise = (gate_noise_draw.to(x.device, torch.float32).reshape(-1, self.n_experts).contiguous() if gate_noise_draw is not None
+                     else torch.randn(x.shape[0], self.n_experts, device=x.device, dtype=torch.float32))
+        y, l_aux, idx = _MoEFunction.apply(self, x, g, self.gates[0].wg.weight, noise, *ex.weights, *ex.bias)
         y = y.view(shape)
         y.l_aux = l_aux                                                                         # :792-796
         if self.return_gates:

@@ -113,7 +113,9 @@ def gather_rows(src, index, out=None):
     return out
 
 
-def gate_fwd(g, ln_w, ln_b, wg):
+def gate_fwd(g, ln_w, ln_b, wg, noise=None, noise_scale: float = 0.0):
+    """LayerNorm + fp32 router + softmax + top-1 -> (gates [P, E], idx, gmax, stats).  noise [P, E] fp32: logits += noise_scale * noise
+    before the softmax (the gate-noise branch of a training forward, swn_gate_fwd_noise)."""
     P, G = g.shape
     E = wg.shape[0]
     dev = g.device
@@ -121,7 +123,12 @@ def gate_fwd(g, ln_w, ln_b, wg):
     idx = torch.empty(P, dtype=torch.int32, device=dev)
     gmax = torch.empty(P, dtype=torch.float32, device=dev)
     stats = torch.empty(P, 2, dtype=torch.float32, device=dev)
-    call("swn_gate_fwd", _p(g), _dt(g), _p(ln_w), _p(ln_b), _p(wg), P, G, E, _p(gates), _p(idx), _p(gmax), _p(stats), _stream())
+    if noise is not None:
+        assert noise.shape == (P, E) and noise.dtype == torch.float32
+        call("swn_gate_fwd_noise", _p(g), _dt(g), _p(ln_w), _p(ln_b), _p(wg), _p(noise.contiguous()), float(noise_scale), P, G, E, _p(gates),
+             _p(idx), _p(gmax), _p(stats), _stream())
+    else:
+        call("swn_gate_fwd", _p(g), _dt(g), _p(ln_w), _p(ln_b), _p(wg), P, G, E, _p(gates), _p(idx), _p(gmax), _p(stats), _stream())
     return gates, idx, gmax, stats
 
 

@@ -1294,3 +1294,34 @@ def test_route_fused_phases_and_one_launch_equal_the_per_phase_kernels():
             assert torch.equal(lean[0], ref[0]) and torch.equal(lean[1], ref[1]) and lean[2] is None and torch.equal(lean[3], ref[3]) and lean[4] is None
     for t in o._route_sync.values():
         assert int(t.abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gate_fwd_with_gate_noise(dtype):
+    """swn_gate_fwd_noise (logits += noise_scale * noise before the softmax: the gate-noise branch of a training forward,
+    tutel_moe_layer_nobatch.py:119-122) against fp64: probabilities to 2e-6, top-1 exact off near-ties, stats unchanged by the noise;
+    without noise the entry point equals swn_gate_fwd bit for bit on the VALU kernel's shapes."""
+    P, Gd, E = 3000, 256, 8
+    rng = np.random.default_rng(71)
+    g = torch.from_numpy(rng.standard_normal((P, Gd)).astype(np.float32)).to(dtype)
+    lw = torch.from_numpy((1 + 0.1 * rng.standard_normal(Gd)).astype(np.float32))
+    lb = torch.from_numpy((0.1 * rng.standard_normal(Gd)).astype(np.float32))
+    wg = torch.from_numpy((rng.standard_normal((E, Gd)) / 16).astype(np.float32))
+    noise = torch.from_numpy(rng.standard_normal((P, E)).astype(np.float32))
+    scale = 1.0 / E
+    gates, idx, gmax, stats = ops().gate_fwd(g.to(dev()), lw.to(dev()), lb.to(dev()), wg.to(dev()), noise=noise.to(dev()), noise_scale=scale)
+    g64 = g.double()
+    xn = torch.nn.functional.layer_norm(g64, (Gd,), lw.double(), lb.double(), 1e-5)
+    logits = xn @ wg.double().t() + scale * noise.double()
+    ref = torch.softmax(logits, 1)
+    assert (gates.cpu().double() - ref).abs().max().item() <= 2e-6
+    top2 = ref.topk(2, 1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-5
+    assert torch.equal(idx.cpu().long()[clear], ref.argmax(1)[clear])
+    assert torch.equal(gmax.cpu(), gates.cpu().gather(1, idx.cpu().long()[:, None])[:, 0])
+    g0, i0, m0, s0 = ops().gate_fwd(g.to(dev()), lw.to(dev()), lb.to(dev()), wg.to(dev()))
+    assert torch.allclose(stats.cpu(), s0.cpu(), rtol=1e-5, atol=1e-6)          # (the LayerNorm statistics do not see the noise)
+    assert (i0.cpu() != idx.cpu()).any()                                       # noise of this size moves expert choices
+    if dtype == torch.float32:      # fp32 rows always take the VALU kernel: zero noise = the plain entry point, bit for bit
+        gz, iz, mz, sz = ops().gate_fwd(g.to(dev()), lw.to(dev()), lb.to(dev()), wg.to(dev()), noise=torch.zeros(P, E, device=dev()), noise_scale=scale)
+        assert torch.equal(gz, g0) and torch.equal(iz, i0) and torch.equal(mz, m0) and torch.equal(sz, s0)

@@ -109,6 +109,49 @@ def test_train_step_vs_oracle_larger_fp32(gate_scale):
         assert err <= (5e-3 if "sigma" in k else 2e-3), (k, err)      # (the sigma head's gradient is a sum of cancelling per-point terms)
 
 
+def test_train_step_with_gate_noise_vs_oracle_fp32():
+    """SwitchNeRF(gate_noise=1.0): a TRAINING step adds gate_noise * noise / E to the router's logits (--gate_noise, opts.py:208;
+    tutel_moe_layer_nobatch.py:119-122) - against the oracle (whose gate-noise branch is pinned on the reference layer's own run,
+    tests/test_oracle_golden.py) fed the same draw: routing, rgb, loss, every gradient; an evaluation forward adds none."""
+    N, S, chunk, gn = 128, 64, 4096, 1.0
+    sd = synth.make_weights(91, synth.BUILDING, gate_scale=1.0)
+    rays, img, rgbs = synth.make_rays(92, N)
+    rng = np.random.default_rng(93)
+    draw = rng.standard_normal((N * S, 8)).astype(np.float32)
+    m = _model(torch.float32, 91, 1.0, gate_noise=gn)
+    m.gate_noise_draw = _dev(draw)
+    st = m.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0, optimizer_step=False)
+    c = st["ctx"]
+    p = O.params_from_numpy(sd, requires_grad=True)
+    kw = dict(gate_noise=gn, gate_noise_draw=torch.from_numpy(draw))
+    ost = O.training_step(p, torch.from_numpy(rays), torch.from_numpy(img), torch.from_numpy(rgbs), synth.BUILDING, S, chunk, **kw)
+    res = ost["results"]
+    ref_idx = np.concatenate([r["idx"] for r in res["routings"]])
+    mis = c["idx"].cpu().numpy() != ref_idx
+    assert mis.mean() < 2e-3, int(mis.sum())
+    if mis.any():      # a near-tie flipped by summation order: both sides on the HIP routing
+        routings = [dict(idx=c["idx"].cpu().numpy()[i:i + chunk], loc=c["loc"].cpu().numpy()[i:i + chunk], capacity=c["cap"])
+                    for i in range(0, N * S, chunk)]
+        p = O.params_from_numpy(sd, requires_grad=True)
+        ost = O.training_step(p, torch.from_numpy(rays), torch.from_numpy(img), torch.from_numpy(rgbs), synth.BUILDING, S, chunk,
+                              routings=routings, **kw)
+        res = ost["results"]
+    ost["loss"].backward()
+    # the noise-free routing of the same weights differs: the draw is what this test is about
+    st0 = _model(torch.float32, 91, 1.0).train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=0.0, optimizer_step=False)
+    assert (st0["ctx"]["idx"] != c["idx"]).float().mean().item() > 0.01
+    np.testing.assert_allclose(c["rgb"].cpu().numpy(), res["rgb_coarse"].detach().numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(st["loss"].item(), ost["loss"].item(), rtol=2e-5)
+    for k, t in m.grad_dict().items():
+        ref = p[k].grad.numpy()
+        err = np.abs(t.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err <= (5e-3 if "sigma" in k else 2e-3), (k, err)
+    # evaluation: no noise
+    with torch.no_grad():
+        ce = m.forward_rays(_dev(rays), _dev(img), S, chunk, 0.0, None, None, training=False)
+    assert torch.equal(ce["idx"], st0["ctx"]["idx"])
+
+
 def test_bf16_step_close_to_fp32_and_adam_moves_loss():
     N, S, chunk = 128, 128, 4096
     rays, img, rgbs = synth.make_rays(88, N)

@@ -95,3 +95,50 @@ def test_moe_layer_bf16_shapes_no_batch_and_errors():
     with pytest.raises(NotImplementedError):
         from switch_nerf_amd.moe import moe_layer
         moe_layer(gate_type=dict(type="top", k=2), model_dim=256, experts=dict(type="expertmlp", count_per_node=8, layer_num=7))
+
+
+def test_moe_layer_gate_noise_vs_reference_golden_fp32():
+    """--gate_noise > 0 (opts.py:208; tutel_moe_layer_nobatch.py:119-122: in training the router's logits get gate_noise * randn / E before
+    the softmax) against the REFERENCE layer's own run with the same noise draw (replayed from its seed by oracle/gen_golden.py, which
+    asserts that the replay reproduces the layer's routing): top-1 indices bit-exact, y, l_aux, input / gate-input / router gradients and
+    the gradients of l_aux alone; an evaluation forward adds no noise."""
+    g = np.load(os.path.join(G, "moe_layer_noise_m256e8.npz"))
+    seed, P, gn = int(g["seed"]), int(g["P"]), float(g["gate_noise"])
+    from switch_nerf_amd.moe import moe_layer
+    cfg = synth.BUILDING
+    moe = moe_layer(gate_type=dict(type="top", k=1, fp32_gate=True, capacity_factor=1.0, batch_prioritized_routing=True, gate_noise=gn,
+                                   gate_dim=cfg["gate_hidden"]), model_dim=cfg["model_dim"],
+                    experts=dict(type="expertmlp", count_per_node=cfg["num_experts"], hidden_size_per_expert=cfg["model_dim"],
+                                 layer_num=cfg["expert_layers"], skips=list(cfg["skips"])), seeds=(1, 1, 1), return_gates=True,
+                    dtype=torch.float32).cuda()
+    _load(moe, seed)
+    moe.train()
+    rng = np.random.default_rng(seed + 1000)
+    x = rng.standard_normal((P, 256)).astype(np.float32)
+    gi = rng.standard_normal((P, 256)).astype(np.float32)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    gt = torch.from_numpy(gi).cuda().requires_grad_(True)
+    y = moe(xt, gate_input=gt, gate_noise_draw=torch.from_numpy(g["noise"]))
+    np.testing.assert_array_equal(y.gate_extras["gates"].cpu().numpy().reshape(-1), g["topk"].reshape(-1))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["y"], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(y.l_aux.item(), float(g["l_aux"]), rtol=1e-6)
+    dy = rng.standard_normal((P, 256)).astype(np.float32)
+    (y * torch.from_numpy(dy).cuda()).sum().backward(retain_graph=True)
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), g["dx"], rtol=1e-3, atol=2e-4 * np.abs(g["dx"]).max())
+    np.testing.assert_allclose(gt.grad.cpu().numpy(), g["dgate_input"], rtol=1e-3, atol=2e-4 * np.abs(g["dgate_input"]).max())
+    np.testing.assert_allclose(moe.gates[0].wg.weight.grad.cpu().numpy(), g["dwg"], rtol=1e-3, atol=5e-4 * np.abs(g["dwg"]).max())
+    d_g, d_wg = torch.autograd.grad(y.l_aux, [gt, moe.gates[0].wg.weight])
+    np.testing.assert_allclose(d_g.cpu().numpy(), g["laux_dgate_input"], rtol=1e-3, atol=2e-4 * np.abs(g["laux_dgate_input"]).max())
+    np.testing.assert_allclose(d_wg.cpu().numpy(), g["laux_dwg"], rtol=1e-3, atol=2e-4 * np.abs(g["laux_dwg"]).max())
+    # evaluation: no noise (self.training is False) - the routing of the noise-free layer; a second training forward draws its own noise
+    moe.eval()
+    with torch.no_grad():
+        ye = moe(xt, gate_input=gt)
+    assert (ye.gate_extras["gates"].cpu().numpy().reshape(-1) != g["topk"].reshape(-1)).any()
+    moe.train()
+    with torch.no_grad():
+        a, b = moe(xt, gate_input=gt), moe(xt, gate_input=gt)
+    assert (a.gate_extras["gates"] != b.gate_extras["gates"]).any()                 # two draws, two routings
+    with pytest.raises(NotImplementedError):
+        moe_layer(gate_type=dict(type="top", k=1, use_load_importance_loss=True), model_dim=256,
+                  experts=dict(type="expertmlp", count_per_node=8, layer_num=7))
