@@ -138,6 +138,9 @@ def main():
                     help="balanced: the MAIN measurement runs with point i -> expert i mod E (used by the counter passes: bytes per kept row)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--loopback", action="store_true", help="--gpus 1 only: run the MULTI-GPU step on one GPU - a world-1 RCCL process "
+                    "group, every collective of the N > 1 path issued for real (gradient all-reduce in two parts around the second "
+                    "backward graph, the expert-parallel all-to-alls with their split sizes on the side stream); not the headline")
     ap.add_argument("--no-ep-probe", action="store_true",
                     help="N > 1, data parallel: skip the expert-parallel measurement that otherwise follows the headline in the same line")
     ap.add_argument("--ep-probe-limit", type=float, default=180.0,
@@ -153,17 +156,20 @@ def main():
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch {a.gpus} ranks (or drop WORLD_SIZE and let bench.py launch them)")
     if local >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: rank {rank} wants device {local} but only {torch.cuda.device_count()} are visible")
-    scaling = a.scaling or ("strong" if world > 1 else "weak")
+    scaling = a.scaling or "strong"      # (the metric splits ONE global batch over the ranks, runner.py:575; N = 1: the same thing either way)
+    if a.loopback and world != 1:
+        raise SystemExit("bench.py: --loopback is the one-GPU rehearsal of the multi-GPU step (--gpus 1)")
+    multi = world > 1 or a.loopback      # the step issues collectives
     if scaling == "strong" and a.rays % world:
         raise SystemExit(f"bench.py: --rays {a.rays} is not divisible by {world} ranks")
     n_rays = a.rays // world if scaling == "strong" else a.rays          # rays of THIS rank per step
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         from switch_nerf_amd import parallel
-        parallel.init_from_env(os.environ.get("SWN_DIST_BACKEND", "nccl"), dev)       # "nccl" = RCCL; gloo only for single-GPU tests of this path
+        parallel.init_from_env(os.environ.get("SWN_DIST_BACKEND", "nccl"), dev, loopback=a.loopback)       # "nccl" = RCCL; gloo only for single-GPU tests of this path
 
     from switch_nerf_amd import _lib
     from switch_nerf_amd.model import SwitchNeRF, BUILDING
@@ -188,11 +194,12 @@ def main():
     P = n_rays * a.samples
     a.chunk = min(a.chunk, P)
 
-    if world > 1:
-        allreduce = parallel.make_grad_allreduce()     # RCCL all-reduce over xGMI, one 16 MB bucket
+    if multi:
+        allreduce = parallel.make_grad_allreduce(loopback=a.loopback)     # RCCL all-reduce over xGMI, one 16 MB bucket
     if a.parallelism == "ep":
         from switch_nerf_amd.parallel import ExpertParallel
-        model.set_expert_parallel(ExpertParallel(rank, world, model.E, padded={"off": False, "on": True, "auto": "auto"}[a.ep_padded]))
+        model.set_expert_parallel(ExpertParallel(rank, world, model.E, padded={"off": False, "on": True, "auto": "auto"}[a.ep_padded],
+                                                 loopback=a.loopback))
 
     radii = torch.full((n_rays, 1), 1e-3, device=dev)
     scene = None
@@ -217,6 +224,7 @@ def main():
     graphed = [None]
     if use_graph:
         from switch_nerf_amd.graph import GraphedTrainStep
+    split_bwd = False if a.no_split_backward else (True if a.loopback else None)      # (None: two backward graphs when N > 1)
 
     def step():
         if a.eval:       # render_rays in eval mode (runner.py:2835-2885 render_image's inner call): forward only
@@ -230,7 +238,7 @@ def main():
                 c = model.forward_rays(rays, idx, a.samples, a.chunk, 0.0, None, None, training=False)
             return dict(ctx=c, loss=c["rgb"].sum() * 0)
         pr = torch.rand(n_rays, a.samples, device=dev)              # rendering.py:582 rand_like
-        ar = allreduce if world > 1 else None
+        ar = allreduce if multi else None
         if a.mip:      # rendering_mip recipe: a.samples edges -> a.samples - 1 frustums per level, coarse + fine level
             nf = n_rays * (a.samples - 1)
             return model.train_step_mip(rgbs, rays, radii, idx, a.samples, a.samples, a.chunk, perturb=1.0, perturb_rand=pr,
@@ -322,7 +330,7 @@ def main():
             out_[name] = best
         kept_ = int(torch.minimum(c_["counts"], torch.tensor(c_["cap"], device=dev)).sum().item())
         fused_tail[0] = bool(c_.get("tail_fused"))
-        fused_tail[1] = fused_tail[0] and os.environ.get("SWN_FUSED_TAIL_BWD", "1") != "0"
+        fused_tail[1] = fused_tail[0] and bool(model.sw["fused_tail_bwd"])
         return out_, kept_
 
     if a.routing == "balanced":
@@ -330,7 +338,7 @@ def main():
     reset_state(4321)
     if use_graph:
         graphed[0] = GraphedTrainStep(model, rgbs, rays, idx, a.samples, a.chunk, perturb=1.0, noise_std=1.0,
-                                      routing_override=route_override[0], split_backward=False if a.no_split_backward else None)
+                                      routing_override=route_override[0], split_backward=split_bwd)
     for _ in range(a.warmup):
         st = step()
     reset_state(1234)
@@ -653,10 +661,9 @@ def main():
 
     # ---- data parallel: the gradient all-reduce - its time and how much of it ran under the second backward graph
     ar_info = None
-    if world > 1 and a.parallelism == "dp" and hasattr(allreduce, "report"):
+    if multi and a.parallelism == "dp" and hasattr(allreduce, "report"):
         if use_graph and graphed[0] is None:
-            graphed[0] = GraphedTrainStep(model, rgbs, rays, idx, a.samples, a.chunk, perturb=1.0, noise_std=1.0,
-                                          split_backward=False if a.no_split_backward else None)
+            graphed[0] = GraphedTrainStep(model, rgbs, rays, idx, a.samples, a.chunk, perturb=1.0, noise_std=1.0, split_backward=split_bwd)
         allreduce.profile = True
         allreduce.report()
         psteps = 5
@@ -693,7 +700,7 @@ def main():
                                + (f", model_dim {a.model_dim}, {a.experts} experts" if (a.model_dim != 256 or a.experts != 8) else ""),
                    "global_batch_rays": gb, "rays_per_gpu": n_rays, "samples": a.samples, "segment_points": a.chunk,
                    "kernel_set": None if a.dense else model.kernel_set(), "csrc_sha256": csrc_sha,
-                   "parallelism": f"{a.parallelism}{world}", "balanced_value": None if balanced is None else balanced["value"],
+                   "parallelism": f"{a.parallelism}{world}" + ("-loopback" if a.loopback else ""), "balanced_value": None if balanced is None else balanced["value"],
                    "kept_token_fraction": round(kept / P, 4), "kept_token_fraction_mean": round(kept_mean / P, 4), "loss": round(loss_main, 6), "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 3),
                    "runner_loop_ms_per_step": None if runner_ms is None else round(runner_ms, 3),
                    "timed_region": ((("forward + backward replayed from a hipGraph, all-reduce + Adam eager" if use_graph else "eager launches")
@@ -714,7 +721,7 @@ def main():
     #      same line (north_star: RCCL all-to-all over xGMI in place of Tutel's; BASELINE configs[2]) - experts sharded E / N per GPU, kept
     #      rows exchanged per routing segment on a side stream, eager launches (the kept-rows mode reads split sizes on the host).
     #      A watchdog prints the line without it if a collective never returns: the headline must not depend on the probe.
-    if world > 1 and a.parallelism == "dp" and plain and not other and not a.no_ep_probe and model.E % world == 0:
+    if multi and a.parallelism == "dp" and plain and not other and not a.no_ep_probe and model.E % world == 0:
         import threading
 
         probe_done = threading.Event()
@@ -733,7 +740,7 @@ def main():
         try:
             from switch_nerf_amd.parallel import ExpertParallel
             graphed[0] = None
-            model.set_expert_parallel(ExpertParallel(rank, world, model.E, padded=False))
+            model.set_expert_parallel(ExpertParallel(rank, world, model.E, padded=False, loopback=a.loopback))
             reset_state(4321)
             for _ in range(3):
                 step()
@@ -749,7 +756,7 @@ def main():
         probe_done.set()
         dog.cancel()
     if rank == 0:
-        if world == 1 and not a.no_cpu_baseline and not other:
+        if world == 1 and not a.no_cpu_baseline and not other and not a.loopback:
             try:
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:      # the baseline must never take the bench line down

@@ -112,18 +112,13 @@ int swn_route_top1(const int32_t* idx, const float* gmax, const float* gates,
                    int32_t* loc, int32_t* counts, int32_t* perm, int32_t* tok2row, float* l_aux,
                    void* workspace, size_t workspace_bytes, void* stream);
 
-/* The same routing with fused phases, plus the list of dropped tokens (swn_route_dropped's outputs: both NULL or both given) from the
- * same call.  Replaces the same reference code as swn_route_top1 (tutel_fast_dispatch.py:136-217) - every output is identical to
- * swn_route_top1 + swn_route_dropped (the tile bodies are the same code, l_aux is added in the same order).
- *   mode 0: the per-phase kernels of swn_route_top1 (+ swn_route_dropped): 20 launches;
- *   mode 1: route_one_kernel launched once per PHASE - keys + histogram + (last tile of a segment) counts and scan | scatter | histogram +
- *           scan | scatter | ... | locations, row spaces, dropped-token lists, l_aux: 9 launches with batch prioritisation, 3 without
- *           (no fill launches: the empty capacity slots of perm are written by the last phase) - measured no faster than mode 0;
- *   mode 2: the same phases in ONE launch of resident workgroups that meet at grid barriers - bit-identical, but SLOWER on this part
- *           (the XCDs' L2s are not coherent inside a kernel: profiles/r05_experiments.md 3).
- *   sync: int32 [swn_route_sync_bytes() / 4], ZERO before the first call and left zero by every call (the per-segment tickets of "the
- *         last tile scans"; mode 2: also the barrier); calls that may overlap (different streams) need different ones.  NULL, more than
- *         255 segments, or more than 2048 (segment, expert) groups with the dropped-token lists: mode 0.
+/* The routing plus the list of dropped tokens (swn_route_dropped's outputs: both NULL or both given) from ONE call.  Replaces the same
+ * reference code as swn_route_top1 (tutel_fast_dispatch.py:136-217) - every output is identical to swn_route_top1 + swn_route_dropped.
+ *   mode: 0 = the per-phase kernels of swn_route_top1 (+ swn_route_dropped): 20 launches - the only mode of the product library.
+ *         Modes 1 / 2 (fused phases / ONE launch with grid barriers: bit-identical, measured no faster / slower on this part - the XCDs'
+ *         L2s are not coherent inside a kernel, profiles/r05_experiments.md 3) exist in the experiment build only
+ *         (scripts/experiments/route_one.inc, build_route_one.sh); the product library rejects them.
+ *   sync: int32 [swn_route_sync_bytes() / 4] of the experimental modes (zero before the first call, left zero); ignored in mode 0, may be NULL.
  *   workspace: swn_route_workspace_bytes() as for swn_route_top1.                                                                    */
 size_t swn_route_sync_bytes(void);
 int swn_route_top1x(const int32_t* idx, const float* gmax, const float* gates,

@@ -193,6 +193,42 @@ def gen_moe_layer_noise():
          dgate_input=gt.grad.numpy(), dwg=gate.wg.weight.grad.numpy(), laux_dgate_input=gl[0].numpy(), laux_dwg=gl[1].numpy())
 
 
+def gen_moe_layer_normal_noise():
+    """use_normal_noise (tutel_moe_layer_nobatch.py:116-117: in training `logits + randn_like(logits) / E`, "Scaling Vision with Sparse
+    Mixture of Experts") TOGETHER with gate_noise (:119-122): the layer draws the normal noise first, the gate noise second - re-seeding
+    and drawing two [P, E] tensors replays both."""
+    print("[G3nn] moe_layer with use_normal_noise + gate noise (training mode)")
+    cfg, P, seed, gate_noise, rng_seed = synth.BUILDING, 512, 35, 0.5, 778
+    sd = synth.make_weights(seed, cfg)
+    nerf, h = build_reference_model(cfg, sd)
+    moe = nerf.layers["0"]
+    moe.train()
+    gate = moe.gates[0]
+    gate.gate_noise = gate_noise
+    gate.use_normal_noise = True
+    E = cfg["num_experts"]
+    rng = np.random.default_rng(seed + 1000)
+    x = rng.standard_normal((P, cfg["model_dim"])).astype(np.float32)
+    gi = rng.standard_normal((P, cfg["gate_hidden"])).astype(np.float32)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    gt = torch.from_numpy(gi).requires_grad_(True)
+    torch.manual_seed(rng_seed)
+    y = moe(xt, gate_input=gt)
+    torch.manual_seed(rng_seed)
+    n1 = torch.randn(P, E)
+    n2 = torch.randn(P, E)
+    logits = gt.detach() @ gate.wg.weight.detach().float().t()
+    top = torch.softmax((logits + n1 / E) + gate_noise * n2 / E, dim=1).argmax(1)
+    assert torch.equal(top, y.gate_extras["gates"].view(-1)), "noise replay does not reproduce the reference's routing"
+    assert not torch.equal(torch.softmax(logits + gate_noise * n2 / E, dim=1).argmax(1), top), "the normal noise must move some expert choices"
+    dy = rng.standard_normal(y.shape).astype(np.float32)
+    (y * torch.from_numpy(dy)).sum().backward(retain_graph=True)
+    gl = torch.autograd.grad(y.l_aux, [gt] + list(moe.gates.parameters()), allow_unused=True)
+    save("moe_layer_normal_noise_m256e8", seed=seed, P=P, gate_noise=gate_noise, normal_noise=n1.numpy(), noise=n2.numpy(), y=y.detach().numpy(),
+         l_aux=y.l_aux.detach().numpy(), topk=y.gate_extras["gates"].numpy().astype(np.int32), dx=xt.grad.numpy(),
+         dgate_input=gt.grad.numpy(), dwg=gate.wg.weight.grad.numpy(), laux_dgate_input=gl[0].numpy(), laux_dwg=gl[1].numpy())
+
+
 # ------------------------------------------------------------------------------------------ G4 model fwd
 def gen_model_forward():
     print("[G4] NeRFMoE.forward building shapes, P=4096")
@@ -601,7 +637,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    todo = dict(routing=gen_routing, pe=gen_pe, moe=gen_moe_layer, moe_noise=gen_moe_layer_noise, model=gen_model_forward, nobatch=gen_model_forward_nobatch, dispatch_nobatch=gen_dispatch_nobatch,
+    todo = dict(routing=gen_routing, pe=gen_pe, moe=gen_moe_layer, moe_noise=gen_moe_layer_noise, moe_normal_noise=gen_moe_layer_normal_noise, model=gen_model_forward, nobatch=gen_model_forward_nobatch, dispatch_nobatch=gen_dispatch_nobatch,
                 render=gen_render, autocast=gen_render_autocast, capacity=gen_render_capacity, fine=gen_render_fine, mip=gen_mip, ckpt=gen_checkpoint_layout, dense=gen_dense, composite=gen_composite, bg=gen_bg)
     for k, fn in todo.items():
         if a.only and k not in a.only.split(","):

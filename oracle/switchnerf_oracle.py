@@ -246,12 +246,16 @@ def expert_mlp(d: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequenc
 
 def moe_layer(h: torch.Tensor, gate_input: torch.Tensor, wg: torch.Tensor, weights, biases, skips,
               capacity_factor: float, batch_prioritized: bool, routing: Optional[dict] = None, no_batch: bool = False,
-              autocast: Optional[Autocast] = None, gate_noise: float = 0.0, noise: Optional[torch.Tensor] = None):
+              autocast: Optional[Autocast] = None, gate_noise: float = 0.0, noise: Optional[torch.Tensor] = None,
+              normal_noise: Optional[torch.Tensor] = None):
     """TopKGate.apply_on_expert_fn, tutel_moe_layer_nobatch.py:98-235 (k=1, fp32 gate, postscore).
     Returns (y [P,M], l_aux, routing dict, gates [P,E]).  `routing` may be injected (idx/loc numpy) to
-    decouple numerics tests from near-tie routing flips.  gate_noise / noise: the gate-noise branch of a training forward."""
+    decouple numerics tests from near-tie routing flips.  gate_noise / noise: the gate-noise branch of a training forward;
+    normal_noise: the use_normal_noise branch's draw (:116-117), added first."""
     E = wg.shape[0]
     logits = gate_input.float() @ wg.float().t()                               # :105-113
+    if normal_noise is not None:                                               # use_normal_noise and training (:116-117)
+        logits = logits + normal_noise / E
     if gate_noise > 0 and noise is not None:                                   # training, --gate_noise > 0 (:119-122): `noise` stands for
         logits = logits + gate_noise * noise / E                               # the layer's torch.randn_like(logits) draw
     gates = torch.softmax(logits, dim=1)                                       # :126

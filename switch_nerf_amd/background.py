@@ -35,9 +35,27 @@ class BackgroundScene:
         # ONE loss scaler over both models (the reference's single GradScaler over both optimizers, runner.py:483, 679-690): when either
         # model computes in fp16, both hold the SAME LossScaler object - one scale multiplies the loss gradient, both unscale by it, one
         # growth tracker is checkpointed whichever model's state_dict is asked (a 16-bit-float foreground beside an fp16 background included)
+        # This MUTATES both models (documented contract of a scene): a model that had no scaler gains one, the background's own
+        # scaler state is replaced by the foreground's.  Build the scene BEFORE capturing graphs on its models (a graph captured on a
+        # scaler-less model does not read the scale); detach() hands the models back their own scalers.
+        self._own_scalers = (nerf.loss_scaler, bg_nerf.loss_scaler)
         self.loss_scaler = nerf.loss_scaler if nerf.loss_scaler is not None else bg_nerf.loss_scaler
         if self.loss_scaler is not None:
+            for m in (nerf, bg_nerf):
+                if m.loss_scaler is not self.loss_scaler and getattr(m, "_train_graphs", None):
+                    raise RuntimeError("BackgroundScene: a model whose training graphs were captured before the scene was built would keep "
+                                       "running without the shared loss scale; build the scene first")
             nerf.loss_scaler = bg_nerf.loss_scaler = self.loss_scaler
+
+    def detach(self):
+        """Undo the scaler sharing: each model gets back the LossScaler (or None) it had before the scene was built; a model that owned
+        one continues from the shared scale."""
+        for m, own in zip((self.nerf, self.bg), self._own_scalers):
+            if own is not None and self.loss_scaler is not None and own is not self.loss_scaler:
+                own.load_state_dict(self.loss_scaler.state_dict())
+            m.loss_scaler = own
+            if own is None:
+                m._ls_dev = None
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, rays, image_indices, n_samples, seg_tokens, perturb=0.0, perturb_rand=None, perturb_rand_bg=None,

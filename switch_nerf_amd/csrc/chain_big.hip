@@ -597,68 +597,15 @@ __global__ __launch_bounds__(G::NT, G::OCC) void chainb_kernel(const Args args) 
 // fragments are read TWO steps ahead (three register sets): the LDS round trip of a lone wave's reads (~300 clocks with four waves
 // reading at once) no longer fits into one 256-clock step.  `wq` holds the fragments of steps 0..2 on entry (issued by the caller before
 // the phase barrier) - on exit nothing is in flight.
-// -DSWN_KPRIO=n: s_setprio n for a wave of chainq_kernel in its K phase (measured: no change at 1 or 3, profiles/r04_experiments.md 12)
+// (Closed experiments, removed from the source in round 6: s_setprio for the K phase's wave - no change, r04_experiments.md 12; the K
+//  loop rolled to four steps per trip - 3-4 % slower, r04 24; row group 1 without its weight loads - the upper bound of any weight
+//  sharing scheme, r05 1.  `git show d737e95:switch_nerf_amd/csrc/chain_big.hip` has all three switches.)
 #ifndef SWN_WQ_DEPTH
 #define SWN_WQ_DEPTH 4            // weight-fragment register sets of a wave's K loop: SWN_WQ_DEPTH - 1 K steps in flight
 #endif
 constexpr int WQD = SWN_WQ_DEPTH, WQA = SWN_WQ_DEPTH - 1;
-#ifdef SWN_ROLLED_K
-// (experiment, NOT in the default build - profiles/r04_experiments.md 24: the same K loop rolled to four steps per trip + the last four
-//  peeled, the step count a run-time argument: the same loads, waits and MFMA order per accumulator; the same spill counts as the
-//  unrolled loop in every chainq instantiation, all chain tests bit-exact - and 3-4 % slower in the K-bound launches.  What it was
-//  for: ONE loop that can run a 128-feature first layer in 8 steps over unpadded weights - a second unrolled instantiation spilled
-//  96-122 registers, section 23 - but the half K phase that would save is about what the rolled loop costs.)
-template <typename E, int NS_UNUSED = KSTEPS>
-__device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, __amdgpu_buffer_rsrc_t rs_cur, u32x4_t (&wq)[WQD][2], int NS = KSTEPS) {
-  static_assert(WQD == 4, "rolled K loop: ring of 4");
-  constexpr int MI = 4;
-  char* smem = cx.smem;
-  const int lane16 = cx.lane * 16;
-  const int fg = cx.w & 3;
-  u32x4_t fa[4][MI];             // (four sets so that the set index is static in a body of 4 steps: ks % 4)
-  uint32_t a_base = cx.a_base;
-  asm volatile("" : "+v"(a_base));
-#define RD_A(ks_, set_, mi_) fa[set_][mi_] = *(const u32x4_t*)(smem + (a_base ^ (uint32_t)((ks_) << 5)) + (mi_) * (32 * ROWB))
-#define LD_W(ks_, set_) { _Pragma("unroll") for (int i = 0; i < 2; ++i) wq[set_][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, lane16, ((2 * fg + i) * NS + (ks_)) * 1024, 0); }
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) RD_A(0, 0, mi);
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) RD_A(1, 1, mi);
-#define SWN_MM(set_, mi, ni) acc[mi][ni] = E::mfma(wq[set_][ni], fa[set_][mi], acc[mi][ni])
-#define STEP(ks_, u_, W_VM, W_LGKM, HAS2, HAS3)                                        \
-  {                                                                                    \
-    W_VM; W_LGKM; SWN_PIN();                                                           \
-    SWN_MM(u_, 0, 0); SWN_PIN();                                                       \
-    if (HAS2) { RD_A((ks_) + 2, (u_ + 2) & 3, 0); RD_A((ks_) + 2, (u_ + 2) & 3, 1); }  \
-    SWN_PIN(); SWN_MM(u_, 0, 1); SWN_PIN();                                            \
-    if (HAS2) { RD_A((ks_) + 2, (u_ + 2) & 3, 2); RD_A((ks_) + 2, (u_ + 2) & 3, 3); }  \
-    SWN_PIN(); SWN_MM(u_, 1, 0); SWN_PIN();                                            \
-    if (HAS3) LD_W((ks_) + 3, (u_ + 3) & 3);                                           \
-    SWN_PIN(); SWN_MM(u_, 1, 1); SWN_PIN(); SWN_MM(u_, 2, 0); SWN_PIN(); SWN_MM(u_, 2, 1); SWN_PIN(); \
-    SWN_MM(u_, 3, 0); SWN_PIN(); SWN_MM(u_, 3, 1); SWN_PIN();                          \
-  }
-  int ks = 0;
-  for (; ks + 4 < NS; ks += 4) {       // steady state: four steps per trip, every wait the same
-    STEP(ks, 0, SWN_WAIT_VM(4), SWN_WAIT_LGKM(4), true, true)
-    STEP(ks + 1, 1, SWN_WAIT_VM(4), SWN_WAIT_LGKM(4), true, true)
-    STEP(ks + 2, 2, SWN_WAIT_VM(4), SWN_WAIT_LGKM(4), true, true)
-    STEP(ks + 3, 3, SWN_WAIT_VM(4), SWN_WAIT_LGKM(4), true, true)
-  }
-  // the last four steps
-  STEP(ks, 0, SWN_WAIT_VM(4), SWN_WAIT_LGKM(4), true, true)
-  STEP(ks + 1, 1, SWN_WAIT_VM(4), SWN_WAIT_LGKM(4), true, false)
-  STEP(ks + 2, 2, SWN_WAIT_VM(2), SWN_WAIT_LGKM(4), false, false)
-  STEP(ks + 3, 3, SWN_WAIT_VM(0), SWN_WAIT_LGKM(0), false, false)
-#undef STEP
-#undef SWN_MM
-#undef RD_A
-#undef LD_W
-}
-#else
 template <typename E, int NS = KSTEPS>
-__device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, __amdgpu_buffer_rsrc_t rs_cur, u32x4_t (&wq)[WQD][2], bool skip_w = false) {
-  // (skip_w: -DSWN_ABL_SHAREW only - the wave leaves its weight fragments as they are: what the chain would cost if row group 1 got
-  //  row group 0's weight stream for free, the upper bound of ANY weight-sharing scheme; results are wrong)
+__device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, __amdgpu_buffer_rsrc_t rs_cur, u32x4_t (&wq)[WQD][2]) {
   constexpr int MI = 4;           // NS = K steps of this layer (K / 16): 16, or 8 for a 128-feature chain input (geometries 6 / 7)
   char* smem = cx.smem;
   const int lane16 = cx.lane * 16;
@@ -692,7 +639,6 @@ __device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, _
 #define SWN_MM(mi, ni) asm volatile("" :: "v"(wq[ks % WQD][ni]), "v"(fa[ks % 3][mi]))
 #else
 #define SWN_MM(mi, ni) acc[mi][ni] = E::mfma(wq[ks % WQD][ni], fa[ks % 3][mi], acc[mi][ni])
-#endif
     SWN_MM(0, 0);
     SWN_PIN();
     if (ks + 2 < NS) { read_a(ks + 2, 0); read_a(ks + 2, 1); }
@@ -703,11 +649,7 @@ __device__ __forceinline__ void k_phase2(f32x16_t (&acc)[4][2], const Ctx& cx, _
     SWN_PIN();
     SWN_MM(1, 0);
     SWN_PIN();
-#ifdef SWN_ABL_SHAREW
-    if (ks + WQA < NS && !skip_w) load_w(ks + WQA);
-#else
     if (ks + WQA < NS) load_w(ks + WQA);    // into the register set of step ks - 1, whose MFMAs were issued a step ago
-#endif
     SWN_PIN();
     SWN_MM(1, 1);
     SWN_PIN();
@@ -1707,14 +1649,8 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     return uniform_rsrc((char*)base + t.grow0 * ROWB, t.rows * ROWB);
   };
   u32x4_t wq[WQD][2];
-#ifdef SWN_ABL_SHAREW
-  const bool skip_w = rg == 1 && TAG != 3 && TAG != 6;      // (the expert launches only: the front chains still route correctly)
-#else
-  constexpr bool skip_w = false;
-#endif
   auto preload_w = [&](int L, int wset, int lane_) {
     const __amdgpu_buffer_rsrc_t r = wrs(L, wset);
-    if (skip_w) return;
 #pragma unroll
     for (int ks = 0; ks < WQA; ++ks)
 #pragma unroll
@@ -1970,13 +1906,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         }
         {
           const Ctx ck = phase_ctx(true);
-#ifdef SWN_KPRIO
-          __builtin_amdgcn_s_setprio(SWN_KPRIO);      // the K phase's wave ahead of its SIMD partner (in an E or S phase: VALU, LDS, stores)
-#endif
-          k_phase2<E>(acc, ck, rs_cur, wq, skip_w);
-#ifdef SWN_KPRIO
-          __builtin_amdgcn_s_setprio(0);
-#endif
+          k_phase2<E>(acc, ck, rs_cur, wq);
         }
 #pragma unroll
         for (int q_ = 0; q_ < WQD; ++q_)
@@ -1994,9 +1924,12 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         const int lane16e = ce.lane * 16;
         uint32_t* mkp = ly.mask ? ly.mask + ((size_t)(cur.vb * G::NW + ce.w) * 64 + ce.lane) * 4 : nullptr;
         // The partner's rows = the input tile of the K loop it is running (same tile: the groups are one phase apart) -> their save
-        // tensor: 16 pieces in 8 batches of 2 through TWO alternating register sets.  Batch 0 is stored in front of the epilogue, batch
-        // h + 1 behind its half row tile h (h < 7); the LDS reads that refill a set are issued a half step after ITS stores, behind the
-        // statement that keeps it allocated (SWN_KEEP) - hundreds of clocks - and the last batch is stored a half step before the phase ends.
+        // tensor: 16 pieces in 8 batches of 2 through TWO alternating register sets.  Batch 0 is READ at the top of the phase and stored
+        // behind the first half row tile (its LDS round trip runs under that half tile - storing it in front of the epilogue, as round 5
+        // did, put the round trip on the critical path of all 19 phases of a tile: +2-3 % on the two fused launches, same-box A/B in
+        // profiles/r06_experiments.md 1); batch h is stored behind half row tile h.  The LDS reads that refill a set are issued a half
+        // step after ITS stores, behind the statement that keeps it allocated (SWN_KEEP) - hundreds of clocks; the last batch's set stays
+        // allocated past the end of the epilogue (`held` below).
         void* wo = rge == 0 ? (L > cur.l0 ? d.layers[L - 1].save : nullptr) : (!last ? ly.save : nullptr);
         // fused tail: the saves from the gate layer on go to TOKEN order; the gate layer and the last layer have their own epilogues
         const bool wo_tok = (TAIL && (rge == 0 ? L - 1 : L) >= d.tail_first - 1) || (HEAD && (rge == 0 ? L - 1 : L) < d.head_layers - 1);
@@ -2053,16 +1986,13 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
               }
             }
           };
-          st(0);                                   // (read at the top of the phase)
-          rd(1);
-          SWN_PIN();
           auto hook_f = [&](int h) {
-            // the set stored a half step ago (batch h) stays ALLOCATED up to here (an empty statement that reads it): a value is dead
-            // behind its store, and the compiler would hand its registers to the very next epilogue temporaries - the VALU write two
-            // instructions behind the store that the hazard is about.  The next write to them is the refill below.
-            asm volatile("" :: "v"(wv[h & 1][0]), "v"(wv[h & 1][1]));
-            if (h < 7) st(h + 1);                  // (from the OTHER set: read a half step ago)
-            if (h < 6) rd(h + 2);
+            // the set stored a half step ago (batch h - 1) stays ALLOCATED up to here (an empty statement that reads it): a value is
+            // dead behind its store, and the compiler would hand its registers to the very next epilogue temporaries.  The next write
+            // to them is the refill below.
+            asm volatile("" :: "v"(wv[(h + 1) & 1][0]), "v"(wv[(h + 1) & 1][1]));
+            st(h);                                 // (read a half step ago; batch 0 at the top of the phase)
+            if (h < 7) rd(h + 1);                  // (into the OTHER set)
             SWN_PIN();
           };
           const HalfHook<decltype(hook_f)> hook{hook_f};
@@ -2073,6 +2003,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         }
         if (ly.relu == 1 && mkp) *(u32x4_t*)mkp = mk;
         SWN_PIN();
+        bool held = false;                         // (the last batch's store operands stay allocated past the end of the epilogue)
         if constexpr (HEAD) {
           if (L + 1 == d.head_layers && cur.l1 == n_layers) {
             // ---- the combine backward on this row group's rows, in place (see comb_pieces16_inplace): the four waves have written the
@@ -2085,6 +2016,8 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
             while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&gcount[rge], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < 4 * n_skip)
               __builtin_amdgcn_s_sleep(2);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (wo) asm volatile("" :: "v"(wv[1][0]), "v"(wv[1][1]));      // (behind the four waves' meeting: hundreds of clocks)
+            held = true;
             comb_pieces16_inplace<E>(ce, 64 * rge + fge, d, idx_cur, cur.rows,
                                      d.comb_dwsig_ws ? d.comb_dwsig_ws + ((long)cur.vb * 8 + ce.w) * 256 : nullptr);
           }
@@ -2096,6 +2029,10 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
           const int lt = fg * 64 + fresh_lane();
           if (lt < 128) ((int*)(smem + ((it & 1) ? Q_YIDX + 1024 : Q_YIDX)))[128 * rg + lt] = yrow;
         }
+        SWN_PIN();
+        // the set stored behind the LAST half row tile: allocated up to here - behind the mask store and the next K loop's six fragment
+        // loads, vector memory instructions that issue in order behind its stores
+        if (wo && !held) asm volatile("" :: "v"(wv[1][0]), "v"(wv[1][1]));
         SWN_PIN();
         SWN_TM(const long long e1 = TICK();)
         if (last) {                                // (behind the other layers the boundary is the one at the top of the next layer)

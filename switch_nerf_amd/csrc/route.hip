@@ -314,374 +314,10 @@ __global__ __launch_bounds__(256) void laux_final_kernel(const float* __restrict
 }
 
 
-// =================================================================================================================================
-// The whole routing in ONE launch (swn_route_top1x; VERDICT round 4, missing 5).
-//
-// The multi-launch form above is 20 launches per call (2 fills, keys, 4 x (histogram, scan, scatter), finalize, 2 for l_aux, 2 for the
-// dropped-token lists): 0.27 ms at 2M tokens for ~200 MB of traffic, 0.13 ms of the 2.16 ms step at 1024 rays per GPU - launch gaps and
-// tails, not bytes.  Here a grid of resident 256-thread workgroups (at most two per CU: always co-resident) walks the SAME tiles through the
-// SAME phases - the tile bodies are the per-phase kernels' code, so every integer output is identical by construction and l_aux is added
-// in the same order - and meets at a grid barrier between the phases:
-//     A   per tile: keys / values, the tile's expert histogram, its digit histogram of pass 0, its l_aux partial sums;
-//         the LAST tile of a segment to arrive (a per-segment ticket) adds up the segment's counts and scans its histogram
-//     B   scatter pass 0
-//     B   per pass q = 1 .. n_pass - 1:  histogram (+ scan by the last tile of the segment)   B   scatter   B
-//     F   per tile: loc / perm / tok2row and the list of dropped tokens from the sorted order; empty capacity slots of perm = -1 (no
-//         fill launch); l_aux per segment
-// 8 grid barriers with batch-prioritised routing (4 passes of 8 bits), 2 without.  A barrier is a wait for the wave's own stores, one
-// agent-scope atomic add and a spin on it by one lane per workgroup; the data that crosses it is coherent by itself (ldc / stc below).  `sync`: int32 [SYNC_WORDS],
-// zero before the first launch, left zero by every launch (the last workgroup out resets it), one per stream that may run a routing
-// (ops.route_sync()).
-// =================================================================================================================================
-constexpr int ROUTE_SYNC_WORDS = 1024;      // [0] barrier arrivals, [1] workgroups that left, [2 + pass * n_seg + seg] tiles of (pass, segment) done
-constexpr int ROUTE_ONE_MAX_GROUPS = 2048;  // (segment, expert) groups whose dropped-token prefix fits the workgroup's LDS table
-
-struct RouteOne {
-  const int32_t* idx; const float* gmax; const float* gates;
-  int n_tokens, seg_tokens, E, capacity, bpr, n_seg, nblk, n_pass, shift0;
-  int32_t* loc; int32_t* counts; int32_t* perm; int32_t* tok2row; float* l_aux; int32_t* drop_begin; int32_t* dropped;
-  uint32_t* k0; uint32_t* k1; int32_t* v0; int32_t* v1; int32_t* hist; int32_t* ehist; float* partial; int32_t* sync;
-  int ph_lo, ph_hi;        // the phases this launch runs (0 = A, 2 q = histogram of pass q >= 1, 2 q + 1 = scatter of pass q, 2 n_pass = F)
-  int kv_plain;            // keys / values with plain loads and stores: every scatter and its readers are in different launches
-};
-
-// Everything one workgroup writes for another to read in a later phase (keys / values, histograms, counts, l_aux partial sums) moves
-// through RELAXED AGENT-SCOPE ATOMIC loads and stores (`sc1`: written through to, and read from, the memory side - the eight XCDs' L2s
-// are not coherent with each other for plain accesses inside a kernel).  A first version used plain accesses and agent-scope release /
-// acquire fences at the barriers: every fence wrote back / invalidated a whole L2 (buffer_wbl2 / buffer_inv sc1, four waves of 512
-// workgroups at each of 8 barriers) - 246 us per call at 1024 rays and 1.2 ms at full size against 0.13 / 0.27 ms of the 20 launches
-// (profiles/r05_experiments.md 3).  With the data itself coherent a barrier is a wait for the wave's own stores, one atomic add and a spin.
-__device__ __forceinline__ uint32_t ldc(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int32_t ldc(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ldc(const float* p) { return __uint_as_float(__hip_atomic_load((const uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-__device__ __forceinline__ void stc(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void stc(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void stc(float* p, float v) { __hip_atomic_store((uint32_t*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-__device__ __forceinline__ void route_grid_barrier(int32_t* ctr, int& epoch) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have reached the memory side
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    ++epoch;
-    __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int target = epoch * (int)gridDim.x;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-  }
-  __syncthreads();
-}
-
-// the exclusive scan of one segment's tile histograms in (digit, tile) order: route_scan_kernel's body for 256 bins on 256 threads
-template <int NB>
-__device__ __forceinline__ void route_scan_seg(int32_t* __restrict__ hist, int seg, int nblk, int32_t* rowsum /* LDS [4] */) {
-  constexpr int BINS = 256;
-  const int d = threadIdx.x;
-  int32_t* row = hist + (long)seg * nblk * BINS + d;
-  int32_t s = 0;
-  int32_t c[NB > 0 ? NB : 1];
-  if constexpr (NB > 0) {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) c[b] = b < nblk ? ldc(row + (long)b * BINS) : 0;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) s += c[b];
-  } else {
-    for (int b = 0; b < nblk; ++b) s += ldc(row + (long)b * BINS);
-  }
-  int32_t v = s;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int32_t t = __shfl_up(v, o, 64);
-    if ((d & 63) >= o) v += t;
-  }
-  __syncthreads();                                     // (rowsum may still be read by the previous use)
-  if ((d & 63) == 63) rowsum[d >> 6] = v;
-  __syncthreads();
-  for (int w = 0; w < (d >> 6); ++w) v += rowsum[w];
-  int32_t run = v - s;
-  if constexpr (NB > 0) {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      if (b < nblk) stc(row + (long)b * BINS, run);
-      run += c[b];
-    }
-  } else {
-    for (int b = 0; b < nblk; ++b) {
-      const int32_t cc = ldc(row + (long)b * BINS);
-      stc(row + (long)b * BINS, run);
-      run += cc;
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void route_one_kernel(const RouteOne a) {
-  constexpr int BITS = 8, BINS = 256;
-  __shared__ int32_t h[BINS];             // a tile's digit histogram
-  __shared__ int32_t wh[4][BINS];         // scatter: per-wave digit counts / bases
-  __shared__ int32_t eh[64];              // a tile's expert histogram
-  __shared__ float red[256];              // l_aux partial sums
-  __shared__ int32_t rowsum[4];
-  __shared__ int32_t flag;
-  __shared__ int32_t dbeg[ROUTE_ONE_MAX_GROUPS + 1];      // F: dropped tokens of the groups before g
-  __shared__ int32_t gstart[65];                          // F: first sorted position of every expert of the tile's segment
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int E = a.E, nblk = a.nblk, n_seg = a.n_seg, seg_tokens = a.seg_tokens;
-  const int n_tiles = n_seg * nblk;
-  int epoch = 0;
-  int32_t* bar = a.sync;
-  int32_t* arrive = a.sync + 2;
-  auto runs = [&](int ph) { return ph >= a.ph_lo && ph <= a.ph_hi; };
-  auto after = [&](int ph) { if (runs(ph) && ph < a.ph_hi) route_grid_barrier(bar, epoch); };      // (a launch boundary is the barrier otherwise)
-  auto ldk = [&](const uint32_t* p) { return a.kv_plain ? *p : ldc(p); };
-  auto ldv = [&](const int32_t* p) { return a.kv_plain ? *p : ldc(p); };
-  auto stk = [&](uint32_t* p, uint32_t v) { if (a.kv_plain) *p = v; else stc(p, v); };
-  auto stv = [&](int32_t* p, int32_t v) { if (a.kv_plain) *p = v; else stc(p, v); };
-
-  // the last tile of (pass, segment) to finish: adds up the counts (pass 0) and scans the segment's histogram
-  auto tile_done = [&](int pass, int seg) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      const int old = __hip_atomic_fetch_add(arrive + pass * n_seg + seg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      flag = old == nblk - 1;
-    }
-    __syncthreads();
-    if (!flag) return;
-    if (pass == 0 && tid < E) {
-      int32_t c = 0;
-      for (int b = 0; b < nblk; ++b) c += ldc(a.ehist + ((long)seg * nblk + b) * E + tid);
-      stc(a.counts + seg * E + tid, c);
-    }
-    if (nblk <= 16) route_scan_seg<16>(a.hist, seg, nblk, rowsum);
-    else if (nblk <= 64) route_scan_seg<64>(a.hist, seg, nblk, rowsum);
-    else route_scan_seg<0>(a.hist, seg, nblk, rowsum);
-  };
-
-  // ================= phase A: keys, values, expert / digit histograms, l_aux partial sums =================
-  for (int t = blockIdx.x; t < (runs(0) ? n_tiles : 0); t += gridDim.x) {
-    const int seg = t / nblk, blk = t - seg * nblk;
-    const long sbase = (long)seg * seg_tokens;
-    for (int d = tid; d < BINS; d += 256) h[d] = 0;
-    if (tid < 64) eh[tid] = 0;
-    __syncthreads();
-    for (int j = 0; j < KPB / 256; ++j) {
-      const int p = blk * KPB + j * 256 + tid;
-      int e = -1;
-      uint32_t key = 0;
-      if (p < seg_tokens) {
-        const long i = sbase + p;
-        e = a.idx[i];
-        uint32_t inv = 0;
-        if (a.bpr) {
-          const int32_t b = (int32_t)0x3F800000 - (int32_t)__float_as_uint(a.gmax[i]);
-          inv = b < 0 ? 0u : (b > 0x03FFFFFF ? 0x03FFFFFFu : (uint32_t)b);
-        }
-        key = ((uint32_t)e << 26) | inv;
-        stk(a.k0 + i, key);
-        stv(a.v0 + i, p);
-        atomicAdd(&h[(key >> a.shift0) & (BINS - 1)], 1);
-      }
-      for (int q = 0; q < E; ++q) {                    // one ballot per expert, one LDS add per wave and expert
-        const unsigned long long m = __ballot(e == q);
-        if (lane == 0 && m) atomicAdd(&eh[q], (int)__popcll(m));
-      }
-    }
-    __syncthreads();
-    for (int d = tid; d < BINS; d += 256) stc(a.hist + ((long)seg * nblk + blk) * BINS + d, h[d]);
-    if (tid < E) stc(a.ehist + ((long)seg * nblk + blk) * E + tid, eh[tid]);
-    if (a.gates && a.l_aux) {                          // laux_partial_kernel's body (same tile, same order of additions)
-      const float* gp = a.gates + sbase * E;
-      const int e = tid % E, t0 = tid / E, tstep = 256 / E;
-      float s = 0.f;
-      const int pbeg = blk * KPB, pend = min(seg_tokens, pbeg + KPB);
-      int p = pbeg + t0;
-      for (; p + 7 * tstep < pend; p += 8 * tstep) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = gp[(long)(p + u * tstep) * E + e];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
-      }
-      for (; p < pend; p += tstep) s += gp[(long)p * E + e];
-      red[tid] = s;
-      __syncthreads();
-      if (tid < E) {
-        float acc = 0.f;
-        for (int q = tid; q < 256; q += E) acc += red[q];
-        stc(a.partial + ((long)seg * nblk + blk) * E + tid, acc);
-      }
-    }
-    tile_done(0, seg);
-  }
-  after(0);
-
-  // ================= the passes =================
-  const uint32_t* ki = a.k0;
-  const int32_t* vi = a.v0;
-  uint32_t* ko = a.k1;
-  int32_t* vo = a.v1;
-  int shift = a.shift0;
-  for (int pass = 0; pass < a.n_pass; ++pass) {
-    if (pass > 0) {      // histogram of this pass's digit in the order the previous pass left (route_hist_kernel's body)
-      for (int t = blockIdx.x; t < (runs(2 * pass) ? n_tiles : 0); t += gridDim.x) {
-        const int seg = t / nblk, blk = t - seg * nblk;
-        for (int d = tid; d < BINS; d += 256) h[d] = 0;
-        __syncthreads();
-        const uint32_t* k = ki + (long)seg * seg_tokens;
-        for (int j = 0; j < KPB / 256; ++j) {
-          const int p = blk * KPB + j * 256 + tid;
-          if (p < seg_tokens) atomicAdd(&h[(ldk(k + p) >> shift) & (BINS - 1)], 1);
-        }
-        __syncthreads();
-        for (int d = tid; d < BINS; d += 256) stc(a.hist + ((long)seg * nblk + blk) * BINS + d, h[d]);
-        tile_done(pass, seg);
-      }
-      after(2 * pass);
-    }
-    // stable scatter (route_scatter_kernel's body)
-    for (int t = blockIdx.x; t < (runs(2 * pass + 1) ? n_tiles : 0); t += gridDim.x) {
-      const int seg = t / nblk, blk = t - seg * nblk;
-      const long sbase = (long)seg * seg_tokens;
-      __syncthreads();
-      for (int j = tid; j < 4 * BINS; j += 256) (&wh[0][0])[j] = 0;
-      __syncthreads();
-      const int p0 = blk * KPB + w * (KPB / 4);
-      for (int r = 0; r < KPB / 4 / 64; ++r) {
-        const int p = p0 + r * 64 + lane;
-        const bool valid = p < seg_tokens;
-        const int d = valid ? (int)((ldk(ki + sbase + p) >> shift) & (BINS - 1)) : 0;
-        const unsigned long long m = match_digit<BITS>(d, valid);
-        if (valid && lane == __ffsll((long long)m) - 1) wh[w][d] += __popcll(m);
-      }
-      __syncthreads();
-      for (int d = tid; d < BINS; d += 256) {
-        int32_t base = ldc(a.hist + ((long)seg * nblk + blk) * BINS + d);
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
-          const int32_t c = wh[ww][d];
-          wh[ww][d] = base;
-          base += c;
-        }
-      }
-      __syncthreads();
-      for (int r = 0; r < KPB / 4 / 64; ++r) {
-        const int p = p0 + r * 64 + lane;
-        const bool valid = p < seg_tokens;
-        uint32_t key = 0;
-        int32_t val = 0;
-        if (valid) { key = ldk(ki + sbase + p); val = ldv(vi + sbase + p); }
-        const int d = (int)((key >> shift) & (BINS - 1));
-        const unsigned long long m = match_digit<BITS>(d, valid);
-        if (valid) {
-          const int rank = __popcll(m & ((1ull << lane) - 1ull));
-          const int32_t pos = wh[w][d] + rank;
-          stk(ko + sbase + pos, key);
-          stv(vo + sbase + pos, val);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (valid && lane == __ffsll((long long)m) - 1) wh[w][d] += __popcll(m);
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-    after(2 * pass + 1);
-    shift += BITS;
-    const uint32_t* tk = ki; ki = ko; ko = (uint32_t*)tk;
-    const int32_t* tv = vi; vi = vo; vo = (int32_t*)tv;
-  }
-
-  // ================= phase F: locations, row spaces, dropped tokens, l_aux =================
-  if (!runs(2 * a.n_pass)) return;
-  const int n_groups = n_seg * E, cap = a.capacity;
-  if (a.drop_begin) {      // every workgroup: the prefix of the dropped-token counts over all groups (LDS; workgroup 0 also writes it out)
-    int32_t* part = wh[0];
-    const int per = (n_groups + 255) / 256;
-    const int g0 = tid * per;
-    int run = 0;
-    for (int q = 0; q < per; ++q) {
-      const int g = g0 + q;
-      if (g < n_groups) run += max(ldc(a.counts + g) - cap, 0);
-    }
-    __syncthreads();
-    part[tid] = run;
-    __syncthreads();
-    int base = 0;
-    for (int t = 0; t < tid; ++t) base += part[t];
-    for (int q = 0; q < per; ++q) {
-      const int g = g0 + q;
-      if (g < n_groups) {
-        dbeg[g] = base;
-        base += max(ldc(a.counts + g) - cap, 0);
-      }
-    }
-    if (tid == 255) dbeg[n_groups] = base;
-    __syncthreads();
-    if (blockIdx.x == 0)
-      for (int g = tid; g <= n_groups; g += 256) a.drop_begin[g] = dbeg[g];
-  }
-  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const int seg = t / nblk, blk = t - seg * nblk;
-    const long sbase = (long)seg * seg_tokens;
-    __syncthreads();
-    if (tid == 0) {
-      int s_ = 0;
-      for (int q = 0; q < E; ++q) { gstart[q] = s_; s_ += ldc(a.counts + seg * E + q); }
-    }
-    __syncthreads();
-    for (int j = 0; j < KPB / 256; ++j) {
-      const int pos = blk * KPB + j * 256 + tid;
-      if (pos >= seg_tokens) continue;
-      const int e = (int)(ldk(ki + sbase + pos) >> 26);
-      const int l = pos - gstart[e];
-      const long tok = sbase + ldv(vi + sbase + pos);
-      a.loc[tok] = l;
-      const long row = ((long)seg * E + e) * cap + l;
-      if (l < cap) {
-        if (a.perm) a.perm[row] = (int32_t)tok;
-        if (a.tok2row) a.tok2row[tok] = (int32_t)row;
-      } else {
-        if (a.tok2row) a.tok2row[tok] = -1;
-        if (a.dropped) a.dropped[dbeg[seg * E + e] + (l - cap)] = (int32_t)tok;
-      }
-    }
-  }
-  if (a.perm) {            // the capacity slots no token took: -1 (the multi-launch form fills the whole tensor first)
-    const long rows = (long)n_groups * cap;
-    for (long r = (long)blockIdx.x * 256 + tid; r < rows; r += (long)gridDim.x * 256) {
-      const int g = (int)(r / cap);
-      const int l = (int)(r - (long)g * cap);
-      if (l >= ldc(a.counts + g)) a.perm[r] = -1;
-    }
-  }
-  if (a.gates && a.l_aux) {      // laux_final_kernel's body, one workgroup per segment
-    for (int seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
-      const int e = tid % E, sub = tid / E, nsub = 256 / E;
-      float me = 0.f;
-      for (int b = sub; b < nblk; b += nsub) me += ldc(a.partial + ((long)seg * nblk + b) * E + e);
-      __syncthreads();
-      red[tid] = me;
-      __syncthreads();
-      if (tid < E) {
-        float acc = 0.f;
-        for (int q = 0; q < nsub; ++q) acc += red[q * E + tid];
-        red[tid] = acc * (float)ldc(a.counts + seg * E + tid);
-      }
-      __syncthreads();
-      if (tid == 0) {
-        float tot = 0.f;
-        for (int q = 0; q < E; ++q) tot += red[q];
-        const float scale = (float)((double)E / ((double)seg_tokens * (double)seg_tokens));
-        a.l_aux[seg] = tot * scale;
-      }
-    }
-  }
-  // ---- leave the synchronisation words at zero for the next launch: the last workgroup out (everyone has passed every barrier) ----
-  __syncthreads();
-  if (tid == 0) {
-    const int old = __hip_atomic_fetch_add(a.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old == (int)gridDim.x - 1) {
-      for (int i = 0; i < 2 + a.n_pass * n_seg; ++i) __hip_atomic_store(a.sync + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
+constexpr int ROUTE_SYNC_WORDS = 1024;      // (swn_route_sync_bytes: the synchronisation words of the experimental one-launch form)
+#ifdef SWN_EXP_ROUTE_ONE
+#include "../../scripts/experiments/route_one.inc"
+#endif
 }  // namespace swn
 
 using namespace swn;
@@ -697,16 +333,6 @@ extern "C" size_t swn_route_workspace_bytes(int n_tokens, int n_seg, int n_exper
 
 extern "C" size_t swn_route_sync_bytes(void) { return (size_t)ROUTE_SYNC_WORDS * 4; }
 
-static int route_compute_units() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    n = cus;
-  }
-  return n;
-}
-
 extern "C" int swn_route_top1x(const int32_t* idx, const float* gmax, const float* gates, int n_tokens, int seg_tokens,
                                int n_experts, int capacity, int bpr, int32_t* loc, int32_t* counts, int32_t* perm,
                                int32_t* tok2row, float* l_aux, int32_t* drop_begin, int32_t* dropped, int32_t* sync, int mode,
@@ -719,43 +345,20 @@ extern "C" int swn_route_top1x(const int32_t* idx, const float* gmax, const floa
   SWN_CHECK((drop_begin == nullptr) == (dropped == nullptr), "swn_route_top1x: drop_begin and dropped come together");
   const int n_seg = n_tokens / seg_tokens;
   SWN_CHECK(workspace_bytes >= swn_route_workspace_bytes(n_tokens, n_seg, n_experts), "swn_route_top1x: workspace too small");
-  // the one-launch form needs its synchronisation words, a ticket per (pass, segment) and - for the dropped-token lists - the group
-  // prefix in LDS; anything else takes the per-phase launches
+  // mode 0 = the per-phase kernels (swn_route_top1 + swn_route_dropped).  Modes 1 / 2 - the fused forms of round 5, measured slower - exist
+  // only in the experiment build (scripts/experiments/route_one.inc, -DSWN_EXP_ROUTE_ONE)
+#ifdef SWN_EXP_ROUTE_ONE
   SWN_CHECK(mode >= 0 && mode <= 2, "swn_route_top1x: mode %d (0 = per-phase kernels, 1 = fused phases, 2 = one launch)", mode);
-  const bool one = mode > 0 && sync != nullptr && 2 + 4 * n_seg <= ROUTE_SYNC_WORDS && (!drop_begin || n_seg * n_experts <= ROUTE_ONE_MAX_GROUPS);
-  if (!one) {
-    int rc = swn_route_top1(idx, gmax, gates, n_tokens, seg_tokens, n_experts, capacity, bpr, loc, counts, perm, tok2row, l_aux, workspace,
-                            workspace_bytes, stream);
-    if (rc == 0 && drop_begin) rc = swn_route_dropped(idx, loc, counts, n_tokens, seg_tokens, n_experts, capacity, drop_begin, dropped, stream);
-    return rc;
-  }
-  const int nblk = cdiv(seg_tokens, KPB);
-  char* ws = (char*)workspace;
-  const size_t tb = align256((size_t)n_tokens * 4), hb = align256((size_t)n_seg * 1024 * nblk * 4), pb = align256((size_t)n_seg * nblk * n_experts * 4);
-  RouteOne a;
-  a.idx = idx; a.gmax = gmax; a.gates = gates;
-  a.n_tokens = n_tokens; a.seg_tokens = seg_tokens; a.E = n_experts; a.capacity = capacity; a.bpr = bpr; a.n_seg = n_seg; a.nblk = nblk;
-  a.n_pass = bpr ? 4 : 1;                  // the key has 26 + ceil(log2 E) significant bits; without BPR only the expert bits differ
-  a.shift0 = bpr ? 0 : 24;
-  a.loc = loc; a.counts = counts; a.perm = perm; a.tok2row = tok2row; a.l_aux = l_aux; a.drop_begin = drop_begin; a.dropped = dropped;
-  a.k0 = (uint32_t*)ws; a.k1 = (uint32_t*)(ws + tb); a.v0 = (int32_t*)(ws + 2 * tb); a.v1 = (int32_t*)(ws + 3 * tb);
-  a.hist = (int32_t*)(ws + 4 * tb); a.partial = (float*)(ws + 4 * tb + hb); a.ehist = (int32_t*)(ws + 4 * tb + hb + pb);
-  a.sync = sync;
-  const int n_tiles = n_seg * nblk;
-  if (mode == 2) {       // every phase in one launch, grid barriers between them
-    a.ph_lo = 0; a.ph_hi = 2 * a.n_pass; a.kv_plain = 0;
-    int grid = 2 * route_compute_units();    // at most two 256-thread workgroups per CU: always co-resident (the grid barrier's condition)
-    if (grid > n_tiles) grid = n_tiles;
-    hipLaunchKernelGGL(route_one_kernel, dim3(grid), dim3(256), 0, as_stream(stream), a);
-  } else {               // one launch per phase (9 with batch prioritisation, 3 without): the launch boundary is the barrier, one tile per workgroup
-    a.kv_plain = 1;
-    for (int ph = 0; ph <= 2 * a.n_pass; ++ph) {
-      a.ph_lo = a.ph_hi = ph;
-      hipLaunchKernelGGL(route_one_kernel, dim3(n_tiles), dim3(256), 0, as_stream(stream), a);
-    }
-  }
-  SWN_LAUNCH_CHECK();
-  return 0;
+  if (mode > 0 && sync != nullptr && 2 + 4 * n_seg <= ROUTE_SYNC_WORDS && (!drop_begin || n_seg * n_experts <= ROUTE_ONE_MAX_GROUPS))
+    return route_one_launch(idx, gmax, gates, n_tokens, seg_tokens, n_experts, capacity, bpr, loc, counts, perm, tok2row, l_aux, drop_begin,
+                            dropped, sync, mode, workspace, stream);
+#else
+  SWN_CHECK(mode == 0, "swn_route_top1x: mode %d needs the experiment build (-DSWN_EXP_ROUTE_ONE); this library has mode 0 only", mode);
+#endif
+  int rc = swn_route_top1(idx, gmax, gates, n_tokens, seg_tokens, n_experts, capacity, bpr, loc, counts, perm, tok2row, l_aux, workspace,
+                          workspace_bytes, stream);
+  if (rc == 0 && drop_begin) rc = swn_route_dropped(idx, loc, counts, n_tokens, seg_tokens, n_experts, capacity, drop_begin, dropped, stream);
+  return rc;
 }
 
 extern "C" int swn_route_top1(const int32_t* idx, const float* gmax, const float* gates, int n_tokens, int seg_tokens,

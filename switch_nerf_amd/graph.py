@@ -124,7 +124,7 @@ class GraphedRender:
 
     def __init__(self, model, rays, image_indices, n_samples: int, seg_tokens: int, fine_samples: int = 0, no_batch: bool = False,
                  warmup: int = 2):
-        if model.ep is not None and model.ep.world > 1:
+        if model.ep is not None and not model.ep.local:
             raise ValueError("GraphedRender: expert-parallel evaluation exchanges host-sized splits and cannot be captured")
         self.model = model
         dev = model.dev
@@ -182,7 +182,7 @@ class GraphedRenderTrain:
 
     def __init__(self, model, rays, image_indices, n_samples: int, fine_samples: int, seg_tokens: int, perturb: float, noise_std: float,
                  warmup: int = 2):
-        if model.ep is not None and model.ep.world > 1:
+        if model.ep is not None and not model.ep.local:
             raise ValueError("GraphedRenderTrain: expert-parallel training is not captured")
         from . import ops
         self.model = model

@@ -39,7 +39,22 @@ def _ceil_to(x, m):
     return (x + m - 1) // m * m
 
 
-_FUSED_HEADS = os.environ.get("SWN_NO_FUSED_HEADS") is None      # sigma / colour heads inside the tail forward chain (swn.h: heads_raw)
+def resolve_kernel_switches(env=None) -> dict:
+    """The kernel-selection switches of a model, resolved ONCE (SwitchNeRF.__init__ reads the process environment through this; no
+    forward / backward looks at os.environ).  Defaults = the shipped kernel set; the SWN_* variables are experiment / test knobs:
+      front_geom (SWN_FRONT_GEOM, 7)      dense front chains: 7 / 6 = the persistent 256-row geometry, 1 = the 64-row kernels
+      chain_geom (SWN_CHAIN_GEOM, 7)      expert chains: include/swn.h swn_chain_desc.geometry (1, 2, 4, 5, 6, 7)
+      tail_geom (SWN_TAIL_GEOM, 1)        the separate tail backward chain: 6 / 7 = persistent geometry (measured slower: off)
+      fused_tail (SWN_FUSED_TAIL, on)     dense tail + heads inside the expert forward launch (chain_big.hip tag 7)
+      fused_tail_bwd (SWN_FUSED_TAIL_BWD, on)   tail backward + combine backward in front of the expert backward chain (tag 8)
+      fused_dwsig (SWN_FUSED_DWSIG, on)   the sigma head's weight gradient from tag 8's combine pass
+      fused_heads (SWN_NO_FUSED_HEADS unset)    sigma / colour heads inside the tail forward chain (swn.h: heads_raw)
+      overlap (SWN_NO_OVERLAP != 1)       side-stream overlap of the expert weight gradients and the per-ray launches"""
+    e = os.environ if env is None else env
+    return dict(front_geom=int(e.get("SWN_FRONT_GEOM", "7")), chain_geom=int(e.get("SWN_CHAIN_GEOM", "7")),
+                tail_geom=int(e.get("SWN_TAIL_GEOM", "1")), fused_tail=e.get("SWN_FUSED_TAIL", "1") != "0",
+                fused_tail_bwd=e.get("SWN_FUSED_TAIL_BWD", "1") != "0", fused_dwsig=e.get("SWN_FUSED_DWSIG", "1") != "0",
+                fused_heads=e.get("SWN_NO_FUSED_HEADS") is None, overlap=e.get("SWN_NO_OVERLAP", "0") != "1")
 
 
 def c_esz(dtype) -> int:
@@ -84,8 +99,13 @@ class LossScaler:
 
 class SwitchNeRF:
     def __init__(self, cfg: dict = BUILDING, dtype=torch.bfloat16, device="cuda", capacity_factor=1.0,
-                 batch_prioritized=True, moe_l_aux_wt=5e-4, lr=5e-4, seed=0, gate_noise=-1.0):
+                 batch_prioritized=True, moe_l_aux_wt=5e-4, lr=5e-4, seed=0, gate_noise=-1.0, kernel_switches=None):
         self.cfg, self.dtype, self.dev = dict(cfg), dtype, torch.device(device)
+        # the kernel selection is resolved HERE, once (environment knobs included); set_kernel_switches() changes it afterwards
+        self.sw = resolve_kernel_switches()
+        self._env_overrides = {k: v for k, v in sorted(os.environ.items()) if k.startswith("SWN_")}
+        if kernel_switches:
+            self.set_kernel_switches(**kernel_switches)
         # the 16-bit compute type selects the build of the library: bfloat16 (amp_use_bfloat16) or IEEE half (the reference's default
         # autocast dtype; BASELINE configs[4] "fp16 MFMA") - see _lib.use_half.  fp16 trains with loss scaling like the reference.
         if dtype == torch.float16:
@@ -124,7 +144,7 @@ class SwitchNeRF:
         self.events: Dict[str, list] = {}
         # side HIP stream: the HBM-bound expert weight-gradient GEMMs overlap with the rest of the backward pass
         self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
-        self.overlap = os.environ.get("SWN_NO_OVERLAP", "0") != "1"   # side-stream overlap of the expert weight gradients
+        self.overlap = self.sw["overlap"]      # side-stream overlap of the expert weight gradients
         self._kernel_sel = {}         # kernel_set(): what the last forward / backward selected
         self.ep = None                # parallel.ExpertParallel: experts sharded over ranks, tokens exchanged (set_expert_parallel)
         self.expert_wgrad_splits = 0         # row splits of the legacy expert weight-gradient launch (0 = heuristic)
@@ -341,8 +361,21 @@ class SwitchNeRF:
         sel = dict(self._kernel_sel)
         sel["wgrad_overlap"] = bool(self.overlap)
         sel["expert_parallel"] = int(self.ep.world) if self.ep is not None else 0
-        sel["env_overrides"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("SWN_")}
+        sel["env_overrides"] = dict(self._env_overrides)          # (the SWN_* variables that were set when the model was built)
         return sel
+
+    def set_kernel_switches(self, **kw):
+        """Change kernel-selection switches of this model (names: resolve_kernel_switches); returns the previous values of the ones
+        changed.  Takes effect with the next forward; compute copies a newly selected kernel needs are packed on demand."""
+        prev = {}
+        for k, v in kw.items():
+            if k not in self.sw:
+                raise KeyError(f"unknown kernel switch {k!r} (known: {sorted(self.sw)})")
+            prev[k] = self.sw[k]
+            self.sw[k] = type(self.sw[k])(v)
+        if "overlap" in kw:
+            self.overlap = self.sw["overlap"]
+        return prev
 
     DEFAULT_KERNEL_SET = dict(geom=7, front_geom=7, tail_fused=True, fused_backward=True, comb_dwsig=True, wgrad_overlap=True)
 
@@ -350,7 +383,7 @@ class SwitchNeRF:
         """The dense front chains (PE -> xyz -> gate MLP, and their backward) on the persistent 256-row geometry: 256-feature layers over
         a 128-feature encoding in a 16-bit compute dtype (building.yaml).  SWN_FRONT_GEOM=1 keeps them on the 64-row kernels."""
         return ("xyz.w" in self.spec and self.M == 256 and self.G == 256 and self.KP == 128 and self.dtype != torch.float32
-                and self.hash is None and os.environ.get("SWN_FRONT_GEOM", "7") != "1")
+                and self.hash is None and self.sw["front_geom"] != 1)
 
     def _tail_big(self) -> bool:
         """The tail backward chain (dh2 -> dh1 -> dy with the combine backward in its write-out) on the persistent 256-row geometry:
@@ -359,14 +392,14 @@ class SwitchNeRF:
         with the combine backward in it (three more operand streams behind the write-out) is the longest of them.  SWN_TAIL_GEOM=7
         turns it on (profiles/r04_experiments.md)."""
         return ("l2h.w" in self.spec and "l1.w" in self.spec and self.M == 256 and self.H2 == 128 and self.dtype != torch.float32
-                and os.environ.get("SWN_TAIL_GEOM", "1") in ("6", "7"))
+                and self.sw["tail_geom"] in (6, 7))
 
     def _tail_fused(self) -> bool:
         """The dense tail (gate scaling + ReLU, Linear "1", Linear "2" + per-ray bias, sigma / colour heads) inside the expert forward
         launch (swn_chain_desc.tail_first, chain_big.hip tag 7): 256-feature experts, 128-feature layer "2", 16-bit compute dtype,
         experts local.  SWN_FUSED_TAIL=0 keeps the 64-row tail chain as its own launch."""
         return ("l2h.w" in self.spec and "l1.w" in self.spec and self.M == 256 and self.H2 == 128 and self.dtype != torch.float32
-                and _FUSED_HEADS and self.L + 2 <= 12 and os.environ.get("SWN_FUSED_TAIL", "1") != "0")
+                and self.sw["fused_heads"] and self.L + 2 <= 12 and self.sw["fused_tail"])
 
     def set_expert_parallel(self, ep):
         """Shard the experts over the ranks of `ep` (parallel.ExpertParallel) and exchange the dispatched rows instead of
@@ -388,7 +421,7 @@ class SwitchNeRF:
         rank-major, exchanged with ONE all_gather, and scattered back per tensor."""
         import torch.distributed as dist
         ep = self.ep
-        if ep is None or ep.world == 1:
+        if ep is None or ep.local:
             return
         W, El, r = ep.world, ep.El, ep.rank
         bufs = [self.flat] + ([self.m, self.v] if include_optimizer else [])
@@ -511,6 +544,18 @@ class SwitchNeRF:
             c[k] = torch.cat([a[k], b[k]], 0)
         return c
 
+    def _join_side_outputs(self, ev, *tensors):
+        """The launch stream waits for work issued on the side stream, and tensors ALLOCATED there are recorded on the launch stream
+        (the caching allocator only tracks the allocating stream: without this a later side-stream allocation could reuse a block the
+        launch stream still reads).  Invariant for the other direction - tensors allocated on the launch stream and read on the side
+        stream (dc_ray, dh2, dsig in backward_net_a): every side-stream section starts with side.wait_event(<launch-stream event>) and
+        its readers' inputs are kept alive in the returned state until the join."""
+        main = torch.cuda.current_stream()
+        main.wait_event(ev)
+        for t in tensors:
+            if t is not None and t.is_cuda:
+                t.record_stream(main)
+
     def _net_forward_rows(self, pe, pe_dir, image_indices, N, S, seg_tokens, sigma_noise, routing_override, no_batch, tag, row_range):
         """One or more whole model chunks: front chain, gate, routing, expert chain, tail chain, heads -> c["raw"] [P, 4].
         row_range = None: all N*S points; (r0, r1): that row range of the ray-major point grid (ragged evaluation)."""
@@ -553,7 +598,7 @@ class SwitchNeRF:
         c["no_grad"] = not sv
         # (the 64-row kernels re-stream the 320 KB of weights from L2 for every 64 rows - 11.8 GB of L2 reads per 2M-point launch against
         #  0.5 GB of input, the CU's L2 -> L1 path is what bounds them - the persistent 256-row geometry a quarter of that)
-        c["front_geom"] = int(os.environ.get("SWN_FRONT_GEOM", "7")) if self._front_big() else 1
+        c["front_geom"] = self.sw["front_geom"] if self._front_big() else 1
         big = c["front_geom"] >= 6
         o.mlp_chain(c["pe"], [o.Layer(self.wf["xyz_pad" if big else "xyz"], self.p["xyz.b"].view(1, M), save=c["h0"]),
                               o.Layer(self.wf["gate0"], self.p["gate0.b"].view(1, G), relu=1, mask=c["m_a1"] if sv else None,
@@ -563,18 +608,30 @@ class SwitchNeRF:
         # ---- gate + routing
         gnoise = None
         if sv and self.gate_noise > 0:       # (training only, like `self.training and self.gate_noise > 0`)
-            gnoise = (self.gate_noise_draw.to(dev, torch.float32).reshape(P, E).contiguous() if self.gate_noise_draw is not None
-                      else torch.randn(P, E, device=dev, dtype=torch.float32))
+            if self.gate_noise_draw is not None:      # a supplied draw (tests): [N * S, E] of this pass's point grid; a row range takes its rows
+                draw = self.gate_noise_draw.to(dev, torch.float32)
+                if draw.numel() != N * S * E:
+                    raise ValueError(f"gate_noise_draw holds {draw.numel()} values, this pass needs [{N * S}, {E}] (one row per point)")
+                draw = draw.reshape(N * S, E)
+                gnoise = (draw if row_range is None else draw[row_range[0]:row_range[1]]).contiguous()
+            else:
+                gnoise = torch.randn(P, E, device=dev, dtype=torch.float32)
         c["gates"], c["idx"], c["gmax"], c["stats"] = o.gate_fwd(c["g"], self.p["ln.w"], self.p["ln.b"], self.p["wg"], noise=gnoise,
                                                                  noise_scale=self.gate_noise / E)
         if routing_override is not None:     # tests: inject the oracle's expert choice (near-tie robustness)
             c["idx"] = routing_override.to(dev).int().contiguous()
             c["gmax"] = c["gates"].gather(1, c["idx"].long()[:, None])[:, 0].contiguous()
         packed = bool(no_batch) and not sv and self.ep is None      # (see below: the no-batch row layout of the inference forward)
-        # (the fused tail's list of dropped tokens comes out of the routing launch: the conditions of c["tail_fused"] below)
-        geom_ = int(os.environ.get("SWN_CHAIN_GEOM", "7")) if (M == 256 and dt != torch.float32 and cap >= 256) else 1
-        want_drops = (self._tail_fused() and self.ep is None and geom_ == 7 and row_range is None and P * M * c_esz(dt) < (1 << 32) - 64
-                      and not packed)
+        # expert chains (forward here, backward-data in backward_net - the pair shares its ReLU mask layout): the 256-row geometry
+        # with phase-shifted row groups as a persistent launch (chain_big.hip, geometry 7 = geometry 4 walking a tile queue) for 256-feature
+        # experts in a 16-bit compute dtype once a group holds at least one full tile.  The chain_geom switch picks another one (1: the
+        # 64-row kernels, 2 / 4 / 5 / 6: see include/swn.h) - tests.
+        c["geom"] = self.sw["chain_geom"] if (M == 256 and dt != torch.float32 and cap >= 256) else 1
+        # the tail inside the expert launch (local experts, standard row space, whole point grid): the expert output never reaches memory
+        c["tail_fused"] = (self._tail_fused() and self.ep is None and c["geom"] == 7 and row_range is None
+                           and P * M * c_esz(dt) < (1 << 32) - 64)
+        # (the fused tail's list of dropped tokens comes out of the routing launch)
+        want_drops = c["tail_fused"] and not packed
         routed = o.route_top1(c["idx"], c["gmax"], c["gates"], seg_tokens, E, cap, self.bpr, want_perm=not packed, want_drops=want_drops)
         c["loc"], c["counts"], c["perm"], c["tok2row"], c["l_aux"] = routed[:5]
         if want_drops:
@@ -596,17 +653,9 @@ class SwitchNeRF:
         nw = max(o.chain_mask_words(dt, ng, cap, M), n_seg * o.chain_mask_words(dt, E, cap, M))    # (expert parallel: one launch per segment)
         c["masks"] = [_b(f"mask{l}", (nw,), torch.int32) if sv else None for l in range(L - 1)]
         skips = set(self.cfg["skips"])
-        # expert chains (forward here, backward-data in backward_net - the pair shares its ReLU mask layout): the 256-row geometry
-        # with phase-shifted row groups as a persistent launch (chain_big.hip, geometry 7 = geometry 4 walking a tile queue) for 256-feature
-        # experts in a 16-bit compute dtype once a group holds at least one full tile.  SWN_CHAIN_GEOM picks another one (1: the 64-row
-        # kernels, 2 / 4 / 5 / 6: see include/swn.h) - tests.
-        c["geom"] = int(os.environ.get("SWN_CHAIN_GEOM", "7")) if (M == 256 and dt != torch.float32 and cap >= 256) else 1
         layers = [o.Layer(self._local_experts(self.wf[f"exp{l}"]), self._local_experts(self.p[f"exp{l}.b"]),
                           relu=1 if l < L - 1 else 0, skip=(l in skips), save=c["saves"][l] if (sv and l < L - 1) else None,
                           mask=c["masks"][l] if (sv and l < L - 1) else None) for l in range(L)]
-        # the tail inside the expert launch (local experts, standard row space, whole point grid): the expert output never reaches memory
-        c["tail_fused"] = (self._tail_fused() and self.ep is None and c["geom"] == 7 and row_range is None
-                           and P * M * c_esz(dt) < (1 << 32) - 64 and os.environ.get("SWN_CHAIN_GEOM", "7") == "7")
         c["eo"] = None if c["tail_fused"] else _b("eo", (rows, M), dt)
         self._kernel_sel.update(geom=c["geom"], front_geom=c["front_geom"], tail_fused=bool(c["tail_fused"]))
         if no_batch and not sv and self.ep is not None:
@@ -635,7 +684,7 @@ class SwitchNeRF:
             # 64-row tail chain (which re-streams its 192 KiB of weights from L2 for every 64 rows) and its launch.
             c["row_of_tok"] = c["tok2row"]
             if ray_feat_ev is not None:
-                torch.cuda.current_stream().wait_event(ray_feat_ev)
+                self._join_side_outputs(ray_feat_ev, c["ray_feat"], c["c_ray"])
             else:
                 c["ray_feat"], c["c_ray"] = o.ray_feat_fwd(pe_dir, self.in_dir, self.p["emb"], image_indices.contiguous(), self.p["l2r.w"], self.p["l2.b"])
             if "dropped" not in c:
@@ -711,8 +760,8 @@ class SwitchNeRF:
             c["ep_perm"], c["ep_plan"] = perm_p, pl
             so, ro = pl["send_off"], pl["recv_off"]
             xr = _b("ep_x", (rows, M), dt)                                  # received rows of all segments (also the first layer's
-            send = xr if W == 1 else _b("ep_send_x", (rows, M), dt)         # weight-gradient operand)
-            eo_r = c["eo"] if W == 1 else _b("ep_eo", (rows, M), dt)        # expert outputs in the received row space
+            send = xr if ep.local else _b("ep_send_x", (rows, M), dt)         # weight-gradient operand)
+            eo_r = c["eo"] if ep.local else _b("ep_eo", (rows, M), dt)        # expert outputs in the received row space
             wseg = o.chain_mask_words(dt, E, cap, M)
             c["ep_mask_words"] = wseg
 
@@ -739,14 +788,14 @@ class SwitchNeRF:
         # ---- per-ray part of layer "2": [PE(dir), appearance embedding] @ W2r + b2   (N_rays x 75, host-side torch)
         # (one launch: swn_ray_feat_fwd - was cat / embedding lookup / addmm in torch)
         if ray_feat_ev is not None:        # (issued on the side stream above; this branch: the fused tail was not taken after all)
-            torch.cuda.current_stream().wait_event(ray_feat_ev)
+            self._join_side_outputs(ray_feat_ev, c["ray_feat"], c["c_ray"])
         else:
             c["ray_feat"], c["c_ray"] = o.ray_feat_fwd(pe_dir, self.in_dir, self.p["emb"], image_indices.contiguous(), self.p["l2r.w"], self.p["l2.b"])
         # ---- tail chain.  Its input load IS the combine: rows gathered from the expert output through tok2row, scaled by
         # the gate value, ReLU'd (dropped tokens -> zero rows) and saved as y;  then layer "1" -> layer "2" (+ per-ray bias)
         # The sigma / colour heads run inside that launch (swn.h: heads_raw): sigma from the staged y tile, colour from the h2 tile.  A
         # training forward still writes y, h1 and h2 (the backward reads them); an inference forward writes nothing but raw.
-        fused = _FUSED_HEADS and M in (256, 512) and H2 in (128, 256) and M * c_esz(dt) <= 1024      # (rows of at most 1 KiB)
+        fused = self.sw["fused_heads"] and M in (256, 512) and H2 in (128, 256) and M * c_esz(dt) <= 1024      # (rows of at most 1 KiB)
         keep = sv or not fused
         c["y"] = _b("y", (P, M), dt) if keep else None
         c["h1"] = _b("h1", (P, M), dt) if sv else None
@@ -806,10 +855,10 @@ class SwitchNeRF:
         _b = lambda name, shape, dtype: self._buf(c["tag"] + ":" + name, shape, dtype)
         # the tail's two backward layers and the combine backward in FRONT of the expert backward chain, one launch (chain_big.hip, tag 8):
         # pairs with the fused forward (its list of dropped tokens); SWN_FUSED_TAIL_BWD=0 keeps the two launches
-        fused_bwd = bool(c.get("tail_fused")) and self.ep is None and os.environ.get("SWN_FUSED_TAIL_BWD", "1") != "0"
+        fused_bwd = bool(c.get("tail_fused")) and self.ep is None and self.sw["fused_tail_bwd"]
         # ... which also forms the sigma head's weight gradient where it reads y anyway (swn_chain_desc.comb_dwsig): the heads' backward
         # launch then runs without y - 512 bytes per point less (SWN_FUSED_DWSIG=0: from y in the heads' launch, as before)
-        fused_dws = fused_bwd and M == 256 and os.environ.get("SWN_FUSED_DWSIG", "1") != "0"
+        fused_dws = fused_bwd and M == 256 and self.sw["fused_dwsig"]
         y_heads = None if fused_dws else c["y"]
         self._kernel_sel.update(fused_backward=fused_bwd, comb_dwsig=fused_dws)
         # per-ray bias gradient (the column sums of a ray's dh2 rows: from the heads' launch) and the tiny per-ray GEMM's parameters
@@ -855,7 +904,7 @@ class SwitchNeRF:
                 self.wb["l2h_pad"] = o.pack_weights_padded(self.p["l2h.w"].unsqueeze(0), dt, False, 0, 256)
         elif M * dout.element_size() <= 1024:      # (a row's 16-byte chunks must fit one wavefront: everything but fp32 rows of 512)
             dgmax = _b("dgmax", (P,), torch.float32)
-            tg = int(os.environ.get("SWN_TAIL_GEOM", "1")) if self._tail_big() else 0
+            tg = self.sw["tail_geom"] if self._tail_big() else 0
             o.mlp_chain(dh2, [o.Layer(self.wb["l2h_pad" if tg >= 6 else "l2h"], None, save=dh1), o.Layer(self.wb["l1"], None)], dout, tag=5,
                         combine=(c["y"], dsig, self.p["sigma.w"], c["gmax"], dgmax), geometry=tg, x_features=H2 if tg >= 6 else 0)
         else:
@@ -868,7 +917,7 @@ class SwitchNeRF:
             pl, perm_p = c["ep_plan"], c["ep_perm"]
             so, ro = pl["send_off"], pl["recv_off"]
             dr = _b("ep_d", (rows, M), dt)
-            dsend = dr if ep.world == 1 else _b("ep_send_d", (rows, M), dt)
+            dsend = dr if ep.local else _b("ep_send_d", (rows, M), dt)
 
             def issue_b(s_):
                 o.gather_rows(dout, perm_p[so[s_]:so[s_ + 1]], dsend[so[s_]:so[s_ + 1]])
@@ -932,7 +981,7 @@ class SwitchNeRF:
             x_first, dz_last = c["ep_x"], dr                     # the received rows, already in group order
             grp_rows = c["ep_counts"].reshape(-1)
             ngs = ep.world * ep.El
-            dx_r = dx if ep.world == 1 else _b("ep_dx", (rows, M), dt)
+            dx_r = dx if ep.local else _b("ep_dx", (rows, M), dt)
             wseg = c["ep_mask_words"]
             returns = []
             with self._timed("expert_bwd"):
@@ -1118,7 +1167,7 @@ class SwitchNeRF:
         holds the same scale."""
         self._applied_loss_scale = self._ls_dev_val if self._ls_dev_val is not None else self.loss_scaler.scale   # what the backward used
         bad = (~torch.isfinite(self.grad).all()).to(torch.float32).view(1)
-        if self.ep is not None and self.ep.world > 1:
+        if self.ep is not None and not self.ep.local:
             import torch.distributed as dist
             dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.ep.group)
         return bool(bad.item() > 0)
@@ -1136,7 +1185,7 @@ class SwitchNeRF:
     def _allreduce_view(self):
         """What the data-parallel all-reduce sums: the whole flat gradient, or - experts sharded over the ranks - its dense
         prefix (a local expert's gradient already holds the contributions of every rank's rows)."""
-        if self.ep is not None and self.ep.world > 1:
+        if self.ep is not None and not self.ep.local:
             return self.grad[: self.n_dense]
         return self.grad
 

@@ -59,7 +59,7 @@ class _MoEFunction(torch.autograd.Function):
         gs = gate_in.detach().to(dt).contiguous()
         wg32 = wg.detach().float().contiguous()
         # gate_noise: the [P, E] draw of a training forward under gate_noise > 0 (tutel_moe_layer_nobatch.py:119-122) or None
-        gates, idx, gmax, stats = o.gate_fwd(gs, None, None, wg32, noise=gate_noise, noise_scale=layer.gate_noise / E if gate_noise is not None else 0.0)
+        gates, idx, gmax, stats = o.gate_fwd(gs, None, None, wg32, noise=gate_noise, noise_scale=layer._noise_scale if gate_noise is not None else 0.0)
         cap = int(layer.capacity_factor * ((P + E - 1) // E))                                  # tutel_fast_dispatch.py:211
         if layer.moe_no_batch:
             cap = P
@@ -150,8 +150,12 @@ class MoELayer(nn.Module):
         # gate noise (--gate_noise, opts.py:208; <= 0 = off like the shipped configs' -1): in TRAINING the router's logits get
         # gate_noise * randn / E before the softmax (tutel_moe_layer_nobatch.py:119-122)
         self.gate_noise = float(gate_type.get("gate_noise", 0.0) or 0.0)
-        if gate_type.get("use_load_importance_loss") or gate_type.get("use_normal_noise"):
-            raise NotImplementedError("use_load_importance_loss / use_normal_noise (tutel_fast_dispatch.py:152-174; no shipped config uses them)")
+        # use_normal_noise (tutel_moe_layer_nobatch.py:116-117): in TRAINING the logits get randn / E - in front of the gate noise; both are
+        # additive, so they reach the router kernel as ONE noise operand (swn_gate_fwd_noise)
+        self.use_normal_noise = bool(gate_type.get("use_normal_noise", False))
+        self._noise_scale = 0.0
+        if gate_type.get("use_load_importance_loss"):
+            raise NotImplementedError("use_load_importance_loss (tutel_fast_dispatch.py:152-174, 219-265; no shipped config uses it)")
         self.moe_no_batch, self.return_gates, self.dtype = bool(moe_no_batch), bool(return_gates), dtype
         gen = None
         if seeds is not None:                      # gate under seeds[0], experts under seeds[1] (tutel_moe_layer_nobatch.py:654-703)
@@ -159,9 +163,11 @@ class MoELayer(nn.Module):
         self.gates = nn.ModuleList([_Gate(self.gate_dim, self.n_experts)])
         self.experts = nn.ModuleList([_ExpertParams(self.n_experts, self.model_dim, self.layer_num, gen)])
 
-    def forward(self, input: torch.Tensor, gate_input: Optional[torch.Tensor] = None, gate_noise_draw: Optional[torch.Tensor] = None):
-        """gate_noise_draw: the [P, E] standard-normal tensor to use as the layer's noise draw (tests replay the reference's); None =
-        drawn here (torch.randn on the device) when the layer trains with gate_noise > 0."""
+    def forward(self, input: torch.Tensor, gate_input: Optional[torch.Tensor] = None, gate_noise_draw: Optional[torch.Tensor] = None,
+                normal_noise_draw: Optional[torch.Tensor] = None):
+        """gate_noise_draw / normal_noise_draw: the [P, E] standard-normal tensors to use as the layer's noise draws (tests replay the
+        reference's); None = drawn here (torch.randn on the device, the normal noise first like the reference) when the layer trains
+        with gate_noise > 0 / use_normal_noise."""
         if not input.is_cuda:
             raise RuntimeError("MoELayer runs on the HIP library only (no CPU fallback)")
         gi = input if gate_input is None else gate_input
@@ -170,9 +176,17 @@ class MoELayer(nn.Module):
         g = gi.reshape(-1, self.gate_dim)
         ex = self.experts[0]
         noise = None
-        if self.training and self.gate_noise > 0:
-            noise = (gate_noise_draw.to(x.device, torch.float32).reshape(-1, self.n_experts).contiguous() if gate_noise_draw is not None
-                     else torch.randn(x.shape[0], self.n_experts, device=x.device, dtype=torch.float32))
+        E = self.n_experts
+        draw = lambda given: (given.to(x.device, torch.float32).reshape(-1, E).contiguous() if given is not None
+                              else torch.randn(x.shape[0], E, device=x.device, dtype=torch.float32))
+        if self.training and self.use_normal_noise:            # logits + n1 / E (+ gate_noise * n2 / E) = logits + (n1 + gate_noise * n2) / E
+            noise = draw(normal_noise_draw)
+            if self.gate_noise > 0:
+                noise = noise + self.gate_noise * draw(gate_noise_draw)
+            self._noise_scale = 1.0 / E
+        elif self.training and self.gate_noise > 0:
+            noise = draw(gate_noise_draw)
+            self._noise_scale = self.gate_noise / E
         y, l_aux, idx = _MoEFunction.apply(self, x, g, self.gates[0].wg.weight, noise, *ex.weights, *ex.bias)
         y = y.view(shape)
         y.l_aux = l_aux                                                                         # :792-796

@@ -159,16 +159,16 @@ def route_sync(dev):
     return t
 
 
-_ROUTE_MODE = int(os.environ.get("SWN_ROUTE_MODE", "0"))
+_ROUTE_MODE = int(os.environ.get("SWN_ROUTE_MODE", "0"))            # (experiment build only: see route_top1)
+CHAINQ_STATIC = os.environ.get("SWN_CHAINQ_STATIC") is not None       # persistent chains without tile queues (tests assign it)
 
 
 def route_top1(idx, gmax, gates, seg_tokens: int, n_experts: int, capacity: int, bpr: bool, want_perm=True, want_drops=False, multi=False,
                mode=None):
     """Top-1 capacity assignment of every routing segment (swn_route_top1x) -> (loc, counts, perm, tok2row, l_aux)
     [+ (drop_begin, dropped) with want_drops: the tokens no expert kept, swn_route_dropped's lists, from the same call].
-    mode (include/swn.h): 0 = the 20 per-phase kernels of rounds 1-4 (the default - still the fastest; SWN_ROUTE_MODE overrides);
-    1 = route_one_kernel launched once per phase (9 launches: no faster), 2 = ONE launch with grid barriers (slower); both bit-identical
-    and kept under their twin test (profiles/r05_experiments.md 3).
+    mode (include/swn.h): 0 = the 20 per-phase kernels (the product library's only mode); 1 / 2 = the fused forms of round 5, in the
+    experiment build only (scripts/experiments/build_route_one.sh; SWN_ROUTE_MODE, read once at import, selects them there).
     multi=True: the round 1-4 entry points themselves (swn_route_top1 + swn_route_dropped) - the twin the tests compare with."""
     P = idx.shape[0]
     n_seg = P // seg_tokens
@@ -399,9 +399,12 @@ _hash_xcd_tables = {}
 HASH_XCD_COPIES = 8          # XCDs of an MI300X / MI355X (the kernel picks its copy by HW_REG_XCC_ID & 7: hashgrid.hip)
 
 
+HASH_XCD_MB = int(os.environ.get("SWN_HASH_XCD_MB", "1024"))      # (read once; tests assign ops.HASH_XCD_MB)
+
+
 def hash_xcd_budget_bytes() -> int:
     """Upper bound on the per-XCD gradient-table workspace of hash_encode_bwd (SWN_HASH_XCD_MB, default 1024 MiB; 0 = never)."""
-    return int(os.environ.get("SWN_HASH_XCD_MB", "1024")) << 20
+    return HASH_XCD_MB << 20
 
 
 def hash_encode_bwd(rays, z, d_out, hc: dict, d_table):
@@ -623,7 +626,7 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
     d.x_scale, d.x_relu = _p(x_scale), int(bool(x_relu))
     d.y_add, d.y_add_gather = _p(y_add), _p(y_add_gather)
     d.x_features = int(x_features)                 # (geometry 6 / 7: 128-feature rows under a zero-padded K = 256 first layer)
-    if sched is None and d.geometry >= 6 and os.environ.get("SWN_CHAINQ_STATIC") is None:
+    if sched is None and d.geometry >= 6 and not CHAINQ_STATIC:
         sched = chain_sched(x.device, d.tag)       # (launches of one role on one stream are ordered: they can share the counters)
     if sched is not None:
         assert sched.dtype == torch.int32 and sched.numel() >= 16

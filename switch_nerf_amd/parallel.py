@@ -16,13 +16,16 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] = None):
-    """Initialise torch.distributed from torchrun's environment (RANK / WORLD_SIZE / MASTER_*).  Returns (rank, world)."""
+def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] = None, loopback: bool = False):
+    """Initialise torch.distributed from torchrun's environment (RANK / WORLD_SIZE / MASTER_*).  Returns (rank, world).
+    loopback: initialise the process group even for ONE rank (a world-1 RCCL communicator: every collective of the multi-GPU step is
+    issued for real - same API calls, streams and graph captures as at W > 1 - and moves its payload inside the GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or loopback) and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl" and device is not None:
@@ -54,12 +57,16 @@ class GradAllReduce:
     Both forms sum the same elements over the same ranks: results are bit-identical.  profile = True records HIP events around the
     collectives and the launch stream's waits (report())."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, loopback: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # loopback: issue the collectives even with ONE rank (init_from_env(loopback=True)): the sums are the identity, the calls,
+        # streams and events are the W > 1 ones
+        self.active = self.world > 1 or (bool(loopback) and dist.is_initialized())
         self.profile = False
         self._pending = None
         self._ev = []            # (kind, start, end)
+        self.stale_drains = 0    # begin() / __call__ found a part whose finish() never ran (see _drain)
 
     def _timed(self, kind, fn):
         if not self.profile or not torch.cuda.is_available():
@@ -77,19 +84,23 @@ class GradAllReduce:
         if self._pending is not None:
             work, _part = self._pending
             self._pending = None
+            self.stale_drains += 1
+            import warnings
+            warnings.warn("GradAllReduce: begin() without finish() - the pending part of the previous step was dropped; if that step's "
+                          "optimizer update ran, its dense gradient block was never reduced", RuntimeWarning, stacklevel=3)
             if work is not None:
                 work.wait()
 
     def __call__(self, flat: torch.Tensor) -> float:
         self._drain()
-        if self.world > 1:
+        if self.active:
             self._timed("coll", lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group))
         return 1.0 / self.world
 
     def begin(self, part: torch.Tensor, stream=None):
         """Start the all-reduce of `part` (final already) on `stream`, ordered after the work queued on the current stream."""
         self._drain()
-        if self.world == 1:
+        if not self.active:
             self._pending = (None, part)
             return
         if stream is None or not part.is_cuda:
@@ -113,7 +124,7 @@ class GradAllReduce:
         assert self._pending is not None, "GradAllReduce.finish without begin"
         work, part = self._pending
         self._pending = None
-        if self.world > 1:
+        if self.active:
             if rest.numel():
                 self._timed("coll", lambda: dist.all_reduce(rest, op=dist.ReduceOp.SUM, group=self.group))
             self._timed("wait", work.wait)
@@ -131,10 +142,10 @@ class GradAllReduce:
         return dict(collectives=n, allreduce_ms=coll, wait_ms=wait, hidden_fraction=(1.0 - wait / coll) if coll > 0 else None)
 
 
-def make_grad_allreduce(group=None) -> GradAllReduce:
+def make_grad_allreduce(group=None, loopback: bool = False) -> GradAllReduce:
     """Returns f(flat_grad) -> grad_scale: sums the flat gradient buffer over ranks in place (one bucket) and returns
     the 1/world factor that swn_adam_step applies; f.begin / f.finish: the overlapped two-part form (GradAllReduce)."""
-    return GradAllReduce(group)
+    return GradAllReduce(group, loopback)
 
 
 
@@ -163,7 +174,7 @@ class ExpertParallel:
     world == 1 degenerates to the identity (no process group needed): the single-GPU parity test runs this path.
     """
 
-    def __init__(self, rank: int, world: int, n_experts: int, group=None, padded=False):
+    def __init__(self, rank: int, world: int, n_experts: int, group=None, padded=False, loopback: bool = False):
         """padded: False = kept rows only, unequal splits sized on the host (one device-to-host read per forward pass: the step cannot
         be captured into a hipGraph); True = the reference's own layout (tutel_moe_layer_nobatch.py:157: every (expert, capacity slot)
         travels, empty slots as zero rows) with EQUAL splits - nothing is read on the host, so the whole step, collectives included,
@@ -173,6 +184,10 @@ class ExpertParallel:
             raise ValueError(f"expert parallelism needs world ({world}) to divide the expert count ({n_experts})")
         self.rank, self.world, self.E, self.El, self.group = rank, world, n_experts, n_experts // world, group
         self.padded = padded
+        # local: ONE rank and no process group - nothing moves, the send buffers ARE the receive buffers.  loopback (one rank WITH a
+        # process group, init_from_env(loopback=True)): every collective is issued like at W > 1 - separate send / receive buffers,
+        # side stream, split sizes - and RCCL moves the payload inside the GPU: the W > 1 code path on a one-GPU box
+        self.local = world == 1 and not (loopback and dist.is_initialized())
 
     PAD_AUTO_BYTES = 64 << 20
 
@@ -215,7 +230,7 @@ class ExpertParallel:
         of the (source rank, local expert) groups, packed, and their sizes.  Way back: pass the counts received on the way in as
         `recv_counts` - the split sizes are swapped and `group_counts` must be what this rank holds per (source rank, local expert)."""
         W, El = self.world, self.El
-        if W == 1:
+        if self.local:
             return rows, group_counts
         if recv_counts is None:
             recv_counts = torch.empty_like(group_counts)
@@ -248,7 +263,7 @@ class ExpertParallel:
         """Unequal-split all-to-all of packed rows (dim 0): chunk r of `send` (in_splits[r] rows) goes to rank r, `recv` receives
         out_splits[w] rows from rank w.  Only rows that exist travel (20 % fewer bytes than the capacity-padded payload at 80 % kept
         rows).  Same stream semantics as all_to_all; returns wait()."""
-        if self.world == 1:
+        if self.local:
             assert recv.data_ptr() == send.data_ptr()
             return lambda: None
         row_bytes = (send.numel() // max(1, send.shape[0])) * send.element_size()
@@ -299,7 +314,7 @@ class ExpertParallel:
         recv.  With `stream` (a side HIP stream) the collective is ordered after the work already queued on the current
         stream and runs concurrently with what the caller queues next.  out: receive buffer (same shape; world == 1: must be
         `send` itself or None - nothing moves)."""
-        if self.world == 1:
+        if self.local:
             assert out is None or out.data_ptr() == send.data_ptr()
             return send, (lambda: None)
         recv = torch.empty_like(send) if out is None else out

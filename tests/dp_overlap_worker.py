@@ -1,7 +1,9 @@
-"""Launched by tests/test_parallel_gpu.py under torchrun (two ranks sharing cuda:0, gloo): the data-parallel step with the backward
+"""Launched by tests/test_parallel_gpu.py under torchrun (two ranks sharing cuda:0, gloo) and by tests/test_rccl_gpu.py (ONE rank,
+backend nccl = RCCL, loopback: `dp_overlap_worker.py nccl 50`): the data-parallel step with the backward
 cut in two captured graphs and the all-reduce of the expert block issued on the side stream between them (graph.GraphedTrainStep,
 split_backward = what DDP's gradient buckets do in the reference, runner.py:203-207) must train bit-identically to (a) the single-graph
-step with one all-reduce behind the whole backward and (b) the eager step - three optimizer steps, every parameter and Adam moment."""
+step with one all-reduce behind the whole backward and (b) the eager step - three optimizer steps (argv[2]: more), every parameter and
+Adam moment."""
 import os
 import sys
 
@@ -18,8 +20,13 @@ from switch_nerf_amd.model import SwitchNeRF  # noqa: E402
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
-parallel.init_from_env("gloo", dev)
-allreduce = parallel.make_grad_allreduce()
+backend = sys.argv[1] if len(sys.argv) > 1 else "gloo"
+n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+loop = world == 1           # one rank: the collectives are issued anyway (parallel.init_from_env(loopback=True))
+parallel.init_from_env(backend, dev, loopback=loop)
+assert torch.distributed.is_initialized() and torch.distributed.get_backend() == backend
+allreduce = parallel.make_grad_allreduce(loopback=loop)
+assert allreduce.active
 N, S, chunk = 128, 64, 2048
 batches = []
 for it in range(3):
@@ -38,7 +45,8 @@ for mode in ("eager", "one_graph", "split"):
                                 split_backward=(mode == "split"))
         assert step.split == (mode == "split") and (step.graph_b is not None) == (mode == "split")
     allreduce.profile = mode == "split"
-    for rays, img, rgbs in batches:
+    for it in range(n_steps):
+        rays, img, rgbs = batches[it % 3]
         if step is None:
             m.train_step(rgbs, rays, img, S, chunk, perturb=0.0, grad_allreduce=allreduce)
         else:
@@ -46,15 +54,16 @@ for mode in ("eager", "one_graph", "split"):
     torch.cuda.synchronize()
     rep = allreduce.report()
     if mode == "split":
-        assert rep["collectives"] == 2 * len(batches), rep          # expert block + dense prefix per step
+        assert rep["collectives"] == 2 * n_steps, rep               # expert block + dense prefix per step
     out[mode] = (m.flat.clone(), m.m.clone(), m.v.clone(), m.step_count)
 ok = True
 for mode in ("one_graph", "split"):
     for a, b in zip(out["eager"][:3], out[mode][:3]):
         ok &= bool(torch.equal(a, b))
-    ok &= out[mode][3] == out["eager"][3] == 3
+    ok &= out[mode][3] == out["eager"][3] == n_steps
 moved = all(bool((out[mode][0] != flat0).any()) for mode in out)       # the optimizer steps changed the parameters in every mode
-print(f"DP_OVERLAP rank {rank}: {'OK' if ok and moved else 'MISMATCH'}", flush=True)
+ok &= allreduce.stale_drains == 0
+print(f"DP_OVERLAP rank {rank} ({backend}, {n_steps} steps): {'OK' if ok and moved else 'MISMATCH'}", flush=True)
 torch.distributed.barrier()
 torch.distributed.destroy_process_group()
 sys.exit(0 if ok and moved else 1)

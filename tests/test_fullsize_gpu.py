@@ -124,7 +124,7 @@ def test_full_batch_bf16_properties():
     d5 = (c5["rgb"] - rgb16[s5]).abs().max().item()
     print(f"full batch bf16: segment 5 alone vs inside the 16-segment launch: routing identical, max |rgb difference| {d5:.2e}")
     assert d5 < 2e-3
-    # the same batch on the other expert-chain geometries (SWN_CHAIN_GEOM is read per forward).  5 = the phase-shifted 256-row
+    # the same batch on the other expert-chain geometries (SwitchNeRF.set_kernel_switches).  5 = the phase-shifted 256-row
     # workgroup with the bias added in the epilogue, 6 = its persistent form and 2 = the lockstep 256-row workgroup are BIT-identical to
     # the 64-row kernels (1); the default (7: persistent) and 4 start their accumulators at the bias: same sums, a different fp32
     # rounding order - and are bit-identical to each other, gradients included.  The DEFAULT launch also carries the dense tail (layer
@@ -133,13 +133,11 @@ def test_full_batch_bf16_properties():
     import os
     runs = {}
     for geom in ("1", "5", "2", "6", "4", "7"):
-        os.environ["SWN_CHAIN_GEOM"] = geom
-        os.environ["SWN_FUSED_TAIL"] = "0"
+        prev = m16.set_kernel_switches(chain_geom=int(geom), fused_tail=False)
         try:
             stg = m16.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=1.0, perturb_rand=pr, sigma_noise=noise, optimizer_step=False)
         finally:
-            os.environ.pop("SWN_CHAIN_GEOM")
-            os.environ.pop("SWN_FUSED_TAIL")
+            m16.set_kernel_switches(**prev)
         assert stg["ctx"]["geom"] == int(geom) and not stg["ctx"]["tail_fused"]
         runs[geom] = (stg["ctx"]["idx"].clone(), stg["ctx"]["rgb"].clone(), m16.grad.clone())
     assert torch.equal(runs["4"][0], runs["7"][0]) and torch.equal(runs["4"][1], runs["7"][1]) and torch.equal(runs["4"][2], runs["7"][2]), \

@@ -49,6 +49,14 @@ def test_hash_encode_fwd_bwd_vs_oracle():
     ops.hash_encode_bwd(_dev(rays), _dev(z.numpy()), _dev(d_out), HC, d_table)
     r = tt.grad.numpy()
     np.testing.assert_allclose(d_table.cpu().numpy(), r, rtol=1e-4, atol=1e-5 * np.abs(r).max())
+    # the fallback of a table whose per-XCD copies would exceed the workspace budget (ops.HASH_XCD_MB): the same gradient
+    prev, ops.HASH_XCD_MB = ops.HASH_XCD_MB, 0
+    try:
+        d_plain = torch.zeros(table.shape, device="cuda")
+        ops.hash_encode_bwd(_dev(rays), _dev(z.numpy()), _dev(d_out), HC, d_plain)
+    finally:
+        ops.HASH_XCD_MB = prev
+    np.testing.assert_allclose(d_plain.cpu().numpy(), r, rtol=1e-4, atol=1e-5 * np.abs(r).max())
     # points outside the bounding box clamp to its faces
     far = rays.copy()
     far[:, :3] += 10.0

@@ -142,3 +142,38 @@ def test_moe_layer_gate_noise_vs_reference_golden_fp32():
     with pytest.raises(NotImplementedError):
         moe_layer(gate_type=dict(type="top", k=1, use_load_importance_loss=True), model_dim=256,
                   experts=dict(type="expertmlp", count_per_node=8, layer_num=7))
+
+
+def test_moe_layer_normal_noise_vs_reference_golden_fp32():
+    """use_normal_noise (tutel_moe_layer_nobatch.py:116-117: `logits + randn / E` in training) together with --gate_noise: against the
+    REFERENCE layer's own run with both of its draws replayed (oracle/gen_golden.py::gen_moe_layer_normal_noise): top-1 indices
+    bit-exact, y, l_aux and the gradients; the two additive terms reach the router kernel as one noise operand."""
+    g = np.load(os.path.join(G, "moe_layer_normal_noise_m256e8.npz"))
+    seed, P, gn = int(g["seed"]), int(g["P"]), float(g["gate_noise"])
+    from switch_nerf_amd.moe import moe_layer
+    cfg = synth.BUILDING
+    moe = moe_layer(gate_type=dict(type="top", k=1, fp32_gate=True, capacity_factor=1.0, batch_prioritized_routing=True, gate_noise=gn,
+                                   use_normal_noise=True, gate_dim=cfg["gate_hidden"]), model_dim=cfg["model_dim"],
+                    experts=dict(type="expertmlp", count_per_node=cfg["num_experts"], hidden_size_per_expert=cfg["model_dim"],
+                                 layer_num=cfg["expert_layers"], skips=list(cfg["skips"])), seeds=(1, 1, 1), return_gates=True,
+                    dtype=torch.float32).cuda()
+    _load(moe, seed)
+    moe.train()
+    rng = np.random.default_rng(seed + 1000)
+    x = rng.standard_normal((P, 256)).astype(np.float32)
+    gi = rng.standard_normal((P, 256)).astype(np.float32)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    gt = torch.from_numpy(gi).cuda().requires_grad_(True)
+    y = moe(xt, gate_input=gt, gate_noise_draw=torch.from_numpy(g["noise"]), normal_noise_draw=torch.from_numpy(g["normal_noise"]))
+    np.testing.assert_array_equal(y.gate_extras["gates"].cpu().numpy().reshape(-1), g["topk"].reshape(-1))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["y"], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(y.l_aux.item(), float(g["l_aux"]), rtol=1e-6)
+    dy = rng.standard_normal((P, 256)).astype(np.float32)
+    (y * torch.from_numpy(dy).cuda()).sum().backward()
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), g["dx"], rtol=1e-3, atol=2e-4 * np.abs(g["dx"]).max())
+    np.testing.assert_allclose(gt.grad.cpu().numpy(), g["dgate_input"], rtol=1e-3, atol=2e-4 * np.abs(g["dgate_input"]).max())
+    np.testing.assert_allclose(moe.gates[0].wg.weight.grad.cpu().numpy(), g["dwg"], rtol=1e-3, atol=5e-4 * np.abs(g["dwg"]).max())
+    moe.eval()                   # evaluation: neither noise
+    with torch.no_grad():
+        ye = moe(xt, gate_input=gt)
+    assert (ye.gate_extras["gates"].cpu().numpy().reshape(-1) != g["topk"].reshape(-1)).any()

@@ -151,6 +151,34 @@ def test_moe_layer_gate_noise_vs_reference():
     np.testing.assert_allclose(gl[1].numpy(), g["laux_dwg"], rtol=0, atol=1e-7)
 
 
+def test_moe_layer_normal_noise_vs_reference():
+    """use_normal_noise (tutel_moe_layer_nobatch.py:116-117) together with gate noise: the fixture carries both draws of the reference
+    layer's own run (normal noise first, gate noise second); the oracle reproduces expert choice, output, l_aux and the gradients."""
+    g = load("moe_layer_normal_noise_m256e8")
+    cfg = synth.BUILDING
+    seed, P, gn = int(g["seed"]), int(g["P"]), float(g["gate_noise"])
+    p = O.params_from_numpy(synth.make_weights(seed, cfg), requires_grad=True)
+    rng = np.random.default_rng(seed + 1000)
+    x = torch.from_numpy(rng.standard_normal((P, cfg["model_dim"])).astype(np.float32)).requires_grad_(True)
+    gi = torch.from_numpy(rng.standard_normal((P, cfg["gate_hidden"])).astype(np.float32)).requires_grad_(True)
+    L = cfg["expert_layers"]
+    W = [p[f"layers.0.experts.0.weights.{l}"] for l in range(L)]
+    B = [p[f"layers.0.experts.0.bias.{l}"] for l in range(L)]
+    wg = p["layers.0.gates.0.wg.weight"]
+    y, l_aux, routing, _ = O.moe_layer(x, gi, wg, W, B, cfg["skips"], 1.0, True, gate_noise=gn, noise=torch.from_numpy(g["noise"]),
+                                       normal_noise=torch.from_numpy(g["normal_noise"]))
+    assert np.array_equal(routing["idx"], g["topk"].reshape(-1))
+    _, _, r0, _ = O.moe_layer(x, gi, wg, W, B, cfg["skips"], 1.0, True, gate_noise=gn, noise=torch.from_numpy(g["noise"]))
+    assert not np.array_equal(r0["idx"], routing["idx"])                 # (the normal noise moves expert choices in this fixture)
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(l_aux.detach().numpy(), g["l_aux"], rtol=1e-6)
+    dy = torch.from_numpy(rng.standard_normal(y.shape).astype(np.float32))
+    (y * dy).sum().backward(retain_graph=True)
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(gi.grad.numpy(), g["dgate_input"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(wg.grad.numpy(), g["dwg"], rtol=0, atol=2e-5)
+
+
 @pytest.mark.parametrize("tag", ["unbalanced", "balanced"])
 def test_model_forward(tag):
     g = load(f"model_fwd_{tag}")
