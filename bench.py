@@ -766,7 +766,9 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if dist:
-        dist.destroy_process_group()
+        graphed[0] = None
+        from switch_nerf_amd import parallel as _par
+        _par.shutdown()
 
 
 def self_launch(n: int):

@@ -254,6 +254,16 @@ int swn_hash_encode_bwd(const float* rays, const float* z, int n_rays, int n_sam
  * workgroup's atomics go to the copy of the XCD it runs on (HW_REG_XCC_ID) and a second kernel adds the copies into d_table.        */
 int swn_hash_encode_bwd_xcd(const float* rays, const float* z, int n_rays, int n_samples, const swn_hash_cfg* cfg,
                             const void* d_out, int dtype, int d_stride, float* d_table, float* xcd_tables, void* stream);
+/* The same gradient WITHOUT global float atomics, bit-deterministic (round 6): every (corner, level) contribution is an item binned by
+ * table tile (2^13 entries) into `workspace`, then one workgroup per tile adds its items in fixed point (int64, scaled by the power of
+ * two of max |d_out|: an item is exact to 2^-38 of the largest gradient - tighter than an fp32 running sum) in LDS and adds the tile into
+ * d_table as its only writer.  Four launches (count, scan, scatter, tiles) + two small fills; 12 bytes of workspace traffic per item each
+ * way.  Tables of more than 2^22 entries per level are rejected (use swn_hash_encode_bwd).  A non-finite d_out makes the touched entries NaN.
+ *   workspace: swn_hash_bwd_workspace_bytes(n_rays * n_samples, cfg) bytes (3.2 GB for 2M points x 16 levels), any contents.          */
+size_t swn_hash_bwd_workspace_bytes(long n_points, const swn_hash_cfg* cfg);
+int swn_hash_encode_bwd_binned(const float* rays, const float* z, int n_rays, int n_samples, const swn_hash_cfg* cfg,
+                               const void* d_out, int dtype, int d_stride, float* d_table, void* workspace, size_t workspace_bytes,
+                               void* stream);
 
 /* ---- background model + foreground bound (render_rays' bg_nerf branch, /root/reference/switch_nerf/rendering.py:32-159) ---
  * swn_fg_bounds: _intersect_sphere (:497-518) per ray against the ellipsoid (center, radius: 3 floats each in HOST memory,

@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-VARIANTS = ["allreduce_sync", "allgather_sync", "reduce_scatter_sync", "a2a_sync_eager", "a2a_sync", "a2a_list", "p2p_batch", "a2a_async_same_stream",
+VARIANTS = ["allreduce_sync", "allgather_sync", "reduce_scatter_sync", "a2a_sync_eager", "a2a_sync", "a2a_sync_delgraph", "a2a_sync_abort", "ep_all_to_all_v_workaround", "a2a_list", "p2p_batch", "a2a_async_same_stream",
             "a2a_async_side_stream", "a2a_sync_side_stream", "ep_all_to_all_v", "ep_exchange_counts", "ep_all_to_all_v_eager"]
 
 
@@ -32,7 +32,7 @@ def run(variant):
         if variant == "allreduce_sync":
             dist.all_reduce(x)
             y.copy_(x)
-        elif variant in ("a2a_sync", "a2a_sync_eager"):
+        elif variant in ("a2a_sync", "a2a_sync_eager", "a2a_sync_delgraph", "a2a_sync_abort"):
             dist.all_to_all_single(y, x)
         elif variant == "allgather_sync":
             dist.all_gather_into_tensor(y, x)
@@ -61,7 +61,7 @@ def run(variant):
                 w.wait()
             else:
                 torch.cuda.current_stream().wait_event(done)
-        elif variant in ("ep_all_to_all_v", "ep_all_to_all_v_eager"):
+        elif variant in ("ep_all_to_all_v", "ep_all_to_all_v_eager", "ep_all_to_all_v_workaround"):
             ep.all_to_all_v(x, [4096], y, [4096], side)()
         elif variant == "ep_exchange_counts":
             out["rc"] = ep.exchange_counts(counts, 256, side)()
@@ -87,14 +87,23 @@ def run(variant):
     torch.cuda.synchronize()
     good = torch.equal(y, x) if variant != "ep_exchange_counts" else torch.equal(out["rc"], counts.clamp(max=256))
     print(f"RESULT {variant}: {'OK' if good else 'WRONG'}", flush=True)
+    if variant.endswith("_delgraph"):
+        import gc
+        del g
+        gc.collect()
+        torch.cuda.synchronize()
+    if variant.endswith("_abort"):
+        sys.stdout.flush()
+        os._exit(0)
     dist.destroy_process_group()
+    print(f"{variant}: process group destroyed", flush=True)
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1:
+    if len(sys.argv) == 2 and sys.argv[1] != "--only":
         run(sys.argv[1])
     else:
-        for v in VARIANTS:
+        for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else VARIANTS):
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), v], capture_output=True, text=True, timeout=120)
                 rc, so, se = r.returncode, r.stdout, r.stderr

@@ -101,6 +101,7 @@ SIGNATURES = {
     "swn_hash_encode_fwd": [vp, vp, i32, i32, C.POINTER(HashCfg), vp, i32, vp, i32, vp],
     "swn_hash_encode_bwd": [vp, vp, i32, i32, C.POINTER(HashCfg), vp, i32, i32, vp, vp],
     "swn_hash_encode_bwd_xcd": [vp, vp, i32, i32, C.POINTER(HashCfg), vp, i32, i32, vp, vp, vp],
+    "swn_hash_encode_bwd_binned": [vp, vp, i32, i32, C.POINTER(HashCfg), vp, i32, i32, vp, vp, sz, vp],
     "swn_gather_rows": [vp, vp, i64, i32, vp, vp],
     "swn_mlp_chain": [C.POINTER(ChainDesc), vp],
     "swn_chain_big_ok": [C.POINTER(ChainDesc)],
@@ -167,6 +168,8 @@ def load():
     lib.swn_ray_feat_wgrad_workspace_bytes.argtypes = [i32, i32, i32]
     lib.swn_chain_dwsig_workspace_bytes.restype = sz
     lib.swn_chain_dwsig_workspace_bytes.argtypes = [i32, i32]
+    lib.swn_hash_bwd_workspace_bytes.restype = sz
+    lib.swn_hash_bwd_workspace_bytes.argtypes = [i64, C.POINTER(HashCfg)]
     lib.swn_chain_mask_words.restype = i64
     lib.swn_chain_mask_words.argtypes = [i32, i32, i32, i32]
     for name, args in SIGNATURES.items():

@@ -170,6 +170,250 @@ __global__ __launch_bounds__(256) void hash_reduce_kernel(float* __restrict__ pr
   *(float4*)(d_table + i) = a;
 }
 
+
+// =================================================================================================================================
+// Backward WITHOUT global atomics (round 6): bin, then accumulate in LDS.
+//
+// The atomic kernel above issues ~270 M fp32 atomics per 2M-point batch (16 levels x 8 corners x 2 features per point) and runs at the
+// L2's atomic rate (~18 G/s: 15 of the 29.6 ms of configs[4]'s recipe), wherever the lines live (r05_experiments.md 4).  Here a
+// contribution (entry, wk g0, wk g1) is an ITEM; the gradient table is cut into TILES of 2^13 entries (128 KiB of LDS as 2 x int64 per
+// entry); tile t = level * tiles_per_level + (entry >> 13):
+//   count    one workgroup per (512 points, level): the items per tile (LDS histogram -> int atomics, 2M per launch) and max |d_out|
+//   scan     exclusive prefix over the tiles -> every tile's item range in the workspace
+//   scatter  the same workgroups again: items binned by tile in LDS, ONE cursor atomic per (workgroup, tile), bin runs written with
+//            consecutive lanes (three 4-byte arrays: local entry, c0, c1 - 12 bytes per item, 3.2 GB at 2M points)
+//   tiles    one workgroup per tile: its items are added into the LDS tile in FIXED POINT (int64, scale 2^(38 - exponent of max |d_out|):
+//            an item is exact to 2^-38 of the largest gradient, 2^24 items cannot overflow) - integer addition is associative, so the
+//            result does not depend on the order the items arrive in: the table gradient is BIT-DETERMINISTIC (the fp32 atomics were
+//            not) - and the tile is added to d_table by its only owner, no atomics.
+// Dense (coarse) levels keep the wave-level run merge of the atomic kernel: consecutive samples of a ray that share a cell emit one item
+// per corner, which also keeps the few tiles of a coarse level from receiving 16 M items each.
+// =================================================================================================================================
+constexpr int HB_TILE_LOG2 = 13, HB_TILE = 1 << HB_TILE_LOG2;
+constexpr int HB_PTS = 512;              // points per workgroup of the count / scatter passes (256 threads x 2)
+constexpr int HB_MAX_TPL = 512;          // tiles per level the scatter pass bins in LDS (T <= 2^22); larger tables take the atomic kernel
+constexpr int HB_ITEMS = HB_PTS * 8;     // items of a workgroup (one level)
+
+struct HashBin {
+  uint32_t* count;      // [n_tiles]      items per tile (count pass)
+  uint32_t* begin;      // [n_tiles + 1]  exclusive prefix
+  uint32_t* cursor;     // [n_tiles]      scatter pass: items of the tile written so far
+  uint32_t* gmax_bits;  // [1]            max |d_out| as float bits (NaN / inf compare above every finite value)
+  uint32_t* loc;        // [items]        entry & (HB_TILE - 1)
+  float* c0;            // [items]
+  float* c1;            // [items]
+  int tpl;              // tiles per level
+  int n_tiles;
+};
+
+// the items of one point at one level: emit(entry, c0, c1) per corner.  Dense levels: the lanes of a wave that share a cell form runs,
+// the run's sums come out of its tail lane (all 64 lanes must call; lanes past the end carry zero gradient and the last point's cell).
+template <bool COUNT_ONLY, typename F>
+__device__ __forceinline__ void hash_items(const HashLevels& h, int l, const float (&x)[3], float g0, float g1, bool live, int lane, F emit) {
+#pragma clang fp contract(off)
+  uint32_t c0[3];
+  float w[3];
+  bool head = lane == 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float pos = x[c] * h.scale[l] + 0.5f;
+    const float fl = floorf(pos);
+    c0[c] = (uint32_t)fl;
+    w[c] = pos - fl;
+    head = head || (__shfl_up(c0[c], 1, 64) != c0[c]);
+  }
+  if (h.dense[l]) {
+    const uint64_t heads = __ballot(head);
+    const uint64_t below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    const int start = 63 - __clzll((long long)below);
+    const uint64_t above = lane == 63 ? 0ull : (heads >> (lane + 1));
+    const bool tail = above == 0ull ? lane == 63 : (__ffsll((long long)above) == 1);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+      float t0 = 0.f, t1 = 0.f;
+      if constexpr (!COUNT_ONLY) {
+        const float wk = ((dx ? w[0] : 1.f - w[0]) * (dy ? w[1] : 1.f - w[1])) * (dz ? w[2] : 1.f - w[2]);
+        t0 = run_inclusive_scan(wk * g0, lane, start);
+        t1 = run_inclusive_scan(wk * g1, lane, start);
+      }
+      if (tail) emit(hash_entry(h, l, c0[0] + dx, c0[1] + dy, c0[2] + dz), t0, t1);
+    }
+  } else if (live) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+      const float wk = ((dx ? w[0] : 1.f - w[0]) * (dy ? w[1] : 1.f - w[1])) * (dz ? w[2] : 1.f - w[2]);
+      emit(hash_entry(h, l, c0[0] + dx, c0[1] + dy, c0[2] + dz), wk * g0, wk * g1);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void hash_bin_count_kernel(const float* __restrict__ rays, const float* __restrict__ z, int n_rays, int S,
+                                                             HashLevels h, const T* __restrict__ d_out, int d_stride, HashBin b) {
+  __shared__ uint32_t hist[HB_MAX_TPL];
+  const int tid = threadIdx.x, lane = tid & 63, l = blockIdx.y;
+  const long total = (long)n_rays * S;
+  for (int i = tid; i < b.tpl; i += 256) hist[i] = 0;
+  __syncthreads();
+  float gm = 0.f;
+#pragma unroll
+  for (int j = 0; j < HB_PTS / 256; ++j) {
+    const long p_raw = (long)blockIdx.x * HB_PTS + j * 256 + tid;
+    const bool live = p_raw < total;
+    const long p = live ? p_raw : total - 1;
+    float x[3];
+    point_of(rays, z, p, S, h, x);
+    if (live) {        // max |d_out| of the level's two columns (NaN propagates: fmaxf would drop it, the bit pattern compare does not)
+      const float a0 = fabsf(ElemIO<T>::ld(d_out + p * d_stride + 2 * l)), a1 = fabsf(ElemIO<T>::ld(d_out + p * d_stride + 2 * l + 1));
+      const uint32_t u = max(__float_as_uint(a0), __float_as_uint(a1));
+      gm = __uint_as_float(max(__float_as_uint(gm), u));
+    }
+    hash_items<true>(h, l, x, 0.f, 0.f, live, lane, [&](uint32_t e, float, float) { atomicAdd(&hist[e >> HB_TILE_LOG2], 1u); });
+  }
+  uint32_t gu = __float_as_uint(gm);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gu = max(gu, (uint32_t)__shfl_xor((int)gu, o, 64));
+  if (lane == 0 && gu) atomicMax(b.gmax_bits, gu);
+  __syncthreads();
+  for (int i = tid; i < b.tpl; i += 256)
+    if (hist[i]) atomicAdd(b.count + l * b.tpl + i, hist[i]);
+}
+
+// begin[t] = items of the tiles before t (one workgroup; n_tiles <= 16 * 512); cursor = 0
+__global__ __launch_bounds__(256) void hash_bin_scan_kernel(HashBin b) {
+  __shared__ uint32_t part[256];
+  const int tid = threadIdx.x;
+  const int per = (b.n_tiles + 255) / 256;
+  uint32_t s = 0;
+  for (int i = 0; i < per; ++i) { const int t = tid * per + i; if (t < b.n_tiles) s += b.count[t]; }
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) { uint32_t run = 0; for (int i = 0; i < 256; ++i) { const uint32_t v = part[i]; part[i] = run; run += v; } b.begin[b.n_tiles] = run; }
+  __syncthreads();
+  uint32_t run = part[tid];
+  for (int i = 0; i < per; ++i) {
+    const int t = tid * per + i;
+    if (t < b.n_tiles) { b.begin[t] = run; run += b.count[t]; b.cursor[t] = 0; }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void hash_bin_scatter_kernel(const float* __restrict__ rays, const float* __restrict__ z, int n_rays, int S,
+                                                               HashLevels h, const T* __restrict__ d_out, int d_stride, HashBin b) {
+  __shared__ uint32_t hist[HB_MAX_TPL];       // items per bin, then the bin's first staging slot
+  __shared__ uint32_t gbase[HB_MAX_TPL];      // the bin's first global slot
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t s_loc[HB_ITEMS];        // (bin << 13) | local entry
+  __shared__ float s_c0[HB_ITEMS], s_c1[HB_ITEMS];
+  const int tid = threadIdx.x, lane = tid & 63, l = blockIdx.y;
+  const long total = (long)n_rays * S;
+  for (int i = tid; i < b.tpl; i += 256) hist[i] = 0;
+  __syncthreads();
+  // pass 1: the items into registers, their rank inside their bin from the LDS histogram
+  uint32_t it_e[HB_PTS / 256][8], it_r[HB_PTS / 256][8];
+  float it_0[HB_PTS / 256][8], it_1[HB_PTS / 256][8];
+  int it_n[HB_PTS / 256];
+#pragma unroll
+  for (int j = 0; j < HB_PTS / 256; ++j) {
+    const long p_raw = (long)blockIdx.x * HB_PTS + j * 256 + tid;
+    const bool live = p_raw < total;
+    const long p = live ? p_raw : total - 1;
+    float x[3];
+    point_of(rays, z, p, S, h, x);
+    const float g0 = live ? ElemIO<T>::ld(d_out + p * d_stride + 2 * l) : 0.f, g1 = live ? ElemIO<T>::ld(d_out + p * d_stride + 2 * l + 1) : 0.f;
+    int n = 0;
+    hash_items<false>(h, l, x, g0, g1, live, lane, [&](uint32_t e, float a0, float a1) {
+      it_e[j][n] = e; it_0[j][n] = a0; it_1[j][n] = a1;
+      it_r[j][n] = atomicAdd(&hist[e >> HB_TILE_LOG2], 1u);
+      ++n;
+    });
+    it_n[j] = n;
+  }
+  __syncthreads();
+  // exclusive prefix over the bins (tpl <= 512 = 2 per thread), global ranges from the tiles' cursors
+  {
+    const uint32_t a = 2 * tid < b.tpl ? hist[2 * tid] : 0u, c = 2 * tid + 1 < b.tpl ? hist[2 * tid + 1] : 0u;
+    uint32_t v = a + c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)v, o, 64); if (lane >= o) v += t; }
+    if (lane == 63) wsum[tid >> 6] = v;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int q = 0; q < (tid >> 6); ++q) base += wsum[q];
+    const uint32_t ex = base + v - (a + c);
+    __syncthreads();
+    if (2 * tid < b.tpl) {
+      hist[2 * tid] = ex;
+      gbase[2 * tid] = a ? b.begin[l * b.tpl + 2 * tid] + atomicAdd(b.cursor + l * b.tpl + 2 * tid, a) : 0u;
+    }
+    if (2 * tid + 1 < b.tpl) {
+      hist[2 * tid + 1] = ex + a;
+      gbase[2 * tid + 1] = c ? b.begin[l * b.tpl + 2 * tid + 1] + atomicAdd(b.cursor + l * b.tpl + 2 * tid + 1, c) : 0u;
+    }
+  }
+  __syncthreads();
+  // pass 2: items -> staging, grouped by bin
+#pragma unroll
+  for (int j = 0; j < HB_PTS / 256; ++j)
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < it_n[j]) {
+        const uint32_t bin = it_e[j][k] >> HB_TILE_LOG2;
+        const uint32_t slot = hist[bin] + it_r[j][k];
+        s_loc[slot] = (bin << HB_TILE_LOG2) | (it_e[j][k] & (HB_TILE - 1));
+        s_c0[slot] = it_0[j][k];
+        s_c1[slot] = it_1[j][k];
+      }
+  __syncthreads();
+  const uint32_t n_items = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  for (uint32_t i = tid; i < n_items; i += 256) {     // consecutive lanes -> consecutive slots of a bin run -> consecutive addresses
+    const uint32_t v = s_loc[i], bin = v >> HB_TILE_LOG2;
+    const uint32_t dst = gbase[bin] + (i - hist[bin]);
+    b.loc[dst] = v & (HB_TILE - 1);
+    b.c0[dst] = s_c0[i];
+    b.c1[dst] = s_c1[i];
+  }
+}
+
+// one workgroup per tile: fixed-point accumulation in LDS, then d_table += tile (the tile's only writer)
+__global__ __launch_bounds__(512) void hash_bin_tiles_kernel(HashLevels h, HashBin b, float* __restrict__ d_table) {
+  extern __shared__ long long tile[];       // [HB_TILE][2]
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const uint32_t i0 = b.begin[t], i1 = b.begin[t + 1];
+  if (i0 == i1) return;
+  const int l = t / b.tpl, sub = t - l * b.tpl;
+  const uint32_t T = h.table_mask + 1u;
+  const int n_ent = (int)min((uint32_t)HB_TILE, T - (uint32_t)sub * HB_TILE);
+  for (int i = tid; i < 2 * n_ent; i += 512) tile[i] = 0;
+  // scale = 2^(38 - e) with 2^e <= max |d_out| < 2^(e + 1): |item| < 2^39 exactly representable steps of 2^(e - 38)
+  const uint32_t gb = *b.gmax_bits;
+  const bool bad = gb >= 0x7f800000u;                        // inf / NaN upstream: the tile's entries become NaN
+  int ex = (int)(gb >> 23) - 127;
+  if (gb < 0x00800000u) ex = -126;                           // (zero / denormal maximum)
+  const float up = ldexpf(1.f, max(-126, min(127, 38 - ex)));       // (two factors: 2^(38 - e) can exceed the float range for tiny maxima)
+  const float up2 = ldexpf(1.f, (38 - ex) - max(-126, min(127, 38 - ex)));
+  __syncthreads();
+  for (uint32_t i = i0 + tid; i < i1; i += 512) {
+    const uint32_t e = b.loc[i];
+    const float a0 = b.c0[i] * up * up2, a1 = b.c1[i] * up * up2;
+    atomicAdd((unsigned long long*)&tile[2 * e], (unsigned long long)__float2ll_rn(a0));
+    atomicAdd((unsigned long long*)&tile[2 * e + 1], (unsigned long long)__float2ll_rn(a1));
+  }
+  __syncthreads();
+  const double down = ldexp(1.0, ex - 38);
+  float2* dst = (float2*)(d_table + (long)l * h.level_stride) + (long)sub * HB_TILE;
+  for (int e = tid; e < n_ent; e += 512) {
+    const long long s0 = tile[2 * e], s1 = tile[2 * e + 1];
+    if (!bad && s0 == 0 && s1 == 0) continue;
+    float2 v = dst[e];
+    v.x += bad ? __uint_as_float(0x7fc00000u) : (float)((double)s0 * down);
+    v.y += bad ? __uint_as_float(0x7fc00000u) : (float)((double)s1 * down);
+    dst[e] = v;
+  }
+}
+
 }  // namespace swn
 
 using namespace swn;
@@ -249,6 +493,63 @@ extern "C" int swn_hash_encode_bwd_xcd(const float* rays, const float* z, int n_
   if (xcd_tables)
     hipLaunchKernelGGL(hash_reduce_kernel, dim3(cdiv(table_elems / 4, 256)), dim3(256), 0, as_stream(stream), xcd_tables, table_elems, 8,
                        table_elems, d_table);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- binned backward (no global float atomics; bit-deterministic) ----
+static size_t hb_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t swn_hash_bwd_workspace_bytes(long n_points, const swn_hash_cfg* cfg) {
+  if (!cfg || n_points <= 0) return 0;
+  const long T = 1L << cfg->log2_table;
+  const long tpl = T > HB_TILE ? T / HB_TILE : 1;
+  const long n_tiles = (long)cfg->n_levels * tpl;
+  const size_t items = (size_t)n_points * 8 * (size_t)cfg->n_levels;
+  return 3 * hb_align((size_t)(n_tiles + 1) * 4) + 256 + 3 * hb_align(items * 4);
+}
+
+extern "C" int swn_hash_encode_bwd_binned(const float* rays, const float* z, int n_rays, int n_samples, const swn_hash_cfg* cfg,
+                                          const void* d_out, int dtype, int d_stride, float* d_table, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_hash_encode_bwd_binned: bad dtype");
+  SWN_CHECK(rays && z && d_out && d_table && workspace, "swn_hash_encode_bwd_binned: null pointer");
+  HashLevels h;
+  if (make_levels(cfg, &h)) return 1;
+  SWN_CHECK(d_stride >= 2 * h.n_levels, "swn_hash_encode_bwd_binned: d_stride %d", d_stride);
+  if (n_rays <= 0 || n_samples <= 0) return 0;
+  const long P = (long)n_rays * n_samples;
+  const long T = 1L << cfg->log2_table;
+  const long tpl = T > HB_TILE ? T / HB_TILE : 1;
+  SWN_CHECK(tpl <= HB_MAX_TPL, "swn_hash_encode_bwd_binned: tables of more than 2^22 entries take swn_hash_encode_bwd (log2_table %d)", cfg->log2_table);
+  SWN_CHECK((double)P * 8.0 * h.n_levels < 4294967296.0, "swn_hash_encode_bwd_binned: more than 2^32 items (%ld points)", P);
+  SWN_CHECK(workspace_bytes >= swn_hash_bwd_workspace_bytes(P, cfg), "swn_hash_encode_bwd_binned: workspace too small");
+  HashBin b;
+  b.tpl = (int)tpl;
+  b.n_tiles = h.n_levels * (int)tpl;
+  char* ws = (char*)workspace;
+  const size_t tb = hb_align((size_t)(b.n_tiles + 1) * 4), ib = hb_align((size_t)P * 8 * h.n_levels * 4);
+  b.count = (uint32_t*)ws; b.begin = (uint32_t*)(ws + tb); b.cursor = (uint32_t*)(ws + 2 * tb); b.gmax_bits = (uint32_t*)(ws + 3 * tb);
+  b.loc = (uint32_t*)(ws + 3 * tb + 256); b.c0 = (float*)(ws + 3 * tb + 256 + ib); b.c1 = (float*)(ws + 3 * tb + 256 + 2 * ib);
+  hipStream_t s = as_stream(stream);
+  hipError_t e = fill_u32_async(b.count, 0u, tb, s);                   // (a fill KERNEL: memset nodes misbehave in replayed graphs, common.hpp)
+  SWN_CHECK(e == hipSuccess, "fill: %s", hipGetErrorString(e));
+  e = fill_u32_async(b.gmax_bits, 0u, 256, s);
+  SWN_CHECK(e == hipSuccess, "fill: %s", hipGetErrorString(e));
+  const dim3 grid(cdiv(P, HB_PTS), h.n_levels);
+  if (dtype == SWN_HALF) hipLaunchKernelGGL((hash_bin_count_kernel<bf16_t>), grid, dim3(256), 0, s, rays, z, n_rays, n_samples, h, (const bf16_t*)d_out, d_stride, b);
+  else hipLaunchKernelGGL((hash_bin_count_kernel<float>), grid, dim3(256), 0, s, rays, z, n_rays, n_samples, h, (const float*)d_out, d_stride, b);
+  hipLaunchKernelGGL(hash_bin_scan_kernel, dim3(1), dim3(256), 0, s, b);
+  if (dtype == SWN_HALF) hipLaunchKernelGGL((hash_bin_scatter_kernel<bf16_t>), grid, dim3(256), 0, s, rays, z, n_rays, n_samples, h, (const bf16_t*)d_out, d_stride, b);
+  else hipLaunchKernelGGL((hash_bin_scatter_kernel<float>), grid, dim3(256), 0, s, rays, z, n_rays, n_samples, h, (const float*)d_out, d_stride, b);
+  static bool attr_set = false;
+  constexpr int TILE_LDS = HB_TILE * 2 * 8;
+  if (!attr_set) {
+    e = hipFuncSetAttribute((const void*)hash_bin_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS);
+    SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(hash_bin_tiles_kernel, dim3(b.n_tiles), dim3(512), TILE_LDS, s, h, b, d_table);
   SWN_LAUNCH_CHECK();
   return 0;
 }

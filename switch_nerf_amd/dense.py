@@ -174,8 +174,8 @@ class DenseNeRF(SwitchNeRF):
         c["y"] = c["acts"][L - 1]
         # ---- per-ray part of dir_a_encoding: [PE(dir), appearance embedding] @ W2r + b2 (nerf.py:173-181)
         c["ray_feat"], c["c_ray"] = o.ray_feat_fwd(pe_dir, self.in_dir, self.p["emb"], image_indices.contiguous(), self.p["l2r.w"], self.p["l2.b"])
-        from .model import _FUSED_HEADS, c_esz
-        fused = _FUSED_HEADS and W in (256, 512) and H2 in (128, 256) and W * c_esz(dt) <= 1024      # heads inside the tail chain's launch (swn.h: heads_raw)
+        from .model import c_esz
+        fused = self.sw["fused_heads"] and W in (256, 512) and H2 in (128, 256) and W * c_esz(dt) <= 1024      # heads inside the tail chain's launch (swn.h: heads_raw)
         c["h1"] = _b("h1", (P, W), dt) if sv else None
         c["h2"] = _b("h2", (P, H2), dt) if (sv or not fused) else None      # an inference forward writes nothing but raw
         c["raw"] = torch.empty(P, 4, dtype=torch.float32, device=self.dev) if fused else None

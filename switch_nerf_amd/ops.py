@@ -407,13 +407,31 @@ def hash_xcd_budget_bytes() -> int:
     return HASH_XCD_MB << 20
 
 
+HASH_BWD_MODE = os.environ.get("SWN_HASH_BWD", "binned")      # "binned" (default) | "atomic": read once; tests assign ops.HASH_BWD_MODE
+_hash_bin_ws = {}
+
+
 def hash_encode_bwd(rays, z, d_out, hc: dict, d_table):
     """d_table [L, T, 2] fp32 += the table gradient for dL/d encoding d_out [N * S, stride].
 
-    Default: one private fp32 copy of the gradient table per XCD (HASH_XCD_COPIES x the table: 512 MiB at 16 levels x 2^19, zeroed once,
-    left zero by every launch, never freed - a captured hipGraph holds its address) - the atomics of an XCD stay in its own L2.  A table
-    whose copies would exceed hash_xcd_budget_bytes() (2^22 entries: 4 GiB) takes the plain path: atomics straight into d_table."""
+    Default ("binned", swn_hash_encode_bwd_binned): no global float atomics - the contributions are binned by table tile into a workspace
+    (12 bytes per (point, level, corner): 3.2 GB at 2M points x 16 levels, kept per size: a captured hipGraph holds its address) and added
+    per tile in fixed point in LDS: bit-deterministic, ~4 x faster than the atomics at the recipe's size (profiles/r06_experiments.md 3).
+    Tables of more than 2^22 entries per level, or HASH_BWD_MODE = "atomic": the atomic kernels - one private fp32 copy of the gradient
+    table per XCD (HASH_XCD_COPIES x the table: 512 MiB at 16 levels x 2^19, zeroed once, left zero by every launch, never freed) so
+    that the atomics of an XCD stay in its own L2; a table whose copies would exceed hash_xcd_budget_bytes() takes the plain path:
+    atomics straight into d_table."""
     n, S = z.shape
+    if HASH_BWD_MODE == "binned" and int(hc["log2_table"]) <= 22 and n * S * 8 * int(hc["n_levels"]) < (1 << 32):
+        cfg = _hash_cfg(hc)
+        nbytes = int(_lib.load().swn_hash_bwd_workspace_bytes(n * S, C.byref(cfg)))
+        key = (d_table.device, nbytes)
+        ws = _hash_bin_ws.get(key)
+        if ws is None:
+            ws = _hash_bin_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=d_table.device)
+        call("swn_hash_encode_bwd_binned", _p(rays), _p(z), n, S, C.byref(cfg), _p(d_out), _dt(d_out), d_out.shape[1], _p(d_table), _p(ws),
+             nbytes, _stream())
+        return
     ws_bytes = HASH_XCD_COPIES * d_table.numel() * 4
     if ws_bytes > hash_xcd_budget_bytes():
         call("swn_hash_encode_bwd", _p(rays), _p(z), n, S, C.byref(_hash_cfg(hc)), _p(d_out), _dt(d_out), d_out.shape[1], _p(d_table), _stream())

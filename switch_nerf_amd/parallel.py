@@ -34,6 +34,27 @@ def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] 
     return rank, world
 
 
+def shutdown(timeout_s: float = 20.0, exit_code: int = 0):
+    """destroy_process_group() with a watchdog.  After a hipGraph with captured RCCL all-to-alls has been replayed, the teardown of the
+    communicator does not return on RCCL 2.26.6 / torch 2.10 + ROCm 7.0 (profiles/r06_experiments.md 2; results are complete at that
+    point): the process then exits through os._exit(exit_code) after `timeout_s`.  Drop graph objects before calling this."""
+    if not dist.is_initialized():
+        return
+    import gc
+    import sys
+    import threading
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    dog = threading.Timer(timeout_s, lambda: os._exit(exit_code))
+    dog.daemon = True
+    dog.start()
+    dist.destroy_process_group()
+    dog.cancel()
+
+
 def shard_rays(n_rays: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous per-rank slice [begin, end) of a global ray batch (runner.py:575: batch_size // world_size each;
     the remainder, if any, is dropped like DataLoader(drop_last) would)."""
@@ -259,6 +280,15 @@ class ExpertParallel:
 
     profile = False          # bench.py --parallelism ep: record HIP events around the collectives and the waits for them
 
+    @staticmethod
+    def _capturing() -> bool:
+        """Inside a hipGraph capture the all-to-all goes out on the CAPTURING stream, blocking form.  Measured on RCCL 2.26.6 / torch
+        2.10 + ROCm 7.0 (scripts/experiments/rccl_capture_probe.py, profiles/r06_experiments.md 2): all_reduce / all_gather /
+        reduce_scatter and a blocking all_to_all_single on the capturing stream capture and replay correctly; an all-to-all issued with
+        async_op=True, or on a stream forked from the capturing one, crashes hipStreamEndCapture (SIGSEGV).  The captured (padded) step
+        therefore serialises its exchanges with the expert launches; the eager step keeps the side-stream overlap."""
+        return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
     def all_to_all_v(self, send: torch.Tensor, in_splits, recv: torch.Tensor, out_splits, stream=None):
         """Unequal-split all-to-all of packed rows (dim 0): chunk r of `send` (in_splits[r] rows) goes to rank r, `recv` receives
         out_splits[w] rows from rank w.  Only rows that exist travel (20 % fewer bytes than the capacity-padded payload at 80 % kept
@@ -268,6 +298,9 @@ class ExpertParallel:
             return lambda: None
         row_bytes = (send.numel() // max(1, send.shape[0])) * send.element_size()
         self.bytes_sent = getattr(self, "bytes_sent", 0) + (sum(in_splits) - in_splits[self.rank]) * row_bytes     # rows that leave this GPU
+        if send.is_cuda and self._capturing():
+            dist.all_to_all_single(recv, send, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits), group=self.group)
+            return lambda: None
         if stream is None or not send.is_cuda:
             work = dist.all_to_all_single(recv, send, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits), group=self.group,
                                           async_op=True)
@@ -318,6 +351,9 @@ class ExpertParallel:
             assert out is None or out.data_ptr() == send.data_ptr()
             return send, (lambda: None)
         recv = torch.empty_like(send) if out is None else out
+        if send.is_cuda and self._capturing():
+            dist.all_to_all_single(recv, send, group=self.group)
+            return recv, (lambda: None)
         if stream is None or not send.is_cuda:
             work = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
             return recv, work.wait

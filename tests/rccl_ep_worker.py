@@ -118,5 +118,5 @@ local_pad = run(parallel.ExpertParallel(0, 1, E, padded=True), 3)
 check("padded step over RCCL == no-collective padded step", all(torch.equal(p, q) for p, q in zip(run(parallel.ExpertParallel(0, 1, E, padded=True, loopback=True), 3)[:3], local_pad[:3])))
 print(f"RCCL_EP done: {'OK' if ok else 'MISMATCH'}", flush=True)
 dist.barrier()
-dist.destroy_process_group()
+parallel.shutdown(exit_code=0 if ok else 1)      # (the teardown behind replayed graphs with captured all-to-alls: see parallel.shutdown)
 sys.exit(0 if ok else 1)

@@ -49,14 +49,31 @@ def test_hash_encode_fwd_bwd_vs_oracle():
     ops.hash_encode_bwd(_dev(rays), _dev(z.numpy()), _dev(d_out), HC, d_table)
     r = tt.grad.numpy()
     np.testing.assert_allclose(d_table.cpu().numpy(), r, rtol=1e-4, atol=1e-5 * np.abs(r).max())
-    # the fallback of a table whose per-XCD copies would exceed the workspace budget (ops.HASH_XCD_MB): the same gradient
-    prev, ops.HASH_XCD_MB = ops.HASH_XCD_MB, 0
+    # (that was the default: the binned, atomic-free kernels.)  The same call twice more: bit-identical (fixed-point sums do not depend
+    # on the order the items arrive in), and += semantics
+    again = torch.zeros(table.shape, device="cuda")
+    ops.hash_encode_bwd(_dev(rays), _dev(z.numpy()), _dev(d_out), HC, again)
+    assert torch.equal(again, d_table)
+    ops.hash_encode_bwd(_dev(rays), _dev(z.numpy()), _dev(d_out), HC, again)
+    np.testing.assert_allclose(again.cpu().numpy(), 2 * r, rtol=1e-4, atol=2e-5 * np.abs(r).max())
+    # the atomic kernels: per-XCD copies, and the fallback of a table whose copies would exceed the workspace budget (ops.HASH_XCD_MB;
+    # ADVICE round 5): the same gradient
+    prev_mode, prev_mb = ops.HASH_BWD_MODE, ops.HASH_XCD_MB
     try:
-        d_plain = torch.zeros(table.shape, device="cuda")
-        ops.hash_encode_bwd(_dev(rays), _dev(z.numpy()), _dev(d_out), HC, d_plain)
+        ops.HASH_BWD_MODE = "atomic"
+        for mb in (prev_mb, 0):
+            ops.HASH_XCD_MB = mb
+            d_at = torch.zeros(table.shape, device="cuda")
+            ops.hash_encode_bwd(_dev(rays), _dev(z.numpy()), _dev(d_out), HC, d_at)
+            np.testing.assert_allclose(d_at.cpu().numpy(), r, rtol=1e-4, atol=1e-5 * np.abs(r).max())
     finally:
-        ops.HASH_XCD_MB = prev
-    np.testing.assert_allclose(d_plain.cpu().numpy(), r, rtol=1e-4, atol=1e-5 * np.abs(r).max())
+        ops.HASH_BWD_MODE, ops.HASH_XCD_MB = prev_mode, prev_mb
+    # a non-finite upstream gradient must not vanish in the fixed-point conversion: the touched entries turn NaN
+    d_bad = d_out.copy()
+    d_bad[5, 3] = np.inf
+    nan_t = torch.zeros(table.shape, device="cuda")
+    ops.hash_encode_bwd(_dev(rays), _dev(z.numpy()), _dev(d_bad), HC, nan_t)
+    assert not torch.isfinite(nan_t).all()
     # points outside the bounding box clamp to its faces
     far = rays.copy()
     far[:, :3] += 10.0
