@@ -39,8 +39,8 @@
 #endif
 #define SWN_AUX (SWN_WIDE || SWN_CONCAT)      // an auxiliary build: kernels + launcher only, no C entry points
 // -DSWN_EXP_TIMING: s_memtime phase timers of wave 0 of the first 4096 workgroups, written through d.y_add_gather (reinterpreted
-// as int64 [4096][8]; scripts/chain_timing.py).  Default build only; off = no code.
-#if defined(SWN_EXP_TIMING) && !SWN_AUX
+// as int64 [4096][8]; scripts/chain_timing.py, scripts/experiments/chain_wide_timing.py).  Default and 8-wave 512-feature builds; off = no code.
+#if defined(SWN_EXP_TIMING) && (!SWN_AUX || SWN_WIDE == 2)
 #define SWN_TIMING_ON 1
 #else
 #define SWN_TIMING_ON 0
@@ -248,10 +248,19 @@ __device__ __forceinline__ void load_rows_to_lds(char* dst, const void* src, con
 // ring[r][ni] holds the weight fragments of step r of this layer on entry (r < RING); on exit it holds the first RING
 // steps of the next layer (prefetched while the last steps of this one run).
 // wcur / wnxt: this wave's fragment streams: [tile ni][step][lane][16 B]; tile stride = steps * 1 KiB.
-template <typename T, int NSTEPS>
+// The write-out of a K loop's INPUT tile (= the previous layer's output: a saved activation) can ride the K loop itself - the tile is only
+// read until the barrier behind the loop.  WoArgs: rows of `out` (row-major, row_bytes each, first row = the tile's first row) for the
+// tile's first `rows` rows; a thread moves chunk tid + j * NT (16 bytes) for j < 16, one every other K step: an LDS read in the even
+// step, the global store in the odd one.  (8-wave 512-feature build: behind the second barrier the same copy was 16 % of a layer's
+// time with the matrix pipe idle - profiles/r06_experiments.md 4.)
+struct WoArgs {
+  char* out;          // nullptr: nothing to write
+  int row_bytes, rows, tid;
+};
+template <typename T, int NSTEPS, bool WO = false>
 __device__ __forceinline__ void k_loop(f32x16_t (&acc)[Cfg<T>::MI][NI], typename Cfg<T>::wfrag_t (&ring)[RING][NI],
                                        const char* act, const int (&aoff)[16], __amdgpu_buffer_rsrc_t wcur,
-                                       __amdgpu_buffer_rsrc_t wnxt, int nxt_steps, int lane16) {
+                                       __amdgpu_buffer_rsrc_t wnxt, int nxt_steps, int lane16, const WoArgs wo = WoArgs{nullptr, 0, 0, 0}) {
   constexpr int MI = Cfg<T>::MI;
   typedef typename Cfg<T>::wfrag_t wfrag_t;
   const int ts_n = nxt_steps * 1024;
@@ -292,9 +301,26 @@ __device__ __forceinline__ void k_loop(f32x16_t (&acc)[Cfg<T>::MI][NI], typename
     bf16x8_t a0 = aread(0, 0), a1;
 #define SWN_PIN() __builtin_amdgcn_sched_barrier(0)
     if constexpr (MI == 4) {
+      // deferred write-out (WO): chunk geometry of the rows being written
+      uint4 wv = make_uint4(0u, 0u, 0u, 0u);
+      const int cpr = WO ? (wo.row_bytes >> 4) : 1;
+      const int wsh = 31 - __builtin_clz(cpr);
+      const int wtotal = WO ? wo.rows * cpr : 0;
+      constexpr int WPIECES = Cfg<T>::BM * (ROW_ELEMS * (int)sizeof(T) / 16) / NT;      // chunks per thread of a full tile (16)
+      static_assert(!WO || 2 * WPIECES <= NSTEPS, "deferred write-out: one chunk every other K step");
 #pragma unroll
       for (int ks = 0; ks < NSTEPS; ++ks) {
         const int r = ks % RING;
+        if constexpr (WO) {
+          if (ks < 2 * WPIECES) {
+            const int c = wo.tid + (ks >> 1) * NT;
+            if (wo.out && c < wtotal) {
+              const int row = c >> wsh, ch = c & (cpr - 1);
+              if ((ks & 1) == 0) wv = load_chunk_from_act<T>(act, row, ch);
+              else *(uint4*)(wo.out + (long)row * wo.row_bytes + ch * 16) = wv;
+            }
+          }
+        }
         a1 = aread(ks, 1);
         SWN_PIN();
         acc[0][0] = SWN_MFMA_32x32x16(ring[r][0], a0, acc[0][0]);
@@ -366,18 +392,34 @@ __device__ __forceinline__ void k_loop(f32x16_t (&acc)[Cfg<T>::MI][NI], typename
 template <typename T, bool DYN, int RELU_, bool SKIP_, bool BIAS_, bool RB_>
 __device__ __forceinline__ void epilogue_body(f32x16_t (&acc)[Cfg<T>::MI][NI], char* act, const char* bias_lds, const float* rbp,
                                               uint32_t* mk, int wn, int l31, int lhi, int nvalid, long grow0, int rows_per_bias,
-                                              int n, int relu_d, bool skip_d, bool bias_d, int rows_in_tile) {
+                                              int n, int relu_d, bool skip_d, bool bias_d, int rows_in_tile,
+                                              const uint32_t* mpre = nullptr) {
   constexpr int MI = Cfg<T>::MI;
   const int relu = DYN ? relu_d : RELU_;
   const bool skip = DYN ? skip_d : SKIP_;
   const bool bias = DYN ? bias_d : BIAS_;
   const bool rowb = DYN ? (rbp != nullptr) : RB_;
+#if SWN_WIDE == 2
+  // (8-wave 512-feature build) the wave's 64 bias values are read ONCE, in front of the row tiles - read inside every group of four
+  // values, behind a scheduling barrier, each of the 32 groups of a lane waited for its own LDS round trip; the stored ReLU masks of a
+  // backward layer arrive in `mpre`, fetched in front of the K loop (profiles/r06_experiments.md 4)
+  float4 bq[NI][4];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      bq[ni][g4] = bias ? *(const float4*)(bias_lds + (wn * (32 * NI) + ni * 32 + g4 * 8 + lhi * 4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = mi * 32 + l31;
     mbits_t mbits = 0;       // 16 bits per feature tile: one word per pair of tiles ([half][mi][lane] per wave)
     if (relu == 2) {
+#if SWN_WIDE == 2
+      mbits = mpre ? mpre[mi] : mk[mi * 64];
+#else
       mbits = mk[mi * 64];
+#endif
       if constexpr (NI == 4) mbits |= (mbits_t)((uint64_t)mk[(MI + mi) * 64] << 32);
     }
     const float* rb = nullptr;
@@ -391,10 +433,14 @@ __device__ __forceinline__ void epilogue_body(f32x16_t (&acc)[Cfg<T>::MI][NI], c
           float v[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][g4 * 4 + j];
+#if SWN_WIDE == 2
+          if (bias) { v[0] += bq[ni][g4].x; v[1] += bq[ni][g4].y; v[2] += bq[ni][g4].z; v[3] += bq[ni][g4].w; }
+#else
           if (bias) {
             const float4 b4 = *(const float4*)(bias_lds + n0 * 4);
             v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
           }
+#endif
           if (rowb) {
             const float4 b4 = *(const float4*)(rb + n0);
             v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
@@ -652,12 +698,29 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
 
     // K loop: no barrier.  (Waves beyond the layer width run it too on a clamped stream - keeps the ring logic
     // uniform - and discard the result.  Only the 128-wide layer "2" has such waves.)
-#if SWN_WIDE
-    if (steps == 512 / KSTEP) k_loop<T, 512 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
-    else
+#if SWN_WIDE == 2
+    uint32_t mpre[MI];        // this layer's stored ReLU masks (backward chains), requested here: the K loop hides their round trip
+    const bool mpre_on = ly.relu == 2 && ly.mask != nullptr && wave_active;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+      mpre[mi] = mpre_on ? ly.mask[(size_t)((g * args.tiles_per_group + tile) * (NT / 64) + wn) * MI * 64 * (NI / 2) + lane + mi * 64] : 0u;
 #endif
 #if SWN_TIMING_ON
     long long q0 = TICK();
+#endif
+#if SWN_WIDE == 2
+    if (steps == 512 / KSTEP) {
+      // (the previous layer's saved activation = this K loop's input tile leaves the LDS DURING the loop: see WoArgs)
+      WoArgs wo{nullptr, 0, 0, 0};
+      if (L > 0 && d.layers[L - 1].save) {
+        const int rb = d.layers[L - 1].n * (int)sizeof(T);
+        wo = WoArgs{(char*)d.layers[L - 1].save + grow0 * rb, rb, rows_in_tile, tid};
+      }
+      k_loop<T, 512 / KSTEP, true>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16, wo);
+    } else
+#elif SWN_WIDE
+    if (steps == 512 / KSTEP) k_loop<T, 512 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
+    else
 #endif
     // (a wave beyond the width of the LAST layer has nothing to compute and nothing to prefetch for: it skips the K loop - for the
     //  128-feature last layer of the tail forward chain that is half the waves, a quarter of the launch's weight stream through the
@@ -692,8 +755,13 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
       const float* rbp = ly.rowbias ? ly.rowbias + (grow0 / ly.rows_per_bias) * (size_t)n : nullptr;   // tile-aligned per-ray bias
       uint32_t* mk = ly.mask ? ly.mask + (size_t)((g * args.tiles_per_group + tile) * (NT / 64) + wn) * MI * 64 * (NI / 2) + lane : nullptr;
       const int nvalid = n - wn * 32 * NI;   // feature tiles of this wave that exist: nvalid >= 32 NI -> all
+#if SWN_WIDE == 2 && !SWN_CONCAT
+      epilogue_body<T, true, 0, false, false, false>(acc, act, bias_lds, rbp, mk, wn, l31e, lhie, nvalid, grow0, ly.rows_per_bias, n,
+                                                     ly.relu, ly.skip == 1, ly.b != nullptr, rows_in_tile, mpre_on ? mpre : nullptr);
+#else
       epilogue_body<T, true, 0, false, false, false>(acc, act, bias_lds, rbp, mk, wn, l31e, lhie, nvalid, grow0, ly.rows_per_bias, n,
                                                      ly.relu, ly.skip == 1, ly.b != nullptr, rows_in_tile);
+#endif
     }
 #if SWN_TIMING_ON
     long long q3 = TICK();
@@ -711,6 +779,9 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
     const bool last = (L == d.n_layers - 1);
     void* outp = last ? d.y : ly.save;
     if (TAG == 5 && last && d.comb_y) outp = nullptr;       // the fused combine backward writes the last layer out behind the loop
+#if SWN_WIDE == 2
+    if (!last && d.layers[L + 1].k / KSTEP == 512 / KSTEP) outp = nullptr;      // rides the next layer's K loop (WoArgs)
+#endif
     if (outp) {
       const int row_bytes = n * (int)sizeof(T);
       const int cpr = row_bytes >> 4;

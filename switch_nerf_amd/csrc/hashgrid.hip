@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void hash_reduce_kernel(float* __restrict__ pr
 // L2's atomic rate (~18 G/s: 15 of the 29.6 ms of configs[4]'s recipe), wherever the lines live (r05_experiments.md 4).  Here a
 // contribution (entry, wk g0, wk g1) is an ITEM; the gradient table is cut into TILES of 2^13 entries (128 KiB of LDS as 2 x int64 per
 // entry); tile t = level * tiles_per_level + (entry >> 13):
-//   count    one workgroup per (512 points, level): the items per tile (LDS histogram -> int atomics, 2M per launch) and max |d_out|
+//   count    one workgroup per 512 points, all levels (a point's d_out row is read once): the items per tile (LDS histogram -> int atomics, 2M per launch) and max |d_out|
 //   scan     exclusive prefix over the tiles -> every tile's item range in the workspace
 //   scatter  the same workgroups again: items binned by tile in LDS, ONE cursor atomic per (workgroup, tile), bin runs written with
 //            consecutive lanes (three 4-byte arrays: local entry, c0, c1 - 12 bytes per item, 3.2 GB at 2M points)
@@ -206,8 +206,9 @@ struct HashBin {
   int n_tiles;
 };
 
-// the items of one point at one level: emit(entry, c0, c1) per corner.  Dense levels: the lanes of a wave that share a cell form runs,
-// the run's sums come out of its tail lane (all 64 lanes must call; lanes past the end carry zero gradient and the last point's cell).
+// the items of one point at one level: emit(has, entry, c0, c1) per corner, called by ALL 64 lanes (has = this lane holds an item).  Dense
+// levels: the lanes of a wave that share a cell form runs, the run's sums come out of its tail lane (lanes past the end carry zero
+// gradient and the last point's cell).
 template <bool COUNT_ONLY, typename F>
 __device__ __forceinline__ void hash_items(const HashLevels& h, int l, const float (&x)[3], float g0, float g1, bool live, int lane, F emit) {
 #pragma clang fp contract(off)
@@ -237,15 +238,60 @@ __device__ __forceinline__ void hash_items(const HashLevels& h, int l, const flo
         t0 = run_inclusive_scan(wk * g0, lane, start);
         t1 = run_inclusive_scan(wk * g1, lane, start);
       }
-      if (tail) emit(hash_entry(h, l, c0[0] + dx, c0[1] + dy, c0[2] + dz), t0, t1);
+      emit(tail, hash_entry(h, l, c0[0] + dx, c0[1] + dy, c0[2] + dz), t0, t1);
     }
-  } else if (live) {
+  } else {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const uint32_t dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
       const float wk = ((dx ? w[0] : 1.f - w[0]) * (dy ? w[1] : 1.f - w[1])) * (dz ? w[2] : 1.f - w[2]);
-      emit(hash_entry(h, l, c0[0] + dx, c0[1] + dy, c0[2] + dz), wk * g0, wk * g1);
+      emit(live, hash_entry(h, l, c0[0] + dx, c0[1] + dy, c0[2] + dz), wk * g0, wk * g1);
     }
+  }
+}
+
+// rank of this lane's item inside its bin (hist[bin] += the wave's items of the bin).  few_bins (dense levels: the lanes of a wave meet
+// in one or two bins - 64 same-address LDS atomics would serialise): one atomic per distinct bin of the wave, ranks from a ballot.
+__device__ __forceinline__ uint32_t bin_rank(uint32_t* hist, uint32_t bin, bool has, bool few_bins, int lane) {
+  if (!few_bins) return has ? atomicAdd(&hist[bin], 1u) : 0u;
+  uint32_t rank = 0;
+  uint64_t todo = __ballot(has);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);
+    const uint64_t m = __ballot(has && bin == b0);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&hist[b0], (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+    if (has && bin == b0) rank = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    todo &= ~m;
+  }
+  return rank;
+}
+
+// a workgroup = HB_PTS consecutive points, ALL levels (a point's d_out row and position are read once)
+template <typename T>
+__device__ __forceinline__ void hb_load_point(const float* __restrict__ rays, const float* __restrict__ z, int S, const HashLevels& h,
+                                              const T* __restrict__ d_out, int d_stride, long p, bool live, float (&x)[3],
+                                              uint32_t (&g)[HASH_MAX_LEVELS]) {
+  point_of(rays, z, p, S, h, x);
+  if constexpr (sizeof(T) == 2) {
+    const uint32_t* row = (const uint32_t*)(d_out + p * d_stride);      // (d_stride is even: rows are 4-byte aligned)
+#pragma unroll
+    for (int l = 0; l < HASH_MAX_LEVELS; ++l) g[l] = (live && l < h.n_levels) ? row[l] : 0u;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void hb_grad(const T* __restrict__ d_out, int d_stride, long p, bool live, const uint32_t (&g)[HASH_MAX_LEVELS], int l,
+                                        float& g0, float& g1) {
+  if constexpr (sizeof(T) == 2) {
+    const uint32_t v = g[l];
+    bf16_t lo = (bf16_t)(v & 0xffffu), hi = (bf16_t)(v >> 16);
+    g0 = ElemIO<bf16_t>::ld(&lo);
+    g1 = ElemIO<bf16_t>::ld(&hi);
+  } else {
+    g0 = live ? ElemIO<T>::ld(d_out + p * d_stride + 2 * l) : 0.f;
+    g1 = live ? ElemIO<T>::ld(d_out + p * d_stride + 2 * l + 1) : 0.f;
   }
 }
 
@@ -253,32 +299,39 @@ template <typename T>
 __global__ __launch_bounds__(256) void hash_bin_count_kernel(const float* __restrict__ rays, const float* __restrict__ z, int n_rays, int S,
                                                              HashLevels h, const T* __restrict__ d_out, int d_stride, HashBin b) {
   __shared__ uint32_t hist[HB_MAX_TPL];
-  const int tid = threadIdx.x, lane = tid & 63, l = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
   const long total = (long)n_rays * S;
-  for (int i = tid; i < b.tpl; i += 256) hist[i] = 0;
-  __syncthreads();
-  float gm = 0.f;
+  float x[HB_PTS / 256][3];
+  uint32_t g[HB_PTS / 256][HASH_MAX_LEVELS];
+  bool live[HB_PTS / 256];
+  long pp[HB_PTS / 256];
+  uint32_t gu = 0;          // max |d_out| as float bits (NaN / inf compare above every finite value; fmaxf would drop a NaN)
 #pragma unroll
   for (int j = 0; j < HB_PTS / 256; ++j) {
     const long p_raw = (long)blockIdx.x * HB_PTS + j * 256 + tid;
-    const bool live = p_raw < total;
-    const long p = live ? p_raw : total - 1;
-    float x[3];
-    point_of(rays, z, p, S, h, x);
-    if (live) {        // max |d_out| of the level's two columns (NaN propagates: fmaxf would drop it, the bit pattern compare does not)
-      const float a0 = fabsf(ElemIO<T>::ld(d_out + p * d_stride + 2 * l)), a1 = fabsf(ElemIO<T>::ld(d_out + p * d_stride + 2 * l + 1));
-      const uint32_t u = max(__float_as_uint(a0), __float_as_uint(a1));
-      gm = __uint_as_float(max(__float_as_uint(gm), u));
-    }
-    hash_items<true>(h, l, x, 0.f, 0.f, live, lane, [&](uint32_t e, float, float) { atomicAdd(&hist[e >> HB_TILE_LOG2], 1u); });
+    live[j] = p_raw < total;
+    pp[j] = live[j] ? p_raw : total - 1;
+    hb_load_point<T>(rays, z, S, h, d_out, d_stride, pp[j], live[j], x[j], g[j]);
   }
-  uint32_t gu = __float_as_uint(gm);
+  for (int l = 0; l < h.n_levels; ++l) {
+    for (int i = tid; i < b.tpl; i += 256) hist[i] = 0;
+    __syncthreads();
+    const bool few = h.dense[l] != 0;
+#pragma unroll
+    for (int j = 0; j < HB_PTS / 256; ++j) {
+      float g0, g1;
+      hb_grad<T>(d_out, d_stride, pp[j], live[j], g[j], l, g0, g1);
+      if (live[j]) gu = max(gu, max(__float_as_uint(fabsf(g0)), __float_as_uint(fabsf(g1))));
+      hash_items<true>(h, l, x[j], 0.f, 0.f, live[j], lane, [&](bool has, uint32_t e, float, float) { bin_rank(hist, e >> HB_TILE_LOG2, has, few, lane); });
+    }
+    __syncthreads();
+    for (int i = tid; i < b.tpl; i += 256)
+      if (hist[i]) atomicAdd(b.count + l * b.tpl + i, hist[i]);
+    __syncthreads();
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) gu = max(gu, (uint32_t)__shfl_xor((int)gu, o, 64));
   if (lane == 0 && gu) atomicMax(b.gmax_bits, gu);
-  __syncthreads();
-  for (int i = tid; i < b.tpl; i += 256)
-    if (hist[i]) atomicAdd(b.count + l * b.tpl + i, hist[i]);
 }
 
 // begin[t] = items of the tiles before t (one workgroup; n_tiles <= 16 * 512); cursor = 0
@@ -307,104 +360,131 @@ __global__ __launch_bounds__(256) void hash_bin_scatter_kernel(const float* __re
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t s_loc[HB_ITEMS];        // (bin << 13) | local entry
   __shared__ float s_c0[HB_ITEMS], s_c1[HB_ITEMS];
-  const int tid = threadIdx.x, lane = tid & 63, l = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
   const long total = (long)n_rays * S;
-  for (int i = tid; i < b.tpl; i += 256) hist[i] = 0;
-  __syncthreads();
-  // pass 1: the items into registers, their rank inside their bin from the LDS histogram
-  uint32_t it_e[HB_PTS / 256][8], it_r[HB_PTS / 256][8];
-  float it_0[HB_PTS / 256][8], it_1[HB_PTS / 256][8];
-  int it_n[HB_PTS / 256];
+  float x[HB_PTS / 256][3];
+  uint32_t g[HB_PTS / 256][HASH_MAX_LEVELS];
+  bool live[HB_PTS / 256];
+  long pp[HB_PTS / 256];
 #pragma unroll
   for (int j = 0; j < HB_PTS / 256; ++j) {
     const long p_raw = (long)blockIdx.x * HB_PTS + j * 256 + tid;
-    const bool live = p_raw < total;
-    const long p = live ? p_raw : total - 1;
-    float x[3];
-    point_of(rays, z, p, S, h, x);
-    const float g0 = live ? ElemIO<T>::ld(d_out + p * d_stride + 2 * l) : 0.f, g1 = live ? ElemIO<T>::ld(d_out + p * d_stride + 2 * l + 1) : 0.f;
-    int n = 0;
-    hash_items<false>(h, l, x, g0, g1, live, lane, [&](uint32_t e, float a0, float a1) {
-      it_e[j][n] = e; it_0[j][n] = a0; it_1[j][n] = a1;
-      it_r[j][n] = atomicAdd(&hist[e >> HB_TILE_LOG2], 1u);
-      ++n;
-    });
-    it_n[j] = n;
+    live[j] = p_raw < total;
+    pp[j] = live[j] ? p_raw : total - 1;
+    hb_load_point<T>(rays, z, S, h, d_out, d_stride, pp[j], live[j], x[j], g[j]);
   }
-  __syncthreads();
-  // exclusive prefix over the bins (tpl <= 512 = 2 per thread), global ranges from the tiles' cursors
-  {
-    const uint32_t a = 2 * tid < b.tpl ? hist[2 * tid] : 0u, c = 2 * tid + 1 < b.tpl ? hist[2 * tid + 1] : 0u;
-    uint32_t v = a + c;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)v, o, 64); if (lane >= o) v += t; }
-    if (lane == 63) wsum[tid >> 6] = v;
+  for (int l = 0; l < h.n_levels; ++l) {
+    for (int i = tid; i < b.tpl; i += 256) hist[i] = 0;
     __syncthreads();
-    uint32_t base = 0;
-    for (int q = 0; q < (tid >> 6); ++q) base += wsum[q];
-    const uint32_t ex = base + v - (a + c);
+    const bool few = h.dense[l] != 0;
+    // pass 1: the items into registers, their rank inside their bin from the LDS histogram
+    uint32_t it_e[HB_PTS / 256][8], it_r[HB_PTS / 256][8];
+    float it_0[HB_PTS / 256][8], it_1[HB_PTS / 256][8];
+    uint32_t it_has[HB_PTS / 256];
+#pragma unroll
+    for (int j = 0; j < HB_PTS / 256; ++j) {
+      float g0, g1;
+      hb_grad<T>(d_out, d_stride, pp[j], live[j], g[j], l, g0, g1);
+      int k = 0;
+      uint32_t hm = 0;
+      hash_items<false>(h, l, x[j], g0, g1, live[j], lane, [&](bool has, uint32_t e, float a0, float a1) {
+        it_e[j][k] = e; it_0[j][k] = a0; it_1[j][k] = a1;
+        it_r[j][k] = bin_rank(hist, e >> HB_TILE_LOG2, has, few, lane);
+        hm |= has ? (1u << k) : 0u;
+        ++k;
+      });
+      it_has[j] = hm;
+    }
     __syncthreads();
-    if (2 * tid < b.tpl) {
-      hist[2 * tid] = ex;
-      gbase[2 * tid] = a ? b.begin[l * b.tpl + 2 * tid] + atomicAdd(b.cursor + l * b.tpl + 2 * tid, a) : 0u;
-    }
-    if (2 * tid + 1 < b.tpl) {
-      hist[2 * tid + 1] = ex + a;
-      gbase[2 * tid + 1] = c ? b.begin[l * b.tpl + 2 * tid + 1] + atomicAdd(b.cursor + l * b.tpl + 2 * tid + 1, c) : 0u;
-    }
-  }
-  __syncthreads();
-  // pass 2: items -> staging, grouped by bin
+    // exclusive prefix over the bins (tpl <= 512 = 2 per thread), global ranges from the tiles' cursors
+    {
+      const uint32_t a = 2 * tid < b.tpl ? hist[2 * tid] : 0u, c = 2 * tid + 1 < b.tpl ? hist[2 * tid + 1] : 0u;
+      uint32_t v = a + c;
 #pragma unroll
-  for (int j = 0; j < HB_PTS / 256; ++j)
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (k < it_n[j]) {
-        const uint32_t bin = it_e[j][k] >> HB_TILE_LOG2;
-        const uint32_t slot = hist[bin] + it_r[j][k];
-        s_loc[slot] = (bin << HB_TILE_LOG2) | (it_e[j][k] & (HB_TILE - 1));
-        s_c0[slot] = it_0[j][k];
-        s_c1[slot] = it_1[j][k];
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)v, o, 64); if (lane >= o) v += t; }
+      if (lane == 63) wsum[tid >> 6] = v;
+      __syncthreads();
+      uint32_t base = 0;
+      for (int q = 0; q < (tid >> 6); ++q) base += wsum[q];
+      const uint32_t ex = base + v - (a + c);
+      if (2 * tid < b.tpl) {
+        hist[2 * tid] = ex;
+        gbase[2 * tid] = a ? b.begin[l * b.tpl + 2 * tid] + atomicAdd(b.cursor + l * b.tpl + 2 * tid, a) : 0u;
       }
-  __syncthreads();
-  const uint32_t n_items = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-  for (uint32_t i = tid; i < n_items; i += 256) {     // consecutive lanes -> consecutive slots of a bin run -> consecutive addresses
-    const uint32_t v = s_loc[i], bin = v >> HB_TILE_LOG2;
-    const uint32_t dst = gbase[bin] + (i - hist[bin]);
-    b.loc[dst] = v & (HB_TILE - 1);
-    b.c0[dst] = s_c0[i];
-    b.c1[dst] = s_c1[i];
+      if (2 * tid + 1 < b.tpl) {
+        hist[2 * tid + 1] = ex + a;
+        gbase[2 * tid + 1] = c ? b.begin[l * b.tpl + 2 * tid + 1] + atomicAdd(b.cursor + l * b.tpl + 2 * tid + 1, c) : 0u;
+      }
+    }
+    __syncthreads();
+    // pass 2: items -> staging, grouped by bin
+#pragma unroll
+    for (int j = 0; j < HB_PTS / 256; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (it_has[j] & (1u << k)) {
+          const uint32_t bin = it_e[j][k] >> HB_TILE_LOG2;
+          const uint32_t slot = hist[bin] + it_r[j][k];
+          s_loc[slot] = (bin << HB_TILE_LOG2) | (it_e[j][k] & (HB_TILE - 1));
+          s_c0[slot] = it_0[j][k];
+          s_c1[slot] = it_1[j][k];
+        }
+    __syncthreads();
+    const uint32_t n_items = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    for (uint32_t i = tid; i < n_items; i += 256) {     // consecutive lanes -> consecutive slots of a bin run -> consecutive addresses
+      const uint32_t v = s_loc[i], bin = v >> HB_TILE_LOG2;
+      const uint32_t dst = gbase[bin] + (i - hist[bin]);
+      b.loc[dst] = v & (HB_TILE - 1);
+      b.c0[dst] = s_c0[i];
+      b.c1[dst] = s_c1[i];
+    }
+    __syncthreads();
   }
 }
 
 // one workgroup per tile: fixed-point accumulation in LDS, then d_table += tile (the tile's only writer)
-__global__ __launch_bounds__(512) void hash_bin_tiles_kernel(HashLevels h, HashBin b, float* __restrict__ d_table) {
+constexpr int HB_TILE_THREADS = 1024;
+__global__ __launch_bounds__(HB_TILE_THREADS) void hash_bin_tiles_kernel(HashLevels h, HashBin b, float* __restrict__ d_table) {
   extern __shared__ long long tile[];       // [HB_TILE][2]
+  constexpr int NTH = HB_TILE_THREADS;
   const int t = blockIdx.x, tid = threadIdx.x;
   const uint32_t i0 = b.begin[t], i1 = b.begin[t + 1];
   if (i0 == i1) return;
   const int l = t / b.tpl, sub = t - l * b.tpl;
   const uint32_t T = h.table_mask + 1u;
   const int n_ent = (int)min((uint32_t)HB_TILE, T - (uint32_t)sub * HB_TILE);
-  for (int i = tid; i < 2 * n_ent; i += 512) tile[i] = 0;
+  for (int i = tid; i < 2 * n_ent; i += NTH) tile[i] = 0;
   // scale = 2^(38 - e) with 2^e <= max |d_out| < 2^(e + 1): |item| < 2^39 exactly representable steps of 2^(e - 38)
   const uint32_t gb = *b.gmax_bits;
   const bool bad = gb >= 0x7f800000u;                        // inf / NaN upstream: the tile's entries become NaN
   int ex = (int)(gb >> 23) - 127;
   if (gb < 0x00800000u) ex = -126;                           // (zero / denormal maximum)
-  const float up = ldexpf(1.f, max(-126, min(127, 38 - ex)));       // (two factors: 2^(38 - e) can exceed the float range for tiny maxima)
-  const float up2 = ldexpf(1.f, (38 - ex) - max(-126, min(127, 38 - ex)));
+  const int sh = 38 - ex, sh1 = max(-126, min(127, sh));
+  const float up = ldexpf(1.f, sh1), up2 = ldexpf(1.f, sh - sh1);     // (two factors: 2^(38 - e) can exceed the float range for tiny maxima)
   __syncthreads();
-  for (uint32_t i = i0 + tid; i < i1; i += 512) {
-    const uint32_t e = b.loc[i];
-    const float a0 = b.c0[i] * up * up2, a1 = b.c1[i] * up * up2;
-    atomicAdd((unsigned long long*)&tile[2 * e], (unsigned long long)__float2ll_rn(a0));
-    atomicAdd((unsigned long long*)&tile[2 * e + 1], (unsigned long long)__float2ll_rn(a1));
+  constexpr int U = 4;                                       // items in flight per thread
+  for (uint32_t i = i0 + tid; i < i1; i += U * NTH) {
+    uint32_t e[U];
+    float a0[U], a1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t q = i + u * NTH;
+      const bool ok = q < i1;
+      e[u] = ok ? b.loc[q] : 0xffffffffu;
+      a0[u] = ok ? b.c0[q] : 0.f;
+      a1[u] = ok ? b.c1[q] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (e[u] != 0xffffffffu) {
+        atomicAdd((unsigned long long*)&tile[2 * e[u]], (unsigned long long)__float2ll_rn(a0[u] * up * up2));
+        atomicAdd((unsigned long long*)&tile[2 * e[u] + 1], (unsigned long long)__float2ll_rn(a1[u] * up * up2));
+      }
   }
   __syncthreads();
   const double down = ldexp(1.0, ex - 38);
   float2* dst = (float2*)(d_table + (long)l * h.level_stride) + (long)sub * HB_TILE;
-  for (int e = tid; e < n_ent; e += 512) {
+  for (int e = tid; e < n_ent; e += NTH) {
     const long long s0 = tile[2 * e], s1 = tile[2 * e + 1];
     if (!bad && s0 == 0 && s1 == 0) continue;
     float2 v = dst[e];
@@ -516,7 +596,7 @@ extern "C" int swn_hash_encode_bwd_binned(const float* rays, const float* z, int
   SWN_CHECK(rays && z && d_out && d_table && workspace, "swn_hash_encode_bwd_binned: null pointer");
   HashLevels h;
   if (make_levels(cfg, &h)) return 1;
-  SWN_CHECK(d_stride >= 2 * h.n_levels, "swn_hash_encode_bwd_binned: d_stride %d", d_stride);
+  SWN_CHECK(d_stride >= 2 * h.n_levels && (dtype != SWN_HALF || d_stride % 2 == 0), "swn_hash_encode_bwd_binned: d_stride %d", d_stride);
   if (n_rays <= 0 || n_samples <= 0) return 0;
   const long P = (long)n_rays * n_samples;
   const long T = 1L << cfg->log2_table;
@@ -536,7 +616,7 @@ extern "C" int swn_hash_encode_bwd_binned(const float* rays, const float* z, int
   SWN_CHECK(e == hipSuccess, "fill: %s", hipGetErrorString(e));
   e = fill_u32_async(b.gmax_bits, 0u, 256, s);
   SWN_CHECK(e == hipSuccess, "fill: %s", hipGetErrorString(e));
-  const dim3 grid(cdiv(P, HB_PTS), h.n_levels);
+  const dim3 grid(cdiv(P, HB_PTS));
   if (dtype == SWN_HALF) hipLaunchKernelGGL((hash_bin_count_kernel<bf16_t>), grid, dim3(256), 0, s, rays, z, n_rays, n_samples, h, (const bf16_t*)d_out, d_stride, b);
   else hipLaunchKernelGGL((hash_bin_count_kernel<float>), grid, dim3(256), 0, s, rays, z, n_rays, n_samples, h, (const float*)d_out, d_stride, b);
   hipLaunchKernelGGL(hash_bin_scan_kernel, dim3(1), dim3(256), 0, s, b);
@@ -549,7 +629,7 @@ extern "C" int swn_hash_encode_bwd_binned(const float* rays, const float* z, int
     SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL(hash_bin_tiles_kernel, dim3(b.n_tiles), dim3(512), TILE_LDS, s, h, b, d_table);
+  hipLaunchKernelGGL(hash_bin_tiles_kernel, dim3(b.n_tiles), dim3(HB_TILE_THREADS), TILE_LDS, s, h, b, d_table);
   SWN_LAUNCH_CHECK();
   return 0;
 }
