@@ -248,19 +248,36 @@ __device__ __forceinline__ void load_rows_to_lds(char* dst, const void* src, con
 // ring[r][ni] holds the weight fragments of step r of this layer on entry (r < RING); on exit it holds the first RING
 // steps of the next layer (prefetched while the last steps of this one run).
 // wcur / wnxt: this wave's fragment streams: [tile ni][step][lane][16 B]; tile stride = steps * 1 KiB.
-// The write-out of a K loop's INPUT tile (= the previous layer's output: a saved activation) can ride the K loop itself - the tile is only
-// read until the barrier behind the loop.  WoArgs: rows of `out` (row-major, row_bytes each, first row = the tile's first row) for the
-// tile's first `rows` rows; a thread moves chunk tid + j * NT (16 bytes) for j < 16, one every other K step: an LDS read in the even
-// step, the global store in the odd one.  (8-wave 512-feature build: behind the second barrier the same copy was 16 % of a layer's
-// time with the matrix pipe idle - profiles/r06_experiments.md 4.)
+// The write-out of a layer's INPUT tile (= the previous layer's output: a saved activation), 8-wave 512-feature build.  Behind the second
+// barrier, in front of the next K loop, this copy was 16 % of a layer's time with the matrix pipe idle.  It cannot ride the K loop: the
+// loop's weight stream already fills the CU's vector memory path at the matrix pipe's pace (512 KiB per 128-row tile-layer = 31 B/clk),
+// and stores retire through the same in-order counter as the fragment loads - measured: the loop got slower by exactly what the copy had
+// cost (profiles/r06_experiments.md 4).  It rides the EPILOGUE instead, which is VALU-bound and issues no loads: wave w copies out the
+// 64-feature column block it is about to overwrite (rows of 128 contiguous bytes: 8 lanes per row), one 32-row tile ahead of its own writes.
 struct WoArgs {
-  char* out;          // nullptr: nothing to write
-  int row_bytes, rows, tid;
+  char* out;          // first row of the tile in the save tensor (row-major, row_bytes per row); nullptr: nothing to write
+  int row_bytes, rows;
 };
-template <typename T, int NSTEPS, bool WO = false>
+template <typename T>
+__device__ __forceinline__ void writeout_cols(const char* act, const WoArgs& wo, int wn, int lane, int mi) {
+  const int cpr = wo.row_bytes >> 4;                    // 16-byte chunks per row
+  const int ch = wn * (NI * 4) + (lane & 7);            // (a wave owns NI * 32 features = NI * 4 chunks of 16-bit elements)
+  if (ch >= cpr) return;
+  uint4 v[4];
+  int row[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    row[q] = mi * 32 + q * 8 + (lane >> 3);
+    v[q] = load_chunk_from_act<T>(act, row[q] < Cfg<T>::BM ? row[q] : 0, ch);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (row[q] < wo.rows) *(uint4*)(wo.out + (long)row[q] * wo.row_bytes + ch * 16) = v[q];
+}
+template <typename T, int NSTEPS>
 __device__ __forceinline__ void k_loop(f32x16_t (&acc)[Cfg<T>::MI][NI], typename Cfg<T>::wfrag_t (&ring)[RING][NI],
                                        const char* act, const int (&aoff)[16], __amdgpu_buffer_rsrc_t wcur,
-                                       __amdgpu_buffer_rsrc_t wnxt, int nxt_steps, int lane16, const WoArgs wo = WoArgs{nullptr, 0, 0, 0}) {
+                                       __amdgpu_buffer_rsrc_t wnxt, int nxt_steps, int lane16) {
   constexpr int MI = Cfg<T>::MI;
   typedef typename Cfg<T>::wfrag_t wfrag_t;
   const int ts_n = nxt_steps * 1024;
@@ -301,26 +318,9 @@ __device__ __forceinline__ void k_loop(f32x16_t (&acc)[Cfg<T>::MI][NI], typename
     bf16x8_t a0 = aread(0, 0), a1;
 #define SWN_PIN() __builtin_amdgcn_sched_barrier(0)
     if constexpr (MI == 4) {
-      // deferred write-out (WO): chunk geometry of the rows being written
-      uint4 wv = make_uint4(0u, 0u, 0u, 0u);
-      const int cpr = WO ? (wo.row_bytes >> 4) : 1;
-      const int wsh = 31 - __builtin_clz(cpr);
-      const int wtotal = WO ? wo.rows * cpr : 0;
-      constexpr int WPIECES = Cfg<T>::BM * (ROW_ELEMS * (int)sizeof(T) / 16) / NT;      // chunks per thread of a full tile (16)
-      static_assert(!WO || 2 * WPIECES <= NSTEPS, "deferred write-out: one chunk every other K step");
 #pragma unroll
       for (int ks = 0; ks < NSTEPS; ++ks) {
         const int r = ks % RING;
-        if constexpr (WO) {
-          if (ks < 2 * WPIECES) {
-            const int c = wo.tid + (ks >> 1) * NT;
-            if (wo.out && c < wtotal) {
-              const int row = c >> wsh, ch = c & (cpr - 1);
-              if ((ks & 1) == 0) wv = load_chunk_from_act<T>(act, row, ch);
-              else *(uint4*)(wo.out + (long)row * wo.row_bytes + ch * 16) = wv;
-            }
-          }
-        }
         a1 = aread(ks, 1);
         SWN_PIN();
         acc[0][0] = SWN_MFMA_32x32x16(ring[r][0], a0, acc[0][0]);
@@ -393,7 +393,7 @@ template <typename T, bool DYN, int RELU_, bool SKIP_, bool BIAS_, bool RB_>
 __device__ __forceinline__ void epilogue_body(f32x16_t (&acc)[Cfg<T>::MI][NI], char* act, const char* bias_lds, const float* rbp,
                                               uint32_t* mk, int wn, int l31, int lhi, int nvalid, long grow0, int rows_per_bias,
                                               int n, int relu_d, bool skip_d, bool bias_d, int rows_in_tile,
-                                              const uint32_t* mpre = nullptr) {
+                                              const uint32_t* mpre = nullptr, const WoArgs wo = WoArgs{nullptr, 0, 0}, int lane_wo = 0) {
   constexpr int MI = Cfg<T>::MI;
   const int relu = DYN ? relu_d : RELU_;
   const bool skip = DYN ? skip_d : SKIP_;
@@ -413,6 +413,9 @@ __device__ __forceinline__ void epilogue_body(f32x16_t (&acc)[Cfg<T>::MI][NI], c
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = mi * 32 + l31;
+#if SWN_WIDE == 2
+    if (wo.out) writeout_cols<T>(act, wo, wn, lane_wo, mi);      // the input tile's rows of this row tile, before they are overwritten
+#endif
     mbits_t mbits = 0;       // 16 bits per feature tile: one word per pair of tiles ([half][mi][lane] per wave)
     if (relu == 2) {
 #if SWN_WIDE == 2
@@ -708,17 +711,7 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
 #if SWN_TIMING_ON
     long long q0 = TICK();
 #endif
-#if SWN_WIDE == 2
-    if (steps == 512 / KSTEP) {
-      // (the previous layer's saved activation = this K loop's input tile leaves the LDS DURING the loop: see WoArgs)
-      WoArgs wo{nullptr, 0, 0, 0};
-      if (L > 0 && d.layers[L - 1].save) {
-        const int rb = d.layers[L - 1].n * (int)sizeof(T);
-        wo = WoArgs{(char*)d.layers[L - 1].save + grow0 * rb, rb, rows_in_tile, tid};
-      }
-      k_loop<T, 512 / KSTEP, true>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16, wo);
-    } else
-#elif SWN_WIDE
+#if SWN_WIDE
     if (steps == 512 / KSTEP) k_loop<T, 512 / KSTEP>(acc, ring, act, aoff, wcur, wnxt, nsteps_next, lane16);
     else
 #endif
@@ -740,6 +733,22 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
 #endif
 
 #endif
+#if SWN_WIDE == 2 && !SWN_CONCAT
+    // the previous layer's saved activation = this layer's input tile, still in LDS: written out by the epilogue below (WoArgs)
+    WoArgs wo{nullptr, 0, 0};
+    if (TAG != 4 && L > 0 && d.layers[L - 1].save) {      // (tag 4 - the tail chain without fused heads - keeps the copy behind the barrier: registers)
+      const int rb = d.layers[L - 1].n * (int)sizeof(T);
+      wo = WoArgs{(char*)d.layers[L - 1].save + grow0 * rb, rb, rows_in_tile};
+    }
+    if (wo.out && (ly.skip || !wave_active)) {      // (a skip layer overwrites the tile with the chain input first; a wave beyond the layer's
+      int ln = lane;                                //  width runs no epilogue: these copy their column block out right here)
+      asm volatile("" : "+v"(ln));
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) writeout_cols<T>(act, wo, wn, ln, mi);
+      wo.out = nullptr;
+      if (ly.skip) __syncthreads();
+    }
+#endif
     if (ly.skip) {  // the input tile is dead: bring the chain input x back into the SAME LDS tile; each lane then reads
                     // its x values and writes h over them in place
       load_rows_to_lds<T>(act, d.x, d.x_gather, nullptr, grow0, rows_in_tile, d.layers[0].k, tid, d.x_scale, d.x_relu);
@@ -757,7 +766,8 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
       const int nvalid = n - wn * 32 * NI;   // feature tiles of this wave that exist: nvalid >= 32 NI -> all
 #if SWN_WIDE == 2 && !SWN_CONCAT
       epilogue_body<T, true, 0, false, false, false>(acc, act, bias_lds, rbp, mk, wn, l31e, lhie, nvalid, grow0, ly.rows_per_bias, n,
-                                                     ly.relu, ly.skip == 1, ly.b != nullptr, rows_in_tile, mpre_on ? mpre : nullptr);
+                                                     ly.relu, ly.skip == 1, ly.b != nullptr, rows_in_tile, mpre_on ? mpre : nullptr, wo,
+                                                     l31e + 32 * lhie);
 #else
       epilogue_body<T, true, 0, false, false, false>(acc, act, bias_lds, rbp, mk, wn, l31e, lhie, nvalid, grow0, ly.rows_per_bias, n,
                                                      ly.relu, ly.skip == 1, ly.b != nullptr, rows_in_tile);
@@ -779,8 +789,8 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
     const bool last = (L == d.n_layers - 1);
     void* outp = last ? d.y : ly.save;
     if (TAG == 5 && last && d.comb_y) outp = nullptr;       // the fused combine backward writes the last layer out behind the loop
-#if SWN_WIDE == 2
-    if (!last && d.layers[L + 1].k / KSTEP == 512 / KSTEP) outp = nullptr;      // rides the next layer's K loop (WoArgs)
+#if SWN_WIDE == 2 && !SWN_CONCAT
+    if (TAG != 4 && !last) outp = nullptr;      // rides the next layer's epilogue (WoArgs)
 #endif
     if (outp) {
       const int row_bytes = n * (int)sizeof(T);
