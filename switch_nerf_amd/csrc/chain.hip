@@ -258,20 +258,22 @@ struct WoArgs {
   char* out;          // first row of the tile in the save tensor (row-major, row_bytes per row); nullptr: nothing to write
   int row_bytes, rows;
 };
-template <typename T>
+template <typename T, int Q0 = 0, int NQ = 4>
 __device__ __forceinline__ void writeout_cols(const char* act, const WoArgs& wo, int wn, int lane, int mi) {
   const int cpr = wo.row_bytes >> 4;                    // 16-byte chunks per row
   const int ch = wn * (NI * 4) + (lane & 7);            // (a wave owns NI * 32 features = NI * 4 chunks of 16-bit elements)
   if (ch >= cpr) return;
-  uint4 v[4];
-  int row[4];
+  uint4 v[NQ];                                          // 8 rows per slice q in [Q0, Q0 + NQ): four slices cover the row tile
+  int row[NQ];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    row[q] = mi * 32 + q * 8 + (lane >> 3);
+  for (int q = 0; q < NQ; ++q) {
+    // (adjacent 8-lane groups read rows 8 apart: their swizzled chunks fall into different halves of the 256-byte bank span - with
+    //  consecutive rows the 16-byte reads of a 16-lane pass were 2-way conflicted)
+    row[q] = mi * 32 + 16 * ((Q0 + q) >> 1) + 4 * ((Q0 + q) & 1) + (lane >> 4) + 8 * ((lane >> 3) & 1);
     v[q] = load_chunk_from_act<T>(act, row[q] < Cfg<T>::BM ? row[q] : 0, ch);
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < NQ; ++q)
     if (row[q] < wo.rows) *(uint4*)(wo.out + (long)row[q] * wo.row_bytes + ch * 16) = v[q];
 }
 template <typename T, int NSTEPS>
@@ -386,6 +388,88 @@ __device__ __forceinline__ void k_loop(f32x16_t (&acc)[Cfg<T>::MI][NI], typename
   }
 }
 
+#if SWN_WIDE == 2
+// ---- the packed 16-bit epilogue of the 8-wave 512-feature build (the idiom of chain_big.hip's epilogue) --------------------------------
+// A non-packed VALU instruction costs a wave 4 clocks and this workgroup runs its epilogue with the matrix pipe idle (two waves per SIMD,
+// lockstep): ~5.5 VALU per value (add, compare, two selects, shift-or, half a convert) were half as long as the K loop.  ReLU and its mask
+// work on the PACKED results - bf16 / fp16 are sign-magnitude, as int16 a negative value or -0 is < 0:
+//   forward:  p = cvt_pk(z0 + b0, z1 + b1);  p = pk_max_i16(p, 0);  m |= pk_min_u16(p, 1) << d        (mask bit = rounded output > 0)
+//   backward: p = pk_mul_lo_u16(cvt_pk(g0, g1), pk_min_u16(m & (0x00010001 << d), 1))
+// Mask layout of THIS build (forward and backward chains of a model run on the same one): one dword per (mi, lane); packed pair
+// d = ni * 8 + g4 * 2 + i has its low half at bit d, its high half at bit d + 16.  Layers with a residual input or a per-row bias keep
+// the generic epilogue below (their masks use the same layout: see `PK_MASK`).
+typedef __attribute__((ext_vector_type(2))) short i16x2_t;
+__device__ __forceinline__ uint32_t pk_relu16(uint32_t p) {
+  const i16x2_t z = {0, 0};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, p), z));
+}
+__device__ __forceinline__ uint32_t pk_nonzero16(uint32_t p) {      // 0 / 1 per half: min(half, 1) unsigned
+  uint32_t q;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(q) : "v"(p), "s"(0x00010001u));
+  return q;
+}
+__device__ __forceinline__ uint32_t pk_mul16(uint32_t p, uint32_t t) {
+  uint32_t q;
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(q) : "v"(p), "v"(t));
+  return q;
+}
+#endif
+
+#if SWN_WIDE == 2
+template <typename T, int RELU, bool BIAS>
+__device__ __forceinline__ void epilogue_packed(f32x16_t (&acc)[Cfg<T>::MI][NI], char* act, const char* bias_lds, uint32_t* mk, int wn, int l31,
+                                                int lhi, const uint32_t* mpre, const WoArgs& wo, int lane_wo) {
+  constexpr int MI = Cfg<T>::MI;
+  const int cbase = wn * (NI * 4);               // first 16-byte chunk of this wave's columns
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = mi * 32 + l31;
+    // (the input tile's rows 32 mi .. + 31 of this wave's columns leave before this row tile is rewritten - all four 8-row slices
+    //  in front of the first write, two in flight at a time: registers)
+    if (wo.out) { writeout_cols<T, 0, 2>(act, wo, wn, lane_wo, mi); writeout_cols<T, 2, 2>(act, wo, wn, lane_wo, mi); }
+    uint32_t mb = 0;
+    if constexpr (RELU == 2) mb = mpre ? mpre[mi] : mk[mi * 64];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      float4 bq[4];
+      if constexpr (BIAS) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) bq[g4] = *(const float4*)(bias_lds + (wn * (32 * NI) + ni * 32 + g4 * 8 + lhi * 4) * 4);
+      }
+      uint32_t pk[4][2];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float z0 = acc[mi][ni][g4 * 4 + 2 * i], z1 = acc[mi][ni][g4 * 4 + 2 * i + 1];
+          if constexpr (BIAS) { z0 += i ? bq[g4].z : bq[g4].x; z1 += i ? bq[g4].w : bq[g4].y; }
+          uint32_t p = pack_bf16x2(z0, z1);
+          const int d = ni * 8 + g4 * 2 + i;
+          if constexpr (RELU == 1) {
+            p = pk_relu16(p);
+            mb |= pk_nonzero16(p) << d;
+          } else if constexpr (RELU == 2) {
+            p = pk_mul16(p, pk_nonzero16(mb & (0x00010001u << d)));
+          }
+          pk[g4][i] = p;
+        }
+      }
+      // The half-waves exchange 8-byte pieces (v_permlane32_swap) so that a lane writes one whole 16-byte chunk: the lower half-wave
+      // ends up with chunk g of its row, the upper one with chunk g + 1 (conflict-free ds_write_b128; the 8-byte form is 2-way conflicted)
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        auto r0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+        const uint4 o = make_uint4((uint32_t)r0[0], (uint32_t)r1[0], (uint32_t)r0[1], (uint32_t)r1[1]);
+        *(uint4*)(act + m * Cfg<T>::ROWB + (((cbase + ni * 4 + g + lhi) ^ (m & 15)) << 4)) = o;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (RELU == 1) { if (mk) mk[mi * 64] = mb; }
+  }
+}
+#endif
+
 // ---- epilogue of one layer: accumulators -> (+bias, +per-ray bias, +skip input) -> ReLU / stored mask -> LDS tile ------
 // A lane owns row m = mi*32 + l31 and, per feature tile ni and group g4, features n0 .. n0+3 (n0 = wn*64+ni*32+g4*8+lhi*4).
 // Compile-time flags keep the hot variants straight-line; `mk` points at this lane's first mask word (stride 64 per mi).
@@ -400,15 +484,16 @@ __device__ __forceinline__ void epilogue_body(f32x16_t (&acc)[Cfg<T>::MI][NI], c
   const bool bias = DYN ? bias_d : BIAS_;
   const bool rowb = DYN ? (rbp != nullptr) : RB_;
 #if SWN_WIDE == 2
-  // (8-wave 512-feature build) the wave's 64 bias values are read ONCE, in front of the row tiles - read inside every group of four
-  // values, behind a scheduling barrier, each of the 32 groups of a lane waited for its own LDS round trip; the stored ReLU masks of a
-  // backward layer arrive in `mpre`, fetched in front of the K loop (profiles/r06_experiments.md 4)
-  float4 bq[NI][4];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4)
-      bq[ni][g4] = bias ? *(const float4*)(bias_lds + (wn * (32 * NI) + ni * 32 + g4 * 8 + lhi * 4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (sizeof(T) == 2) {
+    if (!skip && !rowb && nvalid >= 32 * NI) {       // the packed epilogue (see pk_relu16): every expert / front layer of the 512-feature models
+      // (compile-time variants, dispatched ONCE: with `relu` / `bias` tested inside the unrolled loops every packed pair carried two
+      //  scalar compare-and-branch pairs - the epilogue segment was 2400 scalar and 300 idle instructions for 3200 vector ones)
+      if (relu == 1) { if (bias) epilogue_packed<T, 1, true>(acc, act, bias_lds, mk, wn, l31, lhi, mpre, wo, lane_wo); else epilogue_packed<T, 1, false>(acc, act, bias_lds, mk, wn, l31, lhi, mpre, wo, lane_wo); }
+      else if (relu == 2) { if (bias) epilogue_packed<T, 2, true>(acc, act, bias_lds, mk, wn, l31, lhi, mpre, wo, lane_wo); else epilogue_packed<T, 2, false>(acc, act, bias_lds, mk, wn, l31, lhi, mpre, wo, lane_wo); }
+      else { if (bias) epilogue_packed<T, 0, true>(acc, act, bias_lds, mk, wn, l31, lhi, mpre, wo, lane_wo); else epilogue_packed<T, 0, false>(acc, act, bias_lds, mk, wn, l31, lhi, mpre, wo, lane_wo); }
+      return;
+    }
+  }
 #endif
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
@@ -436,14 +521,10 @@ __device__ __forceinline__ void epilogue_body(f32x16_t (&acc)[Cfg<T>::MI][NI], c
           float v[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][g4 * 4 + j];
-#if SWN_WIDE == 2
-          if (bias) { v[0] += bq[ni][g4].x; v[1] += bq[ni][g4].y; v[2] += bq[ni][g4].z; v[3] += bq[ni][g4].w; }
-#else
           if (bias) {
             const float4 b4 = *(const float4*)(bias_lds + n0 * 4);
             v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
           }
-#endif
           if (rowb) {
             const float4 b4 = *(const float4*)(rb + n0);
             v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
@@ -458,16 +539,21 @@ __device__ __forceinline__ void epilogue_body(f32x16_t (&acc)[Cfg<T>::MI][NI], c
               for (int j = 0; j < 4; ++j) v[j] += *(const float*)(act + act_off((float*)nullptr, m, n0 + j));
             }
           }
+#if SWN_WIDE == 2
+#define SWN_MASK_BIT(ni, g4, j) ((ni) * 8 + (g4) * 2 + ((j) >> 1) + 16 * ((j) & 1))      // the packed epilogue's layout (value j of a group: pair j / 2, half j % 2)
+#else
+#define SWN_MASK_BIT(ni, g4, j) ((ni) * 16 + (g4) * 4 + (j))
+#endif
           if (relu == 1) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const bool pos = v[j] > 0.f;
-              mbits |= (mbits_t)(pos ? 1u : 0u) << (ni * 16 + g4 * 4 + j);
+              mbits |= (mbits_t)(pos ? 1u : 0u) << SWN_MASK_BIT(ni, g4, j);
               v[j] = pos ? v[j] : 0.f;
             }
           } else if (relu == 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = ((mbits >> (ni * 16 + g4 * 4 + j)) & (mbits_t)1) ? v[j] : 0.f;
+            for (int j = 0; j < 4; ++j) v[j] = ((mbits >> SWN_MASK_BIT(ni, g4, j)) & (mbits_t)1) ? v[j] : 0.f;
           }
           if constexpr (sizeof(T) == 2) {
             uint2 pk;
