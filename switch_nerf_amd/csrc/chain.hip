@@ -38,6 +38,9 @@
 #define SWN_NS swn
 #endif
 #define SWN_AUX (SWN_WIDE || SWN_CONCAT)      // an auxiliary build: kernels + launcher only, no C entry points
+#ifndef SWN_STATIC_EPI
+#define SWN_STATIC_EPI 1                      // compile-time variants of the epilogue for the common layers (0: the dynamic one only)
+#endif
 // -DSWN_EXP_TIMING: s_memtime phase timers of wave 0 of the first 4096 workgroups, written through d.y_add_gather (reinterpreted
 // as int64 [4096][8]; scripts/chain_timing.py, scripts/experiments/chain_wide_timing.py).  Default and 8-wave 512-feature builds; off = no code.
 #if defined(SWN_EXP_TIMING) && (!SWN_AUX || SWN_WIDE == 2)
@@ -855,6 +858,17 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
                                                      ly.relu, ly.skip == 1, ly.b != nullptr, rows_in_tile, mpre_on ? mpre : nullptr, wo,
                                                      l31e + 32 * lhie);
 #else
+      // the common layers (no residual input, no per-row bias) as compile-time variants, dispatched once - with the flags tested inside the
+      // unrolled loops every group of four values carried scalar compare-and-branch pairs (profiles/r06_experiments.md 4); the rest: dynamic
+#define SWN_EPI(R_, B_) epilogue_body<T, false, R_, false, B_, false>(acc, act, bias_lds, rbp, mk, wn, l31e, lhie, nvalid, grow0, ly.rows_per_bias, \
+                                                                      n, R_, false, B_, rows_in_tile)
+      // (not in the default build's 16-bit 64-row kernels: two workgroups per CU = 128 registers, the variants spill 28 of them)
+      if (SWN_STATIC_EPI && (SWN_AUX || sizeof(T) == 4) && ly.skip != 1 && rbp == nullptr) {
+        if (ly.relu == 1) { if (ly.b) SWN_EPI(1, true); else SWN_EPI(1, false); }
+        else if (ly.relu == 2) { if (ly.b) SWN_EPI(2, true); else SWN_EPI(2, false); }
+        else { if (ly.b) SWN_EPI(0, true); else SWN_EPI(0, false); }
+      } else
+#undef SWN_EPI
       epilogue_body<T, true, 0, false, false, false>(acc, act, bias_lds, rbp, mk, wn, l31e, lhie, nvalid, grow0, ly.rows_per_bias, n,
                                                      ly.relu, ly.skip == 1, ly.b != nullptr, rows_in_tile);
 #endif
