@@ -1528,10 +1528,29 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
   // ---- the tile queue (wave 0 only) ----
   const int xq = args.n_queues == 8 ? (int)(blockIdx.x & 7) : 0;
   int kq = 0;                                    // (no counters: the kq-th tile of this workgroup is block b + kq * grid)
-  auto claim = [&]() -> int {                    // one ticket of this workgroup's queue (lane 0; NOT waited for: consume with grab)
+  // Work stealing between the eight per-XCD queues: a workgroup whose own queue is exhausted moves on to its neighbours' (sq = how many
+  // queues it has left behind).  The static group -> XCD map balances over MANY segments (XCD x meets expert (x + s) & 7 in segment s);
+  // with the two segments of a 1024-ray share the busiest XCD held 128 tiles, the idlest 3 - the launch ran four rounds where three
+  // tile the chip (profiles/r06_experiments.md 5).  Stolen tiles read their expert's weights through a cold L2: last round only.
+  // (sq lives in LDS - gcount[2], wave 0 only - not in a register that every wave would carry through all its phases)
+  auto cur_sq = [&]() -> int { return __builtin_amdgcn_readfirstlane(*(volatile int*)(gcount + 2)); };
+  auto claim = [&]() -> int {                    // one ticket of the queue this workgroup works on (lane 0; NOT waited for: consume with grab)
     int q = 0;
-    if (d.sched && fresh_lane() == 0) q = __hip_atomic_fetch_add(d.sched + xq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d.sched) {
+      const int sq = cur_sq();
+      if (fresh_lane() == 0) q = __hip_atomic_fetch_add(d.sched + ((xq + sq) & 7), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     return q;
+  };
+  auto next_queue = [&]() -> bool {              // the current queue is empty: mark it (sched[9]: one bit per queue) and move on to the next
+    int m = 0;                                   // queue nobody has marked yet - one round trip, not one claim per dead queue; false: none left
+    int sq = cur_sq();
+    const int bit = 1 << ((xq + sq) & 7);
+    if (fresh_lane() == 0) m = __hip_atomic_fetch_or(d.sched + 9, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | bit;
+    m = __builtin_amdgcn_readfirstlane(m);
+    do { ++sq; } while (sq < 8 && ((m >> ((xq + sq) & 7)) & 1));
+    if (fresh_lane() == 0) *(volatile int*)(gcount + 2) = sq;
+    return sq < 8;
   };
   auto grab = [&](int slot, int ticket) {        // the next tile with at least one valid row -> tinfo[slot] (vb = -1: the queue is empty);
                                                  // `ticket`: a claim issued earlier (its round trip hidden behind other work)
@@ -1546,9 +1565,15 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
         q = first ? ticket : claim();
         first = false;
         q = __builtin_amdgcn_readfirstlane(q);
+        const int xs = (xq + cur_sq()) & 7;      // the queue the ticket came from
         if (args.n_queues != 8) vb = q;
-        else if (args.per_queue == 0) vb = q * 8 + xq;
-        else vb = q < args.per_queue ? xq * args.per_queue + q : args.n_vb;
+        else if (args.per_queue == 0) vb = q * 8 + xs;
+        else vb = q < args.per_queue ? xs * args.per_queue + q : args.n_vb;
+        if (args.n_queues == 8 && vb >= args.n_vb) {      // this queue is empty: the next live one (its tickets are claimed afresh)
+          if (next_queue()) continue;
+          vb = -1;
+          break;
+        }
       } else {
         vb = (int)blockIdx.x + kq * (int)gridDim.x;
         ++kq;
@@ -1560,7 +1585,10 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
           rows_valid = min(*d.tail_n_dropped, d.tail_dropped_max);
           tile = vb - args.n_vb_e;
           g = -1;
-          if (tile * BM >= rows_valid) vb = -1;  // (a queue hands its tiles out in order: everything behind this one is empty too)
+          if (tile * BM >= rows_valid) {         // (a queue hands its tiles out in order: everything behind this one is empty too)
+            if (args.n_queues == 8 && d.sched && next_queue()) continue;
+            vb = -1;
+          }
           break;
         }
       }
@@ -1614,7 +1642,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
       const int done = __hip_atomic_fetch_add(d.sched + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (done == (int)gridDim.x - 1) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) __hip_atomic_store(d.sched + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 10; ++i) __hip_atomic_store(d.sched + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   };
@@ -1762,7 +1790,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
     if (tid < 256) ((float*)(smem + T_WS))[tid] = d.comb_wsig ? d.comb_wsig[tid] : 0.f;
   }
   // ---- prologue: the first tile, its source rows ----
-  if (cx.w == 0 && cx.lane < 2) gcount[cx.lane] = 0;
+  if (cx.w == 0 && cx.lane < 3) gcount[cx.lane] = 0;      // ([2]: queues this workgroup has left behind - work stealing)
   if (cx.w == 0) grab(0, claim());
   SWN_WAIT_LGKM0();
   __builtin_amdgcn_s_barrier();
