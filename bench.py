@@ -766,6 +766,9 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if dist:
+        # (the ONE line is out: whatever the communicator's teardown prints - RCCL writes its version banner to stdout - goes to stderr)
+        sys.stdout.flush()
+        os.dup2(2, 1)
         graphed[0] = None
         from switch_nerf_amd import parallel as _par
         _par.shutdown()
