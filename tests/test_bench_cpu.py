@@ -52,3 +52,17 @@ def test_traffic_table_is_made_by_script_and_tied_to_the_kernel_sources(tmp_path
     assert t["csrc_sha256"] == h and t["points"] == 8192 * 256 and t["kept_rows"] == round(0.78 * 8192 * 256)
     assert t["launches"]["expert_fwd"]["hbm_bytes"] == int((2 * 1.0e6 + 9.0e6) * 1024)
     assert t["launches"]["expert_bwd"]["hbm_bytes"] == int((2 * (2.0e6 + 100) + 9.5e6 + 100) * 1024)
+
+
+def test_kernel_switches_are_resolved_once_from_the_environment():
+    """model.resolve_kernel_switches: the SWN_* knobs parse into the switch set a model keeps (no forward / backward reads os.environ:
+    VERDICT round 5 item 9); an empty environment = the shipped kernel set."""
+    from switch_nerf_amd.model import resolve_kernel_switches, SwitchNeRF
+    d = resolve_kernel_switches({})
+    assert d == dict(front_geom=7, chain_geom=7, tail_geom=1, fused_tail=True, fused_tail_bwd=True, fused_dwsig=True, fused_heads=True, overlap=True)
+    e = resolve_kernel_switches({"SWN_CHAIN_GEOM": "5", "SWN_FUSED_TAIL": "0", "SWN_NO_OVERLAP": "1", "SWN_NO_FUSED_HEADS": "1", "SWN_FRONT_GEOM": "1"})
+    assert (e["chain_geom"], e["fused_tail"], e["overlap"], e["fused_heads"], e["front_geom"]) == (5, False, False, False, 1)
+    import inspect
+    src = inspect.getsource(SwitchNeRF)
+    body = src[src.index("def forward_rays"):]
+    assert "os.environ" not in body, "forward / backward must not read the environment"

@@ -250,3 +250,53 @@ def test_expert_parallel_kept_rows_only_exchange_gloo():
     assert out[0][1] + out[1][1] == out[0][2] + out[1][2]
     for r in range(world):
         assert out[r][3] <= out[r][1] < out[r][4]
+
+
+def _loopback_worker(rank, world, port, out):
+    """ONE rank, gloo, loopback: every collective of the W > 1 code path is issued (the mode tests/test_rccl_gpu.py runs over RCCL)."""
+    import warnings
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from switch_nerf_amd import parallel
+    assert parallel.init_from_env(backend="gloo", loopback=True) == (0, 1) and dist.is_initialized() and dist.get_world_size() == 1
+    ep = parallel.ExpertParallel(0, 1, 8, loopback=True)
+    local = parallel.ExpertParallel(0, 1, 8)
+    res = dict(local_flags=(ep.local, local.local))
+    x = torch.arange(40.0).view(10, 4)
+    recv = torch.zeros(10, 4)
+    ep.all_to_all_v(x[:7], [7], recv[:7], [7])()
+    res["a2a_v"] = bool(torch.equal(recv[:7], x[:7]) and recv[7:].abs().sum() == 0)
+    r2, wait = ep.all_to_all(x)
+    wait()
+    res["a2a"] = bool(r2.data_ptr() != x.data_ptr() and torch.equal(r2, x))
+    counts = torch.tensor([[3, 300, 0, 7, 256, 1, 2, 9]], dtype=torch.int32)
+    res["counts"] = bool(torch.equal(ep.exchange_counts(counts, 256)(), counts.clamp(max=256)))
+    gc = torch.tensor([2, 0, 3, 1, 0, 0, 4, 0], dtype=torch.int32)
+    rows = torch.randn(10, 4)
+    back, rc = ep.all_to_all_ragged(rows, gc)
+    res["ragged"] = bool(torch.equal(back, rows) and torch.equal(rc, gc))
+    ar = parallel.make_grad_allreduce(loopback=True)
+    g = torch.randn(1000)
+    ref = g.clone()
+    ar.begin(g[300:])
+    s = ar.finish(g[:300])
+    res["allreduce"] = bool(ar.active and s == 1.0 and torch.equal(g, ref))
+    # a begin() without its finish(): the stale part is drained with a warning and counted (ADVICE round 5)
+    ar.begin(g[300:])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ar.begin(g[300:])
+        res["stale_warned"] = bool(any("begin() without finish()" in str(x_.message) for x_ in w) and ar.stale_drains == 1)
+    ar.finish(g[:300])
+    parallel.shutdown(timeout_s=30.0)
+    res["down"] = not dist.is_initialized()
+    out[0] = res
+
+
+def test_loopback_mode_issues_every_collective_gloo_world1():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_loopback_worker, args=(1, 29731 + os.getpid() % 200, out), nprocs=1, join=True)
+    r = out[0]
+    assert r["local_flags"] == (False, True)
+    assert all(r[k] for k in ("a2a_v", "a2a", "counts", "ragged", "allreduce", "stale_warned", "down")), r
