@@ -867,6 +867,10 @@ __global__ __launch_bounds__(NT, Cfg<T>::OCC) void chain_kernel(const ChainArgs 
         if (ly.relu == 1) { if (ly.b) SWN_EPI(1, true); else SWN_EPI(1, false); }
         else if (ly.relu == 2) { if (ly.b) SWN_EPI(2, true); else SWN_EPI(2, false); }
         else { if (ly.b) SWN_EPI(0, true); else SWN_EPI(0, false); }
+      } else if (SWN_STATIC_EPI && (SWN_AUX || sizeof(T) == 4) && ly.skip != 1 && rbp != nullptr && !ly.b && ly.relu == 1) {
+        // (layer "2" of the tail chain: per-ray bias, ReLU, no layer bias)
+        epilogue_body<T, false, 1, false, false, true>(acc, act, bias_lds, rbp, mk, wn, l31e, lhie, nvalid, grow0, ly.rows_per_bias, n, 1, false,
+                                                       false, rows_in_tile);
       } else
 #undef SWN_EPI
       epilogue_body<T, true, 0, false, false, false>(acc, act, bias_lds, rbp, mk, wn, l31e, lhie, nvalid, grow0, ly.rows_per_bias, n,
