@@ -301,6 +301,12 @@ int swn_composite_bounded_bwd(const float* raw, const float* z, const float* las
  * Builds the send buffer of the expert-parallel token exchange (the reference's all-to-all payload,
  * tutel_moe_layer_nobatch.py:157, 172) from the routing permutation.                                            */
 int swn_gather_rows(const void* src, const int32_t* index, long n_rows, int row_bytes, void* dst, void* stream);
+/* Sign bits of a 16-bit activation matrix [rows, features] (features a multiple of 32): bit j of word q of a row = (h[row][32 q + j] > 0),
+ * and back into a 0 / 1 matrix of the library's 16-bit type.  Expert parallelism with the tail on the expert's rank (ep_owner.py; replaces
+ * what tutel_moe_layer_nobatch.py:172-185 sends home): the per-ray bias gradient needs of layer "2"'s output only its ReLU mask - 16 bytes
+ * per token at 128 features travel instead of the 256-byte row.                                                                        */
+int swn_sign_bits_pack(const void* h, long rows, int features, uint32_t* bits, void* stream);
+int swn_sign_bits_unpack(const uint32_t* bits, long rows, int features, void* h, void* stream);
 
 /* ---- dense / grouped MLP chains on MFMA ------------------------------------------------------------------------
  * One launch runs `n_layers` (<= SWN_MAX_CHAIN_LAYERS) Linear layers back to back with the activations of a 128-row tile resident in

@@ -103,6 +103,8 @@ SIGNATURES = {
     "swn_hash_encode_bwd_xcd": [vp, vp, i32, i32, C.POINTER(HashCfg), vp, i32, i32, vp, vp, vp],
     "swn_hash_encode_bwd_binned": [vp, vp, i32, i32, C.POINTER(HashCfg), vp, i32, i32, vp, vp, sz, vp],
     "swn_gather_rows": [vp, vp, i64, i32, vp, vp],
+    "swn_sign_bits_pack": [vp, i64, i32, vp, vp],
+    "swn_sign_bits_unpack": [vp, i64, i32, vp, vp],
     "swn_mlp_chain": [C.POINTER(ChainDesc), vp],
     "swn_chain_big_ok": [C.POINTER(ChainDesc)],
     "swn_pack_weights": [vp, vp, i32, i32, i32, i32, i32, vp],

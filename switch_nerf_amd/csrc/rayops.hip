@@ -253,3 +253,61 @@ extern "C" int swn_ray_feat_wgrad(const float* feat, const float* dc_ray, int n_
   SWN_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- sign bits of a 16-bit activation matrix (expert parallelism with the tail on the expert's rank, ep_owner.py) ------------------------
+// The per-ray bias gradient needs of layer "2"'s output only its ReLU mask: the owner returns 1 bit per feature (16 bytes per token at 128
+// features) beside raw, the source rebuilds a 0 / 1 stand-in for swn_heads_bwd.  bit j of word q of a row = (h[row][32 q + j] > 0).
+namespace swn {
+__global__ __launch_bounds__(256) void sign_bits_pack_kernel(const bf16_t* __restrict__ h, long n_words, uint32_t* __restrict__ bits) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_words) return;
+  const uint4* p = (const uint4*)(h + t * 32);
+  uint32_t w = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint4 v = p[q];
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      w |= (bf16_to_f32((bf16_t)(u[i] & 0xFFFFu)) > 0.f ? 1u : 0u) << (q * 8 + 2 * i);
+      w |= (bf16_to_f32((bf16_t)(u[i] >> 16)) > 0.f ? 1u : 0u) << (q * 8 + 2 * i + 1);
+    }
+  }
+  bits[t] = w;
+}
+__global__ __launch_bounds__(256) void sign_bits_unpack_kernel(const uint32_t* __restrict__ bits, long n_words, bf16_t* __restrict__ h) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_words) return;
+  const uint32_t w = bits[t];
+  const uint32_t one = SWN_HALF_ONE_X2 & 0xFFFFu;
+  uint4* p = (uint4*)(h + t * 32);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t u[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      u[i] = (((w >> (q * 8 + 2 * i)) & 1u) ? one : 0u) | (((w >> (q * 8 + 2 * i + 1)) & 1u) ? (one << 16) : 0u);
+    p[q] = make_uint4(u[0], u[1], u[2], u[3]);
+  }
+}
+}  // namespace swn
+
+extern "C" int swn_sign_bits_pack(const void* h, long rows, int features, uint32_t* bits, void* stream) {
+  SWN_CHECK(h && bits, "swn_sign_bits_pack: null pointer");
+  SWN_CHECK(rows >= 0 && features > 0 && features % 32 == 0, "swn_sign_bits_pack: %ld rows of %d features (a multiple of 32)", rows, features);
+  const long n = rows * (features / 32);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(swn::sign_bits_pack_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), (const bf16_t*)h, n, bits);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int swn_sign_bits_unpack(const uint32_t* bits, long rows, int features, void* h, void* stream) {
+  SWN_CHECK(h && bits, "swn_sign_bits_unpack: null pointer");
+  SWN_CHECK(rows >= 0 && features > 0 && features % 32 == 0, "swn_sign_bits_unpack: %ld rows of %d features (a multiple of 32)", rows, features);
+  const long n = rows * (features / 32);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(swn::sign_bits_unpack_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), bits, n, (bf16_t*)h);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}

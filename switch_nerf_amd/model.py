@@ -39,6 +39,9 @@ def _ceil_to(x, m):
     return (x + m - 1) // m * m
 
 
+_EXP_RECORD_STREAM = os.environ.get("SWN_EXP_RECORD_STREAM") == "1"      # see SwitchNeRF._join_side_outputs (read once, experiment only)
+
+
 def resolve_kernel_switches(env=None) -> dict:
     """The kernel-selection switches of a model, resolved ONCE (SwitchNeRF.__init__ reads the process environment through this; no
     forward / backward looks at os.environ).  Defaults = the shipped kernel set; the SWN_* variables are experiment / test knobs:
@@ -545,16 +548,19 @@ class SwitchNeRF:
         return c
 
     def _join_side_outputs(self, ev, *tensors):
-        """The launch stream waits for work issued on the side stream, and tensors ALLOCATED there are recorded on the launch stream
-        (the caching allocator only tracks the allocating stream: without this a later side-stream allocation could reuse a block the
-        launch stream still reads).  Invariant for the other direction - tensors allocated on the launch stream and read on the side
-        stream (dc_ray, dh2, dsig in backward_net_a): every side-stream section starts with side.wait_event(<launch-stream event>) and
-        its readers' inputs are kept alive in the returned state until the join."""
-        main = torch.cuda.current_stream()
-        main.wait_event(ev)
-        for t in tensors:
-            if t is not None and t.is_cuda:
-                t.record_stream(main)
+        """The launch stream waits for work issued on the side stream.  Allocation invariant: tensors allocated on the side
+        stream (ray_feat, c_ray) are consumed on the launch stream, tensors allocated on the launch stream (dc_ray, dh2, dsig in
+        backward_net_a) are read on the side stream - safe because EVERY side-stream section starts with side.wait_event(<launch-stream
+        event>) and ends in an event the launch stream waits for before the tensors' last use, and the readers' inputs are kept alive in the
+        returned state until that join: no block can be handed to the other stream's allocations while it is still in use.
+        (`Tensor.record_stream` is deliberately NOT used: these tensors live in a captured graph's private pool - blocks with recorded
+        streams are freed through deferred events when the graph is dropped; a bench.py run that creates and drops two graphed steps died
+        with SIGSEGV once in a while with it, round 6.)"""
+        torch.cuda.current_stream().wait_event(ev)
+        if _EXP_RECORD_STREAM:      # (experiment only: scripts/experiments/graph_drop_stress.py reproduces the crash with it)
+            for t in tensors:
+                if t is not None and t.is_cuda:
+                    t.record_stream(torch.cuda.current_stream())
 
     def _net_forward_rows(self, pe, pe_dir, image_indices, N, S, seg_tokens, sigma_noise, routing_override, no_batch, tag, row_range):
         """One or more whole model chunks: front chain, gate, routing, expert chain, tail chain, heads -> c["raw"] [P, 4].
@@ -630,8 +636,11 @@ class SwitchNeRF:
         # the tail inside the expert launch (local experts, standard row space, whole point grid): the expert output never reaches memory
         c["tail_fused"] = (self._tail_fused() and self.ep is None and c["geom"] == 7 and row_range is None
                            and P * M * c_esz(dt) < (1 << 32) - 64)
+        # expert parallelism with the tail on the expert's rank (ep_owner.py): the same fused launches, on a received token space
+        from . import ep_owner
+        owner = ep_owner.eligible(self, c, no_batch, row_range)
         # (the fused tail's list of dropped tokens comes out of the routing launch)
-        want_drops = c["tail_fused"] and not packed
+        want_drops = (c["tail_fused"] or owner) and not packed
         routed = o.route_top1(c["idx"], c["gmax"], c["gates"], seg_tokens, E, cap, self.bpr, want_perm=not packed, want_drops=want_drops)
         c["loc"], c["counts"], c["perm"], c["tok2row"], c["l_aux"] = routed[:5]
         if want_drops:
@@ -732,6 +741,8 @@ class SwitchNeRF:
             # the local experts run on the (source rank, local expert) groups (first rows from a device prefix sum) -> all-to-all back into
             # the packed row space the combine gathers from.  The dispatch of segment s + 1 and the return of segment s - 1 travel while
             # the experts work on segment s.  One host read of the counts per forward pass (ExpertParallel.plan).
+            if owner:
+                return ep_owner.forward(self, c, pe_dir, image_indices, sigma_noise, sv)
             ep = self.ep
             W, El = ep.world, ep.El
             ngs = W * El
@@ -848,6 +859,9 @@ class SwitchNeRF:
         if c.get("no_grad"):
             raise RuntimeError("this context comes from an inference forward (training=False): nothing was saved for the backward")
         assert c.get("parts") is None, "ragged contexts go through backward_net"
+        if c.get("ep_owner") is not None:      # expert parallelism with the tail on the expert's rank
+            from . import ep_owner
+            return ep_owner.backward_a(self, c, d_raw, d_laux)
         N, S, P, n_seg, cap, seg_tokens = c["N"], c["S"], c["P"], c["n_seg"], c["cap"], c["seg_tokens"]
         M, E, L, G, H2 = self.M, self.E, self.L, self.G, self.H2
         g = self.g

@@ -102,6 +102,22 @@ def unmerge_grad(d_raw, order, n_fine: int, n_coarse: int):
     return d_fine, d_coarse
 
 
+def sign_bits_pack(h):
+    """[rows, F] 16-bit -> int32 [rows, F / 32]: bit j of word q = (h[:, 32 q + j] > 0) (include/swn.h swn_sign_bits_pack)."""
+    assert h.dim() == 2 and h.is_contiguous() and h.element_size() == 2 and h.shape[1] % 32 == 0
+    bits = torch.empty(h.shape[0], h.shape[1] // 32, dtype=torch.int32, device=h.device)
+    call("swn_sign_bits_pack", _p(h), int(h.shape[0]), int(h.shape[1]), _p(bits), _stream())
+    return bits
+
+
+def sign_bits_unpack(bits, dtype):
+    """int32 [rows, W] -> [rows, 32 W] of `dtype` (the library's 16-bit type): 1 where the bit is set, else 0."""
+    assert bits.dim() == 2 and bits.is_contiguous() and bits.dtype == torch.int32
+    h = torch.empty(bits.shape[0], bits.shape[1] * 32, dtype=dtype, device=bits.device)
+    call("swn_sign_bits_unpack", _p(bits), int(bits.shape[0]), int(h.shape[1]), _p(h), _stream())
+    return h
+
+
 def gather_rows(src, index, out=None):
     """out[r] = src[index[r]] (zero rows for index < 0); src [*, C] row-major, index int32 [R]."""
     R, Cc = index.numel(), src.shape[1]

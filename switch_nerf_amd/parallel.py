@@ -195,7 +195,7 @@ class ExpertParallel:
     world == 1 degenerates to the identity (no process group needed): the single-GPU parity test runs this path.
     """
 
-    def __init__(self, rank: int, world: int, n_experts: int, group=None, padded=False, loopback: bool = False):
+    def __init__(self, rank: int, world: int, n_experts: int, group=None, padded=False, loopback: bool = False, owner_tail: bool = False):
         """padded: False = kept rows only, unequal splits sized on the host (one device-to-host read per forward pass: the step cannot
         be captured into a hipGraph); True = the reference's own layout (tutel_moe_layer_nobatch.py:157: every (expert, capacity slot)
         travels, empty slots as zero rows) with EQUAL splits - nothing is read on the host, so the whole step, collectives included,
@@ -205,6 +205,10 @@ class ExpertParallel:
             raise ValueError(f"expert parallelism needs world ({world}) to divide the expert count ({n_experts})")
         self.rank, self.world, self.E, self.El, self.group = rank, world, n_experts, n_experts // world, group
         self.padded = padded
+        # owner_tail: the dense tail runs on the EXPERT's rank (ep_owner.py): both fused launches stay, 0.53 x the bytes of the default mode
+        # (kept rows out, raw + 16 bytes back; d_raw out, dx + the gate gradient back); eager, host-sized splits; 16-bit 256-feature models
+        # (others fall back to the default exchange)
+        self.owner_tail = bool(owner_tail)
         # local: ONE rank and no process group - nothing moves, the send buffers ARE the receive buffers.  loopback (one rank WITH a
         # process group, init_from_env(loopback=True)): every collective is issued like at W > 1 - separate send / receive buffers,
         # side stream, split sizes - and RCCL moves the payload inside the GPU: the W > 1 code path on a one-GPU box

@@ -1331,3 +1331,32 @@ def test_gate_fwd_with_gate_noise(dtype):
     if dtype == torch.float32:      # fp32 rows always take the VALU kernel: zero noise = the plain entry point, bit for bit
         gz, iz, mz, sz = ops().gate_fwd(g.to(dev()), lw.to(dev()), lb.to(dev()), wg.to(dev()), noise=torch.zeros(P, E, device=dev()), noise_scale=scale)
         assert torch.equal(gz, g0) and torch.equal(iz, i0) and torch.equal(mz, m0) and torch.equal(sz, s0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_sign_bits_pack_unpack(dtype):
+    """swn_sign_bits_pack / _unpack (the ReLU mask of layer "2" that expert parallelism with the tail on the expert's rank sends home instead
+    of the row): bit j of word q = (h[:, 32 q + j] > 0) - negative values, both zeros and NaN give 0 like torch's comparison - and the
+    0 / 1 matrix back; ragged row count."""
+    o = ops()
+    if dtype == torch.float16:
+        from switch_nerf_amd import _lib
+        _lib.use_half("f16")
+    try:
+        g = torch.Generator().manual_seed(5)
+        h = torch.randn(1000, 128, generator=g)
+        h[::7, ::5] = 0.0
+        h[1::7, 1::5] = -0.0
+        h[3, 3] = float("nan")
+        h = torch.relu(h).where(torch.rand(1000, 128, generator=g) > 0.1, h)      # mostly ReLU outputs, some raw values
+        hd = h.to(dev()).to(dtype).contiguous()
+        bits = o.sign_bits_pack(hd)
+        ref = (hd > 0).view(1000, 4, 32).to(torch.int64)
+        want = (ref << torch.arange(32, device=dev())).sum(-1)
+        got = bits.to(torch.int64) & 0xFFFFFFFF
+        assert torch.equal(got, want)
+        back = o.sign_bits_unpack(bits, dtype)
+        assert torch.equal(back, (hd > 0).to(dtype))
+    finally:
+        if dtype == torch.float16:
+            _lib.use_half("bf16")

@@ -305,6 +305,41 @@ def test_expert_parallel_path_single_rank_equals_local_experts(dtype, monkeypatc
         assert (a - b).abs().max().item() <= 1e-5 * max(a.abs().max().item(), 1e-12), name
 
 
+@pytest.mark.parametrize("cf,chunk", [(1.0, 2048), (0.5, 4096), (1.25, 2048)])
+def test_expert_parallel_owner_tail_single_rank_equals_fused_local_path(cf, chunk):
+    """ExpertParallel(owner_tail=True) (ep_owner.py: the dense tail on the expert's rank - the fused launches on a received token space,
+    raw + the sign bits of h2 home, d_raw out, dx + the gate gradient home) with world = 1, where every exchange is a copy: the forward
+    is BIT-identical to the local fused path (the same rows in the same tiles: raw, rgb, loss), the per-ray bias gradient is formed on the
+    source from the returned sign bits, and every parameter gradient agrees to summation order - with dropped tokens (capacity factor
+    0.5), spare capacity (1.25: ragged groups) and two optimizer steps."""
+    from switch_nerf_amd.parallel import ExpertParallel
+    N, S = 128, 64
+    rays, img, rgbs = synth.make_rays(171, N)
+    pr = torch.rand(N, S, generator=torch.Generator().manual_seed(9)).cuda()
+    noise = torch.randn(N * S, generator=torch.Generator().manual_seed(10)).cuda()
+    outs = []
+    for use_ep in (False, True):
+        m = _model(torch.bfloat16, 170, 1.0, capacity_factor=cf)
+        if use_ep:
+            m.set_expert_parallel(ExpertParallel(0, 1, m.E, owner_tail=True))
+        st = m.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=1.0, perturb_rand=pr, sigma_noise=noise, optimizer_step=False)
+        c = st["ctx"]
+        assert (c.get("ep_owner") is not None) == use_ep and c["tail_fused"]
+        g0 = m.grad.clone()
+        st2 = m.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=1.0, perturb_rand=pr, sigma_noise=noise)      # with Adam
+        st3 = m.train_step(_dev(rgbs), _dev(rays), _dev(img), S, chunk, perturb=1.0, perturb_rand=pr, sigma_noise=noise, optimizer_step=False)
+        outs.append((c["raw"].clone(), st["rgb"].clone(), st["loss"].clone(), g0, st3["loss"].clone(), int((c["loc"] >= c["cap"]).sum())))
+    a, b = outs
+    assert (a[5] > 0) == (cf < 1.25 or a[5] > 0) and a[5] == b[5]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert a[3].abs().sum().item() > 0
+    for name, (off, shape) in m.spec.items():
+        n = int(np.prod(shape))
+        x, y = a[3][off:off + n], b[3][off:off + n]
+        assert (x - y).abs().max().item() <= 2e-5 * max(x.abs().max().item(), 1e-12), name
+    assert abs(a[4].item() - b[4].item()) <= 5e-5 * abs(a[4].item())      # after one Adam step on those gradients
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_expert_parallel_padded_mode_is_host_free_and_graph_capturable(dtype, monkeypatch):
     """ExpertParallel(padded=True): the reference's capacity-padded equal-split exchange (tutel_moe_layer_nobatch.py:157) - standard row

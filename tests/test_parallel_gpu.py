@@ -60,6 +60,20 @@ def test_two_ranks_dp_and_ep_agree():
     assert xp["bytes_leaving_this_gpu_per_step"] == xp["capacity_padded_bytes_per_step"] and xp["collectives_per_step"] == 4 * xp["segments"]
 
 
+def test_two_ranks_owner_tail_expert_parallel_trains_like_data_parallel_with_half_the_bytes():
+    """ExpertParallel(owner_tail=True) on two ranks (one GPU, gloo): the experts' owner runs the fused launches on the tokens it receives
+    from both ranks; after two optimizer steps the loss equals the data-parallel run's, and what leaves a GPU is <= 0.55 x the kept-rows
+    mode's bytes (kept rows + 16 B per token out, 32 B per token back; 16 B out, dx + 4 B back)."""
+    dp = _run("dp", 29564, ("--no-ep-probe",))
+    ep = _run("ep", 29565)
+    ot = _run("ep", 29566, ("--ep-owner-tail",))
+    assert abs(dp["config"]["loss"] - ot["config"]["loss"]) <= 5e-5 * abs(dp["config"]["loss"])
+    assert abs(dp["config"]["kept_token_fraction"] - ot["config"]["kept_token_fraction"]) < 1e-3
+    x, y = ep["config"]["expert_parallel"], ot["config"]["expert_parallel"]
+    assert y["owner_tail"] and not x["owner_tail"] and ot["config"]["kernel_set"].get("ep_owner_tail")
+    assert 0 < y["bytes_leaving_this_gpu_per_step"] <= 0.55 * x["bytes_leaving_this_gpu_per_step"], (x["bytes_leaving_this_gpu_per_step"], y["bytes_leaving_this_gpu_per_step"])
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus N` without torchrun's environment must start N ranks itself (the driver calls it that way) - and
     must refuse, not silently run one rank, when the node has fewer devices."""
