@@ -676,7 +676,7 @@ def main():
         mean_rows = sum(per_rank) / max(1, len(per_rank))
         owner_ = c_.get("ep_owner") is not None
         return dict(exchange=("tail on the expert's rank: kept rows + 16 B per token out, raw + 16 B back; d_raw out, dx + gate gradient back "
-                              "(6 unequal-split all_to_all_single per segment and step, blocking)" if owner_ else
+                              "(7 unequal-split all_to_all_single per STEP over all segments, blocking)" if owner_ else
                               ("capacity-padded equal-split" if c_.get("ep_padded") else "kept rows only, unequal-split") +
                               " all_to_all_single per routing segment on a side HIP stream; 4 exchanges per segment and step (dispatch / "
                               "return, forward / backward)"), padded=bool(c_.get("ep_padded")), owner_tail=owner_,

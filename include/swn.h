@@ -307,6 +307,16 @@ int swn_gather_rows(const void* src, const int32_t* index, long n_rows, int row_
  * per token at 128 features travel instead of the 256-byte row.                                                                        */
 int swn_sign_bits_pack(const void* h, long rows, int features, uint32_t* bits, void* stream);
 int swn_sign_bits_unpack(const uint32_t* bits, long rows, int features, void* h, void* stream);
+/* dst[index[r]] = src[r] for rows of row_bytes (a multiple of 4; index < 0: the row goes nowhere; no index twice): the mirror of
+ * swn_gather_rows - what an exchange brought home in send order goes back to token order (the combine's scatter of
+ * tutel_moe_layer_nobatch.py:220-225 for the 16-byte results of the owner-tail mode).                                             */
+int swn_scatter_rows(const void* src, const int32_t* index, long n_rows, int row_bytes, void* dst, void* stream);
+/* The 16-byte record that travels with a kept token's row to its expert's rank (ep_owner.py):
+ *   aux[r] = (gate[t], int bits of (t / rows_per_ray + ray_base), noise[t] (0 if NULL), 0),  t = index[r]     (zero_gate != 0: gate 0)
+ * and its split into the fused launch's planar per-token operands on the receiving side (noise may be NULL).                      */
+int swn_owner_aux(const float* gate, const float* noise, const int32_t* index, long n, int rows_per_ray, int ray_base, int zero_gate,
+                  float* aux, void* stream);
+int swn_owner_aux_split(const float* aux, long n, float* gate, int32_t* ray, float* noise, void* stream);
 
 /* ---- dense / grouped MLP chains on MFMA ------------------------------------------------------------------------
  * One launch runs `n_layers` (<= SWN_MAX_CHAIN_LAYERS) Linear layers back to back with the activations of a 128-row tile resident in
@@ -435,6 +445,10 @@ typedef struct swn_chain_desc {
   const int32_t* tail_n_dropped;/* device int32 scalar                                                                              */
   int32_t tail_dropped_max;
   int32_t tail_tokens;
+  const int32_t* tail_bias_row; /* (tail_first > 0) device int32 [tail_tokens] or NULL: the row of the last layer's rowbias that token t adds,
+                                   instead of t / rows_per_bias - a token space that is not in ray order (expert parallelism with the tail on
+                                   the expert's rank, ep_owner.py: the tokens an owner received from every rank, rowbias = the all-gathered
+                                   per-ray terms)                                                                                       */
   swn_chain_layer layers[SWN_MAX_CHAIN_LAYERS];
 } swn_chain_desc;
 

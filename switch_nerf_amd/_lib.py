@@ -58,7 +58,7 @@ class ChainDesc(C.Structure):
                 ("comb_y", vp), ("comb_dsig", vp), ("comb_wsig", vp), ("comb_gate", vp), ("comb_dgate", vp), ("comb_dwsig", vp), ("comb_dwsig_ws", vp),
                 ("heads_ws", vp), ("heads_bs", vp), ("heads_wc", vp), ("heads_bc", vp), ("heads_noise", vp), ("heads_raw", vp), ("sched", vp), ("x_features", i32),
                 ("head_layers", i32), ("tail_first", i32), ("y_features", i32), ("tail_gate", vp), ("tail_dropped", vp), ("tail_n_dropped", vp),
-                ("tail_dropped_max", i32), ("tail_tokens", i32),
+                ("tail_dropped_max", i32), ("tail_tokens", i32), ("tail_bias_row", vp),
                 ("layers", ChainLayer * 12)]
 
 
@@ -105,6 +105,9 @@ SIGNATURES = {
     "swn_gather_rows": [vp, vp, i64, i32, vp, vp],
     "swn_sign_bits_pack": [vp, i64, i32, vp, vp],
     "swn_sign_bits_unpack": [vp, i64, i32, vp, vp],
+    "swn_scatter_rows": [vp, vp, i64, i32, vp, vp],
+    "swn_owner_aux": [vp, vp, vp, i64, i32, i32, i32, vp, vp],
+    "swn_owner_aux_split": [vp, i64, vp, vp, vp, vp],
     "swn_mlp_chain": [C.POINTER(ChainDesc), vp],
     "swn_chain_big_ok": [C.POINTER(ChainDesc)],
     "swn_pack_weights": [vp, vp, i32, i32, i32, i32, i32, vp],

@@ -1261,7 +1261,7 @@ extern "C" int swn_mlp_chain(const swn_chain_desc* desc, void* stream) {
     if (ly.skip == 1) SWN_CHECK(ly.n == d.layers[0].k, "swn_mlp_chain: skip layer %d needs n == chain input width", l);
     if (ly.skip == 2) SWN_CHECK(l + 1 < d.n_layers && !ly.save && !ly.mask && !ly.b && !ly.rowbias && ly.relu == 0,
                                 "swn_mlp_chain: a concat half (skip = 2) carries no bias / activation / save and is followed by its other half");
-    if (ly.rowbias) SWN_CHECK(ly.rows_per_bias > 0, "swn_mlp_chain: rows_per_bias must be > 0");
+    if (ly.rowbias) SWN_CHECK(ly.rows_per_bias > 0 || (d.tail_first > 0 && d.tail_bias_row), "swn_mlp_chain: rows_per_bias must be > 0 (or tail_bias_row in tail mode)");
     SWN_CHECK(ly.relu >= 0 && ly.relu <= 2, "swn_mlp_chain: relu mode %d", ly.relu);
     if (ly.relu == 2) SWN_CHECK(ly.mask != nullptr, "swn_mlp_chain: relu=2 (apply stored mask) needs a mask");
   }

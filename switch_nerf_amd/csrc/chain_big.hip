@@ -1358,8 +1358,8 @@ __device__ __forceinline__ void comb_pieces16_inplace(const Ctx& cx, int c0, con
 // of the layer arrives as a row bias (fp32 [rays][nf], the row of token / rpb), then ReLU.  nf = 128: the wave quarters beyond the
 // layer's width (zero-padded weights) only run the hooks.
 template <typename E, typename HOOK>
-__device__ __forceinline__ void epilogue_q_rowbias(f32x16_t (&acc)[4][2], const Ctx& cx, const float* rowbias, int rpb, int nf, int idx_off,
-                                                   HOOK hook) {
+__device__ __forceinline__ void epilogue_q_rowbias(f32x16_t (&acc)[4][2], const Ctx& cx, const float* rowbias, int rpb, const int32_t* bias_row,
+                                                   int nf, int idx_off, HOOK hook) {
   char* smem = cx.smem;
   const int fg = cx.w & 3;
   if (fg * 64 >= nf) {
@@ -1379,7 +1379,9 @@ __device__ __forceinline__ void epilogue_q_rowbias(f32x16_t (&acc)[4][2], const 
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     const uint32_t tok = (uint32_t)((const int*)(smem + idx_off))[row0 + 32 * mi];
-    rb[mi] = rowbias ? rowbias + (size_t)(tok / (uint32_t)rpb) * nf + fg * 64 + 4 * cx.lhi : nullptr;
+    // (bias_row: swn_chain_desc.tail_bias_row - a token space that is not in ray order, ep_owner.py)
+    const uint32_t br = bias_row ? (uint32_t)bias_row[tok] : tok / (uint32_t)rpb;
+    rb[mi] = rowbias ? rowbias + (size_t)br * nf + fg * 64 + 4 * cx.lhi : nullptr;
   }
   f32x4_t bq[2][4];
   auto fetch = [&](int t) {                 // the bias chunks of half step t = 4 ni + mi, one half step ahead of their use
@@ -1994,7 +1996,7 @@ __global__ __launch_bounds__(512, 2) void chainq_kernel(const ArgsQ args) {
           typedef decltype(hook) HK;
           if constexpr (TAIL) {
             if (gate_l) { epilogue_q_gate<E, HK>(acc, ce, d.heads_raw != nullptr, hook); return; }
-            if (rb_l) { epilogue_q_rowbias<E, HK>(acc, ce, ly.rowbias, ly.rows_per_bias, yf, idx_cur, hook); return; }
+            if (rb_l) { epilogue_q_rowbias<E, HK>(acc, ce, ly.rowbias, ly.rows_per_bias, d.tail_bias_row, yf, idx_cur, hook); return; }
           }
           epilogue_p_dispatch<E, HK>(acc, ce, mk, ly.relu, bias_epi, ly.skip != 0, (bc % 3) * 1024, hook);
         };
@@ -2141,7 +2143,7 @@ bool chain_persistent_eligible(const swn_chain_desc& d) {
       const swn_chain_layer& ly = d.layers[l];
       const bool last = l + 1 == d.n_layers;
       if (ly.n != 256 || ly.k != 256 || ly.skip > 1 || ly.relu == 2) return false;
-      if (ly.rowbias && (!last || ly.rows_per_bias <= 0)) return false;
+      if (ly.rowbias && (!last || (ly.rows_per_bias <= 0 && !d.tail_bias_row))) return false;
       if (l >= d.tail_first - 1 && (ly.skip || ly.mask)) return false;
       if (l == d.tail_first - 1 && ly.relu) return false;      // (the gate layer: ReLU comes with the scaling)
       if (last && ly.relu != 1) return false;                  // (the last layer's epilogue: row bias, then ReLU)

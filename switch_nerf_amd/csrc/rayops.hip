@@ -311,3 +311,83 @@ extern "C" int swn_sign_bits_unpack(const uint32_t* bits, long rows, int feature
   SWN_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- small index kernels of the owner-tail exchange (ep_owner.py) --------------------------------------------------------------------------
+namespace swn {
+// dst[index[r]] = src[r] (rows of row_bytes, a multiple of 4; index < 0: the row goes nowhere).  The mirror of gather_rows_kernel: what came
+// home in send order goes back to token order (every token at most once: no two rows meet).
+template <typename V>
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const char* __restrict__ src, const int32_t* __restrict__ index, long n_rows,
+                                                           int row_bytes, char* __restrict__ dst) {
+  const int cpr = row_bytes / (int)sizeof(V);
+  const long total = n_rows * cpr;
+  for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < total; c += (long)gridDim.x * 256) {
+    const long r = c / cpr;
+    const int ch = (int)(c - r * cpr);
+    const int d_ = index[r];
+    if (d_ >= 0) *(V*)(dst + (long)d_ * row_bytes + (long)ch * sizeof(V)) = *(const V*)(src + c * (long)sizeof(V));
+  }
+}
+// aux[r] = (gate[tok], bits of (tok / rows_per_ray + ray_base), noise[tok] or 0, 0), tok = index[r]: the 16-byte record that travels with a
+// kept token's row to its expert's rank (zero_gate: the rank's own dropped tokens - their gate value is never used, keep it defined)
+__global__ __launch_bounds__(256) void owner_aux_kernel(const float* __restrict__ gate, const float* __restrict__ noise,
+                                                        const int32_t* __restrict__ index, long n, int rows_per_ray, int ray_base, int zero_gate,
+                                                        float4* __restrict__ aux) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const int tok = index[r];
+  float4 v;
+  v.x = zero_gate ? 0.f : gate[tok];
+  v.y = __int_as_float(tok / rows_per_ray + ray_base);
+  v.z = noise ? noise[tok] : 0.f;
+  v.w = 0.f;
+  aux[r] = v;
+}
+// the records of an owner's token space -> the planar operands of the fused launch
+__global__ __launch_bounds__(256) void owner_aux_split_kernel(const float4* __restrict__ aux, long n, float* __restrict__ gate, int32_t* __restrict__ ray,
+                                                              float* __restrict__ noise) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const float4 v = aux[r];
+  gate[r] = v.x;
+  ray[r] = __float_as_int(v.y);
+  if (noise) noise[r] = v.z;
+}
+}  // namespace swn
+
+extern "C" int swn_scatter_rows(const void* src, const int32_t* index, long n_rows, int row_bytes, void* dst, void* stream) {
+  SWN_CHECK(src && index && dst, "swn_scatter_rows: null pointer");
+  SWN_CHECK(n_rows >= 0 && row_bytes > 0 && row_bytes % 4 == 0, "swn_scatter_rows: %ld rows of %d bytes (a multiple of 4)", n_rows, row_bytes);
+  if (n_rows == 0) return 0;
+  const bool wide = row_bytes % 16 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0);
+  long blocks = cdiv(n_rows * (row_bytes / (wide ? 16 : 4)), 256);
+  if (blocks > 16384) blocks = 16384;
+  if (wide)
+    hipLaunchKernelGGL(swn::scatter_rows_kernel<uint4>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const char*)src, index, n_rows,
+                       row_bytes, (char*)dst);
+  else
+    hipLaunchKernelGGL(swn::scatter_rows_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const char*)src, index, n_rows,
+                       row_bytes, (char*)dst);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int swn_owner_aux(const float* gate, const float* noise, const int32_t* index, long n, int rows_per_ray, int ray_base, int zero_gate,
+                             float* aux, void* stream) {
+  SWN_CHECK(gate && index && aux, "swn_owner_aux: null pointer");
+  SWN_CHECK(n >= 0 && rows_per_ray > 0 && ray_base >= 0, "swn_owner_aux: %ld tokens, %d rows per ray, first ray %d", n, rows_per_ray, ray_base);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(swn::owner_aux_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), gate, noise, index, n, rows_per_ray,
+                     ray_base, zero_gate, (float4*)aux);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int swn_owner_aux_split(const float* aux, long n, float* gate, int32_t* ray, float* noise, void* stream) {
+  SWN_CHECK(aux && gate && ray, "swn_owner_aux_split: null pointer");
+  SWN_CHECK(n >= 0, "swn_owner_aux_split: %ld tokens", n);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(swn::owner_aux_split_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), (const float4*)aux, n, gate, ray, noise);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}

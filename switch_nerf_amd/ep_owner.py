@@ -25,8 +25,11 @@ Here the OWNER of a token's expert runs the whole fused launch on a RECEIVED TOK
 
 1092 bytes per kept token instead of 2048 (0.53 x; dropped tokens cost nothing), and both fused launches back.  Every row's arithmetic is the
 local fused launch's: raw, dx and the gate gradient are bit-identical to the data-parallel step, weight gradients are the same sums in
-another order.  This first version exchanges all segments, then runs ONE launch per direction (no overlap of the exchange with the
-experts yet), reads the split sizes on the host once per forward like the kept-rows mode, and is eager (not captured).
+another order.  Every payload travels as ONE unequal-split all-to-all over all segments (7 collectives per step + the counts + the all-gather
+of the per-ray terms, instead of 4 per segment: xGMI wants few, large transfers), then ONE launch per direction runs (no overlap of the
+exchange with the experts yet); the split sizes are read on the host once per forward like the kept-rows mode; eager (not captured).
+The per-token bias row of layer "2" is found through swn_chain_desc.tail_bias_row (token -> global ray); the index work around the
+exchanges is swn_gather_rows / swn_scatter_rows / swn_owner_aux (no torch indexing in the step).
 """
 from __future__ import annotations
 
@@ -43,12 +46,16 @@ def eligible(m, c, no_batch, row_range) -> bool:
             and "l2r.w" in m.p and ep.world * c["P"] * m.M * esz < (1 << 32) - 64)
 
 
-def _xchg(ep, send, in_splits, recv, out_splits):
-    """One unequal-split all-to-all of packed rows (blocking); no process group: a copy."""
+def _xchg(ep, pl, send, recv, back=False):
+    """ONE unequal-split all-to-all of a payload's rows for ALL segments (blocking): out = source -> owner (splits ks -> kr), back = home.
+    No process group: the caller built `send` inside `recv` (nothing moves)."""
     if ep.local:
-        recv.copy_(send)
-        return
-    ep.all_to_all_v(send, in_splits, recv, out_splits, None)()
+        if recv.data_ptr() != send.data_ptr():
+            recv.copy_(send)
+        return recv
+    a, b = (pl["kr"], pl["ks"]) if back else (pl["ks"], pl["kr"])
+    ep.all_to_all_v(send, a, recv, b, None)()
+    return recv
 
 
 def _all_gather(ep, t):
@@ -59,71 +66,84 @@ def _all_gather(ep, t):
     return out
 
 
+def _excl(t):
+    """exclusive prefix sum of a flattened int tensor, in its shape"""
+    f = t.reshape(-1)
+    return (torch.cumsum(f, 0, dtype=torch.int32) - f.to(torch.int32)).view(t.shape)
+
+
 def _plan(m, c):
-    """Counts exchange + ONE host read: the split sizes of every segment's exchanges (all of them carry KEPT rows: same splits)."""
+    """Counts exchange + ONE host read.  Every payload travels as ONE all-to-all over all segments: this rank's kept rows are sent in
+    (destination rank, segment, local expert, slot) order and arrive in (source rank, segment, local expert, slot) order; the expert kernels
+    find the group (segment, source, local expert) through its first row (swn_chain_desc.group_begin: any order will do)."""
     ep = m.ep
     W, El, n_seg, cap = ep.world, ep.El, c["n_seg"], c["cap"]
-    kept = c["counts"].clamp(max=cap)
+    kept = c["counts"].clamp(max=cap)                              # [n_seg, E]: rows this rank sends per (segment, expert)
     rk = ep.exchange_counts(kept, cap, None)()                     # [n_seg, W * El]: kept rows of every received group
-    per = lambda t: t.view(n_seg, W, El).sum(2)
-    host = torch.cat([per(kept), per(rk), (c["counts"] - kept).sum().view(1, 1).expand(n_seg, 1)], 1).to("cpu", torch.int64).tolist()   # the one sync
-    ks, kr = [r[:W] for r in host], [r[W:2 * W] for r in host]
-    cum = lambda rows: [0] + [sum(sum(r) for r in rows[:i + 1]) for i in range(len(rows))]
-    return dict(ks=ks, kr=kr, rk=rk, kept=kept, n_kept=sum(map(sum, ks)), Rk=sum(map(sum, kr)), n_drop=host[0][2 * W], so=cum(ks), ro=cum(kr))
+    len_s = kept.view(n_seg, W, El).permute(1, 0, 2).contiguous()  # [destination, segment, local expert]
+    len_r = rk.view(n_seg, W, El).permute(1, 0, 2).contiguous()    # [source, segment, local expert]
+    host = torch.cat([len_s.sum((1, 2)), len_r.sum((1, 2)), (c["counts"] - kept).sum().view(1)]).to("cpu", torch.int64).tolist()   # the one sync
+    ks, kr, n_drop = host[:W], host[W:2 * W], host[2 * W]
+    grp_begin = _excl(len_r).permute(1, 0, 2).contiguous().view(-1)      # first received row of group (segment, source, local expert)
+    return dict(ks=ks, kr=kr, rk=rk, kept=kept, len_s=len_s, n_kept=sum(ks), Rk=sum(kr), n_drop=n_drop, grp_begin=grp_begin)
 
 
-def _exchange_rows(ep, pl, send, recv, back=False):
-    """Per segment: the kept rows' records, packed (destination rank, local expert, slot) -> (source rank, local expert, slot); back = home."""
-    for s in range(len(pl["ks"])):
-        if back:
-            _xchg(ep, send[pl["ro"][s]:pl["ro"][s + 1]], pl["kr"][s], recv[pl["so"][s]:pl["so"][s + 1]], pl["ks"][s])
-        else:
-            _xchg(ep, send[pl["so"][s]:pl["so"][s + 1]], pl["ks"][s], recv[pl["ro"][s]:pl["ro"][s + 1]], pl["kr"][s])
+def _send_order(m, c, pl):
+    """(perm, row_of_tok): the token of every kept row in SEND order (destination, segment, local expert, slot), and its inverse (-1: the token
+    was dropped).  One rank: swn_route_pack's order (segment, expert, slot) is the send order."""
+    ep, dev = m.ep, m.dev
+    W, El, n_seg, E, P = ep.world, ep.El, c["n_seg"], m.E, c["P"]
+    n_kept = pl["n_kept"]
+    idx_kept = torch.where(c["loc"] < c["cap"], c["idx"], torch.full_like(c["idx"], -1))
+    _gb, perm_p, row_of_tok = ops.route_pack(idx_kept, c["loc"], pl["kept"], c["seg_tokens"], E)      # packed (segment, expert, slot) order
+    perm_p = perm_p[:n_kept]
+    if W == 1:
+        return perm_p.contiguous(), row_of_tok
+    start_a = _excl(pl["kept"]).view(n_seg, W, El).permute(1, 0, 2)                     # where a run starts in pack order, runs in send order
+    shift = (start_a - _excl(pl["len_s"])).reshape(-1)
+    src = torch.arange(n_kept, dtype=torch.int32, device=dev) + torch.repeat_interleave(shift, pl["len_s"].reshape(-1), output_size=n_kept)
+    perm = perm_p[src.long()].contiguous()
+    row_of_tok = torch.full((P, 1), -1, dtype=torch.int32, device=dev)
+    ops.scatter_rows(torch.arange(n_kept, dtype=torch.int32, device=dev).view(-1, 1), perm, row_of_tok)
+    return perm, row_of_tok.view(-1)
 
 
 def forward(m, c, pe_dir, image_indices, sigma_noise, sv):
     """The expert-parallel branch of SwitchNeRF._net_forward_rows behind the routing: fills c["raw"] (token order) and what backward_a needs."""
     o, ep, dev, dt = ops, m.ep, m.dev, m.dtype
     W, El, E, M, H2, L = ep.world, ep.El, m.E, m.M, m.H2, m.L
-    P, S, N, n_seg, cap, seg_tokens, tag = c["P"], c["S"], c["N"], c["n_seg"], c["cap"], c["seg_tokens"], c["tag"]
+    P, S, N, n_seg, cap, tag = c["P"], c["S"], c["N"], c["n_seg"], c["cap"], c["tag"]
     _b = lambda name, shape, dtype: m._buf(tag + ":ot_" + name, shape, dtype)
     c["ray_feat"], c["c_ray"] = o.ray_feat_fwd(pe_dir, m.in_dir, m.p["emb"], image_indices.contiguous(), m.p["l2r.w"], m.p["l2.b"])
-    c_ray_all = _all_gather(ep, c["c_ray"])
+    c_ray_all = _all_gather(ep, c["c_ray"])                   # the per-ray half of layer "2" of EVERY rank's rays (512 B per ray)
     pl = _plan(m, c)
     n_kept, Rk, n_drop = pl["n_kept"], pl["Rk"], pl["n_drop"]
     assert n_kept + n_drop == P, "every token is either kept or dropped"
     T = Rk + n_drop                                           # this rank's token space: [received kept rows | its OWN dropped tokens]
-    idx_kept = torch.where(c["loc"] < cap, c["idx"], torch.full_like(c["idx"], -1))
-    _gb, perm_p, c["row_of_tok"] = o.route_pack(idx_kept, c["loc"], pl["kept"], seg_tokens, E)      # packed row space of this rank's kept rows
-    tok_k = perm_p[:n_kept].long()                            # token of every kept row this rank sends
-    tok_d = c["dropped"][:n_drop].long()                      # ... and its dropped tokens (they never travel: their tail runs here)
-    # ---- out: the kept tokens' x rows and one 16-byte record each (gate value, global ray, sigma noise) ----
+    perm, c["row_of_tok"] = _send_order(m, c, pl)
+    dropped = c["dropped"][:max(n_drop, 1)]                   # this rank's dropped tokens (they never travel: their tail runs here)
     rows_b = n_seg * E * cap                                  # bound of the received kept rows (capacity of the local experts over all sources)
     TB = rows_b + P                                           # bound of the token space
+    mine = lambda buf, name, shape, dtype: buf if ep.local else _b(name, shape, dtype)[:n_kept]      # (one rank: built where it is read)
+    # ---- out: the kept tokens' x rows and one 16-byte record each (gate value, global ray, sigma noise) ----
     xr = _b("xr", (rows_b, M), dt)
-    if ep.local:                                              # (no process group: the packed rows ARE the received rows)
-        o.gather_rows(c["h0"], perm_p[:n_kept], xr[:n_kept])
-    else:
-        x_send = _b("x_send", (P, M), dt)[:n_kept]
-        o.gather_rows(c["h0"], perm_p[:n_kept], x_send)
-        _exchange_rows(ep, pl, x_send, xr[:Rk])
-    ray_of = lambda tok: (tok // S + ep.rank * N).to(torch.int32)
-    aux_send = torch.zeros(n_kept, 4, dtype=torch.float32, device=dev)
-    aux_send[:, 0] = c["gmax"][tok_k]
-    aux_send[:, 1] = ray_of(tok_k).view(torch.float32)
-    if sigma_noise is not None:
-        aux_send[:, 2] = sigma_noise[tok_k]
-    aux_recv = torch.empty(Rk, 4, dtype=torch.float32, device=dev)
-    _exchange_rows(ep, pl, aux_send, aux_recv)
-    gmax_t = torch.cat([aux_recv[:, 0], torch.zeros(n_drop, dtype=torch.float32, device=dev)])
-    ray_t = torch.cat([aux_recv[:, 1].contiguous().view(torch.int32), ray_of(tok_d)]).long()
-    noise_t = torch.cat([aux_recv[:, 2], sigma_noise[tok_d]]) if sigma_noise is not None else None
-    c_row = _b("c_row", (TB, H2), torch.float32)[:T]
-    torch.index_select(c_ray_all, 0, ray_t, out=c_row)
+    x_send = mine(xr[:n_kept], "x_send", (P, M), dt)
+    o.gather_rows(c["h0"], perm, x_send)
+    _xchg(ep, pl, x_send, xr[:Rk])
+    aux_t = _b("aux", (TB, 4), torch.float32)[:T]
+    aux_send = mine(aux_t[:n_kept], "aux_send", (P, 4), torch.float32)
+    o.owner_aux(c["gmax"], sigma_noise, perm, S, ep.rank * N, aux_send)
+    _xchg(ep, pl, aux_send, aux_t[:Rk])
+    if n_drop:
+        o.owner_aux(c["gmax"], sigma_noise, dropped[:n_drop], S, ep.rank * N, aux_t[Rk:], zero_gate=True)
+    gmax_t = _b("gmax", (TB,), torch.float32)[:T]
+    ray_t = _b("ray", (TB,), torch.int32)[:T]                 # token -> row of c_ray_all
+    noise_t = _b("noise", (TB,), torch.float32)[:T] if sigma_noise is not None else None
+    o.owner_aux_split(aux_t, gmax_t, ray_t, noise_t)
     # ---- the fused launch on the token space ----
     ngs = n_seg * W * El
     grp_rows = pl["rk"].reshape(-1).contiguous()
-    ep_begin = (torch.cumsum(grp_rows, 0, dtype=torch.int32) - grp_rows).contiguous()
+    ep_begin = pl["grp_begin"]
     ident = m._bufs.get(("ot_ident", rows_b))                # the identity gather: a received row IS its token
     if ident is None:
         ident = m._bufs[("ot_ident", rows_b)] = torch.arange(rows_b, dtype=torch.int32, device=dev)
@@ -141,27 +161,25 @@ def forward(m, c, pe_dir, image_indices, sigma_noise, sv):
                    save=saves[l] if (sv and l < L - 1) else None, mask=masks[l] if (sv and l < L - 1) else None) for l in range(L)]
     lys[-1].save = y_t
     lys += [o.Layer(m.wf["l1"], m.p["l1.b"].view(1, M), save=h1_t),
-            o.Layer(m.wf["l2h_pad"], None, relu=1, rowbias=c_row, rows_per_bias=1)]
+            o.Layer(m.wf["l2h_pad"], None, relu=1, rowbias=c_ray_all, rows_per_bias=0)]      # (the bias row of token t: ray_t[t])
     heads = (m.p["sigma.w"], m.p["sigma.b"], m.p["color.w"], m.p["color.b"], noise_t, raw_t)
     with m._timed("expert_fwd"):
         o.mlp_chain(xr, lys, h2_t, n_groups=ngs, n_wsets=El, group_stride=cap, group_rows=grp_rows, group_rows_clamp=cap, x_gather=ident,
-                    tag=7, geometry=7, heads=heads, group_begin=ep_begin, tail=(L, gmax_t, drop_begin_t, dropped_t, H2))
-    # ---- home: raw (+ the sign bits of h2: what the per-ray bias gradient needs of it) ----
-    ncol = 8 if sv else 4
-    ret_t = torch.empty(T, ncol, dtype=torch.float32, device=dev)
-    ret_t[:, :4] = raw_t
-    if sv:
-        ret_t[:, 4:] = o.sign_bits_pack(h2_t).view(torch.float32)      # bit j of word q = (h2[:, 32 q + j] > 0)
-    ret_recv = torch.empty(n_kept, ncol, dtype=torch.float32, device=dev)
-    _exchange_rows(ep, pl, ret_t[:Rk], ret_recv, back=True)
+                    tag=7, geometry=7, heads=heads, group_begin=ep_begin, tail=(L, gmax_t, drop_begin_t, dropped_t, H2, ray_t))
+    # ---- home: raw (+ the sign bits of h2: what the per-ray bias gradient needs of it), back into token order ----
     c["raw"] = torch.empty(P, 4, dtype=torch.float32, device=dev)
-    c["raw"][tok_k] = ret_recv[:, :4]
-    c["raw"][tok_d] = ret_t[Rk:, :4]
+    raw_home = raw_t[:n_kept] if ep.local else torch.empty(n_kept, 4, dtype=torch.float32, device=dev)
+    o.scatter_rows(_xchg(ep, pl, raw_t[:Rk], raw_home, back=True), perm, c["raw"])
+    if n_drop:
+        o.scatter_rows(raw_t[Rk:], dropped[:n_drop], c["raw"])
     if sv:
-        c["h2_bits"] = torch.empty(P, 4, dtype=torch.int32, device=dev)
-        c["h2_bits"][tok_k] = ret_recv[:, 4:].contiguous().view(torch.int32)
-        c["h2_bits"][tok_d] = ret_t[Rk:, 4:].contiguous().view(torch.int32)
-    c["ep_owner"] = dict(pl=pl, tok_k=tok_k, tok_d=tok_d, perm_p=perm_p, xr=xr, saves=saves, masks=masks, y=y_t, h1=h1_t, h2=h2_t, raw=raw_t,
+        bits_t = o.sign_bits_pack(h2_t)                       # bit j of word q = (h2[:, 32 q + j] > 0)
+        c["h2_bits"] = torch.empty(P, H2 // 32, dtype=torch.int32, device=dev)
+        bits_home = bits_t[:n_kept] if ep.local else torch.empty(n_kept, H2 // 32, dtype=torch.int32, device=dev)
+        o.scatter_rows(_xchg(ep, pl, bits_t[:Rk], bits_home, back=True), perm, c["h2_bits"])
+        if n_drop:
+            o.scatter_rows(bits_t[Rk:], dropped[:n_drop], c["h2_bits"])
+    c["ep_owner"] = dict(pl=pl, perm=perm, dropped_src=dropped, xr=xr, saves=saves, masks=masks, y=y_t, h1=h1_t, h2=h2_t, raw=raw_t,
                          gmax=gmax_t, ident=ident, dropped=dropped_t, drop_begin=drop_begin_t, grp_rows=grp_rows, ep_begin=ep_begin, ngs=ngs,
                          T=T, Rk=Rk, rows_b=rows_b, TB=TB)
     c["ep_counts"], c["ep_padded"], c["tail_fused"] = pl["rk"], False, True
@@ -175,8 +193,8 @@ def backward_a(m, c, d_raw, d_laux):
     W, El, E, M, H2, L = ep.world, ep.El, m.E, m.M, m.H2, m.L
     P, S, N, cap, tag = c["P"], c["S"], c["N"], c["cap"], c["tag"]
     g, q = m.g, c["ep_owner"]
-    pl, T, Rk = q["pl"], q["T"], q["Rk"]
-    n_kept = pl["n_kept"]
+    pl, T, Rk, perm = q["pl"], q["T"], q["Rk"], q["perm"]
+    n_kept, n_drop = pl["n_kept"], pl["n_drop"]
     _b = lambda name, shape, dtype: m._buf(tag + ":ot_" + name, shape, dtype)
     # ---- source: the per-ray bias gradient from d_raw, raw and the sign of h2 (dh2 = (h2 > 0) * the colour heads' input gradient) ----
     h2_sign = o.sign_bits_unpack(c["h2_bits"], dt)
@@ -191,9 +209,13 @@ def backward_a(m, c, d_raw, d_laux):
         g["l2.b"].add_(dc_ray.sum(0))
     o.emb_grad(dc_ray @ m.p["l2r.w"][m.in_dir:].t(), c["image_indices"].contiguous(), g["emb"])
     # ---- d_raw to the owners ----
-    d_recv = torch.empty(Rk, 4, dtype=torch.float32, device=dev)
-    _exchange_rows(ep, pl, d_raw[q["tok_k"]], d_recv)
-    d_raw_t = torch.cat([d_recv, d_raw[q["tok_d"]]])
+    d_raw = d_raw.contiguous()
+    d_raw_t = _b("d_raw", (q["TB"], 4), torch.float32)[:T]
+    d_send = d_raw_t[:n_kept] if ep.local else _b("d_send", (P, 4), torch.float32)[:n_kept]
+    o.gather_rows(d_raw, perm, d_send)
+    _xchg(ep, pl, d_send, d_raw_t[:Rk])
+    if n_drop:
+        o.gather_rows(d_raw, q["dropped_src"][:n_drop], d_raw_t[Rk:])
     # ---- owner: heads backward, the fused backward launch, weight gradients ----
     fused_dws = M == 256 and m.sw["fused_dwsig"]
     dh2_t, dsig_t = o.heads_bwd(None if fused_dws else q["y"], q["h2"], m.p["color.w"], q["raw"], d_raw_t, g["sigma.w"], g["sigma.b"],
@@ -231,13 +253,12 @@ def backward_a(m, c, d_raw, d_laux):
         o.wgrad_multi(items, n_groups=ngs, n_wsets=El, group_stride=cap, group_rows=q["grp_rows"], group_rows_clamp=cap, tag=1,
                       group_begin=q["ep_begin"])
     # ---- home: the experts' input gradient (512 B) and the gate gradient (4 B) of every kept row ----
-    if not ep.local:
-        _exchange_rows(ep, pl, dx_r[:Rk], dx[:n_kept], back=True)
-    dg_send = dgmax_t[:Rk].contiguous().view(Rk, 1)
-    dg_recv = torch.empty(n_kept, 1, dtype=torch.float32, device=dev)
-    _exchange_rows(ep, pl, dg_send, dg_recv, back=True)
+    _xchg(ep, pl, dx_r[:Rk], dx[:n_kept], back=True)         # (in send order: c["row_of_tok"] is the front backward's gather)
+    dg_t = dgmax_t[:Rk].view(Rk, 1)
+    dg_home = dg_t if ep.local else torch.empty(n_kept, 1, dtype=torch.float32, device=dev)
+    _xchg(ep, pl, dg_t, dg_home, back=True)
     dgmax = m._buf(tag + ":dgmax", (P,), torch.float32)
     dgmax.zero_()                                             # (a dropped token's gate gradient is zero: no expert saw it)
-    dgmax[q["perm_p"][:n_kept].long()] = dg_recv[:, 0]
+    o.scatter_rows(dg_home, perm, dgmax.view(P, 1))
     return dict(c=c, d_laux=d_laux, dgmax=dgmax, dx=dx, dout=None, returns=[], tail_jobs=[], nsp=max(1, min(256, P // 1024)), side_done=None,
                 keep=(dc_ray, dh2_t, dsig_t))

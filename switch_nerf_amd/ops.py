@@ -129,6 +129,35 @@ def gather_rows(src, index, out=None):
     return out
 
 
+def scatter_rows(src, index, out):
+    """out[index[r]] = src[r] (index < 0: nowhere; no index twice); src [R, C] row-major, index int32 [R], out [*, C] (include/swn.h
+    swn_scatter_rows)."""
+    R = index.numel()
+    assert src.is_contiguous() and out.is_contiguous() and index.dtype == torch.int32 and src.shape[0] >= R and src.dtype == out.dtype
+    rb = (src.numel() // max(1, src.shape[0])) * src.element_size()
+    assert rb == (out.numel() // max(1, out.shape[0])) * out.element_size()
+    if R:
+        call("swn_scatter_rows", _p(src), _p(index), R, rb, _p(out), _stream())
+    return out
+
+
+def owner_aux(gate, noise, index, rows_per_ray: int, ray_base: int, out, zero_gate: bool = False):
+    """out[r] = (gate[t], bits of (t // rows_per_ray + ray_base), noise[t] or 0, 0), t = index[r] (include/swn.h swn_owner_aux)."""
+    n = index.numel()
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] >= n and out.shape[1] == 4 and index.dtype == torch.int32
+    if n:
+        call("swn_owner_aux", _p(gate), _p(noise), _p(index), n, int(rows_per_ray), int(ray_base), int(bool(zero_gate)), _p(out), _stream())
+    return out
+
+
+def owner_aux_split(aux, gate, ray, noise=None):
+    """aux [n, 4] -> gate [n] f32, ray [n] int32, noise [n] f32 (or None) (include/swn.h swn_owner_aux_split)."""
+    n = aux.shape[0]
+    assert aux.dtype == torch.float32 and aux.is_contiguous() and gate.numel() >= n and ray.numel() >= n and ray.dtype == torch.int32
+    if n:
+        call("swn_owner_aux_split", _p(aux), n, _p(gate), _p(ray), _p(noise), _stream())
+
+
 def gate_fwd(g, ln_w, ln_b, wg, noise=None, noise_scale: float = 0.0):
     """LayerNorm + fp32 router + softmax + top-1 -> (gates [P, E], idx, gmax, stats).  noise [P, E] fp32: logits += noise_scale * noise
     before the softmax (the gate-noise branch of a training forward, swn_gate_fwd_noise)."""
@@ -629,7 +658,7 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
     (ops.combine_bwd) fused into the write-out of the last layer.  heads = (w_sigma, b_sigma, w_color, b_color, sigma_noise or None, raw):
     the sigma / colour heads (ops.heads_fwd) fused into the tail forward chain (tag 4) - y may then be None (nothing but raw is written).
     sched: int32 [16] zero-initialised tile-queue counters of the persistent geometries 6 / 7 (chain_sched(); left zero by the kernel).
-    tail = (tail_first, gate [P] f32, drop_begin, dropped, y_features): the dense tail folded into the expert forward chain (include/swn.h,
+    tail = (tail_first, gate [P] f32, drop_begin, dropped, y_features[, bias_row int32 [P]]): the dense tail folded into the expert forward chain (include/swn.h,
     tail_first: geometry 7, tag 7) - layers[tail_first:] are shared layers, the saves from layer tail_first - 1 on, y and the heads'
     raw are in token order (P rows), x_gather maps rows to tokens.
     head = (head_layers, drop_begin, dropped): the mirror image for the backward pass (include/swn.h, head_layers: geometry 7, tag 8) -
@@ -642,7 +671,10 @@ def mlp_chain(x, layers: Sequence[Layer], y, n_groups=1, n_wsets=1, group_stride
     d.n_groups, d.n_wsets = int(n_groups), int(n_wsets)
     d.group_stride = int(group_stride if group_stride is not None else (y if y is not None else heads[5]).shape[0])
     if tail is not None:
-        t_first, t_gate, t_begin, t_dropped, t_yf = tail
+        t_first, t_gate, t_begin, t_dropped, t_yf = tail[:5]
+        if len(tail) > 5 and tail[5] is not None:      # token -> row of the last layer's rowbias (a token space that is not in ray order)
+            assert tail[5].dtype == torch.int32 and tail[5].is_contiguous() and tail[5].numel() >= t_gate.numel()
+            d.tail_bias_row = _p(tail[5])
         assert t_gate.dtype == torch.float32 and t_begin.dtype == torch.int32 and t_dropped.dtype == torch.int32 and x_gather is not None
         d.tail_first, d.y_features, d.tail_gate, d.tail_dropped = int(t_first), int(t_yf), _p(t_gate), _p(t_dropped)
         d.tail_n_dropped = t_begin.data_ptr() + 4 * (t_begin.numel() - 1)

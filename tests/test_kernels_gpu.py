@@ -1360,3 +1360,37 @@ def test_sign_bits_pack_unpack(dtype):
     finally:
         if dtype == torch.float16:
             _lib.use_half("bf16")
+
+
+def test_scatter_rows_and_owner_aux_records():
+    """The index kernels around the owner-tail exchange (ep_owner.py): swn_scatter_rows is the mirror of swn_gather_rows (rows of 4, 16 and
+    512 bytes; negative indices go nowhere), swn_owner_aux builds (gate, global ray, noise, 0) records of listed tokens and
+    swn_owner_aux_split takes them apart again."""
+    o = ops()
+    g = torch.Generator().manual_seed(11)
+    P, S = 5000, 8
+    perm = torch.randperm(P, generator=g)[:3001].to(torch.int32)
+    perm_neg = perm.clone()
+    perm_neg[::9] = -1
+    for cols, dtype in ((1, torch.float32), (4, torch.float32), (256, torch.bfloat16), (4, torch.int32)):
+        src = torch.randn(3001, cols, generator=g).to(dtype) if dtype != torch.int32 else torch.randint(-2**31, 2**31 - 1, (3001, cols), generator=g, dtype=torch.int32)
+        for ix in (perm, perm_neg):
+            out = torch.full((P, cols), 7, dtype=dtype).to(dev())
+            want = out.clone()
+            keep = (ix >= 0).to(dev())
+            want[ix.to(dev()).long()[keep]] = src.to(dev())[keep]
+            o.scatter_rows(src.to(dev()), ix.to(dev()), out)
+            assert torch.equal(out.view(torch.uint8), want.view(torch.uint8))
+    gate, noise = torch.rand(P, generator=g).to(dev()), torch.randn(P, generator=g).to(dev())
+    for nz, zero in ((noise, False), (None, False), (noise, True)):
+        aux = torch.empty(3001, 4, device=dev())
+        o.owner_aux(gate, nz, perm.to(dev()), S, 640, aux, zero_gate=zero)
+        t = perm.to(dev()).long()
+        assert torch.equal(aux[:, 0], torch.zeros_like(gate[t]) if zero else gate[t])
+        assert torch.equal(aux[:, 1].contiguous().view(torch.int32), (t // S + 640).to(torch.int32))
+        assert torch.equal(aux[:, 2], noise[t] if nz is not None else torch.zeros_like(noise[t])) and not aux[:, 3].any()
+        ga, ra, na = torch.empty(3001, device=dev()), torch.empty(3001, dtype=torch.int32, device=dev()), torch.empty(3001, device=dev())
+        o.owner_aux_split(aux, ga, ra, na if nz is not None else None)
+        assert torch.equal(ga, aux[:, 0]) and torch.equal(ra, (t // S + 640).to(torch.int32))
+        if nz is not None:
+            assert torch.equal(na, aux[:, 2])
