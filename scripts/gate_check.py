@@ -7,7 +7,7 @@ HALF = torch.float16 if os.environ.get('GATE_DTYPE') == 'fp16' else torch.bfloat
 if HALF == torch.float16:
     _lib.use_half('f16')
 torch.manual_seed(0)
-G, E = 256, 8
+G, E = int(os.environ.get('GATE_G', 256)), int(os.environ.get('GATE_E', 8))      # GATE_G=512 GATE_E=16: Mission Bay's router
 which = ("VALU" if os.environ.get("SWN_GATE_VALU") else "MFMA") + (" fp16" if os.environ.get("GATE_DTYPE") == "fp16" else "")
 
 
@@ -19,7 +19,7 @@ def ref(g, ln_w, ln_b, wg):
     return torch.softmax(logits, 1)
 
 
-for P, mean_shift, E_ in ((5000, 0.0, 8), (32768, 0.7, 8), (33, 0.0, 8), (4097, 3.0, 5), (131072, 0.2, 8)):
+for P, mean_shift, E_ in ((5000, 0.0, E), (32768, 0.7, E), (33, 0.0, E), (4097, 3.0, E - 3), (131072, 0.2, E)):
     g = (torch.randn(P, G, device=dev) * 1.3 + mean_shift).to(HALF)
     ln_w = 1.0 + 0.2 * torch.randn(G, device=dev)
     ln_b = 0.1 * torch.randn(G, device=dev)
@@ -41,7 +41,7 @@ for P, mean_shift, E_ in ((5000, 0.0, 8), (32768, 0.7, 8), (33, 0.0, 8), (4097, 
         print(f"{which} P {P:7d} E {E_} shift {mean_shift} ln {int(ln)}: max |prob err| {err:.2e}, idx mismatches {int(mis.sum())} (largest top-2 gap among them "
               f"{gap.max().item() if mis.any() else 0:.1e}), gmax consistency {gm_err:.1e}, stats err {st_err:.1e}, sums {(gates.sum(1) - 1).abs().max().item():.1e}")
 
-P = 2097152
+P = 2097152 * 256 // G
 g = (torch.randn(P, G, device=dev) * 1.3).to(HALF)
 ln_w = 1.0 + 0.2 * torch.randn(G, device=dev); ln_b = 0.1 * torch.randn(G, device=dev); wg = torch.randn(E, G, device=dev) * 0.3
 for _ in range(2):
@@ -53,11 +53,11 @@ for _ in range(10):
     o.gate_fwd(g, ln_w, ln_b, wg)
 b.record(); torch.cuda.synchronize()
 ms = a.elapsed_time(b) / 10
-print(f"{which} gate_fwd 2M tokens: {ms:.3f} ms = {P * G * 2 / ms / 1e9:.2f} TB/s of row reads")
+print(f"{which} gate_fwd {P} tokens x {G}: {ms:.3f} ms = {P * G * 2 / ms / 1e9:.2f} TB/s of row reads")
 
 # ---------------------------------------------------------------- backward: against torch autograd in fp64
 print("backward")
-for P, seg, E_, ln in ((8192, 4096, 8, True), (8192, 8192, 8, False), (4099 * 2, 4099, 4, True), (65536, 16384, 8, True)):
+for P, seg, E_, ln in ((8192, 4096, E, True), (8192, 8192, E, False), (4099 * 2, 4099, E // 2, True), (65536, 16384, E, True)):
     g = (torch.randn(P, G, device=dev) * 1.3 + 0.3).to(HALF)
     ln_w = (1.0 + 0.2 * torch.randn(G, device=dev)) if ln else None
     ln_b = (0.1 * torch.randn(G, device=dev)) if ln else None
@@ -86,7 +86,7 @@ for P, seg, E_, ln in ((8192, 4096, 8, True), (8192, 8192, 8, False), (4099 * 2,
         line += f", d_ln_w {rel(d_lw, lw.grad):.2e}, d_ln_b {rel(d_lb, lb.grad):.2e}"
     print(line)
 
-P, seg = 2097152, 131072
+P, seg = 2097152 * 256 // G, 131072
 g = (torch.randn(P, G, device=dev) * 1.3).to(HALF)
 gates, idx, gmax, stats = o.gate_fwd(g, ln_w, ln_b, wg) if False else o.gate_fwd(g, 1.0 + 0.2 * torch.randn(G, device=dev), 0.1 * torch.randn(G, device=dev), torch.randn(E, G, device=dev) * 0.3)
 ln_w = 1.0 + 0.2 * torch.randn(G, device=dev); ln_b = 0.1 * torch.randn(G, device=dev); wg = torch.randn(E, G, device=dev) * 0.3
@@ -98,4 +98,4 @@ a.record()
 for _ in range(10):
     f()
 b.record(); torch.cuda.synchronize()
-print(f"{which} gate_bwd (data path + parameter gradients) 2M tokens: {a.elapsed_time(b) / 10:.3f} ms")
+print(f"{which} gate_bwd (data path + parameter gradients) {P} tokens x {G}: {a.elapsed_time(b) / 10:.3f} ms")

@@ -83,6 +83,12 @@ int gate_bwd_mfma_launch(const void* g, const float* ln_w, const float* wg, cons
                          const float* stats, const int32_t* counts, const float* laux_coef, int seg_tokens, int n_tokens, int n_experts,
                          void* dg, float* dlogits, float* partial, void* stream);
 int gate_bwd_mfma_blocks(int n_tokens);
+// gate_mfma.hip, the 512-feature router (<= 16 experts): forward, and the backward's data path (dlogits, dg)
+int gate_fwd_wide_launch(const void* g, const float* ln_w, const float* ln_b, const float* wg, int n_tokens, int n_experts, float* gates,
+                         int32_t* idx, float* gmax, float* stats, void* stream);
+int gate_bwd_wide_launch(const void* g, const float* ln_w, const float* wg, const float* gates, const int32_t* idx, const float* d_gmax,
+                         const float* stats, const int32_t* counts, const float* laux_coef, int seg_tokens, int n_tokens, int n_experts,
+                         void* dg, float* dlogits, void* stream);
 bool chain_big_eligible(const swn_chain_desc& d);                // chain_big.hip: the 256-row geometry
 bool chain_persistent_eligible(const swn_chain_desc& d);         // chain_big.hip: geometries 6 / 7 (persistent; also the dense front chains)
 int chain_big_launch(const swn_chain_desc& d, void* stream);

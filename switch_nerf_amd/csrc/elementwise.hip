@@ -1186,6 +1186,9 @@ static int gate_fwd_impl(const void* g, int dtype, const float* ln_w, const floa
   static const bool valu_only = getenv("SWN_GATE_VALU") != nullptr;
   if (dtype == SWN_HALF && gate_dim == 256 && n_experts <= 8 && !valu_only && !noise)
     return swn::gate_fwd_mfma_launch(g, ln_w, ln_b, wg, n_tokens, n_experts, gates, idx, gmax, stats, stream);
+  // ... and rows of 512 (Mission Bay's router: up to 16 experts)
+  if (dtype == SWN_HALF && gate_dim == 512 && !valu_only && !noise)
+    return swn::gate_fwd_wide_launch(g, ln_w, ln_b, wg, n_tokens, n_experts, gates, idx, gmax, stats, stream);
   if (dtype == SWN_HALF) {
     const bf16_t* gp = (const bf16_t*)g;
     GATE_DISPATCH_TB(bf16_t, gate_fwd_kernel, SWN_GATE_TB512, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, n_tokens, n_experts,
@@ -1266,6 +1269,10 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
       msum = dwg_partial + (size_t)dwg_blocks * ps;
       const int rc = swn::gate_bwd_mfma_launch(g, ln_w, wg, gates, idx, d_gmax, stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dg,
                                                dlogits, dwg_partial, stream);
+      if (rc) return rc;
+    } else if (gate_dim == 512 && !valu_only) {      // 512-feature rows: the data path on the matrix pipe, the parameter gradients below
+      const int rc = swn::gate_bwd_wide_launch(g, ln_w, wg, gates, idx, d_gmax, stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dg,
+                                               dlogits, stream);
       if (rc) return rc;
     } else
     GATE_DISPATCH_TB(bf16_t, gate_bwd_kernel, 1, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, gates, idx, d_gmax,

@@ -490,4 +490,492 @@ int gate_bwd_mfma_launch(const void* g, const float* ln_w, const float* wg, cons
   return 0;
 }
 
+
+// =================================================================================================================================
+// The 512-feature router (up to 16 experts: the Mission Bay recipe, configs/switch_nerf/mission_bay.yaml) on the matrix pipe.
+//
+// gate_fwd_kernel / gate_bwd_kernel<., 512, 16> spend 16 x (32 FMAs + a 16-lane reduction) per row on the VALU with their weights coming
+// from LDS: 0.8 ms per 852 k rows each, a fifth of the rate the row reads allow.  Same arithmetic as the 256-feature kernels above (the
+// LayerNorm folded into W' = ln_w (.) wg, W' split into three 16-bit terms, fp32 accumulation), different data movement: 49 table rows
+// x 512 columns do not fit a wave's registers and four 32 KiB row tiles do not fit the LDS beside them, so
+//   * the split weight table lives in LDS in FRAGMENT-MAJOR order (64 KiB: two 32-row A tiles x 32 K steps x 64 lanes x 16 bytes -
+//     tile 0: experts 0-7 hi / mid / lo + the row of ones, tile 1: experts 8-15), two ds_read_b128 per K step;
+//   * the rows never pass through LDS: a lane owns HALF a row (token l31, columns [256 lhi, +256)) and reads it as 32 consecutive
+//     16-byte pieces straight into the B operand - the contraction order is free, so K step ks multiplies columns 8 ks .. + 7 of both
+//     halves (the table is laid out to match); 8 K steps (8 KiB per wave) are in flight ahead of the MFMAs, across tile boundaries;
+//   * forward: 2 MFMAs per K step, 64 per 32 tokens.  Backward: dxh = dlogits @ W' is ONE K step per 32 columns (K slots = the 16
+//     experts; dlogits split into head + remainder against W' hi, head against W' mid: 3 MFMAs); the table rows are permuted so that a
+//     lane's 16 accumulator values are 16 CONSECUTIVE columns of its token - x comes from and dg goes to global memory in 32-byte runs,
+//     the whole tile's x (32 KiB per wave) stays in registers between the two passes of the LayerNorm backward.
+// The parameter gradients stay with gate_dwg_kernel (from the dlogits written out).
+// =================================================================================================================================
+constexpr int GW_G = 512;                        // features
+constexpr int GW_KS = GW_G / 16;                 // K steps
+constexpr int GW_TAB_B = 2 * GW_KS * 64 * 16;    // 64 KiB
+constexpr int GW_FWD_LDS = GW_TAB_B + 256;       // + c1[16], c0[16]
+constexpr int GW_BWD_LDS = 2 * 16 * 64 * 16;     // W' hi / mid: [16 column tiles][64 lanes] x 16 bytes each
+
+__device__ __forceinline__ void gw_split3(float wp, bf16_t& hi, bf16_t& mid, bf16_t& lo) {
+  hi = f32_to_bf16(wp);
+  const float r1 = wp - bf16_to_f32(hi);
+  mid = f32_to_bf16(r1);
+  lo = f32_to_bf16(r1 - bf16_to_f32(mid));
+}
+
+template <bool LN>
+__global__ __launch_bounds__(256, 2) void gate_fwd_wide_kernel(const bf16_t* __restrict__ g, const float* __restrict__ ln_w,
+                                                               const float* __restrict__ ln_b, const float* __restrict__ wg, int P, int E,
+                                                               float* __restrict__ gates, int32_t* __restrict__ idx, float* __restrict__ gmax,
+                                                               float* __restrict__ stats, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  float* cst = (float*)(smem + GW_TAB_B);
+
+  // ---- prologue: the fragment-major split table.  Fragment (tile tl, K step ks, lane ln): table row m = ln & 31 (rows 0-7 hi, 8-15 mid,
+  //      16-23 lo of experts 8 tl + (m & 7); row 24 of tile 0 = ones), columns 256 (ln >> 5) + 8 ks .. + 7 ----
+  for (int f = tid; f < 2 * GW_KS * 64; f += 256) {
+    const int ln = f & 63, ks = (f >> 6) & (GW_KS - 1), tl = f >> 11;
+    const int m = ln & 31, h = ln >> 5, term = m >> 3, e = (m & 7) + 8 * tl;
+    uint32_t v[4] = {0u, 0u, 0u, 0u};
+    if (term < 3 && e < E) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = 256 * h + 8 * ks + i;
+        bf16_t hi, mid, lo;
+        gw_split3(wg[(long)e * GW_G + c] * (LN ? ln_w[c] : 1.f) * GM_SW, hi, mid, lo);
+        const bf16_t val = term == 0 ? hi : (term == 1 ? mid : lo);
+        v[i >> 1] |= (uint32_t)val << (16 * (i & 1));
+      }
+    } else if (m == 24 && tl == 0) {
+      v[0] = v[1] = v[2] = v[3] = SWN_HALF_ONE_X2;
+    }
+    *(gm_u32x4_t*)(smem + (size_t)f * 16) = gm_u32x4_t{v[0], v[1], v[2], v[3]};
+  }
+  if (LN) {      // c1[e] = sum_k (what the MFMA multiplies), c0[e] = sum_k ln_b[k] wg[e][k]: 16 lanes per expert, a fixed order
+    const int e = tid >> 4, jj = tid & 15;
+    float a = 0.f, b = 0.f;
+    if (e < E) {
+      for (int c = jj; c < GW_G; c += 16) {
+        const float wv = wg[(long)e * GW_G + c];
+        bf16_t hi, mid, lo;
+        gw_split3(wv * ln_w[c] * GM_SW, hi, mid, lo);
+        a += (bf16_to_f32(hi) + (bf16_to_f32(mid) + bf16_to_f32(lo))) * (1.f / GM_SW);
+        b += ln_b[c] * wv;
+      }
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if (jj == 0) { cst[e] = a; cst[16 + e] = b; }
+  }
+  __syncthreads();
+  float c1[2][4], c0[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = 8 * t + 4 * lhi + j;
+      c1[t][j] = (LN && e < E) ? cst[e] : 0.f;
+      c0[t][j] = (LN && e < E) ? cst[16 + e] : 0.f;
+    }
+
+  const uint32_t a_off = (uint32_t)lane * 16;
+  const int stride = gridDim.x * 4;
+  auto row_ptr = [&](int t) -> const char* {
+    long tok = (long)t * 32 + l31;
+    tok = tok < P ? tok : (long)P - 1;                 // (rows past the end repeat the last token: computed, never written)
+    return (const char*)g + tok * (GW_G * 2) + lhi * GW_G;
+  };
+  gm_u32x4_t xb[2][8];
+  int t = blockIdx.x * 4 + w;
+  if (t < n_tiles) {
+    const char* p0 = row_ptr(t);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) xb[0][s] = *(const gm_u32x4_t*)(p0 + 16 * s);
+  }
+  for (; t < n_tiles; t += stride) {
+    const char* p = row_ptr(t);
+    const bool more = t + stride < n_tiles;
+    const char* pn = row_ptr(more ? t + stride : t);
+    gm_f32x16_t acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    gm_f32x2_t q2a = {0.f, 0.f}, q2b = {0.f, 0.f};
+    // (one K step per scheduling region: left alone the scheduler hoists the 64 table reads of the unrolled loop - 256 registers, 238 spilled;
+    //  the table fragments of step ks + 1 are requested in front of the MFMAs of step ks)
+    gm_u32x4_t af[2][2];
+    af[0][0] = *(const gm_u32x4_t*)(smem + a_off);
+    af[0][1] = *(const gm_u32x4_t*)(smem + a_off + (uint32_t)GW_KS * 1024u);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c < 3) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) xb[(c + 1) & 1][s] = *(const gm_u32x4_t*)(p + 16 * (8 * (c + 1) + s));
+      } else if (more) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) xb[0][s] = *(const gm_u32x4_t*)(pn + 16 * s);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int ks = 8 * c + s;
+        const gm_u32x4_t x = xb[c & 1][s];
+        if (ks + 1 < GW_KS) {
+          af[(ks + 1) & 1][0] = *(const gm_u32x4_t*)(smem + a_off + (uint32_t)(ks + 1) * 1024u);
+          af[(ks + 1) & 1][1] = *(const gm_u32x4_t*)(smem + a_off + (uint32_t)(GW_KS + ks + 1) * 1024u);
+        }
+        acc0 = SWN_MFMA_32x32x16(af[ks & 1][0], x, acc0);
+        acc1 = SWN_MFMA_32x32x16(af[ks & 1][1], x, acc1);
+        if (LN) {
+#pragma unroll
+          for (int i = 0; i < 4; i += 2) {
+            const gm_f32x2_t u0 = {gm_lo(x[i]), gm_hi(x[i])};
+            const gm_f32x2_t u1 = {gm_lo(x[i + 1]), gm_hi(x[i + 1])};
+            q2a += u0 * u0;
+            q2b += u1 * u1;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- this lane: token l31, experts 4 lhi + j (tile 0) and 8 + 4 lhi + j (tile 1); accumulator rows 8 g4 + 4 lhi + j ----
+    float logit[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      logit[0][j] = ((acc0[j] + acc0[4 + j]) + acc0[8 + j]) * (1.f / GM_SW);
+      logit[1][j] = ((acc1[j] + acc1[4 + j]) + acc1[8 + j]) * (1.f / GM_SW);
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (LN) {
+      const float sx = __shfl(acc0[12], l31);                    // table row 24 (the ones) lives in the lower half-wave
+      float q2 = (q2a[0] + q2a[1]) + (q2b[0] + q2b[1]);
+      q2 += __shfl_xor(q2, 32);
+      mean = sx * (1.f / GW_G);
+      const float var = fmaxf(q2 * (1.f / GW_G) - mean * mean, 0.f);
+      rstd = 1.f / sqrtf(var + 1e-5f);                           // torch.nn.LayerNorm, eps 1e-5 (models/nerf_moe.py:301-302)
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) logit[tl][j] = rstd * (logit[tl][j] - mean * c1[tl][j]) + c0[tl][j];
+    }
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (8 * tl + 4 * lhi + j < E) mx = fmaxf(mx, logit[tl][j]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float pr[2][4], dsum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pr[tl][j] = (8 * tl + 4 * lhi + j < E) ? expf(logit[tl][j] - mx) : 0.f;
+        dsum[tl] += pr[tl][j];
+      }
+    // (summed in expert order, four at a time: 0-3, 4-7, 8-11, 12-15)
+    const float den = ((__shfl(dsum[0], l31) + __shfl(dsum[0], l31 + 32)) + __shfl(dsum[1], l31)) + __shfl(dsum[1], l31 + 32);
+    float bv[2] = {-1.f, -1.f};
+    int be[2] = {0, 0};
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pr[tl][j] = pr[tl][j] / den;
+        if (8 * tl + 4 * lhi + j < E && pr[tl][j] > bv[tl]) { bv[tl] = pr[tl][j]; be[tl] = 8 * tl + 4 * lhi + j; }      // first maximum
+      }
+    // first maximum over all 16 in expert order: (lower half, tile 0), (upper, 0), (lower, 1), (upper, 1)
+    float best_v = __shfl(bv[0], l31);
+    int best_e = __shfl(be[0], l31);
+    {
+      const float v1 = __shfl(bv[0], l31 + 32); const int e1 = __shfl(be[0], l31 + 32);
+      if (v1 > best_v) { best_v = v1; best_e = e1; }
+      const float v2 = __shfl(bv[1], l31); const int e2 = __shfl(be[1], l31);
+      if (v2 > best_v) { best_v = v2; best_e = e2; }
+      const float v3 = __shfl(bv[1], l31 + 32); const int e3 = __shfl(be[1], l31 + 32);
+      if (v3 > best_v) { best_v = v3; best_e = e3; }
+    }
+    const long tok = (long)t * 32 + l31;
+    if (tok < P) {
+      if (E == 16) {
+        *(float4*)(gates + tok * 16 + 4 * lhi) = make_float4(pr[0][0], pr[0][1], pr[0][2], pr[0][3]);
+        *(float4*)(gates + tok * 16 + 8 + 4 * lhi) = make_float4(pr[1][0], pr[1][1], pr[1][2], pr[1][3]);
+      } else {
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (8 * tl + 4 * lhi + j < E) gates[tok * E + 8 * tl + 4 * lhi + j] = pr[tl][j];
+      }
+      if (lhi == 0) {
+        idx[tok] = best_e;
+        gmax[tok] = best_v;
+        if (LN) *(float2*)(stats + tok * 2) = make_float2(mean, rstd);
+      }
+    }
+  }
+}
+
+int gate_fwd_wide_launch(const void* g, const float* ln_w, const float* ln_b, const float* wg, int n_tokens, int n_experts, float* gates,
+                         int32_t* idx, float* gmax, float* stats, void* stream) {
+  const int n_tiles = cdiv(n_tokens, 32);
+  int blocks = cdiv(n_tiles, 4);
+  if (blocks > 512) blocks = 512;
+  const void* fn = ln_w ? (const void*)gate_fwd_wide_kernel<true> : (const void*)gate_fwd_wide_kernel<false>;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GW_FWD_LDS);
+  SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  const bf16_t* gp = (const bf16_t*)g;
+  void* kargs[] = {(void*)&gp, (void*)&ln_w, (void*)&ln_b, (void*)&wg, (void*)&n_tokens, (void*)&n_experts, (void*)&gates, (void*)&idx,
+                   (void*)&gmax, (void*)&stats, (void*)&n_tiles};
+  e = hipLaunchKernel(fn, dim3(blocks), dim3(256), kargs, GW_FWD_LDS, as_stream(stream));
+  SWN_CHECK(e == hipSuccess, "swn_gate_fwd (wide mfma) launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+// Router backward, data path, 512 features (see the header of this section): dlogits -> dxh = dlogits @ W' -> LayerNorm backward -> dg.
+// Lane (l31, lhi): token l31; as the B operand it carries the dlogits of experts 8 lhi .. + 7, as the owner of accumulator values it
+// holds columns 32 nt + 16 lhi .. + 15 of column tile nt (= the 32 bytes of its row it loads and stores).
+// The row sums of the LayerNorm backward without a pass over the columns:
+//   s1 = mean_k dxh_k        = (1 / G) sum_e dl_e c1_e,                       c1_e = sum_k W'[e][k]
+//   s2 = mean_k dxh_k xhat_k = (1 / G) sum_e dl_e (rstd u_e - mean rstd c1_e),  u_e = sum_k W'[e][k] x_k
+// (dxh_k = sum_e dl_e W'[e][k], xhat = x rstd - mean rstd) - u is the forward contraction again (W' as hi + mid, 32 MFMAs per 32 tokens,
+// no VALU work), and its B fragments ARE the registers the output pass reads x from: K step 2 nt + hh multiplies columns
+// 32 nt + 16 lhi + 8 hh .. + 7.
+constexpr int GW_BWD_U0 = 2 * 16 * 64 * 16;              // the u table behind the two dxh tables: [32 K steps][64 lanes] x 16 bytes
+constexpr int GW_BWD_C0 = GW_BWD_U0 + GW_KS * 64 * 16;   // c1[16]
+constexpr int GW_BWD_LDS_ALL = GW_BWD_C0 + 64;
+
+template <bool LN>
+__global__ __launch_bounds__(256, 2) void gate_bwd_wide_kernel(const bf16_t* __restrict__ g, const float* __restrict__ ln_w,
+                                                               const float* __restrict__ wg, const float* __restrict__ gates,
+                                                               const int32_t* __restrict__ idx, const float* __restrict__ d_gmax,
+                                                               const float* __restrict__ stats, const int32_t* __restrict__ counts,
+                                                               const float* __restrict__ laux_coef, int seg_tokens, int P, int E,
+                                                               bf16_t* __restrict__ dg, float* __restrict__ dlogits, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  float* cst = (float*)(smem + GW_BWD_C0);
+  // ---- prologue 1: A fragments of the dxh contraction, column tile nt, lane ln: table row m = ln & 31 <-> column
+  //      32 nt + 16 ((m >> 2) & 1) + 4 (m >> 3) + (m & 3) (the accumulator of output lane (token, lhi) then holds columns 32 nt + 16 lhi + r,
+  //      r = 0 .. 15), K slots = experts 8 (ln >> 5) + i ----
+  for (int f = tid; f < 16 * 64; f += 256) {
+    const int ln = f & 63, nt = f >> 6, m = ln & 31, h = ln >> 5;
+    const int col = 32 * nt + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
+    const float lw = LN ? ln_w[col] : 1.f;
+    uint32_t hi[4] = {0u, 0u, 0u, 0u}, mid[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = 8 * h + i;
+      if (e < E) {
+        const float wp = wg[(long)e * GW_G + col] * lw * GM_SW;
+        const bf16_t hh = f32_to_bf16(wp);
+        const bf16_t mm = f32_to_bf16(wp - bf16_to_f32(hh));
+        hi[i >> 1] |= (uint32_t)hh << (16 * (i & 1));
+        mid[i >> 1] |= (uint32_t)mm << (16 * (i & 1));
+      }
+    }
+    *(gm_u32x4_t*)(smem + (size_t)f * 16) = gm_u32x4_t{hi[0], hi[1], hi[2], hi[3]};
+    *(gm_u32x4_t*)(smem + 16384 + (size_t)f * 16) = gm_u32x4_t{mid[0], mid[1], mid[2], mid[3]};
+  }
+  if (LN) {
+    // ---- prologue 2: A fragments of the u contraction, K step ks = 2 nt + hh, lane ln: table row m = 8 g4 + 4 hm + j holds term g4 >> 1
+    //      (hi / mid) of expert 8 hm + 4 (g4 & 1) + j - output lane (token, lhi) then holds u of experts 8 lhi + i, i = 4 (g4 & 1) + j, as
+    //      acc[4 g4 + j] + acc[4 (g4 + 2) + j]; K slots = columns 32 nt + 16 (ln >> 5) + 8 hh + i ----
+    for (int f = tid; f < GW_KS * 64; f += 256) {
+      const int ln = f & 63, ks = f >> 6, m = ln & 31, h = ln >> 5;
+      const int g4 = m >> 3, e = 8 * ((m >> 2) & 1) + 4 * (g4 & 1) + (m & 3), term = g4 >> 1;
+      uint32_t v[4] = {0u, 0u, 0u, 0u};
+      if (e < E) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int c = 32 * (ks >> 1) + 16 * h + 8 * (ks & 1) + i;
+          const float wp = wg[(long)e * GW_G + c] * ln_w[c] * GM_SW;
+          const bf16_t hh = f32_to_bf16(wp);
+          const bf16_t val = term == 0 ? hh : f32_to_bf16(wp - bf16_to_f32(hh));
+          v[i >> 1] |= (uint32_t)val << (16 * (i & 1));
+        }
+      }
+      *(gm_u32x4_t*)(smem + GW_BWD_U0 + (size_t)f * 16) = gm_u32x4_t{v[0], v[1], v[2], v[3]};
+    }
+    {      // c1[e] = sum_k (hi + mid)(e, k): 16 lanes per expert, a fixed order
+      const int e = tid >> 4, jj = tid & 15;
+      float a = 0.f;
+      if (e < E) {
+        for (int c = jj; c < GW_G; c += 16) {
+          const float wp = wg[(long)e * GW_G + c] * ln_w[c] * GM_SW;
+          const bf16_t hh = f32_to_bf16(wp);
+          a += (bf16_to_f32(hh) + bf16_to_f32(f32_to_bf16(wp - bf16_to_f32(hh)))) * (1.f / GM_SW);
+        }
+      }
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+      if (jj == 0) cst[e] = a;
+    }
+  }
+  __syncthreads();
+  float c1[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) c1[i] = (LN && 8 * lhi + i < E) ? cst[8 * lhi + i] : 0.f;
+  const char* wrow = smem + lane * 16;
+  const int stride = gridDim.x * 4;
+  for (int t = blockIdx.x * 4 + w; t < n_tiles; t += stride) {
+    long tok = (long)t * 32 + l31;
+    const bool live = tok < P;
+    tok = live ? tok : (long)P - 1;
+    // ---- the whole tile's rows into registers: this lane's 16 columns of every column tile (LayerNorm only: the plain router needs no x) ----
+    const char* xp = (const char*)g + tok * (GW_G * 2) + lhi * 32;
+    gm_u32x4_t xr[16][2];
+    if (LN) {
+#pragma unroll
+      for (int nt = 0; nt < 16; ++nt) {
+        xr[nt][0] = *(const gm_u32x4_t*)(xp + nt * 64);
+        xr[nt][1] = *(const gm_u32x4_t*)(xp + nt * 64 + 16);
+      }
+    }
+    // ---- dlogits of experts 8 lhi .. + 7 ----
+    const int seg = (int)(tok / seg_tokens);
+    const int my = idx[tok];
+    const float coef = laux_coef ? laux_coef[seg] : 0.f;
+    const float dgm = d_gmax ? d_gmax[tok] : 0.f;
+    float mean = 0.f, rstd = 1.f;
+    if (LN) { const float2 st = *(const float2*)(stats + tok * 2); mean = st.x; rstd = st.y; }
+    // (unconditional, vectorised loads: a guarded scalar load per expert is a branch and a round trip of its own - 20 of them in a row
+    //  made the first version of this kernel no faster than the VALU one)
+    float pr[8], dp[8], dot = 0.f;
+    int cnt[8];
+    if (E == 16) {
+      const float4 g0 = *(const float4*)(gates + tok * 16 + 8 * lhi), g1 = *(const float4*)(gates + tok * 16 + 8 * lhi + 4);
+      const int4 k0 = *(const int4*)(counts + (long)seg * 16 + 8 * lhi), k1 = *(const int4*)(counts + (long)seg * 16 + 8 * lhi + 4);
+      pr[0] = g0.x; pr[1] = g0.y; pr[2] = g0.z; pr[3] = g0.w; pr[4] = g1.x; pr[5] = g1.y; pr[6] = g1.z; pr[7] = g1.w;
+      cnt[0] = k0.x; cnt[1] = k0.y; cnt[2] = k0.z; cnt[3] = k0.w; cnt[4] = k1.x; cnt[5] = k1.y; cnt[6] = k1.z; cnt[7] = k1.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int e = 8 * lhi + i, ec = e < E ? e : E - 1;
+        const float pv = gates[tok * E + ec];
+        cnt[i] = counts[(long)seg * E + ec];
+        pr[i] = e < E ? pv : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = 8 * lhi + i;
+      dp[i] = e < E ? coef * (float)cnt[i] + ((e == my) ? dgm : 0.f) : 0.f;
+      dot += pr[i] * dp[i];
+    }
+    dot = __shfl(dot, l31) + __shfl(dot, l31 + 32);           // experts 0-7 first
+    float dl[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dl[i] = pr[i] * (dp[i] - dot);      // softmax backward
+    if (live) {
+      if (E == 16) {
+        *(float4*)(dlogits + tok * 16 + 8 * lhi) = make_float4(dl[0], dl[1], dl[2], dl[3]);
+        *(float4*)(dlogits + tok * 16 + 8 * lhi + 4) = make_float4(dl[4], dl[5], dl[6], dl[7]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (8 * lhi + i < E) dlogits[tok * E + 8 * lhi + i] = dl[i];
+      }
+    }
+    gm_u32x4_t bh, bl;                                         // B fragments: bf16 heads / remainders of the 8 dlogits
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t vh = 0u, vl = 0u;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float x = dl[2 * i + h] * GM_SD;
+        const bf16_t hd = f32_to_bf16(x);
+        vh |= (uint32_t)hd << (16 * h);
+        vl |= (uint32_t)f32_to_bf16(x - bf16_to_f32(hd)) << (16 * h);
+      }
+      bh[i] = vh;
+      bl[i] = vl;
+    }
+    const float mr = mean * rstd;
+    float s1 = 0.f, s2 = 0.f;
+    if (LN) {
+      // ---- u_e = sum_k W'[e][k] x_k: 32 K steps on two accumulators, the fragments of step ks + 1 requested in front of the MFMA of step ks ----
+      gm_f32x16_t ua, ub;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ua[r] = ub[r] = 0.f;
+      gm_u32x4_t uf[2];
+      uf[0] = *(const gm_u32x4_t*)(wrow + GW_BWD_U0);
+#pragma unroll
+      for (int ks = 0; ks < GW_KS; ++ks) {
+        if (ks + 1 < GW_KS) uf[(ks + 1) & 1] = *(const gm_u32x4_t*)(wrow + GW_BWD_U0 + (ks + 1) * 1024);
+        if (ks & 1) ub = SWN_MFMA_32x32x16(uf[ks & 1], xr[ks >> 1][ks & 1], ub);
+        else ua = SWN_MFMA_32x32x16(uf[ks & 1], xr[ks >> 1][ks & 1], ua);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int g4 = i >> 2, j = i & 3;
+        const float u = ((ua[4 * g4 + j] + ub[4 * g4 + j]) + (ua[4 * (g4 + 2) + j] + ub[4 * (g4 + 2) + j])) * (1.f / GM_SW);
+        s1 += dl[i] * c1[i];
+        s2 += dl[i] * (rstd * u - mr * c1[i]);
+      }
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      s1 *= (1.f / GW_G);
+      s2 *= (1.f / GW_G);
+    }
+    auto dxh_tile = [&](int nt) -> gm_f32x16_t {
+      gm_f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const gm_u32x4_t wh = *(const gm_u32x4_t*)(wrow + nt * 1024), wm = *(const gm_u32x4_t*)(wrow + 16384 + nt * 1024);
+      acc = SWN_MFMA_32x32x16(wh, bh, acc);
+      acc = SWN_MFMA_32x32x16(wh, bl, acc);
+      acc = SWN_MFMA_32x32x16(wm, bh, acc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] *= 1.f / (GM_SW * GM_SD);
+      return acc;
+    };
+    char* op = (char*)dg + tok * (GW_G * 2) + lhi * 32;
+    // (a column tile per scheduling region, the next tile's MFMAs issued in front of this tile's VALU work)
+    gm_f32x16_t acc_n = dxh_tile(0);
+#pragma unroll
+    for (int nt = 0; nt < 16; ++nt) {
+      const gm_f32x16_t acc = acc_n;
+      if (nt + 1 < 16) acc_n = dxh_tile(nt + 1);
+      uint32_t o[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float o0 = acc[2 * q], o1 = acc[2 * q + 1];
+        if (LN) {
+          const uint32_t xv = xr[nt][q >> 2][q & 3];
+          const float xh0 = gm_lo(xv) * rstd - mr, xh1 = gm_hi(xv) * rstd - mr;
+          o0 = rstd * (o0 - s1 - xh0 * s2);
+          o1 = rstd * (o1 - s1 - xh1 * s2);
+        }
+        o[q] = pack_bf16x2(o0, o1);
+      }
+      if (live) {
+        *(gm_u32x4_t*)(op + nt * 64) = gm_u32x4_t{o[0], o[1], o[2], o[3]};
+        *(gm_u32x4_t*)(op + nt * 64 + 16) = gm_u32x4_t{o[4], o[5], o[6], o[7]};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+int gate_bwd_wide_launch(const void* g, const float* ln_w, const float* wg, const float* gates, const int32_t* idx, const float* d_gmax,
+                         const float* stats, const int32_t* counts, const float* laux_coef, int seg_tokens, int n_tokens, int n_experts,
+                         void* dg, float* dlogits, void* stream) {
+  const int n_tiles = cdiv(n_tokens, 32);
+  int blocks = cdiv(n_tiles, 4);
+  if (blocks > 512) blocks = 512;
+  const void* fn = ln_w ? (const void*)gate_bwd_wide_kernel<true> : (const void*)gate_bwd_wide_kernel<false>;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GW_BWD_LDS_ALL);
+  SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  const bf16_t* gp = (const bf16_t*)g;
+  bf16_t* dgp = (bf16_t*)dg;
+  void* kargs[] = {(void*)&gp, (void*)&ln_w, (void*)&wg, (void*)&gates, (void*)&idx, (void*)&d_gmax, (void*)&stats, (void*)&counts,
+                   (void*)&laux_coef, (void*)&seg_tokens, (void*)&n_tokens, (void*)&n_experts, (void*)&dgp, (void*)&dlogits, (void*)&n_tiles};
+  e = hipLaunchKernel(fn, dim3(blocks), dim3(256), kargs, GW_BWD_LDS_ALL, as_stream(stream));
+  SWN_CHECK(e == hipSuccess, "swn_gate_bwd (wide mfma) launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
 }  // namespace swn

@@ -1394,3 +1394,49 @@ def test_scatter_rows_and_owner_aux_records():
         assert torch.equal(ga, aux[:, 0]) and torch.equal(ra, (t // S + 640).to(torch.int32))
         if nz is not None:
             assert torch.equal(na, aux[:, 2])
+
+
+@pytest.mark.parametrize("Gd,E,ln", [(256, 8, True), (512, 16, True), (512, 16, False), (512, 8, True)])
+def test_router_16bit_matrix_pipe_kernels_vs_fp64(Gd, E, ln):
+    """The 16-bit router kernels (gate_mfma.hip: 256 features x <= 8 experts, and 512 features x <= 16 experts - Mission Bay's router) against
+    fp64 on the exact 16-bit rows: probabilities to 2e-6 (1e-5 at 512 features), top-1 exact off near-ties, gmax = the chosen probability, LayerNorm statistics,
+    and the backward (dg to 16-bit rounding, parameter gradients) against autograd in fp64; ragged token count, two segments."""
+    o = ops()
+    torch.manual_seed(3)
+    P, seg = 2 * 4099, 4099
+    g = (torch.randn(P, Gd, device=dev()) * 1.3 + 0.4).to(torch.bfloat16)
+    ln_w = (1.0 + 0.2 * torch.randn(Gd, device=dev())) if ln else None
+    ln_b = (0.1 * torch.randn(Gd, device=dev())) if ln else None
+    wg = torch.randn(E, Gd, device=dev()) * 0.3
+    gates, idx, gmax, stats = o.gate_fwd(g, ln_w, ln_b, wg)
+    x = g.double().requires_grad_(True)
+    W = wg.double().requires_grad_(True)
+    lw = ln_w.double().requires_grad_(True) if ln else None
+    lb = ln_b.double().requires_grad_(True) if ln else None
+    xn = torch.nn.functional.layer_norm(x, (Gd,), lw, lb, 1e-5) if ln else x
+    pr = torch.softmax(xn @ W.t(), 1)
+    # (logits of ~ +-25 here: an fp32 rounding of the logit is 2e-6 of a probability at 512 features)
+    assert (gates.double() - pr).abs().max().item() <= (2e-6 if Gd == 256 else 1e-5)
+    top2 = torch.topk(pr, 2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-5
+    assert torch.equal(idx.long()[safe], pr.argmax(1)[safe])
+    assert torch.equal(gmax, gates.gather(1, idx.long()[:, None])[:, 0])
+    if ln:
+        mu, var = g.double().mean(1), g.double().var(1, unbiased=False)
+        assert (stats[:, 0].double() - mu).abs().max().item() <= 1e-5
+        assert ((stats[:, 1].double() - 1 / torch.sqrt(var + 1e-5)) * torch.sqrt(var + 1e-5)).abs().max().item() <= 1e-5
+    n_seg = P // seg
+    counts = torch.randint(0, seg, (n_seg, E), device=dev(), dtype=torch.int32)
+    coef = torch.rand(n_seg, device=dev()) * 1e-4
+    dgmax = torch.randn(P, device=dev())
+    d_wg = torch.zeros(E, Gd, device=dev())
+    d_lw, d_lb = torch.zeros(Gd, device=dev()), torch.zeros(Gd, device=dev())
+    dg = o.gate_bwd(g, ln_w, ln_b, wg, gates, idx, dgmax, stats, counts, coef, seg, d_wg, d_lw if ln else None, d_lb if ln else None)
+    dp = coef.double().repeat_interleave(seg)[:, None] * counts.double().repeat_interleave(seg, 0)
+    dp = dp + torch.nn.functional.one_hot(idx.long(), E).double() * dgmax.double()[:, None]
+    (pr * dp).sum().backward()
+    rel = lambda a, b: ((a.double() - b).abs().max() / b.abs().max()).item()
+    assert rel(dg, x.grad) <= 6e-3           # (16-bit output rows)
+    assert rel(d_wg, W.grad) <= 2e-4
+    if ln:
+        assert rel(d_lw, lw.grad) <= 2e-4 and rel(d_lb, lb.grad) <= 2e-4
