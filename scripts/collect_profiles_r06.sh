@@ -60,4 +60,8 @@ rm -rf gpurun_out/p_mb
 # (g) the one-GPU rehearsal of the multi-GPU step over RCCL (world-1 loopback)
 python bench.py --gpus 1 --loopback --rays 1024 --steps 50 --warmup 10 --no-cpu-baseline --no-balanced --no-events > $O/${R}_bench_loopback_dp_1024rays.json 2>/dev/null
 python bench.py --gpus 1 --loopback --parallelism ep --steps 10 --warmup 3 --no-cpu-baseline --no-balanced --no-events > $O/${R}_bench_loopback_ep.json 2>/dev/null
+python bench.py --gpus 1 --loopback --parallelism ep --ep-owner-tail --steps 10 --warmup 3 --no-cpu-baseline --no-balanced --no-events > $O/${R}_bench_loopback_ep_owner_tail.json 2>/dev/null
+# (h) the 512-feature router against fp64 + timing, both 16-bit builds
+GATE_G=512 GATE_E=16 python scripts/gate_check.py 2>&1 | grep -v amdgpu > $O/${R}_gate_check_512x16.txt
+GATE_G=512 GATE_E=16 GATE_DTYPE=fp16 python scripts/gate_check.py 2>&1 | grep -v amdgpu > $O/${R}_gate_check_512x16_fp16.txt
 ls -la $O | head -80
