@@ -29,15 +29,22 @@ __device__ __attribute__((aligned(16))) uint32_t g_zero_page[256];   // 1 KiB of
 // 16 bytes per lane from each lane's own global address into LDS at lds_dst (wave-uniform byte address) + lane * 16.  Inline asm on
 // purpose: with the builtin, hipcc treats every later ds_read of the same array as possibly aliasing the pending copy and drains the
 // queue (s_waitcnt vmcnt(0)) in front of it; the waits here are counted by hand.  M0 is saved / restored (cdna_hip_programming.md 5.7).
+// Cache policy of the copy: non-temporal where every operand row is read exactly once (2.555 -> 2.49-2.50 ms for the expert launch, 2.04 -> 2.01 ms
+// for the dense ones, round 4, scripts/wgrad_check.py); the default policy for an operand that ANOTHER job of the launch reads as well - the
+// 256-column blocks of a wider weight gradient (swn_wgrad_blocks: dW [512 x 512] = 4 jobs, every operand block in two of them; the jobs that
+// share a block run on the same XCD at the same time, and a non-temporal line is the first to leave the L2 the second reader hopes to hit:
+// Mission Bay recipe 33.8 -> 33.3 ms, FETCH_SIZE of the weight-gradient launches -11 %, round 6).  -DSWN_WG_NT=0: default policy everywhere.
+template <bool NT>
 __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
   uint32_t keep;
 #if !defined(SWN_WG_NT) || SWN_WG_NT
-#define SWN_WG_LOAD_POLICY " nt"      // non-temporal operand loads (every operand row is read exactly once): 2.555 -> 2.49-2.50 ms for the expert
-#else                                 // launch, 2.04 -> 2.01 ms for the dense ones (round 4, scripts/wgrad_check.py); -DSWN_WG_NT=0: default policy
-#define SWN_WG_LOAD_POLICY ""
+  if (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  else
 #endif
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" SWN_WG_LOAD_POLICY "\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
 template <typename T> struct WCfg;
@@ -133,8 +140,8 @@ __global__ __launch_bounds__(WG_NT) void wgrad_kernel(const WgradArgs p) {
       const long bs = RPP == 2 ? (prow ? bsr[RPP - 1] : bsr[0]) : bsr[0];
       const char* ap = ok ? (const char*)it.a + (as * (long)p.lda) * sizeof(T) + a_colb : zero;
       const char* bp = ok ? (const char*)it.b + (bs * (long)p.ldb) * sizeof(T) + b_colb : zero;
-      dma16(ap, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(slot * 2 * SLAB + piece * 1024)));
-      dma16(bp, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(slot * 2 * SLAB + SLAB + piece * 1024)));
+      dma16<true>(ap, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(slot * 2 * SLAB + piece * 1024)));
+      dma16<true>(bp, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(slot * 2 * SLAB + SLAB + piece * 1024)));
     }
   };
 
@@ -464,6 +471,8 @@ __global__ __launch_bounds__(WG_NT) void wgrad_stream_kernel(const WsArgs p) {
       const int a_colb = pcol < m_dim * (int)sizeof(T) ? pcol : 0, b_colb = pcol < n_dim * (int)sizeof(T) ? pcol : 0;
       const bool active = (wm * 128 < m_dim) && (wn * 64 < n_dim);
       const bool do_bias = (it.db != nullptr) && wm == 0 && (wn * 64 < n_dim);
+      // a column block of a wider operand pair: the block of A is read again by the job of the next column block of B, and the other way round
+      const bool a_shared = it.ldb > n_dim, b_shared = it.lda > m_dim;
       // ---------------------------------------------------------------- one piece: slabs [pa, pb) of (job j, weight set e)
       f32x16_t acc[4][2];
       f32x16_t accb[2];
@@ -560,8 +569,10 @@ __global__ __launch_bounds__(WG_NT) void wgrad_stream_kernel(const WsArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int piece = 2 * wave + i;
-          dma16(src[2 * i], __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(slot * 2 * SLAB + piece * 1024)));
-          dma16(src[2 * i + 1], __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(slot * 2 * SLAB + SLAB + piece * 1024)));
+          const uint32_t da = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(slot * 2 * SLAB + piece * 1024));
+          const uint32_t db_ = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(slot * 2 * SLAB + SLAB + piece * 1024));
+          if (a_shared) dma16<false>(src[2 * i], da); else dma16<true>(src[2 * i], da);
+          if (b_shared) dma16<false>(src[2 * i + 1], db_); else dma16<true>(src[2 * i + 1], db_);
         }
       };
 
