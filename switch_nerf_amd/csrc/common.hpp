@@ -89,6 +89,9 @@ int gate_fwd_wide_launch(const void* g, const float* ln_w, const float* ln_b, co
 int gate_bwd_wide_launch(const void* g, const float* ln_w, const float* wg, const float* gates, const int32_t* idx, const float* d_gmax,
                          const float* stats, const int32_t* counts, const float* laux_coef, int seg_tokens, int n_tokens, int n_experts,
                          void* dg, float* dlogits, void* stream);
+int gate_dwg_wide_blocks(int n_tokens);
+int gate_dwg_wide_launch(const void* g, bool layer_norm, const float* stats, const float* dlogits, int n_tokens, int n_experts, float* partial,
+                         void* stream);
 bool chain_big_eligible(const swn_chain_desc& d);                // chain_big.hip: the 256-row geometry
 bool chain_persistent_eligible(const swn_chain_desc& d);         // chain_big.hip: geometries 6 / 7 (persistent; also the dense front chains)
 int chain_big_launch(const swn_chain_desc& d, void* stream);

@@ -1239,6 +1239,7 @@ extern "C" size_t swn_gate_bwd_scratch_floats(int n_tokens, int gate_dim, int n_
   const size_t ps = (size_t)n_experts * gate_dim + n_experts;
   size_t blocks = (size_t)cdiv(n_tokens, gate_dwg_tokens_per_block(n_tokens));
   if ((size_t)swn::gate_bwd_mfma_blocks(n_tokens) > blocks) blocks = (size_t)swn::gate_bwd_mfma_blocks(n_tokens);
+  if (gate_dim == 512 && (size_t)swn::gate_dwg_wide_blocks(n_tokens) > blocks) blocks = (size_t)swn::gate_dwg_wide_blocks(n_tokens);
   return (size_t)n_tokens * n_experts + (blocks + 1) * ps;
 }
 
@@ -1270,14 +1271,18 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
       const int rc = swn::gate_bwd_mfma_launch(g, ln_w, wg, gates, idx, d_gmax, stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dg,
                                                dlogits, dwg_partial, stream);
       if (rc) return rc;
-    } else if (gate_dim == 512 && !valu_only) {      // 512-feature rows: the data path on the matrix pipe, the parameter gradients below
-      const int rc = swn::gate_bwd_wide_launch(g, ln_w, wg, gates, idx, d_gmax, stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dg,
-                                               dlogits, stream);
+    } else if (gate_dim == 512 && !valu_only) {      // 512-feature rows: data path and parameter-gradient sums on the matrix pipe
+      int rc = swn::gate_bwd_wide_launch(g, ln_w, wg, gates, idx, d_gmax, stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dg,
+                                         dlogits, stream);
+      if (rc) return rc;
+      dwg_blocks = swn::gate_dwg_wide_blocks(n_tokens);
+      msum = dwg_partial + (size_t)dwg_blocks * ps;
+      rc = swn::gate_dwg_wide_launch(g, ln_w != nullptr, stats, dlogits, n_tokens, n_experts, dwg_partial, stream);
       if (rc) return rc;
     } else
     GATE_DISPATCH_TB(bf16_t, gate_bwd_kernel, 1, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, gates, idx, d_gmax,
                   stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dgp, dlogits, d_ln_w, d_ln_b);
-    if (!mfma_path) {
+    if (!mfma_path && !(gate_dim == 512 && !valu_only)) {
       SWN_CHECK(n_experts == 4 || n_experts == 8 || n_experts == 16, "swn_gate_bwd: experts must be 4, 8 or 16");
       DWG_DISPATCH(bf16_t, gp);
     }

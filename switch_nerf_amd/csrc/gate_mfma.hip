@@ -978,4 +978,167 @@ int gate_bwd_wide_launch(const void* g, const float* ln_w, const float* wg, cons
   return 0;
 }
 
+
+// Router parameter gradients, 512 features: M[e][k] = sum_tok dlogits[tok][e] xhat[tok][k] and DL[e] = sum_tok dlogits[tok][e] per block, in
+// gate_dwg_kernel's partial format (finished by ordered_reduce + gate_dwg_finalize_kernel).  gate_dwg_kernel<., 16, 512> walks its tokens
+// with 128 accumulators per lane and 4 KiB per wave in flight: 0.41 ms per 852 k rows, latency-bound at a third of the rate the row reads
+// allow.  Here the sum over the tokens is a GEMM on the matrix pipe, the 256-feature kernel's scheme with the tile shared by the block:
+//   * a 32-token x 1 KiB tile comes in by LDS-DMA (double-buffered: the next tile travels while this one is multiplied), rows swizzled
+//     like every tile of this file; wave w owns columns [128 w, +128);
+//   * v_mfma_f32_16x16x32 per 16 columns: A = dlr^T (16 experts x 32 tokens; dlr = dlogits * rstd split into a 16-bit head and remainder:
+//     two MFMAs), B = x^T read straight from the row-major tile with the transposing LDS read (ds_read_b64_tr_b16);
+//   * xhat = (x - mean) rstd: M = dlr^T x - C, C[e] = sum_tok dlr[tok][e] mean[tok] (fp32, wave 0's lanes).
+constexpr int GD_TILE_B = 32 * 1024;
+constexpr int GD_DST0 = 2 * GD_TILE_B;            // dlr^T staging: head [16][32] + remainder [16][32] (1 KiB each)
+constexpr int GD_CST0 = GD_DST0 + 2048;           // C[16], DL[16]
+constexpr int GD_LDS = GD_CST0 + 128;
+
+// 16 bytes per lane from the lane's own global address into LDS at lds_dst (wave-uniform) + lane * 16; inline asm: the compiler does not
+// see the copy, the waits are written by hand (wgrad.hip's dma16)
+__device__ __forceinline__ void gd_dma16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <bool LN>
+__global__ __launch_bounds__(256, 2) void gate_dwg_wide_kernel(const bf16_t* __restrict__ g, const float* __restrict__ stats,
+                                                               const float* __restrict__ dlogits, int P, int E, int n_tiles,
+                                                               float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5, kg = lane >> 4, n16 = lane & 15;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  float* cst = (float*)(smem + GD_CST0);
+  typedef __attribute__((ext_vector_type(4))) float f32x4_t_;
+  f32x4_t_ macc[8][2];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { macc[j][0] = f32x4_t_{0.f, 0.f, 0.f, 0.f}; macc[j][1] = f32x4_t_{0.f, 0.f, 0.f, 0.f}; }
+  float cacc[16], dlacc[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) cacc[e] = dlacc[e] = 0.f;
+  // transposing read of (tokens 8 kg + 4 h + (n16 >> 2), columns 16 ct + 4 (n16 & 3) .. + 3): row byte address + swizzle seed
+  uint32_t tr_row[2], tr_sw[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = 8 * kg + 4 * h + (n16 >> 2);
+    tr_row[h] = (uint32_t)(r * 1024 + 8 * (n16 & 1));
+    tr_sw[h] = (uint32_t)(r & 15);
+  }
+  auto dma_tile = [&](int t, int buf) {          // wave w copies rows 8 w .. + 7: chunk (lane ^ (row & 15)) of the row -> position `lane`
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int r = 8 * w + c;
+      long tok = (long)t * 32 + r;
+      tok = tok < P ? tok : (long)P - 1;
+      gd_dma16((const char*)g + tok * 1024 + ((lane ^ (r & 15)) << 4),
+               __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(buf * GD_TILE_B + r * 1024)));
+    }
+  };
+  float dlv[16], mu = 0.f, rs = 1.f;
+  bool live = false;
+  auto load_dl = [&](int t) {                    // (wave 0) this lane's token: its dlogits row and statistics
+    long tok = (long)t * 32 + l31;
+    live = tok < P;
+    tok = live ? tok : (long)P - 1;
+    if (E == 16) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *(const float4*)(dlogits + tok * 16 + 4 * q);
+        dlv[4 * q] = v.x; dlv[4 * q + 1] = v.y; dlv[4 * q + 2] = v.z; dlv[4 * q + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v = dlogits[tok * E + (e < E ? e : E - 1)];
+        dlv[e] = e < E ? v : 0.f;
+      }
+    }
+    if (LN) { const float2 st = *(const float2*)(stats + tok * 2); mu = st.x; rs = st.y; }
+  };
+  const int stride = gridDim.x;
+  int t = blockIdx.x;
+  if (t < n_tiles) {
+    dma_tile(t, 0);
+    if (w == 0) load_dl(t);
+  }
+  for (int it = 0; t < n_tiles; t += stride, ++it) {
+    const int buf = it & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this tile's copy (issued one iteration ago) and the dlogits registers
+    if (w == 0) {      // dlr^T: row e of the head (lower half-wave) / remainder (upper) table, column = this lane's token
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float d = live ? dlv[e] : 0.f;
+        const float x = d * rs * GM_SD;
+        const bf16_t hd = f32_to_bf16(x);
+        const bf16_t val = lhi ? f32_to_bf16(x - bf16_to_f32(hd)) : hd;
+        *(bf16_t*)(smem + GD_DST0 + lhi * 1024 + e * 64 + l31 * 2) = val;
+        cacc[e] += d * rs * mu;
+        dlacc[e] += d;
+      }
+    }
+    __syncthreads();
+    const int tn = t + stride;
+    if (tn < n_tiles) {
+      dma_tile(tn, buf ^ 1);
+      if (w == 0) load_dl(tn);
+    }
+    const gm_u32x4_t afr_h = *(const gm_u32x4_t*)(smem + GD_DST0 + n16 * 64 + kg * 16);            // row n16, tokens 8 kg .. + 7
+    const gm_u32x4_t afr_r = *(const gm_u32x4_t*)(smem + GD_DST0 + 1024 + n16 * 64 + kg * 16);
+    const uint32_t tb = (uint32_t)(buf * GD_TILE_B);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t ch = (uint32_t)(2 * (8 * w + j) + ((n16 & 3) >> 1));
+      const uint32_t a0 = tb + tr_row[0] + ((ch ^ tr_sw[0]) << 4), a1 = tb + tr_row[1] + ((ch ^ tr_sw[1]) << 4);
+      uint2 b0, b1;
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b0) : "v"(a0) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b1) : "v"(a1) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const gm_u32x4_t bx = {b0.x, b0.y, b1.x, b1.y};
+      macc[j][0] = GM_MFMA16x16x32(afr_h, bx, macc[j][0]);
+      macc[j][1] = GM_MFMA16x16x32(afr_r, bx, macc[j][1]);
+    }
+    __syncthreads();                                        // the tile and the staging rows are free for the next round
+  }
+  // ---- the block's partial: part[e * 512 + k] = M, part[E * 512 + e] = DL ----
+  if (w == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float a = cacc[e], b = dlacc[e];
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }      // over the 32 tokens (both half-waves hold them)
+      if (lane == 0) { cst[e] = a; cst[16 + e] = b; }
+    }
+  }
+  __syncthreads();
+  float* part = partial + (size_t)blockIdx.x * ((size_t)E * GW_G + E);
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = 4 * kg + r, col = 16 * (8 * w + j) + n16;
+      if (e < E) part[(size_t)e * GW_G + col] = (macc[j][0][r] + macc[j][1][r]) * (1.f / GM_SD) - (LN ? cst[e] : 0.f);
+    }
+  if (tid < E) part[(size_t)E * GW_G + tid] = cst[16 + tid];
+}
+
+int gate_dwg_wide_blocks(int n_tokens) {
+  const int n_tiles = cdiv(n_tokens, 32);
+  return n_tiles > 512 ? 512 : n_tiles;
+}
+
+int gate_dwg_wide_launch(const void* g, bool layer_norm, const float* stats, const float* dlogits, int n_tokens, int n_experts, float* partial,
+                         void* stream) {
+  const int n_tiles = cdiv(n_tokens, 32);
+  const int blocks = gate_dwg_wide_blocks(n_tokens);
+  const void* fn = layer_norm ? (const void*)gate_dwg_wide_kernel<true> : (const void*)gate_dwg_wide_kernel<false>;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GD_LDS);
+  SWN_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  const bf16_t* gp = (const bf16_t*)g;
+  void* kargs[] = {(void*)&gp, (void*)&stats, (void*)&dlogits, (void*)&n_tokens, (void*)&n_experts, (void*)&n_tiles, (void*)&partial};
+  e = hipLaunchKernel(fn, dim3(blocks), dim3(256), kargs, GD_LDS, as_stream(stream));
+  SWN_CHECK(e == hipSuccess, "swn_gate_bwd (wide dwg) launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
 }  // namespace swn

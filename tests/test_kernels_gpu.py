@@ -1396,7 +1396,7 @@ def test_scatter_rows_and_owner_aux_records():
             assert torch.equal(na, aux[:, 2])
 
 
-@pytest.mark.parametrize("Gd,E,ln", [(256, 8, True), (512, 16, True), (512, 16, False), (512, 8, True)])
+@pytest.mark.parametrize("Gd,E,ln", [(256, 8, True), (512, 16, True), (512, 16, False), (512, 13, True), (512, 8, True)])
 def test_router_16bit_matrix_pipe_kernels_vs_fp64(Gd, E, ln):
     """The 16-bit router kernels (gate_mfma.hip: 256 features x <= 8 experts, and 512 features x <= 16 experts - Mission Bay's router) against
     fp64 on the exact 16-bit rows: probabilities to 2e-6 (1e-5 at 512 features), top-1 exact off near-ties, gmax = the chosen probability, LayerNorm statistics,
