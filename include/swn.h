@@ -317,6 +317,12 @@ int swn_scatter_rows(const void* src, const int32_t* index, long n_rows, int row
 int swn_owner_aux(const float* gate, const float* noise, const int32_t* index, long n, int rows_per_ray, int ray_base, int zero_gate,
                   float* aux, void* stream);
 int swn_owner_aux_split(const float* aux, long n, float* gate, int32_t* ray, float* noise, void* stream);
+/* The per-ray bias gradient of layer "2" (nerf_moe.py:419-429: the PE(dir) / embedding_a half of its input is per ray) from what the
+ * owner-tail mode brings home: dc_ray[ray][f] = sum over the ray's rows_per_ray tokens of (bit f of bits[token]) * round16(dc0 wc[0][f] +
+ * dc1 wc[1][f] + dc2 wc[2][f]), dc_c = d_raw[token][c] raw[token][c] (1 - raw[token][c]) - swn_heads_bwd's dh2 and its per-ray sums without h2.
+ * bits: swn_sign_bits_pack's words [tokens][features / 32]; w_color fp32 [3][features]; dc_ray fp32 [n_rays][features].               */
+int swn_ray_bias_grad_bits(const uint32_t* bits, const float* raw, const float* d_raw, const float* w_color, int n_rays, int rows_per_ray,
+                           int features, float* dc_ray, void* stream);
 
 /* ---- dense / grouped MLP chains on MFMA ------------------------------------------------------------------------
  * One launch runs `n_layers` (<= SWN_MAX_CHAIN_LAYERS) Linear layers back to back with the activations of a 128-row tile resident in

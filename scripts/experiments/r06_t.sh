@@ -3,7 +3,7 @@
 # kernels instead of torch indexing): tests, timing against the kept-rows mode and the eager data-parallel step (aliased and RCCL loopback)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r06; mkdir -p $O
-timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -m gpu -q -x -k "sign_bits or scatter_rows or expert_parallel or fused_tail or tail" 2>&1 | tail -6
+timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -m gpu -q -x -k "sign_bits or scatter_rows or ray_bias or expert_parallel or fused_tail or tail" 2>&1 | tail -6
 timeout 900 python -m pytest tests/test_parallel_gpu.py tests/test_rccl_gpu.py -m gpu -q -x 2>&1 | tail -6
 B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-balanced --no-events"
 timeout 300 $B --graph off > $O/t_dp_eager.json 2>/dev/null

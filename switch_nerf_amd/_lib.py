@@ -108,6 +108,7 @@ SIGNATURES = {
     "swn_scatter_rows": [vp, vp, i64, i32, vp, vp],
     "swn_owner_aux": [vp, vp, vp, i64, i32, i32, i32, vp, vp],
     "swn_owner_aux_split": [vp, i64, vp, vp, vp, vp],
+    "swn_ray_bias_grad_bits": [vp, vp, vp, vp, i32, i32, i32, vp, vp],
     "swn_mlp_chain": [C.POINTER(ChainDesc), vp],
     "swn_chain_big_ok": [C.POINTER(ChainDesc)],
     "swn_pack_weights": [vp, vp, i32, i32, i32, i32, i32, vp],

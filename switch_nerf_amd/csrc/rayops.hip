@@ -391,3 +391,57 @@ extern "C" int swn_owner_aux_split(const float* aux, long n, float* gate, int32_
   SWN_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- the per-ray bias gradient from sign bits (owner-tail expert parallelism, ep_owner.py) ---------------------------------------------------
+// dc_ray[ray][f] = sum over the ray's tokens of dh2[token][f], dh2 = (h2 > 0) * (dc0 wc[0][f] + dc1 wc[1][f] + dc2 wc[2][f]) rounded to the
+// 16-bit type (what swn_heads_bwd stores and sums: elementwise.hip heads_bwd_kernel), dc_c = d_raw_c raw_c (1 - raw_c) - with (h2 > 0) given as
+// the bits swn_sign_bits_pack made on the expert's rank.  One workgroup per ray, a thread per feature; 48 bytes per token.
+namespace swn {
+__global__ __launch_bounds__(256) void ray_bias_grad_bits_kernel(const uint32_t* __restrict__ bits, const float* __restrict__ raw,
+                                                                 const float* __restrict__ d_raw, const float* __restrict__ wc, int rows_per_ray,
+                                                                 int features, float* __restrict__ dc_ray) {
+  // a ray's tokens in rounds of 256: the workgroup fetches their raw / d_raw / bit words once (coalesced), leaves (dc0, dc1, dc2) and the words in
+  // LDS, then thread f walks the tokens (broadcast LDS reads) - one memory round trip per 256 tokens instead of one per token
+  __shared__ float4 dcs[256];
+  __shared__ uint32_t wds[256 * 8];
+  const int tid = threadIdx.x, f = tid;
+  const long ray = blockIdx.x;
+  const int wpr = features >> 5;                 // bit words per token
+  const bool mine = f < features;
+  const float w0 = mine ? wc[f] : 0.f, w1 = mine ? wc[features + f] : 0.f, w2 = mine ? wc[2 * features + f] : 0.f;
+  const long t0 = ray * rows_per_ray;
+  float acc = 0.f;
+  for (int s0 = 0; s0 < rows_per_ray; s0 += 256) {
+    const int n = min(256, rows_per_ray - s0);
+    if (tid < n) {
+      const float4 r = *(const float4*)(raw + (t0 + s0 + tid) * 4), d = *(const float4*)(d_raw + (t0 + s0 + tid) * 4);
+      dcs[tid] = make_float4(d.x * r.x * (1.f - r.x), d.y * r.y * (1.f - r.y), d.z * r.z * (1.f - r.z), 0.f);
+    }
+    for (int i = tid; i < n * wpr; i += 256) wds[i] = bits[(t0 + s0) * wpr + i];
+    __syncthreads();
+    if (mine) {
+      const int wq = f >> 5, sh = f & 31;
+#pragma unroll 4
+      for (int s = 0; s < n; ++s) {
+        const float4 dc = dcs[s];
+        const float gg = dc.x * w0 + dc.y * w1 + dc.z * w2;
+        acc += ((wds[s * wpr + wq] >> sh) & 1u) ? bf16_to_f32(f32_to_bf16(gg)) : 0.f;
+      }
+    }
+    __syncthreads();
+  }
+  if (mine) dc_ray[ray * features + f] = acc;
+}
+}  // namespace swn
+
+extern "C" int swn_ray_bias_grad_bits(const uint32_t* bits, const float* raw, const float* d_raw, const float* w_color, int n_rays, int rows_per_ray,
+                                      int features, float* dc_ray, void* stream) {
+  SWN_CHECK(bits && raw && d_raw && w_color && dc_ray, "swn_ray_bias_grad_bits: null pointer");
+  SWN_CHECK(n_rays >= 0 && rows_per_ray > 0 && features > 0 && features % 32 == 0 && features <= 256,
+            "swn_ray_bias_grad_bits: %d rays x %d rows, %d features (a multiple of 32 up to 256)", n_rays, rows_per_ray, features);
+  if (n_rays == 0) return 0;
+  hipLaunchKernelGGL(swn::ray_bias_grad_bits_kernel, dim3((unsigned)n_rays), dim3(256), 0, as_stream(stream), bits,
+                     raw, d_raw, w_color, rows_per_ray, features, dc_ray);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}

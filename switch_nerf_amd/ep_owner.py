@@ -18,7 +18,7 @@ Here the OWNER of a token's expert runs the whole fused launch on a RECEIVED TOK
     raw[token]  <---- raw (16 B) + sign bits of h2 (16 B)    saves y / h1 / h2 / expert activations stay on the owner
     compositing, loss, d_raw
     per-ray bias gradient: dc_ray = per-ray sums of dh2, and dh2 = (h2 > 0) * (colour-head gradient of d_raw, raw) needs h2's SIGN only:
-      swn_heads_bwd on a 0 / 1 stand-in built from the returned bits (its weight-gradient outputs go to scratch)
+      swn_ray_bias_grad_bits forms it from the returned bits, raw and d_raw (48 bytes per token)
     d_raw[token] (16 B)  -------------------------------->   heads backward, tag 8 (tail backward + combine backward + expert backward),
                                                              tail / head / expert weight gradients (dense ones: summed by the all-reduce)
     front backward, router backward  <---- dx (512 B) + gate gradient (4 B) per kept row
@@ -197,11 +197,7 @@ def backward_a(m, c, d_raw, d_laux):
     n_kept, n_drop = pl["n_kept"], pl["n_drop"]
     _b = lambda name, shape, dtype: m._buf(tag + ":ot_" + name, shape, dtype)
     # ---- source: the per-ray bias gradient from d_raw, raw and the sign of h2 (dh2 = (h2 > 0) * the colour heads' input gradient) ----
-    h2_sign = o.sign_bits_unpack(c["h2_bits"], dt)
-    scr = m._bufs.get("_ot_scratch")
-    if scr is None:
-        scr = m._bufs["_ot_scratch"] = [torch.zeros(n, dtype=torch.float32, device=dev) for n in (M, 1, 3 * H2, 3)]
-    _dh2, _dsig, dc_ray = o.heads_bwd(None, h2_sign, m.p["color.w"], c["raw"], d_raw, scr[0], scr[1], scr[2].view(3, H2), scr[3], rows_per_group=S)
+    dc_ray = o.ray_bias_grad_bits(c["h2_bits"], c["raw"], d_raw.contiguous(), m.p["color.w"], S)
     if dc_ray.shape[1] in (64, 128, 256) and c["ray_feat"].shape[1] <= 256:
         o.ray_feat_wgrad(c["ray_feat"], dc_ray, g["l2r.w"], g["l2.b"])
     else:

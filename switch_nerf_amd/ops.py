@@ -158,6 +158,15 @@ def owner_aux_split(aux, gate, ray, noise=None):
         call("swn_owner_aux_split", _p(aux), n, _p(gate), _p(ray), _p(noise), _stream())
 
 
+def ray_bias_grad_bits(bits, raw, d_raw, w_color, rows_per_ray: int):
+    """-> dc_ray [P / rows_per_ray, 32 W] f32: the per-ray sums of dh2 from the sign bits of h2 (include/swn.h swn_ray_bias_grad_bits)."""
+    P, W = bits.shape
+    assert bits.dtype == torch.int32 and raw.shape == (P, 4) and d_raw.shape == (P, 4) and P % rows_per_ray == 0 and w_color.shape == (3, 32 * W)
+    out = torch.empty(P // rows_per_ray, 32 * W, dtype=torch.float32, device=bits.device)
+    call("swn_ray_bias_grad_bits", _p(bits), _p(raw), _p(d_raw), _p(w_color), P // rows_per_ray, int(rows_per_ray), 32 * W, _p(out), _stream())
+    return out
+
+
 def gate_fwd(g, ln_w, ln_b, wg, noise=None, noise_scale: float = 0.0):
     """LayerNorm + fp32 router + softmax + top-1 -> (gates [P, E], idx, gmax, stats).  noise [P, E] fp32: logits += noise_scale * noise
     before the softmax (the gate-noise branch of a training forward, swn_gate_fwd_noise)."""

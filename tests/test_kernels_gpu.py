@@ -1440,3 +1440,24 @@ def test_router_16bit_matrix_pipe_kernels_vs_fp64(Gd, E, ln):
     assert rel(d_wg, W.grad) <= 2e-4
     if ln:
         assert rel(d_lw, lw.grad) <= 2e-4 and rel(d_lb, lb.grad) <= 2e-4
+
+
+def test_ray_bias_grad_from_sign_bits_equals_heads_bwd_row_sums():
+    """swn_ray_bias_grad_bits (owner-tail expert parallelism: the source forms the per-ray bias gradient from the sign bits of h2 that came
+    home, raw and d_raw) against swn_heads_bwd's per-ray sums of the dh2 rows it stores, on the same data: equal to summation order."""
+    o = ops()
+    g = torch.Generator().manual_seed(21)
+    N, S, H2, M = 96, 40, 128, 256
+    P = N * S
+    h2 = torch.relu(torch.randn(P, H2, generator=g)).to(torch.bfloat16).to(dev())
+    wc = (torch.randn(3, H2, generator=g) * 0.2).to(dev())
+    raw = torch.rand(P, 4, generator=g).to(dev())
+    d_raw = torch.randn(P, 4, generator=g).to(dev())
+    scr = [torch.zeros(n, device=dev()) for n in (M, 1, 3 * H2, 3)]
+    _dh2, _dsig, want = o.heads_bwd(None, h2, wc, raw, d_raw, scr[0], scr[1], scr[2].view(3, H2), scr[3], rows_per_group=S)
+    got = o.ray_bias_grad_bits(o.sign_bits_pack(h2), raw, d_raw, wc, S)
+    assert got.shape == want.shape and want.abs().max().item() > 0
+    err = (got - want).abs().max().item()
+    print(f"ray_bias_grad_bits vs heads_bwd row sums: max |diff| {err:.3e} of {want.abs().max().item():.3e}")
+    # (a last-bit difference of one fp32 product can move its 16-bit rounding by an ulp: 2^-8 of one of a ray's 40 terms)
+    assert err <= 1e-4 * want.abs().max().item()
