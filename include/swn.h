@@ -95,6 +95,13 @@ int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const float* ln_b,
                  by the per-block partial sums of the router weight gradient */, float* d_wg, float* d_ln_w, float* d_ln_b,
                  void* stream);
 size_t swn_gate_bwd_scratch_floats(int n_tokens, int gate_dim, int n_experts);
+/* ... with a DENSE gradient w.r.t. the probabilities on top: d_gates[s,e] += d_probs[s,e] (fp32 [n_tokens, n_experts]; the normalised
+ * gates of a top-k layer, swn_topk_gate_bwd - tutel_fast_dispatch.py:204-206 under autograd); d_gmax may be NULL.  VALU kernel. */
+int swn_gate_bwd_dense(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg,
+                       const float* gates, const int32_t* idx, const float* d_gmax, const float* d_probs, const float* stats,
+                       const int32_t* counts, const float* laux_coef, int seg_tokens,
+                       int n_tokens, int gate_dim, int n_experts,
+                       void* dg, float* dlogits, float* d_wg, float* d_ln_w, float* d_ln_b, void* stream);
 
 /* ---- routing: batch-prioritised top-1 capacity assignment ----------------------------------------------------
  * replaces extract_critical / compute_sorted_location / load_balance (tutel_fast_dispatch.py:136-217) and the
@@ -127,6 +134,26 @@ int swn_route_top1x(const int32_t* idx, const float* gmax, const float* gates,
                     int32_t* drop_begin, int32_t* dropped, int32_t* sync, int mode,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- top-k routing, k > 1 (extract_critical, tutel_fast_dispatch.py:176-217 with top_k > 1; no shipped config sets `k` above 1) ----
+ * swn_topk_select: torch.topk(gates, k, dim=1) per token (:177; descending, the lower expert on exact ties) -> idx int32 [k, n_tokens]
+ *   (choice-major: row j = indices_s[j]), gsel fp32 [k, n_tokens] = gates_s before, gnorm = gates_s after the normalisation
+ *   g_j / clamp(sum_j g_j, min=eps) (:204-206).
+ * swn_route_topk: locations of every choice (:192-202).  Choice j ranks its tokens like swn_route_top1 (batch-prioritised: by the TOKEN's
+ *   max gate, `importance_scores = -gates.max(dim=1)`, :187 - gmax is the top-1 gate for every choice; else token order) and adds
+ *   acc_base = the counts of the choices before it (:199-201), so every (token, choice) owns one row of the [n_seg * E, capacity] row
+ *   space, kept iff loc < capacity.  capacity = k * int(cf * ceil(P / E)) (:211) is the caller's.  loc int32 [k, n_tokens], counts int32
+ *   [k, n_seg * E], perm [n_seg * E * capacity] row -> token (all choices; -1 = empty), tok2row [k, n_tokens] or NULL, group_rows
+ *   [n_seg * E] = sum over the choices of counts (the chains' group_rows with group_rows_clamp = capacity), l_aux [n_seg] from choice
+ *   0's mask (load_balance(gates, masks_se[0]), :184) or NULL.  workspace: swn_route_workspace_bytes().
+ * swn_topk_gate_bwd: backward of the normalisation, d_gnorm [k, n_tokens] -> d_probs [n_tokens, E] (zero outside the token's k experts):
+ *   the dense operand of swn_gate_bwd_dense.                                                                                        */
+int swn_topk_select(const float* gates, int n_tokens, int n_experts, int top_k, int32_t* idx, float* gsel, float* gnorm, void* stream);
+int swn_route_topk(const int32_t* idx, const float* gmax, const float* gates, int n_tokens, int seg_tokens, int n_experts,
+                   int capacity, int bpr, int top_k, int32_t* loc, int32_t* counts, int32_t* perm, int32_t* tok2row,
+                   int32_t* group_rows, float* l_aux, void* workspace, size_t workspace_bytes, void* stream);
+int swn_topk_gate_bwd(const float* gates, const int32_t* idx, const float* d_gnorm, int n_tokens, int n_experts, int top_k,
+                      float* d_probs, void* stream);
+
 /* ---- Tutel sparse kernel ABI (batched, capacity padded) ------------------------------------------------------
  * replaces tutel.jit_kernels.sparse func_fwd / func_bwd_data / func_bwd_gate as called from
  * tutel_fast_dispatch.py:27,36,43,61,70,76 - same argument order (gates, indices, locations, reshaped_input,
@@ -142,6 +169,18 @@ int swn_dispatch_bwd_data(const float* gates, const int32_t* indices, const int3
 int swn_dispatch_bwd_gate(float* grad_gates, const int32_t* indices, const int32_t* locations,
                           const void* reshaped_input, const void* dispatched, int dtype,
                           int samples, int hidden, int capacity, void* stream);
+
+/* Top-k layers (k > 1): the reference calls the three kernels once per choice inside `for g, i, l in zip(gates_, indices_, locations_)`
+ * (tutel_fast_dispatch.py:26-27, 34-37, 59-62, 69-70).  The first iteration is the entry point above; these are the later ones:
+ * swn_dispatch_fwd_more writes a further choice's rows into the SAME dispatched buffer (no zero fill: the choices' rows are disjoint,
+ * swn_route_topk), swn_dispatch_bwd_data_more ADDS g * dispatched[row] to grad_reshaped_input (`last_result + grad_data` /
+ * `last_result + single_output`; dropped tokens add nothing).  swn_dispatch_bwd_gate is per choice as it is.                     */
+int swn_dispatch_fwd_more(const float* gates, const int32_t* indices, const int32_t* locations,
+                          const void* reshaped_input, void* dispatched, int dtype,
+                          int samples, int hidden, int capacity, int n_experts, void* stream);
+int swn_dispatch_bwd_data_more(const float* gates, const int32_t* indices, const int32_t* locations,
+                               void* grad_reshaped_input, const void* dispatched, int dtype,
+                               int samples, int hidden, int capacity, void* stream);
 
 /* ---- the no-batch (evaluation) variants: tutel_sparse_nobatch.py:24-133 as called from tutel_fast_dispatch_nobatch.py:36, :47,
  * :53, :73, :87, :93 - the same argument order with `expert_locations_begin` (int32 [n_experts], exclusive prefix sum of

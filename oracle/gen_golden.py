@@ -229,6 +229,45 @@ def gen_moe_layer_normal_noise():
          dgate_input=gt.grad.numpy(), dwg=gate.wg.weight.grad.numpy(), laux_dgate_input=gl[0].numpy(), laux_dwg=gl[1].numpy())
 
 
+def gen_moe_layer_top2():
+    """A top-2 gate (`k: 2` in the model yaml's moe block - every shipped config has 1; extract_critical with top_k > 1,
+    tutel_fast_dispatch.py:176-217): the reference layer's own run with `top_k = 2`, plain and batch-prioritised locations."""
+    print("[G3k] moe_layer with a top-2 gate")
+    for tag, cfg, P, seed, bpr, cf in (("m256e8_bpr", synth.BUILDING, 768, 36, True, 1.0), ("m64e4_plain", synth.small_cfg(64, 4), 512, 37, False, 0.75)):
+        sd = synth.make_weights(seed, cfg)
+        nerf, h = build_reference_model(cfg, sd, bpr=bpr, capacity_factor=cf)
+        moe = nerf.layers["0"]
+        gate = moe.gates[0]
+        gate.top_k = 2
+        E = cfg["num_experts"]
+        rng = np.random.default_rng(seed + 1000)
+        x = rng.standard_normal((P, cfg["model_dim"])).astype(np.float32)
+        gi = rng.standard_normal((P, cfg["gate_hidden"])).astype(np.float32)
+        xt = torch.from_numpy(x).requires_grad_(True)
+        gt = torch.from_numpy(gi).requires_grad_(True)
+        y = moe(xt, gate_input=gt)
+        topk = y.gate_extras["gates"]
+        assert topk.shape == (P, 2)
+        gates = torch.softmax(gt.detach() @ gate.wg.weight.detach().float().t(), dim=1)
+        crit, _ = tfd.extract_critical(gates, 2, cf, True, bpr)
+        cap = crit[4]
+        loc = np.stack([l.numpy().astype(np.int32) for l in crit[2]])
+        assert (loc >= cap).any(), "the fixture must drop some (token, choice) pairs"
+        dy = rng.standard_normal(y.shape).astype(np.float32)
+        (y * torch.from_numpy(dy)).sum().backward(retain_graph=True)
+        grads = {n: p.grad.clone() for n, p in moe.named_parameters()}
+        gx, gg = xt.grad.clone(), gt.grad.clone()
+        gl = torch.autograd.grad(y.l_aux, [gt] + list(moe.gates.parameters()), allow_unused=True)
+        out = dict(seed=seed, P=P, bpr=bpr, cf=cf, capacity=cap, y=y.detach().numpy(), l_aux=y.l_aux.detach().numpy(),
+                   topk=topk.numpy().astype(np.int32), loc=loc, gnorm=np.stack([g.numpy() for g in crit[3]]),
+                   dx=gx.numpy(), dgate_input=gg.numpy(), laux_dgate_input=gl[0].numpy(), laux_dwg=gl[1].numpy())
+        for n, g_ in grads.items():
+            out["grad__" + n] = g_.numpy() if g_.numel() <= 4096 else synth.checksum(g_.numpy())
+            if g_.numel() > 4096:
+                out["gslice__" + n] = g_.numpy().reshape(-1)[:: max(1, g_.numel() // 997)][:997]
+        save(f"moe_layer_top2_{tag}", **out)
+
+
 # ------------------------------------------------------------------------------------------ G4 model fwd
 def gen_model_forward():
     print("[G4] NeRFMoE.forward building shapes, P=4096")
@@ -637,7 +676,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    todo = dict(routing=gen_routing, pe=gen_pe, moe=gen_moe_layer, moe_noise=gen_moe_layer_noise, moe_normal_noise=gen_moe_layer_normal_noise, model=gen_model_forward, nobatch=gen_model_forward_nobatch, dispatch_nobatch=gen_dispatch_nobatch,
+    todo = dict(routing=gen_routing, pe=gen_pe, moe=gen_moe_layer, moe_noise=gen_moe_layer_noise, moe_normal_noise=gen_moe_layer_normal_noise, moe_top2=gen_moe_layer_top2, model=gen_model_forward, nobatch=gen_model_forward_nobatch, dispatch_nobatch=gen_dispatch_nobatch,
                 render=gen_render, autocast=gen_render_autocast, capacity=gen_render_capacity, fine=gen_render_fine, mip=gen_mip, ckpt=gen_checkpoint_layout, dense=gen_dense, composite=gen_composite, bg=gen_bg)
     for k, fn in todo.items():
         if a.only and k not in a.only.split(","):

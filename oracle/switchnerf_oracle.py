@@ -170,6 +170,52 @@ def route_top1(gates: np.ndarray, capacity_factor: float, batch_prioritized: boo
     return dict(idx=idx, loc=loc, gate=gmax.astype(np.float32), capacity=cap, counts=counts.astype(np.int32), top2_gap=gap)
 
 
+def route_topk(gates: np.ndarray, top_k: int, capacity_factor: float, batch_prioritized: bool):
+    """extract_critical, tutel_fast_dispatch.py:176-217, for top_k >= 1: choice j of every token = its j-th largest gate (torch.topk,
+    :177); locations of choice j = the rank among the tokens whose choice j is the same expert - token order, or stable descending order
+    of the TOKEN's max gate (:187: the same importance for every choice) - plus acc_base = the number of tokens earlier choices sent to
+    that expert (:199-201); capacity = top_k * int(cf * ceil(P / E)) (:211).
+    Returns dict(idx int32 [k, P], loc int32 [k, P], capacity, counts int32 [k, E])."""
+    gates = np.ascontiguousarray(gates, dtype=np.float32)
+    P, E = gates.shape
+    topk = np.argsort(-gates, axis=1, kind="stable")[:, :top_k]          # descending, lower expert first on exact ties
+    gmax = gates.max(axis=1)
+    order = np.argsort(-gmax, kind="stable") if batch_prioritized else np.arange(P)
+    idx = np.ascontiguousarray(topk.T).astype(np.int32)
+    loc = np.empty((top_k, P), np.int32)
+    counts = np.zeros((top_k, E), np.int64)
+    base = np.zeros(E, np.int64)
+    for j in range(top_k):
+        ij = idx[j][order]
+        for e in range(E):
+            sel = order[ij == e]
+            loc[j, sel] = base[e] + np.arange(sel.shape[0], dtype=np.int64)
+            counts[j, e] = sel.shape[0]
+        base = base + counts[j]
+    return dict(idx=idx, loc=loc, capacity=capacity_of(P, E, capacity_factor, top_k), counts=counts.astype(np.int32))
+
+
+def moe_layer_topk(h: torch.Tensor, gate_input: torch.Tensor, wg: torch.Tensor, weights, biases, skips, top_k: int,
+                   capacity_factor: float, batch_prioritized: bool):
+    """TopKGate.apply_on_expert_fn (tutel_moe_layer_nobatch.py:98-235) with k > 1, fp32 gate, postscore: gates normalised by the sum of the
+    token's k gates (tutel_fast_dispatch.py:204-206), dispatch / combine summed over the choices (:26-27, :59-62), l_aux from the first
+    choice's mask (:184).  Returns (y, l_aux, routing dict, gates)."""
+    E = wg.shape[0]
+    gates = torch.softmax(gate_input.float() @ wg.float().t(), dim=1)
+    r = route_topk(gates.detach().numpy(), top_k, capacity_factor, batch_prioritized)
+    cap = int(r["capacity"])
+    idx = [torch.from_numpy(r["idx"][j].astype(np.int64)) for j in range(top_k)]
+    loc = [torch.from_numpy(r["loc"][j].astype(np.int64)) for j in range(top_k)]
+    gs = [gates.gather(1, i.unsqueeze(1)).squeeze(1) for i in idx]
+    denom = torch.clamp(sum(gs), min=torch.finfo(gs[0].dtype).eps)
+    gs = [g / denom for g in gs]
+    l_aux = load_balance_loss(gates, idx[0])
+    d = sum(dispatch(h, idx[j], loc[j], E, cap) for j in range(top_k)).view(E, cap, -1)
+    o = expert_mlp(d, weights, biases, skips).reshape(E * cap, -1)
+    y = sum(combine(o, idx[j], loc[j], gs[j], cap) for j in range(top_k))
+    return y, l_aux, r, gates
+
+
 def load_balance_loss(gates: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     """load_balance fp32 branch, tutel_fast_dispatch.py:141-145: sum_e(me*ce) * E / P^2."""
     P, E = gates.shape

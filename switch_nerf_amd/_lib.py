@@ -74,6 +74,12 @@ SIGNATURES = {
     "swn_gate_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
     "swn_gate_fwd_noise": [vp, i32, vp, vp, vp, vp, f32, i32, i32, i32, vp, vp, vp, vp, vp],
     "swn_gate_bwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp],
+    "swn_gate_bwd_dense": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp],
+    "swn_topk_select": [vp, i32, i32, i32, vp, vp, vp, vp],
+    "swn_route_topk": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp],
+    "swn_topk_gate_bwd": [vp, vp, vp, i32, i32, i32, vp, vp],
+    "swn_dispatch_fwd_more": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "swn_dispatch_bwd_data_more": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "swn_route_top1": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp],
     "swn_route_top1x": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, sz, vp],
     "swn_dispatch_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],

@@ -350,7 +350,8 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ g, 
                                                        const int32_t* __restrict__ counts, const float* __restrict__ laux_coef,
                                                        int seg_tokens, int P, int E, T* __restrict__ dg,
                                                        float* __restrict__ dlogits, float* __restrict__ d_ln_w,
-                                                       float* __restrict__ d_ln_b) {
+                                                       float* __restrict__ d_ln_b, const float* __restrict__ d_probs) {
+  // d_probs [P, E] (may be NULL): a dense gradient w.r.t. the probabilities, added to the top-1 / l_aux terms (top-k gates)
   // (TB rows per 16-lane group and pass: see gate_fwd_kernel)
   using R = Row16<T, G>;
   constexpr int VPL = R::VPL;
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ g, 
 #pragma unroll
       for (int e = 0; e < EMAX; ++e) {
         pr[e] = (e < E) ? gates[tok * E + e] : 0.f;
-        dp[e] = (e < E) ? coef * (float)counts[seg * E + e] + ((e == my) ? dgm : 0.f) : 0.f;
+        dp[e] = (e < E) ? coef * (float)counts[seg * E + e] + ((e == my) ? dgm : 0.f) + (d_probs ? d_probs[tok * E + e] : 0.f) : 0.f;
         dot += pr[e] * dp[e];
       }
 #pragma unroll
@@ -549,7 +550,7 @@ __global__ void gate_dwg_finalize_kernel(const float* __restrict__ msum, int E, 
 
 // ------------------------------------------------------------------------------------------------ dispatch / combine
 // Tutel batched sparse kernels: row(i) = seg(i)*E*C + idx[i]*C + loc[i], dropped iff loc >= C or idx < 0.
-template <typename T, int MODE>  // MODE 0: D[row] = g*x   1: out[i] = g*D[row] (+relu)   2: dgate[i] = <D[row], x[i]>
+template <typename T, int MODE>  // MODE 0: D[row] = g*x   1: out[i] = g*D[row] (+relu)   2: dgate[i] = <D[row], x[i]>   3: out[i] += g*D[row]
 // begin != NULL: the no-batch layout (tutel_sparse_nobatch.py:24-133): row(i) = begin[seg(i) * E + idx[i]] + loc[i], rows packed
 // contiguously per expert, NO capacity test (dropped iff idx < 0).
 __global__ __launch_bounds__(256) void sparse_kernel(const float* __restrict__ gates, const int32_t* __restrict__ idx,
@@ -594,7 +595,12 @@ __global__ __launch_bounds__(256) void sparse_kernel(const float* __restrict__ g
         }
       } else {
         T* o = tok_buf + i * hidden + ch * EPC;
-        if (!keep) {
+        if (MODE == 3) {        // a further choice of a top-k routing: added to what the choices before it left (fp32 add, one rounding)
+          if (!keep) continue;
+          const T* s = disp + row * hidden + ch * EPC;
+#pragma unroll
+          for (int j = 0; j < EPC; ++j) ElemIO<T>::st(o + j, ElemIO<T>::ld(o + j) + gt * ElemIO<T>::ld(s + j));
+        } else if (!keep) {
           *(uint4*)o = make_uint4(0, 0, 0, 0);
         } else {
           const T* s = disp + row * hidden + ch * EPC;
@@ -1243,10 +1249,11 @@ extern "C" size_t swn_gate_bwd_scratch_floats(int n_tokens, int gate_dim, int n_
   return (size_t)n_tokens * n_experts + (blocks + 1) * ps;
 }
 
-extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg,
-                            const float* gates, const int32_t* idx, const float* d_gmax, const float* stats,
-                            const int32_t* counts, const float* laux_coef, int seg_tokens, int n_tokens, int gate_dim,
-                            int n_experts, void* dg, float* dlogits, float* d_wg, float* d_ln_w, float* d_ln_b, void* stream) {
+static int gate_bwd_impl(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg,
+                         const float* gates, const int32_t* idx, const float* d_gmax, const float* stats,
+                         const int32_t* counts, const float* laux_coef, int seg_tokens, int n_tokens, int gate_dim,
+                         int n_experts, void* dg, float* dlogits, float* d_wg, float* d_ln_w, float* d_ln_b, void* stream,
+                         const float* d_probs) {
   SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_gate_bwd: bad dtype");
   SWN_CHECK(g && wg && gates && idx && dg && d_wg && counts && dlogits, "swn_gate_bwd: null pointer");
   SWN_CHECK(n_experts >= 1 && n_experts <= 16 && seg_tokens > 0, "swn_gate_bwd: bad sizes");
@@ -1260,7 +1267,8 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
   float* dwg_partial = dlogits + (size_t)n_tokens * n_experts;          // second part of the scratch: [dwg_blocks][E * G + E]
   const int ps = n_experts * gate_dim + n_experts;
   float* msum = dwg_partial + (size_t)dwg_blocks * ps;                  // third part: [E * G + E]
-  static const bool valu_only = getenv("SWN_GATE_VALU") != nullptr;
+  static const bool valu_env = getenv("SWN_GATE_VALU") != nullptr;
+  const bool valu_only = valu_env || d_probs != nullptr;       // (the dense operand exists in the VALU kernel only: top-k layers)
   const bool mfma_path = dtype == SWN_HALF && gate_dim == 256 && n_experts <= 8 && !valu_only;
   if (dtype == SWN_HALF) {
     const bf16_t* gp = (const bf16_t*)g;
@@ -1281,7 +1289,7 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
       if (rc) return rc;
     } else
     GATE_DISPATCH_TB(bf16_t, gate_bwd_kernel, 1, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, gates, idx, d_gmax,
-                  stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dgp, dlogits, d_ln_w, d_ln_b);
+                  stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dgp, dlogits, d_ln_w, d_ln_b, d_probs);
     if (!mfma_path && !(gate_dim == 512 && !valu_only)) {
       SWN_CHECK(n_experts == 4 || n_experts == 8 || n_experts == 16, "swn_gate_bwd: experts must be 4, 8 or 16");
       DWG_DISPATCH(bf16_t, gp);
@@ -1290,7 +1298,7 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
     const float* gp = (const float*)g;
     float* dgp = (float*)dg;
     GATE_DISPATCH_TB(float, gate_bwd_kernel, 1, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, gates, idx, d_gmax,
-                  stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dgp, dlogits, d_ln_w, d_ln_b);
+                  stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dgp, dlogits, d_ln_w, d_ln_b, d_probs);
     SWN_CHECK(n_experts == 4 || n_experts == 8 || n_experts == 16, "swn_gate_bwd: experts must be 4, 8 or 16");
     DWG_DISPATCH(float, gp);
   }
@@ -1302,6 +1310,24 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
   }
   SWN_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg,
+                            const float* gates, const int32_t* idx, const float* d_gmax, const float* stats,
+                            const int32_t* counts, const float* laux_coef, int seg_tokens, int n_tokens, int gate_dim,
+                            int n_experts, void* dg, float* dlogits, float* d_wg, float* d_ln_w, float* d_ln_b, void* stream) {
+  return gate_bwd_impl(g, dtype, ln_w, ln_b, wg, gates, idx, d_gmax, stats, counts, laux_coef, seg_tokens, n_tokens, gate_dim, n_experts, dg,
+                       dlogits, d_wg, d_ln_w, d_ln_b, stream, nullptr);
+}
+// ... with a dense gradient d_probs [n_tokens, n_experts] w.r.t. the softmax probabilities on top (the normalised gates of a top-k layer,
+// swn_topk_gate_bwd); d_gmax may be NULL then
+extern "C" int swn_gate_bwd_dense(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg,
+                                  const float* gates, const int32_t* idx, const float* d_gmax, const float* d_probs, const float* stats,
+                                  const int32_t* counts, const float* laux_coef, int seg_tokens, int n_tokens, int gate_dim,
+                                  int n_experts, void* dg, float* dlogits, float* d_wg, float* d_ln_w, float* d_ln_b, void* stream) {
+  SWN_CHECK(d_probs, "swn_gate_bwd_dense: d_probs is NULL (swn_gate_bwd is the entry point without it)");
+  return gate_bwd_impl(g, dtype, ln_w, ln_b, wg, gates, idx, d_gmax, stats, counts, laux_coef, seg_tokens, n_tokens, gate_dim, n_experts, dg,
+                       dlogits, d_wg, d_ln_w, d_ln_b, stream, d_probs);
 }
 
 template <int MODE>
@@ -1337,6 +1363,21 @@ extern "C" int swn_dispatch_bwd_data(const float* gates, const int32_t* indices,
                                      void* grad_reshaped_input, const void* dispatched, int dtype, int samples,
                                      int hidden, int capacity, void* stream) {
   return launch_sparse<1>(gates, indices, locations, grad_reshaped_input, (void*)dispatched, nullptr, dtype, samples,
+                          hidden, capacity, samples, 1 << 20, 0, stream);
+}
+// top-k (k > 1): the second and later iterations of the reference's `for g, i, l in zip(gates, indices, locations)` loops
+// (tutel_fast_dispatch.py:26-27 / :69-70: further rows of the SAME dispatched buffer - no zero fill; :34-37 / :59-62: `last_result + ...`)
+extern "C" int swn_dispatch_fwd_more(const float* gates, const int32_t* indices, const int32_t* locations,
+                                     const void* reshaped_input, void* dispatched, int dtype, int samples, int hidden,
+                                     int capacity, int n_experts, void* stream) {
+  SWN_CHECK(dispatched, "swn_dispatch_fwd_more: null");
+  return launch_sparse<0>(gates, indices, locations, (void*)reshaped_input, dispatched, nullptr, dtype, samples, hidden,
+                          capacity, samples, n_experts, 0, stream);
+}
+extern "C" int swn_dispatch_bwd_data_more(const float* gates, const int32_t* indices, const int32_t* locations,
+                                          void* grad_reshaped_input, const void* dispatched, int dtype, int samples,
+                                          int hidden, int capacity, void* stream) {
+  return launch_sparse<3>(gates, indices, locations, grad_reshaped_input, (void*)dispatched, nullptr, dtype, samples,
                           hidden, capacity, samples, 1 << 20, 0, stream);
 }
 extern "C" int swn_dispatch_bwd_gate(float* grad_gates, const int32_t* indices, const int32_t* locations,

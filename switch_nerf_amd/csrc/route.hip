@@ -207,9 +207,12 @@ static void route_pass(const uint32_t* ki, const int32_t* vi, uint32_t* ko, int3
   hipLaunchKernelGGL((route_scatter_kernel<BITS>), dim3(nblk, n_seg), dim3(256), 0, s, ki, vi, seg_tokens, shift, nblk, hist, ko, vo);
 }
 
+// prev / n_prev (top-k routing, choice k = n_prev > 0): the counts [n_prev][n_seg * E] of the choices before this one - their sum per
+// (segment, expert) is the `acc_base` that tutel_fast_dispatch.py:199-201 adds to the locations of choice k
 __global__ void route_finalize_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ vals,
                                       const int32_t* __restrict__ counts, int n_tokens, int seg_tokens, int E, int capacity,
-                                      int32_t* __restrict__ loc, int32_t* __restrict__ perm, int32_t* __restrict__ tok2row) {
+                                      int32_t* __restrict__ loc, int32_t* __restrict__ perm, int32_t* __restrict__ tok2row,
+                                      const int32_t* __restrict__ prev, int n_prev) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_tokens) return;
   const int seg = (int)(i / seg_tokens);
@@ -217,7 +220,11 @@ __global__ void route_finalize_kernel(const uint32_t* __restrict__ keys, const i
   const int e = (int)(keys[i] >> 26);
   int start = 0;
   for (int q = 0; q < e; ++q) start += counts[seg * E + q];
-  const int l = pos - start;
+  int l = pos - start;
+  if (n_prev > 0) {
+    const long groups = (long)(n_tokens / seg_tokens) * E;
+    for (int j = 0; j < n_prev; ++j) l += prev[j * groups + seg * E + e];
+  }
   const long tok = (long)seg * seg_tokens + vals[i];
   loc[tok] = l;
   const long row = ((long)seg * E + e) * capacity + l;
@@ -361,9 +368,12 @@ extern "C" int swn_route_top1x(const int32_t* idx, const float* gmax, const floa
   return rc;
 }
 
-extern "C" int swn_route_top1(const int32_t* idx, const float* gmax, const float* gates, int n_tokens, int seg_tokens,
-                              int n_experts, int capacity, int bpr, int32_t* loc, int32_t* counts, int32_t* perm,
-                              int32_t* tok2row, float* l_aux, void* workspace, size_t workspace_bytes, void* stream) {
+// One choice of the (top-k) routing: choice 0 is swn_route_top1 itself; choice n_prev > 0 ranks its tokens the same way and starts
+// each expert's locations behind the rows of the choices before it (prev: their counts), in the SAME perm (filled by choice 0).
+static int route_choice(const int32_t* idx, const float* gmax, const float* gates, int n_tokens, int seg_tokens,
+                        int n_experts, int capacity, int bpr, int32_t* loc, int32_t* counts, int32_t* perm,
+                        int32_t* tok2row, float* l_aux, void* workspace, size_t workspace_bytes, void* stream,
+                        const int32_t* prev, int n_prev) {
   SWN_CHECK(idx && gmax && loc && counts && workspace, "swn_route_top1: null pointer");
   SWN_CHECK(n_tokens > 0 && seg_tokens > 0 && n_tokens % seg_tokens == 0,
             "swn_route_top1: n_tokens (%d) must be a positive multiple of seg_tokens (%d)", n_tokens, seg_tokens);
@@ -387,7 +397,7 @@ extern "C" int swn_route_top1(const int32_t* idx, const float* gmax, const float
   hipError_t e = use_memset ? hipMemsetAsync(counts, 0, (size_t)n_seg * n_experts * 4, s)
                             : fill_u32_async(counts, 0u, (size_t)n_seg * n_experts * 4, s);
   SWN_CHECK(e == hipSuccess, "fill: %s", hipGetErrorString(e));
-  if (perm) {
+  if (perm && n_prev == 0) {
     e = use_memset ? hipMemsetAsync(perm, 0xFF, (size_t)n_seg * n_experts * capacity * 4, s)
                    : fill_u32_async(perm, 0xFFFFFFFFu, (size_t)n_seg * n_experts * capacity * 4, s);
     SWN_CHECK(e == hipSuccess, "fill: %s", hipGetErrorString(e));
@@ -411,13 +421,114 @@ extern "C" int swn_route_top1(const int32_t* idx, const float* gmax, const float
     int32_t* tv = vi; vi = vo; vo = tv;
   }
   hipLaunchKernelGGL(route_finalize_kernel, dim3(cdiv(n_tokens, 256)), dim3(256), 0, s, ki, vi, counts, n_tokens,
-                     seg_tokens, n_experts, capacity, loc, perm, tok2row);
+                     seg_tokens, n_experts, capacity, loc, perm, tok2row, prev, n_prev);
   SWN_LAUNCH_CHECK();
   if (gates && l_aux) {
     hipLaunchKernelGGL(laux_partial_kernel, dim3(nblk, n_seg), dim3(256), 0, s, gates, seg_tokens, n_experts, nblk, partial);
     hipLaunchKernelGGL(laux_final_kernel, dim3(n_seg), dim3(256), 0, s, partial, counts, seg_tokens, n_experts, nblk, l_aux);
     SWN_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+extern "C" int swn_route_top1(const int32_t* idx, const float* gmax, const float* gates, int n_tokens, int seg_tokens,
+                              int n_experts, int capacity, int bpr, int32_t* loc, int32_t* counts, int32_t* perm,
+                              int32_t* tok2row, float* l_aux, void* workspace, size_t workspace_bytes, void* stream) {
+  return route_choice(idx, gmax, gates, n_tokens, seg_tokens, n_experts, capacity, bpr, loc, counts, perm, tok2row, l_aux, workspace,
+                      workspace_bytes, stream, nullptr, 0);
+}
+
+// ---- top-k (k > 1) ------------------------------------------------------------------------------------------------------------
+// torch.topk(gates, k) per token (descending, the lower expert on exact ties), the selected gates and their normalised form
+// g_j / max(sum_j g_j, eps) (tutel_fast_dispatch.py:177-182, 204-206).  One thread per token; E <= 64: the chosen experts are a bit mask.
+__global__ __launch_bounds__(256) void topk_select_kernel(const float* __restrict__ gates, int n_tokens, int E, int K,
+                                                          int32_t* __restrict__ idx, float* __restrict__ gsel, float* __restrict__ gnorm) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_tokens) return;
+  const float* g = gates + i * E;
+  unsigned long long taken = 0ull;
+  float sum = 0.f;
+  for (int k = 0; k < K; ++k) {
+    int best = -1;
+    float bv = 0.f;
+    for (int e = 0; e < E; ++e) {
+      if ((taken >> e) & 1ull) continue;
+      const float v = g[e];
+      if (best < 0 || v > bv) { best = e; bv = v; }
+    }
+    taken |= 1ull << best;
+    idx[(long)k * n_tokens + i] = best;
+    gsel[(long)k * n_tokens + i] = bv;
+    sum += bv;                                  // (sum(gates_s): first choice first, the reference's order)
+  }
+  const float denom = fmaxf(sum, 1.1920928955078125e-07f);      // torch.finfo(torch.float32).eps
+  for (int k = 0; k < K; ++k) gnorm[(long)k * n_tokens + i] = gsel[(long)k * n_tokens + i] / denom;
+}
+
+// backward of the normalisation: d_gnorm [K, P] -> d_probs [P, E] (zero outside the token's K experts).  gn_j = g_j / D, D = max(sum, eps):
+// dg_j = (d_gn_j - sum_m d_gn_m gn_m) / D above the clamp, d_gn_j / eps under it (torch.clamp passes no gradient there).
+__global__ __launch_bounds__(256) void topk_gate_bwd_kernel(const float* __restrict__ gates, const int32_t* __restrict__ idx,
+                                                            const float* __restrict__ d_gnorm, int n_tokens, int E, int K,
+                                                            float* __restrict__ d_probs) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_tokens) return;
+  for (int e = 0; e < E; ++e) d_probs[i * E + e] = 0.f;
+  float sum = 0.f;
+  for (int k = 0; k < K; ++k) sum += gates[i * E + idx[(long)k * n_tokens + i]];
+  const float eps = 1.1920928955078125e-07f;
+  const bool clamped = !(sum >= eps);
+  const float D = clamped ? eps : sum;
+  float s = 0.f;
+  if (!clamped)
+    for (int k = 0; k < K; ++k) s += d_gnorm[(long)k * n_tokens + i] * (gates[i * E + idx[(long)k * n_tokens + i]] / D);
+  for (int k = 0; k < K; ++k) d_probs[i * E + idx[(long)k * n_tokens + i]] = (d_gnorm[(long)k * n_tokens + i] - s) / D;
+}
+
+// valid rows of group g = all choices' tokens of its expert (the chains clamp them to the capacity)
+__global__ void route_group_rows_kernel(const int32_t* __restrict__ counts, int groups, int K, int32_t* __restrict__ group_rows) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= groups) return;
+  int s = 0;
+  for (int k = 0; k < K; ++k) s += counts[(long)k * groups + g];
+  group_rows[g] = s;
+}
+
+extern "C" int swn_topk_select(const float* gates, int n_tokens, int n_experts, int top_k, int32_t* idx, float* gsel, float* gnorm,
+                               void* stream) {
+  SWN_CHECK(gates && idx && gsel && gnorm, "swn_topk_select: null pointer");
+  SWN_CHECK(n_tokens > 0 && n_experts >= 1 && n_experts <= 64 && top_k >= 1 && top_k <= n_experts, "swn_topk_select: need 1 <= k <= E <= 64");
+  hipLaunchKernelGGL(topk_select_kernel, dim3(cdiv(n_tokens, 256)), dim3(256), 0, as_stream(stream), gates, n_tokens, n_experts, top_k, idx,
+                     gsel, gnorm);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int swn_topk_gate_bwd(const float* gates, const int32_t* idx, const float* d_gnorm, int n_tokens, int n_experts, int top_k,
+                                 float* d_probs, void* stream) {
+  SWN_CHECK(gates && idx && d_gnorm && d_probs, "swn_topk_gate_bwd: null pointer");
+  SWN_CHECK(n_tokens > 0 && n_experts >= 1 && n_experts <= 64 && top_k >= 2 && top_k <= n_experts, "swn_topk_gate_bwd: need 2 <= k <= E <= 64");
+  hipLaunchKernelGGL(topk_gate_bwd_kernel, dim3(cdiv(n_tokens, 256)), dim3(256), 0, as_stream(stream), gates, idx, d_gnorm, n_tokens,
+                     n_experts, top_k, d_probs);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int swn_route_topk(const int32_t* idx, const float* gmax, const float* gates, int n_tokens, int seg_tokens, int n_experts,
+                              int capacity, int bpr, int top_k, int32_t* loc, int32_t* counts, int32_t* perm, int32_t* tok2row,
+                              int32_t* group_rows, float* l_aux, void* workspace, size_t workspace_bytes, void* stream) {
+  SWN_CHECK(top_k >= 1 && top_k <= n_experts, "swn_route_topk: need 1 <= k <= E");
+  SWN_CHECK(idx && loc && counts && group_rows, "swn_route_topk: null pointer");
+  SWN_CHECK(n_tokens > 0 && seg_tokens > 0 && n_tokens % seg_tokens == 0, "swn_route_topk: n_tokens must be a multiple of seg_tokens");
+  const long groups = (long)(n_tokens / seg_tokens) * n_experts;
+  for (int k = 0; k < top_k; ++k) {
+    const int rc = route_choice(idx + (long)k * n_tokens, gmax, k == 0 ? gates : nullptr, n_tokens, seg_tokens, n_experts, capacity, bpr,
+                                loc + (long)k * n_tokens, counts + k * groups, perm, tok2row ? tok2row + (long)k * n_tokens : nullptr,
+                                k == 0 ? l_aux : nullptr, workspace, workspace_bytes, stream, counts, k);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(route_group_rows_kernel, dim3(cdiv(groups, 256)), dim3(256), 0, as_stream(stream), counts, (int)groups, top_k,
+                     group_rows);
+  SWN_LAUNCH_CHECK();
   return 0;
 }
 

@@ -7,7 +7,7 @@
 
 Mirrors `moe_layer` / `MOELayer` of /root/reference/switch_nerf/modules/tutel_moe_ext/tutel_moe_layer_nobatch.py (ctor
 :443-460, forward :733-797, TopKGate.apply_on_expert_fn :98-235, ExpertMLP :836-924) for the configuration the reference's
-NeRFMoE builds (models/nerf_moe.py:278-292): top-1 gate with fp32 router (optionally with gate noise in training), post-score dispatch (the gate value is applied on
+NeRFMoE builds (models/nerf_moe.py:278-292): top-k gate (k = 1 in every shipped config; k > 1: _MoETopKFunction) with fp32 router (optionally with gate noise in training), post-score dispatch (the gate value is applied on
 the way back), capacity `int(cf * ceil(P / E))` with optional batch-prioritised ranking, `expertmlp` experts with the
 residual skip, one routing problem per call (the P tokens of the call), no expert parallelism (`parallel.ExpertParallel`
 covers that inside SwitchNeRF).  Parameter names equal the reference's (`gates.0.wg.weight`, `experts.0.weights.{l}`
@@ -129,17 +129,112 @@ class _MoEFunction(torch.autograd.Function):
         return (None, dx.to(ctx.x_dtype), dg.to(ctx.g_dtype), d_wg, None, *dws, *[b.view(E, 1, M) for b in dbs])
 
 
+class _MoETopKFunction(torch.autograd.Function):
+    """The layer with a top-k gate, k > 1 (extract_critical with top_k > 1, tutel_fast_dispatch.py:176-217; GatingEncoder / GatingDecoder
+    looping over the choices, :17-78): every (token, choice) owns one row of the [E, capacity] row space (capacity = k * int(cf *
+    ceil(P / E))), the choices' gates are normalised by their sum, l_aux comes from the first choice's mask.  Same kernels as the
+    top-1 layer - the expert chains gather their rows through ONE permutation over all choices - plus swn_topk_select / swn_route_topk /
+    swn_topk_gate_bwd and the accumulating forms of the sparse kernels."""
+
+    @staticmethod
+    def forward(ctx, layer, x, gate_in, wg, gate_noise, *wb):
+        o, dt = ops, layer.dtype
+        L, E, M, K = layer.layer_num, layer.n_experts, layer.model_dim, layer.top_k
+        P = x.shape[0]
+        xs = x.detach().to(dt).contiguous()
+        gs = gate_in.detach().to(dt).contiguous()
+        wg32 = wg.detach().float().contiguous()
+        gates, _idx0, gmax, stats = o.gate_fwd(gs, None, None, wg32, noise=gate_noise, noise_scale=layer._noise_scale if gate_noise is not None else 0.0)
+        cap = K * int(layer.capacity_factor * ((P + E - 1) // E))                              # tutel_fast_dispatch.py:211
+        if layer.moe_no_batch:
+            cap = P                                                                            # (k distinct experts per token: <= P rows each)
+        idx, _gsel, gn = o.topk_select(gates, K)                                               # :177-182, 204-206
+        loc, counts, perm, _, group_rows, l_aux = o.route_topk(idx, gmax, gates, P, E, cap, layer.bpr)
+        need_grad = any(ctx.needs_input_grad[1:])
+        rows = E * cap
+        wf = [o.pack_weights(w.detach().float().contiguous(), dt, True) for w in wb[:L]]
+        bias = [b.detach().float().reshape(E, M).contiguous() for b in wb[L:]]
+        saves = [torch.empty(rows, M, dtype=dt, device=xs.device) for _ in range(L - 1)] if need_grad else [None] * (L - 1)
+        nw = o.chain_mask_words(dt, E, cap, M)
+        masks = [torch.empty(nw, dtype=torch.int32, device=xs.device) for _ in range(L - 1)] if need_grad else [None] * (L - 1)
+        layers = [o.Layer(wf[l], bias[l], relu=1 if l < L - 1 else 0, skip=(l in layer.skips), save=saves[l] if l < L - 1 else None,
+                          mask=masks[l] if l < L - 1 else None) for l in range(L)]
+        eo = torch.empty(rows, M, dtype=dt, device=xs.device)
+        geom = 7 if (M == 256 and dt != torch.float32 and cap >= 256) else 1
+        o.mlp_chain(xs, layers, eo, n_groups=E, n_wsets=E, group_stride=cap, group_rows=group_rows, group_rows_clamp=cap,
+                    x_gather=perm.view(-1), tag=1, geometry=geom)
+        y = o.combine_fwd(gn[0], idx[0], loc[0], eo, cap, P, E, False)                         # decode, first choice (:59-62)
+        for j in range(1, K):
+            o.dispatch_bwd_data_more(gn[j], idx[j], loc[j], y, eo, cap)                        # ... `last_result + single_output`
+        ctx.layer, ctx.cap, ctx.x_dtype, ctx.g_dtype = layer, cap, x.dtype, gate_in.dtype
+        ctx.save_for_backward(xs, gs, wg32, gates, idx, gn, stats, loc, counts, perm, group_rows, eo, *wb[:L],
+                              *[s for s in saves if s is not None], *[m for m in masks if m is not None])
+        ctx.mark_non_differentiable(idx)
+        return y.to(x.dtype), l_aux.reshape(()), idx
+
+    @staticmethod
+    def backward(ctx, dy, d_laux, _d_idx):
+        o, layer = ops, ctx.layer
+        dt, L, E, M, K, cap = layer.dtype, layer.layer_num, layer.n_experts, layer.model_dim, layer.top_k, ctx.cap
+        sv = ctx.saved_tensors
+        xs, gs, wg32, gates, idx, gn, stats, loc, counts, perm, group_rows, eo = sv[:12]
+        ws = sv[12:12 + L]
+        saves = list(sv[12 + L:12 + L + (L - 1)])
+        masks = list(sv[12 + L + (L - 1):])
+        P = xs.shape[0]
+        dev = xs.device
+        dy = dy.to(dt).contiguous()
+        if d_laux is None:
+            d_laux = torch.zeros((), device=dev)
+        # decode backward per choice (tutel_fast_dispatch.py:66-78): dL/d gate_j = <row_j, dy>, dL/d row_j = gate_j * dy
+        dgn = torch.stack([o.dispatch_bwd_gate(idx[j], loc[j], dy, eo, cap) for j in range(K)])
+        dout = o.dispatch_fwd(gn[0], idx[0], loc[0], dy, E, cap)
+        for j in range(1, K):
+            o.dispatch_fwd_more(gn[j], idx[j], loc[j], dy, dout, E, cap)
+        wbk = [o.pack_weights(w.detach().float().contiguous(), dt, False) for w in ws]
+        dz = [torch.empty(E * cap, M, dtype=dt, device=dev) for _ in range(L - 1)]
+        dxr = torch.empty(E * cap, M, dtype=dt, device=dev)
+        skip_l = layer.skips[0] if layer.skips else None
+        bl = [o.Layer(wbk[l], None, relu=2 if l > 0 else 0, mask=masks[l - 1] if l > 0 else None, save=dz[l - 1] if l > 0 else None)
+              for l in range(L - 1, -1, -1)]
+        o.mlp_chain(dout, bl, dxr, n_groups=E, n_wsets=E, group_stride=cap, group_rows=group_rows, group_rows_clamp=cap,
+                    y_add=dz[skip_l] if skip_l is not None else None, tag=2,
+                    geometry=7 if (M == 256 and dt != torch.float32 and cap >= 256) else 1)
+        dx = o.dispatch_bwd_data(None, idx[0], loc[0], dxr, cap)                               # encode backward (:34-37), summed over the choices
+        for j in range(1, K):
+            o.dispatch_bwd_data_more(None, idx[j], loc[j], dx, dxr, cap)
+        dws = [torch.zeros(E, M, M, dtype=torch.float32, device=dev) for _ in range(L)]
+        dbs = [torch.zeros(E, M, dtype=torch.float32, device=dev) for _ in range(L)]
+        pv = perm.view(-1)
+        items = [(xs if l == 0 else saves[l - 1], dout if l == L - 1 else dz[l], dws[l], dbs[l], pv if l == 0 else None, None)
+                 for l in range(L)]
+        for i0 in range(0, L, 8):
+            o.wgrad_batched(items[i0:i0 + 8], n_groups=E, n_wsets=E, group_stride=cap, group_rows=group_rows, group_rows_clamp=cap,
+                            n_splits=max(1, min(256 // E, cap // 2048)), tag=1)
+        # gate backward: the normalisation (:204-206), the softmax / fp32 router, the load-balance term of the FIRST choice's mask (:184)
+        d_probs = o.topk_gate_bwd(gates, idx, dgn)
+        d_wg = torch.zeros_like(wg32)
+        coef = (d_laux.reshape(1).float() * (E / float(P * P))).contiguous()
+        dg = o.gate_bwd_dense(gs, None, None, wg32, gates, idx[0].contiguous(), None, d_probs, stats, counts[0].contiguous(), coef, P, d_wg,
+                              None, None)
+        return (None, dx.to(ctx.x_dtype), dg.to(ctx.g_dtype), d_wg, None, *dws, *[b.view(E, 1, M) for b in dbs])
+
+
 class MoELayer(nn.Module):
     def __init__(self, gate_type: dict, model_dim: int, experts: dict, scan_expert_func=None, result_func=None, group=None,
                  seeds=None, a2a_ffn_overlap_degree=1, parallel_type="auto", pad_samples=False, moe_no_batch=False,
                  return_gates=False, return_gate_logits=False, dtype=torch.bfloat16):
         super().__init__()
-        if gate_type.get("type", "top") != "top" or int(gate_type.get("k", 1)) != 1:
-            raise NotImplementedError("top-1 gate only (the configuration the reference's NeRFMoE builds)")
+        if gate_type.get("type", "top") != "top":
+            raise NotImplementedError("gate type 'top' only (the one the reference's NeRFMoE builds)")
+        self.top_k = int(gate_type.get("k", 1))                      # `k` of the model yaml's moe block (every shipped config: 1)
+        assert self.top_k > 0, "Top-k value %d is not valid." % self.top_k                     # tutel_moe_layer_nobatch.py:59
         if experts.get("type", "expertmlp") != "expertmlp":
             raise NotImplementedError("expertmlp experts only (seqexperts checkpoints: checkpoint.to_expertmlp)")
         self.model_dim = int(model_dim)
         self.n_experts = int(experts["count_per_node"])
+        if self.top_k > self.n_experts:
+            raise ValueError("top-k gate: k = %d exceeds the %d experts" % (self.top_k, self.n_experts))
         self.layer_num = int(experts["layer_num"])
         self.skips = [int(s) for s in (experts.get("skips") or [])]
         assert int(experts.get("hidden_size_per_expert", model_dim)) == self.model_dim, "uniform-width expert MLP"
@@ -187,11 +282,12 @@ class MoELayer(nn.Module):
         elif self.training and self.gate_noise > 0:
             noise = draw(gate_noise_draw)
             self._noise_scale = self.gate_noise / E
-        y, l_aux, idx = _MoEFunction.apply(self, x, g, self.gates[0].wg.weight, noise, *ex.weights, *ex.bias)
+        fn = _MoEFunction if self.top_k == 1 else _MoETopKFunction
+        y, l_aux, idx = fn.apply(self, x, g, self.gates[0].wg.weight, noise, *ex.weights, *ex.bias)
         y = y.view(shape)
         y.l_aux = l_aux                                                                         # :792-796
-        if self.return_gates:
-            y.gate_extras = {"gates": idx.long().view(-1, 1)}
+        if self.return_gates:                                                                   # torch.topk(gates, k).indices, :229
+            y.gate_extras = {"gates": idx.long().view(-1, 1) if self.top_k == 1 else idx.long().t().contiguous()}
         return y
 
 

@@ -197,6 +197,61 @@ def gate_bwd(g, ln_w, ln_b, wg, gates, idx, d_gmax, stats, counts, laux_coef, se
     return dg
 
 
+def gate_bwd_dense(g, ln_w, ln_b, wg, gates, idx, d_gmax, d_probs, stats, counts, laux_coef, seg_tokens, d_wg, d_ln_w, d_ln_b):
+    """gate_bwd with a dense gradient d_probs [P, E] w.r.t. the probabilities on top (top-k layers; swn_gate_bwd_dense)."""
+    P, G = g.shape
+    E = wg.shape[0]
+    assert d_probs.shape == (P, E) and d_probs.dtype == torch.float32
+    dg = torch.empty_like(g)
+    dlogits = torch.empty(int(_lib.load().swn_gate_bwd_scratch_floats(P, G, E)), dtype=torch.float32, device=g.device)
+    call("swn_gate_bwd_dense", _p(g), _dt(g), _p(ln_w), _p(ln_b), _p(wg), _p(gates), _p(idx), _p(d_gmax), _p(d_probs.contiguous()), _p(stats),
+         _p(counts), _p(laux_coef), int(seg_tokens), P, G, E, _p(dg), _p(dlogits), _p(d_wg), _p(d_ln_w), _p(d_ln_b), _stream())
+    return dg
+
+
+def topk_select(gates, k: int):
+    """torch.topk(gates, k, dim=1) + the normalised gates of a top-k layer (tutel_fast_dispatch.py:177-182, 204-206)
+    -> (idx int32 [k, P], gsel fp32 [k, P], gnorm fp32 [k, P])."""
+    P, E = gates.shape
+    dev = gates.device
+    idx = torch.empty(k, P, dtype=torch.int32, device=dev)
+    gsel = torch.empty(k, P, dtype=torch.float32, device=dev)
+    gnorm = torch.empty(k, P, dtype=torch.float32, device=dev)
+    call("swn_topk_select", _p(gates), P, E, int(k), _p(idx), _p(gsel), _p(gnorm), _stream())
+    return idx, gsel, gnorm
+
+
+def topk_gate_bwd(gates, idx, d_gnorm):
+    """Backward of topk_select's normalisation: d_gnorm [k, P] -> d_probs [P, E]."""
+    P, E = gates.shape
+    k = idx.shape[0]
+    d_probs = torch.empty(P, E, dtype=torch.float32, device=gates.device)
+    call("swn_topk_gate_bwd", _p(gates), _p(idx), _p(d_gnorm.contiguous()), P, E, int(k), _p(d_probs), _stream())
+    return d_probs
+
+
+def route_topk(idx, gmax, gates, seg_tokens: int, n_experts: int, capacity: int, bpr: bool, want_tok2row=False):
+    """Capacity assignment of a top-k routing (swn_route_topk; idx [k, P] from topk_select, gmax [P] the tokens' top-1 gates)
+    -> (loc [k, P], counts [k, n_seg, E], perm [n_seg, E * capacity], tok2row [k, P] or None, group_rows [n_seg * E], l_aux [n_seg])."""
+    k, P = idx.shape
+    n_seg = P // seg_tokens
+    dev = idx.device
+    loc = torch.empty(k, P, dtype=torch.int32, device=dev)
+    counts = torch.empty(k, n_seg, n_experts, dtype=torch.int32, device=dev)
+    perm = torch.empty(n_seg, n_experts * capacity, dtype=torch.int32, device=dev)
+    tok2row = torch.empty(k, P, dtype=torch.int32, device=dev) if want_tok2row else None
+    group_rows = torch.empty(n_seg * n_experts, dtype=torch.int32, device=dev)
+    l_aux = torch.empty(n_seg, dtype=torch.float32, device=dev) if gates is not None else None
+    nbytes = _lib.load().swn_route_workspace_bytes(P, n_seg, n_experts)
+    key = (dev, nbytes)
+    ws = _route_ws.get(key)
+    if ws is None:
+        ws = _route_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    call("swn_route_topk", _p(idx), _p(gmax), _p(gates), P, int(seg_tokens), int(n_experts), int(capacity), int(bool(bpr)), int(k),
+         _p(loc), _p(counts), _p(perm), _p(tok2row), _p(group_rows), _p(l_aux), _p(ws), nbytes, _stream())
+    return loc, counts, perm, tok2row, group_rows, l_aux
+
+
 _route_ws = {}
 
 
@@ -279,6 +334,21 @@ def dispatch_bwd_data(gates, indices, locations, dispatched, capacity: int):
     H = dispatched.shape[1]
     out = torch.empty(S, H, dtype=dispatched.dtype, device=dispatched.device)
     call("swn_dispatch_bwd_data", _p(gates), _p(indices), _p(locations), _p(out), _p(dispatched), _dt(out), S, H, capacity, _stream())
+    return out
+
+
+def dispatch_fwd_more(gates, indices, locations, x, dispatched, n_experts: int, capacity: int):
+    """A further choice's rows into an existing dispatched buffer (top-k: tutel_fast_dispatch.py:26-27, later iterations)."""
+    S, H = x.shape
+    call("swn_dispatch_fwd_more", _p(gates), _p(indices), _p(locations), _p(x), _p(dispatched), _dt(x), S, H, capacity, n_experts, _stream())
+    return dispatched
+
+
+def dispatch_bwd_data_more(gates, indices, locations, out, dispatched, capacity: int):
+    """out[i] += g * dispatched[row] (top-k: `last_result + ...`, tutel_fast_dispatch.py:37, :62)."""
+    S = indices.shape[0]
+    H = dispatched.shape[1]
+    call("swn_dispatch_bwd_data_more", _p(gates), _p(indices), _p(locations), _p(out), _p(dispatched), _dt(out), S, H, capacity, _stream())
     return out
 
 

@@ -92,9 +92,11 @@ def test_moe_layer_bf16_shapes_no_batch_and_errors():
     assert (ynb.abs().sum(-1) == 0).float().mean().item() == 0.0      # eval path: nothing is dropped
     with pytest.raises(RuntimeError, match="HIP library only"):
         moe(x.cpu(), gate_input=gi.cpu())
+    from switch_nerf_amd.moe import moe_layer
     with pytest.raises(NotImplementedError):
-        from switch_nerf_amd.moe import moe_layer
-        moe_layer(gate_type=dict(type="top", k=2), model_dim=256, experts=dict(type="expertmlp", count_per_node=8, layer_num=7))
+        moe_layer(gate_type=dict(type="cosine_top", k=1), model_dim=256, experts=dict(type="expertmlp", count_per_node=8, layer_num=7))
+    with pytest.raises(ValueError, match="exceeds"):
+        moe_layer(gate_type=dict(type="top", k=9), model_dim=256, experts=dict(type="expertmlp", count_per_node=8, layer_num=7))
 
 
 def test_moe_layer_gate_noise_vs_reference_golden_fp32():
@@ -177,3 +179,126 @@ def test_moe_layer_normal_noise_vs_reference_golden_fp32():
     with torch.no_grad():
         ye = moe(xt, gate_input=gt)
     assert (ye.gate_extras["gates"].cpu().numpy().reshape(-1) != g["topk"].reshape(-1)).any()
+
+
+def _top2_layer(cfg, bpr, cf, dtype):
+    from switch_nerf_amd.moe import moe_layer
+    return moe_layer(gate_type=dict(type="top", k=2, fp32_gate=True, capacity_factor=cf, batch_prioritized_routing=bpr, gate_noise=-1.0,
+                                    gate_dim=cfg["gate_hidden"]), model_dim=cfg["model_dim"],
+                     experts=dict(type="expertmlp", count_per_node=cfg["num_experts"], hidden_size_per_expert=cfg["model_dim"],
+                                  layer_num=cfg["expert_layers"], skips=list(cfg["skips"])), seeds=(1, 1, 1), return_gates=True,
+                     dtype=dtype).cuda()
+
+
+def test_moe_layer_top2_vs_reference_golden_fp32():
+    """`k: 2` (extract_critical with top_k > 1, tutel_fast_dispatch.py:176-217; the encoder / decoder loops over the choices, :17-78)
+    against the REFERENCE layer's own run with top_k = 2: both choices' experts bit-exact, output, l_aux, input / gate-input / parameter
+    gradients and the gradients of l_aux alone; underneath, swn_topk_select / swn_route_topk give the reference's locations (acc_base,
+    batch-prioritised by the token's max gate) bit for bit and its normalised gates."""
+    from switch_nerf_amd import ops
+    g = np.load(os.path.join(G, "moe_layer_top2_m256e8_bpr.npz"))
+    cfg = synth.BUILDING
+    seed, P, bpr, cf, cap = int(g["seed"]), int(g["P"]), bool(g["bpr"]), float(g["cf"]), int(g["capacity"])
+    moe = _top2_layer(cfg, bpr, cf, torch.float32)
+    _load(moe, seed)
+    rng = np.random.default_rng(seed + 1000)
+    x = rng.standard_normal((P, 256)).astype(np.float32)
+    gi = rng.standard_normal((P, 256)).astype(np.float32)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    gt = torch.from_numpy(gi).cuda().requires_grad_(True)
+    # the routing kernels on their own
+    gates, idx0, gmax, _ = ops.gate_fwd(gt.detach(), None, None, moe.gates[0].wg.weight.detach().float().contiguous())
+    idx, gsel, gn = ops.topk_select(gates, 2)
+    np.testing.assert_array_equal(idx.cpu().numpy().T, g["topk"])
+    np.testing.assert_array_equal(idx[0].cpu().numpy(), idx0.cpu().numpy())
+    np.testing.assert_allclose(gn.cpu().numpy(), g["gnorm"], rtol=1e-5)
+    loc, counts, perm, tok2row, group_rows, l_aux = ops.route_topk(idx, gmax, gates, P, 8, cap, bpr, want_tok2row=True)
+    np.testing.assert_array_equal(loc.cpu().numpy(), g["loc"])                                   # bit-exact locations, both choices
+    np.testing.assert_array_equal(group_rows.cpu().numpy(), counts.sum(0).view(-1).cpu().numpy())
+    locn, idxn, permn, t2r = g["loc"], g["topk"].T, perm.cpu().numpy().reshape(-1), tok2row.cpu().numpy()
+    for j in range(2):                                                                           # every kept (token, choice) owns its row
+        kept = np.nonzero(locn[j] < cap)[0]
+        rows = idxn[j][kept] * cap + locn[j][kept]
+        np.testing.assert_array_equal(permn[rows], kept)
+        np.testing.assert_array_equal(t2r[j][kept], rows)
+        assert (t2r[j][locn[j] >= cap] == -1).all()
+    assert (permn >= 0).sum() == (locn < cap).sum()
+    # the layer
+    y = moe(xt, gate_input=gt)
+    np.testing.assert_array_equal(y.gate_extras["gates"].cpu().numpy(), g["topk"])
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["y"], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(y.l_aux.item(), float(g["l_aux"]), rtol=1e-6)
+    dy = rng.standard_normal((P, 256)).astype(np.float32)
+    (y * torch.from_numpy(dy).cuda()).sum().backward(retain_graph=True)
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), g["dx"], rtol=1e-3, atol=2e-4 * np.abs(g["dx"]).max())
+    np.testing.assert_allclose(gt.grad.cpu().numpy(), g["dgate_input"], rtol=1e-3, atol=2e-4 * np.abs(g["dgate_input"]).max())
+    for n, p in moe.named_parameters():
+        got = p.grad.cpu().numpy()
+        if "grad__" + n in g and g["grad__" + n].shape == got.shape:
+            ref = g["grad__" + n]
+            np.testing.assert_allclose(got, ref, rtol=1e-3, atol=5e-4 * np.abs(ref).max(), err_msg=n)
+        else:
+            ref_sum = g["grad__" + n]
+            scale = max(1e-12, float(ref_sum[1]))
+            assert abs(synth.checksum(got)[0] - ref_sum[0]) <= 1e-3 * scale, n
+            sl = got.reshape(-1)[:: max(1, got.size // 997)][:997]
+            ref = g["gslice__" + n]
+            np.testing.assert_allclose(sl, ref, rtol=2e-3, atol=5e-4 * np.abs(ref).max(), err_msg=n)
+    d_g, d_wg = torch.autograd.grad(y.l_aux, [gt, moe.gates[0].wg.weight])
+    np.testing.assert_allclose(d_g.cpu().numpy(), g["laux_dgate_input"], rtol=1e-3, atol=2e-4 * np.abs(g["laux_dgate_input"]).max())
+    np.testing.assert_allclose(d_wg.cpu().numpy(), g["laux_dwg"], rtol=1e-3, atol=2e-4 * np.abs(g["laux_dwg"]).max())
+
+
+def test_moe_layer_top2_plain_locations_small_and_bf16():
+    """The second fixture (64 features, 4 experts, token-order locations, capacity factor 0.75) through the routing kernels and the
+    fp32 layer's forward; then the 16-bit top-2 layer on the building shapes (persistent 256-row chains: capacity >= 256) against the
+    fp32 one - same experts off near-ties, outputs within 16-bit rounding; a capacity-limited 16-bit step has finite gradients; no-batch
+    evaluation drops nothing."""
+    from switch_nerf_amd import ops
+    g = np.load(os.path.join(G, "moe_layer_top2_m64e4_plain.npz"))
+    cfg = synth.small_cfg(64, 4)
+    seed, P, bpr, cf, cap = int(g["seed"]), int(g["P"]), bool(g["bpr"]), float(g["cf"]), int(g["capacity"])
+    sd = synth.make_weights(seed, cfg)
+    wg = torch.from_numpy(sd["layers.0.gates.0.wg.weight"]).cuda()
+    rng = np.random.default_rng(seed + 1000)
+    x = rng.standard_normal((P, 64)).astype(np.float32)
+    gi = torch.from_numpy(rng.standard_normal((P, 64)).astype(np.float32)).cuda()
+    logits = gi @ wg.t()
+    gates = torch.softmax(logits, dim=1).contiguous()                        # (64-feature routers have no kernel shape: test input only)
+    gmax = gates.max(dim=1).values.contiguous()
+    idx, gsel, gn = ops.topk_select(gates, 2)
+    np.testing.assert_array_equal(idx.cpu().numpy().T, g["topk"])
+    loc, counts, perm, _, group_rows, l_aux = ops.route_topk(idx, gmax, gates, P, 4, cap, bpr)
+    np.testing.assert_array_equal(loc.cpu().numpy(), g["loc"])
+    np.testing.assert_allclose(gn.cpu().numpy(), g["gnorm"], rtol=1e-5)
+    np.testing.assert_allclose(l_aux.item(), float(g["l_aux"]), rtol=1e-5)
+    # 16-bit layer on the building shapes
+    cfg = synth.BUILDING
+    # (capacity factor 4: nothing is dropped, so a token whose experts agree is the same computation in both precisions - with drops a
+    # rank that moves by one place in 16 bits keeps a (token, choice) pair in one layer and drops it in the other)
+    m16, m32 = _top2_layer(cfg, True, 4.0, torch.bfloat16), _top2_layer(cfg, True, 4.0, torch.float32)
+    _load(m16, 36)
+    m32.load_state_dict(m16.state_dict())
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    xb = torch.randn(4096, 256, device="cuda", generator=gen).requires_grad_(True)
+    gb = torch.randn(4096, 256, device="cuda", generator=gen)
+    y16, y32 = m16(xb, gate_input=gb), m32(xb, gate_input=gb)
+    same = (y16.gate_extras["gates"] == y32.gate_extras["gates"]).all(dim=1)
+    assert same.float().mean().item() > 0.97
+    err = (y16 - y32)[same].abs().max().item()
+    assert err < 0.05 * y32.abs().max().item(), err
+    mc = _top2_layer(cfg, True, 0.5, torch.bfloat16)
+    mc.load_state_dict(m16.state_dict())
+    yc = mc(xb, gate_input=gb)
+    assert 0.0 < (yc.abs().sum(-1) == 0).float().mean().item() < 0.9          # capacity factor 0.5: some tokens lose both choices
+    (yc.float().square().sum() + yc.l_aux).backward()
+    assert torch.isfinite(xb.grad).all() and xb.grad.abs().max().item() > 0
+    for p_ in mc.parameters():
+        assert p_.grad is not None and torch.isfinite(p_.grad).all()
+    nb = _top2_layer(cfg, True, 1.0, torch.float32)
+    nb.moe_no_batch = True
+    nb.load_state_dict(m16.state_dict())
+    with torch.no_grad():
+        ynb = nb(xb, gate_input=gb)
+        kept_rows = (ynb.abs().sum(-1) > 0).float().mean().item()
+    assert kept_rows == 1.0

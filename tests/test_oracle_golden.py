@@ -179,6 +179,49 @@ def test_moe_layer_normal_noise_vs_reference():
     np.testing.assert_allclose(wg.grad.numpy(), g["dwg"], rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("tag,cfg", [("m256e8_bpr", synth.BUILDING), ("m64e4_plain", synth.small_cfg(64, 4))])
+def test_moe_layer_top2_vs_reference(tag, cfg):
+    """A top-2 gate (extract_critical with top_k = 2, tutel_fast_dispatch.py:176-217): the reference layer's own run with `top_k = 2` -
+    both choices' experts and locations exact (acc_base, batch-prioritised and plain), normalised gates, output, l_aux, every gradient."""
+    g = load(f"moe_layer_top2_{tag}")
+    seed, P, bpr, cf = int(g["seed"]), int(g["P"]), bool(g["bpr"]), float(g["cf"])
+    p = O.params_from_numpy(synth.make_weights(seed, cfg), requires_grad=True)
+    rng = np.random.default_rng(seed + 1000)
+    x = torch.from_numpy(rng.standard_normal((P, cfg["model_dim"])).astype(np.float32)).requires_grad_(True)
+    gi = torch.from_numpy(rng.standard_normal((P, cfg["gate_hidden"])).astype(np.float32)).requires_grad_(True)
+    L = cfg["expert_layers"]
+    W = [p[f"layers.0.experts.0.weights.{l}"] for l in range(L)]
+    B = [p[f"layers.0.experts.0.bias.{l}"] for l in range(L)]
+    wg = p["layers.0.gates.0.wg.weight"]
+    y, l_aux, r, gates = O.moe_layer_topk(x, gi, wg, W, B, cfg["skips"], 2, cf, bpr)
+    assert np.array_equal(r["idx"].T, g["topk"])
+    assert np.array_equal(r["loc"], g["loc"]) and int(r["capacity"]) == int(g["capacity"])
+    assert (r["loc"] >= r["capacity"]).any() and (r["loc"][1] < r["capacity"]).any()
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(l_aux.detach().numpy(), g["l_aux"], rtol=1e-6)
+    dy = torch.from_numpy(rng.standard_normal(y.shape).astype(np.float32))
+    (y * dy).sum().backward(retain_graph=True)
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(gi.grad.numpy(), g["dgate_input"], rtol=0, atol=5e-6)
+    names = {"gates.0.wg.weight": "layers.0.gates.0.wg.weight"}
+    for l in range(L):
+        names[f"experts.0.weights.{l}"] = f"layers.0.experts.0.weights.{l}"
+        names[f"experts.0.bias.{l}"] = f"layers.0.experts.0.bias.{l}"
+    for short, full in names.items():
+        got = p[full].grad.numpy()
+        ref = g["grad__" + short]
+        if got.size <= 4096:
+            np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+        else:
+            np.testing.assert_allclose(synth.checksum(got), ref, rtol=2e-5)
+            sl = got.reshape(-1)[:: max(1, got.size // 997)][:997]
+            np.testing.assert_allclose(sl, g["gslice__" + short], rtol=0, atol=2e-5)
+    gi.grad = None
+    gl = torch.autograd.grad(l_aux, [gi, wg])
+    np.testing.assert_allclose(gl[0].numpy(), g["laux_dgate_input"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(gl[1].numpy(), g["laux_dwg"], rtol=0, atol=1e-7)
+
+
 @pytest.mark.parametrize("tag", ["unbalanced", "balanced"])
 def test_model_forward(tag):
     g = load(f"model_fwd_{tag}")
