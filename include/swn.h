@@ -95,10 +95,12 @@ int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const float* ln_b,
                  by the per-block partial sums of the router weight gradient */, float* d_wg, float* d_ln_w, float* d_ln_b,
                  void* stream);
 size_t swn_gate_bwd_scratch_floats(int n_tokens, int gate_dim, int n_experts);
-/* ... with a DENSE gradient w.r.t. the probabilities on top: d_gates[s,e] += d_probs[s,e] (fp32 [n_tokens, n_experts]; the normalised
- * gates of a top-k layer, swn_topk_gate_bwd - tutel_fast_dispatch.py:204-206 under autograd); d_gmax may be NULL.  VALU kernel. */
+/* ... with DENSE operands on top (either may be NULL, not both): d_gates[s,e] += d_probs[s,e] (fp32 [n_tokens, n_experts]; the normalised
+ * gates of a top-k layer, swn_topk_gate_bwd - tutel_fast_dispatch.py:204-206 under autograd), and d_logits_add[s,e] added to the logit
+ * gradient BEHIND the softmax backward (the load / importance loss, swn_load_importance_bwd).  d_gmax may be NULL.  VALU kernel. */
 int swn_gate_bwd_dense(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg,
-                       const float* gates, const int32_t* idx, const float* d_gmax, const float* d_probs, const float* stats,
+                       const float* gates, const int32_t* idx, const float* d_gmax, const float* d_probs,
+                       const float* d_logits_add, const float* stats,
                        const int32_t* counts, const float* laux_coef, int seg_tokens,
                        int n_tokens, int gate_dim, int n_experts,
                        void* dg, float* dlogits, float* d_wg, float* d_ln_w, float* d_ln_b, void* stream);
@@ -137,7 +139,7 @@ int swn_route_top1x(const int32_t* idx, const float* gmax, const float* gates,
 /* ---- top-k routing, k > 1 (extract_critical, tutel_fast_dispatch.py:176-217 with top_k > 1; no shipped config sets `k` above 1) ----
  * swn_topk_select: torch.topk(gates, k, dim=1) per token (:177; descending, the lower expert on exact ties) -> idx int32 [k, n_tokens]
  *   (choice-major: row j = indices_s[j]), gsel fp32 [k, n_tokens] = gates_s before, gnorm = gates_s after the normalisation
- *   g_j / clamp(sum_j g_j, min=eps) (:204-206).
+ *   g_j / clamp(sum_j g_j, min=eps) (:204-206; k = 1: gnorm = gsel, `if top_k > 1`).
  * swn_route_topk: locations of every choice (:192-202).  Choice j ranks its tokens like swn_route_top1 (batch-prioritised: by the TOKEN's
  *   max gate, `importance_scores = -gates.max(dim=1)`, :187 - gmax is the top-1 gate for every choice; else token order) and adds
  *   acc_base = the counts of the choices before it (:199-201), so every (token, choice) owns one row of the [n_seg * E, capacity] row
@@ -147,6 +149,21 @@ int swn_route_top1x(const int32_t* idx, const float* gmax, const float* gates,
  *   0's mask (load_balance(gates, masks_se[0]), :184) or NULL.  workspace: swn_route_workspace_bytes().
  * swn_topk_gate_bwd: backward of the normalisation, d_gnorm [k, n_tokens] -> d_probs [n_tokens, E] (zero outside the token's k experts):
  *   the dense operand of swn_gate_bwd_dense.                                                                                        */
+/* ---- load / importance loss (--use_load_importance_loss: load_importance_loss, tutel_fast_dispatch.py:152-174; needs gate_noise > 0) ----
+ * swn_gate_logits: logits [n_tokens, E] = g @ wg^T (+ noise_scale * noise; fp32 router without LayerNorm, E <= 16): the loss compares
+ *   the noise-free probabilities with the token's k-th largest NOISY LOGIT (`threshold = topk_logits[:, -1]`, :159-160).
+ * swn_load_importance_fwd: l_loss [1] = (cv2(Imp) + cv2(Load)) / 2, Imp_e = sum_t scores[t,e], Load_e = sum_t Normal(0, sigma).cdf(
+ *   scores[t,e] - logits_w_noise[t, idx_last[t]]), cv2(v) = v.var() / (v.mean()^2 + 1e-10), sigma = gate_noise / E; coef [2 E] receives
+ *   dl/dImp_e, dl/dLoad_e for the backward.  workspace: swn_load_importance_workspace_floats() floats.  Sums in a fixed order.
+ * swn_load_importance_bwd: d_logits [n_tokens, E] = dL/d logits through the probabilities and through the threshold entry, times the
+ *   device scalar d_l_loss [1] - swn_gate_bwd_dense's d_logits_add.                                                                  */
+int swn_gate_logits(const void* g, int dtype, const float* wg, const float* noise, float noise_scale, int n_tokens, int gate_dim,
+                    int n_experts, float* logits, void* stream);
+size_t swn_load_importance_workspace_floats(int n_tokens, int n_experts);
+int swn_load_importance_fwd(const float* scores_wo_noise, const float* logits_w_noise, const int32_t* idx_last, float sigma,
+                            int n_tokens, int n_experts, float* l_loss, float* coef, float* workspace, void* stream);
+int swn_load_importance_bwd(const float* scores_wo_noise, const float* logits_w_noise, const int32_t* idx_last, const float* coef,
+                            const float* d_l_loss, float sigma, int n_tokens, int n_experts, float* d_logits, void* stream);
 int swn_topk_select(const float* gates, int n_tokens, int n_experts, int top_k, int32_t* idx, float* gsel, float* gnorm, void* stream);
 int swn_route_topk(const int32_t* idx, const float* gmax, const float* gates, int n_tokens, int seg_tokens, int n_experts,
                    int capacity, int bpr, int top_k, int32_t* loc, int32_t* counts, int32_t* perm, int32_t* tok2row,

@@ -268,6 +268,47 @@ def gen_moe_layer_top2():
         save(f"moe_layer_top2_{tag}", **out)
 
 
+def gen_moe_layer_load_importance():
+    """--use_load_importance_loss (opts.py:210; extract_critical_load_importance, tutel_fast_dispatch.py:219-265) with gate noise in
+    training mode, --compute_balance_loss on: the layer's loss is the load / importance loss, the load-balance loss travels in the
+    extras.  One run with the shipped top-1 gate, one with a top-2 gate; the noise draw is replayed like gen_moe_layer_noise."""
+    print("[G3li] moe_layer with the load / importance loss")
+    for tag, top_k, seed, rng_seed in (("k1", 1, 38, 779), ("k2", 2, 39, 780)):
+        cfg, P, gate_noise = synth.BUILDING, 512, 1.0
+        sd = synth.make_weights(seed, cfg)
+        nerf, h = build_reference_model(cfg, sd)
+        moe = nerf.layers["0"]
+        moe.train()
+        gate = moe.gates[0]
+        gate.gate_noise = gate_noise
+        gate.top_k = top_k
+        gate.use_load_importance_loss = True
+        gate.compute_balance_loss = True
+        E = cfg["num_experts"]
+        rng = np.random.default_rng(seed + 1000)
+        x = rng.standard_normal((P, cfg["model_dim"])).astype(np.float32)
+        gi = rng.standard_normal((P, cfg["gate_hidden"])).astype(np.float32)
+        xt = torch.from_numpy(x).requires_grad_(True)
+        gt = torch.from_numpy(gi).requires_grad_(True)
+        torch.manual_seed(rng_seed)
+        y = moe(xt, gate_input=gt)
+        torch.manual_seed(rng_seed)
+        noise = torch.randn(P, E)
+        logits = gt.detach() @ gate.wg.weight.detach().float().t()
+        top = torch.topk(torch.softmax(logits + gate_noise * noise / E, dim=1), top_k, dim=1).indices
+        assert torch.equal(top, y.gate_extras["gates"]), "noise replay does not reproduce the reference's routing"
+        bal = y.gate_extras["balance_loss"]
+        dy = rng.standard_normal(y.shape).astype(np.float32)
+        (y * torch.from_numpy(dy)).sum().backward(retain_graph=True)
+        dx, dgi, dwg = xt.grad.clone(), gt.grad.clone(), gate.wg.weight.grad.clone()
+        gl = torch.autograd.grad(y.l_aux, [gt, gate.wg.weight], retain_graph=True)
+        gb = torch.autograd.grad(bal, [gt, gate.wg.weight])
+        save(f"moe_layer_load_importance_{tag}", seed=seed, P=P, top_k=top_k, gate_noise=gate_noise, noise=noise.numpy(), y=y.detach().numpy(),
+             l_aux=y.l_aux.detach().numpy(), balance_loss=bal.detach().numpy(), topk=y.gate_extras["gates"].numpy().astype(np.int32),
+             dx=dx.numpy(), dgate_input=dgi.numpy(), dwg=dwg.numpy(), laux_dgate_input=gl[0].numpy(), laux_dwg=gl[1].numpy(),
+             bal_dgate_input=gb[0].numpy(), bal_dwg=gb[1].numpy())
+
+
 # ------------------------------------------------------------------------------------------ G4 model fwd
 def gen_model_forward():
     print("[G4] NeRFMoE.forward building shapes, P=4096")
@@ -676,7 +717,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    todo = dict(routing=gen_routing, pe=gen_pe, moe=gen_moe_layer, moe_noise=gen_moe_layer_noise, moe_normal_noise=gen_moe_layer_normal_noise, moe_top2=gen_moe_layer_top2, model=gen_model_forward, nobatch=gen_model_forward_nobatch, dispatch_nobatch=gen_dispatch_nobatch,
+    todo = dict(routing=gen_routing, pe=gen_pe, moe=gen_moe_layer, moe_noise=gen_moe_layer_noise, moe_normal_noise=gen_moe_layer_normal_noise, moe_top2=gen_moe_layer_top2, moe_li=gen_moe_layer_load_importance, model=gen_model_forward, nobatch=gen_model_forward_nobatch, dispatch_nobatch=gen_dispatch_nobatch,
                 render=gen_render, autocast=gen_render_autocast, capacity=gen_render_capacity, fine=gen_render_fine, mip=gen_mip, ckpt=gen_checkpoint_layout, dense=gen_dense, composite=gen_composite, bg=gen_bg)
     for k, fn in todo.items():
         if a.only and k not in a.only.split(","):

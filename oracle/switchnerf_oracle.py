@@ -195,21 +195,42 @@ def route_topk(gates: np.ndarray, top_k: int, capacity_factor: float, batch_prio
     return dict(idx=idx, loc=loc, capacity=capacity_of(P, E, capacity_factor, top_k), counts=counts.astype(np.int32))
 
 
+def load_importance_loss(scores_wo_noise: torch.Tensor, topk_logits: torch.Tensor, n_experts: int, gate_noise: float) -> torch.Tensor:
+    """load_importance_loss, tutel_fast_dispatch.py:152-174: (cv2(importance) + cv2(load)) / 2 with importance_e = sum_t scores[t, e],
+    load_e = sum_t Normal(0, gate_noise / E).cdf(scores[t, e] - the token's k-th largest noisy logit), cv2(v) = var(v) / (mean(v)^2 + 1e-10)
+    (unbiased variance)."""
+    assert gate_noise > 0
+    sigma = gate_noise / n_experts
+    thr = topk_logits[:, -1].view(-1, 1).float()
+    prob = 0.5 * (1 + torch.erf((scores_wo_noise.float() - thr) / sigma / math.sqrt(2.0)))          # Normal.cdf
+    load = prob.sum(0)
+    imp = scores_wo_noise.float().sum(0)
+    cv2 = lambda v: v.var() / (v.mean() ** 2 + 1e-10)
+    return (cv2(imp) + cv2(load)) / 2.0
+
+
 def moe_layer_topk(h: torch.Tensor, gate_input: torch.Tensor, wg: torch.Tensor, weights, biases, skips, top_k: int,
-                   capacity_factor: float, batch_prioritized: bool):
+                   capacity_factor: float, batch_prioritized: bool, gate_noise: float = 0.0, noise: Optional[torch.Tensor] = None,
+                   load_importance: bool = False):
     """TopKGate.apply_on_expert_fn (tutel_moe_layer_nobatch.py:98-235) with k > 1, fp32 gate, postscore: gates normalised by the sum of the
     token's k gates (tutel_fast_dispatch.py:204-206), dispatch / combine summed over the choices (:26-27, :59-62), l_aux from the first
     choice's mask (:184).  Returns (y, l_aux, routing dict, gates)."""
     E = wg.shape[0]
-    gates = torch.softmax(gate_input.float() @ wg.float().t(), dim=1)
+    logits = gate_input.float() @ wg.float().t()
+    logits_w = logits + gate_noise * noise / E if (gate_noise > 0 and noise is not None) else logits     # tutel_moe_layer_nobatch.py:119-122
+    gates = torch.softmax(logits_w, dim=1)
     r = route_topk(gates.detach().numpy(), top_k, capacity_factor, batch_prioritized)
     cap = int(r["capacity"])
     idx = [torch.from_numpy(r["idx"][j].astype(np.int64)) for j in range(top_k)]
     loc = [torch.from_numpy(r["loc"][j].astype(np.int64)) for j in range(top_k)]
     gs = [gates.gather(1, i.unsqueeze(1)).squeeze(1) for i in idx]
-    denom = torch.clamp(sum(gs), min=torch.finfo(gs[0].dtype).eps)
-    gs = [g / denom for g in gs]
+    if top_k > 1:                                                              # tutel_fast_dispatch.py:196, 204-206
+        denom = torch.clamp(sum(gs), min=torch.finfo(gs[0].dtype).eps)
+        gs = [g / denom for g in gs]
     l_aux = load_balance_loss(gates, idx[0])
+    if load_importance:                                                        # :232 (l_aux -> routing["balance_loss"], the extras' tensor)
+        r = dict(r, balance_loss=l_aux)
+        l_aux = load_importance_loss(torch.softmax(logits, dim=1), logits_w.gather(1, torch.stack(idx, dim=1)), E, gate_noise)
     d = sum(dispatch(h, idx[j], loc[j], E, cap) for j in range(top_k)).view(E, cap, -1)
     o = expert_mlp(d, weights, biases, skips).reshape(E * cap, -1)
     y = sum(combine(o, idx[j], loc[j], gs[j], cap) for j in range(top_k))

@@ -74,7 +74,10 @@ SIGNATURES = {
     "swn_gate_fwd": [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
     "swn_gate_fwd_noise": [vp, i32, vp, vp, vp, vp, f32, i32, i32, i32, vp, vp, vp, vp, vp],
     "swn_gate_bwd": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp],
-    "swn_gate_bwd_dense": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp],
+    "swn_gate_bwd_dense": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp],
+    "swn_gate_logits": [vp, i32, vp, vp, f32, i32, i32, i32, vp, vp],
+    "swn_load_importance_fwd": [vp, vp, vp, f32, i32, i32, vp, vp, vp, vp],
+    "swn_load_importance_bwd": [vp, vp, vp, vp, vp, f32, i32, i32, vp, vp],
     "swn_topk_select": [vp, i32, i32, i32, vp, vp, vp, vp],
     "swn_route_topk": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp],
     "swn_topk_gate_bwd": [vp, vp, vp, i32, i32, i32, vp, vp],
@@ -172,6 +175,8 @@ def load():
     lib.swn_route_sync_bytes.argtypes = []
     lib.swn_gate_bwd_scratch_floats.restype = sz
     lib.swn_gate_bwd_scratch_floats.argtypes = [i32, i32, i32]
+    lib.swn_load_importance_workspace_floats.restype = sz
+    lib.swn_load_importance_workspace_floats.argtypes = [i32, i32]
     lib.swn_wgrad_multi_workspace_bytes.restype = sz
     lib.swn_wgrad_multi_workspace_bytes.argtypes = [i32, i32]
     lib.swn_heads_bwd_workspace_bytes.restype = sz

@@ -350,8 +350,10 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ g, 
                                                        const int32_t* __restrict__ counts, const float* __restrict__ laux_coef,
                                                        int seg_tokens, int P, int E, T* __restrict__ dg,
                                                        float* __restrict__ dlogits, float* __restrict__ d_ln_w,
-                                                       float* __restrict__ d_ln_b, const float* __restrict__ d_probs) {
-  // d_probs [P, E] (may be NULL): a dense gradient w.r.t. the probabilities, added to the top-1 / l_aux terms (top-k gates)
+                                                       float* __restrict__ d_ln_b, const float* __restrict__ d_probs,
+                                                       const float* __restrict__ d_logits_add) {
+  // d_probs [P, E] (may be NULL): a dense gradient w.r.t. the probabilities, added to the top-1 / l_aux terms (top-k gates);
+  // d_logits_add [P, E] (may be NULL): a gradient w.r.t. the logits themselves, added behind the softmax backward (load / importance loss)
   // (TB rows per 16-lane group and pass: see gate_fwd_kernel)
   using R = Row16<T, G>;
   constexpr int VPL = R::VPL;
@@ -395,6 +397,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ g, 
 #pragma unroll
       for (int e = 0; e < EMAX; ++e) {
         dl[t][e] = pr[e] * (dp[e] - dot);  // softmax backward
+        if (d_logits_add && e < E) dl[t][e] += d_logits_add[tok * E + e];
         if (e < E && j == (e & 15) && tok0 + t < P) dlogits[tok * E + e] = dl[t][e];
       }
     }
@@ -1253,7 +1256,7 @@ static int gate_bwd_impl(const void* g, int dtype, const float* ln_w, const floa
                          const float* gates, const int32_t* idx, const float* d_gmax, const float* stats,
                          const int32_t* counts, const float* laux_coef, int seg_tokens, int n_tokens, int gate_dim,
                          int n_experts, void* dg, float* dlogits, float* d_wg, float* d_ln_w, float* d_ln_b, void* stream,
-                         const float* d_probs) {
+                         const float* d_probs, const float* d_logits_add = nullptr) {
   SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_gate_bwd: bad dtype");
   SWN_CHECK(g && wg && gates && idx && dg && d_wg && counts && dlogits, "swn_gate_bwd: null pointer");
   SWN_CHECK(n_experts >= 1 && n_experts <= 16 && seg_tokens > 0, "swn_gate_bwd: bad sizes");
@@ -1268,7 +1271,7 @@ static int gate_bwd_impl(const void* g, int dtype, const float* ln_w, const floa
   const int ps = n_experts * gate_dim + n_experts;
   float* msum = dwg_partial + (size_t)dwg_blocks * ps;                  // third part: [E * G + E]
   static const bool valu_env = getenv("SWN_GATE_VALU") != nullptr;
-  const bool valu_only = valu_env || d_probs != nullptr;       // (the dense operand exists in the VALU kernel only: top-k layers)
+  const bool valu_only = valu_env || d_probs != nullptr || d_logits_add != nullptr;       // (the dense operand exists in the VALU kernel only: top-k layers)
   const bool mfma_path = dtype == SWN_HALF && gate_dim == 256 && n_experts <= 8 && !valu_only;
   if (dtype == SWN_HALF) {
     const bf16_t* gp = (const bf16_t*)g;
@@ -1289,7 +1292,7 @@ static int gate_bwd_impl(const void* g, int dtype, const float* ln_w, const floa
       if (rc) return rc;
     } else
     GATE_DISPATCH_TB(bf16_t, gate_bwd_kernel, 1, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, gates, idx, d_gmax,
-                  stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dgp, dlogits, d_ln_w, d_ln_b, d_probs);
+                  stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dgp, dlogits, d_ln_w, d_ln_b, d_probs, d_logits_add);
     if (!mfma_path && !(gate_dim == 512 && !valu_only)) {
       SWN_CHECK(n_experts == 4 || n_experts == 8 || n_experts == 16, "swn_gate_bwd: experts must be 4, 8 or 16");
       DWG_DISPATCH(bf16_t, gp);
@@ -1298,7 +1301,7 @@ static int gate_bwd_impl(const void* g, int dtype, const float* ln_w, const floa
     const float* gp = (const float*)g;
     float* dgp = (float*)dg;
     GATE_DISPATCH_TB(float, gate_bwd_kernel, 1, dim3(blocks), dim3(256), 0, as_stream(stream), gp, ln_w, ln_b, wg, gates, idx, d_gmax,
-                  stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dgp, dlogits, d_ln_w, d_ln_b, d_probs);
+                  stats, counts, laux_coef, seg_tokens, n_tokens, n_experts, dgp, dlogits, d_ln_w, d_ln_b, d_probs, d_logits_add);
     SWN_CHECK(n_experts == 4 || n_experts == 8 || n_experts == 16, "swn_gate_bwd: experts must be 4, 8 or 16");
     DWG_DISPATCH(float, gp);
   }
@@ -1322,12 +1325,13 @@ extern "C" int swn_gate_bwd(const void* g, int dtype, const float* ln_w, const f
 // ... with a dense gradient d_probs [n_tokens, n_experts] w.r.t. the softmax probabilities on top (the normalised gates of a top-k layer,
 // swn_topk_gate_bwd); d_gmax may be NULL then
 extern "C" int swn_gate_bwd_dense(const void* g, int dtype, const float* ln_w, const float* ln_b, const float* wg,
-                                  const float* gates, const int32_t* idx, const float* d_gmax, const float* d_probs, const float* stats,
+                                  const float* gates, const int32_t* idx, const float* d_gmax, const float* d_probs,
+                                  const float* d_logits_add, const float* stats,
                                   const int32_t* counts, const float* laux_coef, int seg_tokens, int n_tokens, int gate_dim,
                                   int n_experts, void* dg, float* dlogits, float* d_wg, float* d_ln_w, float* d_ln_b, void* stream) {
-  SWN_CHECK(d_probs, "swn_gate_bwd_dense: d_probs is NULL (swn_gate_bwd is the entry point without it)");
+  SWN_CHECK(d_probs || d_logits_add, "swn_gate_bwd_dense: no dense operand (swn_gate_bwd is the entry point without one)");
   return gate_bwd_impl(g, dtype, ln_w, ln_b, wg, gates, idx, d_gmax, stats, counts, laux_coef, seg_tokens, n_tokens, gate_dim, n_experts, dg,
-                       dlogits, d_wg, d_ln_w, d_ln_b, stream, d_probs);
+                       dlogits, d_wg, d_ln_w, d_ln_b, stream, d_probs, d_logits_add);
 }
 
 template <int MODE>

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restric
     gsel[(long)k * n_tokens + i] = bv;
     sum += bv;                                  // (sum(gates_s): first choice first, the reference's order)
   }
-  const float denom = fmaxf(sum, 1.1920928955078125e-07f);      // torch.finfo(torch.float32).eps
+  const float denom = K > 1 ? fmaxf(sum, 1.1920928955078125e-07f) : 1.f;      // torch.finfo(torch.float32).eps; `if top_k > 1:` (:196)
   for (int k = 0; k < K; ++k) gnorm[(long)k * n_tokens + i] = gsel[(long)k * n_tokens + i] / denom;
 }
 
@@ -473,6 +473,7 @@ __global__ __launch_bounds__(256) void topk_gate_bwd_kernel(const float* __restr
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_tokens) return;
   for (int e = 0; e < E; ++e) d_probs[i * E + e] = 0.f;
+  if (K == 1) { d_probs[i * E + idx[i]] = d_gnorm[i]; return; }        // no normalisation for top-1 (:196)
   float sum = 0.f;
   for (int k = 0; k < K; ++k) sum += gates[i * E + idx[(long)k * n_tokens + i]];
   const float eps = 1.1920928955078125e-07f;
@@ -493,6 +494,171 @@ __global__ void route_group_rows_kernel(const int32_t* __restrict__ counts, int 
   group_rows[g] = s;
 }
 
+// ---- load / importance loss (use_load_importance_loss: tutel_fast_dispatch.py:152-174, 219-265) ---------------------------------
+// logits = g @ wg^T (+ noise_scale * noise): the router's logits themselves - the loss compares probabilities with the k-th largest NOISY
+// LOGIT (:159-160), which the probabilities the gate kernels write do not determine.  fp32 accumulation, one wave per token, E <= 16.
+template <typename T>
+__global__ __launch_bounds__(256) void gate_logits_kernel(const T* __restrict__ g, const float* __restrict__ wg,
+                                                          const float* __restrict__ noise, float noise_scale, int P, int G, int E,
+                                                          float* __restrict__ logits) {
+  const int lane = threadIdx.x & 63;
+  const long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long i = wid; i < P; i += nw) {
+    float acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int k = lane; k < G; k += 64) {
+      const float x = ElemIO<T>::ld(g + i * G + k);
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (e < E) acc[e] += x * wg[(long)e * G + k];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      if (e < E) {       // (E is wave-uniform)
+        const float v = wave_sum(acc[e]);
+        if (lane == 0) logits[i * E + e] = v + (noise ? noise_scale * noise[i * E + e] : 0.f);
+      }
+  }
+}
+
+// Normal(0, sigma).cdf(x) as torch.distributions writes it: 0.5 * (1 + erf(x / sigma / sqrt(2)))
+__device__ __forceinline__ float normal_cdf(float x, float inv_sigma) { return 0.5f * (1.f + erff(x * inv_sigma * 0.70710678118654752f)); }
+
+// per-block sums over the tokens of Imp_e = scores[t][e] and Load_e = cdf(scores[t][e] - threshold[t]), threshold = the token's k-th
+// largest noisy logit; partial [nblk][2 E], fixed order (deterministic)
+__global__ __launch_bounds__(256) void load_importance_partial_kernel(const float* __restrict__ scores, const float* __restrict__ logits_w_noise,
+                                                                      const int32_t* __restrict__ idx_last, float inv_sigma, int P, int E,
+                                                                      float* __restrict__ partial) {
+  __shared__ float red[256][33];
+  float imp[16], load[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) imp[e] = load[e] = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long)gridDim.x * 256) {
+    const float thr = logits_w_noise[i * E + idx_last[i]];
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      if (e < E) {
+        const float sc = scores[i * E + e];
+        imp[e] += sc;
+        load[e] += normal_cdf(sc - thr, inv_sigma);
+      }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { red[threadIdx.x][e] = imp[e]; red[threadIdx.x][16 + e] = load[e]; }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int c = threadIdx.x;
+    float a = 0.f;
+    for (int t = 0; t < 256; ++t) a += red[t][c];
+    const int e = c & 15;
+    if (e < E) partial[(long)blockIdx.x * 2 * E + (c >> 4) * E + e] = a;
+  }
+}
+
+// Imp, Load -> l = (cv2(Imp) + cv2(Load)) / 2 with cv2(v) = v.var() / (v.mean()^2 + 1e-10) (unbiased variance, :163, :168), and the
+// loss's gradient w.r.t. every Imp_e / Load_e (coef [2 E]) for the backward
+__global__ __launch_bounds__(64) void load_importance_final_kernel(const float* __restrict__ partial, int nblk, int E, float* __restrict__ l_loss,
+                                                                   float* __restrict__ coef) {
+  __shared__ float v[32];
+  const int c = threadIdx.x;
+  if (c < 2 * E) {
+    float a = 0.f;
+    for (int b = 0; b < nblk; ++b) a += partial[(long)b * 2 * E + c];
+    v[c] = a;
+  }
+  __syncthreads();
+  if (c < 2) {          // thread 0: importance, thread 1: load
+    const float* x = v + c * E;
+    float m = 0.f;
+    for (int e = 0; e < E; ++e) m += x[e];
+    m /= (float)E;
+    float var = 0.f;
+    for (int e = 0; e < E; ++e) var += (x[e] - m) * (x[e] - m);
+    var /= (float)(E - 1);
+    const float den = m * m + 1e-10f;
+    for (int e = 0; e < E; ++e)
+      coef[c * E + e] = 0.5f * (2.f * (x[e] - m) / ((float)(E - 1) * den) - var * (2.f * m / (float)E) / (den * den));
+    v[c * E] = var / den;          // (x is dead now)
+  }
+  __syncthreads();
+  if (c == 0) l_loss[0] = 0.5f * (v[0] + v[E]);
+}
+
+// d_logits [P, E] of the loss: through scores = softmax(logits) (importance + the cdf's argument) and through the threshold (the k-th
+// choice's noisy logit: one entry per token); d_l = dL/d l_loss (device scalar)
+__global__ __launch_bounds__(256) void load_importance_bwd_kernel(const float* __restrict__ scores, const float* __restrict__ logits_w_noise,
+                                                                  const int32_t* __restrict__ idx_last, const float* __restrict__ coef,
+                                                                  const float* __restrict__ d_l, float inv_sigma, int P, int E,
+                                                                  float* __restrict__ d_logits) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const float dl = d_l[0];
+  const int last = idx_last[i];
+  const float thr = logits_w_noise[i * E + last];
+  float sc[16], ds[16], dot = 0.f, dthr = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    sc[e] = ds[e] = 0.f;
+    if (e < E) {
+      sc[e] = scores[i * E + e];
+      const float z = (sc[e] - thr) * inv_sigma;
+      const float pdf = __expf(-0.5f * z * z) * inv_sigma * 0.3989422804014327f;
+      ds[e] = dl * (coef[e] + coef[E + e] * pdf);
+      dthr -= dl * coef[E + e] * pdf;
+      dot += sc[e] * ds[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+    if (e < E) d_logits[i * E + e] = sc[e] * (ds[e] - dot) + (e == last ? dthr : 0.f);
+}
+
+extern "C" int swn_gate_logits(const void* g, int dtype, const float* wg, const float* noise, float noise_scale, int n_tokens, int gate_dim,
+                               int n_experts, float* logits, void* stream) {
+  SWN_CHECK(dtype == SWN_F32 || dtype == SWN_HALF, "swn_gate_logits: bad dtype");
+  SWN_CHECK(g && wg && logits, "swn_gate_logits: null pointer");
+  SWN_CHECK(n_tokens > 0 && gate_dim > 0 && n_experts >= 1 && n_experts <= 16, "swn_gate_logits: experts <= 16");
+  const int blocks = min(cdiv(n_tokens, 4), 4096);
+  if (dtype == SWN_HALF)
+    hipLaunchKernelGGL((gate_logits_kernel<bf16_t>), dim3(blocks), dim3(256), 0, as_stream(stream), (const bf16_t*)g, wg, noise, noise_scale,
+                       n_tokens, gate_dim, n_experts, logits);
+  else
+    hipLaunchKernelGGL((gate_logits_kernel<float>), dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)g, wg, noise, noise_scale,
+                       n_tokens, gate_dim, n_experts, logits);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}
+
+static int load_importance_blocks(int n_tokens) { return min(cdiv(n_tokens, 256), 512); }
+extern "C" size_t swn_load_importance_workspace_floats(int n_tokens, int n_experts) {
+  return (size_t)load_importance_blocks(n_tokens) * 2 * n_experts;
+}
+
+extern "C" int swn_load_importance_fwd(const float* scores_wo_noise, const float* logits_w_noise, const int32_t* idx_last, float sigma,
+                                       int n_tokens, int n_experts, float* l_loss, float* coef, float* workspace, void* stream) {
+  SWN_CHECK(scores_wo_noise && logits_w_noise && idx_last && l_loss && coef && workspace, "swn_load_importance_fwd: null pointer");
+  SWN_CHECK(sigma > 0.f, "swn_load_importance_fwd: `gate_noise` must be > 0 for normalization in load_importance_loss()");
+  SWN_CHECK(n_tokens > 0 && n_experts >= 2 && n_experts <= 16, "swn_load_importance_fwd: 2 <= experts <= 16");
+  const int nblk = load_importance_blocks(n_tokens);
+  hipLaunchKernelGGL(load_importance_partial_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), scores_wo_noise, logits_w_noise, idx_last,
+                     1.f / sigma, n_tokens, n_experts, workspace);
+  hipLaunchKernelGGL(load_importance_final_kernel, dim3(1), dim3(64), 0, as_stream(stream), workspace, nblk, n_experts, l_loss, coef);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int swn_load_importance_bwd(const float* scores_wo_noise, const float* logits_w_noise, const int32_t* idx_last, const float* coef,
+                                       const float* d_l_loss, float sigma, int n_tokens, int n_experts, float* d_logits, void* stream) {
+  SWN_CHECK(scores_wo_noise && logits_w_noise && idx_last && coef && d_l_loss && d_logits, "swn_load_importance_bwd: null pointer");
+  SWN_CHECK(sigma > 0.f && n_tokens > 0 && n_experts >= 2 && n_experts <= 16, "swn_load_importance_bwd: bad sizes");
+  hipLaunchKernelGGL(load_importance_bwd_kernel, dim3(cdiv(n_tokens, 256)), dim3(256), 0, as_stream(stream), scores_wo_noise, logits_w_noise,
+                     idx_last, coef, d_l_loss, 1.f / sigma, n_tokens, n_experts, d_logits);
+  SWN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int swn_topk_select(const float* gates, int n_tokens, int n_experts, int top_k, int32_t* idx, float* gsel, float* gnorm,
                                void* stream) {
   SWN_CHECK(gates && idx && gsel && gnorm, "swn_topk_select: null pointer");
@@ -506,7 +672,7 @@ extern "C" int swn_topk_select(const float* gates, int n_tokens, int n_experts, 
 extern "C" int swn_topk_gate_bwd(const float* gates, const int32_t* idx, const float* d_gnorm, int n_tokens, int n_experts, int top_k,
                                  float* d_probs, void* stream) {
   SWN_CHECK(gates && idx && d_gnorm && d_probs, "swn_topk_gate_bwd: null pointer");
-  SWN_CHECK(n_tokens > 0 && n_experts >= 1 && n_experts <= 64 && top_k >= 2 && top_k <= n_experts, "swn_topk_gate_bwd: need 2 <= k <= E <= 64");
+  SWN_CHECK(n_tokens > 0 && n_experts >= 1 && n_experts <= 64 && top_k >= 1 && top_k <= n_experts, "swn_topk_gate_bwd: need 1 <= k <= E <= 64");
   hipLaunchKernelGGL(topk_gate_bwd_kernel, dim3(cdiv(n_tokens, 256)), dim3(256), 0, as_stream(stream), gates, idx, d_gnorm, n_tokens,
                      n_experts, top_k, d_probs);
   SWN_LAUNCH_CHECK();

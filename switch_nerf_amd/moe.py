@@ -137,19 +137,31 @@ class _MoETopKFunction(torch.autograd.Function):
     swn_topk_gate_bwd and the accumulating forms of the sparse kernels."""
 
     @staticmethod
-    def forward(ctx, layer, x, gate_in, wg, gate_noise, *wb):
+    def forward(ctx, layer, x, gate_in, wg, gate_noise, clean_noise, *wb):
         o, dt = ops, layer.dtype
         L, E, M, K = layer.layer_num, layer.n_experts, layer.model_dim, layer.top_k
         P = x.shape[0]
         xs = x.detach().to(dt).contiguous()
         gs = gate_in.detach().to(dt).contiguous()
         wg32 = wg.detach().float().contiguous()
-        gates, _idx0, gmax, stats = o.gate_fwd(gs, None, None, wg32, noise=gate_noise, noise_scale=layer._noise_scale if gate_noise is not None else 0.0)
+        nscale = layer._noise_scale if gate_noise is not None else 0.0
+        gates, _idx0, gmax, stats = o.gate_fwd(gs, None, None, wg32, noise=gate_noise, noise_scale=nscale)
         cap = K * int(layer.capacity_factor * ((P + E - 1) // E))                              # tutel_fast_dispatch.py:211
         if layer.moe_no_batch:
             cap = P                                                                            # (k distinct experts per token: <= P rows each)
         idx, _gsel, gn = o.topk_select(gates, K)                                               # :177-182, 204-206
         loc, counts, perm, _, group_rows, l_aux = o.route_topk(idx, gmax, gates, P, E, cap, layer.bpr)
+        l_bal = l_aux.reshape(()) if layer.use_load_importance_loss else torch.zeros((), device=xs.device)    # (second output: extras only)
+        li = ()
+        if layer.use_load_importance_loss:
+            # extract_critical_load_importance (:219-265): the layer's loss is load_importance_loss(softmax(logits), the k-th largest noisy
+            # logit) (:232); the load-balance term only travels in the extras (compute_balance_loss)
+            sigma = layer.gate_noise / E
+            logits_w = o.gate_logits(gs, wg32, gate_noise, nscale)
+            scores = gates if gate_noise is None else o.gate_fwd(gs, None, None, wg32, noise=clean_noise, noise_scale=1.0 / E if clean_noise is not None else 0.0)[0]
+            l_imp, coef_li = o.load_importance_fwd(scores, logits_w, idx[K - 1].contiguous(), sigma)
+            l_aux = l_imp
+            li = (scores, logits_w, coef_li)
         need_grad = any(ctx.needs_input_grad[1:])
         rows = E * cap
         wf = [o.pack_weights(w.detach().float().contiguous(), dt, True) for w in wb[:L]]
@@ -168,15 +180,25 @@ class _MoETopKFunction(torch.autograd.Function):
             o.dispatch_bwd_data_more(gn[j], idx[j], loc[j], y, eo, cap)                        # ... `last_result + single_output`
         ctx.layer, ctx.cap, ctx.x_dtype, ctx.g_dtype = layer, cap, x.dtype, gate_in.dtype
         ctx.save_for_backward(xs, gs, wg32, gates, idx, gn, stats, loc, counts, perm, group_rows, eo, *wb[:L],
-                              *[s for s in saves if s is not None], *[m for m in masks if m is not None])
+                              *[s for s in saves if s is not None], *[m for m in masks if m is not None], *li)
         ctx.mark_non_differentiable(idx)
-        return y.to(x.dtype), l_aux.reshape(()), idx
+        return y.to(x.dtype), l_aux.reshape(()), l_bal, idx
 
     @staticmethod
-    def backward(ctx, dy, d_laux, _d_idx):
+    def backward(ctx, dy, d_laux, d_bal, _d_idx):
         o, layer = ops, ctx.layer
         dt, L, E, M, K, cap = layer.dtype, layer.layer_num, layer.n_experts, layer.model_dim, layer.top_k, ctx.cap
         sv = ctx.saved_tensors
+        d_logits_add = None
+        if layer.use_load_importance_loss:
+            scores, logits_w, coef_li = sv[-3:]
+            sv = sv[:-3]
+            if d_laux is not None:
+                d_logits_add = o.load_importance_bwd(scores, logits_w, sv[4][K - 1].contiguous(), coef_li, d_laux.reshape(1).float().contiguous(),
+                                                     layer.gate_noise / E)
+            d_laux = d_bal                       # (the load-balance term's gradient arrives through the extras' tensor)
+        elif d_bal is not None:
+            d_laux = d_bal if d_laux is None else d_laux + d_bal
         xs, gs, wg32, gates, idx, gn, stats, loc, counts, perm, group_rows, eo = sv[:12]
         ws = sv[12:12 + L]
         saves = list(sv[12 + L:12 + L + (L - 1)])
@@ -216,8 +238,8 @@ class _MoETopKFunction(torch.autograd.Function):
         d_wg = torch.zeros_like(wg32)
         coef = (d_laux.reshape(1).float() * (E / float(P * P))).contiguous()
         dg = o.gate_bwd_dense(gs, None, None, wg32, gates, idx[0].contiguous(), None, d_probs, stats, counts[0].contiguous(), coef, P, d_wg,
-                              None, None)
-        return (None, dx.to(ctx.x_dtype), dg.to(ctx.g_dtype), d_wg, None, *dws, *[b.view(E, 1, M) for b in dbs])
+                              None, None, d_logits_add=d_logits_add)
+        return (None, dx.to(ctx.x_dtype), dg.to(ctx.g_dtype), d_wg, None, None, *dws, *[b.view(E, 1, M) for b in dbs])
 
 
 class MoELayer(nn.Module):
@@ -249,8 +271,18 @@ class MoELayer(nn.Module):
         # additive, so they reach the router kernel as ONE noise operand (swn_gate_fwd_noise)
         self.use_normal_noise = bool(gate_type.get("use_normal_noise", False))
         self._noise_scale = 0.0
-        if gate_type.get("use_load_importance_loss"):
-            raise NotImplementedError("use_load_importance_loss (tutel_fast_dispatch.py:152-174, 219-265; no shipped config uses it)")
+        # --use_load_importance_loss (opts.py:210; extract_critical_load_importance, tutel_fast_dispatch.py:219-265): the layer's loss is the
+        # load / importance loss of "Scaling Vision with Sparse MoE" instead of the load-balance loss; needs gate_noise > 0 (:154)
+        self.use_load_importance_loss = bool(gate_type.get("use_load_importance_loss", False))
+        self.compute_balance_loss = bool(gate_type.get("compute_balance_loss", False))
+        if self.use_load_importance_loss:
+            assert self.gate_noise > 0, "`gate_noise` must be > 0 for normalization in load_importance_loss()."
+            if not 2 <= int(experts["count_per_node"]) <= 16:
+                raise ValueError("use_load_importance_loss: 2 <= experts <= 16")
+        elif self.compute_balance_loss:
+            # the reference's layer dies here with a NameError (tutel_moe_layer_nobatch.py:134, :232: `l_balance_loss` only exists in the
+            # load-importance branch); refuse at construction instead
+            raise ValueError("compute_balance_loss needs use_load_importance_loss (tutel_moe_layer_nobatch.py:128-135, 231-232)")
         self.moe_no_batch, self.return_gates, self.dtype = bool(moe_no_batch), bool(return_gates), dtype
         gen = None
         if seeds is not None:                      # gate under seeds[0], experts under seeds[1] (tutel_moe_layer_nobatch.py:654-703)
@@ -270,24 +302,32 @@ class MoELayer(nn.Module):
         x = input.reshape(-1, self.model_dim)
         g = gi.reshape(-1, self.gate_dim)
         ex = self.experts[0]
-        noise = None
+        noise = clean = None
         E = self.n_experts
         draw = lambda given: (given.to(x.device, torch.float32).reshape(-1, E).contiguous() if given is not None
                               else torch.randn(x.shape[0], E, device=x.device, dtype=torch.float32))
         if self.training and self.use_normal_noise:            # logits + n1 / E (+ gate_noise * n2 / E) = logits + (n1 + gate_noise * n2) / E
-            noise = draw(normal_noise_draw)
+            noise = clean = draw(normal_noise_draw)    # (clean: the part that belongs to `logits` in the load / importance loss, :116-117)
             if self.gate_noise > 0:
                 noise = noise + self.gate_noise * draw(gate_noise_draw)
             self._noise_scale = 1.0 / E
         elif self.training and self.gate_noise > 0:
             noise = draw(gate_noise_draw)
             self._noise_scale = self.gate_noise / E
-        fn = _MoEFunction if self.top_k == 1 else _MoETopKFunction
-        y, l_aux, idx = fn.apply(self, x, g, self.gates[0].wg.weight, noise, *ex.weights, *ex.bias)
+        l_bal = None
+        if self.top_k == 1 and not self.use_load_importance_loss:
+            y, l_aux, idx = _MoEFunction.apply(self, x, g, self.gates[0].wg.weight, noise, *ex.weights, *ex.bias)
+        else:
+            y, l_aux, l_bal, idx = _MoETopKFunction.apply(self, x, g, self.gates[0].wg.weight, noise, clean, *ex.weights, *ex.bias)
         y = y.view(shape)
         y.l_aux = l_aux                                                                         # :792-796
+        extras = {}
         if self.return_gates:                                                                   # torch.topk(gates, k).indices, :229
-            y.gate_extras = {"gates": idx.long().view(-1, 1) if self.top_k == 1 else idx.long().t().contiguous()}
+            extras["gates"] = idx.long().view(-1, 1) if idx.dim() == 1 else idx.long().t().contiguous()
+        if self.compute_balance_loss:                                                           # :231-232
+            extras["balance_loss"] = l_bal
+        if extras:
+            y.gate_extras = extras
         return y
 
 

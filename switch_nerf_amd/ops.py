@@ -197,16 +197,48 @@ def gate_bwd(g, ln_w, ln_b, wg, gates, idx, d_gmax, stats, counts, laux_coef, se
     return dg
 
 
-def gate_bwd_dense(g, ln_w, ln_b, wg, gates, idx, d_gmax, d_probs, stats, counts, laux_coef, seg_tokens, d_wg, d_ln_w, d_ln_b):
-    """gate_bwd with a dense gradient d_probs [P, E] w.r.t. the probabilities on top (top-k layers; swn_gate_bwd_dense)."""
+def gate_bwd_dense(g, ln_w, ln_b, wg, gates, idx, d_gmax, d_probs, stats, counts, laux_coef, seg_tokens, d_wg, d_ln_w, d_ln_b,
+                   d_logits_add=None):
+    """gate_bwd with dense operands on top (swn_gate_bwd_dense): d_probs [P, E] w.r.t. the probabilities (top-k layers), d_logits_add
+    [P, E] w.r.t. the logits, added behind the softmax backward (load / importance loss)."""
     P, G = g.shape
     E = wg.shape[0]
-    assert d_probs.shape == (P, E) and d_probs.dtype == torch.float32
+    for t in (d_probs, d_logits_add):
+        assert t is None or (t.shape == (P, E) and t.dtype == torch.float32 and t.is_contiguous())
     dg = torch.empty_like(g)
     dlogits = torch.empty(int(_lib.load().swn_gate_bwd_scratch_floats(P, G, E)), dtype=torch.float32, device=g.device)
-    call("swn_gate_bwd_dense", _p(g), _dt(g), _p(ln_w), _p(ln_b), _p(wg), _p(gates), _p(idx), _p(d_gmax), _p(d_probs.contiguous()), _p(stats),
-         _p(counts), _p(laux_coef), int(seg_tokens), P, G, E, _p(dg), _p(dlogits), _p(d_wg), _p(d_ln_w), _p(d_ln_b), _stream())
+    call("swn_gate_bwd_dense", _p(g), _dt(g), _p(ln_w), _p(ln_b), _p(wg), _p(gates), _p(idx), _p(d_gmax), _p(d_probs), _p(d_logits_add),
+         _p(stats), _p(counts), _p(laux_coef), int(seg_tokens), P, G, E, _p(dg), _p(dlogits), _p(d_wg), _p(d_ln_w), _p(d_ln_b), _stream())
     return dg
+
+
+def gate_logits(g, wg, noise=None, noise_scale: float = 0.0):
+    """The fp32 router's logits g @ wg^T (+ noise_scale * noise) [P, E] (swn_gate_logits; no LayerNorm)."""
+    P, G = g.shape
+    E = wg.shape[0]
+    logits = torch.empty(P, E, dtype=torch.float32, device=g.device)
+    call("swn_gate_logits", _p(g), _dt(g), _p(wg), _p(noise), float(noise_scale), P, G, E, _p(logits), _stream())
+    return logits
+
+
+def load_importance_fwd(scores_wo_noise, logits_w_noise, idx_last, sigma: float):
+    """load_importance_loss (tutel_fast_dispatch.py:152-174) -> (l_loss [1], coef [2 E] for the backward)."""
+    P, E = scores_wo_noise.shape
+    dev = scores_wo_noise.device
+    l = torch.empty(1, dtype=torch.float32, device=dev)
+    coef = torch.empty(2 * E, dtype=torch.float32, device=dev)
+    ws = torch.empty(int(_lib.load().swn_load_importance_workspace_floats(P, E)), dtype=torch.float32, device=dev)
+    call("swn_load_importance_fwd", _p(scores_wo_noise), _p(logits_w_noise), _p(idx_last), float(sigma), P, E, _p(l), _p(coef), _p(ws), _stream())
+    return l, coef
+
+
+def load_importance_bwd(scores_wo_noise, logits_w_noise, idx_last, coef, d_l, sigma: float):
+    """-> d_logits [P, E] of the loss, times the device scalar d_l [1]."""
+    P, E = scores_wo_noise.shape
+    d_logits = torch.empty(P, E, dtype=torch.float32, device=scores_wo_noise.device)
+    call("swn_load_importance_bwd", _p(scores_wo_noise), _p(logits_w_noise), _p(idx_last), _p(coef), _p(d_l), float(sigma), P, E, _p(d_logits),
+         _stream())
+    return d_logits
 
 
 def topk_select(gates, k: int):

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     syms = header_symbols()
     assert len(syms) >= 20
     declared = set(syms)
-    bound = set(_lib.SIGNATURES) | {"swn_last_error", "swn_route_workspace_bytes", "swn_route_sync_bytes", "swn_chain_mask_words", "swn_gate_bwd_scratch_floats", "swn_wgrad_multi_workspace_bytes", "swn_heads_bwd_workspace_bytes", "swn_ray_feat_wgrad_workspace_bytes", "swn_chain_dwsig_workspace_bytes", "swn_hash_bwd_workspace_bytes",
+    bound = set(_lib.SIGNATURES) | {"swn_last_error", "swn_route_workspace_bytes", "swn_route_sync_bytes", "swn_chain_mask_words", "swn_gate_bwd_scratch_floats", "swn_wgrad_multi_workspace_bytes", "swn_heads_bwd_workspace_bytes", "swn_ray_feat_wgrad_workspace_bytes", "swn_chain_dwsig_workspace_bytes", "swn_hash_bwd_workspace_bytes", "swn_load_importance_workspace_floats",
                                     "swn_half_dtype"}
     assert bound == declared, (sorted(bound - declared), sorted(declared - bound))
     for path, half in ((_lib.LIB_PATH, _lib.BF16), (_lib.LIB_PATH_F16, _lib.F16)):

@@ -141,7 +141,7 @@ def test_moe_layer_gate_noise_vs_reference_golden_fp32():
     with torch.no_grad():
         a, b = moe(xt, gate_input=gt), moe(xt, gate_input=gt)
     assert (a.gate_extras["gates"] != b.gate_extras["gates"]).any()                 # two draws, two routings
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError, match="gate_noise"):          # (the reference's own assert, tutel_fast_dispatch.py:154)
         moe_layer(gate_type=dict(type="top", k=1, use_load_importance_loss=True), model_dim=256,
                   experts=dict(type="expertmlp", count_per_node=8, layer_num=7))
 
@@ -302,3 +302,55 @@ def test_moe_layer_top2_plain_locations_small_and_bf16():
         ynb = nb(xb, gate_input=gb)
         kept_rows = (ynb.abs().sum(-1) > 0).float().mean().item()
     assert kept_rows == 1.0
+
+
+@pytest.mark.parametrize("tag", ["k1", "k2"])
+def test_moe_layer_load_importance_vs_reference_golden_fp32(tag):
+    """--use_load_importance_loss (opts.py:210; load_importance_loss / extract_critical_load_importance, tutel_fast_dispatch.py:152-174,
+    219-265) with gate noise in training mode and --compute_balance_loss, against the REFERENCE layer's own run (top-1 and top-2 gate,
+    noise draw replayed): experts bit-exact, output, the load / importance loss as l_aux, the load-balance loss in the extras, the
+    gradients of the output and of both losses."""
+    g = np.load(os.path.join(G, f"moe_layer_load_importance_{tag}.npz"))
+    seed, P, gn, K = int(g["seed"]), int(g["P"]), float(g["gate_noise"]), int(g["top_k"])
+    from switch_nerf_amd.moe import moe_layer
+    cfg = synth.BUILDING
+    mk = lambda **kw: moe_layer(gate_type=dict(type="top", k=K, fp32_gate=True, capacity_factor=1.0, batch_prioritized_routing=True,
+                                               gate_dim=cfg["gate_hidden"], **kw), model_dim=cfg["model_dim"],
+                                experts=dict(type="expertmlp", count_per_node=cfg["num_experts"], hidden_size_per_expert=cfg["model_dim"],
+                                             layer_num=cfg["expert_layers"], skips=list(cfg["skips"])), seeds=(1, 1, 1), return_gates=True,
+                                dtype=torch.float32)
+    with pytest.raises(AssertionError, match="gate_noise"):
+        mk(use_load_importance_loss=True, gate_noise=-1.0)
+    with pytest.raises(ValueError, match="compute_balance_loss"):
+        mk(compute_balance_loss=True, gate_noise=gn)
+    moe = mk(use_load_importance_loss=True, compute_balance_loss=True, gate_noise=gn).cuda()
+    _load(moe, seed)
+    moe.train()
+    rng = np.random.default_rng(seed + 1000)
+    x = rng.standard_normal((P, 256)).astype(np.float32)
+    gi = rng.standard_normal((P, 256)).astype(np.float32)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    gt = torch.from_numpy(gi).cuda().requires_grad_(True)
+    wgp = moe.gates[0].wg.weight
+    y = moe(xt, gate_input=gt, gate_noise_draw=torch.from_numpy(g["noise"]))
+    np.testing.assert_array_equal(y.gate_extras["gates"].cpu().numpy(), g["topk"])
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["y"], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(y.l_aux.item(), float(g["l_aux"]), rtol=2e-4)
+    bal = y.gate_extras["balance_loss"]
+    np.testing.assert_allclose(bal.item(), float(g["balance_loss"]), rtol=1e-6)
+    dy = rng.standard_normal((P, 256)).astype(np.float32)
+    (y * torch.from_numpy(dy).cuda()).sum().backward(retain_graph=True)
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), g["dx"], rtol=1e-3, atol=2e-4 * np.abs(g["dx"]).max())
+    np.testing.assert_allclose(gt.grad.cpu().numpy(), g["dgate_input"], rtol=1e-3, atol=2e-4 * np.abs(g["dgate_input"]).max())
+    np.testing.assert_allclose(wgp.grad.cpu().numpy(), g["dwg"], rtol=1e-3, atol=5e-4 * np.abs(g["dwg"]).max())
+    d_g, d_wg = torch.autograd.grad(y.l_aux, [gt, wgp], retain_graph=True)
+    np.testing.assert_allclose(d_g.cpu().numpy(), g["laux_dgate_input"], rtol=2e-3, atol=1e-3 * np.abs(g["laux_dgate_input"]).max())
+    np.testing.assert_allclose(d_wg.cpu().numpy(), g["laux_dwg"], rtol=2e-3, atol=1e-3 * np.abs(g["laux_dwg"]).max())
+    b_g, b_wg = torch.autograd.grad(bal, [gt, wgp])
+    np.testing.assert_allclose(b_g.cpu().numpy(), g["bal_dgate_input"], rtol=1e-3, atol=2e-4 * np.abs(g["bal_dgate_input"]).max())
+    np.testing.assert_allclose(b_wg.cpu().numpy(), g["bal_dwg"], rtol=1e-3, atol=2e-4 * np.abs(g["bal_dwg"]).max())
+    # evaluation: no noise, the threshold is the clean k-th logit - the loss still evaluates (tutel_moe_layer_nobatch.py:119-122)
+    moe.eval()
+    with torch.no_grad():
+        ye = moe(xt, gate_input=gt)
+    assert np.isfinite(ye.l_aux.item()) and ye.l_aux.item() != y.l_aux.item()

@@ -222,6 +222,41 @@ def test_moe_layer_top2_vs_reference(tag, cfg):
     np.testing.assert_allclose(gl[1].numpy(), g["laux_dwg"], rtol=0, atol=1e-7)
 
 
+@pytest.mark.parametrize("tag", ["k1", "k2"])
+def test_moe_layer_load_importance_vs_reference(tag):
+    """--use_load_importance_loss with gate noise, training mode (extract_critical_load_importance, tutel_fast_dispatch.py:219-265): the
+    reference layer's own run (top-1 and top-2 gate) with its replayed noise draw - experts, output, the load / importance loss, the
+    load-balance loss of the extras, and the gradients of both losses and of the output."""
+    g = load(f"moe_layer_load_importance_{tag}")
+    cfg = synth.BUILDING
+    seed, P, gn, K = int(g["seed"]), int(g["P"]), float(g["gate_noise"]), int(g["top_k"])
+    p = O.params_from_numpy(synth.make_weights(seed, cfg), requires_grad=True)
+    rng = np.random.default_rng(seed + 1000)
+    x = torch.from_numpy(rng.standard_normal((P, cfg["model_dim"])).astype(np.float32)).requires_grad_(True)
+    gi = torch.from_numpy(rng.standard_normal((P, cfg["gate_hidden"])).astype(np.float32)).requires_grad_(True)
+    L = cfg["expert_layers"]
+    W = [p[f"layers.0.experts.0.weights.{l}"] for l in range(L)]
+    B = [p[f"layers.0.experts.0.bias.{l}"] for l in range(L)]
+    wg = p["layers.0.gates.0.wg.weight"]
+    y, l_aux, r, _ = O.moe_layer_topk(x, gi, wg, W, B, cfg["skips"], K, 1.0, True, gate_noise=gn, noise=torch.from_numpy(g["noise"]),
+                                      load_importance=True)
+    assert np.array_equal(r["idx"].T, g["topk"])
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(l_aux.detach().numpy(), g["l_aux"], rtol=2e-6)
+    np.testing.assert_allclose(r["balance_loss"].detach().numpy(), g["balance_loss"], rtol=1e-6)
+    dy = torch.from_numpy(rng.standard_normal(y.shape).astype(np.float32))
+    (y * dy).sum().backward(retain_graph=True)
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(gi.grad.numpy(), g["dgate_input"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(wg.grad.numpy(), g["dwg"], rtol=0, atol=2e-5)
+    gl = torch.autograd.grad(l_aux, [gi, wg], retain_graph=True)
+    np.testing.assert_allclose(gl[0].numpy(), g["laux_dgate_input"], rtol=1e-4, atol=1e-6 * np.abs(g["laux_dgate_input"]).max())
+    np.testing.assert_allclose(gl[1].numpy(), g["laux_dwg"], rtol=1e-4, atol=1e-6 * np.abs(g["laux_dwg"]).max())
+    gb = torch.autograd.grad(r["balance_loss"], [gi, wg])
+    np.testing.assert_allclose(gb[0].numpy(), g["bal_dgate_input"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(gb[1].numpy(), g["bal_dwg"], rtol=0, atol=1e-7)
+
+
 @pytest.mark.parametrize("tag", ["unbalanced", "balanced"])
 def test_model_forward(tag):
     g = load(f"model_fwd_{tag}")
