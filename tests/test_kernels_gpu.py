@@ -157,6 +157,54 @@ def test_route_ragged_and_ties_and_scale():
     _route_check(synth.make_gates(108, 2 * 70, 8, 1.0), 70, 8, 1.25, True)
 
 
+def _route_topk_check(gates_np, seg_tokens, E, K, cf, bpr):
+    """swn_topk_select + swn_route_topk against the oracle's integer routing (oracle.route_topk = extract_critical with k > 1,
+    tutel_fast_dispatch.py:176-217), segment by segment: experts and locations of EVERY choice bit-exact, counts, the shared perm."""
+    P = gates_np.shape[0]
+    n_seg = P // seg_tokens
+    gates = torch.from_numpy(gates_np).to(dev())
+    idx, gsel, gn = ops().topk_select(gates, K)
+    gmax = gates.max(dim=1).values.contiguous()
+    cap = O.capacity_of(seg_tokens, E, cf, K)
+    loc, counts, perm, tok2row, group_rows, l_aux = ops().route_topk(idx, gmax, gates, seg_tokens, E, cap, bpr, want_tok2row=True)
+    idx, loc, counts, perm, tok2row, group_rows, l_aux = [t.cpu().numpy() for t in (idx, loc, counts, perm, tok2row, group_rows, l_aux)]
+    for s in range(n_seg):
+        sl = slice(s * seg_tokens, (s + 1) * seg_tokens)
+        r = O.route_topk(gates_np[sl], K, cf, bpr)
+        assert r["capacity"] == cap
+        assert np.array_equal(idx[:, sl], r["idx"]), f"segment {s}: choices"
+        assert np.array_equal(loc[:, sl], r["loc"]), f"segment {s}: locations"
+        assert np.array_equal(counts[:, s], r["counts"])
+        assert np.array_equal(group_rows[s * E:(s + 1) * E], r["counts"].sum(0))      # (all choices' tokens; the chains clamp to the capacity)
+        exp_perm = np.full(E * cap, -1, np.int64)
+        for j in range(K):
+            kept = r["loc"][j] < cap
+            rows = r["idx"][j][kept].astype(np.int64) * cap + r["loc"][j][kept]
+            assert (exp_perm[rows] == -1).all()                       # a row belongs to one (token, choice) pair
+            exp_perm[rows] = np.nonzero(kept)[0] + s * seg_tokens
+            t2r = np.where(kept, s * E * cap + r["idx"][j].astype(np.int64) * cap + r["loc"][j], -1)
+            assert np.array_equal(tok2row[j, sl], t2r)
+        assert np.array_equal(perm[s], exp_perm)
+        la = O.load_balance_loss(torch.from_numpy(gates_np[sl]), torch.from_numpy(r["idx"][0]))
+        assert abs(l_aux[s] - la.item()) <= 2e-6 * abs(la.item())
+    gs = np.take_along_axis(gates_np, idx.T.astype(np.int64), axis=1).T
+    np.testing.assert_array_equal(gsel.cpu().numpy(), gs)
+    den = np.maximum(gs.sum(0, dtype=np.float32), np.finfo(np.float32).eps) if K > 1 else np.float32(1.0)
+    np.testing.assert_allclose(gn.cpu().numpy(), gs / den, rtol=2e-7)
+
+
+def test_route_topk_ties_ragged_and_scale():
+    """The top-k routing at the sizes and corner cases the top-1 routing is tested on: BASELINE's segment size (131072 tokens, several
+    segments), heavy and total ties, ragged tiles, segments shorter than a wavefront, k = 2 / 3 / E, with and without batch priority."""
+    _route_topk_check(synth.make_gates(203, 16384, 8, 1.0, quantize_bits=3), 16384, 8, 2, 1.0, True)      # heavy ties
+    _route_topk_check(synth.make_gates(204, 3 * 131072, 8, 3.0), 131072, 8, 2, 1.0, True)                 # BASELINE size, 3 segments
+    _route_topk_check(synth.make_gates(205, 131072, 8, 1.0), 131072, 8, 3, 1.25, False)
+    _route_topk_check(synth.make_gates(206, 2 * 2000, 4, 1.0), 2000, 4, 4, 0.5, True)                      # k = E
+    _route_topk_check(synth.make_gates(207, 1000, 16, 2.0), 1000, 16, 2, 1.0, True)
+    _route_topk_check(synth.make_gates(208, 3 * 40, 8, 1.0), 40, 8, 2, 1.0, True)
+    _route_topk_check(synth.make_gates(209, 5 * 24, 4, 2.0), 24, 4, 2, 1.0, False)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_tutel_sparse_abi(dtype):
     P, H, E = 1500, 256, 8
