@@ -203,6 +203,8 @@ static void route_pass(const uint32_t* ki, const int32_t* vi, uint32_t* ko, int3
   hipLaunchKernelGGL((route_hist_kernel<BITS>), dim3(nblk, n_seg), dim3(256), 0, s, ki, seg_tokens, shift, nblk, hist);
   if (nblk <= 16) hipLaunchKernelGGL((route_scan_kernel<BITS, 16>), dim3(n_seg), dim3(1 << BITS), 0, s, hist, nblk);
   else if (nblk <= 64) hipLaunchKernelGGL((route_scan_kernel<BITS, 64>), dim3(n_seg), dim3(1 << BITS), 0, s, hist, nblk);
+  else if (nblk <= 128) hipLaunchKernelGGL((route_scan_kernel<BITS, 128>), dim3(n_seg), dim3(1 << BITS), 0, s, hist, nblk);   // (Mission Bay's
+                                                    // 212,992-token segments = 104 tiles: the serial form took 26 us per pass, 0.2 ms per step)
   else hipLaunchKernelGGL((route_scan_kernel<BITS, 0>), dim3(n_seg), dim3(1 << BITS), 0, s, hist, nblk);
   hipLaunchKernelGGL((route_scatter_kernel<BITS>), dim3(nblk, n_seg), dim3(256), 0, s, ki, vi, seg_tokens, shift, nblk, hist, ko, vo);
 }

@@ -157,6 +157,32 @@ def test_route_ragged_and_ties_and_scale():
     _route_check(synth.make_gates(108, 2 * 70, 8, 1.0), 70, 8, 1.25, True)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pack_weights_batched_equals_single_launches(dtype):
+    """swn_pack_weights_batched (the per-step refresh of every compute copy: 16-byte loads of the backward-data layout, one 16-byte store
+    per lane) writes what swn_pack_weights writes, entry by entry - both layouts, several weight sets, widths 128 / 256 / 512, a master
+    whose rows are not 16-byte aligned sets (in x out = 63-column padded cases go through the scalar path) - and zero-pads."""
+    o = ops()
+    gen = torch.Generator().manual_seed(77)
+    masters = [torch.randn(ws, i, oo, generator=gen).to(dev()) for ws, i, oo in [(8, 256, 256), (1, 512, 512), (3, 128, 256), (16, 512, 256), (1, 256, 128)]]
+    pairs, singles = [], []
+    for m in masters:
+        for tr in (True, False):
+            singles.append(o.pack_weights(m, dtype, tr))
+            pairs.append((m, torch.full_like(singles[-1], 7.0), tr))
+    o.repack_weights_batched(pairs)
+    for (m, packed, tr), ref in zip(pairs, singles):
+        assert torch.equal(packed.view(torch.int16 if dtype != torch.float32 else torch.int32), ref.view(torch.int16 if dtype != torch.float32 else torch.int32)), (tuple(m.shape), tr)
+    # zero padding: out 96 -> 128 columns / in 96 -> 128 rows (master rows of 96 floats = 384 bytes: aligned; 100 columns: the tail chunk is scalar)
+    for i, oo, ipad, opad in [(128, 96, 0, 128), (96, 128, 128, 0), (64, 100, 0, 128)]:
+        m = torch.randn(2, i, oo, generator=gen).to(dev())
+        mp = torch.zeros(2, ipad or i, opad or oo, device=dev())
+        mp[:, :i, :oo] = m
+        for tr in (True, False):
+            a, b = o.pack_weights_padded(m, dtype, tr, ipad, opad), o.pack_weights(mp.contiguous(), dtype, tr)
+            assert torch.equal(a.float(), b.float()), (i, oo, tr)
+
+
 def _route_topk_check(gates_np, seg_tokens, E, K, cf, bpr):
     """swn_topk_select + swn_route_topk against the oracle's integer routing (oracle.route_topk = extract_critical with k > 1,
     tutel_fast_dispatch.py:176-217), segment by segment: experts and locations of EVERY choice bit-exact, counts, the shared perm."""
