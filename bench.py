@@ -767,29 +767,33 @@ def main():
             if probe_done.is_set():
                 return
             if rank == 0:
-                out["config"]["expert_parallel"] = dict(error=f"the expert-parallel probe did not finish within {a.ep_probe_limit:.0f} s")
+                for key in ("expert_parallel", "expert_parallel_owner_tail"):      # (a probe that finished keeps its record)
+                    out["config"].setdefault(key, dict(error=f"the expert-parallel probes did not finish within {a.ep_probe_limit:.0f} s"))
                 out["cpu_baseline"] = None
                 print(json.dumps(out), flush=True)
             os._exit(0)
         dog = threading.Timer(a.ep_probe_limit + (0.0 if rank == 0 else 5.0), give_up)
         dog.daemon = True
         dog.start()
-        try:
-            from switch_nerf_amd.parallel import ExpertParallel
-            graphed[0] = None
-            model.set_expert_parallel(ExpertParallel(rank, world, model.E, padded=False, loopback=a.loopback))
-            reset_state(4321)
-            for _ in range(3):
-                step()
-            reset_state(1234)
-            esteps = max(3, min(10, a.steps))
-            edt_, est_ = timed(esteps, False)
-            x = ep_report()
-            x.update(steps=esteps, ms_per_step=round(edt_ / esteps * 1e3, 3), value=round(n_rays * world * esteps / edt_, 1), unit="rays/s",
-                     launches="eager (compare with config.eager_ms_per_step of the data-parallel step)", loss=round(float(est_["loss"].item()), 6))
-            out["config"]["expert_parallel"] = x
-        except Exception as e:      # (the same exception on every rank: a one-sided failure ends in the watchdog)
-            out["config"]["expert_parallel"] = dict(error=f"{type(e).__name__}: {e}"[:400])
+        def ep_probe(key, **ep_kw):
+            try:
+                from switch_nerf_amd.parallel import ExpertParallel
+                graphed[0] = None
+                model.set_expert_parallel(ExpertParallel(rank, world, model.E, padded=False, loopback=a.loopback, **ep_kw))
+                reset_state(4321)
+                for _ in range(3):
+                    step()
+                reset_state(1234)
+                esteps = max(3, min(10, a.steps))
+                edt_, est_ = timed(esteps, False)
+                x = ep_report()
+                x.update(steps=esteps, ms_per_step=round(edt_ / esteps * 1e3, 3), value=round(n_rays * world * esteps / edt_, 1), unit="rays/s",
+                         launches="eager (compare with config.eager_ms_per_step of the data-parallel step)", loss=round(float(est_["loss"].item()), 6))
+                out["config"][key] = x
+            except Exception as e:      # (the same exception on every rank: a one-sided failure ends in the watchdog)
+                out["config"][key] = dict(error=f"{type(e).__name__}: {e}"[:400])
+        ep_probe("expert_parallel")                                      # kept rows exchanged per segment, side-stream overlap (the reference's placement)
+        ep_probe("expert_parallel_owner_tail", owner_tail=True)          # the dense tail on the expert's rank: 0.53 x the bytes, fused launches (ep_owner.py)
         probe_done.set()
         dog.cancel()
     if rank == 0:

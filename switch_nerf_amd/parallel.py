@@ -306,9 +306,21 @@ class ExpertParallel:
             dist.all_to_all_single(recv, send, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits), group=self.group)
             return lambda: None
         if stream is None or not send.is_cuda:
+            bev = None
+            if self.profile and send.is_cuda:      # (the blocking form on the launch stream - the owner-tail mode: nothing of it is hidden)
+                bev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                bev[0].record()
             work = dist.all_to_all_single(recv, send, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits), group=self.group,
                                           async_op=True)
-            return work.wait
+            if bev is None:
+                return work.wait
+
+            def wait_blocking():
+                work.wait()
+                bev[1].record()
+                self.__dict__.setdefault("ev_coll", []).append(bev)
+                self.__dict__.setdefault("ev_wait", []).append(bev)
+            return wait_blocking
         ready = torch.cuda.Event()
         ready.record()
         with torch.cuda.stream(stream):
