@@ -157,6 +157,29 @@ def test_route_ragged_and_ties_and_scale():
     _route_check(synth.make_gates(108, 2 * 70, 8, 1.0), 70, 8, 1.25, True)
 
 
+def test_route_random_shapes_top1_and_topk():
+    """A seeded sweep over shapes nobody picked by hand: 1 - 64 experts, segments of 1 - 5000 tokens (tile edges +- 1 among them), 1 - 5
+    segments, capacity factors 0.25 - 2, token order / batch priority, tie-free to heavily tied gate values, k = 1 - 3: every integer
+    output of the routing equals the oracle's (extract_critical, tutel_fast_dispatch.py:176-217), segment by segment."""
+    rng = np.random.default_rng(20261001)
+    done = 0
+    while done < 36:
+        E = int(rng.choice([1, 2, 4, 8, 16, 32, 64]))
+        seg = int(rng.choice([1, 2, 63, 64, 65, 255, 2047, 2048, 2049, 4096, int(rng.integers(3, 5000)), int(rng.integers(3, 5000))]))
+        n_seg = int(rng.integers(1, 6))
+        cf = float(rng.choice([0.25, 0.5, 1.0, 1.25, 2.0]))
+        bpr = bool(rng.integers(0, 2))
+        qb = int(rng.choice([0, 0, 2, 4]))
+        K = int(rng.integers(1, min(E, 3) + 1))
+        if O.capacity_of(seg, E, cf, 1) < 1:
+            continue
+        gates = synth.make_gates(3000 + done, seg * n_seg, E, float(rng.choice([0.5, 1.0, 3.0])), quantize_bits=qb)
+        _route_check(gates, seg, E, cf, bpr)
+        if K > 1:
+            _route_topk_check(gates, seg, E, K, cf, bpr)
+        done += 1
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_pack_weights_batched_equals_single_launches(dtype):
     """swn_pack_weights_batched (the per-step refresh of every compute copy: 16-byte loads of the backward-data layout, one 16-byte store
