@@ -277,6 +277,35 @@ def test_tutel_sparse_abi(dtype):
     assert report(f"combine_relu_{dtype}", yr, torch.relu(y_ref)) <= (1e-6 if dtype == torch.float32 else 2e-2)
 
 
+def test_tutel_sparse_abi_random_shapes():
+    """The sparse kernels behind Tutel's func_fwd / func_bwd_data / func_bwd_gate (tutel_fast_dispatch.py:27, 36, 43) over a seeded sweep:
+    row widths of 8 - 1024 features, 1 - 3000 tokens, 1 - 64 experts, capacity factors that drop most tokens or none, fp32 and 16-bit rows."""
+    rng = np.random.default_rng(20261002)
+    for t in range(24):
+        E = int(rng.choice([1, 2, 4, 8, 16, 64]))
+        P = int(rng.choice([1, 2, 63, 64, 65, 1000, int(rng.integers(3, 3000))]))
+        H = int(rng.choice([8, 64, 72, 128, 256, 512, 1024]))
+        cf = float(rng.choice([0.25, 1.0, 1.25, 4.0]))
+        dtype = torch.float32 if rng.integers(0, 2) else torch.bfloat16
+        if O.capacity_of(P, E, cf) < 1:
+            continue
+        r = O.route_top1(synth.make_gates(4000 + t, P, E, 2.0), cf, bool(rng.integers(0, 2)))
+        cap = r["capacity"]
+        x = torch.from_numpy(rng.standard_normal((P, H)).astype(np.float32)).to(dtype)
+        idx, loc, gate = torch.from_numpy(r["idx"]), torch.from_numpy(r["loc"]), torch.from_numpy(r["gate"])
+        tag = f"P{P}_E{E}_H{H}_cf{cf}_{dtype}"
+        d_ref = O.dispatch(x.float(), idx, loc, E, cap)
+        d = ops().dispatch_fwd(None, idx.to(dev()), loc.to(dev()), x.to(dev()), E, cap)
+        assert report("dispatch_fwd_" + tag, d, d_ref) == 0.0
+        y_ref = O.combine(d_ref, idx, loc, gate, cap)
+        y = ops().dispatch_bwd_data(gate.to(dev()), idx.to(dev()), loc.to(dev()), d, cap)
+        assert report("dispatch_bwd_data_" + tag, y, y_ref) <= (1e-6 if dtype == torch.float32 else 2e-2) * max(1.0, y_ref.abs().max().item())
+        assert (y.float().cpu()[(loc >= cap)] == 0).all()                                  # dropped tokens: zero rows
+        gg_ref = (d_ref[(idx.long() * cap + loc.long()).clamp(max=E * cap - 1)] * x.float()).sum(1) * (loc < cap)
+        gg = ops().dispatch_bwd_gate(idx.to(dev()), loc.to(dev()), x.to(dev()), d, cap)
+        assert report("dispatch_bwd_gate_" + tag, gg, gg_ref) <= 2e-3 * max(1.0, gg_ref.abs().max().item())
+
+
 def test_composite_fwd_bwd():
     g = np.load(os.path.join(G, "composite.npz"))
     raw = torch.cat([torch.from_numpy(g["rgbs"]), torch.from_numpy(g["sigmas"])[..., None]], -1).contiguous()
