@@ -354,3 +354,42 @@ def test_moe_layer_load_importance_vs_reference_golden_fp32(tag):
     with torch.no_grad():
         ye = moe(xt, gate_input=gt)
     assert np.isfinite(ye.l_aux.item()) and ye.l_aux.item() != y.l_aux.item()
+
+
+@pytest.mark.parametrize("K", [1, 2])
+def test_moe_layer_load_importance_bf16_and_larger_batch(K):
+    """The load / importance branch in the 16-bit layer (persistent 256-row chains, 16-bit router input) at 4096 tokens against the fp32 layer
+    with the same weights and the same noise draw: the loss within 16-bit rounding of the gate input, finite gradients everywhere, the
+    loss's own gradient reaches the gate weight; sigma = gate_noise / E is what normalises it (tutel_fast_dispatch.py:154-160)."""
+    from switch_nerf_amd.moe import moe_layer
+    cfg = synth.BUILDING
+    mk = lambda dt: moe_layer(gate_type=dict(type="top", k=K, fp32_gate=True, capacity_factor=2.0, batch_prioritized_routing=True,
+                                             gate_dim=cfg["gate_hidden"], use_load_importance_loss=True, compute_balance_loss=True, gate_noise=1.0),
+                              model_dim=cfg["model_dim"],
+                              experts=dict(type="expertmlp", count_per_node=cfg["num_experts"], hidden_size_per_expert=cfg["model_dim"],
+                                           layer_num=cfg["expert_layers"], skips=list(cfg["skips"])), seeds=(1, 1, 1), return_gates=True,
+                              dtype=dt).cuda()
+    m16, m32 = mk(torch.bfloat16), mk(torch.float32)
+    _load(m16, 41)
+    m32.load_state_dict(m16.state_dict())
+    m16.train(), m32.train()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    P = 4096
+    x = torch.randn(P, 256, device="cuda", generator=gen).requires_grad_(True)
+    gi = torch.randn(P, 256, device="cuda", generator=gen).requires_grad_(True)
+    draw = torch.randn(P, cfg["num_experts"], device="cuda", generator=gen)
+    y16, y32 = m16(x, gate_input=gi, gate_noise_draw=draw), m32(x, gate_input=gi, gate_noise_draw=draw)
+    l16, l32 = y16.l_aux.item(), y32.l_aux.item()
+    assert np.isfinite(l16) and l32 > 0 and abs(l16 - l32) <= 0.05 * l32, (l16, l32)
+    b16, b32 = y16.gate_extras["balance_loss"].item(), y32.gate_extras["balance_loss"].item()
+    assert abs(b16 - b32) <= 0.02 * b32, (b16, b32)
+    (y16.float().square().mean() + y16.l_aux + y16.gate_extras["balance_loss"]).backward()
+    assert torch.isfinite(x.grad).all() and torch.isfinite(gi.grad).all() and gi.grad.abs().max().item() > 0
+    for p_ in m16.parameters():
+        assert p_.grad is not None and torch.isfinite(p_.grad).all()
+    wg16 = m16.gates[0].wg.weight
+    d16, = torch.autograd.grad(m16(x, gate_input=gi, gate_noise_draw=draw).l_aux, [wg16])
+    d32, = torch.autograd.grad(m32(x, gate_input=gi, gate_noise_draw=draw).l_aux, [m32.gates[0].wg.weight])
+    assert d32.abs().max().item() > 0
+    cos = torch.nn.functional.cosine_similarity(d16.flatten().float(), d32.flatten().float(), dim=0).item()
+    assert cos > 0.98, cos
