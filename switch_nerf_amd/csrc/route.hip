@@ -357,8 +357,8 @@ extern "C" int swn_route_top1x(const int32_t* idx, const float* gmax, const floa
   // mode 0 = the per-phase kernels (swn_route_top1 + swn_route_dropped).  Modes 1 / 2 - the fused forms of round 5, measured slower - exist
   // only in the experiment build (scripts/experiments/route_one.inc, -DSWN_EXP_ROUTE_ONE)
 #ifdef SWN_EXP_ROUTE_ONE
-  SWN_CHECK(mode >= 0 && mode <= 2, "swn_route_top1x: mode %d (0 = per-phase kernels, 1 = fused phases, 2 = one launch)", mode);
-  if (mode > 0 && sync != nullptr && 2 + 4 * n_seg <= ROUTE_SYNC_WORDS && (!drop_begin || n_seg * n_experts <= ROUTE_ONE_MAX_GROUPS))
+  SWN_CHECK(mode >= 0 && mode <= 3, "swn_route_top1x: mode %d (0 = per-phase kernels, 1 = fused phases, 2 = one launch, 3 = one launch, a segment per XCD)", mode);
+  if (mode > 0 && sync != nullptr && 2 + 4 * n_seg <= ROUTE_TEAM0 && n_seg * n_experts <= 1024)
     return route_one_launch(idx, gmax, gates, n_tokens, seg_tokens, n_experts, capacity, bpr, loc, counts, perm, tok2row, l_aux, drop_begin,
                             dropped, sync, mode, workspace, stream);
 #else

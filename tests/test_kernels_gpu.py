@@ -1415,13 +1415,13 @@ def test_route_fused_phases_and_one_launch_equal_the_per_phase_kernels():
         ref = o.route_top1(idx, gmax, gates, seg, E, cap, bpr, want_drops=True, multi=True)
         nd = int(ref[5][-1].item())
         for rep in range(30 if n in (3, 9) else 2):
-            for mode in (1, 2):
+            for mode in (1, 2, 3):
                 one = o.route_top1(idx, gmax, gates, seg, E, cap, bpr, want_drops=True, mode=mode)
                 for name, a, b in zip(("loc", "counts", "perm", "tok2row", "l_aux", "drop_begin"), one[:6], ref[:6]):
                     assert torch.equal(a, b), (n, rep, mode, name, int((a != b).sum().item()))
                 assert int(one[5][-1].item()) == nd and torch.equal(one[6][:nd], ref[6][:nd]), (n, rep, mode, "dropped")
         # the optional outputs left out
-        for mode in (0, 1, 2):
+        for mode in (0, 1, 2, 3):
             lean = o.route_top1(idx, gmax, None, seg, E, cap, bpr, want_perm=False, mode=mode)
             assert torch.equal(lean[0], ref[0]) and torch.equal(lean[1], ref[1]) and lean[2] is None and torch.equal(lean[3], ref[3]) and lean[4] is None
     for t in o._route_sync.values():
